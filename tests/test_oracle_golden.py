@@ -1,0 +1,118 @@
+"""Pin the CPU oracle (oracle/) against golden vectors generated from the reference itself."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_inf
+from oracle import oracle
+from trajectory_optimization_amd import synth
+
+K, IW, IH = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
+
+
+def _wps_step(d):
+    if float(d["vis_wps_dist"]) == 0.0:
+        return 1
+    return int(np.float32(d["vis_wps_dist"]) / np.float32(d["mean_wps_dist"])) + 1
+
+
+TRAJ = ["traj_bundled_default", "traj_bundled_tilted_all", "traj_synth_1000x3", "traj_synth_10000x8",
+        "traj_synth_20000x32", "traj_synth_ties", "traj_synth_dense"]
+
+
+@pytest.mark.parametrize("name", TRAJ)
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_traj_forward_backward(name, prec):
+    d = load_golden(name)
+    step = _wps_step(d)
+    idx = np.arange(0, len(d["poses"]), step)
+    fwd = oracle.traj_forward(d["points"], d["poses"][idx], d["quats"][idx], K, IW, IH, prec=prec)
+    assert abs(fwd["loss_vis"] - float(d["loss_vis"])) <= 2e-6 * float(d["loss_vis"])
+    # saturated rewards (|lo| up to 13.8 per waypoint) are compared absolutely: f32 sigmoid noise
+    np.testing.assert_allclose(fwd["rewards"], d["rewards"], rtol=2e-5, atol=2e-6)
+    if "vis_poses_grad" in d or name == "traj_bundled_default":
+        pg, qg = oracle.traj_backward(d["points"], d["poses"][idx], d["quats"][idx], K, IW, IH, fwd, prec=prec)
+        if "vis_poses_grad" in d:
+            assert rel_inf(pg, d["vis_poses_grad"][idx]) < 1e-5
+            assert rel_inf(qg, d["vis_quats_grad"][idx]) < 1e-5
+        else:
+            # default fixture: total-loss gradient; quats only get gradient from the visibility term
+            assert rel_inf(qg, d["quats_grad"][idx]) < 1e-5
+            assert np.all(d["quats_grad"][np.setdiff1d(np.arange(len(d["poses"])), idx)] == 0)
+
+
+def test_known_answers_bundled():
+    """SURVEY.md §8c known answers."""
+    d = load_golden("traj_bundled_default")
+    assert _wps_step(d) == 2
+    idx = np.arange(0, 27, 2)
+    fwd = oracle.traj_forward(d["points"], d["poses"][idx], d["quats"][idx], K, IW, IH)
+    assert abs(fwd["loss_vis"] - 1.889989376) < 5e-6
+    assert abs(fwd["mean_reward"] - 0.5291025) < 2e-6
+
+
+@pytest.mark.parametrize("name", ["pose_bundled_nohpr", "pose_bundled_hpr", "pose_bundled_tilted", "pose_synth_10k_hpr"])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_pose(name, prec):
+    d = load_golden(name)
+    mask = None
+    if bool(d["hpr"]):
+        mask = oracle.hidden_pts_removal(d["points"])[1]
+    obs, loss = oracle.pose_forward(d["points"], d["trans0"], d["q0"], K, IW, IH, mask=mask, prec=prec)
+    np.testing.assert_allclose(obs, d["observations"], rtol=3e-5, atol=1e-9)
+    assert abs(loss - float(d["loss"])) <= 3e-6 * float(d["loss"])
+    tg, qg = oracle.pose_backward(d["points"], d["trans0"], d["q0"], K, IW, IH, loss, mask=mask, prec=prec)
+    assert rel_inf(tg, d["trans_grad"]) < 1e-5
+    assert rel_inf(qg, d["quat_grad"]) < 1e-5
+
+
+def test_elementwise_funcs():
+    d = load_golden("funcs")
+    cam = oracle.to_camera_frame(d["points"], d["quat"], d["trans"])
+    np.testing.assert_allclose(cam, d["cam"], rtol=0, atol=2e-5)  # ~1 ulp at |coord| <= 40 m
+    dm, fm = oracle.soft_masks(d["cam"], K, IW, IH)
+    np.testing.assert_allclose(dm, d["dist_mask"], rtol=2e-5, atol=1e-37)
+    np.testing.assert_allclose(fm, d["fov_mask"], rtol=2e-5, atol=1e-37)
+    # binary fov mask of model.py:34-39 == frustum fov mask (bit-exact)
+    cam3 = np.ascontiguousarray(d["cam"].T)
+    _, fov = oracle.frustum_masks(cam3, K, IW, IH)
+    assert np.array_equal(fov, d["fov_mask_binary"])
+    flipped, _ = oracle.spherical_flip(d["points"])
+    assert np.array_equal(flipped, d["flipped"])  # element-wise IEEE ops: bit-exact
+
+
+def test_ego_to_cam_bit_exact():
+    d = load_golden("hard_pipeline_bundled")
+    cam = oracle.to_camera_frame(d["points"], d["quat"], d["trans"], normalize=False)
+    assert np.array_equal(cam.T, d["cam"])
+
+
+@pytest.mark.parametrize("name", ["frustum_synth_10", "frustum_synth_15"])
+def test_frustum_bit_exact(name):
+    d = load_golden(name)
+    cam3 = np.ascontiguousarray(d["points"].T)
+    n = cam3.shape[1]
+    dist, fov = oracle.frustum_masks(cam3, K, IW, IH, float(d["min_dist"]), float(d["max_dist"]))
+    assert np.array_equal(dist, np.unpackbits(d["dist_mask"])[:n].astype(bool))
+    assert np.array_equal(fov, np.unpackbits(d["fov_mask"])[:n].astype(bool))
+    assert np.array_equal(np.flatnonzero(dist & fov), d["kept_idx"])
+
+
+def test_hard_pipeline_bit_exact():
+    d = load_golden("hard_pipeline_bundled")
+    cam = oracle.to_camera_frame(d["points"], d["quat"], d["trans"], normalize=False)
+    cam3 = np.ascontiguousarray(cam.T)
+    dist, fov = oracle.frustum_masks(cam3, K, IW, IH, 1.0, 10.0)
+    kept = np.flatnonzero(dist & fov)
+    assert np.array_equal(kept, d["kept_idx"])
+    assert (dist.sum(), fov.sum(), len(kept)) == (22742, 6699, 4440)
+    vis, _ = oracle.hidden_pts_removal(cam[kept])
+    assert np.array_equal(vis, d["hpr_visible_idx"]) and len(vis) == 677
+
+
+@pytest.mark.parametrize("name", ["hpr_bundled_world", "hpr_synth_10k", "hpr_synth_100k", "hpr_synth_outside",
+                                  "hpr_shell_origin_inside"])
+def test_hpr_index_sets(name):
+    d = load_golden(name)
+    vis, mask = oracle.hidden_pts_removal(d["points"])
+    assert np.array_equal(vis, d["visible_idx"])
+    assert int(mask.sum()) == len(d["visible_idx"])
