@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py — point-visibility evaluations/s (fwd+bwd) of the HIP hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W     -> ONE JSON line on rank 0.
+For N>1 the driver launches it under torch.distributed.run, one rank per GPU (RCCL).
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): a 1 M-point synthetic
+cloud x 128 waypoints per GPU, full forward + backward to (x,y,z) and quaternion gradients, through the
+C ABI of include/trajopt_hip.h.  One "step" = tohip_traj_forward -> [all-reduce of the log-odds vector when
+N>1] -> tohip_traj_reward -> tohip_traj_backward.  With N GPUs the trajectory has 128*N waypoints sharded
+contiguously over the ranks (weak scaling; N=8 is configs[3], 1 M x 1024); value = N_points * W_total / time.
+Inputs are resident in HBM before the timed region.
+
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed on the launch stream) and
+"cpu_baseline" (the CPU oracle — a port, not the reference — on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from trajectory_optimization_amd import synth  # noqa: E402
+
+N_POINTS = 1_000_000
+WPS_PER_GPU = 128
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic bytes per evaluation of a streaming implementation (SURVEY.md §8d / DESIGN.md §4)
+ALGO_BYTES = {"k_traj_pass1": 12.0, "k_traj_pass2": 20.0, "k_traj_bwd": 16.0}
+
+
+def cpu_baseline(points, poses, quats, n_wps_sample):
+    """The oracle (oracle/vis_oracle.c, f32, OpenMP) on a bounded sample of the same workload."""
+    from oracle import oracle
+    K, iw, ih = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
+    sel = np.linspace(0, len(poses) - 1, n_wps_sample).astype(int)
+    p, q = poses[sel], quats[sel]
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    f = oracle.traj_forward(points, p[:1], q[:1], K, iw, ih)  # warm-up (page in, thread pool)
+    t0 = time.perf_counter()
+    f = oracle.traj_forward(points, p, q, K, iw, ih)
+    oracle.traj_backward(points, p, q, K, iw, ih, f)
+    dt = time.perf_counter() - t0
+    return {"value": points.shape[0] * n_wps_sample / dt, "unit": "evals/s", "cores": int(os.environ["OMP_NUM_THREADS"]),
+            "kind": "port", "sample": f"{points.shape[0]} points x {n_wps_sample} waypoints fwd+bwd, oracle f32 "
+            f"(OpenMP), {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=N_POINTS)
+    ap.add_argument("--wps-per-gpu", type=int, default=WPS_PER_GPU)
+    ap.add_argument("--cpu-wps", type=int, default=8, help="waypoints in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    from trajectory_optimization_amd import _lib, ops
+    from trajectory_optimization_amd.distributed import init_from_env, WaypointShard
+    import torch.distributed as dist
+
+    rank, world, device = init_from_env()
+    if world != args.gpus:
+        if args.gpus != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the visibility path has no CPU fallback")
+    n_gpus = world
+    w_total = args.wps_per_gpu * n_gpus
+
+    # ---- synthetic inputs (seeded), resident in HBM ------------------------------------
+    pts = synth.make_cloud(args.points, seed=0)
+    poses_all, quats_all = synth.make_path(w_total, optical=True)
+    lo, hi = rank * args.wps_per_gpu, (rank + 1) * args.wps_per_gpu
+    cloud = ops.PackedCloud(torch.from_numpy(pts).to(device))
+    cam = ops.Camera(synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT)
+    poses = torch.from_numpy(poses_all[lo:hi].copy()).to(device)
+    quats = torch.from_numpy(quats_all[lo:hi].copy()).to(device)
+    ws = ops.TrajWorkspace(cloud, args.wps_per_gpu)
+    gout = torch.ones(1, device=device)
+    shard = WaypointShard() if n_gpus > 1 else None
+
+    def step():
+        lo_sum, minmax = ops.traj_forward(cloud, poses, quats, cam, ws)
+        if shard is not None:
+            shard.allreduce_sum(lo_sum)  # the one data-path collective: N floats over xGMI
+        rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
+        pg, qg = ops.traj_backward(cloud, poses, quats, cam, ws, rewards, minmax, scalars=scalars, gout=gout)
+        return scalars, pg, qg
+
+    def fence():
+        if n_gpus > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    L = _lib.lib()
+    L.tohip_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ms = (ctypes.c_double * 5)()
+    cnt = (ctypes.c_int64 * 5)()
+    _lib.check(L.tohip_profile_read(ms, cnt), "tohip_profile_read")
+    L.tohip_profile_enable(0)
+
+    if n_gpus > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    evals_per_step = args.points * w_total
+    value = evals_per_step * args.steps / dt
+
+    if rank == 0:
+        # dominant kernel by summed device time; achieved = algorithmic bytes per launch / mean duration
+        kern = {L.tohip_profile_name(i).decode(): (ms[i], cnt[i]) for i in range(5) if cnt[i] > 0}
+        dom = max(ALGO_BYTES, key=lambda k: kern.get(k, (0.0, 0))[0])
+        dom_ms = kern[dom][0] / max(kern[dom][1], 1)
+        local_evals = args.points * args.wps_per_gpu
+        achieved = ALGO_BYTES[dom] * local_evals / (dom_ms * 1e-3) / 1e9
+        line = {
+            "metric": "point-visibility evals/sec (fwd+bwd)", "value": value, "unit": "evals/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.points}-point cloud x {args.wps_per_gpu} waypoints per GPU "
+                                   f"({w_total} total), fwd + bwd (x,y,z,quaternion) gradients",
+                       "n_points": args.points, "waypoints_total": w_total,
+                       "parallelism": f"waypoint-shard x{n_gpus}" if n_gpus > 1 else "single GPU",
+                       "loss_vis": float(out[0][1].item())},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in kern.items()},
+                         "algorithmic_bytes_per_eval": ALGO_BYTES[dom],
+                         "fwd_bwd_frac_of_48B_per_eval_roofline": value / n_gpus * 48.0 / (HBM_PEAK_GBS * 1e9)},
+        }
+        if n_gpus == 1 and args.cpu_wps > 0:
+            line["cpu_baseline"] = cpu_baseline(pts, poses_all, quats_all, args.cpu_wps)
+        print(json.dumps(line), flush=True)
+    if n_gpus > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

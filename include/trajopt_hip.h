@@ -1,0 +1,165 @@
+/*
+ * trajopt_hip.h — C ABI of libtrajopt_hip.so: the MI355X (gfx950) implementation of the
+ * differentiable point-cloud visibility + coverage-reward path of ctu-vras/trajectory_optimization.
+ *
+ * The reference has no FFI/plugin seam; its boundary is the Python object API of src/model.py and
+ * src/tools.py.  Each entry point below therefore names the reference code it replaces (file:line,
+ * relative to the reference checkout).  INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - the caller allocates every input, output and workspace buffer; the library keeps no state
+ *     between calls, allocates nothing and frees nothing;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are only enqueued,
+ *     no entry point synchronises unless its comment says so;
+ *   - return value: 0 = ok, >0 = a hipError_t from a launch, <0 = an argument error (TOHIP_E*);
+ *     nothing throws, nothing calls exit();
+ *   - quaternions are (w,x,y,z) like the reference's models (model.py:69,162);
+ *   - float = IEEE binary32 everywhere; indices are int32; counts int64.
+ */
+#ifndef TRAJOPT_HIP_H
+#define TRAJOPT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TOHIP_ABI_VERSION 1
+
+#define TOHIP_OK 0
+#define TOHIP_EINVAL (-1)   /* bad size / null pointer */
+#define TOHIP_ENOSPC (-2)   /* caller-provided workspace or output capacity too small */
+#define TOHIP_ENOTCONV (-3) /* hull construction did not converge within its round limit */
+
+/* Points are processed in tiles of this many; packed clouds are padded to a multiple of it. */
+#define TOHIP_POINT_TILE 1024
+
+/* Camera model shared by all waypoints: load_intrinsics (tools.py:320-325) + the constants the
+ * models keep (model.py:91-94,186-189).  Passed by pointer in HOST memory. */
+typedef struct tohip_camera {
+    float K[9];      /* row-major 3x3 intrinsics */
+    float img_width; /* 1232. */
+    float img_height;/* 1616. */
+    float min_dist;  /* pc_clip_limits[0]  (1.0) */
+    float max_dist;  /* pc_clip_limits[1]  (5.0) */
+    float eps;       /* 1e-6 */
+} tohip_camera;
+
+/* Optional multi-camera rig (BASELINE.json config 5; the reference has no fusion code — each
+ * (camera, waypoint) pair is a virtual waypoint with its own min/max normalisation, all log-odds
+ * summed).  rig_quats: (C,4) unit wxyz rotating camera->body; rig_trans: (C,3) lever arms in the body
+ * frame.  n_cams = 0 or NULL pointers mean "one camera at the body frame". */
+typedef struct tohip_rig {
+    int32_t n_cams;
+    const float *rig_quats; /* device */
+    const float *rig_trans; /* device */
+} tohip_rig;
+
+int tohip_abi_version(void);
+const char *tohip_error_string(int code);
+
+/* ---- cloud packing -------------------------------------------------------------------------
+ * The cloud is constant over an optimisation run (model.py:80,174), so it is packed once:
+ * (N,3) row-major -> x[Npad] | y[Npad] | z[Npad], Npad = tohip_padded_points(N); the pad repeats
+ * the last point. */
+int64_t tohip_padded_points(int64_t n_points);
+int tohip_pack_cloud(const float *xyz, int64_t n_points, float *soa, void *stream);
+
+/* ---- ModelTraj (model.py:200-242 forward, :246 visibility term, autograd backward) ----------
+ * Workspace bytes needed by the three calls below for n_points and n_virtual = W * max(1,n_cams). */
+size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual);
+
+/* Forward over the W evaluated waypoints (caller has applied wps_step, model.py:214-217):
+ * to_camera_frame -> get_dist_mask * get_fov_mask -> per-waypoint (p-min)/max -> clip -> log-odds,
+ * summed over waypoints into lo_sum[0..N) (overwritten; this rank's partial sum when the waypoints
+ * are sharded over GPUs).  minmax[v] = (min p, max(p - min p)) per virtual waypoint, kept for the
+ * backward.  replaces model.py:217-231. */
+int tohip_traj_forward(const float *soa, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
+                       const tohip_camera *cam_host, const tohip_rig *rig_host, float *lo_sum, float *minmax,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* rewards = sigmoid(lo_sum) (model.py:237); scalars[0] = mean(rewards), scalars[1] = loss_vis =
+ * 1/(mean+eps) (model.py:246), scalars[2] = -loss_vis^2/N (d loss_vis / d reward_n). */
+int tohip_traj_reward(const float *lo_sum, int64_t n_points, float eps, float *rewards, float *scalars,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* Backward w.r.t. this rank's waypoints: poses_grad (W,3), quats_grad (W,4).  minmax from the forward.
+ * The upstream gradient is either grad_rewards (N floats, dL/d rewards: any criterion built on
+ * model.rewards, as torch autograd would hand it over), or, when grad_rewards is NULL, the fused
+ * visibility loss: scalars (from tohip_traj_reward) and gout = device pointer to dL/d loss_vis. */
+int tohip_traj_backward(const float *soa, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
+                        const tohip_camera *cam_host, const tohip_rig *rig_host, const float *rewards,
+                        const float *grad_rewards, const float *scalars, const float *minmax, const float *gout,
+                        float *poses_grad, float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- ModelPose (model.py:98-127) -------------------------------------------------------------- */
+size_t tohip_pose_workspace_bytes(int64_t n_points);
+
+/* observations[n] = dist_mask*fov_mask (* occlusion_mask[n] when non-NULL, model.py:112-115);
+ * scalars[0] = sum(observations), scalars[1] = loss = 1/(sum+eps). */
+int tohip_pose_forward(const float *soa, int64_t n_points, const float *trans, const float *quat,
+                       const tohip_camera *cam_host, const float *occlusion_mask, float *observations, float *scalars,
+                       void *workspace, size_t workspace_bytes, void *stream);
+/* Upstream gradient: grad_obs (N floats, dL/d observations) or, when NULL, the fused loss through
+ * scalars (from tohip_pose_forward) and gout (device pointer to dL/d loss). */
+int tohip_pose_backward(const float *soa, int64_t n_points, const float *trans, const float *quat,
+                        const tohip_camera *cam_host, const float *occlusion_mask, const float *grad_obs,
+                        const float *scalars, const float *gout, float *trans_grad, float *quat_grad, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+/* ---- element-wise helpers of model.py (forward values) ---------------------------------------- */
+/* to_camera_frame (model.py:50-57; normalize=1) / ego_to_cam_torch (pc_processor.py:63-70;
+ * normalize=0): bit-identical to the reference's f32 op order.  out_layout 0: (N,3), 1: (3,N). */
+int tohip_to_camera_frame(const float *xyz, int64_t n_points, const float *quat, const float *trans, int normalize,
+                          int out_layout, float *out, void *stream);
+/* get_dist_mask (model.py:13-24) and soft get_fov_mask (model.py:27-47) on (N,3) camera-frame points. */
+int tohip_soft_masks(const float *cam_xyz, int64_t n_points, const tohip_camera *cam_host, float *dist_mask,
+                     float *fov_mask, void *stream);
+
+/* ---- hard frustum cull (tools.py:176-187, pc_processor.py:72-83, model.py:34-39) -------------- */
+size_t tohip_frustum_workspace_bytes(int64_t n_points);
+/* cam_3xN: camera-frame points as (3,N).  dist_mask/fov_mask: N bytes of 0/1 (either may be NULL).
+ * kept_idx (capacity N int32, may be NULL): ascending indices with both masks set; *kept_count (device
+ * int32) their number.  Bit-exact with the reference's CPU path. */
+int tohip_frustum_cull(const float *cam_3xN, int64_t n_points, const tohip_camera *cam_host, float min_dist,
+                       float max_dist, uint8_t *dist_mask, uint8_t *fov_mask, int32_t *kept_idx, int32_t *kept_count,
+                       void *workspace, size_t workspace_bytes, void *stream);
+/* gather rows: out[i,:] = xyz[idx[i],:] for i < *count (device), xyz (N,3) or (3,N) by in_layout. */
+int tohip_gather_points(const float *xyz, int64_t n_points, int in_layout, const int32_t *idx, const int32_t *count,
+                        int64_t capacity, float *out_xyz, void *stream);
+
+/* ---- hidden-point removal (tools.py:38-85) ------------------------------------------------------ */
+size_t tohip_hpr_workspace_bytes(int64_t n_points);
+/* sphericalFlip (tools.py:38-53): flipped (N,3), radius_out[0] = max||p|| * 10^param. Bit-exact. */
+int tohip_spherical_flip(const float *xyz, int64_t n_points, float param, float *flipped, float *radius_out,
+                         void *workspace, size_t workspace_bytes, void *stream);
+/* hidden_pts_removal (tools.py:67-85): flip, convex hull of flipped points + origin (double
+ * precision quickhull on the GPU), visible = hull vertices in ascending index order minus the LAST
+ * one (the reference drops hull.vertices[-1] unconditionally).  visible_idx capacity N int32;
+ * *visible_count device int32; mask (N floats of 0/1, may be NULL).  SYNCHRONISES the stream (the hull
+ * is built in rounds whose convergence is read back). */
+int tohip_hidden_pts_removal(const float *xyz, int64_t n_points, float param, int32_t *visible_idx,
+                             int32_t *visible_count, float *mask, void *workspace, size_t workspace_bytes,
+                             void *stream);
+
+/* ---- optional per-kernel timing (bench.py's roofline leg) -----------------------------------------
+ * When enabled, every launch of the big kernels is bracketed by hipEventRecord on its own stream.
+ * tohip_profile_read synchronises on those events and returns, per kernel id < TOHIP_PROF_NKERNELS,
+ * the summed milliseconds and the number of launches since the last read (HOST arrays). */
+#define TOHIP_PROF_NKERNELS 5
+int tohip_profile_enable(int on);
+const char *tohip_profile_name(int id);
+int tohip_profile_read(double *ms_sum_host, int64_t *counts_host);
+
+/* ---- self tests of cross-lane primitives (used by tests/, cheap) -------------------------------- */
+int tohip_selftest_wave_reduce(const float *in64xK, int32_t k, float *out_sum, float *out_min, float *out_max,
+                               void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAJOPT_HIP_H */

@@ -1,0 +1,122 @@
+"""The reference-shaped Python surface (ModelTraj / ModelPose + Adam loops) on the GPU vs golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_inf
+from trajectory_optimization_amd import synth
+
+pytestmark = pytest.mark.gpu
+K, IW, IH = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _traj_model(d, dev, **kw):
+    from trajectory_optimization_amd.model import ModelTraj
+    return ModelTraj(points=torch.from_numpy(d["points"]), wps_poses=torch.from_numpy(d["poses"]),
+                     wps_quats=torch.from_numpy(d["quats"]), intrins=torch.from_numpy(K), img_width=IW, img_height=IH,
+                     device=dev, **kw)
+
+
+@pytest.mark.parametrize("name", ["traj_bundled_default", "traj_bundled_tilted_all", "traj_synth_10000x8"])
+def test_model_traj_matches_reference(dev, name):
+    d = load_golden(name)
+    kw = {k: float(d[k]) for k in ("smoothness_weight", "traj_length_weight") if k in d}
+    m = _traj_model(d, dev, **kw)
+    loss = m(vis_wps_dist=float(d["vis_wps_dist"]))
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) <= 5e-6 * abs(float(d["loss"]))
+    for k in ("vis", "l2", "smooth", "length"):
+        assert abs(float(m.loss[k]) - float(d["loss_" + k])) <= 5e-6 * max(1.0, abs(float(d["loss_" + k])))
+    np.testing.assert_allclose(m.rewards.detach().cpu().numpy(), d["rewards"], rtol=2e-5, atol=2e-6)
+    assert rel_inf(m.poses.grad.cpu().numpy(), d["poses_grad"]) < 1e-5
+    assert rel_inf(m.quats.grad.cpu().numpy(), d["quats_grad"]) < 1e-5
+
+
+def test_known_answers(dev):
+    """bundled cloud/path, identity quats, defaults."""
+    d = load_golden("traj_bundled_default")
+    m = _traj_model(d, dev)
+    loss = m()
+    assert m._wps_step(0.5) == 2
+    assert abs(loss.item() - 6.954090595) < 3e-5
+    assert abs(float(m.loss["vis"]) - 1.889989376) < 1e-5
+    assert abs(float(m.loss["smooth"]) - 5.064101219) < 2e-5
+    assert abs(m.rewards.mean().item() - 0.5291025) < 2e-6
+    loss.backward()
+    assert torch.all(m.quats.grad[1] == 0)  # not evaluated (wps_step 2): regularisers do not touch quats
+
+
+def test_traj_adam_loop(dev):
+    """/root/reference/src/trajectory_optimization.py:91-116 with the launch-file learning rates."""
+    d = load_golden("traj_adam_bundled")
+    d["points"] = load_golden("bundled")["pts"]
+    m = _traj_model(d, dev)
+    opt = torch.optim.Adam([{"params": [m.poses], "lr": float(d["lr_pose"])},
+                            {"params": [m.quats], "lr": float(d["lr_quat"])}])
+    losses = []
+    for i in range(10):
+        opt.zero_grad()
+        loss = m()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        if i + 1 in (1, 5, 10):
+            # Adam's sign-like first steps amplify 1e-6 gradient noise where g ~ 0: absolute tolerance
+            np.testing.assert_allclose(m.poses.detach().cpu().numpy(), d[f"poses_step{i + 1}"], rtol=0, atol=2e-3)
+            np.testing.assert_allclose(m.quats.detach().cpu().numpy(), d[f"quats_step{i + 1}"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(losses, d["losses"], rtol=2e-3)
+
+
+def _pose_model(d, dev):
+    from trajectory_optimization_amd.model import ModelPose
+    return ModelPose(points=torch.from_numpy(d["points"]), trans0=torch.from_numpy(d["trans0"]),
+                     q0=torch.from_numpy(d["q0"]), intrins=torch.from_numpy(K), img_width=IW, img_height=IH, device=dev)
+
+
+@pytest.mark.parametrize("name", ["pose_bundled_nohpr", "pose_bundled_tilted"])
+def test_model_pose_matches_reference(dev, name):
+    d = load_golden(name)
+    m = _pose_model(d, dev)
+    loss = m(hpr=bool(d["hpr"]))
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) <= 5e-6 * float(d["loss"])
+    np.testing.assert_allclose(m.observations.detach().cpu().numpy(), d["observations"], rtol=5e-5, atol=1e-9)
+    assert rel_inf(m.trans.grad.cpu().numpy(), d["trans_grad"]) < 1e-5
+    assert rel_inf(m.quat.grad.cpu().numpy(), d["quat_grad"]) < 1e-5
+
+
+def test_pose_adam_loop(dev):
+    d = load_golden("pose_adam_bundled")
+    d["points"] = load_golden("bundled")["pts"]
+    m = _pose_model(d, dev)
+    opt = torch.optim.Adam([{"params": [m.trans], "lr": float(d["lr_pose"])},
+                            {"params": [m.quat], "lr": float(d["lr_quat"])}])
+    losses = []
+    for i in range(10):
+        opt.zero_grad()
+        loss = m()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        if i + 1 in (1, 5, 10):
+            np.testing.assert_allclose(m.trans.detach().cpu().numpy(), d[f"trans_step{i + 1}"], rtol=0, atol=1e-3)
+            np.testing.assert_allclose(m.quat.detach().cpu().numpy(), d[f"quat_step{i + 1}"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(losses, d["losses"], rtol=1e-3)
+
+
+def test_errors_like_reference(dev):
+    """W=1 -> the reference's int(NaN) ValueError; CPU device -> loud failure (no fallback)."""
+    from trajectory_optimization_amd.model import ModelTraj
+    pts = torch.from_numpy(synth.make_cloud(1000, seed=1))
+    p, q = synth.make_path(1)
+    m = ModelTraj(pts, torch.from_numpy(p), torch.from_numpy(q), torch.from_numpy(K), IW, IH, device=dev)
+    with pytest.raises(ValueError):
+        m()
+    with pytest.raises(RuntimeError):
+        ModelTraj(pts, torch.from_numpy(p), torch.from_numpy(q), torch.from_numpy(K), IW, IH, device=torch.device("cpu"))

@@ -1,0 +1,123 @@
+"""ctypes loader of libtrajopt_hip.so (the C ABI declared in include/trajopt_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or does not load, importing
+any op raises.  torch is imported first so that the library binds to the HIP runtime torch already
+loaded (same SONAME, libamdhip64.so.7) instead of pulling a second runtime into the process.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede the CDLL below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrajopt_hip.so")
+SRC = os.path.join(_HERE, "csrc", "trajopt_hip.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"]
+
+c_vp, c_i64, c_i32, c_f, c_sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
+
+
+class Camera(ctypes.Structure):
+    """struct tohip_camera (include/trajopt_hip.h)."""
+    _fields_ = [("K", c_f * 9), ("img_width", c_f), ("img_height", c_f), ("min_dist", c_f), ("max_dist", c_f),
+                ("eps", c_f)]
+
+
+class Rig(ctypes.Structure):
+    """struct tohip_rig (include/trajopt_hip.h)."""
+    _fields_ = [("n_cams", c_i32), ("rig_quats", c_vp), ("rig_trans", c_vp)]
+
+
+# name -> (restype, argtypes); every symbol include/trajopt_hip.h declares
+SIGNATURES = {
+    "tohip_abi_version": (ctypes.c_int, []),
+    "tohip_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "tohip_padded_points": (c_i64, [c_i64]),
+    "tohip_pack_cloud": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "tohip_traj_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "tohip_traj_forward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig),
+                                           c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_traj_reward": (ctypes.c_int, [c_vp, c_i64, c_f, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_traj_backward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig),
+                                            c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_pose_workspace_bytes": (c_sz, [c_i64]),
+    "tohip_pose_forward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(Camera), c_vp, c_vp, c_vp, c_vp, c_sz,
+                                           c_vp]),
+    "tohip_pose_backward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(Camera), c_vp, c_vp, c_vp, c_vp, c_vp,
+                                            c_vp, c_vp, c_sz, c_vp]),
+    "tohip_to_camera_frame": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
+    "tohip_soft_masks": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(Camera), c_vp, c_vp, c_vp]),
+    "tohip_frustum_workspace_bytes": (c_sz, [c_i64]),
+    "tohip_frustum_cull": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(Camera), c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                           c_sz, c_vp]),
+    "tohip_gather_points": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "tohip_hpr_workspace_bytes": (c_sz, [c_i64]),
+    "tohip_spherical_flip": (ctypes.c_int, [c_vp, c_i64, c_f, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_hidden_pts_removal": (ctypes.c_int, [c_vp, c_i64, c_f, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "tohip_profile_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "tohip_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    "tohip_selftest_wave_reduce": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/trajopt_hip.hip for gfx950 into libtrajopt_hip.so (in-tree)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "trajopt_hip.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    cmd = [HIPCC] + HIPCC_FLAGS + [SRC, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library with argtypes set.  Raises (never falls back) when it is unavailable."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if handle.tohip_abi_version() != 1:
+            raise ImportError("libtrajopt_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(code, what):
+    if code != 0:
+        raise HipError(f"{what} failed: {lib().tohip_error_string(code).decode()} (code {code})")
+
+
+def make_camera(K, img_width, img_height, min_dist, max_dist, eps=1e-6):
+    """K: 9 floats (row-major) on the host."""
+    cam = Camera()
+    for i, v in enumerate(K):
+        cam.K[i] = float(v)
+    cam.img_width, cam.img_height = float(img_width), float(img_height)
+    cam.min_dist, cam.max_dist, cam.eps = float(min_dist), float(max_dist), float(eps)
+    return cam
+
+
+def stream_ptr():
+    return c_vp(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_vp(t.data_ptr()) if t is not None else c_vp(0)

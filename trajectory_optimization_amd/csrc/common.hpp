@@ -1,0 +1,214 @@
+// common.hpp — device-side building blocks shared by the gfx950 kernels.
+//
+// Compiled with -ffp-contract=off: every fused multiply-add below is written as fmaf(), so the
+// same source gives the same bits in every kernel that recomputes a visibility value (pass 1,
+// pass 2 and the backward compare p against the per-waypoint min/max with ==).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/trajopt_hip.h"
+
+#define TO_WAVE 64
+#define TO_BLOCK 256
+#define TO_WAVES_PER_BLOCK (TO_BLOCK / TO_WAVE)
+
+#define TO_HIP_CHECK_LAUNCH()                       \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+// ----------------------------------------------------------------------------------------------
+// Camera constants (kernel argument -> SGPRs) and per-virtual-waypoint camera records.
+
+struct CamConsts {
+    float k[9];
+    float halfw, halfh;      // img_width/2, img_height/2             model.py:44-45
+    float inv_w, inv_h;      // 1/img_width, 1/img_height
+    float mean;              // (min+max)/2                           model.py:20
+    float inv_var;           // 1/std^2, std=(max-min)/2              model.py:21
+    float eps;               // 1e-6                                  model.py:44
+    float clip_hi;           // float32(1-1e-6)                       model.py:229
+    int pinhole;             // K = [[fx,0,cx],[0,fy,cy],[0,0,1]]
+};
+
+// Hot record, one 64-byte line per virtual waypoint: c = m * (x - t).  a/M/invM are filled by the
+// min/max finishing kernel (p_hat = (p - a) * invM).
+struct __attribute__((aligned(64))) WayHot {
+    float m[9];   // m[3*i+j] = R[j][i]  (R = rotation camera->world of the virtual waypoint)
+    float t[3];
+    float a;      // min_n p
+    float M;      // max_n (p - a)
+    float invM;   // 1/M
+    float pad;
+};
+
+// Cold record used by the gradient chain.
+struct WayCold {
+    float qn[4];  // normalised body quaternion
+    float nrm;    // max(||q||, 1e-12)
+    float pad[3];
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static inline CamConsts make_consts(const tohip_camera* c) {
+    CamConsts k;
+    for (int i = 0; i < 9; ++i) k.k[i] = c->K[i];
+    k.halfw = (float)((double)c->img_width / 2.0);
+    k.halfh = (float)((double)c->img_height / 2.0);
+    k.inv_w = 1.0f / c->img_width;
+    k.inv_h = 1.0f / c->img_height;
+    k.mean = (float)(((double)c->min_dist + (double)c->max_dist) / 2.0);
+    const double sd = ((double)c->max_dist - (double)c->min_dist) / 2.0;
+    k.inv_var = (float)(1.0 / (sd * sd));
+    k.eps = c->eps;
+    k.clip_hi = (float)(1.0 - (double)c->eps);
+    k.pinhole = (c->K[1] == 0.f && c->K[3] == 0.f && c->K[6] == 0.f && c->K[7] == 0.f && c->K[8] == 1.f) ? 1 : 0;
+    return k;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Transcendentals on the hardware units (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each).
+
+__device__ __forceinline__ float to_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// exp(x), ~1.5 ulp: the rounding error of x*log2(e) is recovered with one fma and folded back in.
+// x is clamped to [-150, 88] (results below 2^-149 flush to 0; above: stays finite).
+__device__ __forceinline__ float to_exp(float x) {
+    x = __builtin_amdgcn_fmed3f(x, -150.0f, 88.0f);
+    const float L2E = 1.44269504088896341f, L2E_LO = 1.925963033500519e-8f;
+    const float e = x * L2E;
+    float r = fmaf(x, L2E, -e);
+    r = fmaf(x, L2E_LO, r);
+    const float y = __builtin_amdgcn_exp2f(e);
+    return fmaf(y, r * 0.693147180559945f, y);
+}
+
+__device__ __forceinline__ float to_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+// ----------------------------------------------------------------------------------------------
+// Soft visibility of one camera-frame point: p = D * (S * Gw * Gh)   (model.py:13-47, :110/:223).
+// The three Gaussians share one exponential: exp(a)exp(b)exp(c) = exp(a+b+c).
+
+struct Vis {
+    float p, S, u, v, rz;
+};
+
+template <bool PINHOLE>
+__device__ __forceinline__ float soft_vis(const CamConsts& k, float X, float Y, float Z, Vis* o) {
+    const float dx = X - k.mean, dy = Y - k.mean, dz = Z - k.mean;
+    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    float h0, h1, h2;
+    if (PINHOLE) {
+        h0 = fmaf(k.k[2], Z, k.k[0] * X);
+        h1 = fmaf(k.k[5], Z, k.k[4] * Y);
+        h2 = Z;
+    } else {
+        h0 = fmaf(k.k[2], Z, fmaf(k.k[1], Y, k.k[0] * X));
+        h1 = fmaf(k.k[5], Z, fmaf(k.k[4], Y, k.k[3] * X));
+        h2 = fmaf(k.k[8], Z, fmaf(k.k[7], Y, k.k[6] * X));
+    }
+    const float rz = to_rcp(h2 + k.eps);
+    const float u = h0 * rz, v = h1 * rz;
+    const float au = (u - k.halfw) * k.inv_w, av = (v - k.halfh) * k.inv_h;
+    float arg = d2 * k.inv_var;          // (dist/std)^2
+    arg = fmaf(au, au, arg);
+    arg = fmaf(av, av, arg);
+    const float E = to_exp(-0.5f * arg);
+    const float S = to_rcp(1.0f + to_exp(-h2));
+    const float p = S * E;
+    if (o) {
+        o->p = p; o->S = S; o->u = u; o->v = v; o->rz = rz;
+    }
+    return p;
+}
+
+// d p / d c for the same point; zero where p underflowed.
+template <bool PINHOLE>
+__device__ __forceinline__ void dvis_dc(const CamConsts& k, float X, float Y, float Z, const Vis& s, float g[3]) {
+    const float gw = -(s.u - k.halfw) * (k.inv_w * k.inv_w);
+    const float gh = -(s.v - k.halfh) * (k.inv_h * k.inv_h);
+    const float a0 = gw * s.rz, a1 = gh * s.rz;
+    const float a2 = (1.0f - s.S) - fmaf(gw, s.u, gh * s.v) * s.rz;
+    float k0, k1, k2;
+    if (PINHOLE) {
+        k0 = k.k[0] * a0;
+        k1 = k.k[4] * a1;
+        k2 = fmaf(k.k[2], a0, fmaf(k.k[5], a1, a2));
+    } else {
+        k0 = fmaf(k.k[0], a0, fmaf(k.k[3], a1, k.k[6] * a2));
+        k1 = fmaf(k.k[1], a0, fmaf(k.k[4], a1, k.k[7] * a2));
+        k2 = fmaf(k.k[2], a0, fmaf(k.k[5], a1, k.k[8] * a2));
+    }
+    const bool live = s.p > 0.0f;
+    g[0] = live ? s.p * fmaf(-(X - k.mean), k.inv_var, k0) : 0.0f;
+    g[1] = live ? s.p * fmaf(-(Y - k.mean), k.inv_var, k1) : 0.0f;
+    g[2] = live ? s.p * fmaf(-(Z - k.mean), k.inv_var, k2) : 0.0f;
+}
+
+// world point -> camera frame of a virtual waypoint
+__device__ __forceinline__ void to_cam(const WayHot& h, float x, float y, float z, float& X, float& Y, float& Z,
+                                       float& y0, float& y1, float& y2) {
+    y0 = x - h.t[0]; y1 = y - h.t[1]; y2 = z - h.t[2];
+    X = fmaf(h.m[2], y2, fmaf(h.m[1], y1, h.m[0] * y0));
+    Y = fmaf(h.m[5], y2, fmaf(h.m[4], y1, h.m[3] * y0));
+    Z = fmaf(h.m[8], y2, fmaf(h.m[7], y1, h.m[6] * y0));
+}
+
+// ----------------------------------------------------------------------------------------------
+// Wave64 reductions on the DPP network; the result is valid in lane 63.
+//   quad_perm[1,0,3,2]=0xB1  quad_perm[2,3,0,1]=0x4E  row_half_mirror=0x141  row_mirror=0x140
+//   row_bcast:15=0x142 (row_mask 0xA)  row_bcast:31=0x143 (row_mask 0xC)
+
+#define TO_DPP_F(old, v, ctrl, rmask) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(v)), ctrl, rmask, 0xF, false))
+
+__device__ __forceinline__ float wave_sum63(float v) {
+    v += TO_DPP_F(0.f, v, 0xB1, 0xF);
+    v += TO_DPP_F(0.f, v, 0x4E, 0xF);
+    v += TO_DPP_F(0.f, v, 0x141, 0xF);
+    v += TO_DPP_F(0.f, v, 0x140, 0xF);
+    v += TO_DPP_F(0.f, v, 0x142, 0xA);
+    v += TO_DPP_F(0.f, v, 0x143, 0xC);
+    return v;
+}
+__device__ __forceinline__ float wave_min63(float v) {
+    v = fminf(v, TO_DPP_F(v, v, 0xB1, 0xF));
+    v = fminf(v, TO_DPP_F(v, v, 0x4E, 0xF));
+    v = fminf(v, TO_DPP_F(v, v, 0x141, 0xF));
+    v = fminf(v, TO_DPP_F(v, v, 0x140, 0xF));
+    v = fminf(v, TO_DPP_F(v, v, 0x142, 0xA));
+    v = fminf(v, TO_DPP_F(v, v, 0x143, 0xC));
+    return v;
+}
+__device__ __forceinline__ float wave_max63(float v) {
+    v = fmaxf(v, TO_DPP_F(v, v, 0xB1, 0xF));
+    v = fmaxf(v, TO_DPP_F(v, v, 0x4E, 0xF));
+    v = fmaxf(v, TO_DPP_F(v, v, 0x141, 0xF));
+    v = fmaxf(v, TO_DPP_F(v, v, 0x140, 0xF));
+    v = fmaxf(v, TO_DPP_F(v, v, 0x142, 0xA));
+    v = fmaxf(v, TO_DPP_F(v, v, 0x143, 0xC));
+    return v;
+}
+
+// block-wide double sum through LDS (fixed order -> deterministic); result valid in thread 0
+__device__ __forceinline__ double block_sum_double(double v, double* lds /* TO_BLOCK doubles */) {
+    const int t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int s = TO_BLOCK / 2; s > 0; s >>= 1) {
+        if (t < s) lds[t] += lds[t + s];
+        __syncthreads();
+    }
+    return lds[0];
+}
+
+// Rotation matrix (row-major R, camera->world) from a quaternion, homogeneous quadratic form.
+__host__ __device__ inline void quat_to_R(const float q[4], float R[9]) {
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = w * w + x * x - y * y - z * z; R[1] = 2.f * (x * y - w * z);         R[2] = 2.f * (x * z + w * y);
+    R[3] = 2.f * (x * y + w * z);         R[4] = w * w - x * x + y * y - z * z; R[5] = 2.f * (y * z - w * x);
+    R[6] = 2.f * (x * z - w * y);         R[7] = 2.f * (y * z + w * x);         R[8] = w * w - x * x - y * y + z * z;
+}

@@ -1,0 +1,272 @@
+// hard_kernels.hip — cloud packing, the hard (boolean) frustum cull with ordered compaction, row gather,
+// spherical flip, and a self-test of the cross-lane primitives, for gfx950.
+//
+//   get_cam_frustum_pts     /root/reference/src/tools.py:176-187, /root/reference/src/pc_processor.py:72-83
+//   get_fov_mask(binary)    /root/reference/src/model.py:34-39
+//   sphericalFlip           /root/reference/src/tools.py:38-53
+//
+// These produce index sets that must equal the reference's bit for bit, so the arithmetic is the
+// reference CPU path's, operation by operation: K @ points as the k-ordered FMA chain of its 3x3 sgemm,
+// IEEE division, torch.linalg.norm's FMA chain (all pinned on fixtures, tests/test_oracle_golden.py).
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// (N,3) -> x|y|z padded with copies of the last point
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_pack_cloud(const float* __restrict__ xyz, int64_t n, int64_t npad, float* __restrict__ soa) {
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < npad; i += stride) {
+        const int64_t s = i < n ? i : n - 1;
+        soa[i] = xyz[3 * s];
+        soa[npad + i] = xyz[3 * s + 1];
+        soa[2 * npad + i] = xyz[3 * s + 2];
+    }
+}
+
+extern "C" int64_t tohip_padded_points(int64_t n) {
+    if (n <= 0) return 0;
+    return (n + TOHIP_POINT_TILE - 1) / TOHIP_POINT_TILE * TOHIP_POINT_TILE;
+}
+
+extern "C" int tohip_pack_cloud(const float* xyz, int64_t n, float* soa, void* stream_) {
+    if (!xyz || !soa || n <= 0) return TOHIP_EINVAL;
+    const int64_t npad = tohip_padded_points(n);
+    int64_t nb = npad / TO_BLOCK;
+    if (nb > 4096) nb = 4096;
+    k_pack_cloud<<<(int)nb, TO_BLOCK, 0, (hipStream_t)stream_>>>(xyz, n, npad, soa);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hard frustum
+
+struct FrustumConsts {
+    float k[9];
+    float wl, hl;  // img_width - 1, img_height - 1
+    float dmin, dmax;
+};
+
+__device__ __forceinline__ void frustum_pred(const FrustumConsts& f, float X, float Y, float Z, bool& dist, bool& fov) {
+    const float h0 = fmaf(f.k[2], Z, fmaf(f.k[1], Y, f.k[0] * X));
+    const float h1 = fmaf(f.k[5], Z, fmaf(f.k[4], Y, f.k[3] * X));
+    const float h2 = fmaf(f.k[8], Z, fmaf(f.k[7], Y, f.k[6] * X));
+    const float u = h0 / h2, v = h1 / h2;  // IEEE-rounded division (tools.py:182)
+    dist = (Z > f.dmin) && (Z < f.dmax);
+    fov = (h2 > 0.0f) && (u > 1.0f) && (u < f.wl) && (v > 1.0f) && (v < f.hl);
+}
+
+#define TO_CULL_TILE 1024
+
+// pass A: masks + number of kept points per 1024-point tile
+__global__ void __launch_bounds__(TO_BLOCK)
+k_frustum_count(const float* __restrict__ cam, int64_t n, FrustumConsts f, uint8_t* __restrict__ dist_mask,
+                uint8_t* __restrict__ fov_mask, int32_t* __restrict__ tile_count) {
+    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
+    const int64_t tile0 = (int64_t)blockIdx.x * TO_CULL_TILE;
+    int cnt = 0;
+    for (int j = 0; j < TO_CULL_TILE / TO_BLOCK; ++j) {
+        const int64_t i = tile0 + j * TO_BLOCK + threadIdx.x;
+        bool d = false, v = false;
+        if (i < n) {
+            frustum_pred(f, cam[i], cam[n + i], cam[2 * n + i], d, v);
+            if (dist_mask) dist_mask[i] = d ? 1 : 0;
+            if (fov_mask) fov_mask[i] = v ? 1 : 0;
+        }
+        cnt += __popcll(__ballot(d && v));
+    }
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// pass B: exclusive scan of the tile counts (one block, chunks of 256, in order)
+__global__ void __launch_bounds__(TO_BLOCK)
+k_scan_tiles(const int32_t* __restrict__ tile_count, int ntiles, int32_t* __restrict__ tile_off,
+             int32_t* __restrict__ total) {
+    __shared__ int lds[TO_BLOCK];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < ntiles; c0 += TO_BLOCK) {
+        const int i = c0 + threadIdx.x;
+        const int v = i < ntiles ? tile_count[i] : 0;
+        lds[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 1; s < TO_BLOCK; s <<= 1) {  // Hillis-Steele inclusive scan
+            const int add = threadIdx.x >= s ? lds[threadIdx.x - s] : 0;
+            __syncthreads();
+            lds[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < ntiles) tile_off[i] = carry + lds[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += lds[TO_BLOCK - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+// pass C: ascending indices of kept points
+__global__ void __launch_bounds__(TO_BLOCK)
+k_frustum_write(const float* __restrict__ cam, int64_t n, FrustumConsts f, const int32_t* __restrict__ tile_off,
+                int32_t* __restrict__ kept_idx) {
+    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile0 = (int64_t)blockIdx.x * TO_CULL_TILE;
+    int base = tile_off[blockIdx.x];
+    for (int j = 0; j < TO_CULL_TILE / TO_BLOCK; ++j) {
+        const int64_t i = tile0 + j * TO_BLOCK + threadIdx.x;
+        bool d = false, v = false;
+        if (i < n) frustum_pred(f, cam[i], cam[n + i], cam[2 * n + i], d, v);
+        const bool keep = d && v;
+        const unsigned long long b = __ballot(keep);
+        if (lane == 0) wave_cnt[wave] = __popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (keep) kept_idx[off + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)i;
+        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
+extern "C" size_t tohip_frustum_workspace_bytes(int64_t n) {
+    if (n <= 0) return 256;
+    const size_t ntiles = (size_t)((n + TO_CULL_TILE - 1) / TO_CULL_TILE);
+    return 2 * ((ntiles * sizeof(int32_t) + 255) / 256 * 256) + 256;
+}
+
+extern "C" int tohip_frustum_cull(const float* cam_3xN, int64_t n, const tohip_camera* cam, float min_dist,
+                                  float max_dist, uint8_t* dist_mask, uint8_t* fov_mask, int32_t* kept_idx,
+                                  int32_t* kept_count, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!cam || n < 0 || (n > 0 && !cam_3xN) || n > (int64_t)0x7fffffff || !workspace) return TOHIP_EINVAL;
+    if (workspace_bytes < tohip_frustum_workspace_bytes(n)) return TOHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream_;
+    if (n == 0) {
+        if (kept_count) {
+            hipError_t e = hipMemsetAsync(kept_count, 0, sizeof(int32_t), st);
+            if (e != hipSuccess) return (int)e;
+        }
+        return TOHIP_OK;
+    }
+    FrustumConsts f;
+    for (int i = 0; i < 9; ++i) f.k[i] = cam->K[i];
+    f.wl = (float)((double)cam->img_width - 1.0);
+    f.hl = (float)((double)cam->img_height - 1.0);
+    f.dmin = min_dist;
+    f.dmax = max_dist;
+    const int ntiles = (int)((n + TO_CULL_TILE - 1) / TO_CULL_TILE);
+    const size_t seg = ((size_t)ntiles * sizeof(int32_t) + 255) / 256 * 256;
+    int32_t* tile_count = (int32_t*)workspace;
+    int32_t* tile_off = (int32_t*)((char*)workspace + seg);
+    int32_t* total_scratch = (int32_t*)((char*)workspace + 2 * seg);
+    k_frustum_count<<<ntiles, TO_BLOCK, 0, st>>>(cam_3xN, n, f, dist_mask, fov_mask, tile_count);
+    TO_HIP_CHECK_LAUNCH();
+    if (kept_idx || kept_count) {
+        k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(tile_count, ntiles, tile_off, kept_count ? kept_count : total_scratch);
+        TO_HIP_CHECK_LAUNCH();
+    }
+    if (kept_idx) {
+        k_frustum_write<<<ntiles, TO_BLOCK, 0, st>>>(cam_3xN, n, f, tile_off, kept_idx);
+        TO_HIP_CHECK_LAUNCH();
+    }
+    return TOHIP_OK;
+}
+
+// out[i,:] = xyz[idx[i],:]  for i < *count
+__global__ void __launch_bounds__(TO_BLOCK)
+k_gather_points(const float* __restrict__ xyz, int64_t n, int in_layout, const int32_t* __restrict__ idx,
+                const int32_t* __restrict__ count, float* __restrict__ out) {
+    const int m = *count;
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < m; i += stride) {
+        const int64_t s = idx[i];
+        if (in_layout == 0) {
+            out[3 * i] = xyz[3 * s]; out[3 * i + 1] = xyz[3 * s + 1]; out[3 * i + 2] = xyz[3 * s + 2];
+        } else {
+            out[3 * i] = xyz[s]; out[3 * i + 1] = xyz[n + s]; out[3 * i + 2] = xyz[2 * n + s];
+        }
+    }
+}
+
+extern "C" int tohip_gather_points(const float* xyz, int64_t n, int in_layout, const int32_t* idx, const int32_t* count,
+                                   int64_t capacity, float* out, void* stream_) {
+    if (!xyz || !idx || !count || !out || n <= 0 || capacity < 0) return TOHIP_EINVAL;
+    if (capacity == 0) return TOHIP_OK;
+    int64_t nb = (capacity + TO_BLOCK - 1) / TO_BLOCK;
+    if (nb > 2048) nb = 2048;
+    k_gather_points<<<(int)nb, TO_BLOCK, 0, (hipStream_t)stream_>>>(xyz, n, in_layout, idx, count, out);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// spherical flip
+
+__device__ __forceinline__ float flip_norm(float x, float y, float z) { return sqrtf(fmaf(z, z, fmaf(y, y, x * x))); }
+
+// max of the norms through an integer atomicMax on the float bits: norms are >= 0 so the integer order is
+// the float order, and a NaN (0x7fc00000) sorts above +inf, i.e. propagates like torch.max does.
+__global__ void __launch_bounds__(TO_BLOCK)
+k_norm_max(const float* __restrict__ xyz, int64_t n, int* __restrict__ max_bits) {
+    int m = 0;
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float nr = flip_norm(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+        m = max(m, __float_as_int(nr) & 0x7fffffff);
+    }
+    for (int s = 32; s > 0; s >>= 1) m = max(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, m);
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_flip(const float* __restrict__ xyz, int64_t n, const int* __restrict__ max_bits, float scale,
+       float* __restrict__ flipped, float* __restrict__ radius_out) {
+    const float radius = __int_as_float(*max_bits) * scale;  // tools.py:45
+    if (radius_out && blockIdx.x == 0 && threadIdx.x == 0) radius_out[0] = radius;
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        const float nr = flip_norm(x, y, z);
+        const float r = radius - nr;
+        flipped[3 * i] = (2.0f * (r * x)) / nr + x;  // tools.py:46-52
+        flipped[3 * i + 1] = (2.0f * (r * y)) / nr + y;
+        flipped[3 * i + 2] = (2.0f * (r * z)) / nr + z;
+    }
+}
+
+static int launch_flip(const float* xyz, int64_t n, float param, float* flipped, float* radius_out, int* max_bits,
+                       hipStream_t st) {
+    hipError_t e = hipMemsetAsync(max_bits, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
+    if (nb > 2048) nb = 2048;
+    k_norm_max<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, max_bits);
+    TO_HIP_CHECK_LAUNCH();
+    const float scale = (float)pow(10.0, (double)param);
+    k_flip<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, max_bits, scale, flipped, radius_out);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// self test: column sums / mins / maxs of a (64, K) matrix with the DPP reductions
+
+__global__ void k_selftest_wave_reduce(const float* __restrict__ in, int k, float* __restrict__ osum,
+                                       float* __restrict__ omin, float* __restrict__ omax) {
+    const int lane = threadIdx.x;
+    for (int c = 0; c < k; ++c) {
+        const float v = in[lane * k + c];
+        const float s = wave_sum63(v), mn = wave_min63(v), mx = wave_max63(v);
+        if (lane == 63) { osum[c] = s; omin[c] = mn; omax[c] = mx; }
+    }
+}
+
+extern "C" int tohip_selftest_wave_reduce(const float* in, int32_t k, float* osum, float* omin, float* omax, void* stream_) {
+    if (!in || !osum || !omin || !omax || k <= 0) return TOHIP_EINVAL;
+    k_selftest_wave_reduce<<<1, 64, 0, (hipStream_t)stream_>>>(in, k, osum, omin, omax);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}

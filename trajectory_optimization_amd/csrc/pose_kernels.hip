@@ -1,0 +1,270 @@
+// pose_kernels.hip — ModelPose (single camera pose) forward/backward and the element-wise helper
+// functions of /root/reference/src/model.py for gfx950.
+//
+//   ModelPose.forward / criterion   model.py:98-127
+//   to_camera_frame                 model.py:50-57   (exact f32 op order of the reference)
+//   get_dist_mask / get_fov_mask    model.py:13-47
+#include <type_traits>
+
+#include "common.hpp"
+
+// k_prep_waycams / k_bwd_finish2 come from traj_kernels.hip (same translation unit, see trajopt_hip.hip)
+
+// observations + block partial sums (grid-stride, one point per lane per step: streaming 12 B in, 4 B out)
+template <bool PINHOLE>
+__global__ void __launch_bounds__(TO_BLOCK)
+k_pose_fwd(const float* __restrict__ soa, int64_t npad, int64_t n, const WayHot* __restrict__ hot, CamConsts cc,
+           const float* __restrict__ mask, float* __restrict__ obs, double* __restrict__ part) {
+    __shared__ double lds[TO_BLOCK];
+    const WayHot h = hot[0];
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        float X, Y, Z, y0, y1, y2;
+        to_cam(h, soa[i], soa[npad + i], soa[2 * npad + i], X, Y, Z, y0, y1, y2);
+        float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
+        if (mask) p = mask[i] * p;  // model.py:115
+        obs[i] = p;
+        s += (double)p;
+    }
+    const double tot = block_sum_double(s, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_pose_fwd_finish(const double* __restrict__ part, int nparts, float eps, float* __restrict__ scalars) {
+    __shared__ double lds[TO_BLOCK];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += TO_BLOCK) s += part[i];
+    const double tot = block_sum_double(s, lds);
+    if (threadIdx.x == 0) {
+        const float sum = (float)tot;
+        scalars[0] = sum;
+        scalars[1] = 1.0f / (sum + eps);  // model.py:126
+    }
+}
+
+// dL/d obs_n = -loss^2 * gout (model.py:126); 12 sums per block: sum w g [3], sum w y (x) g [9]
+template <bool PINHOLE>
+__global__ void __launch_bounds__(TO_BLOCK)
+k_pose_bwd(const float* __restrict__ soa, int64_t npad, int64_t n, const WayHot* __restrict__ hot, CamConsts cc,
+           const float* __restrict__ mask, const float* __restrict__ grad_obs, const float* __restrict__ scalars,
+           const float* __restrict__ gout, double* __restrict__ part) {
+    __shared__ double lds[TO_BLOCK];
+    const WayHot h = hot[0];
+    // dL/d obs_n: a caller-supplied vector (general criterion), else the fused loss 1/(sum+eps)
+    const float coef = grad_obs ? 0.f : -scalars[1] * scalars[1] * gout[0];
+    double acc[12];
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        float X, Y, Z, y0, y1, y2;
+        to_cam(h, soa[i], soa[npad + i], soa[2 * npad + i], X, Y, Z, y0, y1, y2);
+        Vis s;
+        soft_vis<PINHOLE>(cc, X, Y, Z, &s);
+        float g[3];
+        dvis_dc<PINHOLE>(cc, X, Y, Z, s, g);
+        const float go = grad_obs ? grad_obs[i] : coef;
+        const float wgt = mask ? go * mask[i] : go;
+        const float w0 = wgt * g[0], w1 = wgt * g[1], w2 = wgt * g[2];
+        acc[0] += w0; acc[1] += w1; acc[2] += w2;
+        acc[3] += y0 * w0; acc[4] += y0 * w1; acc[5] += y0 * w2;
+        acc[6] += y1 * w0; acc[7] += y1 * w1; acc[8] += y1 * w2;
+        acc[9] += y2 * w0; acc[10] += y2 * w1; acc[11] += y2 * w2;
+    }
+    for (int k = 0; k < 12; ++k) {
+        const double r = block_sum_double(acc[k], lds);
+        if (threadIdx.x == 0) part[(int64_t)blockIdx.x * 12 + k] = r;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_pose_bwd_finish(const double* __restrict__ part, int nparts, float* __restrict__ vgrad) {
+    __shared__ double lds[TO_BLOCK];
+    for (int k = 0; k < 12; ++k) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += TO_BLOCK) s += part[(int64_t)i * 12 + k];
+        const double r = block_sum_double(s, lds);
+        if (threadIdx.x == 0) vgrad[k] = (float)r;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// to_camera_frame / ego_to_cam_torch with the reference's exact f32 arithmetic: (x - t), then
+// quaternion_apply(q_inv, .) = two raw Hamilton products, every term rounded, left to right
+// (no fma: this translation unit is built with -ffp-contract=off).
+
+struct ExactCam {
+    float qi[4];  // q_inv
+    float qn[4];  // conj(q_inv)
+    float t[3];
+};
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_to_camera_frame(const float* __restrict__ xyz, int64_t n, const float* __restrict__ quat,
+                  const float* __restrict__ trans, int normalize, int out_layout, float* __restrict__ out) {
+    float q[4] = {quat[0], quat[1], quat[2], quat[3]};
+    if (normalize) {
+        float ss = q[0] * q[0];
+        ss = ss + q[1] * q[1];
+        ss = ss + q[2] * q[2];
+        ss = ss + q[3] * q[3];
+        float nn = sqrtf(ss);
+        nn = nn < 1e-12f ? 1e-12f : nn;
+        for (int i = 0; i < 4; ++i) q[i] = q[i] / nn;
+    }
+    const float aw = q[0], ax = -q[1], ay = -q[2], az = -q[3];
+    const float cw = q[0], cx = q[1], cy = q[2], cz = q[3];
+    const float t0 = trans[0], t1 = trans[1], t2 = trans[2];
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float bx = xyz[3 * i] - t0, by = xyz[3 * i + 1] - t1, bz = xyz[3 * i + 2] - t2;
+        const float bw = 0.f;
+        const float ow = aw * bw - ax * bx - ay * by - az * bz;
+        const float ox = aw * bx + ax * bw + ay * bz - az * by;
+        const float oy = aw * by - ax * bz + ay * bw + az * bx;
+        const float oz = aw * bz + ax * by - ay * bx + az * bw;
+        const float r0 = ow * cx + ox * cw + oy * cz - oz * cy;
+        const float r1 = ow * cy - ox * cz + oy * cw + oz * cx;
+        const float r2 = ow * cz + ox * cy - oy * cx + oz * cw;
+        if (out_layout == 0) {
+            out[3 * i] = r0; out[3 * i + 1] = r1; out[3 * i + 2] = r2;
+        } else {
+            out[i] = r0; out[n + i] = r1; out[2 * n + i] = r2;
+        }
+    }
+}
+
+// get_dist_mask and soft get_fov_mask as separate outputs (reference op order; IEEE divisions)
+__global__ void __launch_bounds__(TO_BLOCK)
+k_soft_masks(const float* __restrict__ cam_xyz, int64_t n, CamConsts cc, float std_, float img_w, float img_h,
+             float* __restrict__ dist_mask, float* __restrict__ fov_mask) {
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float X = cam_xyz[3 * i], Y = cam_xyz[3 * i + 1], Z = cam_xyz[3 * i + 2];
+        if (dist_mask) {
+            const float dx = X - cc.mean, dy = Y - cc.mean, dz = Z - cc.mean;
+            const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+            const float ds = dist / std_;
+            dist_mask[i] = expf(-0.5f * (ds * ds));
+        }
+        if (fov_mask) {
+            const float h0 = fmaf(cc.k[2], Z, fmaf(cc.k[1], Y, cc.k[0] * X));
+            const float h1 = fmaf(cc.k[5], Z, fmaf(cc.k[4], Y, cc.k[3] * X));
+            const float h2 = fmaf(cc.k[8], Z, fmaf(cc.k[7], Y, cc.k[6] * X));
+            const float S = 1.0f / (1.0f + expf(-h2));
+            const float z = h2 + cc.eps;
+            const float au = (h0 / z - cc.halfw) / img_w, av = (h1 / z - cc.halfh) / img_h;
+            const float Gw = expf(-0.5f * (au * au)), Gh = expf(-0.5f * (av * av));
+            fov_mask[i] = S * Gw * Gh;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int kPoseBlocks = 1024;
+struct PosePlan {
+    size_t off_hot, off_cold, off_part, off_vgrad, total;
+};
+inline PosePlan pose_plan() {
+    PosePlan p;
+    size_t o = 0;
+    p.off_hot = o;   o += align_up(sizeof(WayHot), 256);
+    p.off_cold = o;  o += align_up(sizeof(WayCold), 256);
+    p.off_part = o;  o += align_up((size_t)kPoseBlocks * 12 * sizeof(double), 256);
+    p.off_vgrad = o; o += align_up(12 * sizeof(float), 256);
+    p.total = o;
+    return p;
+}
+inline int pose_blocks(int64_t n) {
+    int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
+    return (int)(nb > kPoseBlocks ? kPoseBlocks : nb);
+}
+}  // namespace
+
+extern "C" size_t tohip_pose_workspace_bytes(int64_t n_points) {
+    (void)n_points;
+    return pose_plan().total;
+}
+
+extern "C" int tohip_pose_forward(const float* soa, int64_t n, const float* trans, const float* quat,
+                                  const tohip_camera* cam, const float* mask, float* obs, float* scalars,
+                                  void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!soa || !trans || !quat || !cam || !obs || !scalars || !workspace || n <= 0) return TOHIP_EINVAL;
+    const PosePlan pl = pose_plan();
+    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    WayHot* hot = (WayHot*)(ws + pl.off_hot);
+    WayCold* cold = (WayCold*)(ws + pl.off_cold);
+    double* part = (double*)(ws + pl.off_part);
+    const CamConsts cc = make_consts(cam);
+    const int64_t npad = tohip_padded_points(n);
+    k_prep_waycams<<<1, 64, 0, st>>>(trans, quat, 1, 1, nullptr, nullptr, hot, cold);
+    TO_HIP_CHECK_LAUNCH();
+    const int nb = pose_blocks(n);
+    if (cc.pinhole) k_pose_fwd<true><<<nb, TO_BLOCK, 0, st>>>(soa, npad, n, hot, cc, mask, obs, part);
+    else k_pose_fwd<false><<<nb, TO_BLOCK, 0, st>>>(soa, npad, n, hot, cc, mask, obs, part);
+    TO_HIP_CHECK_LAUNCH();
+    k_pose_fwd_finish<<<1, TO_BLOCK, 0, st>>>(part, nb, cam->eps, scalars);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+extern "C" int tohip_pose_backward(const float* soa, int64_t n, const float* trans, const float* quat,
+                                   const tohip_camera* cam, const float* mask, const float* grad_obs,
+                                   const float* scalars, const float* gout, float* trans_grad, float* quat_grad,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!soa || !trans || !quat || !cam || !trans_grad || !quat_grad || !workspace || n <= 0 ||
+        (!grad_obs && (!scalars || !gout)))
+        return TOHIP_EINVAL;
+    const PosePlan pl = pose_plan();
+    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    WayHot* hot = (WayHot*)(ws + pl.off_hot);
+    WayCold* cold = (WayCold*)(ws + pl.off_cold);
+    double* part = (double*)(ws + pl.off_part);
+    float* vgrad = (float*)(ws + pl.off_vgrad);
+    const CamConsts cc = make_consts(cam);
+    const int64_t npad = tohip_padded_points(n);
+    k_prep_waycams<<<1, 64, 0, st>>>(trans, quat, 1, 1, nullptr, nullptr, hot, cold);
+    TO_HIP_CHECK_LAUNCH();
+    const int nb = pose_blocks(n);
+    if (cc.pinhole) k_pose_bwd<true><<<nb, TO_BLOCK, 0, st>>>(soa, npad, n, hot, cc, mask, grad_obs, scalars, gout, part);
+    else k_pose_bwd<false><<<nb, TO_BLOCK, 0, st>>>(soa, npad, n, hot, cc, mask, grad_obs, scalars, gout, part);
+    TO_HIP_CHECK_LAUNCH();
+    k_pose_bwd_finish<<<1, TO_BLOCK, 0, st>>>(part, nb, vgrad);
+    TO_HIP_CHECK_LAUNCH();
+    k_bwd_finish2<<<1, 64, 0, st>>>(vgrad, hot, cold, 1, 1, nullptr, nullptr, trans_grad, quat_grad);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+extern "C" int tohip_to_camera_frame(const float* xyz, int64_t n, const float* quat, const float* trans, int normalize,
+                                     int out_layout, float* out, void* stream_) {
+    if (!xyz || !quat || !trans || !out || n < 0) return TOHIP_EINVAL;
+    if (n == 0) return TOHIP_OK;
+    int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
+    if (nb > 4096) nb = 4096;
+    k_to_camera_frame<<<(int)nb, TO_BLOCK, 0, (hipStream_t)stream_>>>(xyz, n, quat, trans, normalize, out_layout, out);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+extern "C" int tohip_soft_masks(const float* cam_xyz, int64_t n, const tohip_camera* cam, float* dist_mask,
+                                float* fov_mask, void* stream_) {
+    if (!cam_xyz || !cam || n < 0) return TOHIP_EINVAL;
+    if (n == 0) return TOHIP_OK;
+    const CamConsts cc = make_consts(cam);
+    const float std_ = (float)(((double)cam->max_dist - (double)cam->min_dist) / 2.0);
+    int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
+    if (nb > 4096) nb = 4096;
+    k_soft_masks<<<(int)nb, TO_BLOCK, 0, (hipStream_t)stream_>>>(cam_xyz, n, cc, std_, cam->img_width, cam->img_height,
+                                                                 dist_mask, fov_mask);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}

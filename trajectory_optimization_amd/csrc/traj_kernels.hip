@@ -1,0 +1,617 @@
+// traj_kernels.hip — ModelTraj visibility term, forward + analytic backward, for gfx950.
+//
+// Replaces the per-waypoint Python loop of /root/reference/src/model.py:217-231 (forward),
+// :237/:246 (rewards, visibility loss) and its torch-autograd backward (SURVEY.md §8a rows A-C,E,G).
+//
+// Data layout in HBM
+//   cloud     SoA x|y|z, each Npad floats (packed once, tohip_pack_cloud)           12 B/point
+//   WayHot    one 64-B record per virtual waypoint (rotation, translation, min, max) -> SGPRs
+//   lo_sum / rewards                                                                  4 B/point each
+//   partials  [virtual waypoint][wave slot] min/max pairs (8 B) and gradient sums (64 B)
+//
+// Kernel shape: one lane owns P consecutive points in registers and loops over the waypoints, whose
+// constants arrive through scalar loads; so HBM traffic is ~N*(12+4) bytes per pass, independent of W,
+// and the passes are VALU/transcendental bound (DESIGN.md has the roofline arithmetic).
+#include <type_traits>
+
+#include "common.hpp"
+#include "profile.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// virtual waypoint records
+
+__device__ __forceinline__ void quat_mul_dev(const float a[4], const float b[4], float o[4]) {
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+
+// thread per virtual waypoint v = w*C + c.  F.normalize (model.py:53), rig composition
+// R_v = R(qn_w) R(q_c), t_v = t_w + R(qn_w) l_c.
+__global__ void k_prep_waycams(const float* __restrict__ poses, const float* __restrict__ quats, int W, int C,
+                               const float* __restrict__ rig_q, const float* __restrict__ rig_t,
+                               WayHot* __restrict__ hot, WayCold* __restrict__ cold) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= W * C) return;
+    const int w = v / C, c = v - w * C;
+    float q[4] = {quats[4 * w], quats[4 * w + 1], quats[4 * w + 2], quats[4 * w + 3]};
+    float ss = q[0] * q[0];
+    ss = ss + q[1] * q[1];
+    ss = ss + q[2] * q[2];
+    ss = ss + q[3] * q[3];
+    float n = sqrtf(ss);
+    n = n < 1e-12f ? 1e-12f : n;
+    for (int i = 0; i < 4; ++i) q[i] = q[i] / n;
+    if (c == 0) {
+        WayCold cd;
+        for (int i = 0; i < 4; ++i) cd.qn[i] = q[i];
+        cd.nrm = n;
+        cd.pad[0] = cd.pad[1] = cd.pad[2] = 0.f;
+        cold[w] = cd;
+    }
+    float Rw[9], R[9];
+    quat_to_R(q, Rw);
+    float t[3] = {poses[3 * w], poses[3 * w + 1], poses[3 * w + 2]};
+    if (rig_q != nullptr) {
+        const float qc[4] = {rig_q[4 * c], rig_q[4 * c + 1], rig_q[4 * c + 2], rig_q[4 * c + 3]};
+        float Rc[9];
+        quat_to_R(qc, Rc);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) R[3 * i + j] = Rw[3 * i] * Rc[j] + Rw[3 * i + 1] * Rc[3 + j] + Rw[3 * i + 2] * Rc[6 + j];
+        if (rig_t != nullptr) {
+            const float l[3] = {rig_t[3 * c], rig_t[3 * c + 1], rig_t[3 * c + 2]};
+            for (int i = 0; i < 3; ++i) t[i] += Rw[3 * i] * l[0] + Rw[3 * i + 1] * l[1] + Rw[3 * i + 2] * l[2];
+        }
+    } else {
+        for (int i = 0; i < 9; ++i) R[i] = Rw[i];
+    }
+    WayHot h;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) h.m[3 * i + j] = R[3 * j + i];
+    h.t[0] = t[0]; h.t[1] = t[1]; h.t[2] = t[2];
+    h.a = 0.f; h.M = 1.f; h.invM = 1.f; h.pad = 0.f;
+    hot[v] = h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// point loads: lane owns P consecutive points
+
+template <int P>
+__device__ __forceinline__ void load_points(const float* __restrict__ soa, int64_t npad, int64_t base, float (&x)[P],
+                                            float (&y)[P], float (&z)[P]) {
+    if constexpr (P == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(soa + base);
+        const float4 b = *reinterpret_cast<const float4*>(soa + npad + base);
+        const float4 c = *reinterpret_cast<const float4*>(soa + 2 * npad + base);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+        y[0] = b.x; y[1] = b.y; y[2] = b.z; y[3] = b.w;
+        z[0] = c.x; z[1] = c.y; z[2] = c.z; z[3] = c.w;
+    } else if constexpr (P == 2) {
+        const float2 a = *reinterpret_cast<const float2*>(soa + base);
+        const float2 b = *reinterpret_cast<const float2*>(soa + npad + base);
+        const float2 c = *reinterpret_cast<const float2*>(soa + 2 * npad + base);
+        x[0] = a.x; x[1] = a.y; y[0] = b.x; y[1] = b.y; z[0] = c.x; z[1] = c.y;
+    } else {
+        x[0] = soa[base]; y[0] = soa[npad + base]; z[0] = soa[2 * npad + base];
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void load_vec(const float* __restrict__ src, int64_t base, float (&v)[P]) {
+    if constexpr (P == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(src + base);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    } else if constexpr (P == 2) {
+        const float2 a = *reinterpret_cast<const float2*>(src + base);
+        v[0] = a.x; v[1] = a.y;
+    } else {
+        v[0] = src[base];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass 1: per-waypoint min / max of p over the cloud.  grid = (point blocks, waypoint tiles).
+// part[v * nslots + slot] = (min, max) over the 64*P points of one wave.
+
+template <int P, bool PINHOLE>
+__global__ void __launch_bounds__(TO_BLOCK)
+k_traj_pass1(const float* __restrict__ soa, int64_t npad, const WayHot* __restrict__ hot, int V, int vtile,
+             CamConsts cc, float2* __restrict__ part, int nslots) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * TO_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
+    float x[P], y[P], z[P];
+    load_points<P>(soa, npad, base, x, y, z);
+    const int v0 = blockIdx.y * vtile;
+    const int v1 = min(V, v0 + vtile);
+    for (int v = v0; v < v1; ++v) {
+        const WayHot h = hot[v];
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            float X, Y, Z, y0, y1, y2;
+            to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+            const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
+            mn = fminf(mn, p);
+            mx = fmaxf(mx, p);
+        }
+        mn = wave_min63(mn);
+        mx = wave_max63(mx);
+        if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
+    }
+}
+
+// block per virtual waypoint: a = min, M = max - a (== max(p - a): rounding is monotone)
+__global__ void __launch_bounds__(TO_BLOCK)
+k_minmax_finish(const float2* __restrict__ part, int nslots, WayHot* __restrict__ hot, float* __restrict__ minmax) {
+    __shared__ float smn[TO_BLOCK], smx[TO_BLOCK];
+    const int v = blockIdx.x, t = threadIdx.x;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int s = t; s < nslots; s += TO_BLOCK) {
+        const float2 q = part[(int64_t)v * nslots + s];
+        mn = fminf(mn, q.x);
+        mx = fmaxf(mx, q.y);
+    }
+    smn[t] = mn; smx[t] = mx;
+    __syncthreads();
+    for (int s = TO_BLOCK / 2; s > 0; s >>= 1) {
+        if (t < s) { smn[t] = fminf(smn[t], smn[t + s]); smx[t] = fmaxf(smx[t], smx[t + s]); }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float a = smn[0], M = smx[0] - a;
+        hot[v].a = a;
+        hot[v].M = M;
+        hot[v].invM = 1.0f / M;
+        minmax[2 * v] = a;
+        minmax[2 * v + 1] = M;
+    }
+}
+
+// restore (a, M, 1/M) from a caller-kept minmax array (backward entry point)
+__global__ void k_set_minmax(WayHot* __restrict__ hot, const float* __restrict__ minmax, int V) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float a = minmax[2 * v], M = minmax[2 * v + 1];
+    hot[v].a = a; hot[v].M = M; hot[v].invM = 1.0f / M;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass 2: p_hat = (p - a)/M, clip to [0.5, 1-eps], log-odds, summed over the waypoints in order
+// (model.py:226-231).  ATOMIC=false: one block column owns all waypoints and stores lo_sum once.
+
+template <int P, bool PINHOLE, bool ATOMIC>
+__global__ void __launch_bounds__(TO_BLOCK)
+k_traj_pass2(const float* __restrict__ soa, int64_t npad, const WayHot* __restrict__ hot, int V, int vtile, CamConsts cc,
+             float* __restrict__ lo_sum) {
+    const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
+    float x[P], y[P], z[P], acc[P];
+    load_points<P>(soa, npad, base, x, y, z);
+#pragma unroll
+    for (int i = 0; i < P; ++i) acc[i] = 0.f;
+    const int v0 = blockIdx.y * vtile;
+    const int v1 = min(V, v0 + vtile);
+    bool degenerate = false;  // M == 0: the reference divides 0/0 -> NaN for every point (model.py:227)
+    for (int v = v0; v < v1; ++v) {
+        const WayHot h = hot[v];
+        degenerate |= !(h.M > 0.f);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            float X, Y, Z, y0, y1, y2;
+            to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+            const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
+            float ph = (p - h.a) * h.invM;
+            ph = __builtin_amdgcn_fmed3f(ph, 0.5f, cc.clip_hi);
+            // log(ph/(1-ph)) as a difference of logs: exactly 0 at ph = 0.5
+            const float lo = (to_log2(ph) - to_log2(1.0f - ph)) * 0.693147180559945f;
+            acc[i] += lo;
+        }
+    }
+    if (degenerate) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) acc[i] = __builtin_nanf("");
+    }
+    if (ATOMIC) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) atomicAdd(lo_sum + base + i, acc[i]);
+    } else {
+        if constexpr (P == 4) *reinterpret_cast<float4*>(lo_sum + base) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else if constexpr (P == 2) *reinterpret_cast<float2*>(lo_sum + base) = make_float2(acc[0], acc[1]);
+        else lo_sum[base] = acc[0];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rewards = sigmoid(lo_sum) (model.py:237), mean and visibility loss (model.py:246)
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_reward(const float* __restrict__ lo_sum, int64_t n, float* __restrict__ rewards, double* __restrict__ part) {
+    __shared__ double lds[TO_BLOCK];
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float lo = lo_sum[i];
+        const float r = to_rcp(1.0f + to_exp(-lo));
+        rewards[i] = r;
+        s += (double)r;
+    }
+    const double tot = block_sum_double(s, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_reward_finish(const double* __restrict__ part, int nparts, int64_t n, float eps, float* __restrict__ scalars) {
+    __shared__ double lds[TO_BLOCK];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += TO_BLOCK) s += part[i];
+    const double tot = block_sum_double(s, lds);
+    if (threadIdx.x == 0) {
+        const float mean = (float)(tot / (double)n);
+        const float vis = 1.0f / (mean + eps);
+        scalars[0] = mean;
+        scalars[1] = vis;
+        scalars[2] = (float)(-(double)vis * (double)vis / (double)n);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward.  Per (point, waypoint): G = dL/dp_hat = g_n [0.5 <= p_hat <= 1-eps] / (p_hat (1 - p_hat)),
+// dL/dp = G / M, plus the shares of the min/max points (torch splits them evenly among ties):
+//   S1 = sum G (p_hat - 1)/M  -> argmin set,   S2 = sum G (-p_hat)/M -> argmax set.
+// Per wave and waypoint 14 sums leave through part[(v*nslots+slot)*16 ..]:
+//   [0..2] sum w g   [3..11] sum w y (x) g   [12] S1   [13] S2        (w = G/M, g = dp/dc, y = x - t)
+// The min/max sets (normally one point each) add their unweighted (g, y (x) g) into ties[v*32 ..] with
+// float atomics: [0..11] argmin set, [12..23] argmax set, [24] n_min, [25] n_max.
+
+#define TO_BWD_NSUM 14
+
+template <int P, bool PINHOLE>
+__global__ void __launch_bounds__(TO_BLOCK)
+k_traj_bwd(const float* __restrict__ soa, int64_t npad, int64_t n, const WayHot* __restrict__ hot, int V, int vtile,
+           CamConsts cc, const float* __restrict__ rewards, const float* __restrict__ grad_rewards,
+           const float* __restrict__ scalars, const float* __restrict__ gout, float* __restrict__ part, int nslots,
+           float* __restrict__ ties) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * TO_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
+    float x[P], y[P], z[P], gn[P];
+    load_points<P>(soa, npad, base, x, y, z);
+    // dL/d reward_n: a caller-supplied vector (general criterion), else the fused visibility loss
+    const float coef = grad_rewards ? 0.f : scalars[2] * gout[0];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const bool valid = base + i < n;
+        const float r = valid ? rewards[base + i] : 0.f;
+        const float gr = grad_rewards ? (valid ? grad_rewards[base + i] : 0.f) : coef;
+        gn[i] = valid ? gr * r * (1.0f - r) : 0.f;  // dL/d lo_sum_n; pads carry no gradient
+    }
+    const int v0 = blockIdx.y * vtile;
+    const int v1 = min(V, v0 + vtile);
+    for (int v = v0; v < v1; ++v) {
+        const WayHot h = hot[v];
+        float acc[TO_BWD_NSUM];
+#pragma unroll
+        for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            float X, Y, Z, y0, y1, y2;
+            to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+            Vis s;
+            const float p = soft_vis<PINHOLE>(cc, X, Y, Z, &s);
+            const float pp = p - h.a;
+            const float ph = pp * h.invM;
+            const bool act = (ph >= 0.5f) && (ph <= cc.clip_hi);
+            const bool valid = base + i < n;
+            const bool is_min = valid && (p == h.a) && (p > 0.f);
+            const bool is_max = valid && (pp == h.M) && (h.M > 0.f);
+            if (act || is_min || is_max) {
+                float g[3];
+                dvis_dc<PINHOLE>(cc, X, Y, Z, s, g);
+                if (act) {
+                    const float G = gn[i] * to_rcp(ph * (1.0f - ph));
+                    const float wgt = G * h.invM;
+                    acc[12] = fmaf(wgt, ph - 1.0f, acc[12]);
+                    acc[13] = fmaf(-wgt, ph, acc[13]);
+                    const float w0 = wgt * g[0], w1 = wgt * g[1], w2 = wgt * g[2];
+                    acc[0] += w0; acc[1] += w1; acc[2] += w2;
+                    acc[3] = fmaf(y0, w0, acc[3]); acc[4] = fmaf(y0, w1, acc[4]); acc[5] = fmaf(y0, w2, acc[5]);
+                    acc[6] = fmaf(y1, w0, acc[6]); acc[7] = fmaf(y1, w1, acc[7]); acc[8] = fmaf(y1, w2, acc[8]);
+                    acc[9] = fmaf(y2, w0, acc[9]); acc[10] = fmaf(y2, w1, acc[10]); acc[11] = fmaf(y2, w2, acc[11]);
+                }
+                if (is_min || is_max) {
+                    const float yy[3] = {y0, y1, y2};
+                    float* tb = ties + (int64_t)v * 32;
+                    if (is_min) {
+                        for (int k = 0; k < 3; ++k) atomicAdd(tb + k, g[k]);
+                        for (int j = 0; j < 3; ++j)
+                            for (int k = 0; k < 3; ++k) atomicAdd(tb + 3 + 3 * j + k, yy[j] * g[k]);
+                        atomicAdd(tb + 24, 1.0f);
+                    }
+                    if (is_max) {
+                        for (int k = 0; k < 3; ++k) atomicAdd(tb + 12 + k, g[k]);
+                        for (int j = 0; j < 3; ++j)
+                            for (int k = 0; k < 3; ++k) atomicAdd(tb + 15 + 3 * j + k, yy[j] * g[k]);
+                        atomicAdd(tb + 25, 1.0f);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = wave_sum63(acc[k]);
+        if (lane == 63) {
+            float4* dst = reinterpret_cast<float4*>(part + ((int64_t)v * nslots + slot) * 16);
+            dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            dst[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+            dst[3] = make_float4(acc[12], acc[13], 0.f, 0.f);
+        }
+    }
+}
+
+// block per virtual waypoint: sum the wave partials (double, fixed order), add the min/max shares,
+// write vgrad[v*12 ..] = (sum dL/dc [3], sum y (x) dL/dc [9]).
+__global__ void __launch_bounds__(TO_BLOCK)
+k_bwd_finish1(const float* __restrict__ part, int nslots, const float* __restrict__ ties, float* __restrict__ vgrad) {
+    __shared__ double lds[TO_BLOCK];
+    __shared__ double tot[TO_BWD_NSUM];
+    const int v = blockIdx.x, t = threadIdx.x;
+    double s[TO_BWD_NSUM];
+    for (int k = 0; k < TO_BWD_NSUM; ++k) s[k] = 0.0;
+    for (int sl = t; sl < nslots; sl += TO_BLOCK) {
+        const float4* src = reinterpret_cast<const float4*>(part + ((int64_t)v * nslots + sl) * 16);
+        const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+        s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+        s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
+        s[8] += c.x; s[9] += c.y; s[10] += c.z; s[11] += c.w;
+        s[12] += d.x; s[13] += d.y;
+    }
+    for (int k = 0; k < TO_BWD_NSUM; ++k) {
+        const double r = block_sum_double(s[k], lds);
+        if (t == 0) tot[k] = r;
+        __syncthreads();
+    }
+    if (t < 12) {
+        const float* tb = ties + (int64_t)v * 32;
+        const double nmin = tb[24], nmax = tb[25];
+        const double wmin = nmin > 0.0 ? tot[12] / nmin : 0.0;
+        const double wmax = nmax > 0.0 ? tot[13] / nmax : 0.0;
+        vgrad[v * 12 + t] = (float)(tot[t] + wmin * (double)tb[t] + wmax * (double)tb[12 + t]);
+    }
+}
+
+// thread per body waypoint: rig composition, dL/dt = -R sum dL/dc, dL/dR = sum y (x) dL/dc,
+// quaternion chain through the homogeneous form of R and through F.normalize.
+__global__ void k_bwd_finish2(const float* __restrict__ vgrad, const WayHot* __restrict__ hot,
+                              const WayCold* __restrict__ cold, int W, int C, const float* __restrict__ rig_q,
+                              const float* __restrict__ rig_t, float* __restrict__ poses_grad,
+                              float* __restrict__ quats_grad) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    double dt[3] = {0, 0, 0}, A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // A[3*j+i] = dL/dR_w[j][i]
+    for (int c = 0; c < C; ++c) {
+        const int v = w * C + c;
+        const float* gv = vgrad + (int64_t)v * 12;
+        const WayHot h = hot[v];
+        // dL/dt_v = -R_v Gt,   R_v[j][i] = h.m[3*i+j]
+        double dtv[3];
+        for (int j = 0; j < 3; ++j)
+            dtv[j] = -((double)h.m[j] * gv[0] + (double)h.m[3 + j] * gv[1] + (double)h.m[6 + j] * gv[2]);
+        for (int j = 0; j < 3; ++j) dt[j] += dtv[j];
+        if (rig_q != nullptr) {
+            const float qc[4] = {rig_q[4 * c], rig_q[4 * c + 1], rig_q[4 * c + 2], rig_q[4 * c + 3]};
+            float Rc[9];
+            quat_to_R(qc, Rc);
+            // dL/dR_w = dL/dR_v Rc^T + dL/dt_v l^T
+            for (int j = 0; j < 3; ++j)
+                for (int i = 0; i < 3; ++i) {
+                    double a = 0;
+                    for (int k = 0; k < 3; ++k) a += (double)gv[3 + 3 * j + k] * (double)Rc[3 * i + k];
+                    if (rig_t != nullptr) a += dtv[j] * (double)rig_t[3 * c + i];
+                    A[3 * j + i] += a;
+                }
+        } else {
+            for (int k = 0; k < 9; ++k) A[k] += (double)gv[3 + k];
+        }
+    }
+    for (int j = 0; j < 3; ++j) poses_grad[3 * w + j] = (float)dt[j];
+    const WayCold cd = cold[w];
+    const double qw = cd.qn[0], qx = cd.qn[1], qy = cd.qn[2], qz = cd.qn[3];
+#define AA(j, i) A[3 * (j) + (i)]
+    double dh[4];
+    dh[0] = 2 * (qw * (AA(0, 0) + AA(1, 1) + AA(2, 2)) + qz * (AA(1, 0) - AA(0, 1)) + qy * (AA(0, 2) - AA(2, 0)) + qx * (AA(2, 1) - AA(1, 2)));
+    dh[1] = 2 * (qx * (AA(0, 0) - AA(1, 1) - AA(2, 2)) + qy * (AA(0, 1) + AA(1, 0)) + qz * (AA(0, 2) + AA(2, 0)) + qw * (AA(2, 1) - AA(1, 2)));
+    dh[2] = 2 * (qy * (-AA(0, 0) + AA(1, 1) - AA(2, 2)) + qx * (AA(0, 1) + AA(1, 0)) + qw * (AA(0, 2) - AA(2, 0)) + qz * (AA(1, 2) + AA(2, 1)));
+    dh[3] = 2 * (qz * (-AA(0, 0) - AA(1, 1) + AA(2, 2)) + qw * (AA(1, 0) - AA(0, 1)) + qx * (AA(0, 2) + AA(2, 0)) + qy * (AA(1, 2) + AA(2, 1)));
+#undef AA
+    const double dot = qw * dh[0] + qx * dh[1] + qy * dh[2] + qz * dh[3];
+    const double inv = 1.0 / (double)cd.nrm;
+    quats_grad[4 * w + 0] = (float)((dh[0] - qw * dot) * inv);
+    quats_grad[4 * w + 1] = (float)((dh[1] - qx * dot) * inv);
+    quats_grad[4 * w + 2] = (float)((dh[2] - qy * dot) * inv);
+    quats_grad[4 * w + 3] = (float)((dh[3] - qz * dot) * inv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: workspace layout + launches
+
+namespace {
+
+struct TrajPlan {
+    int64_t npad;
+    int P;         // points per lane
+    int nblk;      // point blocks
+    int nslots;    // wave slots = nblk * 4
+    int V;
+    size_t off_hot, off_cold, off_mm, off_rpart, off_bpart, off_ties, off_vgrad, total;
+};
+
+inline int choose_P(int64_t n) { return n >= (int64_t)512 * 1024 ? 4 : (n >= (int64_t)128 * 1024 ? 2 : 1); }
+
+inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W) {
+    TrajPlan p;
+    p.npad = tohip_padded_points(n);
+    p.P = choose_P(n);
+    p.nblk = (int)(p.npad / (TO_BLOCK * p.P));
+    p.nslots = p.nblk * TO_WAVES_PER_BLOCK;
+    p.V = (int)V;
+    // sized for the smallest P (most slots) so that the plan is a pure function of (n, V)
+    const size_t max_slots = (size_t)(p.npad / TO_WAVE);
+    size_t o = 0;
+    p.off_hot = o;   o += align_up((size_t)V * sizeof(WayHot), 256);
+    p.off_cold = o;  o += align_up((size_t)W * sizeof(WayCold), 256);
+    p.off_mm = o;    o += align_up((size_t)V * max_slots * sizeof(float2), 256);
+    p.off_rpart = o; o += align_up((size_t)4096 * sizeof(double), 256);
+    p.off_bpart = o; o += align_up((size_t)V * max_slots * 16 * sizeof(float), 256);
+    p.off_ties = o;  o += align_up((size_t)V * 32 * sizeof(float), 256);
+    p.off_vgrad = o; o += align_up((size_t)V * 12 * sizeof(float), 256);
+    p.total = o;
+    return p;
+}
+
+// waypoint tiling of the grid's y dimension: enough blocks to fill 256 CUs a few times over
+inline void choose_tiles(int nblk, int V, int* vtile, int* ntiles) {
+    int nt = 1;
+    if (nblk < 1024) nt = (1024 + nblk - 1) / nblk;
+    if (nt > V) nt = V;
+    if (nt < 1) nt = 1;
+    *vtile = (V + nt - 1) / nt;
+    *ntiles = (V + *vtile - 1) / *vtile;
+}
+
+template <typename F>
+inline void dispatch(int P, bool pinhole, F&& f) {
+    if (P == 4) { if (pinhole) f(std::integral_constant<int, 4>(), std::true_type()); else f(std::integral_constant<int, 4>(), std::false_type()); }
+    else if (P == 2) { if (pinhole) f(std::integral_constant<int, 2>(), std::true_type()); else f(std::integral_constant<int, 2>(), std::false_type()); }
+    else { if (pinhole) f(std::integral_constant<int, 1>(), std::true_type()); else f(std::integral_constant<int, 1>(), std::false_type()); }
+}
+
+inline int rig_cams(const tohip_rig* rig) { return (rig && rig->n_cams > 0 && rig->rig_quats) ? rig->n_cams : 1; }
+
+}  // namespace
+
+extern "C" size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual) {
+    if (n_points <= 0 || n_virtual <= 0) return 0;
+    return make_plan(n_points, n_virtual, n_virtual).total;
+}
+
+extern "C" int tohip_traj_forward(const float* soa, int64_t n, const float* poses, const float* quats, int64_t W,
+                                  const tohip_camera* cam, const tohip_rig* rig, float* lo_sum, float* minmax,
+                                  void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!soa || !poses || !quats || !cam || !lo_sum || !minmax || !workspace || n <= 0 || W <= 0) return TOHIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    const int C = rig_cams(rig);
+    const int64_t V = W * C;
+    if (V > (1 << 24)) return TOHIP_EINVAL;
+    const TrajPlan pl = make_plan(n, V, W);
+    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
+    char* ws = (char*)workspace;
+    WayHot* hot = (WayHot*)(ws + pl.off_hot);
+    WayCold* cold = (WayCold*)(ws + pl.off_cold);
+    float2* mm = (float2*)(ws + pl.off_mm);
+    const CamConsts cc = make_consts(cam);
+    const float* rq = (C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
+    const float* rt = rq ? rig->rig_trans : nullptr;
+
+    {
+        TO_PROF(TOHIP_PROF_SMALL, st);
+        k_prep_waycams<<<(int)((V + 127) / 128), 128, 0, st>>>(poses, quats, (int)W, C, rq, rt, hot, cold);
+    }
+    TO_HIP_CHECK_LAUNCH();
+    int vtile, ntiles;
+    choose_tiles(pl.nblk, (int)V, &vtile, &ntiles);
+    {
+        TO_PROF(TOHIP_PROF_PASS1, st);
+        dispatch(pl.P, cc.pinhole != 0, [&](auto Pc, auto Ph) {
+            k_traj_pass1<decltype(Pc)::value, decltype(Ph)::value><<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(
+                soa, pl.npad, hot, (int)V, vtile, cc, mm, pl.nslots);
+        });
+    }
+    TO_HIP_CHECK_LAUNCH();
+    {
+        TO_PROF(TOHIP_PROF_SMALL, st);
+        k_minmax_finish<<<(int)V, TO_BLOCK, 0, st>>>(mm, pl.nslots, hot, minmax);
+    }
+    TO_HIP_CHECK_LAUNCH();
+    TO_PROF(TOHIP_PROF_PASS2, st);
+    if (ntiles > 1) {
+        hipError_t e = hipMemsetAsync(lo_sum, 0, sizeof(float) * (size_t)pl.npad, st);
+        if (e != hipSuccess) return (int)e;
+        dispatch(pl.P, cc.pinhole != 0, [&](auto Pc, auto Ph) {
+            k_traj_pass2<decltype(Pc)::value, decltype(Ph)::value, true><<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(
+                soa, pl.npad, hot, (int)V, vtile, cc, lo_sum);
+        });
+    } else {
+        dispatch(pl.P, cc.pinhole != 0, [&](auto Pc, auto Ph) {
+            k_traj_pass2<decltype(Pc)::value, decltype(Ph)::value, false><<<dim3(pl.nblk, 1), TO_BLOCK, 0, st>>>(
+                soa, pl.npad, hot, (int)V, (int)V, cc, lo_sum);
+        });
+    }
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+extern "C" int tohip_traj_reward(const float* lo_sum, int64_t n, float eps, float* rewards, float* scalars,
+                                 void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!lo_sum || !rewards || !scalars || !workspace || n <= 0) return TOHIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    const TrajPlan pl = make_plan(n, 1, 1);
+    if (workspace_bytes < pl.off_rpart + 4096 * sizeof(double)) return TOHIP_ENOSPC;
+    double* rpart = (double*)((char*)workspace + pl.off_rpart);
+    int nb = (int)((n + TO_BLOCK - 1) / TO_BLOCK);
+    if (nb > 2048) nb = 2048;
+    TO_PROF(TOHIP_PROF_REWARD, st);
+    k_reward<<<nb, TO_BLOCK, 0, st>>>(lo_sum, n, rewards, rpart);
+    TO_HIP_CHECK_LAUNCH();
+    k_reward_finish<<<1, TO_BLOCK, 0, st>>>(rpart, nb, n, eps, scalars);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+extern "C" int tohip_traj_backward(const float* soa, int64_t n, const float* poses, const float* quats, int64_t W,
+                                   const tohip_camera* cam, const tohip_rig* rig, const float* rewards,
+                                   const float* grad_rewards, const float* scalars, const float* minmax,
+                                   const float* gout, float* poses_grad, float* quats_grad, void* workspace,
+                                   size_t workspace_bytes, void* stream_) {
+    if (!soa || !poses || !quats || !cam || !rewards || !minmax || !poses_grad || !quats_grad || !workspace || n <= 0 ||
+        W <= 0 || (!grad_rewards && (!scalars || !gout)))
+        return TOHIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    const int C = rig_cams(rig);
+    const int64_t V = W * C;
+    const TrajPlan pl = make_plan(n, V, W);
+    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
+    char* ws = (char*)workspace;
+    WayHot* hot = (WayHot*)(ws + pl.off_hot);
+    WayCold* cold = (WayCold*)(ws + pl.off_cold);
+    float* bpart = (float*)(ws + pl.off_bpart);
+    float* ties = (float*)(ws + pl.off_ties);
+    float* vgrad = (float*)(ws + pl.off_vgrad);
+    const CamConsts cc = make_consts(cam);
+    const float* rq = (C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
+    const float* rt = rq ? rig->rig_trans : nullptr;
+
+    // the workspace may have been reused since the forward: rebuild the waypoint records
+    k_prep_waycams<<<(int)((V + 127) / 128), 128, 0, st>>>(poses, quats, (int)W, C, rq, rt, hot, cold);
+    TO_HIP_CHECK_LAUNCH();
+    k_set_minmax<<<(int)((V + 127) / 128), 128, 0, st>>>(hot, minmax, (int)V);
+    TO_HIP_CHECK_LAUNCH();
+    hipError_t e = hipMemsetAsync(ties, 0, sizeof(float) * 32 * (size_t)V, st);
+    if (e != hipSuccess) return (int)e;
+    int vtile, ntiles;
+    choose_tiles(pl.nblk, (int)V, &vtile, &ntiles);
+    {
+        TO_PROF(TOHIP_PROF_BWD, st);
+        dispatch(pl.P, cc.pinhole != 0, [&](auto Pc, auto Ph) {
+            k_traj_bwd<decltype(Pc)::value, decltype(Ph)::value><<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(
+                soa, pl.npad, n, hot, (int)V, vtile, cc, rewards, grad_rewards, scalars, gout, bpart, pl.nslots, ties);
+        });
+    }
+    TO_HIP_CHECK_LAUNCH();
+    TO_PROF(TOHIP_PROF_SMALL, st);
+    k_bwd_finish1<<<(int)V, TO_BLOCK, 0, st>>>(bpart, pl.nslots, ties, vgrad);
+    TO_HIP_CHECK_LAUNCH();
+    k_bwd_finish2<<<(int)((W + 63) / 64), 64, 0, st>>>(vgrad, hot, cold, (int)W, C, rq, rt, poses_grad, quats_grad);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}

@@ -1,0 +1,55 @@
+"""Waypoint sharding over the GPUs of one node (not in the reference, which is
+single-process).
+
+One process per GPU; the cloud is replicated (12 MB at 1 M points), the evaluated waypoints are split
+into contiguous per-rank ranges.  The only data-path collective is ONE all-reduce (sum, f32, N floats) of
+the partial log-odds vector per forward — `torch.distributed` backend "nccl" is RCCL over xGMI on ROCm;
+the per-waypoint min/max normalisation is rank-local by construction.  In the backward every rank
+produces the gradient rows of its own waypoints and a (W,7)-float all-reduce assembles them so that a
+replicated optimiser steps identically everywhere.
+
+The class holds no kernels: it only places waypoints and issues collectives, so its logic is covered by
+world_size-2 gloo tests on CPU (tests/test_distributed_cpu.py).
+"""
+import torch
+import torch.distributed as dist
+
+
+class WaypointShard:
+    def __init__(self, process_group=None):
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+
+    def bounds(self, n_wps, rank=None):
+        """Contiguous, balanced range [lo, hi) of the n_wps evaluated waypoints owned by `rank`."""
+        r = self.rank if rank is None else rank
+        base, rem = divmod(n_wps, self.world_size)
+        lo = r * base + min(r, rem)
+        return lo, lo + base + (1 if r < rem else 0)
+
+    def allreduce_sum(self, t):
+        if self.world_size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torchrun contract) and bind
+    this process to its GPU.  Returns (rank, world_size, device)."""
+    import os
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device(f"cuda:{local}") if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {"device_id": device} if use_gpu else {}
+        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world, **kw)
+    return rank, world, device

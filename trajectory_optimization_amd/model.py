@@ -1,0 +1,321 @@
+"""Drop-in ModelPose / ModelTraj (the reference's /root/reference/src/model.py) on MI355X.
+
+Same class names, constructor arguments, attributes and forward()/criterion() semantics as the reference,
+so its optimiser loops (/root/reference/src/trajectory_optimization.py:83-127,
+/root/reference/src/pose_optimization.py:82-136) run unchanged: Adam over model.poses / model.quats (or
+model.trans / model.quat), loss.backward(), reads of model.rewards, model.loss[...], model.observations.
+
+What differs is inside: the visibility / reward forward and its analytic backward run as hand-written
+gfx950 kernels behind the C ABI of include/trajopt_hip.h (see ops.py); the O(W) regularisers of
+criterion() stay in torch.  There is no CPU fallback: constructing a model on a
+non-HIP device raises.
+"""
+from copy import deepcopy
+from time import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .tools import hidden_pts_removal
+
+
+# ------------------------------------------------------------------------------ helper functions
+
+def get_dist_mask(points, min_dist=1.0, max_dist=5.0):
+    """/root/reference/src/model.py:13-24 (forward values, HIP kernel; not differentiable here — the
+    models differentiate through their fused kernels)."""
+    assert isinstance(points, torch.Tensor)
+    assert points.size()[1] == 3
+    cam = ops.Camera(torch.eye(3), 1.0, 1.0, min_dist, max_dist)
+    return ops.soft_masks(points, cam, want_dist=True, want_fov=False)[0]
+
+
+def get_fov_mask(points, img_height, img_width, intrins, eps=1e-6, binary=False):
+    """/root/reference/src/model.py:27-47 (note the reference's positional order: height, then width)."""
+    assert isinstance(points, torch.Tensor)
+    assert points.size()[1] == 3
+    assert isinstance(intrins, torch.Tensor)
+    assert intrins.size() == torch.Size([3, 3])
+    cam = ops.Camera(intrins, img_width, img_height, 1.0, 5.0, eps)
+    if binary:
+        pts3 = points.detach().to(torch.float32).t().contiguous()
+        return ops.frustum_cull(pts3, cam, float("-inf"), float("inf"), want_indices=False)[1]
+    return ops.soft_masks(points, cam, want_dist=False, want_fov=True)[1]
+
+
+def to_camera_frame(verts, quat, trans):
+    """/root/reference/src/model.py:50-57, bit-identical f32 arithmetic."""
+    assert verts.dim() == trans.dim()
+    assert quat.size() == torch.Size([1, 4])
+    return ops.to_camera_frame_exact(verts, quat, trans, normalize=True)
+
+
+def length_calc(traj):
+    """/root/reference/src/model.py:135-139 (vectorised: one norm over the W-1 segments)."""
+    if len(traj) < 2:
+        return 0.0
+    return torch.linalg.norm(traj[1:] - traj[:-1], dim=1).sum()
+
+
+def mean_angle_calc(traj_wps, eps=1e-6):
+    """/root/reference/src/model.py:142-155 (vectorised over the interior waypoints)."""
+    traj_wps = torch.as_tensor(traj_wps)
+    n_wps = len(traj_wps)
+    if n_wps < 3:
+        # the reference divides a python float 0.0 by (N_wps - 2): ZeroDivisionError for 2 waypoints
+        return 0.0 / (n_wps - 2)
+    ab = traj_wps[:-2] - traj_wps[1:-1]
+    ac = traj_wps[2:] - traj_wps[1:-1]
+    cosang = (ab * ac).sum(dim=1) / (torch.linalg.norm(ab, dim=1) * torch.linalg.norm(ac, dim=1) + eps)
+    return torch.arccos(cosang).sum() / (n_wps - 2)
+
+
+# ------------------------------------------------------------------------------ autograd bridges
+
+class _PoseObservations(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, trans, quat, model, mask):
+        t = trans.detach().contiguous()
+        q = quat.detach().contiguous()
+        obs, _ = ops.pose_forward(model._cloud, t, q, model._cam, model._ws, mask)
+        ctx.model, ctx.mask = model, mask
+        ctx.save_for_backward(t, q)
+        return obs
+
+    @staticmethod
+    def backward(ctx, grad_obs):
+        t, q = ctx.saved_tensors
+        m = ctx.model
+        tg, qg = ops.pose_backward(m._cloud, t, q, m._cam, m._ws, ctx.mask, grad_obs=grad_obs.contiguous())
+        return tg, qg, None, None
+
+
+class _TrajRewards(torch.autograd.Function):
+    """rewards(poses, quats) for the evaluated waypoints.  With a process group the waypoints are sharded
+    over the ranks; the only data-path collective is the all-reduce of the log-odds vector."""
+
+    @staticmethod
+    def forward(ctx, poses, quats, model):
+        p = poses.detach().contiguous()
+        q = quats.detach().contiguous()
+        sh = model._shard
+        lo, hi = sh.bounds(p.shape[0])
+        ps, qs = p[lo:hi].contiguous(), q[lo:hi].contiguous()
+        if hi > lo:
+            lo_sum, minmax = ops.traj_forward(model._cloud, ps, qs, model._cam, model._workspace(hi - lo), model._rig)
+        else:
+            lo_sum, minmax = torch.zeros(model._cloud.npad, device=p.device), None
+        lo_sum = sh.allreduce_sum(lo_sum)
+        rewards, _ = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)))
+        ctx.model, ctx.range, ctx.n_wps = model, (lo, hi), p.shape[0]
+        ctx.save_for_backward(ps, qs, rewards, minmax if minmax is not None else torch.empty(0, device=p.device))
+        model.lo_sum = lo_sum[:model._cloud.n]
+        return rewards
+
+    @staticmethod
+    def backward(ctx, grad_rewards):
+        ps, qs, rewards, minmax = ctx.saved_tensors
+        m = ctx.model
+        lo, hi = ctx.range
+        pg = torch.zeros((ctx.n_wps, 3), dtype=torch.float32, device=rewards.device)
+        qg = torch.zeros((ctx.n_wps, 4), dtype=torch.float32, device=rewards.device)
+        if hi > lo:
+            g = grad_rewards.to(torch.float32).contiguous()
+            pg[lo:hi], qg[lo:hi] = ops.traj_backward(m._cloud, ps, qs, m._cam, m._workspace(hi - lo), rewards, minmax,
+                                                     grad_rewards=g, rig=m._rig)
+        pg = m._shard.allreduce_sum(pg)
+        qg = m._shard.allreduce_sum(qg)
+        return pg, qg, None
+
+
+# ------------------------------------------------------------------------------ models
+
+class ModelPose(nn.Module):
+    """Single camera pose optimisation model (/root/reference/src/model.py:65-127)."""
+
+    def __init__(self,
+                 points: torch.tensor,
+                 trans0: torch.tensor,  # t = (x, y, z), example: torch.tensor([[0., 0., 0.]])
+                 q0: torch.tensor,  # q = (w, x, y, z), example: torch.tensor([[1., 0., 0., 0.]])
+                 intrins: torch.tensor,  # torch.tensor, size=(3, 3)
+                 img_width, img_height,
+                 min_dist=1.0, max_dist=5.0,
+                 device=torch.device('cuda:0')):
+        super().__init__()
+        assert trans0.size() == torch.Size([1, 3])
+        assert q0.size() == torch.Size([1, 4])
+        assert intrins.size() == torch.Size([3, 3])
+
+        self.device = torch.device(device)
+        # the reference keeps the caller's dtype (model.py:80) and then fails in get_fov_mask's matmul
+        # for anything but float32; float32 is the contract here
+        self.points = torch.as_tensor(points, dtype=torch.float32).to(self.device)
+        self.rewards = None
+        self.observations = None
+        self.lo_sum = 0.0
+
+        trans = torch.as_tensor(trans0, dtype=torch.float32).to(self.device)
+        self.trans = nn.Parameter(trans)
+        quat = torch.as_tensor(q0, dtype=torch.float32).to(self.device)
+        self.quat = nn.Parameter(quat)
+
+        self.K = torch.as_tensor(intrins, dtype=torch.float32).to(self.device)
+        self.img_width, self.img_height = float(img_width), float(img_height)
+        self.eps = 1e-6
+        self.pc_clip_limits = [min_dist, max_dist]  # [m]
+
+        self.to(self.device)
+        self._cloud = ops.PackedCloud(self.points)
+        self._cam = ops.Camera(self.K, self.img_width, self.img_height, min_dist, max_dist, self.eps)
+        self._ws = ops.PoseWorkspace(self._cloud)
+        self._occlusion_mask = None
+
+    def forward(self, debug=False, hpr=False):
+        t0 = time()
+        mask = None
+        if hpr:
+            # HPR of the WORLD-frame cloud seen from the world origin (model.py:114): pose independent,
+            # so it is computed once per cloud
+            if self._occlusion_mask is None:
+                self._occlusion_mask = hidden_pts_removal(self.points.detach(), device=self.device)[1].contiguous()
+            mask = self._occlusion_mask
+        self.observations = _PoseObservations.apply(self.trans, self.quat, self, mask)
+        if debug:
+            torch.cuda.synchronize(self.device)
+            print(f'Visibility estimation took: {1000 * (time() - t0)} msec')
+            print(f'Point cloud size {self.points.size()}')
+        loss = self.criterion(self.observations)
+        return loss
+
+    def criterion(self, observations):
+        # transform observations to loss function
+        loss = 1. / (torch.sum(observations) + self.eps)
+        return loss
+
+
+class _NoShard:
+    """Single-process placement: every waypoint is local, no collective."""
+    world_size, rank = 1, 0
+
+    @staticmethod
+    def bounds(n):
+        return 0, n
+
+    @staticmethod
+    def allreduce_sum(t):
+        return t
+
+
+class ModelTraj(nn.Module):
+    """Trajectory optimisation model (/root/reference/src/model.py:158-260).
+
+    Extra keyword arguments (absent from the reference): `rig=(quats (C,4), trans (C,3))` evaluates a rigid
+    multi-camera rig at every waypoint; `shard=` a trajectory_optimization_amd.distributed.WaypointShard
+    placing the waypoints over the ranks of a process group (one process per GPU, RCCL).
+    """
+
+    def __init__(self,
+                 points: torch.tensor,
+                 wps_poses: torch.tensor,  # (N, 3): [[[x0, y0, z0]], [[x1, y1, z1]], ...]
+                 wps_quats: torch.tensor,  # (N, 4): torch.tensor: [w, x, y, z]-format
+                 intrins: torch.tensor,  # torch.tensor, size=(3, 3)
+                 img_width, img_height,
+                 min_dist=1.0, max_dist=5.0,
+                 smoothness_weight=14.0, traj_length_weight=0.02,
+                 device=torch.device('cuda'),
+                 *, rig=None, shard=None):
+        super().__init__()
+        assert wps_poses.dim() == wps_quats.dim()
+        assert wps_poses.size()[1] == 3
+        assert wps_quats.size()[1] == 4
+
+        self.device = torch.device(device)
+        self.points = torch.as_tensor(points, dtype=torch.float32).to(self.device)
+        self.rewards = None
+        self.observations = None
+        self.lo_sum = 0.0  # log odds sum for the entire point cloud for the whole trajectory
+
+        self.poses0 = torch.as_tensor(wps_poses, dtype=torch.float32).to(self.device)  # (N, 3)
+        self.quats0 = torch.as_tensor(wps_quats, dtype=torch.float32).to(self.device)  # (N, 4)
+
+        self.poses = nn.Parameter(deepcopy(self.poses0))
+        self.quats = nn.Parameter(deepcopy(self.quats0))
+
+        self.K = torch.as_tensor(intrins, dtype=torch.float32).to(self.device)
+        self.img_width, self.img_height = float(img_width), float(img_height)
+        self.eps = 1e-6
+        self.pc_clip_limits = [min_dist, max_dist]  # [m]
+
+        self.loss = {'vis': float('inf'),
+                     'length': float('inf'),
+                     'l2': float('inf'),
+                     'smooth': float('inf')}
+        self.smoothness_weight = smoothness_weight
+        self.traj_length_weight = traj_length_weight
+
+        self.to(self.device)
+        self._cloud = ops.PackedCloud(self.points)
+        self._cam = ops.Camera(self.K, self.img_width, self.img_height, min_dist, max_dist, self.eps)
+        self._rig = ops.CameraRig(rig[0], rig[1], self.device) if rig is not None else None
+        self._shard = shard if shard is not None else _NoShard()
+        self._ws_cache = {}
+        self._wps_step_cache = {}
+        self._length0 = None
+
+    def _workspace(self, n_local_wps):
+        v = n_local_wps * (self._rig.n_cams if self._rig is not None else 1)
+        ws = self._ws_cache.get(v)
+        if ws is None:
+            ws = self._ws_cache[v] = ops.TrajWorkspace(self._cloud, v)
+        return ws
+
+    def _wps_step(self, vis_wps_dist):
+        # based on the mean waypoint distance of the INITIAL trajectory (model.py:214-215); constant per
+        # model, so the host sync the reference pays on every forward happens once
+        step = self._wps_step_cache.get(vis_wps_dist)
+        if step is None:
+            mean_wps_dist = (self.poses0[1:, :] - self.poses0[:-1, :]).norm(dim=1).mean()
+            step = int(vis_wps_dist / mean_wps_dist) + 1
+            self._wps_step_cache[vis_wps_dist] = step
+        return step
+
+    def forward(self,
+                vis_wps_dist=0.5,  # distance between neighbor waypoints to estimate visibility
+                debug=False):
+        """
+        Trajectory evaluation based on visibility estimation from its waypoints.
+        traj_score = log_odds_sum([visibility_estimation(wp) for wp in traj_waypoints])
+        """
+        t0 = time()
+        N_wps = len(self.poses)
+        wps_step = self._wps_step(vis_wps_dist)
+        if wps_step == 1:
+            poses_eval, quats_eval = self.poses, self.quats
+        else:
+            idx = torch.arange(0, N_wps, wps_step, device=self.device)
+            poses_eval, quats_eval = self.poses.index_select(0, idx), self.quats.index_select(0, idx)
+        self.rewards = _TrajRewards.apply(poses_eval, quats_eval, self)  # total trajectory observations
+        if debug:
+            torch.cuda.synchronize(self.device)
+            print(f'Trajectory evaluation took {1000 * (time() - t0)} msec')
+        loss = self.criterion(self.rewards)
+        return loss
+
+    def criterion(self, rewards):
+        # transform observations to loss function: loss = 1 / mean(prob(observed))
+        self.loss['vis'] = 1. / (torch.mean(rewards) + self.eps)
+
+        # penalties for being far from initial waypoints
+        self.loss['l2'] = torch.linalg.norm(self.poses[0] - self.poses0[0])
+
+        # smoothness estimation based on average angles between waypoints: the bigger the angle the better
+        self.loss['smooth'] = self.smoothness_weight / (mean_angle_calc(self.poses, self.eps) + self.eps)
+
+        # penalty for trajectory length (compared to initial one)
+        if self._length0 is None:
+            self._length0 = length_calc(self.poses0)
+        self.loss['length'] = self.traj_length_weight * torch.abs(length_calc(self.poses) - self._length0)
+
+        return self.loss['vis'] + self.loss['l2'] + self.loss['length'] + self.loss['smooth']

@@ -1,0 +1,219 @@
+"""Thin torch-tensor wrappers over the C ABI (include/trajopt_hip.h).
+
+PyTorch here is plumbing only: device memory, streams and autograd bookkeeping.  Every numeric
+step of the hot path runs in libtrajopt_hip.so; nothing in this module computes on the CPU and
+nothing falls back to torch ops when the library is missing.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+def _dev_f32(t, device):
+    return torch.as_tensor(t, dtype=torch.float32, device=device).contiguous()
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must live on a HIP device (got {t.device}); the visibility path has no CPU fallback")
+
+
+class PackedCloud:
+    """The cloud in the kernels' layout (x|y|z, padded); built once per model (the cloud is constant over
+    an optimisation run: /root/reference/src/model.py:80,174)."""
+
+    def __init__(self, points):
+        _require_cuda(points, "points")
+        pts = points.detach().to(torch.float32).contiguous()
+        if pts.dim() != 2 or pts.shape[1] != 3 or pts.shape[0] == 0:
+            raise ValueError(f"points must be (N,3) with N>0, got {tuple(pts.shape)}")
+        self.n = pts.shape[0]
+        self.npad = _lib.lib().tohip_padded_points(self.n)
+        self.device = pts.device
+        self.soa = torch.empty(3 * self.npad, dtype=torch.float32, device=pts.device)
+        with torch.cuda.device(pts.device):
+            check(_lib.lib().tohip_pack_cloud(ptr(pts), self.n, ptr(self.soa), stream_ptr()), "tohip_pack_cloud")
+
+
+class Camera:
+    """Host-side camera constants (struct tohip_camera)."""
+
+    def __init__(self, K, img_width, img_height, min_dist=1.0, max_dist=5.0, eps=1e-6):
+        Kh = torch.as_tensor(K, dtype=torch.float32).detach().cpu().reshape(9).tolist()
+        self.c = _lib.make_camera(Kh, img_width, img_height, min_dist, max_dist, eps)
+        self.eps = float(eps)
+
+    def ref(self):
+        return ctypes.byref(self.c)
+
+
+class CameraRig:
+    """Multi-camera rig extrinsics on the device (struct tohip_rig)."""
+
+    def __init__(self, rig_quats, rig_trans, device):
+        self.q = _dev_f32(rig_quats, device)
+        self.t = _dev_f32(rig_trans, device) if rig_trans is not None else torch.zeros_like(self.q[:, :3]).contiguous()
+        self.n_cams = self.q.shape[0]
+        self.c = _lib.Rig(self.n_cams, self.q.data_ptr(), self.t.data_ptr())
+
+    def ref(self):
+        return ctypes.byref(self.c)
+
+
+_NULL_RIG = ctypes.POINTER(_lib.Rig)()
+
+
+class TrajWorkspace:
+    def __init__(self, cloud, n_virtual):
+        self.bytes = _lib.lib().tohip_traj_workspace_bytes(cloud.n, n_virtual)
+        self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=cloud.device)
+        self.n_virtual = n_virtual
+
+
+def traj_forward(cloud, poses, quats, cam, ws, rig=None):
+    """-> (lo_sum[npad] (first N valid), minmax[V,2]) for the given waypoints (this rank's shard)."""
+    W = poses.shape[0]
+    C = rig.n_cams if rig is not None else 1
+    lo_sum = torch.empty(cloud.npad, dtype=torch.float32, device=cloud.device)
+    minmax = torch.empty((W * C, 2), dtype=torch.float32, device=cloud.device)
+    with torch.cuda.device(cloud.device):
+        check(_lib.lib().tohip_traj_forward(ptr(cloud.soa), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
+                                            rig.ref() if rig is not None else _NULL_RIG, ptr(lo_sum), ptr(minmax),
+                                            ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_forward")
+    return lo_sum, minmax
+
+
+def traj_reward(cloud, lo_sum, cam, ws):
+    """-> (rewards[N], scalars[4] = mean, loss_vis, dloss/dreward, -)"""
+    rewards = torch.empty(cloud.n, dtype=torch.float32, device=cloud.device)
+    scalars = torch.zeros(4, dtype=torch.float32, device=cloud.device)
+    with torch.cuda.device(cloud.device):
+        check(_lib.lib().tohip_traj_reward(ptr(lo_sum), cloud.n, cam.eps, ptr(rewards), ptr(scalars), ptr(ws.buf),
+                                           ws.bytes, stream_ptr()), "tohip_traj_reward")
+    return rewards, scalars
+
+
+def traj_backward(cloud, poses, quats, cam, ws, rewards, minmax, grad_rewards=None, scalars=None, gout=None, rig=None):
+    W = poses.shape[0]
+    pg = torch.empty((W, 3), dtype=torch.float32, device=cloud.device)
+    qg = torch.empty((W, 4), dtype=torch.float32, device=cloud.device)
+    with torch.cuda.device(cloud.device):
+        check(_lib.lib().tohip_traj_backward(ptr(cloud.soa), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
+                                             rig.ref() if rig is not None else _NULL_RIG, ptr(rewards),
+                                             ptr(grad_rewards), ptr(scalars), ptr(minmax), ptr(gout), ptr(pg), ptr(qg),
+                                             ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_backward")
+    return pg, qg
+
+
+class PoseWorkspace:
+    def __init__(self, cloud):
+        self.bytes = _lib.lib().tohip_pose_workspace_bytes(cloud.n)
+        self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=cloud.device)
+
+
+def pose_forward(cloud, trans, quat, cam, ws, mask=None):
+    obs = torch.empty(cloud.n, dtype=torch.float32, device=cloud.device)
+    scalars = torch.zeros(4, dtype=torch.float32, device=cloud.device)
+    with torch.cuda.device(cloud.device):
+        check(_lib.lib().tohip_pose_forward(ptr(cloud.soa), cloud.n, ptr(trans), ptr(quat), cam.ref(), ptr(mask),
+                                            ptr(obs), ptr(scalars), ptr(ws.buf), ws.bytes, stream_ptr()),
+              "tohip_pose_forward")
+    return obs, scalars
+
+
+def pose_backward(cloud, trans, quat, cam, ws, mask=None, grad_obs=None, scalars=None, gout=None):
+    tg = torch.empty((1, 3), dtype=torch.float32, device=cloud.device)
+    qg = torch.empty((1, 4), dtype=torch.float32, device=cloud.device)
+    with torch.cuda.device(cloud.device):
+        check(_lib.lib().tohip_pose_backward(ptr(cloud.soa), cloud.n, ptr(trans), ptr(quat), cam.ref(), ptr(mask),
+                                             ptr(grad_obs), ptr(scalars), ptr(gout), ptr(tg), ptr(qg), ptr(ws.buf),
+                                             ws.bytes, stream_ptr()), "tohip_pose_backward")
+    return tg, qg
+
+
+def to_camera_frame_exact(points, quat, trans, normalize=True, transpose=False):
+    """Reference-exact f32 transform; (N,3) -> (N,3), or (3,N) when `transpose`."""
+    _require_cuda(points, "points")
+    pts = points.detach().to(torch.float32).contiguous()
+    n = pts.shape[0]
+    q = _dev_f32(quat, pts.device).reshape(4)
+    t = _dev_f32(trans, pts.device).reshape(3)
+    out = torch.empty((3, n) if transpose else (n, 3), dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        check(_lib.lib().tohip_to_camera_frame(ptr(pts), n, ptr(q), ptr(t), int(normalize), int(transpose), ptr(out),
+                                               stream_ptr()), "tohip_to_camera_frame")
+    return out
+
+
+def soft_masks(cam_points, cam, want_dist=True, want_fov=True):
+    _require_cuda(cam_points, "points")
+    pts = cam_points.detach().to(torch.float32).contiguous()
+    n = pts.shape[0]
+    d = torch.empty(n, dtype=torch.float32, device=pts.device) if want_dist else None
+    f = torch.empty(n, dtype=torch.float32, device=pts.device) if want_fov else None
+    with torch.cuda.device(pts.device):
+        check(_lib.lib().tohip_soft_masks(ptr(pts), n, cam.ref(), ptr(d), ptr(f), stream_ptr()), "tohip_soft_masks")
+    return d, f
+
+
+def frustum_cull(cam_3xN, cam, min_dist, max_dist, want_indices=True):
+    """-> (dist_mask bool[N], fov_mask bool[N], kept_idx int32[M] ascending)"""
+    _require_cuda(cam_3xN, "points")
+    pts = cam_3xN.detach().to(torch.float32).contiguous()
+    n = pts.shape[1]
+    dev = pts.device
+    dm = torch.empty(n, dtype=torch.uint8, device=dev)
+    fm = torch.empty(n, dtype=torch.uint8, device=dev)
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = _lib.lib().tohip_frustum_workspace_bytes(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().tohip_frustum_cull(ptr(pts), n, cam.ref(), float(min_dist), float(max_dist), ptr(dm), ptr(fm),
+                                            ptr(idx) if want_indices else None, ptr(cnt), ptr(ws), wsb, stream_ptr()),
+              "tohip_frustum_cull")
+    m = int(cnt.item()) if want_indices else 0
+    return dm.bool(), fm.bool(), idx[:m]
+
+
+def spherical_flip(points, param=2):
+    _require_cuda(points, "points")
+    pts = points.detach().to(torch.float32).contiguous()
+    n = pts.shape[0]
+    out = torch.empty_like(pts)
+    rad = torch.empty(1, dtype=torch.float32, device=pts.device)
+    ws = torch.empty(256, dtype=torch.uint8, device=pts.device)
+    with torch.cuda.device(pts.device):
+        check(_lib.lib().tohip_spherical_flip(ptr(pts), n, float(param), ptr(out), ptr(rad), ptr(ws), 256, stream_ptr()),
+              "tohip_spherical_flip")
+    return out, rad
+
+
+def hidden_pts_removal(points, param=2):
+    """-> (visible_idx int32[V] ascending, mask f32[N])"""
+    _require_cuda(points, "points")
+    pts = points.detach().to(torch.float32).contiguous()
+    n = pts.shape[0]
+    dev = pts.device
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    mask = torch.empty(n, dtype=torch.float32, device=dev)
+    wsb = _lib.lib().tohip_hpr_workspace_bytes(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().tohip_hidden_pts_removal(ptr(pts), n, float(param), ptr(idx), ptr(cnt), ptr(mask), ptr(ws), wsb,
+                                                  stream_ptr()), "tohip_hidden_pts_removal")
+    return idx[:int(cnt.item())], mask
+
+
+def selftest_wave_reduce(mat64xk):
+    k = mat64xk.shape[1]
+    dev = mat64xk.device
+    s, mn, mx = (torch.empty(k, dtype=torch.float32, device=dev) for _ in range(3))
+    with torch.cuda.device(dev):
+        check(_lib.lib().tohip_selftest_wave_reduce(ptr(mat64xk.contiguous()), k, ptr(s), ptr(mn), ptr(mx), stream_ptr()),
+              "tohip_selftest_wave_reduce")
+    return s, mn, mx

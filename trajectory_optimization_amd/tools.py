@@ -1,0 +1,75 @@
+"""Drop-in geometry helpers of the reference's /root/reference/src/tools.py:38-187,320-325 on MI355X:
+hidden-point removal (spherical flip + convex hull), the hard frustum cull, camera intrinsics, and the
+per-camera hard-visibility pipeline of /root/reference/src/pc_processor.py:158-187.
+
+All index sets are bit-exact with the reference's CPU path (tests/test_hip_hard.py).  No CPU fallback.
+"""
+import types
+
+import torch
+
+from . import ops
+
+
+def load_intrinsics(device=torch.device('cuda')):
+    """/root/reference/src/tools.py:320-325 -> (K, width, height)."""
+    width, height = 1232., 1616.
+    K = torch.tensor([[758.03967, 0., 621.46572],
+                      [0., 761.62359, 756.86402],
+                      [0., 0., 1.]], dtype=torch.float32).to(device)
+    return K, width, height
+
+
+def sphericalFlip(points, device, param):
+    """/root/reference/src/tools.py:38-53."""
+    return ops.spherical_flip(torch.as_tensor(points).to(device), param)[0]
+
+
+def convexHull(points, device):
+    """/root/reference/src/tools.py:56-64: hull of `points` plus the origin appended as the last row.
+    Returns an object with `.vertices` (ascending int32 indices, as scipy reports them in 3-D)."""
+    pts = torch.as_tensor(points, dtype=torch.float32).to(device)
+    idx = ops.hull_vertices_with_origin(pts)
+    return types.SimpleNamespace(vertices=idx)
+
+
+def hidden_pts_removal(pts: torch.Tensor, device, R_param: int = 2):
+    """/root/reference/src/tools.py:67-85 -> (pts_visible (V,3), visibleMask (N,) float32 of 0/1).
+    Keeps the reference's quirk: the LAST hull vertex is dropped whether or not it is the origin."""
+    pts = torch.as_tensor(pts).to(device)
+    idx, mask = ops.hidden_pts_removal(pts, R_param)
+    pts_visible = pts[idx.long(), :]
+    return pts_visible, mask
+
+
+def get_cam_frustum_pts(points, img_height, img_width, intrins, min_dist=1.0, max_dist=10.0):
+    """/root/reference/src/tools.py:176-187. `points` is (3,N) in the camera frame.
+    -> (points_kept (M,3), dist_mask bool (N,), fov_mask bool (N,))"""
+    intr = torch.as_tensor(intrins, dtype=torch.float32)[:3, :3]
+    cam = ops.Camera(intr, img_width, img_height, 1.0, 5.0)
+    dist_mask, fov_mask, idx = ops.frustum_cull(points, cam, min_dist, max_dist)
+    kept = points[:, idx.long()].T
+    return kept, dist_mask, fov_mask
+
+
+def ego_to_cam(points, trans, quat):
+    """/root/reference/src/pc_processor.py:63-70: (N,3) ego-frame points -> (3,N) camera frame; the
+    quaternion is NOT normalised there, and is not here."""
+    return ops.to_camera_frame_exact(points, quat, trans, normalize=False, transpose=True)
+
+
+def visible_points_from_camera(points, trans, quat, intrins, img_height, img_width, min_dist=1.0, max_dist=15.0):
+    """The per-camera hard visibility pipeline of /root/reference/src/pc_processor.py:158-187 without the
+    ROS glue: transform -> hard frustum cull -> HPR from the camera centre.
+    -> dict(cam_points (3,N), kept_idx, kept_points (M,3), visible_idx (into kept), visible_points (V,3))"""
+    cam_pts = ego_to_cam(points, trans, quat)
+    intr = torch.as_tensor(intrins, dtype=torch.float32)[:3, :3]
+    cam = ops.Camera(intr, img_width, img_height, 1.0, 5.0)
+    _, _, kept_idx = ops.frustum_cull(cam_pts, cam, min_dist, max_dist)
+    kept = cam_pts[:, kept_idx.long()].T.contiguous()
+    if kept.shape[0] >= 4:
+        vis_idx, _ = ops.hidden_pts_removal(kept, 2)
+    else:
+        vis_idx = torch.empty(0, dtype=torch.int32, device=kept.device)
+    return dict(cam_points=cam_pts, kept_idx=kept_idx, kept_points=kept, visible_idx=vis_idx,
+                visible_points=kept[vis_idx.long()])
