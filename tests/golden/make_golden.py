@@ -221,7 +221,9 @@ def gen_adam():
     # pose optimisation loop (/root/reference/src/pose_optimization.py:82-136, launch rates 0.02/0.02)
     t0 = np.array([[6.0, 2.0, 0.0]], dtype=np.float32)
     q0 = np.array([[1.0, 0.0, 0.0, 0.0]], dtype=np.float32)
-    mp = ref_model.ModelPose(points=torch.from_numpy(pts), trans0=torch.from_numpy(t0), q0=torch.from_numpy(q0),
+    # clones: on CPU the reference's Parameters alias the tensors it is given (model.py:86-89), so Adam would
+    # otherwise overwrite the t0/q0 arrays saved below
+    mp = ref_model.ModelPose(points=torch.from_numpy(pts), trans0=torch.from_numpy(t0.copy()), q0=torch.from_numpy(q0.copy()),
                              intrins=K, img_width=IMG_W, img_height=IMG_H, device=CPU)
     opt = torch.optim.Adam([{"params": [mp.trans], "lr": 0.02}, {"params": [mp.quat], "lr": 0.02}])
     out = dict(points=pts, trans0=t0, q0=q0, lr_pose=0.02, lr_quat=0.02)
