@@ -472,7 +472,7 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W) {
 // waypoint tiling of the grid's y dimension: enough blocks to fill 256 CUs a few times over
 inline void choose_tiles(int nblk, int V, int* vtile, int* ntiles) {
     int nt = 1;
-    if (nblk < 1024) nt = (1024 + nblk - 1) / nblk;
+    if (nblk < 512) nt = (1024 + nblk - 1) / nblk;
     if (nt > V) nt = V;
     if (nt < 1) nt = 1;
     *vtile = (V + nt - 1) / nt;
