@@ -146,6 +146,12 @@ int tohip_hidden_pts_removal(const float *xyz, int64_t n_points, float param, in
                              int32_t *visible_count, float *mask, void *workspace, size_t workspace_bytes,
                              void *stream);
 
+/* convexHull (tools.py:56-64): ascending hull-vertex indices of pts (n,3), optionally with the origin
+ * appended as point n.  idx capacity n+1 int32; *count device int32; *rounds_host (may be NULL) the
+ * number of insertion rounds.  SYNCHRONISES the stream. */
+int tohip_convex_hull_vertices(const float *pts, int64_t n_points, int with_origin, int32_t *idx, int32_t *count,
+                               int32_t *rounds_host, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- optional per-kernel timing (bench.py's roofline leg) -----------------------------------------
  * When enabled, every launch of the big kernels is bracketed by hipEventRecord on its own stream.
  * tohip_profile_read synchronises on those events and returns, per kernel id < TOHIP_PROF_NKERNELS,

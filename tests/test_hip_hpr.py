@@ -1,0 +1,84 @@
+"""Hidden-point removal on the GPU: bit-exact visible-point index sets vs the reference (golden) and vs
+the oracle (scipy/Qhull, the hull the reference itself calls) at sizes beyond the fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_inf
+from trajectory_optimization_amd import synth
+
+pytestmark = pytest.mark.gpu
+K, IW, IH = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("name", ["hpr_synth_outside", "hpr_synth_10k", "hpr_shell_origin_inside", "hpr_bundled_world",
+                                  "hpr_synth_100k"])
+def test_hpr_index_sets_bit_exact(dev, name):
+    from trajectory_optimization_amd.tools import hidden_pts_removal, convexHull, sphericalFlip
+    d = load_golden(name)
+    pts = torch.from_numpy(d["points"]).to(dev)
+    vis, mask = hidden_pts_removal(pts, dev)
+    idx = np.flatnonzero(mask.cpu().numpy())
+    assert np.array_equal(idx, d["visible_idx"])
+    assert np.array_equal(vis.cpu().numpy(), d["points"][d["visible_idx"]])
+    if "hull_vertices" in d:
+        hull = convexHull(sphericalFlip(pts, dev, 2), dev)
+        assert np.array_equal(hull.vertices.cpu().numpy(), d["hull_vertices"])
+        assert bool(hull.vertices[-1].item() == len(d["points"])) == bool(d["origin_is_vertex"])
+
+
+def test_hard_pipeline_bit_exact(dev):
+    """pc_processor.run: transform -> hard cull -> HPR (22742 / 6699 / 4440 / 677)."""
+    from trajectory_optimization_amd.tools import visible_points_from_camera
+    d = load_golden("hard_pipeline_bundled")
+    r = visible_points_from_camera(torch.from_numpy(d["points"]).to(dev), torch.from_numpy(d["trans"]).to(dev),
+                                   torch.from_numpy(d["quat"]).to(dev), torch.from_numpy(K).to(dev), IH, IW,
+                                   float(d["min_dist"]), float(d["max_dist"]))
+    assert np.array_equal(r["kept_idx"].cpu().numpy(), d["kept_idx"]) and len(d["kept_idx"]) == 4440
+    assert np.array_equal(r["kept_points"].cpu().numpy(), d["kept_pts"])
+    assert np.array_equal(r["visible_idx"].cpu().numpy(), d["hpr_visible_idx"]) and len(d["hpr_visible_idx"]) == 677
+    assert np.array_equal(r["visible_points"].cpu().numpy(), d["hpr_visible_pts"])
+
+
+@pytest.mark.parametrize("name", ["pose_bundled_hpr", "pose_synth_10k_hpr"])
+def test_model_pose_hpr(dev, name):
+    from trajectory_optimization_amd.model import ModelPose
+    d = load_golden(name)
+    m = ModelPose(points=torch.from_numpy(d["points"]), trans0=torch.from_numpy(d["trans0"]), q0=torch.from_numpy(d["q0"]),
+                  intrins=torch.from_numpy(K), img_width=IW, img_height=IH, device=dev)
+    loss = m(hpr=True)
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) <= 5e-6 * float(d["loss"])
+    obs = m.observations.detach().cpu().numpy()
+    assert np.array_equal(obs != 0, d["observations"] != 0)  # same occluded set
+    np.testing.assert_allclose(obs, d["observations"], rtol=5e-5, atol=1e-9)
+    assert rel_inf(m.trans.grad.cpu().numpy(), d["trans_grad"]) < 1e-5
+    assert rel_inf(m.quat.grad.cpu().numpy(), d["quat_grad"]) < 1e-5
+
+
+@pytest.mark.parametrize("n,seed,centre", [(1_000_000, 0, (0.0, 0.0, 0.0)), (300_000, 3, (25.0, -3.0, 1.0))])
+def test_hpr_large_vs_qhull(dev, n, seed, centre):
+    """BASELINE-size cloud: index set equal to scipy/Qhull on the same flipped points (oracle)."""
+    from oracle import oracle
+    from trajectory_optimization_amd import ops
+    pts = synth.make_cloud(n, seed=seed) - np.asarray(centre, dtype=np.float32)
+    vis_ref, _ = oracle.hidden_pts_removal(pts)
+    idx, mask = ops.hidden_pts_removal(torch.from_numpy(pts).to(dev))
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), vis_ref)
+    assert int(mask.sum().item()) == len(vis_ref)
+
+
+def test_hpr_degenerate_inputs(dev):
+    from trajectory_optimization_amd import ops, _lib
+    flat = torch.zeros(100, 3, device=dev)
+    flat[:, 0] = torch.arange(100, device=dev)  # collinear with the origin: no 3-D hull (Qhull: QH6154)
+    with pytest.raises(_lib.HipError):
+        ops.hidden_pts_removal(flat)
+    with pytest.raises(_lib.HipError):
+        ops.hidden_pts_removal(torch.rand(3, 3, device=dev))  # fewer than 4 points

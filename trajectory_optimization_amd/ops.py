@@ -209,6 +209,25 @@ def hidden_pts_removal(points, param=2):
     return idx[:int(cnt.item())], mask
 
 
+def hull_vertices_with_origin(points, with_origin=True, return_rounds=False):
+    """Ascending hull-vertex indices of points (n,3) [+ the origin as index n] (tools.py:56-64)."""
+    _require_cuda(points, "points")
+    pts = points.detach().to(torch.float32).contiguous()
+    n = pts.shape[0]
+    dev = pts.device
+    idx = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    rounds = ctypes.c_int32(0)
+    wsb = _lib.lib().tohip_hpr_workspace_bytes(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().tohip_convex_hull_vertices(ptr(pts), n, int(with_origin), ptr(idx), ptr(cnt),
+                                                    ctypes.byref(rounds), ptr(ws), wsb, stream_ptr()),
+              "tohip_convex_hull_vertices")
+    out = idx[:int(cnt.item())]
+    return (out, rounds.value) if return_rounds else out
+
+
 def selftest_wave_reduce(mat64xk):
     k = mat64xk.shape[1]
     dev = mat64xk.device
