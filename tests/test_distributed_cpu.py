@@ -1,0 +1,92 @@
+"""World-size-2 gloo test of the waypoint sharding + collectives (no GPU): the placement logic of
+trajectory_optimization_amd.distributed with the CPU oracle standing in for the local kernels.
+Property: sharded result == single-process result (log-odds are additive over waypoint shards)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_pts, n_wps, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), OMP_NUM_THREADS="2")
+    from trajectory_optimization_amd import synth
+    from trajectory_optimization_amd.distributed import WaypointShard, init_from_env
+    from oracle import oracle
+    r, w, device = init_from_env(backend="gloo")
+    assert (r, w, device.type) == (rank, world, "cpu")
+    shard = WaypointShard()
+    K, iw, ih = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
+    pts = synth.make_cloud(n_pts, seed=5)
+    poses, quats = synth.make_path(n_wps, optical=True, jitter_seed=5)
+    lo, hi = shard.bounds(n_wps)
+    # local forward (stand-in for tohip_traj_forward): partial log-odds of this rank's waypoints
+    f = oracle.traj_forward(pts, poses[lo:hi], quats[lo:hi], K, iw, ih, prec="f64")
+    lo_sum = shard.allreduce_sum(torch.from_numpy(f["lo_sum"].copy()))            # the one data-path collective
+    rewards = 1.0 / (1.0 + torch.exp(-lo_sum))
+    mean = rewards.mean().item()
+    fwd = dict(rewards=rewards.numpy(), mean_reward=mean)
+    pg_l, qg_l = oracle.traj_backward(pts, poses[lo:hi], quats[lo:hi], K, iw, ih, fwd, prec="f64")
+    pg = torch.zeros(n_wps, 3, dtype=torch.float64)
+    qg = torch.zeros(n_wps, 4, dtype=torch.float64)
+    pg[lo:hi], qg[lo:hi] = torch.from_numpy(pg_l), torch.from_numpy(qg_l)
+    pg, qg = shard.allreduce_sum(pg), shard.allreduce_sum(qg)                       # (W,7) gradient assembly
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rewards=rewards.numpy(), pg=pg.numpy(), qg=qg.numpy(),
+             bounds=np.array([lo, hi]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_wps", [7, 8])
+def test_waypoint_sharding_world2(tmp_path, n_wps):
+    sys.path.insert(0, REPO)
+    from trajectory_optimization_amd import synth
+    from oracle import oracle
+    n_pts, world = 5000, 2
+    mp.spawn(_worker, args=(world, _free_port(), n_pts, n_wps, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in range(world))
+    # contiguous balanced cover of the waypoints
+    assert r0["bounds"][0] == 0 and r0["bounds"][1] == r1["bounds"][0] and r1["bounds"][1] == n_wps
+    assert abs((r0["bounds"][1] - r0["bounds"][0]) - (r1["bounds"][1] - r1["bounds"][0])) <= 1
+    # replicated state is identical on both ranks
+    for k in ("rewards", "pg", "qg"):
+        assert np.array_equal(r0[k], r1[k])
+    # and equals the single-process evaluation
+    K, iw, ih = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
+    pts = synth.make_cloud(n_pts, seed=5)
+    poses, quats = synth.make_path(n_wps, optical=True, jitter_seed=5)
+    f = oracle.traj_forward(pts, poses, quats, K, iw, ih, prec="f64")
+    pg, qg = oracle.traj_backward(pts, poses, quats, K, iw, ih, f, prec="f64")
+    np.testing.assert_allclose(r0["rewards"], f["rewards"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(r0["pg"], pg, rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(r0["qg"], qg, rtol=1e-9, atol=1e-15)
+
+
+def test_bounds_cover_all_ranks():
+    sys.path.insert(0, REPO)
+    from trajectory_optimization_amd.distributed import WaypointShard
+    s = WaypointShard.__new__(WaypointShard)
+    for world in (1, 2, 3, 8):
+        s.world_size = world
+        for n in (0, 1, 5, 8, 127, 1024):
+            prev = 0
+            for r in range(world):
+                s.rank = r
+                lo, hi = s.bounds(n)
+                assert lo == prev and hi >= lo
+                prev = hi
+            assert prev == n

@@ -1,0 +1,74 @@
+"""CPU-side checks that need no GPU: the C-ABI library loads and exports every declared symbol, argument
+validation works without touching the device, the product path refuses to run without a GPU, and the
+torch-side regularisers match the reference's values."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, REPO
+
+
+def test_library_exports_every_declared_symbol():
+    from trajectory_optimization_amd import _lib
+    header = open(os.path.join(REPO, "include", "trajopt_hip.h")).read()
+    declared = set(re.findall(r"\b(tohip_\w+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert _lib.lib().tohip_abi_version() == 1
+
+
+def test_sizes_and_argument_errors_without_gpu():
+    from trajectory_optimization_amd import _lib
+    L = _lib.lib()
+    assert L.tohip_padded_points(1) == 1024 and L.tohip_padded_points(1024) == 1024 and L.tohip_padded_points(1025) == 2048
+    assert L.tohip_padded_points(0) == 0
+    assert L.tohip_traj_workspace_bytes(1_000_000, 128) > 128 * 64
+    assert L.tohip_traj_workspace_bytes(0, 5) == 0
+    assert L.tohip_hpr_workspace_bytes(1000) > 1000 * 24
+    assert L.tohip_error_string(-1).decode().startswith("invalid argument")
+    # null pointers / bad sizes are rejected before any launch
+    assert L.tohip_pack_cloud(None, 10, None, None) == -1
+    cam = _lib.make_camera([1, 0, 0, 0, 1, 0, 0, 0, 1], 10, 10, 1, 5)
+    assert L.tohip_traj_forward(None, 10, None, None, 1, ctypes.byref(cam), None, None, None, None, 0, None) == -1
+    assert L.tohip_hidden_pts_removal(None, 2, 2.0, None, None, None, None, 0, None) == -1
+
+
+def test_no_cpu_fallback():
+    from trajectory_optimization_amd import ops
+    from trajectory_optimization_amd.model import ModelTraj, ModelPose
+    pts = torch.rand(100, 3)
+    with pytest.raises(RuntimeError):
+        ops.PackedCloud(pts)
+    with pytest.raises(RuntimeError):
+        ModelTraj(pts, torch.zeros(3, 3), torch.tensor([[1., 0, 0, 0]] * 3), torch.eye(3), 10., 10., device=torch.device("cpu"))
+    with pytest.raises(RuntimeError):
+        ModelPose(pts, torch.zeros(1, 3), torch.tensor([[1., 0, 0, 0]]), torch.eye(3), 10., 10., device=torch.device("cpu"))
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under trajectory_optimization_amd/ may import, load or link it."""
+    pkg = os.path.join(REPO, "trajectory_optimization_amd")
+    bad = re.compile(r"(^\s*(from|import)\s+oracle\b)|liboracle|oracle[/.]_build|oracle\.(traj|pose|hidden|lib|build)",
+                     re.M)
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                assert not bad.search(open(os.path.join(root, f)).read()), f
+
+
+def test_regularisers_match_reference():
+    from trajectory_optimization_amd.model import length_calc, mean_angle_calc
+    d = load_golden("funcs")
+    for key in ("traj", "path27"):
+        t = torch.from_numpy(d[key])
+        assert abs(float(length_calc(t)) - float(d[key + "_length"])) <= 2e-6 * float(d[key + "_length"])
+        assert abs(float(mean_angle_calc(t)) - float(d[key + "_mean_angle"])) <= 2e-6 * float(d[key + "_mean_angle"])
+    with pytest.raises(ZeroDivisionError):
+        mean_angle_calc(torch.zeros(2, 3))  # the reference divides 0.0 by (N_wps - 2) = 0
