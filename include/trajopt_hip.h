@@ -63,50 +63,62 @@ int tohip_abi_version(void);
 const char *tohip_error_string(int code);
 
 /* ---- cloud packing -------------------------------------------------------------------------
- * The cloud is constant over an optimisation run (model.py:80,174), so it is packed once:
- * (N,3) row-major -> x[Npad] | y[Npad] | z[Npad], Npad = tohip_padded_points(N); the pad repeats
- * the last point. */
+ * The cloud is constant over an optimisation run (model.py:80,174), so it is packed once into an opaque
+ * device blob of tohip_packed_cloud_bytes(N) bytes: the points in Morton order as x[Npad] | y[Npad] |
+ * z[Npad] (Npad = tohip_padded_points(N); the pad repeats the last sorted point), the permutation back to
+ * the caller's order, and one bounding sphere per 256 sorted points.  sort = 0 keeps the caller's order
+ * (no spatial coherence: the exact culling then rarely fires).  Needs tohip_pack_workspace_bytes(N)
+ * bytes of scratch. */
 int64_t tohip_padded_points(int64_t n_points);
-int tohip_pack_cloud(const float *xyz, int64_t n_points, float *soa, void *stream);
+size_t tohip_packed_cloud_bytes(int64_t n_points);
+size_t tohip_pack_workspace_bytes(int64_t n_points);
+int tohip_pack_cloud(const float *xyz, int64_t n_points, int sort, void *packed, void *workspace,
+                     size_t workspace_bytes, void *stream);
 
 /* ---- ModelTraj (model.py:200-242 forward, :246 visibility term, autograd backward) ----------
  * Workspace bytes needed by the three calls below for n_points and n_virtual = W * max(1,n_cams). */
 size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual);
 
+/* flags */
+#define TOHIP_TRAJ_DENSE 1 /* evaluate every (point, waypoint) pair; default: skip pairs that provably
+                              contribute exactly nothing (bitwise identical results, see traj_kernels.hip) */
+
 /* Forward over the W evaluated waypoints (caller has applied wps_step, model.py:214-217):
  * to_camera_frame -> get_dist_mask * get_fov_mask -> per-waypoint (p-min)/max -> clip -> log-odds,
- * summed over waypoints into lo_sum[0..N) (overwritten; this rank's partial sum when the waypoints
- * are sharded over GPUs).  minmax[v] = (min p, max(p - min p)) per virtual waypoint, kept for the
- * backward.  replaces model.py:217-231. */
-int tohip_traj_forward(const float *soa, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
-                       const tohip_camera *cam_host, const tohip_rig *rig_host, float *lo_sum, float *minmax,
-                       void *workspace, size_t workspace_bytes, void *stream);
+ * summed over waypoints into lo_sum[0..Npad) IN PACKED (sorted) ORDER (overwritten; this rank's partial
+ * sum when the waypoints are sharded over GPUs — every rank packs the same cloud the same way).
+ * minmax[v] = (min p, max(p - min p)) per virtual waypoint, kept for the backward.
+ * replaces model.py:217-231. */
+int tohip_traj_forward(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
+                       const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, float *lo_sum,
+                       float *minmax, void *workspace, size_t workspace_bytes, void *stream);
 
-/* rewards = sigmoid(lo_sum) (model.py:237); scalars[0] = mean(rewards), scalars[1] = loss_vis =
- * 1/(mean+eps) (model.py:246), scalars[2] = -loss_vis^2/N (d loss_vis / d reward_n). */
-int tohip_traj_reward(const float *lo_sum, int64_t n_points, float eps, float *rewards, float *scalars,
-                      void *workspace, size_t workspace_bytes, void *stream);
+/* rewards[0..N) = sigmoid(lo_sum) in the CALLER'S point order (model.py:237); scalars[0] = mean(rewards),
+ * scalars[1] = loss_vis = 1/(mean+eps) (model.py:246), scalars[2] = -loss_vis^2/N (d loss_vis / d reward_n). */
+int tohip_traj_reward(const void *packed, const float *lo_sum, int64_t n_points, float eps, float *rewards,
+                      float *scalars, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward w.r.t. this rank's waypoints: poses_grad (W,3), quats_grad (W,4).  minmax from the forward.
- * The upstream gradient is either grad_rewards (N floats, dL/d rewards: any criterion built on
- * model.rewards, as torch autograd would hand it over), or, when grad_rewards is NULL, the fused
- * visibility loss: scalars (from tohip_traj_reward) and gout = device pointer to dL/d loss_vis. */
-int tohip_traj_backward(const float *soa, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
-                        const tohip_camera *cam_host, const tohip_rig *rig_host, const float *rewards,
+ * The upstream gradient is either grad_rewards (N floats in the caller's order, dL/d rewards: any
+ * criterion built on model.rewards, as torch autograd would hand it over), or, when grad_rewards is NULL,
+ * the fused visibility loss: scalars (from tohip_traj_reward) and gout = device pointer to dL/d loss_vis. */
+int tohip_traj_backward(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
+                        const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, const float *rewards,
                         const float *grad_rewards, const float *scalars, const float *minmax, const float *gout,
                         float *poses_grad, float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- ModelPose (model.py:98-127) -------------------------------------------------------------- */
 size_t tohip_pose_workspace_bytes(int64_t n_points);
 
-/* observations[n] = dist_mask*fov_mask (* occlusion_mask[n] when non-NULL, model.py:112-115);
+/* observations, occlusion_mask and grad_obs are in the caller's point order.
+ * observations[n] = dist_mask*fov_mask (* occlusion_mask[n] when non-NULL, model.py:112-115);
  * scalars[0] = sum(observations), scalars[1] = loss = 1/(sum+eps). */
-int tohip_pose_forward(const float *soa, int64_t n_points, const float *trans, const float *quat,
+int tohip_pose_forward(const void *packed, int64_t n_points, const float *trans, const float *quat,
                        const tohip_camera *cam_host, const float *occlusion_mask, float *observations, float *scalars,
                        void *workspace, size_t workspace_bytes, void *stream);
 /* Upstream gradient: grad_obs (N floats, dL/d observations) or, when NULL, the fused loss through
  * scalars (from tohip_pose_forward) and gout (device pointer to dL/d loss). */
-int tohip_pose_backward(const float *soa, int64_t n_points, const float *trans, const float *quat,
+int tohip_pose_backward(const void *packed, int64_t n_points, const float *trans, const float *quat,
                         const tohip_camera *cam_host, const float *occlusion_mask, const float *grad_obs,
                         const float *scalars, const float *gout, float *trans_grad, float *quat_grad, void *workspace,
                         size_t workspace_bytes, void *stream);

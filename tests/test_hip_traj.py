@@ -24,18 +24,18 @@ def _ops():
     return ops
 
 
-def _run_ops(dev, points, poses, quats, rig=None):
+def _run_ops(dev, points, poses, quats, rig=None, flags=0, sort=True):
     ops = _ops()
-    cloud = ops.PackedCloud(torch.from_numpy(np.ascontiguousarray(points)).to(dev))
+    cloud = ops.PackedCloud(torch.from_numpy(np.ascontiguousarray(points)).to(dev), sort=sort)
     cam = ops.Camera(K, IW, IH)
     p = torch.from_numpy(np.ascontiguousarray(poses)).to(dev)
     q = torch.from_numpy(np.ascontiguousarray(quats)).to(dev)
     rg = ops.CameraRig(rig[0], rig[1], dev) if rig is not None else None
     ws = ops.TrajWorkspace(cloud, p.shape[0] * (rg.n_cams if rg else 1))
-    lo_sum, minmax = ops.traj_forward(cloud, p, q, cam, ws, rg)
+    lo_sum, minmax = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=flags)
     rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
     gout = torch.ones(1, device=dev)
-    pg, qg = ops.traj_backward(cloud, p, q, cam, ws, rewards, minmax, scalars=scalars, gout=gout, rig=rg)
+    pg, qg = ops.traj_backward(cloud, p, q, cam, ws, rewards, minmax, scalars=scalars, gout=gout, rig=rg, flags=flags)
     torch.cuda.synchronize()
     return dict(lo_sum=lo_sum[:cloud.n].cpu().numpy(), rewards=rewards.cpu().numpy(), minmax=minmax.cpu().numpy(),
                 scalars=scalars.cpu().numpy(), pg=pg.cpu().numpy(), qg=qg.cpu().numpy())
@@ -51,6 +51,20 @@ def test_wave_reduce_selftest(dev):
     assert torch.equal(mn, m.min(0).values) and torch.equal(mx, m.max(0).values)
 
 
+def test_packed_cloud_is_a_permutation(dev):
+    ops = _ops()
+    pts = synth.make_cloud(70_001, seed=2)
+    cloud = ops.PackedCloud(torch.from_numpy(pts).to(dev))
+    perm = cloud.perm.cpu().numpy()
+    n, npad = cloud.n, cloud.npad
+    assert np.array_equal(np.sort(perm[:n]), np.arange(n)) and np.all(perm[n:] == -1)
+    soa = cloud.soa.cpu().numpy().reshape(3, npad)
+    assert np.array_equal(soa[:, :n].T, pts[perm[:n]])
+    assert np.array_equal(soa[:, n:], np.repeat(soa[:, n - 1:n], npad - n, axis=1))
+    unsorted = ops.PackedCloud(torch.from_numpy(pts).to(dev), sort=False)
+    assert np.array_equal(unsorted.perm.cpu().numpy()[:n], np.arange(n))
+
+
 GOLD = ["traj_bundled_tilted_all", "traj_synth_1000x3", "traj_synth_10000x8", "traj_synth_20000x32",
         "traj_synth_ties", "traj_synth_dense"]
 
@@ -63,6 +77,34 @@ def test_c_abi_vs_golden(dev, name):
     np.testing.assert_allclose(r["rewards"], d["rewards"], rtol=REW_RTOL, atol=REW_ATOL)
     assert rel_inf(r["pg"], d["vis_poses_grad"]) < GRAD_TOL
     assert rel_inf(r["qg"], d["vis_quats_grad"]) < GRAD_TOL
+
+
+@pytest.mark.parametrize("name", ["traj_synth_ties", "traj_synth_dense", "traj_synth_20000x32", "traj_bundled_tilted_all"])
+def test_culling_is_bitwise_exact(dev, name):
+    """The default path skips pairs that provably contribute nothing; TOHIP_TRAJ_DENSE evaluates every pair.
+    Same bits out (fixtures incl. ties at the max and a dense cloud with min p > 0)."""
+    ops = _ops()
+    d = load_golden(name)
+    a = _run_ops(dev, d["points"], d["poses"], d["quats"])
+    b = _run_ops(dev, d["points"], d["poses"], d["quats"], flags=ops.DENSE)
+    for k in ("lo_sum", "rewards", "minmax", "scalars", "pg", "qg"):
+        assert np.array_equal(a[k], b[k]), k
+    # caller's order is independent of the internal Morton order (sums differ only by association)
+    c = _run_ops(dev, d["points"], d["poses"], d["quats"], sort=False)
+    np.testing.assert_allclose(c["rewards"], a["rewards"], rtol=1e-6, atol=1e-7)
+    assert rel_inf(c["pg"], a["pg"]) < 2e-6 and rel_inf(c["qg"], a["qg"]) < 2e-6
+
+
+def test_culling_is_bitwise_exact_rig_and_large(dev):
+    ops = _ops()
+    pts = synth.make_cloud(300_000, seed=51)
+    poses, quats = synth.make_path(12, optical=True, jitter_seed=51)
+    rq, rt = synth.camera_rig(5)
+    for rig in (None, (rq, rt)):
+        a = _run_ops(dev, pts, poses, quats, rig=rig)
+        b = _run_ops(dev, pts, poses, quats, rig=rig, flags=ops.DENSE)
+        for k in ("lo_sum", "rewards", "minmax", "scalars", "pg", "qg"):
+            assert np.array_equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize("n,w,seed", [(50_000, 16, 31), (200_000, 8, 32), (600_000, 4, 33), (1_000_003, 3, 34)])
@@ -130,9 +172,11 @@ def test_full_size_properties(dev):
     poses, quats = synth.make_path(w, optical=True)
     r1 = _run_ops(dev, pts, poses, quats)
     r2 = _run_ops(dev, pts, poses, quats)
-    # deterministic: fixed-order reductions, bitwise reproducible
-    for k in ("rewards", "pg", "qg", "scalars"):
+    r3 = _run_ops(dev, pts, poses, quats, flags=ops.DENSE)
+    # deterministic: fixed-order reductions, bitwise reproducible; exact culling == dense evaluation
+    for k in ("rewards", "pg", "qg", "scalars", "minmax"):
         assert np.array_equal(r1[k], r2[k]), k
+        assert np.array_equal(r1[k], r3[k]), k
     # every log-odds term is >= 0, so rewards live in [0.5, 1] (f32 sigmoid saturates to exactly 1)
     assert r1["rewards"].min() >= 0.5 and r1["rewards"].max() <= 1.0
     assert 0.5 < r1["rewards"].mean() < 0.9

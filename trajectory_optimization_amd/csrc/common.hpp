@@ -33,15 +33,25 @@ struct CamConsts {
     int pinhole;             // K = [[fx,0,cx],[0,fy,cy],[0,0,1]]
 };
 
-// Hot record, one 64-byte line per virtual waypoint: c = m * (x - t).  a/M/invM are filled by the
-// min/max finishing kernel (p_hat = (p - a) * invM).
+// Hot record, one 64-byte line per virtual waypoint: c = m * (x - t).  a / invM / thr / sthr are filled by
+// the min/max finishing kernel: p_hat = (p - a) * invM;  d2 > thr  =>  p_hat < 0.5 (log-odds exactly 0).
 struct __attribute__((aligned(64))) WayHot {
     float m[9];   // m[3*i+j] = R[j][i]  (R = rotation camera->world of the virtual waypoint)
     float t[3];
     float a;      // min_n p
+    float invM;   // 1 / max_n (p - a)
+    float thr;    // squared-distance bound of the active set (+inf = no culling)
+    float sthr;   // sqrt(thr)
+};
+
+// Per-waypoint side record (32 B): pass-1 culling data from the probe, and M for the backward.
+struct WayAux {
     float M;      // max_n (p - a)
-    float invM;   // 1/M
-    float pad;
+    float L;      // lower bound of max_n p found by the probe (0 = none)
+    float thr1;   // squared-distance bound for the max search (+inf = no culling)
+    float sthr1;
+    float azero;  // 1 = the probe exhibited a point with p == 0, hence min_n p == 0 exactly
+    float pad[3];
 };
 
 // Cold record used by the gradient chain.
@@ -51,7 +61,31 @@ struct WayCold {
     float pad[3];
 };
 
+// The packed cloud as the kernels see it (tohip_pack_cloud): Morton-sorted SoA + permutation + tile bounds.
+struct CloudView {
+    const float* soa;       // x | y | z, npad each, sorted order, pads repeat the last sorted point
+    const int* perm;        // sorted position -> original index (-1 for pads)
+    const float4* bounds;   // per 256 sorted points: bounding-sphere centre xyz, radius (conservative)
+    int64_t npad;
+    int64_t n;
+};
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Packed cloud blob (tohip_pack_cloud): [x|y|z f32, 3*npad] [perm i32, npad] [bounds float4, npad/256]
+static inline size_t packed_cloud_bytes(int64_t n) {
+    const int64_t npad = tohip_padded_points(n);
+    return (size_t)npad * 16 + (size_t)(npad / 256) * 16;
+}
+static inline CloudView cloud_view(const void* packed, int64_t n) {
+    CloudView cv;
+    cv.npad = tohip_padded_points(n);
+    cv.n = n;
+    cv.soa = (const float*)packed;
+    cv.perm = (const int*)((const char*)packed + (size_t)cv.npad * 12);
+    cv.bounds = (const float4*)((const char*)packed + (size_t)cv.npad * 16);
+    return cv;
+}
 
 static inline CamConsts make_consts(const tohip_camera* c) {
     CamConsts k;
@@ -88,6 +122,26 @@ __device__ __forceinline__ float to_exp(float x) {
 
 __device__ __forceinline__ float to_log2(float x) { return __builtin_amdgcn_logf(x); }
 
+// Squared-distance bound thr such that  d2 > thr  =>  exp(-0.5 * d2 * inv_var) < tau * (1 - 1e-4), i.e. the
+// soft visibility p = S * exp(-0.5 (d2 inv_var + ...)) <= that bound cannot reach tau.  The 1e-4 margin covers
+// every rounding in p (~1e-6).  tau outside (0,1) -> +inf (never cull).
+__device__ inline void cull_threshold(float tau, float inv_var, float* thr, float* sthr) {
+    const double t = (double)tau * (1.0 - 1e-4);
+    float th = INFINITY;
+    if (t > 0.0 && t < 1.0) {
+        th = (float)(-2.0 * log(t) / (double)inv_var * (1.0 + 1e-6));
+        th = nextafterf(th, INFINITY);
+    }
+    *thr = th;
+    *sthr = sqrtf(th) * 1.000001f;
+}
+
+// camera-frame squared distance to the Gaussian centre (model.py:22), same expression as soft_vis uses
+__device__ __forceinline__ float dist2_mean(float X, float Y, float Z, float mean) {
+    const float dx = X - mean, dy = Y - mean, dz = Z - mean;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
 // ----------------------------------------------------------------------------------------------
 // Soft visibility of one camera-frame point: p = D * (S * Gw * Gh)   (model.py:13-47, :110/:223).
 // The three Gaussians share one exponential: exp(a)exp(b)exp(c) = exp(a+b+c).
@@ -98,8 +152,7 @@ struct Vis {
 
 template <bool PINHOLE>
 __device__ __forceinline__ float soft_vis(const CamConsts& k, float X, float Y, float Z, Vis* o) {
-    const float dx = X - k.mean, dy = Y - k.mean, dz = Z - k.mean;
-    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    const float d2 = dist2_mean(X, Y, Z, k.mean);
     float h0, h1, h2;
     if (PINHOLE) {
         h0 = fmaf(k.k[2], Z, k.k[0] * X);

@@ -8,19 +8,114 @@
 // These produce index sets that must equal the reference's bit for bit, so the arithmetic is the
 // reference CPU path's, operation by operation: K @ points as the k-ordered FMA chain of its 3x3 sgemm,
 // IEEE division, torch.linalg.norm's FMA chain (all pinned on fixtures, tests/test_oracle_golden.py).
+#include <hipcub/hipcub.hpp>
+
 #include "common.hpp"
 
 // ---------------------------------------------------------------------------------------------
-// (N,3) -> x|y|z padded with copies of the last point
+// cloud packing: (N,3) -> Morton-sorted x|y|z (padded with copies of the last sorted point), the
+// permutation back to the caller's order, and one bounding sphere per 256 sorted points.
+
+__device__ __forceinline__ unsigned fkey(float f) {  // order-preserving float -> uint
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// bbox[0..2] = min keys, bbox[3..5] = max keys (pre-set to 0xffffffff / 0)
+__global__ void __launch_bounds__(TO_BLOCK) k_bbox(const float* __restrict__ xyz, int64_t n, unsigned* __restrict__ bbox) {
+    unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride)
+        for (int k = 0; k < 3; ++k) {
+            const float f = xyz[3 * i + k];
+            if (f != f) continue;  // NaNs do not shape the box
+            const unsigned u = fkey(f);
+            mn[k] = min(mn[k], u); mx[k] = max(mx[k], u);
+        }
+    for (int k = 0; k < 3; ++k) {
+        for (int s = 32; s > 0; s >>= 1) { mn[k] = min(mn[k], (unsigned)__shfl_xor((int)mn[k], s)); mx[k] = max(mx[k], (unsigned)__shfl_xor((int)mx[k], s)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&bbox[k], mn[k]); atomicMax(&bbox[3 + k], mx[k]); }
+    }
+}
+
+__device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
 
 __global__ void __launch_bounds__(TO_BLOCK)
-k_pack_cloud(const float* __restrict__ xyz, int64_t n, int64_t npad, float* __restrict__ soa) {
+k_morton(const float* __restrict__ xyz, int64_t n, const unsigned* __restrict__ bbox, unsigned* __restrict__ keys,
+         int* __restrict__ vals) {
+    const float lo[3] = {fkey_inv(bbox[0]), fkey_inv(bbox[1]), fkey_inv(bbox[2])};
+    const float hi[3] = {fkey_inv(bbox[3]), fkey_inv(bbox[4]), fkey_inv(bbox[5])};
+    float sc[3];
+    for (int k = 0; k < 3; ++k) sc[k] = hi[k] > lo[k] ? 1023.0f / (hi[k] - lo[k]) : 0.f;
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        unsigned q[3];
+        for (int k = 0; k < 3; ++k) {
+            const float f = (xyz[3 * i + k] - lo[k]) * sc[k];
+            q[k] = (unsigned)fminf(fmaxf(f, 0.f), 1023.f);  // NaN -> 0
+        }
+        keys[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+        vals[i] = (int)i;
+    }
+}
+
+__global__ void __launch_bounds__(TO_BLOCK) k_iota(int* __restrict__ vals, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) vals[i] = (int)i;
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_pack_cloud(const float* __restrict__ xyz, const int* __restrict__ order, int64_t n, int64_t npad, float* __restrict__ soa,
+             int* __restrict__ perm) {
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < npad; i += stride) {
-        const int64_t s = i < n ? i : n - 1;
+        const int64_t s = order[i < n ? i : n - 1];
         soa[i] = xyz[3 * s];
         soa[npad + i] = xyz[3 * s + 1];
         soa[2 * npad + i] = xyz[3 * s + 2];
+        perm[i] = i < n ? (int)s : -1;
+    }
+}
+
+// block per 256 sorted points: centre of the bounding box, radius = max distance to it, padded for
+// the float rounding of the kernels' camera-frame arithmetic (conservative: a larger sphere only culls less)
+__global__ void __launch_bounds__(TO_BLOCK)
+k_tile_bounds(const float* __restrict__ soa, int64_t npad, float4* __restrict__ bounds) {
+    __shared__ float smn[3][TO_BLOCK], smx[3][TO_BLOCK];
+    const int t = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * TO_BLOCK + t;
+    const float p[3] = {soa[i], soa[npad + i], soa[2 * npad + i]};
+    for (int k = 0; k < 3; ++k) { smn[k][t] = p[k]; smx[k][t] = p[k]; }
+    __syncthreads();
+    for (int s = TO_BLOCK / 2; s > 0; s >>= 1) {
+        if (t < s)
+            for (int k = 0; k < 3; ++k) { smn[k][t] = fminf(smn[k][t], smn[k][t + s]); smx[k][t] = fmaxf(smx[k][t], smx[k][t + s]); }
+        __syncthreads();
+    }
+    const float c[3] = {0.5f * (smn[0][0] + smx[0][0]), 0.5f * (smn[1][0] + smx[1][0]), 0.5f * (smn[2][0] + smx[2][0])};
+    __syncthreads();
+    const float dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];
+    float r = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (!(r == r)) r = INFINITY;  // a NaN point: never cull this tile
+    smx[0][t] = r;
+    __syncthreads();
+    for (int s = TO_BLOCK / 2; s > 0; s >>= 1) {
+        if (t < s) smx[0][t] = fmaxf(smx[0][t], smx[0][t + s]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float amax = fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fabsf(c[2])) + smx[0][0];
+        bounds[blockIdx.x] = make_float4(c[0], c[1], c[2], smx[0][0] * 1.0001f + 1e-5f * amax + 1e-6f);
     }
 }
 
@@ -29,12 +124,69 @@ extern "C" int64_t tohip_padded_points(int64_t n) {
     return (n + TOHIP_POINT_TILE - 1) / TOHIP_POINT_TILE * TOHIP_POINT_TILE;
 }
 
-extern "C" int tohip_pack_cloud(const float* xyz, int64_t n, float* soa, void* stream_) {
-    if (!xyz || !soa || n <= 0) return TOHIP_EINVAL;
+extern "C" size_t tohip_packed_cloud_bytes(int64_t n) { return n > 0 ? packed_cloud_bytes(n) : 0; }
+
+namespace {
+struct PackPlan { size_t off_keys, off_keys2, off_vals, off_vals2, off_bbox, off_tmp, tmp_bytes, total; };
+inline PackPlan pack_plan(int64_t n) {
+    PackPlan p;
+    size_t o = 0;
+    p.off_keys = o;  o += align_up(sizeof(unsigned) * (size_t)n, 256);
+    p.off_keys2 = o; o += align_up(sizeof(unsigned) * (size_t)n, 256);
+    p.off_vals = o;  o += align_up(sizeof(int) * (size_t)n, 256);
+    p.off_vals2 = o; o += align_up(sizeof(int) * (size_t)n, 256);
+    p.off_bbox = o;  o += 256;
+    size_t tmp = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
+                                             (int*)nullptr, (int)n, 0, 30, (hipStream_t)0);
+    p.tmp_bytes = tmp;
+    p.off_tmp = o;   o += align_up(tmp, 256);
+    p.total = o;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t tohip_pack_workspace_bytes(int64_t n) { return n > 0 ? pack_plan(n).total : 0; }
+
+extern "C" int tohip_pack_cloud(const float* xyz, int64_t n, int sort, void* packed, void* workspace,
+                                size_t workspace_bytes, void* stream_) {
+    if (!xyz || !packed || !workspace || n <= 0 || n > (int64_t)0x7fffffff) return TOHIP_EINVAL;
+    const PackPlan pl = pack_plan(n);
+    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    unsigned* keys = (unsigned*)(ws + pl.off_keys);
+    unsigned* keys2 = (unsigned*)(ws + pl.off_keys2);
+    int* vals = (int*)(ws + pl.off_vals);
+    int* vals2 = (int*)(ws + pl.off_vals2);
+    unsigned* bbox = (unsigned*)(ws + pl.off_bbox);
     const int64_t npad = tohip_padded_points(n);
-    int64_t nb = npad / TO_BLOCK;
-    if (nb > 4096) nb = 4096;
-    k_pack_cloud<<<(int)nb, TO_BLOCK, 0, (hipStream_t)stream_>>>(xyz, n, npad, soa);
+    int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
+    if (nb > 2048) nb = 2048;
+    const int* order = vals;
+    if (sort) {
+        hipError_t e = hipMemsetAsync(bbox, 0xff, 3 * sizeof(unsigned), st);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemsetAsync(bbox + 3, 0, 3 * sizeof(unsigned), st);
+        if (e != hipSuccess) return (int)e;
+        k_bbox<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, bbox);
+        TO_HIP_CHECK_LAUNCH();
+        k_morton<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, bbox, keys, vals);
+        TO_HIP_CHECK_LAUNCH();
+        size_t tmp = pl.tmp_bytes;
+        e = hipcub::DeviceRadixSort::SortPairs(ws + pl.off_tmp, tmp, keys, keys2, vals, vals2, (int)n, 0, 30, st);
+        if (e != hipSuccess) return (int)e;
+        order = vals2;  // radix sort is stable: equal cells keep the caller's order (deterministic)
+    } else {
+        k_iota<<<(int)nb, TO_BLOCK, 0, st>>>(vals, n);
+        TO_HIP_CHECK_LAUNCH();
+    }
+    const CloudView cv = cloud_view(packed, n);
+    int64_t nbp = npad / TO_BLOCK;
+    if (nbp > 4096) nbp = 4096;
+    k_pack_cloud<<<(int)nbp, TO_BLOCK, 0, st>>>(xyz, order, n, npad, (float*)cv.soa, (int*)cv.perm);
+    TO_HIP_CHECK_LAUNCH();
+    k_tile_bounds<<<(int)(npad / TO_BLOCK), TO_BLOCK, 0, st>>>(cv.soa, npad, (float4*)cv.bounds);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }

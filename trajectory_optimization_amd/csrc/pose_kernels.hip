@@ -13,18 +13,19 @@
 // observations + block partial sums (grid-stride, one point per lane per step: streaming 12 B in, 4 B out)
 template <bool PINHOLE>
 __global__ void __launch_bounds__(TO_BLOCK)
-k_pose_fwd(const float* __restrict__ soa, int64_t npad, int64_t n, const WayHot* __restrict__ hot, CamConsts cc,
-           const float* __restrict__ mask, float* __restrict__ obs, double* __restrict__ part) {
+k_pose_fwd(CloudView cv, const WayHot* __restrict__ hot, CamConsts cc, const float* __restrict__ mask,
+           float* __restrict__ obs, double* __restrict__ part) {
     __shared__ double lds[TO_BLOCK];
     const WayHot h = hot[0];
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < cv.n; i += stride) {
         float X, Y, Z, y0, y1, y2;
-        to_cam(h, soa[i], soa[npad + i], soa[2 * npad + i], X, Y, Z, y0, y1, y2);
+        to_cam(h, cv.soa[i], cv.soa[cv.npad + i], cv.soa[2 * cv.npad + i], X, Y, Z, y0, y1, y2);
         float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
-        if (mask) p = mask[i] * p;  // model.py:115
-        obs[i] = p;
+        const int o = cv.perm[i];  // the caller's point order
+        if (mask) p = mask[o] * p;  // model.py:115
+        obs[o] = p;
         s += (double)p;
     }
     const double tot = block_sum_double(s, lds);
@@ -47,9 +48,9 @@ k_pose_fwd_finish(const double* __restrict__ part, int nparts, float eps, float*
 // dL/d obs_n = -loss^2 * gout (model.py:126); 12 sums per block: sum w g [3], sum w y (x) g [9]
 template <bool PINHOLE>
 __global__ void __launch_bounds__(TO_BLOCK)
-k_pose_bwd(const float* __restrict__ soa, int64_t npad, int64_t n, const WayHot* __restrict__ hot, CamConsts cc,
-           const float* __restrict__ mask, const float* __restrict__ grad_obs, const float* __restrict__ scalars,
-           const float* __restrict__ gout, double* __restrict__ part) {
+k_pose_bwd(CloudView cv, const WayHot* __restrict__ hot, CamConsts cc, const float* __restrict__ mask,
+           const float* __restrict__ grad_obs, const float* __restrict__ scalars, const float* __restrict__ gout,
+           double* __restrict__ part) {
     __shared__ double lds[TO_BLOCK];
     const WayHot h = hot[0];
     // dL/d obs_n: a caller-supplied vector (general criterion), else the fused loss 1/(sum+eps)
@@ -57,15 +58,16 @@ k_pose_bwd(const float* __restrict__ soa, int64_t npad, int64_t n, const WayHot*
     double acc[12];
     for (int k = 0; k < 12; ++k) acc[k] = 0.0;
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < cv.n; i += stride) {
         float X, Y, Z, y0, y1, y2;
-        to_cam(h, soa[i], soa[npad + i], soa[2 * npad + i], X, Y, Z, y0, y1, y2);
+        to_cam(h, cv.soa[i], cv.soa[cv.npad + i], cv.soa[2 * cv.npad + i], X, Y, Z, y0, y1, y2);
         Vis s;
         soft_vis<PINHOLE>(cc, X, Y, Z, &s);
         float g[3];
         dvis_dc<PINHOLE>(cc, X, Y, Z, s, g);
-        const float go = grad_obs ? grad_obs[i] : coef;
-        const float wgt = mask ? go * mask[i] : go;
+        const int o = cv.perm[i];
+        const float go = grad_obs ? grad_obs[o] : coef;
+        const float wgt = mask ? go * mask[o] : go;
         const float w0 = wgt * g[0], w1 = wgt * g[1], w2 = wgt * g[2];
         acc[0] += w0; acc[1] += w1; acc[2] += w2;
         acc[3] += y0 * w0; acc[4] += y0 * w1; acc[5] += y0 * w2;
@@ -190,10 +192,10 @@ extern "C" size_t tohip_pose_workspace_bytes(int64_t n_points) {
     return pose_plan().total;
 }
 
-extern "C" int tohip_pose_forward(const float* soa, int64_t n, const float* trans, const float* quat,
+extern "C" int tohip_pose_forward(const void* packed, int64_t n, const float* trans, const float* quat,
                                   const tohip_camera* cam, const float* mask, float* obs, float* scalars,
                                   void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!soa || !trans || !quat || !cam || !obs || !scalars || !workspace || n <= 0) return TOHIP_EINVAL;
+    if (!packed || !trans || !quat || !cam || !obs || !scalars || !workspace || n <= 0) return TOHIP_EINVAL;
     const PosePlan pl = pose_plan();
     if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream_;
@@ -202,23 +204,23 @@ extern "C" int tohip_pose_forward(const float* soa, int64_t n, const float* tran
     WayCold* cold = (WayCold*)(ws + pl.off_cold);
     double* part = (double*)(ws + pl.off_part);
     const CamConsts cc = make_consts(cam);
-    const int64_t npad = tohip_padded_points(n);
-    k_prep_waycams<<<1, 64, 0, st>>>(trans, quat, 1, 1, nullptr, nullptr, hot, cold);
+    const CloudView cv = cloud_view(packed, n);
+    k_prep_waycams<<<1, 64, 0, st>>>(trans, quat, 1, 1, nullptr, nullptr, hot, cold, nullptr);
     TO_HIP_CHECK_LAUNCH();
     const int nb = pose_blocks(n);
-    if (cc.pinhole) k_pose_fwd<true><<<nb, TO_BLOCK, 0, st>>>(soa, npad, n, hot, cc, mask, obs, part);
-    else k_pose_fwd<false><<<nb, TO_BLOCK, 0, st>>>(soa, npad, n, hot, cc, mask, obs, part);
+    if (cc.pinhole) k_pose_fwd<true><<<nb, TO_BLOCK, 0, st>>>(cv, hot, cc, mask, obs, part);
+    else k_pose_fwd<false><<<nb, TO_BLOCK, 0, st>>>(cv, hot, cc, mask, obs, part);
     TO_HIP_CHECK_LAUNCH();
     k_pose_fwd_finish<<<1, TO_BLOCK, 0, st>>>(part, nb, cam->eps, scalars);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
 
-extern "C" int tohip_pose_backward(const float* soa, int64_t n, const float* trans, const float* quat,
+extern "C" int tohip_pose_backward(const void* packed, int64_t n, const float* trans, const float* quat,
                                    const tohip_camera* cam, const float* mask, const float* grad_obs,
                                    const float* scalars, const float* gout, float* trans_grad, float* quat_grad,
                                    void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!soa || !trans || !quat || !cam || !trans_grad || !quat_grad || !workspace || n <= 0 ||
+    if (!packed || !trans || !quat || !cam || !trans_grad || !quat_grad || !workspace || n <= 0 ||
         (!grad_obs && (!scalars || !gout)))
         return TOHIP_EINVAL;
     const PosePlan pl = pose_plan();
@@ -230,12 +232,12 @@ extern "C" int tohip_pose_backward(const float* soa, int64_t n, const float* tra
     double* part = (double*)(ws + pl.off_part);
     float* vgrad = (float*)(ws + pl.off_vgrad);
     const CamConsts cc = make_consts(cam);
-    const int64_t npad = tohip_padded_points(n);
-    k_prep_waycams<<<1, 64, 0, st>>>(trans, quat, 1, 1, nullptr, nullptr, hot, cold);
+    const CloudView cv = cloud_view(packed, n);
+    k_prep_waycams<<<1, 64, 0, st>>>(trans, quat, 1, 1, nullptr, nullptr, hot, cold, nullptr);
     TO_HIP_CHECK_LAUNCH();
     const int nb = pose_blocks(n);
-    if (cc.pinhole) k_pose_bwd<true><<<nb, TO_BLOCK, 0, st>>>(soa, npad, n, hot, cc, mask, grad_obs, scalars, gout, part);
-    else k_pose_bwd<false><<<nb, TO_BLOCK, 0, st>>>(soa, npad, n, hot, cc, mask, grad_obs, scalars, gout, part);
+    if (cc.pinhole) k_pose_bwd<true><<<nb, TO_BLOCK, 0, st>>>(cv, hot, cc, mask, grad_obs, scalars, gout, part);
+    else k_pose_bwd<false><<<nb, TO_BLOCK, 0, st>>>(cv, hot, cc, mask, grad_obs, scalars, gout, part);
     TO_HIP_CHECK_LAUNCH();
     k_pose_bwd_finish<<<1, TO_BLOCK, 0, st>>>(part, nb, vgrad);
     TO_HIP_CHECK_LAUNCH();

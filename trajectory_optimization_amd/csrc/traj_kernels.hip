@@ -4,14 +4,22 @@
 // :237/:246 (rewards, visibility loss) and its torch-autograd backward (SURVEY.md §8a rows A-C,E,G).
 //
 // Data layout in HBM
-//   cloud     SoA x|y|z, each Npad floats (packed once, tohip_pack_cloud)           12 B/point
-//   WayHot    one 64-B record per virtual waypoint (rotation, translation, min, max) -> SGPRs
-//   lo_sum / rewards                                                                  4 B/point each
+//   cloud     Morton-sorted SoA x|y|z (npad each) + permutation + one bounding sphere per 256 points
+//             (packed once, tohip_pack_cloud)                                          16 B/point
+//   WayHot    one 64-B record per virtual waypoint (rotation, translation, min, 1/max, cull bound) -> SGPRs
+//   lo_sum (sorted order) / rewards (original order)                                    4 B/point each
 //   partials  [virtual waypoint][wave slot] min/max pairs (8 B) and gradient sums (64 B)
 //
-// Kernel shape: one lane owns P consecutive points in registers and loops over the waypoints, whose
-// constants arrive through scalar loads; so HBM traffic is ~N*(12+4) bytes per pass, independent of W,
-// and the passes are VALU/transcendental bound (DESIGN.md has the roofline arithmetic).
+// Kernel shape: one lane owns P consecutive sorted points in registers and loops over the waypoints, whose
+// constants arrive through scalar loads; HBM traffic is ~N*16 B per pass, independent of W.
+//
+// Two evaluation modes with bitwise identical results:
+//   DENSE  every (point, waypoint) pair is evaluated (the streaming reference semantics; bench headline)
+//   CULL   pairs that provably contribute exactly nothing are skipped: the log-odds of a pair is exactly 0
+//          unless p_hat > 0.5, and p <= exp(-0.5 d2/sigma^2) bounds p by the squared distance d2 of the
+//          camera-frame point from (mu,mu,mu).  A wave first tests its 256-point bounding sphere, then the
+//          per-point d2, and only then evaluates.  The per-waypoint max is searched the same way against a
+//          lower bound L <= max found by a strided probe, which also proves min == 0 by exhibiting a zero.
 #include <type_traits>
 
 #include "common.hpp"
@@ -20,18 +28,11 @@
 // ---------------------------------------------------------------------------------------------
 // virtual waypoint records
 
-__device__ __forceinline__ void quat_mul_dev(const float a[4], const float b[4], float o[4]) {
-    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
-    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
-    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
-    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
-}
-
 // thread per virtual waypoint v = w*C + c.  F.normalize (model.py:53), rig composition
 // R_v = R(qn_w) R(q_c), t_v = t_w + R(qn_w) l_c.
 __global__ void k_prep_waycams(const float* __restrict__ poses, const float* __restrict__ quats, int W, int C,
                                const float* __restrict__ rig_q, const float* __restrict__ rig_t,
-                               WayHot* __restrict__ hot, WayCold* __restrict__ cold) {
+                               WayHot* __restrict__ hot, WayCold* __restrict__ cold, WayAux* __restrict__ aux) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= W * C) return;
     const int w = v / C, c = v - w * C;
@@ -70,8 +71,14 @@ __global__ void k_prep_waycams(const float* __restrict__ poses, const float* __r
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) h.m[3 * i + j] = R[3 * j + i];
     h.t[0] = t[0]; h.t[1] = t[1]; h.t[2] = t[2];
-    h.a = 0.f; h.M = 1.f; h.invM = 1.f; h.pad = 0.f;
+    h.a = 0.f; h.invM = 1.f; h.thr = INFINITY; h.sthr = INFINITY;
     hot[v] = h;
+    if (aux) {
+        WayAux a;
+        a.M = 1.f; a.L = 0.f; a.thr1 = INFINITY; a.sthr1 = INFINITY; a.azero = 0.f;
+        a.pad[0] = a.pad[1] = a.pad[2] = 0.f;
+        aux[v] = a;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -97,16 +104,59 @@ __device__ __forceinline__ void load_points(const float* __restrict__ soa, int64
     }
 }
 
-template <int P>
-__device__ __forceinline__ void load_vec(const float* __restrict__ src, int64_t base, float (&v)[P]) {
-    if constexpr (P == 4) {
-        const float4 a = *reinterpret_cast<const float4*>(src + base);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-    } else if constexpr (P == 2) {
-        const float2 a = *reinterpret_cast<const float2*>(src + base);
-        v[0] = a.x; v[1] = a.y;
-    } else {
-        v[0] = src[base];
+// wave-uniform bounding sphere of the 256-point tile this wave's points belong to
+__device__ __forceinline__ float4 wave_tile_bound(const CloudView& cv, int64_t base) {
+    const int tile = __builtin_amdgcn_readfirstlane((int)(base >> 8));
+    float4 b = cv.bounds[tile];
+    b.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b.x)));
+    b.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b.y)));
+    b.z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b.z)));
+    b.w = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b.w)));
+    return b;
+}
+
+// true (wave-uniform) when no point within `tb` can have camera-frame d2 <= thr
+__device__ __forceinline__ bool tile_culled(const WayHot& h, const float4& tb, float mean, float thr, float sthr) {
+    float X, Y, Z, y0, y1, y2;
+    to_cam(h, tb.x, tb.y, tb.z, X, Y, Z, y0, y1, y2);
+    const float D2 = dist2_mean(X, Y, Z, mean);
+    const float bound = fmaf(tb.w, fmaf(2.0f, sthr, tb.w), thr) * 1.00001f;  // (sthr + r)^2, rounded up
+    return __builtin_amdgcn_readfirstlane((int)(D2 > bound)) != 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// probe (CULL mode): block per virtual waypoint evaluates a strided sample of the sorted cloud.
+//   L     = max p over the sample  (a lower bound of the true max: an actual value of p)
+//   azero = some sample has p == 0 exactly  =>  min_n p == 0 (p is never negative)
+
+template <bool PINHOLE>
+__global__ void __launch_bounds__(TO_BLOCK)
+k_traj_probe(CloudView cv, const WayHot* __restrict__ hot, WayAux* __restrict__ aux, CamConsts cc, int step) {
+    __shared__ float smx[TO_BLOCK];
+    __shared__ int szero[TO_BLOCK];
+    const int v = blockIdx.x, t = threadIdx.x;
+    const WayHot h = hot[v];
+    float mx = 0.f;
+    int zero = 0;
+    for (int64_t i = (int64_t)t * step; i < cv.n; i += (int64_t)TO_BLOCK * step) {
+        float X, Y, Z, y0, y1, y2;
+        to_cam(h, cv.soa[i], cv.soa[cv.npad + i], cv.soa[2 * cv.npad + i], X, Y, Z, y0, y1, y2);
+        const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
+        mx = fmaxf(mx, p);
+        zero |= (p == 0.f);
+    }
+    smx[t] = mx; szero[t] = zero;
+    __syncthreads();
+    for (int s = TO_BLOCK / 2; s > 0; s >>= 1) {
+        if (t < s) { smx[t] = fmaxf(smx[t], smx[t + s]); szero[t] |= szero[t + s]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        WayAux a = aux[v];
+        a.L = smx[0];
+        a.azero = szero[0] ? 1.f : 0.f;
+        cull_threshold(a.L, cc.inv_var, &a.thr1, &a.sthr1);
+        aux[v] = a;
     }
 }
 
@@ -114,37 +164,67 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ src, int64_t 
 // pass 1: per-waypoint min / max of p over the cloud.  grid = (point blocks, waypoint tiles).
 // part[v * nslots + slot] = (min, max) over the 64*P points of one wave.
 
-template <int P, bool PINHOLE>
+template <int P, bool PINHOLE, bool CULL>
 __global__ void __launch_bounds__(TO_BLOCK)
-k_traj_pass1(const float* __restrict__ soa, int64_t npad, const WayHot* __restrict__ hot, int V, int vtile,
+k_traj_pass1(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restrict__ aux, int V, int vtile,
              CamConsts cc, float2* __restrict__ part, int nslots) {
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * TO_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
     float x[P], y[P], z[P];
-    load_points<P>(soa, npad, base, x, y, z);
+    load_points<P>(cv.soa, cv.npad, base, x, y, z);
+    float4 tb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (CULL) tb = wave_tile_bound(cv, base);
     const int v0 = blockIdx.y * vtile;
     const int v1 = min(V, v0 + vtile);
     for (int v = v0; v < v1; ++v) {
         const WayHot h = hot[v];
         float mn = INFINITY, mx = -INFINITY;
+        bool culled_mode = false;
+        if (CULL) {
+            const WayAux a = aux[v];
+            culled_mode = a.azero != 0.f;
+            if (culled_mode) {
+                mn = 0.f;  // proven by the probe; only the max is searched, among points that can reach L
+                bool touched = false;
+                if (!tile_culled(h, tb, cc.mean, a.thr1, a.sthr1)) {
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            float X, Y, Z, y0, y1, y2;
-            to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
-            const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
-            mn = fminf(mn, p);
-            mx = fmaxf(mx, p);
+                    for (int i = 0; i < P; ++i) {
+                        float X, Y, Z, y0, y1, y2;
+                        to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+                        if (__any(dist2_mean(X, Y, Z, cc.mean) <= a.thr1)) {
+                            mx = fmaxf(mx, soft_vis<PINHOLE>(cc, X, Y, Z, nullptr));
+                            touched = true;
+                        }
+                    }
+                }
+                if (!touched) {  // wave-uniform: nothing here can beat L
+                    if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(0.f, -INFINITY);
+                    continue;
+                }
+            }
         }
-        mn = wave_min63(mn);
+        if (!culled_mode) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                float X, Y, Z, y0, y1, y2;
+                to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+                const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
+                mn = fminf(mn, p);
+                mx = fmaxf(mx, p);
+            }
+            mn = wave_min63(mn);
+        }
         mx = wave_max63(mx);
         if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
     }
 }
 
-// block per virtual waypoint: a = min, M = max - a (== max(p - a): rounding is monotone)
+// block per virtual waypoint: a = min, M = max - a (== max(p - a): rounding is monotone), cull bound of
+// the active set {p_hat > 0.5} = {p > a + M/2}
 __global__ void __launch_bounds__(TO_BLOCK)
-k_minmax_finish(const float2* __restrict__ part, int nslots, WayHot* __restrict__ hot, float* __restrict__ minmax) {
+k_minmax_finish(const float2* __restrict__ part, int nslots, WayHot* __restrict__ hot, WayAux* __restrict__ aux,
+                float inv_var, int cull, float* __restrict__ minmax) {
     __shared__ float smn[TO_BLOCK], smx[TO_BLOCK];
     const int v = blockIdx.x, t = threadIdx.x;
     float mn = INFINITY, mx = -INFINITY;
@@ -160,52 +240,80 @@ k_minmax_finish(const float2* __restrict__ part, int nslots, WayHot* __restrict_
         __syncthreads();
     }
     if (t == 0) {
-        const float a = smn[0], M = smx[0] - a;
+        float a = smn[0], pmax = smx[0];
+        if (cull) pmax = fmaxf(pmax, aux[v].L);  // L is an attained value of p (defensive: it is never skipped)
+        const float M = pmax - a;
         hot[v].a = a;
-        hot[v].M = M;
         hot[v].invM = 1.0f / M;
+        float thr = INFINITY, sthr = INFINITY;
+        if (cull && M > 0.f) cull_threshold(fmaf(0.5f, M, a), inv_var, &thr, &sthr);
+        hot[v].thr = thr;
+        hot[v].sthr = sthr;
+        aux[v].M = M;
         minmax[2 * v] = a;
         minmax[2 * v + 1] = M;
     }
 }
 
-// restore (a, M, 1/M) from a caller-kept minmax array (backward entry point)
-__global__ void k_set_minmax(WayHot* __restrict__ hot, const float* __restrict__ minmax, int V) {
+// restore (a, M, 1/M, cull bound) from a caller-kept minmax array (backward entry point).  With a > 0 the
+// argmin set {p == a} carries gradient and lies outside the active set, so culling is disabled.
+__global__ void k_set_minmax(WayHot* __restrict__ hot, WayAux* __restrict__ aux, const float* __restrict__ minmax,
+                             int V, float inv_var, int cull) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     const float a = minmax[2 * v], M = minmax[2 * v + 1];
-    hot[v].a = a; hot[v].M = M; hot[v].invM = 1.0f / M;
+    hot[v].a = a; hot[v].invM = 1.0f / M;
+    float thr = INFINITY, sthr = INFINITY;
+    if (cull && M > 0.f && a == 0.f) cull_threshold(0.5f * M, inv_var, &thr, &sthr);
+    hot[v].thr = thr; hot[v].sthr = sthr;
+    aux[v].M = M;
 }
 
 // ---------------------------------------------------------------------------------------------
 // pass 2: p_hat = (p - a)/M, clip to [0.5, 1-eps], log-odds, summed over the waypoints in order
 // (model.py:226-231).  ATOMIC=false: one block column owns all waypoints and stores lo_sum once.
 
-template <int P, bool PINHOLE, bool ATOMIC>
+template <bool PINHOLE>
+__device__ __forceinline__ float log_odds(const CamConsts& cc, const WayHot& h, float X, float Y, float Z) {
+    const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
+    float ph = (p - h.a) * h.invM;
+    ph = __builtin_amdgcn_fmed3f(ph, 0.5f, cc.clip_hi);
+    // log(ph/(1-ph)) as a difference of logs: exactly 0 at ph = 0.5
+    return (to_log2(ph) - to_log2(1.0f - ph)) * 0.693147180559945f;
+}
+
+template <int P, bool PINHOLE, bool ATOMIC, bool CULL>
 __global__ void __launch_bounds__(TO_BLOCK)
-k_traj_pass2(const float* __restrict__ soa, int64_t npad, const WayHot* __restrict__ hot, int V, int vtile, CamConsts cc,
-             float* __restrict__ lo_sum) {
+k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, int vtile, CamConsts cc, float* __restrict__ lo_sum) {
     const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
     float x[P], y[P], z[P], acc[P];
-    load_points<P>(soa, npad, base, x, y, z);
+    load_points<P>(cv.soa, cv.npad, base, x, y, z);
 #pragma unroll
     for (int i = 0; i < P; ++i) acc[i] = 0.f;
+    float4 tb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (CULL) tb = wave_tile_bound(cv, base);
     const int v0 = blockIdx.y * vtile;
     const int v1 = min(V, v0 + vtile);
     bool degenerate = false;  // M == 0: the reference divides 0/0 -> NaN for every point (model.py:227)
     for (int v = v0; v < v1; ++v) {
         const WayHot h = hot[v];
-        degenerate |= !(h.M > 0.f);
+        degenerate |= !(h.invM < INFINITY);
+        if (CULL) {
+            if (tile_culled(h, tb, cc.mean, h.thr, h.sthr)) continue;
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            float X, Y, Z, y0, y1, y2;
-            to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
-            const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
-            float ph = (p - h.a) * h.invM;
-            ph = __builtin_amdgcn_fmed3f(ph, 0.5f, cc.clip_hi);
-            // log(ph/(1-ph)) as a difference of logs: exactly 0 at ph = 0.5
-            const float lo = (to_log2(ph) - to_log2(1.0f - ph)) * 0.693147180559945f;
-            acc[i] += lo;
+            for (int i = 0; i < P; ++i) {
+                float X, Y, Z, y0, y1, y2;
+                to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+                // lanes beyond the bound get p_hat < 0.5 -> exactly 0, so evaluating them too changes nothing
+                if (__any(dist2_mean(X, Y, Z, cc.mean) <= h.thr)) acc[i] += log_odds<PINHOLE>(cc, h, X, Y, Z);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                float X, Y, Z, y0, y1, y2;
+                to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+                acc[i] += log_odds<PINHOLE>(cc, h, X, Y, Z);
+            }
         }
     }
     if (degenerate) {
@@ -223,17 +331,19 @@ k_traj_pass2(const float* __restrict__ soa, int64_t npad, const WayHot* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// rewards = sigmoid(lo_sum) (model.py:237), mean and visibility loss (model.py:246)
+// rewards = sigmoid(lo_sum) (model.py:237) scattered back to the caller's point order, mean and
+// visibility loss (model.py:246)
 
 __global__ void __launch_bounds__(TO_BLOCK)
-k_reward(const float* __restrict__ lo_sum, int64_t n, float* __restrict__ rewards, double* __restrict__ part) {
+k_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, int64_t n, float* __restrict__ rewards,
+         double* __restrict__ part) {
     __shared__ double lds[TO_BLOCK];
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
         const float lo = lo_sum[i];
         const float r = to_rcp(1.0f + to_exp(-lo));
-        rewards[i] = r;
+        rewards[perm[i]] = r;
         s += (double)r;
     }
     const double tot = block_sum_double(s, lds);
@@ -266,9 +376,52 @@ k_reward_finish(const double* __restrict__ part, int nparts, int64_t n, float ep
 
 #define TO_BWD_NSUM 14
 
-template <int P, bool PINHOLE>
+template <bool PINHOLE>
+__device__ __forceinline__ void bwd_eval(const CamConsts& cc, const WayHot& h, float M, float X, float Y, float Z,
+                                         float y0, float y1, float y2, float gn, bool valid, float (&acc)[TO_BWD_NSUM],
+                                         float* __restrict__ tb) {
+    Vis s;
+    const float p = soft_vis<PINHOLE>(cc, X, Y, Z, &s);
+    const float pp = p - h.a;
+    const float ph = pp * h.invM;
+    const bool act = (ph >= 0.5f) && (ph <= cc.clip_hi);
+    const bool is_min = valid && (p == h.a) && (p > 0.f);
+    const bool is_max = valid && (pp == M) && (M > 0.f);
+    if (act || is_min || is_max) {
+        float g[3];
+        dvis_dc<PINHOLE>(cc, X, Y, Z, s, g);
+        if (act) {
+            const float G = gn * to_rcp(ph * (1.0f - ph));
+            const float wgt = G * h.invM;
+            acc[12] = fmaf(wgt, ph - 1.0f, acc[12]);
+            acc[13] = fmaf(-wgt, ph, acc[13]);
+            const float w0 = wgt * g[0], w1 = wgt * g[1], w2 = wgt * g[2];
+            acc[0] += w0; acc[1] += w1; acc[2] += w2;
+            acc[3] = fmaf(y0, w0, acc[3]); acc[4] = fmaf(y0, w1, acc[4]); acc[5] = fmaf(y0, w2, acc[5]);
+            acc[6] = fmaf(y1, w0, acc[6]); acc[7] = fmaf(y1, w1, acc[7]); acc[8] = fmaf(y1, w2, acc[8]);
+            acc[9] = fmaf(y2, w0, acc[9]); acc[10] = fmaf(y2, w1, acc[10]); acc[11] = fmaf(y2, w2, acc[11]);
+        }
+        if (is_min || is_max) {
+            const float yy[3] = {y0, y1, y2};
+            if (is_min) {
+                for (int k = 0; k < 3; ++k) atomicAdd(tb + k, g[k]);
+                for (int j = 0; j < 3; ++j)
+                    for (int k = 0; k < 3; ++k) atomicAdd(tb + 3 + 3 * j + k, yy[j] * g[k]);
+                atomicAdd(tb + 24, 1.0f);
+            }
+            if (is_max) {
+                for (int k = 0; k < 3; ++k) atomicAdd(tb + 12 + k, g[k]);
+                for (int j = 0; j < 3; ++j)
+                    for (int k = 0; k < 3; ++k) atomicAdd(tb + 15 + 3 * j + k, yy[j] * g[k]);
+                atomicAdd(tb + 25, 1.0f);
+            }
+        }
+    }
+}
+
+template <int P, bool PINHOLE, bool CULL>
 __global__ void __launch_bounds__(TO_BLOCK)
-k_traj_bwd(const float* __restrict__ soa, int64_t npad, int64_t n, const WayHot* __restrict__ hot, int V, int vtile,
+k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restrict__ aux, int V, int vtile,
            CamConsts cc, const float* __restrict__ rewards, const float* __restrict__ grad_rewards,
            const float* __restrict__ scalars, const float* __restrict__ gout, float* __restrict__ part, int nslots,
            float* __restrict__ ties) {
@@ -276,69 +429,54 @@ k_traj_bwd(const float* __restrict__ soa, int64_t npad, int64_t n, const WayHot*
     const int slot = blockIdx.x * TO_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
     float x[P], y[P], z[P], gn[P];
-    load_points<P>(soa, npad, base, x, y, z);
+    bool valid[P];
+    load_points<P>(cv.soa, cv.npad, base, x, y, z);
     // dL/d reward_n: a caller-supplied vector (general criterion), else the fused visibility loss
     const float coef = grad_rewards ? 0.f : scalars[2] * gout[0];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        const bool valid = base + i < n;
-        const float r = valid ? rewards[base + i] : 0.f;
-        const float gr = grad_rewards ? (valid ? grad_rewards[base + i] : 0.f) : coef;
-        gn[i] = valid ? gr * r * (1.0f - r) : 0.f;  // dL/d lo_sum_n; pads carry no gradient
+        const int pi = cv.perm[base + i];  // original index; -1 = pad (no gradient)
+        valid[i] = pi >= 0;
+        const float r = valid[i] ? rewards[pi] : 0.f;
+        const float gr = grad_rewards ? (valid[i] ? grad_rewards[pi] : 0.f) : coef;
+        gn[i] = valid[i] ? gr * r * (1.0f - r) : 0.f;  // dL/d lo_sum_n
     }
+    float4 tb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (CULL) tb = wave_tile_bound(cv, base);
     const int v0 = blockIdx.y * vtile;
     const int v1 = min(V, v0 + vtile);
     for (int v = v0; v < v1; ++v) {
         const WayHot h = hot[v];
+        const float M = aux[v].M;
         float acc[TO_BWD_NSUM];
 #pragma unroll
         for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
+        float* tie = ties + (int64_t)v * 32;
+        bool touched = !CULL;
+        if (CULL) {
+            if (!tile_culled(h, tb, cc.mean, h.thr, h.sthr)) {
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            float X, Y, Z, y0, y1, y2;
-            to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
-            Vis s;
-            const float p = soft_vis<PINHOLE>(cc, X, Y, Z, &s);
-            const float pp = p - h.a;
-            const float ph = pp * h.invM;
-            const bool act = (ph >= 0.5f) && (ph <= cc.clip_hi);
-            const bool valid = base + i < n;
-            const bool is_min = valid && (p == h.a) && (p > 0.f);
-            const bool is_max = valid && (pp == h.M) && (h.M > 0.f);
-            if (act || is_min || is_max) {
-                float g[3];
-                dvis_dc<PINHOLE>(cc, X, Y, Z, s, g);
-                if (act) {
-                    const float G = gn[i] * to_rcp(ph * (1.0f - ph));
-                    const float wgt = G * h.invM;
-                    acc[12] = fmaf(wgt, ph - 1.0f, acc[12]);
-                    acc[13] = fmaf(-wgt, ph, acc[13]);
-                    const float w0 = wgt * g[0], w1 = wgt * g[1], w2 = wgt * g[2];
-                    acc[0] += w0; acc[1] += w1; acc[2] += w2;
-                    acc[3] = fmaf(y0, w0, acc[3]); acc[4] = fmaf(y0, w1, acc[4]); acc[5] = fmaf(y0, w2, acc[5]);
-                    acc[6] = fmaf(y1, w0, acc[6]); acc[7] = fmaf(y1, w1, acc[7]); acc[8] = fmaf(y1, w2, acc[8]);
-                    acc[9] = fmaf(y2, w0, acc[9]); acc[10] = fmaf(y2, w1, acc[10]); acc[11] = fmaf(y2, w2, acc[11]);
-                }
-                if (is_min || is_max) {
-                    const float yy[3] = {y0, y1, y2};
-                    float* tb = ties + (int64_t)v * 32;
-                    if (is_min) {
-                        for (int k = 0; k < 3; ++k) atomicAdd(tb + k, g[k]);
-                        for (int j = 0; j < 3; ++j)
-                            for (int k = 0; k < 3; ++k) atomicAdd(tb + 3 + 3 * j + k, yy[j] * g[k]);
-                        atomicAdd(tb + 24, 1.0f);
-                    }
-                    if (is_max) {
-                        for (int k = 0; k < 3; ++k) atomicAdd(tb + 12 + k, g[k]);
-                        for (int j = 0; j < 3; ++j)
-                            for (int k = 0; k < 3; ++k) atomicAdd(tb + 15 + 3 * j + k, yy[j] * g[k]);
-                        atomicAdd(tb + 25, 1.0f);
+                for (int i = 0; i < P; ++i) {
+                    float X, Y, Z, y0, y1, y2;
+                    to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+                    if (__any(dist2_mean(X, Y, Z, cc.mean) <= h.thr)) {
+                        bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], valid[i], acc, tie);
+                        touched = true;
                     }
                 }
             }
-        }
+        } else {
 #pragma unroll
-        for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = wave_sum63(acc[k]);
+            for (int i = 0; i < P; ++i) {
+                float X, Y, Z, y0, y1, y2;
+                to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+                bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], valid[i], acc, tie);
+            }
+        }
+        if (touched) {
+#pragma unroll
+            for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = wave_sum63(acc[k]);
+        }
         if (lane == 63) {
             float4* dst = reinterpret_cast<float4*>(part + ((int64_t)v * nslots + slot) * 16);
             dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -443,7 +581,7 @@ struct TrajPlan {
     int nblk;      // point blocks
     int nslots;    // wave slots = nblk * 4
     int V;
-    size_t off_hot, off_cold, off_mm, off_rpart, off_bpart, off_ties, off_vgrad, total;
+    size_t off_hot, off_cold, off_aux, off_mm, off_rpart, off_bpart, off_ties, off_vgrad, total;
 };
 
 inline int choose_P(int64_t n) { return n >= (int64_t)512 * 1024 ? 4 : (n >= (int64_t)128 * 1024 ? 2 : 1); }
@@ -458,10 +596,11 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W) {
     // sized for the smallest P (most slots) so that the plan is a pure function of (n, V)
     const size_t max_slots = (size_t)(p.npad / TO_WAVE);
     size_t o = 0;
+    p.off_rpart = o; o += align_up((size_t)4096 * sizeof(double), 256);  // first: tohip_traj_reward uses only this
     p.off_hot = o;   o += align_up((size_t)V * sizeof(WayHot), 256);
     p.off_cold = o;  o += align_up((size_t)W * sizeof(WayCold), 256);
+    p.off_aux = o;   o += align_up((size_t)V * sizeof(WayAux), 256);
     p.off_mm = o;    o += align_up((size_t)V * max_slots * sizeof(float2), 256);
-    p.off_rpart = o; o += align_up((size_t)4096 * sizeof(double), 256);
     p.off_bpart = o; o += align_up((size_t)V * max_slots * 16 * sizeof(float), 256);
     p.off_ties = o;  o += align_up((size_t)V * 32 * sizeof(float), 256);
     p.off_vgrad = o; o += align_up((size_t)V * 12 * sizeof(float), 256);
@@ -480,10 +619,14 @@ inline void choose_tiles(int nblk, int V, int* vtile, int* ntiles) {
 }
 
 template <typename F>
-inline void dispatch(int P, bool pinhole, F&& f) {
-    if (P == 4) { if (pinhole) f(std::integral_constant<int, 4>(), std::true_type()); else f(std::integral_constant<int, 4>(), std::false_type()); }
-    else if (P == 2) { if (pinhole) f(std::integral_constant<int, 2>(), std::true_type()); else f(std::integral_constant<int, 2>(), std::false_type()); }
-    else { if (pinhole) f(std::integral_constant<int, 1>(), std::true_type()); else f(std::integral_constant<int, 1>(), std::false_type()); }
+inline void dispatch(int P, bool pinhole, bool cull, F&& f) {
+    auto with_p = [&](auto Pc) {
+        if (pinhole) { if (cull) f(Pc, std::true_type(), std::true_type()); else f(Pc, std::true_type(), std::false_type()); }
+        else { if (cull) f(Pc, std::false_type(), std::true_type()); else f(Pc, std::false_type(), std::false_type()); }
+    };
+    if (P == 4) with_p(std::integral_constant<int, 4>());
+    else if (P == 2) with_p(std::integral_constant<int, 2>());
+    else with_p(std::integral_constant<int, 1>());
 }
 
 inline int rig_cams(const tohip_rig* rig) { return (rig && rig->n_cams > 0 && rig->rig_quats) ? rig->n_cams : 1; }
@@ -495,10 +638,10 @@ extern "C" size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual
     return make_plan(n_points, n_virtual, n_virtual).total;
 }
 
-extern "C" int tohip_traj_forward(const float* soa, int64_t n, const float* poses, const float* quats, int64_t W,
-                                  const tohip_camera* cam, const tohip_rig* rig, float* lo_sum, float* minmax,
+extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
+                                  const tohip_camera* cam, const tohip_rig* rig, int flags, float* lo_sum, float* minmax,
                                   void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!soa || !poses || !quats || !cam || !lo_sum || !minmax || !workspace || n <= 0 || W <= 0) return TOHIP_EINVAL;
+    if (!packed || !poses || !quats || !cam || !lo_sum || !minmax || !workspace || n <= 0 || W <= 0) return TOHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
     const int C = rig_cams(rig);
     const int64_t V = W * C;
@@ -508,73 +651,83 @@ extern "C" int tohip_traj_forward(const float* soa, int64_t n, const float* pose
     char* ws = (char*)workspace;
     WayHot* hot = (WayHot*)(ws + pl.off_hot);
     WayCold* cold = (WayCold*)(ws + pl.off_cold);
+    WayAux* aux = (WayAux*)(ws + pl.off_aux);
     float2* mm = (float2*)(ws + pl.off_mm);
     const CamConsts cc = make_consts(cam);
+    const CloudView cv = cloud_view(packed, n);
+    const bool cull = !(flags & TOHIP_TRAJ_DENSE);
     const float* rq = (C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
     const float* rt = rq ? rig->rig_trans : nullptr;
 
     {
         TO_PROF(TOHIP_PROF_SMALL, st);
-        k_prep_waycams<<<(int)((V + 127) / 128), 128, 0, st>>>(poses, quats, (int)W, C, rq, rt, hot, cold);
+        k_prep_waycams<<<(int)((V + 127) / 128), 128, 0, st>>>(poses, quats, (int)W, C, rq, rt, hot, cold, aux);
+        TO_HIP_CHECK_LAUNCH();
+        if (cull) {
+            int step = (int)(n / 4096);
+            if (step < 1) step = 1;
+            if (cc.pinhole) k_traj_probe<true><<<(int)V, TO_BLOCK, 0, st>>>(cv, hot, aux, cc, step);
+            else k_traj_probe<false><<<(int)V, TO_BLOCK, 0, st>>>(cv, hot, aux, cc, step);
+            TO_HIP_CHECK_LAUNCH();
+        }
     }
-    TO_HIP_CHECK_LAUNCH();
     int vtile, ntiles;
     choose_tiles(pl.nblk, (int)V, &vtile, &ntiles);
     {
         TO_PROF(TOHIP_PROF_PASS1, st);
-        dispatch(pl.P, cc.pinhole != 0, [&](auto Pc, auto Ph) {
-            k_traj_pass1<decltype(Pc)::value, decltype(Ph)::value><<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(
-                soa, pl.npad, hot, (int)V, vtile, cc, mm, pl.nslots);
+        dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
+            k_traj_pass1<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value>
+                <<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(cv, hot, aux, (int)V, vtile, cc, mm, pl.nslots);
         });
     }
     TO_HIP_CHECK_LAUNCH();
     {
         TO_PROF(TOHIP_PROF_SMALL, st);
-        k_minmax_finish<<<(int)V, TO_BLOCK, 0, st>>>(mm, pl.nslots, hot, minmax);
+        k_minmax_finish<<<(int)V, TO_BLOCK, 0, st>>>(mm, pl.nslots, hot, aux, cc.inv_var, cull ? 1 : 0, minmax);
     }
     TO_HIP_CHECK_LAUNCH();
     TO_PROF(TOHIP_PROF_PASS2, st);
     if (ntiles > 1) {
         hipError_t e = hipMemsetAsync(lo_sum, 0, sizeof(float) * (size_t)pl.npad, st);
         if (e != hipSuccess) return (int)e;
-        dispatch(pl.P, cc.pinhole != 0, [&](auto Pc, auto Ph) {
-            k_traj_pass2<decltype(Pc)::value, decltype(Ph)::value, true><<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(
-                soa, pl.npad, hot, (int)V, vtile, cc, lo_sum);
+        dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
+            k_traj_pass2<decltype(Pc)::value, decltype(Ph)::value, true, decltype(Cu)::value>
+                <<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(cv, hot, (int)V, vtile, cc, lo_sum);
         });
     } else {
-        dispatch(pl.P, cc.pinhole != 0, [&](auto Pc, auto Ph) {
-            k_traj_pass2<decltype(Pc)::value, decltype(Ph)::value, false><<<dim3(pl.nblk, 1), TO_BLOCK, 0, st>>>(
-                soa, pl.npad, hot, (int)V, (int)V, cc, lo_sum);
+        dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
+            k_traj_pass2<decltype(Pc)::value, decltype(Ph)::value, false, decltype(Cu)::value>
+                <<<dim3(pl.nblk, 1), TO_BLOCK, 0, st>>>(cv, hot, (int)V, (int)V, cc, lo_sum);
         });
     }
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
 
-extern "C" int tohip_traj_reward(const float* lo_sum, int64_t n, float eps, float* rewards, float* scalars,
-                                 void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!lo_sum || !rewards || !scalars || !workspace || n <= 0) return TOHIP_EINVAL;
+extern "C" int tohip_traj_reward(const void* packed, const float* lo_sum, int64_t n, float eps, float* rewards,
+                                 float* scalars, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!packed || !lo_sum || !rewards || !scalars || !workspace || n <= 0) return TOHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
-    const TrajPlan pl = make_plan(n, 1, 1);
-    if (workspace_bytes < pl.off_rpart + 4096 * sizeof(double)) return TOHIP_ENOSPC;
-    double* rpart = (double*)((char*)workspace + pl.off_rpart);
+    if (workspace_bytes < 4096 * sizeof(double)) return TOHIP_ENOSPC;
+    double* rpart = (double*)workspace;  // TrajPlan::off_rpart == 0
+    const CloudView cv = cloud_view(packed, n);
     int nb = (int)((n + TO_BLOCK - 1) / TO_BLOCK);
     if (nb > 2048) nb = 2048;
     TO_PROF(TOHIP_PROF_REWARD, st);
-    k_reward<<<nb, TO_BLOCK, 0, st>>>(lo_sum, n, rewards, rpart);
+    k_reward<<<nb, TO_BLOCK, 0, st>>>(lo_sum, cv.perm, n, rewards, rpart);
     TO_HIP_CHECK_LAUNCH();
     k_reward_finish<<<1, TO_BLOCK, 0, st>>>(rpart, nb, n, eps, scalars);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
 
-extern "C" int tohip_traj_backward(const float* soa, int64_t n, const float* poses, const float* quats, int64_t W,
-                                   const tohip_camera* cam, const tohip_rig* rig, const float* rewards,
+extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
+                                   const tohip_camera* cam, const tohip_rig* rig, int flags, const float* rewards,
                                    const float* grad_rewards, const float* scalars, const float* minmax,
                                    const float* gout, float* poses_grad, float* quats_grad, void* workspace,
                                    size_t workspace_bytes, void* stream_) {
-    if (!soa || !poses || !quats || !cam || !rewards || !minmax || !poses_grad || !quats_grad || !workspace || n <= 0 ||
-        W <= 0 || (!grad_rewards && (!scalars || !gout)))
+    if (!packed || !poses || !quats || !cam || !rewards || !minmax || !poses_grad || !quats_grad || !workspace ||
+        n <= 0 || W <= 0 || (!grad_rewards && (!scalars || !gout)))
         return TOHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
     const int C = rig_cams(rig);
@@ -584,27 +737,34 @@ extern "C" int tohip_traj_backward(const float* soa, int64_t n, const float* pos
     char* ws = (char*)workspace;
     WayHot* hot = (WayHot*)(ws + pl.off_hot);
     WayCold* cold = (WayCold*)(ws + pl.off_cold);
+    WayAux* aux = (WayAux*)(ws + pl.off_aux);
     float* bpart = (float*)(ws + pl.off_bpart);
     float* ties = (float*)(ws + pl.off_ties);
     float* vgrad = (float*)(ws + pl.off_vgrad);
     const CamConsts cc = make_consts(cam);
+    const CloudView cv = cloud_view(packed, n);
+    const bool cull = !(flags & TOHIP_TRAJ_DENSE);
     const float* rq = (C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
     const float* rt = rq ? rig->rig_trans : nullptr;
 
-    // the workspace may have been reused since the forward: rebuild the waypoint records
-    k_prep_waycams<<<(int)((V + 127) / 128), 128, 0, st>>>(poses, quats, (int)W, C, rq, rt, hot, cold);
-    TO_HIP_CHECK_LAUNCH();
-    k_set_minmax<<<(int)((V + 127) / 128), 128, 0, st>>>(hot, minmax, (int)V);
-    TO_HIP_CHECK_LAUNCH();
-    hipError_t e = hipMemsetAsync(ties, 0, sizeof(float) * 32 * (size_t)V, st);
-    if (e != hipSuccess) return (int)e;
+    {
+        // the workspace may have been reused since the forward: rebuild the waypoint records
+        TO_PROF(TOHIP_PROF_SMALL, st);
+        k_prep_waycams<<<(int)((V + 127) / 128), 128, 0, st>>>(poses, quats, (int)W, C, rq, rt, hot, cold, aux);
+        TO_HIP_CHECK_LAUNCH();
+        k_set_minmax<<<(int)((V + 127) / 128), 128, 0, st>>>(hot, aux, minmax, (int)V, cc.inv_var, cull ? 1 : 0);
+        TO_HIP_CHECK_LAUNCH();
+        hipError_t e = hipMemsetAsync(ties, 0, sizeof(float) * 32 * (size_t)V, st);
+        if (e != hipSuccess) return (int)e;
+    }
     int vtile, ntiles;
     choose_tiles(pl.nblk, (int)V, &vtile, &ntiles);
     {
         TO_PROF(TOHIP_PROF_BWD, st);
-        dispatch(pl.P, cc.pinhole != 0, [&](auto Pc, auto Ph) {
-            k_traj_bwd<decltype(Pc)::value, decltype(Ph)::value><<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(
-                soa, pl.npad, n, hot, (int)V, vtile, cc, rewards, grad_rewards, scalars, gout, bpart, pl.nslots, ties);
+        dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
+            k_traj_bwd<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value>
+                <<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(cv, hot, aux, (int)V, vtile, cc, rewards, grad_rewards,
+                                                             scalars, gout, bpart, pl.nslots, ties);
         });
     }
     TO_HIP_CHECK_LAUNCH();

@@ -104,14 +104,14 @@ class _TrajRewards(torch.autograd.Function):
         lo, hi = sh.bounds(p.shape[0])
         ps, qs = p[lo:hi].contiguous(), q[lo:hi].contiguous()
         if hi > lo:
-            lo_sum, minmax = ops.traj_forward(model._cloud, ps, qs, model._cam, model._workspace(hi - lo), model._rig)
+            lo_sum, minmax = ops.traj_forward(model._cloud, ps, qs, model._cam, model._workspace(hi - lo), model._rig,
+                                              flags=model._flags)
         else:
             lo_sum, minmax = torch.zeros(model._cloud.npad, device=p.device), None
         lo_sum = sh.allreduce_sum(lo_sum)
         rewards, _ = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)))
         ctx.model, ctx.range, ctx.n_wps = model, (lo, hi), p.shape[0]
         ctx.save_for_backward(ps, qs, rewards, minmax if minmax is not None else torch.empty(0, device=p.device))
-        model.lo_sum = lo_sum[:model._cloud.n]
         return rewards
 
     @staticmethod
@@ -124,7 +124,7 @@ class _TrajRewards(torch.autograd.Function):
         if hi > lo:
             g = grad_rewards.to(torch.float32).contiguous()
             pg[lo:hi], qg[lo:hi] = ops.traj_backward(m._cloud, ps, qs, m._cam, m._workspace(hi - lo), rewards, minmax,
-                                                     grad_rewards=g, rig=m._rig)
+                                                     grad_rewards=g, rig=m._rig, flags=m._flags)
         pg = m._shard.allreduce_sum(pg)
         qg = m._shard.allreduce_sum(qg)
         return pg, qg, None
@@ -213,7 +213,8 @@ class ModelTraj(nn.Module):
 
     Extra keyword arguments (absent from the reference): `rig=(quats (C,4), trans (C,3))` evaluates a rigid
     multi-camera rig at every waypoint; `shard=` a trajectory_optimization_amd.distributed.WaypointShard
-    placing the waypoints over the ranks of a process group (one process per GPU, RCCL).
+    placing the waypoints over the ranks of a process group (one process per GPU, RCCL); `dense=True`
+    evaluates every (point, waypoint) pair instead of skipping the pairs that provably contribute nothing.
     """
 
     def __init__(self,
@@ -225,7 +226,7 @@ class ModelTraj(nn.Module):
                  min_dist=1.0, max_dist=5.0,
                  smoothness_weight=14.0, traj_length_weight=0.02,
                  device=torch.device('cuda'),
-                 *, rig=None, shard=None):
+                 *, rig=None, shard=None, dense=False):
         super().__init__()
         assert wps_poses.dim() == wps_quats.dim()
         assert wps_poses.size()[1] == 3
@@ -260,6 +261,7 @@ class ModelTraj(nn.Module):
         self._cam = ops.Camera(self.K, self.img_width, self.img_height, min_dist, max_dist, self.eps)
         self._rig = ops.CameraRig(rig[0], rig[1], self.device) if rig is not None else None
         self._shard = shard if shard is not None else _NoShard()
+        self._flags = ops.DENSE if dense else 0  # dense: evaluate every pair (results are bitwise the same)
         self._ws_cache = {}
         self._wps_step_cache = {}
         self._length0 = None

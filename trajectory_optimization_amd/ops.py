@@ -25,17 +25,24 @@ class PackedCloud:
     """The cloud in the kernels' layout (x|y|z, padded); built once per model (the cloud is constant over
     an optimisation run: /root/reference/src/model.py:80,174)."""
 
-    def __init__(self, points):
+    def __init__(self, points, sort=True):
         _require_cuda(points, "points")
         pts = points.detach().to(torch.float32).contiguous()
         if pts.dim() != 2 or pts.shape[1] != 3 or pts.shape[0] == 0:
             raise ValueError(f"points must be (N,3) with N>0, got {tuple(pts.shape)}")
+        L = _lib.lib()
         self.n = pts.shape[0]
-        self.npad = _lib.lib().tohip_padded_points(self.n)
+        self.npad = L.tohip_padded_points(self.n)
         self.device = pts.device
-        self.soa = torch.empty(3 * self.npad, dtype=torch.float32, device=pts.device)
+        self.blob = torch.empty(L.tohip_packed_cloud_bytes(self.n), dtype=torch.uint8, device=pts.device)
+        wsb = L.tohip_pack_workspace_bytes(self.n)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=pts.device)
         with torch.cuda.device(pts.device):
-            check(_lib.lib().tohip_pack_cloud(ptr(pts), self.n, ptr(self.soa), stream_ptr()), "tohip_pack_cloud")
+            check(L.tohip_pack_cloud(ptr(pts), self.n, int(bool(sort)), ptr(self.blob), ptr(ws), wsb, stream_ptr()),
+                  "tohip_pack_cloud")
+        # views into the blob (for tests / debugging): sorted x|y|z and the permutation to the caller's order
+        self.soa = self.blob[:12 * self.npad].view(torch.float32)
+        self.perm = self.blob[12 * self.npad:16 * self.npad].view(torch.int32)
 
 
 class Camera:
@@ -73,15 +80,18 @@ class TrajWorkspace:
         self.n_virtual = n_virtual
 
 
-def traj_forward(cloud, poses, quats, cam, ws, rig=None):
-    """-> (lo_sum[npad] (first N valid), minmax[V,2]) for the given waypoints (this rank's shard)."""
+DENSE = 1  # TOHIP_TRAJ_DENSE
+
+
+def traj_forward(cloud, poses, quats, cam, ws, rig=None, flags=0):
+    """-> (lo_sum[npad] in packed order (first N valid), minmax[V,2]) for the given waypoints (this rank's shard)."""
     W = poses.shape[0]
     C = rig.n_cams if rig is not None else 1
     lo_sum = torch.empty(cloud.npad, dtype=torch.float32, device=cloud.device)
     minmax = torch.empty((W * C, 2), dtype=torch.float32, device=cloud.device)
     with torch.cuda.device(cloud.device):
-        check(_lib.lib().tohip_traj_forward(ptr(cloud.soa), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
-                                            rig.ref() if rig is not None else _NULL_RIG, ptr(lo_sum), ptr(minmax),
+        check(_lib.lib().tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
+                                            rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(lo_sum), ptr(minmax),
                                             ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_forward")
     return lo_sum, minmax
 
@@ -91,18 +101,19 @@ def traj_reward(cloud, lo_sum, cam, ws):
     rewards = torch.empty(cloud.n, dtype=torch.float32, device=cloud.device)
     scalars = torch.zeros(4, dtype=torch.float32, device=cloud.device)
     with torch.cuda.device(cloud.device):
-        check(_lib.lib().tohip_traj_reward(ptr(lo_sum), cloud.n, cam.eps, ptr(rewards), ptr(scalars), ptr(ws.buf),
+        check(_lib.lib().tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, ptr(rewards), ptr(scalars), ptr(ws.buf),
                                            ws.bytes, stream_ptr()), "tohip_traj_reward")
     return rewards, scalars
 
 
-def traj_backward(cloud, poses, quats, cam, ws, rewards, minmax, grad_rewards=None, scalars=None, gout=None, rig=None):
+def traj_backward(cloud, poses, quats, cam, ws, rewards, minmax, grad_rewards=None, scalars=None, gout=None, rig=None,
+                  flags=0):
     W = poses.shape[0]
     pg = torch.empty((W, 3), dtype=torch.float32, device=cloud.device)
     qg = torch.empty((W, 4), dtype=torch.float32, device=cloud.device)
     with torch.cuda.device(cloud.device):
-        check(_lib.lib().tohip_traj_backward(ptr(cloud.soa), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
-                                             rig.ref() if rig is not None else _NULL_RIG, ptr(rewards),
+        check(_lib.lib().tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
+                                             rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(rewards),
                                              ptr(grad_rewards), ptr(scalars), ptr(minmax), ptr(gout), ptr(pg), ptr(qg),
                                              ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_backward")
     return pg, qg
@@ -118,7 +129,7 @@ def pose_forward(cloud, trans, quat, cam, ws, mask=None):
     obs = torch.empty(cloud.n, dtype=torch.float32, device=cloud.device)
     scalars = torch.zeros(4, dtype=torch.float32, device=cloud.device)
     with torch.cuda.device(cloud.device):
-        check(_lib.lib().tohip_pose_forward(ptr(cloud.soa), cloud.n, ptr(trans), ptr(quat), cam.ref(), ptr(mask),
+        check(_lib.lib().tohip_pose_forward(ptr(cloud.blob), cloud.n, ptr(trans), ptr(quat), cam.ref(), ptr(mask),
                                             ptr(obs), ptr(scalars), ptr(ws.buf), ws.bytes, stream_ptr()),
               "tohip_pose_forward")
     return obs, scalars
@@ -128,7 +139,7 @@ def pose_backward(cloud, trans, quat, cam, ws, mask=None, grad_obs=None, scalars
     tg = torch.empty((1, 3), dtype=torch.float32, device=cloud.device)
     qg = torch.empty((1, 4), dtype=torch.float32, device=cloud.device)
     with torch.cuda.device(cloud.device):
-        check(_lib.lib().tohip_pose_backward(ptr(cloud.soa), cloud.n, ptr(trans), ptr(quat), cam.ref(), ptr(mask),
+        check(_lib.lib().tohip_pose_backward(ptr(cloud.blob), cloud.n, ptr(trans), ptr(quat), cam.ref(), ptr(mask),
                                              ptr(grad_obs), ptr(scalars), ptr(gout), ptr(tg), ptr(qg), ptr(ws.buf),
                                              ws.bytes, stream_ptr()), "tohip_pose_backward")
     return tg, qg
