@@ -55,8 +55,10 @@ k_morton(const float* __restrict__ xyz, int64_t n, const unsigned* __restrict__ 
          int* __restrict__ vals) {
     const float lo[3] = {fkey_inv(bbox[0]), fkey_inv(bbox[1]), fkey_inv(bbox[2])};
     const float hi[3] = {fkey_inv(bbox[3]), fkey_inv(bbox[4]), fkey_inv(bbox[5])};
+    // one cell size for all axes (cubic cells: compact tiles), set by the longest side of the box
+    const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
     float sc[3];
-    for (int k = 0; k < 3; ++k) sc[k] = hi[k] > lo[k] ? 1023.0f / (hi[k] - lo[k]) : 0.f;
+    for (int k = 0; k < 3; ++k) sc[k] = ext > 0.f ? 1023.0f / ext : 0.f;
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
         unsigned q[3];

@@ -124,6 +124,35 @@ __device__ __forceinline__ bool tile_culled(const WayHot& h, const float4& tb, f
     return __builtin_amdgcn_readfirstlane((int)(D2 > bound)) != 0;
 }
 
+// The same test for 64 waypoints at once: lane l tests waypoint vc + l against the wave's tile and the
+// ballot is the set of waypoints whose active sphere may reach the tile.  FROM_AUX: pass-1 bound (thr1)
+// and "min proven zero" flag from the probe; waypoints without the proof always survive (dense search).
+template <bool FROM_AUX>
+__device__ __forceinline__ unsigned long long tile_survivors(const WayHot* __restrict__ hot, const WayAux* __restrict__ aux,
+                                                             int vc, int v1, const float4& tb, float mean) {
+    const int v = vc + (int)(threadIdx.x & 63);
+    bool ok = false;
+    if (v < v1) {
+        const float4* hp = reinterpret_cast<const float4*>(hot + v);
+        const float4 q0 = hp[0], q1 = hp[1], q2 = hp[2], q3 = hp[3];  // m0..3 | m4..7 | m8 t0 t1 t2 | a invM thr sthr
+        float thr = q3.z, sthr = q3.w;
+        bool force = false;
+        if (FROM_AUX) {
+            const WayAux a = aux[v];
+            thr = a.thr1; sthr = a.sthr1;
+            force = a.azero == 0.f;
+        }
+        const float y0 = tb.x - q2.y, y1 = tb.y - q2.z, y2 = tb.z - q2.w;
+        const float X = fmaf(q0.z, y2, fmaf(q0.y, y1, q0.x * y0));
+        const float Y = fmaf(q1.y, y2, fmaf(q1.x, y1, q0.w * y0));
+        const float Z = fmaf(q2.x, y2, fmaf(q1.w, y1, q1.z * y0));
+        const float D2 = dist2_mean(X, Y, Z, mean);
+        const float bound = fmaf(tb.w, fmaf(2.0f, sthr, tb.w), thr) * 1.00001f;
+        ok = force || !(D2 > bound);
+    }
+    return __ballot(ok);
+}
+
 // ---------------------------------------------------------------------------------------------
 // probe (CULL mode): block per virtual waypoint evaluates a strided sample of the sorted cloud.
 //   L     = max p over the sample  (a lower bound of the true max: an actual value of p)
@@ -164,6 +193,19 @@ k_traj_probe(CloudView cv, const WayHot* __restrict__ hot, WayAux* __restrict__ 
 // pass 1: per-waypoint min / max of p over the cloud.  grid = (point blocks, waypoint tiles).
 // part[v * nslots + slot] = (min, max) over the 64*P points of one wave.
 
+template <int P, bool PINHOLE>
+__device__ __forceinline__ void pass1_dense_wp(const CamConsts& cc, const WayHot& h, const float (&x)[P], const float (&y)[P],
+                                               const float (&z)[P], float& mn, float& mx) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        float X, Y, Z, y0, y1, y2;
+        to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+        const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
+        mn = fminf(mn, p);
+        mx = fmaxf(mx, p);
+    }
+}
+
 template <int P, bool PINHOLE, bool CULL>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_pass1(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restrict__ aux, int V, int vtile,
@@ -173,50 +215,45 @@ k_traj_pass1(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restr
     const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
     float x[P], y[P], z[P];
     load_points<P>(cv.soa, cv.npad, base, x, y, z);
-    float4 tb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (CULL) tb = wave_tile_bound(cv, base);
     const int v0 = blockIdx.y * vtile;
     const int v1 = min(V, v0 + vtile);
-    for (int v = v0; v < v1; ++v) {
-        const WayHot h = hot[v];
-        float mn = INFINITY, mx = -INFINITY;
-        bool culled_mode = false;
-        if (CULL) {
-            const WayAux a = aux[v];
-            culled_mode = a.azero != 0.f;
-            if (culled_mode) {
-                mn = 0.f;  // proven by the probe; only the max is searched, among points that can reach L
-                bool touched = false;
-                if (!tile_culled(h, tb, cc.mean, a.thr1, a.sthr1)) {
-#pragma unroll
-                    for (int i = 0; i < P; ++i) {
-                        float X, Y, Z, y0, y1, y2;
-                        to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
-                        if (__any(dist2_mean(X, Y, Z, cc.mean) <= a.thr1)) {
-                            mx = fmaxf(mx, soft_vis<PINHOLE>(cc, X, Y, Z, nullptr));
-                            touched = true;
-                        }
-                    }
-                }
-                if (!touched) {  // wave-uniform: nothing here can beat L
-                    if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(0.f, -INFINITY);
-                    continue;
-                }
-            }
-        }
-        if (!culled_mode) {
-#pragma unroll
-            for (int i = 0; i < P; ++i) {
-                float X, Y, Z, y0, y1, y2;
-                to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
-                const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
-                mn = fminf(mn, p);
-                mx = fmaxf(mx, p);
-            }
+    if (!CULL) {
+        for (int v = v0; v < v1; ++v) {
+            const WayHot h = hot[v];
+            float mn = INFINITY, mx = -INFINITY;
+            pass1_dense_wp<P, PINHOLE>(cc, h, x, y, z, mn, mx);
             mn = wave_min63(mn);
+            mx = wave_max63(mx);
+            if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
         }
-        mx = wave_max63(mx);
-        if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
+        return;
+    }
+    const float4 tb = wave_tile_bound(cv, base);
+    for (int vc = v0; vc < v1; vc += 64) {
+        unsigned long long live = tile_survivors<true>(hot, aux, vc, v1, tb, cc.mean);
+        // waypoints whose max cannot be beaten from this tile: min is the proven 0, max unknown (-inf)
+        if (vc + lane < v1 && !((live >> lane) & 1ull)) part[(int64_t)(vc + lane) * nslots + slot] = make_float2(0.f, -INFINITY);
+        while (live) {
+            const int v = vc + __builtin_ctzll(live);
+            live &= live - 1ull;
+            const WayHot h = hot[v];
+            const WayAux a = aux[v];
+            float mn = INFINITY, mx = -INFINITY;
+            if (a.azero != 0.f) {
+                mn = 0.f;  // proven by the probe; only the max is searched, among points that can reach L
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    float X, Y, Z, y0, y1, y2;
+                    to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+                    if (__any(dist2_mean(X, Y, Z, cc.mean) <= a.thr1)) mx = fmaxf(mx, soft_vis<PINHOLE>(cc, X, Y, Z, nullptr));
+                }
+            } else {
+                pass1_dense_wp<P, PINHOLE>(cc, h, x, y, z, mn, mx);
+                mn = wave_min63(mn);
+            }
+            mx = wave_max63(mx);
+            if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
+        }
     }
 }
 
@@ -282,32 +319,38 @@ __device__ __forceinline__ float log_odds(const CamConsts& cc, const WayHot& h, 
     return (to_log2(ph) - to_log2(1.0f - ph)) * 0.693147180559945f;
 }
 
-template <int P, bool PINHOLE, bool ATOMIC, bool CULL>
+template <int P, bool PINHOLE, bool CULL>
 __global__ void __launch_bounds__(TO_BLOCK)
-k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, int vtile, CamConsts cc, float* __restrict__ lo_sum) {
+k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, float* __restrict__ lo_sum) {
     const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
     float x[P], y[P], z[P], acc[P];
     load_points<P>(cv.soa, cv.npad, base, x, y, z);
 #pragma unroll
     for (int i = 0; i < P; ++i) acc[i] = 0.f;
-    float4 tb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (CULL) tb = wave_tile_bound(cv, base);
-    const int v0 = blockIdx.y * vtile;
-    const int v1 = min(V, v0 + vtile);
     bool degenerate = false;  // M == 0: the reference divides 0/0 -> NaN for every point (model.py:227)
-    for (int v = v0; v < v1; ++v) {
-        const WayHot h = hot[v];
-        degenerate |= !(h.invM < INFINITY);
-        if (CULL) {
-            if (tile_culled(h, tb, cc.mean, h.thr, h.sthr)) continue;
+    if (CULL) {
+        const float4 tb = wave_tile_bound(cv, base);
+        for (int vc = 0; vc < V; vc += 64) {
+            const int vl = vc + (int)(threadIdx.x & 63);
+            degenerate |= __any(vl < V && !(hot[min(vl, V - 1)].invM < INFINITY));
+            unsigned long long live = tile_survivors<false>(hot, nullptr, vc, V, tb, cc.mean);
+            while (live) {  // ascending waypoint order: the same summation order as the dense loop
+                const int v = vc + __builtin_ctzll(live);
+                live &= live - 1ull;
+                const WayHot h = hot[v];
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-                float X, Y, Z, y0, y1, y2;
-                to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
-                // lanes beyond the bound get p_hat < 0.5 -> exactly 0, so evaluating them too changes nothing
-                if (__any(dist2_mean(X, Y, Z, cc.mean) <= h.thr)) acc[i] += log_odds<PINHOLE>(cc, h, X, Y, Z);
+                for (int i = 0; i < P; ++i) {
+                    float X, Y, Z, y0, y1, y2;
+                    to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+                    // lanes beyond the bound get p_hat < 0.5 -> exactly 0, so evaluating them too changes nothing
+                    if (__any(dist2_mean(X, Y, Z, cc.mean) <= h.thr)) acc[i] += log_odds<PINHOLE>(cc, h, X, Y, Z);
+                }
             }
-        } else {
+        }
+    } else {
+        for (int v = 0; v < V; ++v) {
+            const WayHot h = hot[v];
+            degenerate |= !(h.invM < INFINITY);
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 float X, Y, Z, y0, y1, y2;
@@ -320,14 +363,10 @@ k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, int vtile, Cam
 #pragma unroll
         for (int i = 0; i < P; ++i) acc[i] = __builtin_nanf("");
     }
-    if (ATOMIC) {
-#pragma unroll
-        for (int i = 0; i < P; ++i) atomicAdd(lo_sum + base + i, acc[i]);
-    } else {
-        if constexpr (P == 4) *reinterpret_cast<float4*>(lo_sum + base) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        else if constexpr (P == 2) *reinterpret_cast<float2*>(lo_sum + base) = make_float2(acc[0], acc[1]);
-        else lo_sum[base] = acc[0];
-    }
+    // one block column owns all waypoints of its points: a single store, fixed summation order
+    if constexpr (P == 4) *reinterpret_cast<float4*>(lo_sum + base) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    else if constexpr (P == 2) *reinterpret_cast<float2*>(lo_sum + base) = make_float2(acc[0], acc[1]);
+    else lo_sum[base] = acc[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -441,48 +480,66 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
         const float gr = grad_rewards ? (valid[i] ? grad_rewards[pi] : 0.f) : coef;
         gn[i] = valid[i] ? gr * r * (1.0f - r) : 0.f;  // dL/d lo_sum_n
     }
-    float4 tb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (CULL) tb = wave_tile_bound(cv, base);
     const int v0 = blockIdx.y * vtile;
     const int v1 = min(V, v0 + vtile);
-    for (int v = v0; v < v1; ++v) {
-        const WayHot h = hot[v];
-        const float M = aux[v].M;
-        float acc[TO_BWD_NSUM];
+    auto store = [&](int v, const float (&acc)[TO_BWD_NSUM]) {
+        float4* dst = reinterpret_cast<float4*>(part + ((int64_t)v * nslots + slot) * 16);
+        dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        dst[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+        dst[3] = make_float4(acc[12], acc[13], 0.f, 0.f);
+    };
+    if (!CULL) {
+        for (int v = v0; v < v1; ++v) {
+            const WayHot h = hot[v];
+            const float M = aux[v].M;
+            float acc[TO_BWD_NSUM];
 #pragma unroll
-        for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
-        float* tie = ties + (int64_t)v * 32;
-        bool touched = !CULL;
-        if (CULL) {
-            if (!tile_culled(h, tb, cc.mean, h.thr, h.sthr)) {
-#pragma unroll
-                for (int i = 0; i < P; ++i) {
-                    float X, Y, Z, y0, y1, y2;
-                    to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
-                    if (__any(dist2_mean(X, Y, Z, cc.mean) <= h.thr)) {
-                        bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], valid[i], acc, tie);
-                        touched = true;
-                    }
-                }
-            }
-        } else {
+            for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 float X, Y, Z, y0, y1, y2;
                 to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
-                bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], valid[i], acc, tie);
+                bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], valid[i], acc, ties + (int64_t)v * 32);
             }
-        }
-        if (touched) {
 #pragma unroll
             for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = wave_sum63(acc[k]);
+            if (lane == 63) store(v, acc);
         }
-        if (lane == 63) {
-            float4* dst = reinterpret_cast<float4*>(part + ((int64_t)v * nslots + slot) * 16);
-            dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-            dst[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
-            dst[3] = make_float4(acc[12], acc[13], 0.f, 0.f);
+        return;
+    }
+    const float4 tb = wave_tile_bound(cv, base);
+    for (int vc = v0; vc < v1; vc += 64) {
+        unsigned long long live = tile_survivors<false>(hot, nullptr, vc, v1, tb, cc.mean);
+        if (vc + lane < v1 && !((live >> lane) & 1ull)) {  // no active pair in this tile: the partial is exactly 0
+            float zero[TO_BWD_NSUM];
+#pragma unroll
+            for (int k = 0; k < TO_BWD_NSUM; ++k) zero[k] = 0.f;
+            store(vc + lane, zero);
+        }
+        while (live) {
+            const int v = vc + __builtin_ctzll(live);
+            live &= live - 1ull;
+            const WayHot h = hot[v];
+            const float M = aux[v].M;
+            float acc[TO_BWD_NSUM];
+#pragma unroll
+            for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
+            bool touched = false;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                float X, Y, Z, y0, y1, y2;
+                to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+                if (__any(dist2_mean(X, Y, Z, cc.mean) <= h.thr)) {
+                    bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], valid[i], acc, ties + (int64_t)v * 32);
+                    touched = true;
+                }
+            }
+            if (touched) {
+#pragma unroll
+                for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = wave_sum63(acc[k]);
+            }
+            if (lane == 63) store(v, acc);
         }
     }
 }
@@ -687,19 +744,10 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
     }
     TO_HIP_CHECK_LAUNCH();
     TO_PROF(TOHIP_PROF_PASS2, st);
-    if (ntiles > 1) {
-        hipError_t e = hipMemsetAsync(lo_sum, 0, sizeof(float) * (size_t)pl.npad, st);
-        if (e != hipSuccess) return (int)e;
-        dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
-            k_traj_pass2<decltype(Pc)::value, decltype(Ph)::value, true, decltype(Cu)::value>
-                <<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(cv, hot, (int)V, vtile, cc, lo_sum);
-        });
-    } else {
-        dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
-            k_traj_pass2<decltype(Pc)::value, decltype(Ph)::value, false, decltype(Cu)::value>
-                <<<dim3(pl.nblk, 1), TO_BLOCK, 0, st>>>(cv, hot, (int)V, (int)V, cc, lo_sum);
-        });
-    }
+    dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
+        k_traj_pass2<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value>
+            <<<dim3(pl.nblk, 1), TO_BLOCK, 0, st>>>(cv, hot, (int)V, cc, lo_sum);
+    });
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
