@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--wps-per-gpu", type=int, default=WPS_PER_GPU)
+    ap.add_argument("--mode", choices=["both", "dense", "culled"], default="both",
+                    help="dense = headline (every pair evaluated); culled = library default (exact skipping)")
     ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -100,7 +102,7 @@ def main():
         if shard is not None:
             shard.allreduce_sum(lo_sum)  # the one data-path collective: N floats over xGMI
         rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
-        pg, qg = ops.traj_backward(cloud, poses, quats, cam, ws, rewards, minmax, scalars=scalars, gout=gout, flags=flags)
+        pg, qg = ops.traj_backward(cloud, poses, quats, cam, ws, lo_sum, minmax, scalars=scalars, gout=gout, flags=flags)
         return scalars, pg, qg
 
     def fence():
@@ -133,9 +135,9 @@ def main():
         return dt, kern, o
 
     # headline: DENSE — every (point, waypoint) pair is evaluated, forward and backward
-    dt, kern, out = timed(ops.DENSE)
+    dt, kern, out = timed(ops.DENSE if args.mode != "culled" else 0)
     # the library's default path: exact culling (bitwise identical outputs, tests/test_hip_traj.py)
-    dt_c, kern_c, out_c = timed(0)
+    dt_c, kern_c, out_c = timed(0) if args.mode == "both" else (dt, kern, out)
     evals_per_step = args.points * w_total
     value = evals_per_step * args.steps / dt
 

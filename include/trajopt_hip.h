@@ -98,12 +98,13 @@ int tohip_traj_forward(const void *packed, int64_t n_points, const float *poses,
 int tohip_traj_reward(const void *packed, const float *lo_sum, int64_t n_points, float eps, float *rewards,
                       float *scalars, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Backward w.r.t. this rank's waypoints: poses_grad (W,3), quats_grad (W,4).  minmax from the forward.
+/* Backward w.r.t. this rank's waypoints: poses_grad (W,3), quats_grad (W,4).  minmax from the forward;
+ * lo_sum = the (all-reduced) log-odds vector in packed order that tohip_traj_reward turned into rewards.
  * The upstream gradient is either grad_rewards (N floats in the caller's order, dL/d rewards: any
  * criterion built on model.rewards, as torch autograd would hand it over), or, when grad_rewards is NULL,
  * the fused visibility loss: scalars (from tohip_traj_reward) and gout = device pointer to dL/d loss_vis. */
 int tohip_traj_backward(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
-                        const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, const float *rewards,
+                        const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, const float *lo_sum,
                         const float *grad_rewards, const float *scalars, const float *minmax, const float *gout,
                         float *poses_grad, float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
 

@@ -35,7 +35,7 @@ def _run_ops(dev, points, poses, quats, rig=None, flags=0, sort=True):
     lo_sum, minmax = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=flags)
     rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
     gout = torch.ones(1, device=dev)
-    pg, qg = ops.traj_backward(cloud, p, q, cam, ws, rewards, minmax, scalars=scalars, gout=gout, rig=rg, flags=flags)
+    pg, qg = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, scalars=scalars, gout=gout, rig=rg, flags=flags)
     torch.cuda.synchronize()
     return dict(lo_sum=lo_sum[:cloud.n].cpu().numpy(), rewards=rewards.cpu().numpy(), minmax=minmax.cpu().numpy(),
                 scalars=scalars.cpu().numpy(), pg=pg.cpu().numpy(), qg=qg.cpu().numpy())

@@ -104,6 +104,19 @@ __device__ __forceinline__ void load_points(const float* __restrict__ soa, int64
     }
 }
 
+template <int P>
+__device__ __forceinline__ void load_vec(const float* __restrict__ src, int64_t base, float (&v)[P]) {
+    if constexpr (P == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(src + base);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    } else if constexpr (P == 2) {
+        const float2 a = *reinterpret_cast<const float2*>(src + base);
+        v[0] = a.x; v[1] = a.y;
+    } else {
+        v[0] = src[base];
+    }
+}
+
 // wave-uniform bounding sphere of the 256-point tile this wave's points belong to
 __device__ __forceinline__ float4 wave_tile_bound(const CloudView& cv, int64_t base) {
     const int tile = __builtin_amdgcn_readfirstlane((int)(base >> 8));
@@ -124,6 +137,19 @@ __device__ __forceinline__ bool tile_culled(const WayHot& h, const float4& tb, f
     return __builtin_amdgcn_readfirstlane((int)(D2 > bound)) != 0;
 }
 
+// One (tile, waypoint) liveness decision, written once so that the kernels that skip a pair and the
+// finishing kernel that skips its partial agree bit for bit.  q0..q3 = the waypoint's WayHot as 4 float4.
+__device__ __forceinline__ bool tile_live(const float4& q0, const float4& q1, const float4& q2, float thr, float sthr,
+                                          const float4& tb, float mean) {
+    const float y0 = tb.x - q2.y, y1 = tb.y - q2.z, y2 = tb.z - q2.w;
+    const float X = fmaf(q0.z, y2, fmaf(q0.y, y1, q0.x * y0));
+    const float Y = fmaf(q1.y, y2, fmaf(q1.x, y1, q0.w * y0));
+    const float Z = fmaf(q2.x, y2, fmaf(q1.w, y1, q1.z * y0));
+    const float D2 = dist2_mean(X, Y, Z, mean);
+    const float bound = fmaf(tb.w, fmaf(2.0f, sthr, tb.w), thr) * 1.00001f;  // (sthr + r)^2, rounded up
+    return !(D2 > bound);
+}
+
 // The same test for 64 waypoints at once: lane l tests waypoint vc + l against the wave's tile and the
 // ballot is the set of waypoints whose active sphere may reach the tile.  FROM_AUX: pass-1 bound (thr1)
 // and "min proven zero" flag from the probe; waypoints without the proof always survive (dense search).
@@ -142,13 +168,7 @@ __device__ __forceinline__ unsigned long long tile_survivors(const WayHot* __res
             thr = a.thr1; sthr = a.sthr1;
             force = a.azero == 0.f;
         }
-        const float y0 = tb.x - q2.y, y1 = tb.y - q2.z, y2 = tb.z - q2.w;
-        const float X = fmaf(q0.z, y2, fmaf(q0.y, y1, q0.x * y0));
-        const float Y = fmaf(q1.y, y2, fmaf(q1.x, y1, q0.w * y0));
-        const float Z = fmaf(q2.x, y2, fmaf(q1.w, y1, q1.z * y0));
-        const float D2 = dist2_mean(X, Y, Z, mean);
-        const float bound = fmaf(tb.w, fmaf(2.0f, sthr, tb.w), thr) * 1.00001f;
-        ok = force || !(D2 > bound);
+        ok = force || tile_live(q0, q1, q2, thr, sthr, tb, mean);
     }
     return __ballot(ok);
 }
@@ -461,7 +481,7 @@ __device__ __forceinline__ void bwd_eval(const CamConsts& cc, const WayHot& h, f
 template <int P, bool PINHOLE, bool CULL>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restrict__ aux, int V, int vtile,
-           CamConsts cc, const float* __restrict__ rewards, const float* __restrict__ grad_rewards,
+           CamConsts cc, const float* __restrict__ lo_sum, const float* __restrict__ grad_rewards,
            const float* __restrict__ scalars, const float* __restrict__ gout, float* __restrict__ part, int nslots,
            float* __restrict__ ties) {
     const int lane = threadIdx.x & 63;
@@ -472,12 +492,17 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
     load_points<P>(cv.soa, cv.npad, base, x, y, z);
     // dL/d reward_n: a caller-supplied vector (general criterion), else the fused visibility loss
     const float coef = grad_rewards ? 0.f : scalars[2] * gout[0];
+    float lo[P];
+    load_vec<P>(lo_sum, base, lo);
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        const int pi = cv.perm[base + i];  // original index; -1 = pad (no gradient)
-        valid[i] = pi >= 0;
-        const float r = valid[i] ? rewards[pi] : 0.f;
-        const float gr = grad_rewards ? (valid[i] ? grad_rewards[pi] : 0.f) : coef;
+        valid[i] = base + i < cv.n;  // pads carry no gradient
+        const float r = to_rcp(1.0f + to_exp(-lo[i]));  // == k_reward's value of rewards[perm[base+i]]
+        float gr = coef;
+        if (grad_rewards) {
+            const int pi = cv.perm[base + i];  // the caller's index (-1 for pads)
+            gr = pi >= 0 ? grad_rewards[pi] : 0.f;
+        }
         gn[i] = valid[i] ? gr * r * (1.0f - r) : 0.f;  // dL/d lo_sum_n
     }
     const int v0 = blockIdx.y * vtile;
@@ -511,12 +536,7 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
     const float4 tb = wave_tile_bound(cv, base);
     for (int vc = v0; vc < v1; vc += 64) {
         unsigned long long live = tile_survivors<false>(hot, nullptr, vc, v1, tb, cc.mean);
-        if (vc + lane < v1 && !((live >> lane) & 1ull)) {  // no active pair in this tile: the partial is exactly 0
-            float zero[TO_BWD_NSUM];
-#pragma unroll
-            for (int k = 0; k < TO_BWD_NSUM; ++k) zero[k] = 0.f;
-            store(vc + lane, zero);
-        }
+        // (tile, waypoint) pairs that are not live write nothing: k_bwd_finish1 repeats the test and skips them
         while (live) {
             const int v = vc + __builtin_ctzll(live);
             live &= live - 1ull;
@@ -545,15 +565,25 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
 }
 
 // block per virtual waypoint: sum the wave partials (double, fixed order), add the min/max shares,
-// write vgrad[v*12 ..] = (sum dL/dc [3], sum y (x) dL/dc [9]).
+// write vgrad[v*12 ..] = (sum dL/dc [3], sum y (x) dL/dc [9]).  In CULL mode a partial exists only where the
+// (tile, waypoint) pair is live — the same predicate, on the same records, as k_traj_bwd evaluated.
 __global__ void __launch_bounds__(TO_BLOCK)
-k_bwd_finish1(const float* __restrict__ part, int nslots, const float* __restrict__ ties, float* __restrict__ vgrad) {
+k_bwd_finish1(const float* __restrict__ part, int nslots, int slots_per_tile_shift, const float* __restrict__ ties,
+              const WayHot* __restrict__ hot, const float4* __restrict__ bounds, float mean, int cull,
+              float* __restrict__ vgrad) {
     __shared__ double lds[TO_BLOCK];
     __shared__ double tot[TO_BWD_NSUM];
     const int v = blockIdx.x, t = threadIdx.x;
+    const float4* hp = reinterpret_cast<const float4*>(hot + v);
+    const float4 q0 = hp[0], q1 = hp[1], q2 = hp[2], q3 = hp[3];
     double s[TO_BWD_NSUM];
     for (int k = 0; k < TO_BWD_NSUM; ++k) s[k] = 0.0;
     for (int sl = t; sl < nslots; sl += TO_BLOCK) {
+        if (cull) {
+            // slot -> 256-point tile: P=4: slot == tile, P=2: two slots per tile, P=1: four
+            const float4 tb = bounds[sl >> slots_per_tile_shift];
+            if (!tile_live(q0, q1, q2, q3.z, q3.w, tb, mean)) continue;
+        }
         const float4* src = reinterpret_cast<const float4*>(part + ((int64_t)v * nslots + sl) * 16);
         const float4 a = src[0], b = src[1], c = src[2], d = src[3];
         s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
@@ -666,9 +696,12 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W) {
 }
 
 // waypoint tiling of the grid's y dimension: enough blocks to fill 256 CUs a few times over
-inline void choose_tiles(int nblk, int V, int* vtile, int* ntiles) {
+inline void choose_tiles(int nblk, int V, bool cull, int* vtile, int* ntiles) {
     int nt = 1;
     if (nblk < 512) nt = (1024 + nblk - 1) / nblk;
+    // culled kernels: the work sits in the few point blocks near the path; splitting their waypoint range over
+    // grid.y spreads it over more CUs (partials are per (waypoint, wave): results do not depend on the split)
+    if (cull && nt < 8) nt = 8;
     if (nt > V) nt = V;
     if (nt < 1) nt = 1;
     *vtile = (V + nt - 1) / nt;
@@ -729,7 +762,7 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
         }
     }
     int vtile, ntiles;
-    choose_tiles(pl.nblk, (int)V, &vtile, &ntiles);
+    choose_tiles(pl.nblk, (int)V, cull, &vtile, &ntiles);
     {
         TO_PROF(TOHIP_PROF_PASS1, st);
         dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
@@ -770,11 +803,11 @@ extern "C" int tohip_traj_reward(const void* packed, const float* lo_sum, int64_
 }
 
 extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
-                                   const tohip_camera* cam, const tohip_rig* rig, int flags, const float* rewards,
+                                   const tohip_camera* cam, const tohip_rig* rig, int flags, const float* lo_sum,
                                    const float* grad_rewards, const float* scalars, const float* minmax,
                                    const float* gout, float* poses_grad, float* quats_grad, void* workspace,
                                    size_t workspace_bytes, void* stream_) {
-    if (!packed || !poses || !quats || !cam || !rewards || !minmax || !poses_grad || !quats_grad || !workspace ||
+    if (!packed || !poses || !quats || !cam || !lo_sum || !minmax || !poses_grad || !quats_grad || !workspace ||
         n <= 0 || W <= 0 || (!grad_rewards && (!scalars || !gout)))
         return TOHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
@@ -806,18 +839,19 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* p
         if (e != hipSuccess) return (int)e;
     }
     int vtile, ntiles;
-    choose_tiles(pl.nblk, (int)V, &vtile, &ntiles);
+    choose_tiles(pl.nblk, (int)V, cull, &vtile, &ntiles);
     {
         TO_PROF(TOHIP_PROF_BWD, st);
         dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
             k_traj_bwd<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value>
-                <<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(cv, hot, aux, (int)V, vtile, cc, rewards, grad_rewards,
+                <<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(cv, hot, aux, (int)V, vtile, cc, lo_sum, grad_rewards,
                                                              scalars, gout, bpart, pl.nslots, ties);
         });
     }
     TO_HIP_CHECK_LAUNCH();
     TO_PROF(TOHIP_PROF_SMALL, st);
-    k_bwd_finish1<<<(int)V, TO_BLOCK, 0, st>>>(bpart, pl.nslots, ties, vgrad);
+    const int shift = pl.P == 4 ? 0 : (pl.P == 2 ? 1 : 2);
+    k_bwd_finish1<<<(int)V, TO_BLOCK, 0, st>>>(bpart, pl.nslots, shift, ties, hot, cv.bounds, cc.mean, cull ? 1 : 0, vgrad);
     TO_HIP_CHECK_LAUNCH();
     k_bwd_finish2<<<(int)((W + 63) / 64), 64, 0, st>>>(vgrad, hot, cold, (int)W, C, rq, rt, poses_grad, quats_grad);
     TO_HIP_CHECK_LAUNCH();

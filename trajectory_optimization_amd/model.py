@@ -111,19 +111,19 @@ class _TrajRewards(torch.autograd.Function):
         lo_sum = sh.allreduce_sum(lo_sum)
         rewards, _ = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)))
         ctx.model, ctx.range, ctx.n_wps = model, (lo, hi), p.shape[0]
-        ctx.save_for_backward(ps, qs, rewards, minmax if minmax is not None else torch.empty(0, device=p.device))
+        ctx.save_for_backward(ps, qs, lo_sum, minmax if minmax is not None else torch.empty(0, device=p.device))
         return rewards
 
     @staticmethod
     def backward(ctx, grad_rewards):
-        ps, qs, rewards, minmax = ctx.saved_tensors
+        ps, qs, lo_sum, minmax = ctx.saved_tensors
         m = ctx.model
         lo, hi = ctx.range
-        pg = torch.zeros((ctx.n_wps, 3), dtype=torch.float32, device=rewards.device)
-        qg = torch.zeros((ctx.n_wps, 4), dtype=torch.float32, device=rewards.device)
+        pg = torch.zeros((ctx.n_wps, 3), dtype=torch.float32, device=lo_sum.device)
+        qg = torch.zeros((ctx.n_wps, 4), dtype=torch.float32, device=lo_sum.device)
         if hi > lo:
             g = grad_rewards.to(torch.float32).contiguous()
-            pg[lo:hi], qg[lo:hi] = ops.traj_backward(m._cloud, ps, qs, m._cam, m._workspace(hi - lo), rewards, minmax,
+            pg[lo:hi], qg[lo:hi] = ops.traj_backward(m._cloud, ps, qs, m._cam, m._workspace(hi - lo), lo_sum, minmax,
                                                      grad_rewards=g, rig=m._rig, flags=m._flags)
         pg = m._shard.allreduce_sum(pg)
         qg = m._shard.allreduce_sum(qg)

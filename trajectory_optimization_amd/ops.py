@@ -106,14 +106,15 @@ def traj_reward(cloud, lo_sum, cam, ws):
     return rewards, scalars
 
 
-def traj_backward(cloud, poses, quats, cam, ws, rewards, minmax, grad_rewards=None, scalars=None, gout=None, rig=None,
+def traj_backward(cloud, poses, quats, cam, ws, lo_sum, minmax, grad_rewards=None, scalars=None, gout=None, rig=None,
                   flags=0):
+    """lo_sum: the (all-reduced) log-odds vector in packed order, as returned by traj_forward."""
     W = poses.shape[0]
     pg = torch.empty((W, 3), dtype=torch.float32, device=cloud.device)
     qg = torch.empty((W, 4), dtype=torch.float32, device=cloud.device)
     with torch.cuda.device(cloud.device):
         check(_lib.lib().tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
-                                             rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(rewards),
+                                             rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(lo_sum),
                                              ptr(grad_rewards), ptr(scalars), ptr(minmax), ptr(gout), ptr(pg), ptr(qg),
                                              ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_backward")
     return pg, qg
