@@ -120,6 +120,14 @@ __device__ __forceinline__ float to_exp(float x) {
     return fmaf(y, r * 0.693147180559945f, y);
 }
 
+// exp(x) without the correction term: relative error ~|x| * 6e-8.  Used for the depth sigmoid only, where
+// it is harmless: S = 1/(1+e) inherits e/(1+e) of it (< 4e-7 for |Z| <= 6 m, and S ~ e^Z is negligible
+// together with every other factor of p for points far behind the camera).
+__device__ __forceinline__ float to_exp_fast(float x) {
+    x = __builtin_amdgcn_fmed3f(x, -150.0f, 88.0f);
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+}
+
 __device__ __forceinline__ float to_log2(float x) { return __builtin_amdgcn_logf(x); }
 
 // Squared-distance bound thr such that  d2 > thr  =>  exp(-0.5 * d2 * inv_var) < tau * (1 - 1e-4), i.e. the
@@ -170,7 +178,7 @@ __device__ __forceinline__ float soft_vis(const CamConsts& k, float X, float Y, 
     arg = fmaf(au, au, arg);
     arg = fmaf(av, av, arg);
     const float E = to_exp(-0.5f * arg);
-    const float S = to_rcp(1.0f + to_exp(-h2));
+    const float S = to_rcp(1.0f + to_exp_fast(-h2));
     const float p = S * E;
     if (o) {
         o->p = p; o->S = S; o->u = u; o->v = v; o->rz = rz;

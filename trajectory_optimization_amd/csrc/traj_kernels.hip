@@ -20,6 +20,7 @@
 //          camera-frame point from (mu,mu,mu).  A wave first tests its 256-point bounding sphere, then the
 //          per-point d2, and only then evaluates.  The per-waypoint max is searched the same way against a
 //          lower bound L <= max found by a strided probe, which also proves min == 0 by exhibiting a zero.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -436,7 +437,7 @@ k_reward_finish(const double* __restrict__ part, int nparts, int64_t n, float ep
 #define TO_BWD_NSUM 14
 
 template <bool PINHOLE>
-__device__ __forceinline__ void bwd_eval(const CamConsts& cc, const WayHot& h, float M, float X, float Y, float Z,
+__device__ __forceinline__ bool bwd_eval(const CamConsts& cc, const WayHot& h, float M, float X, float Y, float Z,
                                          float y0, float y1, float y2, float gn, bool valid, float (&acc)[TO_BWD_NSUM],
                                          float* __restrict__ tb) {
     Vis s;
@@ -476,6 +477,7 @@ __device__ __forceinline__ void bwd_eval(const CamConsts& cc, const WayHot& h, f
             }
         }
     }
+    return act;
 }
 
 template <int P, bool PINHOLE, bool CULL>
@@ -521,14 +523,19 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
             float acc[TO_BWD_NSUM];
 #pragma unroll
             for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
+            bool any_act = false;
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 float X, Y, Z, y0, y1, y2;
                 to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
-                bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], valid[i], acc, ties + (int64_t)v * 32);
+                any_act |= bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], valid[i], acc, ties + (int64_t)v * 32);
             }
+            // every pair has been evaluated; when no lane of the wave was active all 14 sums are exact zeros
+            // and the cross-lane reduction of zeros is skipped
+            if (__any(any_act)) {
 #pragma unroll
-            for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = wave_sum63(acc[k]);
+                for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = wave_sum63(acc[k]);
+            }
             if (lane == 63) store(v, acc);
         }
         return;
@@ -671,7 +678,11 @@ struct TrajPlan {
     size_t off_hot, off_cold, off_aux, off_mm, off_rpart, off_bpart, off_ties, off_vgrad, total;
 };
 
-inline int choose_P(int64_t n) { return n >= (int64_t)512 * 1024 ? 4 : (n >= (int64_t)128 * 1024 ? 2 : 1); }
+inline int choose_P(int64_t n) {
+    static const int forced = [] { const char* e = getenv("TOHIP_FORCE_P"); return e ? atoi(e) : 0; }();  // experiments
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    return n >= (int64_t)512 * 1024 ? 4 : (n >= (int64_t)128 * 1024 ? 2 : 1);
+}
 
 inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W) {
     TrajPlan p;
