@@ -165,6 +165,25 @@ int tohip_hidden_pts_removal(const float *xyz, int64_t n_points, float param, in
 int tohip_convex_hull_vertices(const float *pts, int64_t n_points, int with_origin, int32_t *idx, int32_t *count,
                                int32_t *rounds_host, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the O(W) remainder of an optimisation step, on the device (no host sync inside a run) ---------
+ * criterion's regularisers (model.py:244-260) with analytic gradients.  loss_terms[0..4] = vis (copied from
+ * scalars[1]), l2, length, smooth, total.  grad_poses (W,3), may be NULL: the regularisers' gradient, added to
+ * the existing content when accumulate != 0 (i.e. on top of the visibility gradient). */
+int tohip_traj_regularizers(const float *poses, const float *poses0, int64_t n_wps, float smoothness_weight,
+                            float traj_length_weight, float eps, const float *scalars, float *loss_terms,
+                            float *grad_poses, int accumulate, void *stream);
+/* rows r*step of a (.., cols) array <-> a compact (n_rows, cols) array: the every-wps_step-th waypoint selection
+ * of model.py:217 (scatter = 0: gather src[r*step] -> dst[r]; 1: scatter src[r] -> dst[r*step]). */
+int tohip_rows_strided(const float *src, int64_t n_rows, int cols, int step, int scatter, float *dst, void *stream);
+/* torch.optim.Adam update of one parameter group (defaults of trajectory_optimization.py:91-94); step is the
+ * 1-based iteration; a no-op once state[2] != 0 (early stop reached).  state may be NULL. */
+int tohip_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, int32_t step, const float *state, void *stream);
+/* early-stop rule of trajectory_optimization.py:100-124 on the device.  state (8 floats, zero-initialised by
+ * the caller): [0] reward0 [1] smooth0 [2] stopped [3] steps taken [4] visibility gain [5] smoothness gain. */
+int tohip_early_stop(const float *scalars, const float *loss_terms, float rewards_th, float smoothness_th, float *state,
+                     void *stream);
+
 /* ---- optional per-kernel timing (bench.py's roofline leg) -----------------------------------------
  * When enabled, every launch of the big kernels is bracketed by hipEventRecord on its own stream.
  * tohip_profile_read synchronises on those events and returns, per kernel id < TOHIP_PROF_NKERNELS,

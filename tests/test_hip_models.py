@@ -129,3 +129,57 @@ def test_errors_like_reference(dev):
         m()
     with pytest.raises(RuntimeError):
         ModelTraj(pts, torch.from_numpy(p), torch.from_numpy(q), torch.from_numpy(K), IW, IH, device=torch.device("cpu"))
+
+
+def test_device_resident_optimizer_matches_reference_adam(dev):
+    """optimizer.optimize_trajectory (launch-only loop: HIP regularisers + Adam + early stop) vs the reference's
+    Adam trajectory on the bundled cloud/path (/root/reference/src/trajectory_optimization.py:91-116)."""
+    from trajectory_optimization_amd.optimizer import optimize_trajectory
+    d = load_golden("traj_adam_bundled")
+    d["points"] = load_golden("bundled")["pts"]
+    for k in (1, 5, 10):
+        m = _traj_model(d, dev)
+        res = optimize_trajectory(m, n_opt_steps=k, lr_pose=float(d["lr_pose"]), lr_quat=float(d["lr_quat"]),
+                                  rewards_th=1e9, smoothness_th=1e9)
+        assert res.steps_taken == k and not res.stopped
+        np.testing.assert_allclose(m.poses.detach().cpu().numpy(), d[f"poses_step{k}"], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(m.quats.detach().cpu().numpy(), d[f"quats_step{k}"], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(res.losses, d["losses"][:k], rtol=2e-3)
+
+
+def test_device_regularizers_match_torch(dev):
+    """HIP regularisers (value + analytic gradient) vs the torch criterion of the model (autograd)."""
+    from trajectory_optimization_amd import _lib
+    from trajectory_optimization_amd._lib import ptr, stream_ptr, check
+    d = load_golden("traj_bundled_tilted_all")
+    m = _traj_model(d, dev, smoothness_weight=28.0, traj_length_weight=0.05)
+    with torch.no_grad():
+        m.poses.add_(0.05 * torch.randn(m.poses.shape, generator=torch.Generator().manual_seed(3)).to(dev))
+    m.loss["vis"] = torch.zeros((), device=dev)
+    reg = m.criterion(torch.full((10,), 0.5, device=dev))  # vis = 1/(0.5+eps): constant w.r.t. poses
+    reg.backward()
+    scal = torch.tensor([0.5, 1.0 / (0.5 + 1e-6), 0, 0], device=dev)
+    lt = torch.zeros(8, device=dev)
+    g = torch.zeros_like(m.poses)
+    check(_lib.lib().tohip_traj_regularizers(ptr(m.poses.data), ptr(m.poses0), m.poses.shape[0], 28.0, 0.05, 1e-6,
+                                             ptr(scal), ptr(lt), ptr(g), 0, stream_ptr()), "regularizers")
+    torch.cuda.synchronize()
+    assert abs(lt[4].item() - reg.item()) <= 2e-5 * abs(reg.item())
+    for k, name in ((1, "l2"), (2, "length"), (3, "smooth")):
+        assert abs(lt[k].item() - float(m.loss[name])) <= 2e-5 * max(1.0, abs(float(m.loss[name])))
+    assert rel_inf(g.cpu().numpy(), m.poses.grad.cpu().numpy()) < 1e-4  # torch side is f32 arccos: 1e-5-level noise
+
+
+def test_device_early_stop_rule(dev):
+    from trajectory_optimization_amd.optimizer import optimize_trajectory
+    d = load_golden("traj_adam_bundled")
+    d["points"] = load_golden("bundled")["pts"]
+    m = _traj_model(d, dev)
+    res = optimize_trajectory(m, n_opt_steps=12, lr_pose=0.12, lr_quat=0.05, rewards_th=1.02, smoothness_th=0.0)
+    # the reference stops at the first step whose mean reward exceeds 1.02 x the initial one
+    gains = np.array(d["mean_rewards"]) / d["mean_rewards"][0]
+    first = int(np.argmax(gains > 1.02)) if (gains > 1.02).any() else None
+    if first is not None:
+        assert res.stopped and res.steps_taken == first + 1
+    else:
+        assert not res.stopped

@@ -60,6 +60,10 @@ SIGNATURES = {
     "tohip_hidden_pts_removal": (ctypes.c_int, [c_vp, c_i64, c_f, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_convex_hull_vertices": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, ctypes.POINTER(c_i32), c_vp, c_sz,
                                                    c_vp]),
+    "tohip_traj_regularizers": (ctypes.c_int, [c_vp, c_vp, c_i64, c_f, c_f, c_f, c_vp, c_vp, c_vp, ctypes.c_int, c_vp]),
+    "tohip_rows_strided": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
+    "tohip_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_i32, c_vp, c_vp]),
+    "tohip_early_stop": (ctypes.c_int, [c_vp, c_vp, c_f, c_f, c_vp, c_vp]),
     "tohip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "tohip_profile_name": (ctypes.c_char_p, [ctypes.c_int]),
     "tohip_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),

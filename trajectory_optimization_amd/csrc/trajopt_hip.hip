@@ -6,6 +6,7 @@
 #include "pose_kernels.hip"
 #include "hard_kernels.hip"
 #include "hull_kernels.hip"
+#include "optim_kernels.hip"
 
 extern "C" int tohip_abi_version(void) { return TOHIP_ABI_VERSION; }
 

@@ -1,0 +1,82 @@
+"""Device-resident optimisation loops.
+
+`optimize_trajectory` is the reference's TrajOpt.run (/root/reference/src/trajectory_optimization.py:100-127):
+Adam over (poses, quats) with two learning rates, the criterion of ModelTraj, and the early stop on visibility
+and smoothness gains — but every step is a fixed sequence of kernel launches through the C ABI (visibility
+forward/backward, regularisers + their analytic gradient, Adam, the early-stop rule), with no host
+synchronisation until the run ends: the stop flag lives on the device and turns the remaining updates into no-ops.
+
+The classes in model.py + torch.optim.Adam remain the drop-in path; this module is the launch-only fast path.
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import check, ptr, stream_ptr
+
+
+class TrajOptResult:
+    def __init__(self, steps_taken, stopped, losses, vis_gain, smooth_gain):
+        self.steps_taken, self.stopped, self.losses = steps_taken, stopped, losses
+        self.visibility_gain, self.smoothness_gain = vis_gain, smooth_gain
+
+
+@torch.no_grad()
+def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards_th=1.2, smoothness_th=0.9,
+                        vis_wps_dist=0.5, betas=(0.9, 0.999), adam_eps=1e-8):
+    """Runs up to n_opt_steps on `model` (a ModelTraj) in place; returns a TrajOptResult (one host sync, at the end).
+    model.poses / model.quats hold the optimised trajectory, model.rewards the last rewards, model.loss the last terms."""
+    L = _lib.lib()
+    dev = model.device
+    cloud, cam, rig = model._cloud, model._cam, model._rig
+    W = model.poses.shape[0]
+    step_w = model._wps_step(vis_wps_dist)
+    n_eval = (W + step_w - 1) // step_w
+    ws = model._workspace(n_eval)
+    f32 = dict(dtype=torch.float32, device=dev)
+    poses_e, quats_e = torch.empty((n_eval, 3), **f32), torch.empty((n_eval, 4), **f32)
+    pg_e, qg_e = torch.empty((n_eval, 3), **f32), torch.empty((n_eval, 4), **f32)
+    pg, qg = torch.zeros((W, 3), **f32), torch.zeros((W, 4), **f32)
+    lo_sum = torch.empty(cloud.npad, **f32)
+    minmax = torch.empty((n_eval * (rig.n_cams if rig else 1), 2), **f32)
+    rewards, scalars = torch.empty(cloud.n, **f32), torch.zeros(4, **f32)
+    loss_terms = torch.zeros((n_opt_steps, 8), **f32)
+    state = torch.zeros(8, **f32)
+    gout = torch.ones(1, **f32)
+    mp, vp = torch.zeros((W, 3), **f32), torch.zeros((W, 3), **f32)
+    mq, vq = torch.zeros((W, 4), **f32), torch.zeros((W, 4), **f32)
+    poses, quats = model.poses.data, model.quats.data
+    rig_ref = rig.ref() if rig is not None else ops._NULL_RIG
+    with torch.cuda.device(dev):
+        s = stream_ptr()
+        for it in range(n_opt_steps):
+            lt = loss_terms[it]
+            check(L.tohip_rows_strided(ptr(poses), n_eval, 3, step_w, 0, ptr(poses_e), s), "gather poses")
+            check(L.tohip_rows_strided(ptr(quats), n_eval, 4, step_w, 0, ptr(quats_e), s), "gather quats")
+            check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), n_eval, cam.ref(), rig_ref,
+                                       model._flags, ptr(lo_sum), ptr(minmax), ptr(ws.buf), ws.bytes, s), "forward")
+            model._shard.allreduce_sum(lo_sum)
+            check(L.tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, ptr(rewards), ptr(scalars),
+                                      ptr(ws.buf), ws.bytes, s), "reward")
+            check(L.tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), n_eval, cam.ref(), rig_ref,
+                                        model._flags, ptr(lo_sum), None, ptr(scalars), ptr(minmax), ptr(gout), ptr(pg_e),
+                                        ptr(qg_e), ptr(ws.buf), ws.bytes, s), "backward")
+            if step_w > 1:
+                pg.zero_()
+                qg.zero_()
+            check(L.tohip_rows_strided(ptr(pg_e), n_eval, 3, step_w, 1, ptr(pg), s), "scatter poses grad")
+            check(L.tohip_rows_strided(ptr(qg_e), n_eval, 4, step_w, 1, ptr(qg), s), "scatter quats grad")
+            check(L.tohip_traj_regularizers(ptr(poses), ptr(model.poses0), W, float(model.smoothness_weight),
+                                            float(model.traj_length_weight), float(model.eps), ptr(scalars), ptr(lt),
+                                            ptr(pg), 1, s), "regularizers")
+            check(L.tohip_adam_step(ptr(poses), ptr(pg), ptr(mp), ptr(vp), W * 3, float(lr_pose), betas[0], betas[1],
+                                    adam_eps, it + 1, ptr(state), s), "adam poses")
+            check(L.tohip_adam_step(ptr(quats), ptr(qg), ptr(mq), ptr(vq), W * 4, float(lr_quat), betas[0], betas[1],
+                                    adam_eps, it + 1, ptr(state), s), "adam quats")
+            check(L.tohip_early_stop(ptr(scalars), ptr(lt), float(rewards_th), float(smoothness_th), ptr(state), s),
+                  "early stop")
+    st = state.cpu()  # the run's only host synchronisation
+    steps = int(st[3].item())
+    lt_host = loss_terms[:max(steps, 1)].cpu()
+    model.rewards = rewards
+    model.loss = {"vis": lt_host[-1, 0], "l2": lt_host[-1, 1], "length": lt_host[-1, 2], "smooth": lt_host[-1, 3]}
+    return TrajOptResult(steps, bool(st[2].item() != 0), lt_host[:, 4].tolist(), float(st[4]), float(st[5]))
