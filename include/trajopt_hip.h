@@ -184,6 +184,27 @@ int tohip_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
 int tohip_early_stop(const float *scalars, const float *loss_terms, float rewards_th, float smoothness_th, float *state,
                      void *stream);
 
+/* ---- input formats (pointcloud_utils.py, launch/voxels_filtering.launch) --------------------------------
+ * PointCloud2 payload -> (N,3) f32 with non-finite rows removed, in message order
+ * (pointcloud2_to_xyz_array, pointcloud_utils.py:197-198, + the callers' cast to f32).  data: the message's
+ * byte buffer on the device, n_points = width*height; x/y/z_off and datatype (7 = FLOAT32, 8 = FLOAT64) from
+ * its PointFields.  out_xyz capacity n_points rows; *out_count device int32. */
+size_t tohip_ingest_workspace_bytes(int64_t n_points);
+int tohip_pointcloud2_to_xyz(const uint8_t *data, int64_t n_points, int32_t point_step, int32_t x_off, int32_t y_off,
+                             int32_t z_off, int32_t datatype, int32_t is_bigendian, int32_t remove_nans, float *out_xyz,
+                             int32_t *out_count, void *workspace, size_t workspace_bytes, void *stream);
+/* pcl::VoxelGrid as configured by launch/voxels_filtering.launch:11-21: drop non-finite points and points whose
+ * filter field (0/1/2 = x/y/z, -1 = none) lies outside [limit_min, limit_max]; one centroid per occupied voxel,
+ * voxels in ascending key order.  out_xyz capacity n rows; *out_count device int32. */
+size_t tohip_voxel_grid_workspace_bytes(int64_t n_points);
+int tohip_voxel_grid(const float *xyz, int64_t n_points, float leaf_x, float leaf_y, float leaf_z, int32_t filter_field,
+                     float limit_min, float limit_max, float *out_xyz, int32_t *out_count, void *workspace,
+                     size_t workspace_bytes, void *stream);
+/* pc_to_voxel (pointcloud_utils.py:279-288): float64 occupancy grid (nx,ny,nz), 1.0 where a point falls.
+ * pc: (n, cols>=3) f32 rows. */
+int tohip_pc_to_voxel(const float *pc, int64_t n_points, int32_t cols, double resolution, double x0, double x1, double y0,
+                      double y1, double z0, double z1, int32_t nx, int32_t ny, int32_t nz, double *voxel, void *stream);
+
 /* ---- optional per-kernel timing (bench.py's roofline leg) -----------------------------------------
  * When enabled, every launch of the big kernels is bracketed by hipEventRecord on its own stream.
  * tohip_profile_read synchronises on those events and returns, per kernel id < TOHIP_PROF_NKERNELS,

@@ -45,6 +45,23 @@ for _name in ["rospy", "cv_bridge", "tf2_ros", "tf", "nav_msgs", "nav_msgs.msg",
     sys.modules[_name] = _Stub(_name)
 
 
+class _PointField:
+    """sensor_msgs/PointField: the message definition's datatype constants (what pointcloud_utils.py keys its
+    numpy dtype tables on) + the four data members."""
+    INT8, UINT8, INT16, UINT16, INT32, UINT32, FLOAT32, FLOAT64 = 1, 2, 3, 4, 5, 6, 7, 8
+
+    def __init__(self, name="", offset=0, datatype=0, count=1):
+        self.name, self.offset, self.datatype, self.count = name, offset, datatype, count
+
+
+class _PointCloud2(types.SimpleNamespace):
+    pass
+
+
+sys.modules["sensor_msgs.msg"].PointField = _PointField
+sys.modules["sensor_msgs.msg"].PointCloud2 = _PointCloud2
+
+
 def _quaternion_raw_multiply(a, b):
     aw, ax, ay, az = torch.unbind(a, -1)
     bw, bx, by, bz = torch.unbind(b, -1)
@@ -344,7 +361,45 @@ def gen_hard():
              kept_idx=np.flatnonzero(torch.logical_and(dmask, fmask).numpy()).astype(np.int32))
 
 
+def gen_ingest():
+    import pointcloud_utils as ref_pcu
+    rng = np.random.default_rng(17)
+    n = 5000
+    pts = (rng.standard_normal((n, 3)) * np.array([10.0, 10.0, 2.0])).astype(np.float32)
+    pts[rng.integers(0, n, 200), rng.integers(0, 3, 200)] = np.nan
+    pts[rng.integers(0, n, 50), rng.integers(0, 3, 50)] = np.inf
+    out = {}
+    # layout A: x,y,z,intensity f32, 20-byte stride with padding (a typical lidar driver layout)
+    recA = np.zeros(n, dtype=np.dtype({"names": ["x", "y", "z", "intensity"], "formats": ["<f4"] * 4,
+                                       "offsets": [0, 4, 8, 16], "itemsize": 20}))
+    recA["x"], recA["y"], recA["z"], recA["intensity"] = pts[:, 0], pts[:, 1], pts[:, 2], rng.random(n)
+    # layout B: float64 coordinates in z,y,x order
+    recB = np.zeros(n, dtype=np.dtype({"names": ["z", "y", "x"], "formats": ["<f8"] * 3, "offsets": [0, 8, 16], "itemsize": 24}))
+    recB["x"], recB["y"], recB["z"] = pts[:, 0].astype(np.float64) * 1.000000123, pts[:, 1], pts[:, 2]
+    for tag, rec, names, dt in (("A", recA, ["x", "y", "z", "intensity"], 7), ("B", recB, ["z", "y", "x"], 8)):
+        msg = _PointCloud2(height=1, width=n, point_step=rec.dtype.itemsize, is_bigendian=False, data=rec.tobytes(),
+                           fields=[_PointField(nm, rec.dtype.fields[nm][1], dt, 1) for nm in names])
+        xyz = ref_pcu.pointcloud2_to_xyz_array(msg)
+        out[f"data_{tag}"] = np.frombuffer(rec.tobytes(), np.uint8)
+        out[f"point_step_{tag}"] = rec.dtype.itemsize
+        out[f"offsets_{tag}"] = np.array([rec.dtype.fields[c][1] for c in "xyz"])
+        out[f"datatype_{tag}"] = dt
+        out[f"xyz_{tag}"] = xyz  # float64, as the reference returns it
+    out["n"] = n
+    # the reference's own writer round-trips
+    m = ref_pcu.xyz_array_to_pointcloud2(np.nan_to_num(pts[:100], posinf=1.0))
+    out["writer_data"] = np.frombuffer(m.data, np.uint8)
+    out["writer_point_step"] = m.point_step
+    # pc_to_voxel on finite points
+    fin = pts[np.isfinite(pts).all(1)] + np.array([20.0, 0.0, 0.0], np.float32)
+    vox = ref_pcu.pc_to_voxel(fin, resolution=0.5, x=(0, 40), y=(-20, 20), z=(-4.5, 5.5))
+    out["vox_points"] = fin
+    out["vox_idx"] = np.argwhere(vox > 0).astype(np.int32)
+    out["vox_shape"] = np.array(vox.shape)
+    save("ingest", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["traj", "adam", "pose", "funcs", "hard"]
+    which = sys.argv[1:] or ["traj", "adam", "pose", "funcs", "hard", "ingest"]
     for w in which:
         globals()["gen_" + w]()

@@ -64,6 +64,14 @@ SIGNATURES = {
     "tohip_rows_strided": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     "tohip_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_i32, c_vp, c_vp]),
     "tohip_early_stop": (ctypes.c_int, [c_vp, c_vp, c_f, c_f, c_vp, c_vp]),
+    "tohip_ingest_workspace_bytes": (c_sz, [c_i64]),
+    "tohip_pointcloud2_to_xyz": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                                 c_sz, c_vp]),
+    "tohip_voxel_grid_workspace_bytes": (c_sz, [c_i64]),
+    "tohip_voxel_grid": (ctypes.c_int, [c_vp, c_i64, c_f, c_f, c_f, c_i32, c_f, c_f, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_pc_to_voxel": (ctypes.c_int, [c_vp, c_i64, c_i32, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                          ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_i32, c_i32,
+                                          c_i32, c_vp, c_vp]),
     "tohip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "tohip_profile_name": (ctypes.c_char_p, [ctypes.c_int]),
     "tohip_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),

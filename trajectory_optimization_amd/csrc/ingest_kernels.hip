@@ -1,0 +1,333 @@
+// ingest_kernels.hip — the data formats on the input side of the hot path, for gfx950.
+//
+//   PointCloud2 bytes -> (N,3) f32 with NaN rows removed   /root/reference/src/pointcloud_utils.py:22-80,180-198
+//                                                          (callers cast to f32: trajectory_optimization.py:62-63)
+//   VoxelGrid down-sampling in front of the optimisers      /root/reference/launch/voxels_filtering.launch:11-21
+//                                                          (pcl::VoxelGrid, third-party C++, restated from its published
+//                                                          algorithm: field filter -> voxel keys -> centroid per voxel,
+//                                                          output in ascending voxel-key order)
+//   pc_to_voxel occupancy grid                              /root/reference/src/pointcloud_utils.py:279-288
+#include <hipcub/hipcub.hpp>
+
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// PointCloud2 unpack.  datatype: sensor_msgs/PointField FLOAT32 = 7, FLOAT64 = 8.
+
+__device__ __forceinline__ float load_field(const uint8_t* p, int datatype, int big_endian) {
+    if (datatype == 8) {
+        unsigned long long u = 0;
+        for (int k = 0; k < 8; ++k) u |= (unsigned long long)p[big_endian ? 7 - k : k] << (8 * k);
+        return (float)__longlong_as_double((long long)u);
+    }
+    unsigned u = 0;
+    for (int k = 0; k < 4; ++k) u |= (unsigned)p[big_endian ? 3 - k : k] << (8 * k);
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ bool unpack_point(const uint8_t* data, int64_t i, int point_step, int xo, int yo, int zo,
+                                             int datatype, int be, int remove_nans, float& x, float& y, float& z) {
+    const uint8_t* p = data + i * point_step;
+    x = load_field(p + xo, datatype, be);
+    y = load_field(p + yo, datatype, be);
+    z = load_field(p + zo, datatype, be);
+    // np.isfinite on the stored values (pointcloud_utils.py:186); a finite f64 beyond f32 range stays "kept"
+    if (!remove_nans) return true;
+    if (datatype == 8) {
+        // classify on the f64 bits: exponent all ones = inf/nan
+        bool fin = true;
+        const int offs[3] = {xo, yo, zo};
+        for (int a = 0; a < 3; ++a) {
+            const uint8_t* q = p + offs[a];
+            const unsigned hi = ((unsigned)q[be ? 0 : 7] << 8) | q[be ? 1 : 6];
+            fin = fin && (((hi >> 4) & 0x7ffu) != 0x7ffu);
+        }
+        return fin;
+    }
+    return isfinite(x) && isfinite(y) && isfinite(z);
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_pc2_count(const uint8_t* __restrict__ data, int64_t n, int point_step, int xo, int yo, int zo, int datatype, int be,
+            int remove_nans, int32_t* __restrict__ tile_count) {
+    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
+    const int64_t tile0 = (int64_t)blockIdx.x * 1024;
+    int cnt = 0;
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = tile0 + j * TO_BLOCK + threadIdx.x;
+        float x, y, z;
+        const bool keep = i < n && unpack_point(data, i, point_step, xo, yo, zo, datatype, be, remove_nans, x, y, z);
+        cnt += __popcll(__ballot(keep));
+    }
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_pc2_write(const uint8_t* __restrict__ data, int64_t n, int point_step, int xo, int yo, int zo, int datatype, int be,
+            int remove_nans, const int32_t* __restrict__ tile_off, float* __restrict__ out) {
+    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile0 = (int64_t)blockIdx.x * 1024;
+    int base = tile_off[blockIdx.x];
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = tile0 + j * TO_BLOCK + threadIdx.x;
+        float x = 0, y = 0, z = 0;
+        const bool keep = i < n && unpack_point(data, i, point_step, xo, yo, zo, datatype, be, remove_nans, x, y, z);
+        const unsigned long long b = __ballot(keep);
+        if (lane == 0) wave_cnt[wave] = __popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (keep) {
+            const int64_t d = off + __popcll(b & ((1ull << lane) - 1ull));
+            out[3 * d] = x; out[3 * d + 1] = y; out[3 * d + 2] = z;
+        }
+        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
+extern "C" size_t tohip_ingest_workspace_bytes(int64_t n) {
+    if (n <= 0) return 256;
+    const size_t ntiles = (size_t)((n + 1023) / 1024);
+    return 2 * align_up(ntiles * sizeof(int32_t), 256) + 256;
+}
+
+extern "C" int tohip_pointcloud2_to_xyz(const uint8_t* data, int64_t n_points, int32_t point_step, int32_t x_off,
+                                        int32_t y_off, int32_t z_off, int32_t datatype, int32_t is_bigendian,
+                                        int32_t remove_nans, float* out_xyz, int32_t* out_count, void* workspace,
+                                        size_t workspace_bytes, void* stream_) {
+    if (!out_count || !workspace || n_points < 0 || n_points > 0x7fffffffLL || point_step <= 0 ||
+        (datatype != 7 && datatype != 8))
+        return TOHIP_EINVAL;
+    const int fsz = datatype == 8 ? 8 : 4;
+    if (x_off < 0 || y_off < 0 || z_off < 0 || x_off + fsz > point_step || y_off + fsz > point_step || z_off + fsz > point_step)
+        return TOHIP_EINVAL;
+    if (workspace_bytes < tohip_ingest_workspace_bytes(n_points)) return TOHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream_;
+    if (n_points == 0) {
+        hipError_t e = hipMemsetAsync(out_count, 0, sizeof(int32_t), st);
+        return e == hipSuccess ? TOHIP_OK : (int)e;
+    }
+    if (!data || !out_xyz) return TOHIP_EINVAL;
+    const int ntiles = (int)((n_points + 1023) / 1024);
+    const size_t sg = align_up((size_t)ntiles * sizeof(int32_t), 256);
+    int32_t* tile_count = (int32_t*)workspace;
+    int32_t* tile_off = (int32_t*)((char*)workspace + sg);
+    k_pc2_count<<<ntiles, TO_BLOCK, 0, st>>>(data, n_points, point_step, x_off, y_off, z_off, datatype, is_bigendian,
+                                              remove_nans, tile_count);
+    TO_HIP_CHECK_LAUNCH();
+    k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(tile_count, ntiles, tile_off, out_count);
+    TO_HIP_CHECK_LAUNCH();
+    k_pc2_write<<<ntiles, TO_BLOCK, 0, st>>>(data, n_points, point_step, x_off, y_off, z_off, datatype, is_bigendian,
+                                              remove_nans, tile_off, out_xyz);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// VoxelGrid (pcl::VoxelGrid<PointXYZ>::applyFilter restated): points with a non-finite coordinate or with the
+// filter field outside [lim_min, lim_max] are dropped; the grid origin is floor(min corner / leaf) of the kept
+// points; a voxel's output is the centroid of its points, voxels in ascending key order
+// key = i + j*div_x + k*div_x*div_y.
+
+struct VoxParams {
+    float inv_leaf[3];
+    int field;  // 0,1,2 = x,y,z ; -1 = no field filter
+    float lim_min, lim_max;
+};
+
+__device__ __forceinline__ bool vox_keep(const VoxParams& vp, float x, float y, float z) {
+    if (!(isfinite(x) && isfinite(y) && isfinite(z))) return false;
+    if (vp.field >= 0) {
+        const float f = vp.field == 0 ? x : (vp.field == 1 ? y : z);
+        if (f > vp.lim_max || f < vp.lim_min) return false;
+    }
+    return true;
+}
+
+// ctrl ints: [0..2] min cell (int, via atomicMin) [3..5] max cell (atomicMax) [6] n kept [7] n voxels [8] overflow
+__global__ void __launch_bounds__(TO_BLOCK)
+k_vox_bounds(const float* __restrict__ xyz, int64_t n, VoxParams vp, int* __restrict__ ctrl) {
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        if (!vox_keep(vp, p[0], p[1], p[2])) continue;
+        for (int k = 0; k < 3; ++k) {
+            // floor(min_p * inv_leaf) == min over points of floor(p * inv_leaf): floor and the scaling are monotone
+            const int c = (int)floorf(p[k] * vp.inv_leaf[k]);
+            mn[k] = min(mn[k], c); mx[k] = max(mx[k], c);
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        for (int s = 32; s > 0; s >>= 1) { mn[k] = min(mn[k], __shfl_xor(mn[k], s)); mx[k] = max(mx[k], __shfl_xor(mx[k], s)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&ctrl[k], mn[k]); atomicMax(&ctrl[3 + k], mx[k]); }
+    }
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_vox_keys(const float* __restrict__ xyz, int64_t n, VoxParams vp, int* __restrict__ ctrl, unsigned long long* __restrict__ keys,
+           int* __restrict__ vals) {
+    const long long dx = (long long)ctrl[3] - ctrl[0] + 1, dy = (long long)ctrl[4] - ctrl[1] + 1, dz = (long long)ctrl[5] - ctrl[2] + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ctrl[0] <= ctrl[3] && dx * dy * dz > 0x7fffffffLL) ctrl[8] = 1;  // PCL: "leaf size too small"
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        unsigned long long key = ~0ull;  // dropped points sort to the end
+        if (vox_keep(vp, x, y, z)) {
+            const long long ci = (long long)((int)floorf(x * vp.inv_leaf[0]) - ctrl[0]);
+            const long long cj = (long long)((int)floorf(y * vp.inv_leaf[1]) - ctrl[1]);
+            const long long ck = (long long)((int)floorf(z * vp.inv_leaf[2]) - ctrl[2]);
+            key = (unsigned long long)(ci + cj * dx + ck * dx * dy);
+        }
+        keys[i] = key;
+        vals[i] = (int)i;
+    }
+}
+
+// run heads in the sorted key array -> head flags (int) for the ordered compaction
+__global__ void __launch_bounds__(TO_BLOCK)
+k_vox_heads(const unsigned long long* __restrict__ keys, int64_t n, int* __restrict__ head) {
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride)
+        head[i] = (keys[i] != ~0ull && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
+}
+
+// thread per voxel: sequential f32 centroid over its run (stable sort: the caller's point order inside a voxel)
+__global__ void __launch_bounds__(TO_BLOCK)
+k_vox_centroids(const float* __restrict__ xyz, const unsigned long long* __restrict__ keys, const int* __restrict__ order,
+                int64_t n, const int* __restrict__ head_pos, const int* __restrict__ n_vox, float* __restrict__ out) {
+    const int m = *n_vox;
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t v = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; v < m; v += stride) {
+        int64_t i = head_pos[v];
+        const unsigned long long key = keys[i];
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        int cnt = 0;
+        for (; i < n && keys[i] == key; ++i) {
+            const int64_t s = order[i];
+            sx += xyz[3 * s]; sy += xyz[3 * s + 1]; sz += xyz[3 * s + 2];
+            ++cnt;
+        }
+        const float c = (float)cnt;
+        out[3 * v] = sx / c; out[3 * v + 1] = sy / c; out[3 * v + 2] = sz / c;
+    }
+}
+
+namespace {
+struct VoxPlan { size_t off_keys, off_keys2, off_vals, off_vals2, off_head, off_hpos, off_tcnt, off_toff, off_ctrl, off_tmp, tmp_bytes, total; };
+inline VoxPlan vox_plan(int64_t n) {
+    VoxPlan p;
+    size_t o = 0;
+    const size_t ntiles = (size_t)((n + 1023) / 1024);
+    p.off_keys = o;  o += align_up(sizeof(unsigned long long) * (size_t)n, 256);
+    p.off_keys2 = o; o += align_up(sizeof(unsigned long long) * (size_t)n, 256);
+    p.off_vals = o;  o += align_up(sizeof(int) * (size_t)n, 256);
+    p.off_vals2 = o; o += align_up(sizeof(int) * (size_t)n, 256);
+    p.off_head = o;  o += align_up(sizeof(int) * (size_t)n, 256);
+    p.off_hpos = o;  o += align_up(sizeof(int) * (size_t)n, 256);
+    p.off_tcnt = o;  o += align_up(sizeof(int) * ntiles, 256);
+    p.off_toff = o;  o += align_up(sizeof(int) * ntiles, 256);
+    p.off_ctrl = o;  o += 256;
+    size_t tmp = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                             (const int*)nullptr, (int*)nullptr, (int)n, 0, 64, (hipStream_t)0);
+    p.tmp_bytes = tmp;
+    p.off_tmp = o;   o += align_up(tmp, 256);
+    p.total = o;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t tohip_voxel_grid_workspace_bytes(int64_t n) { return n > 0 ? vox_plan(n).total : 256; }
+
+// out_xyz capacity n rows; *out_count (device) = number of voxels.  filter_field: 0/1/2 or -1.
+extern "C" int tohip_voxel_grid(const float* xyz, int64_t n, float leaf_x, float leaf_y, float leaf_z, int32_t filter_field,
+                                float limit_min, float limit_max, float* out_xyz, int32_t* out_count, void* workspace,
+                                size_t workspace_bytes, void* stream_) {
+    if (!out_count || !workspace || n < 0 || n > 0x7fffffffLL || !(leaf_x > 0.f) || !(leaf_y > 0.f) || !(leaf_z > 0.f) ||
+        filter_field > 2)
+        return TOHIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(out_count, 0, sizeof(int32_t), st);
+        return e == hipSuccess ? TOHIP_OK : (int)e;
+    }
+    if (!xyz || !out_xyz) return TOHIP_EINVAL;
+    const VoxPlan pl = vox_plan(n);
+    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
+    char* ws = (char*)workspace;
+    auto* keys = (unsigned long long*)(ws + pl.off_keys);
+    auto* keys2 = (unsigned long long*)(ws + pl.off_keys2);
+    int* vals = (int*)(ws + pl.off_vals);
+    int* vals2 = (int*)(ws + pl.off_vals2);
+    int* head = (int*)(ws + pl.off_head);
+    int* hpos = (int*)(ws + pl.off_hpos);
+    int* tcnt = (int*)(ws + pl.off_tcnt);
+    int* toff = (int*)(ws + pl.off_toff);
+    int* ctrl = (int*)(ws + pl.off_ctrl);
+    VoxParams vp;
+    vp.inv_leaf[0] = 1.0f / leaf_x; vp.inv_leaf[1] = 1.0f / leaf_y; vp.inv_leaf[2] = 1.0f / leaf_z;  // pcl: inverse_leaf_size_
+    vp.field = filter_field < 0 ? -1 : filter_field;
+    vp.lim_min = limit_min; vp.lim_max = limit_max;
+    const int init[9] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0, 0};
+    hipError_t e = hipMemcpyAsync(ctrl, init, sizeof(init), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipStreamSynchronize(st);  // `init` lives on this stack frame
+    if (e != hipSuccess) return (int)e;
+    int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
+    if (nb > 2048) nb = 2048;
+    k_vox_bounds<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, vp, ctrl);
+    TO_HIP_CHECK_LAUNCH();
+    k_vox_keys<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, vp, ctrl, keys, vals);
+    TO_HIP_CHECK_LAUNCH();
+    size_t tmp = pl.tmp_bytes;
+    e = hipcub::DeviceRadixSort::SortPairs(ws + pl.off_tmp, tmp, keys, keys2, vals, vals2, (int)n, 0, 64, st);
+    if (e != hipSuccess) return (int)e;
+    k_vox_heads<<<(int)nb, TO_BLOCK, 0, st>>>(keys2, n, head);
+    TO_HIP_CHECK_LAUNCH();
+    const int ntiles = (int)((n + 1023) / 1024);
+    hull::k_flag_count<<<ntiles, TO_BLOCK, 0, st>>>(head, (int)n, tcnt);
+    TO_HIP_CHECK_LAUNCH();
+    k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(tcnt, ntiles, toff, out_count);
+    TO_HIP_CHECK_LAUNCH();
+    hull::k_flag_write<<<ntiles, TO_BLOCK, 0, st>>>(head, (int)n, toff, hpos, (int)n);
+    TO_HIP_CHECK_LAUNCH();
+    k_vox_centroids<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, keys2, vals2, n, hpos, out_count, out_xyz);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pc_to_voxel: 1.0 at the cell of every point inside [x0,x1) x [y0,y1) x [z0,z1), float64 like np.zeros
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_pc_to_voxel(const float* __restrict__ pc, int64_t n, int cols, double res, double x0, double x1, double y0, double y1,
+              double z0, double z1, int nx, int ny, int nz, double* __restrict__ voxel) {
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        const double x = pc[cols * i], y = pc[cols * i + 1], z = pc[cols * i + 2];
+        if (!(x >= x0 && x < x1 && y >= y0 && y < y1 && z >= z0 && z < z1)) continue;
+        const int ci = (int)((x - x0) / res), cj = (int)((y - y0) / res), ck = (int)((z - z0) / res);  // astype(int32) truncates
+        if (ci < nx && cj < ny && ck < nz) voxel[((int64_t)ci * ny + cj) * nz + ck] = 1.0;
+    }
+}
+
+extern "C" int tohip_pc_to_voxel(const float* pc, int64_t n, int32_t cols, double resolution, double x0, double x1, double y0,
+                                 double y1, double z0, double z1, int32_t nx, int32_t ny, int32_t nz, double* voxel,
+                                 void* stream_) {
+    if (!voxel || n < 0 || cols < 3 || !(resolution > 0) || nx <= 0 || ny <= 0 || nz <= 0) return TOHIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    hipError_t e = hipMemsetAsync(voxel, 0, sizeof(double) * (size_t)nx * ny * nz, st);
+    if (e != hipSuccess) return (int)e;
+    if (n == 0) return TOHIP_OK;
+    if (!pc) return TOHIP_EINVAL;
+    int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
+    if (nb > 2048) nb = 2048;
+    k_pc_to_voxel<<<(int)nb, TO_BLOCK, 0, st>>>(pc, n, cols, resolution, x0, x1, y0, y1, z0, z1, nx, ny, nz, voxel);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}

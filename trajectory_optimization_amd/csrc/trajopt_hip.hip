@@ -7,6 +7,7 @@
 #include "hard_kernels.hip"
 #include "hull_kernels.hip"
 #include "optim_kernels.hip"
+#include "ingest_kernels.hip"
 
 extern "C" int tohip_abi_version(void) { return TOHIP_ABI_VERSION; }
 
