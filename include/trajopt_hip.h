@@ -205,6 +205,15 @@ int tohip_voxel_grid(const float *xyz, int64_t n_points, float leaf_x, float lea
 int tohip_pc_to_voxel(const float *pc, int64_t n_points, int32_t cols, double resolution, double x0, double x1, double y0,
                       double y1, double z0, double z1, int32_t nx, int32_t ny, int32_t nz, double *voxel, void *stream);
 
+/* ---- frustum rasterisation (render_pc_image, tools.py:122-173; pulsar itself cannot be pinned, see
+ * render_kernels.hip): nearest-depth sphere splat of camera-frame points.  K9_host: row-major intrinsics in
+ * HOST memory; image (height,width,3) f32; owner (may be NULL) (height,width) int32 winning point or -1;
+ * owns_pixel (may be NULL) n int32 flags: the z-buffer visibility set. */
+size_t tohip_render_workspace_bytes(int32_t width, int32_t height);
+int tohip_render_points(const float *verts, int64_t n_points, const float *K9_host, int32_t width, int32_t height,
+                        float radius, float znear, float zfar, float background, float *image, int32_t *owner,
+                        int32_t *owns_pixel, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- optional per-kernel timing (bench.py's roofline leg) -----------------------------------------
  * When enabled, every launch of the big kernels is bracketed by hipEventRecord on its own stream.
  * tohip_profile_read synchronises on those events and returns, per kernel id < TOHIP_PROF_NKERNELS,

@@ -1,0 +1,34 @@
+"""numpy restatement of the nearest-depth sphere splat of trajectory_optimization_amd/csrc/render_kernels.hip
+(TEST INFRASTRUCTURE ONLY).  The reference's renderer is pytorch3d pulsar (/root/reference/src/tools.py:147-172),
+third-party CUDA absent from the tree and the image: PARITY UNPINNED — this pins the build's own specification."""
+import numpy as np
+
+
+def render_points(verts, K, height, width, radius=0.03, znear=1.0, zfar=10.0, background=1.0):
+    v = np.asarray(verts, np.float32)
+    fx, cx, fy, cy = (np.float32(K[0][0]), np.float32(K[0][2]), np.float32(K[1][1]), np.float32(K[1][2]))
+    H, W = int(height), int(width)
+    zbuf = np.full((H, W), np.inf, np.float32)
+    owner = np.full((H, W), -1, np.int64)
+    for i, (X, Y, Z) in enumerate(v):
+        if not (Z >= znear and Z <= zfar):
+            continue
+        u, w_ = fx * X / Z + cx, fy * Y / Z + cy
+        rho = fx * np.float32(radius) / Z
+        j0, j1 = max(0, int(np.floor(u - rho - np.float32(0.5)))), min(W - 1, int(np.ceil(u + rho - np.float32(0.5))))
+        i0, i1 = max(0, int(np.floor(w_ - rho - np.float32(0.5)))), min(H - 1, int(np.ceil(w_ + rho - np.float32(0.5))))
+        if j1 < j0 or i1 < i0:
+            continue
+        pj = np.arange(j0, j1 + 1, dtype=np.float32) + np.float32(0.5) - u
+        pi = np.arange(i0, i1 + 1, dtype=np.float32) + np.float32(0.5) - w_
+        inside = (pj[None, :] * pj[None, :] + pi[:, None] * pi[:, None]) <= rho * rho
+        zb = zbuf[i0:i1 + 1, j0:j1 + 1]
+        ow = owner[i0:i1 + 1, j0:j1 + 1]
+        win = inside & ((Z < zb) | ((Z == zb) & (i < ow)))
+        zb[win] = Z
+        ow[win] = i
+    lo, hi = v.min(), v.max()
+    img = np.full((H, W, 3), background, np.float32)
+    hit = owner >= 0
+    img[hit] = (v[owner[hit]] - lo) / (hi - lo)
+    return img, owner

@@ -1,0 +1,136 @@
+// render_kernels.hip — frustum rasterisation of a camera-frame point cloud.
+//
+// The reference renders with pytorch3d's pulsar sphere renderer (/root/reference/src/tools.py:122-173,
+// /root/reference/src/pc_processor.py:85-125): radius 0.03 m in world units, one point per pixel, white
+// background, colours = coordinates min-max normalised over the whole tensor, znear/zfar clipping; the image is
+// only displayed (pc_processor.py:190-197), never differentiated.  pulsar is third-party CUDA that is neither in
+// the reference tree nor installable here, so its blending cannot be pinned; this file implements the
+// deterministic core of that configuration — a nearest-depth sphere splat:
+//
+//   u = fx X/Z + cx, v = fy Y/Z + cy (pixel units, the frustum cull's projection), disc radius rho = fx r / Z,
+//   pixel (i, j) has its centre at (j + 0.5, i + 0.5); among the discs covering a pixel centre the smallest Z
+//   wins, ties by the smaller point index; uncovered pixels keep the background colour.
+//
+// Besides the image it yields, per point, whether it owns a pixel: a z-buffer visibility set.
+#include "common.hpp"
+
+struct RenderParams {
+    float fx, fy, cx, cy;
+    int width, height;
+    float radius, znear, zfar;
+};
+
+__global__ void __launch_bounds__(TO_BLOCK) k_zbuf_clear(unsigned long long* __restrict__ zbuf, int64_t npix) {
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < npix; i += stride) zbuf[i] = ~0ull;
+}
+
+// thread per point: rasterise its disc with 64-bit atomicMin of (Z bits << 32 | index); Z > 0 so the bit
+// pattern of the float orders like the value
+__global__ void __launch_bounds__(TO_BLOCK)
+k_splat(const float* __restrict__ verts, int64_t n, RenderParams rp, unsigned long long* __restrict__ zbuf) {
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float X = verts[3 * i], Y = verts[3 * i + 1], Z = verts[3 * i + 2];
+        if (!(Z >= rp.znear && Z <= rp.zfar)) continue;
+        const float u = rp.fx * X / Z + rp.cx, v = rp.fy * Y / Z + rp.cy;
+        const float rho = rp.fx * rp.radius / Z;
+        if (!(u + rho >= 0.f && u - rho <= (float)rp.width && v + rho >= 0.f && v - rho <= (float)rp.height)) continue;
+        const int j0 = max(0, (int)floorf(u - rho - 0.5f)), j1 = min(rp.width - 1, (int)ceilf(u + rho - 0.5f));
+        const int i0 = max(0, (int)floorf(v - rho - 0.5f)), i1 = min(rp.height - 1, (int)ceilf(v + rho - 0.5f));
+        const unsigned long long key = ((unsigned long long)__float_as_uint(Z) << 32) | (unsigned)i;
+        const float r2 = rho * rho;
+        for (int pi = i0; pi <= i1; ++pi) {
+            const float dy = ((float)pi + 0.5f) - v;
+            for (int pj = j0; pj <= j1; ++pj) {
+                const float dx = ((float)pj + 0.5f) - u;
+                if (dx * dx + dy * dy <= r2) atomicMin(&zbuf[(int64_t)pi * rp.width + pj], key);
+            }
+        }
+    }
+}
+
+// whole-tensor min and max of the coordinates (tools.py:137-138) through ordered integer atomics
+__global__ void __launch_bounds__(TO_BLOCK)
+k_minmax_all(const float* __restrict__ v, int64_t m, unsigned* __restrict__ mm) {
+    unsigned mn = 0xffffffffu, mx = 0u;
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < m; i += stride) {
+        const unsigned b = __float_as_uint(v[i]);
+        const unsigned k = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+        mn = min(mn, k); mx = max(mx, k);
+    }
+    for (int s = 32; s > 0; s >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, s)); mx = max(mx, (unsigned)__shfl_xor((int)mx, s)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], mn); atomicMax(&mm[1], mx); }
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_resolve(const unsigned long long* __restrict__ zbuf, int64_t npix, const float* __restrict__ verts,
+          const unsigned* __restrict__ mm, float bg, float* __restrict__ image, int32_t* __restrict__ owner,
+          int* __restrict__ owns_pixel) {
+    const unsigned k0 = mm[0], k1 = mm[1];
+    const float lo = __uint_as_float((k0 & 0x80000000u) ? (k0 & 0x7fffffffu) : ~k0);
+    const float hi = __uint_as_float((k1 & 0x80000000u) ? (k1 & 0x7fffffffu) : ~k1);
+    const float span = hi - lo;  // rgb = (verts - min) / max(verts - min)
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t p = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; p < npix; p += stride) {
+        const unsigned long long key = zbuf[p];
+        if (key == ~0ull) {
+            image[3 * p] = bg; image[3 * p + 1] = bg; image[3 * p + 2] = bg;
+            if (owner) owner[p] = -1;
+        } else {
+            const int64_t i = (int64_t)(key & 0xffffffffull);
+            image[3 * p] = (verts[3 * i] - lo) / span;
+            image[3 * p + 1] = (verts[3 * i + 1] - lo) / span;
+            image[3 * p + 2] = (verts[3 * i + 2] - lo) / span;
+            if (owner) owner[p] = (int32_t)i;
+            if (owns_pixel) owns_pixel[i] = 1;
+        }
+    }
+}
+
+extern "C" size_t tohip_render_workspace_bytes(int32_t width, int32_t height) {
+    if (width <= 0 || height <= 0) return 256;
+    return align_up((size_t)width * height * sizeof(unsigned long long), 256) + 256;
+}
+
+// image: (height, width, 3) f32; owner (may be NULL): (height, width) int32 winning point or -1;
+// owns_pixel (may be NULL): n ints set to 1 for points that won at least one pixel (zeroed here).
+extern "C" int tohip_render_points(const float* verts, int64_t n, const float* K9_host, int32_t width, int32_t height,
+                                   float radius, float znear, float zfar, float background, float* image, int32_t* owner,
+                                   int32_t* owns_pixel, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!K9_host || !image || !workspace || width <= 0 || height <= 0 || n < 0 || n > 0x7fffffffLL || (n > 0 && !verts) ||
+        !(radius > 0.f) || !(znear > 0.f))
+        return TOHIP_EINVAL;
+    if (workspace_bytes < tohip_render_workspace_bytes(width, height)) return TOHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream_;
+    const int64_t npix = (int64_t)width * height;
+    unsigned long long* zbuf = (unsigned long long*)workspace;
+    unsigned* mm = (unsigned*)((char*)workspace + align_up((size_t)npix * sizeof(unsigned long long), 256));
+    RenderParams rp;
+    rp.fx = K9_host[0]; rp.cx = K9_host[2]; rp.fy = K9_host[4]; rp.cy = K9_host[5];
+    rp.width = width; rp.height = height; rp.radius = radius; rp.znear = znear; rp.zfar = zfar;
+    hipError_t e = hipMemsetAsync(mm, 0xff, sizeof(unsigned), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(mm + 1, 0, sizeof(unsigned), st);
+    if (e != hipSuccess) return (int)e;
+    if (owns_pixel && n > 0) {
+        e = hipMemsetAsync(owns_pixel, 0, sizeof(int32_t) * (size_t)n, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    int64_t nbp = (npix + TO_BLOCK - 1) / TO_BLOCK;
+    if (nbp > 4096) nbp = 4096;
+    k_zbuf_clear<<<(int)nbp, TO_BLOCK, 0, st>>>(zbuf, npix);
+    TO_HIP_CHECK_LAUNCH();
+    if (n > 0) {
+        int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
+        if (nb > 4096) nb = 4096;
+        k_minmax_all<<<(int)nb, TO_BLOCK, 0, st>>>(verts, 3 * n, mm);
+        TO_HIP_CHECK_LAUNCH();
+        k_splat<<<(int)nb, TO_BLOCK, 0, st>>>(verts, n, rp, zbuf);
+        TO_HIP_CHECK_LAUNCH();
+    }
+    k_resolve<<<(int)nbp, TO_BLOCK, 0, st>>>(zbuf, npix, verts, mm, background, image, owner, owns_pixel);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}

@@ -8,6 +8,7 @@
 #include "hull_kernels.hip"
 #include "optim_kernels.hip"
 #include "ingest_kernels.hip"
+#include "render_kernels.hip"
 
 extern "C" int tohip_abi_version(void) { return TOHIP_ABI_VERSION; }
 

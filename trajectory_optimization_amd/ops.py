@@ -240,6 +240,26 @@ def hull_vertices_with_origin(points, with_origin=True, return_rounds=False):
     return (out, rounds.value) if return_rounds else out
 
 
+def render_points(verts, K, height, width, radius=0.03, znear=1.0, zfar=10.0, background=1.0, want_owner=False):
+    """-> (image (H,W,3) f32, owner (H,W) int32 or None, owns_pixel (n,) bool)"""
+    _require_cuda(verts, "verts")
+    v = verts.detach().to(torch.float32).contiguous()
+    n = v.shape[0]
+    dev = v.device
+    H, W = int(height), int(width)
+    Kh = torch.as_tensor(K, dtype=torch.float32).detach().cpu()[:3, :3].reshape(9).tolist()
+    Kc = (ctypes.c_float * 9)(*Kh)
+    img = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    owner = torch.empty((H, W), dtype=torch.int32, device=dev) if want_owner else None
+    owns = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    wsb = _lib.lib().tohip_render_workspace_bytes(W, H)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().tohip_render_points(ptr(v), n, Kc, W, H, float(radius), float(znear), float(zfar), float(background),
+                                             ptr(img), ptr(owner), ptr(owns), ptr(ws), wsb, stream_ptr()), "tohip_render_points")
+    return img, owner, owns[:n].bool()
+
+
 def selftest_wave_reduce(mat64xk):
     k = mat64xk.shape[1]
     dev = mat64xk.device

@@ -52,6 +52,28 @@ def get_cam_frustum_pts(points, img_height, img_width, intrins, min_dist=1.0, ma
     return kept, dist_mask, fov_mask
 
 
+def render_pc_image(verts, K, height, width, R=None, T=None, device=torch.device('cuda'), gamma=1.0e-1, znear=1.0,
+                    zfar=10.0):
+    """/root/reference/src/tools.py:122-173: image (height, width, 3) of a camera-frame cloud (N,3): spheres of
+    0.03 m, nearest point per pixel, white background, colours = coordinates min-max normalised over the whole
+    tensor.  The reference delegates to pytorch3d's pulsar renderer, which cannot be pinned offline; this is its
+    deterministic nearest-depth core (`gamma`, pulsar's blending softness, is accepted and ignored).
+    R, T (pytorch3d row-vector convention X_cam = X R + T) default to the identity like the reference's."""
+    v = torch.as_tensor(verts, dtype=torch.float32).to(device)
+    if R is not None or T is not None:
+        Rm = torch.eye(3, device=v.device) if R is None else torch.as_tensor(R, dtype=torch.float32).to(v.device).reshape(3, 3)
+        Tv = torch.zeros(3, device=v.device) if T is None else torch.as_tensor(T, dtype=torch.float32).to(v.device).reshape(3)
+        v = v @ Rm + Tv
+    return ops.render_points(v, K, int(height), int(width), radius=0.03, znear=znear, zfar=zfar, background=1.0)[0]
+
+
+def zbuffer_visible_points(verts, K, height, width, znear=1.0, zfar=10.0, radius=0.03):
+    """Indices of the camera-frame points that win at least one pixel of the splat: the z-buffer counterpart of
+    hidden_pts_removal (resolution dependent, approximate)."""
+    _, _, owns = ops.render_points(torch.as_tensor(verts), K, int(height), int(width), radius, znear, zfar)
+    return torch.nonzero(owns).squeeze(1).to(torch.int32)
+
+
 def ego_to_cam(points, trans, quat):
     """/root/reference/src/pc_processor.py:63-70: (N,3) ego-frame points -> (3,N) camera frame; the
     quaternion is NOT normalised there, and is not here."""
