@@ -219,6 +219,80 @@ __device__ __forceinline__ void to_cam(const WayHot& h, float x, float y, float 
 }
 
 // ----------------------------------------------------------------------------------------------
+// Packed-f32 twins of the functions above: two points per lane in a 64-bit register pair, so that the
+// FMA-class arithmetic issues as v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (one wave64 VALU instruction
+// occupies its SIMD for 4 cycles whether it carries one float per lane or two).  Every element goes through
+// exactly the operation sequence of the scalar function, each operation IEEE-rounded per element, so the
+// results are bit-identical to the scalar path; transcendentals, med3 and min/max stay per element.
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 pk_splat(float s) { return (f2)(s); }
+__device__ __forceinline__ f2 pk_rcp(f2 x) { return f2{to_rcp(x.x), to_rcp(x.y)}; }
+
+__device__ __forceinline__ f2 to_exp_pk(f2 x) {
+    x = f2{__builtin_amdgcn_fmed3f(x.x, -150.0f, 88.0f), __builtin_amdgcn_fmed3f(x.y, -150.0f, 88.0f)};
+    const float L2E = 1.44269504088896341f, L2E_LO = 1.925963033500519e-8f;
+    const f2 e = x * pk_splat(L2E);
+    f2 r = pk_fma(x, pk_splat(L2E), -e);
+    r = pk_fma(x, pk_splat(L2E_LO), r);
+    const f2 y = f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    return pk_fma(y, r * pk_splat(0.693147180559945f), y);
+}
+
+__device__ __forceinline__ f2 to_exp_fast_pk(f2 x) {
+    x = f2{__builtin_amdgcn_fmed3f(x.x, -150.0f, 88.0f), __builtin_amdgcn_fmed3f(x.y, -150.0f, 88.0f)};
+    const f2 e = x * pk_splat(1.44269504088896341f);
+    return f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+}
+
+__device__ __forceinline__ f2 dist2_mean_pk(f2 X, f2 Y, f2 Z, float mean) {
+    const f2 m = pk_splat(mean);
+    const f2 dx = X - m, dy = Y - m, dz = Z - m;
+    return pk_fma(dz, dz, pk_fma(dy, dy, dx * dx));
+}
+
+struct Vis2 {
+    f2 p, S, u, v, rz;
+};
+
+template <bool PINHOLE>
+__device__ __forceinline__ f2 soft_vis_pk(const CamConsts& k, f2 X, f2 Y, f2 Z, Vis2* o) {
+    const f2 d2 = dist2_mean_pk(X, Y, Z, k.mean);
+    f2 h0, h1, h2;
+    if (PINHOLE) {
+        h0 = pk_fma(pk_splat(k.k[2]), Z, pk_splat(k.k[0]) * X);
+        h1 = pk_fma(pk_splat(k.k[5]), Z, pk_splat(k.k[4]) * Y);
+        h2 = Z;
+    } else {
+        h0 = pk_fma(pk_splat(k.k[2]), Z, pk_fma(pk_splat(k.k[1]), Y, pk_splat(k.k[0]) * X));
+        h1 = pk_fma(pk_splat(k.k[5]), Z, pk_fma(pk_splat(k.k[4]), Y, pk_splat(k.k[3]) * X));
+        h2 = pk_fma(pk_splat(k.k[8]), Z, pk_fma(pk_splat(k.k[7]), Y, pk_splat(k.k[6]) * X));
+    }
+    const f2 rz = pk_rcp(h2 + pk_splat(k.eps));
+    const f2 u = h0 * rz, v = h1 * rz;
+    const f2 au = (u - pk_splat(k.halfw)) * pk_splat(k.inv_w), av = (v - pk_splat(k.halfh)) * pk_splat(k.inv_h);
+    f2 arg = d2 * pk_splat(k.inv_var);
+    arg = pk_fma(au, au, arg);
+    arg = pk_fma(av, av, arg);
+    const f2 E = to_exp_pk(pk_splat(-0.5f) * arg);
+    const f2 S = pk_rcp(pk_splat(1.0f) + to_exp_fast_pk(-h2));
+    const f2 p = S * E;
+    if (o) {
+        o->p = p; o->S = S; o->u = u; o->v = v; o->rz = rz;
+    }
+    return p;
+}
+
+__device__ __forceinline__ void to_cam_pk(const WayHot& h, f2 x, f2 y, f2 z, f2& X, f2& Y, f2& Z, f2& y0, f2& y1, f2& y2) {
+    y0 = x - pk_splat(h.t[0]); y1 = y - pk_splat(h.t[1]); y2 = z - pk_splat(h.t[2]);
+    X = pk_fma(pk_splat(h.m[2]), y2, pk_fma(pk_splat(h.m[1]), y1, pk_splat(h.m[0]) * y0));
+    Y = pk_fma(pk_splat(h.m[5]), y2, pk_fma(pk_splat(h.m[4]), y1, pk_splat(h.m[3]) * y0));
+    Z = pk_fma(pk_splat(h.m[8]), y2, pk_fma(pk_splat(h.m[7]), y1, pk_splat(h.m[6]) * y0));
+}
+
+// ----------------------------------------------------------------------------------------------
 // Wave64 reductions on the DPP network; the result is valid in lane 63.
 //   quad_perm[1,0,3,2]=0xB1  quad_perm[2,3,0,1]=0x4E  row_half_mirror=0x141  row_mirror=0x140
 //   row_bcast:15=0x142 (row_mask 0xA)  row_bcast:31=0x143 (row_mask 0xC)

@@ -217,10 +217,18 @@ k_traj_probe(CloudView cv, const WayHot* __restrict__ hot, WayAux* __restrict__ 
 template <int P, bool PINHOLE>
 __device__ __forceinline__ void pass1_dense_wp(const CamConsts& cc, const WayHot& h, const float (&x)[P], const float (&y)[P],
                                                const float (&z)[P], float& mn, float& mx) {
+    if constexpr (P >= 2) {  // two points per packed instruction
 #pragma unroll
-    for (int i = 0; i < P; ++i) {
+        for (int i = 0; i < P; i += 2) {
+            f2 X, Y, Z, y0, y1, y2;
+            to_cam_pk(h, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, X, Y, Z, y0, y1, y2);
+            const f2 p = soft_vis_pk<PINHOLE>(cc, X, Y, Z, nullptr);
+            mn = fminf(mn, fminf(p.x, p.y));
+            mx = fmaxf(mx, fmaxf(p.x, p.y));
+        }
+    } else {
         float X, Y, Z, y0, y1, y2;
-        to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+        to_cam(h, x[0], y[0], z[0], X, Y, Z, y0, y1, y2);
         const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
         mn = fminf(mn, p);
         mx = fmaxf(mx, p);
@@ -340,6 +348,16 @@ __device__ __forceinline__ float log_odds(const CamConsts& cc, const WayHot& h, 
     return (to_log2(ph) - to_log2(1.0f - ph)) * 0.693147180559945f;
 }
 
+template <bool PINHOLE>
+__device__ __forceinline__ f2 log_odds_pk(const CamConsts& cc, const WayHot& h, f2 X, f2 Y, f2 Z) {
+    const f2 p = soft_vis_pk<PINHOLE>(cc, X, Y, Z, nullptr);
+    f2 ph = (p - pk_splat(h.a)) * pk_splat(h.invM);
+    ph = f2{__builtin_amdgcn_fmed3f(ph.x, 0.5f, cc.clip_hi), __builtin_amdgcn_fmed3f(ph.y, 0.5f, cc.clip_hi)};
+    const f2 q = pk_splat(1.0f) - ph;
+    const f2 l = f2{to_log2(ph.x), to_log2(ph.y)} - f2{to_log2(q.x), to_log2(q.y)};
+    return l * pk_splat(0.693147180559945f);
+}
+
 template <int P, bool PINHOLE, bool CULL>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, float* __restrict__ lo_sum) {
@@ -372,11 +390,19 @@ k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, 
         for (int v = 0; v < V; ++v) {
             const WayHot h = hot[v];
             degenerate |= !(h.invM < INFINITY);
+            if constexpr (P >= 2) {
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
+                for (int i = 0; i < P; i += 2) {
+                    f2 X, Y, Z, y0, y1, y2;
+                    to_cam_pk(h, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, X, Y, Z, y0, y1, y2);
+                    const f2 lo = log_odds_pk<PINHOLE>(cc, h, X, Y, Z);
+                    acc[i] += lo.x;
+                    acc[i + 1] += lo.y;
+                }
+            } else {
                 float X, Y, Z, y0, y1, y2;
-                to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
-                acc[i] += log_odds<PINHOLE>(cc, h, X, Y, Z);
+                to_cam(h, x[0], y[0], z[0], X, Y, Z, y0, y1, y2);
+                acc[0] += log_odds<PINHOLE>(cc, h, X, Y, Z);
             }
         }
     }
@@ -437,11 +463,37 @@ k_reward_finish(const double* __restrict__ part, int nparts, int64_t n, float ep
 #define TO_BWD_NSUM 14
 
 template <bool PINHOLE>
+__device__ __forceinline__ bool bwd_accum(const CamConsts& cc, const WayHot& h, float M, const Vis& s, float X, float Y,
+                                          float Z, float y0, float y1, float y2, float gn, bool valid,
+                                          float (&acc)[TO_BWD_NSUM], float* __restrict__ tb);
+
+template <bool PINHOLE>
 __device__ __forceinline__ bool bwd_eval(const CamConsts& cc, const WayHot& h, float M, float X, float Y, float Z,
                                          float y0, float y1, float y2, float gn, bool valid, float (&acc)[TO_BWD_NSUM],
                                          float* __restrict__ tb) {
     Vis s;
-    const float p = soft_vis<PINHOLE>(cc, X, Y, Z, &s);
+    soft_vis<PINHOLE>(cc, X, Y, Z, &s);
+    return bwd_accum<PINHOLE>(cc, h, M, s, X, Y, Z, y0, y1, y2, gn, valid, acc, tb);
+}
+
+// the same for two points whose visibility is computed with packed arithmetic
+template <bool PINHOLE>
+__device__ __forceinline__ bool bwd_eval_pk(const CamConsts& cc, const WayHot& h, float M, f2 X, f2 Y, f2 Z, f2 y0, f2 y1,
+                                            f2 y2, float gn0, float gn1, bool valid0, bool valid1,
+                                            float (&acc)[TO_BWD_NSUM], float* __restrict__ tb) {
+    Vis2 s2;
+    soft_vis_pk<PINHOLE>(cc, X, Y, Z, &s2);
+    const Vis sa = {s2.p.x, s2.S.x, s2.u.x, s2.v.x, s2.rz.x}, sb = {s2.p.y, s2.S.y, s2.u.y, s2.v.y, s2.rz.y};
+    const bool a = bwd_accum<PINHOLE>(cc, h, M, sa, X.x, Y.x, Z.x, y0.x, y1.x, y2.x, gn0, valid0, acc, tb);
+    const bool b = bwd_accum<PINHOLE>(cc, h, M, sb, X.y, Y.y, Z.y, y0.y, y1.y, y2.y, gn1, valid1, acc, tb);
+    return a || b;
+}
+
+template <bool PINHOLE>
+__device__ __forceinline__ bool bwd_accum(const CamConsts& cc, const WayHot& h, float M, const Vis& s, float X, float Y,
+                                          float Z, float y0, float y1, float y2, float gn, bool valid,
+                                          float (&acc)[TO_BWD_NSUM], float* __restrict__ tb) {
+    const float p = s.p;
     const float pp = p - h.a;
     const float ph = pp * h.invM;
     const bool act = (ph >= 0.5f) && (ph <= cc.clip_hi);
@@ -524,11 +576,18 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
 #pragma unroll
             for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
             bool any_act = false;
+            if constexpr (P >= 2) {
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
+                for (int i = 0; i < P; i += 2) {
+                    f2 X, Y, Z, y0, y1, y2;
+                    to_cam_pk(h, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, X, Y, Z, y0, y1, y2);
+                    any_act |= bwd_eval_pk<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], gn[i + 1], valid[i], valid[i + 1],
+                                                    acc, ties + (int64_t)v * 32);
+                }
+            } else {
                 float X, Y, Z, y0, y1, y2;
-                to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
-                any_act |= bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], valid[i], acc, ties + (int64_t)v * 32);
+                to_cam(h, x[0], y[0], z[0], X, Y, Z, y0, y1, y2);
+                any_act |= bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[0], valid[0], acc, ties + (int64_t)v * 32);
             }
             // every pair has been evaluated; when no lane of the wave was active all 14 sums are exact zeros
             // and the cross-lane reduction of zeros is skipped
