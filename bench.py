@@ -36,6 +36,21 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 ALGO_BYTES = {"k_traj_pass1": 12.0, "k_traj_pass2": 20.0, "k_traj_bwd": 16.0}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_bench_dense_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes), or None."""
+    path = os.path.join(REPO, "profiles", "r01_bench_dense_pmc.json")
+    try:
+        with open(path) as f:
+            ks = json.load(f)["kernels"]
+        for name, v in ks.items():
+            if kernel in name and "hbm_bytes_per_launch_corrected" in v:
+                return float(v["hbm_bytes_per_launch_corrected"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(points, poses, quats, n_wps_sample, budget_s=12.0):
     """The oracle (oracle/vis_oracle.c, f32, OpenMP over the host cores this process may use) on a bounded
     sample of the same workload: fwd+bwd over `n_wps_sample` of the waypoints, repeated for ~budget_s."""
@@ -158,7 +173,10 @@ def main():
                        "mode": "dense: every (point, waypoint) pair evaluated, no data-dependent skipping",
                        "loss_vis": float(out[0][1].item())},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
+                         "traffic_note": "HBM bytes per launch from profiles/r01_bench_dense_pmc.json (separate --pmc "
+                                         "passes of this command); far below the algorithmic bytes: the kernels keep "
+                                         "points in registers and loop over waypoints, so they are VALU-issue bound",
                          "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in kern.items()},
                          "algorithmic_bytes_per_eval": ALGO_BYTES[dom],
                          "fwd_bwd_frac_of_48B_per_eval_roofline": value / n_gpus * 48.0 / (HBM_PEAK_GBS * 1e9)},
