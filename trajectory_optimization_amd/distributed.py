@@ -32,7 +32,13 @@ class WaypointShard:
 
     def allreduce_sum(self, t):
         if self.world_size > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                # rehearsal setups (several ranks on one GPU, gloo): stage through the host; RCCL reduces in place
+                h = t.detach().cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
 
