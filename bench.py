@@ -143,7 +143,7 @@ def main():
         _lib.check(L.tohip_profile_read(ms, cnt), "tohip_profile_read")
         L.tohip_profile_enable(0)
         if n_gpus > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         kern = {L.tohip_profile_name(i).decode(): (ms[i], cnt[i]) for i in range(5) if cnt[i] > 0}

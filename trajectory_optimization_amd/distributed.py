@@ -50,12 +50,16 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available()
+    backend = backend or os.environ.get("TOHIP_DIST_BACKEND")  # "gloo": rehearse N ranks on fewer GPUs
+    if use_gpu and backend == "gloo":
+        local = local % torch.cuda.device_count()
     device = torch.device(f"cuda:{local}") if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        kw = {"device_id": device} if use_gpu else {}
-        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world, **kw)
+        backend = backend or ("nccl" if use_gpu else "gloo")
+        kw = {"device_id": device} if (use_gpu and backend == "nccl") else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, device
