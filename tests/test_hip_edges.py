@@ -56,7 +56,8 @@ def test_tiny_and_ragged_clouds(dev, n):
             assert np.isnan(f["rewards"]).all() and np.isnan(r).all()
             continue
         np.testing.assert_allclose(r, f["rewards"], rtol=2e-5, atol=2e-6)
-        np.testing.assert_allclose(mm[:, 0], f["pmin"], rtol=1e-5, atol=1e-30)
+        # min p is exp(-arg) with arg ~ 50: its f32 relative error is ~|arg| * 2^-23 (the reference's too)
+        np.testing.assert_allclose(mm[:, 0], f["pmin"], rtol=2e-4, atol=1e-30)
         np.testing.assert_allclose(mm[:, 1], f["pmax"], rtol=1e-5, atol=1e-30)
         assert rel_inf(pg, opg) < 1e-5 and rel_inf(qg, oqg) < 1e-5
 

@@ -428,7 +428,8 @@ k_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, int64_t
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
         const float lo = lo_sum[i];
-        const float r = to_rcp(1.0f + to_exp(-lo));
+        float r = to_rcp(1.0f + to_exp(-lo));
+        if (lo != lo) r = lo;  // a degenerate waypoint (max == min) makes the reference's rewards NaN: propagate
         rewards[perm[i]] = r;
         s += (double)r;
     }
@@ -551,7 +552,8 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         valid[i] = base + i < cv.n;  // pads carry no gradient
-        const float r = to_rcp(1.0f + to_exp(-lo[i]));  // == k_reward's value of rewards[perm[base+i]]
+        float r = to_rcp(1.0f + to_exp(-lo[i]));  // == k_reward's value of rewards[perm[base+i]]
+        if (lo[i] != lo[i]) r = lo[i];
         float gr = coef;
         if (grad_rewards) {
             const int pi = cv.perm[base + i];  // the caller's index (-1 for pads)
