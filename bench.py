@@ -75,6 +75,27 @@ def cpu_baseline(points, poses, quats, n_wps_sample, budget_s=12.0):
                       f"oracle f32 (C + OpenMP), {dt:.2f} s"}
 
 
+def hpr_leg(points, device):
+    """Hidden-point removal (flip + convex hull) of the same cloud seen from the origin: not bandwidth-characterisable,
+    reported as time and hull points/s, next to scipy/Qhull — the hull the reference calls — on one host core."""
+    from trajectory_optimization_amd import ops
+    from oracle import oracle
+    P = torch.from_numpy(points).to(device)
+    ops.hidden_pts_removal(P)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        idx, _ = ops.hidden_pts_removal(P)
+    torch.cuda.synchronize(device)
+    gpu_s = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    ref, _ = oracle.hidden_pts_removal(points)
+    cpu_s = time.perf_counter() - t0
+    return {"points": int(points.shape[0]), "visible": int(idx.numel()), "gpu_ms": 1e3 * gpu_s,
+            "hull_points_per_s": points.shape[0] / gpu_s, "qhull_ms_host_1core": 1e3 * cpu_s,
+            "index_set_equal_to_qhull": bool(np.array_equal(idx.cpu().numpy().astype(np.int64), ref))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +210,7 @@ def main():
             "note": "library default: pairs whose log-odds term is provably exactly 0 are skipped via a "
                     "Morton-sorted cloud, per-256-point bounding spheres and a distance bound on p"}
         if n_gpus == 1 and args.cpu_wps > 0:
+            line["hpr"] = hpr_leg(pts, device)
             line["cpu_baseline"] = cpu_baseline(pts, poses_all, quats_all, args.cpu_wps)
         print(json.dumps(line), flush=True)
     if n_gpus > 1:

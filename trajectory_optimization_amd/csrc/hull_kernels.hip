@@ -27,7 +27,9 @@ namespace hull {
 
 constexpr int kNone = -1;
 constexpr int kCtrlNFaces = 0, kCtrlAnyOutside = 1, kCtrlChanged = 2, kCtrlError = 3, kCtrlAccepted = 4,
-              kCtrlRound = 5, kCtrlInts = 16;
+              kCtrlRound = 5, kCtrlChanged2 = 6, kCtrlAnyOutside2 = 7, kCtrlAccepted2 = 9 /* the round's values, published by
+              k_commit for the host while the live counters are cleared for the next round; [8] = staged face counter */,
+              kCtrlInts = 16;
 constexpr int kErrCapacity = 1, kErrFlat = 2, kErrTopology = 4;
 
 struct Bufs {
@@ -124,6 +126,27 @@ __device__ __forceinline__ void set_plane(const Bufs& b, int f) {
     b.nz[f] = ux * vy - uy * vx;
 }
 
+// atomicMax of `key` into fmax[f] for every lane with f >= 0; when all live lanes of the wave share one face the
+// maximum is reduced in the wave first and ONE atomic is issued (same-address atomics serialise at ~90/us, and
+// in the early rounds a handful of faces own a million points).  Must be called by all lanes of the wave.
+__device__ __forceinline__ void wave_face_max(const Bufs& b, int f, unsigned long long key) {
+    unsigned long long todo = __ballot(f >= 0);
+    // up to 8 distinct faces per wave are reduced in the wave and cost one atomic each; the rest go lane by lane
+    for (int it = 0; it < 8 && todo != 0ull; ++it) {
+        const int f0 = __shfl(f, __builtin_ctzll(todo));
+        const bool mine = f == f0;
+        unsigned long long m = mine ? key : 0ull;
+        for (int s = 32; s > 0; s >>= 1) {
+            const unsigned long long o = ((unsigned long long)(unsigned)__shfl_xor((int)(m >> 32), s) << 32) | (unsigned)__shfl_xor((int)m, s);
+            m = o > m ? o : m;
+        }
+        if ((threadIdx.x & 63) == 0) atomicMax(&b.fmax[f0], m);
+        todo &= ~__ballot(mine);
+        if (mine) f = kNone;
+    }
+    if (f >= 0) atomicMax(&b.fmax[f], key);
+}
+
 __global__ void __launch_bounds__(TO_BLOCK)
 k_load(Bufs b, const float* __restrict__ pts, int n, int with_origin) {
     const int stride = gridDim.x * TO_BLOCK;
@@ -211,6 +234,8 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
             set_plane(b, f);
             b.fflags[f] = 1;
             b.fowner[f] = kNone;
+            b.fmax[f] = 0ull;
+            b.fapex[f] = 0x7fffffff;
         }
         b.ctrl[kCtrlNFaces] = 4;
         b.ctrl[kCtrlNFaces + 8] = 4;  // staged face counter (k_new_faces allocates from it, k_commit publishes it)
@@ -222,52 +247,47 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
     const int stride = gridDim.x * TO_BLOCK;
     int sv[4];
     sv[0] = b.fv[0]; sv[1] = b.fv[1]; sv[2] = b.fv[2]; sv[3] = b.fv[5];
-    for (int i = blockIdx.x * TO_BLOCK + threadIdx.x; i < b.m1; i += stride) {
-        if (i == sv[0] || i == sv[1] || i == sv[2] || i == sv[3]) continue;
+    const int nloop = (b.m1 + stride - 1) / stride;
+    for (int it = 0; it < nloop; ++it) {
+        const int i = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
         double best = 0.0; int bf = kNone;
-        for (int f = 0; f < 4; ++f) { const double d = fdist(b, f, i); if (d > best) { best = d; bf = f; } }
-        b.pface[i] = bf;
+        if (i < b.m1 && !(i == sv[0] || i == sv[1] || i == sv[2] || i == sv[3])) {
+            for (int f = 0; f < 4; ++f) { const double d = fdist(b, f, i); if (d > best) { best = d; bf = f; } }
+            b.pface[i] = bf;
+        }
+        wave_face_max(b, bf, dkey(best));
     }
 }
 
 // ---- round --------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TO_BLOCK) k_round_reset(Bufs b) {
+    // per-round state of every face; faces that still have points outside them become candidates (owner = self)
     const int nf = b.ctrl[kCtrlNFaces];
     const int stride = gridDim.x * TO_BLOCK;
-    for (int f = blockIdx.x * TO_BLOCK + threadIdx.x; f < nf; f += stride) {
-        b.fmax[f] = 0ull; b.fapex[f] = 0x7fffffff; b.fowner[f] = kNone; b.nfhead[f] = kNone;
-        b.fflags[f] &= 1;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { b.ctrl[kCtrlAnyOutside] = 0; b.ctrl[kCtrlAccepted] = 0; }
-}
-
-__global__ void __launch_bounds__(TO_BLOCK) k_far_max(Bufs b) {
-    const int stride = gridDim.x * TO_BLOCK;
     bool any = false;
-    for (int i = blockIdx.x * TO_BLOCK + threadIdx.x; i < b.m1; i += stride) {
-        const int f = b.pface[i];
-        if (f < 0) continue;
-        any = true;
-        atomicMax(&b.fmax[f], dkey(fdist(b, f, i)));
+    for (int f = blockIdx.x * TO_BLOCK + threadIdx.x; f < nf; f += stride) {
+        const int alive = b.fflags[f] & 1;
+        const bool cand = alive && b.fapex[f] != 0x7fffffff;  // fmax / fapex persist: an outside set is fixed at creation
+        b.fowner[f] = cand ? f : kNone;
+        b.nfhead[f] = kNone;
+        b.fflags[f] = alive | (cand ? 2 : 0);
+        any |= cand;
     }
-    if (__any(any) && (threadIdx.x & 63) == 0) b.ctrl[kCtrlAnyOutside] = 1;
+    if (any) b.ctrl[kCtrlAnyOutside] = 1;
 }
 
-__global__ void __launch_bounds__(TO_BLOCK) k_far_arg(Bufs b) {
+// apex of the faces with id >= f_lo (the faces created since the last call): lowest-index point among those at
+// the face's maximum distance.  A face's outside set never changes after its creation round, so its apex is
+// computed once; older faces keep theirs.
+__global__ void __launch_bounds__(TO_BLOCK) k_far_arg(Bufs b, int f_lo) {
     const int stride = gridDim.x * TO_BLOCK;
     for (int i = blockIdx.x * TO_BLOCK + threadIdx.x; i < b.m1; i += stride) {
         const int f = b.pface[i];
-        if (f < 0) continue;
+        if (f < f_lo) continue;
         if (dkey(fdist(b, f, i)) == b.fmax[f]) atomicMin(&b.fapex[f], i);
     }
 }
 
-__global__ void __launch_bounds__(TO_BLOCK) k_owner_init(Bufs b) {
-    const int nf = b.ctrl[kCtrlNFaces];
-    const int stride = gridDim.x * TO_BLOCK;
-    for (int f = blockIdx.x * TO_BLOCK + threadIdx.x; f < nf; f += stride)
-        if ((b.fflags[f] & 1) && b.fapex[f] != 0x7fffffff) { b.fowner[f] = f; b.fflags[f] |= 2; }
-}
 
 // each live face adopts the best-priority owner among its neighbours whose apex sees it
 __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b) {
@@ -310,13 +330,6 @@ __global__ void __launch_bounds__(TO_BLOCK) k_accept(Bufs b) {
     }
 }
 
-// candidates whose own face was taken over are not candidates
-__global__ void __launch_bounds__(TO_BLOCK) k_accept_fix(Bufs b) {
-    const int nf = b.ctrl[kCtrlNFaces];
-    const int stride = gridDim.x * TO_BLOCK;
-    for (int f = blockIdx.x * TO_BLOCK + threadIdx.x; f < nf; f += stride)
-        if ((b.fflags[f] & 2) && b.fowner[f] != f) b.fflags[f] &= ~2;
-}
 
 __device__ __forceinline__ bool owned_accepted(const Bufs& b, int g, int* owner) {
     const int o = b.fowner[g];
@@ -385,18 +398,23 @@ __global__ void __launch_bounds__(TO_BLOCK) k_link_faces(Bufs b, int nf_before) 
 // outside of, or retire inside the hull
 __global__ void __launch_bounds__(TO_BLOCK) k_reassign(Bufs b) {
     const int stride = gridDim.x * TO_BLOCK;
-    for (int i = blockIdx.x * TO_BLOCK + threadIdx.x; i < b.m1; i += stride) {
-        const int g = b.pface[i];
-        if (g < 0) continue;
+    const int nloop = (b.m1 + stride - 1) / stride;
+    for (int it = 0; it < nloop; ++it) {
+        const int i = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
+        double best = 0.0; int bf = kNone;
+        const int g = i < b.m1 ? b.pface[i] : kNone;
         int o;
-        if (!owned_accepted(b, g, &o)) continue;
-        if (i == b.fapex[o]) { b.pface[i] = kNone; continue; }
-        double best = 0.0; int bf = kNone, steps = 0;
-        for (int f = b.nfhead[o]; f >= 0 && steps < (1 << 20); f = b.nfnext[f], ++steps) {
-            const double d = fdist(b, f, i);
-            if (d > best) { best = d; bf = f; }
+        if (g >= 0 && owned_accepted(b, g, &o)) {
+            if (i != b.fapex[o]) {
+                int steps = 0;
+                for (int f = b.nfhead[o]; f >= 0 && steps < (1 << 20); f = b.nfnext[f], ++steps) {
+                    const double d = fdist(b, f, i);
+                    if (d > best) { best = d; bf = f; }
+                }
+            }
+            b.pface[i] = bf;  // the apex retires as a vertex; a point outside no new face retires inside the hull
         }
-        b.pface[i] = bf;
+        wave_face_max(b, bf, dkey(best));  // feeds the apex search of the new face
     }
 }
 
@@ -417,7 +435,12 @@ __global__ void __launch_bounds__(TO_BLOCK) k_commit(Bufs b, int nf_before) {
         if (nf > b.fcap) nf = b.fcap;
         b.ctrl[kCtrlNFaces] = nf;
         b.ctrl[kCtrlRound] += 1;
+        b.ctrl[kCtrlChanged2] = b.ctrl[kCtrlChanged];
+        b.ctrl[kCtrlAnyOutside2] = b.ctrl[kCtrlAnyOutside];
+        b.ctrl[kCtrlAccepted2] = b.ctrl[kCtrlAccepted];
         b.ctrl[kCtrlChanged] = 0;
+        b.ctrl[kCtrlAnyOutside] = 0;
+        b.ctrl[kCtrlAccepted] = 0;
     }
 }
 
@@ -489,6 +512,7 @@ static int build(const Bufs& b, const float* pts, int n, int with_origin, hipStr
     k_init<<<1, HULL_INIT_THREADS, 0, st>>>(b);
     TO_HIP_CHECK_LAUNCH();
     k_assign0<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);
+    k_far_arg<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, 0);
     TO_HIP_CHECK_LAUNCH();
     int h[kCtrlInts];
     hipError_t e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);
@@ -499,43 +523,55 @@ static int build(const Bufs& b, const float* pts, int n, int with_origin, hipStr
     int nf = h[kCtrlNFaces];
     const int max_rounds = 100000;
     int round = 0;
+    bool careful = false;  // after a round without progress: propagate ownership to convergence (host-checked)
+    int sweeps = 8;        // ownership sweeps per round, adapted from the previous round's convergence flag
     for (; round < max_rounds; ++round) {
         const int gf = nblocks(nf), gp = nblocks(b.m1);
         k_round_reset<<<gf, TO_BLOCK, 0, st>>>(b);
-        k_far_max<<<gp, TO_BLOCK, 0, st>>>(b);
-        k_far_arg<<<gp, TO_BLOCK, 0, st>>>(b);
-        k_owner_init<<<gf, TO_BLOCK, 0, st>>>(b);
         TO_HIP_CHECK_LAUNCH();
-        bool first = true;
-        while (true) {
-            k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);
-            k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);
-            TO_HIP_CHECK_LAUNCH();
-            e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);
-            if (e != hipSuccess) return (int)e;
-            e = hipStreamSynchronize(st);
-            if (e != hipSuccess) return (int)e;
-            if (h[kCtrlError]) return (h[kCtrlError] & kErrCapacity) ? TOHIP_ENOSPC : TOHIP_ENOTCONV;
-            if (first && !h[kCtrlAnyOutside]) goto done;
-            first = false;
-            if (!h[kCtrlChanged]) break;
+        if (!careful) {
+            // Fast path: a fixed number of propagation sweeps, no readback.  Unconverged ownership is safe — a
+            // candidate is accepted only if it owns every face its apex sees (k_accept) — it can only cost progress.
+            for (int it = 0; it < sweeps - 1; ++it) k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);
             e = hipMemsetAsync(b.ctrl + kCtrlChanged, 0, sizeof(int), st);
             if (e != hipSuccess) return (int)e;
+            k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);  // still changing here = not converged (seen in the round's readback)
+            TO_HIP_CHECK_LAUNCH();
+        } else {
+            while (true) {
+                e = hipMemsetAsync(b.ctrl + kCtrlChanged, 0, sizeof(int), st);
+                if (e != hipSuccess) return (int)e;
+                k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);
+                k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);
+                TO_HIP_CHECK_LAUNCH();
+                e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);
+                if (e != hipSuccess) return (int)e;
+                e = hipStreamSynchronize(st);
+                if (e != hipSuccess) return (int)e;
+                if (!h[kCtrlChanged]) break;
+            }
         }
         k_accept<<<gf, TO_BLOCK, 0, st>>>(b);
-        k_accept_fix<<<gf, TO_BLOCK, 0, st>>>(b);
         k_new_faces<<<gf, TO_BLOCK, 0, st>>>(b);
         k_link_faces<<<gf, TO_BLOCK, 0, st>>>(b, nf);
-        k_reassign<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);
+        k_reassign<<<gp, TO_BLOCK, 0, st>>>(b);
+        k_far_arg<<<gp, TO_BLOCK, 0, st>>>(b, nf);  // apexes of the faces created this round (ids >= nf)
         k_kill_faces<<<gf, TO_BLOCK, 0, st>>>(b, nf);
         k_commit<<<gf, TO_BLOCK, 0, st>>>(b, nf);
         TO_HIP_CHECK_LAUNCH();
-        e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);
+        e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);  // the round's one readback
         if (e != hipSuccess) return (int)e;
         e = hipStreamSynchronize(st);
         if (e != hipSuccess) return (int)e;
         if (h[kCtrlError]) return (h[kCtrlError] & kErrCapacity) ? TOHIP_ENOSPC : TOHIP_ENOTCONV;
-        if (h[kCtrlAccepted] <= 0) return TOHIP_ENOTCONV;  // no progress: inconsistent predicates
+        if (!h[kCtrlAnyOutside2]) break;  // no point outside any face: the round was a no-op and the hull is complete
+        if (h[kCtrlAccepted2] <= 0) {
+            if (careful) return TOHIP_ENOTCONV;  // converged ownership always admits the best candidate: inconsistent predicates
+            careful = true;
+        } else {
+            if (!careful) sweeps = h[kCtrlChanged2] ? (sweeps < 64 ? sweeps * 2 : 64) : (sweeps > 4 ? sweeps - 1 : 4);
+            careful = false;
+        }
         nf = h[kCtrlNFaces];
     }
 done:
