@@ -90,8 +90,15 @@ size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual);
  * minmax[v] = (min p, max(p - min p)) per virtual waypoint, kept for the backward.
  * replaces model.py:217-231. */
 int tohip_traj_forward(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
-                       const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, float *lo_sum,
-                       float *minmax, void *workspace, size_t workspace_bytes, void *stream);
+                       const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits,
+                       float *lo_sum, float *minmax, void *workspace, size_t workspace_bytes, void *stream);
+/* occlusion_bits (may be NULL = nothing occluded): per virtual waypoint a row of Npad/32 words, bit i = 1 when the
+ * packed (sorted) point i is NOT occluded from that waypoint; an occluded pair has p = 0.  The per-waypoint
+ * analogue of ModelPose's occlusion mask (model.py:112-115) that the reference leaves as a TODO (tools.py:61-62).
+ * Rows are built with tohip_occlusion_row from a hard-frustum cull + HPR (or z-buffer) of the camera-frame cloud. */
+int tohip_inverse_permutation(const void *packed, int64_t n_points, int32_t *inv_perm, void *stream);
+int tohip_occlusion_row(int64_t n_points, const int32_t *inv_perm, const int32_t *kept_idx, const int32_t *kept_count,
+                        const int32_t *visible_idx_in_kept, const int32_t *visible_count, uint32_t *row, void *stream);
 
 /* rewards[0..N) = sigmoid(lo_sum) in the CALLER'S point order (model.py:237); scalars[0] = mean(rewards),
  * scalars[1] = loss_vis = 1/(mean+eps) (model.py:246), scalars[2] = -loss_vis^2/N (d loss_vis / d reward_n). */
@@ -104,8 +111,8 @@ int tohip_traj_reward(const void *packed, const float *lo_sum, int64_t n_points,
  * criterion built on model.rewards, as torch autograd would hand it over), or, when grad_rewards is NULL,
  * the fused visibility loss: scalars (from tohip_traj_reward) and gout = device pointer to dL/d loss_vis. */
 int tohip_traj_backward(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
-                        const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, const float *lo_sum,
-                        const float *grad_rewards, const float *scalars, const float *minmax, const float *gout,
+                        const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits,
+                        const float *lo_sum, const float *grad_rewards, const float *scalars, const float *minmax, const float *gout,
                         float *poses_grad, float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- ModelPose (model.py:98-127) -------------------------------------------------------------- */

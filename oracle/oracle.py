@@ -43,9 +43,11 @@ _DT = {"f32": np.float32, "f64": np.float64}
 c_f, c_d, c_i64, c_int = ctypes.c_float, ctypes.c_double, ctypes.c_int64, ctypes.c_int
 
 
-def traj_forward(points, poses, quats, K, img_w, img_h, min_dist=1.0, max_dist=5.0, prec="f32"):
-    """Visibility term of ModelTraj.forward over the given (already subsampled) waypoints."""
+def traj_forward(points, poses, quats, K, img_w, img_h, min_dist=1.0, max_dist=5.0, prec="f32", occ=None):
+    """Visibility term of ModelTraj.forward over the given (already subsampled) waypoints.
+    occ: optional (W,N) 0/1 occlusion masks multiplied into p per waypoint."""
     pts, poses, quats, K = _f32(points), _f32(poses), _f32(quats), _f32(K)
+    occ = _f32(occ) if occ is not None else None
     N, W = pts.shape[0], poses.shape[0]
     dt = _DT[prec]
     lo, rew = np.empty(N, dt), np.empty(N, dt)
@@ -53,10 +55,10 @@ def traj_forward(points, poses, quats, K, img_w, img_h, min_dist=1.0, max_dist=5
     mean, loss = c_d(), c_d()
     fn = getattr(lib(), "oracle_traj_forward_" + prec)
     rc = fn(_ptr(pts), c_i64(N), _ptr(poses), _ptr(quats), c_i64(W), _ptr(K), c_f(img_w), c_f(img_h),
-            c_f(min_dist), c_f(max_dist), _ptr(lo), _ptr(rew), _ptr(pmin), _ptr(pmax),
+            c_f(min_dist), c_f(max_dist), _ptr(occ), _ptr(lo), _ptr(rew), _ptr(pmin), _ptr(pmax),
             ctypes.byref(mean), ctypes.byref(loss))
     assert rc == 0
-    return dict(lo_sum=lo, rewards=rew, pmin=pmin, pmax=pmax, mean_reward=mean.value, loss_vis=loss.value)
+    return dict(lo_sum=lo, rewards=rew, pmin=pmin, pmax=pmax, mean_reward=mean.value, loss_vis=loss.value, occ=occ)
 
 
 def traj_backward(points, poses, quats, K, img_w, img_h, fwd, gout=1.0, min_dist=1.0, max_dist=5.0, prec="f32"):
@@ -67,7 +69,8 @@ def traj_backward(points, poses, quats, K, img_w, img_h, fwd, gout=1.0, min_dist
     rew = np.ascontiguousarray(fwd["rewards"], dtype=dt)
     fn = getattr(lib(), "oracle_traj_backward_" + prec)
     rc = fn(_ptr(pts), c_i64(N), _ptr(poses), _ptr(quats), c_i64(W), _ptr(K), c_f(img_w), c_f(img_h),
-            c_f(min_dist), c_f(max_dist), _ptr(rew), c_d(fwd["mean_reward"]), c_d(gout), _ptr(pg), _ptr(qg))
+            c_f(min_dist), c_f(max_dist), _ptr(fwd.get("occ")), _ptr(rew), c_d(fwd["mean_reward"]), c_d(gout), _ptr(pg),
+            _ptr(qg))
     assert rc == 0
     return pg, qg
 
@@ -132,6 +135,26 @@ def spherical_flip(points, param=2):
     assert lib().oracle_spherical_flip(_ptr(pts), c_i64(pts.shape[0]), c_d(float(param)), _ptr(out),
                                        ctypes.byref(rad)) == 0
     return out, rad.value
+
+
+def occlusion_masks(points, poses, quats, K, img_w, img_h, min_dist=1.0, max_dist=15.0, param=2):
+    """Per-waypoint occlusion masks (W,N) f32 by the reference's hard per-camera pipeline
+    (/root/reference/src/pc_processor.py:158-187): to_camera_frame (normalised quaternion, model.py:50-57) ->
+    get_cam_frustum_pts -> hidden_pts_removal of the kept points seen from the camera centre.  A point inside the
+    hard frustum that HPR hides gets 0; everything else 1 (the soft weights of the model already fade it out)."""
+    pts = _f32(points)
+    W, N = len(poses), pts.shape[0]
+    occ = np.ones((W, N), np.float32)
+    for w in range(W):
+        cam = to_camera_frame(pts, quats[w], poses[w], normalize=True)
+        d, f = frustum_masks(np.ascontiguousarray(cam.T), K, img_w, img_h, min_dist, max_dist)
+        kept = np.flatnonzero(d & f)
+        if len(kept) >= 4:
+            vis, _ = hidden_pts_removal(cam[kept], param)
+            hidden = np.ones(len(kept), bool)
+            hidden[vis] = False
+            occ[w, kept[hidden]] = 0.0
+    return occ
 
 
 def hidden_pts_removal(points, param=2):

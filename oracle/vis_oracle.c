@@ -192,8 +192,10 @@ static void FN(pose_chain)(const FN(cam_t) * cam, const double Gt[3], const doub
  * xyz: (N,3) row-major f32.  Outputs (caller-allocated): lo_sum[N], rewards[N], pmin[W] (=min p),
  * pmax[W] (=max(p - min p)), *mean_reward, *loss_vis.  scratch: N REALs. */
 int FN(oracle_traj_forward)(const float *xyz, int64_t N, const float *poses, const float *quats, int64_t W,
-                            const float *K, float img_w, float img_h, float min_dist, float max_dist,
+                            const float *K, float img_w, float img_h, float min_dist, float max_dist, const float *occ,
                             REAL *lo_sum, REAL *rewards, REAL *pmin, REAL *pmax, double *mean_reward, double *loss_vis) {
+    /* occ (may be NULL): (W,N) 0/1 occlusion masks multiplied into p, the per-waypoint analogue of
+     * ModelPose's `mask = occlusion_mask * mask` (model.py:112-115); SURVEY.md 8f.3 */
     FN(consts_t) k;
     FN(make_consts)(&k, K, img_w, img_h, min_dist, max_dist);
     REAL *p = (REAL *)malloc(sizeof(REAL) * (size_t)(N > 0 ? N : 1));
@@ -208,6 +210,7 @@ int FN(oracle_traj_forward)(const float *xyz, int64_t N, const float *poses, con
             REAL x[3] = {(REAL)xyz[3 * n], (REAL)xyz[3 * n + 1], (REAL)xyz[3 * n + 2]}, c[3];
             FN(to_cam)(&cam, x, c);
             p[n] = FN(soft_vis)(&k, c, NULL);
+            if (occ) p[n] = (REAL)occ[w * N + n] * p[n];
             if (p[n] < a) a = p[n];
         }
         REAL M = -INFINITY;
@@ -242,7 +245,7 @@ int FN(oracle_traj_forward)(const float *xyz, int64_t N, const float *poses, con
 /* Backward of loss_vis w.r.t. the evaluated waypoints' (poses, quats).  rewards/pmin/pmax from the
  * forward; gout = dL/d loss_vis.  Outputs poses_grad[W*3], quats_grad[W*4]. */
 int FN(oracle_traj_backward)(const float *xyz, int64_t N, const float *poses, const float *quats, int64_t W,
-                             const float *K, float img_w, float img_h, float min_dist, float max_dist,
+                             const float *K, float img_w, float img_h, float min_dist, float max_dist, const float *occ,
                              const REAL *rewards, double mean_reward, double gout, REAL *poses_grad, REAL *quats_grad) {
     FN(consts_t) k;
     FN(make_consts)(&k, K, img_w, img_h, min_dist, max_dist);
@@ -259,6 +262,7 @@ int FN(oracle_traj_backward)(const float *xyz, int64_t N, const float *poses, co
             REAL x[3] = {(REAL)xyz[3 * n], (REAL)xyz[3 * n + 1], (REAL)xyz[3 * n + 2]}, c[3];
             FN(to_cam)(&cam, x, c);
             p[n] = FN(soft_vis)(&k, c, NULL);
+            if (occ) p[n] = (REAL)occ[w * N + n] * p[n];
             if (p[n] < a) a = p[n];
         }
         REAL M = -INFINITY;
@@ -287,6 +291,7 @@ int FN(oracle_traj_backward)(const float *xyz, int64_t N, const float *poses, co
                 FN(to_cam)(&cam, x, c);
                 FN(soft_vis)(&k, c, &s);
                 FN(dvis_dc)(&k, c, &s, g);
+                if (occ) for (int i = 0; i < 3; ++i) g[i] = (REAL)occ[w * N + n] * g[i]; /* d(occ*p)/dc */
                 const double y[3] = {(double)x[0] - (double)cam.t[0], (double)x[1] - (double)cam.t[1], (double)x[2] - (double)cam.t[2]};
                 if (act) {
                     const double r = (double)rewards[n];

@@ -118,6 +118,17 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ src, int64_t 
     }
 }
 
+// Optional per-(virtual waypoint, point) occlusion bits in packed order: row v holds npad bits,
+// bit i = 1 when sorted point i is NOT occluded from waypoint v.  om[] = 1.0f / 0.0f multipliers of p; without a
+// bit array every multiplier is exactly 1 (p * 1.0f == p, so the unoccluded results do not change by a bit).
+template <int P>
+__device__ __forceinline__ void load_occ(const uint32_t* __restrict__ occ, int64_t occw, int v, int64_t base, float (&om)[P]) {
+    unsigned bits = ~0u;
+    if (occ) bits = occ[(int64_t)v * occw + (base >> 5)] >> (unsigned)(base & 31);
+#pragma unroll
+    for (int i = 0; i < P; ++i) om[i] = ((bits >> i) & 1u) ? 1.0f : 0.0f;
+}
+
 // wave-uniform bounding sphere of the 256-point tile this wave's points belong to
 __device__ __forceinline__ float4 wave_tile_bound(const CloudView& cv, int64_t base) {
     const int tile = __builtin_amdgcn_readfirstlane((int)(base >> 8));
@@ -181,7 +192,8 @@ __device__ __forceinline__ unsigned long long tile_survivors(const WayHot* __res
 
 template <bool PINHOLE>
 __global__ void __launch_bounds__(TO_BLOCK)
-k_traj_probe(CloudView cv, const WayHot* __restrict__ hot, WayAux* __restrict__ aux, CamConsts cc, int step) {
+k_traj_probe(CloudView cv, const WayHot* __restrict__ hot, WayAux* __restrict__ aux, CamConsts cc, int step,
+             const uint32_t* __restrict__ occ, int64_t occw) {
     __shared__ float smx[TO_BLOCK];
     __shared__ int szero[TO_BLOCK];
     const int v = blockIdx.x, t = threadIdx.x;
@@ -191,7 +203,9 @@ k_traj_probe(CloudView cv, const WayHot* __restrict__ hot, WayAux* __restrict__ 
     for (int64_t i = (int64_t)t * step; i < cv.n; i += (int64_t)TO_BLOCK * step) {
         float X, Y, Z, y0, y1, y2;
         to_cam(h, cv.soa[i], cv.soa[cv.npad + i], cv.soa[2 * cv.npad + i], X, Y, Z, y0, y1, y2);
-        const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
+        float om[1];
+        load_occ<1>(occ, occw, v, i, om);
+        const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr) * om[0];
         mx = fmaxf(mx, p);
         zero |= (p == 0.f);
     }
@@ -216,20 +230,20 @@ k_traj_probe(CloudView cv, const WayHot* __restrict__ hot, WayAux* __restrict__ 
 
 template <int P, bool PINHOLE>
 __device__ __forceinline__ void pass1_dense_wp(const CamConsts& cc, const WayHot& h, const float (&x)[P], const float (&y)[P],
-                                               const float (&z)[P], float& mn, float& mx) {
+                                               const float (&z)[P], const float (&om)[P], float& mn, float& mx) {
     if constexpr (P >= 2) {  // two points per packed instruction
 #pragma unroll
         for (int i = 0; i < P; i += 2) {
             f2 X, Y, Z, y0, y1, y2;
             to_cam_pk(h, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, X, Y, Z, y0, y1, y2);
-            const f2 p = soft_vis_pk<PINHOLE>(cc, X, Y, Z, nullptr);
+            const f2 p = soft_vis_pk<PINHOLE>(cc, X, Y, Z, nullptr) * f2{om[i], om[i + 1]};
             mn = fminf(mn, fminf(p.x, p.y));
             mx = fmaxf(mx, fmaxf(p.x, p.y));
         }
     } else {
         float X, Y, Z, y0, y1, y2;
         to_cam(h, x[0], y[0], z[0], X, Y, Z, y0, y1, y2);
-        const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
+        const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr) * om[0];
         mn = fminf(mn, p);
         mx = fmaxf(mx, p);
     }
@@ -238,7 +252,7 @@ __device__ __forceinline__ void pass1_dense_wp(const CamConsts& cc, const WayHot
 template <int P, bool PINHOLE, bool CULL>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_pass1(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restrict__ aux, int V, int vtile,
-             CamConsts cc, float2* __restrict__ part, int nslots) {
+             CamConsts cc, float2* __restrict__ part, int nslots, const uint32_t* __restrict__ occ, int64_t occw) {
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * TO_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
@@ -250,7 +264,9 @@ k_traj_pass1(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restr
         for (int v = v0; v < v1; ++v) {
             const WayHot h = hot[v];
             float mn = INFINITY, mx = -INFINITY;
-            pass1_dense_wp<P, PINHOLE>(cc, h, x, y, z, mn, mx);
+            float om[P];
+            load_occ<P>(occ, occw, v, base, om);
+            pass1_dense_wp<P, PINHOLE>(cc, h, x, y, z, om, mn, mx);
             mn = wave_min63(mn);
             mx = wave_max63(mx);
             if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
@@ -268,16 +284,18 @@ k_traj_pass1(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restr
             const WayHot h = hot[v];
             const WayAux a = aux[v];
             float mn = INFINITY, mx = -INFINITY;
+            float om[P];
+            load_occ<P>(occ, occw, v, base, om);
             if (a.azero != 0.f) {
                 mn = 0.f;  // proven by the probe; only the max is searched, among points that can reach L
 #pragma unroll
                 for (int i = 0; i < P; ++i) {
                     float X, Y, Z, y0, y1, y2;
                     to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
-                    if (__any(dist2_mean(X, Y, Z, cc.mean) <= a.thr1)) mx = fmaxf(mx, soft_vis<PINHOLE>(cc, X, Y, Z, nullptr));
+                    if (__any(dist2_mean(X, Y, Z, cc.mean) <= a.thr1)) mx = fmaxf(mx, soft_vis<PINHOLE>(cc, X, Y, Z, nullptr) * om[i]);
                 }
             } else {
-                pass1_dense_wp<P, PINHOLE>(cc, h, x, y, z, mn, mx);
+                pass1_dense_wp<P, PINHOLE>(cc, h, x, y, z, om, mn, mx);
                 mn = wave_min63(mn);
             }
             mx = wave_max63(mx);
@@ -340,8 +358,8 @@ __global__ void k_set_minmax(WayHot* __restrict__ hot, WayAux* __restrict__ aux,
 // (model.py:226-231).  ATOMIC=false: one block column owns all waypoints and stores lo_sum once.
 
 template <bool PINHOLE>
-__device__ __forceinline__ float log_odds(const CamConsts& cc, const WayHot& h, float X, float Y, float Z) {
-    const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr);
+__device__ __forceinline__ float log_odds(const CamConsts& cc, const WayHot& h, float X, float Y, float Z, float om) {
+    const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr) * om;
     float ph = (p - h.a) * h.invM;
     ph = __builtin_amdgcn_fmed3f(ph, 0.5f, cc.clip_hi);
     // log(ph/(1-ph)) as a difference of logs: exactly 0 at ph = 0.5
@@ -349,8 +367,8 @@ __device__ __forceinline__ float log_odds(const CamConsts& cc, const WayHot& h, 
 }
 
 template <bool PINHOLE>
-__device__ __forceinline__ f2 log_odds_pk(const CamConsts& cc, const WayHot& h, f2 X, f2 Y, f2 Z) {
-    const f2 p = soft_vis_pk<PINHOLE>(cc, X, Y, Z, nullptr);
+__device__ __forceinline__ f2 log_odds_pk(const CamConsts& cc, const WayHot& h, f2 X, f2 Y, f2 Z, f2 om) {
+    const f2 p = soft_vis_pk<PINHOLE>(cc, X, Y, Z, nullptr) * om;
     f2 ph = (p - pk_splat(h.a)) * pk_splat(h.invM);
     ph = f2{__builtin_amdgcn_fmed3f(ph.x, 0.5f, cc.clip_hi), __builtin_amdgcn_fmed3f(ph.y, 0.5f, cc.clip_hi)};
     const f2 q = pk_splat(1.0f) - ph;
@@ -360,7 +378,8 @@ __device__ __forceinline__ f2 log_odds_pk(const CamConsts& cc, const WayHot& h, 
 
 template <int P, bool PINHOLE, bool CULL>
 __global__ void __launch_bounds__(TO_BLOCK)
-k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, float* __restrict__ lo_sum) {
+k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, float* __restrict__ lo_sum,
+             const uint32_t* __restrict__ occ, int64_t occw) {
     const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
     float x[P], y[P], z[P], acc[P];
     load_points<P>(cv.soa, cv.npad, base, x, y, z);
@@ -377,12 +396,14 @@ k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, 
                 const int v = vc + __builtin_ctzll(live);
                 live &= live - 1ull;
                 const WayHot h = hot[v];
+                float om[P];
+                load_occ<P>(occ, occw, v, base, om);
 #pragma unroll
                 for (int i = 0; i < P; ++i) {
                     float X, Y, Z, y0, y1, y2;
                     to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
                     // lanes beyond the bound get p_hat < 0.5 -> exactly 0, so evaluating them too changes nothing
-                    if (__any(dist2_mean(X, Y, Z, cc.mean) <= h.thr)) acc[i] += log_odds<PINHOLE>(cc, h, X, Y, Z);
+                    if (__any(dist2_mean(X, Y, Z, cc.mean) <= h.thr)) acc[i] += log_odds<PINHOLE>(cc, h, X, Y, Z, om[i]);
                 }
             }
         }
@@ -390,19 +411,21 @@ k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, 
         for (int v = 0; v < V; ++v) {
             const WayHot h = hot[v];
             degenerate |= !(h.invM < INFINITY);
+            float om[P];
+            load_occ<P>(occ, occw, v, base, om);
             if constexpr (P >= 2) {
 #pragma unroll
                 for (int i = 0; i < P; i += 2) {
                     f2 X, Y, Z, y0, y1, y2;
                     to_cam_pk(h, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, X, Y, Z, y0, y1, y2);
-                    const f2 lo = log_odds_pk<PINHOLE>(cc, h, X, Y, Z);
+                    const f2 lo = log_odds_pk<PINHOLE>(cc, h, X, Y, Z, f2{om[i], om[i + 1]});
                     acc[i] += lo.x;
                     acc[i + 1] += lo.y;
                 }
             } else {
                 float X, Y, Z, y0, y1, y2;
                 to_cam(h, x[0], y[0], z[0], X, Y, Z, y0, y1, y2);
-                acc[0] += log_odds<PINHOLE>(cc, h, X, Y, Z);
+                acc[0] += log_odds<PINHOLE>(cc, h, X, Y, Z, om[0]);
             }
         }
     }
@@ -470,20 +493,22 @@ __device__ __forceinline__ bool bwd_accum(const CamConsts& cc, const WayHot& h, 
 
 template <bool PINHOLE>
 __device__ __forceinline__ bool bwd_eval(const CamConsts& cc, const WayHot& h, float M, float X, float Y, float Z,
-                                         float y0, float y1, float y2, float gn, bool valid, float (&acc)[TO_BWD_NSUM],
-                                         float* __restrict__ tb) {
+                                         float y0, float y1, float y2, float gn, bool valid, float om,
+                                         float (&acc)[TO_BWD_NSUM], float* __restrict__ tb) {
     Vis s;
     soft_vis<PINHOLE>(cc, X, Y, Z, &s);
+    s.p *= om;  // an occluded pair has p = 0: inactive, and dp/dc = p * (...) = 0
     return bwd_accum<PINHOLE>(cc, h, M, s, X, Y, Z, y0, y1, y2, gn, valid, acc, tb);
 }
 
 // the same for two points whose visibility is computed with packed arithmetic
 template <bool PINHOLE>
 __device__ __forceinline__ bool bwd_eval_pk(const CamConsts& cc, const WayHot& h, float M, f2 X, f2 Y, f2 Z, f2 y0, f2 y1,
-                                            f2 y2, float gn0, float gn1, bool valid0, bool valid1,
+                                            f2 y2, float gn0, float gn1, bool valid0, bool valid1, f2 om,
                                             float (&acc)[TO_BWD_NSUM], float* __restrict__ tb) {
     Vis2 s2;
     soft_vis_pk<PINHOLE>(cc, X, Y, Z, &s2);
+    s2.p = s2.p * om;
     const Vis sa = {s2.p.x, s2.S.x, s2.u.x, s2.v.x, s2.rz.x}, sb = {s2.p.y, s2.S.y, s2.u.y, s2.v.y, s2.rz.y};
     const bool a = bwd_accum<PINHOLE>(cc, h, M, sa, X.x, Y.x, Z.x, y0.x, y1.x, y2.x, gn0, valid0, acc, tb);
     const bool b = bwd_accum<PINHOLE>(cc, h, M, sb, X.y, Y.y, Z.y, y0.y, y1.y, y2.y, gn1, valid1, acc, tb);
@@ -538,7 +563,7 @@ __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restrict__ aux, int V, int vtile,
            CamConsts cc, const float* __restrict__ lo_sum, const float* __restrict__ grad_rewards,
            const float* __restrict__ scalars, const float* __restrict__ gout, float* __restrict__ part, int nslots,
-           float* __restrict__ ties) {
+           float* __restrict__ ties, const uint32_t* __restrict__ occ, int64_t occw) {
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * TO_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
@@ -578,6 +603,8 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
             const WayHot h = hot[v];
             const float M = aux[v].M;
             bool any_act = false;
+            float om[P];
+            load_occ<P>(occ, occw, v, base, om);
             if constexpr (P >= 2) {
                 // phase 1 (packed, branch-free): visibility of every pair and whether any element needs the
                 // gradient path; phase 2 runs under ONE wave-uniform branch per waypoint
@@ -590,7 +617,8 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
                     const int i = 2 * k;
                     to_cam_pk(h, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, Xs[k], Ys[k], Zs[k], y0s[k], y1s[k],
                               y2s[k]);
-                    const f2 p = soft_vis_pk<PINHOLE>(cc, Xs[k], Ys[k], Zs[k], &s2[k]);
+                    s2[k].p = soft_vis_pk<PINHOLE>(cc, Xs[k], Ys[k], Zs[k], &s2[k]) * f2{om[i], om[i + 1]};
+                    const f2 p = s2[k].p;
                     const f2 pp = p - pk_splat(h.a);
                     const f2 ph = pp * pk_splat(h.invM);
                     // superset of (act | is_min | is_max): exact flags are recomputed in bwd_accum
@@ -611,7 +639,7 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
             } else {
                 float X, Y, Z, y0, y1, y2;
                 to_cam(h, x[0], y[0], z[0], X, Y, Z, y0, y1, y2);
-                any_act |= bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[0], valid[0], acc, ties + (int64_t)v * 32);
+                any_act |= bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[0], valid[0], om[0], acc, ties + (int64_t)v * 32);
             }
             // every pair has been evaluated; when no lane of the wave was active all 14 sums are exact zeros
             // and the cross-lane reduction of zeros is skipped
@@ -641,12 +669,14 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
 #pragma unroll
             for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
             bool touched = false;
+            float om[P];
+            load_occ<P>(occ, occw, v, base, om);
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 float X, Y, Z, y0, y1, y2;
                 to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
                 if (__any(dist2_mean(X, Y, Z, cc.mean) <= h.thr)) {
-                    bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], valid[i], acc, ties + (int64_t)v * 32);
+                    bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], valid[i], om[i], acc, ties + (int64_t)v * 32);
                     touched = true;
                 }
             }
@@ -753,6 +783,60 @@ __global__ void k_bwd_finish2(const float* __restrict__ vgrad, const WayHot* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// occlusion bits: row = all ones, then every point kept by the hard frustum cull is cleared and
+// every point HPR (or the z-buffer) found visible among the kept ones is set again.
+
+__global__ void k_inverse_perm(const int* __restrict__ perm, int64_t n, int* __restrict__ inv) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv[perm[i]] = (int)i;
+}
+
+__global__ void k_occ_clear_kept(const int* __restrict__ inv, const int32_t* __restrict__ kept_idx,
+                                 const int32_t* __restrict__ kept_count, uint32_t* __restrict__ row) {
+    const int m = *kept_count;
+    const int stride = gridDim.x * blockDim.x;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const int s = inv[kept_idx[j]];
+        atomicAnd(&row[s >> 5], ~(1u << (s & 31)));
+    }
+}
+
+__global__ void k_occ_set_visible(const int* __restrict__ inv, const int32_t* __restrict__ kept_idx,
+                                  const int32_t* __restrict__ vis_idx, const int32_t* __restrict__ vis_count,
+                                  uint32_t* __restrict__ row) {
+    const int m = *vis_count;
+    const int stride = gridDim.x * blockDim.x;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const int s = inv[kept_idx[vis_idx[j]]];
+        atomicOr(&row[s >> 5], 1u << (s & 31));
+    }
+}
+
+extern "C" int tohip_inverse_permutation(const void* packed, int64_t n, int32_t* inv, void* stream_) {
+    if (!packed || !inv || n <= 0) return TOHIP_EINVAL;
+    const CloudView cv = cloud_view(packed, n);
+    k_inverse_perm<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>(cv.perm, n, inv);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+extern "C" int tohip_occlusion_row(int64_t n, const int32_t* inv_perm, const int32_t* kept_idx, const int32_t* kept_count,
+                                   const int32_t* vis_idx, const int32_t* vis_count, uint32_t* row, void* stream_) {
+    if (!inv_perm || !kept_idx || !kept_count || !vis_idx || !vis_count || !row || n <= 0) return TOHIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    const int64_t npad = tohip_padded_points(n);
+    hipError_t e = hipMemsetAsync(row, 0xff, (size_t)(npad / 32) * sizeof(uint32_t), st);
+    if (e != hipSuccess) return (int)e;
+    int nb = (int)((n + 255) / 256);
+    if (nb > 1024) nb = 1024;
+    k_occ_clear_kept<<<nb, 256, 0, st>>>(inv_perm, kept_idx, kept_count, row);
+    TO_HIP_CHECK_LAUNCH();
+    k_occ_set_visible<<<nb, 256, 0, st>>>(inv_perm, kept_idx, vis_idx, vis_count, row);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: workspace layout + launches
 
 namespace {
@@ -828,8 +912,8 @@ extern "C" size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual
 }
 
 extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
-                                  const tohip_camera* cam, const tohip_rig* rig, int flags, float* lo_sum, float* minmax,
-                                  void* workspace, size_t workspace_bytes, void* stream_) {
+                                  const tohip_camera* cam, const tohip_rig* rig, int flags, const uint32_t* occlusion_bits,
+                                  float* lo_sum, float* minmax, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!packed || !poses || !quats || !cam || !lo_sum || !minmax || !workspace || n <= 0 || W <= 0) return TOHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
     const int C = rig_cams(rig);
@@ -855,8 +939,8 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
         if (cull) {
             int step = (int)(n / 4096);
             if (step < 1) step = 1;
-            if (cc.pinhole) k_traj_probe<true><<<(int)V, TO_BLOCK, 0, st>>>(cv, hot, aux, cc, step);
-            else k_traj_probe<false><<<(int)V, TO_BLOCK, 0, st>>>(cv, hot, aux, cc, step);
+            if (cc.pinhole) k_traj_probe<true><<<(int)V, TO_BLOCK, 0, st>>>(cv, hot, aux, cc, step, occlusion_bits, cv.npad / 32);
+            else k_traj_probe<false><<<(int)V, TO_BLOCK, 0, st>>>(cv, hot, aux, cc, step, occlusion_bits, cv.npad / 32);
             TO_HIP_CHECK_LAUNCH();
         }
     }
@@ -866,7 +950,8 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
         TO_PROF(TOHIP_PROF_PASS1, st);
         dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
             k_traj_pass1<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value>
-                <<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(cv, hot, aux, (int)V, vtile, cc, mm, pl.nslots);
+                <<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(cv, hot, aux, (int)V, vtile, cc, mm, pl.nslots, occlusion_bits,
+                                                             cv.npad / 32);
         });
     }
     TO_HIP_CHECK_LAUNCH();
@@ -878,7 +963,7 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
     TO_PROF(TOHIP_PROF_PASS2, st);
     dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
         k_traj_pass2<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value>
-            <<<dim3(pl.nblk, 1), TO_BLOCK, 0, st>>>(cv, hot, (int)V, cc, lo_sum);
+            <<<dim3(pl.nblk, 1), TO_BLOCK, 0, st>>>(cv, hot, (int)V, cc, lo_sum, occlusion_bits, cv.npad / 32);
     });
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
@@ -902,8 +987,9 @@ extern "C" int tohip_traj_reward(const void* packed, const float* lo_sum, int64_
 }
 
 extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
-                                   const tohip_camera* cam, const tohip_rig* rig, int flags, const float* lo_sum,
-                                   const float* grad_rewards, const float* scalars, const float* minmax,
+                                   const tohip_camera* cam, const tohip_rig* rig, int flags,
+                                   const uint32_t* occlusion_bits, const float* lo_sum, const float* grad_rewards,
+                                   const float* scalars, const float* minmax,
                                    const float* gout, float* poses_grad, float* quats_grad, void* workspace,
                                    size_t workspace_bytes, void* stream_) {
     if (!packed || !poses || !quats || !cam || !lo_sum || !minmax || !poses_grad || !quats_grad || !workspace ||
@@ -944,7 +1030,8 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* p
         dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
             k_traj_bwd<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value>
                 <<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(cv, hot, aux, (int)V, vtile, cc, lo_sum, grad_rewards,
-                                                             scalars, gout, bpart, pl.nslots, ties);
+                                                             scalars, gout, bpart, pl.nslots, ties, occlusion_bits,
+                                                             cv.npad / 32);
         });
     }
     TO_HIP_CHECK_LAUNCH();

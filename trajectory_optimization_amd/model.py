@@ -103,14 +103,19 @@ class _TrajRewards(torch.autograd.Function):
         sh = model._shard
         lo, hi = sh.bounds(p.shape[0])
         ps, qs = p[lo:hi].contiguous(), q[lo:hi].contiguous()
+        occ = None
+        if hi > lo and model._occlusion is not None:
+            # occlusion masks are piecewise constant in the poses: computed per forward, not differentiated
+            occ = ops.occlusion_bits(model._cloud, model.points, ps, qs, model._cam, model._occlusion_limits[0],
+                                     model._occlusion_limits[1], model._occlusion)
         if hi > lo:
             lo_sum, minmax = ops.traj_forward(model._cloud, ps, qs, model._cam, model._workspace(hi - lo), model._rig,
-                                              flags=model._flags)
+                                              flags=model._flags, occ=occ)
         else:
             lo_sum, minmax = torch.zeros(model._cloud.npad, device=p.device), None
         lo_sum = sh.allreduce_sum(lo_sum)
         rewards, _ = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)))
-        ctx.model, ctx.range, ctx.n_wps = model, (lo, hi), p.shape[0]
+        ctx.model, ctx.range, ctx.n_wps, ctx.occ = model, (lo, hi), p.shape[0], occ
         ctx.save_for_backward(ps, qs, lo_sum, minmax if minmax is not None else torch.empty(0, device=p.device))
         return rewards
 
@@ -124,7 +129,7 @@ class _TrajRewards(torch.autograd.Function):
         if hi > lo:
             g = grad_rewards.to(torch.float32).contiguous()
             pg[lo:hi], qg[lo:hi] = ops.traj_backward(m._cloud, ps, qs, m._cam, m._workspace(hi - lo), lo_sum, minmax,
-                                                     grad_rewards=g, rig=m._rig, flags=m._flags)
+                                                     grad_rewards=g, rig=m._rig, flags=m._flags, occ=ctx.occ)
         pg = m._shard.allreduce_sum(pg)
         qg = m._shard.allreduce_sum(qg)
         return pg, qg, None
@@ -214,7 +219,11 @@ class ModelTraj(nn.Module):
     Extra keyword arguments (absent from the reference): `rig=(quats (C,4), trans (C,3))` evaluates a rigid
     multi-camera rig at every waypoint; `shard=` a trajectory_optimization_amd.distributed.WaypointShard
     placing the waypoints over the ranks of a process group (one process per GPU, RCCL); `dense=True`
-    evaluates every (point, waypoint) pair instead of skipping the pairs that provably contribute nothing.
+    evaluates every (point, waypoint) pair instead of skipping the pairs that provably contribute nothing;
+    `occlusion='hpr'|'zbuffer'` makes the reward occlusion-aware per waypoint — the reference's TODO
+    (/root/reference/src/tools.py:61-62, /root/reference/src/model.py:210): each waypoint's camera-frame cloud goes
+    through the hard pipeline of /root/reference/src/pc_processor.py:171-178 (frustum cull with `occlusion_limits`,
+    then HPR from the camera centre) and the points it hides get p = 0 for that waypoint.
     """
 
     def __init__(self,
@@ -226,7 +235,7 @@ class ModelTraj(nn.Module):
                  min_dist=1.0, max_dist=5.0,
                  smoothness_weight=14.0, traj_length_weight=0.02,
                  device=torch.device('cuda'),
-                 *, rig=None, shard=None, dense=False):
+                 *, rig=None, shard=None, dense=False, occlusion=None, occlusion_limits=(1.0, 15.0)):
         super().__init__()
         assert wps_poses.dim() == wps_quats.dim()
         assert wps_poses.size()[1] == 3
@@ -262,6 +271,11 @@ class ModelTraj(nn.Module):
         self._rig = ops.CameraRig(rig[0], rig[1], self.device) if rig is not None else None
         self._shard = shard if shard is not None else _NoShard()
         self._flags = ops.DENSE if dense else 0  # dense: evaluate every pair (results are bitwise the same)
+        if occlusion not in (None, "hpr", "zbuffer"):
+            raise ValueError("occlusion must be None, 'hpr' or 'zbuffer'")
+        if occlusion is not None and rig is not None:
+            raise NotImplementedError("per-waypoint occlusion with a camera rig")
+        self._occlusion, self._occlusion_limits = occlusion, occlusion_limits
         self._ws_cache = {}
         self._wps_step_cache = {}
         self._length0 = None

@@ -83,7 +83,7 @@ class TrajWorkspace:
 DENSE = 1  # TOHIP_TRAJ_DENSE
 
 
-def traj_forward(cloud, poses, quats, cam, ws, rig=None, flags=0):
+def traj_forward(cloud, poses, quats, cam, ws, rig=None, flags=0, occ=None):
     """-> (lo_sum[npad] in packed order (first N valid), minmax[V,2]) for the given waypoints (this rank's shard)."""
     W = poses.shape[0]
     C = rig.n_cams if rig is not None else 1
@@ -91,7 +91,7 @@ def traj_forward(cloud, poses, quats, cam, ws, rig=None, flags=0):
     minmax = torch.empty((W * C, 2), dtype=torch.float32, device=cloud.device)
     with torch.cuda.device(cloud.device):
         check(_lib.lib().tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
-                                            rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(lo_sum), ptr(minmax),
+                                            rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(occ), ptr(lo_sum), ptr(minmax),
                                             ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_forward")
     return lo_sum, minmax
 
@@ -107,14 +107,14 @@ def traj_reward(cloud, lo_sum, cam, ws):
 
 
 def traj_backward(cloud, poses, quats, cam, ws, lo_sum, minmax, grad_rewards=None, scalars=None, gout=None, rig=None,
-                  flags=0):
+                  flags=0, occ=None):
     """lo_sum: the (all-reduced) log-odds vector in packed order, as returned by traj_forward."""
     W = poses.shape[0]
     pg = torch.empty((W, 3), dtype=torch.float32, device=cloud.device)
     qg = torch.empty((W, 4), dtype=torch.float32, device=cloud.device)
     with torch.cuda.device(cloud.device):
         check(_lib.lib().tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
-                                             rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(lo_sum),
+                                             rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(occ), ptr(lo_sum),
                                              ptr(grad_rewards), ptr(scalars), ptr(minmax), ptr(gout), ptr(pg), ptr(qg),
                                              ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_backward")
     return pg, qg
@@ -144,6 +144,46 @@ def pose_backward(cloud, trans, quat, cam, ws, mask=None, grad_obs=None, scalars
                                              ptr(grad_obs), ptr(scalars), ptr(gout), ptr(tg), ptr(qg), ptr(ws.buf),
                                              ws.bytes, stream_ptr()), "tohip_pose_backward")
     return tg, qg
+
+
+def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method="hpr"):
+    """(W, npad/32) int32 occlusion bit rows for the given waypoints: the hard per-camera pipeline of
+    /root/reference/src/pc_processor.py:158-187 (exact transform -> hard frustum cull -> HPR from the camera
+    centre, or the z-buffer splat for method="zbuffer") turned into the bit layout the kernels read."""
+    L = _lib.lib()
+    dev = cloud.device
+    if not hasattr(cloud, "inv_perm"):
+        cloud.inv_perm = torch.empty(cloud.n, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.tohip_inverse_permutation(ptr(cloud.blob), cloud.n, ptr(cloud.inv_perm), stream_ptr()), "inverse_perm")
+    W = poses.shape[0]
+    rows = torch.empty((W, cloud.npad // 32), dtype=torch.int32, device=dev)
+    n = cloud.n
+    wsb = L.tohip_frustum_workspace_bytes(n)
+    fws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    kept = torch.empty(n, dtype=torch.int32, device=dev)
+    kcnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    for w in range(W):
+        cam3 = to_camera_frame_exact(points, quats[w], poses[w], normalize=True, transpose=True)
+        with torch.cuda.device(dev):
+            check(L.tohip_frustum_cull(ptr(cam3), n, cam.ref(), float(min_dist), float(max_dist), None, None, ptr(kept),
+                                       ptr(kcnt), ptr(fws), wsb, stream_ptr()), "tohip_frustum_cull")
+        m = int(kcnt.item())
+        kept_pts = cam3[:, kept[:m].long()].t().contiguous()
+        if m >= 4:
+            if method == "zbuffer":
+                owns = render_points(kept_pts, [cam.c.K[i] for i in range(9)], cam.c.img_height, cam.c.img_width,
+                                     znear=min_dist, zfar=max_dist)[2]
+                vis = torch.nonzero(owns).squeeze(1).to(torch.int32)
+            else:
+                vis, _ = hidden_pts_removal(kept_pts, 2)
+        else:
+            vis = torch.arange(m, dtype=torch.int32, device=dev)
+        vcnt = torch.tensor([vis.numel()], dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.tohip_occlusion_row(n, ptr(cloud.inv_perm), ptr(kept), ptr(kcnt), ptr(vis.contiguous()), ptr(vcnt),
+                                        ptr(rows[w]), stream_ptr()), "tohip_occlusion_row")
+    return rows
 
 
 def to_camera_frame_exact(points, quat, trans, normalize=True, transpose=False):

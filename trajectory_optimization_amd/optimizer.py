@@ -53,12 +53,12 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
             check(L.tohip_rows_strided(ptr(poses), n_eval, 3, step_w, 0, ptr(poses_e), s), "gather poses")
             check(L.tohip_rows_strided(ptr(quats), n_eval, 4, step_w, 0, ptr(quats_e), s), "gather quats")
             check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), n_eval, cam.ref(), rig_ref,
-                                       model._flags, ptr(lo_sum), ptr(minmax), ptr(ws.buf), ws.bytes, s), "forward")
+                                       model._flags, None, ptr(lo_sum), ptr(minmax), ptr(ws.buf), ws.bytes, s), "forward")
             model._shard.allreduce_sum(lo_sum)
             check(L.tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, ptr(rewards), ptr(scalars),
                                       ptr(ws.buf), ws.bytes, s), "reward")
             check(L.tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), n_eval, cam.ref(), rig_ref,
-                                        model._flags, ptr(lo_sum), None, ptr(scalars), ptr(minmax), ptr(gout), ptr(pg_e),
+                                        model._flags, None, ptr(lo_sum), None, ptr(scalars), ptr(minmax), ptr(gout), ptr(pg_e),
                                         ptr(qg_e), ptr(ws.buf), ws.bytes, s), "backward")
             if step_w > 1:
                 pg.zero_()
