@@ -172,7 +172,8 @@ def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method=
         kept_pts = cam3[:, kept[:m].long()].t().contiguous()
         if m >= 4:
             if method == "zbuffer":
-                owns = render_points(kept_pts, [cam.c.K[i] for i in range(9)], cam.c.img_height, cam.c.img_width,
+                owns = render_points(kept_pts, torch.tensor([cam.c.K[i] for i in range(9)]).reshape(3, 3), cam.c.img_height,
+                                     cam.c.img_width,
                                      znear=min_dist, zfar=max_dist)[2]
                 vis = torch.nonzero(owns).squeeze(1).to(torch.int32)
             else:
