@@ -121,12 +121,17 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ src, int64_t 
 // Optional per-(virtual waypoint, point) occlusion bits in packed order: row v holds npad bits,
 // bit i = 1 when sorted point i is NOT occluded from waypoint v.  om[] = 1.0f / 0.0f multipliers of p; without a
 // bit array every multiplier is exactly 1 (p * 1.0f == p, so the unoccluded results do not change by a bit).
-template <int P>
+template <int P, bool OCC = true>
 __device__ __forceinline__ void load_occ(const uint32_t* __restrict__ occ, int64_t occw, int v, int64_t base, float (&om)[P]) {
-    unsigned bits = ~0u;
-    if (occ) bits = occ[(int64_t)v * occw + (base >> 5)] >> (unsigned)(base & 31);
+    if constexpr (!OCC) {
 #pragma unroll
-    for (int i = 0; i < P; ++i) om[i] = ((bits >> i) & 1u) ? 1.0f : 0.0f;
+        for (int i = 0; i < P; ++i) om[i] = 1.0f;  // compile-time ones: the multiplications fold away
+    } else {
+        unsigned bits = ~0u;
+        if (occ) bits = occ[(int64_t)v * occw + (base >> 5)] >> (unsigned)(base & 31);
+#pragma unroll
+        for (int i = 0; i < P; ++i) om[i] = ((bits >> i) & 1u) ? 1.0f : 0.0f;
+    }
 }
 
 // wave-uniform bounding sphere of the 256-point tile this wave's points belong to
@@ -249,7 +254,7 @@ __device__ __forceinline__ void pass1_dense_wp(const CamConsts& cc, const WayHot
     }
 }
 
-template <int P, bool PINHOLE, bool CULL>
+template <int P, bool PINHOLE, bool CULL, bool OCC>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_pass1(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restrict__ aux, int V, int vtile,
              CamConsts cc, float2* __restrict__ part, int nslots, const uint32_t* __restrict__ occ, int64_t occw) {
@@ -265,7 +270,7 @@ k_traj_pass1(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restr
             const WayHot h = hot[v];
             float mn = INFINITY, mx = -INFINITY;
             float om[P];
-            load_occ<P>(occ, occw, v, base, om);
+            load_occ<P, OCC>(occ, occw, v, base, om);
             pass1_dense_wp<P, PINHOLE>(cc, h, x, y, z, om, mn, mx);
             mn = wave_min63(mn);
             mx = wave_max63(mx);
@@ -285,7 +290,7 @@ k_traj_pass1(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restr
             const WayAux a = aux[v];
             float mn = INFINITY, mx = -INFINITY;
             float om[P];
-            load_occ<P>(occ, occw, v, base, om);
+            load_occ<P, OCC>(occ, occw, v, base, om);
             if (a.azero != 0.f) {
                 mn = 0.f;  // proven by the probe; only the max is searched, among points that can reach L
 #pragma unroll
@@ -376,7 +381,7 @@ __device__ __forceinline__ f2 log_odds_pk(const CamConsts& cc, const WayHot& h, 
     return l * pk_splat(0.693147180559945f);
 }
 
-template <int P, bool PINHOLE, bool CULL>
+template <int P, bool PINHOLE, bool CULL, bool OCC>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, float* __restrict__ lo_sum,
              const uint32_t* __restrict__ occ, int64_t occw) {
@@ -397,7 +402,7 @@ k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, 
                 live &= live - 1ull;
                 const WayHot h = hot[v];
                 float om[P];
-                load_occ<P>(occ, occw, v, base, om);
+                load_occ<P, OCC>(occ, occw, v, base, om);
 #pragma unroll
                 for (int i = 0; i < P; ++i) {
                     float X, Y, Z, y0, y1, y2;
@@ -412,7 +417,7 @@ k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, 
             const WayHot h = hot[v];
             degenerate |= !(h.invM < INFINITY);
             float om[P];
-            load_occ<P>(occ, occw, v, base, om);
+            load_occ<P, OCC>(occ, occw, v, base, om);
             if constexpr (P >= 2) {
 #pragma unroll
                 for (int i = 0; i < P; i += 2) {
@@ -558,7 +563,7 @@ __device__ __forceinline__ bool bwd_accum(const CamConsts& cc, const WayHot& h, 
     return act;
 }
 
-template <int P, bool PINHOLE, bool CULL>
+template <int P, bool PINHOLE, bool CULL, bool OCC>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restrict__ aux, int V, int vtile,
            CamConsts cc, const float* __restrict__ lo_sum, const float* __restrict__ grad_rewards,
@@ -604,7 +609,7 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
             const float M = aux[v].M;
             bool any_act = false;
             float om[P];
-            load_occ<P>(occ, occw, v, base, om);
+            load_occ<P, OCC>(occ, occw, v, base, om);
             if constexpr (P >= 2) {
                 // phase 1 (packed, branch-free): visibility of every pair and whether any element needs the
                 // gradient path; phase 2 runs under ONE wave-uniform branch per waypoint
@@ -670,7 +675,7 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
             for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
             bool touched = false;
             float om[P];
-            load_occ<P>(occ, occw, v, base, om);
+            load_occ<P, OCC>(occ, occw, v, base, om);
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 float X, Y, Z, y0, y1, y2;
@@ -892,10 +897,13 @@ inline void choose_tiles(int nblk, int V, bool cull, int* vtile, int* ntiles) {
 }
 
 template <typename F>
-inline void dispatch(int P, bool pinhole, bool cull, F&& f) {
+inline void dispatch(int P, bool pinhole, bool cull, bool occ, F&& f) {
     auto with_p = [&](auto Pc) {
-        if (pinhole) { if (cull) f(Pc, std::true_type(), std::true_type()); else f(Pc, std::true_type(), std::false_type()); }
-        else { if (cull) f(Pc, std::false_type(), std::true_type()); else f(Pc, std::false_type(), std::false_type()); }
+        auto with_o = [&](auto Oc) {
+            if (pinhole) { if (cull) f(Pc, std::true_type(), std::true_type(), Oc); else f(Pc, std::true_type(), std::false_type(), Oc); }
+            else { if (cull) f(Pc, std::false_type(), std::true_type(), Oc); else f(Pc, std::false_type(), std::false_type(), Oc); }
+        };
+        if (occ) with_o(std::true_type()); else with_o(std::false_type());
     };
     if (P == 4) with_p(std::integral_constant<int, 4>());
     else if (P == 2) with_p(std::integral_constant<int, 2>());
@@ -948,8 +956,8 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
     choose_tiles(pl.nblk, (int)V, cull, &vtile, &ntiles);
     {
         TO_PROF(TOHIP_PROF_PASS1, st);
-        dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
-            k_traj_pass1<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value>
+        dispatch(pl.P, cc.pinhole != 0, cull, occlusion_bits != nullptr, [&](auto Pc, auto Ph, auto Cu, auto Oc) {
+            k_traj_pass1<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value, decltype(Oc)::value>
                 <<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(cv, hot, aux, (int)V, vtile, cc, mm, pl.nslots, occlusion_bits,
                                                              cv.npad / 32);
         });
@@ -961,8 +969,8 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
     }
     TO_HIP_CHECK_LAUNCH();
     TO_PROF(TOHIP_PROF_PASS2, st);
-    dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
-        k_traj_pass2<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value>
+    dispatch(pl.P, cc.pinhole != 0, cull, occlusion_bits != nullptr, [&](auto Pc, auto Ph, auto Cu, auto Oc) {
+        k_traj_pass2<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value, decltype(Oc)::value>
             <<<dim3(pl.nblk, 1), TO_BLOCK, 0, st>>>(cv, hot, (int)V, cc, lo_sum, occlusion_bits, cv.npad / 32);
     });
     TO_HIP_CHECK_LAUNCH();
@@ -1027,8 +1035,8 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* p
     choose_tiles(pl.nblk, (int)V, cull, &vtile, &ntiles);
     {
         TO_PROF(TOHIP_PROF_BWD, st);
-        dispatch(pl.P, cc.pinhole != 0, cull, [&](auto Pc, auto Ph, auto Cu) {
-            k_traj_bwd<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value>
+        dispatch(pl.P, cc.pinhole != 0, cull, occlusion_bits != nullptr, [&](auto Pc, auto Ph, auto Cu, auto Oc) {
+            k_traj_bwd<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value, decltype(Oc)::value>
                 <<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(cv, hot, aux, (int)V, vtile, cc, lo_sum, grad_rewards,
                                                              scalars, gout, bpart, pl.nslots, ties, occlusion_bits,
                                                              cv.npad / 32);
