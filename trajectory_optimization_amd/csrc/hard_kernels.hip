@@ -414,7 +414,10 @@ __global__ void k_selftest_wave_reduce(const float* __restrict__ in, int k, floa
     for (int c = 0; c < k; ++c) {
         const float v = in[lane * k + c];
         const float s = wave_sum63(v), mn = wave_min63(v), mx = wave_max63(v);
-        if (lane == 63) { osum[c] = s; omin[c] = mn; omax[c] = mx; }
+        // the non-negative variants, checked on |v| and folded back in: any mismatch poisons the outputs
+        const float a = fabsf(v);
+        const bool ok = wave_min63_nn(a) == wave_min63(a) && wave_max63_nn(a) == wave_max63(a);
+        if (lane == 63) { osum[c] = ok ? s : __builtin_nanf(""); omin[c] = ok ? mn : __builtin_nanf(""); omax[c] = mx; }
     }
 }
 

@@ -268,12 +268,12 @@ k_traj_pass1(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restr
     if (!CULL) {
         for (int v = v0; v < v1; ++v) {
             const WayHot h = hot[v];
-            float mn = INFINITY, mx = -INFINITY;
+            float mn = INFINITY, mx = 0.f;  // p >= +0 always
             float om[P];
             load_occ<P, OCC>(occ, occw, v, base, om);
             pass1_dense_wp<P, PINHOLE>(cc, h, x, y, z, om, mn, mx);
-            mn = wave_min63(mn);
-            mx = wave_max63(mx);
+            mn = wave_min63_nn(mn);
+            mx = wave_max63_nn(mx);
             if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
         }
         return;
@@ -288,7 +288,7 @@ k_traj_pass1(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restr
             live &= live - 1ull;
             const WayHot h = hot[v];
             const WayAux a = aux[v];
-            float mn = INFINITY, mx = -INFINITY;
+            float mn = INFINITY, mx = 0.f;  // p >= +0 always (an all-culled wave reports max 0 <= the probe's L)
             float om[P];
             load_occ<P, OCC>(occ, occw, v, base, om);
             if (a.azero != 0.f) {
@@ -301,9 +301,9 @@ k_traj_pass1(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restr
                 }
             } else {
                 pass1_dense_wp<P, PINHOLE>(cc, h, x, y, z, om, mn, mx);
-                mn = wave_min63(mn);
+                mn = wave_min63_nn(mn);
             }
-            mx = wave_max63(mx);
+            mx = wave_max63_nn(mx);
             if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
         }
     }
@@ -868,8 +868,8 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W) {
     p.nblk = (int)(p.npad / (TO_BLOCK * p.P));
     p.nslots = p.nblk * TO_WAVES_PER_BLOCK;
     p.V = (int)V;
-    // sized for the smallest P (most slots) so that the plan is a pure function of (n, V)
-    const size_t max_slots = (size_t)(p.npad / TO_WAVE);
+    // P is a pure function of n, hence so are the slot count and the whole plan
+    const size_t max_slots = (size_t)p.nslots;
     size_t o = 0;
     p.off_rpart = o; o += align_up((size_t)4096 * sizeof(double), 256);  // first: tohip_traj_reward uses only this
     p.off_hot = o;   o += align_up((size_t)V * sizeof(WayHot), 256);
