@@ -123,10 +123,9 @@ __device__ __forceinline__ float to_exp(float x) {
 // exp(x) without the correction term: relative error ~|x| * 6e-8.  Used for the depth sigmoid only, where
 // it is harmless: S = 1/(1+e) inherits e/(1+e) of it (< 4e-7 for |Z| <= 6 m, and S ~ e^Z is negligible
 // together with every other factor of p for points far behind the camera).
-__device__ __forceinline__ float to_exp_fast(float x) {
-    x = __builtin_amdgcn_fmed3f(x, -150.0f, 88.0f);
-    return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
-}
+// No clamp: v_exp_f32 saturates to 0 / +inf by itself and there is no correction term that could turn that into a NaN
+// (1 + inf = inf, rcp(inf) = 0).
+__device__ __forceinline__ float to_exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
 __device__ __forceinline__ float to_log2(float x) { return __builtin_amdgcn_logf(x); }
 
@@ -242,7 +241,6 @@ __device__ __forceinline__ f2 to_exp_pk(f2 x) {
 }
 
 __device__ __forceinline__ f2 to_exp_fast_pk(f2 x) {
-    x = f2{__builtin_amdgcn_fmed3f(x.x, -150.0f, 88.0f), __builtin_amdgcn_fmed3f(x.y, -150.0f, 88.0f)};
     const f2 e = x * pk_splat(1.44269504088896341f);
     return f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
 }
