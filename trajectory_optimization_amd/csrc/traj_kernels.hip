@@ -627,7 +627,9 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
                     const f2 pp = p - pk_splat(h.a);
                     const f2 ph = pp * pk_splat(h.invM);
                     // superset of (act | is_min | is_max): exact flags are recomputed in bwd_accum
-                    need |= (ph.x >= 0.5f) | (ph.y >= 0.5f) | (p.x == h.a) | (p.y == h.a);
+                    // (the argmin set only matters when a > 0: bwd_accum requires p == a && p > 0; with a = 0 — the
+                    // usual case — half the cloud has p == 0 and must not drag every wave into the gradient path)
+                    need |= (ph.x >= 0.5f) | (ph.y >= 0.5f) | ((h.a > 0.f) & ((p.x == h.a) | (p.y == h.a)));
                 }
                 if (__any(need)) {
 #pragma unroll
