@@ -201,3 +201,27 @@ def test_full_size_properties(dev):
     pg, qg = oracle.traj_backward(pts, poses[sel], quats[sel], K, IW, IH, f, prec="f64")
     np.testing.assert_allclose(rs["rewards"], f["rewards"], rtol=REW_RTOL, atol=REW_ATOL)
     assert rel_inf(rs["pg"], pg) < GRAD_TOL and rel_inf(rs["qg"], qg) < GRAD_TOL
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_culling_randomized_bitwise(dev, seed):
+    """Random clouds (uniform slabs, clustered blobs, thin walls), random paths and cameras: exact culling must
+    reproduce the dense evaluation bit for bit (the tile bounds and distance bounds are conservative)."""
+    ops = _ops()
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([300, 5_000, 40_000, 150_000, 600_000]))
+    kind = seed % 3
+    if kind == 0:
+        pts = (rng.random((n, 3)) * rng.uniform(5, 60, 3) - rng.uniform(2, 30, 3)).astype(np.float32)
+    elif kind == 1:
+        centres = rng.uniform(-15, 15, (6, 3))
+        pts = (centres[rng.integers(0, 6, n)] + rng.standard_normal((n, 3)) * rng.uniform(0.05, 2.0)).astype(np.float32)
+    else:
+        pts = np.stack([rng.uniform(-20, 20, n), rng.uniform(-0.02, 0.02, n) + 4.0, rng.uniform(-3, 3, n)], 1).astype(np.float32)
+    w = int(rng.integers(3, 40))
+    poses = rng.uniform(-8, 8, (w, 3)).astype(np.float32)
+    quats = rng.standard_normal((w, 4)).astype(np.float32)
+    a = _run_ops(dev, pts, poses, quats)
+    b = _run_ops(dev, pts, poses, quats, flags=ops.DENSE)
+    for k in ("lo_sum", "rewards", "minmax", "scalars", "pg", "qg"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), (k, n, w)
