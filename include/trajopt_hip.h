@@ -178,7 +178,10 @@ int tohip_convex_hull_vertices(const float *pts, int64_t n_points, int with_orig
  * the existing content when accumulate != 0 (i.e. on top of the visibility gradient). */
 int tohip_traj_regularizers(const float *poses, const float *poses0, int64_t n_wps, float smoothness_weight,
                             float traj_length_weight, float eps, const float *scalars, float *loss_terms,
-                            float *grad_poses, int accumulate, void *stream);
+                            float *grad_poses, int accumulate, const float *state, void *stream);
+/* state (may be NULL): when given, loss_terms is the base of an (n_steps, 8) log and the row written is
+ * state[3] = steps taken so far — the launch then carries no per-step host value and can be replayed from a
+ * hipGraph.  Same convention for tohip_adam_step (step <= 0: step index = state[3] + 1) and tohip_early_stop. */
 /* rows r*step of a (.., cols) array <-> a compact (n_rows, cols) array: the every-wps_step-th waypoint selection
  * of model.py:217 (scatter = 0: gather src[r*step] -> dst[r]; 1: scatter src[r] -> dst[r*step]). */
 int tohip_rows_strided(const float *src, int64_t n_rows, int cols, int step, int scatter, float *dst, void *stream);
@@ -189,7 +192,7 @@ int tohip_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
 /* early-stop rule of trajectory_optimization.py:100-124 on the device.  state (8 floats, zero-initialised by
  * the caller): [0] reward0 [1] smooth0 [2] stopped [3] steps taken [4] visibility gain [5] smoothness gain. */
 int tohip_early_stop(const float *scalars, const float *loss_terms, float rewards_th, float smoothness_th, float *state,
-                     void *stream);
+                     int row_from_state, void *stream);
 
 /* ---- input formats (pointcloud_utils.py, launch/voxels_filtering.launch) --------------------------------
  * PointCloud2 payload -> (N,3) f32 with non-finite rows removed, in message order

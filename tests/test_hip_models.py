@@ -137,10 +137,10 @@ def test_device_resident_optimizer_matches_reference_adam(dev):
     from trajectory_optimization_amd.optimizer import optimize_trajectory
     d = load_golden("traj_adam_bundled")
     d["points"] = load_golden("bundled")["pts"]
-    for k in (1, 5, 10):
+    for k, graph in ((1, False), (5, True), (10, True), (10, False)):
         m = _traj_model(d, dev)
         res = optimize_trajectory(m, n_opt_steps=k, lr_pose=float(d["lr_pose"]), lr_quat=float(d["lr_quat"]),
-                                  rewards_th=1e9, smoothness_th=1e9)
+                                  rewards_th=1e9, smoothness_th=1e9, use_graph=graph)
         assert res.steps_taken == k and not res.stopped
         np.testing.assert_allclose(m.poses.detach().cpu().numpy(), d[f"poses_step{k}"], rtol=0, atol=2e-3)
         np.testing.assert_allclose(m.quats.detach().cpu().numpy(), d[f"quats_step{k}"], rtol=0, atol=2e-3)
@@ -162,7 +162,7 @@ def test_device_regularizers_match_torch(dev):
     lt = torch.zeros(8, device=dev)
     g = torch.zeros_like(m.poses)
     check(_lib.lib().tohip_traj_regularizers(ptr(m.poses.data), ptr(m.poses0), m.poses.shape[0], 28.0, 0.05, 1e-6,
-                                             ptr(scal), ptr(lt), ptr(g), 0, stream_ptr()), "regularizers")
+                                             ptr(scal), ptr(lt), ptr(g), 0, None, stream_ptr()), "regularizers")
     torch.cuda.synchronize()
     assert abs(lt[4].item() - reg.item()) <= 2e-5 * abs(reg.item())
     for k, name in ((1, "l2"), (2, "length"), (3, "smooth")):

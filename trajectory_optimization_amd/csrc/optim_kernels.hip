@@ -18,7 +18,9 @@
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_regularizers(const float* __restrict__ poses, const float* __restrict__ poses0, int W, float smooth_w,
                     float length_w, float eps, const float* __restrict__ scalars /* [1] = loss_vis */,
-                    float* __restrict__ loss_terms, float* __restrict__ grad_poses, int accumulate) {
+                    float* __restrict__ loss_terms, float* __restrict__ grad_poses, int accumulate,
+                    const float* __restrict__ state /* may be NULL; else loss row = state[3] (steps taken so far) */) {
+    if (state) loss_terms += 8 * (int)state[3];
     __shared__ double lds[TO_BLOCK];
     __shared__ double sh[4];
     const int t = threadIdx.x;
@@ -138,6 +140,7 @@ __global__ void k_gather_rows(const float* __restrict__ src, int n_rows, int col
 __global__ void k_adam(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
                        int n, float lr, float beta1, float beta2, float eps, int t, const float* __restrict__ state) {
     if (state && state[2] != 0.f) return;
+    if (t <= 0) t = (int)state[3] + 1;  // step index kept on the device: the same launch can be replayed from a hipGraph
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float g = grad[i];
@@ -152,10 +155,11 @@ __global__ void k_adam(float* __restrict__ param, const float* __restrict__ grad
 
 // The reference's early-stop rule, evaluated after the step: gains relative to the first step's values.
 __global__ void k_early_stop(const float* __restrict__ scalars /* [0] = mean reward */, const float* __restrict__ loss_terms,
-                             float rewards_th, float smoothness_th, float* __restrict__ state) {
+                             float rewards_th, float smoothness_th, float* __restrict__ state, int row_from_state) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (row_from_state) loss_terms += 8 * (int)state[3];
     if (state[2] != 0.f) return;
-    const float mean_r = scalars[0], smooth = loss_terms[3];
+    const float mean_r = scalars[0], smooth = loss_terms[3];  // loss_terms: this step's row
     if (state[3] == 0.f) { state[0] = mean_r; state[1] = smooth; }
     state[3] += 1.f;
     const float vg = mean_r / state[0], sg = state[1] / smooth;
@@ -165,11 +169,11 @@ __global__ void k_early_stop(const float* __restrict__ scalars /* [0] = mean rew
 
 extern "C" int tohip_traj_regularizers(const float* poses, const float* poses0, int64_t W, float smoothness_weight,
                                        float traj_length_weight, float eps, const float* scalars, float* loss_terms,
-                                       float* grad_poses, int accumulate, void* stream_) {
+                                       float* grad_poses, int accumulate, const float* state, void* stream_) {
     if (!poses || !poses0 || !scalars || !loss_terms || W < 3) return TOHIP_EINVAL;
     k_traj_regularizers<<<1, TO_BLOCK, 0, (hipStream_t)stream_>>>(poses, poses0, (int)W, smoothness_weight,
                                                                   traj_length_weight, eps, scalars, loss_terms, grad_poses,
-                                                                  accumulate);
+                                                                  accumulate, state);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
@@ -186,7 +190,7 @@ extern "C" int tohip_rows_strided(const float* src, int64_t n_rows, int cols, in
 
 extern "C" int tohip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                                float beta1, float beta2, float eps, int32_t step, const float* state, void* stream_) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) return TOHIP_EINVAL;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || (step < 1 && !state)) return TOHIP_EINVAL;
     k_adam<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>(param, grad, exp_avg, exp_avg_sq, (int)n, lr, beta1, beta2,
                                                                       eps, step, state);
     TO_HIP_CHECK_LAUNCH();
@@ -194,9 +198,9 @@ extern "C" int tohip_adam_step(float* param, const float* grad, float* exp_avg, 
 }
 
 extern "C" int tohip_early_stop(const float* scalars, const float* loss_terms, float rewards_th, float smoothness_th,
-                                float* state, void* stream_) {
+                                float* state, int row_from_state, void* stream_) {
     if (!scalars || !loss_terms || !state) return TOHIP_EINVAL;
-    k_early_stop<<<1, 64, 0, (hipStream_t)stream_>>>(scalars, loss_terms, rewards_th, smoothness_th, state);
+    k_early_stop<<<1, 64, 0, (hipStream_t)stream_>>>(scalars, loss_terms, rewards_th, smoothness_th, state, row_from_state);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }

@@ -22,9 +22,13 @@ class TrajOptResult:
 
 @torch.no_grad()
 def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards_th=1.2, smoothness_th=0.9,
-                        vis_wps_dist=0.5, betas=(0.9, 0.999), adam_eps=1e-8):
+                        vis_wps_dist=0.5, betas=(0.9, 0.999), adam_eps=1e-8, use_graph=True):
     """Runs up to n_opt_steps on `model` (a ModelTraj) in place; returns a TrajOptResult (one host sync, at the end).
-    model.poses / model.quats hold the optimised trajectory, model.rewards the last rewards, model.loss the last terms."""
+    model.poses / model.quats hold the optimised trajectory, model.rewards the last rewards, model.loss the last terms.
+
+    use_graph: capture one iteration (≈20 launches, every per-step value read from device state) into a hipGraph and
+    replay it n_opt_steps times — the launch-bound regime of small clouds (not used with waypoint sharding, whose
+    all-reduce stays outside a capture, nor with per-waypoint occlusion, whose hull construction syncs)."""
     L = _lib.lib()
     dev = model.device
     cloud, cam, rig = model._cloud, model._cam, model._rig
@@ -39,41 +43,62 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
     lo_sum = torch.empty(cloud.npad, **f32)
     minmax = torch.empty((n_eval * (rig.n_cams if rig else 1), 2), **f32)
     rewards, scalars = torch.empty(cloud.n, **f32), torch.zeros(4, **f32)
-    loss_terms = torch.zeros((n_opt_steps, 8), **f32)
+    loss_terms = torch.zeros((n_opt_steps + 1, 8), **f32)
     state = torch.zeros(8, **f32)
     gout = torch.ones(1, **f32)
     mp, vp = torch.zeros((W, 3), **f32), torch.zeros((W, 3), **f32)
     mq, vq = torch.zeros((W, 4), **f32), torch.zeros((W, 4), **f32)
     poses, quats = model.poses.data, model.quats.data
     rig_ref = rig.ref() if rig is not None else ops._NULL_RIG
-    with torch.cuda.device(dev):
+    sharded = model._shard.world_size > 1
+    occluded = model._occlusion is not None
+
+    def iteration():
         s = stream_ptr()
-        for it in range(n_opt_steps):
-            lt = loss_terms[it]
-            check(L.tohip_rows_strided(ptr(poses), n_eval, 3, step_w, 0, ptr(poses_e), s), "gather poses")
-            check(L.tohip_rows_strided(ptr(quats), n_eval, 4, step_w, 0, ptr(quats_e), s), "gather quats")
-            check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), n_eval, cam.ref(), rig_ref,
-                                       model._flags, None, ptr(lo_sum), ptr(minmax), ptr(ws.buf), ws.bytes, s), "forward")
-            model._shard.allreduce_sum(lo_sum)
-            check(L.tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, ptr(rewards), ptr(scalars),
-                                      ptr(ws.buf), ws.bytes, s), "reward")
-            check(L.tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), n_eval, cam.ref(), rig_ref,
-                                        model._flags, None, ptr(lo_sum), None, ptr(scalars), ptr(minmax), ptr(gout), ptr(pg_e),
-                                        ptr(qg_e), ptr(ws.buf), ws.bytes, s), "backward")
-            if step_w > 1:
-                pg.zero_()
-                qg.zero_()
-            check(L.tohip_rows_strided(ptr(pg_e), n_eval, 3, step_w, 1, ptr(pg), s), "scatter poses grad")
-            check(L.tohip_rows_strided(ptr(qg_e), n_eval, 4, step_w, 1, ptr(qg), s), "scatter quats grad")
-            check(L.tohip_traj_regularizers(ptr(poses), ptr(model.poses0), W, float(model.smoothness_weight),
-                                            float(model.traj_length_weight), float(model.eps), ptr(scalars), ptr(lt),
-                                            ptr(pg), 1, s), "regularizers")
-            check(L.tohip_adam_step(ptr(poses), ptr(pg), ptr(mp), ptr(vp), W * 3, float(lr_pose), betas[0], betas[1],
-                                    adam_eps, it + 1, ptr(state), s), "adam poses")
-            check(L.tohip_adam_step(ptr(quats), ptr(qg), ptr(mq), ptr(vq), W * 4, float(lr_quat), betas[0], betas[1],
-                                    adam_eps, it + 1, ptr(state), s), "adam quats")
-            check(L.tohip_early_stop(ptr(scalars), ptr(lt), float(rewards_th), float(smoothness_th), ptr(state), s),
-                  "early stop")
+        check(L.tohip_rows_strided(ptr(poses), n_eval, 3, step_w, 0, ptr(poses_e), s), "gather poses")
+        check(L.tohip_rows_strided(ptr(quats), n_eval, 4, step_w, 0, ptr(quats_e), s), "gather quats")
+        occ = None
+        if occluded:
+            occ = ops.occlusion_bits(cloud, model.points, poses_e, quats_e, cam, model._occlusion_limits[0],
+                                     model._occlusion_limits[1], model._occlusion)
+        check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), n_eval, cam.ref(), rig_ref,
+                                   model._flags, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(ws.buf), ws.bytes, s), "forward")
+        model._shard.allreduce_sum(lo_sum)
+        check(L.tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, ptr(rewards), ptr(scalars),
+                                  ptr(ws.buf), ws.bytes, s), "reward")
+        check(L.tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), n_eval, cam.ref(), rig_ref,
+                                    model._flags, ptr(occ), ptr(lo_sum), None, ptr(scalars), ptr(minmax), ptr(gout),
+                                    ptr(pg_e), ptr(qg_e), ptr(ws.buf), ws.bytes, s), "backward")
+        if step_w > 1:
+            pg.zero_()
+            qg.zero_()
+        check(L.tohip_rows_strided(ptr(pg_e), n_eval, 3, step_w, 1, ptr(pg), s), "scatter poses grad")
+        check(L.tohip_rows_strided(ptr(qg_e), n_eval, 4, step_w, 1, ptr(qg), s), "scatter quats grad")
+        # every per-step quantity (loss-log row, Adam's step index) is read from `state` on the device
+        check(L.tohip_traj_regularizers(ptr(poses), ptr(model.poses0), W, float(model.smoothness_weight),
+                                        float(model.traj_length_weight), float(model.eps), ptr(scalars), ptr(loss_terms),
+                                        ptr(pg), 1, ptr(state), s), "regularizers")
+        check(L.tohip_adam_step(ptr(poses), ptr(pg), ptr(mp), ptr(vp), W * 3, float(lr_pose), betas[0], betas[1],
+                                adam_eps, 0, ptr(state), s), "adam poses")
+        check(L.tohip_adam_step(ptr(quats), ptr(qg), ptr(mq), ptr(vq), W * 4, float(lr_quat), betas[0], betas[1],
+                                adam_eps, 0, ptr(state), s), "adam quats")
+        check(L.tohip_early_stop(ptr(scalars), ptr(loss_terms), float(rewards_th), float(smoothness_th), ptr(state), 1, s),
+              "early stop")
+
+    with torch.cuda.device(dev):
+        if use_graph and not sharded and not occluded and n_opt_steps > 1:
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    iteration()
+                for _ in range(n_opt_steps):
+                    graph.replay()
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            for _ in range(n_opt_steps):
+                iteration()
     st = state.cpu()  # the run's only host synchronisation
     steps = int(st[3].item())
     lt_host = loss_terms[:max(steps, 1)].cpu()
