@@ -606,47 +606,39 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
         for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
         for (int v = v0; v < v1; ++v) {
             const WayHot h = hot[v];
-            const float M = aux[v].M;
             bool any_act = false;
             float om[P];
             load_occ<P, OCC>(occ, occw, v, base, om);
             if constexpr (P >= 2) {
-                // phase 1 (packed, branch-free): visibility of every pair and whether any element needs the
-                // gradient path; phase 2 runs under ONE wave-uniform branch per waypoint
-                constexpr int NP = P / 2;
-                Vis2 s2[NP];
-                f2 Xs[NP], Ys[NP], Zs[NP], y0s[NP], y1s[NP], y2s[NP];
+                // phase 1 (packed, branch-free): p and p_hat of every pair, and whether any element of the wave needs
+                // the gradient path; phase 2, under ONE wave-uniform branch per waypoint, re-evaluates those few
+                // elements with the scalar twin (bit-identical p), so nothing but `need` stays live across the branch
                 bool need = false;
 #pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    const int i = 2 * k;
-                    to_cam_pk(h, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, Xs[k], Ys[k], Zs[k], y0s[k], y1s[k],
-                              y2s[k]);
-                    s2[k].p = soft_vis_pk<PINHOLE>(cc, Xs[k], Ys[k], Zs[k], &s2[k]) * f2{om[i], om[i + 1]};
-                    const f2 p = s2[k].p;
-                    const f2 pp = p - pk_splat(h.a);
-                    const f2 ph = pp * pk_splat(h.invM);
-                    // superset of (act | is_min | is_max): exact flags are recomputed in bwd_accum
-                    // (the argmin set only matters when a > 0: bwd_accum requires p == a && p > 0; with a = 0 — the
-                    // usual case — half the cloud has p == 0 and must not drag every wave into the gradient path)
+                for (int i = 0; i < P; i += 2) {
+                    f2 X, Y, Z, y0, y1, y2;
+                    to_cam_pk(h, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, X, Y, Z, y0, y1, y2);
+                    const f2 p = soft_vis_pk<PINHOLE>(cc, X, Y, Z, nullptr) * f2{om[i], om[i + 1]};
+                    const f2 ph = (p - pk_splat(h.a)) * pk_splat(h.invM);
+                    // superset of (act | is_min | is_max); the argmin set only matters when a > 0 (bwd_accum requires
+                    // p == a && p > 0; with a = 0 — the usual case — half the cloud has p == 0)
                     need |= (ph.x >= 0.5f) | (ph.y >= 0.5f) | ((h.a > 0.f) & ((p.x == h.a) | (p.y == h.a)));
                 }
                 if (__any(need)) {
+                    const float M = aux[v].M;  // only the gradient path compares against the max
 #pragma unroll
-                    for (int k = 0; k < NP; ++k) {
-                        const int i = 2 * k;
-                        const Vis sa = {s2[k].p.x, s2[k].S.x, s2[k].u.x, s2[k].v.x, s2[k].rz.x};
-                        const Vis sb = {s2[k].p.y, s2[k].S.y, s2[k].u.y, s2[k].v.y, s2[k].rz.y};
-                        any_act |= bwd_accum<PINHOLE>(cc, h, M, sa, Xs[k].x, Ys[k].x, Zs[k].x, y0s[k].x, y1s[k].x, y2s[k].x,
-                                                      gn[i], valid[i], acc, ties + (int64_t)v * 32);
-                        any_act |= bwd_accum<PINHOLE>(cc, h, M, sb, Xs[k].y, Ys[k].y, Zs[k].y, y0s[k].y, y1s[k].y, y2s[k].y,
-                                                      gn[i + 1], valid[i + 1], acc, ties + (int64_t)v * 32);
+                    for (int i = 0; i < P; ++i) {
+                        float X, Y, Z, y0, y1, y2;
+                        to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+                        any_act |= bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], valid[i], om[i], acc,
+                                                     ties + (int64_t)v * 32);
                     }
                 }
             } else {
                 float X, Y, Z, y0, y1, y2;
                 to_cam(h, x[0], y[0], z[0], X, Y, Z, y0, y1, y2);
-                any_act |= bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[0], valid[0], om[0], acc, ties + (int64_t)v * 32);
+                any_act |= bwd_eval<PINHOLE>(cc, h, aux[v].M, X, Y, Z, y0, y1, y2, gn[0], valid[0], om[0], acc,
+                                             ties + (int64_t)v * 32);
             }
             // every pair has been evaluated; when no lane of the wave was active all 14 sums are exact zeros
             // and the cross-lane reduction of zeros is skipped
