@@ -574,7 +574,6 @@ static int build(const Bufs& b, const float* pts, int n, int with_origin, hipStr
         }
         nf = h[kCtrlNFaces];
     }
-done:
     if (round >= max_rounds) return TOHIP_ENOTCONV;
     if (rounds_out) *rounds_out = round;
     k_mark_vertices<<<nblocks(nf), TO_BLOCK, 0, st>>>(b);

@@ -98,12 +98,6 @@ k_pose_bwd_finish(const double* __restrict__ part, int nparts, float* __restrict
 // quaternion_apply(q_inv, .) = two raw Hamilton products, every term rounded, left to right
 // (no fma: this translation unit is built with -ffp-contract=off).
 
-struct ExactCam {
-    float qi[4];  // q_inv
-    float qn[4];  // conj(q_inv)
-    float t[3];
-};
-
 __global__ void __launch_bounds__(TO_BLOCK)
 k_to_camera_frame(const float* __restrict__ xyz, int64_t n, const float* __restrict__ quat,
                   const float* __restrict__ trans, int normalize, int out_layout, float* __restrict__ out) {

@@ -145,15 +145,6 @@ __device__ __forceinline__ float4 wave_tile_bound(const CloudView& cv, int64_t b
     return b;
 }
 
-// true (wave-uniform) when no point within `tb` can have camera-frame d2 <= thr
-__device__ __forceinline__ bool tile_culled(const WayHot& h, const float4& tb, float mean, float thr, float sthr) {
-    float X, Y, Z, y0, y1, y2;
-    to_cam(h, tb.x, tb.y, tb.z, X, Y, Z, y0, y1, y2);
-    const float D2 = dist2_mean(X, Y, Z, mean);
-    const float bound = fmaf(tb.w, fmaf(2.0f, sthr, tb.w), thr) * 1.00001f;  // (sthr + r)^2, rounded up
-    return __builtin_amdgcn_readfirstlane((int)(D2 > bound)) != 0;
-}
-
 // One (tile, waypoint) liveness decision, written once so that the kernels that skip a pair and the
 // finishing kernel that skips its partial agree bit for bit.  q0..q3 = the waypoint's WayHot as 4 float4.
 __device__ __forceinline__ bool tile_live(const float4& q0, const float4& q1, const float4& q2, float thr, float sthr,
@@ -504,20 +495,6 @@ __device__ __forceinline__ bool bwd_eval(const CamConsts& cc, const WayHot& h, f
     soft_vis<PINHOLE>(cc, X, Y, Z, &s);
     s.p *= om;  // an occluded pair has p = 0: inactive, and dp/dc = p * (...) = 0
     return bwd_accum<PINHOLE>(cc, h, M, s, X, Y, Z, y0, y1, y2, gn, valid, acc, tb);
-}
-
-// the same for two points whose visibility is computed with packed arithmetic
-template <bool PINHOLE>
-__device__ __forceinline__ bool bwd_eval_pk(const CamConsts& cc, const WayHot& h, float M, f2 X, f2 Y, f2 Z, f2 y0, f2 y1,
-                                            f2 y2, float gn0, float gn1, bool valid0, bool valid1, f2 om,
-                                            float (&acc)[TO_BWD_NSUM], float* __restrict__ tb) {
-    Vis2 s2;
-    soft_vis_pk<PINHOLE>(cc, X, Y, Z, &s2);
-    s2.p = s2.p * om;
-    const Vis sa = {s2.p.x, s2.S.x, s2.u.x, s2.v.x, s2.rz.x}, sb = {s2.p.y, s2.S.y, s2.u.y, s2.v.y, s2.rz.y};
-    const bool a = bwd_accum<PINHOLE>(cc, h, M, sa, X.x, Y.x, Z.x, y0.x, y1.x, y2.x, gn0, valid0, acc, tb);
-    const bool b = bwd_accum<PINHOLE>(cc, h, M, sb, X.y, Y.y, Z.y, y0.y, y1.y, y2.y, gn1, valid1, acc, tb);
-    return a || b;
 }
 
 template <bool PINHOLE>
