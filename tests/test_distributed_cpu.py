@@ -27,7 +27,7 @@ def _worker(rank, world, port, n_pts, n_wps, out_dir):
     from trajectory_optimization_amd import synth
     from trajectory_optimization_amd.distributed import WaypointShard, init_from_env
     from oracle import oracle
-    r, w, device = init_from_env(backend="gloo")
+    r, w, device = init_from_env(backend="gloo", use_gpu=False)
     assert (r, w, device.type) == (rank, world, "cpu")
     shard = WaypointShard()
     K, iw, ih = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT

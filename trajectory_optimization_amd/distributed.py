@@ -42,14 +42,14 @@ class WaypointShard:
         return t
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, use_gpu=None):
     """Initialise torch.distributed from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torchrun contract) and bind
-    this process to its GPU.  Returns (rank, world_size, device)."""
+    this process to its GPU (use_gpu=False: stay on the CPU, e.g. the gloo tests).  Returns (rank, world_size, device)."""
     import os
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_gpu = torch.cuda.is_available()
+    use_gpu = torch.cuda.is_available() if use_gpu is None else (use_gpu and torch.cuda.is_available())
     backend = backend or os.environ.get("TOHIP_DIST_BACKEND")  # "gloo": rehearse N ranks on fewer GPUs
     if use_gpu and backend == "gloo":
         local = local % torch.cuda.device_count()
