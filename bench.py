@@ -7,7 +7,7 @@ For N>1 the driver launches it under torch.distributed.run, one rank per GPU (RC
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): a 1 M-point synthetic
 cloud x 128 waypoints per GPU, full forward + backward to (x,y,z) and quaternion gradients, through the
 C ABI of include/trajopt_hip.h.  One "step" = tohip_traj_forward -> [all-reduce of the log-odds vector when
-N>1] -> tohip_traj_reward -> tohip_traj_backward.  With N GPUs the trajectory has 128*N waypoints sharded
+N>1] -> tohip_traj_reward -> tohip_traj_backward [-> all-gather of the (W,7) gradient rows when N>1].  With N GPUs the trajectory has 128*N waypoints sharded
 contiguously over the ranks (weak scaling; N=8 is configs[3], 1 M x 1024); value = N_points * W_total / time.
 Inputs are resident in HBM before the timed region.
 
@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--wps-per-gpu", type=int, default=WPS_PER_GPU)
     ap.add_argument("--mode", choices=["both", "dense", "culled"], default="both",
                     help="dense = headline (every pair evaluated); culled = library default (exact skipping)")
+    ap.add_argument("--cameras", type=int, default=1,
+                    help="cameras per waypoint (BASELINE.json configs[4]: 5, with --wps-per-gpu 32); each (camera, "
+                         "waypoint) pair is one virtual waypoint with its own min-max normalisation")
     ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -129,16 +132,21 @@ def main():
     cam = ops.Camera(synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT)
     poses = torch.from_numpy(poses_all[lo:hi].copy()).to(device)
     quats = torch.from_numpy(quats_all[lo:hi].copy()).to(device)
-    ws = ops.TrajWorkspace(cloud, args.wps_per_gpu)
+    n_virtual = args.wps_per_gpu * args.cameras
+    rig = ops.CameraRig(*synth.camera_rig(args.cameras), device) if args.cameras > 1 else None
+    ws = ops.TrajWorkspace(cloud, n_virtual)
     gout = torch.ones(1, device=device)
     shard = WaypointShard() if n_gpus > 1 else None
 
     def step(flags):
-        lo_sum, minmax = ops.traj_forward(cloud, poses, quats, cam, ws, flags=flags)
+        lo_sum, minmax = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags)
         if shard is not None:
             shard.allreduce_sum(lo_sum)  # the one data-path collective: N floats over xGMI
         rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
-        pg, qg = ops.traj_backward(cloud, poses, quats, cam, ws, lo_sum, minmax, scalars=scalars, gout=gout, flags=flags)
+        pg, qg = ops.traj_backward(cloud, poses, quats, cam, ws, lo_sum, minmax, scalars=scalars, gout=gout, rig=rig, flags=flags)
+        if shard is not None:
+            g = shard.allgather_rows(torch.cat([pg, qg], dim=1))  # (W_total, 7) floats: every rank can step the optimiser
+            pg, qg = g[:, :3], g[:, 3:]
         return scalars, pg, qg
 
     def fence():
@@ -174,22 +182,23 @@ def main():
     dt, kern, out = timed(ops.DENSE if args.mode != "culled" else 0)
     # the library's default path: exact culling (bitwise identical outputs, tests/test_hip_traj.py)
     dt_c, kern_c, out_c = timed(0) if args.mode == "both" else (dt, kern, out)
-    evals_per_step = args.points * w_total
+    evals_per_step = args.points * w_total * args.cameras
     value = evals_per_step * args.steps / dt
 
     if rank == 0:
         # dominant kernel by summed device time; achieved = algorithmic bytes per launch / mean duration
         dom = max(ALGO_BYTES, key=lambda k: kern.get(k, (0.0, 0))[0])
         dom_ms = kern[dom][0] / max(kern[dom][1], 1)
-        local_evals = args.points * args.wps_per_gpu
+        local_evals = args.points * n_virtual
         achieved = ALGO_BYTES[dom] * local_evals / (dom_ms * 1e-3) / 1e9
         line = {
             "metric": "point-visibility evals/sec (fwd+bwd)", "value": value, "unit": "evals/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.points}-point cloud x {args.wps_per_gpu} waypoints per GPU "
-                                   f"({w_total} total), fwd + bwd (x,y,z,quaternion) gradients",
-                       "n_points": args.points, "waypoints_total": w_total,
+                                   f"({w_total} total)" + (f" x {args.cameras} cameras" if args.cameras > 1 else "") +
+                                   ", fwd + bwd (x,y,z,quaternion) gradients",
+                       "n_points": args.points, "waypoints_total": w_total, "cameras": args.cameras,
                        "parallelism": f"waypoint-shard x{n_gpus}" if n_gpus > 1 else "single GPU",
                        "mode": "dense: every (point, waypoint) pair evaluated, no data-dependent skipping",
                        "loss_vis": float(out[0][1].item())},
@@ -209,7 +218,7 @@ def main():
             "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in kern_c.items()},
             "note": "library default: pairs whose log-odds term is provably exactly 0 are skipped via a "
                     "Morton-sorted cloud, per-256-point bounding spheres and a distance bound on p"}
-        if n_gpus == 1 and args.cpu_wps > 0:
+        if n_gpus == 1 and args.cpu_wps > 0 and args.cameras == 1:
             line["hpr"] = hpr_leg(pts, device)
             line["cpu_baseline"] = cpu_baseline(pts, poses_all, quats_all, args.cpu_wps)
         print(json.dumps(line), flush=True)

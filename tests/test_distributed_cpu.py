@@ -45,8 +45,12 @@ def _worker(rank, world, port, n_pts, n_wps, out_dir):
     qg = torch.zeros(n_wps, 4, dtype=torch.float64)
     pg[lo:hi], qg[lo:hi] = torch.from_numpy(pg_l), torch.from_numpy(qg_l)
     pg, qg = shard.allreduce_sum(pg), shard.allreduce_sum(qg)                       # (W,7) gradient assembly
+    gathered = None
+    if n_wps % world == 0:  # equal shards (bench.py's weak-scaling layout): rows assembled by one all-gather instead
+        gathered = shard.allgather_rows(torch.from_numpy(np.concatenate([pg_l, qg_l], axis=1)))
+        assert torch.equal(gathered, torch.cat([pg, qg], dim=1))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rewards=rewards.numpy(), pg=pg.numpy(), qg=qg.numpy(),
-             bounds=np.array([lo, hi]))
+             bounds=np.array([lo, hi]), gathered=np.zeros(0) if gathered is None else gathered.numpy())
     dist.barrier()
     dist.destroy_process_group()
 

@@ -42,6 +42,18 @@ class WaypointShard:
         return t
 
 
+    def allgather_rows(self, t):
+        """Concatenate every rank's (rows, k) block in rank order (equal row counts): the per-waypoint gradient
+        rows of a contiguous shard -> the whole trajectory's, on every rank."""
+        if self.world_size == 1:
+            return t
+        staged = t.is_cuda and dist.get_backend(self.group) == "gloo"
+        src = t.detach().cpu() if staged else t.contiguous()
+        out = src.new_empty((self.world_size * src.shape[0],) + tuple(src.shape[1:]))
+        dist.all_gather_into_tensor(out, src, group=self.group)
+        return out.to(t.device) if staged else out
+
+
 def init_from_env(backend=None, use_gpu=None):
     """Initialise torch.distributed from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torchrun contract) and bind
     this process to its GPU (use_gpu=False: stay on the CPU, e.g. the gloo tests).  Returns (rank, world_size, device)."""
