@@ -166,6 +166,23 @@ int tohip_hidden_pts_removal(const float *xyz, int64_t n_points, float param, in
                              int32_t *visible_count, float *mask, void *workspace, size_t workspace_bytes,
                              void *stream);
 
+/* hidden_pts_removal of n_segments independent clouds in one pass, each seen from its own origin: the
+ * per-camera use of HPR in pc_processor.py:171-178 (one segment per camera topic / per waypoint).  xyz holds the
+ * segments end to end; segment s = rows [seg_offsets_host[s], seg_offsets_host[s+1]) (HOST array, n_segments+1,
+ * seg_offsets_host[0] = 0).  Every segment gets its own flip radius (max norm of ITS points) and its own
+ * "drop the last hull vertex".  All hulls advance in the same rounds.
+ *   visible_idx          capacity n_total int32: rows of xyz, ascending; segment s's visible rows are
+ *                        visible_idx[seg_visible_offsets[s] : seg_visible_offsets[s+1]]
+ *   seg_visible_offsets  n_segments+1 int32 (device)
+ *   mask                 n_total floats 0/1, or NULL
+ *   seg_status           n_segments int32 (device) or NULL: 0 ok; 1 fewer than 4 points, 2 flat — scipy raises
+ *                        QhullError for both, here the segment reports no visible points
+ * SYNCHRONISES the stream. */
+size_t tohip_hpr_batched_workspace_bytes(int64_t n_total, int32_t n_segments);
+int tohip_hidden_pts_removal_batched(const float *xyz, const int64_t *seg_offsets_host, int32_t n_segments, float param,
+                                     int32_t *visible_idx, int32_t *seg_visible_offsets, float *mask, int32_t *seg_status,
+                                     void *workspace, size_t workspace_bytes, void *stream);
+
 /* convexHull (tools.py:56-64): ascending hull-vertex indices of pts (n,3), optionally with the origin
  * appended as point n.  idx capacity n+1 int32; *count device int32; *rounds_host (may be NULL) the
  * number of insertion rounds.  SYNCHRONISES the stream. */

@@ -86,3 +86,70 @@ def test_hpr_degenerate_inputs(dev):
         ops.hidden_pts_removal(flat)
     with pytest.raises(_lib.HipError):
         ops.hidden_pts_removal(torch.rand(3, 3, device=dev))  # fewer than 4 points
+
+
+def test_hpr_batched_matches_qhull_per_segment(dev):
+    """Many viewpoints in one pass: every segment's visible set equals scipy/Qhull's on that segment alone, with its
+    own flip radius and its own dropped last vertex; short, empty and flat segments report a status and nothing else."""
+    from oracle import oracle
+    from trajectory_optimization_amd import ops
+    rng = np.random.default_rng(11)
+    segs = []
+    for k, n in enumerate([5000, 0, 37, 3, 12000, 800, 4, 25000, 1]):
+        c = rng.uniform(-15, 15, 3).astype(np.float32) * (k % 3 != 0)  # some viewpoints inside their cloud, some outside
+        segs.append(synth.make_cloud(n, seed=20 + k) * np.float32(0.5 + 0.2 * k) - c if n else np.zeros((0, 3), np.float32))
+    flat = np.zeros((50, 3), np.float32)
+    flat[:, 0] = np.arange(1, 51)
+    flat[:, 1] = rng.uniform(-1, 1, 50)  # coplanar with the appended origin (z = 0)
+    segs.insert(4, flat)
+    # origin strictly inside a closed shell: the origin is no hull vertex and the highest real vertex is dropped
+    u = rng.normal(size=(3000, 3))
+    segs.append((u / np.linalg.norm(u, axis=1, keepdims=True) * rng.uniform(4, 6, (3000, 1))).astype(np.float32))
+    offs = np.concatenate([[0], np.cumsum([len(s) for s in segs])])
+    allp = np.concatenate(segs).astype(np.float32)
+    idx, voff, mask, status = ops.hidden_pts_removal_batched(torch.from_numpy(allp).to(dev), offs)
+    idx, mask, status = idx.cpu().numpy().astype(np.int64), mask.cpu().numpy(), status.cpu().numpy()
+    assert voff[0] == 0 and voff[-1] == len(idx)
+    for s, pts in enumerate(segs):
+        got = idx[voff[s]:voff[s + 1]] - offs[s]
+        if len(pts) < 4:
+            assert status[s] == 1 and len(got) == 0
+        elif s == 4:
+            assert status[s] == 2 and len(got) == 0
+        else:
+            ref, ref_mask = oracle.hidden_pts_removal(pts)
+            assert status[s] == 0
+            assert np.array_equal(got, ref), f"segment {s}"
+            assert np.array_equal(mask[offs[s]:offs[s + 1]], ref_mask)
+            one, _ = ops.hidden_pts_removal(torch.from_numpy(pts).to(dev))
+            assert np.array_equal(one.cpu().numpy(), got)
+
+
+def test_hpr_batched_single_segment_and_errors(dev):
+    from trajectory_optimization_amd import ops
+    pts = torch.from_numpy(synth.make_cloud(20000, seed=2)).to(dev)
+    idx, voff, mask, status = ops.hidden_pts_removal_batched(pts, [0, 20000])
+    one, one_mask = ops.hidden_pts_removal(pts)
+    assert torch.equal(idx, one) and torch.equal(mask, one_mask) and status.tolist() == [0] and voff.tolist() == [0, one.numel()]
+    with pytest.raises(ValueError):
+        ops.hidden_pts_removal_batched(pts, [0, 100])
+    with pytest.raises(Exception):
+        ops.hidden_pts_removal_batched(pts, [0, 15000, 10000, 20000])  # offsets must not decrease
+
+
+def test_hard_pipeline_many_cameras(dev):
+    """The per-camera pipeline over a rig in one batched hull pass == camera by camera (and camera 0 == the golden run)."""
+    from trajectory_optimization_amd.tools import visible_points_from_camera, visible_points_from_cameras
+    d = load_golden("hard_pipeline_bundled")
+    pts = torch.from_numpy(d["points"]).to(dev)
+    rq, _ = synth.camera_rig(5)
+    quats = np.stack([synth.quat_mul(d["quat"].reshape(4), q) for q in rq]).astype(np.float32)
+    trans = np.repeat(d["trans"].reshape(1, 3), 5, axis=0) + np.arange(5, dtype=np.float32)[:, None] * np.float32(0.5)
+    args = (torch.from_numpy(K).to(dev), IH, IW, float(d["min_dist"]), float(d["max_dist"]))
+    many = visible_points_from_cameras(pts, torch.from_numpy(trans).to(dev), torch.from_numpy(quats).to(dev), *args)
+    assert len(many) == 5
+    for c in range(5):
+        one = visible_points_from_camera(pts, torch.from_numpy(trans[c]).to(dev), torch.from_numpy(quats[c]).to(dev), *args)
+        for k in ("kept_idx", "kept_points", "visible_idx", "visible_points"):
+            assert torch.equal(many[c][k], one[k]), (c, k)
+    assert np.array_equal(many[0]["visible_idx"].cpu().numpy(), d["hpr_visible_idx"])

@@ -60,6 +60,9 @@ SIGNATURES = {
     "tohip_hpr_workspace_bytes": (c_sz, [c_i64]),
     "tohip_spherical_flip": (ctypes.c_int, [c_vp, c_i64, c_f, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_hidden_pts_removal": (ctypes.c_int, [c_vp, c_i64, c_f, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_hpr_batched_workspace_bytes": (c_sz, [c_i64, ctypes.c_int32]),
+    "tohip_hidden_pts_removal_batched": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int32, c_f, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
+                                                         c_vp]),
     "tohip_convex_hull_vertices": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, ctypes.POINTER(c_i32), c_vp, c_sz,
                                                    c_vp]),
     "tohip_traj_regularizers": (ctypes.c_int, [c_vp, c_vp, c_i64, c_f, c_f, c_f, c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_vp]),

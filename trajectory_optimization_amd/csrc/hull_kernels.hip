@@ -21,6 +21,8 @@
 //
 // Predicates are plain f64 (coordinate differences of f32 inputs are exact; products are rounded):
 // like Qhull's own, they are not exact on nearly coplanar quadruples — DESIGN.md §6.
+#include <vector>
+
 #include "common.hpp"
 
 namespace hull {
@@ -50,9 +52,18 @@ struct Bufs {
     int* tile_cnt;         // ntiles(M1)
     int* tile_off;         // ntiles(M1)
     float* flipped;        // 3 * M (only used by hidden_pts_removal)
-    int* flip_max;         // 1
+    int* flip_max;         // nseg
+    // segments: independent point sets (one hull each) laid end to end; segment s owns the expanded indices
+    // [seg_off[s], seg_off[s+1]) — its points followed by ONE slot for the appended origin — and the faces it
+    // grows never reference another segment, so every round kernel below serves all hulls at once
+    int* seg_off;          // nseg + 1
+    int* seg_status;       // nseg   0 ok, 1 fewer than 4 points (no hull), 2 flat (Qhull: QH6154)
+    int* seg_start;        // nseg + 1   first position of each segment in the compacted vertex list
+    int* seg_cnt;          // nseg
+    int* idx_all;          // M1 (batched result staging)
     int m1;
     int fcap;
+    int nseg;
 };
 
 __host__ inline size_t seg(size_t bytes) { return align_up(bytes, 256); }
@@ -62,8 +73,8 @@ __host__ inline int face_capacity(int64_t m1) {
     return (int)(c > 0x3fffffff ? 0x3fffffff : c);
 }
 
-__host__ inline size_t carve(Bufs* b, char* base, int64_t n_points) {
-    const int64_t m1 = n_points + 1;
+__host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg = 1) {
+    const int64_t m1 = n_points + nseg;
     const int fcap = face_capacity(m1);
     const int ntiles = (int)((m1 + 1023) / 1024);
     size_t o = 0;
@@ -90,8 +101,13 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points) {
     p = take(sizeof(int) * ntiles); if (b) b->tile_cnt = (int*)p;
     p = take(sizeof(int) * ntiles); if (b) b->tile_off = (int*)p;
     p = take(sizeof(float) * 3 * (size_t)n_points); if (b) b->flipped = (float*)p;
-    p = take(sizeof(int) * 4); if (b) b->flip_max = (int*)p;
-    if (b) { b->m1 = (int)m1; b->fcap = fcap; }
+    p = take(sizeof(int) * nseg); if (b) b->flip_max = (int*)p;
+    p = take(sizeof(int) * (nseg + 1)); if (b) b->seg_off = (int*)p;
+    p = take(sizeof(int) * nseg); if (b) b->seg_status = (int*)p;
+    p = take(sizeof(int) * (nseg + 1)); if (b) b->seg_start = (int*)p;
+    p = take(sizeof(int) * nseg); if (b) b->seg_cnt = (int*)p;
+    p = take(sizeof(int) * (nseg > 1 ? m1 : 1)); if (b) b->idx_all = (int*)p;
+    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; }
     return o;
 }
 
@@ -147,22 +163,37 @@ __device__ __forceinline__ void wave_face_max(const Bufs& b, int f, unsigned lon
     if (f >= 0) atomicMax(&b.fmax[f], key);
 }
 
+// segment of expanded index i: the largest s with seg_off[s] <= i
+__device__ __forceinline__ int find_seg(const Bufs& b, int i) {
+    int lo = 0, hi = b.nseg;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (b.seg_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_single_segment(Bufs b) { b.seg_off[0] = 0; b.seg_off[1] = b.m1; }
+
 __global__ void __launch_bounds__(TO_BLOCK)
-k_load(Bufs b, const float* __restrict__ pts, int n, int with_origin) {
+k_load(Bufs b, const float* __restrict__ pts, int with_origin) {
     const int stride = gridDim.x * TO_BLOCK;
     for (int i = blockIdx.x * TO_BLOCK + threadIdx.x; i < b.m1; i += stride) {
-        if (i < n) {
-            b.px[i] = (double)pts[3 * i]; b.py[i] = (double)pts[3 * i + 1]; b.pz[i] = (double)pts[3 * i + 2];
-        } else {
-            // the appended origin (tools.py:60); without it the slot repeats point 0 (never a new vertex)
-            b.px[i] = with_origin ? 0.0 : (double)pts[0];
-            b.py[i] = with_origin ? 0.0 : (double)pts[1];
-            b.pz[i] = with_origin ? 0.0 : (double)pts[2];
-        }
+        const int s = find_seg(b, i);
+        // row of the source array: every earlier segment has spent one slot on its origin.  The segment's last
+        // slot is the appended origin (tools.py:60); without it the slot repeats the segment's first point
+        // (never a new vertex)
+        const bool extra = i == b.seg_off[s + 1] - 1;
+        const int r = extra ? b.seg_off[s] - s : i - s;
+        const bool zero = extra && with_origin;
+        b.px[i] = zero ? 0.0 : (double)pts[3 * r];
+        b.py[i] = zero ? 0.0 : (double)pts[3 * r + 1];
+        b.pz[i] = zero ? 0.0 : (double)pts[3 * r + 2];
         b.pface[i] = kNone;
         b.vflag[i] = 0;
     }
-    if (blockIdx.x == 0 && threadIdx.x < kCtrlInts) b.ctrl[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < kCtrlInts)
+        b.ctrl[threadIdx.x] = (threadIdx.x == kCtrlNFaces || threadIdx.x == kCtrlNFaces + 8) ? 4 * b.nseg : 0;
 }
 
 // block-wide argmax of (key, lowest index on ties); all threads get the winner
@@ -184,76 +215,89 @@ __device__ int block_argmax(double key, int idx, double* skey, int* sidx, double
     return r;
 }
 
-// initial tetrahedron: lowest-x point, the point farthest from it, farthest from their line, farthest
-// from their plane.  One block.
+// initial tetrahedron of one segment per block: lowest-x point, the point farthest from it, farthest from their
+// line, farthest from their plane.  Segment s owns the face slots 4s .. 4s+3.
 __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
     __shared__ double skey[HULL_INIT_THREADS];
     __shared__ int sidx[HULL_INIT_THREADS];
-    const int t = threadIdx.x, m1 = b.m1;
-    double best = -INFINITY; int bi = 0x7fffffff;
-    for (int i = t; i < m1; i += HULL_INIT_THREADS) { const double k = -b.px[i]; if (k > best) { best = k; bi = i; } }
-    const int i0 = block_argmax(best, bi, skey, sidx, nullptr);
-    const double x0 = b.px[i0], y0 = b.py[i0], z0 = b.pz[i0];
-    best = -INFINITY; bi = 0x7fffffff;
-    for (int i = t; i < m1; i += HULL_INIT_THREADS) {
-        const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
-        const double k = dx * dx + dy * dy + dz * dz;
-        if (k > best) { best = k; bi = i; }
+    const int t = threadIdx.x, sg = blockIdx.x, lo = b.seg_off[sg], hi = b.seg_off[sg + 1], fb = 4 * sg;
+    double kk = 0.0, k2 = 0.0, k3 = 0.0, nx = 0.0, ny = 0.0, nz = 0.0, x0 = 0.0, y0 = 0.0, z0 = 0.0;
+    int i0 = lo, i1 = lo, i2 = lo, i3 = lo;
+    const bool enough = hi - lo - 1 >= 4;  // Qhull needs d+1 input points; the appended origin comes on top
+    if (enough) {
+        double best = -INFINITY; int bi = 0x7fffffff;
+        for (int i = lo + t; i < hi; i += HULL_INIT_THREADS) { const double k = -b.px[i]; if (k > best) { best = k; bi = i; } }
+        i0 = block_argmax(best, bi, skey, sidx, nullptr);
+        x0 = b.px[i0]; y0 = b.py[i0]; z0 = b.pz[i0];
+        best = -INFINITY; bi = 0x7fffffff;
+        for (int i = lo + t; i < hi; i += HULL_INIT_THREADS) {
+            const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
+            const double k = dx * dx + dy * dy + dz * dz;
+            if (k > best) { best = k; bi = i; }
+        }
+        i1 = block_argmax(best, bi, skey, sidx, &kk);
+        const double ex = b.px[i1] - x0, ey = b.py[i1] - y0, ez = b.pz[i1] - z0;
+        best = -INFINITY; bi = 0x7fffffff;
+        for (int i = lo + t; i < hi; i += HULL_INIT_THREADS) {
+            const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
+            const double cx = dy * ez - dz * ey, cy = dz * ex - dx * ez, cz = dx * ey - dy * ex;
+            const double k = cx * cx + cy * cy + cz * cz;
+            if (k > best) { best = k; bi = i; }
+        }
+        i2 = block_argmax(best, bi, skey, sidx, &k2);
+        const double fx = b.px[i2] - x0, fy = b.py[i2] - y0, fz = b.pz[i2] - z0;
+        nx = ey * fz - ez * fy; ny = ez * fx - ex * fz; nz = ex * fy - ey * fx;
+        best = -INFINITY; bi = 0x7fffffff;
+        for (int i = lo + t; i < hi; i += HULL_INIT_THREADS) {
+            const double k = fabs(nx * (b.px[i] - x0) + ny * (b.py[i] - y0) + nz * (b.pz[i] - z0));
+            if (k > best) { best = k; bi = i; }
+        }
+        i3 = block_argmax(best, bi, skey, sidx, &k3);
     }
-    double kk;
-    const int i1 = block_argmax(best, bi, skey, sidx, &kk);
-    const double ex = b.px[i1] - x0, ey = b.py[i1] - y0, ez = b.pz[i1] - z0;
-    best = -INFINITY; bi = 0x7fffffff;
-    for (int i = t; i < m1; i += HULL_INIT_THREADS) {
-        const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
-        const double cx = dy * ez - dz * ey, cy = dz * ex - dx * ez, cz = dx * ey - dy * ex;
-        const double k = cx * cx + cy * cy + cz * cz;
-        if (k > best) { best = k; bi = i; }
-    }
-    double k2;
-    const int i2 = block_argmax(best, bi, skey, sidx, &k2);
-    const double fx = b.px[i2] - x0, fy = b.py[i2] - y0, fz = b.pz[i2] - z0;
-    const double nx = ey * fz - ez * fy, ny = ez * fx - ex * fz, nz = ex * fy - ey * fx;
-    best = -INFINITY; bi = 0x7fffffff;
-    for (int i = t; i < m1; i += HULL_INIT_THREADS) {
-        const double k = fabs(nx * (b.px[i] - x0) + ny * (b.py[i] - y0) + nz * (b.pz[i] - z0));
-        if (k > best) { best = k; bi = i; }
-    }
-    double k3;
-    const int i3 = block_argmax(best, bi, skey, sidx, &k3);
     if (t == 0) {
-        if (!(kk > 0.0) || !(k2 > 0.0) || !(k3 > 0.0)) { b.ctrl[kCtrlError] = kErrFlat; return; }
+        const bool flat = enough && (!(kk > 0.0) || !(k2 > 0.0) || !(k3 > 0.0));
+        b.seg_status[sg] = !enough ? 1 : (flat ? 2 : 0);
+        if (!enough || flat) {
+            if (b.nseg == 1) b.ctrl[kCtrlError] = kErrFlat;  // the single-hull entry points refuse, like Qhull (QH6154/QH6214)
+            // no hull for this segment: its four face slots stay dead (never candidates, never neighbours of a live face)
+            for (int f = fb; f < fb + 4; ++f) {
+                for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = lo; b.fn[3 * f + k] = f; }
+                b.nx[f] = 0.0; b.ny[f] = 0.0; b.nz[f] = 0.0;
+                b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = 0x7fffffff;
+            }
+            return;
+        }
         int a = i0, c1 = i1, c2 = i2;
         const int d = i3;
         const double s = nx * (b.px[d] - x0) + ny * (b.py[d] - y0) + nz * (b.pz[d] - z0);
         if (s > 0.0) { const int tmp = c1; c1 = c2; c2 = tmp; }  // d must lie below face (a,c1,c2)
         const int F[4][3] = {{a, c1, c2}, {c1, a, d}, {c2, c1, d}, {a, c2, d}};
         const int Nb[4][3] = {{1, 2, 3}, {0, 3, 2}, {0, 1, 3}, {0, 2, 1}};
-        for (int f = 0; f < 4; ++f) {
-            for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = F[f][k]; b.fn[3 * f + k] = Nb[f][k]; }
+        for (int j = 0; j < 4; ++j) {
+            const int f = fb + j;
+            for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = F[j][k]; b.fn[3 * f + k] = fb + Nb[j][k]; }
             set_plane(b, f);
             b.fflags[f] = 1;
             b.fowner[f] = kNone;
             b.fmax[f] = 0ull;
             b.fapex[f] = 0x7fffffff;
         }
-        b.ctrl[kCtrlNFaces] = 4;
-        b.ctrl[kCtrlNFaces + 8] = 4;  // staged face counter (k_new_faces allocates from it, k_commit publishes it)
     }
 }
 
 __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
-    if (b.ctrl[kCtrlError]) return;
     const int stride = gridDim.x * TO_BLOCK;
-    int sv[4];
-    sv[0] = b.fv[0]; sv[1] = b.fv[1]; sv[2] = b.fv[2]; sv[3] = b.fv[5];
     const int nloop = (b.m1 + stride - 1) / stride;
     for (int it = 0; it < nloop; ++it) {
         const int i = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
         double best = 0.0; int bf = kNone;
-        if (i < b.m1 && !(i == sv[0] || i == sv[1] || i == sv[2] || i == sv[3])) {
-            for (int f = 0; f < 4; ++f) { const double d = fdist(b, f, i); if (d > best) { best = d; bf = f; } }
-            b.pface[i] = bf;
+        if (i < b.m1) {
+            const int fb = 4 * find_seg(b, i);
+            // the tetrahedron's corners: faces fb and fb+1 are (a,c1,c2) and (c1,a,d)
+            if ((b.fflags[fb] & 1) && !(i == b.fv[3 * fb] || i == b.fv[3 * fb + 1] || i == b.fv[3 * fb + 2] || i == b.fv[3 * fb + 5])) {
+                for (int f = fb; f < fb + 4; ++f) { const double d = fdist(b, f, i); if (d > best) { best = d; bf = f; } }
+                b.pface[i] = bf;
+            }
         }
         wave_face_max(b, bf, dkey(best));
     }
@@ -506,10 +550,11 @@ inline int nblocks(int64_t n, int cap = 2048) {
 }
 
 // Builds the hull of pts (n,3) [+ origin]; leaves vflag set.  Synchronises the stream.
-static int build(const Bufs& b, const float* pts, int n, int with_origin, hipStream_t st, int* rounds_out) {
-    k_load<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, pts, n, with_origin);
+// b.seg_off must already be on the device (k_single_segment for one hull).
+static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t st, int* rounds_out) {
+    k_load<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, pts, with_origin);
     TO_HIP_CHECK_LAUNCH();
-    k_init<<<1, HULL_INIT_THREADS, 0, st>>>(b);
+    k_init<<<b.nseg, HULL_INIT_THREADS, 0, st>>>(b);
     TO_HIP_CHECK_LAUNCH();
     k_assign0<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);
     k_far_arg<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, 0);
@@ -519,7 +564,7 @@ static int build(const Bufs& b, const float* pts, int n, int with_origin, hipStr
     if (e != hipSuccess) return (int)e;
     e = hipStreamSynchronize(st);
     if (e != hipSuccess) return (int)e;
-    if (h[kCtrlError] & kErrFlat) return TOHIP_EINVAL;  // all points coplanar: Qhull refuses too (QH6154)
+    if (b.nseg == 1 && (h[kCtrlError] & kErrFlat)) return TOHIP_EINVAL;
     int nf = h[kCtrlNFaces];
     const int max_rounds = 100000;
     int round = 0;
@@ -593,11 +638,101 @@ static int compact(const Bufs& b, int* out, int cap, int* total_dev, hipStream_t
     return TOHIP_OK;
 }
 
+// ---- batched hidden-point removal: per-segment flip radius, per-segment "drop the last hull vertex" -------
+__device__ __forceinline__ int find_src_seg(const Bufs& b, int r) {  // segment of source row r (seg_off[s] - s <= r)
+    int lo = 0, hi = b.nseg;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (b.seg_off[mid] - mid <= r) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(TO_BLOCK) k_norm_max_seg(Bufs b, const float* __restrict__ xyz, int n) {
+    const int stride = gridDim.x * TO_BLOCK;
+    const int nloop = (n + stride - 1) / stride;
+    for (int it = 0; it < nloop; ++it) {
+        const int i = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
+        int sg = -1, m = 0;
+        if (i < n) {
+            sg = find_src_seg(b, i);
+            m = __float_as_int(flip_norm(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])) & 0x7fffffff;
+        }
+        // a wave usually lies inside one segment: reduce there and issue one atomic
+        const int s0 = __shfl(sg, 0);
+        if (__all(sg == s0) && s0 >= 0) {
+            for (int s = 32; s > 0; s >>= 1) m = max(m, __shfl_xor(m, s));
+            if ((threadIdx.x & 63) == 0) atomicMax(&b.flip_max[s0], m);
+        } else if (sg >= 0) {
+            atomicMax(&b.flip_max[sg], m);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_flip_seg(Bufs b, const float* __restrict__ xyz, int n, float scale, float* __restrict__ flipped) {
+    const int stride = gridDim.x * TO_BLOCK;
+    for (int i = blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float radius = __int_as_float(b.flip_max[find_src_seg(b, i)]) * scale;  // tools.py:45, per viewpoint
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        const float nr = flip_norm(x, y, z);
+        const float r = radius - nr;
+        flipped[3 * i] = (2.0f * (r * x)) / nr + x;  // tools.py:46-52
+        flipped[3 * i + 1] = (2.0f * (r * y)) / nr + y;
+        flipped[3 * i + 2] = (2.0f * (r * z)) / nr + z;
+    }
+}
+
+// first position of every segment in the ascending vertex list (+ the total as entry nseg), and the number of
+// visible points it yields: all of its hull vertices but the last (tools.py:79)
+__global__ void __launch_bounds__(TO_BLOCK) k_seg_ranges(Bufs b, const int* __restrict__ total) {
+    const int T = *total;
+    const int stride = gridDim.x * TO_BLOCK;
+    for (int s = blockIdx.x * TO_BLOCK + threadIdx.x; s <= b.nseg; s += stride) {
+        const int key = b.seg_off[s];
+        int lo = 0, hi = T;  // lower bound of key in idx_all[0:T)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (b.idx_all[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        b.seg_start[s] = lo;
+    }
+}
+
+__global__ void __launch_bounds__(TO_BLOCK) k_seg_counts(Bufs b) {
+    const int stride = gridDim.x * TO_BLOCK;
+    for (int s = blockIdx.x * TO_BLOCK + threadIdx.x; s < b.nseg; s += stride)
+        b.seg_cnt[s] = max(0, b.seg_start[s + 1] - b.seg_start[s] - 1);
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_seg_write(Bufs b, const int* __restrict__ total, const int32_t* __restrict__ out_off, int32_t* __restrict__ out,
+            float* __restrict__ mask) {
+    const int T = *total;
+    const int stride = gridDim.x * TO_BLOCK;
+    for (int p = blockIdx.x * TO_BLOCK + threadIdx.x; p < T; p += stride) {
+        int lo = 0, hi = b.nseg;  // the last segment whose start is <= p (earlier ones with the same start are empty)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (b.seg_start[mid] <= p) lo = mid; else hi = mid;
+        }
+        if (p >= b.seg_start[lo + 1] - 1) continue;  // the segment's last hull vertex is dropped
+        const int row = b.idx_all[p] - lo;           // back to a row of the caller's concatenated array
+        out[out_off[lo] + p - b.seg_start[lo]] = row;
+        if (mask) mask[row] = 1.0f;
+    }
+}
+
 }  // namespace hull
 
 extern "C" size_t tohip_hpr_workspace_bytes(int64_t n) {
     if (n <= 0) return 256;
     return hull::carve(nullptr, nullptr, n);
+}
+
+extern "C" size_t tohip_hpr_batched_workspace_bytes(int64_t n_total, int32_t n_segments) {
+    if (n_total < 0 || n_segments <= 0) return 256;
+    return hull::carve(nullptr, nullptr, n_total, n_segments);
 }
 
 extern "C" int tohip_spherical_flip(const float* xyz, int64_t n, float param, float* flipped, float* radius_out,
@@ -616,8 +751,10 @@ extern "C" int tohip_convex_hull_vertices(const float* pts, int64_t n, int with_
     hipStream_t st = (hipStream_t)stream_;
     hull::Bufs b;
     hull::carve(&b, (char*)workspace, n);
+    hull::k_single_segment<<<1, 1, 0, st>>>(b);
+    TO_HIP_CHECK_LAUNCH();
     int rounds = 0;
-    int rc = hull::build(b, pts, (int)n, with_origin, st, &rounds);
+    int rc = hull::build(b, pts, with_origin, st, &rounds);
     if (rc != TOHIP_OK) return rc;
     if (rounds_host) *rounds_host = rounds;
     return hull::compact(b, idx, (int)n + 1, count, st);
@@ -631,9 +768,11 @@ extern "C" int tohip_hidden_pts_removal(const float* xyz, int64_t n, float param
     hipStream_t st = (hipStream_t)stream_;
     hull::Bufs b;
     hull::carve(&b, (char*)workspace, n);
+    hull::k_single_segment<<<1, 1, 0, st>>>(b);
+    TO_HIP_CHECK_LAUNCH();
     int rc = launch_flip(xyz, n, param, b.flipped, nullptr, b.flip_max, st);
     if (rc != TOHIP_OK) return rc;
-    rc = hull::build(b, b.flipped, (int)n, 1, st, nullptr);
+    rc = hull::build(b, b.flipped, 1, st, nullptr);
     if (rc != TOHIP_OK) return rc;
     // the hull lists at most n+1 vertices; visible_idx holds n: the last one is dropped anyway
     rc = hull::compact(b, visible_idx, (int)n, b.ctrl + hull::kCtrlChanged, st);
@@ -645,5 +784,67 @@ extern "C" int tohip_hidden_pts_removal(const float* xyz, int64_t n, float param
     hull::k_finish_visible<<<hull::nblocks(n), TO_BLOCK, 0, st>>>(visible_idx, b.ctrl + hull::kCtrlChanged, 1, (int)n,
                                                                    visible_count, mask);
     TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+// hidden_pts_removal of n_segments independent clouds in ONE pass (each seen from its own origin: the per-camera
+// use of /root/reference/src/pc_processor.py:171-178, one segment per camera or waypoint).  xyz holds the segments
+// end to end, segment s = rows [seg_offsets_host[s], seg_offsets_host[s+1]).  All hulls advance in the same rounds,
+// so the cost of a round (launches + one readback) is shared by every viewpoint.
+//   visible_idx          n_total ints: rows of xyz, ascending; segment s's visible rows are
+//                        visible_idx[seg_visible_offsets[s] : seg_visible_offsets[s+1]]
+//   seg_visible_offsets  n_segments + 1 ints (device)
+//   mask                 n_total floats 0/1, or NULL
+//   seg_status           n_segments ints (device) or NULL: 0 ok; 1 fewer than 4 points and 2 flat — Qhull raises for
+//                        both (the reference would throw); here such a segment just reports no visible points
+extern "C" int tohip_hidden_pts_removal_batched(const float* xyz, const int64_t* seg_offsets_host, int32_t n_segments,
+                                                float param, int32_t* visible_idx, int32_t* seg_visible_offsets,
+                                                float* mask, int32_t* seg_status, void* workspace, size_t workspace_bytes,
+                                                void* stream_) {
+    if (!seg_offsets_host || n_segments <= 0 || !visible_idx || !seg_visible_offsets || !workspace) return TOHIP_EINVAL;
+    if (seg_offsets_host[0] != 0) return TOHIP_EINVAL;
+    for (int32_t s = 0; s < n_segments; ++s)
+        if (seg_offsets_host[s + 1] < seg_offsets_host[s]) return TOHIP_EINVAL;
+    const int64_t n = seg_offsets_host[n_segments];
+    if (n + n_segments > (int64_t)100000000 || (n > 0 && !xyz)) return TOHIP_EINVAL;
+    if (workspace_bytes < hull::carve(nullptr, nullptr, n, n_segments)) return TOHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream_;
+    hull::Bufs b;
+    hull::carve(&b, (char*)workspace, n, n_segments);
+    std::vector<int> off((size_t)n_segments + 1);
+    for (int32_t s = 0; s <= n_segments; ++s) off[s] = (int)(seg_offsets_host[s] + s);  // + one origin slot per segment
+    hipError_t e = hipMemcpyAsync(b.seg_off, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipStreamSynchronize(st);  // `off` is pageable host memory owned by this call
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(b.flip_max, 0, sizeof(int) * (size_t)n_segments, st);
+    if (e != hipSuccess) return (int)e;
+    if (n > 0) {
+        hull::k_norm_max_seg<<<hull::nblocks(n), TO_BLOCK, 0, st>>>(b, xyz, (int)n);
+        TO_HIP_CHECK_LAUNCH();
+        hull::k_flip_seg<<<hull::nblocks(n), TO_BLOCK, 0, st>>>(b, xyz, (int)n, (float)pow(10.0, (double)param), b.flipped);
+        TO_HIP_CHECK_LAUNCH();
+    }
+    int rc = hull::build(b, b.flipped, 1, st, nullptr);
+    if (rc != TOHIP_OK) return rc;
+    int* total = b.ctrl + hull::kCtrlChanged;
+    rc = hull::compact(b, b.idx_all, b.m1, total, st);
+    if (rc != TOHIP_OK) return rc;
+    hull::k_seg_ranges<<<hull::nblocks(n_segments + 1), TO_BLOCK, 0, st>>>(b, total);
+    TO_HIP_CHECK_LAUNCH();
+    hull::k_seg_counts<<<hull::nblocks(n_segments), TO_BLOCK, 0, st>>>(b);
+    TO_HIP_CHECK_LAUNCH();
+    k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(b.seg_cnt, n_segments, seg_visible_offsets, seg_visible_offsets + n_segments);
+    TO_HIP_CHECK_LAUNCH();
+    if (mask && n > 0) {
+        e = hipMemsetAsync(mask, 0, sizeof(float) * (size_t)n, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hull::k_seg_write<<<hull::nblocks(b.m1), TO_BLOCK, 0, st>>>(b, total, seg_visible_offsets, visible_idx, mask);
+    TO_HIP_CHECK_LAUNCH();
+    if (seg_status) {
+        e = hipMemcpyAsync(seg_status, b.seg_status, sizeof(int) * (size_t)n_segments, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
     return TOHIP_OK;
 }

@@ -146,6 +146,9 @@ def pose_backward(cloud, trans, quat, cam, ws, mask=None, grad_obs=None, scalars
     return tg, qg
 
 
+HPR_BATCH_POINTS = 8_000_000  # points per batched hull pass (workspace ~0.8 KB per point)
+
+
 def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method="hpr"):
     """(W, npad/32) int32 occlusion bit rows for the given waypoints: the hard per-camera pipeline of
     /root/reference/src/pc_processor.py:158-187 (exact transform -> hard frustum cull -> HPR from the camera
@@ -163,26 +166,48 @@ def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method=
     fws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     kept = torch.empty(n, dtype=torch.int32, device=dev)
     kcnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    kept_idx, kept_pts = [], []
     for w in range(W):
         cam3 = to_camera_frame_exact(points, quats[w], poses[w], normalize=True, transpose=True)
         with torch.cuda.device(dev):
             check(L.tohip_frustum_cull(ptr(cam3), n, cam.ref(), float(min_dist), float(max_dist), None, None, ptr(kept),
                                        ptr(kcnt), ptr(fws), wsb, stream_ptr()), "tohip_frustum_cull")
-        m = int(kcnt.item())
-        kept_pts = cam3[:, kept[:m].long()].t().contiguous()
-        if m >= 4:
-            if method == "zbuffer":
-                owns = render_points(kept_pts, torch.tensor([cam.c.K[i] for i in range(9)]).reshape(3, 3), cam.c.img_height,
-                                     cam.c.img_width,
-                                     znear=min_dist, zfar=max_dist)[2]
-                vis = torch.nonzero(owns).squeeze(1).to(torch.int32)
-            else:
-                vis, _ = hidden_pts_removal(kept_pts, 2)
-        else:
-            vis = torch.arange(m, dtype=torch.int32, device=dev)
-        vcnt = torch.tensor([vis.numel()], dtype=torch.int32, device=dev)
+        k = kept[:int(kcnt.item())].clone()
+        kept_idx.append(k)
+        kept_pts.append(cam3[:, k.long()].t().contiguous())
+    vis = [None] * W
+    if method == "zbuffer":
+        K33 = torch.tensor([cam.c.K[i] for i in range(9)]).reshape(3, 3)
+        for w in range(W):
+            if kept_idx[w].numel() >= 4:
+                owns = render_points(kept_pts[w], K33, cam.c.img_height, cam.c.img_width, znear=min_dist, zfar=max_dist)[2]
+                vis[w] = torch.nonzero(owns).squeeze(1).to(torch.int32)
+    else:
+        # one batched hull pass over the waypoints' culled clouds (chunked to bound the workspace: ~0.8 KB per point)
+        w0 = 0
+        while w0 < W:
+            w1, tot = w0, 0
+            while w1 < W and (w1 == w0 or tot + kept_idx[w1].numel() <= HPR_BATCH_POINTS):
+                tot += kept_idx[w1].numel()
+                w1 += 1
+            offs = [0]
+            for w in range(w0, w1):
+                offs.append(offs[-1] + kept_idx[w].numel())
+            idx, voff, _, status = hidden_pts_removal_batched(torch.cat(kept_pts[w0:w1]), offs, 2)
+            if bool((status == 2).any()):
+                raise _lib.HipError("occlusion_bits: a waypoint's culled cloud is flat (no 3-D hull; Qhull raises QH6154)")
+            for j, w in enumerate(range(w0, w1)):
+                if kept_idx[w].numel() >= 4:
+                    vis[w] = (idx[int(voff[j]):int(voff[j + 1])] - offs[j]).contiguous()
+            w0 = w1
+    for w in range(W):
+        m = kept_idx[w].numel()
+        v = vis[w] if vis[w] is not None else torch.arange(m, dtype=torch.int32, device=dev)  # < 4 points: nothing to occlude
+        kc = torch.tensor([m], dtype=torch.int32, device=dev)
+        vc = torch.tensor([v.numel()], dtype=torch.int32, device=dev)
+        kk = kept_idx[w] if m > 0 else kept
         with torch.cuda.device(dev):
-            check(L.tohip_occlusion_row(n, ptr(cloud.inv_perm), ptr(kept), ptr(kcnt), ptr(vis.contiguous()), ptr(vcnt),
+            check(L.tohip_occlusion_row(n, ptr(cloud.inv_perm), ptr(kk), ptr(kc), ptr(v if v.numel() else kept), ptr(vc),
                                         ptr(rows[w]), stream_ptr()), "tohip_occlusion_row")
     return rows
 
@@ -260,6 +285,33 @@ def hidden_pts_removal(points, param=2):
         check(_lib.lib().tohip_hidden_pts_removal(ptr(pts), n, float(param), ptr(idx), ptr(cnt), ptr(mask), ptr(ws), wsb,
                                                   stream_ptr()), "tohip_hidden_pts_removal")
     return idx[:int(cnt.item())], mask
+
+
+def hidden_pts_removal_batched(points, seg_offsets, param=2):
+    """HPR of several independent clouds in one pass (one viewpoint = the origin of each): `points` (n_total,3)
+    holds the segments end to end, `seg_offsets` (B+1 ints, host) their row ranges.
+    -> (visible_idx int32 (rows of `points`, ascending), seg_visible_offsets int64 (B+1, host), mask f32[n_total],
+        status int32[B] (0 ok, 1 fewer than 4 points, 2 flat))"""
+    _require_cuda(points, "points")
+    pts = points.detach().to(torch.float32).contiguous()
+    n, dev = pts.shape[0], pts.device
+    offs = [int(o) for o in seg_offsets]
+    B = len(offs) - 1
+    if B < 1 or offs[0] != 0 or offs[-1] != n:
+        raise ValueError("seg_offsets must run from 0 to len(points)")
+    c_offs = (ctypes.c_int64 * (B + 1))(*offs)
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    voff = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    mask = torch.empty(n, dtype=torch.float32, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    wsb = L.tohip_hpr_batched_workspace_bytes(n, B)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(L.tohip_hidden_pts_removal_batched(ptr(pts), c_offs, B, float(param), ptr(idx), ptr(voff), ptr(mask), ptr(status),
+                                                 ptr(ws), wsb, stream_ptr()), "tohip_hidden_pts_removal_batched")
+    voff_h = voff.cpu().to(torch.int64)
+    return idx[:int(voff_h[-1])], voff_h, mask, status
 
 
 def hull_vertices_with_origin(points, with_origin=True, return_rounds=False):

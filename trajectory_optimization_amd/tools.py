@@ -95,3 +95,29 @@ def visible_points_from_camera(points, trans, quat, intrins, img_height, img_wid
         vis_idx = torch.empty(0, dtype=torch.int32, device=kept.device)
     return dict(cam_points=cam_pts, kept_idx=kept_idx, kept_points=kept, visible_idx=vis_idx,
                 visible_points=kept[vis_idx.long()])
+
+
+def visible_points_from_cameras(points, trans, quats, intrins, img_height, img_width, min_dist=1.0, max_dist=15.0):
+    """visible_points_from_camera for C cameras at once (the reference repeats the pipeline per camera topic,
+    /root/reference/src/pc_processor.py:57-59,158-187): per camera transform -> hard cull, then ONE batched hull pass
+    for all cameras.  trans (C,3), quats (C,4) wxyz.  -> list of dicts as visible_points_from_camera returns."""
+    trans = torch.as_tensor(trans, dtype=torch.float32).reshape(-1, 3)
+    quats = torch.as_tensor(quats, dtype=torch.float32).reshape(-1, 4)
+    intr = torch.as_tensor(intrins, dtype=torch.float32)[:3, :3]
+    cam = ops.Camera(intr, img_width, img_height, 1.0, 5.0)
+    out = []
+    for c in range(trans.shape[0]):
+        cam_pts = ego_to_cam(points, trans[c], quats[c])
+        _, _, kept_idx = ops.frustum_cull(cam_pts, cam, min_dist, max_dist)
+        out.append(dict(cam_points=cam_pts, kept_idx=kept_idx, kept_points=cam_pts[:, kept_idx.long()].T.contiguous()))
+    offs = [0]
+    for r in out:
+        offs.append(offs[-1] + r["kept_points"].shape[0])
+    idx, voff, _, status = ops.hidden_pts_removal_batched(torch.cat([r["kept_points"] for r in out]), offs, 2)
+    for c, r in enumerate(out):
+        if int(status[c]) == 2:
+            raise RuntimeError(f"camera {c}: the culled cloud is flat, no 3-D hull (Qhull raises QH6154)")
+        # fewer than 4 kept points: no hull and nothing hidden-point removal could say -> empty, as the single-camera call
+        r["visible_idx"] = (idx[int(voff[c]):int(voff[c + 1])] - offs[c]).contiguous()
+        r["visible_points"] = r["kept_points"][r["visible_idx"].long()]
+    return out
