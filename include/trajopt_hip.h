@@ -153,6 +153,9 @@ int tohip_gather_points(const float *xyz, int64_t n_points, int in_layout, const
                         int64_t capacity, float *out_xyz, void *stream);
 
 /* ---- hidden-point removal (tools.py:38-85) ------------------------------------------------------ */
+/* Recommended workspace.  The hull's face pool takes every byte beyond the per-point part; the recommendation holds
+ * n/2 faces (HPR of a scene keeps a few % of the points).  A hull that creates more returns TOHIP_ENOSPC: call again
+ * with a larger workspace (4x is what the Python host does; 8 faces per point is never exceeded). */
 size_t tohip_hpr_workspace_bytes(int64_t n_points);
 /* sphericalFlip (tools.py:38-53): flipped (N,3), radius_out[0] = max||p|| * 10^param. Bit-exact. */
 int tohip_spherical_flip(const float *xyz, int64_t n_points, float param, float *flipped, float *radius_out,

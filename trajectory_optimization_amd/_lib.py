@@ -120,13 +120,18 @@ def lib():
     return _lib
 
 
+ENOSPC = -2  # TOHIP_ENOSPC
+
+
 class HipError(RuntimeError):
-    pass
+    code = None
 
 
 def check(code, what):
     if code != 0:
-        raise HipError(f"{what} failed: {lib().tohip_error_string(code).decode()} (code {code})")
+        err = HipError(f"{what} failed: {lib().tohip_error_string(code).decode()} (code {code})")
+        err.code = code
+        raise err
 
 
 def make_camera(K, img_width, img_height, min_dist, max_dist, eps=1e-6):

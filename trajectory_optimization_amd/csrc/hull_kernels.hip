@@ -31,6 +31,7 @@ constexpr int kNone = -1;
 constexpr int kCtrlNFaces = 0, kCtrlAnyOutside = 1, kCtrlChanged = 2, kCtrlError = 3, kCtrlAccepted = 4,
               kCtrlRound = 5, kCtrlChanged2 = 6, kCtrlAnyOutside2 = 7, kCtrlAccepted2 = 9 /* the round's values, published by
               k_commit for the host while the live counters are cleared for the next round; [8] = staged face counter */,
+              kCtrlFront = 10 /* [10..12]: three rotating frontier counters of the ownership sweeps */,
               kCtrlInts = 16;
 constexpr int kErrCapacity = 1, kErrFlat = 2, kErrTopology = 4;
 
@@ -47,6 +48,8 @@ struct Bufs {
     int* nfhead;           // fcap
     int* nfnext;           // fcap
     int* newface;          // 3 * fcap
+    int* front[2];         // fcap each: ping-pong frontiers of the ownership propagation
+    int* fstamp;           // fcap: sweep id a face was last queued in (one queue entry per face and sweep)
     int* ctrl;             // kCtrlInts
     int* vflag;            // M1
     int* tile_cnt;         // ntiles(M1)
@@ -68,14 +71,21 @@ struct Bufs {
 
 __host__ inline size_t seg(size_t bytes) { return align_up(bytes, 256); }
 
-__host__ inline int face_capacity(int64_t m1) {
-    int64_t c = 8 * m1 + 1024;
+// Faces are never recycled within a build, so the capacity bounds the faces ever CREATED (a few per hull vertex).
+// The default suits clouds whose hull is a small fraction of the points (HPR of a scene: 2-5 %); a build that runs out
+// returns TOHIP_ENOSPC and the caller retries with a larger workspace — every byte beyond the fixed part is used for
+// faces (faces_for_bytes), up to the never-exceeded-in-practice 8 per point.
+constexpr size_t kBytesPerFace = 17 * sizeof(int) + 4 * sizeof(double);  // the per-face arrays carved below
+constexpr int kFaceArrays = 16;
+
+__host__ inline int default_face_capacity(int64_t m1, int64_t nseg) {
+    int64_t c = m1 / 2 + 64 * nseg + 4096;
+    if (c < 262144) c = 262144 < 8 * m1 + 1024 ? 262144 : 8 * m1 + 1024;  // small clouds: memory is no concern, a retry is
     return (int)(c > 0x3fffffff ? 0x3fffffff : c);
 }
 
-__host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg = 1) {
+__host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg, int fcap) {
     const int64_t m1 = n_points + nseg;
-    const int fcap = face_capacity(m1);
     const int ntiles = (int)((m1 + 1023) / 1024);
     size_t o = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += seg(bytes); return p; };
@@ -96,6 +106,9 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * (size_t)fcap); if (b) b->nfhead = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->nfnext = (int*)p;
     p = take(sizeof(int) * 3 * (size_t)fcap); if (b) b->newface = (int*)p;
+    p = take(sizeof(int) * (size_t)fcap); if (b) b->front[0] = (int*)p;
+    p = take(sizeof(int) * (size_t)fcap); if (b) b->front[1] = (int*)p;
+    p = take(sizeof(int) * (size_t)fcap); if (b) b->fstamp = (int*)p;
     p = take(sizeof(int) * kCtrlInts); if (b) b->ctrl = (int*)p;
     p = take(sizeof(int) * m1); if (b) b->vflag = (int*)p;
     p = take(sizeof(int) * ntiles); if (b) b->tile_cnt = (int*)p;
@@ -109,6 +122,18 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * (nseg > 1 ? m1 : 1)); if (b) b->idx_all = (int*)p;
     if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; }
     return o;
+}
+
+// the largest face capacity a workspace of `bytes` holds for this input (0 if not even the minimum fits)
+__host__ inline int faces_for_bytes(int64_t n_points, int64_t nseg, size_t bytes) {
+    const size_t fixed = carve(nullptr, nullptr, n_points, nseg, 0) + (size_t)kFaceArrays * 256;
+    if (bytes <= fixed) return 0;
+    size_t f = (bytes - fixed) / kBytesPerFace;
+    const size_t hi = (size_t)8 * (size_t)(n_points + nseg) + 1024;
+    if (f > hi) f = hi;
+    if (f > 0x3fffffff) f = 0x3fffffff;
+    if ((int64_t)f < 4 * nseg + 64) return 0;
+    return (int)f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -142,12 +167,32 @@ __device__ __forceinline__ void set_plane(const Bufs& b, int f) {
     b.nz[f] = ux * vy - uy * vx;
 }
 
-// atomicMax of `key` into fmax[f] for every lane with f >= 0; when all live lanes of the wave share one face the
-// maximum is reduced in the wave first and ONE atomic is issued (same-address atomics serialise at ~90/us, and
-// in the early rounds a handful of faces own a million points).  Must be called by all lanes of the wave.
-__device__ __forceinline__ void wave_face_max(const Bufs& b, int f, unsigned long long key) {
+// Per-face maximum of `key` over many points.  Early rounds aim a million points at a handful of faces, and
+// same-address global atomics serialise (~90 per microsecond), so the maximum is reduced in three levels: in the
+// wave (up to 8 distinct faces per call), in a 256-entry table in LDS shared by the block across all iterations of
+// its point loop, and only then — once per block and face — in global memory.  A face that does not get a table
+// slot (late rounds: thousands of faces, no contention) goes to global memory directly.
+constexpr int kFaceMaxSlots = TO_BLOCK;
+struct FaceMaxTable {
+    unsigned long long key[kFaceMaxSlots];
+    int face[kFaceMaxSlots];
+};
+
+__device__ __forceinline__ void face_max_init(FaceMaxTable& t) {
+    t.key[threadIdx.x] = 0ull; t.face[threadIdx.x] = kNone;
+    __syncthreads();
+}
+
+__device__ __forceinline__ void face_max_put(const Bufs& b, FaceMaxTable& t, int f, unsigned long long key) {
+    const int slot = (int)(hash32((unsigned)f) & (unsigned)(kFaceMaxSlots - 1));
+    const int old = atomicCAS(&t.face[slot], kNone, f);
+    if (old == kNone || old == f) atomicMax(&t.key[slot], key);
+    else atomicMax(&b.fmax[f], key);
+}
+
+// must be called by all lanes of the wave
+__device__ __forceinline__ void wave_face_max(const Bufs& b, FaceMaxTable& t, int f, unsigned long long key) {
     unsigned long long todo = __ballot(f >= 0);
-    // up to 8 distinct faces per wave are reduced in the wave and cost one atomic each; the rest go lane by lane
     for (int it = 0; it < 8 && todo != 0ull; ++it) {
         const int f0 = __shfl(f, __builtin_ctzll(todo));
         const bool mine = f == f0;
@@ -156,11 +201,38 @@ __device__ __forceinline__ void wave_face_max(const Bufs& b, int f, unsigned lon
             const unsigned long long o = ((unsigned long long)(unsigned)__shfl_xor((int)(m >> 32), s) << 32) | (unsigned)__shfl_xor((int)m, s);
             m = o > m ? o : m;
         }
-        if ((threadIdx.x & 63) == 0) atomicMax(&b.fmax[f0], m);
+        if ((threadIdx.x & 63) == 0) face_max_put(b, t, f0, m);
         todo &= ~__ballot(mine);
         if (mine) f = kNone;
     }
-    if (f >= 0) atomicMax(&b.fmax[f], key);
+    if (f >= 0) face_max_put(b, t, f, key);
+}
+
+__device__ __forceinline__ void face_max_flush(const Bufs& b, FaceMaxTable& t) {
+    __syncthreads();
+    if (t.face[threadIdx.x] != kNone) atomicMax(&b.fmax[t.face[threadIdx.x]], t.key[threadIdx.x]);
+}
+
+// Reserve `want` (>= 0) consecutive slots per thread from *counter with ONE atomic per block (a same-address atomic
+// per lane or wave serialises); returns the thread's first slot.  Must be called by all threads of the block.
+__device__ __forceinline__ int block_alloc(int* counter, int want) {
+    __shared__ int wave_tot[TO_WAVES_PER_BLOCK];
+    __shared__ int block_base;
+    int incl = want;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int s = 1; s < 64; s <<= 1) {
+        const int o = __shfl_up(incl, s);
+        if (lane >= s) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < TO_WAVES_PER_BLOCK; ++w) { const int c = wave_tot[w]; total += c; if (w < wave) before += c; }
+    if (threadIdx.x == 0) block_base = total > 0 ? atomicAdd(counter, total) : 0;
+    __syncthreads();
+    const int base = block_base;
+    __syncthreads();  // block_base / wave_tot are reused by the next call
+    return base + before + incl - want;
 }
 
 // segment of expanded index i: the largest s with seg_off[s] <= i
@@ -263,7 +335,7 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
             for (int f = fb; f < fb + 4; ++f) {
                 for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = lo; b.fn[3 * f + k] = f; }
                 b.nx[f] = 0.0; b.ny[f] = 0.0; b.nz[f] = 0.0;
-                b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = 0x7fffffff;
+                b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = 0x7fffffff; b.fstamp[f] = 0;
             }
             return;
         }
@@ -281,11 +353,14 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
             b.fowner[f] = kNone;
             b.fmax[f] = 0ull;
             b.fapex[f] = 0x7fffffff;
+            b.fstamp[f] = 0;
         }
     }
 }
 
 __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
+    __shared__ FaceMaxTable tab;
+    face_max_init(tab);
     const int stride = gridDim.x * TO_BLOCK;
     const int nloop = (b.m1 + stride - 1) / stride;
     for (int it = 0; it < nloop; ++it) {
@@ -299,8 +374,9 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
                 b.pface[i] = bf;
             }
         }
-        wave_face_max(b, bf, dkey(best));
+        wave_face_max(b, tab, bf, dkey(best));
     }
+    face_max_flush(b, tab);
 }
 
 // ---- round --------------------------------------------------------------------------------------
@@ -332,6 +408,55 @@ __global__ void __launch_bounds__(TO_BLOCK) k_far_arg(Bufs b, int f_lo) {
     }
 }
 
+// One push sweep of the ownership propagation: every queued face offers its owner to the neighbours that owner's
+// apex sees; a neighbour takes it if the owner ranks better than its current one, and is queued for the next sweep.
+// Work is proportional to the faces whose owner changed in the previous sweep, not to the size of the hull.
+// Sweep 0 takes the candidates straight from the face array (flag bit 1); sweep i > 0 reads queue i&1 / counter i%3.
+// Every sweep fills queue (i+1)&1 / counter (i+1)%3 and clears counter (i+2)%3.
+__global__ void __launch_bounds__(TO_BLOCK) k_owner_push(Bufs b, int sweep, int epoch) {
+    const int round = b.ctrl[kCtrlRound];
+    const int* __restrict__ in = b.front[sweep & 1];
+    int* __restrict__ out = b.front[(sweep + 1) & 1];
+    const int n_in = sweep == 0 ? b.ctrl[kCtrlNFaces] : min(b.ctrl[kCtrlFront + sweep % 3], b.fcap);
+    int* out_cnt = &b.ctrl[kCtrlFront + (sweep + 1) % 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlFront + (sweep + 2) % 3] = 0;
+    const int stride = gridDim.x * TO_BLOCK;
+    const int nloop = (n_in + stride - 1) / stride;
+    for (int it = 0; it < nloop; ++it) {
+        const int q = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
+        int push[3] = {kNone, kNone, kNone};
+        int want = 0;
+        int g = kNone;
+        if (q < n_in) {
+            if (sweep == 0) { if (b.fflags[q] & 2) g = q; }
+            else g = in[q];
+        }
+        if (g >= 0) {
+            const int o = b.fowner[g];
+            if (o >= 0) {
+                const unsigned long long po = prio(o, round);
+                const int apex = b.fapex[o];
+                for (int k = 0; k < 3; ++k) {
+                    const int n = b.fn[3 * g + k];
+                    int cur = b.fowner[n];
+                    if (cur == o || (cur >= 0 && prio(cur, round) <= po)) continue;
+                    if (!(fdist(b, n, apex) > 0.0)) continue;
+                    bool claimed = false;
+                    while (true) {
+                        const int old = atomicCAS(&b.fowner[n], cur, o);
+                        if (old == cur) { claimed = true; break; }
+                        cur = old;
+                        if (cur == o || (cur >= 0 && prio(cur, round) <= po)) break;
+                    }
+                    if (claimed && atomicExch(&b.fstamp[n], epoch) != epoch) push[want++] = n;
+                }
+            }
+        }
+        int slot = block_alloc(out_cnt, want);
+        for (int k = 0; k < want; ++k, ++slot)
+            if (slot < b.fcap) out[slot] = push[k];
+    }
+}
 
 // each live face adopts the best-priority owner among its neighbours whose apex sees it
 __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b) {
@@ -353,8 +478,10 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b) {
     if (__any(changed) && (threadIdx.x & 63) == 0) b.ctrl[kCtrlChanged] = 1;
 }
 
-__global__ void __launch_bounds__(TO_BLOCK) k_accept(Bufs b) {
+__global__ void __launch_bounds__(TO_BLOCK) k_accept(Bufs b, int last_front) {
     const int nf = b.ctrl[kCtrlNFaces], round = b.ctrl[kCtrlRound];
+    // faces still queued after the last push sweep = ownership not converged (the host adapts the sweep count)
+    if (last_front >= 0 && blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlChanged] = b.ctrl[kCtrlFront + last_front] > 0;
     const int stride = gridDim.x * TO_BLOCK;
     for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf; g += stride) {
         if (!(b.fflags[g] & 1)) continue;
@@ -385,26 +512,36 @@ __device__ __forceinline__ bool owned_accepted(const Bufs& b, int g, int* owner)
 __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b) {
     const int nf = b.ctrl[kCtrlNFaces];
     const int stride = gridDim.x * TO_BLOCK;
-    for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf; g += stride) {
-        if (!(b.fflags[g] & 1)) continue;
-        int o;
-        if (!owned_accepted(b, g, &o)) continue;
-        if (g == o) atomicAdd(&b.ctrl[kCtrlAccepted], 1);
+    const int nloop = (nf + stride - 1) / stride;
+    for (int it = 0; it < nloop; ++it) {
+        const int g = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
+        int o = kNone, want = 0;
+        bool hor[3] = {false, false, false};
+        if (g < nf && (b.fflags[g] & 1) && owned_accepted(b, g, &o)) {
+            for (int k = 0; k < 3; ++k) { hor[k] = b.fowner[b.fn[3 * g + k]] != o; want += hor[k]; }
+        } else {
+            o = kNone;
+        }
+        const unsigned long long acc = __ballot(o >= 0 && g == o);
+        if (acc != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&b.ctrl[kCtrlAccepted], __popcll(acc));
+        int id = block_alloc(&b.ctrl[kCtrlNFaces + 8], want);  // staged counter, folded in by k_commit
+        if (want == 0) continue;
         const int apex = b.fapex[o];
         for (int k = 0; k < 3; ++k) {
+            if (!hor[k]) continue;
+            if (id >= b.fcap) { b.ctrl[kCtrlError] |= kErrCapacity; break; }
             const int n = b.fn[3 * g + k];
-            if (b.fowner[n] == o) continue;
-            const int id = atomicAdd(&b.ctrl[kCtrlNFaces + 8], 1);  // staged counter, folded in by k_commit
-            if (id >= b.fcap) { b.ctrl[kCtrlError] |= kErrCapacity; continue; }
             const int u = b.fv[3 * g + k], v = b.fv[3 * g + (k + 1) % 3];
             b.fv[3 * id] = u; b.fv[3 * id + 1] = v; b.fv[3 * id + 2] = apex;
             b.fn[3 * id] = n; b.fn[3 * id + 1] = kNone; b.fn[3 * id + 2] = kNone;
             set_plane(b, id);
             b.fflags[id] = 1; b.fowner[id] = kNone; b.fmax[id] = 0ull; b.fapex[id] = 0x7fffffff; b.nfhead[id] = kNone;
+            b.fstamp[id] = 0;
             b.newface[3 * g + k] = id;
             b.nfnext[id] = atomicExch(&b.nfhead[o], id);
             for (int j = 0; j < 3; ++j)
                 if (b.fn[3 * n + j] == g) b.fn[3 * n + j] = id;
+            ++id;
         }
     }
 }
@@ -441,6 +578,8 @@ __global__ void __launch_bounds__(TO_BLOCK) k_link_faces(Bufs b, int nf_before) 
 // points of deleted faces: the apex retires as a vertex, the rest move to the new face they are farthest
 // outside of, or retire inside the hull
 __global__ void __launch_bounds__(TO_BLOCK) k_reassign(Bufs b) {
+    __shared__ FaceMaxTable tab;
+    face_max_init(tab);
     const int stride = gridDim.x * TO_BLOCK;
     const int nloop = (b.m1 + stride - 1) / stride;
     for (int it = 0; it < nloop; ++it) {
@@ -458,8 +597,9 @@ __global__ void __launch_bounds__(TO_BLOCK) k_reassign(Bufs b) {
             }
             b.pface[i] = bf;  // the apex retires as a vertex; a point outside no new face retires inside the hull
         }
-        wave_face_max(b, bf, dkey(best));  // feeds the apex search of the new face
+        wave_face_max(b, tab, bf, dkey(best));  // feeds the apex search of the new face
     }
+    face_max_flush(b, tab);
 }
 
 __global__ void __launch_bounds__(TO_BLOCK) k_kill_faces(Bufs b, int nf_before) {
@@ -485,6 +625,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_commit(Bufs b, int nf_before) {
         b.ctrl[kCtrlChanged] = 0;
         b.ctrl[kCtrlAnyOutside] = 0;
         b.ctrl[kCtrlAccepted] = 0;
+        b.ctrl[kCtrlFront] = 0; b.ctrl[kCtrlFront + 1] = 0; b.ctrl[kCtrlFront + 2] = 0;
     }
 }
 
@@ -556,7 +697,7 @@ static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t s
     TO_HIP_CHECK_LAUNCH();
     k_init<<<b.nseg, HULL_INIT_THREADS, 0, st>>>(b);
     TO_HIP_CHECK_LAUNCH();
-    k_assign0<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);
+    k_assign0<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
     k_far_arg<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, 0);
     TO_HIP_CHECK_LAUNCH();
     int h[kCtrlInts];
@@ -574,14 +715,15 @@ static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t s
         const int gf = nblocks(nf), gp = nblocks(b.m1);
         k_round_reset<<<gf, TO_BLOCK, 0, st>>>(b);
         TO_HIP_CHECK_LAUNCH();
+        int last_front = -1;
         if (!careful) {
-            // Fast path: a fixed number of propagation sweeps, no readback.  Unconverged ownership is safe — a
-            // candidate is accepted only if it owns every face its apex sees (k_accept) — it can only cost progress.
-            for (int it = 0; it < sweeps - 1; ++it) k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);
-            e = hipMemsetAsync(b.ctrl + kCtrlChanged, 0, sizeof(int), st);
-            if (e != hipSuccess) return (int)e;
-            k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);  // still changing here = not converged (seen in the round's readback)
+            // Fast path: a fixed number of push sweeps, no readback.  Unconverged ownership is safe — a candidate is
+            // accepted only if it owns every face its apex sees (k_accept) — it can only cost progress.
+            const int gs = gf < 256 ? gf : 256;
+            for (int it = 0; it < sweeps; ++it)
+                k_owner_push<<<it == 0 ? gf : gs, TO_BLOCK, 0, st>>>(b, it, ((round & 0xffffff) << 7) + it + 1);
             TO_HIP_CHECK_LAUNCH();
+            last_front = sweeps % 3;  // faces still queued here = not converged (seen in the round's readback)
         } else {
             while (true) {
                 e = hipMemsetAsync(b.ctrl + kCtrlChanged, 0, sizeof(int), st);
@@ -596,10 +738,10 @@ static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t s
                 if (!h[kCtrlChanged]) break;
             }
         }
-        k_accept<<<gf, TO_BLOCK, 0, st>>>(b);
+        k_accept<<<gf, TO_BLOCK, 0, st>>>(b, last_front);
         k_new_faces<<<gf, TO_BLOCK, 0, st>>>(b);
         k_link_faces<<<gf, TO_BLOCK, 0, st>>>(b, nf);
-        k_reassign<<<gp, TO_BLOCK, 0, st>>>(b);
+        k_reassign<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
         k_far_arg<<<gp, TO_BLOCK, 0, st>>>(b, nf);  // apexes of the faces created this round (ids >= nf)
         k_kill_faces<<<gf, TO_BLOCK, 0, st>>>(b, nf);
         k_commit<<<gf, TO_BLOCK, 0, st>>>(b, nf);
@@ -614,7 +756,7 @@ static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t s
             if (careful) return TOHIP_ENOTCONV;  // converged ownership always admits the best candidate: inconsistent predicates
             careful = true;
         } else {
-            if (!careful) sweeps = h[kCtrlChanged2] ? (sweeps < 64 ? sweeps * 2 : 64) : (sweeps > 4 ? sweeps - 1 : 4);
+            if (!careful) sweeps = h[kCtrlChanged2] ? (sweeps < 64 ? sweeps * 2 : 64) : (sweeps > 6 ? sweeps - 1 : 6);
             careful = false;
         }
         nf = h[kCtrlNFaces];
@@ -727,12 +869,12 @@ k_seg_write(Bufs b, const int* __restrict__ total, const int32_t* __restrict__ o
 
 extern "C" size_t tohip_hpr_workspace_bytes(int64_t n) {
     if (n <= 0) return 256;
-    return hull::carve(nullptr, nullptr, n);
+    return hull::carve(nullptr, nullptr, n, 1, hull::default_face_capacity(n + 1, 1));
 }
 
 extern "C" size_t tohip_hpr_batched_workspace_bytes(int64_t n_total, int32_t n_segments) {
     if (n_total < 0 || n_segments <= 0) return 256;
-    return hull::carve(nullptr, nullptr, n_total, n_segments);
+    return hull::carve(nullptr, nullptr, n_total, n_segments, hull::default_face_capacity(n_total + n_segments, n_segments));
 }
 
 extern "C" int tohip_spherical_flip(const float* xyz, int64_t n, float param, float* flipped, float* radius_out,
@@ -747,10 +889,11 @@ extern "C" int tohip_spherical_flip(const float* xyz, int64_t n, float param, fl
 extern "C" int tohip_convex_hull_vertices(const float* pts, int64_t n, int with_origin, int32_t* idx, int32_t* count,
                                           int32_t* rounds_host, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!pts || !idx || !count || !workspace || n < 4 || n > (int64_t)100000000) return TOHIP_EINVAL;
-    if (workspace_bytes < hull::carve(nullptr, nullptr, n)) return TOHIP_ENOSPC;
+    const int fcap = hull::faces_for_bytes(n, 1, workspace_bytes);
+    if (fcap == 0) return TOHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream_;
     hull::Bufs b;
-    hull::carve(&b, (char*)workspace, n);
+    hull::carve(&b, (char*)workspace, n, 1, fcap);
     hull::k_single_segment<<<1, 1, 0, st>>>(b);
     TO_HIP_CHECK_LAUNCH();
     int rounds = 0;
@@ -764,10 +907,11 @@ extern "C" int tohip_hidden_pts_removal(const float* xyz, int64_t n, float param
                                         int32_t* visible_count, float* mask, void* workspace, size_t workspace_bytes,
                                         void* stream_) {
     if (!xyz || !visible_idx || !visible_count || !workspace || n < 4 || n > (int64_t)100000000) return TOHIP_EINVAL;
-    if (workspace_bytes < hull::carve(nullptr, nullptr, n)) return TOHIP_ENOSPC;
+    const int fcap = hull::faces_for_bytes(n, 1, workspace_bytes);
+    if (fcap == 0) return TOHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream_;
     hull::Bufs b;
-    hull::carve(&b, (char*)workspace, n);
+    hull::carve(&b, (char*)workspace, n, 1, fcap);
     hull::k_single_segment<<<1, 1, 0, st>>>(b);
     TO_HIP_CHECK_LAUNCH();
     int rc = launch_flip(xyz, n, param, b.flipped, nullptr, b.flip_max, st);
@@ -807,10 +951,11 @@ extern "C" int tohip_hidden_pts_removal_batched(const float* xyz, const int64_t*
         if (seg_offsets_host[s + 1] < seg_offsets_host[s]) return TOHIP_EINVAL;
     const int64_t n = seg_offsets_host[n_segments];
     if (n + n_segments > (int64_t)100000000 || (n > 0 && !xyz)) return TOHIP_EINVAL;
-    if (workspace_bytes < hull::carve(nullptr, nullptr, n, n_segments)) return TOHIP_ENOSPC;
+    const int fcap = hull::faces_for_bytes(n, n_segments, workspace_bytes);
+    if (fcap == 0) return TOHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream_;
     hull::Bufs b;
-    hull::carve(&b, (char*)workspace, n, n_segments);
+    hull::carve(&b, (char*)workspace, n, n_segments, fcap);
     std::vector<int> off((size_t)n_segments + 1);
     for (int32_t s = 0; s <= n_segments; ++s) off[s] = (int)(seg_offsets_host[s] + s);  // + one origin slot per segment
     hipError_t e = hipMemcpyAsync(b.seg_off, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice, st);

@@ -146,7 +146,7 @@ def pose_backward(cloud, trans, quat, cam, ws, mask=None, grad_obs=None, scalars
     return tg, qg
 
 
-HPR_BATCH_POINTS = 8_000_000  # points per batched hull pass (workspace ~0.8 KB per point)
+HPR_BATCH_POINTS = 32_000_000  # points per batched hull pass (workspace ~0.12 KB per point)
 
 
 def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method="hpr"):
@@ -183,7 +183,7 @@ def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method=
                 owns = render_points(kept_pts[w], K33, cam.c.img_height, cam.c.img_width, znear=min_dist, zfar=max_dist)[2]
                 vis[w] = torch.nonzero(owns).squeeze(1).to(torch.int32)
     else:
-        # one batched hull pass over the waypoints' culled clouds (chunked to bound the workspace: ~0.8 KB per point)
+        # one batched hull pass over the waypoints' culled clouds (chunked to bound the workspace)
         w0 = 0
         while w0 < W:
             w1, tot = w0, 0
@@ -270,6 +270,21 @@ def spherical_flip(points, param=2):
     return out, rad
 
 
+def _with_hull_workspace(wsb, dev, call):
+    """Run call(ws, wsb) with the recommended hull workspace; a cloud whose hull needs more faces than that holds
+    (TOHIP_ENOSPC: most of its points are hull vertices) is retried with 4x the bytes — every extra byte goes to faces."""
+    for _ in range(4):
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        try:
+            return call(ws, wsb)
+        except _lib.HipError as e:
+            if e.code != _lib.ENOSPC:
+                raise
+            del ws
+            wsb *= 4
+    raise _lib.HipError("hull workspace: still out of face capacity at 64x the recommended size")
+
+
 def hidden_pts_removal(points, param=2):
     """-> (visible_idx int32[V] ascending, mask f32[N])"""
     _require_cuda(points, "points")
@@ -279,11 +294,11 @@ def hidden_pts_removal(points, param=2):
     idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     mask = torch.empty(n, dtype=torch.float32, device=dev)
-    wsb = _lib.lib().tohip_hpr_workspace_bytes(n)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
-        check(_lib.lib().tohip_hidden_pts_removal(ptr(pts), n, float(param), ptr(idx), ptr(cnt), ptr(mask), ptr(ws), wsb,
-                                                  stream_ptr()), "tohip_hidden_pts_removal")
+    def call(ws, wsb):
+        with torch.cuda.device(dev):
+            check(_lib.lib().tohip_hidden_pts_removal(ptr(pts), n, float(param), ptr(idx), ptr(cnt), ptr(mask), ptr(ws), wsb,
+                                                      stream_ptr()), "tohip_hidden_pts_removal")
+    _with_hull_workspace(_lib.lib().tohip_hpr_workspace_bytes(n), dev, call)
     return idx[:int(cnt.item())], mask
 
 
@@ -305,11 +320,11 @@ def hidden_pts_removal_batched(points, seg_offsets, param=2):
     mask = torch.empty(n, dtype=torch.float32, device=dev)
     status = torch.empty(B, dtype=torch.int32, device=dev)
     L = _lib.lib()
-    wsb = L.tohip_hpr_batched_workspace_bytes(n, B)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
-        check(L.tohip_hidden_pts_removal_batched(ptr(pts), c_offs, B, float(param), ptr(idx), ptr(voff), ptr(mask), ptr(status),
-                                                 ptr(ws), wsb, stream_ptr()), "tohip_hidden_pts_removal_batched")
+    def call(ws, wsb):
+        with torch.cuda.device(dev):
+            check(L.tohip_hidden_pts_removal_batched(ptr(pts), c_offs, B, float(param), ptr(idx), ptr(voff), ptr(mask),
+                                                     ptr(status), ptr(ws), wsb, stream_ptr()), "tohip_hidden_pts_removal_batched")
+    _with_hull_workspace(L.tohip_hpr_batched_workspace_bytes(n, B), dev, call)
     voff_h = voff.cpu().to(torch.int64)
     return idx[:int(voff_h[-1])], voff_h, mask, status
 
@@ -323,12 +338,12 @@ def hull_vertices_with_origin(points, with_origin=True, return_rounds=False):
     idx = torch.empty(n + 1, dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     rounds = ctypes.c_int32(0)
-    wsb = _lib.lib().tohip_hpr_workspace_bytes(n)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
-        check(_lib.lib().tohip_convex_hull_vertices(ptr(pts), n, int(with_origin), ptr(idx), ptr(cnt),
-                                                    ctypes.byref(rounds), ptr(ws), wsb, stream_ptr()),
-              "tohip_convex_hull_vertices")
+    def call(ws, wsb):
+        with torch.cuda.device(dev):
+            check(_lib.lib().tohip_convex_hull_vertices(ptr(pts), n, int(with_origin), ptr(idx), ptr(cnt),
+                                                        ctypes.byref(rounds), ptr(ws), wsb, stream_ptr()),
+                  "tohip_convex_hull_vertices")
+    _with_hull_workspace(_lib.lib().tohip_hpr_workspace_bytes(n), dev, call)
     out = idx[:int(cnt.item())]
     return (out, rounds.value) if return_rounds else out
 
