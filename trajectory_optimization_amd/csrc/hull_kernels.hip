@@ -35,18 +35,25 @@ constexpr int kCtrlNFaces = 0, kCtrlAnyOutside = 1, kCtrlChanged = 2, kCtrlError
               kCtrlInts = 16;
 constexpr int kErrCapacity = 1, kErrFlat = 2, kErrTopology = 4;
 
+// what a distance test needs of a face, in one 64-byte line: the unnormalised normal, the coordinates of the face's
+// first vertex (a copy: the differences below are the same numbers) and the link of the owner's new-face list
+struct __attribute__((aligned(64))) FaceRec {
+    double nx, ny, nz, x0, y0, z0;
+    int next;
+    int pad[3];
+};
+
 struct Bufs {
     double *px, *py, *pz;  // M1 points
     int* pface;            // M1
     int* fv;               // 3 * fcap
     int* fn;               // 3 * fcap
-    double *nx, *ny, *nz;  // fcap
+    FaceRec* frec;         // fcap
     unsigned long long* fmax;  // fcap
     int* fapex;            // fcap
     int* fowner;           // fcap
     int* fflags;           // fcap   bit0 alive, bit1 candidate accepted
     int* nfhead;           // fcap
-    int* nfnext;           // fcap
     int* newface;          // 3 * fcap
     int* front[2];         // fcap each: ping-pong frontiers of the ownership propagation
     int* fstamp;           // fcap: sweep id a face was last queued in (one queue entry per face and sweep)
@@ -75,7 +82,7 @@ __host__ inline size_t seg(size_t bytes) { return align_up(bytes, 256); }
 // The default suits clouds whose hull is a small fraction of the points (HPR of a scene: 2-5 %); a build that runs out
 // returns TOHIP_ENOSPC and the caller retries with a larger workspace — every byte beyond the fixed part is used for
 // faces (faces_for_bytes), up to the never-exceeded-in-practice 8 per point.
-constexpr size_t kBytesPerFace = 17 * sizeof(int) + 4 * sizeof(double);  // the per-face arrays carved below
+constexpr size_t kBytesPerFace = 16 * sizeof(int) + sizeof(double) + 64;  // the per-face arrays carved below
 constexpr int kFaceArrays = 16;
 
 __host__ inline int default_face_capacity(int64_t m1, int64_t nseg) {
@@ -96,15 +103,12 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * m1); if (b) b->pface = (int*)p;
     p = take(sizeof(int) * 3 * (size_t)fcap); if (b) b->fv = (int*)p;
     p = take(sizeof(int) * 3 * (size_t)fcap); if (b) b->fn = (int*)p;
-    p = take(sizeof(double) * (size_t)fcap); if (b) b->nx = (double*)p;
-    p = take(sizeof(double) * (size_t)fcap); if (b) b->ny = (double*)p;
-    p = take(sizeof(double) * (size_t)fcap); if (b) b->nz = (double*)p;
+    p = take(sizeof(FaceRec) * (size_t)fcap); if (b) b->frec = (FaceRec*)p;
     p = take(sizeof(unsigned long long) * (size_t)fcap); if (b) b->fmax = (unsigned long long*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->fapex = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->fowner = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->fflags = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->nfhead = (int*)p;
-    p = take(sizeof(int) * (size_t)fcap); if (b) b->nfnext = (int*)p;
     p = take(sizeof(int) * 3 * (size_t)fcap); if (b) b->newface = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->front[0] = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->front[1] = (int*)p;
@@ -153,18 +157,22 @@ __device__ __forceinline__ unsigned long long prio(int f, int round) {
 
 // signed (unnormalised) distance of point i from the plane of face f; > 0 = strictly outside
 __device__ __forceinline__ double fdist(const Bufs& b, int f, int i) {
-    const int v0 = b.fv[3 * f];
-    const double dx = b.px[i] - b.px[v0], dy = b.py[i] - b.py[v0], dz = b.pz[i] - b.pz[v0];
-    return b.nx[f] * dx + b.ny[f] * dy + b.nz[f] * dz;
+    const FaceRec& r = b.frec[f];
+    const double dx = b.px[i] - r.x0, dy = b.py[i] - r.y0, dz = b.pz[i] - r.z0;
+    return r.nx * dx + r.ny * dy + r.nz * dz;
 }
 
 __device__ __forceinline__ void set_plane(const Bufs& b, int f) {
     const int a = b.fv[3 * f], c1 = b.fv[3 * f + 1], c2 = b.fv[3 * f + 2];
-    const double ux = b.px[c1] - b.px[a], uy = b.py[c1] - b.py[a], uz = b.pz[c1] - b.pz[a];
-    const double vx = b.px[c2] - b.px[a], vy = b.py[c2] - b.py[a], vz = b.pz[c2] - b.pz[a];
-    b.nx[f] = uy * vz - uz * vy;
-    b.ny[f] = uz * vx - ux * vz;
-    b.nz[f] = ux * vy - uy * vx;
+    const double ax = b.px[a], ay = b.py[a], az = b.pz[a];
+    const double ux = b.px[c1] - ax, uy = b.py[c1] - ay, uz = b.pz[c1] - az;
+    const double vx = b.px[c2] - ax, vy = b.py[c2] - ay, vz = b.pz[c2] - az;
+    FaceRec& r = b.frec[f];
+    r.nx = uy * vz - uz * vy;
+    r.ny = uz * vx - ux * vz;
+    r.nz = ux * vy - uy * vx;
+    r.x0 = ax; r.y0 = ay; r.z0 = az;
+    r.next = kNone;
 }
 
 // Per-face maximum of `key` over many points.  Early rounds aim a million points at a handful of faces, and
@@ -334,8 +342,9 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
             // no hull for this segment: its four face slots stay dead (never candidates, never neighbours of a live face)
             for (int f = fb; f < fb + 4; ++f) {
                 for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = lo; b.fn[3 * f + k] = f; }
-                b.nx[f] = 0.0; b.ny[f] = 0.0; b.nz[f] = 0.0;
+                b.frec[f] = FaceRec{0.0, 0.0, 0.0, b.px[lo], b.py[lo], b.pz[lo], kNone, {0, 0, 0}};
                 b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = 0x7fffffff; b.fstamp[f] = 0;
+                b.newface[3 * f] = kNone;
             }
             return;
         }
@@ -354,6 +363,7 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
             b.fmax[f] = 0ull;
             b.fapex[f] = 0x7fffffff;
             b.fstamp[f] = 0;
+            b.newface[3 * f] = kNone;
         }
     }
 }
@@ -399,7 +409,9 @@ __global__ void __launch_bounds__(TO_BLOCK) k_round_reset(Bufs b) {
 // apex of the faces with id >= f_lo (the faces created since the last call): lowest-index point among those at
 // the face's maximum distance.  A face's outside set never changes after its creation round, so its apex is
 // computed once; older faces keep theirs.
-__global__ void __launch_bounds__(TO_BLOCK) k_far_arg(Bufs b, int f_lo) {
+__global__ void __launch_bounds__(TO_BLOCK) k_far_arg(Bufs b, int all_faces) {
+    // inside a round the published face count is still the count before this round's insertions
+    const int f_lo = all_faces ? 0 : b.ctrl[kCtrlNFaces];
     const int stride = gridDim.x * TO_BLOCK;
     for (int i = blockIdx.x * TO_BLOCK + threadIdx.x; i < b.m1; i += stride) {
         const int f = b.pface[i];
@@ -537,8 +549,9 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b) {
             set_plane(b, id);
             b.fflags[id] = 1; b.fowner[id] = kNone; b.fmax[id] = 0ull; b.fapex[id] = 0x7fffffff; b.nfhead[id] = kNone;
             b.fstamp[id] = 0;
+            b.newface[3 * id] = kNone;
             b.newface[3 * g + k] = id;
-            b.nfnext[id] = atomicExch(&b.nfhead[o], id);
+            b.frec[id].next = atomicExch(&b.nfhead[o], id);
             for (int j = 0; j < 3; ++j)
                 if (b.fn[3 * n + j] == g) b.fn[3 * n + j] = id;
             ++id;
@@ -547,7 +560,8 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b) {
 }
 
 // sibling links: rotate around the horizon vertex v through the region's faces to the next horizon edge
-__global__ void __launch_bounds__(TO_BLOCK) k_link_faces(Bufs b, int nf_before) {
+__global__ void __launch_bounds__(TO_BLOCK) k_link_faces(Bufs b) {
+    const int nf_before = b.ctrl[kCtrlNFaces];
     const int stride = gridDim.x * TO_BLOCK;
     for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf_before; g += stride) {
         if (!(b.fflags[g] & 1)) continue;
@@ -590,9 +604,12 @@ __global__ void __launch_bounds__(TO_BLOCK) k_reassign(Bufs b) {
         if (g >= 0 && owned_accepted(b, g, &o)) {
             if (i != b.fapex[o]) {
                 int steps = 0;
-                for (int f = b.nfhead[o]; f >= 0 && steps < (1 << 20); f = b.nfnext[f], ++steps) {
-                    const double d = fdist(b, f, i);
+                const double x = b.px[i], y = b.py[i], z = b.pz[i];
+                for (int f = b.nfhead[o]; f >= 0 && steps < (1 << 20); ++steps) {
+                    const FaceRec r = b.frec[f];  // one line per step of the list: plane, anchor and link
+                    const double d = r.nx * (x - r.x0) + r.ny * (y - r.y0) + r.nz * (z - r.z0);
                     if (d > best) { best = d; bf = f; }
+                    f = r.next;
                 }
             }
             b.pface[i] = bf;  // the apex retires as a vertex; a point outside no new face retires inside the hull
@@ -602,7 +619,8 @@ __global__ void __launch_bounds__(TO_BLOCK) k_reassign(Bufs b) {
     face_max_flush(b, tab);
 }
 
-__global__ void __launch_bounds__(TO_BLOCK) k_kill_faces(Bufs b, int nf_before) {
+__global__ void __launch_bounds__(TO_BLOCK) k_kill_faces(Bufs b) {
+    const int nf_before = b.ctrl[kCtrlNFaces];
     const int stride = gridDim.x * TO_BLOCK;
     for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf_before; g += stride) {
         int o;
@@ -610,9 +628,12 @@ __global__ void __launch_bounds__(TO_BLOCK) k_kill_faces(Bufs b, int nf_before) 
     }
 }
 
-__global__ void __launch_bounds__(TO_BLOCK) k_commit(Bufs b, int nf_before) {
+__global__ void __launch_bounds__(TO_BLOCK) k_commit(Bufs b) {
+    // bound: the staged count (final since k_new_faces ended) — the published one is rewritten below while other blocks
+    // of this kernel may still be starting; faces created this round carry no kill mark
+    const int nf_all = min(b.ctrl[kCtrlNFaces + 8], b.fcap);
     const int stride = gridDim.x * TO_BLOCK;
-    for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf_before; g += stride)
+    for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf_all; g += stride)
         if (b.newface[3 * g] == -2) { b.fflags[g] = 0; b.newface[3 * g] = kNone; }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int nf = b.ctrl[kCtrlNFaces + 8];
@@ -698,7 +719,7 @@ static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t s
     k_init<<<b.nseg, HULL_INIT_THREADS, 0, st>>>(b);
     TO_HIP_CHECK_LAUNCH();
     k_assign0<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
-    k_far_arg<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, 0);
+    k_far_arg<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, 1);
     TO_HIP_CHECK_LAUNCH();
     int h[kCtrlInts];
     hipError_t e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);
@@ -710,48 +731,56 @@ static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t s
     const int max_rounds = 100000;
     int round = 0;
     bool careful = false;  // after a round without progress: propagate ownership to convergence (host-checked)
-    int sweeps = 8;        // ownership sweeps per round, adapted from the previous round's convergence flag
-    for (; round < max_rounds; ++round) {
-        const int gf = nblocks(nf), gp = nblocks(b.m1);
-        k_round_reset<<<gf, TO_BLOCK, 0, st>>>(b);
-        TO_HIP_CHECK_LAUNCH();
-        int last_front = -1;
-        if (!careful) {
-            // Fast path: a fixed number of push sweeps, no readback.  Unconverged ownership is safe — a candidate is
-            // accepted only if it owns every face its apex sees (k_accept) — it can only cost progress.
-            const int gs = gf < 256 ? gf : 256;
-            for (int it = 0; it < sweeps; ++it)
-                k_owner_push<<<it == 0 ? gf : gs, TO_BLOCK, 0, st>>>(b, it, ((round & 0xffffff) << 7) + it + 1);
+    int sweeps = 8;        // ownership sweeps per round, adapted from the convergence flag of the last readback
+    // Rounds are enqueued in batches with ONE readback per batch: every kernel takes its face counts from the control
+    // block on the device and walks its arrays with a grid stride, so the host's (stale) counts only size the grids.
+    // A round enqueued after the hull is complete finds no candidate and changes nothing.
+    const int batch = 4;
+    while (round < max_rounds) {
+        const int nrounds = careful ? 1 : batch;
+        const int gf = nblocks((int64_t)nf * 2), gp = nblocks(b.m1);
+        for (int r = 0; r < nrounds; ++r, ++round) {
+            k_round_reset<<<gf, TO_BLOCK, 0, st>>>(b);
             TO_HIP_CHECK_LAUNCH();
-            last_front = sweeps % 3;  // faces still queued here = not converged (seen in the round's readback)
-        } else {
-            while (true) {
-                e = hipMemsetAsync(b.ctrl + kCtrlChanged, 0, sizeof(int), st);
-                if (e != hipSuccess) return (int)e;
-                k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);
-                k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);
+            int last_front = -1;
+            if (!careful) {
+                // Fast path: a fixed number of push sweeps, no readback.  Unconverged ownership is safe — a candidate
+                // is accepted only if it owns every face its apex sees (k_accept) — it can only cost progress.
+                const int gs = gf < 256 ? gf : 256;
+                for (int it = 0; it < sweeps; ++it)
+                    k_owner_push<<<it == 0 ? gf : gs, TO_BLOCK, 0, st>>>(b, it, ((round & 0xffffff) << 7) + it + 1);
                 TO_HIP_CHECK_LAUNCH();
-                e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);
-                if (e != hipSuccess) return (int)e;
-                e = hipStreamSynchronize(st);
-                if (e != hipSuccess) return (int)e;
-                if (!h[kCtrlChanged]) break;
+                last_front = sweeps % 3;  // faces still queued here = not converged (seen in the batch's readback)
+            } else {
+                while (true) {
+                    e = hipMemsetAsync(b.ctrl + kCtrlChanged, 0, sizeof(int), st);
+                    if (e != hipSuccess) return (int)e;
+                    k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);
+                    k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);
+                    TO_HIP_CHECK_LAUNCH();
+                    e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);
+                    if (e != hipSuccess) return (int)e;
+                    e = hipStreamSynchronize(st);
+                    if (e != hipSuccess) return (int)e;
+                    if (!h[kCtrlChanged]) break;
+                }
             }
+            k_accept<<<gf, TO_BLOCK, 0, st>>>(b, last_front);
+            k_new_faces<<<gf, TO_BLOCK, 0, st>>>(b);
+            k_link_faces<<<gf, TO_BLOCK, 0, st>>>(b);
+            k_reassign<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
+            k_far_arg<<<gp, TO_BLOCK, 0, st>>>(b, 0);  // apexes of the faces created this round
+            k_kill_faces<<<gf, TO_BLOCK, 0, st>>>(b);
+            k_commit<<<nblocks((int64_t)nf * 4), TO_BLOCK, 0, st>>>(b);
+            TO_HIP_CHECK_LAUNCH();
         }
-        k_accept<<<gf, TO_BLOCK, 0, st>>>(b, last_front);
-        k_new_faces<<<gf, TO_BLOCK, 0, st>>>(b);
-        k_link_faces<<<gf, TO_BLOCK, 0, st>>>(b, nf);
-        k_reassign<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
-        k_far_arg<<<gp, TO_BLOCK, 0, st>>>(b, nf);  // apexes of the faces created this round (ids >= nf)
-        k_kill_faces<<<gf, TO_BLOCK, 0, st>>>(b, nf);
-        k_commit<<<gf, TO_BLOCK, 0, st>>>(b, nf);
-        TO_HIP_CHECK_LAUNCH();
-        e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);  // the round's one readback
+        e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);  // the batch's one readback
         if (e != hipSuccess) return (int)e;
         e = hipStreamSynchronize(st);
         if (e != hipSuccess) return (int)e;
         if (h[kCtrlError]) return (h[kCtrlError] & kErrCapacity) ? TOHIP_ENOSPC : TOHIP_ENOTCONV;
-        if (!h[kCtrlAnyOutside2]) break;  // no point outside any face: the round was a no-op and the hull is complete
+        nf = h[kCtrlNFaces];
+        if (!h[kCtrlAnyOutside2]) break;  // the last round found no point outside any face: the hull is complete
         if (h[kCtrlAccepted2] <= 0) {
             if (careful) return TOHIP_ENOTCONV;  // converged ownership always admits the best candidate: inconsistent predicates
             careful = true;
@@ -759,7 +788,6 @@ static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t s
             if (!careful) sweeps = h[kCtrlChanged2] ? (sweeps < 64 ? sweeps * 2 : 64) : (sweeps > 6 ? sweeps - 1 : 6);
             careful = false;
         }
-        nf = h[kCtrlNFaces];
     }
     if (round >= max_rounds) return TOHIP_ENOTCONV;
     if (rounds_out) *rounds_out = round;
