@@ -50,7 +50,7 @@ struct Bufs {
     int* fn;               // 3 * fcap
     FaceRec* frec;         // fcap
     unsigned long long* fmax;  // fcap
-    int* fapex;            // fcap
+    int* fapex;            // fcap   apex candidate as an EXPANDED index (ties go to the caller's lowest index); 0x7fffffff = none
     int* fowner;           // fcap
     int* fflags;           // fcap   bit0 alive, bit1 candidate accepted
     int* nfhead;           // fcap
@@ -71,6 +71,17 @@ struct Bufs {
     int* seg_start;        // nseg + 1   first position of each segment in the compacted vertex list
     int* seg_cnt;          // nseg
     int* idx_all;          // M1 (batched result staging)
+    // spatial order: the points are worked on in Morton order of their position inside the segment's bounding box, so
+    // that the lanes of a wave hold neighbouring points — which share conflict faces and new-face lists for the whole
+    // build (coalesced, mostly wave-uniform reads instead of 64 scattered lists per wave).  px/py/pz, pface and the
+    // faces' vertex ids live in this order; perm/inv translate from/to the caller's (expanded) numbering.
+    int* perm;             // M1   position -> expanded index
+    int* inv;              // M1   expanded index -> position
+    unsigned long long *keys, *keys2;  // M1 each
+    int* vals;             // M1
+    unsigned* seg_bbox;    // 6 * nseg (ordered-float keys: min x,y,z, max x,y,z)
+    char* sort_tmp;
+    size_t sort_tmp_bytes;
     int m1;
     int fcap;
     int nseg;
@@ -124,6 +135,16 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * (nseg + 1)); if (b) b->seg_start = (int*)p;
     p = take(sizeof(int) * nseg); if (b) b->seg_cnt = (int*)p;
     p = take(sizeof(int) * (nseg > 1 ? m1 : 1)); if (b) b->idx_all = (int*)p;
+    p = take(sizeof(int) * m1); if (b) b->perm = (int*)p;
+    p = take(sizeof(int) * m1); if (b) b->inv = (int*)p;
+    p = take(sizeof(unsigned long long) * m1); if (b) b->keys = (unsigned long long*)p;
+    p = take(sizeof(unsigned long long) * m1); if (b) b->keys2 = (unsigned long long*)p;
+    p = take(sizeof(int) * m1); if (b) b->vals = (int*)p;
+    p = take(sizeof(unsigned) * 6 * nseg); if (b) b->seg_bbox = (unsigned*)p;
+    size_t tmp = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                             (const int*)nullptr, (int*)nullptr, (int)m1, 0, 64, (hipStream_t)0);
+    p = take(tmp); if (b) { b->sort_tmp = p; b->sort_tmp_bytes = tmp; }
     if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; }
     return o;
 }
@@ -255,22 +276,95 @@ __device__ __forceinline__ int find_seg(const Bufs& b, int i) {
 
 __global__ void k_single_segment(Bufs b) { b.seg_off[0] = 0; b.seg_off[1] = b.m1; }
 
+// coordinates of expanded index e of segment sg: a row of the source array (every earlier segment has spent one slot
+// on its origin), or — the segment's last slot — the appended origin (tools.py:60); without an origin that slot
+// repeats the segment's first point (never a new vertex)
+__device__ __forceinline__ void source_point(const Bufs& b, const float* __restrict__ pts, int with_origin, int e, int sg,
+                                             float* x, float* y, float* z) {
+    const bool extra = e == b.seg_off[sg + 1] - 1;
+    const int r = extra ? b.seg_off[sg] - sg : e - sg;
+    const bool zero = extra && with_origin;
+    *x = zero ? 0.0f : pts[3 * r];
+    *y = zero ? 0.0f : pts[3 * r + 1];
+    *z = zero ? 0.0f : pts[3 * r + 2];
+}
+
+__global__ void __launch_bounds__(TO_BLOCK) k_bbox_init(Bufs b) {
+    const int i = blockIdx.x * TO_BLOCK + threadIdx.x;
+    if (i < 6 * b.nseg) b.seg_bbox[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+}
+
+__global__ void __launch_bounds__(TO_BLOCK) k_bbox(Bufs b, const float* __restrict__ pts, int with_origin) {
+    const int stride = gridDim.x * TO_BLOCK;
+    const int nloop = (b.m1 + stride - 1) / stride;
+    for (int it = 0; it < nloop; ++it) {
+        const int e = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
+        int sg = -1;
+        unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+        if (e < b.m1) {
+            sg = find_seg(b, e);
+            float c[3];
+            source_point(b, pts, with_origin, e, sg, &c[0], &c[1], &c[2]);
+            for (int k = 0; k < 3; ++k)
+                if (c[k] == c[k]) lo[k] = hi[k] = fkey(c[k]);  // NaN coordinates take no part in the box
+        }
+        const int s0 = __shfl(sg, 0);
+        if (__all(sg == s0) && s0 >= 0) {  // a wave usually lies inside one segment: reduce there, six atomics
+            for (int k = 0; k < 3; ++k) {
+                for (int s = 32; s > 0; s >>= 1) {
+                    lo[k] = min(lo[k], (unsigned)__shfl_xor((int)lo[k], s));
+                    hi[k] = max(hi[k], (unsigned)__shfl_xor((int)hi[k], s));
+                }
+            }
+            if ((threadIdx.x & 63) == 0)
+                for (int k = 0; k < 3; ++k) { atomicMin(&b.seg_bbox[6 * s0 + k], lo[k]); atomicMax(&b.seg_bbox[6 * s0 + 3 + k], hi[k]); }
+        } else if (sg >= 0) {
+            for (int k = 0; k < 3; ++k) { atomicMin(&b.seg_bbox[6 * sg + k], lo[k]); atomicMax(&b.seg_bbox[6 * sg + 3 + k], hi[k]); }
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// sort key: segment in the high bits (segments stay where they are), 30-bit Morton code of the position in the
+// segment's bounding box below; the value is the expanded index
+__global__ void __launch_bounds__(TO_BLOCK) k_sort_keys(Bufs b, const float* __restrict__ pts, int with_origin) {
+    const int stride = gridDim.x * TO_BLOCK;
+    for (int e = blockIdx.x * TO_BLOCK + threadIdx.x; e < b.m1; e += stride) {
+        const int sg = find_seg(b, e);
+        float c[3];
+        source_point(b, pts, with_origin, e, sg, &c[0], &c[1], &c[2]);
+        unsigned q[3];
+        for (int k = 0; k < 3; ++k) {
+            const float lo = fkey_inv(b.seg_bbox[6 * sg + k]), hi = fkey_inv(b.seg_bbox[6 * sg + 3 + k]);
+            const float t = (c[k] - lo) / (hi - lo) * 1023.0f;  // NaN / empty extent -> 0 below
+            q[k] = t >= 0.0f ? (t < 1023.0f ? (unsigned)t : 1023u) : 0u;
+        }
+        const unsigned m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+        b.keys[e] = ((unsigned long long)(unsigned)sg << 30) | m;
+        b.vals[e] = e;
+    }
+}
+
+// position j takes the point perm[j]
 __global__ void __launch_bounds__(TO_BLOCK)
 k_load(Bufs b, const float* __restrict__ pts, int with_origin) {
     const int stride = gridDim.x * TO_BLOCK;
-    for (int i = blockIdx.x * TO_BLOCK + threadIdx.x; i < b.m1; i += stride) {
-        const int s = find_seg(b, i);
-        // row of the source array: every earlier segment has spent one slot on its origin.  The segment's last
-        // slot is the appended origin (tools.py:60); without it the slot repeats the segment's first point
-        // (never a new vertex)
-        const bool extra = i == b.seg_off[s + 1] - 1;
-        const int r = extra ? b.seg_off[s] - s : i - s;
-        const bool zero = extra && with_origin;
-        b.px[i] = zero ? 0.0 : (double)pts[3 * r];
-        b.py[i] = zero ? 0.0 : (double)pts[3 * r + 1];
-        b.pz[i] = zero ? 0.0 : (double)pts[3 * r + 2];
-        b.pface[i] = kNone;
-        b.vflag[i] = 0;
+    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < b.m1; j += stride) {
+        const int e = b.perm[j];
+        float x, y, z;
+        source_point(b, pts, with_origin, e, find_seg(b, e), &x, &y, &z);
+        b.px[j] = (double)x; b.py[j] = (double)y; b.pz[j] = (double)z;
+        b.inv[e] = j;
+        b.pface[j] = kNone;
+        b.vflag[j] = 0;
     }
     if (blockIdx.x == 0 && threadIdx.x < kCtrlInts)
         b.ctrl[threadIdx.x] = (threadIdx.x == kCtrlNFaces || threadIdx.x == kCtrlNFaces + 8) ? 4 * b.nseg : 0;
@@ -305,34 +399,38 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
     int i0 = lo, i1 = lo, i2 = lo, i3 = lo;
     const bool enough = hi - lo - 1 >= 4;  // Qhull needs d+1 input points; the appended origin comes on top
     if (enough) {
+        // ties go to the caller's lowest index (perm), whatever the internal order
         double best = -INFINITY; int bi = 0x7fffffff;
-        for (int i = lo + t; i < hi; i += HULL_INIT_THREADS) { const double k = -b.px[i]; if (k > best) { best = k; bi = i; } }
-        i0 = block_argmax(best, bi, skey, sidx, nullptr);
+        for (int i = lo + t; i < hi; i += HULL_INIT_THREADS) {
+            const double k = -b.px[i]; const int e = b.perm[i];
+            if (k > best || (k == best && e < bi)) { best = k; bi = e; }
+        }
+        i0 = b.inv[block_argmax(best, bi, skey, sidx, nullptr)];
         x0 = b.px[i0]; y0 = b.py[i0]; z0 = b.pz[i0];
         best = -INFINITY; bi = 0x7fffffff;
         for (int i = lo + t; i < hi; i += HULL_INIT_THREADS) {
             const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
-            const double k = dx * dx + dy * dy + dz * dz;
-            if (k > best) { best = k; bi = i; }
+            const double k = dx * dx + dy * dy + dz * dz; const int e = b.perm[i];
+            if (k > best || (k == best && e < bi)) { best = k; bi = e; }
         }
-        i1 = block_argmax(best, bi, skey, sidx, &kk);
+        i1 = b.inv[block_argmax(best, bi, skey, sidx, &kk)];
         const double ex = b.px[i1] - x0, ey = b.py[i1] - y0, ez = b.pz[i1] - z0;
         best = -INFINITY; bi = 0x7fffffff;
         for (int i = lo + t; i < hi; i += HULL_INIT_THREADS) {
             const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
             const double cx = dy * ez - dz * ey, cy = dz * ex - dx * ez, cz = dx * ey - dy * ex;
-            const double k = cx * cx + cy * cy + cz * cz;
-            if (k > best) { best = k; bi = i; }
+            const double k = cx * cx + cy * cy + cz * cz; const int e = b.perm[i];
+            if (k > best || (k == best && e < bi)) { best = k; bi = e; }
         }
-        i2 = block_argmax(best, bi, skey, sidx, &k2);
+        i2 = b.inv[block_argmax(best, bi, skey, sidx, &k2)];
         const double fx = b.px[i2] - x0, fy = b.py[i2] - y0, fz = b.pz[i2] - z0;
         nx = ey * fz - ez * fy; ny = ez * fx - ex * fz; nz = ex * fy - ey * fx;
         best = -INFINITY; bi = 0x7fffffff;
         for (int i = lo + t; i < hi; i += HULL_INIT_THREADS) {
-            const double k = fabs(nx * (b.px[i] - x0) + ny * (b.py[i] - y0) + nz * (b.pz[i] - z0));
-            if (k > best) { best = k; bi = i; }
+            const double k = fabs(nx * (b.px[i] - x0) + ny * (b.py[i] - y0) + nz * (b.pz[i] - z0)); const int e = b.perm[i];
+            if (k > best || (k == best && e < bi)) { best = k; bi = e; }
         }
-        i3 = block_argmax(best, bi, skey, sidx, &k3);
+        i3 = b.inv[block_argmax(best, bi, skey, sidx, &k3)];
     }
     if (t == 0) {
         const bool flat = enough && (!(kk > 0.0) || !(k2 > 0.0) || !(k3 > 0.0));
@@ -416,7 +514,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_far_arg(Bufs b, int all_faces) {
     for (int i = blockIdx.x * TO_BLOCK + threadIdx.x; i < b.m1; i += stride) {
         const int f = b.pface[i];
         if (f < f_lo) continue;
-        if (dkey(fdist(b, f, i)) == b.fmax[f]) atomicMin(&b.fapex[f], i);
+        if (dkey(fdist(b, f, i)) == b.fmax[f]) atomicMin(&b.fapex[f], b.perm[i]);
     }
 }
 
@@ -447,7 +545,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_push(Bufs b, int sweep, int 
             const int o = b.fowner[g];
             if (o >= 0) {
                 const unsigned long long po = prio(o, round);
-                const int apex = b.fapex[o];
+                const int apex = b.inv[b.fapex[o]];
                 for (int k = 0; k < 3; ++k) {
                     const int n = b.fn[3 * g + k];
                     int cur = b.fowner[n];
@@ -483,7 +581,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b) {
             const int o = b.fowner[b.fn[3 * g + k]];
             if (o < 0 || o == best) continue;
             const unsigned long long op = prio(o, round);
-            if (op < bp && fdist(b, g, b.fapex[o]) > 0.0) { best = o; bp = op; }
+            if (op < bp && fdist(b, g, b.inv[b.fapex[o]]) > 0.0) { best = o; bp = op; }
         }
         if (best != b.fowner[g]) { b.fowner[g] = best; changed = true; }
     }
@@ -500,7 +598,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_accept(Bufs b, int last_front) {
         const int o = b.fowner[g];
         if (o < 0) continue;
         if (b.fowner[o] != o) { continue; }  // o lost its own face: not a candidate (its flag is cleared below)
-        const int apex = b.fapex[o];
+        const int apex = b.inv[b.fapex[o]];
         bool ok = true;
         for (int k = 0; k < 3; ++k) {
             const int n = b.fn[3 * g + k];
@@ -538,7 +636,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b) {
         if (acc != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&b.ctrl[kCtrlAccepted], __popcll(acc));
         int id = block_alloc(&b.ctrl[kCtrlNFaces + 8], want);  // staged counter, folded in by k_commit
         if (want == 0) continue;
-        const int apex = b.fapex[o];
+        const int apex = b.inv[b.fapex[o]];
         for (int k = 0; k < 3; ++k) {
             if (!hor[k]) continue;
             if (id >= b.fcap) { b.ctrl[kCtrlError] |= kErrCapacity; break; }
@@ -602,7 +700,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_reassign(Bufs b) {
         const int g = i < b.m1 ? b.pface[i] : kNone;
         int o;
         if (g >= 0 && owned_accepted(b, g, &o)) {
-            if (i != b.fapex[o]) {
+            if (b.perm[i] != b.fapex[o]) {
                 int steps = 0;
                 const double x = b.px[i], y = b.py[i], z = b.pz[i];
                 for (int f = b.nfhead[o]; f >= 0 && steps < (1 << 20); ++steps) {
@@ -654,7 +752,8 @@ __global__ void __launch_bounds__(TO_BLOCK) k_mark_vertices(Bufs b) {
     const int nf = b.ctrl[kCtrlNFaces];
     const int stride = gridDim.x * TO_BLOCK;
     for (int f = blockIdx.x * TO_BLOCK + threadIdx.x; f < nf; f += stride)
-        if (b.fflags[f] & 1) { b.vflag[b.fv[3 * f]] = 1; b.vflag[b.fv[3 * f + 1]] = 1; b.vflag[b.fv[3 * f + 2]] = 1; }
+        if (b.fflags[f] & 1)
+            for (int k = 0; k < 3; ++k) b.vflag[b.perm[b.fv[3 * f + k]]] = 1;  // flags in the caller's (expanded) numbering
 }
 
 // ---- ordered compaction of the flagged indices (same scheme as the frustum cull) ----------------
@@ -714,6 +813,18 @@ inline int nblocks(int64_t n, int cap = 2048) {
 // Builds the hull of pts (n,3) [+ origin]; leaves vflag set.  Synchronises the stream.
 // b.seg_off must already be on the device (k_single_segment for one hull).
 static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t st, int* rounds_out) {
+    k_bbox_init<<<(6 * b.nseg + TO_BLOCK - 1) / TO_BLOCK, TO_BLOCK, 0, st>>>(b);
+    k_bbox<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, pts, with_origin);
+    k_sort_keys<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, pts, with_origin);
+    TO_HIP_CHECK_LAUNCH();
+    {
+        int seg_bits = 0;
+        while ((1 << seg_bits) < b.nseg) ++seg_bits;
+        size_t tmp = b.sort_tmp_bytes;
+        const hipError_t es = hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, tmp, b.keys, b.keys2, b.vals, b.perm, b.m1, 0,
+                                                                 30 + seg_bits, st);  // stable: equal cells keep the caller's order
+        if (es != hipSuccess) return (int)es;
+    }
     k_load<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, pts, with_origin);
     TO_HIP_CHECK_LAUNCH();
     k_init<<<b.nseg, HULL_INIT_THREADS, 0, st>>>(b);
