@@ -36,19 +36,20 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 ALGO_BYTES = {"k_traj_pass1": 12.0, "k_traj_pass2": 20.0, "k_traj_bwd": 16.0}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r01_bench_dense_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes), or None."""
+def pmc_figures(kernel):
+    """(HBM bytes per launch, VALU busy fraction) of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_bench_dense_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes; SQ_ACTIVE_INST_VALU x4 /
+    SQ_BUSY_CYCLES-normalised SIMD cycles), or (None, None)."""
     path = os.path.join(REPO, "profiles", "r01_bench_dense_pmc.json")
     try:
         with open(path) as f:
             ks = json.load(f)["kernels"]
         for name, v in ks.items():
             if kernel in name and "hbm_bytes_per_launch_corrected" in v:
-                return float(v["hbm_bytes_per_launch_corrected"])
+                return float(v["hbm_bytes_per_launch_corrected"]), v.get("valu_busy_fraction")
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return None, None
 
 
 def cpu_baseline(points, poses, quats, n_wps_sample, budget_s=12.0):
@@ -191,6 +192,7 @@ def main():
         dom_ms = kern[dom][0] / max(kern[dom][1], 1)
         local_evals = args.points * n_virtual
         achieved = ALGO_BYTES[dom] * local_evals / (dom_ms * 1e-3) / 1e9
+        traffic, valu_busy = pmc_figures(dom)
         line = {
             "metric": "point-visibility evals/sec (fwd+bwd)", "value": value, "unit": "evals/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -203,7 +205,7 @@ def main():
                        "mode": "dense: every (point, waypoint) pair evaluated, no data-dependent skipping",
                        "loss_vis": float(out[0][1].item())},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_busy": valu_busy,
                          "traffic_note": "HBM bytes per launch from profiles/r01_bench_dense_pmc.json (separate --pmc "
                                          "passes of this command); far below the algorithmic bytes: the kernels keep "
                                          "points in registers and loop over waypoints, so they are VALU-issue bound",
