@@ -34,6 +34,7 @@ extern "C" {
 #define TOHIP_EINVAL (-1)   /* bad size / null pointer */
 #define TOHIP_ENOSPC (-2)   /* caller-provided workspace or output capacity too small */
 #define TOHIP_ENOTCONV (-3) /* hull construction did not converge within its round limit */
+#define TOHIP_ENAN (-4)     /* hull input holds a NaN (a zero-norm point flips to NaN, tools.py:49-52): scipy raises ValueError */
 
 /* Points are processed in tiles of this many; packed clouds are padded to a multiple of it. */
 #define TOHIP_POINT_TILE 1024
@@ -179,7 +180,8 @@ int tohip_hidden_pts_removal(const float *xyz, int64_t n_points, float param, in
  *   seg_visible_offsets  n_segments+1 int32 (device)
  *   mask                 n_total floats 0/1, or NULL
  *   seg_status           n_segments int32 (device) or NULL: 0 ok; 1 fewer than 4 points, 2 flat — scipy raises
- *                        QhullError for both, here the segment reports no visible points
+ *                        QhullError for both; 3 a NaN among its (flipped) points —
+ *                        scipy raises ValueError; here such a segment reports no visible points
  * SYNCHRONISES the stream. */
 size_t tohip_hpr_batched_workspace_bytes(int64_t n_total, int32_t n_segments);
 int tohip_hidden_pts_removal_batched(const float *xyz, const int64_t *seg_offsets_host, int32_t n_segments, float param,

@@ -121,6 +121,7 @@ def lib():
 
 
 ENOSPC = -2  # TOHIP_ENOSPC
+ENAN = -4    # TOHIP_ENAN
 
 
 class HipError(RuntimeError):
@@ -128,6 +129,8 @@ class HipError(RuntimeError):
 
 
 def check(code, what):
+    if code == ENAN:
+        raise ValueError("Points cannot contain NaN")  # what scipy.spatial.ConvexHull raises in the reference (tools.py:63)
     if code != 0:
         err = HipError(f"{what} failed: {lib().tohip_error_string(code).decode()} (code {code})")
         err.code = code

@@ -33,7 +33,7 @@ constexpr int kCtrlNFaces = 0, kCtrlAnyOutside = 1, kCtrlChanged = 2, kCtrlError
               k_commit for the host while the live counters are cleared for the next round; [8] = staged face counter */,
               kCtrlFront = 10 /* [10..12]: three rotating frontier counters of the ownership sweeps */,
               kCtrlInts = 16;
-constexpr int kErrCapacity = 1, kErrFlat = 2, kErrTopology = 4;
+constexpr int kErrCapacity = 1, kErrFlat = 2, kErrTopology = 4, kErrNaN = 8;
 
 // what a distance test needs of a face, in one 64-byte line: the unnormalised normal, the coordinates of the face's
 // first vertex (a copy: the differences below are the same numbers) and the link of the owner's new-face list
@@ -67,7 +67,8 @@ struct Bufs {
     // [seg_off[s], seg_off[s+1]) — its points followed by ONE slot for the appended origin — and the faces it
     // grows never reference another segment, so every round kernel below serves all hulls at once
     int* seg_off;          // nseg + 1
-    int* seg_status;       // nseg   0 ok, 1 fewer than 4 points (no hull), 2 flat (Qhull: QH6154)
+    int* seg_status;       // nseg   0 ok, 1 fewer than 4 points (no hull), 2 flat (Qhull: QH6154), 3 NaN coordinates
+    int* seg_nan;          // nseg   set by k_bbox when a coordinate of the segment is NaN
     int* seg_start;        // nseg + 1   first position of each segment in the compacted vertex list
     int* seg_cnt;          // nseg
     int* idx_all;          // M1 (batched result staging)
@@ -132,6 +133,7 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * nseg); if (b) b->flip_max = (int*)p;
     p = take(sizeof(int) * (nseg + 1)); if (b) b->seg_off = (int*)p;
     p = take(sizeof(int) * nseg); if (b) b->seg_status = (int*)p;
+    p = take(sizeof(int) * nseg); if (b) b->seg_nan = (int*)p;
     p = take(sizeof(int) * (nseg + 1)); if (b) b->seg_start = (int*)p;
     p = take(sizeof(int) * nseg); if (b) b->seg_cnt = (int*)p;
     p = take(sizeof(int) * (nseg > 1 ? m1 : 1)); if (b) b->idx_all = (int*)p;
@@ -292,6 +294,7 @@ __device__ __forceinline__ void source_point(const Bufs& b, const float* __restr
 __global__ void __launch_bounds__(TO_BLOCK) k_bbox_init(Bufs b) {
     const int i = blockIdx.x * TO_BLOCK + threadIdx.x;
     if (i < 6 * b.nseg) b.seg_bbox[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+    if (i < b.nseg) b.seg_nan[i] = 0;
 }
 
 __global__ void __launch_bounds__(TO_BLOCK) k_bbox(Bufs b, const float* __restrict__ pts, int with_origin) {
@@ -305,8 +308,10 @@ __global__ void __launch_bounds__(TO_BLOCK) k_bbox(Bufs b, const float* __restri
             sg = find_seg(b, e);
             float c[3];
             source_point(b, pts, with_origin, e, sg, &c[0], &c[1], &c[2]);
-            for (int k = 0; k < 3; ++k)
-                if (c[k] == c[k]) lo[k] = hi[k] = fkey(c[k]);  // NaN coordinates take no part in the box
+            for (int k = 0; k < 3; ++k) {
+                if (c[k] == c[k]) lo[k] = hi[k] = fkey(c[k]);  // NaN coordinates take no part in the box ...
+                else b.seg_nan[sg] = 1;                          // ... and void the segment (scipy: "Points cannot contain NaN")
+            }
         }
         const int s0 = __shfl(sg, 0);
         if (__all(sg == s0) && s0 >= 0) {  // a wave usually lies inside one segment: reduce there, six atomics
@@ -397,7 +402,8 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
     const int t = threadIdx.x, sg = blockIdx.x, lo = b.seg_off[sg], hi = b.seg_off[sg + 1], fb = 4 * sg;
     double kk = 0.0, k2 = 0.0, k3 = 0.0, nx = 0.0, ny = 0.0, nz = 0.0, x0 = 0.0, y0 = 0.0, z0 = 0.0;
     int i0 = lo, i1 = lo, i2 = lo, i3 = lo;
-    const bool enough = hi - lo - 1 >= 4;  // Qhull needs d+1 input points; the appended origin comes on top
+    const bool has_nan = b.seg_nan[sg] != 0;
+    const bool enough = hi - lo - 1 >= 4 && !has_nan;  // Qhull needs d+1 input points; the appended origin comes on top
     if (enough) {
         // ties go to the caller's lowest index (perm), whatever the internal order
         double best = -INFINITY; int bi = 0x7fffffff;
@@ -434,9 +440,10 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
     }
     if (t == 0) {
         const bool flat = enough && (!(kk > 0.0) || !(k2 > 0.0) || !(k3 > 0.0));
-        b.seg_status[sg] = !enough ? 1 : (flat ? 2 : 0);
+        b.seg_status[sg] = has_nan ? 3 : (!enough ? 1 : (flat ? 2 : 0));
         if (!enough || flat) {
-            if (b.nseg == 1) b.ctrl[kCtrlError] = kErrFlat;  // the single-hull entry points refuse, like Qhull (QH6154/QH6214)
+            // the single-hull entry points refuse, like scipy (ValueError) and Qhull (QH6154/QH6214)
+            if (b.nseg == 1) b.ctrl[kCtrlError] = has_nan ? kErrNaN : kErrFlat;
             // no hull for this segment: its four face slots stay dead (never candidates, never neighbours of a live face)
             for (int f = fb; f < fb + 4; ++f) {
                 for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = lo; b.fn[3 * f + k] = f; }
@@ -837,6 +844,7 @@ static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t s
     if (e != hipSuccess) return (int)e;
     e = hipStreamSynchronize(st);
     if (e != hipSuccess) return (int)e;
+    if (b.nseg == 1 && (h[kCtrlError] & kErrNaN)) return TOHIP_ENAN;
     if (b.nseg == 1 && (h[kCtrlError] & kErrFlat)) return TOHIP_EINVAL;
     int nf = h[kCtrlNFaces];
     const int max_rounds = 100000;

@@ -18,6 +18,7 @@ extern "C" const char* tohip_error_string(int code) {
         case TOHIP_EINVAL: return "invalid argument (null pointer or bad size)";
         case TOHIP_ENOSPC: return "workspace or output capacity too small";
         case TOHIP_ENOTCONV: return "convex hull did not converge within the round limit";
+        case TOHIP_ENAN: return "points cannot contain NaN";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }

@@ -194,6 +194,8 @@ def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method=
             for w in range(w0, w1):
                 offs.append(offs[-1] + kept_idx[w].numel())
             idx, voff, _, status = hidden_pts_removal_batched(torch.cat(kept_pts[w0:w1]), offs, 2)
+            if bool((status == 3).any()):
+                raise ValueError("Points cannot contain NaN")  # scipy's error in the reference's pipeline
             if bool((status == 2).any()):
                 raise _lib.HipError("occlusion_bits: a waypoint's culled cloud is flat (no 3-D hull; Qhull raises QH6154)")
             for j, w in enumerate(range(w0, w1)):
@@ -306,7 +308,7 @@ def hidden_pts_removal_batched(points, seg_offsets, param=2):
     """HPR of several independent clouds in one pass (one viewpoint = the origin of each): `points` (n_total,3)
     holds the segments end to end, `seg_offsets` (B+1 ints, host) their row ranges.
     -> (visible_idx int32 (rows of `points`, ascending), seg_visible_offsets int64 (B+1, host), mask f32[n_total],
-        status int32[B] (0 ok, 1 fewer than 4 points, 2 flat))"""
+        status int32[B] (0 ok, 1 fewer than 4 points, 2 flat, 3 NaN coordinates))"""
     _require_cuda(points, "points")
     pts = points.detach().to(torch.float32).contiguous()
     n, dev = pts.shape[0], pts.device

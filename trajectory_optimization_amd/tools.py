@@ -115,6 +115,8 @@ def visible_points_from_cameras(points, trans, quats, intrins, img_height, img_w
         offs.append(offs[-1] + r["kept_points"].shape[0])
     idx, voff, _, status = ops.hidden_pts_removal_batched(torch.cat([r["kept_points"] for r in out]), offs, 2)
     for c, r in enumerate(out):
+        if int(status[c]) == 3:
+            raise ValueError("Points cannot contain NaN")
         if int(status[c]) == 2:
             raise RuntimeError(f"camera {c}: the culled cloud is flat, no 3-D hull (Qhull raises QH6154)")
         # fewer than 4 kept points: no hull and nothing hidden-point removal could say -> empty, as the single-camera call
