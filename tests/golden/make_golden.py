@@ -399,6 +399,35 @@ def gen_ingest():
     save("ingest", **out)
 
 
+def gen_timing():
+    """Not a fixture: wall time of the reference itself (torch CPU, this container) on the bench workload's shape, for
+    the record kept in profiles/r01_reference_cpu_timing.txt.  python tests/golden/make_golden.py timing"""
+    import time
+    print(f"reference ModelTraj / hidden_pts_removal on torch {torch.__version__} CPU, {torch.get_num_threads()} threads, "
+          f"{os.cpu_count()} vCPUs")
+    for n, w in ((100_000, 32), (1_000_000, 16)):
+        pts = synth.make_cloud(n, seed=0)
+        poses, quats = synth.make_path(w, optical=True)
+        best = None
+        for rep in range(3):
+            m = ref_model.ModelTraj(points=torch.from_numpy(pts), wps_poses=torch.from_numpy(poses),
+                                    wps_quats=torch.from_numpy(quats), intrins=K, img_width=IMG_W, img_height=IMG_H, device=CPU)
+            t0 = time.perf_counter()
+            m(vis_wps_dist=0.0)
+            t1 = time.perf_counter()
+            m.loss["vis"].backward()
+            t2 = time.perf_counter()
+            if best is None or t2 - t0 < best[0]:
+                best = (t2 - t0, t1 - t0, t2 - t1)
+        print(f"ModelTraj {n} points x {w} waypoints: fwd {best[1]:.3f} s, bwd {best[2]:.3f} s, fwd+bwd {best[0]:.3f} s "
+              f"= {n * w / best[0]:.3e} evals/s (best of 3)")
+    for n in (100_000, 1_000_000):
+        pts = torch.from_numpy(synth.make_cloud(n, seed=0))
+        t0 = time.perf_counter()
+        vis, _ = ref_tools.hidden_pts_removal(pts, CPU)
+        print(f"hidden_pts_removal {n} points: {time.perf_counter() - t0:.3f} s ({vis.shape[0]} visible)")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["traj", "adam", "pose", "funcs", "hard", "ingest"]
     for w in which:
