@@ -124,15 +124,15 @@ class _TrajRewards(torch.autograd.Function):
         ps, qs, lo_sum, minmax = ctx.saved_tensors
         m = ctx.model
         lo, hi = ctx.range
-        pg = torch.zeros((ctx.n_wps, 3), dtype=torch.float32, device=lo_sum.device)
-        qg = torch.zeros((ctx.n_wps, 4), dtype=torch.float32, device=lo_sum.device)
+        # every rank fills the rows of its own waypoints; ONE (W,7) all-reduce assembles positions and quaternions
+        grads = torch.zeros((ctx.n_wps, 7), dtype=torch.float32, device=lo_sum.device)
         if hi > lo:
             g = grad_rewards.to(torch.float32).contiguous()
-            pg[lo:hi], qg[lo:hi] = ops.traj_backward(m._cloud, ps, qs, m._cam, m._workspace(hi - lo), lo_sum, minmax,
-                                                     grad_rewards=g, rig=m._rig, flags=m._flags, occ=ctx.occ)
-        pg = m._shard.allreduce_sum(pg)
-        qg = m._shard.allreduce_sum(qg)
-        return pg, qg, None
+            pg, qg = ops.traj_backward(m._cloud, ps, qs, m._cam, m._workspace(hi - lo), lo_sum, minmax,
+                                       grad_rewards=g, rig=m._rig, flags=m._flags, occ=ctx.occ)
+            grads[lo:hi, :3], grads[lo:hi, 3:] = pg, qg
+        grads = m._shard.allreduce_sum(grads)
+        return grads[:, :3].contiguous(), grads[:, 3:].contiguous(), None
 
 
 # ------------------------------------------------------------------------------ models
