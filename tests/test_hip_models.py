@@ -119,6 +119,34 @@ def test_pose_adam_loop(dev):
     np.testing.assert_allclose(losses, d["losses"], rtol=1e-3)
 
 
+def test_device_resident_pose_optimizer(dev):
+    """optimizer.optimize_pose (launch-only loop: pose forward/backward + HIP Adam) vs the reference's torch.optim.Adam run,
+    and vs the drop-in path (model + torch.optim.Adam) step for step."""
+    from trajectory_optimization_amd.optimizer import optimize_pose
+    d = load_golden("pose_adam_bundled")
+    d["points"] = load_golden("bundled")["pts"]
+    for steps in (1, 5, 10):
+        m = _pose_model(d, dev)
+        res = optimize_pose(m, n_opt_steps=steps, lr_pose=float(d["lr_pose"]), lr_quat=float(d["lr_quat"]))
+        np.testing.assert_allclose(m.trans.detach().cpu().numpy(), d[f"trans_step{steps}"], rtol=0, atol=1e-3)
+        np.testing.assert_allclose(m.quat.detach().cpu().numpy(), d[f"quat_step{steps}"], rtol=0, atol=1e-3)
+        np.testing.assert_allclose(res.losses, d["losses"][:steps], rtol=1e-3)
+    # with the (pose-independent) world-frame HPR mask of model.py:114
+    m1, m2 = _pose_model(d, dev), _pose_model(d, dev)
+    res = optimize_pose(m1, n_opt_steps=4, lr_pose=0.05, lr_quat=0.02, hpr=True)
+    opt = torch.optim.Adam([{"params": [m2.trans], "lr": 0.05}, {"params": [m2.quat], "lr": 0.02}])
+    ref = []
+    for _ in range(4):
+        opt.zero_grad()
+        loss = m2(hpr=True)
+        loss.backward()
+        opt.step()
+        ref.append(loss.item())
+    np.testing.assert_allclose(res.losses, ref, rtol=1e-5)
+    np.testing.assert_allclose(m1.trans.detach().cpu().numpy(), m2.trans.detach().cpu().numpy(), atol=1e-5)
+    np.testing.assert_allclose(m1.quat.detach().cpu().numpy(), m2.quat.detach().cpu().numpy(), atol=1e-5)
+
+
 def test_errors_like_reference(dev):
     """W=1 -> the reference's int(NaN) ValueError; CPU device -> loud failure (no fallback)."""
     from trajectory_optimization_amd.model import ModelTraj

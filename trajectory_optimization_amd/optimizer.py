@@ -108,3 +108,46 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
     model.rewards = rewards
     model.loss = {"vis": lt_host[-1, 0], "l2": lt_host[-1, 1], "length": lt_host[-1, 2], "smooth": lt_host[-1, 3]}
     return TrajOptResult(steps, bool(st[2].item() != 0), lt_host[:, 4].tolist(), float(st[4]), float(st[5]))
+
+
+class PoseOptResult:
+    def __init__(self, losses):
+        self.losses = losses
+
+
+@torch.no_grad()
+def optimize_pose(model, n_opt_steps=100, lr_pose=0.1, lr_quat=0.1, hpr=False, betas=(0.9, 0.999), adam_eps=1e-8):
+    """The reference's PoseOpt loop (/root/reference/src/pose_optimization.py:93-97,124-141): n_opt_steps of
+    `loss = model(hpr); loss.backward(); Adam(trans @ lr_pose, quat @ lr_quat).step()` on a ModelPose, in place, as
+    launches only — forward, fused-loss backward and the two Adam updates per step, the loss of every step logged on the
+    device — with one host synchronisation when the run ends.  model.trans / model.quat hold the optimised pose (the
+    reference normalises the quaternion only when publishing, :102), model.observations the last observations."""
+    L = _lib.lib()
+    dev = model.device
+    cloud, cam, ws = model._cloud, model._cam, model._ws
+    f32 = dict(dtype=torch.float32, device=dev)
+    mask = None
+    if hpr:
+        model(hpr=True)  # builds (and caches) the world-frame occlusion mask of model.py:114
+        mask = model._occlusion_mask
+    obs, scalars = torch.empty(cloud.n, **f32), torch.zeros(4, **f32)
+    gout = torch.ones(1, **f32)
+    tg, qg = torch.empty((1, 3), **f32), torch.empty((1, 4), **f32)
+    mt, vt = torch.zeros(3, **f32), torch.zeros(3, **f32)
+    mq, vq = torch.zeros(4, **f32), torch.zeros(4, **f32)
+    losses = torch.empty(max(n_opt_steps, 1), **f32)
+    trans, quat = model.trans.data, model.quat.data
+    with torch.cuda.device(dev):
+        for i in range(n_opt_steps):
+            s = stream_ptr()
+            check(L.tohip_pose_forward(ptr(cloud.blob), cloud.n, ptr(trans), ptr(quat), cam.ref(), ptr(mask), ptr(obs),
+                                       ptr(scalars), ptr(ws.buf), ws.bytes, s), "pose forward")
+            losses[i:i + 1].copy_(scalars[1:2])
+            check(L.tohip_pose_backward(ptr(cloud.blob), cloud.n, ptr(trans), ptr(quat), cam.ref(), ptr(mask), None,
+                                        ptr(scalars), ptr(gout), ptr(tg), ptr(qg), ptr(ws.buf), ws.bytes, s), "pose backward")
+            check(L.tohip_adam_step(ptr(trans), ptr(tg), ptr(mt), ptr(vt), 3, float(lr_pose), betas[0], betas[1], adam_eps,
+                                    i + 1, None, s), "adam trans")
+            check(L.tohip_adam_step(ptr(quat), ptr(qg), ptr(mq), ptr(vq), 4, float(lr_quat), betas[0], betas[1], adam_eps,
+                                    i + 1, None, s), "adam quat")
+    model.observations = obs
+    return PoseOptResult(losses[:n_opt_steps].cpu().tolist())  # the run's only host synchronisation
