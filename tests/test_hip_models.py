@@ -251,3 +251,42 @@ def test_occlusion_aware_traj_model(dev, method):
                    device=dev, occlusion=method, dense=True)
     md(vis_wps_dist=0.0)
     assert torch.equal(md.rewards, m.rewards)
+
+
+def test_sample_script_and_npz_format(dev, tmp_path):
+    """The ROS-free twin of trajectory_optimization_sample.py on files in the reference's .npz sample format
+    ((3,N) point layout included): runs, improves visibility, writes normalised quaternions."""
+    import importlib.util
+    import os
+    from trajectory_optimization_amd import samples
+    b = load_golden("bundled")
+    np.savez(tmp_path / "point_cloud_0.npz", pts=b["pts"].T)  # the (3,N) layout the sample transposes
+    np.savez(tmp_path / "path_poses_0.npz", poses=b["poses"])
+    pts, poses, quats = samples.load_data(tmp_path / "point_cloud_0.npz", tmp_path / "path_poses_0.npz")
+    assert np.array_equal(pts, b["pts"]) and np.array_equal(poses, b["poses"]) and quats.shape == (len(poses), 4)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("sample", os.path.join(repo, "examples", "trajectory_optimization_sample.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "res.npz"
+    log = mod.main(["--points", str(tmp_path / "point_cloud_0.npz"), "--poses", str(tmp_path / "path_poses_0.npz"),
+                    "--opt-steps", "20", "--out", str(out)])
+    r = np.load(out)
+    assert r["poses"].shape == poses.shape and r["rewards"].shape == (len(pts),)
+    np.testing.assert_allclose(np.linalg.norm(r["quats_wxyz"], axis=1), 1.0, atol=1e-6)
+    assert log["visibility"][-1] > 1.0  # Adam on the visibility loss raises the mean reward within 20 steps
+
+
+def test_pose_sample_script(dev, tmp_path):
+    import importlib.util
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pose_sample", os.path.join(repo, "examples", "pose_optimization_sample.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "pose.npz"
+    losses = mod.main(["--opt-steps", "30", "--out", str(out)])
+    r = np.load(out)
+    assert r["trans"].shape == (1, 3) and abs(np.linalg.norm(r["quat_wxyz"]) - 1.0) < 1e-6
+    assert r["observations"].shape == (len(load_golden("bundled")["pts"]),)
+    assert min(losses) < losses[0]  # more of the cloud in view than at the start

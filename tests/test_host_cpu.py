@@ -73,3 +73,24 @@ def test_regularisers_match_reference():
         assert abs(float(mean_angle_calc(t)) - float(d[key + "_mean_angle"])) <= 2e-6 * float(d[key + "_mean_angle"])
     with pytest.raises(ZeroDivisionError):
         mean_angle_calc(torch.zeros(2, 3))  # the reference divides 0.0 by (N_wps - 2) = 0
+
+
+def test_sample_npz_format(tmp_path):
+    """samples.load_data: both point layouts of the reference's .npz samples, identity quaternions, shape errors."""
+    from trajectory_optimization_amd import samples
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(50, 3)).astype(np.float64)
+    poses = rng.normal(size=(7, 3))
+    np.savez(tmp_path / "a.npz", pts=pts)
+    np.savez(tmp_path / "b.npz", pts=pts.T)
+    np.savez(tmp_path / "p.npz", poses=poses)
+    for f in ("a.npz", "b.npz"):
+        x, p, q = samples.load_data(tmp_path / f, tmp_path / "p.npz")
+        assert x.dtype == np.float32 and x.shape == (50, 3) and np.array_equal(x, pts.astype(np.float32))
+        assert p.shape == (7, 3) and np.array_equal(q, np.tile([[1, 0, 0, 0]], (7, 1)))
+    np.savez(tmp_path / "bad.npz", pts=np.zeros((4, 5)))
+    with pytest.raises(ValueError):
+        samples.load_data(tmp_path / "bad.npz")
+    samples.save_result(tmp_path / "r.npz", poses, np.tile([[1, 0, 0, 0]], (7, 1)), rewards=np.ones(50), log={"visibility": [1.0, 1.1]})
+    r = np.load(tmp_path / "r.npz")
+    assert set(r.files) == {"poses", "quats_wxyz", "rewards", "log_visibility"}
