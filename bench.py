@@ -7,7 +7,7 @@ For N>1 the driver launches it under torch.distributed.run, one rank per GPU (RC
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): a 1 M-point synthetic
 cloud x 128 waypoints per GPU, full forward + backward to (x,y,z) and quaternion gradients, through the
 C ABI of include/trajopt_hip.h.  One "step" = tohip_traj_forward -> [all-reduce of the log-odds vector when
-N>1] -> tohip_traj_reward -> tohip_traj_backward [-> all-gather of the (W,7) gradient rows when N>1].  With N GPUs the trajectory has 128*N waypoints sharded
+N>1, overlapped with tohip_traj_backward_scan] -> tohip_traj_reward -> tohip_traj_backward [-> all-gather of the (W,7) gradient rows when N>1].  With N GPUs the trajectory has 128*N waypoints sharded
 contiguously over the ranks (weak scaling; N=8 is configs[3], 1 M x 1024); value = N_points * W_total / time.
 Inputs are resident in HBM before the timed region.
 
@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--cameras", type=int, default=1,
                     help="cameras per waypoint (BASELINE.json configs[4]: 5, with --wps-per-gpu 32); each (camera, "
                          "waypoint) pair is one virtual waypoint with its own min-max normalisation")
+    ap.add_argument("--split-backward", action="store_true",
+                    help="use the scan + masked backward pair also at N=1 (at N>1 dense mode always does, to overlap "
+                         "the scan with the all-reduce)")
     ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -136,15 +139,29 @@ def main():
     n_virtual = args.wps_per_gpu * args.cameras
     rig = ops.CameraRig(*synth.camera_rig(args.cameras), device) if args.cameras > 1 else None
     ws = ops.TrajWorkspace(cloud, n_virtual)
+    L0 = _lib.lib()
     gout = torch.ones(1, device=device)
     shard = WaypointShard() if n_gpus > 1 else None
 
+    need_buf = torch.empty(L0.tohip_traj_need_mask_bytes(cloud.n, n_virtual), dtype=torch.uint8, device=device)
+
     def step(flags):
         lo_sum, minmax = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags)
+        need = None
+        if shard is None and args.split_backward and (flags & ops.DENSE):
+            need = ops.traj_backward_scan(cloud, poses, quats, cam, ws, minmax, rig=rig, flags=flags, out=need_buf)
         if shard is not None:
-            shard.allreduce_sum(lo_sum)  # the one data-path collective: N floats over xGMI
+            # the one data-path collective: N floats over xGMI.  In dense mode the first half of the backward (every
+            # pair re-evaluated: which of them carry gradient) does not depend on lo_sum and runs while RCCL reduces it
+            if flags & ops.DENSE:
+                pending = shard.allreduce_sum_async(lo_sum)
+                need = ops.traj_backward_scan(cloud, poses, quats, cam, ws, minmax, rig=rig, flags=flags, out=need_buf)
+                pending.wait()
+            else:
+                shard.allreduce_sum(lo_sum)
         rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
-        pg, qg = ops.traj_backward(cloud, poses, quats, cam, ws, lo_sum, minmax, scalars=scalars, gout=gout, rig=rig, flags=flags)
+        pg, qg = ops.traj_backward(cloud, poses, quats, cam, ws, lo_sum, minmax, scalars=scalars, gout=gout, rig=rig, flags=flags,
+                                   need_mask=need)
         if shard is not None:
             g = shard.allgather_rows(torch.cat([pg, qg], dim=1))  # (W_total, 7) floats: every rank can step the optimiser
             pg, qg = g[:, :3], g[:, 3:]

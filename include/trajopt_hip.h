@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOHIP_ABI_VERSION 1
+#define TOHIP_ABI_VERSION 2
 
 #define TOHIP_OK 0
 #define TOHIP_EINVAL (-1)   /* bad size / null pointer */
@@ -114,7 +114,19 @@ int tohip_traj_reward(const void *packed, const float *lo_sum, int64_t n_points,
 int tohip_traj_backward(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
                         const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits,
                         const float *lo_sum, const float *grad_rewards, const float *scalars, const float *minmax, const float *gout,
-                        float *poses_grad, float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
+                        const void *need_mask, float *poses_grad, float *quats_grad, void *workspace, size_t workspace_bytes,
+                        void *stream);
+/* Split backward for the multi-GPU step (TOHIP_TRAJ_DENSE only).  Which (wave of points, waypoint) combinations hold a
+ * pair with a non-zero gradient depends on p and the per-waypoint min/max alone, not on lo_sum: tohip_traj_backward_scan
+ * evaluates every pair and records that (need_mask, tohip_traj_need_mask_bytes bytes) and can therefore run while lo_sum
+ * is still being all-reduced; tohip_traj_backward with that need_mask then only walks the flagged combinations.  Same
+ * results, bit for bit, as tohip_traj_backward with need_mask = NULL.  (poses, quats, flags, occlusion_bits, minmax) must
+ * be the same in both calls. */
+size_t tohip_traj_need_mask_bytes(int64_t n_points, int64_t n_virtual_wps);
+int tohip_traj_backward_scan(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
+                             const tohip_camera *cam_host, const tohip_rig *rig_host, int flags,
+                             const uint32_t *occlusion_bits, const float *minmax, void *need_mask, void *workspace,
+                             size_t workspace_bytes, void *stream);
 
 /* ---- ModelPose (model.py:98-127) -------------------------------------------------------------- */
 size_t tohip_pose_workspace_bytes(int64_t n_points);

@@ -225,3 +225,32 @@ def test_culling_randomized_bitwise(dev, seed):
     b = _run_ops(dev, pts, poses, quats, flags=ops.DENSE)
     for k in ("lo_sum", "rewards", "minmax", "scalars", "pg", "qg"):
         assert np.array_equal(a[k], b[k], equal_nan=True), (k, n, w)
+
+
+@pytest.mark.parametrize("n,w,cams,occ", [(1_000_000, 24, 1, False), (200_000, 16, 1, True), (60_000, 9, 3, False), (3000, 5, 1, False)])
+def test_split_backward_is_bitwise_the_fused_one(dev, n, w, cams, occ):
+    """tohip_traj_backward_scan + tohip_traj_backward(need_mask) == tohip_traj_backward, bit for bit (every P, rig,
+    occlusion bits), with a general dL/d rewards vector and with the fused visibility loss."""
+    ops = _ops()
+    pts = synth.make_cloud(n, seed=3)
+    poses, quats = synth.make_path(w, optical=True, jitter_seed=2)
+    P = torch.from_numpy(pts).to(dev)
+    cloud = ops.PackedCloud(P)
+    cam = ops.Camera(K, IW, IH)
+    p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
+    rg = ops.CameraRig(*synth.camera_rig(cams), dev) if cams > 1 else None
+    ws = ops.TrajWorkspace(cloud, w * cams)
+    bits = ops.occlusion_bits(cloud, P, p, q, cam, 1.0, 15.0, "zbuffer") if occ else None
+    lo_sum, minmax = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=ops.DENSE, occ=bits)
+    rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
+    gout = torch.ones(1, device=dev)
+    g = torch.rand(n, generator=torch.Generator().manual_seed(1)).to(dev) - 0.3
+    for kw in (dict(scalars=scalars, gout=gout), dict(grad_rewards=g)):
+        ref = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, rig=rg, flags=ops.DENSE, occ=bits, **kw)
+        mask = ops.traj_backward_scan(cloud, p, q, cam, ws, minmax, rig=rg, flags=ops.DENSE, occ=bits)
+        assert 0 < int(mask.count_nonzero()) < mask.numel()
+        got = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, rig=rg, flags=ops.DENSE, occ=bits, need_mask=mask, **kw)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    from trajectory_optimization_amd import _lib
+    with pytest.raises(_lib.HipError):  # the split belongs to the dense mode
+        ops.traj_backward_scan(cloud, p, q, cam, ws, minmax, rig=rg, flags=0, occ=bits)

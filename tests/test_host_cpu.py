@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), name
-    assert _lib.lib().tohip_abi_version() == 1
+    assert _lib.lib().tohip_abi_version() == 2
 
 
 def test_sizes_and_argument_errors_without_gpu():

@@ -45,7 +45,11 @@ SIGNATURES = {
     "tohip_occlusion_row": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tohip_traj_reward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_f, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_traj_backward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig),
-                                            ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+                                            ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
+                                            c_vp]),
+    "tohip_traj_need_mask_bytes": (c_sz, [c_i64, c_i64]),
+    "tohip_traj_backward_scan": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig),
+                                                 ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_pose_workspace_bytes": (c_sz, [c_i64]),
     "tohip_pose_forward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(Camera), c_vp, c_vp, c_vp, c_vp, c_sz,
                                            c_vp]),
@@ -114,7 +118,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.tohip_abi_version() != 1:
+        if handle.tohip_abi_version() != 2:
             raise ImportError("libtrajopt_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -540,12 +540,59 @@ __device__ __forceinline__ bool bwd_accum(const CamConsts& cc, const WayHot& h, 
     return act;
 }
 
-template <int P, bool PINHOLE, bool CULL, bool OCC>
+// First half of the dense backward, split off so that it can run while the log-odds vector is still being all-reduced
+// (multi-GPU): for every (wave of points, virtual waypoint) whether any pair needs the gradient path.  That depends on
+// p and the waypoint's min/max only — not on lo_sum.  Every pair is evaluated here (the packed, branch-free phase 1 of
+// k_traj_bwd); bit (v & 63) of need[(v >> 6) * nslots + slot].  Waypoint tiles (grid.y) start at multiples of 64, so a
+// word has one writer.
+template <int P, bool PINHOLE, bool OCC>
+__global__ void __launch_bounds__(TO_BLOCK)
+k_traj_bwd_scan(CloudView cv, const WayHot* __restrict__ hot, int V, int vtile, CamConsts cc,
+                unsigned long long* __restrict__ need_out, int nslots, const uint32_t* __restrict__ occ, int64_t occw) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * TO_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
+    float x[P], y[P], z[P];
+    load_points<P>(cv.soa, cv.npad, base, x, y, z);
+    const int v0 = blockIdx.y * vtile;
+    const int v1 = min(V, v0 + vtile);
+    unsigned long long bits = 0ull;
+    for (int v = v0; v < v1; ++v) {
+        const WayHot h = hot[v];
+        float om[P];
+        load_occ<P, OCC>(occ, occw, v, base, om);
+        bool need = false;
+        if constexpr (P >= 2) {
+#pragma unroll
+            for (int i = 0; i < P; i += 2) {
+                f2 X, Y, Z, y0, y1, y2;
+                to_cam_pk(h, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, X, Y, Z, y0, y1, y2);
+                const f2 p = soft_vis_pk<PINHOLE>(cc, X, Y, Z, nullptr) * f2{om[i], om[i + 1]};
+                const f2 ph = (p - pk_splat(h.a)) * pk_splat(h.invM);
+                need |= (ph.x >= 0.5f) | (ph.y >= 0.5f) | ((h.a > 0.f) & ((p.x == h.a) | (p.y == h.a)));
+            }
+        } else {
+            float X, Y, Z, y0, y1, y2;
+            to_cam(h, x[0], y[0], z[0], X, Y, Z, y0, y1, y2);
+            const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr) * om[0];
+            const float ph = (p - h.a) * h.invM;
+            need = (ph >= 0.5f) | ((h.a > 0.f) & (p == h.a));
+        }
+        if (__any(need)) bits |= 1ull << (v & 63);
+        if ((v & 63) == 63 || v == v1 - 1) {
+            if (lane == 0) need_out[(int64_t)(v >> 6) * nslots + slot] = bits;
+            bits = 0ull;
+        }
+    }
+}
+
+template <int P, bool PINHOLE, bool CULL, bool OCC, bool MASKED = false>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restrict__ aux, int V, int vtile,
            CamConsts cc, const float* __restrict__ lo_sum, const float* __restrict__ grad_rewards,
            const float* __restrict__ scalars, const float* __restrict__ gout, float* __restrict__ part, int nslots,
-           float* __restrict__ ties, const uint32_t* __restrict__ occ, int64_t occw) {
+           float* __restrict__ ties, const uint32_t* __restrict__ occ, int64_t occw,
+           unsigned long long* __restrict__ tmask, const unsigned long long* __restrict__ need_in = nullptr) {
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * TO_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
@@ -577,10 +624,53 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
         dst[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
         dst[3] = make_float4(acc[12], acc[13], 0.f, 0.f);
     };
+    // Dense mode writes a partial only where the wave had an active pair and records that in tmask (bit (v & 63) of
+    // tmask[(v >> 6) * nslots + slot]; tiles start at multiples of 64: one writer per word): k_bwd_finish1 sums the
+    // recorded partials.  Most (wave, waypoint) combinations are untouched, and 64 bytes of zeros each were a quarter of
+    // this kernel's time and most of the finish kernel's.
+    if constexpr (!CULL && MASKED) {
+        // second half of the split backward: k_traj_bwd_scan has evaluated every pair; only the flagged
+        // (wave, waypoint) combinations take the gradient path (the scalar twin: bit-identical p)
+        float acc[TO_BWD_NSUM];
+#pragma unroll
+        for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
+        for (int vc = v0; vc < v1; vc += 64) {
+            unsigned long long live = need_in[(int64_t)(vc >> 6) * nslots + slot];
+            unsigned long long done = 0ull;
+            while (live) {
+                const int b = __builtin_ctzll(live);
+                live &= live - 1ull;
+                const int v = vc + b;
+                const WayHot h = hot[v];
+                const float M = aux[v].M;
+                float om[P];
+                load_occ<P, OCC>(occ, occw, v, base, om);
+                bool any_act = false;
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    float X, Y, Z, y0, y1, y2;
+                    to_cam(h, x[i], y[i], z[i], X, Y, Z, y0, y1, y2);
+                    any_act |= bwd_eval<PINHOLE>(cc, h, M, X, Y, Z, y0, y1, y2, gn[i], valid[i], om[i], acc,
+                                                 ties + (int64_t)v * 32);
+                }
+                if (__any(any_act)) {
+#pragma unroll
+                    for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = wave_sum63(acc[k]);
+                    if (lane == 63) store(v, acc);
+#pragma unroll
+                    for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
+                    done |= 1ull << b;
+                }
+            }
+            if (lane == 0) tmask[(int64_t)(vc >> 6) * nslots + slot] = done;
+        }
+        return;
+    }
     if (!CULL) {
         float acc[TO_BWD_NSUM];
 #pragma unroll
         for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
+        unsigned long long bits = 0ull;
         for (int v = v0; v < v1; ++v) {
             const WayHot h = hot[v];
             bool any_act = false;
@@ -617,17 +707,19 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
                 any_act |= bwd_eval<PINHOLE>(cc, h, aux[v].M, X, Y, Z, y0, y1, y2, gn[0], valid[0], om[0], acc,
                                              ties + (int64_t)v * 32);
             }
-            // every pair has been evaluated; when no lane of the wave was active all 14 sums are exact zeros
-            // and the cross-lane reduction of zeros is skipped
-            const bool touched = __any(any_act);
-            if (touched) {
+            // every pair has been evaluated; when no lane of the wave was active all 14 sums are exact zeros: nothing to
+            // reduce and nothing to store
+            if (__any(any_act)) {
 #pragma unroll
                 for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = wave_sum63(acc[k]);
-            }
-            if (lane == 63) store(v, acc);
-            if (touched) {  // untouched accumulators are still exact zeros: re-zero only after use
+                if (lane == 63) store(v, acc);
 #pragma unroll
                 for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
+                bits |= 1ull << (v & 63);
+            }
+            if ((v & 63) == 63 || v == v1 - 1) {
+                if (lane == 0) tmask[(int64_t)(v >> 6) * nslots + slot] = bits;
+                bits = 0ull;
             }
         }
         return;
@@ -667,11 +759,12 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
 
 // block per virtual waypoint: sum the wave partials (double, fixed order), add the min/max shares,
 // write vgrad[v*12 ..] = (sum dL/dc [3], sum y (x) dL/dc [9]).  In CULL mode a partial exists only where the
-// (tile, waypoint) pair is live — the same predicate, on the same records, as k_traj_bwd evaluated.
+// (tile, waypoint) pair is live — the same predicate, on the same records, as k_traj_bwd evaluated; in dense mode where
+// k_traj_bwd recorded one in tmask.
 __global__ void __launch_bounds__(TO_BLOCK)
 k_bwd_finish1(const float* __restrict__ part, int nslots, int slots_per_tile_shift, const float* __restrict__ ties,
               const WayHot* __restrict__ hot, const float4* __restrict__ bounds, float mean, int cull,
-              float* __restrict__ vgrad) {
+              const unsigned long long* __restrict__ tmask, float* __restrict__ vgrad) {
     __shared__ double lds[TO_BLOCK];
     __shared__ double tot[TO_BWD_NSUM];
     const int v = blockIdx.x, t = threadIdx.x;
@@ -684,6 +777,8 @@ k_bwd_finish1(const float* __restrict__ part, int nslots, int slots_per_tile_shi
             // slot -> 256-point tile: P=4: slot == tile, P=2: two slots per tile, P=1: four
             const float4 tb = bounds[sl >> slots_per_tile_shift];
             if (!tile_live(q0, q1, q2, q3.z, q3.w, tb, mean)) continue;
+        } else {
+            if (!((tmask[(int64_t)(v >> 6) * nslots + sl] >> (v & 63)) & 1ull)) continue;  // dense: the recorded partials
         }
         const float4* src = reinterpret_cast<const float4*>(part + ((int64_t)v * nslots + sl) * 16);
         const float4 a = src[0], b = src[1], c = src[2], d = src[3];
@@ -823,7 +918,7 @@ struct TrajPlan {
     int nblk;      // point blocks
     int nslots;    // wave slots = nblk * 4
     int V;
-    size_t off_hot, off_cold, off_aux, off_mm, off_rpart, off_bpart, off_ties, off_vgrad, total;
+    size_t off_hot, off_cold, off_aux, off_mm, off_rpart, off_bpart, off_ties, off_vgrad, off_tmask, total;
 };
 
 inline int choose_P(int64_t n) {
@@ -850,6 +945,7 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W) {
     p.off_bpart = o; o += align_up((size_t)V * max_slots * 16 * sizeof(float), 256);
     p.off_ties = o;  o += align_up((size_t)V * 32 * sizeof(float), 256);
     p.off_vgrad = o; o += align_up((size_t)V * 12 * sizeof(float), 256);
+    p.off_tmask = o; o += align_up((size_t)((V + 63) / 64) * max_slots * sizeof(unsigned long long), 256);
     p.total = o;
     return p;
 }
@@ -864,6 +960,7 @@ inline void choose_tiles(int nblk, int V, bool cull, int* vtile, int* ntiles) {
     if (nt > V) nt = V;
     if (nt < 1) nt = 1;
     *vtile = (V + nt - 1) / nt;
+    if (!cull) *vtile = (*vtile + 63) / 64 * 64;  // dense: a 64-waypoint word of the touched/need masks has one writer
     *ntiles = (V + *vtile - 1) / *vtile;
 }
 
@@ -965,15 +1062,63 @@ extern "C" int tohip_traj_reward(const void* packed, const float* lo_sum, int64_
     return TOHIP_OK;
 }
 
+extern "C" size_t tohip_traj_need_mask_bytes(int64_t n, int64_t n_virtual) {
+    if (n <= 0 || n_virtual <= 0) return 256;
+    const TrajPlan pl = make_plan(n, n_virtual, n_virtual);
+    return align_up((size_t)((n_virtual + 63) / 64) * (size_t)pl.nslots * sizeof(unsigned long long), 256);
+}
+
+extern "C" int tohip_traj_backward_scan(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
+                                        const tohip_camera* cam, const tohip_rig* rig, int flags,
+                                        const uint32_t* occlusion_bits, const float* minmax, void* need_mask,
+                                        void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!packed || !poses || !quats || !cam || !minmax || !need_mask || !workspace || n <= 0 || W <= 0) return TOHIP_EINVAL;
+    if (!(flags & TOHIP_TRAJ_DENSE)) return TOHIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    const int C = rig_cams(rig);
+    const int64_t V = W * C;
+    const TrajPlan pl = make_plan(n, V, W);
+    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
+    char* ws = (char*)workspace;
+    WayHot* hot = (WayHot*)(ws + pl.off_hot);
+    WayCold* cold = (WayCold*)(ws + pl.off_cold);
+    WayAux* aux = (WayAux*)(ws + pl.off_aux);
+    const CamConsts cc = make_consts(cam);
+    const CloudView cv = cloud_view(packed, n);
+    const float* rq = (C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
+    const float* rt = rq ? rig->rig_trans : nullptr;
+    {
+        TO_PROF(TOHIP_PROF_SMALL, st);
+        k_prep_waycams<<<(int)((V + 127) / 128), 128, 0, st>>>(poses, quats, (int)W, C, rq, rt, hot, cold, aux);
+        TO_HIP_CHECK_LAUNCH();
+        k_set_minmax<<<(int)((V + 127) / 128), 128, 0, st>>>(hot, aux, minmax, (int)V, cc.inv_var, 0);
+        TO_HIP_CHECK_LAUNCH();
+    }
+    int vtile, ntiles;
+    choose_tiles(pl.nblk, (int)V, false, &vtile, &ntiles);
+    {
+        TO_PROF(TOHIP_PROF_BWD, st);
+        dispatch(pl.P, cc.pinhole != 0, false, occlusion_bits != nullptr, [&](auto Pc, auto Ph, auto Cu, auto Oc) {
+            if constexpr (!decltype(Cu)::value)
+                k_traj_bwd_scan<decltype(Pc)::value, decltype(Ph)::value, decltype(Oc)::value>
+                    <<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(cv, hot, (int)V, vtile, cc, (unsigned long long*)need_mask,
+                                                                 pl.nslots, occlusion_bits, cv.npad / 32);
+        });
+    }
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
 extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
                                    const tohip_camera* cam, const tohip_rig* rig, int flags,
                                    const uint32_t* occlusion_bits, const float* lo_sum, const float* grad_rewards,
                                    const float* scalars, const float* minmax,
-                                   const float* gout, float* poses_grad, float* quats_grad, void* workspace,
-                                   size_t workspace_bytes, void* stream_) {
+                                   const float* gout, const void* need_mask, float* poses_grad, float* quats_grad,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
     if (!packed || !poses || !quats || !cam || !lo_sum || !minmax || !poses_grad || !quats_grad || !workspace ||
         n <= 0 || W <= 0 || (!grad_rewards && (!scalars || !gout)))
         return TOHIP_EINVAL;
+    if (need_mask && !(flags & TOHIP_TRAJ_DENSE)) return TOHIP_EINVAL;  // the split backward is the dense mode's
     hipStream_t st = (hipStream_t)stream_;
     const int C = rig_cams(rig);
     const int64_t V = W * C;
@@ -986,6 +1131,7 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* p
     float* bpart = (float*)(ws + pl.off_bpart);
     float* ties = (float*)(ws + pl.off_ties);
     float* vgrad = (float*)(ws + pl.off_vgrad);
+    unsigned long long* tmask = (unsigned long long*)(ws + pl.off_tmask);
     const CamConsts cc = make_consts(cam);
     const CloudView cv = cloud_view(packed, n);
     const bool cull = !(flags & TOHIP_TRAJ_DENSE);
@@ -1007,16 +1153,25 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* p
     {
         TO_PROF(TOHIP_PROF_BWD, st);
         dispatch(pl.P, cc.pinhole != 0, cull, occlusion_bits != nullptr, [&](auto Pc, auto Ph, auto Cu, auto Oc) {
-            k_traj_bwd<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value, decltype(Oc)::value>
-                <<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(cv, hot, aux, (int)V, vtile, cc, lo_sum, grad_rewards,
-                                                             scalars, gout, bpart, pl.nslots, ties, occlusion_bits,
-                                                             cv.npad / 32);
+            constexpr int Pv = decltype(Pc)::value;
+            constexpr bool Phv = decltype(Ph)::value, Cuv = decltype(Cu)::value, Ocv = decltype(Oc)::value;
+            if constexpr (!Cuv) {
+                if (need_mask) {
+                    k_traj_bwd<Pv, Phv, false, Ocv, true><<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(
+                        cv, hot, aux, (int)V, vtile, cc, lo_sum, grad_rewards, scalars, gout, bpart, pl.nslots, ties,
+                        occlusion_bits, cv.npad / 32, tmask, (const unsigned long long*)need_mask);
+                    return;
+                }
+            }
+            k_traj_bwd<Pv, Phv, Cuv, Ocv><<<dim3(pl.nblk, ntiles), TO_BLOCK, 0, st>>>(
+                cv, hot, aux, (int)V, vtile, cc, lo_sum, grad_rewards, scalars, gout, bpart, pl.nslots, ties, occlusion_bits,
+                cv.npad / 32, tmask);
         });
     }
     TO_HIP_CHECK_LAUNCH();
     TO_PROF(TOHIP_PROF_SMALL, st);
     const int shift = pl.P == 4 ? 0 : (pl.P == 2 ? 1 : 2);
-    k_bwd_finish1<<<(int)V, TO_BLOCK, 0, st>>>(bpart, pl.nslots, shift, ties, hot, cv.bounds, cc.mean, cull ? 1 : 0, vgrad);
+    k_bwd_finish1<<<(int)V, TO_BLOCK, 0, st>>>(bpart, pl.nslots, shift, ties, hot, cv.bounds, cc.mean, cull ? 1 : 0, tmask, vgrad);
     TO_HIP_CHECK_LAUNCH();
     k_bwd_finish2<<<(int)((W + 63) / 64), 64, 0, st>>>(vgrad, hot, cold, (int)W, C, rq, rt, poses_grad, quats_grad);
     TO_HIP_CHECK_LAUNCH();

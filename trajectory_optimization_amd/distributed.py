@@ -42,6 +42,19 @@ class WaypointShard:
         return t
 
 
+    def allreduce_sum_async(self, t):
+        """Starts the in-place sum of `t` and returns a handle whose wait() makes the CURRENT stream wait for it (RCCL
+        runs the collective on its own stream): kernels enqueued in between that do not touch `t` overlap with it —
+        the dense backward's scan half (ops.traj_backward_scan) is independent of the log-odds vector being reduced."""
+        if self.world_size > 1 and not (t.is_cuda and dist.get_backend(self.group) == "gloo"):
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.allreduce_sum(t)  # single rank, or the host-staged rehearsal path: nothing left in flight
+
+        class _Done:
+            def wait(self):
+                return True
+        return _Done()
+
     def allgather_rows(self, t):
         """Concatenate every rank's (rows, k) block in rank order (equal row counts): the per-waypoint gradient
         rows of a contiguous shard -> the whole trajectory's, on every rank."""

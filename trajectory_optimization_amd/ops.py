@@ -107,17 +107,32 @@ def traj_reward(cloud, lo_sum, cam, ws):
 
 
 def traj_backward(cloud, poses, quats, cam, ws, lo_sum, minmax, grad_rewards=None, scalars=None, gout=None, rig=None,
-                  flags=0, occ=None):
-    """lo_sum: the (all-reduced) log-odds vector in packed order, as returned by traj_forward."""
+                  flags=0, occ=None, need_mask=None):
+    """lo_sum: the (all-reduced) log-odds vector in packed order, as returned by traj_forward.
+    need_mask: the result of traj_backward_scan on the same inputs (dense mode; second half of the split backward)."""
     W = poses.shape[0]
     pg = torch.empty((W, 3), dtype=torch.float32, device=cloud.device)
     qg = torch.empty((W, 4), dtype=torch.float32, device=cloud.device)
     with torch.cuda.device(cloud.device):
         check(_lib.lib().tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
                                              rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(occ), ptr(lo_sum),
-                                             ptr(grad_rewards), ptr(scalars), ptr(minmax), ptr(gout), ptr(pg), ptr(qg),
-                                             ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_backward")
+                                             ptr(grad_rewards), ptr(scalars), ptr(minmax), ptr(gout), ptr(need_mask), ptr(pg),
+                                             ptr(qg), ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_backward")
     return pg, qg
+
+
+def traj_backward_scan(cloud, poses, quats, cam, ws, minmax, rig=None, flags=DENSE, occ=None, out=None):
+    """First half of the split dense backward: independent of lo_sum, so it can be enqueued while the all-reduce of lo_sum
+    is in flight on another stream.  -> need_mask (uint8), to be handed to traj_backward."""
+    W = poses.shape[0]
+    V = W * (rig.n_cams if rig is not None else 1)
+    nbytes = _lib.lib().tohip_traj_need_mask_bytes(cloud.n, V)
+    mask = out if out is not None and out.numel() >= nbytes else torch.empty(nbytes, dtype=torch.uint8, device=cloud.device)
+    with torch.cuda.device(cloud.device):
+        check(_lib.lib().tohip_traj_backward_scan(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
+                                                  rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(occ), ptr(minmax),
+                                                  ptr(mask), ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_backward_scan")
+    return mask
 
 
 class PoseWorkspace:

@@ -71,7 +71,7 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
                                   ptr(ws.buf), ws.bytes, s), "reward")
         check(L.tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), n_eval, cam.ref(), rig_ref,
                                     model._flags, ptr(occ), ptr(lo_sum), None, ptr(scalars), ptr(minmax), ptr(gout),
-                                    ptr(pg_e), ptr(qg_e), ptr(ws.buf), ws.bytes, s), "backward")
+                                    None, ptr(pg_e), ptr(qg_e), ptr(ws.buf), ws.bytes, s), "backward")
         if step_w > 1:
             pg.zero_()
             qg.zero_()
