@@ -31,9 +31,16 @@
 
 // thread per virtual waypoint v = w*C + c.  F.normalize (model.py:53), rig composition
 // R_v = R(qn_w) R(q_c), t_v = t_w + R(qn_w) l_c.
+// With `minmax` (the backward, which rebuilds the records from the forward's result) the normalisation constants go
+// in right away (apply_minmax) and the waypoint's row of the tie accumulators is cleared: one launch
+// where there were three.
+__device__ __forceinline__ void apply_minmax(WayHot& h, float& auxM, float a, float M, float inv_var, int cull);
+
 __global__ void k_prep_waycams(const float* __restrict__ poses, const float* __restrict__ quats, int W, int C,
                                const float* __restrict__ rig_q, const float* __restrict__ rig_t,
-                               WayHot* __restrict__ hot, WayCold* __restrict__ cold, WayAux* __restrict__ aux) {
+                               WayHot* __restrict__ hot, WayCold* __restrict__ cold, WayAux* __restrict__ aux,
+                               const float* __restrict__ minmax = nullptr, float inv_var = 0.f, int cull = 0,
+                               float* __restrict__ ties = nullptr) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= W * C) return;
     const int w = v / C, c = v - w * C;
@@ -73,12 +80,18 @@ __global__ void k_prep_waycams(const float* __restrict__ poses, const float* __r
         for (int j = 0; j < 3; ++j) h.m[3 * i + j] = R[3 * j + i];
     h.t[0] = t[0]; h.t[1] = t[1]; h.t[2] = t[2];
     h.a = 0.f; h.invM = 1.f; h.thr = INFINITY; h.sthr = INFINITY;
+    float auxM = 1.f;
+    if (minmax) apply_minmax(h, auxM, minmax[2 * v], minmax[2 * v + 1], inv_var, cull);
     hot[v] = h;
     if (aux) {
         WayAux a;
-        a.M = 1.f; a.L = 0.f; a.thr1 = INFINITY; a.sthr1 = INFINITY; a.azero = 0.f;
+        a.M = auxM; a.L = 0.f; a.thr1 = INFINITY; a.sthr1 = INFINITY; a.azero = 0.f;
         a.pad[0] = a.pad[1] = a.pad[2] = 0.f;
         aux[v] = a;
+    }
+    if (ties) {
+        float4* tz = reinterpret_cast<float4*>(ties + (int64_t)v * 32);
+        for (int i = 0; i < 8; ++i) tz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -337,16 +350,12 @@ k_minmax_finish(const float2* __restrict__ part, int nslots, WayHot* __restrict_
 
 // restore (a, M, 1/M, cull bound) from a caller-kept minmax array (backward entry point).  With a > 0 the
 // argmin set {p == a} carries gradient and lies outside the active set, so culling is disabled.
-__global__ void k_set_minmax(WayHot* __restrict__ hot, WayAux* __restrict__ aux, const float* __restrict__ minmax,
-                             int V, float inv_var, int cull) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
-    const float a = minmax[2 * v], M = minmax[2 * v + 1];
-    hot[v].a = a; hot[v].invM = 1.0f / M;
+__device__ __forceinline__ void apply_minmax(WayHot& h, float& auxM, float a, float M, float inv_var, int cull) {
+    h.a = a; h.invM = 1.0f / M;
     float thr = INFINITY, sthr = INFINITY;
     if (cull && M > 0.f && a == 0.f) cull_threshold(0.5f * M, inv_var, &thr, &sthr);
-    hot[v].thr = thr; hot[v].sthr = sthr;
-    aux[v].M = M;
+    h.thr = thr; h.sthr = sthr;
+    auxM = M;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -468,6 +477,7 @@ k_reward_finish(const double* __restrict__ part, int nparts, int64_t n, float ep
         scalars[0] = mean;
         scalars[1] = vis;
         scalars[2] = (float)(-(double)vis * (double)vis / (double)n);
+        scalars[3] = 0.f;  // reserved; written so that callers need not clear the vector
     }
 }
 
@@ -757,58 +767,12 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
     }
 }
 
-// block per virtual waypoint: sum the wave partials (double, fixed order), add the min/max shares,
-// write vgrad[v*12 ..] = (sum dL/dc [3], sum y (x) dL/dc [9]).  In CULL mode a partial exists only where the
-// (tile, waypoint) pair is live — the same predicate, on the same records, as k_traj_bwd evaluated; in dense mode where
-// k_traj_bwd recorded one in tmask.
-__global__ void __launch_bounds__(TO_BLOCK)
-k_bwd_finish1(const float* __restrict__ part, int nslots, int slots_per_tile_shift, const float* __restrict__ ties,
-              const WayHot* __restrict__ hot, const float4* __restrict__ bounds, float mean, int cull,
-              const unsigned long long* __restrict__ tmask, float* __restrict__ vgrad) {
-    __shared__ double lds[TO_BLOCK];
-    __shared__ double tot[TO_BWD_NSUM];
-    const int v = blockIdx.x, t = threadIdx.x;
-    const float4* hp = reinterpret_cast<const float4*>(hot + v);
-    const float4 q0 = hp[0], q1 = hp[1], q2 = hp[2], q3 = hp[3];
-    double s[TO_BWD_NSUM];
-    for (int k = 0; k < TO_BWD_NSUM; ++k) s[k] = 0.0;
-    for (int sl = t; sl < nslots; sl += TO_BLOCK) {
-        if (cull) {
-            // slot -> 256-point tile: P=4: slot == tile, P=2: two slots per tile, P=1: four
-            const float4 tb = bounds[sl >> slots_per_tile_shift];
-            if (!tile_live(q0, q1, q2, q3.z, q3.w, tb, mean)) continue;
-        } else {
-            if (!((tmask[(int64_t)(v >> 6) * nslots + sl] >> (v & 63)) & 1ull)) continue;  // dense: the recorded partials
-        }
-        const float4* src = reinterpret_cast<const float4*>(part + ((int64_t)v * nslots + sl) * 16);
-        const float4 a = src[0], b = src[1], c = src[2], d = src[3];
-        s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
-        s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
-        s[8] += c.x; s[9] += c.y; s[10] += c.z; s[11] += c.w;
-        s[12] += d.x; s[13] += d.y;
-    }
-    for (int k = 0; k < TO_BWD_NSUM; ++k) {
-        const double r = block_sum_double(s[k], lds);
-        if (t == 0) tot[k] = r;
-        __syncthreads();
-    }
-    if (t < 12) {
-        const float* tb = ties + (int64_t)v * 32;
-        const double nmin = tb[24], nmax = tb[25];
-        const double wmin = nmin > 0.0 ? tot[12] / nmin : 0.0;
-        const double wmax = nmax > 0.0 ? tot[13] / nmax : 0.0;
-        vgrad[v * 12 + t] = (float)(tot[t] + wmin * (double)tb[t] + wmax * (double)tb[12 + t]);
-    }
-}
-
 // thread per body waypoint: rig composition, dL/dt = -R sum dL/dc, dL/dR = sum y (x) dL/dc,
 // quaternion chain through the homogeneous form of R and through F.normalize.
-__global__ void k_bwd_finish2(const float* __restrict__ vgrad, const WayHot* __restrict__ hot,
-                              const WayCold* __restrict__ cold, int W, int C, const float* __restrict__ rig_q,
-                              const float* __restrict__ rig_t, float* __restrict__ poses_grad,
-                              float* __restrict__ quats_grad) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= W) return;
+__device__ void finish_waypoint(int w, const float* __restrict__ vgrad, const WayHot* __restrict__ hot,
+                                const WayCold* __restrict__ cold, int C, const float* __restrict__ rig_q,
+                                const float* __restrict__ rig_t, float* __restrict__ poses_grad,
+                                float* __restrict__ quats_grad) {
     double dt[3] = {0, 0, 0}, A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // A[3*j+i] = dL/dR_w[j][i]
     for (int c = 0; c < C; ++c) {
         const int v = w * C + c;
@@ -851,6 +815,63 @@ __global__ void k_bwd_finish2(const float* __restrict__ vgrad, const WayHot* __r
     quats_grad[4 * w + 1] = (float)((dh[1] - qx * dot) * inv);
     quats_grad[4 * w + 2] = (float)((dh[2] - qy * dot) * inv);
     quats_grad[4 * w + 3] = (float)((dh[3] - qz * dot) * inv);
+}
+
+__global__ void k_bwd_finish2(const float* __restrict__ vgrad, const WayHot* __restrict__ hot,
+                              const WayCold* __restrict__ cold, int W, int C, const float* __restrict__ rig_q,
+                              const float* __restrict__ rig_t, float* __restrict__ poses_grad,
+                              float* __restrict__ quats_grad) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < W) finish_waypoint(w, vgrad, hot, cold, C, rig_q, rig_t, poses_grad, quats_grad);
+}
+
+// block per virtual waypoint: sum the wave partials (double, fixed order), add the min/max shares,
+// write vgrad[v*12 ..] = (sum dL/dc [3], sum y (x) dL/dc [9]).  In CULL mode a partial exists only where the
+// (tile, waypoint) pair is live — the same predicate, on the same records, as k_traj_bwd evaluated; in dense mode where
+// k_traj_bwd recorded one in tmask.
+__global__ void __launch_bounds__(TO_BLOCK)
+k_bwd_finish1(const float* __restrict__ part, int nslots, int slots_per_tile_shift, const float* __restrict__ ties,
+              const WayHot* __restrict__ hot, const float4* __restrict__ bounds, float mean, int cull,
+              const unsigned long long* __restrict__ tmask, float* __restrict__ vgrad,
+              const WayCold* __restrict__ cold, int C, float* __restrict__ poses_grad, float* __restrict__ quats_grad) {
+    __shared__ double lds[TO_BLOCK];
+    __shared__ double tot[TO_BWD_NSUM];
+    const int v = blockIdx.x, t = threadIdx.x;
+    const float4* hp = reinterpret_cast<const float4*>(hot + v);
+    const float4 q0 = hp[0], q1 = hp[1], q2 = hp[2], q3 = hp[3];
+    double s[TO_BWD_NSUM];
+    for (int k = 0; k < TO_BWD_NSUM; ++k) s[k] = 0.0;
+    for (int sl = t; sl < nslots; sl += TO_BLOCK) {
+        if (cull) {
+            // slot -> 256-point tile: P=4: slot == tile, P=2: two slots per tile, P=1: four
+            const float4 tb = bounds[sl >> slots_per_tile_shift];
+            if (!tile_live(q0, q1, q2, q3.z, q3.w, tb, mean)) continue;
+        } else {
+            if (!((tmask[(int64_t)(v >> 6) * nslots + sl] >> (v & 63)) & 1ull)) continue;  // dense: the recorded partials
+        }
+        const float4* src = reinterpret_cast<const float4*>(part + ((int64_t)v * nslots + sl) * 16);
+        const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+        s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+        s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
+        s[8] += c.x; s[9] += c.y; s[10] += c.z; s[11] += c.w;
+        s[12] += d.x; s[13] += d.y;
+    }
+    for (int k = 0; k < TO_BWD_NSUM; ++k) {
+        const double r = block_sum_double(s[k], lds);
+        if (t == 0) tot[k] = r;
+        __syncthreads();
+    }
+    if (t < 12) {
+        const float* tb = ties + (int64_t)v * 32;
+        const double nmin = tb[24], nmax = tb[25];
+        const double wmin = nmin > 0.0 ? tot[12] / nmin : 0.0;
+        const double wmax = nmax > 0.0 ? tot[13] / nmax : 0.0;
+        vgrad[v * 12 + t] = (float)(tot[t] + wmin * (double)tb[t] + wmax * (double)tb[12 + t]);
+    }
+    if (C == 1) {  // one camera per waypoint: the waypoint's gradient follows at once (k_bwd_finish2's work, no launch)
+        __syncthreads();
+        if (t == 0) finish_waypoint(v, vgrad, hot, cold, 1, nullptr, nullptr, poses_grad, quats_grad);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1089,9 +1110,8 @@ extern "C" int tohip_traj_backward_scan(const void* packed, int64_t n, const flo
     const float* rt = rq ? rig->rig_trans : nullptr;
     {
         TO_PROF(TOHIP_PROF_SMALL, st);
-        k_prep_waycams<<<(int)((V + 127) / 128), 128, 0, st>>>(poses, quats, (int)W, C, rq, rt, hot, cold, aux);
-        TO_HIP_CHECK_LAUNCH();
-        k_set_minmax<<<(int)((V + 127) / 128), 128, 0, st>>>(hot, aux, minmax, (int)V, cc.inv_var, 0);
+        k_prep_waycams<<<(int)((V + 127) / 128), 128, 0, st>>>(poses, quats, (int)W, C, rq, rt, hot, cold, aux, minmax,
+                                                                cc.inv_var, 0);
         TO_HIP_CHECK_LAUNCH();
     }
     int vtile, ntiles;
@@ -1141,12 +1161,9 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* p
     {
         // the workspace may have been reused since the forward: rebuild the waypoint records
         TO_PROF(TOHIP_PROF_SMALL, st);
-        k_prep_waycams<<<(int)((V + 127) / 128), 128, 0, st>>>(poses, quats, (int)W, C, rq, rt, hot, cold, aux);
+        k_prep_waycams<<<(int)((V + 127) / 128), 128, 0, st>>>(poses, quats, (int)W, C, rq, rt, hot, cold, aux, minmax,
+                                                                cc.inv_var, cull ? 1 : 0, ties);
         TO_HIP_CHECK_LAUNCH();
-        k_set_minmax<<<(int)((V + 127) / 128), 128, 0, st>>>(hot, aux, minmax, (int)V, cc.inv_var, cull ? 1 : 0);
-        TO_HIP_CHECK_LAUNCH();
-        hipError_t e = hipMemsetAsync(ties, 0, sizeof(float) * 32 * (size_t)V, st);
-        if (e != hipSuccess) return (int)e;
     }
     int vtile, ntiles;
     choose_tiles(pl.nblk, (int)V, cull, &vtile, &ntiles);
@@ -1171,9 +1188,13 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* p
     TO_HIP_CHECK_LAUNCH();
     TO_PROF(TOHIP_PROF_SMALL, st);
     const int shift = pl.P == 4 ? 0 : (pl.P == 2 ? 1 : 2);
-    k_bwd_finish1<<<(int)V, TO_BLOCK, 0, st>>>(bpart, pl.nslots, shift, ties, hot, cv.bounds, cc.mean, cull ? 1 : 0, tmask, vgrad);
+    const bool single = C == 1 && rq == nullptr;
+    k_bwd_finish1<<<(int)V, TO_BLOCK, 0, st>>>(bpart, pl.nslots, shift, ties, hot, cv.bounds, cc.mean, cull ? 1 : 0, tmask, vgrad,
+                                               cold, single ? 1 : 0, poses_grad, quats_grad);
     TO_HIP_CHECK_LAUNCH();
-    k_bwd_finish2<<<(int)((W + 63) / 64), 64, 0, st>>>(vgrad, hot, cold, (int)W, C, rq, rt, poses_grad, quats_grad);
-    TO_HIP_CHECK_LAUNCH();
+    if (!single) {
+        k_bwd_finish2<<<(int)((W + 63) / 64), 64, 0, st>>>(vgrad, hot, cold, (int)W, C, rq, rt, poses_grad, quats_grad);
+        TO_HIP_CHECK_LAUNCH();
+    }
     return TOHIP_OK;
 }

@@ -99,7 +99,7 @@ def traj_forward(cloud, poses, quats, cam, ws, rig=None, flags=0, occ=None):
 def traj_reward(cloud, lo_sum, cam, ws):
     """-> (rewards[N], scalars[4] = mean, loss_vis, dloss/dreward, -)"""
     rewards = torch.empty(cloud.n, dtype=torch.float32, device=cloud.device)
-    scalars = torch.zeros(4, dtype=torch.float32, device=cloud.device)
+    scalars = torch.empty(4, dtype=torch.float32, device=cloud.device)  # all four written by the finish kernel
     with torch.cuda.device(cloud.device):
         check(_lib.lib().tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, ptr(rewards), ptr(scalars), ptr(ws.buf),
                                            ws.bytes, stream_ptr()), "tohip_traj_reward")
