@@ -530,6 +530,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_far_arg(Bufs b, int all_faces) {
 // Work is proportional to the faces whose owner changed in the previous sweep, not to the size of the hull.
 // Sweep 0 takes the candidates straight from the face array (flag bit 1); sweep i > 0 reads queue i&1 / counter i%3.
 // Every sweep fills queue (i+1)&1 / counter (i+1)%3 and clears counter (i+2)%3.
+constexpr int kWalk = 4;
 __global__ void __launch_bounds__(TO_BLOCK) k_owner_push(Bufs b, int sweep, int epoch) {
     const int round = b.ctrl[kCtrlRound];
     const int* __restrict__ in = b.front[sweep & 1];
@@ -541,7 +542,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_push(Bufs b, int sweep, int 
     const int nloop = (n_in + stride - 1) / stride;
     for (int it = 0; it < nloop; ++it) {
         const int q = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
-        int push[3] = {kNone, kNone, kNone};
+        int push[2 * kWalk + 1];
         int want = 0;
         int g = kNone;
         if (q < n_in) {
@@ -553,19 +554,34 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_push(Bufs b, int sweep, int 
             if (o >= 0) {
                 const unsigned long long po = prio(o, round);
                 const int apex = b.inv[b.fapex[o]];
-                for (int k = 0; k < 3; ++k) {
-                    const int n = b.fn[3 * g + k];
-                    int cur = b.fowner[n];
-                    if (cur == o || (cur >= 0 && prio(cur, round) <= po)) continue;
-                    if (!(fdist(b, n, apex) > 0.0)) continue;
-                    bool claimed = false;
-                    while (true) {
-                        const int old = atomicCAS(&b.fowner[n], cur, o);
-                        if (old == cur) { claimed = true; break; }
-                        cur = old;
-                        if (cur == o || (cur >= 0 && prio(cur, round) <= po)) break;
+                // The thread keeps walking: of the neighbours it claims it continues with one itself (up to kWalk faces
+                // deep) and queues the others, so a region of a few faces is covered in one or two sweeps instead of
+                // one sweep — one launch — per ring.
+                int pending = g, depth = 0;
+                while (pending != kNone) {
+                    const int cg = pending;
+                    pending = kNone;
+                    if (depth == kWalk) {  // out of steps: the last claimed face goes to the queue like the others
+                        if (atomicExch(&b.fstamp[cg], epoch) != epoch) push[want++] = cg;
+                        break;
                     }
-                    if (claimed && atomicExch(&b.fstamp[n], epoch) != epoch) push[want++] = n;
+                    ++depth;
+                    for (int k = 0; k < 3; ++k) {
+                        const int n = b.fn[3 * cg + k];
+                        int cur = b.fowner[n];
+                        if (cur == o || (cur >= 0 && prio(cur, round) <= po)) continue;
+                        if (!(fdist(b, n, apex) > 0.0)) continue;
+                        bool claimed = false;
+                        while (true) {
+                            const int old = atomicCAS(&b.fowner[n], cur, o);
+                            if (old == cur) { claimed = true; break; }
+                            cur = old;
+                            if (cur == o || (cur >= 0 && prio(cur, round) <= po)) break;
+                        }
+                        if (!claimed) continue;
+                        if (pending == kNone) pending = n;
+                        else if (atomicExch(&b.fstamp[n], epoch) != epoch) push[want++] = n;
+                    }
                 }
             }
         }
@@ -850,7 +866,8 @@ static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t s
     const int max_rounds = 100000;
     int round = 0;
     bool careful = false;  // after a round without progress: propagate ownership to convergence (host-checked)
-    int sweeps = 8;        // ownership sweeps per round, adapted from the convergence flag of the last readback
+    const int min_sweeps = 4;
+    int sweeps = 6;        // ownership sweeps per round, adapted from the convergence flag of the last readback
     // Rounds are enqueued in batches with ONE readback per batch: every kernel takes its face counts from the control
     // block on the device and walks its arrays with a grid stride, so the host's (stale) counts only size the grids.
     // A round enqueued after the hull is complete finds no candidate and changes nothing.
@@ -904,7 +921,7 @@ static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t s
             if (careful) return TOHIP_ENOTCONV;  // converged ownership always admits the best candidate: inconsistent predicates
             careful = true;
         } else {
-            if (!careful) sweeps = h[kCtrlChanged2] ? (sweeps < 64 ? sweeps * 2 : 64) : (sweeps > 6 ? sweeps - 1 : 6);
+            if (!careful) sweeps = h[kCtrlChanged2] ? (sweeps < 64 ? sweeps * 2 : 64) : (sweeps > min_sweeps ? sweeps - 1 : min_sweeps);
             careful = false;
         }
     }
