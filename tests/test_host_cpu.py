@@ -21,7 +21,8 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), name
-    assert _lib.lib().tohip_abi_version() == 2
+    header = open(os.path.join(REPO, 'include', 'trajopt_hip.h')).read()
+    assert int(re.search(r'#define TOHIP_ABI_VERSION (\d+)', header).group(1)) == _lib.ABI_VERSION == _lib.lib().tohip_abi_version()
 
 
 def test_sizes_and_argument_errors_without_gpu():

@@ -118,12 +118,13 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.tohip_abi_version() != 2:
+        if handle.tohip_abi_version() != ABI_VERSION:
             raise ImportError("libtrajopt_hip.so ABI version mismatch")
         _lib = handle
     return _lib
 
 
+ABI_VERSION = 2  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
 ENOSPC = -2  # TOHIP_ENOSPC
 ENAN = -4    # TOHIP_ENAN
 
