@@ -163,3 +163,28 @@ def test_hard_pipeline_many_cameras(dev):
         for k in ("kept_idx", "kept_points", "visible_idx", "visible_points"):
             assert torch.equal(many[c][k], one[k]), (c, k)
     assert np.array_equal(many[0]["visible_idx"].cpu().numpy(), d["hpr_visible_idx"])
+
+
+def test_hpr_batched_many_small_segments(dev):
+    """A thousand tiny viewpoints (sizes 0..60, many below the 4 points a hull needs) and an all-empty batch."""
+    from oracle import oracle
+    from trajectory_optimization_amd import ops
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(0, 61, 1000)
+    segs = [(rng.normal(size=(n, 3)) * 3 + rng.uniform(-8, 8, 3)).astype(np.float32) for n in sizes]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    idx, voff, mask, status = ops.hidden_pts_removal_batched(torch.from_numpy(np.concatenate(segs)).to(dev), offs)
+    idx, status = idx.cpu().numpy().astype(np.int64), status.cpu().numpy()
+    checked = 0
+    for s in range(0, 1000, 7):
+        got = idx[voff[s]:voff[s + 1]] - offs[s]
+        if sizes[s] < 4:
+            assert status[s] == 1 and len(got) == 0
+            continue
+        assert status[s] == 0
+        assert np.array_equal(got, oracle.hidden_pts_removal(segs[s])[0]), s
+        checked += 1
+    assert checked > 100
+    assert np.array_equal(status[sizes < 4], np.ones((sizes < 4).sum(), np.int32))
+    idx, voff, mask, status = ops.hidden_pts_removal_batched(torch.empty((0, 3), device=dev), [0, 0, 0])
+    assert idx.numel() == 0 and voff.tolist() == [0, 0, 0] and status.tolist() == [1, 1] and mask.numel() == 0
