@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run ON THE GPU BOX (gpurun): rocprofv3 summaries of the bench command, written under gpurun_out/prof_<tag>/.
+#   kernel-trace + stats for the dense and the culled mode, then counter passes of the dense mode in their own runs
+#   (FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ_* in a third), as MI355X_MICROARCH.md prescribes.
+# Afterwards, here:  python tools/summarize_profiles.py gpurun_out/prof_<tag> rNN   -> profiles/rNN_*
+set -euo pipefail
+tag=${1:-r01}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/prof_$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+common="--steps 5 --warmup 1 --cpu-wps 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/dense" -o dense -- python3 "$root/bench.py" $common --mode dense > "$out/dense.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/culled" -o culled -- python3 "$root/bench.py" $common --mode culled > "$out/culled.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -o pmc -- python3 "$root/bench.py" $common --mode dense > "$out/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -o pmc -- python3 "$root/bench.py" $common --mode dense > "$out/pmc_write.log" 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_sq" -o pmc -- python3 "$root/bench.py" $common --mode dense > "$out/pmc_sq.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/hpr" -o hpr -- python3 "$root/tools/prof_hpr_batched.py" > "$out/hpr.log" 2>&1
+find "$out" -name "*.csv" | head -40

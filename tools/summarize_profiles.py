@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 output of tools/collect_profiles.sh into the committed summaries:
+    python tools/summarize_profiles.py gpurun_out/prof_r01 r01
+ -> profiles/r01_bench_{dense,culled}_kernel_stats.csv, profiles/r01_hpr_batched_kernel_stats.csv (copies) and
+    profiles/r01_bench_dense_pmc.json: per kernel, HBM bytes per launch = 2 x FETCH_SIZE (gfx950 counts a wide coalesced read
+    at half its bytes, MI355X_MICROARCH.md) + WRITE_SIZE, both reported in KB, and the VALU busy fraction
+    SQ_ACTIVE_INST_VALU / (32 x GRBM_GUI_ACTIVE)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+
+def per_kernel(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    seen = set()
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            k = r["Kernel_Name"]
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Dispatch_Id"] not in seen:
+                seen.add(r["Dispatch_Id"])
+                dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return acc, dur
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0]
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dst = os.path.join(repo, "profiles")
+    for mode in ("dense", "culled"):
+        shutil.copy(os.path.join(src, mode, f"{mode}_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_{mode}_kernel_stats.csv"))
+    if os.path.exists(os.path.join(src, "hpr", "hpr_kernel_stats.csv")):
+        shutil.copy(os.path.join(src, "hpr", "hpr_kernel_stats.csv"), os.path.join(dst, f"{tag}_hpr_batched_kernel_stats.csv"))
+    out = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --kernel-trace -- python3 bench.py --steps 5 --warmup 1 "
+                      "--cpu-wps 0 --mode dense   (three separate runs, tools/collect_profiles.sh)",
+           "units": "FETCH_SIZE/WRITE_SIZE in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)",
+           "kernels": {}}
+    ks = out["kernels"]
+    for sub, names in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]),
+                       ("pmc_sq", ["SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])):
+        acc, dur = per_kernel(os.path.join(src, sub, "pmc_counter_collection.csv"))
+        for k, counters in acc.items():
+            if "k_" not in k or "rocprim" in k or "at::" in k:
+                continue
+            e = ks.setdefault(short(k), {})
+            e["launches"] = len(dur[k])
+            e[f"duration_ns_mean_{sub}"] = sum(dur[k]) / len(dur[k])
+            for n in names:
+                if n in counters:
+                    e[f"{n}_mean_per_launch"] = sum(counters[n]) / len(counters[n])
+    for k, e in ks.items():
+        if "FETCH_SIZE_mean_per_launch" in e and "WRITE_SIZE_mean_per_launch" in e:
+            e["hbm_bytes_per_launch_corrected"] = (2.0 * e["FETCH_SIZE_mean_per_launch"] + e["WRITE_SIZE_mean_per_launch"]) * 1024.0
+        if "SQ_ACTIVE_INST_VALU_mean_per_launch" in e and e.get("GRBM_GUI_ACTIVE_mean_per_launch"):
+            # SQ_ACTIVE_INST_VALU is summed over the 32 SQ counter instances (8 XCDs x 4 shader engines); GRBM_GUI_ACTIVE is
+            # the kernel's busy cycles: fraction of cycles in which VALU work is in flight, averaged over those instances
+            e["valu_busy_fraction"] = e["SQ_ACTIVE_INST_VALU_mean_per_launch"] / (32.0 * e["GRBM_GUI_ACTIVE_mean_per_launch"])
+    with open(os.path.join(dst, f"{tag}_bench_dense_pmc.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    for k, e in ks.items():
+        print(k[:40], {kk: round(v, 3) if isinstance(v, float) else v for kk, v in e.items()
+                       if kk in ("launches", "hbm_bytes_per_launch_corrected", "valu_busy_fraction")})
+
+
+if __name__ == "__main__":
+    main()

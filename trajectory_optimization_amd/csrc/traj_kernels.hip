@@ -841,20 +841,35 @@ k_bwd_finish1(const float* __restrict__ part, int nslots, int slots_per_tile_shi
     const float4 q0 = hp[0], q1 = hp[1], q2 = hp[2], q3 = hp[3];
     double s[TO_BWD_NSUM];
     for (int k = 0; k < TO_BWD_NSUM; ++k) s[k] = 0.0;
-    for (int sl = t; sl < nslots; sl += TO_BLOCK) {
-        if (cull) {
-            // slot -> 256-point tile: P=4: slot == tile, P=2: two slots per tile, P=1: four
-            const float4 tb = bounds[sl >> slots_per_tile_shift];
-            if (!tile_live(q0, q1, q2, q3.z, q3.w, tb, mean)) continue;
-        } else {
-            if (!((tmask[(int64_t)(v >> 6) * nslots + sl] >> (v & 63)) & 1ull)) continue;  // dense: the recorded partials
+    // four slots per trip: their liveness loads are issued together (the loop is a chain of dependent loads otherwise);
+    // the partials are still added in increasing slot order
+    for (int sl0 = t; sl0 < nslots; sl0 += 4 * TO_BLOCK) {
+        bool live[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sl = sl0 + j * TO_BLOCK;
+            live[j] = false;
+            if (sl < nslots) {
+                if (cull) {
+                    // slot -> 256-point tile: P=4: slot == tile, P=2: two slots per tile, P=1: four
+                    const float4 tb = bounds[sl >> slots_per_tile_shift];
+                    live[j] = tile_live(q0, q1, q2, q3.z, q3.w, tb, mean);
+                } else {
+                    live[j] = (tmask[(int64_t)(v >> 6) * nslots + sl] >> (v & 63)) & 1ull;  // dense: the recorded partials
+                }
+            }
         }
-        const float4* src = reinterpret_cast<const float4*>(part + ((int64_t)v * nslots + sl) * 16);
-        const float4 a = src[0], b = src[1], c = src[2], d = src[3];
-        s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
-        s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
-        s[8] += c.x; s[9] += c.y; s[10] += c.z; s[11] += c.w;
-        s[12] += d.x; s[13] += d.y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!live[j]) continue;
+            const int sl = sl0 + j * TO_BLOCK;
+            const float4* src = reinterpret_cast<const float4*>(part + ((int64_t)v * nslots + sl) * 16);
+            const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+            s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+            s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
+            s[8] += c.x; s[9] += c.y; s[10] += c.z; s[11] += c.w;
+            s[12] += d.x; s[13] += d.y;
+        }
     }
     for (int k = 0; k < TO_BWD_NSUM; ++k) {
         const double r = block_sum_double(s[k], lds);
