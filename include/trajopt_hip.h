@@ -212,7 +212,9 @@ int tohip_convex_hull_vertices(const float *pts, int64_t n_points, int with_orig
  * the existing content when accumulate != 0 (i.e. on top of the visibility gradient). */
 int tohip_traj_regularizers(const float *poses, const float *poses0, int64_t n_wps, float smoothness_weight,
                             float traj_length_weight, float eps, const float *scalars, float *loss_terms,
-                            float *grad_poses, int accumulate, const float *state, void *stream);
+                            float *grad_poses, int accumulate, const float *state, float *grad_terms, void *stream);
+/* grad_terms (may be NULL): (3, W, 3) floats, the gradients of l2, length and smooth separately (their sum is what
+ * grad_poses receives) — for callers that differentiate a single term of model.loss. */
 /* state (may be NULL): when given, loss_terms is the base of an (n_steps, 8) log and the row written is
  * state[3] = steps taken so far — the launch then carries no per-step host value and can be replayed from a
  * hipGraph.  Same convention for tohip_adam_step (step <= 0: step index = state[3] + 1) and tohip_early_stop. */

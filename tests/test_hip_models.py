@@ -189,9 +189,11 @@ def test_device_regularizers_match_torch(dev):
     scal = torch.tensor([0.5, 1.0 / (0.5 + 1e-6), 0, 0], device=dev)
     lt = torch.zeros(8, device=dev)
     g = torch.zeros_like(m.poses)
+    gt = torch.zeros((3,) + tuple(m.poses.shape), device=dev)
     check(_lib.lib().tohip_traj_regularizers(ptr(m.poses.data), ptr(m.poses0), m.poses.shape[0], 28.0, 0.05, 1e-6,
-                                             ptr(scal), ptr(lt), ptr(g), 0, None, stream_ptr()), "regularizers")
+                                             ptr(scal), ptr(lt), ptr(g), 0, None, ptr(gt), stream_ptr()), "regularizers")
     torch.cuda.synchronize()
+    np.testing.assert_allclose(gt.sum(0).cpu().numpy(), g.cpu().numpy(), rtol=1e-5, atol=1e-7)  # the per-term gradients add up
     assert abs(lt[4].item() - reg.item()) <= 2e-5 * abs(reg.item())
     for k, name in ((1, "l2"), (2, "length"), (3, "smooth")):
         assert abs(lt[k].item() - float(m.loss[name])) <= 2e-5 * max(1.0, abs(float(m.loss[name])))
@@ -290,3 +292,82 @@ def test_pose_sample_script(dev, tmp_path):
     assert r["trans"].shape == (1, 3) and abs(np.linalg.norm(r["quat_wxyz"]) - 1.0) < 1e-6
     assert r["observations"].shape == (len(load_golden("bundled")["pts"]),)
     assert min(losses) < losses[0]  # more of the cloud in view than at the start
+
+
+@pytest.mark.parametrize("case", ["bundled_step2", "synth_all", "three_wps"])
+def test_fused_loss_node_equals_op_by_op_criterion(dev, case):
+    """ModelTraj.forward as one autograd node (visibility + criterion regularisers on the device) against the
+    rewards node + torch criterion it replaces: same loss terms and gradients; a loss built on model.rewards
+    still differentiates; a subclass that overrides criterion keeps the op-by-op path."""
+    from trajectory_optimization_amd.model import ModelTraj
+    if case == "bundled_step2":
+        b = load_golden("bundled")
+        pts, poses, vwd = b["pts"], b["poses"], 0.5
+        quats = np.tile(np.array([[1, 0, 0, 0]], np.float32), (len(poses), 1))
+    elif case == "synth_all":
+        pts = synth.make_cloud(60_000, seed=4)
+        poses, quats = synth.make_path(11, optical=True, jitter_seed=3)
+        vwd = 0.0
+    else:
+        pts = synth.make_cloud(5000, seed=4)
+        poses, quats = synth.make_path(3, optical=True, jitter_seed=1)
+        vwd = 0.0
+
+    def build(fused, cls=ModelTraj):
+        m = cls(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(K), IW, IH, device=dev)
+        m.fused_loss = fused
+        return m
+
+    a, b_ = build(True), build(False)
+    la, lb = a(vis_wps_dist=vwd), b_(vis_wps_dist=vwd)
+    la.backward()
+    lb.backward()
+    assert la.grad_fn.__class__.__name__.startswith("_TrajLoss") and not lb.grad_fn.__class__.__name__.startswith("_TrajLoss")
+    assert abs(la.item() - lb.item()) <= 5e-6 * abs(lb.item())
+    for k in ("vis", "l2", "length", "smooth"):
+        assert abs(float(a.loss[k]) - float(b_.loss[k])) <= 5e-6 * max(1.0, abs(float(b_.loss[k]))), k
+    assert torch.equal(a.rewards, b_.rewards)
+    assert rel_inf(a.poses.grad.cpu().numpy(), b_.poses.grad.cpu().numpy()) < 1e-4
+    assert rel_inf(a.quats.grad.cpu().numpy(), b_.quats.grad.cpu().numpy()) < 1e-5
+    # a criterion of the caller's own on model.rewards (+ the model's loss): the general dL/d rewards path
+    c, d = build(True), build(False)
+    w = torch.linspace(0.5, 1.5, len(pts), device=dev)
+    for m in (c, d):
+        loss = m(vis_wps_dist=vwd)
+        (2.0 * loss + (w * m.rewards).sum() / len(pts)).backward()
+    assert rel_inf(c.poses.grad.cpu().numpy(), d.poses.grad.cpu().numpy()) < 1e-4
+    assert rel_inf(c.quats.grad.cpu().numpy(), d.quats.grad.cpu().numpy()) < 1e-5
+
+    class Mine(ModelTraj):
+        def criterion(self, rewards):
+            return 1.0 / (rewards.mean() + self.eps)
+
+    e = build(True, Mine)
+    le = e(vis_wps_dist=vwd)
+    assert not le.grad_fn.__class__.__name__.startswith("_TrajLoss")
+    assert abs(le.item() - float(a.loss["vis"])) <= 5e-6 * le.item()
+
+
+def test_fused_loss_terms_are_differentiable(dev):
+    """Every entry of model.loss keeps a grad_fn (the reference's are torch expressions): each term alone gives the
+    gradient the op-by-op criterion gives for it."""
+    from trajectory_optimization_amd.model import ModelTraj
+    pts = synth.make_cloud(40_000, seed=6)
+    poses, quats = synth.make_path(9, optical=True, jitter_seed=4)
+    for term in ("vis", "l2", "length", "smooth"):
+        grads = []
+        for fused in (True, False):
+            m = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(K), IW, IH, device=dev)
+            m.fused_loss = fused
+            with torch.no_grad():
+                m.poses += 0.05 * torch.randn(m.poses.shape, generator=torch.Generator().manual_seed(1)).to(dev)  # l2 > 0
+            m(vis_wps_dist=0.0)
+            (3.0 * m.loss[term]).backward()
+            grads.append((m.poses.grad.clone(), None if m.quats.grad is None else m.quats.grad.clone()))
+        (pa, qa), (pb, qb) = grads
+        # the op-by-op side differentiates arccos in f32 (1e-4-level noise on the smoothness term); the kernel works in f64
+        assert rel_inf(pa.cpu().numpy(), pb.cpu().numpy()) < (5e-4 if term == "smooth" else 1e-4), term
+        if term == "vis":
+            assert rel_inf(qa.cpu().numpy(), qb.cpu().numpy()) < 1e-5
+        else:
+            assert qa is None or float(qa.abs().max()) == 0.0

@@ -19,7 +19,8 @@ __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_regularizers(const float* __restrict__ poses, const float* __restrict__ poses0, int W, float smooth_w,
                     float length_w, float eps, const float* __restrict__ scalars /* [1] = loss_vis */,
                     float* __restrict__ loss_terms, float* __restrict__ grad_poses, int accumulate,
-                    const float* __restrict__ state /* may be NULL; else loss row = state[3] (steps taken so far) */) {
+                    const float* __restrict__ state /* may be NULL; else loss row = state[3] (steps taken so far) */,
+                    float* __restrict__ grad_terms /* may be NULL; else (3, W, 3): d l2, d length, d smooth separately */) {
     if (state) loss_terms += 8 * (int)state[3];
     __shared__ double lds[TO_BLOCK];
     __shared__ double sh[4];
@@ -66,27 +67,27 @@ k_traj_regularizers(const float* __restrict__ poses, const float* __restrict__ p
         loss_terms[0] = (float)vis; loss_terms[1] = (float)l2; loss_terms[2] = (float)length; loss_terms[3] = (float)smooth;
         loss_terms[4] = (float)(vis + l2 + length + smooth);
     }
-    if (!grad_poses) return;
+    if (!grad_poses && !grad_terms) return;
     // ---- gradients: thread per waypoint gathers the terms it appears in ------------------------------
     const double dsm_dang = -smooth / (mean_angle + (double)eps) / (double)(W - 2);  // d smooth / d phi_i
     const double dlen_w = (double)length_w * (dlen > 0 ? 1.0 : (dlen < 0 ? -1.0 : 0.0));
     for (int j = t; j < W; j += TO_BLOCK) {
-        double g[3] = {0, 0, 0};
+        double gl[3] = {0, 0, 0}, g2[3] = {0, 0, 0}, gs[3] = {0, 0, 0};  // length, l2, smooth
         // length: segments (j-1, j) and (j, j+1)
         if (j > 0) {
             double d[3], s = 0;
             for (int k = 0; k < 3; ++k) { d[k] = P(poses, j, k) - P(poses, j - 1, k); s += d[k] * d[k]; }
             s = sqrt(s);
-            if (s > 0) for (int k = 0; k < 3; ++k) g[k] += dlen_w * d[k] / s;
+            if (s > 0) for (int k = 0; k < 3; ++k) gl[k] += dlen_w * d[k] / s;
         }
         if (j < W - 1) {
             double d[3], s = 0;
             for (int k = 0; k < 3; ++k) { d[k] = P(poses, j + 1, k) - P(poses, j, k); s += d[k] * d[k]; }
             s = sqrt(s);
-            if (s > 0) for (int k = 0; k < 3; ++k) g[k] -= dlen_w * d[k] / s;
+            if (s > 0) for (int k = 0; k < 3; ++k) gl[k] -= dlen_w * d[k] / s;
         }
         // l2 on the first waypoint
-        if (j == 0 && l2 > 0) for (int k = 0; k < 3; ++k) g[k] += (P(poses, 0, k) - P(poses0, 0, k)) / l2;
+        if (j == 0 && l2 > 0) for (int k = 0; k < 3; ++k) g2[k] += (P(poses, 0, k) - P(poses0, 0, k)) / l2;
         // smoothness: waypoint j is the corner of angle j and an end point of angles j-1 and j+1
         for (int i = j - 1; i <= j + 1; ++i) {
             if (i < 1 || i > W - 2) continue;
@@ -111,12 +112,19 @@ k_traj_regularizers(const float* __restrict__ poses, const float* __restrict__ p
                 if (j == i - 1) dc = dab[k];
                 else if (j == i + 1) dc = dac[k];
                 else dc = -dab[k] - dac[k];
-                g[k] += dsm_dang * dphi_dc * dc;
+                gs[k] += dsm_dang * dphi_dc * dc;
             }
         }
         for (int k = 0; k < 3; ++k) {
-            const float prev = accumulate ? grad_poses[3 * j + k] : 0.f;
-            grad_poses[3 * j + k] = prev + (float)g[k];
+            if (grad_poses) {
+                const float prev = accumulate ? grad_poses[3 * j + k] : 0.f;
+                grad_poses[3 * j + k] = prev + (float)(gl[k] + g2[k] + gs[k]);
+            }
+            if (grad_terms) {
+                grad_terms[3 * j + k] = (float)g2[k];
+                grad_terms[3 * (W + j) + k] = (float)gl[k];
+                grad_terms[3 * (2 * W + j) + k] = (float)gs[k];
+            }
         }
     }
 }
@@ -169,11 +177,12 @@ __global__ void k_early_stop(const float* __restrict__ scalars /* [0] = mean rew
 
 extern "C" int tohip_traj_regularizers(const float* poses, const float* poses0, int64_t W, float smoothness_weight,
                                        float traj_length_weight, float eps, const float* scalars, float* loss_terms,
-                                       float* grad_poses, int accumulate, const float* state, void* stream_) {
+                                       float* grad_poses, int accumulate, const float* state, float* grad_terms,
+                                       void* stream_) {
     if (!poses || !poses0 || !scalars || !loss_terms || W < 3) return TOHIP_EINVAL;
     k_traj_regularizers<<<1, TO_BLOCK, 0, (hipStream_t)stream_>>>(poses, poses0, (int)W, smoothness_weight,
                                                                   traj_length_weight, eps, scalars, loss_terms, grad_poses,
-                                                                  accumulate, state);
+                                                                  accumulate, state, grad_terms);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }

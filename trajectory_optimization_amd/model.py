@@ -17,7 +17,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
+from ._lib import check, ptr, stream_ptr
 from .tools import hidden_pts_removal
 
 
@@ -133,6 +134,94 @@ class _TrajRewards(torch.autograd.Function):
             grads[lo:hi, :3], grads[lo:hi, 3:] = pg, qg
         grads = m._shard.allreduce_sum(grads)
         return grads[:, :3].contiguous(), grads[:, 3:].contiguous(), None
+
+
+class _TrajLoss(torch.autograd.Function):
+    """ModelTraj.forward in one autograd node: (poses, quats) -> (loss, rewards, vis, l2, length, smooth).
+
+    Same launches as optimizer.optimize_trajectory's step — visibility forward, [all-reduce], reward, criterion
+    regularisers with their analytic gradients — instead of the ~60 small torch kernels and as many autograd nodes
+    the op-by-op criterion costs: on an MI355X the forward/backward pair of the drop-in loop is bound by those
+    launches, not by the kernels.  Every output stays differentiable, as in the reference: `loss.backward()` takes the
+    fused visibility-loss path; a loss built on model.rewards or on single entries of model.loss back-propagates
+    through the general dL/d rewards path and the per-term regulariser gradients."""
+
+    @staticmethod
+    def forward(ctx, poses, quats, model, step_w):
+        L = _lib.lib()
+        dev = poses.device
+        p_all, q_all = poses.detach().contiguous(), quats.detach().contiguous()
+        W = p_all.shape[0]
+        p_eval = p_all[::step_w].contiguous() if step_w > 1 else p_all
+        q_eval = q_all[::step_w].contiguous() if step_w > 1 else q_all
+        sh = model._shard
+        lo, hi = sh.bounds(p_eval.shape[0])
+        ps, qs = p_eval[lo:hi].contiguous(), q_eval[lo:hi].contiguous()
+        occ = None
+        if hi > lo and model._occlusion is not None:
+            occ = ops.occlusion_bits(model._cloud, model.points, ps, qs, model._cam, model._occlusion_limits[0],
+                                     model._occlusion_limits[1], model._occlusion)
+        if hi > lo:
+            lo_sum, minmax = ops.traj_forward(model._cloud, ps, qs, model._cam, model._workspace(hi - lo), model._rig,
+                                              flags=model._flags, occ=occ)
+        else:
+            lo_sum, minmax = torch.zeros(model._cloud.npad, device=dev), None
+        lo_sum = sh.allreduce_sum(lo_sum)
+        rewards, scalars = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)))
+        terms = torch.empty(8, dtype=torch.float32, device=dev)
+        reg_sum = torch.empty((W, 3), dtype=torch.float32, device=dev)
+        reg_terms = torch.empty((3, W, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.tohip_traj_regularizers(ptr(p_all), ptr(model.poses0), W, float(model.smoothness_weight),
+                                            float(model.traj_length_weight), float(model.eps), ptr(scalars), ptr(terms),
+                                            ptr(reg_sum), 0, None, ptr(reg_terms), stream_ptr()), "tohip_traj_regularizers")
+        ctx.model, ctx.range, ctx.step_w, ctx.W, ctx.occ = model, (lo, hi), step_w, W, occ
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(ps, qs, lo_sum, minmax if minmax is not None else torch.empty(0, device=dev), scalars, reg_sum,
+                              reg_terms)
+        vis, l2, length, smooth, total = terms[:5].unbind()
+        return total, rewards, vis, l2, length, smooth
+
+    @staticmethod
+    def backward(ctx, g_loss, g_rewards, g_vis, g_l2, g_length, g_smooth):
+        ps, qs, lo_sum, minmax, scalars, reg_sum, reg_terms = ctx.saved_tensors
+        m = ctx.model
+        lo, hi = ctx.range
+        dev = lo_sum.device
+
+        def f32(g):
+            return None if g is None else g.to(torch.float32)
+
+        def plus(a, b):
+            return b if a is None else (a if b is None else a + b)
+
+        g_loss, g_vis = f32(g_loss), f32(g_vis)
+        c_vis = plus(g_loss, g_vis)  # dL/d loss_vis: the visibility term enters the total with weight 1
+        grads = torch.zeros((ctx.W, 7), dtype=torch.float32, device=dev)
+        if hi > lo and (c_vis is not None or g_rewards is not None):
+            if g_rewards is None:
+                kw = dict(scalars=scalars, gout=c_vis.reshape(1).contiguous())  # fused visibility loss, read on the device
+            else:
+                g = g_rewards.to(torch.float32)
+                if c_vis is not None:
+                    g = g + c_vis * scalars[2]  # d loss_vis / d reward_n = -vis^2 / N
+                kw = dict(grad_rewards=g.contiguous())
+            pg, qg = ops.traj_backward(m._cloud, ps, qs, m._cam, m._workspace(hi - lo), lo_sum, minmax, rig=m._rig,
+                                       flags=m._flags, occ=ctx.occ, **kw)
+            rows = slice(lo * ctx.step_w, (hi - 1) * ctx.step_w + 1, ctx.step_w)
+            grads[rows, :3], grads[rows, 3:] = pg, qg
+        grads = m._shard.allreduce_sum(grads)
+        pg_all, qg_all = grads[:, :3], grads[:, 3:]
+        # regularisers: identical on every rank, so added after the all-reduce
+        if g_l2 is None and g_length is None and g_smooth is None:
+            if g_loss is not None:
+                pg_all = pg_all + g_loss * reg_sum
+        else:
+            for k, g in enumerate((g_l2, g_length, g_smooth)):
+                c = plus(g_loss, f32(g))
+                if c is not None:
+                    pg_all = pg_all + c * reg_terms[k]
+        return pg_all.contiguous(), qg_all.contiguous(), None, None
 
 
 # ------------------------------------------------------------------------------ models
@@ -279,6 +368,9 @@ class ModelTraj(nn.Module):
         self._ws_cache = {}
         self._wps_step_cache = {}
         self._length0 = None
+        # forward() as ONE autograd node (visibility + criterion on the device); False: rewards node + the op-by-op
+        # torch criterion below (always used when a subclass overrides criterion, or for fewer than 3 waypoints)
+        self.fused_loss = True
 
     def _workspace(self, n_local_wps):
         v = n_local_wps * (self._rig.n_cams if self._rig is not None else 1)
@@ -307,6 +399,13 @@ class ModelTraj(nn.Module):
         t0 = time()
         N_wps = len(self.poses)
         wps_step = self._wps_step(vis_wps_dist)
+        if self.fused_loss and N_wps >= 3 and type(self).criterion is ModelTraj.criterion:
+            loss, self.rewards, vis, l2, length, smooth = _TrajLoss.apply(self.poses, self.quats, self, wps_step)
+            self.loss = {'vis': vis, 'length': length, 'l2': l2, 'smooth': smooth}
+            if debug:
+                torch.cuda.synchronize(self.device)
+                print(f'Trajectory evaluation took {1000 * (time() - t0)} msec')
+            return loss
         if wps_step == 1:
             poses_eval, quats_eval = self.poses, self.quats
         else:

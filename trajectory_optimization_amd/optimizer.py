@@ -80,7 +80,7 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
         # every per-step quantity (loss-log row, Adam's step index) is read from `state` on the device
         check(L.tohip_traj_regularizers(ptr(poses), ptr(model.poses0), W, float(model.smoothness_weight),
                                         float(model.traj_length_weight), float(model.eps), ptr(scalars), ptr(loss_terms),
-                                        ptr(pg), 1, ptr(state), s), "regularizers")
+                                        ptr(pg), 1, ptr(state), None, s), "regularizers")
         check(L.tohip_adam_step(ptr(poses), ptr(pg), ptr(mp), ptr(vp), W * 3, float(lr_pose), betas[0], betas[1],
                                 adam_eps, 0, ptr(state), s), "adam poses")
         check(L.tohip_adam_step(ptr(quats), ptr(qg), ptr(mq), ptr(vq), W * 4, float(lr_quat), betas[0], betas[1],
