@@ -371,3 +371,27 @@ def test_fused_loss_terms_are_differentiable(dev):
             assert rel_inf(qa.cpu().numpy(), qb.cpu().numpy()) < 1e-5
         else:
             assert qa is None or float(qa.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("hpr", [False, True])
+def test_pose_fused_loss_node(dev, hpr):
+    """ModelPose.forward as one autograd node vs the observations node + torch criterion; observations stay differentiable."""
+    from trajectory_optimization_amd.model import ModelPose
+    d = load_golden("pose_bundled_hpr")
+    out = []
+    for fused in (True, False):
+        for custom in (False, True):
+            m = ModelPose(points=torch.from_numpy(d["points"]), trans0=torch.from_numpy(d["trans0"]), q0=torch.from_numpy(d["q0"]),
+                          intrins=torch.from_numpy(K), img_width=IW, img_height=IH, device=dev)
+            m.fused_loss = fused
+            loss = m(hpr=hpr)
+            assert loss.grad_fn.__class__.__name__.startswith("_PoseLoss") == fused
+            if custom:
+                w = torch.linspace(0.0, 2.0, m.observations.numel(), device=dev)
+                (5.0 * loss + 1e-4 * (w * m.observations).sum()).backward()
+            else:
+                loss.backward()
+            out.append((loss.item(), m.observations.detach().clone(), m.trans.grad.clone(), m.quat.grad.clone()))
+    for a, b in ((out[0], out[2]), (out[1], out[3])):
+        assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0]) and torch.equal(a[1], b[1])
+        assert rel_inf(a[2].cpu().numpy(), b[2].cpu().numpy()) < 1e-5 and rel_inf(a[3].cpu().numpy(), b[3].cpu().numpy()) < 1e-5

@@ -93,6 +93,38 @@ class _PoseObservations(torch.autograd.Function):
         return tg, qg, None, None
 
 
+class _PoseLoss(torch.autograd.Function):
+    """ModelPose.forward in one autograd node: (trans, quat) -> (loss, observations).  `loss.backward()` takes the fused
+    path of tohip_pose_backward (dL/d loss read on the device); a loss built on model.observations goes through the
+    general dL/d observations path."""
+
+    @staticmethod
+    def forward(ctx, trans, quat, model, mask):
+        t = trans.detach().contiguous()
+        q = quat.detach().contiguous()
+        obs, scalars = ops.pose_forward(model._cloud, t, q, model._cam, model._ws, mask)
+        ctx.model, ctx.mask = model, mask
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(t, q, scalars)
+        return scalars[1].clone(), obs
+
+    @staticmethod
+    def backward(ctx, g_loss, g_obs):
+        t, q, scalars = ctx.saved_tensors
+        m = ctx.model
+        if g_loss is None and g_obs is None:
+            return None, None, None, None
+        if g_obs is None:
+            kw = dict(scalars=scalars, gout=g_loss.to(torch.float32).reshape(1).contiguous())
+        else:
+            g = g_obs.to(torch.float32)
+            if g_loss is not None:
+                g = g - g_loss.to(torch.float32) * scalars[1] * scalars[1]  # d loss / d observation_n = -loss^2
+            kw = dict(grad_obs=g.contiguous())
+        tg, qg = ops.pose_backward(m._cloud, t, q, m._cam, m._ws, ctx.mask, **kw)
+        return tg, qg, None, None
+
+
 class _TrajRewards(torch.autograd.Function):
     """rewards(poses, quats) for the evaluated waypoints.  With a process group the waypoints are sharded
     over the ranks; the only data-path collective is the all-reduce of the log-odds vector."""
@@ -265,6 +297,7 @@ class ModelPose(nn.Module):
         self._cam = ops.Camera(self.K, self.img_width, self.img_height, min_dist, max_dist, self.eps)
         self._ws = ops.PoseWorkspace(self._cloud)
         self._occlusion_mask = None
+        self.fused_loss = True  # forward() as one autograd node; False (or an overridden criterion): observations node + torch ops
 
     def forward(self, debug=False, hpr=False):
         t0 = time()
@@ -275,12 +308,17 @@ class ModelPose(nn.Module):
             if self._occlusion_mask is None:
                 self._occlusion_mask = hidden_pts_removal(self.points.detach(), device=self.device)[1].contiguous()
             mask = self._occlusion_mask
-        self.observations = _PoseObservations.apply(self.trans, self.quat, self, mask)
+        fused = self.fused_loss and type(self).criterion is ModelPose.criterion
+        if fused:
+            loss, self.observations = _PoseLoss.apply(self.trans, self.quat, self, mask)
+        else:
+            self.observations = _PoseObservations.apply(self.trans, self.quat, self, mask)
         if debug:
             torch.cuda.synchronize(self.device)
             print(f'Visibility estimation took: {1000 * (time() - t0)} msec')
             print(f'Point cloud size {self.points.size()}')
-        loss = self.criterion(self.observations)
+        if not fused:
+            loss = self.criterion(self.observations)
         return loss
 
     def criterion(self, observations):
