@@ -151,3 +151,43 @@ def optimize_pose(model, n_opt_steps=100, lr_pose=0.1, lr_quat=0.1, hpr=False, b
                                     i + 1, None, s), "adam quat")
     model.observations = obs
     return PoseOptResult(losses[:n_opt_steps].cpu().tolist())  # the run's only host synchronisation
+
+
+class Adam(torch.optim.Optimizer):
+    """torch.optim.Adam for the models' Parameters (defaults of the reference's loops: betas (0.9, 0.999), eps 1e-8, no
+    weight decay, no amsgrad) with ONE kernel launch per parameter (tohip_adam_step) instead of the dozen small foreach
+    kernels per step — the drop-in loop is launch-bound.  Same constructor (parameter groups with their own `lr`), so
+    `ExponentialLR` and friends work unchanged:
+
+        optimizer = Adam([{'params': [model.poses], 'lr': 0.1}, {'params': [model.quats], 'lr': 0.02}])
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise RuntimeError("trajectory_optimization_amd.optimizer.Adam steps contiguous float32 HIP tensors only")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                with torch.cuda.device(p.device):
+                    check(L.tohip_adam_step(ptr(p.data), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), p.numel(),
+                                            float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), None,
+                                            stream_ptr()), "tohip_adam_step")
+        return loss
