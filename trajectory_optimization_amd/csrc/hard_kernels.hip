@@ -249,7 +249,7 @@ k_scan_tiles(const int32_t* __restrict__ tile_count, int ntiles, int32_t* __rest
         lds[threadIdx.x] = v;
         __syncthreads();
         for (int s = 1; s < TO_BLOCK; s <<= 1) {  // Hillis-Steele inclusive scan
-            const int add = threadIdx.x >= s ? lds[threadIdx.x - s] : 0;
+            const int add = (int)threadIdx.x >= s ? lds[threadIdx.x - s] : 0;
             __syncthreads();
             lds[threadIdx.x] += add;
             __syncthreads();
