@@ -171,7 +171,7 @@ extern "C" int tohip_pack_cloud(const float* xyz, int64_t n, int sort, void* pac
         if (e != hipSuccess) return (int)e;
         e = hipMemsetAsync(bbox + 3, 0, 3 * sizeof(unsigned), st);
         if (e != hipSuccess) return (int)e;
-        k_bbox<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, bbox);
+        k_bbox<<<(int)(nb < 256 ? nb : 256), TO_BLOCK, 0, st>>>(xyz, n, bbox);  // six same-address atomics per wave: few waves
         TO_HIP_CHECK_LAUNCH();
         k_morton<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, bbox, keys, vals);
         TO_HIP_CHECK_LAUNCH();
@@ -397,7 +397,7 @@ static int launch_flip(const float* xyz, int64_t n, float param, float* flipped,
     if (e != hipSuccess) return (int)e;
     int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
     if (nb > 2048) nb = 2048;
-    k_norm_max<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, max_bits);
+    k_norm_max<<<(int)(nb < 256 ? nb : 256), TO_BLOCK, 0, st>>>(xyz, n, max_bits);  // one same-address atomic per wave
     TO_HIP_CHECK_LAUNCH();
     const float scale = (float)pow(10.0, (double)param);
     k_flip<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, max_bits, scale, flipped, radius_out);
