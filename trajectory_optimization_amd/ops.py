@@ -179,17 +179,23 @@ def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method=
     n = cloud.n
     wsb = L.tohip_frustum_workspace_bytes(n)
     fws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    kept = torch.empty(n, dtype=torch.int32, device=dev)
-    kcnt = torch.zeros(1, dtype=torch.int32, device=dev)
-    kept_idx, kept_pts = [], []
+    # transform -> cull -> gather for every waypoint without a host round trip: the kept counts stay on the device
+    # (tohip_gather_points reads them there) and are fetched once, after the loop; the per-waypoint buffers are sized for
+    # the worst case (16 B per point and waypoint: 2 GB at 1 M x 128, small change on this part)
+    kept_all = torch.empty((W, max(n, 1)), dtype=torch.int32, device=dev)
+    pts_all = torch.empty((W, max(n, 1), 3), dtype=torch.float32, device=dev)
+    kcnt_all = torch.zeros(W, dtype=torch.int32, device=dev)
     for w in range(W):
         cam3 = to_camera_frame_exact(points, quats[w], poses[w], normalize=True, transpose=True)
         with torch.cuda.device(dev):
-            check(L.tohip_frustum_cull(ptr(cam3), n, cam.ref(), float(min_dist), float(max_dist), None, None, ptr(kept),
-                                       ptr(kcnt), ptr(fws), wsb, stream_ptr()), "tohip_frustum_cull")
-        k = kept[:int(kcnt.item())].clone()
-        kept_idx.append(k)
-        kept_pts.append(cam3[:, k.long()].t().contiguous())
+            check(L.tohip_frustum_cull(ptr(cam3), n, cam.ref(), float(min_dist), float(max_dist), None, None, ptr(kept_all[w]),
+                                       ptr(kcnt_all[w:w + 1]), ptr(fws), wsb, stream_ptr()), "tohip_frustum_cull")
+            check(L.tohip_gather_points(ptr(cam3), n, 1, ptr(kept_all[w]), ptr(kcnt_all[w:w + 1]), n, ptr(pts_all[w]),
+                                        stream_ptr()), "tohip_gather_points")
+    counts = kcnt_all.cpu().tolist()  # the one synchronisation of the cull stage
+    kept = kept_all[0]
+    kept_idx = [kept_all[w, :counts[w]] for w in range(W)]
+    kept_pts = [pts_all[w, :counts[w]] for w in range(W)]
     vis = [None] * W
     if method == "zbuffer":
         K33 = torch.tensor([cam.c.K[i] for i in range(9)]).reshape(3, 3)
