@@ -1204,6 +1204,12 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* p
     }
     int vtile, ntiles;
     choose_tiles(pl.nblk, (int)V, cull, &vtile, &ntiles);
+    if (need_mask) {
+        // the masked half only walks flagged waypoints, a handful per wave near the path: one 64-waypoint mask word per
+        // block row spreads those tails over more CUs
+        vtile = 64;
+        ntiles = (int)((V + 63) / 64);
+    }
     {
         TO_PROF(TOHIP_PROF_BWD, st);
         dispatch(pl.P, cc.pinhole != 0, cull, occlusion_bits != nullptr, [&](auto Pc, auto Ph, auto Cu, auto Oc) {
