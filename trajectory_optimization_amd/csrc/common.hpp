@@ -31,6 +31,13 @@ struct CamConsts {
     float eps;               // 1e-6                                  model.py:44
     float clip_hi;           // float32(1-1e-6)                       model.py:229
     int pinhole;             // K = [[fx,0,cx],[0,fy,cy],[0,0,1]]
+    // The two image-plane Gaussians with their constants folded: with s = sqrt(1/2),
+    //   a_u = ((K0 . c)/z - W/2)/W * s = (ks0 . c) * (1/z) - cw,   ks0 = K[0,:] * s / W,  cw = s / 2   (same for v, H)
+    // so that  -1/2 ((dist/std)^2 + ((u-W/2)/W)^2 + ((v-H/2)/H)^2) = -(d2 * half_inv_var + a_u^2 + a_v^2):
+    // 9 instead of 14 FMA-class operations per evaluation in the three big kernels.
+    float ks0[3], ks1[3];
+    float cw, ch;
+    float half_inv_var;
 };
 
 // Hot record, one 64-byte line per virtual waypoint: c = m * (x - t).  a / invM / thr / sthr are filled by
@@ -100,6 +107,14 @@ static inline CamConsts make_consts(const tohip_camera* c) {
     k.eps = c->eps;
     k.clip_hi = (float)(1.0 - (double)c->eps);
     k.pinhole = (c->K[1] == 0.f && c->K[3] == 0.f && c->K[6] == 0.f && c->K[7] == 0.f && c->K[8] == 1.f) ? 1 : 0;
+    const double sq = 0.70710678118654752440;
+    for (int i = 0; i < 3; ++i) {
+        k.ks0[i] = (float)((double)c->K[i] * sq / (double)c->img_width);
+        k.ks1[i] = (float)((double)c->K[3 + i] * sq / (double)c->img_height);
+    }
+    k.cw = (float)(0.5 * sq);
+    k.ch = (float)(0.5 * sq);
+    k.half_inv_var = (float)(0.5 / (sd * sd));
     return k;
 }
 
@@ -160,27 +175,34 @@ struct Vis {
 template <bool PINHOLE>
 __device__ __forceinline__ float soft_vis(const CamConsts& k, float X, float Y, float Z, Vis* o) {
     const float d2 = dist2_mean(X, Y, Z, k.mean);
-    float h0, h1, h2;
+    float g0, g1, h2;  // the scaled projections (ks0 . c), (ks1 . c) and the depth
     if (PINHOLE) {
-        h0 = fmaf(k.k[2], Z, k.k[0] * X);
-        h1 = fmaf(k.k[5], Z, k.k[4] * Y);
+        g0 = fmaf(k.ks0[2], Z, k.ks0[0] * X);
+        g1 = fmaf(k.ks1[2], Z, k.ks1[1] * Y);
         h2 = Z;
     } else {
-        h0 = fmaf(k.k[2], Z, fmaf(k.k[1], Y, k.k[0] * X));
-        h1 = fmaf(k.k[5], Z, fmaf(k.k[4], Y, k.k[3] * X));
+        g0 = fmaf(k.ks0[2], Z, fmaf(k.ks0[1], Y, k.ks0[0] * X));
+        g1 = fmaf(k.ks1[2], Z, fmaf(k.ks1[1], Y, k.ks1[0] * X));
         h2 = fmaf(k.k[8], Z, fmaf(k.k[7], Y, k.k[6] * X));
     }
     const float rz = to_rcp(h2 + k.eps);
-    const float u = h0 * rz, v = h1 * rz;
-    const float au = (u - k.halfw) * k.inv_w, av = (v - k.halfh) * k.inv_h;
-    float arg = d2 * k.inv_var;          // (dist/std)^2
+    const float au = fmaf(g0, rz, -k.cw), av = fmaf(g1, rz, -k.ch);
+    float arg = d2 * k.half_inv_var;     // 1/2 (dist/std)^2
     arg = fmaf(au, au, arg);
     arg = fmaf(av, av, arg);
-    const float E = to_exp(-0.5f * arg);
+    const float E = to_exp(-arg);
     const float S = to_rcp(1.0f + to_exp_fast(-h2));
     const float p = S * E;
-    if (o) {
-        o->p = p; o->S = S; o->u = u; o->v = v; o->rz = rz;
+    if (o) {  // the gradient also wants the pixel coordinates themselves
+        float h0, h1;
+        if (PINHOLE) {
+            h0 = fmaf(k.k[2], Z, k.k[0] * X);
+            h1 = fmaf(k.k[5], Z, k.k[4] * Y);
+        } else {
+            h0 = fmaf(k.k[2], Z, fmaf(k.k[1], Y, k.k[0] * X));
+            h1 = fmaf(k.k[5], Z, fmaf(k.k[4], Y, k.k[3] * X));
+        }
+        o->p = p; o->S = S; o->u = h0 * rz; o->v = h1 * rz; o->rz = rz;
     }
     return p;
 }
@@ -258,27 +280,34 @@ struct Vis2 {
 template <bool PINHOLE>
 __device__ __forceinline__ f2 soft_vis_pk(const CamConsts& k, f2 X, f2 Y, f2 Z, Vis2* o) {
     const f2 d2 = dist2_mean_pk(X, Y, Z, k.mean);
-    f2 h0, h1, h2;
+    f2 g0, g1, h2;
     if (PINHOLE) {
-        h0 = pk_fma(pk_splat(k.k[2]), Z, pk_splat(k.k[0]) * X);
-        h1 = pk_fma(pk_splat(k.k[5]), Z, pk_splat(k.k[4]) * Y);
+        g0 = pk_fma(pk_splat(k.ks0[2]), Z, pk_splat(k.ks0[0]) * X);
+        g1 = pk_fma(pk_splat(k.ks1[2]), Z, pk_splat(k.ks1[1]) * Y);
         h2 = Z;
     } else {
-        h0 = pk_fma(pk_splat(k.k[2]), Z, pk_fma(pk_splat(k.k[1]), Y, pk_splat(k.k[0]) * X));
-        h1 = pk_fma(pk_splat(k.k[5]), Z, pk_fma(pk_splat(k.k[4]), Y, pk_splat(k.k[3]) * X));
+        g0 = pk_fma(pk_splat(k.ks0[2]), Z, pk_fma(pk_splat(k.ks0[1]), Y, pk_splat(k.ks0[0]) * X));
+        g1 = pk_fma(pk_splat(k.ks1[2]), Z, pk_fma(pk_splat(k.ks1[1]), Y, pk_splat(k.ks1[0]) * X));
         h2 = pk_fma(pk_splat(k.k[8]), Z, pk_fma(pk_splat(k.k[7]), Y, pk_splat(k.k[6]) * X));
     }
     const f2 rz = pk_rcp(h2 + pk_splat(k.eps));
-    const f2 u = h0 * rz, v = h1 * rz;
-    const f2 au = (u - pk_splat(k.halfw)) * pk_splat(k.inv_w), av = (v - pk_splat(k.halfh)) * pk_splat(k.inv_h);
-    f2 arg = d2 * pk_splat(k.inv_var);
+    const f2 au = pk_fma(g0, rz, pk_splat(-k.cw)), av = pk_fma(g1, rz, pk_splat(-k.ch));
+    f2 arg = d2 * pk_splat(k.half_inv_var);
     arg = pk_fma(au, au, arg);
     arg = pk_fma(av, av, arg);
-    const f2 E = to_exp_pk(pk_splat(-0.5f) * arg);
+    const f2 E = to_exp_pk(-arg);
     const f2 S = pk_rcp(pk_splat(1.0f) + to_exp_fast_pk(-h2));
     const f2 p = S * E;
     if (o) {
-        o->p = p; o->S = S; o->u = u; o->v = v; o->rz = rz;
+        f2 h0, h1;
+        if (PINHOLE) {
+            h0 = pk_fma(pk_splat(k.k[2]), Z, pk_splat(k.k[0]) * X);
+            h1 = pk_fma(pk_splat(k.k[5]), Z, pk_splat(k.k[4]) * Y);
+        } else {
+            h0 = pk_fma(pk_splat(k.k[2]), Z, pk_fma(pk_splat(k.k[1]), Y, pk_splat(k.k[0]) * X));
+            h1 = pk_fma(pk_splat(k.k[5]), Z, pk_fma(pk_splat(k.k[4]), Y, pk_splat(k.k[3]) * X));
+        }
+        o->p = p; o->S = S; o->u = h0 * rz; o->v = h1 * rz; o->rz = rz;
     }
     return p;
 }
