@@ -663,12 +663,16 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
         float acc[TO_BWD_NSUM];
 #pragma unroll
         for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
-        for (int vc = v0; vc < v1; vc += 64) {
-            unsigned long long live = need_in[(int64_t)(vc >> 6) * nslots + slot];
-            unsigned long long done = 0ull;
+        // a block row owns 16 waypoints — a quarter of a mask word (vtile = 16 here): the flagged waypoints of the few
+        // waves near the path are walked one after the other, and sixteen at most keeps that tail short
+        {
+            const int vc = v0;
+            const int64_t word = (int64_t)(vc >> 6) * nslots + slot;
+            unsigned live = (unsigned)(need_in[word] >> (vc & 63)) & 0xffffu;
+            unsigned done = 0u;
             while (live) {
-                const int b = __builtin_ctzll(live);
-                live &= live - 1ull;
+                const int b = __builtin_ctz(live);
+                live &= live - 1u;
                 const int v = vc + b;
                 const WayHot h = hot[v];
                 const float M = aux[v].M;
@@ -688,10 +692,11 @@ k_traj_bwd(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restric
                     if (lane == 63) store(v, acc);
 #pragma unroll
                     for (int k = 0; k < TO_BWD_NSUM; ++k) acc[k] = 0.f;
-                    done |= 1ull << b;
+                    done |= 1u << b;
                 }
             }
-            if (lane == 0) tmask[(int64_t)(vc >> 6) * nslots + slot] = done;
+            // the quarter of the (little-endian) 64-bit word this row owns
+            if (lane == 0) reinterpret_cast<unsigned short*>(tmask)[word * 4 + ((vc & 63) >> 4)] = (unsigned short)done;
         }
         return;
     }
@@ -1205,10 +1210,10 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* p
     int vtile, ntiles;
     choose_tiles(pl.nblk, (int)V, cull, &vtile, &ntiles);
     if (need_mask) {
-        // the masked half only walks flagged waypoints, a handful per wave near the path: one 64-waypoint mask word per
-        // block row spreads those tails over more CUs
-        vtile = 64;
-        ntiles = (int)((V + 63) / 64);
+        // the masked half only walks flagged waypoints, a handful per wave near the path: a quarter of a mask word
+        // (16 waypoints) per block row spreads those tails over more CUs
+        vtile = 16;
+        ntiles = (int)((V + 15) / 16);
     }
     {
         TO_PROF(TOHIP_PROF_BWD, st);
