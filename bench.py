@@ -221,7 +221,8 @@ def main():
     if rank == 0:
         # dominant kernel by summed device time; achieved = algorithmic bytes per launch / mean duration
         dom = max(ALGO_BYTES, key=lambda k: kern.get(k, (0.0, 0))[0])
-        dom_ms = kern[dom][0] / max(kern[dom][1], 1)
+        # per step, not per launch: the split backward (N > 1) is two launches of the same class per step
+        dom_ms = kern[dom][0] / args.steps
         local_evals = args.points * n_virtual
         achieved = ALGO_BYTES[dom] * local_evals / (dom_ms * 1e-3) / 1e9
         traffic, valu_busy = pmc_figures(dom)
@@ -241,8 +242,8 @@ def main():
                          "traffic_note": "HBM bytes per launch from profiles/r01_bench_dense_pmc.json (separate --pmc "
                                          "passes of this command); far below the algorithmic bytes: the kernels keep "
                                          "points in registers and loop over waypoints, so they are VALU-issue bound",
-                         "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in kern.items()},
-                         "kernel_ms_note": "HIP events on the launch stream over a second pass of the same K steps (the events "
+                         "kernel_ms": {k: v[0] / args.steps for k, v in kern.items()},
+                         "kernel_ms_note": "per step and kernel class; HIP events on the launch stream over a second pass of the same K steps (the events "
                                            "themselves cost ~0.06 ms per step, so the timed pass runs without them)",
                          "algorithmic_bytes_per_eval": ALGO_BYTES[dom],
                          "fwd_bwd_frac_of_48B_per_eval_roofline": value / n_gpus * 48.0 / (HBM_PEAK_GBS * 1e9)},
@@ -251,7 +252,7 @@ def main():
         line["culled_exact"] = {
             "value": evals_per_step * args.steps / dt_c, "unit": "evals/s", "ms_per_step": 1e3 * dt_c / args.steps,
             "bitwise_identical_to_dense": bool(same),
-            "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in kern_c.items()},
+            "kernel_ms": {k: v[0] / args.steps for k, v in kern_c.items()},
             "note": "library default: pairs whose log-odds term is provably exactly 0 are skipped via a "
                     "Morton-sorted cloud, per-256-point bounding spheres and a distance bound on p"}
         if n_gpus == 1 and args.cpu_wps > 0 and args.cameras == 1:
