@@ -210,6 +210,31 @@ def gen_traj():
     save("traj_synth_dense", **d)
 
 
+def gen_clip():
+    """Non-default pc_clip_limits (min_dist, max_dist): the Gaussian of get_dist_mask moves to (0.5+8)/2 = 4.25 with
+    std 3.75 (model.py:18-21).  python tests/golden/make_golden.py clip"""
+    cloud = synth.make_cloud(6000, seed=31)
+    p, q = synth.make_path(5, optical=True, jitter_seed=31)
+    d = run_traj(cloud, p, q, 0.0, min_dist=0.5, max_dist=8.0)
+
+    def visonly():
+        m = ref_model.ModelTraj(points=torch.from_numpy(cloud), wps_poses=torch.from_numpy(p), wps_quats=torch.from_numpy(q),
+                                intrins=K, img_width=IMG_W, img_height=IMG_H, device=CPU, min_dist=0.5, max_dist=8.0)
+        m(vis_wps_dist=0.0)
+        m.loss["vis"].backward()
+        return dict(vis_poses_grad=m.poses.grad, vis_quats_grad=m.quats.grad)
+    d.update(visonly())
+    save("traj_synth_clip", **d)
+    mp = ref_model.ModelPose(points=torch.from_numpy(cloud), trans0=torch.tensor([[1.0, -2.0, 0.3]]),
+                             q0=torch.from_numpy(q[2:3].copy()), intrins=K, img_width=IMG_W, img_height=IMG_H,
+                             min_dist=0.5, max_dist=8.0, device=CPU)
+    loss = mp()
+    loss.backward()
+    save("pose_synth_clip", points=cloud, trans0=np.array([[1.0, -2.0, 0.3]], np.float32), q0=q[2:3].copy(), hpr=np.asarray(False),
+         min_dist=np.float64(0.5), max_dist=np.float64(8.0), loss=loss, observations=mp.observations, trans_grad=mp.trans.grad,
+         quat_grad=mp.quat.grad)
+
+
 def gen_adam():
     """Parameter values after k Adam steps on the bundled cloud/path
     (/root/reference/src/trajectory_optimization.py:91-124 loop, launch-file rates)."""

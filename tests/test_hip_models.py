@@ -23,10 +23,10 @@ def _traj_model(d, dev, **kw):
                      device=dev, **kw)
 
 
-@pytest.mark.parametrize("name", ["traj_bundled_default", "traj_bundled_tilted_all", "traj_synth_10000x8"])
+@pytest.mark.parametrize("name", ["traj_bundled_default", "traj_bundled_tilted_all", "traj_synth_10000x8", "traj_synth_clip"])
 def test_model_traj_matches_reference(dev, name):
     d = load_golden(name)
-    kw = {k: float(d[k]) for k in ("smoothness_weight", "traj_length_weight") if k in d}
+    kw = {k: float(d[k]) for k in ("smoothness_weight", "traj_length_weight", "min_dist", "max_dist") if k in d}
     m = _traj_model(d, dev, **kw)
     loss = m(vis_wps_dist=float(d["vis_wps_dist"]))
     loss.backward()
@@ -84,11 +84,12 @@ def test_traj_adam_loop(dev):
 
 def _pose_model(d, dev):
     from trajectory_optimization_amd.model import ModelPose
+    kw = {k: float(d[k]) for k in ("min_dist", "max_dist") if k in d}
     return ModelPose(points=torch.from_numpy(d["points"]), trans0=torch.from_numpy(d["trans0"]),
-                     q0=torch.from_numpy(d["q0"]), intrins=torch.from_numpy(K), img_width=IW, img_height=IH, device=dev)
+                     q0=torch.from_numpy(d["q0"]), intrins=torch.from_numpy(K), img_width=IW, img_height=IH, device=dev, **kw)
 
 
-@pytest.mark.parametrize("name", ["pose_bundled_nohpr", "pose_bundled_tilted"])
+@pytest.mark.parametrize("name", ["pose_bundled_nohpr", "pose_bundled_tilted", "pose_synth_clip"])
 def test_model_pose_matches_reference(dev, name):
     d = load_golden(name)
     m = _pose_model(d, dev)

@@ -24,10 +24,10 @@ def _ops():
     return ops
 
 
-def _run_ops(dev, points, poses, quats, rig=None, flags=0, sort=True):
+def _run_ops(dev, points, poses, quats, rig=None, flags=0, sort=True, clip=(1.0, 5.0)):
     ops = _ops()
     cloud = ops.PackedCloud(torch.from_numpy(np.ascontiguousarray(points)).to(dev), sort=sort)
-    cam = ops.Camera(K, IW, IH)
+    cam = ops.Camera(K, IW, IH, clip[0], clip[1])
     p = torch.from_numpy(np.ascontiguousarray(poses)).to(dev)
     q = torch.from_numpy(np.ascontiguousarray(quats)).to(dev)
     rg = ops.CameraRig(rig[0], rig[1], dev) if rig is not None else None
@@ -66,13 +66,16 @@ def test_packed_cloud_is_a_permutation(dev):
 
 
 GOLD = ["traj_bundled_tilted_all", "traj_synth_1000x3", "traj_synth_10000x8", "traj_synth_20000x32",
-        "traj_synth_ties", "traj_synth_dense"]
+        "traj_synth_ties", "traj_synth_dense", "traj_synth_clip"]
 
 
 @pytest.mark.parametrize("name", GOLD)
 def test_c_abi_vs_golden(dev, name):
     d = load_golden(name)
-    r = _run_ops(dev, d["points"], d["poses"], d["quats"])
+    clip = (float(d["min_dist"]), float(d["max_dist"])) if "min_dist" in d else (1.0, 5.0)  # pc_clip_limits of the fixture
+    r = _run_ops(dev, d["points"], d["poses"], d["quats"], clip=clip)
+    for flags in (0, _ops().DENSE):
+        assert np.array_equal(_run_ops(dev, d["points"], d["poses"], d["quats"], clip=clip, flags=flags)["pg"], r["pg"])
     assert abs(r["scalars"][1] - float(d["loss_vis"])) <= 3e-6 * float(d["loss_vis"])
     np.testing.assert_allclose(r["rewards"], d["rewards"], rtol=REW_RTOL, atol=REW_ATOL)
     assert rel_inf(r["pg"], d["vis_poses_grad"]) < GRAD_TOL

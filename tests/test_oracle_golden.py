@@ -16,7 +16,12 @@ def _wps_step(d):
 
 
 TRAJ = ["traj_bundled_default", "traj_bundled_tilted_all", "traj_synth_1000x3", "traj_synth_10000x8",
-        "traj_synth_20000x32", "traj_synth_ties", "traj_synth_dense"]
+        "traj_synth_20000x32", "traj_synth_ties", "traj_synth_dense", "traj_synth_clip"]
+
+
+def _clip(d):
+    """pc_clip_limits of the fixture (default 1, 5)."""
+    return dict(min_dist=float(d["min_dist"]) if "min_dist" in d else 1.0, max_dist=float(d["max_dist"]) if "max_dist" in d else 5.0)
 
 
 @pytest.mark.parametrize("name", TRAJ)
@@ -25,12 +30,12 @@ def test_traj_forward_backward(name, prec):
     d = load_golden(name)
     step = _wps_step(d)
     idx = np.arange(0, len(d["poses"]), step)
-    fwd = oracle.traj_forward(d["points"], d["poses"][idx], d["quats"][idx], K, IW, IH, prec=prec)
+    fwd = oracle.traj_forward(d["points"], d["poses"][idx], d["quats"][idx], K, IW, IH, prec=prec, **_clip(d))
     assert abs(fwd["loss_vis"] - float(d["loss_vis"])) <= 2e-6 * float(d["loss_vis"])
     # saturated rewards (|lo| up to 13.8 per waypoint) are compared absolutely: f32 sigmoid noise
     np.testing.assert_allclose(fwd["rewards"], d["rewards"], rtol=2e-5, atol=2e-6)
     if "vis_poses_grad" in d or name == "traj_bundled_default":
-        pg, qg = oracle.traj_backward(d["points"], d["poses"][idx], d["quats"][idx], K, IW, IH, fwd, prec=prec)
+        pg, qg = oracle.traj_backward(d["points"], d["poses"][idx], d["quats"][idx], K, IW, IH, fwd, prec=prec, **_clip(d))
         if "vis_poses_grad" in d:
             assert rel_inf(pg, d["vis_poses_grad"][idx]) < 1e-5
             assert rel_inf(qg, d["vis_quats_grad"][idx]) < 1e-5
@@ -50,17 +55,18 @@ def test_known_answers_bundled():
     assert abs(fwd["mean_reward"] - 0.5291025) < 2e-6
 
 
-@pytest.mark.parametrize("name", ["pose_bundled_nohpr", "pose_bundled_hpr", "pose_bundled_tilted", "pose_synth_10k_hpr"])
+@pytest.mark.parametrize("name", ["pose_bundled_nohpr", "pose_bundled_hpr", "pose_bundled_tilted", "pose_synth_10k_hpr",
+                                  "pose_synth_clip"])
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 def test_pose(name, prec):
     d = load_golden(name)
     mask = None
     if bool(d["hpr"]):
         mask = oracle.hidden_pts_removal(d["points"])[1]
-    obs, loss = oracle.pose_forward(d["points"], d["trans0"], d["q0"], K, IW, IH, mask=mask, prec=prec)
+    obs, loss = oracle.pose_forward(d["points"], d["trans0"], d["q0"], K, IW, IH, mask=mask, prec=prec, **_clip(d))
     np.testing.assert_allclose(obs, d["observations"], rtol=3e-5, atol=1e-9)
     assert abs(loss - float(d["loss"])) <= 3e-6 * float(d["loss"])
-    tg, qg = oracle.pose_backward(d["points"], d["trans0"], d["q0"], K, IW, IH, loss, mask=mask, prec=prec)
+    tg, qg = oracle.pose_backward(d["points"], d["trans0"], d["q0"], K, IW, IH, loss, mask=mask, prec=prec, **_clip(d))
     assert rel_inf(tg, d["trans_grad"]) < 1e-5
     assert rel_inf(qg, d["quat_grad"]) < 1e-5
 
