@@ -36,7 +36,11 @@ def _worker(rank, world, port, n_pts, n_wps, out_dir):
     lo, hi = shard.bounds(n_wps)
     # local forward (stand-in for tohip_traj_forward): partial log-odds of this rank's waypoints
     f = oracle.traj_forward(pts, poses[lo:hi], quats[lo:hi], K, iw, ih, prec="f64")
-    lo_sum = shard.allreduce_sum(torch.from_numpy(f["lo_sum"].copy()))            # the one data-path collective
+    lo_sum = torch.from_numpy(f["lo_sum"].copy())
+    pending = shard.allreduce_sum_async(lo_sum)                                     # the one data-path collective, started ...
+    overlapped = float(np.square(poses[lo:hi]).sum())                               # ... independent work in between (bench: the scan)
+    pending.wait()
+    assert overlapped >= 0.0
     rewards = 1.0 / (1.0 + torch.exp(-lo_sum))
     mean = rewards.mean().item()
     fwd = dict(rewards=rewards.numpy(), mean_reward=mean)
