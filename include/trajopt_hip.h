@@ -67,7 +67,7 @@ const char *tohip_error_string(int code);
  * The cloud is constant over an optimisation run (model.py:80,174), so it is packed once into an opaque
  * device blob of tohip_packed_cloud_bytes(N) bytes: the points in Morton order as x[Npad] | y[Npad] |
  * z[Npad] (Npad = tohip_padded_points(N); the pad repeats the last sorted point), the permutation back to
- * the caller's order, and one bounding sphere per 256 sorted points.  sort = 0 keeps the caller's order
+ * the caller's order and its inverse, and one bounding sphere per 256 sorted points.  sort = 0 keeps the caller's order
  * (no spatial coherence: the exact culling then rarely fires).  Needs tohip_pack_workspace_bytes(N)
  * bytes of scratch. */
 int64_t tohip_padded_points(int64_t n_points);

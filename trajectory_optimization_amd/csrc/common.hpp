@@ -73,16 +73,17 @@ struct CloudView {
     const float* soa;       // x | y | z, npad each, sorted order, pads repeat the last sorted point
     const int* perm;        // sorted position -> original index (-1 for pads)
     const float4* bounds;   // per 256 sorted points: bounding-sphere centre xyz, radius (conservative)
+    const int* inv;         // original index -> sorted position (n entries)
     int64_t npad;
     int64_t n;
 };
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Packed cloud blob (tohip_pack_cloud): [x|y|z f32, 3*npad] [perm i32, npad] [bounds float4, npad/256]
+// Packed cloud blob (tohip_pack_cloud): [x|y|z f32, 3*npad] [perm i32, npad] [bounds float4, npad/256] [inv i32, npad]
 static inline size_t packed_cloud_bytes(int64_t n) {
     const int64_t npad = tohip_padded_points(n);
-    return (size_t)npad * 16 + (size_t)(npad / 256) * 16;
+    return (size_t)npad * 16 + (size_t)(npad / 256) * 16 + (size_t)npad * 4;
 }
 static inline CloudView cloud_view(const void* packed, int64_t n) {
     CloudView cv;
@@ -91,6 +92,7 @@ static inline CloudView cloud_view(const void* packed, int64_t n) {
     cv.soa = (const float*)packed;
     cv.perm = (const int*)((const char*)packed + (size_t)cv.npad * 12);
     cv.bounds = (const float4*)((const char*)packed + (size_t)cv.npad * 16);
+    cv.inv = (const int*)((const char*)packed + (size_t)cv.npad * 16 + (size_t)(cv.npad / 256) * 16);
     return cv;
 }
 

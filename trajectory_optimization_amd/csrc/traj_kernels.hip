@@ -468,16 +468,18 @@ k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, 
 // visibility loss (model.py:246)
 
 __global__ void __launch_bounds__(TO_BLOCK)
-k_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, int64_t n, float* __restrict__ rewards,
+k_reward(const float* __restrict__ lo_sum, const int* __restrict__ inv, int64_t n, float* __restrict__ rewards,
          double* __restrict__ part) {
     __shared__ double lds[TO_BLOCK];
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
-        const float lo = lo_sum[i];
+    // thread per OUTPUT element (the caller's order): a scattered 4-byte read of lo_sum and a coalesced store, rather
+    // than a coalesced read and a scattered store
+    for (int64_t o = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; o < n; o += stride) {
+        const float lo = lo_sum[inv[o]];
         float r = to_rcp(1.0f + to_exp(-lo));
         if (lo != lo) r = lo;  // a degenerate waypoint (max == min) makes the reference's rewards NaN: propagate
-        rewards[perm[i]] = r;
+        rewards[o] = r;
         s += (double)r;
     }
     const double tot = block_sum_double(s, lds);
@@ -1118,7 +1120,7 @@ extern "C" int tohip_traj_reward(const void* packed, const float* lo_sum, int64_
     int nb = (int)((n + TO_BLOCK - 1) / TO_BLOCK);
     if (nb > 2048) nb = 2048;
     TO_PROF(TOHIP_PROF_REWARD, st);
-    k_reward<<<nb, TO_BLOCK, 0, st>>>(lo_sum, cv.perm, n, rewards, rpart);
+    k_reward<<<nb, TO_BLOCK, 0, st>>>(lo_sum, cv.inv, n, rewards, rpart);
     TO_HIP_CHECK_LAUNCH();
     k_reward_finish<<<1, TO_BLOCK, 0, st>>>(rpart, nb, n, eps, scalars);
     TO_HIP_CHECK_LAUNCH();

@@ -43,6 +43,8 @@ class PackedCloud:
         # views into the blob (for tests / debugging): sorted x|y|z and the permutation to the caller's order
         self.soa = self.blob[:12 * self.npad].view(torch.float32)
         self.perm = self.blob[12 * self.npad:16 * self.npad].view(torch.int32)
+        inv0 = 16 * self.npad + 16 * (self.npad // 256)
+        self.inv_perm = self.blob[inv0:inv0 + 4 * self.n].view(torch.int32)  # caller's index -> sorted position
 
 
 class Camera:
@@ -170,10 +172,6 @@ def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method=
     centre, or the z-buffer splat for method="zbuffer") turned into the bit layout the kernels read."""
     L = _lib.lib()
     dev = cloud.device
-    if not hasattr(cloud, "inv_perm"):
-        cloud.inv_perm = torch.empty(cloud.n, dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
-            check(L.tohip_inverse_permutation(ptr(cloud.blob), cloud.n, ptr(cloud.inv_perm), stream_ptr()), "inverse_perm")
     W = poses.shape[0]
     rows = torch.empty((W, cloud.npad // 32), dtype=torch.int32, device=dev)
     n = cloud.n
