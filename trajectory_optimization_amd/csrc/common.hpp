@@ -383,16 +383,18 @@ __device__ __forceinline__ float wave_max63_nn(float f) {
     return __builtin_bit_cast(float, v);
 }
 
-// block-wide double sum through LDS (fixed order -> deterministic); result valid in thread 0
-__device__ __forceinline__ double block_sum_double(double v, double* lds /* TO_BLOCK doubles */) {
-    const int t = threadIdx.x;
-    lds[t] = v;
+// block-wide double sum (fixed order -> deterministic), valid in every thread: a butterfly inside each wave, then the
+// waves' totals through LDS — two barriers instead of the nine of a tree over all 256 threads (the finishing kernels call
+// this up to 14 times in a row and were bound by the barriers).
+__device__ __forceinline__ double block_sum_double(double v, double* lds /* >= one double per wave */) {
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+    __syncthreads();  // a previous call's totals may still be being read
+    if (lane == 0) lds[wave] = v;
     __syncthreads();
-    for (int s = TO_BLOCK / 2; s > 0; s >>= 1) {
-        if (t < s) lds[t] += lds[t + s];
-        __syncthreads();
-    }
-    return lds[0];
+    double r = 0.0;
+    for (int w = 0; w < nwaves; ++w) r += lds[w];
+    return r;
 }
 
 // Rotation matrix (row-major R, camera->world) from a quaternion, homogeneous quadratic form.
