@@ -315,25 +315,23 @@ k_traj_pass1(CloudView cv, const WayHot* __restrict__ hot, const WayAux* __restr
 
 // block per virtual waypoint: a = min, M = max - a (== max(p - a): rounding is monotone), cull bound of
 // the active set {p_hat > 0.5} = {p > a + M/2}
-__global__ void __launch_bounds__(TO_BLOCK)
+__global__ void __launch_bounds__(1024)
 k_minmax_finish(const float2* __restrict__ part, int nslots, WayHot* __restrict__ hot, WayAux* __restrict__ aux,
                 float inv_var, int cull, float* __restrict__ minmax) {
-    __shared__ float smn[TO_BLOCK], smx[TO_BLOCK];
-    const int v = blockIdx.x, t = threadIdx.x;
+    __shared__ float smn[16], smx[16];
+    const int v = blockIdx.x, t = threadIdx.x, nthreads = blockDim.x;
     float mn = INFINITY, mx = -INFINITY;
-    for (int s = t; s < nslots; s += TO_BLOCK) {
+    for (int s = t; s < nslots; s += nthreads) {
         const float2 q = part[(int64_t)v * nslots + s];
         mn = fminf(mn, q.x);
         mx = fmaxf(mx, q.y);
     }
-    smn[t] = mn; smx[t] = mx;
+    for (int s = 32; s > 0; s >>= 1) { mn = fminf(mn, __shfl_xor(mn, s)); mx = fmaxf(mx, __shfl_xor(mx, s)); }
+    if ((t & 63) == 0) { smn[t >> 6] = mn; smx[t >> 6] = mx; }
     __syncthreads();
-    for (int s = TO_BLOCK / 2; s > 0; s >>= 1) {
-        if (t < s) { smn[t] = fminf(smn[t], smn[t + s]); smx[t] = fmaxf(smx[t], smx[t + s]); }
-        __syncthreads();
-    }
     if (t == 0) {
         float a = smn[0], pmax = smx[0];
+        for (int w = 1; w < (nthreads + 63) / 64; ++w) { a = fminf(a, smn[w]); pmax = fmaxf(pmax, smx[w]); }
         if (cull) pmax = fmaxf(pmax, aux[v].L);  // L is an attained value of p (defensive: it is never skipped)
         const float M = pmax - a;
         hot[v].a = a;
@@ -853,7 +851,8 @@ __global__ void k_bwd_finish2(const float* __restrict__ vgrad, const WayHot* __r
 // write vgrad[v*12 ..] = (sum dL/dc [3], sum y (x) dL/dc [9]).  In CULL mode a partial exists only where the
 // (tile, waypoint) pair is live — the same predicate, on the same records, as k_traj_bwd evaluated; in dense mode where
 // k_traj_bwd recorded one in tmask.
-__global__ void __launch_bounds__(TO_BLOCK)
+#define TO_FINISH_THREADS 256  // (1024 threads measured slower: 19 vs 16 us — the 14 block sums then cross 16 waves)
+__global__ void __launch_bounds__(TO_FINISH_THREADS)
 k_bwd_finish1(const float* __restrict__ part, int nslots, int slots_per_tile_shift, const float* __restrict__ ties,
               const WayHot* __restrict__ hot, const float4* __restrict__ bounds, float mean, int cull,
               const unsigned long long* __restrict__ tmask, float* __restrict__ vgrad,
@@ -867,11 +866,11 @@ k_bwd_finish1(const float* __restrict__ part, int nslots, int slots_per_tile_shi
     for (int k = 0; k < TO_BWD_NSUM; ++k) s[k] = 0.0;
     // four slots per trip: their liveness loads are issued together (the loop is a chain of dependent loads otherwise);
     // the partials are still added in increasing slot order
-    for (int sl0 = t; sl0 < nslots; sl0 += 4 * TO_BLOCK) {
+    for (int sl0 = t; sl0 < nslots; sl0 += 4 * TO_FINISH_THREADS) {
         bool live[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int sl = sl0 + j * TO_BLOCK;
+            const int sl = sl0 + j * TO_FINISH_THREADS;
             live[j] = false;
             if (sl < nslots) {
                 if (cull) {
@@ -886,7 +885,7 @@ k_bwd_finish1(const float* __restrict__ part, int nslots, int slots_per_tile_shi
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (!live[j]) continue;
-            const int sl = sl0 + j * TO_BLOCK;
+            const int sl = sl0 + j * TO_FINISH_THREADS;
             const float4* src = reinterpret_cast<const float4*>(part + ((int64_t)v * nslots + sl) * 16);
             const float4 a = src[0], b = src[1], c = src[2], d = src[3];
             s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
@@ -1093,7 +1092,7 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
     TO_HIP_CHECK_LAUNCH();
     {
         TO_PROF(TOHIP_PROF_SMALL, st);
-        k_minmax_finish<<<(int)V, TO_BLOCK, 0, st>>>(mm, pl.nslots, hot, aux, cc.inv_var, cull ? 1 : 0, minmax);
+        k_minmax_finish<<<(int)V, 1024, 0, st>>>(mm, pl.nslots, hot, aux, cc.inv_var, cull ? 1 : 0, minmax);
     }
     TO_HIP_CHECK_LAUNCH();
     TO_PROF(TOHIP_PROF_PASS2, st);
@@ -1239,7 +1238,7 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* p
     TO_PROF(TOHIP_PROF_SMALL, st);
     const int shift = pl.P == 4 ? 0 : (pl.P == 2 ? 1 : 2);
     const bool single = C == 1 && rq == nullptr;
-    k_bwd_finish1<<<(int)V, TO_BLOCK, 0, st>>>(bpart, pl.nslots, shift, ties, hot, cv.bounds, cc.mean, cull ? 1 : 0, tmask, vgrad,
+    k_bwd_finish1<<<(int)V, TO_FINISH_THREADS, 0, st>>>(bpart, pl.nslots, shift, ties, hot, cv.bounds, cc.mean, cull ? 1 : 0, tmask, vgrad,
                                                cold, single ? 1 : 0, poses_grad, quats_grad);
     TO_HIP_CHECK_LAUNCH();
     if (!single) {
