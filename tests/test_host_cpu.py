@@ -95,3 +95,17 @@ def test_sample_npz_format(tmp_path):
     samples.save_result(tmp_path / "r.npz", poses, np.tile([[1, 0, 0, 0]], (7, 1)), rewards=np.ones(50), log={"visibility": [1.0, 1.1]})
     r = np.load(tmp_path / "r.npz")
     assert set(r.files) == {"poses", "quats_wxyz", "rewards", "log_visibility"}
+
+
+def test_denormalize_like_reference():
+    """tools.denormalize (tools.py:190-196): percentile stretch, numpy and torch inputs agree."""
+    from trajectory_optimization_amd.tools import denormalize
+    rng = np.random.default_rng(1)
+    img = rng.normal(size=(40, 30, 3)).astype(np.float32) * 5 + 2
+    a = denormalize(img)
+    x_max, x_min = np.percentile(img, 98), np.percentile(img, 2)
+    np.testing.assert_allclose(a, ((img - x_min) / max(x_max - x_min, 1e-6)).clip(0, 1), rtol=0, atol=0)
+    b = denormalize(torch.from_numpy(img)).numpy()
+    np.testing.assert_allclose(a, b, atol=2e-6)
+    assert a.min() == 0.0 and a.max() == 1.0
+    assert np.all(denormalize(np.zeros((4, 4), np.float32)) == 0.0)  # flat image: eps keeps it finite

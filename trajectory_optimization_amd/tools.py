@@ -74,6 +74,18 @@ def zbuffer_visible_points(verts, K, height, width, znear=1.0, zfar=10.0, radius
     return torch.nonzero(owns).squeeze(1).to(torch.int32)
 
 
+def denormalize(x, eps=1e-6):
+    """/root/reference/src/tools.py:190-196: scale an image to 0..1 between its 2nd and 98th percentiles (for display).
+    Accepts a numpy array or a tensor; returns the same kind."""
+    if torch.is_tensor(x):
+        flat = x.detach().to(torch.float32).flatten()
+        hi, lo = torch.quantile(flat, 0.98), torch.quantile(flat, 0.02)
+        return ((x - lo) / torch.clamp(hi - lo, min=eps)).clamp(0, 1)
+    import numpy as np
+    x_max, x_min = np.percentile(x, 98), np.percentile(x, 2)
+    return ((x - x_min) / np.max([(x_max - x_min), eps])).clip(0, 1)
+
+
 def ego_to_cam(points, trans, quat):
     """/root/reference/src/pc_processor.py:63-70: (N,3) ego-frame points -> (3,N) camera frame; the
     quaternion is NOT normalised there, and is not here."""
