@@ -104,7 +104,7 @@ def test_denormalize_like_reference():
     img = rng.normal(size=(40, 30, 3)).astype(np.float32) * 5 + 2
     a = denormalize(img)
     x_max, x_min = np.percentile(img, 98), np.percentile(img, 2)
-    np.testing.assert_allclose(a, ((img - x_min) / max(x_max - x_min, 1e-6)).clip(0, 1), rtol=0, atol=0)
+    np.testing.assert_allclose(a, ((img - x_min) / max(x_max - x_min, 1e-6)).clip(0, 1), rtol=0, atol=1e-7)
     b = denormalize(torch.from_numpy(img)).numpy()
     np.testing.assert_allclose(a, b, atol=2e-6)
     assert a.min() == 0.0 and a.max() == 1.0
