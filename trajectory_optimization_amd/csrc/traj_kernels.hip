@@ -36,13 +36,11 @@
 // where there were three.
 __device__ __forceinline__ void apply_minmax(WayHot& h, float& auxM, float a, float M, float inv_var, int cull);
 
-__global__ void k_prep_waycams(const float* __restrict__ poses, const float* __restrict__ quats, int W, int C,
-                               const float* __restrict__ rig_q, const float* __restrict__ rig_t,
-                               WayHot* __restrict__ hot, WayCold* __restrict__ cold, WayAux* __restrict__ aux,
-                               const float* __restrict__ minmax = nullptr, float inv_var = 0.f, int cull = 0,
-                               float* __restrict__ ties = nullptr) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= W * C) return;
+__device__ __forceinline__ void prep_waycam(int v, const float* __restrict__ poses, const float* __restrict__ quats, int C,
+                                            const float* __restrict__ rig_q, const float* __restrict__ rig_t,
+                                            WayHot* __restrict__ hot, WayCold* __restrict__ cold, WayAux* __restrict__ aux,
+                                            const float* __restrict__ minmax, float inv_var, int cull,
+                                            float* __restrict__ ties) {
     const int w = v / C, c = v - w * C;
     float q[4] = {quats[4 * w], quats[4 * w + 1], quats[4 * w + 2], quats[4 * w + 3]};
     float ss = q[0] * q[0];
@@ -93,6 +91,15 @@ __global__ void k_prep_waycams(const float* __restrict__ poses, const float* __r
         float4* tz = reinterpret_cast<float4*>(ties + (int64_t)v * 32);
         for (int i = 0; i < 8; ++i) tz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+}
+
+__global__ void k_prep_waycams(const float* __restrict__ poses, const float* __restrict__ quats, int W, int C,
+                               const float* __restrict__ rig_q, const float* __restrict__ rig_t,
+                               WayHot* __restrict__ hot, WayCold* __restrict__ cold, WayAux* __restrict__ aux,
+                               const float* __restrict__ minmax = nullptr, float inv_var = 0.f, int cull = 0,
+                               float* __restrict__ ties = nullptr) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < W * C) prep_waycam(v, poses, quats, C, rig_q, rig_t, hot, cold, aux, minmax, inv_var, cull, ties);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -199,17 +206,24 @@ __device__ __forceinline__ unsigned long long tile_survivors(const WayHot* __res
 //   L     = max p over the sample  (a lower bound of the true max: an actual value of p)
 //   azero = some sample has p == 0 exactly  =>  min_n p == 0 (p is never negative)
 
+// The block first builds its waypoint's record itself (k_prep_waycams' work: one launch less on the forward), and it is
+// 1024 threads wide: the samples are scattered single loads, so the kernel is as long as one thread's chain of them.
+#define TO_PROBE_THREADS 1024
 template <bool PINHOLE>
-__global__ void __launch_bounds__(TO_BLOCK)
-k_traj_probe(CloudView cv, const WayHot* __restrict__ hot, WayAux* __restrict__ aux, CamConsts cc, int step,
+__global__ void __launch_bounds__(TO_PROBE_THREADS)
+k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restrict__ quats, int C,
+             const float* __restrict__ rig_q, const float* __restrict__ rig_t, WayHot* __restrict__ hot,
+             WayCold* __restrict__ cold, WayAux* __restrict__ aux, CamConsts cc, int step,
              const uint32_t* __restrict__ occ, int64_t occw) {
-    __shared__ float smx[TO_BLOCK];
-    __shared__ int szero[TO_BLOCK];
+    __shared__ float smx[TO_PROBE_THREADS / 64];
+    __shared__ int szero[TO_PROBE_THREADS / 64];
     const int v = blockIdx.x, t = threadIdx.x;
+    if (t == 0) prep_waycam(v, poses, quats, C, rig_q, rig_t, hot, cold, aux, nullptr, 0.f, 0, nullptr);
+    __syncthreads();
     const WayHot h = hot[v];
     float mx = 0.f;
     int zero = 0;
-    for (int64_t i = (int64_t)t * step; i < cv.n; i += (int64_t)TO_BLOCK * step) {
+    for (int64_t i = (int64_t)t * step; i < cv.n; i += (int64_t)TO_PROBE_THREADS * step) {
         float X, Y, Z, y0, y1, y2;
         to_cam(h, cv.soa[i], cv.soa[cv.npad + i], cv.soa[2 * cv.npad + i], X, Y, Z, y0, y1, y2);
         float om[1];
@@ -218,16 +232,14 @@ k_traj_probe(CloudView cv, const WayHot* __restrict__ hot, WayAux* __restrict__ 
         mx = fmaxf(mx, p);
         zero |= (p == 0.f);
     }
-    smx[t] = mx; szero[t] = zero;
+    for (int s = 32; s > 0; s >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, s)); zero |= __shfl_xor(zero, s); }
+    if ((t & 63) == 0) { smx[t >> 6] = mx; szero[t >> 6] = zero; }
     __syncthreads();
-    for (int s = TO_BLOCK / 2; s > 0; s >>= 1) {
-        if (t < s) { smx[t] = fmaxf(smx[t], smx[t + s]); szero[t] |= szero[t + s]; }
-        __syncthreads();
-    }
     if (t == 0) {
+        for (int w = 1; w < TO_PROBE_THREADS / 64; ++w) { mx = fmaxf(mx, smx[w]); zero |= szero[w]; }
         WayAux a = aux[v];
-        a.L = smx[0];
-        a.azero = szero[0] ? 1.f : 0.f;
+        a.L = mx;
+        a.azero = zero ? 1.f : 0.f;
         cull_threshold(a.L, cc.inv_var, &a.thr1, &a.sthr1);
         aux[v] = a;
     }
@@ -1069,15 +1081,19 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
 
     {
         TO_PROF(TOHIP_PROF_SMALL, st);
-        k_prep_waycams<<<(int)((V + 127) / 128), 128, 0, st>>>(poses, quats, (int)W, C, rq, rt, hot, cold, aux);
-        TO_HIP_CHECK_LAUNCH();
         if (cull) {
             int step = (int)(n / 4096);
             if (step < 1) step = 1;
-            if (cc.pinhole) k_traj_probe<true><<<(int)V, TO_BLOCK, 0, st>>>(cv, hot, aux, cc, step, occlusion_bits, cv.npad / 32);
-            else k_traj_probe<false><<<(int)V, TO_BLOCK, 0, st>>>(cv, hot, aux, cc, step, occlusion_bits, cv.npad / 32);
-            TO_HIP_CHECK_LAUNCH();
+            if (cc.pinhole)
+                k_traj_probe<true><<<(int)V, TO_PROBE_THREADS, 0, st>>>(cv, poses, quats, C, rq, rt, hot, cold, aux, cc, step,
+                                                                        occlusion_bits, cv.npad / 32);
+            else
+                k_traj_probe<false><<<(int)V, TO_PROBE_THREADS, 0, st>>>(cv, poses, quats, C, rq, rt, hot, cold, aux, cc, step,
+                                                                         occlusion_bits, cv.npad / 32);
+        } else {
+            k_prep_waycams<<<(int)((V + 127) / 128), 128, 0, st>>>(poses, quats, (int)W, C, rq, rt, hot, cold, aux);
         }
+        TO_HIP_CHECK_LAUNCH();
     }
     int vtile, ntiles;
     choose_tiles(pl.nblk, (int)V, cull, &vtile, &ntiles);
