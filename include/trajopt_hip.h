@@ -230,6 +230,21 @@ int tohip_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
 int tohip_early_stop(const float *scalars, const float *loss_terms, float rewards_th, float smoothness_th, float *state,
                      int row_from_state, void *stream);
 
+/* The same step remainder in ONE launch (one block; W up to a few thousand): scatter of the evaluated waypoints'
+ * visibility gradients (rows r -> waypoint r*step, zero elsewhere) into poses_grad (W,3) / quats_grad (W,4), criterion
+ * regularisers and their gradient on top, both Adam updates (step index state[3]+1, skipped once stopped), the loss log
+ * row state[3] and the early-stop rule.  Equivalent to tohip_rows_strided x2 + tohip_traj_regularizers +
+ * tohip_adam_step x2 + tohip_early_stop with `state`. */
+int tohip_traj_step_tail(float *poses, float *quats, const float *poses0, int64_t n_wps, const float *poses_grad_eval,
+                         const float *quats_grad_eval, int64_t n_eval, int step, float *poses_grad, float *quats_grad,
+                         float *exp_avg_p, float *exp_avg_sq_p, float *exp_avg_q, float *exp_avg_sq_q,
+                         float smoothness_weight, float traj_length_weight, float eps, float lr_pose, float lr_quat,
+                         float beta1, float beta2, float adam_eps, float rewards_th, float smoothness_th,
+                         const float *scalars, float *loss_terms, float *state, void *stream);
+/* poses_e[r] = poses[r*step], quats_e[r] = quats[r*step] for r < n_eval, in one launch. */
+int tohip_gather_waypoints(const float *poses, const float *quats, int64_t n_eval, int step, float *poses_e, float *quats_e,
+                           void *stream);
+
 /* ---- input formats (pointcloud_utils.py, launch/voxels_filtering.launch) --------------------------------
  * PointCloud2 payload -> (N,3) f32 with non-finite rows removed, in message order
  * (pointcloud2_to_xyz_array, pointcloud_utils.py:197-198, + the callers' cast to f32).  data: the message's

@@ -34,8 +34,15 @@ def _worker(rank, world, port, out_dir):
                   synth.IMG_WIDTH, synth.IMG_HEIGHT, device=device, shard=WaypointShard())
     loss = m(vis_wps_dist=0.0)
     loss.backward()
+    # the launch-only optimiser on the sharded model: local forward/backward rows, all-reduced log-odds and gradient rows,
+    # replicated step remainder
+    from trajectory_optimization_amd.optimizer import optimize_trajectory
+    m2 = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(synth.K_INTRINS),
+                   synth.IMG_WIDTH, synth.IMG_HEIGHT, device=device, shard=WaypointShard())
+    res = optimize_trajectory(m2, n_opt_steps=4, lr_pose=0.05, lr_quat=0.01, rewards_th=1e9, vis_wps_dist=0.0)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=loss.item(), rewards=m.rewards.detach().cpu().numpy(),
-             pg=m.poses.grad.cpu().numpy(), qg=m.quats.grad.cpu().numpy())
+             pg=m.poses.grad.cpu().numpy(), qg=m.quats.grad.cpu().numpy(), opt_poses=m2.poses.detach().cpu().numpy(),
+             opt_quats=m2.quats.detach().cpu().numpy(), opt_losses=np.asarray(res.losses))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -47,7 +54,7 @@ def test_sharded_model_equals_single_process(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in range(world))
-    for k in ("loss", "rewards", "pg", "qg"):
+    for k in ("loss", "rewards", "pg", "qg", "opt_poses", "opt_quats", "opt_losses"):
         assert np.array_equal(r0[k], r1[k]), k  # replicated state identical on both ranks
     dev = torch.device("cuda:0")
     pts = synth.make_cloud(60_000, seed=9)
@@ -62,3 +69,10 @@ def test_sharded_model_equals_single_process(tmp_path):
     pg, qg = m.poses.grad.cpu().numpy(), m.quats.grad.cpu().numpy()
     assert np.abs(r0["pg"] - pg).max() <= 2e-5 * np.abs(pg).max()
     assert np.abs(r0["qg"] - qg).max() <= 2e-5 * np.abs(qg).max()
+    from trajectory_optimization_amd.optimizer import optimize_trajectory
+    m2 = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(synth.K_INTRINS),
+                   synth.IMG_WIDTH, synth.IMG_HEIGHT, device=dev)
+    res = optimize_trajectory(m2, n_opt_steps=4, lr_pose=0.05, lr_quat=0.01, rewards_th=1e9, vis_wps_dist=0.0)
+    np.testing.assert_allclose(r0["opt_losses"], res.losses, rtol=2e-5)
+    np.testing.assert_allclose(r0["opt_poses"], m2.poses.detach().cpu().numpy(), atol=2e-4)
+    np.testing.assert_allclose(r0["opt_quats"], m2.quats.detach().cpu().numpy(), atol=2e-4)

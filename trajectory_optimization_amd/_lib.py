@@ -71,6 +71,9 @@ SIGNATURES = {
                                                    c_vp]),
     "tohip_traj_regularizers": (ctypes.c_int, [c_vp, c_vp, c_i64, c_f, c_f, c_f, c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_vp,
                                                 c_vp]),
+    "tohip_traj_step_tail": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                             c_vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_vp, c_vp, c_vp]),
+    "tohip_gather_waypoints": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_vp]),
     "tohip_rows_strided": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     "tohip_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_i32, c_vp, c_vp]),
     "tohip_early_stop": (ctypes.c_int, [c_vp, c_vp, c_f, c_f, c_vp, ctypes.c_int, c_vp]),

@@ -15,15 +15,14 @@
 
 // loss_terms[0..4] = vis, l2, length, smooth, total.  grad_poses (W,3) receives the regularisers' gradient
 // ADDED to what the visibility backward wrote (pass accumulate = 1), scaled by gout (dL/d total = 1).
-__global__ void __launch_bounds__(TO_BLOCK)
-k_traj_regularizers(const float* __restrict__ poses, const float* __restrict__ poses0, int W, float smooth_w,
-                    float length_w, float eps, const float* __restrict__ scalars /* [1] = loss_vis */,
-                    float* __restrict__ loss_terms, float* __restrict__ grad_poses, int accumulate,
-                    const float* __restrict__ state /* may be NULL; else loss row = state[3] (steps taken so far) */,
-                    float* __restrict__ grad_terms /* may be NULL; else (3, W, 3): d l2, d length, d smooth separately */) {
+__device__ __forceinline__ void
+regularizers_block(const float* __restrict__ poses, const float* __restrict__ poses0, int W, float smooth_w,
+                   float length_w, float eps, const float* __restrict__ scalars /* [1] = loss_vis */,
+                   float* __restrict__ loss_terms, float* __restrict__ grad_poses, int accumulate,
+                   const float* __restrict__ state /* may be NULL; else loss row = state[3] (steps taken so far) */,
+                   float* __restrict__ grad_terms /* may be NULL; else (3, W, 3): d l2, d length, d smooth separately */,
+                   double* lds /* TO_BLOCK doubles */, double* sh /* 4 doubles */) {
     if (state) loss_terms += 8 * (int)state[3];
-    __shared__ double lds[TO_BLOCK];
-    __shared__ double sh[4];
     const int t = threadIdx.x;
     auto P = [&](const float* a, int i, int k) { return (double)a[3 * i + k]; };
     // ---- forward sums -----------------------------------------------------------------------------
@@ -129,6 +128,17 @@ k_traj_regularizers(const float* __restrict__ poses, const float* __restrict__ p
     }
 }
 
+__global__ void __launch_bounds__(TO_BLOCK)
+k_traj_regularizers(const float* __restrict__ poses, const float* __restrict__ poses0, int W, float smooth_w,
+                    float length_w, float eps, const float* __restrict__ scalars, float* __restrict__ loss_terms,
+                    float* __restrict__ grad_poses, int accumulate, const float* __restrict__ state,
+                    float* __restrict__ grad_terms) {
+    __shared__ double lds[TO_BLOCK];
+    __shared__ double sh[4];
+    regularizers_block(poses, poses0, W, smooth_w, length_w, eps, scalars, loss_terms, grad_poses, accumulate, state,
+                       grad_terms, lds, sh);
+}
+
 // scatter the gradient rows of the evaluated waypoints (every wps_step-th) into full (W,3)/(W,4) arrays
 __global__ void k_scatter_rows(const float* __restrict__ src, int n_rows, int cols, int step, float* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -145,13 +155,19 @@ __global__ void k_gather_rows(const float* __restrict__ src, int n_rows, int col
 
 // torch.optim.Adam (defaults betas=(0.9,0.999), eps=1e-8, no weight decay / amsgrad), one call per parameter group.
 // No-op once state[2] (stopped) is set.  `t` = 1-based step index.
+__device__ __forceinline__ void adam_element(float* __restrict__ param, float g, float* __restrict__ m, float* __restrict__ v,
+                                             int i, float lr, float beta1, float beta2, float eps, int t);
+
 __global__ void k_adam(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
                        int n, float lr, float beta1, float beta2, float eps, int t, const float* __restrict__ state) {
     if (state && state[2] != 0.f) return;
     if (t <= 0) t = (int)state[3] + 1;  // step index kept on the device: the same launch can be replayed from a hipGraph
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float g = grad[i];
+    if (i < n) adam_element(param, grad[i], m, v, i, lr, beta1, beta2, eps, t);
+}
+
+__device__ __forceinline__ void adam_element(float* __restrict__ param, float g, float* __restrict__ m, float* __restrict__ v,
+                                             int i, float lr, float beta1, float beta2, float eps, int t) {
     const float mi = beta1 * m[i] + (1.0f - beta1) * g;      // exp_avg.lerp_(grad, 1 - beta1)
     const float vi = beta2 * v[i] + (1.0f - beta2) * g * g;   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     m[i] = mi; v[i] = vi;
@@ -162,9 +178,18 @@ __global__ void k_adam(float* __restrict__ param, const float* __restrict__ grad
 }
 
 // The reference's early-stop rule, evaluated after the step: gains relative to the first step's values.
+__device__ __forceinline__ void early_stop_rule(const float* __restrict__ scalars, const float* __restrict__ loss_terms,
+                                                float rewards_th, float smoothness_th, float* __restrict__ state,
+                                                int row_from_state);
+
 __global__ void k_early_stop(const float* __restrict__ scalars /* [0] = mean reward */, const float* __restrict__ loss_terms,
                              float rewards_th, float smoothness_th, float* __restrict__ state, int row_from_state) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x == 0 && blockIdx.x == 0) early_stop_rule(scalars, loss_terms, rewards_th, smoothness_th, state, row_from_state);
+}
+
+__device__ __forceinline__ void early_stop_rule(const float* __restrict__ scalars, const float* __restrict__ loss_terms,
+                                                float rewards_th, float smoothness_th, float* __restrict__ state,
+                                                int row_from_state) {
     if (row_from_state) loss_terms += 8 * (int)state[3];
     if (state[2] != 0.f) return;
     const float mean_r = scalars[0], smooth = loss_terms[3];  // loss_terms: this step's row
@@ -173,6 +198,88 @@ __global__ void k_early_stop(const float* __restrict__ scalars /* [0] = mean rew
     const float vg = mean_r / state[0], sg = state[1] / smooth;
     state[4] = vg; state[5] = sg;
     if (vg > rewards_th && sg > smoothness_th) state[2] = 1.f;
+}
+
+// One block does the whole O(W) remainder of an optimisation step (optimizer.optimize_trajectory): scatter of the
+// evaluated waypoints' visibility gradients into full (W,3)/(W,4) arrays, criterion regularisers + their gradient on top,
+// the two Adam updates, the early-stop rule — five launches and two memsets otherwise.  Every gradient is complete
+// before any parameter moves (the regularisers read their neighbours' positions).
+struct StepTail {
+    float *poses, *quats;
+    const float* poses0;
+    const float *pg_eval, *qg_eval;  // (n_eval, 3), (n_eval, 4): rows r -> waypoint r * step
+    float *pg, *qg;                  // (W, 3), (W, 4): full gradients (outputs)
+    float *mp, *vp, *mq, *vq;        // Adam moments
+    const float* scalars;
+    float* loss_terms;               // (n_steps, 8) log, row = state[3]
+    float* state;
+    int W, n_eval, step;
+    float smooth_w, length_w, eps, lr_pose, lr_quat, beta1, beta2, adam_eps, rewards_th, smoothness_th;
+};
+
+__global__ void __launch_bounds__(TO_BLOCK) k_traj_step_tail(StepTail a) {
+    __shared__ double lds[TO_BLOCK];
+    __shared__ double sh[4];
+    const int t = threadIdx.x;
+    for (int i = t; i < a.W * 3; i += TO_BLOCK) {
+        const int j = i / 3, k = i - 3 * j, r = j / a.step;
+        a.pg[i] = (j == r * a.step && r < a.n_eval) ? a.pg_eval[3 * r + k] : 0.f;
+    }
+    for (int i = t; i < a.W * 4; i += TO_BLOCK) {
+        const int j = i >> 2, k = i & 3, r = j / a.step;
+        a.qg[i] = (j == r * a.step && r < a.n_eval) ? a.qg_eval[4 * r + k] : 0.f;
+    }
+    __syncthreads();
+    regularizers_block(a.poses, a.poses0, a.W, a.smooth_w, a.length_w, a.eps, a.scalars, a.loss_terms, a.pg, 1, a.state,
+                       nullptr, lds, sh);
+    __syncthreads();
+    if (a.state[2] == 0.f) {  // not stopped yet (uniform)
+        const int step_idx = (int)a.state[3] + 1;
+        for (int i = t; i < a.W * 3; i += TO_BLOCK)
+            adam_element(a.poses, a.pg[i], a.mp, a.vp, i, a.lr_pose, a.beta1, a.beta2, a.adam_eps, step_idx);
+        for (int i = t; i < a.W * 4; i += TO_BLOCK)
+            adam_element(a.quats, a.qg[i], a.mq, a.vq, i, a.lr_quat, a.beta1, a.beta2, a.adam_eps, step_idx);
+    }
+    __syncthreads();
+    if (t == 0) early_stop_rule(a.scalars, a.loss_terms, a.rewards_th, a.smoothness_th, a.state, 1);
+}
+
+// poses_e[r] = poses[r * step], quats_e[r] = quats[r * step] in one launch (model.py:217's waypoint selection)
+__global__ void k_gather_waypoints(const float* __restrict__ poses, const float* __restrict__ quats, int n_eval, int step,
+                                   float* __restrict__ poses_e, float* __restrict__ quats_e) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_eval * 3) { const int r = i / 3, k = i - 3 * r; poses_e[i] = poses[(int64_t)r * step * 3 + k]; }
+    if (i < n_eval * 4) { const int r = i >> 2, k = i & 3; quats_e[i] = quats[(int64_t)r * step * 4 + k]; }
+}
+
+extern "C" int tohip_gather_waypoints(const float* poses, const float* quats, int64_t n_eval, int step, float* poses_e,
+                                      float* quats_e, void* stream_) {
+    if (!poses || !quats || !poses_e || !quats_e || n_eval <= 0 || step <= 0) return TOHIP_EINVAL;
+    const int n = (int)(n_eval * 4);
+    k_gather_waypoints<<<(n + 255) / 256, 256, 0, (hipStream_t)stream_>>>(poses, quats, (int)n_eval, step, poses_e, quats_e);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+extern "C" int tohip_traj_step_tail(float* poses, float* quats, const float* poses0, int64_t W, const float* poses_grad_eval,
+                                    const float* quats_grad_eval, int64_t n_eval, int step, float* poses_grad, float* quats_grad,
+                                    float* exp_avg_p, float* exp_avg_sq_p, float* exp_avg_q, float* exp_avg_sq_q,
+                                    float smoothness_weight, float traj_length_weight, float eps, float lr_pose, float lr_quat,
+                                    float beta1, float beta2, float adam_eps, float rewards_th, float smoothness_th,
+                                    const float* scalars, float* loss_terms, float* state, void* stream_) {
+    if (!poses || !quats || !poses0 || !poses_grad_eval || !quats_grad_eval || !poses_grad || !quats_grad || !exp_avg_p ||
+        !exp_avg_sq_p || !exp_avg_q || !exp_avg_sq_q || !scalars || !loss_terms || !state || W < 3 || n_eval <= 0 || step <= 0 ||
+        (n_eval - 1) * step >= W)
+        return TOHIP_EINVAL;
+    StepTail a;
+    a.poses = poses; a.quats = quats; a.poses0 = poses0; a.pg_eval = poses_grad_eval; a.qg_eval = quats_grad_eval;
+    a.pg = poses_grad; a.qg = quats_grad; a.mp = exp_avg_p; a.vp = exp_avg_sq_p; a.mq = exp_avg_q; a.vq = exp_avg_sq_q;
+    a.scalars = scalars; a.loss_terms = loss_terms; a.state = state; a.W = (int)W; a.n_eval = (int)n_eval; a.step = step;
+    a.smooth_w = smoothness_weight; a.length_w = traj_length_weight; a.eps = eps; a.lr_pose = lr_pose; a.lr_quat = lr_quat;
+    a.beta1 = beta1; a.beta2 = beta2; a.adam_eps = adam_eps; a.rewards_th = rewards_th; a.smoothness_th = smoothness_th;
+    k_traj_step_tail<<<1, TO_BLOCK, 0, (hipStream_t)stream_>>>(a);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
 }
 
 extern "C" int tohip_traj_regularizers(const float* poses, const float* poses0, int64_t W, float smoothness_weight,

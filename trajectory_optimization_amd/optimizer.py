@@ -26,7 +26,7 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
     """Runs up to n_opt_steps on `model` (a ModelTraj) in place; returns a TrajOptResult (one host sync, at the end).
     model.poses / model.quats hold the optimised trajectory, model.rewards the last rewards, model.loss the last terms.
 
-    use_graph: capture one iteration (≈20 launches, every per-step value read from device state) into a hipGraph and
+    use_graph: capture one iteration (≈11 launches, every per-step value read from device state) into a hipGraph and
     replay it n_opt_steps times (not with waypoint sharding, whose all-reduce stays outside a capture, nor with
     per-waypoint occlusion, whose hull construction syncs).  Measured on the reference's bundled cloud (40 452 points,
     14 evaluated waypoints, MI355X): eager launch-only loop 0.124 ms/step, graph replay 0.168 ms/step, the
@@ -38,13 +38,19 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
     W = model.poses.shape[0]
     step_w = model._wps_step(vis_wps_dist)
     n_eval = (W + step_w - 1) // step_w
-    ws = model._workspace(n_eval)
+    # waypoint sharding (one process per GPU): this rank evaluates rows [lo_e, hi_e) of the evaluated waypoints; the
+    # log-odds vector and the (n_eval, 7) gradient rows are all-reduced, everything else is replicated
+    lo_e, hi_e = model._shard.bounds(n_eval)
+    n_loc = hi_e - lo_e
+    ws = model._workspace(max(n_loc, 1))
     f32 = dict(dtype=torch.float32, device=dev)
     poses_e, quats_e = torch.empty((n_eval, 3), **f32), torch.empty((n_eval, 4), **f32)
+    g_e = torch.zeros((n_eval, 7), **f32)  # rows outside this rank's range stay zero
     pg_e, qg_e = torch.empty((n_eval, 3), **f32), torch.empty((n_eval, 4), **f32)
+    pg_loc, qg_loc = torch.empty((max(n_loc, 1), 3), **f32), torch.empty((max(n_loc, 1), 4), **f32)
     pg, qg = torch.zeros((W, 3), **f32), torch.zeros((W, 4), **f32)
     lo_sum = torch.empty(cloud.npad, **f32)
-    minmax = torch.empty((n_eval * (rig.n_cams if rig else 1), 2), **f32)
+    minmax = torch.empty((max(n_loc, 1) * (rig.n_cams if rig else 1), 2), **f32)
     rewards, scalars = torch.empty(cloud.n, **f32), torch.zeros(4, **f32)
     loss_terms = torch.zeros((n_opt_steps + 1, 8), **f32)
     state = torch.zeros(8, **f32)
@@ -58,35 +64,39 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
 
     def iteration():
         s = stream_ptr()
-        check(L.tohip_rows_strided(ptr(poses), n_eval, 3, step_w, 0, ptr(poses_e), s), "gather poses")
-        check(L.tohip_rows_strided(ptr(quats), n_eval, 4, step_w, 0, ptr(quats_e), s), "gather quats")
+        check(L.tohip_gather_waypoints(ptr(poses), ptr(quats), n_eval, step_w, ptr(poses_e), ptr(quats_e), s), "gather waypoints")
+        p_loc, q_loc = poses_e[lo_e:hi_e], quats_e[lo_e:hi_e]  # contiguous row ranges of the compact arrays
         occ = None
-        if occluded:
-            occ = ops.occlusion_bits(cloud, model.points, poses_e, quats_e, cam, model._occlusion_limits[0],
+        if occluded and n_loc > 0:
+            occ = ops.occlusion_bits(cloud, model.points, p_loc, q_loc, cam, model._occlusion_limits[0],
                                      model._occlusion_limits[1], model._occlusion)
-        check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), n_eval, cam.ref(), rig_ref,
-                                   model._flags, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(ws.buf), ws.bytes, s), "forward")
+        if n_loc > 0:
+            check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref,
+                                       model._flags, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(ws.buf), ws.bytes, s), "forward")
+        else:
+            lo_sum.zero_()
         model._shard.allreduce_sum(lo_sum)
         check(L.tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, ptr(rewards), ptr(scalars),
                                   ptr(ws.buf), ws.bytes, s), "reward")
-        check(L.tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), n_eval, cam.ref(), rig_ref,
-                                    model._flags, ptr(occ), ptr(lo_sum), None, ptr(scalars), ptr(minmax), ptr(gout),
-                                    None, ptr(pg_e), ptr(qg_e), ptr(ws.buf), ws.bytes, s), "backward")
-        if step_w > 1:
-            pg.zero_()
-            qg.zero_()
-        check(L.tohip_rows_strided(ptr(pg_e), n_eval, 3, step_w, 1, ptr(pg), s), "scatter poses grad")
-        check(L.tohip_rows_strided(ptr(qg_e), n_eval, 4, step_w, 1, ptr(qg), s), "scatter quats grad")
-        # every per-step quantity (loss-log row, Adam's step index) is read from `state` on the device
-        check(L.tohip_traj_regularizers(ptr(poses), ptr(model.poses0), W, float(model.smoothness_weight),
-                                        float(model.traj_length_weight), float(model.eps), ptr(scalars), ptr(loss_terms),
-                                        ptr(pg), 1, ptr(state), None, s), "regularizers")
-        check(L.tohip_adam_step(ptr(poses), ptr(pg), ptr(mp), ptr(vp), W * 3, float(lr_pose), betas[0], betas[1],
-                                adam_eps, 0, ptr(state), s), "adam poses")
-        check(L.tohip_adam_step(ptr(quats), ptr(qg), ptr(mq), ptr(vq), W * 4, float(lr_quat), betas[0], betas[1],
-                                adam_eps, 0, ptr(state), s), "adam quats")
-        check(L.tohip_early_stop(ptr(scalars), ptr(loss_terms), float(rewards_th), float(smoothness_th), ptr(state), 1, s),
-              "early stop")
+        tgt_p, tgt_q = (pg_loc, qg_loc) if sharded else (pg_e, qg_e)
+        if n_loc > 0:
+            check(L.tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref,
+                                        model._flags, ptr(occ), ptr(lo_sum), None, ptr(scalars), ptr(minmax), ptr(gout),
+                                        None, ptr(tgt_p), ptr(tgt_q), ptr(ws.buf), ws.bytes, s), "backward")
+        if sharded:
+            # assemble every rank's gradient rows: ONE (n_eval, 7) all-reduce, then the replicated remainder of the step
+            if n_loc > 0:
+                g_e[lo_e:hi_e, :3], g_e[lo_e:hi_e, 3:] = pg_loc, qg_loc
+            model._shard.allreduce_sum(g_e)
+            pg_e.copy_(g_e[:, :3])
+            qg_e.copy_(g_e[:, 3:])
+            g_e.zero_()  # the other ranks' rows must be zero again before the next sum
+        # the O(W) remainder of the step in one launch: scatter, regularisers, both Adam updates, early stop
+        check(L.tohip_traj_step_tail(ptr(poses), ptr(quats), ptr(model.poses0), W, ptr(pg_e), ptr(qg_e), n_eval, step_w,
+                                     ptr(pg), ptr(qg), ptr(mp), ptr(vp), ptr(mq), ptr(vq), float(model.smoothness_weight),
+                                     float(model.traj_length_weight), float(model.eps), float(lr_pose), float(lr_quat),
+                                     betas[0], betas[1], adam_eps, float(rewards_th), float(smoothness_th), ptr(scalars),
+                                     ptr(loss_terms), ptr(state), s), "step tail")
 
     with torch.cuda.device(dev):
         if use_graph and not sharded and not occluded and n_opt_steps > 1:
