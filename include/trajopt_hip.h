@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOHIP_ABI_VERSION 2
+#define TOHIP_ABI_VERSION 3
 
 #define TOHIP_OK 0
 #define TOHIP_EINVAL (-1)   /* bad size / null pointer */
@@ -92,7 +92,12 @@ size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual);
  * replaces model.py:217-231. */
 int tohip_traj_forward(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
                        const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits,
-                       float *lo_sum, float *minmax, void *workspace, size_t workspace_bytes, void *stream);
+                       float *lo_sum, float *minmax, void *need_mask_out, void *workspace, size_t workspace_bytes,
+                       void *stream);
+/* need_mask_out (may be NULL; else tohip_traj_need_mask_bytes bytes): the forward's second pass has p_hat of every pair
+ * it evaluates in hand and can record which (wave of points, waypoint) combinations will carry gradient — what
+ * tohip_traj_backward_scan would compute.  Hand it to tohip_traj_backward as need_mask (either mode; same poses, quats,
+ * flags, occlusion_bits): the backward then walks only those combinations.  Results are the same, bit for bit. */
 /* occlusion_bits (may be NULL = nothing occluded): per virtual waypoint a row of Npad/32 words, bit i = 1 when the
  * packed (sorted) point i is NOT occluded from that waypoint; an occluded pair has p = 0.  The per-waypoint
  * analogue of ModelPose's occlusion mask (model.py:112-115) that the reference leaves as a TODO (tools.py:61-62).
@@ -116,7 +121,7 @@ int tohip_traj_backward(const void *packed, int64_t n_points, const float *poses
                         const float *lo_sum, const float *grad_rewards, const float *scalars, const float *minmax, const float *gout,
                         const void *need_mask, float *poses_grad, float *quats_grad, void *workspace, size_t workspace_bytes,
                         void *stream);
-/* Split backward for the multi-GPU step (TOHIP_TRAJ_DENSE only).  Which (wave of points, waypoint) combinations hold a
+/* Split backward for the multi-GPU step (the scan is the dense mode's: TOHIP_TRAJ_DENSE).  Which (wave of points, waypoint) combinations hold a
  * pair with a non-zero gradient depends on p and the per-waypoint min/max alone, not on lo_sum: tohip_traj_backward_scan
  * evaluates every pair and records that (need_mask, tohip_traj_need_mask_bytes bytes) and can therefore run while lo_sum
  * is still being all-reduced; tohip_traj_backward with that need_mask then only walks the flagged combinations.  Same

@@ -420,3 +420,24 @@ def test_fused_adam_optimizer_equals_torch_adam(dev):
     # parameters of magnitude ~1 after 25 steps of size ~0.1: a few ulp (1.2e-7 each) of accumulated rounding
     np.testing.assert_allclose(runs[0][0].cpu().numpy(), runs[1][0].cpu().numpy(), rtol=2e-6, atol=1e-6)
     np.testing.assert_allclose(runs[0][1].cpu().numpy(), runs[1][1].cpu().numpy(), rtol=2e-6, atol=1e-6)
+
+
+def test_dense_model_uses_the_forwards_record(dev):
+    """ModelTraj(dense=True) hands the forward's need mask to the backward; results equal the default (culled) model's
+    to the bit, through the fused node and through the rewards node."""
+    from trajectory_optimization_amd.model import ModelTraj
+    pts = synth.make_cloud(150_000, seed=7)
+    poses, quats = synth.make_path(10, optical=True, jitter_seed=5)
+    out = []
+    for dense in (False, True):
+        for fused in (True, False):
+            m = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(K), IW, IH,
+                          device=dev, dense=dense)
+            m.fused_loss = fused
+            loss = m(vis_wps_dist=0.0)
+            loss.backward()
+            out.append((loss.detach().clone(), m.rewards.detach().clone(), m.poses.grad.clone(), m.quats.grad.clone()))
+    for fused_idx in (0, 1):
+        a, b = out[fused_idx], out[2 + fused_idx]
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)

@@ -257,3 +257,38 @@ def test_split_backward_is_bitwise_the_fused_one(dev, n, w, cams, occ):
     from trajectory_optimization_amd import _lib
     with pytest.raises(_lib.HipError):  # the split belongs to the dense mode
         ops.traj_backward_scan(cloud, p, q, cam, ws, minmax, rig=rg, flags=0, occ=bits)
+
+
+@pytest.mark.parametrize("n,w,cams,occ", [(1_000_000, 24, 1, False), (200_000, 70, 1, True), (60_000, 9, 3, False), (3000, 5, 1, False),
+                                         (300_000, 130, 1, False)])
+@pytest.mark.parametrize("dense", [False, True])
+def test_backward_with_the_forwards_need_mask_is_bitwise_the_same(dev, n, w, cams, occ, dense):
+    """tohip_traj_forward(need_mask_out) -> tohip_traj_backward(need_mask): same gradients, bit for bit, as the backward
+    that finds the active pairs itself — both modes, every points-per-lane variant, rig, occlusion bits, more than 64 and
+    more than 128 waypoints (mask words), fused loss and a general dL/d rewards vector."""
+    ops = _ops()
+    pts = synth.make_cloud(n, seed=5)
+    poses, quats = synth.make_path(w, optical=True, jitter_seed=4)
+    P = torch.from_numpy(pts).to(dev)
+    cloud = ops.PackedCloud(P)
+    cam = ops.Camera(K, IW, IH)
+    p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
+    rg = ops.CameraRig(*synth.camera_rig(cams), dev) if cams > 1 else None
+    ws = ops.TrajWorkspace(cloud, w * cams)
+    bits = ops.occlusion_bits(cloud, P, p, q, cam, 1.0, 15.0, "zbuffer") if occ else None
+    flags = ops.DENSE if dense else 0
+    lo_ref, mm_ref = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=flags, occ=bits)
+    lo_sum, minmax, need = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=flags, occ=bits, want_need=True)
+    assert torch.equal(lo_sum, lo_ref) and torch.equal(minmax, mm_ref)  # recording the mask does not change the forward
+    if dense:
+        scan = ops.traj_backward_scan(cloud, p, q, cam, ws, minmax, rig=rg, flags=flags, occ=bits)
+        P_lane = 4 if n >= 512 * 1024 else (2 if n >= 128 * 1024 else 1)  # points per lane the library picks
+        used = ((w * cams + 63) // 64) * (cloud.npad // (64 * P_lane)) * 8   # mask words in use (the buffers are padded)
+        assert torch.equal(scan[:used], need[:used])  # the same predicate, evaluated by the two kernels
+    rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
+    gout = torch.ones(1, device=dev)
+    g = torch.rand(n, generator=torch.Generator().manual_seed(2)).to(dev) - 0.3
+    for kw in (dict(scalars=scalars, gout=gout), dict(grad_rewards=g)):
+        ref = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, rig=rg, flags=flags, occ=bits, **kw)
+        got = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, rig=rg, flags=flags, occ=bits, need_mask=need, **kw)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])

@@ -372,30 +372,59 @@ __device__ __forceinline__ void apply_minmax(WayHot& h, float& auxM, float a, fl
 // pass 2: p_hat = (p - a)/M, clip to [0.5, 1-eps], log-odds, summed over the waypoints in order
 // (model.py:226-231).  ATOMIC=false: one block column owns all waypoints and stores lo_sum once.
 
+// `need` (optional): set when the pair will carry gradient in the backward — p_hat >= 1/2 before the clip, or a member of
+// the argmin set when min p > 0 — the predicate of k_traj_bwd_scan, recorded by the forward for the backward to use.
 template <bool PINHOLE>
-__device__ __forceinline__ float log_odds(const CamConsts& cc, const WayHot& h, float X, float Y, float Z, float om) {
+__device__ __forceinline__ float log_odds(const CamConsts& cc, const WayHot& h, float X, float Y, float Z, float om,
+                                          bool* need = nullptr) {
     const float p = soft_vis<PINHOLE>(cc, X, Y, Z, nullptr) * om;
     float ph = (p - h.a) * h.invM;
+    if (need) *need |= (ph >= 0.5f) | ((h.a > 0.f) & (p == h.a));
     ph = __builtin_amdgcn_fmed3f(ph, 0.5f, cc.clip_hi);
     // log(ph/(1-ph)) as a difference of logs: exactly 0 at ph = 0.5
     return (to_log2(ph) - to_log2(1.0f - ph)) * 0.693147180559945f;
 }
 
 template <bool PINHOLE>
-__device__ __forceinline__ f2 log_odds_pk(const CamConsts& cc, const WayHot& h, f2 X, f2 Y, f2 Z, f2 om) {
+__device__ __forceinline__ f2 log_odds_pk(const CamConsts& cc, const WayHot& h, f2 X, f2 Y, f2 Z, f2 om, bool* need = nullptr) {
     const f2 p = soft_vis_pk<PINHOLE>(cc, X, Y, Z, nullptr) * om;
     f2 ph = (p - pk_splat(h.a)) * pk_splat(h.invM);
+    if (need) *need |= (ph.x >= 0.5f) | (ph.y >= 0.5f) | ((h.a > 0.f) & ((p.x == h.a) | (p.y == h.a)));
     ph = f2{__builtin_amdgcn_fmed3f(ph.x, 0.5f, cc.clip_hi), __builtin_amdgcn_fmed3f(ph.y, 0.5f, cc.clip_hi)};
     const f2 q = pk_splat(1.0f) - ph;
     const f2 l = f2{to_log2(ph.x), to_log2(ph.y)} - f2{to_log2(q.x), to_log2(q.y)};
     return l * pk_splat(0.693147180559945f);
 }
 
-template <int P, bool PINHOLE, bool CULL, bool OCC>
+// NEED: also record, per (backward wave slot, waypoint), whether any pair will carry gradient (bit (v & 63) of
+// need_out[(v >> 6) * nslots + slot], the layout of k_traj_bwd_scan) — the forward has p_hat of every pair it evaluates in
+// hand, so the backward need not look for the active pairs again.  A backward slot is 64 * Pb points: `wps` = Pb / P waves
+// of this kernel, consecutive in a block, whose bits are ORed through LDS.
+template <int P, bool PINHOLE, bool CULL, bool OCC, bool NEED = false>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, float* __restrict__ lo_sum,
-             const uint32_t* __restrict__ occ, int64_t occw) {
+             const uint32_t* __restrict__ occ, int64_t occw, unsigned long long* __restrict__ need_out = nullptr,
+             int nslots = 0, int wps = 1) {
+    __shared__ unsigned long long sbits[TO_WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t base = ((int64_t)blockIdx.x * TO_BLOCK + threadIdx.x) * P;
+    // all waves of the block meet here once per 64 waypoints (V is uniform): the group's first wave writes the word
+    auto put_need = [&](int vword, unsigned long long bits) {
+        if constexpr (NEED) {
+            if (wps == 1) {
+                if (lane == 0) need_out[(int64_t)vword * nslots + (blockIdx.x * TO_WAVES_PER_BLOCK + wave)] = bits;
+            } else {
+                if (lane == 0) sbits[wave] = bits;
+                __syncthreads();
+                if (lane == 0 && wave % wps == 0) {
+                    unsigned long long b = 0ull;
+                    for (int j = 0; j < wps; ++j) b |= sbits[wave + j];
+                    need_out[(int64_t)vword * nslots + (blockIdx.x * TO_WAVES_PER_BLOCK + wave) / wps] = b;
+                }
+                __syncthreads();
+            }
+        }
+    };
     float x[P], y[P], z[P], acc[P];
     load_points<P>(cv.soa, cv.npad, base, x, y, z);
 #pragma unroll
@@ -407,6 +436,7 @@ k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, 
             const int vl = vc + (int)(threadIdx.x & 63);
             degenerate |= __any(vl < V && !(hot[min(vl, V - 1)].invM < INFINITY));
             unsigned long long live = tile_survivors<false>(hot, nullptr, vc, V, tb, cc.mean);
+            unsigned long long nbits = 0ull;
             // ascending waypoint order: the same summation order as the dense loop.  The next survivor's record is
             // requested before the current one is worked on: its index comes out of the bit mask, so without this the
             // scalar load's latency would be paid once per survivor — the tail of the heavy tiles.
@@ -420,6 +450,8 @@ k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, 
                 if (live) { vn = vc + __builtin_ctzll(live); hn = hot[vn]; }
                 float om[P];
                 load_occ<P, OCC>(occ, occw, v, base, om);
+                bool need = false;
+                bool* np = NEED ? &need : nullptr;
                 // lanes beyond the bound get p_hat < 0.5 -> exactly 0, so evaluating them too changes nothing
                 if constexpr (P >= 2) {
                     // two points per instruction, like the dense loop (the packed twins give the scalar results bit for bit)
@@ -429,7 +461,7 @@ k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, 
                         to_cam_pk(h, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, X, Y, Z, y0, y1, y2);
                         const bool in0 = dist2_mean(X.x, Y.x, Z.x, cc.mean) <= h.thr, in1 = dist2_mean(X.y, Y.y, Z.y, cc.mean) <= h.thr;
                         if (__any(in0 | in1)) {
-                            const f2 lo = log_odds_pk<PINHOLE>(cc, h, X, Y, Z, f2{om[i], om[i + 1]});
+                            const f2 lo = log_odds_pk<PINHOLE>(cc, h, X, Y, Z, f2{om[i], om[i + 1]}, np);
                             acc[i] += lo.x;
                             acc[i + 1] += lo.y;
                         }
@@ -437,29 +469,41 @@ k_traj_pass2(CloudView cv, const WayHot* __restrict__ hot, int V, CamConsts cc, 
                 } else {
                     float X, Y, Z, y0, y1, y2;
                     to_cam(h, x[0], y[0], z[0], X, Y, Z, y0, y1, y2);
-                    if (__any(dist2_mean(X, Y, Z, cc.mean) <= h.thr)) acc[0] += log_odds<PINHOLE>(cc, h, X, Y, Z, om[0]);
+                    if (__any(dist2_mean(X, Y, Z, cc.mean) <= h.thr)) acc[0] += log_odds<PINHOLE>(cc, h, X, Y, Z, om[0], np);
                 }
+                if (NEED && __any(need)) nbits |= 1ull << (v - vc);
             }
+            put_need(vc >> 6, nbits);
         }
     } else {
+        unsigned long long nbits = 0ull;
         for (int v = 0; v < V; ++v) {
             const WayHot h = hot[v];
             degenerate |= !(h.invM < INFINITY);
             float om[P];
             load_occ<P, OCC>(occ, occw, v, base, om);
+            bool need = false;
+            bool* np = NEED ? &need : nullptr;
             if constexpr (P >= 2) {
 #pragma unroll
                 for (int i = 0; i < P; i += 2) {
                     f2 X, Y, Z, y0, y1, y2;
                     to_cam_pk(h, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, X, Y, Z, y0, y1, y2);
-                    const f2 lo = log_odds_pk<PINHOLE>(cc, h, X, Y, Z, f2{om[i], om[i + 1]});
+                    const f2 lo = log_odds_pk<PINHOLE>(cc, h, X, Y, Z, f2{om[i], om[i + 1]}, np);
                     acc[i] += lo.x;
                     acc[i + 1] += lo.y;
                 }
             } else {
                 float X, Y, Z, y0, y1, y2;
                 to_cam(h, x[0], y[0], z[0], X, Y, Z, y0, y1, y2);
-                acc[0] += log_odds<PINHOLE>(cc, h, X, Y, Z, om[0]);
+                acc[0] += log_odds<PINHOLE>(cc, h, X, Y, Z, om[0], np);
+            }
+            if constexpr (NEED) {
+                if (__any(need)) nbits |= 1ull << (v & 63);
+                if ((v & 63) == 63 || v == V - 1) {
+                    put_need(v >> 6, nbits);
+                    nbits = 0ull;
+                }
             }
         }
     }
@@ -1060,7 +1104,8 @@ extern "C" size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual
 
 extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
                                   const tohip_camera* cam, const tohip_rig* rig, int flags, const uint32_t* occlusion_bits,
-                                  float* lo_sum, float* minmax, void* workspace, size_t workspace_bytes, void* stream_) {
+                                  float* lo_sum, float* minmax, void* need_mask_out, void* workspace, size_t workspace_bytes,
+                                  void* stream_) {
     if (!packed || !poses || !quats || !cam || !lo_sum || !minmax || !workspace || n <= 0 || W <= 0) return TOHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
     const int C = rig_cams(rig);
@@ -1116,10 +1161,16 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
     // its survivors one after the other; pass 2 has no per-wave partials, so the points-per-lane factor is free to choose
     // and P = 1 cuts that tail four-fold (1 M x 128: 45 -> 28 us).  The result does not depend on P.
     const int P2 = cull ? 1 : pl.P;
+    const int wps = pl.P / P2;  // waves of this launch per backward wave slot (64 * pl.P points)
     dispatch(P2, cc.pinhole != 0, cull, occlusion_bits != nullptr, [&](auto Pc, auto Ph, auto Cu, auto Oc) {
-        k_traj_pass2<decltype(Pc)::value, decltype(Ph)::value, decltype(Cu)::value, decltype(Oc)::value>
-            <<<dim3((unsigned)(pl.npad / (TO_BLOCK * P2)), 1), TO_BLOCK, 0, st>>>(cv, hot, (int)V, cc, lo_sum, occlusion_bits,
-                                                                                 cv.npad / 32);
+        constexpr int Pv = decltype(Pc)::value;
+        constexpr bool Phv = decltype(Ph)::value, Cuv = decltype(Cu)::value, Ocv = decltype(Oc)::value;
+        const dim3 grid((unsigned)(pl.npad / (TO_BLOCK * P2)), 1);
+        if (need_mask_out)
+            k_traj_pass2<Pv, Phv, Cuv, Ocv, true><<<grid, TO_BLOCK, 0, st>>>(cv, hot, (int)V, cc, lo_sum, occlusion_bits, cv.npad / 32,
+                                                                             (unsigned long long*)need_mask_out, pl.nslots, wps);
+        else
+            k_traj_pass2<Pv, Phv, Cuv, Ocv><<<grid, TO_BLOCK, 0, st>>>(cv, hot, (int)V, cc, lo_sum, occlusion_bits, cv.npad / 32);
     });
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
@@ -1197,7 +1248,7 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* p
     if (!packed || !poses || !quats || !cam || !lo_sum || !minmax || !poses_grad || !quats_grad || !workspace ||
         n <= 0 || W <= 0 || (!grad_rewards && (!scalars || !gout)))
         return TOHIP_EINVAL;
-    if (need_mask && !(flags & TOHIP_TRAJ_DENSE)) return TOHIP_EINVAL;  // the split backward is the dense mode's
+
     hipStream_t st = (hipStream_t)stream_;
     const int C = rig_cams(rig);
     const int64_t V = W * C;
@@ -1213,7 +1264,9 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, const float* p
     unsigned long long* tmask = (unsigned long long*)(ws + pl.off_tmask);
     const CamConsts cc = make_consts(cam);
     const CloudView cv = cloud_view(packed, n);
-    const bool cull = !(flags & TOHIP_TRAJ_DENSE);
+    // with a need mask (from tohip_traj_forward or tohip_traj_backward_scan) the flagged (wave, waypoint) combinations are
+    // walked directly, whatever the mode: no culling tests, partials recorded in the touched mask
+    const bool cull = !(flags & TOHIP_TRAJ_DENSE) && !need_mask;
     const float* rq = (C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
     const float* rt = rq ? rig->rig_trans : nullptr;
 

@@ -125,6 +125,16 @@ class _PoseLoss(torch.autograd.Function):
         return tg, qg, None, None
 
 
+def _forward_with_need(model, ps, qs, n_local, occ):
+    """tohip_traj_forward for the model's local waypoints -> (lo_sum, minmax, need mask or None)."""
+    if model._flags & ops.DENSE:
+        return ops.traj_forward(model._cloud, ps, qs, model._cam, model._workspace(n_local), model._rig, flags=model._flags,
+                                occ=occ, want_need=True)
+    lo_sum, minmax = ops.traj_forward(model._cloud, ps, qs, model._cam, model._workspace(n_local), model._rig,
+                                      flags=model._flags, occ=occ)
+    return lo_sum, minmax, None
+
+
 class _TrajRewards(torch.autograd.Function):
     """rewards(poses, quats) for the evaluated waypoints.  With a process group the waypoints are sharded
     over the ranks; the only data-path collective is the all-reduce of the log-odds vector."""
@@ -141,14 +151,16 @@ class _TrajRewards(torch.autograd.Function):
             # occlusion masks are piecewise constant in the poses: computed per forward, not differentiated
             occ = ops.occlusion_bits(model._cloud, model.points, ps, qs, model._cam, model._occlusion_limits[0],
                                      model._occlusion_limits[1], model._occlusion)
+        need = None
         if hi > lo:
-            lo_sum, minmax = ops.traj_forward(model._cloud, ps, qs, model._cam, model._workspace(hi - lo), model._rig,
-                                              flags=model._flags, occ=occ)
+            # dense mode: the forward also records which (wave, waypoint) combinations will carry gradient and the backward
+            # walks those (0.05 instead of 0.19 ms at 1 M x 128); the culled backward is already that cheap without it
+            lo_sum, minmax, need = _forward_with_need(model, ps, qs, hi - lo, occ)
         else:
             lo_sum, minmax = torch.zeros(model._cloud.npad, device=p.device), None
         lo_sum = sh.allreduce_sum(lo_sum)
         rewards, _ = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)))
-        ctx.model, ctx.range, ctx.n_wps, ctx.occ = model, (lo, hi), p.shape[0], occ
+        ctx.model, ctx.range, ctx.n_wps, ctx.occ, ctx.need = model, (lo, hi), p.shape[0], occ, need
         ctx.save_for_backward(ps, qs, lo_sum, minmax if minmax is not None else torch.empty(0, device=p.device))
         return rewards
 
@@ -162,7 +174,7 @@ class _TrajRewards(torch.autograd.Function):
         if hi > lo:
             g = grad_rewards.to(torch.float32).contiguous()
             pg, qg = ops.traj_backward(m._cloud, ps, qs, m._cam, m._workspace(hi - lo), lo_sum, minmax,
-                                       grad_rewards=g, rig=m._rig, flags=m._flags, occ=ctx.occ)
+                                       grad_rewards=g, rig=m._rig, flags=m._flags, occ=ctx.occ, need_mask=ctx.need)
             grads[lo:hi, :3], grads[lo:hi, 3:] = pg, qg
         grads = m._shard.allreduce_sum(grads)
         return grads[:, :3].contiguous(), grads[:, 3:].contiguous(), None
@@ -193,9 +205,9 @@ class _TrajLoss(torch.autograd.Function):
         if hi > lo and model._occlusion is not None:
             occ = ops.occlusion_bits(model._cloud, model.points, ps, qs, model._cam, model._occlusion_limits[0],
                                      model._occlusion_limits[1], model._occlusion)
+        need = None
         if hi > lo:
-            lo_sum, minmax = ops.traj_forward(model._cloud, ps, qs, model._cam, model._workspace(hi - lo), model._rig,
-                                              flags=model._flags, occ=occ)
+            lo_sum, minmax, need = _forward_with_need(model, ps, qs, hi - lo, occ)
         else:
             lo_sum, minmax = torch.zeros(model._cloud.npad, device=dev), None
         lo_sum = sh.allreduce_sum(lo_sum)
@@ -207,7 +219,7 @@ class _TrajLoss(torch.autograd.Function):
             check(L.tohip_traj_regularizers(ptr(p_all), ptr(model.poses0), W, float(model.smoothness_weight),
                                             float(model.traj_length_weight), float(model.eps), ptr(scalars), ptr(terms),
                                             ptr(reg_sum), 0, None, ptr(reg_terms), stream_ptr()), "tohip_traj_regularizers")
-        ctx.model, ctx.range, ctx.step_w, ctx.W, ctx.occ = model, (lo, hi), step_w, W, occ
+        ctx.model, ctx.range, ctx.step_w, ctx.W, ctx.occ, ctx.need = model, (lo, hi), step_w, W, occ, need
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(ps, qs, lo_sum, minmax if minmax is not None else torch.empty(0, device=dev), scalars, reg_sum,
                               reg_terms)
@@ -239,7 +251,7 @@ class _TrajLoss(torch.autograd.Function):
                     g = g + c_vis * scalars[2]  # d loss_vis / d reward_n = -vis^2 / N
                 kw = dict(grad_rewards=g.contiguous())
             pg, qg = ops.traj_backward(m._cloud, ps, qs, m._cam, m._workspace(hi - lo), lo_sum, minmax, rig=m._rig,
-                                       flags=m._flags, occ=ctx.occ, **kw)
+                                       flags=m._flags, occ=ctx.occ, need_mask=ctx.need, **kw)
             rows = slice(lo * ctx.step_w, (hi - 1) * ctx.step_w + 1, ctx.step_w)
             grads[rows, :3], grads[rows, 3:] = pg, qg
         grads = m._shard.allreduce_sum(grads)

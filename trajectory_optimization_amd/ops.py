@@ -85,17 +85,21 @@ class TrajWorkspace:
 DENSE = 1  # TOHIP_TRAJ_DENSE
 
 
-def traj_forward(cloud, poses, quats, cam, ws, rig=None, flags=0, occ=None):
-    """-> (lo_sum[npad] in packed order (first N valid), minmax[V,2]) for the given waypoints (this rank's shard)."""
+def traj_forward(cloud, poses, quats, cam, ws, rig=None, flags=0, occ=None, want_need=False):
+    """-> (lo_sum[npad] in packed order (first N valid), minmax[V,2]) for the given waypoints (this rank's shard);
+    with want_need=True also the need mask (uint8 buffer) that lets traj_backward walk only the pairs with gradient."""
     W = poses.shape[0]
     C = rig.n_cams if rig is not None else 1
     lo_sum = torch.empty(cloud.npad, dtype=torch.float32, device=cloud.device)
     minmax = torch.empty((W * C, 2), dtype=torch.float32, device=cloud.device)
+    need = None
+    if want_need:
+        need = torch.empty(_lib.lib().tohip_traj_need_mask_bytes(cloud.n, W * C), dtype=torch.uint8, device=cloud.device)
     with torch.cuda.device(cloud.device):
         check(_lib.lib().tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
                                             rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(occ), ptr(lo_sum), ptr(minmax),
-                                            ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_forward")
-    return lo_sum, minmax
+                                            ptr(need), ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_forward")
+    return (lo_sum, minmax, need) if want_need else (lo_sum, minmax)
 
 
 def traj_reward(cloud, lo_sum, cam, ws):

@@ -51,6 +51,12 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
     pg, qg = torch.zeros((W, 3), **f32), torch.zeros((W, 4), **f32)
     lo_sum = torch.empty(cloud.npad, **f32)
     minmax = torch.empty((max(n_loc, 1) * (rig.n_cams if rig else 1), 2), **f32)
+    # the forward records which (wave, waypoint) combinations carry gradient; the backward walks only those
+    # (dense mode only: the culled backward is as cheap without it and the forward would pay for the record)
+    need = None
+    if model._flags & ops.DENSE:
+        need = torch.empty(L.tohip_traj_need_mask_bytes(cloud.n, max(n_loc, 1) * (rig.n_cams if rig else 1)), dtype=torch.uint8,
+                           device=dev)
     rewards, scalars = torch.empty(cloud.n, **f32), torch.zeros(4, **f32)
     loss_terms = torch.zeros((n_opt_steps + 1, 8), **f32)
     state = torch.zeros(8, **f32)
@@ -72,7 +78,8 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
                                      model._occlusion_limits[1], model._occlusion)
         if n_loc > 0:
             check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref,
-                                       model._flags, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(ws.buf), ws.bytes, s), "forward")
+                                       model._flags, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(need), ptr(ws.buf), ws.bytes, s),
+                  "forward")
         else:
             lo_sum.zero_()
         model._shard.allreduce_sum(lo_sum)
@@ -82,7 +89,7 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
         if n_loc > 0:
             check(L.tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref,
                                         model._flags, ptr(occ), ptr(lo_sum), None, ptr(scalars), ptr(minmax), ptr(gout),
-                                        None, ptr(tgt_p), ptr(tgt_q), ptr(ws.buf), ws.bytes, s), "backward")
+                                        ptr(need), ptr(tgt_p), ptr(tgt_q), ptr(ws.buf), ws.bytes, s), "backward")
         if sharded:
             # assemble every rank's gradient rows: ONE (n_eval, 7) all-reduce, then the replicated remainder of the step
             if n_loc > 0:
