@@ -292,3 +292,46 @@ def test_backward_with_the_forwards_need_mask_is_bitwise_the_same(dev, n, w, cam
         ref = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, rig=rg, flags=flags, occ=bits, **kw)
         got = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, rig=rg, flags=flags, occ=bits, need_mask=need, **kw)
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_all_backward_variants_agree_on_random_configs(dev, seed):
+    """Random clouds (compact ones with min p > 0 included), paths, rigs, clip limits, unsorted packing, duplicated points:
+    culled == dense, and the backward with the forward's record / with the scan's record == the backward without, bit for
+    bit.  (tools/stress_bitwise.py runs more of the same.)"""
+    ops = _ops()
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([700, 5000, 40_000, 140_000, 300_000]))
+    cams = int(rng.choice([1, 1, 2, 5]))
+    w = max(1, int(rng.integers(1, 90)) // cams)
+    scale = float(rng.choice([0.3, 0.3, 1.0, 2.5]))  # 0.3: everything in front of the cameras -> min p > 0 at some waypoints
+    pts = (synth.make_cloud(n, seed=int(rng.integers(1 << 30))) * np.float32(scale)).astype(np.float32)
+    if rng.random() < 0.4:
+        pts = np.concatenate([pts, pts[: n // 5]])
+    poses, quats = synth.make_path(w, optical=True, jitter_seed=int(rng.integers(1 << 30)))
+    quats = (quats * np.float32(rng.uniform(0.5, 2.0))).astype(np.float32)
+    P = torch.from_numpy(pts).to(dev)
+    cloud = ops.PackedCloud(P, sort=bool(rng.random() < 0.8))
+    cam = ops.Camera(K, IW, IH, float(rng.uniform(0.2, 2.0)), float(rng.uniform(3.0, 12.0)))
+    p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
+    rg = ops.CameraRig(*synth.camera_rig(cams), dev) if cams > 1 else None
+    ws = ops.TrajWorkspace(cloud, w * cams)
+    gout = torch.ones(1, device=dev)
+
+    def same(x, y):
+        return torch.equal(torch.isnan(x), torch.isnan(y)) and torch.equal(torch.nan_to_num(x), torch.nan_to_num(y))
+
+    grads = []
+    for flags in (0, ops.DENSE):
+        lo, mm, need = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=flags, want_need=True)
+        rew, sc = ops.traj_reward(cloud, lo, cam, ws)
+        plain = ops.traj_backward(cloud, p, q, cam, ws, lo, mm, rig=rg, flags=flags, scalars=sc, gout=gout)
+        masked = ops.traj_backward(cloud, p, q, cam, ws, lo, mm, rig=rg, flags=flags, scalars=sc, gout=gout, need_mask=need)
+        assert same(plain[0], masked[0]) and same(plain[1], masked[1]), ("forward's record", flags)
+        if flags:
+            scan = ops.traj_backward_scan(cloud, p, q, cam, ws, mm, rig=rg, flags=flags)
+            via_scan = ops.traj_backward(cloud, p, q, cam, ws, lo, mm, rig=rg, flags=flags, scalars=sc, gout=gout, need_mask=scan)
+            assert same(plain[0], via_scan[0]) and same(plain[1], via_scan[1]), "scan's record"
+        grads.append((lo, mm, rew, plain[0], plain[1]))
+    for a, b in zip(grads[0], grads[1]):
+        assert same(a, b)  # culled == dense

@@ -349,7 +349,9 @@ k_minmax_finish(const float2* __restrict__ part, int nslots, WayHot* __restrict_
         hot[v].a = a;
         hot[v].invM = 1.0f / M;
         float thr = INFINITY, sthr = INFINITY;
-        if (cull && M > 0.f) cull_threshold(fmaf(0.5f, M, a), inv_var, &thr, &sthr);
+        // cull == 2 (the forward also records the backward's need mask): the argmin set {p == a} carries gradient when
+        // a > 0 and lies outside the active set, so such a waypoint is not culled — the rule of apply_minmax below
+        if (cull && M > 0.f && (cull == 1 || a == 0.f)) cull_threshold(fmaf(0.5f, M, a), inv_var, &thr, &sthr);
         hot[v].thr = thr;
         hot[v].sthr = sthr;
         aux[v].M = M;
@@ -1153,7 +1155,7 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
     TO_HIP_CHECK_LAUNCH();
     {
         TO_PROF(TOHIP_PROF_SMALL, st);
-        k_minmax_finish<<<(int)V, 1024, 0, st>>>(mm, pl.nslots, hot, aux, cc.inv_var, cull ? 1 : 0, minmax);
+        k_minmax_finish<<<(int)V, 1024, 0, st>>>(mm, pl.nslots, hot, aux, cc.inv_var, cull ? (need_mask_out ? 2 : 1) : 0, minmax);
     }
     TO_HIP_CHECK_LAUNCH();
     TO_PROF(TOHIP_PROF_PASS2, st);
