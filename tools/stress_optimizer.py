@@ -1,0 +1,35 @@
+"""Stress (GPU box): the launch-only optimiser against the drop-in loop (model(); backward(); Adam.step()) on random
+configurations — waypoint subsampling, rigs, dense flag, weights.  python tools/stress_optimizer.py [n_configs] [seed]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from trajectory_optimization_amd import synth
+from trajectory_optimization_amd.model import ModelTraj
+from trajectory_optimization_amd.optimizer import optimize_trajectory, Adam
+K, IW, IH = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4)
+bad = 0
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 16):
+    n = int(rng.choice([3000, 40_000, 200_000]))
+    w = int(rng.integers(3, 40))
+    cams = int(rng.choice([1, 1, 3]))
+    pts = synth.make_cloud(n, seed=int(rng.integers(1 << 30)))
+    poses, quats = synth.make_path(w, optical=True, jitter_seed=int(rng.integers(1 << 30)))
+    vwd = float(rng.choice([0.0, 0.5, 1.5]))
+    kw = dict(smoothness_weight=float(rng.uniform(5, 30)), traj_length_weight=float(rng.uniform(0.01, 0.1)), dense=bool(rng.random() < 0.5))
+    if cams > 1: kw["rig"] = synth.camera_rig(cams)
+    lr_p, lr_q, steps = float(rng.uniform(0.01, 0.1)), float(rng.uniform(0.0, 0.03)), int(rng.integers(1, 7))
+    def build():
+        return ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(K), IW, IH, device=dev, **kw)
+    a, b = build(), build()
+    res = optimize_trajectory(a, n_opt_steps=steps, lr_pose=lr_p, lr_quat=lr_q, rewards_th=1e9, vis_wps_dist=vwd)
+    opt = Adam([{"params": [b.poses], "lr": lr_p}, {"params": [b.quats], "lr": lr_q}])
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad(); loss = b(vis_wps_dist=vwd); loss.backward(); opt.step(); losses.append(loss.item())
+    dp = float((a.poses - b.poses).abs().max()); dq = float((a.quats - b.quats).abs().max())
+    dl = max(abs(x - y) / abs(y) for x, y in zip(res.losses, losses))
+    if not (dp < 5e-5 and dq < 5e-5 and dl < 2e-5):
+        bad += 1; print("MISMATCH", it, n, w, cams, vwd, kw["dense"], steps, f"dp {dp:.2e} dq {dq:.2e} dl {dl:.2e}")
+print("optimizer stress done, failures:", bad)
