@@ -166,6 +166,14 @@ size_t tohip_frustum_workspace_bytes(int64_t n_points);
 int tohip_frustum_cull(const float *cam_3xN, int64_t n_points, const tohip_camera *cam_host, float min_dist,
                        float max_dist, uint8_t *dist_mask, uint8_t *fov_mask, int32_t *kept_idx, int32_t *kept_count,
                        void *workspace, size_t workspace_bytes, void *stream);
+/* The cull stage of the per-camera pipeline (pc_processor.py:158-170) for n_wps poses at once: exact transform of the cloud
+ * (to_camera_frame arithmetic; normalize as in tohip_to_camera_frame), hard frustum test, ordered compaction.
+ * kept_idx (n_wps, n) int32 and kept_pts (n_wps, n, 3) f32 (camera frame) receive each pose's kept points in input
+ * order in their first kept_count[w] rows (device int32 per pose) — worst-case sized, no host round trip. */
+size_t tohip_cull_waypoints_workspace_bytes(int64_t n_points, int64_t n_wps);
+int tohip_cull_waypoints(const float *xyz, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
+                         int normalize, const tohip_camera *cam_host, float min_dist, float max_dist, int32_t *kept_idx,
+                         float *kept_pts, int32_t *kept_count, void *workspace, size_t workspace_bytes, void *stream);
 /* gather rows: out[i,:] = xyz[idx[i],:] for i < *count (device), xyz (N,3) or (3,N) by in_layout. */
 int tohip_gather_points(const float *xyz, int64_t n_points, int in_layout, const int32_t *idx, const int32_t *count,
                         int64_t capacity, float *out_xyz, void *stream);

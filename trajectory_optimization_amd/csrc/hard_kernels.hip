@@ -330,6 +330,130 @@ extern "C" int tohip_frustum_cull(const float* cam_3xN, int64_t n, const tohip_c
     return TOHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The cull stage of the per-camera pipeline (pc_processor.py:158-170) for W waypoints at once: exact transform of the
+// whole cloud into every waypoint's camera frame, hard frustum test, ordered compaction — three launches instead of
+// five per waypoint.  kept_idx[w*n ..] / kept_pts[(w*n + j)*3 ..] receive waypoint w's kept points in input order,
+// kept_count[w] their number.
+__global__ void __launch_bounds__(TO_BLOCK)
+k_cull_wps_count(const float* __restrict__ xyz, int64_t n, const float* __restrict__ poses, const float* __restrict__ quats,
+                 int normalize, FrustumConsts f, int ntiles, int32_t* __restrict__ tile_count) {
+    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
+    const int w = blockIdx.y;
+    const ExactPose e = exact_pose(quats + 4 * w, poses + 3 * w, normalize);
+    const int64_t tile0 = (int64_t)blockIdx.x * TO_CULL_TILE;
+    int cnt = 0;
+    for (int j = 0; j < TO_CULL_TILE / TO_BLOCK; ++j) {
+        const int64_t i = tile0 + j * TO_BLOCK + threadIdx.x;
+        bool d = false, v = false;
+        if (i < n) {
+            float X, Y, Z;
+            exact_to_cam(e, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], X, Y, Z);
+            frustum_pred(f, X, Y, Z, d, v);
+        }
+        cnt += __popcll(__ballot(d && v));
+    }
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[(int64_t)w * ntiles + blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// block per waypoint: exclusive scan of its tile counts (in place) and its total
+__global__ void __launch_bounds__(TO_BLOCK)
+k_cull_wps_scan(int32_t* __restrict__ tile_count, int ntiles, int32_t* __restrict__ kept_count) {
+    __shared__ int lds[TO_BLOCK];
+    __shared__ int carry;
+    int32_t* tc = tile_count + (int64_t)blockIdx.x * ntiles;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < ntiles; c0 += TO_BLOCK) {
+        const int i = c0 + threadIdx.x;
+        const int v = i < ntiles ? tc[i] : 0;
+        lds[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 1; s < TO_BLOCK; s <<= 1) {
+            const int add = (int)threadIdx.x >= s ? lds[threadIdx.x - s] : 0;
+            __syncthreads();
+            lds[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < ntiles) tc[i] = carry + lds[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += lds[TO_BLOCK - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) kept_count[blockIdx.x] = carry;
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_cull_wps_write(const float* __restrict__ xyz, int64_t n, const float* __restrict__ poses, const float* __restrict__ quats,
+                 int normalize, FrustumConsts f, int ntiles, const int32_t* __restrict__ tile_off,
+                 int32_t* __restrict__ kept_idx, float* __restrict__ kept_pts) {
+    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const ExactPose e = exact_pose(quats + 4 * w, poses + 3 * w, normalize);
+    const int64_t tile0 = (int64_t)blockIdx.x * TO_CULL_TILE;
+    int base = tile_off[(int64_t)w * ntiles + blockIdx.x];
+    int32_t* ki = kept_idx + (int64_t)w * n;
+    float* kp = kept_pts + (int64_t)w * n * 3;
+    for (int j = 0; j < TO_CULL_TILE / TO_BLOCK; ++j) {
+        const int64_t i = tile0 + j * TO_BLOCK + threadIdx.x;
+        bool d = false, v = false;
+        float X = 0.f, Y = 0.f, Z = 0.f;
+        if (i < n) {
+            exact_to_cam(e, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], X, Y, Z);
+            frustum_pred(f, X, Y, Z, d, v);
+        }
+        const bool keep = d && v;
+        const unsigned long long b = __ballot(keep);
+        if (lane == 0) wave_cnt[wave] = __popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < wave; ++k) off += wave_cnt[k];
+        if (keep) {
+            const int dst = off + __popcll(b & ((1ull << lane) - 1ull));
+            ki[dst] = (int32_t)i;
+            kp[3 * (int64_t)dst] = X; kp[3 * (int64_t)dst + 1] = Y; kp[3 * (int64_t)dst + 2] = Z;
+        }
+        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
+extern "C" size_t tohip_cull_waypoints_workspace_bytes(int64_t n, int64_t n_wps) {
+    if (n <= 0 || n_wps <= 0) return 256;
+    const size_t ntiles = (size_t)((n + TO_CULL_TILE - 1) / TO_CULL_TILE);
+    return (ntiles * (size_t)n_wps * sizeof(int32_t) + 255) / 256 * 256 + 256;
+}
+
+extern "C" int tohip_cull_waypoints(const float* xyz, int64_t n, const float* poses, const float* quats, int64_t n_wps,
+                                    int normalize, const tohip_camera* cam, float min_dist, float max_dist, int32_t* kept_idx,
+                                    float* kept_pts, int32_t* kept_count, void* workspace, size_t workspace_bytes,
+                                    void* stream_) {
+    if (!xyz || !poses || !quats || !cam || !kept_idx || !kept_pts || !kept_count || !workspace || n <= 0 || n_wps <= 0 ||
+        n > (int64_t)0x7fffffff || n_wps > 65535)
+        return TOHIP_EINVAL;
+    if (workspace_bytes < tohip_cull_waypoints_workspace_bytes(n, n_wps)) return TOHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream_;
+    const int ntiles = (int)((n + TO_CULL_TILE - 1) / TO_CULL_TILE);
+    int32_t* tile_count = (int32_t*)workspace;
+    FrustumConsts f;
+    for (int i = 0; i < 9; ++i) f.k[i] = cam->K[i];
+    f.wl = (float)((double)cam->img_width - 1.0);
+    f.hl = (float)((double)cam->img_height - 1.0);
+    f.dmin = min_dist;
+    f.dmax = max_dist;
+    const dim3 grid((unsigned)ntiles, (unsigned)n_wps);
+    k_cull_wps_count<<<grid, TO_BLOCK, 0, st>>>(xyz, n, poses, quats, normalize, f, ntiles, tile_count);
+    TO_HIP_CHECK_LAUNCH();
+    k_cull_wps_scan<<<(unsigned)n_wps, TO_BLOCK, 0, st>>>(tile_count, ntiles, kept_count);
+    TO_HIP_CHECK_LAUNCH();
+    k_cull_wps_write<<<grid, TO_BLOCK, 0, st>>>(xyz, n, poses, quats, normalize, f, ntiles, tile_count, kept_idx, kept_pts);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
 // out[i,:] = xyz[idx[i],:]  for i < *count
 __global__ void __launch_bounds__(TO_BLOCK)
 k_gather_points(const float* __restrict__ xyz, int64_t n, int in_layout, const int32_t* __restrict__ idx,

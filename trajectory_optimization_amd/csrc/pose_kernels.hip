@@ -98,9 +98,12 @@ k_pose_bwd_finish(const double* __restrict__ part, int nparts, float* __restrict
 // quaternion_apply(q_inv, .) = two raw Hamilton products, every term rounded, left to right
 // (no fma: this translation unit is built with -ffp-contract=off).
 
-__global__ void __launch_bounds__(TO_BLOCK)
-k_to_camera_frame(const float* __restrict__ xyz, int64_t n, const float* __restrict__ quat,
-                  const float* __restrict__ trans, int normalize, int out_layout, float* __restrict__ out) {
+struct ExactPose {
+    float q[4], t[3];
+};
+
+__device__ __forceinline__ ExactPose exact_pose(const float* __restrict__ quat, const float* __restrict__ trans, int normalize) {
+    ExactPose e;
     float q[4] = {quat[0], quat[1], quat[2], quat[3]};
     if (normalize) {
         float ss = q[0] * q[0];
@@ -111,20 +114,33 @@ k_to_camera_frame(const float* __restrict__ xyz, int64_t n, const float* __restr
         nn = nn < 1e-12f ? 1e-12f : nn;
         for (int i = 0; i < 4; ++i) q[i] = q[i] / nn;
     }
-    const float aw = q[0], ax = -q[1], ay = -q[2], az = -q[3];
-    const float cw = q[0], cx = q[1], cy = q[2], cz = q[3];
-    const float t0 = trans[0], t1 = trans[1], t2 = trans[2];
+    for (int i = 0; i < 4; ++i) e.q[i] = q[i];
+    e.t[0] = trans[0]; e.t[1] = trans[1]; e.t[2] = trans[2];
+    return e;
+}
+
+__device__ __forceinline__ void exact_to_cam(const ExactPose& e, float x, float y, float z, float& r0, float& r1, float& r2) {
+    const float aw = e.q[0], ax = -e.q[1], ay = -e.q[2], az = -e.q[3];
+    const float cw = e.q[0], cx = e.q[1], cy = e.q[2], cz = e.q[3];
+    const float bx = x - e.t[0], by = y - e.t[1], bz = z - e.t[2];
+    const float bw = 0.f;
+    const float ow = aw * bw - ax * bx - ay * by - az * bz;
+    const float ox = aw * bx + ax * bw + ay * bz - az * by;
+    const float oy = aw * by - ax * bz + ay * bw + az * bx;
+    const float oz = aw * bz + ax * by - ay * bx + az * bw;
+    r0 = ow * cx + ox * cw + oy * cz - oz * cy;
+    r1 = ow * cy - ox * cz + oy * cw + oz * cx;
+    r2 = ow * cz + ox * cy - oy * cx + oz * cw;
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_to_camera_frame(const float* __restrict__ xyz, int64_t n, const float* __restrict__ quat,
+                  const float* __restrict__ trans, int normalize, int out_layout, float* __restrict__ out) {
+    const ExactPose e = exact_pose(quat, trans, normalize);
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
-        const float bx = xyz[3 * i] - t0, by = xyz[3 * i + 1] - t1, bz = xyz[3 * i + 2] - t2;
-        const float bw = 0.f;
-        const float ow = aw * bw - ax * bx - ay * by - az * bz;
-        const float ox = aw * bx + ax * bw + ay * bz - az * by;
-        const float oy = aw * by - ax * bz + ay * bw + az * bx;
-        const float oz = aw * bz + ax * by - ay * bx + az * bw;
-        const float r0 = ow * cx + ox * cw + oy * cz - oz * cy;
-        const float r1 = ow * cy - ox * cz + oy * cw + oz * cx;
-        const float r2 = ow * cz + ox * cy - oy * cx + oz * cw;
+        float r0, r1, r2;
+        exact_to_cam(e, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], r0, r1, r2);
         if (out_layout == 0) {
             out[3 * i] = r0; out[3 * i + 1] = r1; out[3 * i + 2] = r2;
         } else {

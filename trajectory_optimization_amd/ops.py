@@ -179,21 +179,21 @@ def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method=
     W = poses.shape[0]
     rows = torch.empty((W, cloud.npad // 32), dtype=torch.int32, device=dev)
     n = cloud.n
-    wsb = L.tohip_frustum_workspace_bytes(n)
-    fws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    # transform -> cull -> gather for every waypoint without a host round trip: the kept counts stay on the device
-    # (tohip_gather_points reads them there) and are fetched once, after the loop; the per-waypoint buffers are sized for
-    # the worst case (16 B per point and waypoint: 2 GB at 1 M x 128, small change on this part)
+    # transform -> cull -> gather for all waypoints in three launches (tohip_cull_waypoints); the kept counts are fetched
+    # once; the per-waypoint buffers are sized for the worst case (16 B per point and waypoint: 2 GB at 1 M x 128)
     kept_all = torch.empty((W, max(n, 1)), dtype=torch.int32, device=dev)
     pts_all = torch.empty((W, max(n, 1), 3), dtype=torch.float32, device=dev)
     kcnt_all = torch.zeros(W, dtype=torch.int32, device=dev)
-    for w in range(W):
-        cam3 = to_camera_frame_exact(points, quats[w], poses[w], normalize=True, transpose=True)
+    pts_in = points.detach().to(torch.float32).contiguous()
+    p_in, q_in = poses.detach().to(torch.float32).contiguous(), quats.detach().to(torch.float32).contiguous()
+    for w0 in range(0, W, 65535):  # grid.y limit
+        w1 = min(W, w0 + 65535)
+        wsb = L.tohip_cull_waypoints_workspace_bytes(n, w1 - w0)
+        fws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            check(L.tohip_frustum_cull(ptr(cam3), n, cam.ref(), float(min_dist), float(max_dist), None, None, ptr(kept_all[w]),
-                                       ptr(kcnt_all[w:w + 1]), ptr(fws), wsb, stream_ptr()), "tohip_frustum_cull")
-            check(L.tohip_gather_points(ptr(cam3), n, 1, ptr(kept_all[w]), ptr(kcnt_all[w:w + 1]), n, ptr(pts_all[w]),
-                                        stream_ptr()), "tohip_gather_points")
+            check(L.tohip_cull_waypoints(ptr(pts_in), n, ptr(p_in[w0:w1]), ptr(q_in[w0:w1]), w1 - w0, 1, cam.ref(), float(min_dist),
+                                         float(max_dist), ptr(kept_all[w0:w1]), ptr(pts_all[w0:w1]), ptr(kcnt_all[w0:w1]), ptr(fws),
+                                         wsb, stream_ptr()), "tohip_cull_waypoints")
     counts = kcnt_all.cpu().tolist()  # the one synchronisation of the cull stage
     kept = kept_all[0]
     kept_idx = [kept_all[w, :counts[w]] for w in range(W)]
