@@ -3,7 +3,6 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_inf
 from trajectory_optimization_amd import synth
 
 pytestmark = pytest.mark.gpu

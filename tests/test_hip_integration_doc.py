@@ -4,7 +4,6 @@ import os
 import re
 import types
 
-import numpy as np
 import pytest
 import torch
 

@@ -3,7 +3,6 @@ import numpy as np
 import pytest
 import torch
 
-from trajectory_optimization_amd import synth
 
 
 def _scene(n, seed):

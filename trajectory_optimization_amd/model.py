@@ -15,7 +15,6 @@ from time import time
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
