@@ -144,6 +144,12 @@ def main():
     shard = WaypointShard() if n_gpus > 1 else None
 
     need_buf = torch.empty(L0.tohip_traj_need_mask_bytes(cloud.n, n_virtual), dtype=torch.uint8, device=device)
+    if shard is not None:
+        # communicator set-up (RCCL rings over xGMI) happens on the first collective of each kind: keep it out of the timed
+        # region whatever --warmup says
+        shard.allreduce_sum(torch.zeros(cloud.npad, device=device))
+        shard.allgather_rows(torch.zeros((args.wps_per_gpu, 7), device=device))
+        torch.cuda.synchronize(device)
 
     def step(flags, saved=False):
         """saved: the forward records which (wave, waypoint) combinations carry gradient and the backward walks only
