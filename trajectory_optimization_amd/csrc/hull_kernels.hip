@@ -32,6 +32,7 @@ constexpr int kCtrlNFaces = 0, kCtrlAnyOutside = 1, kCtrlChanged = 2, kCtrlError
               kCtrlRound = 5, kCtrlChanged2 = 6, kCtrlAnyOutside2 = 7, kCtrlAccepted2 = 9 /* the round's values, published by
               k_commit for the host while the live counters are cleared for the next round; [8] = staged face counter */,
               kCtrlFront = 10 /* [10..12]: three rotating frontier counters of the ownership sweeps */,
+              kCtrlNLive = 14 /* entries of the live-point list */,
               kCtrlInts = 16;
 constexpr int kErrCapacity = 1, kErrFlat = 2, kErrTopology = 4, kErrNaN = 8;
 
@@ -72,6 +73,9 @@ struct Bufs {
     int* seg_start;        // nseg + 1   first position of each segment in the compacted vertex list
     int* seg_cnt;          // nseg
     int* idx_all;          // M1 (batched result staging)
+    // points still outside some face, in position order; shrinks as the hull grows and is compacted every few rounds, so
+    // that the per-round point kernels walk the tens of thousands of live points of the late rounds, not all M1
+    int *live, *live2;     // M1 each
     // spatial order: the points are worked on in Morton order of their position inside the segment's bounding box, so
     // that the lanes of a wave hold neighbouring points — which share conflict faces and new-face lists for the whole
     // build (coalesced, mostly wave-uniform reads instead of 64 scattered lists per wave).  px/py/pz, pface and the
@@ -137,6 +141,8 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * (nseg + 1)); if (b) b->seg_start = (int*)p;
     p = take(sizeof(int) * nseg); if (b) b->seg_cnt = (int*)p;
     p = take(sizeof(int) * (nseg > 1 ? m1 : 1)); if (b) b->idx_all = (int*)p;
+    p = take(sizeof(int) * m1); if (b) b->live = (int*)p;
+    p = take(sizeof(int) * m1); if (b) b->live2 = (int*)p;
     p = take(sizeof(int) * m1); if (b) b->perm = (int*)p;
     p = take(sizeof(int) * m1); if (b) b->inv = (int*)p;
     p = take(sizeof(unsigned long long) * m1); if (b) b->keys = (unsigned long long*)p;
@@ -391,9 +397,11 @@ k_load(Bufs b, const float* __restrict__ pts, int with_origin) {
         b.inv[e] = j;
         b.pface[j] = kNone;
         b.vflag[j] = 0;
+        b.live[j] = j;
     }
     if (blockIdx.x == 0 && threadIdx.x < kCtrlInts)
-        b.ctrl[threadIdx.x] = (threadIdx.x == kCtrlNFaces || threadIdx.x == kCtrlNFaces + 8) ? 4 * b.nseg : 0;
+        b.ctrl[threadIdx.x] = (threadIdx.x == kCtrlNFaces || threadIdx.x == kCtrlNFaces + 8) ? 4 * b.nseg
+                                                                                         : (threadIdx.x == kCtrlNLive ? b.m1 : 0);
 }
 
 // block-wide argmax of (key, lowest index on ties); all threads get the winner
@@ -538,8 +546,10 @@ __global__ void __launch_bounds__(TO_BLOCK) k_round_reset(Bufs b) {
 __global__ void __launch_bounds__(TO_BLOCK) k_far_arg(Bufs b, int all_faces) {
     // inside a round the published face count is still the count before this round's insertions
     const int f_lo = all_faces ? 0 : b.ctrl[kCtrlNFaces];
+    const int nlive = b.ctrl[kCtrlNLive];
     const int stride = gridDim.x * TO_BLOCK;
-    for (int i = blockIdx.x * TO_BLOCK + threadIdx.x; i < b.m1; i += stride) {
+    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < nlive; j += stride) {
+        const int i = b.live[j];
         const int f = b.pface[i];
         if (f < f_lo) continue;
         if (dkey(fdist(b, f, i)) == b.fmax[f]) atomicMin(&b.fapex[f], b.perm[i]);
@@ -737,11 +747,13 @@ __global__ void __launch_bounds__(TO_BLOCK) k_reassign(Bufs b) {
     __shared__ FaceMaxTable tab;
     face_max_init(tab);
     const int stride = gridDim.x * TO_BLOCK;
-    const int nloop = (b.m1 + stride - 1) / stride;
+    const int nlive = b.ctrl[kCtrlNLive];
+    const int nloop = (nlive + stride - 1) / stride;
     for (int it = 0; it < nloop; ++it) {
-        const int i = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
+        const int j = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
+        const int i = j < nlive ? b.live[j] : 0;
         double best = 0.0; int bf = kNone;
-        const int g = i < b.m1 ? b.pface[i] : kNone;
+        const int g = j < nlive ? b.pface[i] : kNone;
         int o;
         if (g >= 0 && owned_accepted(b, g, &o)) {
             if (b.perm[i] != b.fapex[o]) {
@@ -800,6 +812,40 @@ __global__ void __launch_bounds__(TO_BLOCK) k_mark_vertices(Bufs b) {
             for (int k = 0; k < 3; ++k) b.vflag[b.perm[b.fv[3 * f + k]]] = 1;  // flags in the caller's (expanded) numbering
 }
 
+// ---- compaction of the live-point list (ordered: the Morton locality stays) -----------------------
+__global__ void __launch_bounds__(TO_BLOCK) k_live_count(Bufs b, int nlive, int* __restrict__ tile_cnt) {
+    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
+    const int tile0 = blockIdx.x * 1024;
+    int cnt = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int j = tile0 + k * TO_BLOCK + threadIdx.x;
+        cnt += __popcll(__ballot(j < nlive && b.pface[b.live[j]] >= 0));
+    }
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+__global__ void __launch_bounds__(TO_BLOCK) k_live_write(Bufs b, int nlive_old, const int* __restrict__ tile_off) {
+    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile0 = blockIdx.x * 1024;
+    int base = tile_off[blockIdx.x];
+    for (int k = 0; k < 4; ++k) {
+        const int j = tile0 + k * TO_BLOCK + threadIdx.x;
+        const int i = j < nlive_old ? b.live[j] : 0;
+        const bool keep = j < nlive_old && b.pface[i] >= 0;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (keep) b.live2[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
 // ---- ordered compaction of the flagged indices (same scheme as the frustum cull) ----------------
 __global__ void __launch_bounds__(TO_BLOCK) k_flag_count(const int* __restrict__ flag, int n, int* __restrict__ tile_cnt) {
     __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
@@ -856,7 +902,8 @@ inline int nblocks(int64_t n, int cap = 2048) {
 
 // Builds the hull of pts (n,3) [+ origin]; leaves vflag set.  Synchronises the stream.
 // b.seg_off must already be on the device (k_single_segment for one hull).
-static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t st, int* rounds_out) {
+static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_t st, int* rounds_out) {
+    Bufs b = b_in;  // local copy: the two live-point buffers swap roles at every compaction
     k_bbox_init<<<(6 * b.nseg + TO_BLOCK - 1) / TO_BLOCK, TO_BLOCK, 0, st>>>(b);
     k_bbox<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b, pts, with_origin);
     k_sort_keys<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, pts, with_origin);
@@ -893,9 +940,10 @@ static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t s
     // block on the device and walks its arrays with a grid stride, so the host's (stale) counts only size the grids.
     // A round enqueued after the hull is complete finds no candidate and changes nothing.
     const int batch = 4;
+    int batches_since_compaction = 0, live_bound = b.m1;
     while (round < max_rounds) {
         const int nrounds = careful ? 1 : batch;
-        const int gf = nblocks((int64_t)nf * 2), gp = nblocks(b.m1);
+        const int gf = nblocks((int64_t)nf * 2);
         for (int r = 0; r < nrounds; ++r, ++round) {
             k_round_reset<<<gf, TO_BLOCK, 0, st>>>(b);
             TO_HIP_CHECK_LAUNCH();
@@ -925,8 +973,8 @@ static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t s
             k_accept<<<gf, TO_BLOCK, 0, st>>>(b, last_front);
             k_new_faces<<<gf, TO_BLOCK, 0, st>>>(b);
             k_link_faces<<<gf, TO_BLOCK, 0, st>>>(b);
-            k_reassign<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
-            k_far_arg<<<gp, TO_BLOCK, 0, st>>>(b, 0);  // apexes of the faces created this round
+            k_reassign<<<nblocks(live_bound, 1024), TO_BLOCK, 0, st>>>(b);
+            k_far_arg<<<nblocks(live_bound), TO_BLOCK, 0, st>>>(b, 0);  // apexes of the faces created this round
             k_kill_faces<<<gf, TO_BLOCK, 0, st>>>(b);
             k_commit<<<nblocks((int64_t)nf * 4), TO_BLOCK, 0, st>>>(b);
             TO_HIP_CHECK_LAUNCH();
@@ -938,6 +986,17 @@ static int build(const Bufs& b, const float* pts, int with_origin, hipStream_t s
         if (h[kCtrlError]) return (h[kCtrlError] & kErrCapacity) ? TOHIP_ENOSPC : TOHIP_ENOTCONV;
         nf = h[kCtrlNFaces];
         if (!h[kCtrlAnyOutside2]) break;  // the last round found no point outside any face: the hull is complete
+        if (++batches_since_compaction >= 2 && h[kCtrlNLive] > 4096) {
+            // drop the points that have retired inside the hull from the list the point kernels walk
+            const int nlive = h[kCtrlNLive], ntl = (nlive + 1023) / 1024;
+            k_live_count<<<ntl, TO_BLOCK, 0, st>>>(b, nlive, b.tile_cnt);
+            k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(b.tile_cnt, ntl, b.tile_off, b.ctrl + kCtrlNLive);
+            k_live_write<<<ntl, TO_BLOCK, 0, st>>>(b, nlive, b.tile_off);
+            TO_HIP_CHECK_LAUNCH();
+            int* t = b.live; b.live = b.live2; b.live2 = t;
+            batches_since_compaction = 0;
+            live_bound = nlive;  // the new count is on the device only; this bounds it
+        }
         if (h[kCtrlAccepted2] <= 0) {
             if (careful) return TOHIP_ENOTCONV;  // converged ownership always admits the best candidate: inconsistent predicates
             careful = true;
