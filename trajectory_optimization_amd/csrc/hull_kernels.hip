@@ -33,6 +33,7 @@ constexpr int kCtrlNFaces = 0, kCtrlAnyOutside = 1, kCtrlChanged = 2, kCtrlError
               k_commit for the host while the live counters are cleared for the next round; [8] = staged face counter */,
               kCtrlFront = 10 /* [10..12]: three rotating frontier counters of the ownership sweeps */,
               kCtrlNLive = 14 /* entries of the live-point list */,
+              kCtrlNAlive = 13 /* entries of the alive-face list */, kCtrlNFc = 15 /* face count when that list was made */,
               kCtrlInts = 16;
 constexpr int kErrCapacity = 1, kErrFlat = 2, kErrTopology = 4, kErrNaN = 8;
 
@@ -62,6 +63,7 @@ struct Bufs {
     int* vflag;            // M1
     int* tile_cnt;         // ntiles(M1)
     int* tile_off;         // ntiles(M1)
+    int *ftile_cnt, *ftile_off;  // ntiles(fcap): scan scratch of the alive-face compaction
     float* flipped;        // 3 * M (only used by hidden_pts_removal)
     int* flip_max;         // nseg
     // segments: independent point sets (one hull each) laid end to end; segment s owns the expanded indices
@@ -76,6 +78,9 @@ struct Bufs {
     // points still outside some face, in position order; shrinks as the hull grows and is compacted every few rounds, so
     // that the per-round point kernels walk the tens of thousands of live points of the late rounds, not all M1
     int *live, *live2;     // M1 each
+    // faces alive at the last compaction, ascending; the per-round face kernels walk this list and then the ids created
+    // since (a contiguous range) instead of every face ever created (three quarters of which are dead by the end)
+    int *alist, *alist2;   // fcap each
     // spatial order: the points are worked on in Morton order of their position inside the segment's bounding box, so
     // that the lanes of a wave hold neighbouring points — which share conflict faces and new-face lists for the whole
     // build (coalesced, mostly wave-uniform reads instead of 64 scattered lists per wave).  px/py/pz, pface and the
@@ -98,8 +103,8 @@ __host__ inline size_t seg(size_t bytes) { return align_up(bytes, 256); }
 // The default suits clouds whose hull is a small fraction of the points (HPR of a scene: 2-5 %); a build that runs out
 // returns TOHIP_ENOSPC and the caller retries with a larger workspace — every byte beyond the fixed part is used for
 // faces (faces_for_bytes), up to the never-exceeded-in-practice 8 per point.
-constexpr size_t kBytesPerFace = 16 * sizeof(int) + sizeof(double) + 64;  // the per-face arrays carved below
-constexpr int kFaceArrays = 16;
+constexpr size_t kBytesPerFace = 18 * sizeof(int) + sizeof(double) + 64 + 1;  // the per-face arrays carved below (+ scan scratch)
+constexpr int kFaceArrays = 20;
 
 __host__ inline int default_face_capacity(int64_t m1, int64_t nseg) {
     int64_t c = m1 / 2 + 64 * nseg + 4096;
@@ -129,10 +134,14 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * (size_t)fcap); if (b) b->front[0] = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->front[1] = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->fstamp = (int*)p;
+    p = take(sizeof(int) * (size_t)fcap); if (b) b->alist = (int*)p;
+    p = take(sizeof(int) * (size_t)fcap); if (b) b->alist2 = (int*)p;
     p = take(sizeof(int) * kCtrlInts); if (b) b->ctrl = (int*)p;
     p = take(sizeof(int) * m1); if (b) b->vflag = (int*)p;
     p = take(sizeof(int) * ntiles); if (b) b->tile_cnt = (int*)p;
     p = take(sizeof(int) * ntiles); if (b) b->tile_off = (int*)p;
+    p = take(sizeof(int) * (((size_t)fcap + 1023) / 1024)); if (b) b->ftile_cnt = (int*)p;
+    p = take(sizeof(int) * (((size_t)fcap + 1023) / 1024)); if (b) b->ftile_off = (int*)p;
     p = take(sizeof(float) * 3 * (size_t)n_points); if (b) b->flipped = (float*)p;
     p = take(sizeof(int) * nseg); if (b) b->flip_max = (int*)p;
     p = take(sizeof(int) * (nseg + 1)); if (b) b->seg_off = (int*)p;
@@ -280,6 +289,22 @@ __device__ __forceinline__ int find_seg(const Bufs& b, int i) {
         if (b.seg_off[mid] <= i) lo = mid; else hi = mid;
     }
     return lo;
+}
+
+// The faces a per-round kernel has to look at: the alive list of the last compaction, then the ids created since.
+// Before the first compaction the list is empty and the range starts at 0: every id.
+struct FaceWalk {
+    int nal, nfc, total;
+};
+__device__ __forceinline__ FaceWalk face_walk(const Bufs& b, int nf_upper) {
+    FaceWalk w;
+    w.nal = b.ctrl[kCtrlNAlive];
+    w.nfc = b.ctrl[kCtrlNFc];
+    w.total = w.nal + (nf_upper - w.nfc);
+    return w;
+}
+__device__ __forceinline__ int face_at(const Bufs& b, const FaceWalk& w, int j) {
+    return j < w.nal ? b.alist[j] : w.nfc + (j - w.nal);
 }
 
 __global__ void k_single_segment(Bufs b) { b.seg_off[0] = 0; b.seg_off[1] = b.m1; }
@@ -526,10 +551,11 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
 // ---- round --------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TO_BLOCK) k_round_reset(Bufs b) {
     // per-round state of every face; faces that still have points outside them become candidates (owner = self)
-    const int nf = b.ctrl[kCtrlNFaces];
+    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
     const int stride = gridDim.x * TO_BLOCK;
     bool any = false;
-    for (int f = blockIdx.x * TO_BLOCK + threadIdx.x; f < nf; f += stride) {
+    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
+        const int f = face_at(b, fw, j);
         const int alive = b.fflags[f] & 1;
         const bool cand = alive && b.fapex[f] != 0x7fffffff;  // fmax / fapex persist: an outside set is fixed at creation
         b.fowner[f] = cand ? f : kNone;
@@ -566,7 +592,8 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_push(Bufs b, int sweep, int 
     const int round = b.ctrl[kCtrlRound];
     const int* __restrict__ in = b.front[sweep & 1];
     int* __restrict__ out = b.front[(sweep + 1) & 1];
-    const int n_in = sweep == 0 ? b.ctrl[kCtrlNFaces] : min(b.ctrl[kCtrlFront + sweep % 3], b.fcap);
+    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
+    const int n_in = sweep == 0 ? fw.total : min(b.ctrl[kCtrlFront + sweep % 3], b.fcap);
     int* out_cnt = &b.ctrl[kCtrlFront + (sweep + 1) % 3];
     if (blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlFront + (sweep + 2) % 3] = 0;
     const int stride = gridDim.x * TO_BLOCK;
@@ -577,7 +604,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_push(Bufs b, int sweep, int 
         int want = 0;
         int g = kNone;
         if (q < n_in) {
-            if (sweep == 0) { if (b.fflags[q] & 2) g = q; }
+            if (sweep == 0) { const int f = face_at(b, fw, q); if (b.fflags[f] & 2) g = f; }
             else g = in[q];
         }
         if (g >= 0) {
@@ -624,10 +651,12 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_push(Bufs b, int sweep, int 
 
 // each live face adopts the best-priority owner among its neighbours whose apex sees it
 __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b) {
-    const int nf = b.ctrl[kCtrlNFaces], round = b.ctrl[kCtrlRound];
+    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
+    const int round = b.ctrl[kCtrlRound];
     const int stride = gridDim.x * TO_BLOCK;
     bool changed = false;
-    for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf; g += stride) {
+    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
+        const int g = face_at(b, fw, j);
         if (!(b.fflags[g] & 1)) continue;
         int best = b.fowner[g];
         unsigned long long bp = best >= 0 ? prio(best, round) : ~0ull;
@@ -643,11 +672,13 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b) {
 }
 
 __global__ void __launch_bounds__(TO_BLOCK) k_accept(Bufs b, int last_front) {
-    const int nf = b.ctrl[kCtrlNFaces], round = b.ctrl[kCtrlRound];
+    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
+    const int round = b.ctrl[kCtrlRound];
     // faces still queued after the last push sweep = ownership not converged (the host adapts the sweep count)
     if (last_front >= 0 && blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlChanged] = b.ctrl[kCtrlFront + last_front] > 0;
     const int stride = gridDim.x * TO_BLOCK;
-    for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf; g += stride) {
+    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
+        const int g = face_at(b, fw, j);
         if (!(b.fflags[g] & 1)) continue;
         const int o = b.fowner[g];
         if (o < 0) continue;
@@ -674,14 +705,15 @@ __device__ __forceinline__ bool owned_accepted(const Bufs& b, int g, int* owner)
 
 // one new triangle (u, v, apex) per horizon edge (u, v) of an accepted region
 __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b) {
-    const int nf = b.ctrl[kCtrlNFaces];
+    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
     const int stride = gridDim.x * TO_BLOCK;
-    const int nloop = (nf + stride - 1) / stride;
+    const int nloop = (fw.total + stride - 1) / stride;
     for (int it = 0; it < nloop; ++it) {
-        const int g = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
+        const int j = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
+        const int g = j < fw.total ? face_at(b, fw, j) : kNone;
         int o = kNone, want = 0;
         bool hor[3] = {false, false, false};
-        if (g < nf && (b.fflags[g] & 1) && owned_accepted(b, g, &o)) {
+        if (g >= 0 && (b.fflags[g] & 1) && owned_accepted(b, g, &o)) {
             for (int k = 0; k < 3; ++k) { hor[k] = b.fowner[b.fn[3 * g + k]] != o; want += hor[k]; }
         } else {
             o = kNone;
@@ -713,9 +745,10 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b) {
 
 // sibling links: rotate around the horizon vertex v through the region's faces to the next horizon edge
 __global__ void __launch_bounds__(TO_BLOCK) k_link_faces(Bufs b) {
-    const int nf_before = b.ctrl[kCtrlNFaces];
+    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);  // the published count: the faces that existed before this round
     const int stride = gridDim.x * TO_BLOCK;
-    for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf_before; g += stride) {
+    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
+        const int g = face_at(b, fw, j);
         if (!(b.fflags[g] & 1)) continue;
         int o;
         if (!owned_accepted(b, g, &o)) continue;
@@ -774,9 +807,10 @@ __global__ void __launch_bounds__(TO_BLOCK) k_reassign(Bufs b) {
 }
 
 __global__ void __launch_bounds__(TO_BLOCK) k_kill_faces(Bufs b) {
-    const int nf_before = b.ctrl[kCtrlNFaces];
+    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
     const int stride = gridDim.x * TO_BLOCK;
-    for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf_before; g += stride) {
+    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
+        const int g = face_at(b, fw, j);
         int o;
         if ((b.fflags[g] & 1) && owned_accepted(b, g, &o)) b.newface[3 * g] = -2;  // mark; cleared in k_commit
     }
@@ -785,10 +819,12 @@ __global__ void __launch_bounds__(TO_BLOCK) k_kill_faces(Bufs b) {
 __global__ void __launch_bounds__(TO_BLOCK) k_commit(Bufs b) {
     // bound: the staged count (final since k_new_faces ended) — the published one is rewritten below while other blocks
     // of this kernel may still be starting; faces created this round carry no kill mark
-    const int nf_all = min(b.ctrl[kCtrlNFaces + 8], b.fcap);
+    const FaceWalk fw = face_walk(b, min(b.ctrl[kCtrlNFaces + 8], b.fcap));
     const int stride = gridDim.x * TO_BLOCK;
-    for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf_all; g += stride)
+    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
+        const int g = face_at(b, fw, j);
         if (b.newface[3 * g] == -2) { b.fflags[g] = 0; b.newface[3 * g] = kNone; }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int nf = b.ctrl[kCtrlNFaces + 8];
         if (nf > b.fcap) nf = b.fcap;
@@ -845,6 +881,44 @@ __global__ void __launch_bounds__(TO_BLOCK) k_live_write(Bufs b, int nlive_old, 
         __syncthreads();
     }
 }
+
+// ---- compaction of the alive-face list: walk (old list + ids since), keep the alive ones, ascending ----------
+__global__ void __launch_bounds__(TO_BLOCK) k_alive_count(Bufs b, int nal, int nfc, int total, int* __restrict__ tile_cnt) {
+    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
+    const int tile0 = blockIdx.x * 1024;
+    int cnt = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int j = tile0 + k * TO_BLOCK + threadIdx.x;
+        const int f = j < total ? (j < nal ? b.alist[j] : nfc + (j - nal)) : 0;
+        cnt += __popcll(__ballot(j < total && (b.fflags[f] & 1)));
+    }
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_alive_write(Bufs b, int nal, int nfc, int total, const int* __restrict__ tile_off) {
+    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile0 = blockIdx.x * 1024;
+    int base = tile_off[blockIdx.x];
+    for (int k = 0; k < 4; ++k) {
+        const int j = tile0 + k * TO_BLOCK + threadIdx.x;
+        const int f = j < total ? (j < nal ? b.alist[j] : nfc + (j - nal)) : 0;
+        const bool keep = j < total && (b.fflags[f] & 1);
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (keep) b.alist2[off + __popcll(bal & ((1ull << lane) - 1ull))] = f;
+        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
+__global__ void k_set_int(int* p, int v) { *p = v; }
 
 // ---- ordered compaction of the flagged indices (same scheme as the frustum cull) ----------------
 __global__ void __launch_bounds__(TO_BLOCK) k_flag_count(const int* __restrict__ flag, int n, int* __restrict__ tile_cnt) {
@@ -941,6 +1015,8 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
     // A round enqueued after the hull is complete finds no candidate and changes nothing.
     const int batch = 4;
     int batches_since_compaction = 0, live_bound = b.m1;
+    const int face_tiles_cap = (b.fcap + 1023) / 1024;
+
     while (round < max_rounds) {
         const int nrounds = careful ? 1 : batch;
         const int gf = nblocks((int64_t)nf * 2);
@@ -996,6 +1072,15 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
             int* t = b.live; b.live = b.live2; b.live2 = t;
             batches_since_compaction = 0;
             live_bound = nlive;  // the new count is on the device only; this bounds it
+            // and the faces: walk = (alive list of the last compaction) + (ids created since); keep the alive ones
+            const int nal = h[kCtrlNAlive], nfc = h[kCtrlNFc], total = nal + (nf - nfc), ntf = (total + 1023) / 1024;
+            if (ntf > face_tiles_cap) return TOHIP_ENOSPC;
+            k_alive_count<<<ntf, TO_BLOCK, 0, st>>>(b, nal, nfc, total, b.ftile_cnt);
+            k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(b.ftile_cnt, ntf, b.ftile_off, b.ctrl + kCtrlNAlive);
+            k_alive_write<<<ntf, TO_BLOCK, 0, st>>>(b, nal, nfc, total, b.ftile_off);
+            k_set_int<<<1, 1, 0, st>>>(b.ctrl + kCtrlNFc, nf);
+            TO_HIP_CHECK_LAUNCH();
+            t = b.alist; b.alist = b.alist2; b.alist2 = t;
         }
         if (h[kCtrlAccepted2] <= 0) {
             if (careful) return TOHIP_ENOTCONV;  // converged ownership always admits the best candidate: inconsistent predicates
