@@ -105,6 +105,12 @@ int tohip_traj_forward(const void *packed, int64_t n_points, const float *poses,
 int tohip_inverse_permutation(const void *packed, int64_t n_points, int32_t *inv_perm, void *stream);
 int tohip_occlusion_row(int64_t n_points, const int32_t *inv_perm, const int32_t *kept_idx, const int32_t *kept_count,
                         const int32_t *visible_idx_in_kept, const int32_t *visible_count, uint32_t *row, void *stream);
+/* The same for n_wps waypoints in three launches.  kept_idx (n_wps, n): waypoint w's kept points in its first kept_count[w]
+ * entries (the layout tohip_cull_waypoints writes); vis_idx: the visible ones as positions in that list, waypoint w's in
+ * [vis_off[w], vis_off[w+1]) (n_wps+1 device int32); all_visible[w] != 0: nothing of w is occluded.  rows: (n_wps, Npad/32). */
+int tohip_occlusion_rows(int64_t n_points, const int32_t *inv_perm, const int32_t *kept_idx, const int32_t *kept_count,
+                         const int32_t *vis_idx, const int32_t *vis_off, const int32_t *all_visible, int64_t n_wps,
+                         uint32_t *rows, void *stream);
 
 /* rewards[0..N) = sigmoid(lo_sum) in the CALLER'S point order (model.py:237); scalars[0] = mean(rewards),
  * scalars[1] = loss_vis = 1/(mean+eps) (model.py:246), scalars[2] = -loss_vis^2/N (d loss_vis / d reward_n). */

@@ -42,6 +42,7 @@ SIGNATURES = {
     "tohip_traj_forward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig),
                                            ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_inverse_permutation": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "tohip_occlusion_rows": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "tohip_occlusion_row": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tohip_traj_reward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_f, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_traj_backward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig),

@@ -1000,6 +1000,59 @@ __global__ void k_occ_set_visible(const int* __restrict__ inv, const int32_t* __
     }
 }
 
+// all waypoints' rows in three launches: grid.y = waypoint.  kept_idx (W, n): waypoint w's kept points in its first
+// kept_count[w] entries; vis_idx: the visible ones among them as positions in that list, waypoint w's in
+// [vis_off[w], vis_off[w+1]); all_visible[w] != 0: nothing of w is occluded (its row stays all ones).
+__global__ void k_occ_rows_clear(const int* __restrict__ inv, const int32_t* __restrict__ kept_idx, int64_t n,
+                                 const int32_t* __restrict__ kept_count, const int32_t* __restrict__ all_visible,
+                                 uint32_t* __restrict__ rows, int64_t roww) {
+    const int w = blockIdx.y;
+    if (all_visible[w]) return;
+    const int m = kept_count[w];
+    const int32_t* k = kept_idx + (int64_t)w * n;
+    uint32_t* row = rows + (int64_t)w * roww;
+    const int stride = gridDim.x * blockDim.x;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const int s = inv[k[j]];
+        atomicAnd(&row[s >> 5], ~(1u << (s & 31)));
+    }
+}
+
+__global__ void k_occ_rows_set(const int* __restrict__ inv, const int32_t* __restrict__ kept_idx, int64_t n,
+                               const int32_t* __restrict__ vis_idx, const int32_t* __restrict__ vis_off,
+                               const int32_t* __restrict__ all_visible, uint32_t* __restrict__ rows, int64_t roww) {
+    const int w = blockIdx.y;
+    if (all_visible[w]) return;
+    const int j0 = vis_off[w], j1 = vis_off[w + 1];
+    const int32_t* k = kept_idx + (int64_t)w * n;
+    uint32_t* row = rows + (int64_t)w * roww;
+    const int stride = gridDim.x * blockDim.x;
+    for (int j = j0 + blockIdx.x * blockDim.x + threadIdx.x; j < j1; j += stride) {
+        const int s = inv[k[vis_idx[j]]];
+        atomicOr(&row[s >> 5], 1u << (s & 31));
+    }
+}
+
+extern "C" int tohip_occlusion_rows(int64_t n, const int32_t* inv_perm, const int32_t* kept_idx, const int32_t* kept_count,
+                                    const int32_t* vis_idx, const int32_t* vis_off, const int32_t* all_visible, int64_t n_wps,
+                                    uint32_t* rows, void* stream_) {
+    if (!inv_perm || !kept_idx || !kept_count || !vis_idx || !vis_off || !all_visible || !rows || n <= 0 || n_wps <= 0 ||
+        n_wps > 65535)
+        return TOHIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    const int64_t roww = tohip_padded_points(n) / 32;
+    hipError_t e = hipMemsetAsync(rows, 0xff, (size_t)roww * (size_t)n_wps * sizeof(uint32_t), st);
+    if (e != hipSuccess) return (int)e;
+    int nb = (int)((n + 255) / 256);
+    if (nb > 256) nb = 256;
+    const dim3 grid((unsigned)nb, (unsigned)n_wps);
+    k_occ_rows_clear<<<grid, 256, 0, st>>>(inv_perm, kept_idx, n, kept_count, all_visible, rows, roww);
+    TO_HIP_CHECK_LAUNCH();
+    k_occ_rows_set<<<grid, 256, 0, st>>>(inv_perm, kept_idx, n, vis_idx, vis_off, all_visible, rows, roww);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
 extern "C" int tohip_inverse_permutation(const void* packed, int64_t n, int32_t* inv, void* stream_) {
     if (!packed || !inv || n <= 0) return TOHIP_EINVAL;
     const CloudView cv = cloud_view(packed, n);

@@ -6,6 +6,8 @@ nothing falls back to torch ops when the library is missing.
 """
 import ctypes
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -225,15 +227,18 @@ def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method=
                 if kept_idx[w].numel() >= 4:
                     vis[w] = (idx[int(voff[j]):int(voff[j + 1])] - offs[j]).contiguous()
             w0 = w1
-    for w in range(W):
-        m = kept_idx[w].numel()
-        v = vis[w] if vis[w] is not None else torch.arange(m, dtype=torch.int32, device=dev)  # < 4 points: nothing to occlude
-        kc = torch.tensor([m], dtype=torch.int32, device=dev)
-        vc = torch.tensor([v.numel()], dtype=torch.int32, device=dev)
-        kk = kept_idx[w] if m > 0 else kept
+    # all rows in three launches: the visible positions of every waypoint end to end, with their offsets
+    all_visible = torch.tensor([1 if vis[w] is None else 0 for w in range(W)], dtype=torch.int32, device=dev)  # < 4 kept points
+    lens = [0 if vis[w] is None else int(vis[w].numel()) for w in range(W)]
+    vis_off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=dev)
+    parts = [vis[w] for w in range(W) if vis[w] is not None and vis[w].numel() > 0]
+    vis_cat = torch.cat(parts).to(torch.int32).contiguous() if parts else torch.zeros(1, dtype=torch.int32, device=dev)
+    for w0 in range(0, W, 65535):
+        w1 = min(W, w0 + 65535)
         with torch.cuda.device(dev):
-            check(L.tohip_occlusion_row(n, ptr(cloud.inv_perm), ptr(kk), ptr(kc), ptr(v if v.numel() else kept), ptr(vc),
-                                        ptr(rows[w]), stream_ptr()), "tohip_occlusion_row")
+            check(L.tohip_occlusion_rows(n, ptr(cloud.inv_perm), ptr(kept_all[w0:w1]), ptr(kcnt_all[w0:w1]), ptr(vis_cat),
+                                         ptr(vis_off[w0:w1 + 1]), ptr(all_visible[w0:w1]), w1 - w0, ptr(rows[w0:w1]), stream_ptr()),
+                  "tohip_occlusion_rows")
     return rows
 
 
