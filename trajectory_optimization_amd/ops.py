@@ -181,23 +181,9 @@ def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method=
     W = poses.shape[0]
     rows = torch.empty((W, cloud.npad // 32), dtype=torch.int32, device=dev)
     n = cloud.n
-    # transform -> cull -> gather for all waypoints in three launches (tohip_cull_waypoints); the kept counts are fetched
-    # once; the per-waypoint buffers are sized for the worst case (16 B per point and waypoint: 2 GB at 1 M x 128)
-    kept_all = torch.empty((W, max(n, 1)), dtype=torch.int32, device=dev)
-    pts_all = torch.empty((W, max(n, 1), 3), dtype=torch.float32, device=dev)
-    kcnt_all = torch.zeros(W, dtype=torch.int32, device=dev)
-    pts_in = points.detach().to(torch.float32).contiguous()
-    p_in, q_in = poses.detach().to(torch.float32).contiguous(), quats.detach().to(torch.float32).contiguous()
-    for w0 in range(0, W, 65535):  # grid.y limit
-        w1 = min(W, w0 + 65535)
-        wsb = L.tohip_cull_waypoints_workspace_bytes(n, w1 - w0)
-        fws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            check(L.tohip_cull_waypoints(ptr(pts_in), n, ptr(p_in[w0:w1]), ptr(q_in[w0:w1]), w1 - w0, 1, cam.ref(), float(min_dist),
-                                         float(max_dist), ptr(kept_all[w0:w1]), ptr(pts_all[w0:w1]), ptr(kcnt_all[w0:w1]), ptr(fws),
-                                         wsb, stream_ptr()), "tohip_cull_waypoints")
-    counts = kcnt_all.cpu().tolist()  # the one synchronisation of the cull stage
-    kept = kept_all[0]
+    # transform -> cull -> gather for all waypoints in three launches; the per-waypoint buffers are sized for the worst case
+    # (16 B per point and waypoint: 2 GB at 1 M x 128)
+    kept_all, pts_all, counts, kcnt_all = cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True)
     kept_idx = [kept_all[w, :counts[w]] for w in range(W)]
     kept_pts = [pts_all[w, :counts[w]] for w in range(W)]
     vis = [None] * W
@@ -240,6 +226,30 @@ def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method=
                                          ptr(vis_off[w0:w1 + 1]), ptr(all_visible[w0:w1]), w1 - w0, ptr(rows[w0:w1]), stream_ptr()),
                   "tohip_occlusion_rows")
     return rows
+
+
+def cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True):
+    """Exact transform + hard frustum cull of `points` (N,3) for W poses at once (tohip_cull_waypoints).
+    -> (kept_idx (W,N) int32, kept_pts (W,N,3) f32 camera frame, counts list[int], counts on the device (W,) int32): pose
+    w's kept points are the first counts[w] rows of kept_idx[w] / kept_pts[w], in input order.  One host synchronisation
+    (the counts)."""
+    _require_cuda(points, "points")
+    pts = points.detach().to(torch.float32).contiguous()
+    dev, n, W = pts.device, pts.shape[0], poses.shape[0]
+    p_in, q_in = poses.detach().to(torch.float32).contiguous(), quats.detach().to(torch.float32).contiguous()
+    kept_all = torch.empty((W, max(n, 1)), dtype=torch.int32, device=dev)
+    pts_all = torch.empty((W, max(n, 1), 3), dtype=torch.float32, device=dev)
+    kcnt_all = torch.zeros(W, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    for w0 in range(0, W, 65535):  # grid.y limit
+        w1 = min(W, w0 + 65535)
+        wsb = L.tohip_cull_waypoints_workspace_bytes(n, w1 - w0)
+        fws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(L.tohip_cull_waypoints(ptr(pts), n, ptr(p_in[w0:w1]), ptr(q_in[w0:w1]), w1 - w0, int(bool(normalize)), cam.ref(),
+                                         float(min_dist), float(max_dist), ptr(kept_all[w0:w1]), ptr(pts_all[w0:w1]),
+                                         ptr(kcnt_all[w0:w1]), ptr(fws), wsb, stream_ptr()), "tohip_cull_waypoints")
+    return kept_all, pts_all, kcnt_all.cpu().tolist(), kcnt_all
 
 
 def to_camera_frame_exact(points, quat, trans, normalize=True, transpose=False):

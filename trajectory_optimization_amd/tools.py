@@ -113,15 +113,19 @@ def visible_points_from_cameras(points, trans, quats, intrins, img_height, img_w
     """visible_points_from_camera for C cameras at once (the reference repeats the pipeline per camera topic,
     /root/reference/src/pc_processor.py:57-59,158-187): per camera transform -> hard cull, then ONE batched hull pass
     for all cameras.  trans (C,3), quats (C,4) wxyz.  -> list of dicts as visible_points_from_camera returns."""
-    trans = torch.as_tensor(trans, dtype=torch.float32).reshape(-1, 3)
-    quats = torch.as_tensor(quats, dtype=torch.float32).reshape(-1, 4)
+    pts = torch.as_tensor(points, dtype=torch.float32)
+    dev = pts.device
+    trans = torch.as_tensor(trans, dtype=torch.float32).reshape(-1, 3).to(dev).contiguous()
+    quats = torch.as_tensor(quats, dtype=torch.float32).reshape(-1, 4).to(dev).contiguous()
     intr = torch.as_tensor(intrins, dtype=torch.float32)[:3, :3]
     cam = ops.Camera(intr, img_width, img_height, 1.0, 5.0)
+    C, n = trans.shape[0], pts.shape[0]
+    # transform + hard cull of every camera in one batched call (quaternions NOT normalised: ego_to_cam_torch)
+    kept_idx, kept_pts, counts, _ = ops.cull_waypoints(pts, trans, quats, cam, min_dist, max_dist, normalize=False)
     out = []
-    for c in range(trans.shape[0]):
-        cam_pts = ego_to_cam(points, trans[c], quats[c])
-        _, _, kept_idx = ops.frustum_cull(cam_pts, cam, min_dist, max_dist)
-        out.append(dict(cam_points=cam_pts, kept_idx=kept_idx, kept_points=cam_pts[:, kept_idx.long()].T.contiguous()))
+    for c in range(C):
+        m = counts[c]
+        out.append(dict(cam_points=ego_to_cam(pts, trans[c], quats[c]), kept_idx=kept_idx[c, :m], kept_points=kept_pts[c, :m]))
     offs = [0]
     for r in out:
         offs.append(offs[-1] + r["kept_points"].shape[0])
