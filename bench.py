@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bench.py — point-visibility evaluations/s (fwd+bwd) of the HIP hot path on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W     -> ONE JSON line on rank 0.
@@ -7,12 +6,20 @@ For N>1 the driver launches it under torch.distributed.run, one rank per GPU (RC
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): a 1 M-point synthetic
 cloud x 128 waypoints per GPU, full forward + backward to (x,y,z) and quaternion gradients, through the
 C ABI of include/trajopt_hip.h.  One "step" = tohip_traj_forward -> [all-reduce of the log-odds vector when
-N>1, overlapped with tohip_traj_backward_scan] -> tohip_traj_reward -> tohip_traj_backward [-> all-gather of the (W,7) gradient rows when N>1].  With N GPUs the trajectory has 128*N waypoints sharded
-contiguously over the ranks (weak scaling; N=8 is configs[3], 1 M x 1024); value = N_points * W_total / time.
-Inputs are resident in HBM before the timed region.
+N>1] -> tohip_traj_reward -> tohip_traj_backward [-> all-gather of the (W,7) gradient rows when N>1].  With N
+GPUs the trajectory has 128*N waypoints sharded contiguously over the ranks (weak scaling; N=8 is configs[3],
+1 M x 1024); value = N_points * W_total / time.  Inputs are resident in HBM before the timed region.
 
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed on the launch stream) and
 "cpu_baseline" (the CPU oracle — a port, not the reference — on a bounded sample, rank 0, N=1 only).
+
+The roofline is a VALU-ISSUE roofline: the kernels keep points in registers and stream waypoint records through SGPRs,
+so a launch moves ~N*16 B whatever W is (1 % of HBM peak) and is bound by vector-instruction issue.
+  achieved = issue cycles the launch's instruction stream needs / kernel time
+             (instruction mix of the compiled inner loop: profiles/r02_pass1_isa_mix.json, from tools/isa_stats.py;
+              prices per wave64 instruction measured on this chip: profiles/r02_valu_peak.json, tools/valu_peak.hip —
+              packed f32 4, transcendental 8, other VALU 4 cycles)
+  peak     = 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, max clock)
 """
 import argparse
 import ctypes
@@ -31,23 +38,42 @@ from trajectory_optimization_amd import synth  # noqa: E402
 
 N_POINTS = 1_000_000
 WPS_PER_GPU = 128
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# algorithmic bytes per evaluation of a streaming implementation (SURVEY.md §8d / DESIGN.md §4)
-ALGO_BYTES = {"k_traj_pass1": 12.0, "k_traj_pass2": 20.0, "k_traj_bwd": 16.0}
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMDS = 1024          # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4         # max clock (the chip holds 2.2-2.4 GHz under this load: profiles/r02_valu_peak.json)
+ISSUE_CYCLES = {"packed_f32": 4.0, "transcendental": 8.0, "other_valu": 4.0}  # per wave64 instruction, measured
+# algorithmic bytes per evaluation of a STREAMING implementation of the reference's loop: kept as a named
+# secondary figure only — the kernels do not stream, so it exceeds the HBM peak
+ALGO_BYTES_FWD_BWD = 48.0
+PASS1 = "k_traj_pass1"
+
+
+def _profile_json(name):
+    try:
+        with open(os.path.join(REPO, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def isa_mix():
+    """VALU instructions of one (wave, waypoint) iteration of k_traj_pass1's dense inner loop (= 64*P evaluations), by class."""
+    d = _profile_json("r02_pass1_isa_mix.json")
+    if d is None:
+        raise SystemExit("profiles/r02_pass1_isa_mix.json is missing (tools/isa_stats.py --json writes it)")
+    return d
 
 
 def pmc_figures(kernel):
     """(HBM bytes per launch, VALU busy fraction) of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r01_bench_dense_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes; SQ_ACTIVE_INST_VALU x4 /
-    SQ_BUSY_CYCLES-normalised SIMD cycles), or (None, None)."""
-    path = os.path.join(REPO, "profiles", "r01_bench_dense_pmc.json")
+    (profiles/r02_bench_dense_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes; SQ_ACTIVE_INST_VALU x4 over the SIMD
+    cycles of the kernel), or (None, None)."""
+    d = _profile_json("r02_bench_dense_pmc.json")
     try:
-        with open(path) as f:
-            ks = json.load(f)["kernels"]
-        for name, v in ks.items():
+        for name, v in d["kernels"].items():
             if kernel in name and "hbm_bytes_per_launch_corrected" in v:
                 return float(v["hbm_bytes_per_launch_corrected"]), v.get("valu_busy_fraction")
-    except (OSError, KeyError, ValueError):
+    except (TypeError, KeyError, ValueError):
         pass
     return None, None
 
@@ -109,9 +135,6 @@ def main():
     ap.add_argument("--cameras", type=int, default=1,
                     help="cameras per waypoint (BASELINE.json configs[4]: 5, with --wps-per-gpu 32); each (camera, "
                          "waypoint) pair is one virtual waypoint with its own min-max normalisation")
-    ap.add_argument("--split-backward", action="store_true",
-                    help="use the scan + masked backward pair also at N=1 (at N>1 dense mode always does, to overlap "
-                         "the scan with the all-reduce)")
     ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -139,11 +162,9 @@ def main():
     n_virtual = args.wps_per_gpu * args.cameras
     rig = ops.CameraRig(*synth.camera_rig(args.cameras), device) if args.cameras > 1 else None
     ws = ops.TrajWorkspace(cloud, n_virtual)
-    L0 = _lib.lib()
     gout = torch.ones(1, device=device)
     shard = WaypointShard() if n_gpus > 1 else None
 
-    need_buf = torch.empty(L0.tohip_traj_need_mask_bytes(cloud.n, n_virtual), dtype=torch.uint8, device=device)
     if shard is not None:
         # communicator set-up (RCCL rings over xGMI) happens on the first collective of each kind: keep it out of the timed
         # region whatever --warmup says
@@ -151,35 +172,16 @@ def main():
         shard.allgather_rows(torch.zeros((args.wps_per_gpu, 7), device=device))
         torch.cuda.synchronize(device)
 
-    def step(flags, saved=False):
-        """saved: the forward records which (wave, waypoint) combinations carry gradient and the backward walks only
-        those — what ModelTraj(dense=True) does.  The headline (saved=False) re-evaluates every pair in the backward."""
-        need = None
-        if saved:
-            lo_sum, minmax, need = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags, want_need=True)
-        else:
-            lo_sum, minmax = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags)
-        if saved:
-            if shard is not None:
-                shard.allreduce_sum(lo_sum)
-        elif shard is None and args.split_backward and (flags & ops.DENSE):
-            need = ops.traj_backward_scan(cloud, poses, quats, cam, ws, minmax, rig=rig, flags=flags, out=need_buf)
-        if shard is not None and not saved:
-            # the one data-path collective: N floats over xGMI.  In dense mode the first half of the backward (every
-            # pair re-evaluated: which of them carry gradient) does not depend on lo_sum and runs while RCCL reduces it
-            if flags & ops.DENSE:
-                pending = shard.allreduce_sum_async(lo_sum)
-                need = ops.traj_backward_scan(cloud, poses, quats, cam, ws, minmax, rig=rig, flags=flags, out=need_buf)
-                pending.wait()
-            else:
-                shard.allreduce_sum(lo_sum)
+    def step(flags):
+        lo_sum, minmax = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags)
+        if shard is not None:
+            shard.allreduce_sum(lo_sum)  # the one data-path collective: N floats over xGMI
         rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
-        pg, qg = ops.traj_backward(cloud, poses, quats, cam, ws, lo_sum, minmax, scalars=scalars, gout=gout, rig=rig, flags=flags,
-                                   need_mask=need)
+        pg, qg = ops.traj_backward(cloud, args.wps_per_gpu, cam, ws, lo_sum, scalars=scalars, gout=gout, rig=rig, flags=flags)
         if shard is not None:
             g = shard.allgather_rows(torch.cat([pg, qg], dim=1))  # (W_total, 7) floats: every rank can step the optimiser
             pg, qg = g[:, :3], g[:, 3:]
-        return scalars, pg, qg
+        return scalars, pg, qg, rewards
 
     def fence():
         if n_gpus > 1:
@@ -190,15 +192,15 @@ def main():
     ms = (ctypes.c_double * 5)()
     cnt = (ctypes.c_int64 * 5)()
 
-    def timed(flags, saved=False):
+    def timed(flags):
         """W warm-up steps, then exactly K steps between two (barrier + synchronize) fences; MAX over ranks.
-        No instrumentation inside: the library's per-kernel HIP events cost ~0.06 ms per step (10 % of a dense step)."""
+        No instrumentation inside: the library's per-kernel HIP events cost ~0.06 ms per step."""
         for _ in range(args.warmup):
-            step(flags, saved)
+            step(flags)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            o = step(flags, saved)
+            o = step(flags)
         fence()
         dt = time.perf_counter() - t0
         if n_gpus > 1:
@@ -207,19 +209,19 @@ def main():
             dt = float(t.item())
         return dt, o
 
-    def kernel_times(flags, saved=False):
+    def kernel_times(flags):
         """The same K steps once more with HIP events recorded around every kernel on the launch stream
         (tohip_profile_*): mean duration per launch, for the roofline object."""
         fence()
         L.tohip_profile_enable(1)
         for _ in range(args.steps):
-            step(flags, saved)
+            step(flags)
         fence()
         _lib.check(L.tohip_profile_read(ms, cnt), "tohip_profile_read")
         L.tohip_profile_enable(0)
         return {L.tohip_profile_name(i).decode(): (ms[i], cnt[i]) for i in range(5) if cnt[i] > 0}
 
-    # headline: DENSE — every (point, waypoint) pair is evaluated, forward and backward
+    # headline: DENSE — every (point, waypoint) pair is evaluated
     dense_flags = ops.DENSE if args.mode != "culled" else 0
     dt, out = timed(dense_flags)
     kern = kernel_times(dense_flags)
@@ -227,58 +229,70 @@ def main():
     if args.mode == "both":
         dt_c, out_c = timed(0)
         kern_c = kernel_times(0)
-        dt_s, out_s = timed(ops.DENSE, saved=True)  # dense forward, backward over the forward's record
     else:
         dt_c, out_c, kern_c = dt, out, kern
-        dt_s, out_s = dt, out
     evals_per_step = args.points * w_total * args.cameras
     value = evals_per_step * args.steps / dt
 
     if rank == 0:
-        # dominant kernel by summed device time; achieved = algorithmic bytes per launch / mean duration
-        dom = max(ALGO_BYTES, key=lambda k: kern.get(k, (0.0, 0))[0])
-        # per step, not per launch: the split backward (N > 1) is two launches of the same class per step
-        dom_ms = kern[dom][0] / args.steps
+        # dominant kernel: pass 1, the one launch that evaluates every pair.  VALU-issue roofline (module docstring).
+        mix = isa_mix()
         local_evals = args.points * n_virtual
-        achieved = ALGO_BYTES[dom] * local_evals / (dom_ms * 1e-3) / 1e9
-        traffic, valu_busy = pmc_figures(dom)
+        evals_per_iter = 64 * mix["points_per_lane"]
+        cyc_per_iter = (mix["packed_f32"] * ISSUE_CYCLES["packed_f32"] + mix["transcendental"] * ISSUE_CYCLES["transcendental"] +
+                        mix["other_valu"] * ISSUE_CYCLES["other_valu"])
+        p1_ms = kern[PASS1][0] / kern[PASS1][1]
+        issue_cycles = cyc_per_iter * local_evals / evals_per_iter
+        achieved = issue_cycles / (p1_ms * 1e-3) / 1e9           # G issue-cycles/s
+        peak = N_SIMDS * CLOCK_GHZ
+        traffic, valu_busy = pmc_figures(PASS1)
+        step_ms = 1e3 * dt / args.steps
         line = {
             "metric": "point-visibility evals/sec (fwd+bwd)", "value": value, "unit": "evals/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.points}-point cloud x {args.wps_per_gpu} waypoints per GPU "
                                    f"({w_total} total)" + (f" x {args.cameras} cameras" if args.cameras > 1 else "") +
                                    ", fwd + bwd (x,y,z,quaternion) gradients",
                        "n_points": args.points, "waypoints_total": w_total, "cameras": args.cameras,
                        "parallelism": f"waypoint-shard x{n_gpus}" if n_gpus > 1 else "single GPU",
-                       "mode": "dense: every (point, waypoint) pair evaluated, no data-dependent skipping",
+                       "mode": "dense: every (point, waypoint) pair evaluated, no data-dependent skipping; the 0.7 % of "
+                               "(256-point slot, waypoint) pairs that can contribute are then revisited by the sparse kernels",
                        "loss_vis": float(out[0][1].item())},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_busy": valu_busy,
-                         "traffic_note": "HBM bytes per launch from profiles/r01_bench_dense_pmc.json (separate --pmc "
-                                         "passes of this command); far below the algorithmic bytes: the kernels keep "
-                                         "points in registers and loop over waypoints, so they are VALU-issue bound",
+            "roofline": {"bound": "valu", "kernel": PASS1, "achieved": achieved, "peak": peak, "unit": "G VALU-issue-cycles/s",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "kernel_ms_per_launch": p1_ms, "kernel_share_of_step": p1_ms / step_ms,
+                         "issue_cycles_per_launch": issue_cycles,
+                         "isa_mix_per_wave_iteration": mix, "issue_cycles_per_instruction": ISSUE_CYCLES,
+                         "peak_note": f"{N_SIMDS} SIMDs x {CLOCK_GHZ} GHz; frac is a lower bound of the SIMDs' VALU-busy fraction "
+                                      "(the chip clocks 2.2-2.4 GHz under this load; packed f32 measures 4.0-4.4 cycles)",
+                         "valu_busy_pmc": valu_busy,
+                         "hbm_counter_frac": (traffic / (p1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "traffic_note": "HBM bytes per launch from profiles/r02_bench_dense_pmc.json (separate --pmc passes of "
+                                         "this command); ~1 % of the HBM peak: points live in registers, waypoints stream "
+                                         "through SGPRs",
+                         "algorithmic_bytes_frac": value / n_gpus * ALGO_BYTES_FWD_BWD / (HBM_PEAK_GBS * 1e9),
+                         "algorithmic_bytes_note": "48 B/eval of a streaming implementation (SURVEY.md 8d) x evals/s / 8 TB/s: above 1 "
+                                                   "because nothing streams — kept for comparison with the survey's model only",
                          "kernel_ms": {k: v[0] / args.steps for k, v in kern.items()},
-                         "kernel_ms_note": "per step and kernel class; HIP events on the launch stream over a second pass of the same K steps (the events "
-                                           "themselves cost ~0.06 ms per step, so the timed pass runs without them)",
-                         "algorithmic_bytes_per_eval": ALGO_BYTES[dom],
-                         "fwd_bwd_frac_of_48B_per_eval_roofline": value / n_gpus * 48.0 / (HBM_PEAK_GBS * 1e9)},
+                         "kernel_ms_note": "per step and kernel class; HIP events on the launch stream over a second pass of the "
+                                           "same K steps (the events themselves cost ~0.06 ms per step, so the timed pass runs "
+                                           "without them)"},
         }
         same = all(torch.equal(a, b) for a, b in zip(out, out_c))
         line["culled_exact"] = {
             "value": evals_per_step * args.steps / dt_c, "unit": "evals/s", "ms_per_step": 1e3 * dt_c / args.steps,
             "bitwise_identical_to_dense": bool(same),
             "kernel_ms": {k: v[0] / args.steps for k, v in kern_c.items()},
-            "note": "library default (what ModelTraj runs): pairs whose log-odds term is provably exactly 0 are skipped via a "
-                    "Morton-sorted cloud, per-256-point bounding spheres and a distance bound on p"}
-        line["dense_forward_recorded_backward"] = {
-            "value": evals_per_step * args.steps / dt_s, "unit": "evals/s", "ms_per_step": 1e3 * dt_s / args.steps,
-            "bitwise_identical_to_dense": bool(all(torch.equal(a, b) for a, b in zip(out, out_s))),
-            "note": "every pair evaluated in both forward passes; the backward uses the forward's record of the active "
-                    "pairs instead of evaluating every pair a third time (not the headline)"}
+            "note": "library default (what ModelTraj runs): pass 1 skips pairs that provably can neither be a waypoint's maximum "
+                    "nor contribute, via a Morton-sorted cloud, per-256-point bounding spheres and a distance bound on p"}
         if n_gpus == 1 and args.cpu_wps > 0 and args.cameras == 1:
             line["hpr"] = hpr_leg(pts, device)
             line["cpu_baseline"] = cpu_baseline(pts, poses_all, quats_all, args.cpu_wps)
+            line["reference_cpu_container"] = {
+                "value": 1.3e7, "unit": "evals/s", "cores": 8,
+                "note": "the reference ITSELF (torch CPU, fwd+bwd, 1 M x 16) timed in the build container — it cannot travel to the "
+                        "GPU box; profiles/r01_reference_cpu_timing.txt"}
         print(json.dumps(line), flush=True)
     if n_gpus > 1:
         dist.barrier()

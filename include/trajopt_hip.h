@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOHIP_ABI_VERSION 3
+#define TOHIP_ABI_VERSION 4
 
 #define TOHIP_OK 0
 #define TOHIP_EINVAL (-1)   /* bad size / null pointer */
@@ -77,7 +77,10 @@ int tohip_pack_cloud(const float *xyz, int64_t n_points, int sort, void *packed,
                      size_t workspace_bytes, void *stream);
 
 /* ---- ModelTraj (model.py:200-242 forward, :246 visibility term, autograd backward) ----------
- * Workspace bytes needed by the three calls below for n_points and n_virtual = W * max(1,n_cams). */
+ * Workspace bytes needed by the three calls below for n_points and n_virtual = W * max(1,n_cams).
+ * THE WORKSPACE MUST BE ZERO-FILLED ONCE BEFORE ITS FIRST USE (hipMemset); the calls keep that invariant.  The forward
+ * leaves its state there (waypoint records, per-waypoint extrema, the flags and lists of the pairs that contribute) and
+ * the backward of the same step reads it: do not touch the workspace between the two. */
 size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual);
 
 /* flags */
@@ -88,24 +91,20 @@ size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual);
  * to_camera_frame -> get_dist_mask * get_fov_mask -> per-waypoint (p-min)/max -> clip -> log-odds,
  * summed over waypoints into lo_sum[0..Npad) IN PACKED (sorted) ORDER (overwritten; this rank's partial
  * sum when the waypoints are sharded over GPUs — every rank packs the same cloud the same way).
- * minmax[v] = (min p, max(p - min p)) per virtual waypoint, kept for the backward.
+ * minmax[v] = (min p, max(p - min p)) per virtual waypoint (for inspection; the backward reads the workspace).
  * replaces model.py:217-231. */
 int tohip_traj_forward(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
                        const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits,
-                       float *lo_sum, float *minmax, void *need_mask_out, void *workspace, size_t workspace_bytes,
-                       void *stream);
-/* need_mask_out (may be NULL; else tohip_traj_need_mask_bytes bytes): the forward's second pass has p_hat of every pair
- * it evaluates in hand and can record which (wave of points, waypoint) combinations will carry gradient — what
- * tohip_traj_backward_scan would compute.  Hand it to tohip_traj_backward as need_mask (either mode; same poses, quats,
- * flags, occlusion_bits): the backward then walks only those combinations.  Results are the same, bit for bit. */
+                       float *lo_sum, float *minmax, void *workspace, size_t workspace_bytes, void *stream);
 /* occlusion_bits (may be NULL = nothing occluded): per virtual waypoint a row of Npad/32 words, bit i = 1 when the
  * packed (sorted) point i is NOT occluded from that waypoint; an occluded pair has p = 0.  The per-waypoint
  * analogue of ModelPose's occlusion mask (model.py:112-115) that the reference leaves as a TODO (tools.py:61-62).
- * Rows are built with tohip_occlusion_row from a hard-frustum cull + HPR (or z-buffer) of the camera-frame cloud. */
+ * Rows are built with tohip_occlusion_row(s) from a hard-frustum cull + HPR (or z-buffer) of the camera-frame cloud;
+ * the bits of the pad positions [N, Npad) repeat the bit of the last sorted point. */
 int tohip_inverse_permutation(const void *packed, int64_t n_points, int32_t *inv_perm, void *stream);
 int tohip_occlusion_row(int64_t n_points, const int32_t *inv_perm, const int32_t *kept_idx, const int32_t *kept_count,
                         const int32_t *visible_idx_in_kept, const int32_t *visible_count, uint32_t *row, void *stream);
-/* The same for n_wps waypoints in three launches.  kept_idx (n_wps, n): waypoint w's kept points in its first kept_count[w]
+/* The same for n_wps waypoints in four launches.  kept_idx (n_wps, n): waypoint w's kept points in its first kept_count[w]
  * entries (the layout tohip_cull_waypoints writes); vis_idx: the visible ones as positions in that list, waypoint w's in
  * [vis_off[w], vis_off[w+1]) (n_wps+1 device int32); all_visible[w] != 0: nothing of w is occluded.  rows: (n_wps, Npad/32). */
 int tohip_occlusion_rows(int64_t n_points, const int32_t *inv_perm, const int32_t *kept_idx, const int32_t *kept_count,
@@ -113,31 +112,23 @@ int tohip_occlusion_rows(int64_t n_points, const int32_t *inv_perm, const int32_
                          uint32_t *rows, void *stream);
 
 /* rewards[0..N) = sigmoid(lo_sum) in the CALLER'S point order (model.py:237); scalars[0] = mean(rewards),
- * scalars[1] = loss_vis = 1/(mean+eps) (model.py:246), scalars[2] = -loss_vis^2/N (d loss_vis / d reward_n). */
+ * scalars[1] = loss_vis = 1/(mean+eps) (model.py:246), scalars[2] = -loss_vis^2/N (d loss_vis / d reward_n).
+ * One launch.  workspace: a zero-filled-once region of at least tohip_traj_workspace_bytes(n_points, 1) bytes — normally
+ * the forward's workspace (only its first 64 KB are used, and none of the forward's state). */
 int tohip_traj_reward(const void *packed, const float *lo_sum, int64_t n_points, float eps, float *rewards,
                       float *scalars, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Backward w.r.t. this rank's waypoints: poses_grad (W,3), quats_grad (W,4).  minmax from the forward;
+/* Backward w.r.t. this rank's waypoints: poses_grad (W,3), quats_grad (W,4), for the step whose tohip_traj_forward last
+ * used `workspace` (same n_points, n_wps, rig, flags, occlusion_bits).
  * lo_sum = the (all-reduced) log-odds vector in packed order that tohip_traj_reward turned into rewards.
  * The upstream gradient is either grad_rewards (N floats in the caller's order, dL/d rewards: any
  * criterion built on model.rewards, as torch autograd would hand it over), or, when grad_rewards is NULL,
- * the fused visibility loss: scalars (from tohip_traj_reward) and gout = device pointer to dL/d loss_vis. */
-int tohip_traj_backward(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
-                        const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits,
-                        const float *lo_sum, const float *grad_rewards, const float *scalars, const float *minmax, const float *gout,
-                        const void *need_mask, float *poses_grad, float *quats_grad, void *workspace, size_t workspace_bytes,
-                        void *stream);
-/* Split backward for the multi-GPU step (the scan is the dense mode's: TOHIP_TRAJ_DENSE).  Which (wave of points, waypoint) combinations hold a
- * pair with a non-zero gradient depends on p and the per-waypoint min/max alone, not on lo_sum: tohip_traj_backward_scan
- * evaluates every pair and records that (need_mask, tohip_traj_need_mask_bytes bytes) and can therefore run while lo_sum
- * is still being all-reduced; tohip_traj_backward with that need_mask then only walks the flagged combinations.  Same
- * results, bit for bit, as tohip_traj_backward with need_mask = NULL.  (poses, quats, flags, occlusion_bits, minmax) must
- * be the same in both calls. */
-size_t tohip_traj_need_mask_bytes(int64_t n_points, int64_t n_virtual_wps);
-int tohip_traj_backward_scan(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
-                             const tohip_camera *cam_host, const tohip_rig *rig_host, int flags,
-                             const uint32_t *occlusion_bits, const float *minmax, void *need_mask, void *workspace,
-                             size_t workspace_bytes, void *stream);
+ * the fused visibility loss: scalars (from tohip_traj_reward) and gout = device pointer to dL/d loss_vis.
+ * Deterministic: no float atomics anywhere, tie sets of the per-waypoint min()/max() included. */
+int tohip_traj_backward(const void *packed, int64_t n_points, int64_t n_wps, const tohip_camera *cam_host,
+                        const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits, const float *lo_sum,
+                        const float *grad_rewards, const float *scalars, const float *gout, float *poses_grad,
+                        float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- ModelPose (model.py:98-127) -------------------------------------------------------------- */
 size_t tohip_pose_workspace_bytes(int64_t n_points);

@@ -47,7 +47,7 @@ def test_cpp_host_matches_python_path(tmp_path):
     ws = ops.TrajWorkspace(cloud, W)
     lo_sum, minmax = ops.traj_forward(cloud, p, q, cam, ws)
     rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
-    pg, qg = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, scalars=scalars, gout=torch.ones(1, device=dev))
+    pg, qg = ops.traj_backward(cloud, W, cam, ws, lo_sum, scalars=scalars, gout=torch.ones(1, device=dev))
     # same library, same inputs, same launch sequence: identical bits
     assert np.float32(out["mean_reward"]) == scalars[0].item() and np.float32(out["loss_vis"]) == scalars[1].item()
     assert np.array_equal(np.asarray(out["poses_grad"], np.float32).reshape(W, 3), pg.cpu().numpy())

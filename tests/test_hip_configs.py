@@ -78,7 +78,7 @@ def test_config4_five_cameras_1m_x256(dev):
     for flags in (0, ops.DENSE):
         lo, mm = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=flags)
         r, sc = ops.traj_reward(cloud, lo, cam, ws)
-        pg, qg = ops.traj_backward(cloud, p, q, cam, ws, lo, mm, scalars=sc, gout=gout, rig=rg, flags=flags)
+        pg, qg = ops.traj_backward(cloud, p.shape[0], cam, ws, lo, scalars=sc, gout=gout, rig=rg, flags=flags)
         out[flags] = (lo.clone(), r.clone(), pg.clone(), qg.clone(), mm.clone())
     for a, b in zip(out[0], out[ops.DENSE]):
         assert torch.equal(a, b)

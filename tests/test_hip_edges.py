@@ -25,7 +25,7 @@ def _run(dev, pts, poses, quats, Kmat=K, iw=IW, ih=IH, min_dist=1.0, max_dist=5.
     ws = ops.TrajWorkspace(cloud, p.shape[0])
     lo, mm = ops.traj_forward(cloud, p, q, cam, ws, flags=flags)
     r, sc = ops.traj_reward(cloud, lo, cam, ws)
-    pg, qg = ops.traj_backward(cloud, p, q, cam, ws, lo, mm, scalars=sc, gout=torch.ones(1, device=dev), flags=flags)
+    pg, qg = ops.traj_backward(cloud, p.shape[0], cam, ws, lo, scalars=sc, gout=torch.ones(1, device=dev), flags=flags)
     torch.cuda.synchronize()
     return r.cpu().numpy(), sc.cpu().numpy(), pg.cpu().numpy(), qg.cpu().numpy(), mm.cpu().numpy()
 

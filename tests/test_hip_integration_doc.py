@@ -33,7 +33,7 @@ def test_integration_stub_runs_and_matches(monkeypatch):
     m.packed = torch.empty(L.tohip_packed_cloud_bytes(n), dtype=torch.uint8, device=dev)
     scratch = torch.empty(L.tohip_pack_workspace_bytes(n), dtype=torch.uint8, device=dev)
     assert L.tohip_pack_cloud(pts.data_ptr(), n, 1, m.packed.data_ptr(), scratch.data_ptr(), scratch.numel(), ns["_stream"]()) == 0
-    m.ws = torch.empty(L.tohip_traj_workspace_bytes(n, W), dtype=torch.uint8, device=dev)
+    m.ws = torch.zeros(L.tohip_traj_workspace_bytes(n, W), dtype=torch.uint8, device=dev)
     import ctypes
     m.cam = Cam((ctypes.c_float * 9)(*synth.K_INTRINS.flatten().tolist()), synth.IMG_WIDTH, synth.IMG_HEIGHT, 1.0, 5.0, 1e-6)
     poses = torch.from_numpy(poses_np).to(dev).requires_grad_(True)
@@ -48,7 +48,7 @@ def test_integration_stub_runs_and_matches(monkeypatch):
     p, q = poses.detach(), quats.detach()
     lo_sum, minmax = ops.traj_forward(cloud, p, q, cam, ws)
     ref_rewards, _ = ops.traj_reward(cloud, lo_sum, cam, ws)
-    pg, qg = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, grad_rewards=w.contiguous())
+    pg, qg = ops.traj_backward(cloud, W, cam, ws, lo_sum, grad_rewards=w.contiguous())
     assert torch.equal(rewards.detach(), ref_rewards)
     assert torch.equal(poses.grad, pg) and torch.equal(quats.grad, qg)
     assert float(pg.abs().max()) > 0

@@ -422,9 +422,9 @@ def test_fused_adam_optimizer_equals_torch_adam(dev):
     np.testing.assert_allclose(runs[0][1].cpu().numpy(), runs[1][1].cpu().numpy(), rtol=2e-6, atol=1e-6)
 
 
-def test_dense_model_uses_the_forwards_record(dev):
-    """ModelTraj(dense=True) hands the forward's need mask to the backward; results equal the default (culled) model's
-    to the bit, through the fused node and through the rewards node."""
+def test_dense_model_equals_the_default_model(dev):
+    """ModelTraj(dense=True) evaluates every pair in pass 1; results equal the default (culled) model's to the bit,
+    through the fused node and through the rewards node."""
     from trajectory_optimization_amd.model import ModelTraj
     pts = synth.make_cloud(150_000, seed=7)
     poses, quats = synth.make_path(10, optical=True, jitter_seed=5)

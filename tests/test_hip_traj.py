@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 K, IW, IH = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
 GRAD_TOL = 1e-5     # north star: gradients within 1e-5 relative (||g-g_ref||_inf / ||g_ref||_inf)
-REW_RTOL, REW_ATOL = 2e-5, 2e-6
+REW_RTOL, REW_ATOL = 1e-5, 0.0   # north star: rewards within 1e-5 relative (rewards live in [0.5, 1]: no absolute slack needed)
+# measured (MI355X, r02): rewards 4e-7 .. 7e-7 max relative error, gradients 2e-7 .. 8e-7 against the f64 oracle
 
 
 @pytest.fixture(scope="module")
@@ -35,7 +36,7 @@ def _run_ops(dev, points, poses, quats, rig=None, flags=0, sort=True, clip=(1.0,
     lo_sum, minmax = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=flags)
     rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
     gout = torch.ones(1, device=dev)
-    pg, qg = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, scalars=scalars, gout=gout, rig=rg, flags=flags)
+    pg, qg = ops.traj_backward(cloud, p.shape[0], cam, ws, lo_sum, scalars=scalars, gout=gout, rig=rg, flags=flags)
     torch.cuda.synchronize()
     return dict(lo_sum=lo_sum[:cloud.n].cpu().numpy(), rewards=rewards.cpu().numpy(), minmax=minmax.cpu().numpy(),
                 scalars=scalars.cpu().numpy(), pg=pg.cpu().numpy(), qg=qg.cpu().numpy())
@@ -196,14 +197,16 @@ def test_full_size_properties(dev):
     # quaternion gradient is tangent to the unit sphere: <q, dL/dq> = 0 (F.normalize)
     dots = (quats.astype(np.float64) * r1["qg"]).sum(1)
     assert np.abs(dots).max() <= 1e-5 * np.abs(r1["qg"]).max()
-    # sampled parity against the f64 oracle on a 1/16 subsample of the waypoints at full N
+    # parity against the f64 oracle at the full size: all 128 waypoints, rewards and gradients
     from oracle import oracle
-    sel = np.arange(0, w, 16)
-    rs = _run_ops(dev, pts, poses[sel], quats[sel])
-    f = oracle.traj_forward(pts, poses[sel], quats[sel], K, IW, IH, prec="f64")
-    pg, qg = oracle.traj_backward(pts, poses[sel], quats[sel], K, IW, IH, f, prec="f64")
-    np.testing.assert_allclose(rs["rewards"], f["rewards"], rtol=REW_RTOL, atol=REW_ATOL)
-    assert rel_inf(rs["pg"], pg) < GRAD_TOL and rel_inf(rs["qg"], qg) < GRAD_TOL
+    f = oracle.traj_forward(pts, poses, quats, K, IW, IH, prec="f64")
+    pg, qg = oracle.traj_backward(pts, poses, quats, K, IW, IH, f, prec="f64")
+    rew_err = float(np.abs(r1["rewards"] - f["rewards"]).max() / 0.5)
+    print(f"1M x 128 vs f64 oracle: rewards max rel err {rew_err:.2e}, poses grad {rel_inf(r1['pg'], pg):.2e}, "
+          f"quats grad {rel_inf(r1['qg'], qg):.2e}, loss_vis {abs(r1['scalars'][1] - f['loss_vis']) / f['loss_vis']:.2e}")
+    np.testing.assert_allclose(r1["rewards"], f["rewards"], rtol=REW_RTOL, atol=REW_ATOL)
+    assert abs(r1["scalars"][1] - f["loss_vis"]) <= 1e-6 * f["loss_vis"]
+    assert rel_inf(r1["pg"], pg) < GRAD_TOL and rel_inf(r1["qg"], qg) < GRAD_TOL
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
@@ -230,13 +233,10 @@ def test_culling_randomized_bitwise(dev, seed):
         assert np.array_equal(a[k], b[k], equal_nan=True), (k, n, w)
 
 
-@pytest.mark.parametrize("n,w,cams,occ", [(1_000_000, 24, 1, False), (200_000, 16, 1, True), (60_000, 9, 3, False), (3000, 5, 1, False)])
-def test_split_backward_is_bitwise_the_fused_one(dev, n, w, cams, occ):
-    """tohip_traj_backward_scan + tohip_traj_backward(need_mask) == tohip_traj_backward, bit for bit (every P, rig,
-    occlusion bits), with a general dL/d rewards vector and with the fused visibility loss."""
+def _setup(dev, n, w, cams=1, occ=False, seed=5, dense=False):
     ops = _ops()
-    pts = synth.make_cloud(n, seed=3)
-    poses, quats = synth.make_path(w, optical=True, jitter_seed=2)
+    pts = synth.make_cloud(n, seed=seed)
+    poses, quats = synth.make_path(w, optical=True, jitter_seed=seed - 1)
     P = torch.from_numpy(pts).to(dev)
     cloud = ops.PackedCloud(P)
     cam = ops.Camera(K, IW, IH)
@@ -244,61 +244,105 @@ def test_split_backward_is_bitwise_the_fused_one(dev, n, w, cams, occ):
     rg = ops.CameraRig(*synth.camera_rig(cams), dev) if cams > 1 else None
     ws = ops.TrajWorkspace(cloud, w * cams)
     bits = ops.occlusion_bits(cloud, P, p, q, cam, 1.0, 15.0, "zbuffer") if occ else None
-    lo_sum, minmax = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=ops.DENSE, occ=bits)
-    rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
-    gout = torch.ones(1, device=dev)
-    g = torch.rand(n, generator=torch.Generator().manual_seed(1)).to(dev) - 0.3
-    for kw in (dict(scalars=scalars, gout=gout), dict(grad_rewards=g)):
-        ref = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, rig=rg, flags=ops.DENSE, occ=bits, **kw)
-        mask = ops.traj_backward_scan(cloud, p, q, cam, ws, minmax, rig=rg, flags=ops.DENSE, occ=bits)
-        assert 0 < int(mask.count_nonzero()) < mask.numel()
-        got = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, rig=rg, flags=ops.DENSE, occ=bits, need_mask=mask, **kw)
-        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
-    from trajectory_optimization_amd import _lib
-    with pytest.raises(_lib.HipError):  # the split belongs to the dense mode
-        ops.traj_backward_scan(cloud, p, q, cam, ws, minmax, rig=rg, flags=0, occ=bits)
+    return dict(pts=pts, poses=poses, quats=quats, cloud=cloud, cam=cam, p=p, q=q, rig=rg, ws=ws, occ=bits,
+                flags=ops.DENSE if dense else 0)
 
 
 @pytest.mark.parametrize("n,w,cams,occ", [(1_000_000, 24, 1, False), (200_000, 70, 1, True), (60_000, 9, 3, False), (3000, 5, 1, False),
                                          (300_000, 130, 1, False)])
-@pytest.mark.parametrize("dense", [False, True])
-def test_backward_with_the_forwards_need_mask_is_bitwise_the_same(dev, n, w, cams, occ, dense):
-    """tohip_traj_forward(need_mask_out) -> tohip_traj_backward(need_mask): same gradients, bit for bit, as the backward
-    that finds the active pairs itself — both modes, every points-per-lane variant, rig, occlusion bits, more than 64 and
-    more than 128 waypoints (mask words), fused loss and a general dL/d rewards vector."""
+def test_backward_paths_and_modes_agree_bitwise(dev, n, w, cams, occ):
+    """Culled == dense, bit for bit, for the fused visibility loss and for a general dL/d rewards vector: rig, occlusion bits,
+    more than 64 and more than 128 waypoints (flag words), ragged sizes; and the backward is a pure function of the forward's
+    state (called twice: same bits)."""
     ops = _ops()
-    pts = synth.make_cloud(n, seed=5)
-    poses, quats = synth.make_path(w, optical=True, jitter_seed=4)
-    P = torch.from_numpy(pts).to(dev)
-    cloud = ops.PackedCloud(P)
-    cam = ops.Camera(K, IW, IH)
-    p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
-    rg = ops.CameraRig(*synth.camera_rig(cams), dev) if cams > 1 else None
-    ws = ops.TrajWorkspace(cloud, w * cams)
-    bits = ops.occlusion_bits(cloud, P, p, q, cam, 1.0, 15.0, "zbuffer") if occ else None
-    flags = ops.DENSE if dense else 0
-    lo_ref, mm_ref = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=flags, occ=bits)
-    lo_sum, minmax, need = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=flags, occ=bits, want_need=True)
-    assert torch.equal(lo_sum, lo_ref) and torch.equal(minmax, mm_ref)  # recording the mask does not change the forward
-    if dense:
-        scan = ops.traj_backward_scan(cloud, p, q, cam, ws, minmax, rig=rg, flags=flags, occ=bits)
-        P_lane = 4 if n >= 512 * 1024 else (2 if n >= 128 * 1024 else 1)  # points per lane the library picks
-        used = ((w * cams + 63) // 64) * (cloud.npad // (64 * P_lane)) * 8   # mask words in use (the buffers are padded)
-        assert torch.equal(scan[:used], need[:used])  # the same predicate, evaluated by the two kernels
-    rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
-    gout = torch.ones(1, device=dev)
-    g = torch.rand(n, generator=torch.Generator().manual_seed(2)).to(dev) - 0.3
-    for kw in (dict(scalars=scalars, gout=gout), dict(grad_rewards=g)):
-        ref = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, rig=rg, flags=flags, occ=bits, **kw)
-        got = ops.traj_backward(cloud, p, q, cam, ws, lo_sum, minmax, rig=rg, flags=flags, occ=bits, need_mask=need, **kw)
-        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    out = []
+    for dense in (False, True):
+        c = _setup(dev, n, w, cams, occ, dense=dense)
+        lo_sum, minmax = ops.traj_forward(c["cloud"], c["p"], c["q"], c["cam"], c["ws"], c["rig"], flags=c["flags"], occ=c["occ"])
+        rewards, scalars = ops.traj_reward(c["cloud"], lo_sum, c["cam"], c["ws"])
+        gout = torch.ones(1, device=dev)
+        g = torch.rand(n, generator=torch.Generator().manual_seed(2)).to(dev) - 0.3
+        res = [lo_sum, minmax, rewards, scalars]
+        for kw in (dict(scalars=scalars, gout=gout), dict(grad_rewards=g)):
+            a = ops.traj_backward(c["cloud"], w, c["cam"], c["ws"], lo_sum, rig=c["rig"], flags=c["flags"], occ=c["occ"], **kw)
+            b = ops.traj_backward(c["cloud"], w, c["cam"], c["ws"], lo_sum, rig=c["rig"], flags=c["flags"], occ=c["occ"], **kw)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+            assert bool(torch.isfinite(a[0]).all()) and float(a[0].abs().max()) > 0
+            res += [a[0], a[1]]
+        out.append(res)
+    for x, y in zip(out[0], out[1]):
+        assert torch.equal(x, y)
+
+
+def test_general_grad_rewards_matches_the_fused_loss(dev):
+    """dL/d rewards = d loss_vis / d rewards handed over as a vector == the fused path (same arithmetic, same bits apart
+    from the host-side product), and a scaled upstream gradient scales the result."""
+    ops = _ops()
+    c = _setup(dev, 120_000, 20)
+    lo_sum, _ = ops.traj_forward(c["cloud"], c["p"], c["q"], c["cam"], c["ws"])
+    rewards, scalars = ops.traj_reward(c["cloud"], lo_sum, c["cam"], c["ws"])
+    fused = ops.traj_backward(c["cloud"], 20, c["cam"], c["ws"], lo_sum, scalars=scalars, gout=torch.ones(1, device=dev))
+    g = torch.full((120_000,), float(scalars[2]), device=dev)
+    general = ops.traj_backward(c["cloud"], 20, c["cam"], c["ws"], lo_sum, grad_rewards=g)
+    assert rel_inf(general[0].cpu().numpy(), fused[0].cpu().numpy()) < 1e-6
+    assert rel_inf(general[1].cpu().numpy(), fused[1].cpu().numpy()) < 1e-6
+    twice = ops.traj_backward(c["cloud"], 20, c["cam"], c["ws"], lo_sum, scalars=scalars, gout=torch.full((1,), 2.0, device=dev))
+    assert rel_inf(twice[0].cpu().numpy(), 2 * fused[0].cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("copies", [3, 5, 40])
+def test_tie_sets_are_deterministic_and_split_evenly(dev, copies):
+    """torch splits the gradient of min()/max() evenly among tied elements (model.py:226-227).  A cloud whose argmax (and,
+    for a compact cloud with min p > 0, argmin) points exist in `copies` exact copies: the gradients are the oracle's
+    (which implements that rule), identical from run to run and between the two modes — there are no float atomics on the
+    path — including more tied rows than the select kernel records (40 copies spread by the Morton sort)."""
+    from oracle import oracle
+    ops = _ops()
+    base = (synth.make_cloud(6000, seed=77) * np.float32(0.3)).astype(np.float32)   # compact: min p > 0 at some waypoints
+    poses, quats = synth.make_path(5, optical=True, jitter_seed=77)
+    f0 = oracle.traj_forward(base, poses, quats, K, IW, IH, prec="f64")
+    # replicate, for every waypoint, its argmax and argmin points
+    extra = []
+    for v in range(5):
+        pv = oracle.pose_forward(base, poses[v], quats[v], K, IW, IH, prec="f64")[0]   # p of every point for waypoint v
+        extra += [base[int(np.argmax(pv))]] * (copies - 1) + [base[int(np.argmin(pv))]] * (copies - 1)
+    pts = np.concatenate([base, np.asarray(extra, np.float32)])
+    rng = np.random.default_rng(0)
+    pts = pts[rng.permutation(len(pts))]
+    f = oracle.traj_forward(pts, poses, quats, K, IW, IH, prec="f64")
+    pg, qg = oracle.traj_backward(pts, poses, quats, K, IW, IH, f, prec="f64")
+    assert (f0["pmin"] > 0).any()
+    runs = [_run_ops(dev, pts, poses, quats, flags=fl) for fl in (0, 0, ops.DENSE)]
+    for k in ("pg", "qg", "rewards"):
+        assert np.array_equal(runs[0][k], runs[1][k]) and np.array_equal(runs[0][k], runs[2][k]), k
+    assert rel_inf(runs[0]["pg"], pg) < GRAD_TOL and rel_inf(runs[0]["qg"], qg) < GRAD_TOL
+
+
+def test_workspace_state_contract(dev):
+    """The backward reads the state its forward left in the workspace.  ModelTraj notices when another forward has used the
+    workspace in between and rebuilds the state: gradients of the first loss are the same either way."""
+    from trajectory_optimization_amd.model import ModelTraj
+    pts = synth.make_cloud(30_000, seed=9)
+    poses, quats = synth.make_path(6, optical=True, jitter_seed=9)
+    def grads(second_forward):
+        m = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(K), IW, IH, device=dev)
+        loss = m(vis_wps_dist=0.0)
+        if second_forward:
+            with torch.no_grad():
+                m.poses.add_(0.05)
+            m(vis_wps_dist=0.0)
+            with torch.no_grad():
+                m.poses.sub_(0.05)
+        loss.backward()
+        return m.poses.grad.clone(), m.quats.grad.clone()
+    a, b = grads(False), grads(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
 @pytest.mark.parametrize("seed", range(10))
-def test_all_backward_variants_agree_on_random_configs(dev, seed):
+def test_modes_agree_on_random_configs(dev, seed):
     """Random clouds (compact ones with min p > 0 included), paths, rigs, clip limits, unsorted packing, duplicated points:
-    culled == dense, and the backward with the forward's record / with the scan's record == the backward without, bit for
-    bit.  (tools/stress_bitwise.py runs more of the same.)"""
+    culled == dense, bit for bit.  (tools/stress_bitwise.py runs more of the same.)"""
     ops = _ops()
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([700, 5000, 40_000, 140_000, 300_000]))
@@ -323,15 +367,9 @@ def test_all_backward_variants_agree_on_random_configs(dev, seed):
 
     grads = []
     for flags in (0, ops.DENSE):
-        lo, mm, need = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=flags, want_need=True)
+        lo, mm = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=flags)
         rew, sc = ops.traj_reward(cloud, lo, cam, ws)
-        plain = ops.traj_backward(cloud, p, q, cam, ws, lo, mm, rig=rg, flags=flags, scalars=sc, gout=gout)
-        masked = ops.traj_backward(cloud, p, q, cam, ws, lo, mm, rig=rg, flags=flags, scalars=sc, gout=gout, need_mask=need)
-        assert same(plain[0], masked[0]) and same(plain[1], masked[1]), ("forward's record", flags)
-        if flags:
-            scan = ops.traj_backward_scan(cloud, p, q, cam, ws, mm, rig=rg, flags=flags)
-            via_scan = ops.traj_backward(cloud, p, q, cam, ws, lo, mm, rig=rg, flags=flags, scalars=sc, gout=gout, need_mask=scan)
-            assert same(plain[0], via_scan[0]) and same(plain[1], via_scan[1]), "scan's record"
-        grads.append((lo, mm, rew, plain[0], plain[1]))
+        pg, qg = ops.traj_backward(cloud, w, cam, ws, lo, rig=rg, flags=flags, scalars=sc, gout=gout)
+        grads.append((lo.clone(), mm.clone(), rew, pg, qg))
     for a, b in zip(grads[0], grads[1]):
         assert same(a, b)  # culled == dense

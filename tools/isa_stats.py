@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
-"""Instruction mix of the gfx950 kernels: hipcc -S --cuda-device-only, then count mnemonics per kernel
-(and inside the hottest loop).  Usage: tools/isa_stats.py [kernel-name-substring ...]"""
+"""Instruction mix of the gfx950 kernels: hipcc -S --cuda-device-only, then count mnemonics per kernel and inside its
+innermost loop.
+
+  tools/isa_stats.py [kernel-name-substring ...]          print the mixes
+  tools/isa_stats.py --json profiles/r02_pass1_isa_mix.json
+        write the VALU mix of ONE (wave, waypoint) iteration of k_traj_pass1's dense inner loop — what bench.py prices for the
+        VALU-issue roofline (packed f32 / transcendental / other VALU; SALU, s_nop and memory instructions issue on other ports)
+"""
 import collections
+import json
 import os
 import re
 import subprocess
@@ -10,40 +17,79 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "trajectory_optimization_amd", "csrc", "trajopt_hip.hip")
+DENSE_PASS1 = "k_traj_pass1ILi4ELb0ELb0E"   # <P = 4, CULL = false, OCC = false>
+TRANS = re.compile(r"v_(exp|log|rcp|rsq|sqrt|sin|cos)_")
 
 
-def main():
-    pats = sys.argv[1:] or ["k_traj_pass1ILi4ELb1", "k_traj_pass2ILi4ELb1ELb0", "k_traj_bwdILi4ELb1"]
+def disassemble():
     out = os.path.join(tempfile.gettempdir(), "trajopt_isa.s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17",
-                           "-S", "--cuda-device-only", SRC, "-o", out])
-    text = open(out).read().split("\n")
+                           "-S", "--cuda-device-only", SRC, "-o", out], stderr=subprocess.DEVNULL)
+    return open(out).read().split("\n")
+
+
+def kernels(text):
+    """name -> (all instructions, instructions of blocks inside a loop)"""
+    res = {}
     i = 0
     while i < len(text):
         m = re.match(r"^(_Z\w+):", text[i])
-        if m and any(p in m.group(1) for p in pats):
-            name = m.group(1)
-            j = i + 1
-            body = []
-            while j < len(text) and "s_endpgm" not in text[j]:
-                body.append(text[j])
-                j += 1
-            ins = []
-            for l in body:
-                l = l.strip()
-                if not l or l.startswith((".", ";", "/")) or l.endswith(":"):
-                    continue
-                ins.append(l.split()[0])
-            c = collections.Counter(ins)
-            trans = sum(v for k, v in c.items() if re.match(r"v_(exp|log|rcp|rsq|sqrt|sin|cos)_", k))
-            valu = sum(v for k, v in c.items() if k.startswith("v_"))
-            print(f"{name[:60]}: {len(ins)} instrs, VALU {valu} (transcendental {trans}), "
-                  f"SALU/SMEM {sum(v for k, v in c.items() if k.startswith('s_'))}, "
-                  f"VMEM {sum(v for k, v in c.items() if k.startswith(('global_', 'buffer_', 'flat_')))}, "
-                  f"DS {sum(v for k, v in c.items() if k.startswith('ds_'))}")
-            print("   ", dict(c.most_common(28)))
-            i = j
-        i += 1
+        if not m:
+            i += 1
+            continue
+        name, j, ins, loop, in_loop = m.group(1), i + 1, [], [], False
+        while j < len(text) and "s_endpgm" not in text[j]:
+            l = text[j].strip()
+            j += 1
+            if re.match(r"^(\.LBB\w+:|; %bb\.\d+:)", l):
+                in_loop = "Loop" in l
+                continue
+            if not l or l.startswith((".", ";", "/")) or l.endswith(":"):
+                continue
+            op = l.split()[0]
+            ins.append(op)
+            if in_loop:
+                loop.append(op)
+        res[name] = (ins, loop)
+        i = j
+    return res
+
+
+def classes(ops):
+    c = collections.Counter(ops)
+    trans = sum(v for k, v in c.items() if TRANS.match(k))
+    pk = sum(v for k, v in c.items() if k.startswith("v_pk_"))
+    valu = sum(v for k, v in c.items() if k.startswith("v_"))
+    return c, dict(packed_f32=pk, transcendental=trans, other_valu=valu - pk - trans,
+                   salu_smem=sum(v for k, v in c.items() if k.startswith("s_")),
+                   vmem=sum(v for k, v in c.items() if k.startswith(("global_", "buffer_", "flat_"))),
+                   lds=sum(v for k, v in c.items() if k.startswith("ds_")))
+
+
+def main():
+    args = sys.argv[1:]
+    ks = kernels(disassemble())
+    if args and args[0] == "--json":
+        name = next(n for n in ks if DENSE_PASS1 in n)
+        c, cl = classes(ks[name][1])
+        out = dict(kernel=name, points_per_lane=4, evaluations_per_iteration=256,
+                   packed_f32=cl["packed_f32"], transcendental=cl["transcendental"], other_valu=cl["other_valu"],
+                   salu_smem=cl["salu_smem"], vmem=cl["vmem"],
+                   note="VALU instructions of one (wave, waypoint) iteration of the dense inner loop (hipcc -O3 --offload-arch=gfx950, "
+                        "ROCm 7.2); per evaluation: 26 FMA-class operations as 13 packed instructions per pair, 4 transcendentals",
+                   mnemonics=dict(c.most_common()))
+        with open(args[1], "w") as f:
+            json.dump(out, f, indent=1)
+        print(json.dumps({k: out[k] for k in ("packed_f32", "transcendental", "other_valu", "salu_smem", "vmem")}))
+        return
+    pats = args or ["k_traj_pass1ILi4E", "k_traj_lo_sparse", "k_traj_bwd_sparse", "k_traj_select"]
+    for name, (ins, loop) in ks.items():
+        if not any(p in name for p in pats):
+            continue
+        for what, ops in (("kernel", ins), ("loops", loop)):
+            c, cl = classes(ops)
+            print(f"{name[:70]} [{what}]: {len(ops)} instrs {cl}")
+            print("   ", dict(c.most_common(24)))
 
 
 if __name__ == "__main__":

@@ -404,3 +404,143 @@ __host__ __device__ inline void quat_to_R(const float q[4], float R[9]) {
     R[3] = 2.f * (x * y + w * z);         R[4] = w * w - x * x + y * y - z * z; R[5] = 2.f * (y * z - w * x);
     R[6] = 2.f * (x * z - w * y);         R[7] = 2.f * (y * z + w * x);         R[8] = w * w - x * x - y * y + z * z;
 }
+
+// ==============================================================================================
+// ModelTraj records and evaluation (traj_kernels.hip).
+//
+// Per evaluation the reference computes c = R^T (x - t), h = K c, z = h2 + eps, u = h0/z, v = h1/z and
+//   p = sigmoid(h2) * exp(-1/2 (|c - mu|^2/sigma^2 + ((u - W/2)/W)^2 + ((v - H/2)/H)^2))      model.py:13-47,:223
+// Everything the camera contributes is linear in y = x - t, so the per-waypoint record holds three row vectors
+//   g0 = f0 . y,  g1 = f1 . y,  z = f2 . y + eps       f0 = sqrt(L2E/2)/W * K[0,:] R^T,  f1 likewise,  f2 = K[2,:] R^T
+// and the world-aligned offset of the Gaussian's centre, sp = R mu (|c - mu| = |y - sp|: rotations keep lengths).
+// With cd = L2E/(2 sigma^2), cw = ch = sqrt(L2E/2)/2 the exponent arrives in base 2 without further scaling:
+//   A = cd |y - sp|^2 + (g0/z - cw)^2 + (g1/z - ch)^2,    p = 2^-A / (1 + 2^(-L2E (z - eps)))
+// 26 FMA-class operations and 4 transcendentals (v_rcp x2, v_exp x2) per evaluation; any K (no pinhole special case).
+// The scalar and the packed function apply the same IEEE operations per element, so pass 1 (packed) and the sparse
+// kernels (scalar) see bit-identical p — they compare it with == against the per-waypoint extrema.
+
+#define TO_L2E 1.4426950408889634
+
+// 128 bytes = two 64-byte lines per virtual waypoint; line 0 is all a plain evaluation reads (one s_load_dwordx16).
+struct __attribute__((aligned(128))) WayRec {
+    float t[3];    //  0..2   translation of the virtual waypoint
+    float f0[3];   //  3..5
+    float f1[3];   //  6..8
+    float f2[3];   //  9..11
+    float sp[3];   // 12..14
+    float a;       // 15      min_n p                      (k_select)
+    float invM;    // 16      1 / max_n (p - a)            (k_select)
+    float M;       // 17      max_n (p - a)
+    float L;       // 18      probe: an attained value of p (lower bound of the max); 0 = none
+    float thr1;    // 19      probe: squared-distance bound, d2 > thr1  =>  p < L/2  (+inf = never cull)
+    float sthr1;   // 20      sqrt(thr1), rounded up
+    float azero;   // 21      probe: 1 = a point with p == 0 was exhibited, hence min_n p == 0 exactly
+    float m[9];    // 22..30  m[3*i+j] = R[j][i]: c = m y (the gradient chain wants R)
+    float pad;
+};
+static_assert(sizeof(WayRec) == 128, "WayRec is two 64-byte lines");
+
+struct EvalK {
+    float eps, cw, ch, cd;
+    float nl2e;      // -L2E
+    float l2e_eps;   //  L2E * eps
+    float clip_hi;   // float32(1 - 1e-6)                                   model.py:229
+    float inv_var;   // 1/sigma^2 (cull bounds)
+    float su, sv;    // sqrt(L2E/2)/W, sqrt(L2E/2)/H (record construction)
+    float mean;      // (min+max)/2
+    float k[9];      // intrinsics (record construction)
+};
+
+static inline EvalK make_evalk(const tohip_camera* c) {
+    EvalK k;
+    const double sd = ((double)c->max_dist - (double)c->min_dist) / 2.0;
+    const double s = sqrt(TO_L2E * 0.5);
+    k.eps = c->eps;
+    k.cw = k.ch = (float)(0.5 * s);
+    k.cd = (float)(TO_L2E * 0.5 / (sd * sd));
+    k.nl2e = (float)(-TO_L2E);
+    k.l2e_eps = (float)(TO_L2E * (double)c->eps);
+    k.clip_hi = (float)(1.0 - (double)c->eps);
+    k.inv_var = (float)(1.0 / (sd * sd));
+    k.su = (float)(s / (double)c->img_width);
+    k.sv = (float)(s / (double)c->img_height);
+    k.mean = (float)(((double)c->min_dist + (double)c->max_dist) / 2.0);
+    for (int i = 0; i < 9; ++i) k.k[i] = c->K[i];
+    return k;
+}
+
+__device__ __forceinline__ float to_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// everything the gradient wants besides p
+struct VisGrad {
+    float y0, y1, y2, d0, d1, d2, g0, g1, rz, au, av, S;
+};
+
+__device__ __forceinline__ float vis_p(const WayRec& r, const EvalK& k, float x, float y, float z, VisGrad* o = nullptr) {
+    const float y0 = x - r.t[0], y1 = y - r.t[1], y2 = z - r.t[2];
+    const float g0 = fmaf(r.f0[2], y2, fmaf(r.f0[1], y1, r.f0[0] * y0));
+    const float g1 = fmaf(r.f1[2], y2, fmaf(r.f1[1], y1, r.f1[0] * y0));
+    const float zz = fmaf(r.f2[2], y2, fmaf(r.f2[1], y1, fmaf(r.f2[0], y0, k.eps)));
+    const float d0 = y0 - r.sp[0], d1 = y1 - r.sp[1], d2 = y2 - r.sp[2];
+    const float dd = fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
+    const float rz = to_rcp(zz);
+    const float au = fmaf(g0, rz, -k.cw), av = fmaf(g1, rz, -k.ch);
+    const float A = fmaf(av, av, fmaf(au, au, dd * k.cd));
+    const float E = to_exp2(-A);
+    const float e = to_exp2(fmaf(zz, k.nl2e, k.l2e_eps));
+    const float S = to_rcp(1.0f + e);
+    if (o) { o->y0 = y0; o->y1 = y1; o->y2 = y2; o->d0 = d0; o->d1 = d1; o->d2 = d2; o->g0 = g0; o->g1 = g1; o->rz = rz; o->au = au; o->av = av; o->S = S; }
+    return S * E;
+}
+
+__device__ __forceinline__ f2 vis_p_pk(const WayRec& r, const EvalK& k, f2 x, f2 y, f2 z) {
+    const f2 y0 = x - pk_splat(r.t[0]), y1 = y - pk_splat(r.t[1]), y2 = z - pk_splat(r.t[2]);
+    const f2 g0 = pk_fma(pk_splat(r.f0[2]), y2, pk_fma(pk_splat(r.f0[1]), y1, pk_splat(r.f0[0]) * y0));
+    const f2 g1 = pk_fma(pk_splat(r.f1[2]), y2, pk_fma(pk_splat(r.f1[1]), y1, pk_splat(r.f1[0]) * y0));
+    const f2 zz = pk_fma(pk_splat(r.f2[2]), y2, pk_fma(pk_splat(r.f2[1]), y1, pk_fma(pk_splat(r.f2[0]), y0, pk_splat(k.eps))));
+    const f2 d0 = y0 - pk_splat(r.sp[0]), d1 = y1 - pk_splat(r.sp[1]), d2 = y2 - pk_splat(r.sp[2]);
+    const f2 dd = pk_fma(d2, d2, pk_fma(d1, d1, d0 * d0));
+    const f2 rz = pk_rcp(zz);
+    const f2 au = pk_fma(g0, rz, pk_splat(-k.cw)), av = pk_fma(g1, rz, pk_splat(-k.ch));
+    const f2 A = pk_fma(av, av, pk_fma(au, au, dd * pk_splat(k.cd)));
+    const f2 E = f2{to_exp2(-A.x), to_exp2(-A.y)};
+    const f2 ea = pk_fma(zz, pk_splat(k.nl2e), pk_splat(k.l2e_eps));
+    const f2 S = pk_rcp(pk_splat(1.0f) + f2{to_exp2(ea.x), to_exp2(ea.y)});
+    return S * E;
+}
+
+// d p / d y (y = x - t, world-aligned) of the same evaluation; zero where p underflowed or the pair is occluded.
+//   ln p = ln S - ln2 A,   d ln S / dy = (1 - S) f2,
+//   dA/dy = 2 cd (y - sp) + 2 rz [ au (f0 - g0 rz f2) + av (f1 - g1 rz f2) ]
+__device__ __forceinline__ void dvis_dy(const WayRec& r, const EvalK& k, float p, const VisGrad& s, float g[3]) {
+    const float q0 = s.g0 * s.rz, q1 = s.g1 * s.rz;
+    const float oneS = 1.0f - s.S;
+    const float c2 = 2.0f * 0.693147180559945f;
+    const float dk[3] = {s.d0, s.d1, s.d2};
+    const bool live = p > 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float w0 = fmaf(-q0, r.f2[i], r.f0[i]);   // f0 - g0 rz f2
+        const float w1 = fmaf(-q1, r.f2[i], r.f1[i]);
+        const float dA = fmaf(s.rz, fmaf(s.av, w1, s.au * w0), k.cd * dk[i]);   // (dA/dy)/2
+        g[i] = live ? p * fmaf(-c2, dA, oneS * r.f2[i]) : 0.0f;
+    }
+}
+
+// in-row (16 lanes) reductions of non-negative floats on their bit patterns: every lane of the row ends up with the result
+__device__ __forceinline__ float row_min16_nn(float f) {
+    int v = __builtin_bit_cast(int, f);
+    v = min(v, TO_DPP_I(v, v, 0xB1, 0xF, true));
+    v = min(v, TO_DPP_I(v, v, 0x4E, 0xF, true));
+    v = min(v, TO_DPP_I(v, v, 0x141, 0xF, true));
+    v = min(v, TO_DPP_I(v, v, 0x140, 0xF, true));
+    return __builtin_bit_cast(float, v);
+}
+__device__ __forceinline__ float row_max16_nn(float f) {
+    int v = __builtin_bit_cast(int, f);
+    v = max(v, TO_DPP_I(v, v, 0xB1, 0xF, true));
+    v = max(v, TO_DPP_I(v, v, 0x4E, 0xF, true));
+    v = max(v, TO_DPP_I(v, v, 0x141, 0xF, true));
+    v = max(v, TO_DPP_I(v, v, 0x140, 0xF, true));
+    return __builtin_bit_cast(float, v);
+}

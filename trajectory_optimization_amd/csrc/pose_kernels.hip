@@ -8,7 +8,34 @@
 
 #include "common.hpp"
 
-// k_prep_waycams / k_bwd_finish2 come from traj_kernels.hip (same translation unit, see trajopt_hip.hip)
+// k_bwd_finish2 (the quaternion chain) comes from traj_kernels.hip (same translation unit, see trajopt_hip.hip)
+
+// the pose's camera record: F.normalize (model.py:53), m = R(q/|q|)^T
+__global__ void k_prep_posecam(const float* __restrict__ trans, const float* __restrict__ quat, WayHot* __restrict__ hot,
+                               WayCold* __restrict__ cold) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float q[4] = {quat[0], quat[1], quat[2], quat[3]};
+    float ss = q[0] * q[0];
+    ss = ss + q[1] * q[1];
+    ss = ss + q[2] * q[2];
+    ss = ss + q[3] * q[3];
+    float n = sqrtf(ss);
+    n = n < 1e-12f ? 1e-12f : n;
+    for (int i = 0; i < 4; ++i) q[i] = q[i] / n;
+    WayCold cd;
+    for (int i = 0; i < 4; ++i) cd.qn[i] = q[i];
+    cd.nrm = n;
+    cd.pad[0] = cd.pad[1] = cd.pad[2] = 0.f;
+    cold[0] = cd;
+    float R[9];
+    quat_to_R(q, R);
+    WayHot h;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) h.m[3 * i + j] = R[3 * j + i];
+    h.t[0] = trans[0]; h.t[1] = trans[1]; h.t[2] = trans[2];
+    h.a = 0.f; h.invM = 1.f; h.thr = INFINITY; h.sthr = INFINITY;
+    hot[0] = h;
+}
 
 // observations + block partial sums (grid-stride, one point per lane per step: streaming 12 B in, 4 B out)
 template <bool PINHOLE>
@@ -215,7 +242,7 @@ extern "C" int tohip_pose_forward(const void* packed, int64_t n, const float* tr
     double* part = (double*)(ws + pl.off_part);
     const CamConsts cc = make_consts(cam);
     const CloudView cv = cloud_view(packed, n);
-    k_prep_waycams<<<1, 64, 0, st>>>(trans, quat, 1, 1, nullptr, nullptr, hot, cold, nullptr);
+    k_prep_posecam<<<1, 64, 0, st>>>(trans, quat, hot, cold);
     TO_HIP_CHECK_LAUNCH();
     const int nb = pose_blocks(n);
     if (cc.pinhole) k_pose_fwd<true><<<nb, TO_BLOCK, 0, st>>>(cv, hot, cc, mask, obs, part);
@@ -243,7 +270,7 @@ extern "C" int tohip_pose_backward(const void* packed, int64_t n, const float* t
     float* vgrad = (float*)(ws + pl.off_vgrad);
     const CamConsts cc = make_consts(cam);
     const CloudView cv = cloud_view(packed, n);
-    k_prep_waycams<<<1, 64, 0, st>>>(trans, quat, 1, 1, nullptr, nullptr, hot, cold, nullptr);
+    k_prep_posecam<<<1, 64, 0, st>>>(trans, quat, hot, cold);
     TO_HIP_CHECK_LAUNCH();
     const int nb = pose_blocks(n);
     if (cc.pinhole) k_pose_bwd<true><<<nb, TO_BLOCK, 0, st>>>(cv, hot, cc, mask, grad_obs, scalars, gout, part);

@@ -33,8 +33,8 @@ extern "C" int tohip_profile_enable(int on) {
 }
 
 extern "C" const char* tohip_profile_name(int id) {
-    static const char* names[TOHIP_PROF_NKERNELS] = {"k_traj_pass1", "k_traj_pass2", "k_traj_bwd", "k_reward(+finish)",
-                                                      "prep/finish kernels"};
+    static const char* names[TOHIP_PROF_NKERNELS] = {"k_traj_pass1", "k_traj_lo_sparse", "k_traj_bwd_sparse", "k_traj_reward",
+                                                      "prep/probe + select + finish kernels"};
     return (id >= 0 && id < TOHIP_PROF_NKERNELS) ? names[id] : "?";
 }
 

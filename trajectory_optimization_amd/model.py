@@ -124,14 +124,19 @@ class _PoseLoss(torch.autograd.Function):
         return tg, qg, None, None
 
 
-def _forward_with_need(model, ps, qs, n_local, occ):
-    """tohip_traj_forward for the model's local waypoints -> (lo_sum, minmax, need mask or None)."""
-    if model._flags & ops.DENSE:
-        return ops.traj_forward(model._cloud, ps, qs, model._cam, model._workspace(n_local), model._rig, flags=model._flags,
-                                occ=occ, want_need=True)
-    lo_sum, minmax = ops.traj_forward(model._cloud, ps, qs, model._cam, model._workspace(n_local), model._rig,
-                                      flags=model._flags, occ=occ)
-    return lo_sum, minmax, None
+def _local_forward(model, ps, qs, occ):
+    """tohip_traj_forward for this rank's waypoints -> (lo_sum, minmax, workspace, its generation)."""
+    ws = model._workspace(ps.shape[0])
+    lo_sum, minmax = ops.traj_forward(model._cloud, ps, qs, model._cam, ws, model._rig, flags=model._flags, occ=occ)
+    return lo_sum, minmax, ws, ws.generation
+
+
+def _local_backward(model, ctx_ws, ctx_gen, ps, qs, occ, lo_sum, **kw):
+    """tohip_traj_backward reads the state the step's forward left in the workspace.  If another forward has used the
+    workspace since (model() called again before backward()), that state is rebuilt first — same inputs, same bits."""
+    if ctx_ws.generation != ctx_gen:
+        ops.traj_forward(model._cloud, ps, qs, model._cam, ctx_ws, model._rig, flags=model._flags, occ=occ)
+    return ops.traj_backward(model._cloud, ps.shape[0], model._cam, ctx_ws, lo_sum, rig=model._rig, flags=model._flags, occ=occ, **kw)
 
 
 class _TrajRewards(torch.autograd.Function):
@@ -144,36 +149,32 @@ class _TrajRewards(torch.autograd.Function):
         q = quats.detach().contiguous()
         sh = model._shard
         lo, hi = sh.bounds(p.shape[0])
-        ps, qs = p[lo:hi].contiguous(), q[lo:hi].contiguous()
+        ps, qs = p[lo:hi].clone(), q[lo:hi].clone()  # own copies: the step's inputs, whatever happens to the Parameters
         occ = None
         if hi > lo and model._occlusion is not None:
             # occlusion masks are piecewise constant in the poses: computed per forward, not differentiated
-            occ = ops.occlusion_bits(model._cloud, model.points, ps, qs, model._cam, model._occlusion_limits[0],
-                                     model._occlusion_limits[1], model._occlusion)
-        need = None
+            occ = model._occlusion_rows(ps, qs)
+        ws, gen = None, 0
         if hi > lo:
-            # dense mode: the forward also records which (wave, waypoint) combinations will carry gradient and the backward
-            # walks those (0.05 instead of 0.19 ms at 1 M x 128); the culled backward is already that cheap without it
-            lo_sum, minmax, need = _forward_with_need(model, ps, qs, hi - lo, occ)
+            lo_sum, _, ws, gen = _local_forward(model, ps, qs, occ)
         else:
-            lo_sum, minmax = torch.zeros(model._cloud.npad, device=p.device), None
+            lo_sum = torch.zeros(model._cloud.npad, device=p.device)
         lo_sum = sh.allreduce_sum(lo_sum)
         rewards, _ = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)))
-        ctx.model, ctx.range, ctx.n_wps, ctx.occ, ctx.need = model, (lo, hi), p.shape[0], occ, need
-        ctx.save_for_backward(ps, qs, lo_sum, minmax if minmax is not None else torch.empty(0, device=p.device))
+        ctx.model, ctx.range, ctx.n_wps, ctx.occ, ctx.ws, ctx.gen = model, (lo, hi), p.shape[0], occ, ws, gen
+        ctx.save_for_backward(ps, qs, lo_sum)
         return rewards
 
     @staticmethod
     def backward(ctx, grad_rewards):
-        ps, qs, lo_sum, minmax = ctx.saved_tensors
+        ps, qs, lo_sum = ctx.saved_tensors
         m = ctx.model
         lo, hi = ctx.range
         # every rank fills the rows of its own waypoints; ONE (W,7) all-reduce assembles positions and quaternions
         grads = torch.zeros((ctx.n_wps, 7), dtype=torch.float32, device=lo_sum.device)
         if hi > lo:
             g = grad_rewards.to(torch.float32).contiguous()
-            pg, qg = ops.traj_backward(m._cloud, ps, qs, m._cam, m._workspace(hi - lo), lo_sum, minmax,
-                                       grad_rewards=g, rig=m._rig, flags=m._flags, occ=ctx.occ, need_mask=ctx.need)
+            pg, qg = _local_backward(m, ctx.ws, ctx.gen, ps, qs, ctx.occ, lo_sum, grad_rewards=g)
             grads[lo:hi, :3], grads[lo:hi, 3:] = pg, qg
         grads = m._shard.allreduce_sum(grads)
         return grads[:, :3].contiguous(), grads[:, 3:].contiguous(), None
@@ -199,16 +200,15 @@ class _TrajLoss(torch.autograd.Function):
         q_eval = q_all[::step_w].contiguous() if step_w > 1 else q_all
         sh = model._shard
         lo, hi = sh.bounds(p_eval.shape[0])
-        ps, qs = p_eval[lo:hi].contiguous(), q_eval[lo:hi].contiguous()
+        ps, qs = p_eval[lo:hi].clone(), q_eval[lo:hi].clone()  # own copies: the step's inputs, whatever happens to the Parameters
         occ = None
         if hi > lo and model._occlusion is not None:
-            occ = ops.occlusion_bits(model._cloud, model.points, ps, qs, model._cam, model._occlusion_limits[0],
-                                     model._occlusion_limits[1], model._occlusion)
-        need = None
+            occ = model._occlusion_rows(ps, qs)
+        ws, gen = None, 0
         if hi > lo:
-            lo_sum, minmax, need = _forward_with_need(model, ps, qs, hi - lo, occ)
+            lo_sum, _, ws, gen = _local_forward(model, ps, qs, occ)
         else:
-            lo_sum, minmax = torch.zeros(model._cloud.npad, device=dev), None
+            lo_sum = torch.zeros(model._cloud.npad, device=dev)
         lo_sum = sh.allreduce_sum(lo_sum)
         rewards, scalars = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)))
         terms = torch.empty(8, dtype=torch.float32, device=dev)
@@ -218,16 +218,15 @@ class _TrajLoss(torch.autograd.Function):
             check(L.tohip_traj_regularizers(ptr(p_all), ptr(model.poses0), W, float(model.smoothness_weight),
                                             float(model.traj_length_weight), float(model.eps), ptr(scalars), ptr(terms),
                                             ptr(reg_sum), 0, None, ptr(reg_terms), stream_ptr()), "tohip_traj_regularizers")
-        ctx.model, ctx.range, ctx.step_w, ctx.W, ctx.occ, ctx.need = model, (lo, hi), step_w, W, occ, need
+        ctx.model, ctx.range, ctx.step_w, ctx.W, ctx.occ, ctx.ws, ctx.gen = model, (lo, hi), step_w, W, occ, ws, gen
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(ps, qs, lo_sum, minmax if minmax is not None else torch.empty(0, device=dev), scalars, reg_sum,
-                              reg_terms)
+        ctx.save_for_backward(ps, qs, lo_sum, scalars, reg_sum, reg_terms)
         vis, l2, length, smooth, total = terms[:5].unbind()
         return total, rewards, vis, l2, length, smooth
 
     @staticmethod
     def backward(ctx, g_loss, g_rewards, g_vis, g_l2, g_length, g_smooth):
-        ps, qs, lo_sum, minmax, scalars, reg_sum, reg_terms = ctx.saved_tensors
+        ps, qs, lo_sum, scalars, reg_sum, reg_terms = ctx.saved_tensors
         m = ctx.model
         lo, hi = ctx.range
         dev = lo_sum.device
@@ -249,8 +248,7 @@ class _TrajLoss(torch.autograd.Function):
                 if c_vis is not None:
                     g = g + c_vis * scalars[2]  # d loss_vis / d reward_n = -vis^2 / N
                 kw = dict(grad_rewards=g.contiguous())
-            pg, qg = ops.traj_backward(m._cloud, ps, qs, m._cam, m._workspace(hi - lo), lo_sum, minmax, rig=m._rig,
-                                       flags=m._flags, occ=ctx.occ, need_mask=ctx.need, **kw)
+            pg, qg = _local_backward(m, ctx.ws, ctx.gen, ps, qs, ctx.occ, lo_sum, **kw)
             rows = slice(lo * ctx.step_w, (hi - 1) * ctx.step_w + 1, ctx.step_w)
             grads[rows, :3], grads[rows, 3:] = pg, qg
         grads = m._shard.allreduce_sum(grads)
@@ -420,6 +418,11 @@ class ModelTraj(nn.Module):
         # forward() as ONE autograd node (visibility + criterion on the device); False: rewards node + the op-by-op
         # torch criterion below (always used when a subclass overrides criterion, or for fewer than 3 waypoints)
         self.fused_loss = True
+
+    def _occlusion_rows(self, ps, qs):
+        """Occlusion bit rows of the given body waypoints (one row per virtual waypoint)."""
+        return ops.occlusion_bits(self._cloud, self.points, ps, qs, self._cam, self._occlusion_limits[0],
+                                  self._occlusion_limits[1], self._occlusion)
 
     def _workspace(self, n_local_wps):
         v = n_local_wps * (self._rig.n_cams if self._rig is not None else 1)

@@ -78,69 +78,59 @@ _NULL_RIG = ctypes.POINTER(_lib.Rig)()
 
 
 class TrajWorkspace:
+    """Scratch + step state of the ModelTraj kernels.  Zero-filled once (the C ABI's contract); `generation` counts the
+    forwards that used it — the backward of a step must find the state its own forward left (model.py checks)."""
+
     def __init__(self, cloud, n_virtual):
         self.bytes = _lib.lib().tohip_traj_workspace_bytes(cloud.n, n_virtual)
-        self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=cloud.device)
+        self.buf = torch.zeros(self.bytes, dtype=torch.uint8, device=cloud.device)
         self.n_virtual = n_virtual
+        self.generation = 0
 
 
 DENSE = 1  # TOHIP_TRAJ_DENSE
 
 
-def traj_forward(cloud, poses, quats, cam, ws, rig=None, flags=0, occ=None, want_need=False):
-    """-> (lo_sum[npad] in packed order (first N valid), minmax[V,2]) for the given waypoints (this rank's shard);
-    with want_need=True also the need mask (uint8 buffer) that lets traj_backward walk only the pairs with gradient."""
+def traj_forward(cloud, poses, quats, cam, ws, rig=None, flags=0, occ=None, lo_sum=None, minmax=None):
+    """-> (lo_sum[npad] in packed order (first N valid), minmax[V,2]) for the given waypoints (this rank's shard).
+    Leaves the step's state in `ws` for traj_backward."""
     W = poses.shape[0]
     C = rig.n_cams if rig is not None else 1
-    lo_sum = torch.empty(cloud.npad, dtype=torch.float32, device=cloud.device)
-    minmax = torch.empty((W * C, 2), dtype=torch.float32, device=cloud.device)
-    need = None
-    if want_need:
-        need = torch.empty(_lib.lib().tohip_traj_need_mask_bytes(cloud.n, W * C), dtype=torch.uint8, device=cloud.device)
+    if lo_sum is None:
+        lo_sum = torch.empty(cloud.npad, dtype=torch.float32, device=cloud.device)
+    if minmax is None:
+        minmax = torch.empty((W * C, 2), dtype=torch.float32, device=cloud.device)
+    ws.generation += 1
     with torch.cuda.device(cloud.device):
         check(_lib.lib().tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
                                             rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(occ), ptr(lo_sum), ptr(minmax),
-                                            ptr(need), ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_forward")
-    return (lo_sum, minmax, need) if want_need else (lo_sum, minmax)
+                                            ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_forward")
+    return lo_sum, minmax
 
 
-def traj_reward(cloud, lo_sum, cam, ws):
+def traj_reward(cloud, lo_sum, cam, ws, rewards=None, scalars=None):
     """-> (rewards[N], scalars[4] = mean, loss_vis, dloss/dreward, -)"""
-    rewards = torch.empty(cloud.n, dtype=torch.float32, device=cloud.device)
-    scalars = torch.empty(4, dtype=torch.float32, device=cloud.device)  # all four written by the finish kernel
+    if rewards is None:
+        rewards = torch.empty(cloud.n, dtype=torch.float32, device=cloud.device)
+    if scalars is None:
+        scalars = torch.empty(4, dtype=torch.float32, device=cloud.device)  # all four written by the kernel
     with torch.cuda.device(cloud.device):
         check(_lib.lib().tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, ptr(rewards), ptr(scalars), ptr(ws.buf),
                                            ws.bytes, stream_ptr()), "tohip_traj_reward")
     return rewards, scalars
 
 
-def traj_backward(cloud, poses, quats, cam, ws, lo_sum, minmax, grad_rewards=None, scalars=None, gout=None, rig=None,
-                  flags=0, occ=None, need_mask=None):
-    """lo_sum: the (all-reduced) log-odds vector in packed order, as returned by traj_forward.
-    need_mask: the result of traj_backward_scan on the same inputs (dense mode; second half of the split backward)."""
-    W = poses.shape[0]
-    pg = torch.empty((W, 3), dtype=torch.float32, device=cloud.device)
-    qg = torch.empty((W, 4), dtype=torch.float32, device=cloud.device)
+def traj_backward(cloud, n_wps, cam, ws, lo_sum, grad_rewards=None, scalars=None, gout=None, rig=None, flags=0, occ=None):
+    """Gradients of the step whose traj_forward last used `ws` (same cloud, n_wps, rig, flags, occ).
+    lo_sum: the (all-reduced) log-odds vector in packed order, as returned by traj_forward."""
+    pg = torch.empty((n_wps, 3), dtype=torch.float32, device=cloud.device)
+    qg = torch.empty((n_wps, 4), dtype=torch.float32, device=cloud.device)
     with torch.cuda.device(cloud.device):
-        check(_lib.lib().tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
+        check(_lib.lib().tohip_traj_backward(ptr(cloud.blob), cloud.n, n_wps, cam.ref(),
                                              rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(occ), ptr(lo_sum),
-                                             ptr(grad_rewards), ptr(scalars), ptr(minmax), ptr(gout), ptr(need_mask), ptr(pg),
-                                             ptr(qg), ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_backward")
+                                             ptr(grad_rewards), ptr(scalars), ptr(gout), ptr(pg), ptr(qg), ptr(ws.buf), ws.bytes,
+                                             stream_ptr()), "tohip_traj_backward")
     return pg, qg
-
-
-def traj_backward_scan(cloud, poses, quats, cam, ws, minmax, rig=None, flags=DENSE, occ=None, out=None):
-    """First half of the split dense backward: independent of lo_sum, so it can be enqueued while the all-reduce of lo_sum
-    is in flight on another stream.  -> need_mask (uint8), to be handed to traj_backward."""
-    W = poses.shape[0]
-    V = W * (rig.n_cams if rig is not None else 1)
-    nbytes = _lib.lib().tohip_traj_need_mask_bytes(cloud.n, V)
-    mask = out if out is not None and out.numel() >= nbytes else torch.empty(nbytes, dtype=torch.uint8, device=cloud.device)
-    with torch.cuda.device(cloud.device):
-        check(_lib.lib().tohip_traj_backward_scan(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
-                                                  rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(occ), ptr(minmax),
-                                                  ptr(mask), ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_backward_scan")
-    return mask
 
 
 class PoseWorkspace:

@@ -26,7 +26,7 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
     """Runs up to n_opt_steps on `model` (a ModelTraj) in place; returns a TrajOptResult (one host sync, at the end).
     model.poses / model.quats hold the optimised trajectory, model.rewards the last rewards, model.loss the last terms.
 
-    use_graph: capture one iteration (≈11 launches, every per-step value read from device state) into a hipGraph and
+    use_graph: capture one iteration (≈9 launches, every per-step value read from device state) into a hipGraph and
     replay it n_opt_steps times (not with waypoint sharding, whose all-reduce stays outside a capture, nor with
     per-waypoint occlusion, whose hull construction syncs).  Measured on the reference's bundled cloud (40 452 points,
     14 evaluated waypoints, MI355X): eager launch-only loop 0.124 ms/step, graph replay 0.168 ms/step, the
@@ -51,12 +51,6 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
     pg, qg = torch.zeros((W, 3), **f32), torch.zeros((W, 4), **f32)
     lo_sum = torch.empty(cloud.npad, **f32)
     minmax = torch.empty((max(n_loc, 1) * (rig.n_cams if rig else 1), 2), **f32)
-    # the forward records which (wave, waypoint) combinations carry gradient; the backward walks only those
-    # (dense mode only: the culled backward is as cheap without it and the forward would pay for the record)
-    need = None
-    if model._flags & ops.DENSE:
-        need = torch.empty(L.tohip_traj_need_mask_bytes(cloud.n, max(n_loc, 1) * (rig.n_cams if rig else 1)), dtype=torch.uint8,
-                           device=dev)
     rewards, scalars = torch.empty(cloud.n, **f32), torch.zeros(4, **f32)
     loss_terms = torch.zeros((n_opt_steps + 1, 8), **f32)
     state = torch.zeros(8, **f32)
@@ -78,8 +72,9 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
                                      model._occlusion_limits[1], model._occlusion)
         if n_loc > 0:
             check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref,
-                                       model._flags, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(need), ptr(ws.buf), ws.bytes, s),
+                                       model._flags, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(ws.buf), ws.bytes, s),
                   "forward")
+            ws.generation += 1
         else:
             lo_sum.zero_()
         model._shard.allreduce_sum(lo_sum)
@@ -87,9 +82,8 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
                                   ptr(ws.buf), ws.bytes, s), "reward")
         tgt_p, tgt_q = (pg_loc, qg_loc) if sharded else (pg_e, qg_e)
         if n_loc > 0:
-            check(L.tohip_traj_backward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref,
-                                        model._flags, ptr(occ), ptr(lo_sum), None, ptr(scalars), ptr(minmax), ptr(gout),
-                                        ptr(need), ptr(tgt_p), ptr(tgt_q), ptr(ws.buf), ws.bytes, s), "backward")
+            check(L.tohip_traj_backward(ptr(cloud.blob), cloud.n, n_loc, cam.ref(), rig_ref, model._flags, ptr(occ), ptr(lo_sum),
+                                        None, ptr(scalars), ptr(gout), ptr(tgt_p), ptr(tgt_q), ptr(ws.buf), ws.bytes, s), "backward")
         if sharded:
             # assemble every rank's gradient rows: ONE (n_eval, 7) all-reduce, then the replicated remainder of the step
             if n_loc > 0:
