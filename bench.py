@@ -173,10 +173,11 @@ def main():
         torch.cuda.synchronize(device)
 
     def step(flags):
-        lo_sum, minmax = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags)
+        rewards = torch.empty(cloud.n, dtype=torch.float32, device=device)
+        lo_sum, minmax = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags, rewards_half=rewards)
         if shard is not None:
             shard.allreduce_sum(lo_sum)  # the one data-path collective: N floats over xGMI
-        rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws)
+        rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws, rewards=rewards, prefilled=True)
         pg, qg = ops.traj_backward(cloud, args.wps_per_gpu, cam, ws, lo_sum, scalars=scalars, gout=gout, rig=rig, flags=flags)
         if shard is not None:
             g = shard.allgather_rows(torch.cat([pg, qg], dim=1))  # (W_total, 7) floats: every rank can step the optimiser

@@ -70,8 +70,8 @@ int main(int argc, char** argv) {
     HIP_OK(hipStreamCreate(&st));
     TO_OK(tohip_pack_cloud(d_pts, n, 1, d_packed, d_ws, pack_ws, st));
     HIP_OK(hipMemsetAsync(d_ws, 0, traj_ws, st));  // the workspace is zero-filled once before its first use
-    TO_OK(tohip_traj_forward(d_packed, n, d_poses, d_quats, W, &cam, nullptr, 0, nullptr, d_lo, d_minmax, d_ws, traj_ws, st));
-    TO_OK(tohip_traj_reward(d_packed, d_lo, n, cam.eps, d_rewards, d_scalars, d_ws, traj_ws, st));
+    TO_OK(tohip_traj_forward(d_packed, n, d_poses, d_quats, W, &cam, nullptr, 0, nullptr, d_lo, d_minmax, d_rewards, d_ws, traj_ws, st));
+    TO_OK(tohip_traj_reward(d_packed, d_lo, n, cam.eps, 1, d_rewards, d_scalars, d_ws, traj_ws, st));
     TO_OK(tohip_traj_backward(d_packed, n, W, &cam, nullptr, 0, nullptr, d_lo, nullptr, d_scalars, d_gout, d_pg, d_qg, d_ws, traj_ws,
                               st));
     HIP_OK(hipStreamSynchronize(st));

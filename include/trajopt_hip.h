@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOHIP_ABI_VERSION 4
+#define TOHIP_ABI_VERSION 5
 
 #define TOHIP_OK 0
 #define TOHIP_EINVAL (-1)   /* bad size / null pointer */
@@ -95,7 +95,11 @@ size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual);
  * replaces model.py:217-231. */
 int tohip_traj_forward(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
                        const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits,
-                       float *lo_sum, float *minmax, void *workspace, size_t workspace_bytes, void *stream);
+                       float *lo_sum, float *minmax, float *rewards_half, void *workspace, size_t workspace_bytes,
+                       void *stream);
+/* rewards_half (may be NULL): N floats that the forward fills with sigmoid(0) = 0.5 on its way — hand the same array to
+ * tohip_traj_reward with prefilled = 1 and that call only stores the rewards of the points with a non-zero log-odds (2 % of
+ * the cloud on the BASELINE workloads) instead of scattering all N. */
 /* occlusion_bits (may be NULL = nothing occluded): per virtual waypoint a row of Npad/32 words, bit i = 1 when the
  * packed (sorted) point i is NOT occluded from that waypoint; an occluded pair has p = 0.  The per-waypoint
  * analogue of ModelPose's occlusion mask (model.py:112-115) that the reference leaves as a TODO (tools.py:61-62).
@@ -113,9 +117,10 @@ int tohip_occlusion_rows(int64_t n_points, const int32_t *inv_perm, const int32_
 
 /* rewards[0..N) = sigmoid(lo_sum) in the CALLER'S point order (model.py:237); scalars[0] = mean(rewards),
  * scalars[1] = loss_vis = 1/(mean+eps) (model.py:246), scalars[2] = -loss_vis^2/N (d loss_vis / d reward_n).
- * One launch.  workspace: a zero-filled-once region of at least tohip_traj_workspace_bytes(n_points, 1) bytes — normally
- * the forward's workspace (only its first 64 KB are used, and none of the forward's state). */
-int tohip_traj_reward(const void *packed, const float *lo_sum, int64_t n_points, float eps, float *rewards,
+ * One launch.  prefilled != 0: the caller promises rewards[0..N) == 0.5 on entry (tohip_traj_forward's rewards_half).
+ * workspace: a zero-filled-once region of at least 256 bytes — normally the forward's workspace (none of the forward's
+ * state is touched). */
+int tohip_traj_reward(const void *packed, const float *lo_sum, int64_t n_points, float eps, int prefilled, float *rewards,
                       float *scalars, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward w.r.t. this rank's waypoints: poses_grad (W,3), quats_grad (W,4), for the step whose tohip_traj_forward last

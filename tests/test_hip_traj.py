@@ -373,3 +373,21 @@ def test_modes_agree_on_random_configs(dev, seed):
         grads.append((lo.clone(), mm.clone(), rew, pg, qg))
     for a, b in zip(grads[0], grads[1]):
         assert same(a, b)  # culled == dense
+
+
+@pytest.mark.parametrize("n,w", [(1_000_003, 9), (70_001, 33), (300, 2)])
+def test_prefilled_rewards_equal_the_scattered_ones(dev, n, w):
+    """tohip_traj_forward can fill the rewards vector with sigmoid(0) = 0.5 on its way, after which tohip_traj_reward only
+    stores the points with a non-zero log-odds: same rewards and the same mean / loss, bit for bit, as the plain call."""
+    ops = _ops()
+    c = _setup(dev, n, w)
+    lo_a, _ = ops.traj_forward(c["cloud"], c["p"], c["q"], c["cam"], c["ws"])
+    rew_a, sc_a = ops.traj_reward(c["cloud"], lo_a, c["cam"], c["ws"])
+    half = torch.full((n,), -7.0, device=dev)
+    lo_b, _ = ops.traj_forward(c["cloud"], c["p"], c["q"], c["cam"], c["ws"], rewards_half=half)
+    assert bool((half == 0.5).all())
+    rew_b, sc_b = ops.traj_reward(c["cloud"], lo_b, c["cam"], c["ws"], rewards=half, prefilled=True)
+    assert torch.equal(lo_a, lo_b) and torch.equal(rew_a, rew_b) and torch.equal(sc_a, sc_b)
+    assert float(rew_a.min()) >= 0.5 and float(rew_a.max()) > 0.5
+    # the mean is the f64 mean of the rewards
+    assert abs(float(sc_a[0]) - float(rew_a.double().mean())) <= 1e-7

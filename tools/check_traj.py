@@ -15,8 +15,9 @@ def run(pts, poses, quats, flags, rig=None, grad_rewards=None):
     p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
     rg = ops.CameraRig(rig[0], rig[1], dev) if rig is not None else None
     ws = ops.TrajWorkspace(cloud, p.shape[0] * (rg.n_cams if rg else 1))
-    lo, mm = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=flags)
-    rew, sc = ops.traj_reward(cloud, lo, cam, ws)
+    half = torch.empty(cloud.n, device=dev)
+    lo, mm = ops.traj_forward(cloud, p, q, cam, ws, rg, flags=flags, rewards_half=half)
+    rew, sc = ops.traj_reward(cloud, lo, cam, ws, rewards=half, prefilled=True)
     gout = torch.ones(1, device=dev)
     pg, qg = ops.traj_backward(cloud, p.shape[0], cam, ws, lo, scalars=sc, gout=gout, rig=rg, flags=flags)
     torch.cuda.synchronize()
@@ -50,8 +51,9 @@ L = _lib.lib()
 outs = {}
 for name, flags in (("dense", ops.DENSE), ("cull", 0)):
     def step():
-        lo, mm = ops.traj_forward(cloud, p, q, cam, ws, flags=flags)
-        rew, sc = ops.traj_reward(cloud, lo, cam, ws)
+        half = torch.empty(cloud.n, device=dev)
+        lo, mm = ops.traj_forward(cloud, p, q, cam, ws, flags=flags, rewards_half=half)
+        rew, sc = ops.traj_reward(cloud, lo, cam, ws, rewards=half, prefilled=True)
         pg, qg = ops.traj_backward(cloud, w, cam, ws, lo, scalars=sc, gout=gout, flags=flags)
         return sc, pg, qg, rew
     for _ in range(5): o = step()

@@ -17,7 +17,7 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "trajectory_optimization_amd", "csrc", "trajopt_hip.hip")
-DENSE_PASS1 = "k_traj_pass1ILi4ELb0ELb0E"   # <P = 4, CULL = false, OCC = false>
+DENSE_PASS1 = "k_traj_pass1ILb0ELb0E"   # <CULL = false, OCC = false>
 TRANS = re.compile(r"v_(exp|log|rcp|rsq|sqrt|sin|cos)_")
 
 
@@ -29,7 +29,7 @@ def disassemble():
 
 
 def kernels(text):
-    """name -> (all instructions, instructions of blocks inside a loop)"""
+    """name -> (all instructions, instructions of blocks inside a loop, {loop header: its instructions})"""
     res = {}
     i = 0
     while i < len(text):
@@ -37,12 +37,15 @@ def kernels(text):
         if not m:
             i += 1
             continue
-        name, j, ins, loop, in_loop = m.group(1), i + 1, [], [], False
+        name, j, ins, loop, in_loop, by_header, hdr = m.group(1), i + 1, [], [], False, collections.defaultdict(list), None
         while j < len(text) and "s_endpgm" not in text[j]:
             l = text[j].strip()
             j += 1
-            if re.match(r"^(\.LBB\w+:|; %bb\.\d+:)", l):
+            mb = re.match(r"^(\.LBB(\w+):|; %bb\.\d+:)", l)
+            if mb:
                 in_loop = "Loop" in l
+                mh = re.search(r"Header=BB(\w+)", l)
+                hdr = mh.group(1) if mh else (mb.group(2) if (in_loop and mb.group(2)) else None)
                 continue
             if not l or l.startswith((".", ";", "/")) or l.endswith(":"):
                 continue
@@ -50,7 +53,8 @@ def kernels(text):
             ins.append(op)
             if in_loop:
                 loop.append(op)
-        res[name] = (ins, loop)
+                by_header[hdr].append(op)
+        res[name] = (ins, loop, by_header)
         i = j
     return res
 
@@ -71,7 +75,9 @@ def main():
     ks = kernels(disassemble())
     if args and args[0] == "--json":
         name = next(n for n in ks if DENSE_PASS1 in n)
-        c, cl = classes(ks[name][1])
+        # the waypoint loop: the one that loads a waypoint record (s_load_dwordx16)
+        body = next(ops for ops in ks[name][2].values() if "s_load_dwordx16" in ops)
+        c, cl = classes(body)
         out = dict(kernel=name, points_per_lane=4, evaluations_per_iteration=256,
                    packed_f32=cl["packed_f32"], transcendental=cl["transcendental"], other_valu=cl["other_valu"],
                    salu_smem=cl["salu_smem"], vmem=cl["vmem"],
@@ -83,7 +89,7 @@ def main():
         print(json.dumps({k: out[k] for k in ("packed_f32", "transcendental", "other_valu", "salu_smem", "vmem")}))
         return
     pats = args or ["k_traj_pass1ILi4E", "k_traj_lo_sparse", "k_traj_bwd_sparse", "k_traj_select"]
-    for name, (ins, loop) in ks.items():
+    for name, (ins, loop, _) in ks.items():
         if not any(p in name for p in pats):
             continue
         for what, ops in (("kernel", ins), ("loops", loop)):

@@ -16,8 +16,9 @@ L = _lib.lib()
 for name in modes:
     flags = ops.DENSE if name == "dense" else 0
     def step():
-        lo, mm = ops.traj_forward(cloud, p, q, cam, ws, flags=flags)
-        rew, sc = ops.traj_reward(cloud, lo, cam, ws)
+        half = torch.empty(cloud.n, device=dev)
+        lo, mm = ops.traj_forward(cloud, p, q, cam, ws, flags=flags, rewards_half=half)
+        rew, sc = ops.traj_reward(cloud, lo, cam, ws, rewards=half, prefilled=True)
         pg, qg = ops.traj_backward(cloud, w, cam, ws, lo, scalars=sc, gout=gout, flags=flags)
         return sc, pg, qg, rew
     for _ in range(5): o = step()

@@ -40,11 +40,11 @@ SIGNATURES = {
     "tohip_pack_cloud": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_sz, c_vp]),
     "tohip_traj_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "tohip_traj_forward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig),
-                                           ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+                                           ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_inverse_permutation": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "tohip_occlusion_rows": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "tohip_occlusion_row": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "tohip_traj_reward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_f, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_traj_reward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_f, ctypes.c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_traj_backward": (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig), ctypes.c_int, c_vp,
                                             c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_pose_workspace_bytes": (c_sz, [c_i64]),
@@ -128,7 +128,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 4  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
+ABI_VERSION = 5  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
 ENOSPC = -2  # TOHIP_ENOSPC
 ENAN = -4    # TOHIP_ENAN
 

@@ -74,16 +74,22 @@ struct CloudView {
     const int* perm;        // sorted position -> original index (-1 for pads)
     const float4* bounds;   // per 256 sorted points: bounding-sphere centre xyz, radius (conservative)
     const int* inv;         // original index -> sorted position (n entries)
+    const float* samples;   // every sample_step-th sorted point, x | y | z (TO_PROBE_MAX each): the probe's strided sample, contiguous
     int64_t npad;
     int64_t n;
+    int nsamples, sample_step;
 };
+
+#define TO_PROBE_MAX 8192   // capacity of the sample section: step = max(1, n / 4096) gives at most 8191 samples
+static inline int probe_step(int64_t n) { const int64_t s = n / 4096; return (int)(s < 1 ? 1 : s); }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Packed cloud blob (tohip_pack_cloud): [x|y|z f32, 3*npad] [perm i32, npad] [bounds float4, npad/256] [inv i32, npad]
+// [samples x|y|z f32, 3*TO_PROBE_MAX]
 static inline size_t packed_cloud_bytes(int64_t n) {
     const int64_t npad = tohip_padded_points(n);
-    return (size_t)npad * 16 + (size_t)(npad / 256) * 16 + (size_t)npad * 4;
+    return (size_t)npad * 16 + (size_t)(npad / 256) * 16 + (size_t)npad * 4 + (size_t)TO_PROBE_MAX * 12;
 }
 static inline CloudView cloud_view(const void* packed, int64_t n) {
     CloudView cv;
@@ -93,6 +99,9 @@ static inline CloudView cloud_view(const void* packed, int64_t n) {
     cv.perm = (const int*)((const char*)packed + (size_t)cv.npad * 12);
     cv.bounds = (const float4*)((const char*)packed + (size_t)cv.npad * 16);
     cv.inv = (const int*)((const char*)packed + (size_t)cv.npad * 16 + (size_t)(cv.npad / 256) * 16);
+    cv.samples = (const float*)((const char*)packed + (size_t)cv.npad * 16 + (size_t)(cv.npad / 256) * 16 + (size_t)cv.npad * 4);
+    cv.sample_step = probe_step(n);
+    cv.nsamples = (int)((n + cv.sample_step - 1) / cv.sample_step);
     return cv;
 }
 
@@ -542,5 +551,22 @@ __device__ __forceinline__ float row_max16_nn(float f) {
     v = max(v, TO_DPP_I(v, v, 0x4E, 0xF, true));
     v = max(v, TO_DPP_I(v, v, 0x141, 0xF, true));
     v = max(v, TO_DPP_I(v, v, 0x140, 0xF, true));
+    return __builtin_bit_cast(float, v);
+}
+
+// Wave64 min / max of non-negative floats, valid in lane 63: the four in-row steps above, then the two cross-row steps as
+// single instructions (v_max_i32_dpp with dst == src1: the rows outside row_mask keep their value, which is what the step
+// wants; hipcc emits a v_mov_b32_dpp plus the ALU op for the same thing).  DPP reads a VGPR written by the previous VALU
+// instruction only after two wait states: s_nop 1.
+__device__ __forceinline__ float wave_min63_nn_fused(float f) {
+    int v = __builtin_bit_cast(int, row_min16_nn(f));
+    asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+    return __builtin_bit_cast(float, v);
+}
+__device__ __forceinline__ float wave_max63_nn_fused(float f) {
+    int v = __builtin_bit_cast(int, row_max16_nn(f));
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
     return __builtin_bit_cast(float, v);
 }

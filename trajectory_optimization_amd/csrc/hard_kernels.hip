@@ -78,13 +78,18 @@ __global__ void __launch_bounds__(TO_BLOCK) k_iota(int* __restrict__ vals, int64
 
 __global__ void __launch_bounds__(TO_BLOCK)
 k_pack_cloud(const float* __restrict__ xyz, const int* __restrict__ order, int64_t n, int64_t npad, float* __restrict__ soa,
-             int* __restrict__ perm, int* __restrict__ inv) {
+             int* __restrict__ perm, int* __restrict__ inv, float* __restrict__ samples, int sample_step) {
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < npad; i += stride) {
         const int64_t s = order[i < n ? i : n - 1];
-        soa[i] = xyz[3 * s];
-        soa[npad + i] = xyz[3 * s + 1];
-        soa[2 * npad + i] = xyz[3 * s + 2];
+        const float px = xyz[3 * s], py = xyz[3 * s + 1], pz = xyz[3 * s + 2];
+        soa[i] = px;
+        soa[npad + i] = py;
+        soa[2 * npad + i] = pz;
+        if (i < n && i % sample_step == 0) {  // the probe's strided sample of the sorted cloud, kept contiguous
+            const int64_t j = i / sample_step;
+            samples[j] = px; samples[TO_PROBE_MAX + j] = py; samples[2 * TO_PROBE_MAX + j] = pz;
+        }
         perm[i] = i < n ? (int)s : -1;
         if (i < n) inv[s] = (int)i;  // the way back, for kernels that produce their output in the caller's order
     }
@@ -187,7 +192,8 @@ extern "C" int tohip_pack_cloud(const float* xyz, int64_t n, int sort, void* pac
     const CloudView cv = cloud_view(packed, n);
     int64_t nbp = npad / TO_BLOCK;
     if (nbp > 4096) nbp = 4096;
-    k_pack_cloud<<<(int)nbp, TO_BLOCK, 0, st>>>(xyz, order, n, npad, (float*)cv.soa, (int*)cv.perm, (int*)cv.inv);
+    k_pack_cloud<<<(int)nbp, TO_BLOCK, 0, st>>>(xyz, order, n, npad, (float*)cv.soa, (int*)cv.perm, (int*)cv.inv, (float*)cv.samples,
+                                                cv.sample_step);
     TO_HIP_CHECK_LAUNCH();
     k_tile_bounds<<<(int)(npad / TO_BLOCK), TO_BLOCK, 0, st>>>(cv.soa, npad, (float4*)cv.bounds);
     TO_HIP_CHECK_LAUNCH();

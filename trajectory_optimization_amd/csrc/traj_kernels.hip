@@ -7,7 +7,7 @@
 // after it works on the few pairs that can contribute:
 //
 //   k_traj_prep / k_traj_probe   waypoint records (WayRec, common.hpp); the probe (CULL mode) also samples the cloud
-//   k_traj_pass1                 p of every pair -> (min, max) per (waypoint, row of 16 lanes)      the dense kernel
+//   k_traj_pass1                 p of every pair -> (min, max) per (waypoint, wave of 256 points)   the dense kernel
 //   k_traj_select                block per waypoint: a = min p, M = max (p - a); a (256-point slot, waypoint) pair
 //                                is FLAGGED when its maximum reaches p_hat >= 1/2 (or it holds an argmin point and
 //                                a > 0): only flagged pairs have a non-zero log-odds term or a gradient.  Flags in
@@ -28,7 +28,7 @@
 //             (packed once, tohip_pack_cloud)                                          16 B/point
 //   WayRec    two 64-B lines per virtual waypoint; line 0 -> SGPRs by one s_load_dwordx16
 //   lo_sum (sorted order) / rewards (original order)                                    4 B/point each
-//   part      [virtual waypoint][row]: (min, max) of p over the 16*P points of a DPP row   8 B
+//   part      [virtual waypoint][slot]: (min, max) of p over the 256 points of a wave       8 B
 //   bpart     [virtual waypoint][slot]: 14 gradient sums of a flagged pair                 64 B (written where flagged)
 //
 // Two evaluation modes with bitwise identical results:
@@ -47,21 +47,19 @@
 #include "profile.hpp"
 
 #define TO_SLOT 256            // points per flag slot (= bounding-sphere tile)
-#define TO_TIE_CAP 7           // recorded rows per extremum and waypoint; more -> the finish kernel scans all rows
+#define TO_TIE_CAP 7           // recorded slots per extremum and waypoint; more -> the finish kernel scans all slots
 #define TO_BWD_NSUM 14
 
 // ---------------------------------------------------------------------------------------------
 // workspace control block
 
-#define TO_REWARD_SHARDS 32
 struct TrajCtl {
-    int degenerate;        // some waypoint has max == min (or a NaN): the reference's rewards are all NaN
-    int pad[15];
-    int reward_done[TO_REWARD_SHARDS + 16];   // k_traj_reward's arrival counters: one per shard of 64 blocks, [TO_REWARD_SHARDS] on top
+    unsigned long long reward_acc;   // k_traj_reward's accumulator (arrivals | NaN marks | fixed-point sum); zero between launches
+    int pad[14];
 };
 
-struct TieRec {            // rows (ascending) whose max equals the waypoint's max / whose min equals its min (a > 0)
-    int nmax, nmin;        // counts; > TO_TIE_CAP: overflow, scan every row
+struct TieRec {            // slots (ascending) whose max equals the waypoint's max / whose min equals its min (a > 0)
+    int nmax, nmin;        // counts; > TO_TIE_CAP: overflow, scan every slot
     int maxrow[TO_TIE_CAP];
     int minrow[TO_TIE_CAP];
 };
@@ -128,20 +126,19 @@ __device__ __forceinline__ void prep_wayrec(int v, const float* __restrict__ pos
     rec[v] = r;
 }
 
-// also clears what k_traj_select accumulates into (slot-major flags, the degenerate mark)
-__device__ __forceinline__ void clear_select_state(unsigned long long* __restrict__ ft, int64_t ft_words, TrajCtl* __restrict__ ctl) {
+// clears what k_traj_select accumulates into (the slot-major flags)
+__device__ __forceinline__ void clear_select_state(unsigned long long* __restrict__ ft, int64_t ft_words) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = tid; i < ft_words; i += nth) ft[i] = 0ull;
-    if (tid == 0) ctl->degenerate = 0;
 }
 
 __global__ void __launch_bounds__(256)
 k_traj_prep(const float* __restrict__ poses, const float* __restrict__ quats, int V, int C, const float* __restrict__ rig_q,
             const float* __restrict__ rig_t, EvalK k, WayRec* __restrict__ rec, WayCold* __restrict__ cold,
-            unsigned long long* __restrict__ ft, int64_t ft_words, TrajCtl* __restrict__ ctl) {
+            unsigned long long* __restrict__ ft, int64_t ft_words) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v < V) prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, rec, cold);
-    clear_select_state(ft, ft_words, ctl);
+    clear_select_state(ft, ft_words);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -231,21 +228,35 @@ __device__ inline void cull_bound(float tau, float inv_var, float* thr, float* s
 __global__ void __launch_bounds__(TO_PROBE_THREADS)
 k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restrict__ quats, int C,
              const float* __restrict__ rig_q, const float* __restrict__ rig_t, EvalK k, WayRec* __restrict__ rec,
-             WayCold* __restrict__ cold, int step, const uint32_t* __restrict__ occ, int64_t occw,
-             unsigned long long* __restrict__ ft, int64_t ft_words, TrajCtl* __restrict__ ctl) {
+             WayCold* __restrict__ cold, const uint32_t* __restrict__ occ, int64_t occw,
+             unsigned long long* __restrict__ ft, int64_t ft_words) {
     __shared__ float smx[TO_PROBE_THREADS / 64];
     __shared__ int szero[TO_PROBE_THREADS / 64];
     const int v = blockIdx.x, t = threadIdx.x;
-    clear_select_state(ft, ft_words, ctl);
+    clear_select_state(ft, ft_words);
+    // the samples (a contiguous copy of every step-th sorted point, made at pack time) are requested first, the record is
+    // built meanwhile
+    constexpr int kBatch = TO_PROBE_MAX / TO_PROBE_THREADS;
+    float px[kBatch], py[kBatch], pz[kBatch];
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+        const int sj = t + j * TO_PROBE_THREADS;
+        const int sc = sj < cv.nsamples ? sj : 0;
+        px[j] = cv.samples[sc]; py[j] = cv.samples[TO_PROBE_MAX + sc]; pz[j] = cv.samples[2 * TO_PROBE_MAX + sc];
+    }
     if (t == 0) prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, rec, cold);
     __syncthreads();
     const WayRec r = rec[v];
     float mx = 0.f;
     int zero = 0;
-    for (int64_t i = (int64_t)t * step; i < cv.n; i += (int64_t)TO_PROBE_THREADS * step) {
-        const float p = vis_p(r, k, cv.soa[i], cv.soa[cv.npad + i], cv.soa[2 * cv.npad + i]) * occ_one(occ, occw, v, i);
-        mx = fmaxf(mx, p);
-        zero |= (p == 0.f);
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+        const int sj = t + j * TO_PROBE_THREADS;
+        if (sj < cv.nsamples) {
+            const float p = vis_p(r, k, px[j], py[j], pz[j]) * occ_one(occ, occw, v, (int64_t)sj * cv.sample_step);
+            mx = fmaxf(mx, p);
+            zero |= (p == 0.f);
+        }
     }
     for (int s = 32; s > 0; s >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, s)); zero |= __shfl_xor(zero, s); }
     if ((t & 63) == 0) { smx[t >> 6] = mx; szero[t >> 6] = zero; }
@@ -262,119 +273,121 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// pass 1: p of every (point, waypoint) pair of the block's tile -> per-row (min, max).  grid = (point blocks, waypoint
-// tiles).  A lane owns P consecutive sorted points; a DPP row (16 lanes) covers 16*P consecutive points and writes
-// part[v * nrows + row] = (min, max) — four in-row DPP steps per extremum instead of six across the wave plus moves.
+// pass 1: p of every (point, waypoint) pair of the block's tile -> per-wave (min, max).  grid = (point blocks, waypoint
+// tiles).  A lane owns 4 consecutive sorted points, a wave one 256-point slot; part[v * nslots + slot] = (min, max).
 
-template <int P>
-__device__ __forceinline__ void pass1_eval(const EvalK& k, const WayRec& r, const float (&x)[P], const float (&y)[P],
-                                           const float (&z)[P], const float (&om)[P], float& mn, float& mx) {
-#pragma unroll
-    for (int i = 0; i < P; i += 2) {
-        const f2 p = vis_p_pk(r, k, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}) * f2{om[i], om[i + 1]};
-        mn = fminf(mn, fminf(p.x, p.y));
-        mx = fmaxf(mx, fmaxf(p.x, p.y));
-    }
+#define TO_P 4   // points per lane: a wave is one slot (and one bounding-sphere tile)
+
+__device__ __forceinline__ void pass1_eval(const EvalK& k, const WayRec& r, const float (&x)[TO_P], const float (&y)[TO_P],
+                                           const float (&z)[TO_P], const float (&om)[TO_P], float& mn, float& mx) {
+    const f2 p0 = vis_p_pk(r, k, f2{x[0], x[1]}, f2{y[0], y[1]}, f2{z[0], z[1]}) * f2{om[0], om[1]};
+    const f2 p1 = vis_p_pk(r, k, f2{x[2], x[3]}, f2{y[2], y[3]}, f2{z[2], z[3]}) * f2{om[2], om[3]};
+    mn = fminf(fminf(p0.x, p0.y), fminf(p1.x, p1.y));   // p >= +0 always
+    mx = fmaxf(fmaxf(p0.x, p0.y), fmaxf(p1.x, p1.y));
 }
 
-template <int P, bool CULL, bool OCC>
+template <bool CULL, bool OCC>
 __global__ void __launch_bounds__(TO_BLOCK)
-k_traj_pass1(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile, EvalK k, float2* __restrict__ part, int nrows,
-             const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ lo_zero) {
+k_traj_pass1(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile, EvalK k, float2* __restrict__ part, int nslots,
+             const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ lo_zero, float* __restrict__ rewards_half) {
+    constexpr int P = TO_P;
     const int lane = threadIdx.x & 63;
     const int gthread = blockIdx.x * TO_BLOCK + threadIdx.x;
     const int64_t base = (int64_t)gthread * P;
-    const int row = gthread >> 4;
-    const bool writer = (lane & 15) == 0;
+    const int slot = gthread >> 6;
     float x[P], y[P], z[P];
     load_points<P>(cv.soa, cv.npad, base, x, y, z);
-    if (lo_zero != nullptr && blockIdx.y == 0) {  // the log-odds vector starts from zero; k_traj_lo_sparse fills the flagged slots
-#pragma unroll
-        for (int j = 0; j < P; j += 4) *reinterpret_cast<float4*>(lo_zero + base + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.y == 0) {
+        // the log-odds vector starts from zero (k_traj_lo_sparse fills the flagged slots) and, when the caller asks for it, the
+        // rewards vector from sigmoid(0) = 1/2 (k_traj_reward then only stores the others)
+        *reinterpret_cast<float4*>(lo_zero + base) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rewards_half != nullptr && base < cv.n) {
+            if (base + 4 <= cv.n) *reinterpret_cast<float4*>(rewards_half + base) = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
+            else for (int64_t i = base; i < cv.n; ++i) rewards_half[i] = 0.5f;
+        }
     }
     const int v0 = blockIdx.y * vtile;
     const int v1 = min(V, v0 + vtile);
     if constexpr (!CULL) {
         for (int v = v0; v < v1; ++v) {
             const WayRec& r = rec[v];
-            float mn = INFINITY, mx = 0.f;  // p >= +0 always
-            float om[P];
+            float mn, mx, om[P];
             load_occ<P, OCC>(occ, occw, v, base, om);
-            pass1_eval<P>(k, r, x, y, z, om, mn, mx);
-            mn = row_min16_nn(mn);
-            mx = row_max16_nn(mx);
-            if (writer) part[(int64_t)v * nrows + row] = make_float2(mn, mx);
+            pass1_eval(k, r, x, y, z, om, mn, mx);
+            mn = wave_min63_nn_fused(mn);
+            mx = wave_max63_nn_fused(mx);
+            if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
         }
     } else {
-        static_assert(!CULL || P == 4, "culled pass 1: one 256-point tile per wave");
+        // vtile <= 64: one ballot covers the block row's waypoints.  A live (tile, waypoint) pair is evaluated like in the dense
+        // kernel (packed, every point of the wave): per-point distance tests cost as much as they save once the tile is live.
         const float4 tb = wave_tile_bound(cv, base);
-        const int row0 = __builtin_amdgcn_readfirstlane(row & ~3);  // the wave's four rows
-        for (int vc = v0; vc < v1; vc += 64) {
-            unsigned long long live = tile_survivors(rec, vc, v1, tb);
-            // waypoints that cannot be affected from this tile: min is the proven 0, max unknown (-inf: never flagged)
-            if (vc + lane < v1 && !((live >> lane) & 1ull)) {
-                float4* dst = reinterpret_cast<float4*>(part + (int64_t)(vc + lane) * nrows + row0);
-                dst[0] = make_float4(0.f, -INFINITY, 0.f, -INFINITY);
-                dst[1] = make_float4(0.f, -INFINITY, 0.f, -INFINITY);
-            }
-            while (live) {
-                const int v = vc + __builtin_ctzll(live);
-                live &= live - 1ull;
-                const WayRec& r = rec[v];
-                float mn = INFINITY, mx = 0.f;  // an all-culled row reports max 0: p_hat = 0, never flagged
-                float om[P];
-                load_occ<P, OCC>(occ, occw, v, base, om);
-                if (r.azero != 0.f) {
-                    mn = 0.f;  // proven by the probe; only points that can reach L/2 are evaluated
-                    const float thr1 = r.thr1;
-#pragma unroll
-                    for (int i = 0; i < P; ++i)
-                        if (__any(dist2_sp(r, x[i], y[i], z[i]) <= thr1)) mx = fmaxf(mx, vis_p(r, k, x[i], y[i], z[i]) * om[i]);
-                } else {
-                    pass1_eval<P>(k, r, x, y, z, om, mn, mx);
-                    mn = row_min16_nn(mn);
-                }
-                mx = row_max16_nn(mx);
-                if (writer) part[(int64_t)v * nrows + row] = make_float2(mn, mx);
-            }
+        unsigned long long live = tile_survivors(rec, v0, v1, tb);
+        // waypoints that cannot be affected from this tile: min is the proven 0, max unknown (-inf: never flagged)
+        if (v0 + lane < v1 && !((live >> lane) & 1ull)) part[(int64_t)(v0 + lane) * nslots + slot] = make_float2(0.f, -INFINITY);
+        while (live) {
+            const int v = v0 + __builtin_ctzll(live);
+            live &= live - 1ull;
+            const WayRec& r = rec[v];
+            float mn, mx, om[P];
+            load_occ<P, OCC>(occ, occw, v, base, om);
+            pass1_eval(k, r, x, y, z, om, mn, mx);
+            mn = wave_min63_nn_fused(mn);
+            mx = wave_max63_nn_fused(mx);
+            if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // select: block per virtual waypoint.
-//   sweep 1  a = min, pmax = max over the row partials; M = pmax - a (== max(p - a): rounding is monotone)
-//   sweep 2  thread per 256-point slot: flagged when some row of the slot has p_hat(max) >= 1/2 — the predicate the
-//            sparse kernels evaluate per point, applied to an attained value — or holds an argmin point while a > 0
-//            (that set carries gradient, model.py:226); rows holding the extrema are recorded for the finish kernel.
+//   sweep 1  a = min, pmax = max over the slot partials; M = pmax - a (== max(p - a): rounding is monotone)
+//   sweep 2  thread per 256-point slot: flagged when its maximum has p_hat >= 1/2 — the predicate the sparse kernels
+//            evaluate per point, applied to an attained value — or it holds an argmin point while a > 0 (that set carries
+//            gradient, model.py:226); the slots holding the extrema are recorded for the finish kernel.
 // Flags: fv[v][slot word] (finish kernel), ft[slot][v word] (forward); vlist[v][0..vcnt[v]) = the flagged slots of v
 // (backward).  Everything a block appends to is its own: the only global atomics are the ft bits, fire and forget.
 
 #define TO_SELECT_THREADS 1024
+#define TO_SELECT_FAST_SLOTS (4 * TO_SELECT_THREADS)   // up to this many slots (1 M points) a thread keeps its slots' partials in registers
+template <bool FAST>
 __global__ void __launch_bounds__(TO_SELECT_THREADS)
-k_traj_select(const float2* __restrict__ part, int nrows, int rps /* rows per slot */, int nslots, int V, WayRec* __restrict__ rec,
-              int cull, float* __restrict__ minmax, unsigned long long* __restrict__ fv, int fv_words,
-              unsigned long long* __restrict__ ft, int vwords, int* __restrict__ vlist, int* __restrict__ vcnt,
-              TieRec* __restrict__ ties, TrajCtl* __restrict__ ctl) {
+k_traj_select(const float2* __restrict__ part, int nslots, int V, WayRec* __restrict__ rec, int cull, float* __restrict__ minmax,
+              unsigned long long* __restrict__ fv, int fv_words, unsigned long long* __restrict__ ft, int vwords,
+              int* __restrict__ vlist, int* __restrict__ vcnt, TieRec* __restrict__ ties, float* __restrict__ lo_sum, int64_t npad) {
     __shared__ float smn[TO_SELECT_THREADS / 64], smx[TO_SELECT_THREADS / 64];
     __shared__ float s_a, s_pmax;
     __shared__ int s_nmax, s_nmin, s_npairs, s_maxrow[TO_TIE_CAP], s_minrow[TO_TIE_CAP];
     const int v = blockIdx.x, t = threadIdx.x, lane = t & 63;
-    const float2* pv = part + (int64_t)v * nrows;
+    const float2* pv = part + (int64_t)v * nslots;
     float mn = INFINITY, mx = -INFINITY;
     bool nan = false;
-    for (int s0 = 0; s0 < nrows; s0 += 4 * TO_SELECT_THREADS) {  // four loads in flight per thread
-        float2 q[4];
+    float2 q[4];   // FAST: thread t owns slots t, t + 1024, ...: requested at once, kept for sweep 2
+    if constexpr (FAST) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int sidx = s0 + j * TO_SELECT_THREADS + t;
-            q[j] = sidx < nrows ? pv[sidx] : make_float2(INFINITY, -INFINITY);
+        for (int kk = 0; kk < 4; ++kk) {
+            const int s = t + kk * TO_SELECT_THREADS;
+            q[kk] = s < nslots ? pv[s] : make_float2(INFINITY, -INFINITY);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            mn = fminf(mn, q[j].x);
-            mx = fmaxf(mx, q[j].y);
-            nan |= (q[j].y != q[j].y);   // a NaN p wins the max in pass 1 (integer order): the reference's max() is NaN too
+        for (int kk = 0; kk < 4; ++kk) {
+            mn = fminf(mn, q[kk].x);
+            mx = fmaxf(mx, q[kk].y);
+            nan |= (q[kk].y != q[kk].y);   // a NaN p wins the max in pass 1 (integer order): the reference's max() is NaN too
+        }
+    } else {
+        for (int s0 = 0; s0 < nslots; s0 += 4 * TO_SELECT_THREADS) {  // four loads in flight per thread
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sidx = s0 + j * TO_SELECT_THREADS + t;
+                q[j] = sidx < nslots ? pv[sidx] : make_float2(INFINITY, -INFINITY);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mn = fminf(mn, q[j].x);
+                mx = fmaxf(mx, q[j].y);
+                nan |= (q[j].y != q[j].y);
+            }
         }
     }
     for (int s = 32; s > 0; s >>= 1) { mn = fminf(mn, __shfl_xor(mn, s)); mx = fmaxf(mx, __shfl_xor(mx, s)); }
@@ -382,38 +395,43 @@ k_traj_select(const float2* __restrict__ part, int nrows, int rps /* rows per sl
     if (lane == 0) { smn[t >> 6] = mn; smx[t >> 6] = nan ? __builtin_nanf("") : mx; }
     if (t == 0) { s_nmax = 0; s_nmin = 0; s_npairs = 0; }
     __syncthreads();
-    if (t == 0) {
-        float a = smn[0], pmax = smx[0];
-        bool anynan = pmax != pmax;
-        for (int w = 1; w < TO_SELECT_THREADS / 64; ++w) { a = fminf(a, smn[w]); anynan |= smx[w] != smx[w]; pmax = fmaxf(pmax, smx[w]); }
-        if (cull) pmax = fmaxf(pmax, rec[v].L);  // L is an attained value of p (defensive: its tile is never skipped)
-        if (anynan) pmax = __builtin_nanf("");
-        const float M = pmax - a;
-        rec[v].a = a;
-        rec[v].invM = 1.0f / M;
-        rec[v].M = M;
-        minmax[2 * v] = a;
-        minmax[2 * v + 1] = M;
-        if (!(M > 0.f) || !(1.0f / M < INFINITY)) atomicOr(&ctl->degenerate, 1);  // max == min (0/0 for every point) or NaN
-        s_a = a;
-        s_pmax = pmax;
+    if (t < 64) {   // wave 0: the 16 wave results
+        float a = t < TO_SELECT_THREADS / 64 ? smn[t] : INFINITY, pm = t < TO_SELECT_THREADS / 64 ? smx[t] : -INFINITY;
+        bool anynan = pm != pm;
+        for (int s = 8; s > 0; s >>= 1) { a = fminf(a, __shfl_xor(a, s)); pm = fmaxf(pm, __shfl_xor(pm, s)); }
+        anynan = __any(anynan);
+        if (t == 0) {
+            float pmax = pm;
+            if (cull) pmax = fmaxf(pmax, rec[v].L);  // L is an attained value of p (defensive: its tile is never skipped)
+            if (anynan) pmax = __builtin_nanf("");
+            const float M = pmax - a;
+            rec[v].a = a;
+            rec[v].invM = 1.0f / M;
+            rec[v].M = M;
+            minmax[2 * v] = a;
+            minmax[2 * v + 1] = M;
+            s_a = a;
+            s_pmax = pmax;
+        }
     }
     __syncthreads();
     const float a = s_a, pmax = s_pmax;
     const float M = pmax - a, invM = 1.0f / M;
     const bool amin = a > 0.f;
+    if (!(M > 0.f) || !(invM < INFINITY)) {
+        // max == min, or a NaN: the reference's p / max is 0/0 for EVERY point of this waypoint (model.py:227), so every
+        // log-odds sum is NaN.  Rare: this block stores it; k_traj_lo_sparse adds onto it.
+        const float nanv = __builtin_nanf("");
+        for (int64_t i = t; i < npad; i += TO_SELECT_THREADS) lo_sum[i] = nanv;
+    }
     int* myl = vlist + (int64_t)v * nslots;
-    for (int s0 = 0; s0 < nslots; s0 += TO_SELECT_THREADS) {
+    auto sweep2 = [&](const float2 qq, const int s0) {
         const int s = s0 + t;
         bool flag = false;
         if (s < nslots) {
-            for (int j = 0; j < rps; ++j) {
-                const int rr = s * rps + j;
-                const float2 q = pv[rr];
-                flag |= ((q.y - a) * invM >= 0.5f) | (amin & (q.x == a));
-                if (q.y == pmax && M > 0.f) { const int kk = atomicAdd(&s_nmax, 1); if (kk < TO_TIE_CAP) s_maxrow[kk] = rr; }
-                if (amin && q.x == a) { const int kk = atomicAdd(&s_nmin, 1); if (kk < TO_TIE_CAP) s_minrow[kk] = rr; }
-            }
+            flag = ((qq.y - a) * invM >= 0.5f) | (amin & (qq.x == a));
+            if (qq.y == pmax && M > 0.f) { const int i = atomicAdd(&s_nmax, 1); if (i < TO_TIE_CAP) s_maxrow[i] = s; }
+            if (amin && qq.x == a) { const int i = atomicAdd(&s_nmin, 1); if (i < TO_TIE_CAP) s_minrow[i] = s; }
         }
         const unsigned long long b = __ballot(flag);
         if (lane == 0 && (s0 + (t & ~63)) < nslots) fv[(int64_t)v * fv_words + ((s0 + t) >> 6)] = b;
@@ -426,24 +444,35 @@ k_traj_select(const float2* __restrict__ part, int nrows, int rps /* rows per sl
                 atomicOr(&ft[(int64_t)s * vwords + (v >> 6)], 1ull << (v & 63));
             }
         }
+    };
+    if constexpr (FAST) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            if (kk * TO_SELECT_THREADS < nslots) sweep2(q[kk], kk * TO_SELECT_THREADS);
+    } else {
+        for (int s0 = 0; s0 < nslots; s0 += TO_SELECT_THREADS) sweep2(s0 + t < nslots ? pv[s0 + t] : make_float2(0.f, 0.f), s0);
     }
     __syncthreads();
     if (t == 0) {
         vcnt[v] = s_npairs;
-        TieRec tr;
-        tr.nmax = s_nmax; tr.nmin = s_nmin;
+        // ascending slot order: the tie sums are added in a fixed order (insertion sort of <= 7 entries, in LDS)
         const int na = min(s_nmax, TO_TIE_CAP), nb = min(s_nmin, TO_TIE_CAP);
-        for (int i = 0; i < TO_TIE_CAP; ++i) { tr.maxrow[i] = i < na ? s_maxrow[i] : 0x7fffffff; tr.minrow[i] = i < nb ? s_minrow[i] : 0x7fffffff; }
-        // ascending row order: the tie sums are added in a fixed order (insertion sort of <= 7 entries)
-        for (int i = 1; i < TO_TIE_CAP; ++i) {
-            int x = tr.maxrow[i], j = i - 1;
-            while (j >= 0 && tr.maxrow[j] > x) { tr.maxrow[j + 1] = tr.maxrow[j]; --j; }
-            tr.maxrow[j + 1] = x;
-            x = tr.minrow[i]; j = i - 1;
-            while (j >= 0 && tr.minrow[j] > x) { tr.minrow[j + 1] = tr.minrow[j]; --j; }
-            tr.minrow[j + 1] = x;
+        for (int i = 1; i < na; ++i) {
+            const int x = s_maxrow[i];
+            int j = i - 1;
+            while (j >= 0 && s_maxrow[j] > x) { s_maxrow[j + 1] = s_maxrow[j]; --j; }
+            s_maxrow[j + 1] = x;
         }
-        ties[v] = tr;
+        for (int i = 1; i < nb; ++i) {
+            const int x = s_minrow[i];
+            int j = i - 1;
+            while (j >= 0 && s_minrow[j] > x) { s_minrow[j + 1] = s_minrow[j]; --j; }
+            s_minrow[j + 1] = x;
+        }
+        int* tp = reinterpret_cast<int*>(ties + v);   // TieRec: nmax, nmin, maxrow[7], minrow[7]
+        tp[0] = s_nmax;
+        tp[1] = s_nmin;
+        for (int i = 0; i < TO_TIE_CAP; ++i) { tp[2 + i] = i < na ? s_maxrow[i] : 0; tp[2 + TO_TIE_CAP + i] = i < nb ? s_minrow[i] : 0; }
     }
 }
 
@@ -460,46 +489,43 @@ __device__ __forceinline__ float log_odds(const EvalK& k, const WayRec& r, float
     return (to_log2(ph) - to_log2(1.0f - ph)) * 0.693147180559945f;
 }
 
-#define TO_LO_SLOTS 1   // slots per block: most blocks find theirs unflagged and leave after one look
 __global__ void __launch_bounds__(1024)
 k_traj_lo_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const unsigned long long* __restrict__ ft, int vwords,
-                 int nslots, const TrajCtl* __restrict__ ctl, float* __restrict__ lo_sum, const uint32_t* __restrict__ occ, int64_t occw) {
+                 float* __restrict__ lo_sum, const uint32_t* __restrict__ occ, int64_t occw) {
+    // block per slot; the unflagged ones (94 % on the BASELINE workloads) leave after one scalar load of their flag words — a
+    // block's life is that latency, and only two 1024-thread blocks fit a CU.  The sum is ADDED to what lo_sum holds: zero from
+    // pass 1, or the NaN k_traj_select stored everywhere for a degenerate waypoint (the reference divides 0/0 for every point
+    // then, model.py:227)
     __shared__ float spart[3][TO_SLOT];
+    const int s = blockIdx.x;
     const int pt = threadIdx.x & (TO_SLOT - 1), g = threadIdx.x >> 8;
-    const int s_begin = blockIdx.x * TO_LO_SLOTS, s_end = min(nslots, s_begin + TO_LO_SLOTS);
-    if (ctl->degenerate) {  // the reference divides 0/0 for every point of that waypoint (model.py:227): all NaN
-        for (int s = s_begin + g; s < s_end; s += 4) lo_sum[(int64_t)s * TO_SLOT + pt] = __builtin_nanf("");
-        return;
-    }
-    for (int s = s_begin; s < s_end; ++s) {
-        unsigned long long any = 0ull;
-        for (int w = 0; w < vwords; ++w) any |= ft[(int64_t)s * vwords + w];
-        if (!any) continue;   // unflagged (94 % on the BASELINE workloads): pass 1 has zeroed its log-odds
-        const int64_t i = (int64_t)s * TO_SLOT + pt;
-        const float x = cv.soa[i], y = cv.soa[cv.npad + i], z = cv.soa[2 * cv.npad + i];
-        float acc = 0.f;
-        int rank = 0;
-        for (int w = 0; w < vwords; ++w) {
-            unsigned long long bits = ft[(int64_t)s * vwords + w];
-            while (bits) {
-                const int v = w * 64 + __builtin_ctzll(bits);
-                bits &= bits - 1ull;
-                if (((rank++) & 3) == g) {
-                    const WayRec& r = rec[v];
-                    acc += log_odds(k, r, vis_p(r, k, x, y, z) * occ_one(occ, occw, v, i));
-                }
+    const int64_t i = (int64_t)s * TO_SLOT + pt;
+    const unsigned long long* fts = ft + (int64_t)s * vwords;
+    unsigned long long any = fts[0];
+    for (int w = 1; w < vwords; ++w) any |= fts[w];
+    if (!any) return;
+    const float x = cv.soa[i], y = cv.soa[cv.npad + i], z = cv.soa[2 * cv.npad + i];
+    float acc = 0.f;
+    int rank = 0;
+    for (int w = 0; w < vwords; ++w) {
+        unsigned long long bits = fts[w];
+        while (bits) {
+            const int v = w * 64 + __builtin_ctzll(bits);
+            bits &= bits - 1ull;
+            if (((rank++) & 3) == g) {
+                const WayRec& r = rec[v];
+                acc += log_odds(k, r, vis_p(r, k, x, y, z) * occ_one(occ, occw, v, i));
             }
         }
-        if (g) spart[g - 1][pt] = acc;
-        __syncthreads();
-        if (!g) lo_sum[i] = ((acc + spart[0][pt]) + spart[1][pt]) + spart[2][pt];
-        __syncthreads();
     }
+    if (g) spart[g - 1][pt] = acc;
+    __syncthreads();
+    if (!g) lo_sum[i] = lo_sum[i] + (((acc + spart[0][pt]) + spart[1][pt]) + spart[2][pt]);
 }
 
 // ---------------------------------------------------------------------------------------------
 // rewards = sigmoid(lo_sum) (model.py:237) scattered back to the caller's point order, mean and
-// visibility loss (model.py:246).  The last block to arrive adds the block partials in block order.
+// visibility loss (model.py:246).
 
 // f64 sum of one value per lane in a fixed order (xor butterfly); every lane gets the result
 __device__ __forceinline__ double wave_sum_double(double v) {
@@ -507,58 +533,62 @@ __device__ __forceinline__ double wave_sum_double(double v) {
     return v;
 }
 
-// One launch: a few fat blocks (<= 256 x 1024 threads), four elements in flight per thread (the gather is a chain of two
-// dependent loads: index, then log-odds), block partials handed to the last-arriving block, which adds them in block order.
-// Hand-off without fences (a release fence would write back this XCD's L2, dirty with the rewards just stored): the partial
-// leaves as a write-through agent-scope store, is drained, and only then the arrival is counted; the reader uses agent-scope
-// loads (MI355X guide, G16).  done: one counter, zero before and after the launch.
+// One launch, thread per PACKED position: lo_sum and the permutation are read coalesced, the reward goes to the caller's
+// order with a scattered 4-byte store — which is skipped for the points whose log-odds is exactly 0 when the caller says the
+// rewards vector already holds sigmoid(0) = 1/2 everywhere (`prefilled`: tohip_traj_forward's rewards_half output; 98 % of the
+// points on the BASELINE workloads).
+// The mean needs one more dependent step only: every block adds ONE 64-bit word to an accumulator — its f64 partial as a
+// fixed-point integer (bits 0..47), a NaN mark (bits 48..55) and its arrival (bits 56..63).  Integer addition commutes, so the
+// total does not depend on the arrival order; the block whose add returns the last arrival has the complete sum in hand
+// (returned value + its own word) and writes the scalars.  The fixed-point step is 2^-shift with shift = 47 - ceil(log2 n): at
+// most 128 roundings of 2^-(shift+1) on a sum of >= n/2 (1 M points: 5e-13 relative).  acc: zero before and after the launch.
 #define TO_REWARD_THREADS 1024
-#define TO_REWARD_BLOCKS 256
+#define TO_REWARD_BLOCKS 128
 __global__ void __launch_bounds__(TO_REWARD_THREADS)
-k_traj_reward(const float* __restrict__ lo_sum, const int* __restrict__ inv, int64_t n, float eps, float* __restrict__ rewards,
-              double* __restrict__ part, int* __restrict__ done, float* __restrict__ scalars) {
+k_traj_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, int64_t n, float eps, int shift, int prefilled,
+              float* __restrict__ rewards, unsigned long long* __restrict__ acc, float* __restrict__ scalars) {
     __shared__ double lds[TO_REWARD_THREADS / 64];
-    __shared__ int s_last;
     double s = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * TO_REWARD_THREADS;
-    // thread per OUTPUT element (the caller's order): a scattered 4-byte read of lo_sum and a coalesced store
-    for (int64_t o0 = (int64_t)blockIdx.x * TO_REWARD_THREADS + threadIdx.x; o0 < n; o0 += 4 * stride) {
-        int idx[4];
-        float lo[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int64_t o = o0 + j * stride; idx[j] = o < n ? inv[o] : 0; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lo[j] = lo_sum[idx[j]];
+    const int64_t stride = (int64_t)gridDim.x * TO_REWARD_THREADS * 4;
+    for (int64_t i0 = ((int64_t)blockIdx.x * TO_REWARD_THREADS + threadIdx.x) * 4; i0 < n; i0 += stride) {
+        const float4 lo4 = *reinterpret_cast<const float4*>(lo_sum + i0);   // npad is a multiple of 4: in bounds
+        const float lo[4] = {lo4.x, lo4.y, lo4.z, lo4.w};
+        const bool all0 = (lo4.x == 0.f) & (lo4.y == 0.f) & (lo4.z == 0.f) & (lo4.w == 0.f);
+        if (prefilled && all0) {
+            // sigmoid(0) evaluated as below is exactly 0.5: rcp(1 + 1)
+            const int cnt = (int)min((int64_t)4, n - i0);
+            s += 0.5 * (double)cnt;
+            continue;
+        }
+        const int4 o4 = *reinterpret_cast<const int4*>(perm + i0);
+        const int o[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t o = o0 + j * stride;
-            if (o < n) {
+            if (i0 + j < n) {
                 float r = to_rcp(1.0f + to_exp(-lo[j]));
                 if (lo[j] != lo[j]) r = lo[j];  // a degenerate waypoint (max == min) makes the reference's rewards NaN: propagate
-                rewards[o] = r;
+                if (!prefilled || lo[j] != 0.f) rewards[o[j]] = r;
                 s += (double)r;
             }
         }
     }
     const double tot = block_sum_double(s, lds);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&part[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const double q = threadIdx.x < gridDim.x ? __hip_atomic_load(&part[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    const double all = block_sum_double(q, lds);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-        const float mean = (float)(all / (double)n);
-        const float vis = 1.0f / (mean + eps);
-        scalars[0] = mean;
-        scalars[1] = vis;
-        scalars[2] = (float)(-(double)vis * (double)vis / (double)n);
-        scalars[3] = 0.f;  // reserved; written so that callers need not clear the vector
-    }
+    if (threadIdx.x != 0) return;
+    const bool isnan_ = tot != tot;
+    const unsigned long long fixed = isnan_ ? 0ull : (unsigned long long)__double2ll_rn(ldexp(tot, shift));
+    const unsigned long long word = (1ull << 56) | (isnan_ ? (1ull << 48) : 0ull) | fixed;
+    const unsigned long long old = __hip_atomic_fetch_add(acc, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)(old >> 56) != (int)gridDim.x - 1) return;
+    const unsigned long long all = old + word;
+    __hip_atomic_store(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    const bool anynan = ((all >> 48) & 0xffull) != 0ull;
+    const double sum = ldexp((double)(all & 0xffffffffffffull), -shift);
+    const float mean = anynan ? __builtin_nanf("") : (float)(sum / (double)n);
+    const float vis = 1.0f / (mean + eps);
+    scalars[0] = mean;
+    scalars[1] = vis;
+    scalars[2] = (float)(-(double)vis * (double)vis / (double)n);
+    scalars[3] = 0.f;  // reserved; written so that callers need not clear the vector
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -720,7 +750,7 @@ __global__ void k_bwd_finish2(const float* __restrict__ vgrad, const WayHot* __r
 __global__ void __launch_bounds__(TO_FINISH_THREADS)
 k_traj_bwd_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const unsigned long long* __restrict__ fv, int fv_words,
                   const WayRec* __restrict__ rec, EvalK k, const TieRec* __restrict__ ties, const float2* __restrict__ part,
-                  int nrows, int row_pts, const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ vgrad,
+                  const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ vgrad,
                   const WayCold* __restrict__ cold, int single, float* __restrict__ poses_grad, float* __restrict__ quats_grad) {
     __shared__ double sgrp[64][16];
     __shared__ double stie[2][13];   // [0] argmin set, [1] argmax set: 12 sums + count
@@ -738,53 +768,55 @@ k_traj_bwd_finish(CloudView cv, const float* __restrict__ bpart, int nslots, con
             if ((sfv[w] >> g) & 1ull) acc += (double)bpart[((int64_t)v * nslots + ((w0 + w) * 64 + g)) * 16 + kq];
     }
     sgrp[g][kq] = acc;
-    // ---- argmin / argmax sets (wave 0) ----
-    if (t < 64) {
-        const TieRec tr = ties[v];
+    // ---- argmin / argmax sets: waves 0..3 take a quarter (64 points) of every recorded slot each ----
+    __shared__ double stie4[2][4][13];
+    if (t < 256) {
+        const int wq = t >> 6, ln = t & 63;
+        const int* tp = reinterpret_cast<const int*>(ties + v);   // TieRec: nmax, nmin, maxrow[7], minrow[7]
         const float a = r.a, M = r.M;
         for (int set = 0; set < 2; ++set) {
-            const int cnt = set ? tr.nmax : tr.nmin;
+            const int cnt = set ? tp[0] : tp[1];
             double tot[13];
             for (int j = 0; j < 13; ++j) tot[j] = 0.0;
-            auto do_row = [&](int rr) {
-                for (int j0 = 0; j0 < row_pts; j0 += 64) {
-                    const int64_t i = (int64_t)rr * row_pts + j0 + t;
-                    float gq[13];
-                    for (int j = 0; j < 13; ++j) gq[j] = 0.f;
-                    if (j0 + t < row_pts && i < cv.n) {  // pads are not members
-                        VisGrad vg;
-                        const float p = vis_p(r, k, cv.soa[i], cv.soa[cv.npad + i], cv.soa[2 * cv.npad + i], &vg) * occ_one(occ, occw, v, i);
-                        const bool member = set ? ((p - a == M) && (M > 0.f)) : ((p == a) && (p > 0.f));
-                        if (member) {
-                            float gy[3];
-                            dvis_dy(r, k, p, vg, gy);
-                            const float yy[3] = {vg.y0, vg.y1, vg.y2};
-                            for (int q = 0; q < 3; ++q) gq[q] = gy[q];
-                            for (int j = 0; j < 3; ++j)
-                                for (int q = 0; q < 3; ++q) gq[3 + 3 * j + q] = yy[j] * gy[q];
-                            gq[12] = 1.0f;
-                        }
+            auto do_slot = [&](int rr) {   // rr: a slot holding the extremum
+                const int64_t i = (int64_t)rr * TO_SLOT + wq * 64 + ln;
+                float gq[13];
+                for (int j = 0; j < 13; ++j) gq[j] = 0.f;
+                if (i < cv.n) {  // pads are not members
+                    VisGrad vg;
+                    const float p = vis_p(r, k, cv.soa[i], cv.soa[cv.npad + i], cv.soa[2 * cv.npad + i], &vg) * occ_one(occ, occw, v, i);
+                    const bool member = set ? ((p - a == M) && (M > 0.f)) : ((p == a) && (p > 0.f));
+                    if (member) {
+                        float gy[3];
+                        dvis_dy(r, k, p, vg, gy);
+                        const float yy[3] = {vg.y0, vg.y1, vg.y2};
+                        for (int q = 0; q < 3; ++q) gq[q] = gy[q];
+                        for (int j = 0; j < 3; ++j)
+                            for (int q = 0; q < 3; ++q) gq[3 + 3 * j + q] = yy[j] * gy[q];
+                        gq[12] = 1.0f;
                     }
-                    for (int j = 0; j < 13; ++j) tot[j] += (double)wave_sum63(gq[j]);  // valid in lane 63
                 }
+                for (int j = 0; j < 13; ++j) tot[j] += (double)wave_sum63(gq[j]);  // valid in lane 63
             };
             if (cnt <= TO_TIE_CAP) {
-                for (int q = 0; q < cnt; ++q) do_row(set ? tr.maxrow[q] : tr.minrow[q]);
+                for (int q = 0; q < cnt; ++q) do_slot(tp[2 + (set ? 0 : TO_TIE_CAP) + q]);
             } else {
-                // more rows hold the extremum than were recorded: walk every row partial (rare: many exact duplicates)
-                const float target = set ? (a + M) : a;  // not used for ==: compare through the partials below
-                (void)target;
-                for (int rr = 0; rr < nrows; ++rr) {
-                    const float2 q = part[(int64_t)v * nrows + rr];
+                // more slots hold the extremum than were recorded: walk every slot partial (rare: many exact duplicates)
+                for (int rr = 0; rr < nslots; ++rr) {
+                    const float2 q = part[(int64_t)v * nslots + rr];
                     const bool hit = set ? (q.y - a == M) : (q.x == a);
-                    if (hit) do_row(rr);
+                    if (hit) do_slot(rr);
                 }
             }
-            if (t == 63)
-                for (int j = 0; j < 13; ++j) stie[set][j] = tot[j];
+            if (ln == 63)
+                for (int j = 0; j < 13; ++j) stie4[set][wq][j] = tot[j];
         }
     }
     __syncthreads();
+    if (t < 26) {   // ascending slot order inside a quarter, quarters in order: a fixed summation order
+        const int set = t / 13, j = t % 13;
+        stie[set][j] = ((stie4[set][0][j] + stie4[set][1][j]) + stie4[set][2][j]) + stie4[set][3][j];
+    }
     __shared__ double stot[16];
     if (t < 16) {
         double q = 0.0;
@@ -952,40 +984,27 @@ namespace {
 
 struct TrajPlan {
     int64_t npad;
-    int P;         // points per lane in pass 1
-    int nblk;      // pass-1 point blocks
-    int nrows;     // DPP rows = npad / (16 P)
-    int rps;       // rows per 256-point slot
+    int nblk;      // pass-1 point blocks (1024 points each)
     int nslots;    // npad / 256
     int fv_words;  // (nslots + 63) / 64
     int vwords;    // (V + 63) / 64
     int V;
-    size_t off_rpart, off_ctl, off_rec, off_cold, off_part, off_fv, off_ft, off_vcnt, off_vlist, off_ties,
-        off_bpart, off_vgrad, total;
+    size_t off_ctl, off_rec, off_cold, off_part, off_fv, off_ft, off_vcnt, off_vlist, off_ties, off_bpart, off_vgrad, total;
 };
-
-inline int choose_P() {
-    static const int forced = [] { const char* e = getenv("TOHIP_FORCE_P"); return e ? atoi(e) : 0; }();  // experiments
-    return forced == 8 ? 8 : 4;
-}
 
 inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W) {
     TrajPlan p;
     p.npad = tohip_padded_points(n);
-    p.P = choose_P();
-    p.nblk = (int)(p.npad / (TO_BLOCK * p.P));
-    p.nrows = (int)(p.npad / (16 * p.P));
-    p.rps = TO_SLOT / (16 * p.P);
+    p.nblk = (int)(p.npad / (TO_BLOCK * TO_P));
     p.nslots = (int)(p.npad / TO_SLOT);
     p.fv_words = (p.nslots + 63) / 64;
     p.vwords = (int)((V + 63) / 64);
     p.V = (int)V;
     size_t o = 0;
-    p.off_rpart = o; o += align_up((size_t)(2048 + TO_REWARD_SHARDS) * sizeof(double), 256);  // first: tohip_traj_reward uses only these two
-    p.off_ctl = o;   o += align_up(sizeof(TrajCtl), 256);
+    p.off_ctl = o;   o += align_up(sizeof(TrajCtl), 256);   // first: all tohip_traj_reward uses
     p.off_rec = o;   o += align_up((size_t)V * sizeof(WayRec), 256);
     p.off_cold = o;  o += align_up((size_t)W * sizeof(WayCold), 256);
-    p.off_part = o;  o += align_up((size_t)V * (size_t)(p.npad / 64) * sizeof(float2), 256);  // rows of the finest variant (P = 4)
+    p.off_part = o;  o += align_up((size_t)V * (size_t)p.nslots * sizeof(float2), 256);
     p.off_fv = o;    o += align_up((size_t)V * (size_t)p.fv_words * sizeof(unsigned long long), 256);
     p.off_ft = o;    o += align_up((size_t)p.nslots * (size_t)p.vwords * sizeof(unsigned long long), 256);
     p.off_vcnt = o;  o += align_up((size_t)V * sizeof(int), 256);
@@ -1001,13 +1020,13 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W) {
 inline void choose_tiles(int nblk, int V, bool cull, int* vtile, int* ntiles) {
     static const int forced = [] { const char* e = getenv("TOHIP_FORCE_VTILE"); return e ? atoi(e) : 0; }();  // experiments
     int vt;
-    if (forced > 0) vt = forced;
+    if (forced > 0 && !cull) vt = forced;
     else if (cull) {
-        // the work sits in the few point blocks near the path: split their waypoint range over grid.y
-        int nt = nblk < 512 ? (1024 + nblk - 1) / nblk : 1;
-        if (nt < 8) nt = 8;
-        vt = (V + nt - 1) / nt;
-        vt = (vt + 63) / 64 * 64;  // the survivor ballots cover 64 waypoints
+        // the work sits in the few point blocks near the path, where a wave walks its live waypoints one after the other:
+        // at most this many per block row (one ballot), the rest of the range goes to other block rows
+        static const int cvt = [] { const char* e = getenv("TOHIP_CULL_VTILE"); return e ? atoi(e) : 0; }();  // experiments
+        vt = cvt > 0 ? cvt : 32;
+        if (vt > 64) vt = 64;
     } else {
         // ~8192 blocks when the problem allows it: 2048 resident at a time (8 per CU), the rest dealt dynamically
         const int want = 8192;
@@ -1025,16 +1044,6 @@ inline void choose_tiles(int nblk, int V, bool cull, int* vtile, int* ntiles) {
 
 inline int rig_cams(const tohip_rig* rig) { return (rig && rig->n_cams > 0 && rig->rig_quats) ? rig->n_cams : 1; }
 
-template <typename F>
-inline void dispatch_pass1(int P, bool cull, bool occ, F&& f) {
-    auto with_o = [&](auto Oc) {
-        if (cull) f(std::integral_constant<int, 4>(), std::true_type(), Oc);
-        else if (P == 8) f(std::integral_constant<int, 8>(), std::false_type(), Oc);
-        else f(std::integral_constant<int, 4>(), std::false_type(), Oc);
-    };
-    if (occ) with_o(std::true_type()); else with_o(std::false_type());
-}
-
 }  // namespace
 
 extern "C" size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual) {
@@ -1044,7 +1053,8 @@ extern "C" size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual
 
 extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
                                   const tohip_camera* cam, const tohip_rig* rig, int flags, const uint32_t* occlusion_bits,
-                                  float* lo_sum, float* minmax, void* workspace, size_t workspace_bytes, void* stream_) {
+                                  float* lo_sum, float* minmax, float* rewards_half, void* workspace, size_t workspace_bytes,
+                                  void* stream_) {
     if (!packed || !poses || !quats || !cam || !lo_sum || !minmax || !workspace || n <= 0 || W <= 0) return TOHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
     const int C = rig_cams(rig);
@@ -1053,7 +1063,6 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
     const TrajPlan pl = make_plan(n, V, W);
     if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
     char* ws = (char*)workspace;
-    TrajCtl* ctl = (TrajCtl*)(ws + pl.off_ctl);
     WayRec* rec = (WayRec*)(ws + pl.off_rec);
     WayCold* cold = (WayCold*)(ws + pl.off_cold);
     float2* part = (float2*)(ws + pl.off_part);
@@ -1073,15 +1082,13 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
     {
         TO_PROF(TOHIP_PROF_SMALL, st);
         if (cull) {
-            int step = (int)(n / 4096);
-            if (step < 1) step = 1;
-            k_traj_probe<<<(int)V, TO_PROBE_THREADS, 0, st>>>(cv, poses, quats, C, rq, rt, k, rec, cold, step, occlusion_bits, occw,
-                                                              ft, ft_words, ctl);
+            k_traj_probe<<<(int)V, TO_PROBE_THREADS, 0, st>>>(cv, poses, quats, C, rq, rt, k, rec, cold, occlusion_bits, occw,
+                                                              ft, ft_words);
         } else {
             int nb = (int)((V + 255) / 256);
             const int want = (int)((ft_words + 255) / 256);
             if (nb < want) nb = want > 256 ? 256 : want;
-            k_traj_prep<<<nb, 256, 0, st>>>(poses, quats, (int)V, C, rq, rt, k, rec, cold, ft, ft_words, ctl);
+            k_traj_prep<<<nb, 256, 0, st>>>(poses, quats, (int)V, C, rq, rt, k, rec, cold, ft, ft_words);
         }
         TO_HIP_CHECK_LAUNCH();
     }
@@ -1089,47 +1096,48 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
     choose_tiles(pl.nblk, (int)V, cull, &vtile, &ntiles);
     {
         TO_PROF(TOHIP_PROF_PASS1, st);
-        dispatch_pass1(pl.P, cull, occlusion_bits != nullptr, [&](auto Pc, auto Cu, auto Oc) {
-            constexpr int Pv = decltype(Pc)::value;
-            const int nblk = (int)(pl.npad / (TO_BLOCK * Pv));
-            const int nrows = (int)(pl.npad / (16 * Pv));
-            k_traj_pass1<Pv, decltype(Cu)::value, decltype(Oc)::value>
-                <<<dim3(nblk, ntiles), TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, nrows, occlusion_bits, occw, lo_sum);
-        });
+        const dim3 grid(pl.nblk, ntiles);
+        const bool occ = occlusion_bits != nullptr;
+        if (cull) {
+            if (occ) k_traj_pass1<true, true><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half);
+            else k_traj_pass1<true, false><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half);
+        } else {
+            if (occ) k_traj_pass1<false, true><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half);
+            else k_traj_pass1<false, false><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half);
+        }
         TO_HIP_CHECK_LAUNCH();
     }
-    // culled pass 1 always runs with P = 4 (one tile per wave): its rows are 64 points whatever pl.P says
-    const int nrows = cull ? (int)(pl.npad / 64) : pl.nrows;
-    const int rps = cull ? 4 : pl.rps;
     {
         TO_PROF(TOHIP_PROF_SMALL, st);
-        k_traj_select<<<(int)V, TO_SELECT_THREADS, 0, st>>>(part, nrows, rps, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
-                                                            pl.vwords, vlist, vcnt, ties, ctl);
+        if (pl.nslots <= TO_SELECT_FAST_SLOTS)
+            k_traj_select<true><<<(int)V, TO_SELECT_THREADS, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
+                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad);
+        else
+            k_traj_select<false><<<(int)V, TO_SELECT_THREADS, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
+                                                                       pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad);
         TO_HIP_CHECK_LAUNCH();
     }
     {
         TO_PROF(TOHIP_PROF_PASS2, st);
-        k_traj_lo_sparse<<<(pl.nslots + TO_LO_SLOTS - 1) / TO_LO_SLOTS, 1024, 0, st>>>(cv, rec, k, ft, pl.vwords, pl.nslots, ctl, lo_sum,
-                                                                                       occlusion_bits, occw);
+        k_traj_lo_sparse<<<pl.nslots, 1024, 0, st>>>(cv, rec, k, ft, pl.vwords, lo_sum, occlusion_bits, occw);
         TO_HIP_CHECK_LAUNCH();
     }
     return TOHIP_OK;
 }
 
-extern "C" int tohip_traj_reward(const void* packed, const float* lo_sum, int64_t n, float eps, float* rewards,
+extern "C" int tohip_traj_reward(const void* packed, const float* lo_sum, int64_t n, float eps, int prefilled, float* rewards,
                                  float* scalars, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!packed || !lo_sum || !rewards || !scalars || !workspace || n <= 0) return TOHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
-    const TrajPlan pl = make_plan(n, 1, 1);  // the first two regions do not depend on V
-    if (workspace_bytes < pl.off_ctl + sizeof(TrajCtl)) return TOHIP_ENOSPC;
-    char* ws = (char*)workspace;
-    double* rpart = (double*)(ws + pl.off_rpart);
-    TrajCtl* ctl = (TrajCtl*)(ws + pl.off_ctl);
+    if (workspace_bytes < sizeof(TrajCtl)) return TOHIP_ENOSPC;
+    TrajCtl* ctl = (TrajCtl*)workspace;   // TrajPlan::off_ctl == 0
     const CloudView cv = cloud_view(packed, n);
     int nb = (int)((n + 4 * TO_REWARD_THREADS - 1) / (4 * TO_REWARD_THREADS));
     if (nb > TO_REWARD_BLOCKS) nb = TO_REWARD_BLOCKS;
+    int lg = 0;
+    while (((int64_t)1 << lg) < n) ++lg;
     TO_PROF(TOHIP_PROF_REWARD, st);
-    k_traj_reward<<<nb, TO_REWARD_THREADS, 0, st>>>(lo_sum, cv.inv, n, eps, rewards, rpart, ctl->reward_done, scalars);
+    k_traj_reward<<<nb, TO_REWARD_THREADS, 0, st>>>(lo_sum, cv.perm, n, eps, 47 - lg, prefilled ? 1 : 0, rewards, &ctl->reward_acc, scalars);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
@@ -1162,8 +1170,6 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, int64_t W, con
     const float* rq = (C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
     const float* rt = rq ? rig->rig_trans : nullptr;
     const int64_t occw = cv.npad / 32;
-    const int nrows = cull ? (int)(pl.npad / 64) : pl.nrows;
-    const int row_pts = cull ? 64 : 16 * pl.P;
     {
         TO_PROF(TOHIP_PROF_BWD, st);
         for (int64_t v0 = 0; v0 < V; v0 += 65535) {  // grid.y limit
@@ -1176,7 +1182,7 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, int64_t W, con
     }
     TO_PROF(TOHIP_PROF_SMALL, st);
     const bool single = C == 1 && rq == nullptr;
-    k_traj_bwd_finish<<<(int)V, TO_FINISH_THREADS, 0, st>>>(cv, bpart, pl.nslots, fv, pl.fv_words, rec, k, ties, part, nrows, row_pts,
+    k_traj_bwd_finish<<<(int)V, TO_FINISH_THREADS, 0, st>>>(cv, bpart, pl.nslots, fv, pl.fv_words, rec, k, ties, part,
                                                             occlusion_bits, occw, vgrad, cold, single ? 1 : 0, poses_grad, quats_grad);
     TO_HIP_CHECK_LAUNCH();
     if (!single) {

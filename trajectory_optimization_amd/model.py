@@ -125,10 +125,11 @@ class _PoseLoss(torch.autograd.Function):
 
 
 def _local_forward(model, ps, qs, occ):
-    """tohip_traj_forward for this rank's waypoints -> (lo_sum, minmax, workspace, its generation)."""
+    """tohip_traj_forward for this rank's waypoints -> (lo_sum, rewards pre-filled with 0.5, workspace, its generation)."""
     ws = model._workspace(ps.shape[0])
-    lo_sum, minmax = ops.traj_forward(model._cloud, ps, qs, model._cam, ws, model._rig, flags=model._flags, occ=occ)
-    return lo_sum, minmax, ws, ws.generation
+    half = torch.empty(model._cloud.n, dtype=torch.float32, device=ps.device)
+    lo_sum, _ = ops.traj_forward(model._cloud, ps, qs, model._cam, ws, model._rig, flags=model._flags, occ=occ, rewards_half=half)
+    return lo_sum, half, ws, ws.generation
 
 
 def _local_backward(model, ctx_ws, ctx_gen, ps, qs, occ, lo_sum, **kw):
@@ -154,13 +155,14 @@ class _TrajRewards(torch.autograd.Function):
         if hi > lo and model._occlusion is not None:
             # occlusion masks are piecewise constant in the poses: computed per forward, not differentiated
             occ = model._occlusion_rows(ps, qs)
-        ws, gen = None, 0
+        ws, gen, half = None, 0, None
         if hi > lo:
-            lo_sum, _, ws, gen = _local_forward(model, ps, qs, occ)
+            lo_sum, half, ws, gen = _local_forward(model, ps, qs, occ)
         else:
             lo_sum = torch.zeros(model._cloud.npad, device=p.device)
         lo_sum = sh.allreduce_sum(lo_sum)
-        rewards, _ = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)))
+        rewards, _ = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)), rewards=half,
+                                     prefilled=half is not None)
         ctx.model, ctx.range, ctx.n_wps, ctx.occ, ctx.ws, ctx.gen = model, (lo, hi), p.shape[0], occ, ws, gen
         ctx.save_for_backward(ps, qs, lo_sum)
         return rewards
@@ -204,13 +206,14 @@ class _TrajLoss(torch.autograd.Function):
         occ = None
         if hi > lo and model._occlusion is not None:
             occ = model._occlusion_rows(ps, qs)
-        ws, gen = None, 0
+        ws, gen, half = None, 0, None
         if hi > lo:
-            lo_sum, _, ws, gen = _local_forward(model, ps, qs, occ)
+            lo_sum, half, ws, gen = _local_forward(model, ps, qs, occ)
         else:
             lo_sum = torch.zeros(model._cloud.npad, device=dev)
         lo_sum = sh.allreduce_sum(lo_sum)
-        rewards, scalars = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)))
+        rewards, scalars = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)), rewards=half,
+                                           prefilled=half is not None)
         terms = torch.empty(8, dtype=torch.float32, device=dev)
         reg_sum = torch.empty((W, 3), dtype=torch.float32, device=dev)
         reg_terms = torch.empty((3, W, 3), dtype=torch.float32, device=dev)

@@ -91,9 +91,10 @@ class TrajWorkspace:
 DENSE = 1  # TOHIP_TRAJ_DENSE
 
 
-def traj_forward(cloud, poses, quats, cam, ws, rig=None, flags=0, occ=None, lo_sum=None, minmax=None):
+def traj_forward(cloud, poses, quats, cam, ws, rig=None, flags=0, occ=None, lo_sum=None, minmax=None, rewards_half=None):
     """-> (lo_sum[npad] in packed order (first N valid), minmax[V,2]) for the given waypoints (this rank's shard).
-    Leaves the step's state in `ws` for traj_backward."""
+    Leaves the step's state in `ws` for traj_backward.  rewards_half: optional (N,) f32 tensor filled with 0.5 on the way
+    (hand it to traj_reward as `rewards=` with prefilled=True)."""
     W = poses.shape[0]
     C = rig.n_cams if rig is not None else 1
     if lo_sum is None:
@@ -104,19 +105,20 @@ def traj_forward(cloud, poses, quats, cam, ws, rig=None, flags=0, occ=None, lo_s
     with torch.cuda.device(cloud.device):
         check(_lib.lib().tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, cam.ref(),
                                             rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(occ), ptr(lo_sum), ptr(minmax),
-                                            ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_forward")
+                                            ptr(rewards_half), ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_forward")
     return lo_sum, minmax
 
 
-def traj_reward(cloud, lo_sum, cam, ws, rewards=None, scalars=None):
-    """-> (rewards[N], scalars[4] = mean, loss_vis, dloss/dreward, -)"""
+def traj_reward(cloud, lo_sum, cam, ws, rewards=None, scalars=None, prefilled=False):
+    """-> (rewards[N], scalars[4] = mean, loss_vis, dloss/dreward, -).  prefilled: `rewards` holds 0.5 everywhere (traj_forward's
+    rewards_half): only the others are stored."""
     if rewards is None:
         rewards = torch.empty(cloud.n, dtype=torch.float32, device=cloud.device)
     if scalars is None:
         scalars = torch.empty(4, dtype=torch.float32, device=cloud.device)  # all four written by the kernel
     with torch.cuda.device(cloud.device):
-        check(_lib.lib().tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, ptr(rewards), ptr(scalars), ptr(ws.buf),
-                                           ws.bytes, stream_ptr()), "tohip_traj_reward")
+        check(_lib.lib().tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, int(bool(prefilled)), ptr(rewards), ptr(scalars),
+                                           ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_reward")
     return rewards, scalars
 
 

@@ -72,13 +72,13 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
                                      model._occlusion_limits[1], model._occlusion)
         if n_loc > 0:
             check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref,
-                                       model._flags, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(ws.buf), ws.bytes, s),
+                                       model._flags, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(ws.buf), ws.bytes, s),
                   "forward")
             ws.generation += 1
         else:
             lo_sum.zero_()
         model._shard.allreduce_sum(lo_sum)
-        check(L.tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, ptr(rewards), ptr(scalars),
+        check(L.tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, 1 if n_loc > 0 else 0, ptr(rewards), ptr(scalars),
                                   ptr(ws.buf), ws.bytes, s), "reward")
         tgt_p, tgt_q = (pg_loc, qg_loc) if sharded else (pg_e, qg_e)
         if n_loc > 0:
