@@ -37,7 +37,7 @@ extern "C" {
 #define TOHIP_ENAN (-4)     /* hull input holds a NaN (a zero-norm point flips to NaN, tools.py:49-52): scipy raises ValueError */
 
 /* Points are processed in tiles of this many; packed clouds are padded to a multiple of it. */
-#define TOHIP_POINT_TILE 1024
+#define TOHIP_POINT_TILE 2048
 
 /* Camera model shared by all waypoints: load_intrinsics (tools.py:320-325) + the constants the
  * models keep (model.py:91-94,186-189).  Passed by pointer in HOST memory. */
@@ -298,6 +298,12 @@ int tohip_render_points(const float *verts, int64_t n_points, const float *K9_ho
 int tohip_profile_enable(int on);
 const char *tohip_profile_name(int id);
 int tohip_profile_read(double *ms_sum_host, int64_t *counts_host);
+/* Diagnostic: while a device buffer is set, every block of k_traj_pass1 (the dense kernel) stores two 64-bit words — its
+ * lifetime in shader-clock ticks (s_memtime) and in 100 MHz ticks (s_memrealtime) — at [2*block], capacity
+ * tohip_profile_clock_blocks(n_points, n_virtual, flags) blocks; NULL switches it off.  Their quotient x 100 MHz is the clock
+ * the chip actually holds under this kernel (it gives clock back under load).  Never set during a timed pass. */
+int tohip_profile_clock(void *device_buffer);
+int64_t tohip_profile_clock_blocks(int64_t n_points, int64_t n_virtual, int flags);
 
 /* ---- self tests of cross-lane primitives (used by tests/, cheap) -------------------------------- */
 int tohip_selftest_wave_reduce(const float *in64xK, int32_t k, float *out_sum, float *out_min, float *out_max,

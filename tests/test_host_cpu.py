@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_sizes_and_argument_errors_without_gpu():
     from trajectory_optimization_amd import _lib
     L = _lib.lib()
-    assert L.tohip_padded_points(1) == 1024 and L.tohip_padded_points(1024) == 1024 and L.tohip_padded_points(1025) == 2048
+    assert L.tohip_padded_points(1) == 2048 and L.tohip_padded_points(2048) == 2048 and L.tohip_padded_points(2049) == 4096
     assert L.tohip_padded_points(0) == 0
     assert L.tohip_traj_workspace_bytes(1_000_000, 128) > 128 * 64
     assert L.tohip_traj_workspace_bytes(0, 5) == 0
@@ -37,7 +37,7 @@ def test_sizes_and_argument_errors_without_gpu():
     # null pointers / bad sizes are rejected before any launch
     assert L.tohip_pack_cloud(None, 10, 1, None, None, 0, None) == -1
     # x|y|z, perm, bounds, inverse perm, the probe's samples
-    assert L.tohip_packed_cloud_bytes(1000) == 1024 * 16 + 4 * 16 + 1024 * 4 + 8192 * 12
+    assert L.tohip_packed_cloud_bytes(1000) == 2048 * 16 + 8 * 16 + 2048 * 4 + 8192 * 12
     cam = _lib.make_camera([1, 0, 0, 0, 1, 0, 0, 0, 1], 10, 10, 1, 5)
     assert L.tohip_traj_forward(None, 10, None, None, 1, ctypes.byref(cam), None, 0, None, None, None, None, None, 0, None) == -1
     assert L.tohip_hidden_pts_removal(None, 2, 2.0, None, None, None, None, 0, None) == -1

@@ -17,7 +17,7 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "trajectory_optimization_amd", "csrc", "trajopt_hip.hip")
-DENSE_PASS1 = "k_traj_pass1ILb0ELb0E"   # <CULL = false, OCC = false>
+DENSE_PASS1 = "k_traj_pass1_denseILb0E"   # <OCC = false>
 TRANS = re.compile(r"v_(exp|log|rcp|rsq|sqrt|sin|cos)_")
 
 
@@ -78,17 +78,17 @@ def main():
         # the waypoint loop: the one that loads a waypoint record (s_load_dwordx16)
         body = next(ops for ops in ks[name][2].values() if "s_load_dwordx16" in ops)
         c, cl = classes(body)
-        out = dict(kernel=name, points_per_lane=4, evaluations_per_iteration=256,
+        out = dict(kernel=name, points_per_lane=8, evaluations_per_iteration=512,
                    packed_f32=cl["packed_f32"], transcendental=cl["transcendental"], other_valu=cl["other_valu"],
                    salu_smem=cl["salu_smem"], vmem=cl["vmem"],
                    note="VALU instructions of one (wave, waypoint) iteration of the dense inner loop (hipcc -O3 --offload-arch=gfx950, "
-                        "ROCm 7.2); per evaluation: 26 FMA-class operations as 13 packed instructions per pair, 4 transcendentals",
+                        "ROCm 7.2); a lane owns 8 points = 4 packed pairs; per evaluation: 26 FMA-class operations (13 packed instructions per pair), 4 transcendentals",
                    mnemonics=dict(c.most_common()))
         with open(args[1], "w") as f:
             json.dump(out, f, indent=1)
         print(json.dumps({k: out[k] for k in ("packed_f32", "transcendental", "other_valu", "salu_smem", "vmem")}))
         return
-    pats = args or ["k_traj_pass1ILi4E", "k_traj_lo_sparse", "k_traj_bwd_sparse", "k_traj_select"]
+    pats = args or ["k_traj_pass1_dense", "k_traj_pass1_cull", "k_traj_lo_sparse", "k_traj_bwd_sparse", "k_traj_select"]
     for name, (ins, loop, _) in ks.items():
         if not any(p in name for p in pats):
             continue

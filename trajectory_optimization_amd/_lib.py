@@ -91,6 +91,8 @@ SIGNATURES = {
     "tohip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "tohip_profile_name": (ctypes.c_char_p, [ctypes.c_int]),
     "tohip_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    "tohip_profile_clock": (ctypes.c_int, [c_vp]),
+    "tohip_profile_clock_blocks": (c_i64, [c_i64, c_i64, ctypes.c_int]),
     "tohip_selftest_wave_reduce": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
 }
 

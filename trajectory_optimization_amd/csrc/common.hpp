@@ -570,3 +570,16 @@ __device__ __forceinline__ float wave_max63_nn_fused(float f) {
                  "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
     return __builtin_bit_cast(float, v);
 }
+
+// the same over each HALF of the wave (lanes 0..31 and 32..63): valid in lanes 31 and 63 — the dense pass 1 holds two
+// 256-point slots per wave (8 points per lane)
+__device__ __forceinline__ float half_min31_nn_fused(float f) {
+    int v = __builtin_bit_cast(int, row_min16_nn(f));
+    asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    return __builtin_bit_cast(float, v);
+}
+__device__ __forceinline__ float half_max31_nn_fused(float f) {
+    int v = __builtin_bit_cast(int, row_max16_nn(f));
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    return __builtin_bit_cast(float, v);
+}

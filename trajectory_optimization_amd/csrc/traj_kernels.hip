@@ -286,10 +286,82 @@ __device__ __forceinline__ void pass1_eval(const EvalK& k, const WayRec& r, cons
     mx = fmaxf(fmaxf(p0.x, p0.y), fmaxf(p1.x, p1.y));
 }
 
-template <bool CULL, bool OCC>
+// the log-odds vector starts from zero (k_traj_lo_sparse fills the flagged slots) and, when the caller asks for it, the rewards
+// vector from sigmoid(0) = 1/2 (k_traj_reward then only stores the others): done by whoever evaluates a point block's first waypoint
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void init_outputs(int64_t base, int64_t n, float* __restrict__ lo_zero, float* __restrict__ rewards_half) {
+    // streaming stores: nothing of this is read again by this kernel, and lines left dirty in L2 are written back at its end
+    __builtin_nontemporal_store(f4v{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4v*>(lo_zero + base));
+    if (rewards_half != nullptr && base < n) {
+        if (base + 4 <= n) __builtin_nontemporal_store(f4v{0.5f, 0.5f, 0.5f, 0.5f}, reinterpret_cast<f4v*>(rewards_half + base));
+        else for (int64_t i = base; i < n; ++i) rewards_half[i] = 0.5f;
+    }
+}
+
+// DENSE: persistent blocks, as many as the chip holds at once (host: occupancy x CUs).  A lane owns EIGHT consecutive points
+// (four independent packed evaluation chains per waypoint: a SIMD holds only ~5 of these waves, which issue in age order, so the
+// instruction-level parallelism has to come from inside the wave), a wave two 256-point slots, a block 2048 points.  The
+// (point block, waypoint) pairs are one flat range cut into gridDim.x equal pieces: a block's piece is a run of consecutive
+// waypoints of one point block (seldom two), so every block does the same number of evaluations to within one waypoint, loads
+// its points once (twice), and all blocks end together: no dispatch order, no tail.
+#define TO_PD 8
+template <bool OCC>
 __global__ void __launch_bounds__(TO_BLOCK)
-k_traj_pass1(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile, EvalK k, float2* __restrict__ part, int nslots,
-             const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ lo_zero, float* __restrict__ rewards_half) {
+k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk, EvalK k, float2* __restrict__ part, int nslots,
+                   const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ lo_zero, float* __restrict__ rewards_half,
+                   unsigned long long* __restrict__ stamps) {
+    constexpr int P = TO_PD;
+    const int lane = threadIdx.x & 63;
+    // diagnostic only (tohip_profile_clock): shader-clock and 100 MHz real-time stamps of this block, to a buffer nothing else reads
+    unsigned long long st0 = 0, sr0 = 0;
+    if (stamps != nullptr && threadIdx.x == 0) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
+    const int64_t total = (int64_t)nblk * V;
+    int64_t u = total * blockIdx.x / gridDim.x;
+    const int64_t u_end = total * (blockIdx.x + 1) / gridDim.x;
+    while (u < u_end) {
+        const int pb = (int)(u / V);
+        const int v0 = (int)(u - (int64_t)pb * V);
+        const int v1 = (int)min((int64_t)V, v0 + (u_end - u));
+        const int gthread = pb * TO_BLOCK + threadIdx.x;
+        const int64_t base = (int64_t)gthread * P;
+        const int slot = gthread >> 5;   // 32 lanes x 8 points
+        float x[P], y[P], z[P];
+        load_points<P>(cv.soa, cv.npad, base, x, y, z);
+        if (v0 == 0) { init_outputs(base, cv.n, lo_zero, rewards_half); init_outputs(base + 4, cv.n, lo_zero, rewards_half); }
+        for (int v = v0; v < v1; ++v) {
+            const WayRec& r = rec[v];
+            float om[P];
+            load_occ<P, OCC>(occ, occw, v, base, om);
+            f2 p[P / 2];
+#pragma unroll
+            for (int i = 0; i < P; i += 2)
+                p[i / 2] = vis_p_pk(r, k, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}) * f2{om[i], om[i + 1]};
+            float mn = fminf(fminf(fminf(p[0].x, p[0].y), fminf(p[1].x, p[1].y)), fminf(fminf(p[2].x, p[2].y), fminf(p[3].x, p[3].y)));
+            float mx = fmaxf(fmaxf(fmaxf(p[0].x, p[0].y), fmaxf(p[1].x, p[1].y)), fmaxf(fmaxf(p[2].x, p[2].y), fmaxf(p[3].x, p[3].y)));
+            mn = half_min31_nn_fused(mn);
+            mx = half_max31_nn_fused(mx);
+            if ((lane & 31) == 31) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
+        }
+        u += v1 - v0;
+    }
+    if (stamps != nullptr && threadIdx.x == 0) {
+        stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st0;
+        stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
+        unsigned long long* ext = stamps + 2 * (int64_t)gridDim.x + 4 * (int64_t)blockIdx.x;   // where and when the block ran
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        ext[0] = sr0; ext[1] = __builtin_amdgcn_s_memrealtime(); ext[2] = hw; ext[3] = xcc;
+    }
+}
+
+// CULL: grid = (point blocks, waypoint tiles of <= 64): one ballot covers the block row's waypoints.  A live (tile, waypoint)
+// pair is evaluated like in the dense kernel (packed, every point of the wave): per-point distance tests cost as much as they
+// save once the tile is live.  The work sits in the few point blocks near the path, hence many short block rows.
+template <bool OCC>
+__global__ void __launch_bounds__(TO_BLOCK)
+k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile, EvalK k, float2* __restrict__ part, int nslots,
+                  const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ lo_zero, float* __restrict__ rewards_half) {
     constexpr int P = TO_P;
     const int lane = threadIdx.x & 63;
     const int gthread = blockIdx.x * TO_BLOCK + threadIdx.x;
@@ -297,45 +369,23 @@ k_traj_pass1(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile, Eva
     const int slot = gthread >> 6;
     float x[P], y[P], z[P];
     load_points<P>(cv.soa, cv.npad, base, x, y, z);
-    if (blockIdx.y == 0) {
-        // the log-odds vector starts from zero (k_traj_lo_sparse fills the flagged slots) and, when the caller asks for it, the
-        // rewards vector from sigmoid(0) = 1/2 (k_traj_reward then only stores the others)
-        *reinterpret_cast<float4*>(lo_zero + base) = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rewards_half != nullptr && base < cv.n) {
-            if (base + 4 <= cv.n) *reinterpret_cast<float4*>(rewards_half + base) = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
-            else for (int64_t i = base; i < cv.n; ++i) rewards_half[i] = 0.5f;
-        }
-    }
+    if (blockIdx.y == 0) init_outputs(base, cv.n, lo_zero, rewards_half);
     const int v0 = blockIdx.y * vtile;
     const int v1 = min(V, v0 + vtile);
-    if constexpr (!CULL) {
-        for (int v = v0; v < v1; ++v) {
-            const WayRec& r = rec[v];
-            float mn, mx, om[P];
-            load_occ<P, OCC>(occ, occw, v, base, om);
-            pass1_eval(k, r, x, y, z, om, mn, mx);
-            mn = wave_min63_nn_fused(mn);
-            mx = wave_max63_nn_fused(mx);
-            if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
-        }
-    } else {
-        // vtile <= 64: one ballot covers the block row's waypoints.  A live (tile, waypoint) pair is evaluated like in the dense
-        // kernel (packed, every point of the wave): per-point distance tests cost as much as they save once the tile is live.
-        const float4 tb = wave_tile_bound(cv, base);
-        unsigned long long live = tile_survivors(rec, v0, v1, tb);
-        // waypoints that cannot be affected from this tile: min is the proven 0, max unknown (-inf: never flagged)
-        if (v0 + lane < v1 && !((live >> lane) & 1ull)) part[(int64_t)(v0 + lane) * nslots + slot] = make_float2(0.f, -INFINITY);
-        while (live) {
-            const int v = v0 + __builtin_ctzll(live);
-            live &= live - 1ull;
-            const WayRec& r = rec[v];
-            float mn, mx, om[P];
-            load_occ<P, OCC>(occ, occw, v, base, om);
-            pass1_eval(k, r, x, y, z, om, mn, mx);
-            mn = wave_min63_nn_fused(mn);
-            mx = wave_max63_nn_fused(mx);
-            if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
-        }
+    const float4 tb = wave_tile_bound(cv, base);
+    unsigned long long live = tile_survivors(rec, v0, v1, tb);
+    // waypoints that cannot be affected from this tile: min is the proven 0, max unknown (-inf: never flagged)
+    if (v0 + lane < v1 && !((live >> lane) & 1ull)) part[(int64_t)(v0 + lane) * nslots + slot] = make_float2(0.f, -INFINITY);
+    while (live) {
+        const int v = v0 + __builtin_ctzll(live);
+        live &= live - 1ull;
+        const WayRec& r = rec[v];
+        float mn, mx, om[P];
+        load_occ<P, OCC>(occ, occw, v, base, om);
+        pass1_eval(k, r, x, y, z, om, mn, mx);
+        mn = wave_min63_nn_fused(mn);
+        mx = wave_max63_nn_fused(mx);
+        if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
     }
 }
 
@@ -982,6 +1032,9 @@ extern "C" int tohip_occlusion_row(int64_t n, const int32_t* inv_perm, const int
 
 namespace {
 
+// diagnostic: device buffer for k_traj_pass1's per-block clock stamps (tohip_profile_clock); normally none
+inline unsigned long long*& clock_stamps() { static unsigned long long* p = nullptr; return p; }
+
 struct TrajPlan {
     int64_t npad;
     int nblk;      // pass-1 point blocks (1024 points each)
@@ -1016,30 +1069,36 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W) {
     return p;
 }
 
-// waypoint tiling of pass 1's grid.y: enough blocks to keep eight waves per SIMD in flight, re-dealt as they finish
-inline void choose_tiles(int nblk, int V, bool cull, int* vtile, int* ntiles) {
-    static const int forced = [] { const char* e = getenv("TOHIP_FORCE_VTILE"); return e ? atoi(e) : 0; }();  // experiments
-    int vt;
-    if (forced > 0 && !cull) vt = forced;
-    else if (cull) {
-        // the work sits in the few point blocks near the path, where a wave walks its live waypoints one after the other:
-        // at most this many per block row (one ballot), the rest of the range goes to other block rows
-        static const int cvt = [] { const char* e = getenv("TOHIP_CULL_VTILE"); return e ? atoi(e) : 0; }();  // experiments
-        vt = cvt > 0 ? cvt : 32;
-        if (vt > 64) vt = 64;
-    } else {
-        // ~8192 blocks when the problem allows it: 2048 resident at a time (8 per CU), the rest dealt dynamically
-        const int want = 8192;
-        int nt = (want + nblk - 1) / nblk;
-        if (nt > V) nt = V;
-        if (nt < 1) nt = 1;
-        vt = (V + nt - 1) / nt;
-        if (vt < 8 && V >= 8) vt = 8;
-    }
+// culled pass 1: block rows of at most this many waypoints (one ballot; a wave walks its live waypoints one after the other)
+inline void cull_tiles(int V, int* vtile, int* ntiles) {
+    static const int cvt = [] { const char* e = getenv("TOHIP_CULL_VTILE"); return e ? atoi(e) : 0; }();  // experiments
+    int vt = cvt > 0 ? cvt : 32;
+    if (vt > 64) vt = 64;
     if (vt > V) vt = V;
     if (vt < 1) vt = 1;
     *vtile = vt;
     *ntiles = (V + vt - 1) / vt;
+}
+
+// dense pass 1: as many persistent blocks as are resident at once (never more than one per (point block, waypoint) pair)
+inline int dense_blocks(int nblk, int V, bool occ) {
+    static const int forced = [] { const char* e = getenv("TOHIP_DENSE_BLOCKS"); return e ? atoi(e) : 0; }();  // experiments
+    static int per_cu[2] = {0, 0}, cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+        int a = 0, b = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_traj_pass1_dense<false>, TO_BLOCK, 0) != hipSuccess || a <= 0) a = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_traj_pass1_dense<true>, TO_BLOCK, 0) != hipSuccess || b <= 0) b = 4;
+        per_cu[0] = a > 8 ? 8 : a;
+        per_cu[1] = b > 8 ? 8 : b;
+    }
+    int64_t nb = forced > 0 ? forced : (int64_t)per_cu[occ ? 1 : 0] * cus;
+    const int64_t total = (int64_t)nblk * V;
+    if (nb > total) nb = total;
+    return (int)nb;
 }
 
 inline int rig_cams(const tohip_rig* rig) { return (rig && rig->n_cams > 0 && rig->rig_quats) ? rig->n_cams : 1; }
@@ -1092,18 +1151,20 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
         }
         TO_HIP_CHECK_LAUNCH();
     }
-    int vtile, ntiles;
-    choose_tiles(pl.nblk, (int)V, cull, &vtile, &ntiles);
     {
         TO_PROF(TOHIP_PROF_PASS1, st);
-        const dim3 grid(pl.nblk, ntiles);
         const bool occ = occlusion_bits != nullptr;
         if (cull) {
-            if (occ) k_traj_pass1<true, true><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half);
-            else k_traj_pass1<true, false><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half);
+            int vtile, ntiles;
+            cull_tiles((int)V, &vtile, &ntiles);
+            const dim3 grid(pl.nblk, ntiles);
+            if (occ) k_traj_pass1_cull<true><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half);
+            else k_traj_pass1_cull<false><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half);
         } else {
-            if (occ) k_traj_pass1<false, true><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half);
-            else k_traj_pass1<false, false><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half);
+            const int nblk8 = (int)(pl.npad / (TO_BLOCK * TO_PD));
+            const int nb = dense_blocks(nblk8, (int)V, occ);
+            if (occ) k_traj_pass1_dense<true><<<nb, TO_BLOCK, 0, st>>>(cv, rec, (int)V, nblk8, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half, clock_stamps());
+            else k_traj_pass1_dense<false><<<nb, TO_BLOCK, 0, st>>>(cv, rec, (int)V, nblk8, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half, clock_stamps());
         }
         TO_HIP_CHECK_LAUNCH();
     }
@@ -1190,4 +1251,19 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, int64_t W, con
         TO_HIP_CHECK_LAUNCH();
     }
     return TOHIP_OK;
+}
+
+// Diagnostic (bench.py's roofline leg, never on in a timed pass): k_traj_pass1 stamps s_memtime / s_memrealtime per block into
+// `buffer` (16 bytes per block; capacity for grid.x * grid.y blocks: tohip_profile_clock_blocks) while it is set; NULL turns it off.
+// The in-kernel clock is d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).
+extern "C" int tohip_profile_clock(void* buffer) {
+    clock_stamps() = (unsigned long long*)buffer;
+    return TOHIP_OK;
+}
+extern "C" int64_t tohip_profile_clock_blocks(int64_t n_points, int64_t n_virtual, int flags) {
+    if (n_points <= 0 || n_virtual <= 0 || !(flags & TOHIP_TRAJ_DENSE)) return 0;   // only the dense kernel stamps
+    const TrajPlan pl = make_plan(n_points, n_virtual, n_virtual);
+    const int nblk8 = (int)(pl.npad / (TO_BLOCK * TO_PD));
+    return dense_blocks(nblk8, (int)n_virtual, true) > dense_blocks(nblk8, (int)n_virtual, false)
+               ? dense_blocks(nblk8, (int)n_virtual, true) : dense_blocks(nblk8, (int)n_virtual, false);
 }
