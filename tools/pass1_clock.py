@@ -3,7 +3,7 @@ import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trajectory_optimization_amd import synth, ops, _lib
 dev = torch.device("cuda:0")
-n, w = 1_000_000, 128
+n, w = int(os.environ.get('N', 1_000_000)), int(os.environ.get('W', 128))
 pts = synth.make_cloud(n, seed=0)
 poses, quats = synth.make_path(w, optical=True)
 cloud = ops.PackedCloud(torch.from_numpy(pts).to(dev))

@@ -318,6 +318,11 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
     const int64_t total = (int64_t)nblk * V;
     int64_t u = total * blockIdx.x / gridDim.x;
     const int64_t u_end = total * (blockIdx.x + 1) / gridDim.x;
+    // The SIMD arbiter serves its waves oldest first, so equal pieces do not end together: the old waves race ahead, retire, and
+    // the last wave of a SIMD finishes alone at ~70 % of the issue rate.  Priority outranks age: a wave steps its priority down
+    // as it completes quarters of its piece, so whoever is behind is served first and all waves stay within a quarter of each other.
+    const int64_t q1 = u + (u_end - u) / 4, q2 = u + (u_end - u) / 2, q3 = u + 3 * (u_end - u) / 4;
+    __builtin_amdgcn_s_setprio(3);
     while (u < u_end) {
         const int pb = (int)(u / V);
         const int v0 = (int)(u - (int64_t)pb * V);
@@ -329,6 +334,10 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
         load_points<P>(cv.soa, cv.npad, base, x, y, z);
         if (v0 == 0) { init_outputs(base, cv.n, lo_zero, rewards_half); init_outputs(base + 4, cv.n, lo_zero, rewards_half); }
         for (int v = v0; v < v1; ++v) {
+            const int64_t uu = u + (v - v0);
+            if (uu == q1) __builtin_amdgcn_s_setprio(2);
+            if (uu == q2) __builtin_amdgcn_s_setprio(1);
+            if (uu == q3) __builtin_amdgcn_s_setprio(0);
             const WayRec& r = rec[v];
             float om[P];
             load_occ<P, OCC>(occ, occw, v, base, om);
@@ -1092,8 +1101,12 @@ inline int dense_blocks(int nblk, int V, bool occ) {
         int a = 0, b = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_traj_pass1_dense<false>, TO_BLOCK, 0) != hipSuccess || a <= 0) a = 4;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_traj_pass1_dense<true>, TO_BLOCK, 0) != hipSuccess || b <= 0) b = 4;
-        per_cu[0] = a > 8 ? 8 : a;
-        per_cu[1] = b > 8 ? 8 : b;
+        // the API answers one block per CU too many at this kernel's SGPR count (82-96; measured: 6 resident where it says 7,
+        // MI355X_MICROARCH.md "Residency"); a block that is not resident from the start would run alone at the end
+        per_cu[0] = (a > 8 ? 8 : a) - 1;
+        per_cu[1] = (b > 8 ? 8 : b) - 1;
+        if (per_cu[0] < 1) per_cu[0] = 1;
+        if (per_cu[1] < 1) per_cu[1] = 1;
     }
     int64_t nb = forced > 0 ? forced : (int64_t)per_cu[occ ? 1 : 0] * cus;
     const int64_t total = (int64_t)nblk * V;
