@@ -136,6 +136,8 @@ def main():
                     help="cameras per waypoint (BASELINE.json configs[4]: 5, with --wps-per-gpu 32); each (camera, "
                          "waypoint) pair is one virtual waypoint with its own min-max normalisation")
     ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--dump", default=None, help="write the last dense step's outputs (scalars, gradient rows, rewards) to this .npz "
+                                                 "(rank 0): tests compare runs at different N")
     args = ap.parse_args()
 
     from trajectory_optimization_amd import _lib, ops
@@ -163,7 +165,8 @@ def main():
     rig = ops.CameraRig(*synth.camera_rig(args.cameras), device) if args.cameras > 1 else None
     ws = ops.TrajWorkspace(cloud, n_virtual)
     gout = torch.ones(1, device=device)
-    shard = WaypointShard() if n_gpus > 1 else None
+    forced = os.environ.get("TOHIP_DIST_FORCE_INIT") == "1"   # one-rank process group: the RCCL calls of the N>1 step on one GPU
+    shard = WaypointShard(force_collectives=forced) if (n_gpus > 1 or forced) else None
 
     if shard is not None:
         # communicator set-up (RCCL rings over xGMI) happens on the first collective of each kind: keep it out of the timed
@@ -185,7 +188,7 @@ def main():
         return scalars, pg, qg, rewards
 
     def fence():
-        if n_gpus > 1:
+        if n_gpus > 1 or forced:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -204,7 +207,7 @@ def main():
             o = step(flags)
         fence()
         dt = time.perf_counter() - t0
-        if n_gpus > 1:
+        if n_gpus > 1 or forced:
             t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -235,6 +238,8 @@ def main():
     evals_per_step = args.points * w_total * args.cameras
     value = evals_per_step * args.steps / dt
 
+    if rank == 0 and args.dump:
+        np.savez(args.dump, scalars=out[0].cpu().numpy(), pg=out[1].cpu().numpy(), qg=out[2].cpu().numpy(), rewards=out[3].cpu().numpy())
     if rank == 0:
         # dominant kernel: pass 1, the one launch that evaluates every pair.  VALU-issue roofline (module docstring).
         mix = isa_mix()
@@ -295,7 +300,7 @@ def main():
                 "note": "the reference ITSELF (torch CPU, fwd+bwd, 1 M x 16) timed in the build container — it cannot travel to the "
                         "GPU box; profiles/r01_reference_cpu_timing.txt"}
         print(json.dumps(line), flush=True)
-    if n_gpus > 1:
+    if n_gpus > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

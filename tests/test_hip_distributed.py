@@ -76,3 +76,61 @@ def test_sharded_model_equals_single_process(tmp_path):
     np.testing.assert_allclose(r0["opt_losses"], res.losses, rtol=2e-5)
     np.testing.assert_allclose(r0["opt_poses"], m2.poses.detach().cpu().numpy(), atol=2e-4)
     np.testing.assert_allclose(r0["opt_quats"], m2.quats.detach().cpu().numpy(), atol=2e-4)
+
+
+# ---- bench.py's own N>1 step (the code the driver's 8-GPU run executes), rehearsed on the one GPU of the test box ------------
+
+def _run(cmd, env_extra, timeout=600):
+    import subprocess
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n---\n" + r.stderr[-3000:]
+    return r.stdout
+
+
+_BENCH_COMMON = ["--points", "200000", "--steps", "2", "--warmup", "1", "--cpu-wps", "0", "--mode", "dense"]
+
+
+@pytest.fixture(scope="module")
+def bench_one_rank(tmp_path_factory):
+    import json
+    d = tmp_path_factory.mktemp("bench")
+    out = _run([sys.executable, "bench.py", "--gpus", "1", "--wps-per-gpu", "64", "--dump", str(d / "n1.npz")] + _BENCH_COMMON, {})
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["roofline"]["bound"] == "valu" and 0.0 < line["roofline"]["frac"] <= 1.0
+    return np.load(d / "n1.npz")
+
+
+def test_bench_step_two_ranks_equal_one_rank(bench_one_rank, tmp_path):
+    """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` (gloo rendezvous, both ranks on the one GPU, host-staged
+    collectives): waypoint shards of 32 + 32, ONE all-reduce of the log-odds vector, all-gather of the (W,7) gradient rows —
+    the step's outputs equal the single-rank run over the same 64 waypoints."""
+    import json
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--wps-per-gpu", "32", "--dump", str(tmp_path / "n2.npz")]
+               + _BENCH_COMMON, {"TOHIP_DIST_BACKEND": "gloo"})
+    line = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["waypoints_total"] == 64 and line["scaling"] == "weak"
+    a, b = bench_one_rank, np.load(tmp_path / "n2.npz")
+    # the two shards' log-odds are added in a different association than the single run's: 1e-6-level differences
+    np.testing.assert_allclose(b["rewards"], a["rewards"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(b["scalars"][:2], a["scalars"][:2], rtol=2e-6)
+    assert b["pg"].shape == a["pg"].shape == (64, 3) and b["qg"].shape == (64, 4)
+    assert np.abs(b["pg"] - a["pg"]).max() <= 2e-5 * np.abs(a["pg"]).max()
+    assert np.abs(b["qg"] - a["qg"]).max() <= 2e-5 * np.abs(a["qg"]).max()
+
+
+def test_bench_step_through_rccl_on_one_rank(bench_one_rank, tmp_path):
+    """The same step with a ONE-rank `nccl` process group (TOHIP_DIST_FORCE_INIT): init_process_group(device_id=...), the
+    all-reduce of the log-odds vector and the all-gather of the gradient rows all go through RCCL on the GPU — the calls the
+    8-GPU run makes — and the outputs are the single-process ones to the bit."""
+    import json
+    out = _run([sys.executable, "bench.py", "--gpus", "1", "--wps-per-gpu", "64", "--dump", str(tmp_path / "rccl.npz")] + _BENCH_COMMON,
+               {"TOHIP_DIST_FORCE_INIT": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(_free_port())})
+    line = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1
+    a, b = bench_one_rank, np.load(tmp_path / "rccl.npz")
+    for k in ("scalars", "pg", "qg", "rewards"):
+        assert np.array_equal(a[k], b[k]), k

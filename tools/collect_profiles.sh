@@ -4,7 +4,7 @@
 #   (FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ_* in a third), as MI355X_MICROARCH.md prescribes.
 # Afterwards, here:  python tools/summarize_profiles.py gpurun_out/prof_<tag> rNN   -> profiles/rNN_*
 set -euo pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"

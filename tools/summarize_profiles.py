@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 output of tools/collect_profiles.sh into the committed summaries:
-    python tools/summarize_profiles.py gpurun_out/prof_r01 r01
- -> profiles/r01_bench_{dense,culled}_kernel_stats.csv, profiles/r01_hpr_batched_kernel_stats.csv (copies) and
-    profiles/r01_bench_dense_pmc.json: per kernel, HBM bytes per launch = 2 x FETCH_SIZE (gfx950 counts a wide coalesced read
+    python tools/summarize_profiles.py gpurun_out/prof_r02 r02
+ -> profiles/rNN_bench_{dense,culled}_kernel_stats.csv, profiles/rNN_hpr_batched_kernel_stats.csv (copies) and
+    profiles/rNN_bench_dense_pmc.json: per kernel, HBM bytes per launch = 2 x FETCH_SIZE (gfx950 counts a wide coalesced read
     at half its bytes, MI355X_MICROARCH.md) + WRITE_SIZE, both reported in KB, and the VALU busy fraction
     SQ_ACTIVE_INST_VALU / (32 x GRBM_GUI_ACTIVE)."""
 import collections
@@ -61,9 +61,13 @@ def main():
         if "FETCH_SIZE_mean_per_launch" in e and "WRITE_SIZE_mean_per_launch" in e:
             e["hbm_bytes_per_launch_corrected"] = (2.0 * e["FETCH_SIZE_mean_per_launch"] + e["WRITE_SIZE_mean_per_launch"]) * 1024.0
         if "SQ_ACTIVE_INST_VALU_mean_per_launch" in e and e.get("GRBM_GUI_ACTIVE_mean_per_launch"):
-            # SQ_ACTIVE_INST_VALU is summed over the 32 SQ counter instances (8 XCDs x 4 shader engines); GRBM_GUI_ACTIVE is
-            # the kernel's busy cycles: fraction of cycles in which VALU work is in flight, averaged over those instances
+            # SQ_ACTIVE_INST_VALU counts quad-cycles of VALU issue summed over the chip (x4 = SIMD cycles spent issuing vector
+            # instructions: it equals the ISA-derived count, 4 cycles per packed/other, 8 per transcendental instruction);
+            # GRBM_GUI_ACTIVE is the kernel's busy cycles summed over the 8 XCDs; 1024 SIMDs:
+            #   busy = 4 * ACTIVE / (1024 * GUI / 8) = ACTIVE / (32 * GUI)
+            e["valu_issue_cycles_per_launch"] = 4.0 * e["SQ_ACTIVE_INST_VALU_mean_per_launch"]
             e["valu_busy_fraction"] = e["SQ_ACTIVE_INST_VALU_mean_per_launch"] / (32.0 * e["GRBM_GUI_ACTIVE_mean_per_launch"])
+            e["clock_ghz_from_grbm"] = e["GRBM_GUI_ACTIVE_mean_per_launch"] / 8.0 / e["duration_ns_mean_pmc_sq"]
     with open(os.path.join(dst, f"{tag}_bench_dense_pmc.json"), "w") as f:
         json.dump(out, f, indent=1)
     for k, e in ks.items():

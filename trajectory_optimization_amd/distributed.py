@@ -16,12 +16,14 @@ import torch.distributed as dist
 
 
 class WaypointShard:
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, force_collectives=False):
+        """force_collectives: issue the collectives even in a one-rank group (a rehearsal of the RCCL calls on one GPU)."""
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = process_group
         self.world_size = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
+        self._always = bool(force_collectives)
 
     def bounds(self, n_wps, rank=None):
         """Contiguous, balanced range [lo, hi) of the n_wps evaluated waypoints owned by `rank`."""
@@ -31,7 +33,7 @@ class WaypointShard:
         return lo, lo + base + (1 if r < rem else 0)
 
     def allreduce_sum(self, t):
-        if self.world_size > 1:
+        if self.world_size > 1 or self._always:
             if t.is_cuda and dist.get_backend(self.group) == "gloo":
                 # rehearsal setups (several ranks on one GPU, gloo): stage through the host; RCCL reduces in place
                 h = t.detach().cpu()
@@ -44,9 +46,8 @@ class WaypointShard:
 
     def allreduce_sum_async(self, t):
         """Starts the in-place sum of `t` and returns a handle whose wait() makes the CURRENT stream wait for it (RCCL
-        runs the collective on its own stream): kernels enqueued in between that do not touch `t` overlap with it —
-        the dense backward's scan half (ops.traj_backward_scan) is independent of the log-odds vector being reduced."""
-        if self.world_size > 1 and not (t.is_cuda and dist.get_backend(self.group) == "gloo"):
+        runs the collective on its own stream): kernels enqueued in between that do not touch `t` overlap with it."""
+        if (self.world_size > 1 or self._always) and not (t.is_cuda and dist.get_backend(self.group) == "gloo"):
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.allreduce_sum(t)  # single rank, or the host-staged rehearsal path: nothing left in flight
 
@@ -58,7 +59,7 @@ class WaypointShard:
     def allgather_rows(self, t):
         """Concatenate every rank's (rows, k) block in rank order (equal row counts): the per-waypoint gradient
         rows of a contiguous shard -> the whole trajectory's, on every rank."""
-        if self.world_size == 1:
+        if self.world_size == 1 and not self._always:
             return t
         staged = t.is_cuda and dist.get_backend(self.group) == "gloo"
         src = t.detach().cpu() if staged else t.contiguous()
@@ -67,9 +68,10 @@ class WaypointShard:
         return out.to(t.device) if staged else out
 
 
-def init_from_env(backend=None, use_gpu=None):
+def init_from_env(backend=None, use_gpu=None, force=False):
     """Initialise torch.distributed from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torchrun contract) and bind
-    this process to its GPU (use_gpu=False: stay on the CPU, e.g. the gloo tests).  Returns (rank, world_size, device)."""
+    this process to its GPU (use_gpu=False: stay on the CPU, e.g. the gloo tests).  Returns (rank, world_size, device).
+    force (or TOHIP_DIST_FORCE_INIT=1): create the process group even for one rank — the RCCL rehearsal on a single GPU."""
     import os
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,7 +83,8 @@ def init_from_env(backend=None, use_gpu=None):
     device = torch.device(f"cuda:{local}") if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    force = force or os.environ.get("TOHIP_DIST_FORCE_INIT") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if use_gpu else "gloo")
