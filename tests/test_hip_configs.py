@@ -35,7 +35,7 @@ def test_config1_100k_x32_forward_only(dev):
         lo, mm = ops.traj_forward(cloud, p, q, cam, ws)
         r, sc = ops.traj_reward(cloud, lo, cam, ws)
     f = oracle.traj_forward(pts, poses, quats, K, IW, IH, prec="f64")
-    np.testing.assert_allclose(r.cpu().numpy(), f["rewards"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(r.cpu().numpy(), f["rewards"], rtol=1e-5, atol=0)
     assert abs(sc[1].item() - f["loss_vis"]) <= 3e-6 * f["loss_vis"]
 
 
@@ -62,7 +62,7 @@ def test_config3_1m_x1024_sharded_over_8(dev):
     lo_s, _ = ops.traj_forward(cloud, p[sel].contiguous(), q[sel].contiguous(), cam, ops.TrajWorkspace(cloud, len(sel)))
     r_s, _ = ops.traj_reward(cloud, lo_s, cam, ws)
     f = oracle.traj_forward(pts, poses[sel], quats[sel], K, IW, IH, prec="f64")
-    np.testing.assert_allclose(r_s.cpu().numpy(), f["rewards"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(r_s.cpu().numpy(), f["rewards"], rtol=1e-5, atol=0)
 
 
 def test_config4_five_cameras_1m_x256(dev):
@@ -94,3 +94,28 @@ def test_config4_five_cameras_1m_x256(dev):
     assert np.isfinite(pg.cpu().numpy()).all() and np.abs(pg.cpu().numpy()).max() > 0
     dots = (quats.astype(np.float64) * qg.cpu().numpy()).sum(1)
     assert np.abs(dots).max() <= 1e-5 * np.abs(qg.cpu().numpy()).max()
+    # the f64 oracle on the explicit 1280 virtual waypoints at the full size: rewards, loss, and the body-pose gradients through
+    # the chain rule of the rig composition (autograd in f64 over q_v = q_w/|q_w| (x) q_c, t_v = t_w + R(q_w) l_c)
+    from oracle import oracle
+    f = oracle.traj_forward(pts, vt, vq, K, IW, IH, prec="f64")
+    rew_err = float(np.abs(r.cpu().numpy() - f["rewards"]).max() / 0.5)
+    print(f"config 4 vs f64 oracle: rewards max rel err {rew_err:.2e}")
+    np.testing.assert_allclose(r.cpu().numpy(), f["rewards"], rtol=1e-5, atol=0)
+    g_vt, g_vq = oracle.traj_backward(pts, vt, vq, K, IW, IH, f, prec="f64")
+    P = torch.tensor(poses, dtype=torch.float64, requires_grad=True)
+    Q = torch.tensor(quats, dtype=torch.float64, requires_grad=True)
+    Qn = Q / Q.norm(dim=1, keepdim=True)
+    rqt = torch.tensor(rq, dtype=torch.float64)
+
+    def qmul(a, b):
+        aw, ax, ay, az = a.unbind(-1)
+        bw, bx, by, bz = b.unbind(-1)
+        return torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                            aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], -1)
+    VQ = qmul(Qn[:, None, :], rqt[None]).reshape(-1, 4)
+    VT = P[:, None, :].expand(-1, 5, -1).reshape(-1, 3)   # zero lever arms
+    ((VT * torch.tensor(g_vt)).sum() + (VQ * torch.tensor(g_vq)).sum()).backward()
+    from conftest import rel_inf
+    print(f"config 4 body gradients vs oracle chain rule: poses {rel_inf(pg.cpu().numpy(), P.grad.numpy()):.2e}, "
+          f"quats {rel_inf(qg.cpu().numpy(), Q.grad.numpy()):.2e}")
+    assert rel_inf(pg.cpu().numpy(), P.grad.numpy()) < 1e-5 and rel_inf(qg.cpu().numpy(), Q.grad.numpy()) < 1e-5

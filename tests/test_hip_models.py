@@ -441,3 +441,118 @@ def test_dense_model_equals_the_default_model(dev):
         a, b = out[fused_idx], out[2 + fused_idx]
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+def test_occlusion_with_a_rig_equals_explicit_virtual_waypoints(dev):
+    """ModelTraj(rig=..., occlusion='hpr'): each (waypoint, camera) pair gets its own occlusion row, built at the camera's own
+    pose.  Equal to a rig-less model whose waypoints are the cameras written out (same rows, same rewards)."""
+    from trajectory_optimization_amd.model import ModelTraj
+    pts = synth.make_cloud(50_000, seed=23)
+    poses, quats = synth.make_path(4, optical=True, jitter_seed=23)
+    rq, rt = synth.camera_rig(3)
+    rt = rt + np.array([[0.1, 0.0, 0.2], [0.0, 0.15, 0.2], [-0.1, 0.0, 0.25]], dtype=np.float32)
+    m = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(K), IW, IH,
+                  device=dev, rig=(rq, rt), occlusion="hpr")
+    loss = m(vis_wps_dist=0.0)
+    loss.backward()
+    assert bool(torch.isfinite(m.poses.grad).all()) and float(m.poses.grad.abs().max()) > 0
+    # explicit virtual waypoints on the host (f64), unit quaternions
+    qn = quats.astype(np.float64) / np.linalg.norm(quats.astype(np.float64), axis=1, keepdims=True)
+    vq = synth.quat_mul(qn[:, None, :], rq[None].astype(np.float64)).reshape(-1, 4)
+    w, x, y, z = qn.T
+    R = np.stack([w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+                  w * w - x * x + y * y - z * z, 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+                  w * w - x * x - y * y + z * z], -1).reshape(-1, 3, 3)
+    vt = (poses.astype(np.float64)[:, None, :] + np.einsum("wij,cj->wci", R, rt.astype(np.float64))).reshape(-1, 3)
+    mv = ModelTraj(torch.from_numpy(pts), torch.from_numpy(vt.astype(np.float32)), torch.from_numpy(vq.astype(np.float32)),
+                   torch.from_numpy(K), IW, IH, device=dev, occlusion="hpr")
+    mv(vis_wps_dist=0.0)
+    np.testing.assert_allclose(m.rewards.detach().cpu().numpy(), mv.rewards.detach().cpu().numpy(), rtol=2e-5, atol=0)
+    # occlusion changes something: the unoccluded rig model sees more
+    m0 = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(K), IW, IH,
+                   device=dev, rig=(rq, rt))
+    m0(vis_wps_dist=0.0)
+    assert m.rewards.mean().item() < m0.rewards.mean().item()
+
+
+def test_occlusion_pad_bits_follow_the_last_sorted_point(dev):
+    """The packed cloud is padded with copies of its last sorted point.  When that point is hidden for a waypoint, its copies
+    must be hidden too (an occlusion row's pad bits repeat the bit of position n-1) — otherwise a hidden point's p could
+    still win the waypoint's max through a pad.  N is not a multiple of the padding; the last sorted point is forced to be the
+    cloud's best-seen point and is marked occluded by hand."""
+    from oracle import oracle
+    from trajectory_optimization_amd import ops
+    n = 5_003
+    pts = synth.make_cloud(n, seed=29)
+    poses, quats = synth.make_path(3, optical=True, jitter_seed=29)
+    cloud = ops.PackedCloud(torch.from_numpy(pts).to(dev))
+    cam = ops.Camera(K, IW, IH)
+    p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
+    perm = cloud.perm.cpu().numpy()
+    last = int(perm[n - 1])                                   # caller's index of the last sorted point
+    # move that point to where waypoint 0 sees best: it becomes the argmax of waypoint 0
+    p0 = oracle.pose_forward(pts, poses[0], quats[0], K, IW, IH, prec="f64")[0]
+    pts2 = pts.copy()
+    pts2[last] = pts[int(np.argmax(p0))] + np.float32(1e-3)
+    cloud = ops.PackedCloud(torch.from_numpy(pts2).to(dev), sort=False)   # caller's order kept: `last` stays last only if it is
+    # unsorted packing keeps the caller's order, so put the special point at the end
+    order = np.r_[np.delete(np.arange(n), last), last]
+    pts3 = pts2[order]
+    cloud = ops.PackedCloud(torch.from_numpy(pts3).to(dev), sort=False)
+    # occlusion rows through the library's own builder: kept = everything, visible = everything but the last point (waypoint 0)
+    npad = cloud.npad
+    rows = torch.empty((3, npad // 32), dtype=torch.int32, device=dev)
+    kept = torch.arange(n, dtype=torch.int32, device=dev).repeat(3, 1).contiguous()
+    kcnt = torch.full((3,), n, dtype=torch.int32, device=dev)
+    vis_lists = [torch.arange(n - 1, dtype=torch.int32, device=dev), torch.arange(n, dtype=torch.int32, device=dev),
+                 torch.arange(n, dtype=torch.int32, device=dev)]
+    vis_off = torch.tensor([0, n - 1, 2 * n - 1, 3 * n - 1], dtype=torch.int32, device=dev)
+    allv = torch.zeros(3, dtype=torch.int32, device=dev)
+    from trajectory_optimization_amd._lib import check, lib, ptr, stream_ptr
+    check(lib().tohip_occlusion_rows(n, ptr(cloud.inv_perm), ptr(kept), ptr(kcnt), ptr(torch.cat(vis_lists)), ptr(vis_off), ptr(allv), 3,
+                                     ptr(rows), stream_ptr()), "rows")
+    bits = ((rows.cpu().numpy().view(np.uint32)[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(3, -1)
+    assert bits[0, n - 1] == 0 and not bits[0, n:].any()        # pads of row 0 are hidden like the point they copy
+    assert bits[1, n - 1] == 1 and bits[1, n:].all()
+    ws = ops.TrajWorkspace(cloud, 3)
+    for flags in (0, ops.DENSE):
+        lo, mm = ops.traj_forward(cloud, p, q, cam, ws, flags=flags, occ=rows)
+        rew, sc = ops.traj_reward(cloud, lo, cam, ws)
+        occ = np.ones((3, n), np.float32)
+        occ[0, n - 1] = 0.0
+        f = oracle.traj_forward(pts3, poses, quats, K, IW, IH, prec="f64", occ=occ)
+        np.testing.assert_allclose(mm.cpu().numpy()[:, 1], f["pmax"] - f["pmin"], rtol=1e-5)   # the hidden point did not set the max
+        np.testing.assert_allclose(rew.cpu().numpy(), f["rewards"], rtol=1e-5, atol=0)
+
+
+def test_xy_yaw_gradient_matches_finite_differences(dev):
+    """tools.xy_yaw_gradient: (dL/dx, dL/dy, dL/dyaw) from poses.grad / quats.grad, against central differences of the f64
+    oracle's visibility loss under a planar move and a turn about the world z axis."""
+    from oracle import oracle
+    from trajectory_optimization_amd.model import ModelTraj
+    from trajectory_optimization_amd.tools import xy_yaw_gradient
+    pts = synth.make_cloud(40_000, seed=33)
+    poses, quats = synth.make_path(5, optical=True, jitter_seed=33)
+    m = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(K), IW, IH, device=dev)
+    m(vis_wps_dist=0.0)
+    m.loss["vis"].backward()
+    g = xy_yaw_gradient(m.poses.grad, m.quats.data, m.quats.grad).cpu().numpy()
+    assert g.shape == (5, 3)
+
+    def loss(P, Q):
+        return oracle.traj_forward(pts, P, Q, K, IW, IH, prec="f64")["loss_vis"]
+    h = 2e-3
+    for wi in (0, 2, 4):
+        for ci in (0, 1):
+            Pp, Pm = poses.astype(np.float64).copy(), poses.astype(np.float64).copy()
+            Pp[wi, ci] += h
+            Pm[wi, ci] -= h
+            fd = (loss(Pp.astype(np.float32), quats) - loss(Pm.astype(np.float32), quats)) / (2 * h)
+            assert abs(g[wi, ci] - fd) <= 0.03 * np.abs(g[:, :2]).max() + 1e-7
+        def turned(a):
+            r = np.array([np.cos(a / 2), 0, 0, np.sin(a / 2)])
+            Q = quats.astype(np.float64).copy()
+            Q[wi] = synth.quat_mul(r, Q[wi])
+            return Q.astype(np.float32)
+        fd = (loss(poses, turned(h)) - loss(poses, turned(-h))) / (2 * h)
+        assert abs(g[wi, 2] - fd) <= 0.03 * np.abs(g[:, 2]).max() + 1e-7

@@ -412,8 +412,6 @@ class ModelTraj(nn.Module):
         self._flags = ops.DENSE if dense else 0  # dense: evaluate every pair (results are bitwise the same)
         if occlusion not in (None, "hpr", "zbuffer"):
             raise ValueError("occlusion must be None, 'hpr' or 'zbuffer'")
-        if occlusion is not None and rig is not None:
-            raise NotImplementedError("per-waypoint occlusion with a camera rig")
         self._occlusion, self._occlusion_limits = occlusion, occlusion_limits
         self._ws_cache = {}
         self._wps_step_cache = {}
@@ -423,7 +421,21 @@ class ModelTraj(nn.Module):
         self.fused_loss = True
 
     def _occlusion_rows(self, ps, qs):
-        """Occlusion bit rows of the given body waypoints (one row per virtual waypoint)."""
+        """Occlusion bit rows of the given body waypoints, one row per virtual waypoint v = w*C + c (with a rig: the cameras'
+        own poses t_v = t_w + R(q_w) l_c, q_v = q_w/|q_w| (x) q_c — the composition the kernels apply)."""
+        if self._rig is not None:
+            qn = qs / qs.norm(dim=1, keepdim=True).clamp_min(1e-12)
+            qc, lc = self._rig.q, self._rig.t
+            aw, ax, ay, az = qn[:, None, :].unbind(-1)
+            bw, bx, by, bz = qc[None, :, :].unbind(-1)
+            vq = torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                              aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], -1).reshape(-1, 4)
+            w, x, y, z = qn.unbind(-1)
+            R = torch.stack([w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y),
+                             2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x),
+                             2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z], -1).reshape(-1, 3, 3)
+            vt = (ps[:, None, :] + torch.einsum("wij,cj->wci", R, lc)).reshape(-1, 3)
+            ps, qs = vt.contiguous(), vq.contiguous()
         return ops.occlusion_bits(self._cloud, self.points, ps, qs, self._cam, self._occlusion_limits[0],
                                   self._occlusion_limits[1], self._occlusion)
 

@@ -68,8 +68,7 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
         p_loc, q_loc = poses_e[lo_e:hi_e], quats_e[lo_e:hi_e]  # contiguous row ranges of the compact arrays
         occ = None
         if occluded and n_loc > 0:
-            occ = ops.occlusion_bits(cloud, model.points, p_loc, q_loc, cam, model._occlusion_limits[0],
-                                     model._occlusion_limits[1], model._occlusion)
+            occ = model._occlusion_rows(p_loc, q_loc)
         if n_loc > 0:
             check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref,
                                        model._flags, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(ws.buf), ws.bytes, s),

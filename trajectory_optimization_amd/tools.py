@@ -139,3 +139,17 @@ def visible_points_from_cameras(points, trans, quats, intrins, img_height, img_w
         r["visible_idx"] = (idx[int(voff[c]):int(voff[c + 1])] - offs[c]).contiguous()
         r["visible_points"] = r["kept_points"][r["visible_idx"].long()]
     return out
+
+
+def xy_yaw_gradient(poses_grad, quats, quats_grad):
+    """(dL/dx, dL/dy, dL/dyaw) per waypoint from the gradients the models produce (`model.poses.grad`, `model.quats.grad`):
+    the planar parametrisation of a ground robot's waypoint.  Yaw turns the waypoint about the world z axis,
+    q(yaw) = r_z(yaw) (x) q, so dq/dyaw = 1/2 (0,0,0,1) (x) q = 1/2 (-z, -y, x, w) for q = (w, x, y, z) and
+    dL/dyaw = <dL/dq, dq/dyaw>.  `quats` are the models' raw quaternions (they are normalised inside the kernels; the
+    gradient w.r.t. the raw quaternion is what autograd returns).  -> (W, 3) tensor."""
+    q = torch.as_tensor(quats).detach()
+    gq = torch.as_tensor(quats_grad).detach()
+    gp = torch.as_tensor(poses_grad).detach()
+    w, x, y, z = q.unbind(-1)
+    dq = 0.5 * torch.stack([-z, -y, x, w], dim=-1)
+    return torch.cat([gp[..., :2], (gq * dq).sum(-1, keepdim=True)], dim=-1)
