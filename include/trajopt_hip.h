@@ -159,6 +159,15 @@ int tohip_to_camera_frame(const float *xyz, int64_t n_points, const float *quat,
 /* get_dist_mask (model.py:13-24) and soft get_fov_mask (model.py:27-47) on (N,3) camera-frame points. */
 int tohip_soft_masks(const float *cam_xyz, int64_t n_points, const tohip_camera *cam_host, float *dist_mask,
                      float *fov_mask, void *stream);
+/* Their backward passes (the reference's helpers are plain torch ops, differentiable by autograd):
+ * grad_xyz (N,3) = grad_dist[n] dD/dp + grad_fov[n] dF/dp (either upstream gradient may be NULL = zero);
+ * to_camera_frame: grad_xyz (N,3, may be NULL) = R grad_out, grad_quat (4) w.r.t. the raw quaternion (through F.normalize),
+ * grad_trans (3); workspace of tohip_pose_workspace_bytes bytes. */
+int tohip_soft_masks_backward(const float *cam_xyz, int64_t n_points, const tohip_camera *cam_host, const float *grad_dist,
+                              const float *grad_fov, float *grad_xyz, void *stream);
+int tohip_to_camera_frame_backward(const float *xyz, int64_t n_points, const float *quat, const float *trans,
+                                   const float *grad_out, float *grad_xyz, float *grad_quat, float *grad_trans,
+                                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- hard frustum cull (tools.py:176-187, pc_processor.py:72-83, model.py:34-39) -------------- */
 size_t tohip_frustum_workspace_bytes(int64_t n_points);

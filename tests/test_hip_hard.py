@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, rel_inf
 from trajectory_optimization_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -76,3 +76,58 @@ def test_spherical_flip_bit_exact(dev):
         g = load_golden(name)
         fl = sphericalFlip(torch.from_numpy(g["points"]), dev, 2)
         assert np.array_equal(fl[:64].cpu().numpy(), g["flipped_head"])
+
+
+def test_helper_functions_are_differentiable_like_the_reference(dev):
+    """The reference's get_dist_mask / get_fov_mask / to_camera_frame are plain torch ops, so autograd differentiates through
+    them (model.py:13-57).  Here they are HIP kernels with HIP backward kernels: gradients w.r.t. the points, the raw
+    quaternion and the translation against a float64 torch restatement of the same formulas, composed the way ModelPose
+    composes them (loss = sum w * dist_mask * fov_mask of the camera-frame points)."""
+    from trajectory_optimization_amd.model import get_dist_mask, get_fov_mask, to_camera_frame
+    g = torch.Generator().manual_seed(5)
+    n = 20_000
+    pts = (torch.rand(n, 3, generator=g) * torch.tensor([12.0, 12.0, 4.0]) - torch.tensor([6.0, 6.0, 2.0]))
+    quat = torch.tensor([[0.9, 0.1, -0.3, 0.25]]) * 1.7     # not normalised: exercises F.normalize
+    trans = torch.tensor([[0.5, -1.0, 0.2]])
+    w = torch.rand(n, generator=g)
+    Kt = torch.from_numpy(K)
+
+    def ref(verts, q, t):
+        qn = q / q.norm()
+        ww, x, y, z = qn[0]
+        R = torch.stack([ww * ww + x * x - y * y - z * z, 2 * (x * y - ww * z), 2 * (x * z + ww * y),
+                         2 * (x * y + ww * z), ww * ww - x * x + y * y - z * z, 2 * (y * z - ww * x),
+                         2 * (x * z - ww * y), 2 * (y * z + ww * x), ww * ww - x * x - y * y + z * z]).reshape(3, 3)
+        c = (verts - t) @ R                                  # c = R^T (x - t)
+        mean, std = 3.0, 2.0
+        D = torch.exp(-0.5 * (((c - mean).norm(dim=1)) / std) ** 2)
+        h = c @ Kt.double().T
+        S = torch.sigmoid(h[:, 2])
+        Gw = torch.exp(-0.5 * ((h[:, 0] / (h[:, 2] + 1e-6) - IW / 2) / IW) ** 2)
+        Gh = torch.exp(-0.5 * ((h[:, 1] / (h[:, 2] + 1e-6) - IH / 2) / IH) ** 2)
+        return c, D, S * Gw * Gh
+
+    V64 = pts.double().requires_grad_(True); Q64 = quat.double().requires_grad_(True); T64 = trans.double().requires_grad_(True)
+    c64, D64, F64 = ref(V64, Q64, T64)
+    (w.double() * D64 * F64).sum().backward()
+
+    V = pts.to(dev).requires_grad_(True); Q = quat.to(dev).requires_grad_(True); T = trans.to(dev).requires_grad_(True)
+    c = to_camera_frame(V, Q, T)
+    D = get_dist_mask(c, 1.0, 5.0)
+    F = get_fov_mask(c, IH, IW, Kt.to(dev))
+    np.testing.assert_allclose(c.detach().cpu().numpy(), c64.detach().numpy(), rtol=0, atol=5e-6)
+    np.testing.assert_allclose((D * F).detach().cpu().numpy(), (D64 * F64).detach().numpy(), rtol=3e-5, atol=1e-12)
+    (w.to(dev) * D * F).sum().backward()
+    assert rel_inf(V.grad.cpu().numpy(), V64.grad.numpy()) < 1e-4
+    assert rel_inf(Q.grad.cpu().numpy(), Q64.grad.numpy()) < 1e-4
+    assert rel_inf(T.grad.cpu().numpy(), T64.grad.numpy()) < 1e-4
+    assert abs(float((Q.grad.cpu().double() * quat.double()).sum())) <= 1e-5 * float(Q.grad.abs().max())   # tangent to the sphere
+    # each helper alone, and the non-differentiable corners
+    c2 = c.detach().requires_grad_(True)
+    get_dist_mask(c2).sum().backward()
+    cc = c64.detach().requires_grad_(True)
+    torch.exp(-0.5 * (((cc - 3.0).norm(dim=1)) / 2.0) ** 2).sum().backward()
+    assert rel_inf(c2.grad.cpu().numpy(), cc.grad.numpy()) < 1e-4
+    with pytest.raises(NotImplementedError):
+        get_fov_mask(c.detach(), IH, IW, Kt.to(dev).requires_grad_(True))
+    assert get_fov_mask(c.detach(), IH, IW, Kt.to(dev), binary=True).dtype == torch.bool

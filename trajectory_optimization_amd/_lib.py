@@ -54,6 +54,8 @@ SIGNATURES = {
                                             c_vp, c_vp, c_sz, c_vp]),
     "tohip_to_camera_frame": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     "tohip_soft_masks": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(Camera), c_vp, c_vp, c_vp]),
+    "tohip_soft_masks_backward": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(Camera), c_vp, c_vp, c_vp, c_vp]),
+    "tohip_to_camera_frame_backward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_frustum_workspace_bytes": (c_sz, [c_i64]),
     "tohip_frustum_cull": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(Camera), c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            c_sz, c_vp]),

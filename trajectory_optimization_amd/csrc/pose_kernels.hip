@@ -202,6 +202,73 @@ k_soft_masks(const float* __restrict__ cam_xyz, int64_t n, CamConsts cc, float s
     }
 }
 
+// Backward of the two masks w.r.t. the camera-frame points: grad_xyz[n] = g_dist[n] dD/dp + g_fov[n] dF/dp (either upstream
+// gradient may be absent).  D = exp(-|p - mean|^2 / (2 std^2)); F = S Gw Gh, ln F = ln S - au^2/2 - av^2/2 with
+// au = (h0/z - W/2)/W, av = (h1/z - H/2)/H, z = h2 + eps, h = K p  (model.py:13-47).
+__global__ void __launch_bounds__(TO_BLOCK)
+k_soft_masks_bwd(const float* __restrict__ cam_xyz, int64_t n, CamConsts cc, float std_, float img_w, float img_h,
+                 const float* __restrict__ g_dist, const float* __restrict__ g_fov, float* __restrict__ grad_xyz) {
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float X = cam_xyz[3 * i], Y = cam_xyz[3 * i + 1], Z = cam_xyz[3 * i + 2];
+        float g[3] = {0.f, 0.f, 0.f};
+        if (g_dist) {
+            const float d[3] = {X - cc.mean, Y - cc.mean, Z - cc.mean};
+            const float dist = sqrtf(fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0])));
+            const float ds = dist / std_;
+            const float D = expf(-0.5f * (ds * ds));
+            const float w = -g_dist[i] * D / (std_ * std_);
+            for (int k = 0; k < 3; ++k) g[k] = w * d[k];
+        }
+        if (g_fov) {
+            const float h0 = fmaf(cc.k[2], Z, fmaf(cc.k[1], Y, cc.k[0] * X));
+            const float h1 = fmaf(cc.k[5], Z, fmaf(cc.k[4], Y, cc.k[3] * X));
+            const float h2 = fmaf(cc.k[8], Z, fmaf(cc.k[7], Y, cc.k[6] * X));
+            const float S = 1.0f / (1.0f + expf(-h2));
+            const float z = h2 + cc.eps, rz = 1.0f / z;
+            const float u = h0 * rz, v = h1 * rz;
+            const float au = (u - cc.halfw) / img_w, av = (v - cc.halfh) / img_h;
+            const float F = S * expf(-0.5f * (au * au)) * expf(-0.5f * (av * av));
+            const float gf = g_fov[i] * F;
+            const float cu = -au / img_w * rz, cv = -av / img_h * rz;      // d(-au^2/2)/dh0, d(-av^2/2)/dh1
+            const float c2 = (1.0f - S) - (cu * u + cv * v);               // d ln F / d h2
+            if (F > 0.f)
+                for (int k = 0; k < 3; ++k) g[k] += gf * (cu * cc.k[k] + cv * cc.k[3 + k] + c2 * cc.k[6 + k]);
+        }
+        grad_xyz[3 * i] = g[0]; grad_xyz[3 * i + 1] = g[1]; grad_xyz[3 * i + 2] = g[2];
+    }
+}
+
+// Backward of to_camera_frame, c = R(q/|q|)^T (x - t): grad_xyz[n] = R g_n; per block the 12 sums (sum g, sum y (x) g) that
+// k_pose_bwd_finish + k_bwd_finish2 turn into the translation and quaternion gradients.
+__global__ void __launch_bounds__(TO_BLOCK)
+k_to_camera_frame_bwd(const float* __restrict__ xyz, int64_t n, const WayHot* __restrict__ hot, const float* __restrict__ g_out,
+                      float* __restrict__ grad_xyz, double* __restrict__ part) {
+    __shared__ double lds[TO_BLOCK];
+    const WayHot h = hot[0];
+    double acc[12];
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float y0 = xyz[3 * i] - h.t[0], y1 = xyz[3 * i + 1] - h.t[1], y2 = xyz[3 * i + 2] - h.t[2];
+        const float g0 = g_out[3 * i], g1 = g_out[3 * i + 1], g2 = g_out[3 * i + 2];
+        if (grad_xyz) {   // dL/dx = R g,  R[j][i] = m[3*i+j]
+            grad_xyz[3 * i] = fmaf(h.m[6], g2, fmaf(h.m[3], g1, h.m[0] * g0));
+            grad_xyz[3 * i + 1] = fmaf(h.m[7], g2, fmaf(h.m[4], g1, h.m[1] * g0));
+            grad_xyz[3 * i + 2] = fmaf(h.m[8], g2, fmaf(h.m[5], g1, h.m[2] * g0));
+        }
+        acc[0] += g0; acc[1] += g1; acc[2] += g2;
+        acc[3] += y0 * g0; acc[4] += y0 * g1; acc[5] += y0 * g2;
+        acc[6] += y1 * g0; acc[7] += y1 * g1; acc[8] += y1 * g2;
+        acc[9] += y2 * g0; acc[10] += y2 * g1; acc[11] += y2 * g2;
+    }
+    for (int k = 0; k < 12; ++k) {
+        const double r = block_sum_double(acc[k], lds);
+        if (threadIdx.x == 0) part[(int64_t)blockIdx.x * 12 + k] = r;
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 namespace {
 constexpr int kPoseBlocks = 1024;
@@ -304,6 +371,44 @@ extern "C" int tohip_soft_masks(const float* cam_xyz, int64_t n, const tohip_cam
     if (nb > 4096) nb = 4096;
     k_soft_masks<<<(int)nb, TO_BLOCK, 0, (hipStream_t)stream_>>>(cam_xyz, n, cc, std_, cam->img_width, cam->img_height,
                                                                  dist_mask, fov_mask);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+extern "C" int tohip_soft_masks_backward(const float* cam_xyz, int64_t n, const tohip_camera* cam, const float* grad_dist,
+                                         const float* grad_fov, float* grad_xyz, void* stream_) {
+    if (!cam_xyz || !cam || !grad_xyz || n < 0) return TOHIP_EINVAL;
+    if (n == 0) return TOHIP_OK;
+    const CamConsts cc = make_consts(cam);
+    const float std_ = (float)(((double)cam->max_dist - (double)cam->min_dist) / 2.0);
+    int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
+    if (nb > 4096) nb = 4096;
+    k_soft_masks_bwd<<<(int)nb, TO_BLOCK, 0, (hipStream_t)stream_>>>(cam_xyz, n, cc, std_, cam->img_width, cam->img_height, grad_dist,
+                                                                     grad_fov, grad_xyz);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+extern "C" int tohip_to_camera_frame_backward(const float* xyz, int64_t n, const float* quat, const float* trans,
+                                              const float* grad_out, float* grad_xyz, float* grad_quat, float* grad_trans,
+                                              void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!xyz || !quat || !trans || !grad_out || !grad_quat || !grad_trans || !workspace || n <= 0) return TOHIP_EINVAL;
+    const PosePlan pl = pose_plan();
+    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    WayHot* hot = (WayHot*)(ws + pl.off_hot);
+    WayCold* cold = (WayCold*)(ws + pl.off_cold);
+    double* part = (double*)(ws + pl.off_part);
+    float* vgrad = (float*)(ws + pl.off_vgrad);
+    k_prep_posecam<<<1, 64, 0, st>>>(trans, quat, hot, cold);
+    TO_HIP_CHECK_LAUNCH();
+    const int nb = pose_blocks(n);
+    k_to_camera_frame_bwd<<<nb, TO_BLOCK, 0, st>>>(xyz, n, hot, grad_out, grad_xyz, part);
+    TO_HIP_CHECK_LAUNCH();
+    k_pose_bwd_finish<<<1, TO_BLOCK, 0, st>>>(part, nb, vgrad);
+    TO_HIP_CHECK_LAUNCH();
+    k_bwd_finish2<<<1, 64, 0, st>>>(vgrad, hot, cold, 1, 1, nullptr, nullptr, grad_trans, grad_quat);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }

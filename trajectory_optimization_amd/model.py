@@ -23,33 +23,77 @@ from .tools import hidden_pts_removal
 
 # ------------------------------------------------------------------------------ helper functions
 
+class _DistMask(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, cam):
+        ctx.cam = cam
+        ctx.save_for_backward(points)
+        return ops.soft_masks(points, cam, want_dist=True, want_fov=False)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (points,) = ctx.saved_tensors
+        return ops.soft_masks_backward(points, ctx.cam, grad_dist=g).to(points.dtype), None
+
+
+class _FovMask(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, cam):
+        ctx.cam = cam
+        ctx.save_for_backward(points)
+        return ops.soft_masks(points, cam, want_dist=False, want_fov=True)[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        (points,) = ctx.saved_tensors
+        return ops.soft_masks_backward(points, ctx.cam, grad_fov=g).to(points.dtype), None
+
+
+class _ToCameraFrame(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, quat, trans):
+        ctx.save_for_backward(verts, quat, trans)
+        return ops.to_camera_frame_exact(verts, quat, trans, normalize=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        verts, quat, trans = ctx.saved_tensors
+        gx, gq, gt = ops.to_camera_frame_backward(verts, quat, trans, g, want_points_grad=ctx.needs_input_grad[0])
+        return (gx.to(verts.dtype) if gx is not None else None, gq.reshape(quat.shape).to(quat.dtype),
+                gt.reshape(trans.shape).to(trans.dtype))
+
+
 def get_dist_mask(points, min_dist=1.0, max_dist=5.0):
-    """/root/reference/src/model.py:13-24 (forward values, HIP kernel; not differentiable here — the
-    models differentiate through their fused kernels)."""
+    """/root/reference/src/model.py:13-24.  HIP kernels forward and backward: differentiable w.r.t. `points` like the
+    reference's torch ops."""
     assert isinstance(points, torch.Tensor)
     assert points.size()[1] == 3
     cam = ops.Camera(torch.eye(3), 1.0, 1.0, min_dist, max_dist)
-    return ops.soft_masks(points, cam, want_dist=True, want_fov=False)[0]
+    return _DistMask.apply(points, cam)
 
 
 def get_fov_mask(points, img_height, img_width, intrins, eps=1e-6, binary=False):
-    """/root/reference/src/model.py:27-47 (note the reference's positional order: height, then width)."""
+    """/root/reference/src/model.py:27-47 (note the reference's positional order: height, then width).  The soft mask is
+    differentiable w.r.t. `points`; a gradient w.r.t. the intrinsics is not provided and asking for one raises."""
     assert isinstance(points, torch.Tensor)
     assert points.size()[1] == 3
     assert isinstance(intrins, torch.Tensor)
     assert intrins.size() == torch.Size([3, 3])
+    if intrins.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("get_fov_mask: no gradient w.r.t. the camera intrinsics (pass intrins.detach())")
     cam = ops.Camera(intrins, img_width, img_height, 1.0, 5.0, eps)
     if binary:
         pts3 = points.detach().to(torch.float32).t().contiguous()
         return ops.frustum_cull(pts3, cam, float("-inf"), float("inf"), want_indices=False)[1]
-    return ops.soft_masks(points, cam, want_dist=False, want_fov=True)[1]
+    return _FovMask.apply(points, cam)
 
 
 def to_camera_frame(verts, quat, trans):
-    """/root/reference/src/model.py:50-57, bit-identical f32 arithmetic."""
+    """/root/reference/src/model.py:50-57, bit-identical f32 arithmetic; differentiable w.r.t. all three arguments (the
+    quaternion gradient goes through F.normalize, as in the reference)."""
     assert verts.dim() == trans.dim()
     assert quat.size() == torch.Size([1, 4])
-    return ops.to_camera_frame_exact(verts, quat, trans, normalize=True)
+    return _ToCameraFrame.apply(verts, quat, trans)
 
 
 def length_calc(traj):

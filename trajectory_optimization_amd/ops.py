@@ -269,6 +269,38 @@ def soft_masks(cam_points, cam, want_dist=True, want_fov=True):
     return d, f
 
 
+def soft_masks_backward(cam_points, cam, grad_dist=None, grad_fov=None):
+    """dL/d cam_points (N,3) for upstream gradients of get_dist_mask and / or the soft get_fov_mask."""
+    pts = cam_points.detach().to(torch.float32).contiguous()
+    n = pts.shape[0]
+    out = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
+    gd = grad_dist.to(torch.float32).contiguous() if grad_dist is not None else None
+    gf = grad_fov.to(torch.float32).contiguous() if grad_fov is not None else None
+    with torch.cuda.device(pts.device):
+        check(_lib.lib().tohip_soft_masks_backward(ptr(pts), n, cam.ref(), ptr(gd), ptr(gf), ptr(out), stream_ptr()),
+              "tohip_soft_masks_backward")
+    return out
+
+
+def to_camera_frame_backward(points, quat, trans, grad_out, want_points_grad=True):
+    """-> (dL/d points (N,3) or None, dL/d quat (4,) raw quaternion, dL/d trans (3,))"""
+    pts = points.detach().to(torch.float32).contiguous()
+    n, dev = pts.shape[0], pts.device
+    q = _dev_f32(quat, dev).reshape(4)
+    t = _dev_f32(trans, dev).reshape(3)
+    g = grad_out.to(torch.float32).contiguous()
+    gx = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_points_grad else None
+    gq = torch.empty(4, dtype=torch.float32, device=dev)
+    gt = torch.empty(3, dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    wsb = L.tohip_pose_workspace_bytes(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(L.tohip_to_camera_frame_backward(ptr(pts), n, ptr(q), ptr(t), ptr(g), ptr(gx), ptr(gq), ptr(gt), ptr(ws), wsb, stream_ptr()),
+              "tohip_to_camera_frame_backward")
+    return gx, gq, gt
+
+
 def frustum_cull(cam_3xN, cam, min_dist, max_dist, want_indices=True):
     """-> (dist_mask bool[N], fov_mask bool[N], kept_idx int32[M] ascending)"""
     _require_cuda(cam_3xN, "points")
