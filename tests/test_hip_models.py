@@ -556,3 +556,19 @@ def test_xy_yaw_gradient_matches_finite_differences(dev):
             return Q.astype(np.float32)
         fd = (loss(poses, turned(h)) - loss(poses, turned(-h))) / (2 * h)
         assert abs(g[wi, 2] - fd) <= 0.03 * np.abs(g[:, 2]).max() + 1e-7
+
+
+def test_occlusion_rows_do_not_depend_on_the_chunking(dev, monkeypatch):
+    """occlusion_bits sends the waypoints through the cull stage in chunks sized by a memory budget: same rows whatever the budget."""
+    from trajectory_optimization_amd import ops
+    pts = synth.make_cloud(30_000, seed=44)
+    poses, quats = synth.make_path(7, optical=True, jitter_seed=44)
+    P = torch.from_numpy(pts).to(dev)
+    cloud = ops.PackedCloud(P)
+    cam = ops.Camera(K, IW, IH)
+    p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
+    a = ops.occlusion_bits(cloud, P, p, q, cam, 1.0, 15.0, "hpr")
+    monkeypatch.setattr(ops, "OCCLUSION_CULL_BYTES", 16 * 30_000 * 2)   # two waypoints per chunk
+    b = ops.occlusion_bits(cloud, P, p, q, cam, 1.0, 15.0, "hpr")
+    assert torch.equal(a, b)
+    assert 0 < int((a != -1).sum())   # something is occluded

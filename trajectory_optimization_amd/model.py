@@ -352,7 +352,7 @@ class ModelPose(nn.Module):
         self._cloud = ops.PackedCloud(self.points)
         self._cam = ops.Camera(self.K, self.img_width, self.img_height, min_dist, max_dist, self.eps)
         self._ws = ops.PoseWorkspace(self._cloud)
-        self._occlusion_mask = None
+        self._occlusion_mask, self._occlusion_key = None, None
         self.fused_loss = True  # forward() as one autograd node; False (or an overridden criterion): observations node + torch ops
 
     def forward(self, debug=False, hpr=False):
@@ -361,8 +361,10 @@ class ModelPose(nn.Module):
         if hpr:
             # HPR of the WORLD-frame cloud seen from the world origin (model.py:114): pose independent,
             # so it is computed once per cloud
-            if self._occlusion_mask is None:
+            key = (self.points.data_ptr(), self.points._version, tuple(self.points.shape))
+            if self._occlusion_mask is None or self._occlusion_key != key:   # a replaced or edited cloud gets a new mask
                 self._occlusion_mask = hidden_pts_removal(self.points.detach(), device=self.device)[1].contiguous()
+                self._occlusion_key = key
             mask = self._occlusion_mask
         fused = self.fused_loss and type(self).criterion is ModelPose.criterion
         if fused:

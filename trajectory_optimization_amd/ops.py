@@ -164,17 +164,31 @@ def pose_backward(cloud, trans, quat, cam, ws, mask=None, grad_obs=None, scalars
 HPR_BATCH_POINTS = 32_000_000  # points per batched hull pass (workspace ~0.12 KB per point)
 
 
+OCCLUSION_CULL_BYTES = 4 << 30  # budget for the cull stage's worst-case buffers (16 B per point and waypoint): waypoints are chunked
+
+
 def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method="hpr"):
     """(W, npad/32) int32 occlusion bit rows for the given waypoints: the hard per-camera pipeline of
     /root/reference/src/pc_processor.py:158-187 (exact transform -> hard frustum cull -> HPR from the camera
-    centre, or the z-buffer splat for method="zbuffer") turned into the bit layout the kernels read."""
-    L = _lib.lib()
+    centre, or the z-buffer splat for method="zbuffer") turned into the bit layout the kernels read.
+    The waypoints go through in chunks sized by OCCLUSION_CULL_BYTES (the cull stage sizes its outputs for the worst case)."""
     dev = cloud.device
     W = poses.shape[0]
     rows = torch.empty((W, cloud.npad // 32), dtype=torch.int32, device=dev)
+    chunk = max(1, min(W, OCCLUSION_CULL_BYTES // (16 * max(cloud.n, 1))))
+    for w0 in range(0, W, chunk):
+        w1 = min(W, w0 + chunk)
+        _occlusion_rows_chunk(cloud, points, poses[w0:w1].contiguous(), quats[w0:w1].contiguous(), cam, min_dist, max_dist, method,
+                              rows[w0:w1])
+    return rows
+
+
+def _occlusion_rows_chunk(cloud, points, poses, quats, cam, min_dist, max_dist, method, rows):
+    L = _lib.lib()
+    dev = cloud.device
+    W = poses.shape[0]
     n = cloud.n
-    # transform -> cull -> gather for all waypoints in three launches; the per-waypoint buffers are sized for the worst case
-    # (16 B per point and waypoint: 2 GB at 1 M x 128)
+    # transform -> cull -> gather for all waypoints of the chunk in three launches
     kept_all, pts_all, counts, kcnt_all = cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True)
     kept_idx = [kept_all[w, :counts[w]] for w in range(W)]
     kept_pts = [pts_all[w, :counts[w]] for w in range(W)]
@@ -205,7 +219,7 @@ def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method=
                 if kept_idx[w].numel() >= 4:
                     vis[w] = (idx[int(voff[j]):int(voff[j + 1])] - offs[j]).contiguous()
             w0 = w1
-    # all rows in three launches: the visible positions of every waypoint end to end, with their offsets
+    # all rows in four launches: the visible positions of every waypoint end to end, with their offsets
     all_visible = torch.tensor([1 if vis[w] is None else 0 for w in range(W)], dtype=torch.int32, device=dev)  # < 4 kept points
     lens = [0 if vis[w] is None else int(vis[w].numel()) for w in range(W)]
     vis_off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=dev)
@@ -217,7 +231,6 @@ def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method=
             check(L.tohip_occlusion_rows(n, ptr(cloud.inv_perm), ptr(kept_all[w0:w1]), ptr(kcnt_all[w0:w1]), ptr(vis_cat),
                                          ptr(vis_off[w0:w1 + 1]), ptr(all_visible[w0:w1]), w1 - w0, ptr(rows[w0:w1]), stream_ptr()),
                   "tohip_occlusion_rows")
-    return rows
 
 
 def cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True):
