@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOHIP_ABI_VERSION 5
+#define TOHIP_ABI_VERSION 6
 
 #define TOHIP_OK 0
 #define TOHIP_EINVAL (-1)   /* bad size / null pointer */
@@ -134,6 +134,25 @@ int tohip_traj_backward(const void *packed, int64_t n_points, int64_t n_wps, con
                         const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits, const float *lo_sum,
                         const float *grad_rewards, const float *scalars, const float *gout, float *poses_grad,
                         float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- several trajectories over one cloud in one pass ("many trajectories optimised concurrently") ----------
+ * n_traj trajectories' waypoints laid end to end (poses (W,3), quats (W,4), W = their total); traj_offsets: n_traj + 1 ascending
+ * body-waypoint offsets on the DEVICE (int32; [0] = 0, [n_traj] = W; may be NULL when n_traj == 1).  Every trajectory has its
+ * own log-odds vector (lo_sum: n_traj x Npad), rewards (n_traj x N), scalars (n_traj x 4) and upstream gradient (gout: n_traj
+ * floats; grad_rewards: n_traj x N); the per-waypoint outputs (minmax, gradients) are simply concatenated.  Each trajectory's
+ * results are, bit for bit, those of a call with that trajectory alone.  The single-trajectory entry points above are these
+ * with n_traj = 1. */
+size_t tohip_traj_workspace_bytes_multi(int64_t n_points, int64_t n_virtual, int64_t n_traj);
+int tohip_traj_forward_multi(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
+                             const int32_t *traj_offsets, int64_t n_traj, const tohip_camera *cam_host, const tohip_rig *rig_host,
+                             int flags, const uint32_t *occlusion_bits, float *lo_sum, float *minmax, float *rewards_half,
+                             void *workspace, size_t workspace_bytes, void *stream);
+int tohip_traj_reward_multi(const void *packed, const float *lo_sum, int64_t n_points, int64_t n_traj, float eps, int prefilled,
+                            float *rewards, float *scalars, void *workspace, size_t workspace_bytes, void *stream);
+int tohip_traj_backward_multi(const void *packed, int64_t n_points, int64_t n_wps, int64_t n_traj, const tohip_camera *cam_host,
+                              const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits, const float *lo_sum,
+                              const float *grad_rewards, const float *scalars, const float *gout, float *poses_grad,
+                              float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- ModelPose (model.py:98-127) -------------------------------------------------------------- */
 size_t tohip_pose_workspace_bytes(int64_t n_points);
@@ -265,6 +284,17 @@ int tohip_traj_step_tail(float *poses, float *quats, const float *poses0, int64_
                          float smoothness_weight, float traj_length_weight, float eps, float lr_pose, float lr_quat,
                          float beta1, float beta2, float adam_eps, float rewards_th, float smoothness_th,
                          const float *scalars, float *loss_terms, float *state, void *stream);
+/* The same for n_traj equal-length trajectories laid end to end (block b = trajectory b): poses / quats / poses0 / gradients /
+ * Adam moments (n_traj x W rows), poses_grad_eval / quats_grad_eval (n_traj x n_eval rows), scalars (n_traj x 4),
+ * state (n_traj x 8), loss_terms: trajectory b's log starts at loss_terms + b * loss_terms_stride floats. */
+int tohip_traj_step_tail_multi(float *poses, float *quats, const float *poses0, int64_t n_wps, int64_t n_traj,
+                               const float *poses_grad_eval, const float *quats_grad_eval, int64_t n_eval, int step,
+                               float *poses_grad, float *quats_grad, float *exp_avg_p, float *exp_avg_sq_p, float *exp_avg_q,
+                               float *exp_avg_sq_q, float smoothness_weight, float traj_length_weight, float eps, float lr_pose,
+                               float lr_quat, float beta1, float beta2, float adam_eps, float rewards_th, float smoothness_th,
+                               const float *scalars, float *loss_terms, int64_t loss_terms_stride, float *state, void *stream);
+int tohip_gather_waypoints_multi(const float *poses, const float *quats, int64_t n_wps, int64_t n_traj, int64_t n_eval, int step,
+                                 float *poses_e, float *quats_e, void *stream);
 /* poses_e[r] = poses[r*step], quats_e[r] = quats[r*step] for r < n_eval, in one launch. */
 int tohip_gather_waypoints(const float *poses, const float *quats, int64_t n_eval, int step, float *poses_e, float *quats_e,
                            void *stream);

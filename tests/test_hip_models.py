@@ -572,3 +572,78 @@ def test_occlusion_rows_do_not_depend_on_the_chunking(dev, monkeypatch):
     b = ops.occlusion_bits(cloud, P, p, q, cam, 1.0, 15.0, "hpr")
     assert torch.equal(a, b)
     assert 0 < int((a != -1).sum())   # something is occluded
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_several_trajectories_in_one_pass_equal_separate_calls(dev, dense):
+    """tohip_traj_*_multi: B trajectories' waypoints as one batch of virtual waypoints, each with its own log-odds vector,
+    rewards, loss scalars and gradients — bit for bit what B separate calls give (unequal lengths, a rig, both modes)."""
+    from trajectory_optimization_amd import ops
+    pts = synth.make_cloud(150_000, seed=61)
+    P = torch.from_numpy(pts).to(dev)
+    cloud = ops.PackedCloud(P)
+    cam = ops.Camera(K, IW, IH)
+    flags = ops.DENSE if dense else 0
+    rg = ops.CameraRig(*synth.camera_rig(2), dev)
+    lens = [9, 17, 5]
+    paths = [synth.make_path(w, optical=True, jitter_seed=70 + i) for i, w in enumerate(lens)]
+    # move the second and third path so that the three see different parts of the cloud (and share some slots)
+    paths[1] = (paths[1][0] + np.float32([0.0, 4.0, 0.0]), paths[1][1])
+    paths[2] = (paths[2][0] * np.float32(0.5), paths[2][1])
+    p_all = torch.from_numpy(np.concatenate([p for p, _ in paths])).to(dev)
+    q_all = torch.from_numpy(np.concatenate([q for _, q in paths])).to(dev)
+    toff = torch.tensor(np.r_[0, np.cumsum(lens)], dtype=torch.int32, device=dev)
+    B, W = len(lens), sum(lens)
+    ws = ops.TrajWorkspace(cloud, W * 2, B)
+    half = torch.empty((B, cloud.n), device=dev)
+    lo, mm = ops.traj_forward_multi(cloud, p_all, q_all, toff, cam, ws, rig=rg, flags=flags, rewards_half=half)
+    rew, sc = ops.traj_reward_multi(cloud, lo, cam, ws, rewards=half, prefilled=True)
+    gout = torch.tensor([1.0, 0.5, 2.0], device=dev)
+    pg, qg = ops.traj_backward_multi(cloud, W, B, cam, ws, lo, scalars=sc, gout=gout, rig=rg, flags=flags)
+    g = torch.rand((B, cloud.n), generator=torch.Generator().manual_seed(3)).to(dev) - 0.3
+    pg2, qg2 = ops.traj_backward_multi(cloud, W, B, cam, ws, lo, grad_rewards=g, rig=rg, flags=flags)
+    assert float(rew.max()) > 0.5
+    o = 0
+    for b, w in enumerate(lens):
+        wsb = ops.TrajWorkspace(cloud, w * 2)
+        p, q = p_all[o:o + w].contiguous(), q_all[o:o + w].contiguous()
+        lo1, mm1 = ops.traj_forward(cloud, p, q, cam, wsb, rg, flags=flags)
+        rew1, sc1 = ops.traj_reward(cloud, lo1, cam, wsb)
+        pg1, qg1 = ops.traj_backward(cloud, w, cam, wsb, lo1, scalars=sc1, gout=gout[b:b + 1].contiguous(), rig=rg, flags=flags)
+        pg3, qg3 = ops.traj_backward(cloud, w, cam, wsb, lo1, grad_rewards=g[b].contiguous(), rig=rg, flags=flags)
+        assert torch.equal(lo[b], lo1) and torch.equal(mm[2 * o:2 * (o + w)], mm1)
+        assert torch.equal(rew[b], rew1) and torch.equal(sc[b], sc1)
+        assert torch.equal(pg[o:o + w], pg1) and torch.equal(qg[o:o + w], qg1)
+        assert torch.equal(pg2[o:o + w], pg3) and torch.equal(qg2[o:o + w], qg3)
+        o += w
+
+
+def test_optimize_trajectories_equals_independent_runs(dev):
+    """optimizer.optimize_trajectories: several candidate trajectories over one cloud, one set of launches per step — every
+    model ends up where its own optimize_trajectory run puts it, bit for bit, early stops included."""
+    from trajectory_optimization_amd.model import ModelTraj
+    from trajectory_optimization_amd.optimizer import optimize_trajectories, optimize_trajectory
+    pts = synth.make_cloud(120_000, seed=62)
+    P = torch.from_numpy(pts)
+    paths = []
+    for i in range(4):
+        p, q = synth.make_path(14, optical=True, jitter_seed=80 + i)
+        paths.append((p + np.float32([0.0, 1.5 * i - 2.0, 0.0]), q))
+
+    def models():
+        return [ModelTraj(P, torch.from_numpy(p), torch.from_numpy(q), torch.from_numpy(K), IW, IH, device=dev) for p, q in paths]
+    kw = dict(n_opt_steps=6, lr_pose=0.05, lr_quat=0.01, rewards_th=1.004, smoothness_th=0.5, vis_wps_dist=0.5)
+    batch = models()
+    res_b = optimize_trajectories(batch, **kw)
+    single = models()
+    res_s = [optimize_trajectory(m, **kw) for m in single]
+    assert any(r.stopped for r in res_s) and not all(r.stopped and r.steps_taken == 1 for r in res_s)
+    for mb, ms, rb, rs in zip(batch, single, res_b, res_s):
+        assert torch.equal(mb.poses.data, ms.poses.data) and torch.equal(mb.quats.data, ms.quats.data)
+        assert torch.equal(mb.rewards, ms.rewards)
+        assert rb.steps_taken == rs.steps_taken and rb.stopped == rs.stopped and rb.losses == rs.losses
+        for kk in ("vis", "l2", "length", "smooth"):
+            assert float(mb.loss[kk]) == float(ms.loss[kk])
+    with pytest.raises(ValueError):
+        optimize_trajectories([batch[0], ModelTraj(P, torch.from_numpy(paths[0][0][:9]), torch.from_numpy(paths[0][1][:9]),
+                                                    torch.from_numpy(K), IW, IH, device=dev)], **kw)

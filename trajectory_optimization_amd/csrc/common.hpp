@@ -445,7 +445,7 @@ struct __attribute__((aligned(128))) WayRec {
     float sthr1;   // 20      sqrt(thr1), rounded up
     float azero;   // 21      probe: 1 = a point with p == 0 was exhibited, hence min_n p == 0 exactly
     float m[9];    // 22..30  m[3*i+j] = R[j][i]: c = m y (the gradient chain wants R)
-    float pad;
+    int seg;       // 31      trajectory the waypoint belongs to (several trajectories evaluated in one pass; else 0)
 };
 static_assert(sizeof(WayRec) == 128, "WayRec is two 64-byte lines");
 

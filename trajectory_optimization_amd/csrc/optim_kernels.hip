@@ -215,12 +215,21 @@ struct StepTail {
     float* state;
     int W, n_eval, step;
     float smooth_w, length_w, eps, lr_pose, lr_quat, beta1, beta2, adam_eps, rewards_th, smoothness_th;
+    int64_t log_stride;              // floats between two trajectories' loss logs (several trajectories: one block each)
 };
 
 __global__ void __launch_bounds__(TO_BLOCK) k_traj_step_tail(StepTail a) {
     __shared__ double lds[TO_BLOCK];
     __shared__ double sh[4];
     const int t = threadIdx.x;
+    {   // block b = trajectory b: equal-length trajectories laid end to end, each with its own state, scalars and log
+        const int64_t b = blockIdx.x;
+        a.poses += b * a.W * 3; a.quats += b * a.W * 4; a.poses0 += b * a.W * 3;
+        a.pg_eval += b * a.n_eval * 3; a.qg_eval += b * a.n_eval * 4;
+        a.pg += b * a.W * 3; a.qg += b * a.W * 4;
+        a.mp += b * a.W * 3; a.vp += b * a.W * 3; a.mq += b * a.W * 4; a.vq += b * a.W * 4;
+        a.scalars += b * 4; a.state += b * 8; a.loss_terms += b * a.log_stride;
+    }
     for (int i = t; i < a.W * 3; i += TO_BLOCK) {
         const int j = i / 3, k = i - 3 * j, r = j / a.step;
         a.pg[i] = (j == r * a.step && r < a.n_eval) ? a.pg_eval[3 * r + k] : 0.f;
@@ -252,11 +261,53 @@ __global__ void k_gather_waypoints(const float* __restrict__ poses, const float*
     if (i < n_eval * 4) { const int r = i >> 2, k = i & 3; quats_e[i] = quats[(int64_t)r * step * 4 + k]; }
 }
 
+// several equal-length trajectories laid end to end: rows r*step of each (blockIdx.y = trajectory)
+__global__ void k_gather_waypoints_multi(const float* __restrict__ poses, const float* __restrict__ quats, int W, int n_eval, int step,
+                                         float* __restrict__ poses_e, float* __restrict__ quats_e) {
+    const int64_t b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_eval * 3) { const int r = i / 3, kk = i - 3 * r; poses_e[b * n_eval * 3 + i] = poses[(b * W + (int64_t)r * step) * 3 + kk]; }
+    if (i < n_eval * 4) { const int r = i >> 2, kk = i & 3; quats_e[b * n_eval * 4 + i] = quats[(b * W + (int64_t)r * step) * 4 + kk]; }
+}
+
+extern "C" int tohip_gather_waypoints_multi(const float* poses, const float* quats, int64_t W, int64_t n_traj, int64_t n_eval, int step,
+                                            float* poses_e, float* quats_e, void* stream_) {
+    if (!poses || !quats || !poses_e || !quats_e || n_eval <= 0 || step <= 0 || W <= 0 || n_traj <= 0 || n_traj > 65535) return TOHIP_EINVAL;
+    const int n = (int)(n_eval * 4);
+    k_gather_waypoints_multi<<<dim3((n + 255) / 256, (unsigned)n_traj), 256, 0, (hipStream_t)stream_>>>(poses, quats, (int)W, (int)n_eval, step,
+                                                                                                       poses_e, quats_e);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
 extern "C" int tohip_gather_waypoints(const float* poses, const float* quats, int64_t n_eval, int step, float* poses_e,
                                       float* quats_e, void* stream_) {
     if (!poses || !quats || !poses_e || !quats_e || n_eval <= 0 || step <= 0) return TOHIP_EINVAL;
     const int n = (int)(n_eval * 4);
     k_gather_waypoints<<<(n + 255) / 256, 256, 0, (hipStream_t)stream_>>>(poses, quats, (int)n_eval, step, poses_e, quats_e);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+extern "C" int tohip_traj_step_tail_multi(float* poses, float* quats, const float* poses0, int64_t W, int64_t n_traj,
+                                          const float* poses_grad_eval, const float* quats_grad_eval, int64_t n_eval, int step,
+                                          float* poses_grad, float* quats_grad, float* exp_avg_p, float* exp_avg_sq_p, float* exp_avg_q,
+                                          float* exp_avg_sq_q, float smoothness_weight, float traj_length_weight, float eps,
+                                          float lr_pose, float lr_quat, float beta1, float beta2, float adam_eps, float rewards_th,
+                                          float smoothness_th, const float* scalars, float* loss_terms, int64_t loss_terms_stride,
+                                          float* state, void* stream_) {
+    if (!poses || !quats || !poses0 || !poses_grad_eval || !quats_grad_eval || !poses_grad || !quats_grad || !exp_avg_p ||
+        !exp_avg_sq_p || !exp_avg_q || !exp_avg_sq_q || !scalars || !loss_terms || !state || W < 3 || n_eval <= 0 || step <= 0 ||
+        (n_eval - 1) * step >= W || n_traj <= 0)
+        return TOHIP_EINVAL;
+    StepTail a;
+    a.poses = poses; a.quats = quats; a.poses0 = poses0; a.pg_eval = poses_grad_eval; a.qg_eval = quats_grad_eval;
+    a.pg = poses_grad; a.qg = quats_grad; a.mp = exp_avg_p; a.vp = exp_avg_sq_p; a.mq = exp_avg_q; a.vq = exp_avg_sq_q;
+    a.scalars = scalars; a.loss_terms = loss_terms; a.state = state; a.W = (int)W; a.n_eval = (int)n_eval; a.step = step;
+    a.smooth_w = smoothness_weight; a.length_w = traj_length_weight; a.eps = eps; a.lr_pose = lr_pose; a.lr_quat = lr_quat;
+    a.beta1 = beta1; a.beta2 = beta2; a.adam_eps = adam_eps; a.rewards_th = rewards_th; a.smoothness_th = smoothness_th;
+    a.log_stride = loss_terms_stride;
+    k_traj_step_tail<<<(int)n_traj, TO_BLOCK, 0, (hipStream_t)stream_>>>(a);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
@@ -267,19 +318,9 @@ extern "C" int tohip_traj_step_tail(float* poses, float* quats, const float* pos
                                     float smoothness_weight, float traj_length_weight, float eps, float lr_pose, float lr_quat,
                                     float beta1, float beta2, float adam_eps, float rewards_th, float smoothness_th,
                                     const float* scalars, float* loss_terms, float* state, void* stream_) {
-    if (!poses || !quats || !poses0 || !poses_grad_eval || !quats_grad_eval || !poses_grad || !quats_grad || !exp_avg_p ||
-        !exp_avg_sq_p || !exp_avg_q || !exp_avg_sq_q || !scalars || !loss_terms || !state || W < 3 || n_eval <= 0 || step <= 0 ||
-        (n_eval - 1) * step >= W)
-        return TOHIP_EINVAL;
-    StepTail a;
-    a.poses = poses; a.quats = quats; a.poses0 = poses0; a.pg_eval = poses_grad_eval; a.qg_eval = quats_grad_eval;
-    a.pg = poses_grad; a.qg = quats_grad; a.mp = exp_avg_p; a.vp = exp_avg_sq_p; a.mq = exp_avg_q; a.vq = exp_avg_sq_q;
-    a.scalars = scalars; a.loss_terms = loss_terms; a.state = state; a.W = (int)W; a.n_eval = (int)n_eval; a.step = step;
-    a.smooth_w = smoothness_weight; a.length_w = traj_length_weight; a.eps = eps; a.lr_pose = lr_pose; a.lr_quat = lr_quat;
-    a.beta1 = beta1; a.beta2 = beta2; a.adam_eps = adam_eps; a.rewards_th = rewards_th; a.smoothness_th = smoothness_th;
-    k_traj_step_tail<<<1, TO_BLOCK, 0, (hipStream_t)stream_>>>(a);
-    TO_HIP_CHECK_LAUNCH();
-    return TOHIP_OK;
+    return tohip_traj_step_tail_multi(poses, quats, poses0, W, 1, poses_grad_eval, quats_grad_eval, n_eval, step, poses_grad, quats_grad,
+                                      exp_avg_p, exp_avg_sq_p, exp_avg_q, exp_avg_sq_q, smoothness_weight, traj_length_weight, eps, lr_pose,
+                                      lr_quat, beta1, beta2, adam_eps, rewards_th, smoothness_th, scalars, loss_terms, 0, state, stream_);
 }
 
 extern "C" int tohip_traj_regularizers(const float* poses, const float* poses0, int64_t W, float smoothness_weight,

@@ -53,10 +53,8 @@
 // ---------------------------------------------------------------------------------------------
 // workspace control block
 
-struct TrajCtl {
-    unsigned long long reward_acc;   // k_traj_reward's accumulator (arrivals | NaN marks | fixed-point sum); zero between launches
-    int pad[14];
-};
+// head of the workspace: k_traj_reward's accumulators, one 64-bit word per trajectory (arrivals | NaN marks | fixed-point
+// sum); zero between launches
 
 struct TieRec {            // slots (ascending) whose max equals the waypoint's max / whose min equals its min (a > 0)
     int nmax, nmin;        // counts; > TO_TIE_CAP: overflow, scan every slot
@@ -68,10 +66,15 @@ struct TieRec {            // slots (ascending) whose max equals the waypoint's 
 // virtual waypoint records: thread per virtual waypoint v = w*C + c.  F.normalize (model.py:53), rig composition
 // R_v = R(qn_w) R(q_c), t_v = t_w + R(qn_w) l_c, then the three projection rows and the Gaussian's centre.
 
+// traj_off (optional): n_traj + 1 ascending body-waypoint offsets of several trajectories laid end to end
 __device__ __forceinline__ void prep_wayrec(int v, const float* __restrict__ poses, const float* __restrict__ quats, int C,
                                             const float* __restrict__ rig_q, const float* __restrict__ rig_t,
-                                            const EvalK& k, WayRec* __restrict__ rec, WayCold* __restrict__ cold) {
+                                            const EvalK& k, WayRec* __restrict__ rec, WayCold* __restrict__ cold,
+                                            const int* __restrict__ traj_off, int n_traj) {
     const int w = v / C, c = v - w * C;
+    int seg = 0;
+    if (traj_off != nullptr)
+        while (seg + 1 < n_traj && w >= traj_off[seg + 1]) ++seg;
     float q[4] = {quats[4 * w], quats[4 * w + 1], quats[4 * w + 2], quats[4 * w + 3]};
     float ss = q[0] * q[0];
     ss = ss + q[1] * q[1];
@@ -122,7 +125,7 @@ __device__ __forceinline__ void prep_wayrec(int v, const float* __restrict__ pos
         r.f2[kk] = (float)h2;
         r.sp[kk] = (float)((double)k.mean * s);
     }
-    r.a = 0.f; r.invM = 1.f; r.M = 1.f; r.L = 0.f; r.thr1 = INFINITY; r.sthr1 = INFINITY; r.azero = 0.f; r.pad = 0.f;
+    r.a = 0.f; r.invM = 1.f; r.M = 1.f; r.L = 0.f; r.thr1 = INFINITY; r.sthr1 = INFINITY; r.azero = 0.f; r.seg = seg;
     rec[v] = r;
 }
 
@@ -135,9 +138,9 @@ __device__ __forceinline__ void clear_select_state(unsigned long long* __restric
 __global__ void __launch_bounds__(256)
 k_traj_prep(const float* __restrict__ poses, const float* __restrict__ quats, int V, int C, const float* __restrict__ rig_q,
             const float* __restrict__ rig_t, EvalK k, WayRec* __restrict__ rec, WayCold* __restrict__ cold,
-            unsigned long long* __restrict__ ft, int64_t ft_words) {
+            unsigned long long* __restrict__ ft, int64_t ft_words, const int* __restrict__ traj_off, int n_traj) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < V) prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, rec, cold);
+    if (v < V) prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, rec, cold, traj_off, n_traj);
     clear_select_state(ft, ft_words);
 }
 
@@ -229,7 +232,7 @@ __global__ void __launch_bounds__(TO_PROBE_THREADS)
 k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restrict__ quats, int C,
              const float* __restrict__ rig_q, const float* __restrict__ rig_t, EvalK k, WayRec* __restrict__ rec,
              WayCold* __restrict__ cold, const uint32_t* __restrict__ occ, int64_t occw,
-             unsigned long long* __restrict__ ft, int64_t ft_words) {
+             unsigned long long* __restrict__ ft, int64_t ft_words, const int* __restrict__ traj_off, int n_traj) {
     __shared__ float smx[TO_PROBE_THREADS / 64];
     __shared__ int szero[TO_PROBE_THREADS / 64];
     const int v = blockIdx.x, t = threadIdx.x;
@@ -244,7 +247,7 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
         const int sc = sj < cv.nsamples ? sj : 0;
         px[j] = cv.samples[sc]; py[j] = cv.samples[TO_PROBE_MAX + sc]; pz[j] = cv.samples[2 * TO_PROBE_MAX + sc];
     }
-    if (t == 0) prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, rec, cold);
+    if (t == 0) prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, rec, cold, traj_off, n_traj);
     __syncthreads();
     const WayRec r = rec[v];
     float mx = 0.f;
@@ -289,12 +292,23 @@ __device__ __forceinline__ void pass1_eval(const EvalK& k, const WayRec& r, cons
 // the log-odds vector starts from zero (k_traj_lo_sparse fills the flagged slots) and, when the caller asks for it, the rewards
 // vector from sigmoid(0) = 1/2 (k_traj_reward then only stores the others): done by whoever evaluates a point block's first waypoint
 typedef float f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void init_outputs(int64_t base, int64_t n, float* __restrict__ lo_zero, float* __restrict__ rewards_half) {
-    // streaming stores: nothing of this is read again by this kernel, and lines left dirty in L2 are written back at its end
-    __builtin_nontemporal_store(f4v{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4v*>(lo_zero + base));
-    if (rewards_half != nullptr && base < n) {
-        if (base + 4 <= n) __builtin_nontemporal_store(f4v{0.5f, 0.5f, 0.5f, 0.5f}, reinterpret_cast<f4v*>(rewards_half + base));
-        else for (int64_t i = base; i < n; ++i) rewards_half[i] = 0.5f;
+struct OutInit {   // n_traj log-odds vectors of npad floats (and rewards vectors of n floats) one after the other
+    float* lo_zero;
+    float* rewards_half;
+    int64_t npad, n;
+    int n_traj;
+};
+__device__ __forceinline__ void init_outputs(int64_t base, const OutInit& o) {
+    // streaming stores: nothing of this is read again by this kernel
+    for (int b = 0; b < o.n_traj; ++b) {
+        __builtin_nontemporal_store(f4v{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4v*>(o.lo_zero + (int64_t)b * o.npad + base));
+        if (o.rewards_half != nullptr && base < o.n) {
+            float* rh = o.rewards_half + (int64_t)b * o.n;
+            if (base + 4 <= o.n && ((((int64_t)b * o.n) & 3) == 0))   // (n need not be a multiple of 4: a later vector may start unaligned)
+                __builtin_nontemporal_store(f4v{0.5f, 0.5f, 0.5f, 0.5f}, reinterpret_cast<f4v*>(rh + base));
+            else
+                for (int64_t i = base; i < base + 4 && i < o.n; ++i) rh[i] = 0.5f;
+        }
     }
 }
 
@@ -308,8 +322,7 @@ __device__ __forceinline__ void init_outputs(int64_t base, int64_t n, float* __r
 template <bool OCC>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk, EvalK k, float2* __restrict__ part, int nslots,
-                   const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ lo_zero, float* __restrict__ rewards_half,
-                   unsigned long long* __restrict__ stamps) {
+                   const uint32_t* __restrict__ occ, int64_t occw, OutInit oi, unsigned long long* __restrict__ stamps) {
     constexpr int P = TO_PD;
     const int lane = threadIdx.x & 63;
     // diagnostic only (tohip_profile_clock): shader-clock and 100 MHz real-time stamps of this block, to a buffer nothing else reads
@@ -332,7 +345,7 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
         const int slot = gthread >> 5;   // 32 lanes x 8 points
         float x[P], y[P], z[P];
         load_points<P>(cv.soa, cv.npad, base, x, y, z);
-        if (v0 == 0) { init_outputs(base, cv.n, lo_zero, rewards_half); init_outputs(base + 4, cv.n, lo_zero, rewards_half); }
+        if (v0 == 0) { init_outputs(base, oi); init_outputs(base + 4, oi); }
         for (int v = v0; v < v1; ++v) {
             const int64_t uu = u + (v - v0);
             if (uu == q1) __builtin_amdgcn_s_setprio(2);
@@ -370,7 +383,7 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
 template <bool OCC>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile, EvalK k, float2* __restrict__ part, int nslots,
-                  const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ lo_zero, float* __restrict__ rewards_half) {
+                  const uint32_t* __restrict__ occ, int64_t occw, OutInit oi) {
     constexpr int P = TO_P;
     const int lane = threadIdx.x & 63;
     const int gthread = blockIdx.x * TO_BLOCK + threadIdx.x;
@@ -378,7 +391,7 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile
     const int slot = gthread >> 6;
     float x[P], y[P], z[P];
     load_points<P>(cv.soa, cv.npad, base, x, y, z);
-    if (blockIdx.y == 0) init_outputs(base, cv.n, lo_zero, rewards_half);
+    if (blockIdx.y == 0) init_outputs(base, oi);
     const int v0 = blockIdx.y * vtile;
     const int v1 = min(V, v0 + vtile);
     const float4 tb = wave_tile_bound(cv, base);
@@ -481,7 +494,8 @@ k_traj_select(const float2* __restrict__ part, int nslots, int V, WayRec* __rest
         // max == min, or a NaN: the reference's p / max is 0/0 for EVERY point of this waypoint (model.py:227), so every
         // log-odds sum is NaN.  Rare: this block stores it; k_traj_lo_sparse adds onto it.
         const float nanv = __builtin_nanf("");
-        for (int64_t i = t; i < npad; i += TO_SELECT_THREADS) lo_sum[i] = nanv;
+        float* lo_t = lo_sum + (int64_t)rec[v].seg * npad;   // its trajectory's vector
+        for (int64_t i = t; i < npad; i += TO_SELECT_THREADS) lo_t[i] = nanv;
     }
     int* myl = vlist + (int64_t)v * nslots;
     auto sweep2 = [&](const float2 qq, const int s0) {
@@ -550,11 +564,13 @@ __device__ __forceinline__ float log_odds(const EvalK& k, const WayRec& r, float
 
 __global__ void __launch_bounds__(1024)
 k_traj_lo_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const unsigned long long* __restrict__ ft, int vwords,
-                 float* __restrict__ lo_sum, const uint32_t* __restrict__ occ, int64_t occw) {
+                 float* __restrict__ lo_sum, const uint32_t* __restrict__ occ, int64_t occw, const int* __restrict__ toff, int n_traj,
+                 int C) {
     // block per slot; the unflagged ones (94 % on the BASELINE workloads) leave after one scalar load of their flag words — a
     // block's life is that latency, and only two 1024-thread blocks fit a CU.  The sum is ADDED to what lo_sum holds: zero from
     // pass 1, or the NaN k_traj_select stored everywhere for a degenerate waypoint (the reference divides 0/0 for every point
-    // then, model.py:227)
+    // then, model.py:227).  Several trajectories (toff: their n_traj + 1 body-waypoint offsets; C cameras each): each has its own vector and
+    // its own rank count, so its sum is the one a run of that trajectory alone produces.
     __shared__ float spart[3][TO_SLOT];
     const int s = blockIdx.x;
     const int pt = threadIdx.x & (TO_SLOT - 1), g = threadIdx.x >> 8;
@@ -565,21 +581,36 @@ k_traj_lo_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const un
     if (!any) return;
     const float x = cv.soa[i], y = cv.soa[cv.npad + i], z = cv.soa[2 * cv.npad + i];
     float acc = 0.f;
-    int rank = 0;
+    int rank = 0, cur = 0, v_next = toff ? toff[1] * C : 0x7fffffff;
+    bool open_ = false;   // the current trajectory has a flagged waypoint in this slot (uniform)
+    auto flush = [&]() {
+        if (g) spart[g - 1][pt] = acc;
+        __syncthreads();
+        if (!g) {
+            float* dst = lo_sum + (int64_t)cur * cv.npad + i;
+            *dst = *dst + (((acc + spart[0][pt]) + spart[1][pt]) + spart[2][pt]);
+        }
+        __syncthreads();
+        acc = 0.f; rank = 0; open_ = false;
+    };
     for (int w = 0; w < vwords; ++w) {
         unsigned long long bits = fts[w];
         while (bits) {
             const int v = w * 64 + __builtin_ctzll(bits);
             bits &= bits - 1ull;
+            if (v >= v_next) {   // the walk enters a later trajectory
+                if (open_) flush();
+                while (cur + 1 < n_traj && v >= toff[cur + 1] * C) ++cur;
+                v_next = cur + 1 < n_traj ? toff[cur + 1] * C : 0x7fffffff;
+            }
+            open_ = true;
             if (((rank++) & 3) == g) {
                 const WayRec& r = rec[v];
                 acc += log_odds(k, r, vis_p(r, k, x, y, z) * occ_one(occ, occw, v, i));
             }
         }
     }
-    if (g) spart[g - 1][pt] = acc;
-    __syncthreads();
-    if (!g) lo_sum[i] = lo_sum[i] + (((acc + spart[0][pt]) + spart[1][pt]) + spart[2][pt]);
+    if (open_) flush();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -604,13 +635,18 @@ __device__ __forceinline__ double wave_sum_double(double v) {
 #define TO_REWARD_THREADS 1024
 #define TO_REWARD_BLOCKS 128
 __global__ void __launch_bounds__(TO_REWARD_THREADS)
-k_traj_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, int64_t n, float eps, int shift, int prefilled,
+k_traj_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, int64_t n, int64_t npad, float eps, int shift, int prefilled,
               float* __restrict__ rewards, unsigned long long* __restrict__ acc, float* __restrict__ scalars) {
     __shared__ double lds[TO_REWARD_THREADS / 64];
+    // blockIdx.y = trajectory: its own log-odds vector, rewards vector, accumulator word and scalars
+    lo_sum += (int64_t)blockIdx.y * npad;
+    rewards += (int64_t)blockIdx.y * n;
+    acc += blockIdx.y;
+    scalars += 4 * blockIdx.y;
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * TO_REWARD_THREADS * 4;
     for (int64_t i0 = ((int64_t)blockIdx.x * TO_REWARD_THREADS + threadIdx.x) * 4; i0 < n; i0 += stride) {
-        const float4 lo4 = *reinterpret_cast<const float4*>(lo_sum + i0);   // npad is a multiple of 4: in bounds
+        const float4 lo4 = *reinterpret_cast<const float4*>(lo_sum + i0);   // npad is a multiple of 2048: aligned, in bounds
         const float lo[4] = {lo4.x, lo4.y, lo4.z, lo4.w};
         const bool all0 = (lo4.x == 0.f) & (lo4.y == 0.f) & (lo4.z == 0.f) & (lo4.w == 0.f);
         if (prefilled && all0) {
@@ -668,7 +704,11 @@ k_traj_bwd_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const i
     const int v = blockIdx.y;
     const int npairs = vcnt[v];
     if ((int)blockIdx.x >= npairs) return;
-    const float coef = grad_rewards ? 0.f : scalars[2] * gout[0];
+    // the waypoint's trajectory: its log-odds vector, upstream gradient and loss scalars
+    const int seg = rec[v].seg;
+    lo_sum += (int64_t)seg * cv.npad;
+    if (grad_rewards) grad_rewards += (int64_t)seg * cv.n;
+    const float coef = grad_rewards ? 0.f : scalars[4 * seg + 2] * gout[seg];
     for (int it = blockIdx.x; it < npairs; it += gridDim.x) {
         const int s = vlist[(int64_t)v * nslots + it];
         const int64_t i = (int64_t)s * TO_SLOT + t;
@@ -1054,7 +1094,7 @@ struct TrajPlan {
     size_t off_ctl, off_rec, off_cold, off_part, off_fv, off_ft, off_vcnt, off_vlist, off_ties, off_bpart, off_vgrad, total;
 };
 
-inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W) {
+inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
     TrajPlan p;
     p.npad = tohip_padded_points(n);
     p.nblk = (int)(p.npad / (TO_BLOCK * TO_P));
@@ -1063,7 +1103,7 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W) {
     p.vwords = (int)((V + 63) / 64);
     p.V = (int)V;
     size_t o = 0;
-    p.off_ctl = o;   o += align_up(sizeof(TrajCtl), 256);   // first: all tohip_traj_reward uses
+    p.off_ctl = o;   o += align_up(sizeof(unsigned long long) * (size_t)(n_traj < 1 ? 1 : n_traj), 256);   // first: all tohip_traj_reward uses
     p.off_rec = o;   o += align_up((size_t)V * sizeof(WayRec), 256);
     p.off_cold = o;  o += align_up((size_t)W * sizeof(WayCold), 256);
     p.off_part = o;  o += align_up((size_t)V * (size_t)p.nslots * sizeof(float2), 256);
@@ -1118,21 +1158,26 @@ inline int rig_cams(const tohip_rig* rig) { return (rig && rig->n_cams > 0 && ri
 
 }  // namespace
 
+extern "C" size_t tohip_traj_workspace_bytes_multi(int64_t n_points, int64_t n_virtual, int64_t n_traj) {
+    if (n_points <= 0 || n_virtual <= 0 || n_traj <= 0) return 0;
+    return make_plan(n_points, n_virtual, n_virtual, n_traj).total;
+}
 extern "C" size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual) {
-    if (n_points <= 0 || n_virtual <= 0) return 0;
-    return make_plan(n_points, n_virtual, n_virtual).total;
+    return tohip_traj_workspace_bytes_multi(n_points, n_virtual, 1);
 }
 
-extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
-                                  const tohip_camera* cam, const tohip_rig* rig, int flags, const uint32_t* occlusion_bits,
-                                  float* lo_sum, float* minmax, float* rewards_half, void* workspace, size_t workspace_bytes,
-                                  void* stream_) {
-    if (!packed || !poses || !quats || !cam || !lo_sum || !minmax || !workspace || n <= 0 || W <= 0) return TOHIP_EINVAL;
+extern "C" int tohip_traj_forward_multi(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
+                                        const int32_t* traj_offsets, int64_t n_traj, const tohip_camera* cam, const tohip_rig* rig,
+                                        int flags, const uint32_t* occlusion_bits, float* lo_sum, float* minmax, float* rewards_half,
+                                        void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!packed || !poses || !quats || !cam || !lo_sum || !minmax || !workspace || n <= 0 || W <= 0 || n_traj <= 0 ||
+        (n_traj > 1 && !traj_offsets))
+        return TOHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
     const int C = rig_cams(rig);
     const int64_t V = W * C;
     if (V > (1 << 24)) return TOHIP_EINVAL;
-    const TrajPlan pl = make_plan(n, V, W);
+    const TrajPlan pl = make_plan(n, V, W, n_traj);
     if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
     char* ws = (char*)workspace;
     WayRec* rec = (WayRec*)(ws + pl.off_rec);
@@ -1150,17 +1195,19 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
     const float* rt = rq ? rig->rig_trans : nullptr;
     const int64_t ft_words = (int64_t)pl.nslots * pl.vwords;
     const int64_t occw = cv.npad / 32;
+    const int* toff = n_traj > 1 ? traj_offsets : nullptr;
+    const OutInit oi{lo_sum, rewards_half, cv.npad, n, (int)n_traj};
 
     {
         TO_PROF(TOHIP_PROF_SMALL, st);
         if (cull) {
             k_traj_probe<<<(int)V, TO_PROBE_THREADS, 0, st>>>(cv, poses, quats, C, rq, rt, k, rec, cold, occlusion_bits, occw,
-                                                              ft, ft_words);
+                                                              ft, ft_words, toff, (int)n_traj);
         } else {
             int nb = (int)((V + 255) / 256);
             const int want = (int)((ft_words + 255) / 256);
             if (nb < want) nb = want > 256 ? 256 : want;
-            k_traj_prep<<<nb, 256, 0, st>>>(poses, quats, (int)V, C, rq, rt, k, rec, cold, ft, ft_words);
+            k_traj_prep<<<nb, 256, 0, st>>>(poses, quats, (int)V, C, rq, rt, k, rec, cold, ft, ft_words, toff, (int)n_traj);
         }
         TO_HIP_CHECK_LAUNCH();
     }
@@ -1171,13 +1218,13 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
             int vtile, ntiles;
             cull_tiles((int)V, &vtile, &ntiles);
             const dim3 grid(pl.nblk, ntiles);
-            if (occ) k_traj_pass1_cull<true><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half);
-            else k_traj_pass1_cull<false><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half);
+            if (occ) k_traj_pass1_cull<true><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, oi);
+            else k_traj_pass1_cull<false><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, oi);
         } else {
             const int nblk8 = (int)(pl.npad / (TO_BLOCK * TO_PD));
             const int nb = dense_blocks(nblk8, (int)V, occ);
-            if (occ) k_traj_pass1_dense<true><<<nb, TO_BLOCK, 0, st>>>(cv, rec, (int)V, nblk8, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half, clock_stamps());
-            else k_traj_pass1_dense<false><<<nb, TO_BLOCK, 0, st>>>(cv, rec, (int)V, nblk8, k, part, pl.nslots, occlusion_bits, occw, lo_sum, rewards_half, clock_stamps());
+            if (occ) k_traj_pass1_dense<true><<<nb, TO_BLOCK, 0, st>>>(cv, rec, (int)V, nblk8, k, part, pl.nslots, occlusion_bits, occw, oi, clock_stamps());
+            else k_traj_pass1_dense<false><<<nb, TO_BLOCK, 0, st>>>(cv, rec, (int)V, nblk8, k, part, pl.nslots, occlusion_bits, occw, oi, clock_stamps());
         }
         TO_HIP_CHECK_LAUNCH();
     }
@@ -1193,40 +1240,54 @@ extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* po
     }
     {
         TO_PROF(TOHIP_PROF_PASS2, st);
-        k_traj_lo_sparse<<<pl.nslots, 1024, 0, st>>>(cv, rec, k, ft, pl.vwords, lo_sum, occlusion_bits, occw);
+        k_traj_lo_sparse<<<pl.nslots, 1024, 0, st>>>(cv, rec, k, ft, pl.vwords, lo_sum, occlusion_bits, occw, toff, (int)n_traj, C);
         TO_HIP_CHECK_LAUNCH();
     }
     return TOHIP_OK;
 }
 
-extern "C" int tohip_traj_reward(const void* packed, const float* lo_sum, int64_t n, float eps, int prefilled, float* rewards,
-                                 float* scalars, void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!packed || !lo_sum || !rewards || !scalars || !workspace || n <= 0) return TOHIP_EINVAL;
+extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
+                                  const tohip_camera* cam, const tohip_rig* rig, int flags, const uint32_t* occlusion_bits,
+                                  float* lo_sum, float* minmax, float* rewards_half, void* workspace, size_t workspace_bytes,
+                                  void* stream_) {
+    return tohip_traj_forward_multi(packed, n, poses, quats, W, nullptr, 1, cam, rig, flags, occlusion_bits, lo_sum, minmax, rewards_half,
+                                    workspace, workspace_bytes, stream_);
+}
+
+extern "C" int tohip_traj_reward_multi(const void* packed, const float* lo_sum, int64_t n, int64_t n_traj, float eps, int prefilled,
+                                       float* rewards, float* scalars, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!packed || !lo_sum || !rewards || !scalars || !workspace || n <= 0 || n_traj <= 0 || n_traj > 65535) return TOHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
-    if (workspace_bytes < sizeof(TrajCtl)) return TOHIP_ENOSPC;
-    TrajCtl* ctl = (TrajCtl*)workspace;   // TrajPlan::off_ctl == 0
+    if (workspace_bytes < sizeof(unsigned long long) * (size_t)n_traj) return TOHIP_ENOSPC;
+    unsigned long long* acc = (unsigned long long*)workspace;   // TrajPlan::off_ctl == 0
     const CloudView cv = cloud_view(packed, n);
     int nb = (int)((n + 4 * TO_REWARD_THREADS - 1) / (4 * TO_REWARD_THREADS));
     if (nb > TO_REWARD_BLOCKS) nb = TO_REWARD_BLOCKS;
     int lg = 0;
     while (((int64_t)1 << lg) < n) ++lg;
     TO_PROF(TOHIP_PROF_REWARD, st);
-    k_traj_reward<<<nb, TO_REWARD_THREADS, 0, st>>>(lo_sum, cv.perm, n, eps, 47 - lg, prefilled ? 1 : 0, rewards, &ctl->reward_acc, scalars);
+    k_traj_reward<<<dim3(nb, (unsigned)n_traj), TO_REWARD_THREADS, 0, st>>>(lo_sum, cv.perm, n, cv.npad, eps, 47 - lg, prefilled ? 1 : 0, rewards,
+                                                                            acc, scalars);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
 
-extern "C" int tohip_traj_backward(const void* packed, int64_t n, int64_t W, const tohip_camera* cam, const tohip_rig* rig,
-                                   int flags, const uint32_t* occlusion_bits, const float* lo_sum, const float* grad_rewards,
-                                   const float* scalars, const float* gout, float* poses_grad, float* quats_grad,
-                                   void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!packed || !cam || !lo_sum || !poses_grad || !quats_grad || !workspace || n <= 0 || W <= 0 ||
+extern "C" int tohip_traj_reward(const void* packed, const float* lo_sum, int64_t n, float eps, int prefilled, float* rewards,
+                                 float* scalars, void* workspace, size_t workspace_bytes, void* stream_) {
+    return tohip_traj_reward_multi(packed, lo_sum, n, 1, eps, prefilled, rewards, scalars, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int tohip_traj_backward_multi(const void* packed, int64_t n, int64_t W, int64_t n_traj, const tohip_camera* cam,
+                                         const tohip_rig* rig, int flags, const uint32_t* occlusion_bits, const float* lo_sum,
+                                         const float* grad_rewards, const float* scalars, const float* gout, float* poses_grad,
+                                         float* quats_grad, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!packed || !cam || !lo_sum || !poses_grad || !quats_grad || !workspace || n <= 0 || W <= 0 || n_traj <= 0 ||
         (!grad_rewards && (!scalars || !gout)))
         return TOHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
     const int C = rig_cams(rig);
     const int64_t V = W * C;
-    const TrajPlan pl = make_plan(n, V, W);
+    const TrajPlan pl = make_plan(n, V, W, n_traj);
     if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
     char* ws = (char*)workspace;
     WayRec* rec = (WayRec*)(ws + pl.off_rec);
@@ -1240,10 +1301,10 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, int64_t W, con
     float* vgrad = (float*)(ws + pl.off_vgrad);
     const EvalK k = make_evalk(cam);
     const CloudView cv = cloud_view(packed, n);
-    const bool cull = !(flags & TOHIP_TRAJ_DENSE);
     const float* rq = (C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
     const float* rt = rq ? rig->rig_trans : nullptr;
     const int64_t occw = cv.npad / 32;
+    (void)flags;
     {
         TO_PROF(TOHIP_PROF_BWD, st);
         for (int64_t v0 = 0; v0 < V; v0 += 65535) {  // grid.y limit
@@ -1264,6 +1325,14 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, int64_t W, con
         TO_HIP_CHECK_LAUNCH();
     }
     return TOHIP_OK;
+}
+
+extern "C" int tohip_traj_backward(const void* packed, int64_t n, int64_t W, const tohip_camera* cam, const tohip_rig* rig,
+                                   int flags, const uint32_t* occlusion_bits, const float* lo_sum, const float* grad_rewards,
+                                   const float* scalars, const float* gout, float* poses_grad, float* quats_grad,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+    return tohip_traj_backward_multi(packed, n, W, 1, cam, rig, flags, occlusion_bits, lo_sum, grad_rewards, scalars, gout, poses_grad,
+                                     quats_grad, workspace, workspace_bytes, stream_);
 }
 
 // Diagnostic (bench.py's roofline leg, never on in a timed pass): k_traj_pass1 stamps s_memtime / s_memrealtime per block into

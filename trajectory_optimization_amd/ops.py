@@ -81,10 +81,10 @@ class TrajWorkspace:
     """Scratch + step state of the ModelTraj kernels.  Zero-filled once (the C ABI's contract); `generation` counts the
     forwards that used it — the backward of a step must find the state its own forward left (model.py checks)."""
 
-    def __init__(self, cloud, n_virtual):
-        self.bytes = _lib.lib().tohip_traj_workspace_bytes(cloud.n, n_virtual)
+    def __init__(self, cloud, n_virtual, n_traj=1):
+        self.bytes = _lib.lib().tohip_traj_workspace_bytes_multi(cloud.n, n_virtual, n_traj)
         self.buf = torch.zeros(self.bytes, dtype=torch.uint8, device=cloud.device)
-        self.n_virtual = n_virtual
+        self.n_virtual, self.n_traj = n_virtual, n_traj
         self.generation = 0
 
 
@@ -132,6 +132,48 @@ def traj_backward(cloud, n_wps, cam, ws, lo_sum, grad_rewards=None, scalars=None
                                              rig.ref() if rig is not None else _NULL_RIG, int(flags), ptr(occ), ptr(lo_sum),
                                              ptr(grad_rewards), ptr(scalars), ptr(gout), ptr(pg), ptr(qg), ptr(ws.buf), ws.bytes,
                                              stream_ptr()), "tohip_traj_backward")
+    return pg, qg
+
+
+def traj_forward_multi(cloud, poses, quats, traj_offsets, cam, ws, rig=None, flags=0, lo_sum=None, minmax=None, rewards_half=None):
+    """Several trajectories over one cloud in one pass: `poses` (W,3) / `quats` (W,4) hold their waypoints end to end,
+    `traj_offsets` (B+1 int32 on the device) where each starts.  -> (lo_sum (B, npad), minmax (V, 2)); ws = TrajWorkspace(cloud, V, B)."""
+    W, B = poses.shape[0], traj_offsets.numel() - 1
+    C = rig.n_cams if rig is not None else 1
+    if lo_sum is None:
+        lo_sum = torch.empty((B, cloud.npad), dtype=torch.float32, device=cloud.device)
+    if minmax is None:
+        minmax = torch.empty((W * C, 2), dtype=torch.float32, device=cloud.device)
+    ws.generation += 1
+    with torch.cuda.device(cloud.device):
+        check(_lib.lib().tohip_traj_forward_multi(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, ptr(traj_offsets), B, cam.ref(),
+                                                  rig.ref() if rig is not None else _NULL_RIG, int(flags), None, ptr(lo_sum), ptr(minmax),
+                                                  ptr(rewards_half), ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_forward_multi")
+    return lo_sum, minmax
+
+
+def traj_reward_multi(cloud, lo_sum, cam, ws, rewards=None, scalars=None, prefilled=False):
+    """-> (rewards (B, N), scalars (B, 4)) for the B log-odds vectors of traj_forward_multi."""
+    B = lo_sum.shape[0]
+    if rewards is None:
+        rewards = torch.empty((B, cloud.n), dtype=torch.float32, device=cloud.device)
+    if scalars is None:
+        scalars = torch.empty((B, 4), dtype=torch.float32, device=cloud.device)
+    with torch.cuda.device(cloud.device):
+        check(_lib.lib().tohip_traj_reward_multi(ptr(cloud.blob), ptr(lo_sum), cloud.n, B, cam.eps, int(bool(prefilled)), ptr(rewards),
+                                                 ptr(scalars), ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_traj_reward_multi")
+    return rewards, scalars
+
+
+def traj_backward_multi(cloud, n_wps, n_traj, cam, ws, lo_sum, grad_rewards=None, scalars=None, gout=None, rig=None, flags=0):
+    """Gradients (W,3), (W,4) of all trajectories' waypoints; gout: (B,) dL/d loss_vis per trajectory."""
+    pg = torch.empty((n_wps, 3), dtype=torch.float32, device=cloud.device)
+    qg = torch.empty((n_wps, 4), dtype=torch.float32, device=cloud.device)
+    with torch.cuda.device(cloud.device):
+        check(_lib.lib().tohip_traj_backward_multi(ptr(cloud.blob), cloud.n, n_wps, n_traj, cam.ref(),
+                                                   rig.ref() if rig is not None else _NULL_RIG, int(flags), None, ptr(lo_sum),
+                                                   ptr(grad_rewards), ptr(scalars), ptr(gout), ptr(pg), ptr(qg), ptr(ws.buf), ws.bytes,
+                                                   stream_ptr()), "tohip_traj_backward_multi")
     return pg, qg
 
 

@@ -120,6 +120,79 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
     return TrajOptResult(steps, bool(st[2].item() != 0), lt_host[:, 4].tolist(), float(st[4]), float(st[5]))
 
 
+@torch.no_grad()
+def optimize_trajectories(models, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards_th=1.2, smoothness_th=0.9,
+                          vis_wps_dist=0.5, betas=(0.9, 0.999), adam_eps=1e-8):
+    """`optimize_trajectory` for several candidate trajectories over the SAME cloud at once: every step is one
+    set of launches for all of them — their evaluated waypoints go through the visibility kernels as one batch of virtual
+    waypoints, each trajectory keeps its own log-odds vector, rewards, loss terms, Adam moments and early-stop state (a
+    trajectory that has stopped stays put while the others go on).  Each model ends up exactly — bit for bit — where its own
+    `optimize_trajectory` run would have put it.  Models: ModelTraj built on the same points with the same camera, rig and
+    mode, equal numbers of waypoints and the same waypoint step; no sharding, no occlusion.  -> [TrajOptResult]."""
+    L = _lib.lib()
+    m0 = models[0]
+    B, dev = len(models), m0.device
+    cloud, cam, rig = m0._cloud, m0._cam, m0._rig
+    W = m0.poses.shape[0]
+    step_w = m0._wps_step(vis_wps_dist)
+    for m in models:
+        if (m.poses.shape[0] != W or m._wps_step(vis_wps_dist) != step_w or m._cloud.n != cloud.n or m._flags != m0._flags or
+                (m._rig is None) != (rig is None) or m._shard.world_size > 1 or m._occlusion is not None or
+                bytes(m._cam.c) != bytes(cam.c) or m.smoothness_weight != m0.smoothness_weight or
+                m.traj_length_weight != m0.traj_length_weight):
+            raise ValueError("optimize_trajectories: the models must share the cloud, camera, rig, mode, waypoint count and step")
+        if m is not m0 and m.points.data_ptr() != m0.points.data_ptr() and not torch.equal(m.points, m0.points):
+            raise ValueError("optimize_trajectories: the models must be built on the same points")
+    n_eval = (W + step_w - 1) // step_w
+    C = rig.n_cams if rig else 1
+    f32 = dict(dtype=torch.float32, device=dev)
+    poses = torch.cat([m.poses.data for m in models]).contiguous()
+    quats = torch.cat([m.quats.data for m in models]).contiguous()
+    poses0 = torch.cat([m.poses0 for m in models]).contiguous()
+    toff = (torch.arange(B + 1, dtype=torch.int32) * n_eval).to(dev)
+    ws = ops.TrajWorkspace(cloud, B * n_eval * C, B)
+    poses_e, quats_e = torch.empty((B * n_eval, 3), **f32), torch.empty((B * n_eval, 4), **f32)
+    pg_e, qg_e = torch.empty((B * n_eval, 3), **f32), torch.empty((B * n_eval, 4), **f32)
+    pg, qg = torch.zeros((B * W, 3), **f32), torch.zeros((B * W, 4), **f32)
+    lo_sum = torch.empty((B, cloud.npad), **f32)
+    minmax = torch.empty((B * n_eval * C, 2), **f32)
+    rewards, scalars = torch.empty((B, cloud.n), **f32), torch.zeros((B, 4), **f32)
+    loss_terms = torch.zeros((B, n_opt_steps + 1, 8), **f32)
+    state = torch.zeros((B, 8), **f32)
+    gout = torch.ones(B, **f32)
+    mp, vp = torch.zeros((B * W, 3), **f32), torch.zeros((B * W, 3), **f32)
+    mq, vq = torch.zeros((B * W, 4), **f32), torch.zeros((B * W, 4), **f32)
+    rig_ref = rig.ref() if rig is not None else ops._NULL_RIG
+    with torch.cuda.device(dev):
+        for _ in range(n_opt_steps):
+            s = stream_ptr()
+            check(L.tohip_gather_waypoints_multi(ptr(poses), ptr(quats), W, B, n_eval, step_w, ptr(poses_e), ptr(quats_e), s), "gather")
+            check(L.tohip_traj_forward_multi(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), B * n_eval, ptr(toff), B, cam.ref(), rig_ref,
+                                             m0._flags, None, ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(ws.buf), ws.bytes, s), "forward")
+            ws.generation += 1
+            check(L.tohip_traj_reward_multi(ptr(cloud.blob), ptr(lo_sum), cloud.n, B, cam.eps, 1, ptr(rewards), ptr(scalars), ptr(ws.buf),
+                                            ws.bytes, s), "reward")
+            check(L.tohip_traj_backward_multi(ptr(cloud.blob), cloud.n, B * n_eval, B, cam.ref(), rig_ref, m0._flags, None, ptr(lo_sum), None,
+                                              ptr(scalars), ptr(gout), ptr(pg_e), ptr(qg_e), ptr(ws.buf), ws.bytes, s), "backward")
+            check(L.tohip_traj_step_tail_multi(ptr(poses), ptr(quats), ptr(poses0), W, B, ptr(pg_e), ptr(qg_e), n_eval, step_w, ptr(pg), ptr(qg),
+                                               ptr(mp), ptr(vp), ptr(mq), ptr(vq), float(m0.smoothness_weight), float(m0.traj_length_weight),
+                                               float(m0.eps), float(lr_pose), float(lr_quat), betas[0], betas[1], adam_eps, float(rewards_th),
+                                               float(smoothness_th), ptr(scalars), ptr(loss_terms), (n_opt_steps + 1) * 8, ptr(state), s),
+                  "step tail")
+    st = state.cpu()  # the run's only host synchronisation
+    lt = loss_terms.cpu()
+    results = []
+    for b, m in enumerate(models):
+        m.poses.data.copy_(poses[b * W:(b + 1) * W])
+        m.quats.data.copy_(quats[b * W:(b + 1) * W])
+        steps = int(st[b, 3].item())
+        row = lt[b, max(steps, 1) - 1]
+        m.rewards = rewards[b]
+        m.loss = {"vis": row[0], "l2": row[1], "length": row[2], "smooth": row[3]}
+        results.append(TrajOptResult(steps, bool(st[b, 2].item() != 0), lt[b, :max(steps, 1), 4].tolist(), float(st[b, 4]), float(st[b, 5])))
+    return results
+
+
 class PoseOptResult:
     def __init__(self, losses):
         self.losses = losses
