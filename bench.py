@@ -225,14 +225,36 @@ def main():
         L.tohip_profile_enable(0)
         return {L.tohip_profile_name(i).decode(): (ms[i], cnt[i]) for i in range(5) if cnt[i] > 0}
 
-    # headline: DENSE — every (point, waypoint) pair is evaluated
+    def in_kernel_span(flags):
+        """Diagnostic, outside every timed region: the dense kernel's blocks stamp s_memrealtime (100 MHz) at their start and end
+        (tohip_profile_clock); first start -> last end per XCD (each XCD has its own counter), the longest of the eight.
+        rocprofv3 / HIP-event durations of back-to-back launches also contain the queueing behind the previous kernel."""
+        nb = L.tohip_profile_clock_blocks(cloud.n, n_virtual, flags)
+        if nb <= 0:
+            return None, None
+        buf = torch.zeros(6 * nb, dtype=torch.int64, device=device)
+        L.tohip_profile_clock(buf.data_ptr())
+        for _ in range(3):
+            step(flags)
+        torch.cuda.synchronize(device)
+        L.tohip_profile_clock(None)
+        raw = buf.cpu().numpy()
+        pair, ext = raw[:2 * nb].reshape(nb, 2).astype(np.float64), raw[2 * nb:].reshape(nb, 4)
+        ok = pair[:, 1] > 0
+        spans = [(ext[(ext[:, 3] & 0xf) == x, 1].max() - ext[(ext[:, 3] & 0xf) == x, 0].min()) * 1e-5
+                 for x in range(8) if ((ext[:, 3] & 0xf) == x).any()]
+        return max(spans), float(np.median(pair[ok, 0] / pair[ok, 1]) * 0.1)
+
+    # headline: DENSE — every (point, waypoint) pair is evaluated.  The instrumented pass runs first (the chip is at its working
+    # clocks by the time the timed pass starts), then W warm-up + exactly K timed steps.
     dense_flags = ops.DENSE if args.mode != "culled" else 0
-    dt, out = timed(dense_flags)
     kern = kernel_times(dense_flags)
+    dt, out = timed(dense_flags)
+    span_ms, clock_ghz = in_kernel_span(dense_flags) if (dense_flags and n_gpus == 1) else (None, None)
     # the library's default path: exact culling (bitwise identical outputs, tests/test_hip_traj.py)
     if args.mode == "both":
-        dt_c, out_c = timed(0)
         kern_c = kernel_times(0)
+        dt_c, out_c = timed(0)
     else:
         dt_c, out_c, kern_c = dt, out, kern
     evals_per_step = args.points * w_total * args.cameras
@@ -273,6 +295,13 @@ def main():
                          "peak_note": f"{N_SIMDS} SIMDs x {CLOCK_GHZ} GHz; frac is a lower bound of the SIMDs' VALU-busy fraction "
                                       "(the chip clocks 2.2-2.4 GHz under this load; packed f32 measures 4.0-4.4 cycles)",
                          "valu_busy_pmc": valu_busy,
+                         "in_kernel": None if span_ms is None else {
+                             "span_ms": span_ms, "clock_ghz": clock_ghz,
+                             "frac_of_peak": issue_cycles / (span_ms * 1e-3) / 1e9 / peak,
+                             "frac_at_measured_clock": issue_cycles / (span_ms * 1e-3) / 1e9 / (N_SIMDS * clock_ghz),
+                             "note": "first block start -> last block end (s_memrealtime stamps inside the kernel, a separate "
+                                     "diagnostic pass): what the blocks themselves take; kernel_ms_per_launch also holds the "
+                                     "launch / queueing share of a back-to-back dependent launch"},
                          "hbm_counter_frac": (traffic / (p1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "traffic_note": "HBM bytes per launch from profiles/r02_bench_dense_pmc.json (separate --pmc passes of "
                                          "this command); ~1 % of the HBM peak: points live in registers, waypoints stream "

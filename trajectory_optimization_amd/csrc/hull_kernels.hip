@@ -21,6 +21,8 @@
 //
 // Predicates are plain f64 (coordinate differences of f32 inputs are exact; products are rounded):
 // like Qhull's own, they are not exact on nearly coplanar quadruples — DESIGN.md §6.
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -1061,6 +1063,9 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
         if (e != hipSuccess) return (int)e;
         if (h[kCtrlError]) return (h[kCtrlError] & kErrCapacity) ? TOHIP_ENOSPC : TOHIP_ENOTCONV;
         nf = h[kCtrlNFaces];
+        static const bool trace = getenv("TOHIP_HULL_TRACE") != nullptr;   // experiments: the build's progress, one line per readback
+        if (trace) fprintf(stderr, "hull: round %d faces %d live %d alive %d accepted(last) %d sweeps %d careful %d\n", round, nf, h[kCtrlNLive],
+                           h[kCtrlNAlive], h[kCtrlAccepted2], sweeps, (int)careful);
         if (!h[kCtrlAnyOutside2]) break;  // the last round found no point outside any face: the hull is complete
         if (++batches_since_compaction >= 2 && h[kCtrlNLive] > 4096) {
             // drop the points that have retired inside the hull from the list the point kernels walk
