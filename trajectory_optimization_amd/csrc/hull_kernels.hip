@@ -651,6 +651,49 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_push(Bufs b, int sweep, int 
     }
 }
 
+// The ownership propagation of a round in ONE launch: the thread of a candidate face walks the region its apex sees
+// (depth first, a private stack) and claims every face of it that no better candidate holds, stealing from worse ones —
+// what the push sweeps above spread over 4..12 launches of frontier queues.  Which faces end up claimed by a LOSING candidate
+// depends on arrival order, the winners' regions do not: k_accept admits a candidate only if it owns every face its apex sees
+// and borders no better region, so an incomplete walk (stack or claim budget exhausted, a face stolen later) can only cost
+// that candidate this round.  Regions are a handful of faces on average (the visible set of a point just outside a polytope);
+// a candidate whose region outgrows the budget waits for the careful path (k_owner_prop to convergence).
+constexpr int kClaimStack = 64, kClaimMax = 512;
+__global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b) {
+    const int round = b.ctrl[kCtrlRound];
+    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
+    const int stride = gridDim.x * TO_BLOCK;
+    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
+        const int o = face_at(b, fw, j);
+        if (!(b.fflags[o] & 2)) continue;          // candidates only (k_round_reset)
+        if (b.fowner[o] != o) continue;            // a better candidate's walk has already taken this face
+        const unsigned long long po = prio(o, round);
+        const int apex = b.inv[b.fapex[o]];
+        int stack[kClaimStack];
+        int sp = 0, claimed = 0;
+        stack[sp++] = o;
+        while (sp > 0 && claimed < kClaimMax) {
+            const int cg = stack[--sp];
+            for (int k = 0; k < 3; ++k) {
+                const int n = b.fn[3 * cg + k];
+                int cur = b.fowner[n];
+                if (cur == o || (cur >= 0 && prio(cur, round) <= po)) continue;
+                if (!(fdist(b, n, apex) > 0.0)) continue;
+                bool mine = false;
+                while (true) {
+                    const int old = atomicCAS(&b.fowner[n], cur, o);
+                    if (old == cur) { mine = true; break; }
+                    cur = old;
+                    if (cur == o || (cur >= 0 && prio(cur, round) <= po)) break;
+                }
+                if (!mine) continue;
+                ++claimed;
+                if (sp < kClaimStack) stack[sp++] = n;   // a full stack drops the face's neighbours: the walk stays incomplete (safe)
+            }
+        }
+    }
+}
+
 // each live face adopts the best-priority owner among its neighbours whose apex sees it
 __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b) {
     const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
@@ -825,7 +868,10 @@ __global__ void __launch_bounds__(TO_BLOCK) k_commit(Bufs b) {
     const int stride = gridDim.x * TO_BLOCK;
     for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
         const int g = face_at(b, fw, j);
-        if (b.newface[3 * g] == -2) { b.fflags[g] = 0; b.newface[3 * g] = kNone; }
+        // the faces of the accepted regions die.  Only the alive bit goes: owned_accepted() of the region's other faces — read
+        // by other threads of this launch — looks at the owner's ACCEPTED bit and at fowner, which stay until the next round's reset
+        int o;
+        if ((b.fflags[g] & 1) && owned_accepted(b, g, &o)) { b.fflags[g] &= ~1; b.newface[3 * g] = kNone; }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int nf = b.ctrl[kCtrlNFaces + 8];
@@ -1026,9 +1072,13 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
             k_round_reset<<<gf, TO_BLOCK, 0, st>>>(b);
             TO_HIP_CHECK_LAUNCH();
             int last_front = -1;
-            if (!careful) {
-                // Fast path: a fixed number of push sweeps, no readback.  Unconverged ownership is safe — a candidate
-                // is accepted only if it owns every face its apex sees (k_accept) — it can only cost progress.
+            static const bool use_sweeps = getenv("TOHIP_HULL_SWEEPS") != nullptr;   // experiments: the frontier-queue sweeps
+            if (!careful && !use_sweeps) {
+                // Fast path: every candidate's thread walks and claims its region (one launch, no readback).  Incomplete
+                // ownership is safe — a candidate is accepted only if it owns every face its apex sees (k_accept).
+                k_owner_claim<<<gf, TO_BLOCK, 0, st>>>(b);
+                TO_HIP_CHECK_LAUNCH();
+            } else if (!careful) {
                 const int gs = gf < 256 ? gf : 256;
                 for (int it = 0; it < sweeps; ++it)
                     k_owner_push<<<it == 0 ? gf : gs, TO_BLOCK, 0, st>>>(b, it, ((round & 0xffffff) << 7) + it + 1);
@@ -1053,7 +1103,6 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
             k_link_faces<<<gf, TO_BLOCK, 0, st>>>(b);
             k_reassign<<<nblocks(live_bound, 1024), TO_BLOCK, 0, st>>>(b);
             k_far_arg<<<nblocks(live_bound), TO_BLOCK, 0, st>>>(b, 0);  // apexes of the faces created this round
-            k_kill_faces<<<gf, TO_BLOCK, 0, st>>>(b);
             k_commit<<<nblocks((int64_t)nf * 4), TO_BLOCK, 0, st>>>(b);
             TO_HIP_CHECK_LAUNCH();
         }
