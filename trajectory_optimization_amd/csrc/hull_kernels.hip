@@ -433,6 +433,45 @@ k_load(Bufs b, const float* __restrict__ pts, int with_origin) {
 
 // block-wide argmax of (key, lowest index on ties); all threads get the winner
 #define HULL_INIT_THREADS 1024
+// thread 0 of a segment's block: status, and the four faces of its initial tetrahedron (face slots 4*sg .. 4*sg+3)
+__device__ void init_tetrahedron(const Bufs& b, int sg, bool enough, bool has_nan, int i0, int i1, int i2, int i3, double kk, double k2,
+                                 double k3, double nx, double ny, double nz, double x0, double y0, double z0) {
+    const int lo = b.seg_off[sg], fb = 4 * sg;
+    {
+        const bool flat = enough && (!(kk > 0.0) || !(k2 > 0.0) || !(k3 > 0.0));
+        b.seg_status[sg] = has_nan ? 3 : (!enough ? 1 : (flat ? 2 : 0));
+        if (!enough || flat) {
+            // the single-hull entry points refuse, like scipy (ValueError) and Qhull (QH6154/QH6214)
+            if (b.nseg == 1) b.ctrl[kCtrlError] = has_nan ? kErrNaN : kErrFlat;
+            // no hull for this segment: its four face slots stay dead (never candidates, never neighbours of a live face)
+            for (int f = fb; f < fb + 4; ++f) {
+                for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = lo; b.fn[3 * f + k] = f; }
+                b.frec[f] = FaceRec{0.0, 0.0, 0.0, b.px[lo], b.py[lo], b.pz[lo], kNone, {0, 0, 0}};
+                b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = 0x7fffffff; b.fstamp[f] = 0;
+                b.newface[3 * f] = kNone;
+            }
+            return;
+        }
+        int a = i0, c1 = i1, c2 = i2;
+        const int d = i3;
+        const double s = nx * (b.px[d] - x0) + ny * (b.py[d] - y0) + nz * (b.pz[d] - z0);
+        if (s > 0.0) { const int tmp = c1; c1 = c2; c2 = tmp; }  // d must lie below face (a,c1,c2)
+        const int F[4][3] = {{a, c1, c2}, {c1, a, d}, {c2, c1, d}, {a, c2, d}};
+        const int Nb[4][3] = {{1, 2, 3}, {0, 3, 2}, {0, 1, 3}, {0, 2, 1}};
+        for (int j = 0; j < 4; ++j) {
+            const int f = fb + j;
+            for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = F[j][k]; b.fn[3 * f + k] = fb + Nb[j][k]; }
+            set_plane(b, f);
+            b.fflags[f] = 1;
+            b.fowner[f] = kNone;
+            b.fmax[f] = 0ull;
+            b.fapex[f] = 0x7fffffff;
+            b.fstamp[f] = 0;
+            b.newface[3 * f] = kNone;
+        }
+    }
+}
+
 __device__ int block_argmax(double key, int idx, double* skey, int* sidx, double* out_key) {
     const int t = threadIdx.x;
     skey[t] = key; sidx[t] = idx;
@@ -494,38 +533,84 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
         }
         i3 = b.inv[block_argmax(best, bi, skey, sidx, &k3)];
     }
-    if (t == 0) {
-        const bool flat = enough && (!(kk > 0.0) || !(k2 > 0.0) || !(k3 > 0.0));
-        b.seg_status[sg] = has_nan ? 3 : (!enough ? 1 : (flat ? 2 : 0));
-        if (!enough || flat) {
-            // the single-hull entry points refuse, like scipy (ValueError) and Qhull (QH6154/QH6214)
-            if (b.nseg == 1) b.ctrl[kCtrlError] = has_nan ? kErrNaN : kErrFlat;
-            // no hull for this segment: its four face slots stay dead (never candidates, never neighbours of a live face)
-            for (int f = fb; f < fb + 4; ++f) {
-                for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = lo; b.fn[3 * f + k] = f; }
-                b.frec[f] = FaceRec{0.0, 0.0, 0.0, b.px[lo], b.py[lo], b.pz[lo], kNone, {0, 0, 0}};
-                b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = 0x7fffffff; b.fstamp[f] = 0;
-                b.newface[3 * f] = kNone;
-            }
-            return;
+    if (t == 0) init_tetrahedron(b, sg, enough, has_nan, i0, i1, i2, i3, kk, k2, k3, nx, ny, nz, x0, y0, z0);
+}
+
+// ---- the same for ONE large segment, spread over many blocks: four passes over the points, each block leaving its best
+// (key, caller's index) in `part`; the next launch's blocks first fold the previous pass's partials (all of them, redundantly)
+// and go on.  A single block walking a million points four times was 1.5 ms of a 19 ms build.
+constexpr int kInitBlocks = 128;
+struct InitSel { int i[4]; double key[4]; };
+
+__device__ __forceinline__ int init_fold(const Bufs& b, const double* __restrict__ pkey, const int* __restrict__ pidx, int nparts,
+                                         double* skey, int* sidx, double* out_key) {
+    const int t = threadIdx.x;
+    double best = -INFINITY; int bi = 0x7fffffff;
+    for (int j = t; j < nparts; j += HULL_INIT_THREADS) {
+        const double k = pkey[j]; const int e = pidx[j];
+        if (k > best || (k == best && e < bi)) { best = k; bi = e; }
+    }
+    return b.inv[block_argmax(best, bi, skey, sidx, out_key)];
+}
+
+__global__ void __launch_bounds__(HULL_INIT_THREADS) k_init1_pass(Bufs b, int pass, double* __restrict__ pkey, int* __restrict__ pidx,
+                                                                  InitSel* __restrict__ sel) {
+    __shared__ double skey[HULL_INIT_THREADS];
+    __shared__ int sidx[HULL_INIT_THREADS];
+    const int t = threadIdx.x, lo = b.seg_off[0], hi = b.seg_off[1];
+    const int nparts = gridDim.x;
+    double x0 = 0, y0 = 0, z0 = 0, ex = 0, ey = 0, ez = 0, nx = 0, ny = 0, nz = 0;
+    if (b.seg_nan[0] != 0) return;  // refused in the finish kernel; no keys to compare
+    if (pass >= 1) {
+        // previous pass's result (every block folds the same partials: same answer everywhere; block 0 records it)
+        double key;
+        const int ip = init_fold(b, pkey + (size_t)(pass - 1) * kInitBlocks, pidx + (size_t)(pass - 1) * kInitBlocks, nparts, skey, sidx, &key);
+        if (blockIdx.x == 0 && t == 0) { sel->i[pass - 1] = ip; sel->key[pass - 1] = key; }
+        const int i0 = pass == 1 ? ip : sel->i[0];
+        x0 = b.px[i0]; y0 = b.py[i0]; z0 = b.pz[i0];
+        if (pass >= 2) {
+            const int i1 = pass == 2 ? ip : sel->i[1];
+            ex = b.px[i1] - x0; ey = b.py[i1] - y0; ez = b.pz[i1] - z0;
         }
-        int a = i0, c1 = i1, c2 = i2;
-        const int d = i3;
-        const double s = nx * (b.px[d] - x0) + ny * (b.py[d] - y0) + nz * (b.pz[d] - z0);
-        if (s > 0.0) { const int tmp = c1; c1 = c2; c2 = tmp; }  // d must lie below face (a,c1,c2)
-        const int F[4][3] = {{a, c1, c2}, {c1, a, d}, {c2, c1, d}, {a, c2, d}};
-        const int Nb[4][3] = {{1, 2, 3}, {0, 3, 2}, {0, 1, 3}, {0, 2, 1}};
-        for (int j = 0; j < 4; ++j) {
-            const int f = fb + j;
-            for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = F[j][k]; b.fn[3 * f + k] = fb + Nb[j][k]; }
-            set_plane(b, f);
-            b.fflags[f] = 1;
-            b.fowner[f] = kNone;
-            b.fmax[f] = 0ull;
-            b.fapex[f] = 0x7fffffff;
-            b.fstamp[f] = 0;
-            b.newface[3 * f] = kNone;
+        if (pass >= 3) {
+            const double fx = b.px[ip] - x0, fy = b.py[ip] - y0, fz = b.pz[ip] - z0;
+            nx = ey * fz - ez * fy; ny = ez * fx - ex * fz; nz = ex * fy - ey * fx;
         }
+    }
+    double best = -INFINITY; int bi = 0x7fffffff;
+    for (int i = lo + blockIdx.x * HULL_INIT_THREADS + t; i < hi; i += nparts * HULL_INIT_THREADS) {
+        const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
+        double k;
+        if (pass == 0) k = -b.px[i];
+        else if (pass == 1) k = dx * dx + dy * dy + dz * dz;
+        else if (pass == 2) { const double cx = dy * ez - dz * ey, cy = dz * ex - dx * ez, cz = dx * ey - dy * ex; k = cx * cx + cy * cy + cz * cz; }
+        else k = fabs(nx * dx + ny * dy + nz * dz);
+        const int e = b.perm[i];
+        if (k > best || (k == best && e < bi)) { best = k; bi = e; }
+    }
+    double bk;
+    const int r = block_argmax(best, bi, skey, sidx, &bk);
+    if (t == 0) { pkey[(size_t)pass * kInitBlocks + blockIdx.x] = bk; pidx[(size_t)pass * kInitBlocks + blockIdx.x] = r; }
+}
+
+__global__ void __launch_bounds__(HULL_INIT_THREADS) k_init1_finish(Bufs b, int nparts, const double* __restrict__ pkey,
+                                                                    const int* __restrict__ pidx, const InitSel* __restrict__ sel) {
+    __shared__ double skey[HULL_INIT_THREADS];
+    __shared__ int sidx[HULL_INIT_THREADS];
+    if (b.seg_nan[0] != 0) {
+        const int lo = b.seg_off[0];
+        if (threadIdx.x == 0) init_tetrahedron(b, 0, false, true, lo, lo, lo, lo, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);
+        return;
+    }
+    double k3;
+    const int i3 = init_fold(b, pkey + (size_t)3 * kInitBlocks, pidx + (size_t)3 * kInitBlocks, nparts, skey, sidx, &k3);
+    if (threadIdx.x == 0) {
+        const int i0 = sel->i[0], i1 = sel->i[1], i2 = sel->i[2];
+        const double x0 = b.px[i0], y0 = b.py[i0], z0 = b.pz[i0];
+        const double ex = b.px[i1] - x0, ey = b.py[i1] - y0, ez = b.pz[i1] - z0;
+        const double fx = b.px[i2] - x0, fy = b.py[i2] - y0, fz = b.pz[i2] - z0;
+        init_tetrahedron(b, 0, true, false, i0, i1, i2, i3, sel->key[1], sel->key[2], k3, ey * fz - ez * fy, ez * fx - ex * fz,
+                         ex * fy - ey * fx, x0, y0, z0);
     }
 }
 
@@ -1040,7 +1125,16 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
     }
     k_load<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, pts, with_origin);
     TO_HIP_CHECK_LAUNCH();
-    k_init<<<b.nseg, HULL_INIT_THREADS, 0, st>>>(b);
+    if (b.nseg == 1 && b.m1 >= 65536) {
+        // keys2 (8 bytes per point) is free again after the sort: the passes' partials and the selections live there
+        double* pkey = (double*)b.keys2;
+        int* pidx = (int*)(pkey + 4 * kInitBlocks);
+        InitSel* sel = (InitSel*)(pidx + 4 * kInitBlocks);
+        for (int pass = 0; pass < 4; ++pass) k_init1_pass<<<kInitBlocks, HULL_INIT_THREADS, 0, st>>>(b, pass, pkey, pidx, sel);
+        k_init1_finish<<<1, HULL_INIT_THREADS, 0, st>>>(b, kInitBlocks, pkey, pidx, sel);
+    } else {
+        k_init<<<b.nseg, HULL_INIT_THREADS, 0, st>>>(b);
+    }
     TO_HIP_CHECK_LAUNCH();
     k_assign0<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
     k_far_arg<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, 1);
@@ -1061,7 +1155,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
     // Rounds are enqueued in batches with ONE readback per batch: every kernel takes its face counts from the control
     // block on the device and walks its arrays with a grid stride, so the host's (stale) counts only size the grids.
     // A round enqueued after the hull is complete finds no candidate and changes nothing.
-    const int batch = 4;
+    static const int batch = getenv("TOHIP_HULL_BATCH") ? atoi(getenv("TOHIP_HULL_BATCH")) : 4;  // experiments: rounds per readback
     int batches_since_compaction = 0, live_bound = b.m1;
     const int face_tiles_cap = (b.fcap + 1023) / 1024;
 
