@@ -30,10 +30,8 @@
 namespace hull {
 
 constexpr int kNone = -1;
-constexpr int kCtrlNFaces = 0, kCtrlAnyOutside = 1, kCtrlChanged = 2, kCtrlError = 3, kCtrlAccepted = 4,
-              kCtrlRound = 5, kCtrlChanged2 = 6, kCtrlAnyOutside2 = 7, kCtrlAccepted2 = 9 /* the round's values, published by
-              k_commit for the host while the live counters are cleared for the next round; [8] = staged face counter */,
-              kCtrlFront = 10 /* [10..12]: three rotating frontier counters of the ownership sweeps */,
+constexpr int kCtrlNFaces = 0 /* published face count; [8] = staged face counter */, kCtrlChanged = 2, kCtrlError = 3,
+              kCtrlAccepted = 4, kCtrlRound = 5, kCtrlNCand = 10 /* entries of the candidate list */,
               kCtrlNLive = 14 /* entries of the live-point list */,
               kCtrlNAlive = 13 /* entries of the alive-face list */, kCtrlNFc = 15 /* face count when that list was made */,
               kCtrlInts = 16;
@@ -56,11 +54,10 @@ struct Bufs {
     unsigned long long* fmax;  // fcap
     int* fapex;            // fcap   apex candidate as an EXPANDED index (ties go to the caller's lowest index); 0x7fffffff = none
     int* fowner;           // fcap
-    int* fflags;           // fcap   bit0 alive, bit1 candidate accepted
+    int* fflags;           // fcap   bit0 alive, bit1 candidate / accepted, bit2 dies at the end of this round
     int* nfhead;           // fcap
     int* newface;          // 3 * fcap
-    int* front[2];         // fcap each: ping-pong frontiers of the ownership propagation
-    int* fstamp;           // fcap: sweep id a face was last queued in (one queue entry per face and sweep)
+    int* front;            // fcap: the round's candidate faces (written by the previous round's tail)
     int* ctrl;             // kCtrlInts
     int* vflag;            // M1
     int* tile_cnt;         // ntiles(M1)
@@ -105,8 +102,8 @@ __host__ inline size_t seg(size_t bytes) { return align_up(bytes, 256); }
 // The default suits clouds whose hull is a small fraction of the points (HPR of a scene: 2-5 %); a build that runs out
 // returns TOHIP_ENOSPC and the caller retries with a larger workspace — every byte beyond the fixed part is used for
 // faces (faces_for_bytes), up to the never-exceeded-in-practice 8 per point.
-constexpr size_t kBytesPerFace = 18 * sizeof(int) + sizeof(double) + 64 + 1;  // the per-face arrays carved below (+ scan scratch)
-constexpr int kFaceArrays = 20;
+constexpr size_t kBytesPerFace = 16 * sizeof(int) + sizeof(double) + 64 + 1;  // the per-face arrays carved below (+ scan scratch)
+constexpr int kFaceArrays = 18;
 
 __host__ inline int default_face_capacity(int64_t m1, int64_t nseg) {
     int64_t c = m1 / 2 + 64 * nseg + 4096;
@@ -133,9 +130,7 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * (size_t)fcap); if (b) b->fflags = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->nfhead = (int*)p;
     p = take(sizeof(int) * 3 * (size_t)fcap); if (b) b->newface = (int*)p;
-    p = take(sizeof(int) * (size_t)fcap); if (b) b->front[0] = (int*)p;
-    p = take(sizeof(int) * (size_t)fcap); if (b) b->front[1] = (int*)p;
-    p = take(sizeof(int) * (size_t)fcap); if (b) b->fstamp = (int*)p;
+    p = take(sizeof(int) * (size_t)fcap); if (b) b->front = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->alist = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->alist2 = (int*)p;
     p = take(sizeof(int) * kCtrlInts); if (b) b->ctrl = (int*)p;
@@ -196,11 +191,11 @@ __device__ __forceinline__ unsigned long long prio(int f, int round) {
 }
 
 // signed (unnormalised) distance of point i from the plane of face f; > 0 = strictly outside
-__device__ __forceinline__ double fdist(const Bufs& b, int f, int i) {
-    const FaceRec& r = b.frec[f];
-    const double dx = b.px[i] - r.x0, dy = b.py[i] - r.y0, dz = b.pz[i] - r.z0;
+__device__ __forceinline__ double plane_dist(const FaceRec& r, double x, double y, double z) {
+    const double dx = x - r.x0, dy = y - r.y0, dz = z - r.z0;
     return r.nx * dx + r.ny * dy + r.nz * dz;
 }
+__device__ __forceinline__ double fdist(const Bufs& b, int f, int i) { return plane_dist(b.frec[f], b.px[i], b.py[i], b.pz[i]); }
 
 __device__ __forceinline__ void set_plane(const Bufs& b, int f) {
     const int a = b.fv[3 * f], c1 = b.fv[3 * f + 1], c2 = b.fv[3 * f + 2];
@@ -447,7 +442,7 @@ __device__ void init_tetrahedron(const Bufs& b, int sg, bool enough, bool has_na
             for (int f = fb; f < fb + 4; ++f) {
                 for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = lo; b.fn[3 * f + k] = f; }
                 b.frec[f] = FaceRec{0.0, 0.0, 0.0, b.px[lo], b.py[lo], b.pz[lo], kNone, {0, 0, 0}};
-                b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = 0x7fffffff; b.fstamp[f] = 0;
+                b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = 0x7fffffff;
                 b.newface[3 * f] = kNone;
             }
             return;
@@ -466,7 +461,6 @@ __device__ void init_tetrahedron(const Bufs& b, int sg, bool enough, bool has_na
             b.fowner[f] = kNone;
             b.fmax[f] = 0ull;
             b.fapex[f] = 0x7fffffff;
-            b.fstamp[f] = 0;
             b.newface[3 * f] = kNone;
         }
     }
@@ -636,32 +630,20 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
 }
 
 // ---- round --------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(TO_BLOCK) k_round_reset(Bufs b) {
-    // per-round state of every face; faces that still have points outside them become candidates (owner = self)
-    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
-    const int stride = gridDim.x * TO_BLOCK;
-    bool any = false;
-    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
-        const int f = face_at(b, fw, j);
-        const int alive = b.fflags[f] & 1;
-        const bool cand = alive && b.fapex[f] != 0x7fffffff;  // fmax / fapex persist: an outside set is fixed at creation
-        b.fowner[f] = cand ? f : kNone;
-        b.nfhead[f] = kNone;
-        b.fflags[f] = alive | (cand ? 2 : 0);
-        any |= cand;
-    }
-    if (any) b.ctrl[kCtrlAnyOutside] = 1;
-}
+// Five launches: claim | accept | new faces | link + reassign | tail.  What each reads of the control block:
+//   kCtrlNFaces     published face count = the faces that existed before THIS round's insertions (written by k_accept)
+//   kCtrlNFaces + 8 staged count: every face created so far (k_new_faces allocates from it)
+//   kCtrlNCand      entries of the candidate list the tail of the previous round (or k_round_tail after the initial
+//                   tetrahedra) left for this round; 0 after a tail = the hulls are complete
+//   kCtrlAccepted   regions accepted this round
+// The tail prepares the NEXT round (per-face reset, candidate list), so a round has no separate reset launch.
 
-// apex of the faces with id >= f_lo (the faces created since the last call): lowest-index point among those at
-// the face's maximum distance.  A face's outside set never changes after its creation round, so its apex is
-// computed once; older faces keep theirs.
-__global__ void __launch_bounds__(TO_BLOCK) k_far_arg(Bufs b, int all_faces) {
-    // inside a round the published face count is still the count before this round's insertions
-    const int f_lo = all_faces ? 0 : b.ctrl[kCtrlNFaces];
+// apex of the faces with id >= f_lo: lowest caller's index among the points at the face's maximum distance.  A face's
+// outside set never changes after its creation round, so its apex is computed once; older faces keep theirs.
+__device__ __forceinline__ void far_arg_points(const Bufs& b, int f_lo, int vblock, int nvblocks) {
     const int nlive = b.ctrl[kCtrlNLive];
-    const int stride = gridDim.x * TO_BLOCK;
-    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < nlive; j += stride) {
+    const int stride = nvblocks * TO_BLOCK;
+    for (int j = vblock * TO_BLOCK + threadIdx.x; j < nlive; j += stride) {
         const int i = b.live[j];
         const int f = b.pface[i];
         if (f < f_lo) continue;
@@ -669,119 +651,72 @@ __global__ void __launch_bounds__(TO_BLOCK) k_far_arg(Bufs b, int all_faces) {
     }
 }
 
-// One push sweep of the ownership propagation: every queued face offers its owner to the neighbours that owner's
-// apex sees; a neighbour takes it if the owner ranks better than its current one, and is queued for the next sweep.
-// Work is proportional to the faces whose owner changed in the previous sweep, not to the size of the hull.
-// Sweep 0 takes the candidates straight from the face array (flag bit 1); sweep i > 0 reads queue i&1 / counter i%3.
-// Every sweep fills queue (i+1)&1 / counter (i+1)%3 and clears counter (i+2)%3.
-constexpr int kWalk = 4;
-__global__ void __launch_bounds__(TO_BLOCK) k_owner_push(Bufs b, int sweep, int epoch) {
-    const int round = b.ctrl[kCtrlRound];
-    const int* __restrict__ in = b.front[sweep & 1];
-    int* __restrict__ out = b.front[(sweep + 1) & 1];
-    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
-    const int n_in = sweep == 0 ? fw.total : min(b.ctrl[kCtrlFront + sweep % 3], b.fcap);
-    int* out_cnt = &b.ctrl[kCtrlFront + (sweep + 1) % 3];
-    if (blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlFront + (sweep + 2) % 3] = 0;
-    const int stride = gridDim.x * TO_BLOCK;
-    const int nloop = (n_in + stride - 1) / stride;
-    for (int it = 0; it < nloop; ++it) {
-        const int q = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
-        int push[2 * kWalk + 1];
-        int want = 0;
-        int g = kNone;
-        if (q < n_in) {
-            if (sweep == 0) { const int f = face_at(b, fw, q); if (b.fflags[f] & 2) g = f; }
-            else g = in[q];
-        }
-        if (g >= 0) {
-            const int o = b.fowner[g];
-            if (o >= 0) {
-                const unsigned long long po = prio(o, round);
-                const int apex = b.inv[b.fapex[o]];
-                // The thread keeps walking: of the neighbours it claims it continues with one itself (up to kWalk faces
-                // deep) and queues the others, so a region of a few faces is covered in one or two sweeps instead of
-                // one sweep — one launch — per ring.
-                int pending = g, depth = 0;
-                while (pending != kNone) {
-                    const int cg = pending;
-                    pending = kNone;
-                    if (depth == kWalk) {  // out of steps: the last claimed face goes to the queue like the others
-                        if (atomicExch(&b.fstamp[cg], epoch) != epoch) push[want++] = cg;
-                        break;
-                    }
-                    ++depth;
-                    for (int k = 0; k < 3; ++k) {
-                        const int n = b.fn[3 * cg + k];
-                        int cur = b.fowner[n];
-                        if (cur == o || (cur >= 0 && prio(cur, round) <= po)) continue;
-                        if (!(fdist(b, n, apex) > 0.0)) continue;
-                        bool claimed = false;
-                        while (true) {
-                            const int old = atomicCAS(&b.fowner[n], cur, o);
-                            if (old == cur) { claimed = true; break; }
-                            cur = old;
-                            if (cur == o || (cur >= 0 && prio(cur, round) <= po)) break;
-                        }
-                        if (!claimed) continue;
-                        if (pending == kNone) pending = n;
-                        else if (atomicExch(&b.fstamp[n], epoch) != epoch) push[want++] = n;
-                    }
-                }
-            }
-        }
-        int slot = block_alloc(out_cnt, want);
-        for (int k = 0; k < want; ++k, ++slot)
-            if (slot < b.fcap) out[slot] = push[k];
-    }
-}
+__global__ void __launch_bounds__(TO_BLOCK) k_far_arg_all(Bufs b) { far_arg_points(b, 0, blockIdx.x, gridDim.x); }
 
-// The ownership propagation of a round in ONE launch: the thread of a candidate face walks the region its apex sees
-// (depth first, a private stack) and claims every face of it that no better candidate holds, stealing from worse ones —
-// what the push sweeps above spread over 4..12 launches of frontier queues.  Which faces end up claimed by a LOSING candidate
-// depends on arrival order, the winners' regions do not: k_accept admits a candidate only if it owns every face its apex sees
-// and borders no better region, so an incomplete walk (stack or claim budget exhausted, a face stolen later) can only cost
-// that candidate this round.  Regions are a handful of faces on average (the visible set of a point just outside a polytope);
-// a candidate whose region outgrows the budget waits for the careful path (k_owner_prop to convergence).
-constexpr int kClaimStack = 64, kClaimMax = 512;
+// The ownership propagation of a round in ONE launch, one WAVE per candidate: breadth first over the region the candidate's
+// apex sees, the frontier in LDS, every (frontier face, edge) pair on its own lane — a level costs one chain of dependent
+// loads (neighbour id -> its owner -> its plane -> the claim) whatever the frontier's size, where one thread per candidate
+// paid that chain once per face (38 us per round at a million points against 10).  A face is claimed unless a better
+// candidate holds it (worse ones are robbed).  Which faces end up with a LOSING candidate depends on arrival order, the
+// winners' regions do not: k_accept admits a candidate only if it owns every face its apex sees and borders no better
+// region, so an incomplete walk (frontier or claim budget exhausted, a face stolen later) can only cost that candidate
+// this round; a round that accepts nobody is repeated with k_owner_prop run to convergence.
+constexpr int kClaimFront = 128, kClaimMax = 4096;
 __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b) {
+    __shared__ int fr[TO_WAVES_PER_BLOCK][2][kClaimFront];
     const int round = b.ctrl[kCtrlRound];
-    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
-    const int stride = gridDim.x * TO_BLOCK;
-    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
-        const int o = face_at(b, fw, j);
-        if (!(b.fflags[o] & 2)) continue;          // candidates only (k_round_reset)
-        if (b.fowner[o] != o) continue;            // a better candidate's walk has already taken this face
+    const int ncand = min(b.ctrl[kCtrlNCand], b.fcap);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nwaves = gridDim.x * TO_WAVES_PER_BLOCK;
+    const int* __restrict__ cand = b.front;
+    for (int c = blockIdx.x * TO_WAVES_PER_BLOCK + wid; c < ncand; c += nwaves) {
+        const int o = cand[c];
+        const int ax = b.fapex[o];
+        if (ax == 0x7fffffff) {  // no apex found for a face with points outside it (never seen): not a candidate
+            if (lane == 0) { b.fowner[o] = kNone; atomicAnd(&b.fflags[o], ~2); }
+            continue;
+        }
+        if (__hip_atomic_load(&b.fowner[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != o) continue;  // taken by a better one
         const unsigned long long po = prio(o, round);
-        const int apex = b.inv[b.fapex[o]];
-        int stack[kClaimStack];
-        int sp = 0, claimed = 0;
-        stack[sp++] = o;
-        while (sp > 0 && claimed < kClaimMax) {
-            const int cg = stack[--sp];
-            for (int k = 0; k < 3; ++k) {
-                const int n = b.fn[3 * cg + k];
-                int cur = b.fowner[n];
-                if (cur == o || (cur >= 0 && prio(cur, round) <= po)) continue;
-                if (!(fdist(b, n, apex) > 0.0)) continue;
+        const int apex = b.inv[ax];
+        const double px = b.px[apex], py = b.py[apex], pz = b.pz[apex];
+        int cur = 0, ncur = 1, claimed = 0;
+        if (lane == 0) fr[wid][0][0] = o;
+        while (ncur > 0 && claimed < kClaimMax) {
+            int nnext = 0;
+            for (int base = 0; base < 3 * ncur; base += 64) {
+                const int t = base + lane;
                 bool mine = false;
-                while (true) {
-                    const int old = atomicCAS(&b.fowner[n], cur, o);
-                    if (old == cur) { mine = true; break; }
-                    cur = old;
-                    if (cur == o || (cur >= 0 && prio(cur, round) <= po)) break;
+                int n = kNone;
+                if (t < 3 * ncur) {
+                    const int cg = fr[wid][cur][t / 3];
+                    n = b.fn[3 * cg + t % 3];
+                    int co = __hip_atomic_load(&b.fowner[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool sees = plane_dist(b.frec[n], px, py, pz) > 0.0;  // loaded alongside the owner, not after it
+                    if (sees && !(co == o || (co >= 0 && prio(co, round) <= po))) {
+                        while (true) {
+                            const int old = atomicCAS(&b.fowner[n], co, o);
+                            if (old == co) { mine = true; break; }  // two lanes on the same face: the second finds `o` there
+                            co = old;
+                            if (co == o || (co >= 0 && prio(co, round) <= po)) break;
+                        }
+                    }
                 }
-                if (!mine) continue;
-                ++claimed;
-                if (sp < kClaimStack) stack[sp++] = n;   // a full stack drops the face's neighbours: the walk stays incomplete (safe)
+                const unsigned long long bal = __ballot(mine);
+                const int pos = nnext + __popcll(bal & ((1ull << lane) - 1ull));
+                if (mine && pos < kClaimFront) fr[wid][cur ^ 1][pos] = n;  // beyond the frontier's size: the walk stays incomplete (safe)
+                nnext += __popcll(bal);
             }
+            claimed += nnext;
+            ncur = nnext < kClaimFront ? nnext : kClaimFront;
+            cur ^= 1;
         }
     }
 }
 
-// each live face adopts the best-priority owner among its neighbours whose apex sees it
+// each live face adopts the best-priority owner among its neighbours whose apex sees it (the careful path, to convergence)
 __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b) {
-    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
+    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces + 8]);
     const int round = b.ctrl[kCtrlRound];
     const int stride = gridDim.x * TO_BLOCK;
     bool changed = false;
@@ -789,10 +724,11 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b) {
         const int g = face_at(b, fw, j);
         if (!(b.fflags[g] & 1)) continue;
         int best = b.fowner[g];
+        if (best == g && b.fapex[g] == 0x7fffffff) { b.fowner[g] = kNone; atomicAnd(&b.fflags[g], ~2); continue; }
         unsigned long long bp = best >= 0 ? prio(best, round) : ~0ull;
         for (int k = 0; k < 3; ++k) {
             const int o = b.fowner[b.fn[3 * g + k]];
-            if (o < 0 || o == best) continue;
+            if (o < 0 || o == best || b.fapex[o] == 0x7fffffff) continue;
             const unsigned long long op = prio(o, round);
             if (op < bp && fdist(b, g, b.inv[b.fapex[o]]) > 0.0) { best = o; bp = op; }
         }
@@ -801,18 +737,23 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b) {
     if (__any(changed) && (threadIdx.x & 63) == 0) b.ctrl[kCtrlChanged] = 1;
 }
 
-__global__ void __launch_bounds__(TO_BLOCK) k_accept(Bufs b, int last_front) {
-    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
+__global__ void __launch_bounds__(TO_BLOCK) k_accept(Bufs b) {
+    // nothing has been inserted yet this round: the staged count is the face count; it is published here for the kernels
+    // that run while k_new_faces raises the staged one
+    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces + 8]);
     const int round = b.ctrl[kCtrlRound];
-    // faces still queued after the last push sweep = ownership not converged (the host adapts the sweep count)
-    if (last_front >= 0 && blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlChanged] = b.ctrl[kCtrlFront + last_front] > 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        b.ctrl[kCtrlNFaces] = min(b.ctrl[kCtrlNFaces + 8], b.fcap);
+        b.ctrl[kCtrlAccepted] = 0;
+        b.ctrl[kCtrlNCand] = 0;  // read by the claim before this launch; refilled by the tail
+    }
     const int stride = gridDim.x * TO_BLOCK;
     for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
         const int g = face_at(b, fw, j);
         if (!(b.fflags[g] & 1)) continue;
         const int o = b.fowner[g];
         if (o < 0) continue;
-        if (b.fowner[o] != o) { continue; }  // o lost its own face: not a candidate (its flag is cleared below)
+        if (b.fowner[o] != o) { continue; }  // o lost its own face: not a candidate (owned_accepted() checks the same)
         const int apex = b.inv[b.fapex[o]];
         bool ok = true;
         for (int k = 0; k < 3; ++k) {
@@ -833,7 +774,8 @@ __device__ __forceinline__ bool owned_accepted(const Bufs& b, int g, int* owner)
     return o >= 0 && b.fowner[o] == o && (b.fflags[o] & 2);
 }
 
-// one new triangle (u, v, apex) per horizon edge (u, v) of an accepted region
+// one new triangle (u, v, apex) per horizon edge (u, v) of an accepted region; the region's faces get their death mark
+// (bit 2; the alive bit goes in the tail, when nobody looks at the region any more)
 __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b) {
     const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
     const int stride = gridDim.x * TO_BLOCK;
@@ -845,12 +787,13 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b) {
         bool hor[3] = {false, false, false};
         if (g >= 0 && (b.fflags[g] & 1) && owned_accepted(b, g, &o)) {
             for (int k = 0; k < 3; ++k) { hor[k] = b.fowner[b.fn[3 * g + k]] != o; want += hor[k]; }
+            atomicOr(&b.fflags[g], 4);
         } else {
             o = kNone;
         }
         const unsigned long long acc = __ballot(o >= 0 && g == o);
         if (acc != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&b.ctrl[kCtrlAccepted], __popcll(acc));
-        int id = block_alloc(&b.ctrl[kCtrlNFaces + 8], want);  // staged counter, folded in by k_commit
+        int id = block_alloc(&b.ctrl[kCtrlNFaces + 8], want);
         if (want == 0) continue;
         const int apex = b.inv[b.fapex[o]];
         for (int k = 0; k < 3; ++k) {
@@ -862,8 +805,6 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b) {
             b.fn[3 * id] = n; b.fn[3 * id + 1] = kNone; b.fn[3 * id + 2] = kNone;
             set_plane(b, id);
             b.fflags[id] = 1; b.fowner[id] = kNone; b.fmax[id] = 0ull; b.fapex[id] = 0x7fffffff; b.nfhead[id] = kNone;
-            b.fstamp[id] = 0;
-            b.newface[3 * id] = kNone;
             b.newface[3 * g + k] = id;
             b.frec[id].next = atomicExch(&b.nfhead[o], id);
             for (int j = 0; j < 3; ++j)
@@ -874,14 +815,13 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b) {
 }
 
 // sibling links: rotate around the horizon vertex v through the region's faces to the next horizon edge
-__global__ void __launch_bounds__(TO_BLOCK) k_link_faces(Bufs b) {
+__device__ __forceinline__ void link_faces(const Bufs& b, int vblock, int nvblocks) {
     const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);  // the published count: the faces that existed before this round
-    const int stride = gridDim.x * TO_BLOCK;
-    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
+    const int stride = nvblocks * TO_BLOCK;
+    for (int j = vblock * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
         const int g = face_at(b, fw, j);
-        if (!(b.fflags[g] & 1)) continue;
-        int o;
-        if (!owned_accepted(b, g, &o)) continue;
+        if (!(b.fflags[g] & 4)) continue;  // faces of the accepted regions only
+        const int o = b.fowner[g];
         for (int k = 0; k < 3; ++k) {
             // NB fn[g][k] of a region face is never rewritten, so "across a horizon edge" is still decidable
             if (b.fowner[b.fn[3 * g + k]] == o) continue;
@@ -906,25 +846,24 @@ __global__ void __launch_bounds__(TO_BLOCK) k_link_faces(Bufs b) {
 
 // points of deleted faces: the apex retires as a vertex, the rest move to the new face they are farthest
 // outside of, or retire inside the hull
-__global__ void __launch_bounds__(TO_BLOCK) k_reassign(Bufs b) {
-    __shared__ FaceMaxTable tab;
+__device__ __forceinline__ void reassign_points(const Bufs& b, FaceMaxTable& tab, int vblock, int nvblocks) {
     face_max_init(tab);
-    const int stride = gridDim.x * TO_BLOCK;
+    const int stride = nvblocks * TO_BLOCK;
     const int nlive = b.ctrl[kCtrlNLive];
     const int nloop = (nlive + stride - 1) / stride;
     for (int it = 0; it < nloop; ++it) {
-        const int j = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
+        const int j = vblock * TO_BLOCK + threadIdx.x + it * stride;
         const int i = j < nlive ? b.live[j] : 0;
         double best = 0.0; int bf = kNone;
         const int g = j < nlive ? b.pface[i] : kNone;
-        int o;
-        if (g >= 0 && owned_accepted(b, g, &o)) {
+        if (g >= 0 && (b.fflags[g] & 4)) {
+            const int o = b.fowner[g];
             if (b.perm[i] != b.fapex[o]) {
                 int steps = 0;
                 const double x = b.px[i], y = b.py[i], z = b.pz[i];
                 for (int f = b.nfhead[o]; f >= 0 && steps < (1 << 20); ++steps) {
                     const FaceRec r = b.frec[f];  // one line per step of the list: plane, anchor and link
-                    const double d = r.nx * (x - r.x0) + r.ny * (y - r.y0) + r.nz * (z - r.z0);
+                    const double d = plane_dist(r, x, y, z);
                     if (d > best) { best = d; bf = f; }
                     f = r.next;
                 }
@@ -936,45 +875,50 @@ __global__ void __launch_bounds__(TO_BLOCK) k_reassign(Bufs b) {
     face_max_flush(b, tab);
 }
 
-__global__ void __launch_bounds__(TO_BLOCK) k_kill_faces(Bufs b) {
-    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
-    const int stride = gridDim.x * TO_BLOCK;
-    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
-        const int g = face_at(b, fw, j);
-        int o;
-        if ((b.fflags[g] & 1) && owned_accepted(b, g, &o)) b.newface[3 * g] = -2;  // mark; cleared in k_commit
-    }
+// the new faces' links and the points' new conflict faces need the same thing — every face of the round created — and
+// nothing of each other: one launch, the first `link_blocks` blocks link, the others move points
+__global__ void __launch_bounds__(TO_BLOCK) k_link_reassign(Bufs b, int link_blocks) {
+    __shared__ FaceMaxTable tab;
+    if ((int)blockIdx.x < link_blocks) link_faces(b, blockIdx.x, link_blocks);
+    else reassign_points(b, tab, blockIdx.x - link_blocks, gridDim.x - link_blocks);
 }
 
-__global__ void __launch_bounds__(TO_BLOCK) k_commit(Bufs b) {
-    // bound: the staged count (final since k_new_faces ended) — the published one is rewritten below while other blocks
-    // of this kernel may still be starting; faces created this round carry no kill mark
-    const FaceWalk fw = face_walk(b, min(b.ctrl[kCtrlNFaces + 8], b.fcap));
+// End of a round = start of the next: apexes of the faces created this round (point loop), then per face: the accepted
+// regions' faces die, the per-round state is cleared, and the faces with points outside them enter the candidate list as
+// their own owners.  Also run once after the initial tetrahedra.
+__global__ void __launch_bounds__(TO_BLOCK) k_far_arg_new(Bufs b) { far_arg_points(b, b.ctrl[kCtrlNFaces], blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(TO_BLOCK) k_link_only(Bufs b) { link_faces(b, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(TO_BLOCK) k_reassign_only(Bufs b) {
+    __shared__ FaceMaxTable tab;
+    reassign_points(b, tab, blockIdx.x, gridDim.x);
+}
+
+__global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int with_far_arg) {
+    if (with_far_arg) far_arg_points(b, b.ctrl[kCtrlNFaces], blockIdx.x, gridDim.x);
+    const FaceWalk fw = face_walk(b, min(b.ctrl[kCtrlNFaces + 8], b.fcap));  // final since k_new_faces ended
     const int stride = gridDim.x * TO_BLOCK;
-    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
-        const int g = face_at(b, fw, j);
-        // the faces of the accepted regions die.  Only the alive bit goes: owned_accepted() of the region's other faces — read
-        // by other threads of this launch — looks at the owner's ACCEPTED bit and at fowner, which stay until the next round's reset
-        int o;
-        if ((b.fflags[g] & 1) && owned_accepted(b, g, &o)) { b.fflags[g] &= ~1; b.newface[3 * g] = kNone; }
+    const int nloop = (fw.total + stride - 1) / stride;
+    for (int it = 0; it < nloop; ++it) {
+        const int j = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
+        bool cand = false;
+        int f = kNone;
+        if (j < fw.total) {
+            f = face_at(b, fw, j);
+            const int fl = b.fflags[f];
+            const int alive = (fl & 1) && !(fl & 4);
+            cand = alive && b.fmax[f] != 0ull;  // fmax persists: an outside set is fixed at the face's creation
+            b.fowner[f] = cand ? f : kNone;
+            b.nfhead[f] = kNone;
+            b.fflags[f] = alive | (cand ? 2 : 0);
+        }
+        const int slot = block_alloc(&b.ctrl[kCtrlNCand], cand ? 1 : 0);
+        if (cand && slot < b.fcap) b.front[slot] = f;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int nf = b.ctrl[kCtrlNFaces + 8];
-        if (nf > b.fcap) nf = b.fcap;
-        b.ctrl[kCtrlNFaces] = nf;
-        b.ctrl[kCtrlRound] += 1;
-        b.ctrl[kCtrlChanged2] = b.ctrl[kCtrlChanged];
-        b.ctrl[kCtrlAnyOutside2] = b.ctrl[kCtrlAnyOutside];
-        b.ctrl[kCtrlAccepted2] = b.ctrl[kCtrlAccepted];
-        b.ctrl[kCtrlChanged] = 0;
-        b.ctrl[kCtrlAnyOutside] = 0;
-        b.ctrl[kCtrlAccepted] = 0;
-        b.ctrl[kCtrlFront] = 0; b.ctrl[kCtrlFront + 1] = 0; b.ctrl[kCtrlFront + 2] = 0;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlRound] += 1;  // nobody in this launch reads it
 }
 
 __global__ void __launch_bounds__(TO_BLOCK) k_mark_vertices(Bufs b) {
-    const int nf = b.ctrl[kCtrlNFaces];
+    const int nf = min(b.ctrl[kCtrlNFaces + 8], b.fcap);  // every face created (the published count lags by the last round)
     const int stride = gridDim.x * TO_BLOCK;
     for (int f = blockIdx.x * TO_BLOCK + threadIdx.x; f < nf; f += stride)
         if (b.fflags[f] & 1)
@@ -1112,7 +1056,8 @@ inline int nblocks(int64_t n, int cap = 2048) {
 static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_t st, int* rounds_out) {
     Bufs b = b_in;  // local copy: the two live-point buffers swap roles at every compaction
     k_bbox_init<<<(6 * b.nseg + TO_BLOCK - 1) / TO_BLOCK, TO_BLOCK, 0, st>>>(b);
-    k_bbox<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b, pts, with_origin);
+    // six same-address atomics per wave and segment: 4096 waves on ONE segment's box cost 0.27 ms, 512 cost 0.03
+    k_bbox<<<nblocks(b.m1, b.nseg == 1 ? 128 : 1024), TO_BLOCK, 0, st>>>(b, pts, with_origin);
     k_sort_keys<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, pts, with_origin);
     TO_HIP_CHECK_LAUNCH();
     {
@@ -1137,7 +1082,8 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
     }
     TO_HIP_CHECK_LAUNCH();
     k_assign0<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
-    k_far_arg<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, 1);
+    k_far_arg_all<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);
+    k_round_tail<<<nblocks(4 * (int64_t)b.nseg), TO_BLOCK, 0, st>>>(b, 0);  // the first round's candidates
     TO_HIP_CHECK_LAUNCH();
     int h[kCtrlInts];
     hipError_t e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);
@@ -1146,38 +1092,27 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
     if (e != hipSuccess) return (int)e;
     if (b.nseg == 1 && (h[kCtrlError] & kErrNaN)) return TOHIP_ENAN;
     if (b.nseg == 1 && (h[kCtrlError] & kErrFlat)) return TOHIP_EINVAL;
-    int nf = h[kCtrlNFaces];
+    int nf = h[kCtrlNFaces + 8];
     const int max_rounds = 100000;
     int round = 0;
     bool careful = false;  // after a round without progress: propagate ownership to convergence (host-checked)
-    const int min_sweeps = 4;
-    int sweeps = 6;        // ownership sweeps per round, adapted from the convergence flag of the last readback
-    // Rounds are enqueued in batches with ONE readback per batch: every kernel takes its face counts from the control
-    // block on the device and walks its arrays with a grid stride, so the host's (stale) counts only size the grids.
-    // A round enqueued after the hull is complete finds no candidate and changes nothing.
+    // Rounds are enqueued in batches with ONE readback per batch: every kernel takes its counts from the control block on
+    // the device and walks its arrays with a grid stride, so the host's (stale) counts only size the grids.  A round
+    // enqueued after the hull is complete finds no candidate and changes nothing.
     static const int batch = getenv("TOHIP_HULL_BATCH") ? atoi(getenv("TOHIP_HULL_BATCH")) : 4;  // experiments: rounds per readback
     int batches_since_compaction = 0, live_bound = b.m1;
     const int face_tiles_cap = (b.fcap + 1023) / 1024;
 
-    while (round < max_rounds) {
+    while (h[kCtrlNCand] > 0 && round < max_rounds) {
         const int nrounds = careful ? 1 : batch;
         const int gf = nblocks((int64_t)nf * 2);
         for (int r = 0; r < nrounds; ++r, ++round) {
-            k_round_reset<<<gf, TO_BLOCK, 0, st>>>(b);
-            TO_HIP_CHECK_LAUNCH();
-            int last_front = -1;
-            static const bool use_sweeps = getenv("TOHIP_HULL_SWEEPS") != nullptr;   // experiments: the frontier-queue sweeps
-            if (!careful && !use_sweeps) {
-                // Fast path: every candidate's thread walks and claims its region (one launch, no readback).  Incomplete
+            static const bool always_careful = getenv("TOHIP_HULL_CAREFUL") != nullptr;  // experiments
+            if (!careful && !always_careful) {
+                // Fast path: a wave per candidate walks and claims its region (one launch, no readback).  Incomplete
                 // ownership is safe — a candidate is accepted only if it owns every face its apex sees (k_accept).
-                k_owner_claim<<<gf, TO_BLOCK, 0, st>>>(b);
+                k_owner_claim<<<nblocks((int64_t)nf * 16), TO_BLOCK, 0, st>>>(b);
                 TO_HIP_CHECK_LAUNCH();
-            } else if (!careful) {
-                const int gs = gf < 256 ? gf : 256;
-                for (int it = 0; it < sweeps; ++it)
-                    k_owner_push<<<it == 0 ? gf : gs, TO_BLOCK, 0, st>>>(b, it, ((round & 0xffffff) << 7) + it + 1);
-                TO_HIP_CHECK_LAUNCH();
-                last_front = sweeps % 3;  // faces still queued here = not converged (seen in the batch's readback)
             } else {
                 while (true) {
                     e = hipMemsetAsync(b.ctrl + kCtrlChanged, 0, sizeof(int), st);
@@ -1192,12 +1127,18 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
                     if (!h[kCtrlChanged]) break;
                 }
             }
-            k_accept<<<gf, TO_BLOCK, 0, st>>>(b, last_front);
+            const int gr = nblocks(live_bound, 1024);
+            k_accept<<<gf, TO_BLOCK, 0, st>>>(b);
             k_new_faces<<<gf, TO_BLOCK, 0, st>>>(b);
-            k_link_faces<<<gf, TO_BLOCK, 0, st>>>(b);
-            k_reassign<<<nblocks(live_bound, 1024), TO_BLOCK, 0, st>>>(b);
-            k_far_arg<<<nblocks(live_bound), TO_BLOCK, 0, st>>>(b, 0);  // apexes of the faces created this round
-            k_commit<<<nblocks((int64_t)nf * 4), TO_BLOCK, 0, st>>>(b);
+            static const bool split_d = getenv("TOHIP_HULL_SPLIT_D") != nullptr, split_e = getenv("TOHIP_HULL_SPLIT_E") != nullptr;
+            if (split_d) {
+                k_link_only<<<gf, TO_BLOCK, 0, st>>>(b);
+                k_reassign_only<<<gr, TO_BLOCK, 0, st>>>(b);
+            } else {
+                k_link_reassign<<<gf + gr, TO_BLOCK, 0, st>>>(b, gf);
+            }
+            if (split_e) k_far_arg_new<<<nblocks(live_bound), TO_BLOCK, 0, st>>>(b);
+            k_round_tail<<<nblocks(live_bound > (int64_t)nf * 4 ? live_bound : (int64_t)nf * 4), TO_BLOCK, 0, st>>>(b, split_e ? 0 : 1);
             TO_HIP_CHECK_LAUNCH();
         }
         e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);  // the batch's one readback
@@ -1205,12 +1146,13 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
         e = hipStreamSynchronize(st);
         if (e != hipSuccess) return (int)e;
         if (h[kCtrlError]) return (h[kCtrlError] & kErrCapacity) ? TOHIP_ENOSPC : TOHIP_ENOTCONV;
-        nf = h[kCtrlNFaces];
+        nf = h[kCtrlNFaces + 8] < b.fcap ? h[kCtrlNFaces + 8] : b.fcap;
         static const bool trace = getenv("TOHIP_HULL_TRACE") != nullptr;   // experiments: the build's progress, one line per readback
-        if (trace) fprintf(stderr, "hull: round %d faces %d live %d alive %d accepted(last) %d sweeps %d careful %d\n", round, nf, h[kCtrlNLive],
-                           h[kCtrlNAlive], h[kCtrlAccepted2], sweeps, (int)careful);
-        if (!h[kCtrlAnyOutside2]) break;  // the last round found no point outside any face: the hull is complete
-        if (++batches_since_compaction >= 2 && h[kCtrlNLive] > 4096) {
+        if (trace) fprintf(stderr, "hull: round %d faces %d live %d alive %d candidates %d accepted(last) %d careful %d\n", round, nf,
+                           h[kCtrlNLive], h[kCtrlNAlive], h[kCtrlNCand], h[kCtrlAccepted], (int)careful);
+        if (h[kCtrlNCand] == 0) break;  // no face has a point outside it: the hull is complete
+        static const int compact_every = getenv("TOHIP_HULL_COMPACT") ? atoi(getenv("TOHIP_HULL_COMPACT")) : 2;  // experiments
+        if (++batches_since_compaction >= compact_every && h[kCtrlNLive] > 4096) {
             // drop the points that have retired inside the hull from the list the point kernels walk
             const int nlive = h[kCtrlNLive], ntl = (nlive + 1023) / 1024;
             k_live_count<<<ntl, TO_BLOCK, 0, st>>>(b, nlive, b.tile_cnt);
@@ -1230,11 +1172,10 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
             TO_HIP_CHECK_LAUNCH();
             t = b.alist; b.alist = b.alist2; b.alist2 = t;
         }
-        if (h[kCtrlAccepted2] <= 0) {
+        if (h[kCtrlAccepted] <= 0) {
             if (careful) return TOHIP_ENOTCONV;  // converged ownership always admits the best candidate: inconsistent predicates
             careful = true;
         } else {
-            if (!careful) sweeps = h[kCtrlChanged2] ? (sweeps < 64 ? sweeps * 2 : 64) : (sweeps > min_sweeps ? sweeps - 1 : min_sweeps);
             careful = false;
         }
     }
