@@ -21,6 +21,7 @@
 //
 // Predicates are plain f64 (coordinate differences of f32 inputs are exact; products are rounded):
 // like Qhull's own, they are not exact on nearly coplanar quadruples — DESIGN.md §6.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -31,10 +32,15 @@ namespace hull {
 
 constexpr int kNone = -1;
 constexpr int kCtrlNFaces = 0 /* published face count; [8] = staged face counter */, kCtrlChanged = 2, kCtrlError = 3,
-              kCtrlAccepted = 4, kCtrlRound = 5, kCtrlNCand = 10 /* entries of the candidate list */,
-              kCtrlNLive = 14 /* entries of the live-point list */,
-              kCtrlNAlive = 13 /* entries of the alive-face list */, kCtrlNFc = 15 /* face count when that list was made */,
-              kCtrlInts = 16;
+              kCtrlAccepted = 4, kCtrlOverflow = 5 /* a sub-list of claimed faces ran full this round */,
+              kCtrlNLive = 14 /* entries of the live-point list */, kCtrlInts = 16;
+// The faces a round works on are kept in lists, each cut into kSubLists sub-lists with counters 128 bytes apart (appends to
+// ONE counter serialise at ~90 per microsecond; a block appends to, and later walks, the sub-list blockIdx % kSubLists):
+//   candidates  the faces with points outside them, two lists alternating by round parity (the tail of round r fills r+1's)
+//   claimed     the faces a candidate's walk claimed this round, same parity scheme
+// Counters live behind the scalars of the control block: ccnt(par, s), ocnt(par, s).
+constexpr int kSubLists = 64, kCntStride = 32;
+constexpr int kCtrlTotal = kCtrlInts + 2 * 2 * kSubLists * kCntStride;
 constexpr int kErrCapacity = 1, kErrFlat = 2, kErrTopology = 4, kErrNaN = 8;
 
 // what a distance test needs of a face, in one 64-byte line: the unnormalised normal, the coordinates of the face's
@@ -57,12 +63,12 @@ struct Bufs {
     int* fflags;           // fcap   bit0 alive, bit1 candidate / accepted, bit2 dies at the end of this round
     int* nfhead;           // fcap
     int* newface;          // 3 * fcap
-    int* front;            // fcap: the round's candidate faces (written by the previous round's tail)
+    int* cand[2];          // fcap each: candidate faces of even / odd rounds, kSubLists sub-lists of fcap / kSubLists
+    int* olist;            // fcap: faces claimed this round, same sub-list layout
     int* ctrl;             // kCtrlInts
     int* vflag;            // M1
     int* tile_cnt;         // ntiles(M1)
     int* tile_off;         // ntiles(M1)
-    int *ftile_cnt, *ftile_off;  // ntiles(fcap): scan scratch of the alive-face compaction
     float* flipped;        // 3 * M (only used by hidden_pts_removal)
     int* flip_max;         // nseg
     // segments: independent point sets (one hull each) laid end to end; segment s owns the expanded indices
@@ -77,9 +83,6 @@ struct Bufs {
     // points still outside some face, in position order; shrinks as the hull grows and is compacted every few rounds, so
     // that the per-round point kernels walk the tens of thousands of live points of the late rounds, not all M1
     int *live, *live2;     // M1 each
-    // faces alive at the last compaction, ascending; the per-round face kernels walk this list and then the ids created
-    // since (a contiguous range) instead of every face ever created (three quarters of which are dead by the end)
-    int *alist, *alist2;   // fcap each
     // spatial order: the points are worked on in Morton order of their position inside the segment's bounding box, so
     // that the lanes of a wave hold neighbouring points — which share conflict faces and new-face lists for the whole
     // build (coalesced, mostly wave-uniform reads instead of 64 scattered lists per wave).  px/py/pz, pface and the
@@ -102,8 +105,8 @@ __host__ inline size_t seg(size_t bytes) { return align_up(bytes, 256); }
 // The default suits clouds whose hull is a small fraction of the points (HPR of a scene: 2-5 %); a build that runs out
 // returns TOHIP_ENOSPC and the caller retries with a larger workspace — every byte beyond the fixed part is used for
 // faces (faces_for_bytes), up to the never-exceeded-in-practice 8 per point.
-constexpr size_t kBytesPerFace = 16 * sizeof(int) + sizeof(double) + 64 + 1;  // the per-face arrays carved below (+ scan scratch)
-constexpr int kFaceArrays = 18;
+constexpr size_t kBytesPerFace = 16 * sizeof(int) + sizeof(double) + 64;  // the per-face arrays carved below
+constexpr int kFaceArrays = 12;
 
 __host__ inline int default_face_capacity(int64_t m1, int64_t nseg) {
     int64_t c = m1 / 2 + 64 * nseg + 4096;
@@ -130,15 +133,13 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * (size_t)fcap); if (b) b->fflags = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->nfhead = (int*)p;
     p = take(sizeof(int) * 3 * (size_t)fcap); if (b) b->newface = (int*)p;
-    p = take(sizeof(int) * (size_t)fcap); if (b) b->front = (int*)p;
-    p = take(sizeof(int) * (size_t)fcap); if (b) b->alist = (int*)p;
-    p = take(sizeof(int) * (size_t)fcap); if (b) b->alist2 = (int*)p;
-    p = take(sizeof(int) * kCtrlInts); if (b) b->ctrl = (int*)p;
+    p = take(sizeof(int) * (size_t)fcap); if (b) b->cand[0] = (int*)p;
+    p = take(sizeof(int) * (size_t)fcap); if (b) b->cand[1] = (int*)p;
+    p = take(sizeof(int) * (size_t)fcap); if (b) b->olist = (int*)p;
+    p = take(sizeof(int) * kCtrlTotal); if (b) b->ctrl = (int*)p;
     p = take(sizeof(int) * m1); if (b) b->vflag = (int*)p;
     p = take(sizeof(int) * ntiles); if (b) b->tile_cnt = (int*)p;
     p = take(sizeof(int) * ntiles); if (b) b->tile_off = (int*)p;
-    p = take(sizeof(int) * (((size_t)fcap + 1023) / 1024)); if (b) b->ftile_cnt = (int*)p;
-    p = take(sizeof(int) * (((size_t)fcap + 1023) / 1024)); if (b) b->ftile_off = (int*)p;
     p = take(sizeof(float) * 3 * (size_t)n_points); if (b) b->flipped = (float*)p;
     p = take(sizeof(int) * nseg); if (b) b->flip_max = (int*)p;
     p = take(sizeof(int) * (nseg + 1)); if (b) b->seg_off = (int*)p;
@@ -288,20 +289,34 @@ __device__ __forceinline__ int find_seg(const Bufs& b, int i) {
     return lo;
 }
 
-// The faces a per-round kernel has to look at: the alive list of the last compaction, then the ids created since.
-// Before the first compaction the list is empty and the range starts at 0: every id.
-struct FaceWalk {
-    int nal, nfc, total;
+__device__ __forceinline__ int* ccnt(const Bufs& b, int par, int s) { return b.ctrl + kCtrlInts + (par * kSubLists + s) * kCntStride; }
+__device__ __forceinline__ int* ocnt(const Bufs& b, int par, int s) { return ccnt(b, 2 + par, s); }
+__device__ __forceinline__ int sub_cap(const Bufs& b) { return b.fcap / kSubLists; }
+
+// The faces a per-round face kernel has to look at: the round's candidates (their own faces are theirs without a claim) and
+// the claimed faces — a few thousand of the hundreds of thousands alive.  Virtual block vb of nvb (a multiple of kSubLists)
+// walks sub-list vb % kSubLists of both, part vb / kSubLists.  A face can show up more than once (a candidate whose face
+// was claimed by a better one; a face claimed twice): the kernels are idempotent or de-duplicate (k_new_faces).
+struct ListWalk {
+    const int *cl, *ol;
+    int ncand, total, first, step, loops;
 };
-__device__ __forceinline__ FaceWalk face_walk(const Bufs& b, int nf_upper) {
-    FaceWalk w;
-    w.nal = b.ctrl[kCtrlNAlive];
-    w.nfc = b.ctrl[kCtrlNFc];
-    w.total = w.nal + (nf_upper - w.nfc);
+__device__ __forceinline__ ListWalk list_walk(const Bufs& b, int par, int vb, int nvb) {
+    ListWalk w;
+    const int sl = vb % kSubLists, cap = sub_cap(b);
+    w.cl = b.cand[par] + (size_t)sl * cap;
+    w.ol = b.olist + (size_t)sl * cap;
+    w.ncand = min(*ccnt(b, par, sl), cap);
+    w.total = w.ncand + min(*ocnt(b, par, sl), cap);  // one index space: the candidates, then the claimed faces
+    w.first = (vb / kSubLists) * TO_BLOCK + threadIdx.x;
+    w.step = (nvb / kSubLists) * TO_BLOCK;
+    w.loops = (w.total + w.step - 1) / w.step;  // the same for every thread of the block
     return w;
 }
-__device__ __forceinline__ int face_at(const Bufs& b, const FaceWalk& w, int j) {
-    return j < w.nal ? b.alist[j] : w.nfc + (j - w.nal);
+__device__ __forceinline__ int list_face(const ListWalk& w, int it, bool* is_cand = nullptr) {
+    const int j = w.first + it * w.step;
+    if (is_cand) *is_cand = j < w.ncand;
+    return j < w.ncand ? w.cl[j] : (j < w.total ? w.ol[j - w.ncand] : kNone);
 }
 
 __global__ void k_single_segment(Bufs b) { b.seg_off[0] = 0; b.seg_off[1] = b.m1; }
@@ -421,9 +436,8 @@ k_load(Bufs b, const float* __restrict__ pts, int with_origin) {
         b.vflag[j] = 0;
         b.live[j] = j;
     }
-    if (blockIdx.x == 0 && threadIdx.x < kCtrlInts)
-        b.ctrl[threadIdx.x] = (threadIdx.x == kCtrlNFaces || threadIdx.x == kCtrlNFaces + 8) ? 4 * b.nseg
-                                                                                         : (threadIdx.x == kCtrlNLive ? b.m1 : 0);
+    // the control block was zero-filled by the host; no face is published before the first round's k_accept
+    if (blockIdx.x == 0 && threadIdx.x == 0) { b.ctrl[kCtrlNFaces + 8] = 4 * b.nseg; b.ctrl[kCtrlNLive] = b.m1; }
 }
 
 // block-wide argmax of (key, lowest index on ties); all threads get the winner
@@ -442,7 +456,7 @@ __device__ void init_tetrahedron(const Bufs& b, int sg, bool enough, bool has_na
             for (int f = fb; f < fb + 4; ++f) {
                 for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = lo; b.fn[3 * f + k] = f; }
                 b.frec[f] = FaceRec{0.0, 0.0, 0.0, b.px[lo], b.py[lo], b.pz[lo], kNone, {0, 0, 0}};
-                b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = 0x7fffffff;
+                b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = 0x7fffffff; b.nfhead[f] = kNone;
                 b.newface[3 * f] = kNone;
             }
             return;
@@ -461,6 +475,7 @@ __device__ void init_tetrahedron(const Bufs& b, int sg, bool enough, bool has_na
             b.fowner[f] = kNone;
             b.fmax[f] = 0ull;
             b.fapex[f] = 0x7fffffff;
+            b.nfhead[f] = kNone;
             b.newface[3 * f] = kNone;
         }
     }
@@ -630,13 +645,13 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
 }
 
 // ---- round --------------------------------------------------------------------------------------
-// Five launches: claim | accept | new faces | link + reassign | tail.  What each reads of the control block:
-//   kCtrlNFaces     published face count = the faces that existed before THIS round's insertions (written by k_accept)
-//   kCtrlNFaces + 8 staged count: every face created so far (k_new_faces allocates from it)
-//   kCtrlNCand      entries of the candidate list the tail of the previous round (or k_round_tail after the initial
-//                   tetrahedra) left for this round; 0 after a tail = the hulls are complete
-//   kCtrlAccepted   regions accepted this round
-// The tail prepares the NEXT round (per-face reset, candidate list), so a round has no separate reset launch.
+// Five launches: claim | accept | new faces | link + reassign | tail, all of them over the round's face LISTS (candidates and
+// claimed faces, list_walk) and the live points — never over every face of the hull.  `par` is the round's parity (which of
+// the two candidate lists it reads), `round` salts the candidates' ranking.  What each reads of the control block:
+//   kCtrlNFaces      published face count = the faces that existed before THIS round's insertions (written by k_accept)
+//   kCtrlNFaces + 8  staged count: every face created so far (k_new_faces allocates from it)
+//   kCtrlAccepted    regions accepted this round
+// The tail prepares the NEXT round (per-face reset, next candidate list), so a round has no reset launch of its own.
 
 // apex of the faces with id >= f_lo: lowest caller's index among the points at the face's maximum distance.  A face's
 // outside set never changes after its creation round, so its apex is computed once; older faces keep theirs.
@@ -655,21 +670,37 @@ __global__ void __launch_bounds__(TO_BLOCK) k_far_arg_all(Bufs b) { far_arg_poin
 
 // The ownership propagation of a round in ONE launch, one WAVE per candidate: breadth first over the region the candidate's
 // apex sees, the frontier in LDS, every (frontier face, edge) pair on its own lane — a level costs one chain of dependent
-// loads (neighbour id -> its owner -> its plane -> the claim) whatever the frontier's size, where one thread per candidate
-// paid that chain once per face (38 us per round at a million points against 10).  A face is claimed unless a better
-// candidate holds it (worse ones are robbed).  Which faces end up with a LOSING candidate depends on arrival order, the
-// winners' regions do not: k_accept admits a candidate only if it owns every face its apex sees and borders no better
-// region, so an incomplete walk (frontier or claim budget exhausted, a face stolen later) can only cost that candidate
-// this round; a round that accepts nobody is repeated with k_owner_prop run to convergence.
-constexpr int kClaimFront = 128, kClaimMax = 4096;
-__global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b) {
+// loads (neighbour id -> its owner and plane -> the claim) whatever the frontier's size, where one thread per candidate
+// paid that chain once per face.  A face is claimed unless a better candidate holds it (worse ones are robbed); every claim
+// is logged (LDS, flushed to the block's sub-list of claimed faces with one counter update per candidate).  Which faces end
+// up with a LOSING candidate depends on arrival order, the winners' regions do not: k_accept admits a candidate only if it
+// owns every face its apex sees and borders no better region, so an incomplete walk (frontier or claim budget exhausted, a
+// face stolen later) can only cost that candidate this round; a round that accepts nobody is repeated with k_owner_prop
+// run to convergence.
+constexpr int kClaimFront = 128, kClaimMax = 4096, kClaimLog = 192;
+__global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int par) {
     __shared__ int fr[TO_WAVES_PER_BLOCK][2][kClaimFront];
-    const int round = b.ctrl[kCtrlRound];
-    const int ncand = min(b.ctrl[kCtrlNCand], b.fcap);
+    __shared__ int lg[TO_WAVES_PER_BLOCK][kClaimLog];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int nwaves = gridDim.x * TO_WAVES_PER_BLOCK;
-    const int* __restrict__ cand = b.front;
-    for (int c = blockIdx.x * TO_WAVES_PER_BLOCK + wid; c < ncand; c += nwaves) {
+    const int sl = blockIdx.x % kSubLists, cap = sub_cap(b);
+    const int* __restrict__ cand = b.cand[par] + (size_t)sl * cap;
+    int* __restrict__ own = b.olist + (size_t)sl * cap;
+    int* own_n = ocnt(b, par, sl);
+    const int ncand = min(*ccnt(b, par, sl), cap);
+    const int wstep = (gridDim.x / kSubLists) * TO_WAVES_PER_BLOCK;
+    int logn = 0;
+    auto flush = [&]() {  // wave-uniform
+        if (logn == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(own_n, logn);
+        base = __shfl(base, 0);
+        for (int i = lane; i < logn; i += 64) {
+            if (base + i < cap) own[base + i] = lg[wid][i];
+            else { b.ctrl[kCtrlOverflow] = 1; b.ctrl[kCtrlError] |= kErrCapacity; }  // k_accept turns everybody down; the build ends
+        }
+        logn = 0;
+    };
+    for (int c = (blockIdx.x / kSubLists) * TO_WAVES_PER_BLOCK + wid; c < ncand; c += wstep) {
         const int o = cand[c];
         const int ax = b.fapex[o];
         if (ax == 0x7fffffff) {  // no apex found for a face with points outside it (never seen): not a candidate
@@ -703,25 +734,29 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b) {
                     }
                 }
                 const unsigned long long bal = __ballot(mine);
-                const int pos = nnext + __popcll(bal & ((1ull << lane) - 1ull));
-                if (mine && pos < kClaimFront) fr[wid][cur ^ 1][pos] = n;  // beyond the frontier's size: the walk stays incomplete (safe)
-                nnext += __popcll(bal);
+                const int cnt = __popcll(bal), rank = __popcll(bal & ((1ull << lane) - 1ull));
+                if (logn + cnt > kClaimLog) flush();
+                if (mine) lg[wid][logn + rank] = n;
+                logn += cnt;
+                if (mine && nnext + rank < kClaimFront) fr[wid][cur ^ 1][nnext + rank] = n;  // beyond: the walk stays incomplete (safe)
+                nnext += cnt;
             }
             claimed += nnext;
             ncur = nnext < kClaimFront ? nnext : kClaimFront;
             cur ^= 1;
         }
     }
+    flush();
 }
 
-// each live face adopts the best-priority owner among its neighbours whose apex sees it (the careful path, to convergence)
-__global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b) {
-    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces + 8]);
-    const int round = b.ctrl[kCtrlRound];
+// The careful path (after a round that accepted nobody): each live face adopts the best-priority owner among its neighbours
+// whose apex sees it, launched until nothing changes (host-checked); k_owned_list then lists the owned faces.  Both walk
+// every face ever created — rare enough not to deserve a list of the alive ones.
+__global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b, int round) {
+    const int nf = min(b.ctrl[kCtrlNFaces + 8], b.fcap);
     const int stride = gridDim.x * TO_BLOCK;
     bool changed = false;
-    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
-        const int g = face_at(b, fw, j);
+    for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf; g += stride) {
         if (!(b.fflags[g] & 1)) continue;
         int best = b.fowner[g];
         if (best == g && b.fapex[g] == 0x7fffffff) { b.fowner[g] = kNone; atomicAnd(&b.fflags[g], ~2); continue; }
@@ -737,25 +772,39 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b) {
     if (__any(changed) && (threadIdx.x & 63) == 0) b.ctrl[kCtrlChanged] = 1;
 }
 
-__global__ void __launch_bounds__(TO_BLOCK) k_accept(Bufs b) {
-    // nothing has been inserted yet this round: the staged count is the face count; it is published here for the kernels
-    // that run while k_new_faces raises the staged one
-    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces + 8]);
-    const int round = b.ctrl[kCtrlRound];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        b.ctrl[kCtrlNFaces] = min(b.ctrl[kCtrlNFaces + 8], b.fcap);
-        b.ctrl[kCtrlAccepted] = 0;
-        b.ctrl[kCtrlNCand] = 0;  // read by the claim before this launch; refilled by the tail
-    }
+__global__ void __launch_bounds__(TO_BLOCK) k_owned_list(Bufs b, int par) {
+    const int nf = min(b.ctrl[kCtrlNFaces + 8], b.fcap);
+    const int sl = blockIdx.x % kSubLists, cap = sub_cap(b);
     const int stride = gridDim.x * TO_BLOCK;
-    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
-        const int g = face_at(b, fw, j);
-        if (!(b.fflags[g] & 1)) continue;
+    const int nloop = (nf + stride - 1) / stride;
+    for (int it = 0; it < nloop; ++it) {
+        const int g = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
+        const bool put = g < nf && (b.fflags[g] & 1) && b.fowner[g] >= 0 && b.fowner[g] != g;
+        const int slot = block_alloc(ocnt(b, par, sl), put ? 1 : 0);
+        if (put) {
+            if (slot < cap) b.olist[(size_t)sl * cap + slot] = g;
+            else b.ctrl[kCtrlError] |= kErrCapacity;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(TO_BLOCK) k_accept(Bufs b, int round, int par) {
+    if (blockIdx.x == 0) {
+        // nothing has been inserted yet this round: the staged count is the face count; it is published here for the
+        // kernels that run while k_new_faces raises the staged one.  The next round's lists start empty.
+        if (threadIdx.x == 0) { b.ctrl[kCtrlNFaces] = min(b.ctrl[kCtrlNFaces + 8], b.fcap); b.ctrl[kCtrlAccepted] = 0; }
+        if (threadIdx.x < kSubLists) { *ccnt(b, par ^ 1, threadIdx.x) = 0; *ocnt(b, par ^ 1, threadIdx.x) = 0; }
+    }
+    const bool overflow = b.ctrl[kCtrlOverflow] != 0;  // a claimed face is missing from the lists: nobody can be checked
+    const ListWalk w = list_walk(b, par, blockIdx.x, gridDim.x);
+    for (int it = 0; it < w.loops; ++it) {
+        const int g = list_face(w, it);
+        if (g < 0 || !(b.fflags[g] & 1)) continue;
         const int o = b.fowner[g];
         if (o < 0) continue;
         if (b.fowner[o] != o) { continue; }  // o lost its own face: not a candidate (owned_accepted() checks the same)
         const int apex = b.inv[b.fapex[o]];
-        bool ok = true;
+        bool ok = !overflow;
         for (int k = 0; k < 3; ++k) {
             const int n = b.fn[3 * g + k];
             const int on = b.fowner[n];
@@ -775,19 +824,16 @@ __device__ __forceinline__ bool owned_accepted(const Bufs& b, int g, int* owner)
 }
 
 // one new triangle (u, v, apex) per horizon edge (u, v) of an accepted region; the region's faces get their death mark
-// (bit 2; the alive bit goes in the tail, when nobody looks at the region any more)
-__global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b) {
-    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);
-    const int stride = gridDim.x * TO_BLOCK;
-    const int nloop = (fw.total + stride - 1) / stride;
-    for (int it = 0; it < nloop; ++it) {
-        const int j = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
-        const int g = j < fw.total ? face_at(b, fw, j) : kNone;
+// (bit 2; the alive bit goes in the tail, when nobody looks at the region any more) — which also tells a face's second
+// list entry that the first one has been here
+__global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
+    const ListWalk w = list_walk(b, par, blockIdx.x, gridDim.x);
+    for (int it = 0; it < w.loops; ++it) {
+        const int g = list_face(w, it);
         int o = kNone, want = 0;
         bool hor[3] = {false, false, false};
-        if (g >= 0 && (b.fflags[g] & 1) && owned_accepted(b, g, &o)) {
+        if (g >= 0 && (b.fflags[g] & 1) && owned_accepted(b, g, &o) && !(atomicOr(&b.fflags[g], 4) & 4)) {
             for (int k = 0; k < 3; ++k) { hor[k] = b.fowner[b.fn[3 * g + k]] != o; want += hor[k]; }
-            atomicOr(&b.fflags[g], 4);
         } else {
             o = kNone;
         }
@@ -815,12 +861,11 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b) {
 }
 
 // sibling links: rotate around the horizon vertex v through the region's faces to the next horizon edge
-__device__ __forceinline__ void link_faces(const Bufs& b, int vblock, int nvblocks) {
-    const FaceWalk fw = face_walk(b, b.ctrl[kCtrlNFaces]);  // the published count: the faces that existed before this round
-    const int stride = nvblocks * TO_BLOCK;
-    for (int j = vblock * TO_BLOCK + threadIdx.x; j < fw.total; j += stride) {
-        const int g = face_at(b, fw, j);
-        if (!(b.fflags[g] & 4)) continue;  // faces of the accepted regions only
+__device__ __forceinline__ void link_faces(const Bufs& b, int par, int vblock, int nvblocks) {
+    const ListWalk w = list_walk(b, par, vblock, nvblocks);
+    for (int it = 0; it < w.loops; ++it) {
+        const int g = list_face(w, it);
+        if (g < 0 || !(b.fflags[g] & 4)) continue;  // faces of the accepted regions only (a second entry repeats the same writes)
         const int o = b.fowner[g];
         for (int k = 0; k < 3; ++k) {
             // NB fn[g][k] of a region face is never rewritten, so "across a horizon edge" is still decidable
@@ -877,44 +922,54 @@ __device__ __forceinline__ void reassign_points(const Bufs& b, FaceMaxTable& tab
 
 // the new faces' links and the points' new conflict faces need the same thing — every face of the round created — and
 // nothing of each other: one launch, the first `link_blocks` blocks link, the others move points
-__global__ void __launch_bounds__(TO_BLOCK) k_link_reassign(Bufs b, int link_blocks) {
+__global__ void __launch_bounds__(TO_BLOCK) k_link_reassign(Bufs b, int par, int link_blocks) {
     __shared__ FaceMaxTable tab;
-    if ((int)blockIdx.x < link_blocks) link_faces(b, blockIdx.x, link_blocks);
+    if ((int)blockIdx.x < link_blocks) link_faces(b, par, blockIdx.x, link_blocks);
     else reassign_points(b, tab, blockIdx.x - link_blocks, gridDim.x - link_blocks);
 }
 
-// End of a round = start of the next: apexes of the faces created this round (point loop), then per face: the accepted
-// regions' faces die, the per-round state is cleared, and the faces with points outside them enter the candidate list as
-// their own owners.  Also run once after the initial tetrahedra.
-__global__ void __launch_bounds__(TO_BLOCK) k_far_arg_new(Bufs b) { far_arg_points(b, b.ctrl[kCtrlNFaces], blockIdx.x, gridDim.x); }
-__global__ void __launch_bounds__(TO_BLOCK) k_link_only(Bufs b) { link_faces(b, blockIdx.x, gridDim.x); }
-__global__ void __launch_bounds__(TO_BLOCK) k_reassign_only(Bufs b) {
-    __shared__ FaceMaxTable tab;
-    reassign_points(b, tab, blockIdx.x, gridDim.x);
-}
-
-__global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int with_far_arg) {
+// End of a round = start of the next: apexes of the faces created this round (point loop), then per listed face: the accepted
+// regions' faces die and the round's ownership is cleared; the candidates that are still alive and the new faces with points
+// outside them enter the next round's candidate list as their own owners.  Also run once after the initial tetrahedra
+// (no lists yet; every face is new).  Needs a grid that is a multiple of kSubLists.
+__global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int with_far_arg) {
     if (with_far_arg) far_arg_points(b, b.ctrl[kCtrlNFaces], blockIdx.x, gridDim.x);
-    const FaceWalk fw = face_walk(b, min(b.ctrl[kCtrlNFaces + 8], b.fcap));  // final since k_new_faces ended
-    const int stride = gridDim.x * TO_BLOCK;
-    const int nloop = (fw.total + stride - 1) / stride;
-    for (int it = 0; it < nloop; ++it) {
-        const int j = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
+    const int sl = blockIdx.x % kSubLists, cap = sub_cap(b);
+    int* __restrict__ next = b.cand[par ^ 1] + (size_t)sl * cap;
+    int* next_n = ccnt(b, par ^ 1, sl);
+    auto enter = [&](int f, bool yes) {  // all threads of the block
+        const int slot = block_alloc(next_n, yes ? 1 : 0);
+        if (yes) {
+            if (slot < cap) next[slot] = f;
+            else b.ctrl[kCtrlError] |= kErrCapacity;
+        }
+    };
+    const ListWalk w = list_walk(b, par, blockIdx.x, gridDim.x);
+    for (int it = 0; it < w.loops; ++it) {
+        bool from_cand;
+        const int f = list_face(w, it, &from_cand);
         bool cand = false;
-        int f = kNone;
-        if (j < fw.total) {
-            f = face_at(b, fw, j);
+        if (f >= 0) {
             const int fl = b.fflags[f];
             const int alive = (fl & 1) && !(fl & 4);
             cand = alive && b.fmax[f] != 0ull;  // fmax persists: an outside set is fixed at the face's creation
             b.fowner[f] = cand ? f : kNone;
-            b.nfhead[f] = kNone;
             b.fflags[f] = alive | (cand ? 2 : 0);
+            if (from_cand) b.nfhead[f] = kNone;
         }
-        const int slot = block_alloc(&b.ctrl[kCtrlNCand], cand ? 1 : 0);
-        if (cand && slot < b.fcap) b.front[slot] = f;
+        enter(f, cand && from_cand);  // a candidate enters through its own entry, not through a claim's
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlRound] += 1;  // nobody in this launch reads it
+    const int f_lo = b.ctrl[kCtrlNFaces], nf = min(b.ctrl[kCtrlNFaces + 8], b.fcap);  // final since k_new_faces ended
+    const int stride = gridDim.x * TO_BLOCK;
+    const int nloop = (nf - f_lo + stride - 1) / stride;
+    for (int it = 0; it < nloop; ++it) {
+        // consecutive faces to consecutive blocks: a round's few hundred new faces spread over all sub-lists
+        const int f = f_lo + (it * TO_BLOCK + threadIdx.x) * gridDim.x + blockIdx.x;
+        const bool cand = f < nf && (b.fflags[f] & 1) && b.fmax[f] != 0ull;
+        if (cand) { b.fowner[f] = f; b.fflags[f] = 3; }
+        enter(f, cand);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlOverflow] = 0;  // read by k_accept only
 }
 
 __global__ void __launch_bounds__(TO_BLOCK) k_mark_vertices(Bufs b) {
@@ -958,44 +1013,6 @@ __global__ void __launch_bounds__(TO_BLOCK) k_live_write(Bufs b, int nlive_old, 
         __syncthreads();
     }
 }
-
-// ---- compaction of the alive-face list: walk (old list + ids since), keep the alive ones, ascending ----------
-__global__ void __launch_bounds__(TO_BLOCK) k_alive_count(Bufs b, int nal, int nfc, int total, int* __restrict__ tile_cnt) {
-    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
-    const int tile0 = blockIdx.x * 1024;
-    int cnt = 0;
-    for (int k = 0; k < 4; ++k) {
-        const int j = tile0 + k * TO_BLOCK + threadIdx.x;
-        const int f = j < total ? (j < nal ? b.alist[j] : nfc + (j - nal)) : 0;
-        cnt += __popcll(__ballot(j < total && (b.fflags[f] & 1)));
-    }
-    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-}
-
-__global__ void __launch_bounds__(TO_BLOCK)
-k_alive_write(Bufs b, int nal, int nfc, int total, const int* __restrict__ tile_off) {
-    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile0 = blockIdx.x * 1024;
-    int base = tile_off[blockIdx.x];
-    for (int k = 0; k < 4; ++k) {
-        const int j = tile0 + k * TO_BLOCK + threadIdx.x;
-        const int f = j < total ? (j < nal ? b.alist[j] : nfc + (j - nal)) : 0;
-        const bool keep = j < total && (b.fflags[f] & 1);
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) wave_cnt[wave] = __popcll(bal);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        if (keep) b.alist2[off + __popcll(bal & ((1ull << lane) - 1ull))] = f;
-        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
-    }
-}
-
-__global__ void k_set_int(int* p, int v) { *p = v; }
 
 // ---- ordered compaction of the flagged indices (same scheme as the frustum cull) ----------------
 __global__ void __launch_bounds__(TO_BLOCK) k_flag_count(const int* __restrict__ flag, int n, int* __restrict__ tile_cnt) {
@@ -1055,6 +1072,8 @@ inline int nblocks(int64_t n, int cap = 2048) {
 // b.seg_off must already be on the device (k_single_segment for one hull).
 static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_t st, int* rounds_out) {
     Bufs b = b_in;  // local copy: the two live-point buffers swap roles at every compaction
+    hipError_t e = hipMemsetAsync(b.ctrl, 0, sizeof(int) * kCtrlTotal, st);
+    if (e != hipSuccess) return (int)e;
     k_bbox_init<<<(6 * b.nseg + TO_BLOCK - 1) / TO_BLOCK, TO_BLOCK, 0, st>>>(b);
     // six same-address atomics per wave and segment: 4096 waves on ONE segment's box cost 0.27 ms, 512 cost 0.03
     k_bbox<<<nblocks(b.m1, b.nseg == 1 ? 128 : 1024), TO_BLOCK, 0, st>>>(b, pts, with_origin);
@@ -1083,76 +1102,135 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
     TO_HIP_CHECK_LAUNCH();
     k_assign0<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
     k_far_arg_all<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);
-    k_round_tail<<<nblocks(4 * (int64_t)b.nseg), TO_BLOCK, 0, st>>>(b, 0);  // the first round's candidates
+    k_round_tail<<<kSubLists, TO_BLOCK, 0, st>>>(b, 1, 0);  // round 0's candidates: the tetrahedra's faces with points outside
     TO_HIP_CHECK_LAUNCH();
-    int h[kCtrlInts];
-    hipError_t e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipStreamSynchronize(st);
+    // One readback = the scalars and the candidate counters of both parities, into pinned memory behind an event: the host
+    // keeps ONE batch of rounds enqueued ahead of the readback it is waiting for, so the GPU never idles while the host looks
+    // at the counts (35 us per readback, 50 readbacks per million-point build).  Rounds enqueued after the hull is complete
+    // find no candidate and change nothing; the counts only size grids, and every kernel strides over its lists.
+    constexpr int kRead = kCtrlInts + 2 * kSubLists * kCntStride;
+    struct Pinned {
+        int* buf[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool ok = false;
+        Pinned() {
+            ok = hipHostMalloc((void**)&buf[0], sizeof(int) * kRead) == hipSuccess && hipHostMalloc((void**)&buf[1], sizeof(int) * kRead) == hipSuccess &&
+                 hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+        }
+    };
+    static thread_local Pinned pin;  // lives as long as the thread: a build must not pay two pinned allocations
+    if (!pin.ok) return TOHIP_EINVAL;
+    const int* h = pin.buf[0];
+    int wslot = 0, rslot = 0, inflight = 0;
+    auto post_readback = [&]() -> hipError_t {  // enqueue the copy; collect() waits for it
+        hipError_t er = hipMemcpyAsync(pin.buf[wslot], b.ctrl, sizeof(int) * kRead, hipMemcpyDeviceToHost, st);
+        if (er == hipSuccess) er = hipEventRecord(pin.ev[wslot], st);
+        wslot ^= 1; ++inflight;
+        return er;
+    };
+    auto collect = [&]() -> hipError_t {
+        const hipError_t er = hipEventSynchronize(pin.ev[rslot]);
+        h = pin.buf[rslot];
+        rslot ^= 1; --inflight;
+        return er;
+    };
+    auto candidates = [&](int par) { int n = 0; for (int sl = 0; sl < kSubLists; ++sl) n += h[kCtrlInts + (par * kSubLists + sl) * kCntStride]; return n; };
+    auto cdiv = [](int64_t a, int64_t d) { return (a + d - 1) / d; };
+    e = post_readback();
+    if (e == hipSuccess) e = collect();
     if (e != hipSuccess) return (int)e;
     if (b.nseg == 1 && (h[kCtrlError] & kErrNaN)) return TOHIP_ENAN;
     if (b.nseg == 1 && (h[kCtrlError] & kErrFlat)) return TOHIP_EINVAL;
     int nf = h[kCtrlNFaces + 8];
     const int max_rounds = 100000;
-    int round = 0;
-    bool careful = false;  // after a round without progress: propagate ownership to convergence (host-checked)
-    // Rounds are enqueued in batches with ONE readback per batch: every kernel takes its counts from the control block on
-    // the device and walks its arrays with a grid stride, so the host's (stale) counts only size the grids.  A round
-    // enqueued after the hull is complete finds no candidate and changes nothing.
+    int round = 0 /* rounds enqueued */, ncand = candidates(0), live_bound = b.m1;
     static const int batch = getenv("TOHIP_HULL_BATCH") ? atoi(getenv("TOHIP_HULL_BATCH")) : 4;  // experiments: rounds per readback
-    int batches_since_compaction = 0, live_bound = b.m1;
-    const int face_tiles_cap = (b.fcap + 1023) / 1024;
+    static const bool always_careful = getenv("TOHIP_HULL_CAREFUL") != nullptr;                   // experiments: the slow path only
+    static const int compact_every = getenv("TOHIP_HULL_COMPACT") ? atoi(getenv("TOHIP_HULL_COMPACT")) : 2;
+    static const bool trace = getenv("TOHIP_HULL_TRACE") != nullptr;   // experiments: the build's progress, one line per readback
 
-    while (h[kCtrlNCand] > 0 && round < max_rounds) {
-        const int nrounds = careful ? 1 : batch;
-        const int gf = nblocks((int64_t)nf * 2);
+    // `careful`: ownership propagated to convergence with the host checking (after a batch that accepted nobody)
+    auto enqueue_rounds = [&](int nrounds, bool careful) -> int {
+        // grids: a wave per candidate; a thread per listed face (a candidate claims a handful of faces; lists grow within a batch)
+        const int ga = kSubLists * (int)std::min<int64_t>(32, std::max<int64_t>(1, cdiv(ncand, kSubLists * TO_WAVES_PER_BLOCK)));
+        const int gl = kSubLists * (int)std::min<int64_t>(16, std::max<int64_t>(1, cdiv((int64_t)ncand * 16, kSubLists * TO_BLOCK)));
         for (int r = 0; r < nrounds; ++r, ++round) {
-            static const bool always_careful = getenv("TOHIP_HULL_CAREFUL") != nullptr;  // experiments
-            if (!careful && !always_careful) {
+            const int par = round & 1;
+            if (!careful) {
                 // Fast path: a wave per candidate walks and claims its region (one launch, no readback).  Incomplete
                 // ownership is safe — a candidate is accepted only if it owns every face its apex sees (k_accept).
-                k_owner_claim<<<nblocks((int64_t)nf * 16), TO_BLOCK, 0, st>>>(b);
+                k_owner_claim<<<ga, TO_BLOCK, 0, st>>>(b, round, par);
                 TO_HIP_CHECK_LAUNCH();
             } else {
                 while (true) {
-                    e = hipMemsetAsync(b.ctrl + kCtrlChanged, 0, sizeof(int), st);
-                    if (e != hipSuccess) return (int)e;
-                    k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);
-                    k_owner_prop<<<gf, TO_BLOCK, 0, st>>>(b);
+                    hipError_t ec = hipMemsetAsync(b.ctrl + kCtrlChanged, 0, sizeof(int), st);
+                    if (ec != hipSuccess) return (int)ec;
+                    k_owner_prop<<<nblocks(nf), TO_BLOCK, 0, st>>>(b, round);
+                    k_owner_prop<<<nblocks(nf), TO_BLOCK, 0, st>>>(b, round);
                     TO_HIP_CHECK_LAUNCH();
-                    e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);
-                    if (e != hipSuccess) return (int)e;
-                    e = hipStreamSynchronize(st);
-                    if (e != hipSuccess) return (int)e;
+                    ec = post_readback();
+                    if (ec == hipSuccess) ec = collect();
+                    if (ec != hipSuccess) return (int)ec;
                     if (!h[kCtrlChanged]) break;
                 }
+                k_owned_list<<<kSubLists * (int)std::min<int64_t>(16, std::max<int64_t>(1, cdiv(nf, kSubLists * TO_BLOCK))), TO_BLOCK, 0, st>>>(b, par);
+                TO_HIP_CHECK_LAUNCH();
             }
             const int gr = nblocks(live_bound, 1024);
-            k_accept<<<gf, TO_BLOCK, 0, st>>>(b);
-            k_new_faces<<<gf, TO_BLOCK, 0, st>>>(b);
-            static const bool split_d = getenv("TOHIP_HULL_SPLIT_D") != nullptr, split_e = getenv("TOHIP_HULL_SPLIT_E") != nullptr;
-            if (split_d) {
-                k_link_only<<<gf, TO_BLOCK, 0, st>>>(b);
-                k_reassign_only<<<gr, TO_BLOCK, 0, st>>>(b);
-            } else {
-                k_link_reassign<<<gf + gr, TO_BLOCK, 0, st>>>(b, gf);
-            }
-            if (split_e) k_far_arg_new<<<nblocks(live_bound), TO_BLOCK, 0, st>>>(b);
-            k_round_tail<<<nblocks(live_bound > (int64_t)nf * 4 ? live_bound : (int64_t)nf * 4), TO_BLOCK, 0, st>>>(b, split_e ? 0 : 1);
+            k_accept<<<gl, TO_BLOCK, 0, st>>>(b, round, par);
+            k_new_faces<<<gl, TO_BLOCK, 0, st>>>(b, par);
+            k_link_reassign<<<gl + gr, TO_BLOCK, 0, st>>>(b, par, gl);
+            const int gt = std::max(gl, std::min(2048, (nblocks(live_bound) + kSubLists - 1) / kSubLists * kSubLists));
+            k_round_tail<<<gt, TO_BLOCK, 0, st>>>(b, par, 1);
             TO_HIP_CHECK_LAUNCH();
         }
-        e = hipMemcpyAsync(h, b.ctrl, sizeof(h), hipMemcpyDeviceToHost, st);  // the batch's one readback
-        if (e != hipSuccess) return (int)e;
-        e = hipStreamSynchronize(st);
-        if (e != hipSuccess) return (int)e;
-        if (h[kCtrlError]) return (h[kCtrlError] & kErrCapacity) ? TOHIP_ENOSPC : TOHIP_ENOTCONV;
+        return TOHIP_OK;
+    };
+
+    int rounds_seen = 0;                 // rounds covered by the last collected readback
+    int round_of[2] = {0, 0};            // rounds enqueued when each in-flight readback was posted
+    int batches_since_compaction = 0;
+    int compaction_pending_until = -1;   // a compaction was enqueued when `round` was this: older readbacks hold the old live count
+    bool stalled = false;                // the last collected batch accepted nobody
+    int careful_at = -1;                 // `round` right after the careful round was enqueued
+    const int ahead = always_careful ? 1 : 2;
+    auto drain = [&](int rc) { while (inflight > 0) (void)collect(); return rc; };
+    while (ncand > 0 && round < max_rounds) {
+        if (!stalled) {
+            while (inflight < ahead) {  // keep one batch ahead of the readback being waited for
+                const int rc = enqueue_rounds(always_careful ? 1 : batch, always_careful);
+                if (rc != TOHIP_OK) return drain(rc);
+                round_of[wslot] = round;
+                e = post_readback();
+                if (e != hipSuccess) return drain((int)e);
+            }
+        } else if (inflight == 0) {
+            // every enqueued round has reported and the last one accepted nobody: one round with converged ownership
+            const int rc = enqueue_rounds(1, true);
+            if (rc != TOHIP_OK) return drain(rc);
+            round_of[wslot] = round;
+            careful_at = round;
+            e = post_readback();
+            if (e != hipSuccess) return drain((int)e);
+        }
+        const int posted_at = round_of[rslot];
+        e = collect();
+        if (e != hipSuccess) return drain((int)e);
+        rounds_seen = posted_at;
+        if (h[kCtrlError]) return drain((h[kCtrlError] & kErrCapacity) ? TOHIP_ENOSPC : TOHIP_ENOTCONV);
         nf = h[kCtrlNFaces + 8] < b.fcap ? h[kCtrlNFaces + 8] : b.fcap;
-        static const bool trace = getenv("TOHIP_HULL_TRACE") != nullptr;   // experiments: the build's progress, one line per readback
-        if (trace) fprintf(stderr, "hull: round %d faces %d live %d alive %d candidates %d accepted(last) %d careful %d\n", round, nf,
-                           h[kCtrlNLive], h[kCtrlNAlive], h[kCtrlNCand], h[kCtrlAccepted], (int)careful);
-        if (h[kCtrlNCand] == 0) break;  // no face has a point outside it: the hull is complete
-        static const int compact_every = getenv("TOHIP_HULL_COMPACT") ? atoi(getenv("TOHIP_HULL_COMPACT")) : 2;  // experiments
-        if (++batches_since_compaction >= compact_every && h[kCtrlNLive] > 4096) {
+        ncand = candidates(posted_at & 1);
+        if (trace) fprintf(stderr, "hull: round %d faces %d live %d candidates %d accepted(last) %d\n", posted_at, nf, h[kCtrlNLive], ncand,
+                           h[kCtrlAccepted]);
+        if (ncand == 0) break;  // no face has a point outside it: the hull is complete (rounds still in flight are no-ops)
+        if (h[kCtrlAccepted] <= 0) {
+            // converged ownership always admits the best candidate: a careful round without progress = inconsistent predicates
+            if (posted_at == careful_at || always_careful) return drain(TOHIP_ENOTCONV);
+            stalled = true;   // let what is in flight report, then run a careful round
+            continue;
+        }
+        stalled = false;
+        if (++batches_since_compaction >= compact_every && h[kCtrlNLive] > 4096 && posted_at > compaction_pending_until) {
             // drop the points that have retired inside the hull from the list the point kernels walk
             const int nlive = h[kCtrlNLive], ntl = (nlive + 1023) / 1024;
             k_live_count<<<ntl, TO_BLOCK, 0, st>>>(b, nlive, b.tile_cnt);
@@ -1162,27 +1240,18 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
             int* t = b.live; b.live = b.live2; b.live2 = t;
             batches_since_compaction = 0;
             live_bound = nlive;  // the new count is on the device only; this bounds it
-            // and the faces: walk = (alive list of the last compaction) + (ids created since); keep the alive ones
-            const int nal = h[kCtrlNAlive], nfc = h[kCtrlNFc], total = nal + (nf - nfc), ntf = (total + 1023) / 1024;
-            if (ntf > face_tiles_cap) return TOHIP_ENOSPC;
-            k_alive_count<<<ntf, TO_BLOCK, 0, st>>>(b, nal, nfc, total, b.ftile_cnt);
-            k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(b.ftile_cnt, ntf, b.ftile_off, b.ctrl + kCtrlNAlive);
-            k_alive_write<<<ntf, TO_BLOCK, 0, st>>>(b, nal, nfc, total, b.ftile_off);
-            k_set_int<<<1, 1, 0, st>>>(b.ctrl + kCtrlNFc, nf);
-            TO_HIP_CHECK_LAUNCH();
-            t = b.alist; b.alist = b.alist2; b.alist2 = t;
-        }
-        if (h[kCtrlAccepted] <= 0) {
-            if (careful) return TOHIP_ENOTCONV;  // converged ownership always admits the best candidate: inconsistent predicates
-            careful = true;
-        } else {
-            careful = false;
+            compaction_pending_until = round;  // readbacks posted up to now still show the count before this compaction
         }
     }
-    if (round >= max_rounds) return TOHIP_ENOTCONV;
+    if (round >= max_rounds && ncand > 0) return drain(TOHIP_ENOTCONV);
+    round = rounds_seen;
     if (rounds_out) *rounds_out = round;
     k_mark_vertices<<<nblocks(nf), TO_BLOCK, 0, st>>>(b);
     TO_HIP_CHECK_LAUNCH();
+    while (inflight > 0) {  // the pinned buffers and events are this thread's next build's too
+        e = collect();
+        if (e != hipSuccess) return (int)e;
+    }
     return TOHIP_OK;
 }
 
