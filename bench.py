@@ -304,8 +304,9 @@ def main():
                                      "launch / queueing share of a back-to-back dependent launch"},
                          "hbm_counter_frac": (traffic / (p1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "traffic_note": "HBM bytes per launch from profiles/r02_bench_dense_pmc.json (separate --pmc passes of "
-                                         "this command); ~1 % of the HBM peak: points live in registers, waypoints stream "
-                                         "through SGPRs",
+                                         "this command: 2 x FETCH_SIZE + WRITE_SIZE); a few per cent of the HBM peak: points live "
+                                         "in registers, waypoints stream through SGPRs, the 8-byte (min, max) stores go out as "
+                                         "32-byte sectors",
                          "algorithmic_bytes_frac": value / n_gpus * ALGO_BYTES_FWD_BWD / (HBM_PEAK_GBS * 1e9),
                          "algorithmic_bytes_note": "48 B/eval of a streaming implementation (SURVEY.md 8d) x evals/s / 8 TB/s: above 1 "
                                                    "because nothing streams — kept for comparison with the survey's model only",

@@ -15,5 +15,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/culled" -o culled 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -o pmc -- python3 "$root/bench.py" $common --mode dense > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -o pmc -- python3 "$root/bench.py" $common --mode dense > "$out/pmc_write.log" 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_sq" -o pmc -- python3 "$root/bench.py" $common --mode dense > "$out/pmc_sq.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/hpr" -o hpr -- python3 "$root/tools/prof_hpr_batched.py" > "$out/hpr.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/hpr" -o hpr -- python3 "$root/tools/hpr_batched_once.py" 3 > "$out/hpr.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/hpr1m" -o hpr1m -- python3 "$root/tools/hpr_once.py" 1000000 3 > "$out/hpr1m.log" 2>&1
 find "$out" -name "*.csv" | head -40

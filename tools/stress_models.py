@@ -10,6 +10,22 @@ K, IW, IH = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 def rel(a, b): return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def threshold_margin(pts, pose, q, clip):
+    """f64 restatement of p-hat for one waypoint: distance of the nearest point to the activity thresholds (0.5 and 1 - 1e-6)
+    of the clipped log-odds (model.py:229).  The gradient jumps there, and f32 rounding decides the side."""
+    pts, pose, q = pts.astype(np.float64), pose.astype(np.float64), q.astype(np.float64)
+    mean, std = np.float64(np.float32((clip[0] + clip[1]) / 2)), np.float64(np.float32((clip[1] - clip[0]) / 2))
+    w, x, y, z = q / np.linalg.norm(q)
+    R = np.array([[w*w+x*x-y*y-z*z, 2*(x*y-w*z), 2*(x*z+w*y)], [2*(x*y+w*z), w*w-x*x+y*y-z*z, 2*(y*z-w*x)], [2*(x*z-w*y), 2*(y*z+w*x), w*w-x*x-y*y+z*z]])
+    C = (pts - pose) @ R
+    H = C @ K.astype(np.float64).T
+    zz = H[:, 2] + 1e-6
+    au, av = (H[:, 0] / zz - IW / 2) / IW, (H[:, 1] / zz - IH / 2) / IH
+    p = np.exp(-0.5 * (np.linalg.norm(C - mean, axis=1) / std) ** 2) / (1 + np.exp(-H[:, 2])) * np.exp(-0.5 * au * au) * np.exp(-0.5 * av * av)
+    ph = (p - p.min()) / (p - p.min()).max()
+    return float(min(np.abs(ph - 0.5).min(), np.abs(ph[ph < 1] - np.float64(np.float32(1 - 1e-6))).min()))
 bad = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
     n = int(rng.choice([900, 6000, 30_000, 90_000]))
@@ -20,6 +36,8 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
     quats = (quats * np.float32(rng.uniform(0.5, 2.0))).astype(np.float32)
     clip = (float(rng.uniform(0.3, 2.0)), float(rng.uniform(3.0, 10.0)))
     dense = bool(rng.random() < 0.5)
+    j = int(rng.integers(0, w))
+    if len(sys.argv) > 3 and it != int(sys.argv[3]): continue  # replay one configuration
     m = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(K), IW, IH,
                   min_dist=clip[0], max_dist=clip[1], device=dev, dense=dense)
     m(vis_wps_dist=0.0)
@@ -31,7 +49,6 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
     # the oracle restates the reference in f64; f32 noise at the clip edges can flip single pairs: allow 3e-5 on gradients here
     ok = e["vis"] < 5e-6 and e["rew"] < 5e-5 and e["pg"] < 3e-5 and e["qg"] < 3e-5
     # ModelPose at one of the waypoints
-    j = int(rng.integers(0, w))
     mp = ModelPose(torch.from_numpy(pts), torch.from_numpy(poses[j:j + 1].copy()), torch.from_numpy(quats[j:j + 1].copy()), torch.from_numpy(K),
                    IW, IH, min_dist=clip[0], max_dist=clip[1], device=dev)
     lp = mp(); lp.backward()
@@ -42,4 +59,16 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
     if not ok:
         bad += 1
         print("FAIL", it, n, w, scale, clip, dense, {k: f"{v:.2e}" for k, v in e.items()}, {k: f"{v:.2e}" for k, v in ep.items()})
+        # is it the f32 arithmetic of the reference itself?  (the f32 oracle against the f64 one, and ours against the f32 one)
+        f32 = oracle.traj_forward(pts, poses, quats, K, IW, IH, clip[0], clip[1], prec="f32")
+        pg32, qg32 = oracle.traj_backward(pts, poses, quats, K, IW, IH, f32, min_dist=clip[0], max_dist=clip[1], prec="f32")
+        print("     f32 oracle vs f64 oracle: pg", f"{rel(pg32, pg):.2e}", "qg", f"{rel(qg32, qg):.2e}", "| ours vs f32 oracle: pg",
+              f"{rel(m.poses.grad.cpu().numpy(), pg32):.2e}", "qg", f"{rel(m.quats.grad.cpu().numpy(), qg32):.2e}")
+        d = np.abs(m.poses.grad.cpu().numpy() - pg).max(axis=1)
+        off = np.flatnonzero(d > 1e-5 * np.abs(pg).max())
+        margins = [threshold_margin(pts, poses[k], quats[k], clip) for k in off]
+        print("     waypoints off:", off, "nearest point to an activity threshold of p-hat (f64):", [f"{v:.1e}" for v in margins])
+        if len(off) and all(v < 3e-7 for v in margins) and ep["loss"] < 5e-6 and ep["tg"] < 2e-5 and ep["qg"] < 2e-5:
+            bad -= 1
+            print("     -> a point within f32 rounding of a threshold in every waypoint that is off: not counted")
 print("model stress done, failures:", bad)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 output of tools/collect_profiles.sh into the committed summaries:
     python tools/summarize_profiles.py gpurun_out/prof_r02 r02
- -> profiles/rNN_bench_{dense,culled}_kernel_stats.csv, profiles/rNN_hpr_batched_kernel_stats.csv (copies) and
+ -> profiles/rNN_bench_{dense,culled}_kernel_stats.csv, profiles/rNN_hpr_{batched,1m}_kernel_stats.csv (copies) and
     profiles/rNN_bench_dense_pmc.json: per kernel, HBM bytes per launch = 2 x FETCH_SIZE (gfx950 counts a wide coalesced read
     at half its bytes, MI355X_MICROARCH.md) + WRITE_SIZE, both reported in KB, and the VALU busy fraction
     SQ_ACTIVE_INST_VALU / (32 x GRBM_GUI_ACTIVE)."""
@@ -40,6 +40,8 @@ def main():
         shutil.copy(os.path.join(src, mode, f"{mode}_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_{mode}_kernel_stats.csv"))
     if os.path.exists(os.path.join(src, "hpr", "hpr_kernel_stats.csv")):
         shutil.copy(os.path.join(src, "hpr", "hpr_kernel_stats.csv"), os.path.join(dst, f"{tag}_hpr_batched_kernel_stats.csv"))
+    if os.path.exists(os.path.join(src, "hpr1m", "hpr1m_kernel_stats.csv")):
+        shutil.copy(os.path.join(src, "hpr1m", "hpr1m_kernel_stats.csv"), os.path.join(dst, f"{tag}_hpr_1m_kernel_stats.csv"))
     out = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --kernel-trace -- python3 bench.py --steps 5 --warmup 1 "
                       "--cpu-wps 0 --mode dense   (three separate runs, tools/collect_profiles.sh)",
            "units": "FETCH_SIZE/WRITE_SIZE in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)",
