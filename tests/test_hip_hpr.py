@@ -188,3 +188,32 @@ def test_hpr_batched_many_small_segments(dev):
     assert np.array_equal(status[sizes < 4], np.ones((sizes < 4).sum(), np.int32))
     idx, voff, mask, status = ops.hidden_pts_removal_batched(torch.empty((0, 3), device=dev), [0, 0, 0])
     assert idx.numel() == 0 and voff.tolist() == [0, 0, 0] and status.tolist() == [1, 1] and mask.numel() == 0
+
+
+def test_hull_all_points_on_a_sphere_retries_with_a_larger_face_pool(dev):
+    """Every point a hull vertex: the default face pool / face lists run out (TOHIP_ENOSPC) and ops retries with 4x the bytes."""
+    from scipy.spatial import ConvexHull
+    from trajectory_optimization_amd import ops
+    rng = np.random.default_rng(11)
+    v = rng.normal(size=(300_000, 3))
+    pts = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    got = ops.hull_vertices_with_origin(torch.from_numpy(pts).to(dev), False).cpu().numpy()
+    ref = np.sort(ConvexHull(pts.astype(np.float64)).vertices)
+    assert np.array_equal(got.astype(np.int64), ref)
+
+
+def test_hull_careful_path_in_a_child_process():
+    """The slow path of the hull build (ownership propagated to convergence with the host checking, taken after a round that
+    accepts nobody) is switched on for a whole process by TOHIP_HULL_CAREFUL: same index sets."""
+    import os, subprocess, sys
+    from conftest import REPO
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, 'tests'); from conftest import load_golden\n"
+            "from trajectory_optimization_amd import ops\n"
+            "for name in ('hpr_synth_10k', 'hpr_synth_outside'):\n"
+            "    d = load_golden(name)\n"
+            "    idx, _ = ops.hidden_pts_removal(torch.from_numpy(d['points']).cuda())\n"
+            "    assert np.array_equal(idx.cpu().numpy(), d['visible_idx']), name\n"
+            "print('careful ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=dict(os.environ, TOHIP_HULL_CAREFUL="1"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "careful ok" in r.stdout, r.stdout + r.stderr
