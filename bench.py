@@ -110,15 +110,17 @@ def hpr_leg(points, device):
     P = torch.from_numpy(points).to(device)
     ops.hidden_pts_removal(P)
     torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(3):
+    times = []
+    for _ in range(8):   # the number of hull rounds (and with it the time) varies from build to build: mean and best of eight
+        t0 = time.perf_counter()
         idx, _ = ops.hidden_pts_removal(P)
-    torch.cuda.synchronize(device)
-    gpu_s = (time.perf_counter() - t0) / 3
+        torch.cuda.synchronize(device)
+        times.append(time.perf_counter() - t0)
+    gpu_s = sum(times) / len(times)
     t0 = time.perf_counter()
     ref, _ = oracle.hidden_pts_removal(points)
     cpu_s = time.perf_counter() - t0
-    return {"points": int(points.shape[0]), "visible": int(idx.numel()), "gpu_ms": 1e3 * gpu_s,
+    return {"points": int(points.shape[0]), "visible": int(idx.numel()), "gpu_ms": 1e3 * gpu_s, "gpu_ms_best": 1e3 * min(times),
             "hull_points_per_s": points.shape[0] / gpu_s, "qhull_ms_host_1core": 1e3 * cpu_s,
             "index_set_equal_to_qhull": bool(np.array_equal(idx.cpu().numpy().astype(np.int64), ref))}
 
