@@ -22,6 +22,7 @@
 // Predicates are plain f64 (coordinate differences of f32 inputs are exact; products are rounded):
 // like Qhull's own, they are not exact on nearly coplanar quadruples — DESIGN.md §6.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -97,6 +98,7 @@ struct Bufs {
     int m1;
     int fcap;
     int nseg;
+    int sub;               // > 1 while only every sub-th point (in Morton order) takes part: the first rounds of a large build
 };
 
 __host__ inline size_t seg(size_t bytes) { return align_up(bytes, 256); }
@@ -160,7 +162,7 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                              (const int*)nullptr, (int*)nullptr, (int)m1, 0, 64, (hipStream_t)0);
     p = take(tmp); if (b) { b->sort_tmp = p; b->sort_tmp_bytes = tmp; }
-    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; }
+    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; }
     return o;
 }
 
@@ -634,7 +636,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
         if (i < b.m1) {
             const int fb = 4 * find_seg(b, i);
             // the tetrahedron's corners: faces fb and fb+1 are (a,c1,c2) and (c1,a,d)
-            if ((b.fflags[fb] & 1) && !(i == b.fv[3 * fb] || i == b.fv[3 * fb + 1] || i == b.fv[3 * fb + 2] || i == b.fv[3 * fb + 5])) {
+            if ((b.fflags[fb] & 1) && i % b.sub == 0 && !(i == b.fv[3 * fb] || i == b.fv[3 * fb + 1] || i == b.fv[3 * fb + 2] || i == b.fv[3 * fb + 5])) {
                 for (int f = fb; f < fb + 4; ++f) { const double d = fdist(b, f, i); if (d > best) { best = d; bf = f; } }
                 b.pface[i] = bf;
             }
@@ -972,6 +974,116 @@ __global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int wi
     if (blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlOverflow] = 0;  // read by k_accept only
 }
 
+// ---- the first rounds of a large build on a sample of the points ----------------------------------------------------
+// While a hull has a few hundred faces, a round inserts a handful of points but moves EVERY point still outside it (the point
+// kernels of the first 40-60 rounds were half the time of a 128 x 107 k batched build).  So those rounds run on every sub-th
+// point (Morton order: a uniform spatial sample); the hull they grow is a convex polytope on input points like any other
+// intermediate state.  Then every other point is given its conflict face by testing it against ALL faces of its segment's
+// polytope (k_assign_all: f64 plane tests from LDS, ~1 ms for 13.6 M points x 500 faces) — points inside retire without ever
+// having been moved — and the build goes on with all of them.
+
+__global__ void __launch_bounds__(TO_BLOCK) k_live_stride(Bufs b) {  // live list = the sample
+    const int cnt = (b.m1 + b.sub - 1) / b.sub;
+    const int stride = gridDim.x * TO_BLOCK;
+    for (int k = blockIdx.x * TO_BLOCK + threadIdx.x; k < cnt; k += stride) b.live[k] = k * b.sub;
+    if (blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlNLive] = cnt;
+}
+
+__global__ void __launch_bounds__(TO_BLOCK) k_live_all(Bufs b) {
+    const int stride = gridDim.x * TO_BLOCK;
+    for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < b.m1; j += stride) b.live[j] = j;
+    if (blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlNLive] = b.m1;
+}
+
+// alive faces grouped by segment: counts, then (after a scan) the faces themselves into `list` (b.olist between two rounds)
+__global__ void __launch_bounds__(TO_BLOCK) k_seg_faces(Bufs b, int* __restrict__ cnt, const int* __restrict__ off, int* __restrict__ list) {
+    const int nf = min(b.ctrl[kCtrlNFaces + 8], b.fcap);
+    const int stride = gridDim.x * TO_BLOCK;
+    for (int f = blockIdx.x * TO_BLOCK + threadIdx.x; f < nf; f += stride) {
+        if (!(b.fflags[f] & 1)) continue;
+        const int sg = find_seg(b, b.fv[3 * f]);  // positions are grouped by segment like the expanded indices
+        const int k = atomicAdd(&cnt[sg], 1);
+        if (list) list[off[sg] + k] = f;
+        // every alive face gets a fresh apex search (k_far_arg_all) once the dormant points have joined its outside set
+        if (list) b.fapex[f] = 0x7fffffff;
+    }
+}
+
+constexpr int kAssignPts = 8, kAssignTile = 256;
+__global__ void __launch_bounds__(TO_BLOCK) k_assign_all(Bufs b, const int* __restrict__ off, const int* __restrict__ list) {
+    struct Plane { double nx, ny, nz, x0, y0, z0; };
+    __shared__ Plane pl[kAssignTile];
+    __shared__ int pf[kAssignTile];
+    __shared__ FaceMaxTable tab;
+    face_max_init(tab);
+    const int sg = blockIdx.y, lo = b.seg_off[sg], hi = b.seg_off[sg + 1];
+    const int f0 = off[sg], f1 = off[sg + 1];
+    // the tetrahedron's corners were picked among ALL points: a dormant one is a vertex already (its distance to its own faces
+    // is rounding noise, not a conflict)
+    const int fb = 4 * sg;
+    const int c0 = b.fv[3 * fb], c1 = b.fv[3 * fb + 1], c2 = b.fv[3 * fb + 2], c3 = b.fv[3 * fb + 5];
+    const int chunk = TO_BLOCK * kAssignPts;
+    for (int base = lo + blockIdx.x * chunk; base < hi; base += gridDim.x * chunk) {  // block-uniform
+        double x[kAssignPts], y[kAssignPts], z[kAssignPts], best[kAssignPts];
+        int bf[kAssignPts];
+        bool mine[kAssignPts];
+        for (int k = 0; k < kAssignPts; ++k) {
+            const int j = base + k * TO_BLOCK + threadIdx.x;
+            mine[k] = j < hi && j % b.sub != 0 && j != c0 && j != c1 && j != c2 && j != c3;  // the sample's points have their faces (or have retired) already
+            x[k] = mine[k] ? b.px[j] : 0.0; y[k] = mine[k] ? b.py[j] : 0.0; z[k] = mine[k] ? b.pz[j] : 0.0;
+            best[k] = 0.0; bf[k] = kNone;
+        }
+        for (int t0 = f0; t0 < f1; t0 += kAssignTile) {
+            const int nt = min(kAssignTile, f1 - t0);
+            __syncthreads();
+            if ((int)threadIdx.x < nt) {
+                const int f = list[t0 + threadIdx.x];
+                const FaceRec r = b.frec[f];
+                pl[threadIdx.x] = Plane{r.nx, r.ny, r.nz, r.x0, r.y0, r.z0};
+                pf[threadIdx.x] = f;
+            }
+            __syncthreads();
+            for (int q = 0; q < nt; ++q) {
+                const Plane P = pl[q];
+                const int f = pf[q];
+                FaceRec r;  // the same expression as every other distance test (plane_dist)
+                r.nx = P.nx; r.ny = P.ny; r.nz = P.nz; r.x0 = P.x0; r.y0 = P.y0; r.z0 = P.z0;
+                for (int k = 0; k < kAssignPts; ++k) {
+                    const double d = plane_dist(r, x[k], y[k], z[k]);
+                    if (d > best[k]) { best[k] = d; bf[k] = f; }
+                }
+            }
+        }
+        for (int k = 0; k < kAssignPts; ++k) {
+            const int j = base + k * TO_BLOCK + threadIdx.x;
+            if (mine[k]) b.pface[j] = bf[k];
+            wave_face_max(b, tab, mine[k] ? bf[k] : kNone, dkey(best[k]));
+        }
+    }
+    face_max_flush(b, tab);
+}
+
+// the candidate list of parity `par` from scratch: every alive face with points outside it, as its own owner
+__global__ void __launch_bounds__(TO_BLOCK) k_rebuild_candidates(Bufs b, int par) {
+    const int sl = blockIdx.x % kSubLists, cap = sub_cap(b);
+    int* __restrict__ next = b.cand[par] + (size_t)sl * cap;
+    int* next_n = ccnt(b, par, sl);
+    const int nf = min(b.ctrl[kCtrlNFaces + 8], b.fcap);
+    const int stride = gridDim.x * TO_BLOCK;
+    const int nloop = (nf + stride - 1) / stride;
+    for (int it = 0; it < nloop; ++it) {
+        const int f = (it * TO_BLOCK + threadIdx.x) * gridDim.x + blockIdx.x;
+        const bool alive = f < nf && (b.fflags[f] & 1);
+        const bool cand = alive && b.fmax[f] != 0ull;
+        if (alive) { b.fowner[f] = cand ? f : kNone; b.fflags[f] = 1 | (cand ? 2 : 0); b.nfhead[f] = kNone; }
+        const int slot = block_alloc(next_n, cand ? 1 : 0);
+        if (cand) {
+            if (slot < cap) next[slot] = f;
+            else b.ctrl[kCtrlError] |= kErrCapacity;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(TO_BLOCK) k_mark_vertices(Bufs b) {
     const int nf = min(b.ctrl[kCtrlNFaces + 8], b.fcap);  // every face created (the published count lags by the last round)
     const int stride = gridDim.x * TO_BLOCK;
@@ -1070,8 +1182,15 @@ inline int nblocks(int64_t n, int cap = 2048) {
 
 // Builds the hull of pts (n,3) [+ origin]; leaves vflag set.  Synchronises the stream.
 // b.seg_off must already be on the device (k_single_segment for one hull).
-static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_t st, int* rounds_out) {
+static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t max_seg_points, hipStream_t st, int* rounds_out) {
     Bufs b = b_in;  // local copy: the two live-point buffers swap roles at every compaction
+    {
+        // large segments: the first rounds on a sample (see k_assign_all)
+        static const int force_sub = getenv("TOHIP_HULL_SUB") ? atoi(getenv("TOHIP_HULL_SUB")) : 0;  // experiments: 1 = off
+        const int64_t avg = b.m1 / b.nseg;
+        b.sub = (avg >= 32768 && b.nseg <= 65535) ? (int)std::min<int64_t>(256, std::max<int64_t>(2, avg / 512)) : 1;
+        if (force_sub > 0) b.sub = force_sub;
+    }
     hipError_t e = hipMemsetAsync(b.ctrl, 0, sizeof(int) * kCtrlTotal, st);
     if (e != hipSuccess) return (int)e;
     k_bbox_init<<<(6 * b.nseg + TO_BLOCK - 1) / TO_BLOCK, TO_BLOCK, 0, st>>>(b);
@@ -1100,6 +1219,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
         k_init<<<b.nseg, HULL_INIT_THREADS, 0, st>>>(b);
     }
     TO_HIP_CHECK_LAUNCH();
+    if (b.sub > 1) k_live_stride<<<nblocks((b.m1 + b.sub - 1) / b.sub), TO_BLOCK, 0, st>>>(b);
     k_assign0<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
     k_far_arg_all<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);
     k_round_tail<<<kSubLists, TO_BLOCK, 0, st>>>(b, 1, 0);  // round 0's candidates: the tetrahedra's faces with points outside
@@ -1128,8 +1248,11 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
         wslot ^= 1; ++inflight;
         return er;
     };
+    double host_enqueue_us = 0.0, host_wait_us = 0.0;  // for the trace: where the host's time goes
     auto collect = [&]() -> hipError_t {
+        const auto t0 = std::chrono::steady_clock::now();
         const hipError_t er = hipEventSynchronize(pin.ev[rslot]);
+        host_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         h = pin.buf[rslot];
         rslot ^= 1; --inflight;
         return er;
@@ -1143,14 +1266,15 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
     if (b.nseg == 1 && (h[kCtrlError] & kErrFlat)) return TOHIP_EINVAL;
     int nf = h[kCtrlNFaces + 8];
     const int max_rounds = 100000;
-    int round = 0 /* rounds enqueued */, ncand = candidates(0), live_bound = b.m1;
+    int round = 0 /* rounds enqueued */, ncand = candidates(0), live_bound = (b.m1 + b.sub - 1) / b.sub;
     static const int batch = getenv("TOHIP_HULL_BATCH") ? atoi(getenv("TOHIP_HULL_BATCH")) : 4;  // experiments: rounds per readback
     static const bool always_careful = getenv("TOHIP_HULL_CAREFUL") != nullptr;                   // experiments: the slow path only
     static const int compact_every = getenv("TOHIP_HULL_COMPACT") ? atoi(getenv("TOHIP_HULL_COMPACT")) : 2;
     static const bool trace = getenv("TOHIP_HULL_TRACE") != nullptr;   // experiments: the build's progress, one line per readback
+    static const int join_faces = getenv("TOHIP_HULL_JOIN_FACES") ? atoi(getenv("TOHIP_HULL_JOIN_FACES")) : 1536;  // experiments
 
     // `careful`: ownership propagated to convergence with the host checking (after a batch that accepted nobody)
-    auto enqueue_rounds = [&](int nrounds, bool careful) -> int {
+    auto enqueue_rounds_inner = [&](int nrounds, bool careful) -> int {
         // grids: a wave per candidate; a thread per listed face (a candidate claims a handful of faces; lists grow within a batch)
         const int ga = kSubLists * (int)std::min<int64_t>(32, std::max<int64_t>(1, cdiv(ncand, kSubLists * TO_WAVES_PER_BLOCK)));
         const int gl = kSubLists * (int)std::min<int64_t>(16, std::max<int64_t>(1, cdiv((int64_t)ncand * 16, kSubLists * TO_BLOCK)));
@@ -1187,6 +1311,12 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
         return TOHIP_OK;
     };
 
+    auto enqueue_rounds = [&](int nrounds, bool careful) -> int {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = enqueue_rounds_inner(nrounds, careful);
+        host_enqueue_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    };
     int rounds_seen = 0;                 // rounds covered by the last collected readback
     int round_of[2] = {0, 0};            // rounds enqueued when each in-flight readback was posted
     int batches_since_compaction = 0;
@@ -1195,7 +1325,58 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
     int careful_at = -1;                 // `round` right after the careful round was enqueued
     const int ahead = always_careful ? 1 : 2;
     auto drain = [&](int rc) { while (inflight > 0) (void)collect(); return rc; };
-    while (ncand > 0 && round < max_rounds) {
+    // the sample's rounds end when its hulls have a few hundred faces each (faces created ~ 3x faces alive), are complete, or late
+    const int64_t switch_faces = (int64_t)join_faces * b.nseg;
+    auto join_all_points = [&]() -> int {
+        hipError_t ej = hipMemsetAsync(b.seg_cnt, 0, sizeof(int) * (size_t)b.nseg, st);
+        if (ej != hipSuccess) return (int)ej;
+        k_seg_faces<<<nblocks(nf), TO_BLOCK, 0, st>>>(b, b.seg_cnt, nullptr, nullptr);
+        k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(b.seg_cnt, b.nseg, b.seg_start, b.seg_start + b.nseg);
+        ej = hipMemsetAsync(b.flip_max, 0, sizeof(int) * (size_t)b.nseg, st);  // free since the flip: the scatter's cursors
+        if (ej != hipSuccess) return (int)ej;
+        k_seg_faces<<<nblocks(nf), TO_BLOCK, 0, st>>>(b, b.flip_max, b.seg_start, b.olist);  // olist is free between two rounds
+        const int gx = (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv(max_seg_points + 1, TO_BLOCK * kAssignPts)));
+        k_assign_all<<<dim3(gx, b.nseg), TO_BLOCK, 0, st>>>(b, b.seg_start, b.olist);
+        TO_HIP_CHECK_LAUNCH();
+        // the live list: every point that has a conflict face now
+        k_live_all<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);
+        const int ntl = (b.m1 + 1023) / 1024;
+        k_live_count<<<ntl, TO_BLOCK, 0, st>>>(b, b.m1, b.tile_cnt);
+        k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(b.tile_cnt, ntl, b.tile_off, b.ctrl + kCtrlNLive);
+        k_live_write<<<ntl, TO_BLOCK, 0, st>>>(b, b.m1, b.tile_off);
+        TO_HIP_CHECK_LAUNCH();
+        int* t = b.live; b.live = b.live2; b.live2 = t;
+        k_far_arg_all<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);  // apexes over the whole outside sets (k_seg_faces cleared them)
+        const int par = round & 1;
+        ej = hipMemsetAsync(b.ctrl + kCtrlInts + par * kSubLists * kCntStride, 0, sizeof(int) * kSubLists * kCntStride, st);
+        if (ej != hipSuccess) return (int)ej;
+        k_rebuild_candidates<<<kSubLists * (int)std::min<int64_t>(16, std::max<int64_t>(1, cdiv(nf, kSubLists * TO_BLOCK))), TO_BLOCK, 0, st>>>(b, par);
+        TO_HIP_CHECK_LAUNCH();
+        b.sub = 1;
+        return TOHIP_OK;
+    };
+    while ((ncand > 0 || b.sub > 1) && round < max_rounds) {
+        if (b.sub > 1 && (nf >= switch_faces || ncand == 0 || round >= 96)) {
+            while (inflight > 0) {  // the rounds in flight belong to the sample
+                e = collect();
+                if (e != hipSuccess) return drain((int)e);
+                if (h[kCtrlError]) return drain((h[kCtrlError] & kErrCapacity) ? TOHIP_ENOSPC : TOHIP_ENOTCONV);
+            }
+            nf = h[kCtrlNFaces + 8] < b.fcap ? h[kCtrlNFaces + 8] : b.fcap;
+            const int rc = join_all_points();
+            if (rc != TOHIP_OK) return rc;
+            e = post_readback();
+            if (e == hipSuccess) e = collect();
+            if (e != hipSuccess) return drain((int)e);
+            if (h[kCtrlError]) return (h[kCtrlError] & kErrCapacity) ? TOHIP_ENOSPC : TOHIP_ENOTCONV;
+            ncand = candidates(round & 1);
+            if (trace) fprintf(stderr, "hull: all points joined after round %d: faces %d live %d candidates %d\n", round, nf, h[kCtrlNLive], ncand);
+            stalled = false;
+            live_bound = b.m1;
+            batches_since_compaction = 0;
+            compaction_pending_until = round;
+            continue;
+        }
         if (!stalled) {
             while (inflight < ahead) {  // keep one batch ahead of the readback being waited for
                 const int rc = enqueue_rounds(always_careful ? 1 : batch, always_careful);
@@ -1206,6 +1387,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
             }
         } else if (inflight == 0) {
             // every enqueued round has reported and the last one accepted nobody: one round with converged ownership
+            if (trace) fprintf(stderr, "hull: careful round %d (candidates %d)\n", round, ncand);
             const int rc = enqueue_rounds(1, true);
             if (rc != TOHIP_OK) return drain(rc);
             round_of[wslot] = round;
@@ -1217,12 +1399,18 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
         e = collect();
         if (e != hipSuccess) return drain((int)e);
         rounds_seen = posted_at;
-        if (h[kCtrlError]) return drain((h[kCtrlError] & kErrCapacity) ? TOHIP_ENOSPC : TOHIP_ENOTCONV);
+        if (h[kCtrlError]) {
+            if (trace) fprintf(stderr, "hull: error bits %d at round %d\n", h[kCtrlError], posted_at);
+            return drain((h[kCtrlError] & kErrCapacity) ? TOHIP_ENOSPC : TOHIP_ENOTCONV);
+        }
         nf = h[kCtrlNFaces + 8] < b.fcap ? h[kCtrlNFaces + 8] : b.fcap;
         ncand = candidates(posted_at & 1);
         if (trace) fprintf(stderr, "hull: round %d faces %d live %d candidates %d accepted(last) %d\n", posted_at, nf, h[kCtrlNLive], ncand,
                            h[kCtrlAccepted]);
-        if (ncand == 0) break;  // no face has a point outside it: the hull is complete (rounds still in flight are no-ops)
+        if (ncand == 0) {  // no face has a point outside it: the hull is complete (rounds still in flight are no-ops) ...
+            if (b.sub > 1) continue;  // ... of the sample: time for the other points
+            break;
+        }
         if (h[kCtrlAccepted] <= 0) {
             // converged ownership always admits the best candidate: a careful round without progress = inconsistent predicates
             if (posted_at == careful_at || always_careful) return drain(TOHIP_ENOTCONV);
@@ -1245,6 +1433,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, hipStream_
     }
     if (round >= max_rounds && ncand > 0) return drain(TOHIP_ENOTCONV);
     round = rounds_seen;
+    if (trace) fprintf(stderr, "hull: %d rounds; host: %.0f us enqueueing rounds, %.0f us waiting for readbacks\n", round, host_enqueue_us, host_wait_us);
     if (rounds_out) *rounds_out = round;
     k_mark_vertices<<<nblocks(nf), TO_BLOCK, 0, st>>>(b);
     TO_HIP_CHECK_LAUNCH();
@@ -1398,7 +1587,7 @@ extern "C" int tohip_convex_hull_vertices(const float* pts, int64_t n, int with_
     hull::k_single_segment<<<1, 1, 0, st>>>(b);
     TO_HIP_CHECK_LAUNCH();
     int rounds = 0;
-    int rc = hull::build(b, pts, with_origin, st, &rounds);
+    int rc = hull::build(b, pts, with_origin, n, st, &rounds);
     if (rc != TOHIP_OK) return rc;
     if (rounds_host) *rounds_host = rounds;
     return hull::compact(b, idx, (int)n + 1, count, st);
@@ -1417,7 +1606,7 @@ extern "C" int tohip_hidden_pts_removal(const float* xyz, int64_t n, float param
     TO_HIP_CHECK_LAUNCH();
     int rc = launch_flip(xyz, n, param, b.flipped, nullptr, b.flip_max, st);
     if (rc != TOHIP_OK) return rc;
-    rc = hull::build(b, b.flipped, 1, st, nullptr);
+    rc = hull::build(b, b.flipped, 1, n, st, nullptr);
     if (rc != TOHIP_OK) return rc;
     // the hull lists at most n+1 vertices; visible_idx holds n: the last one is dropped anyway
     rc = hull::compact(b, visible_idx, (int)n, b.ctrl + hull::kCtrlChanged, st);
@@ -1471,7 +1660,9 @@ extern "C" int tohip_hidden_pts_removal_batched(const float* xyz, const int64_t*
         hull::k_flip_seg<<<hull::nblocks(n), TO_BLOCK, 0, st>>>(b, xyz, (int)n, (float)pow(10.0, (double)param), b.flipped);
         TO_HIP_CHECK_LAUNCH();
     }
-    int rc = hull::build(b, b.flipped, 1, st, nullptr);
+    int64_t max_seg = 0;
+    for (int32_t s = 0; s < n_segments; ++s) max_seg = std::max<int64_t>(max_seg, seg_offsets_host[s + 1] - seg_offsets_host[s]);
+    int rc = hull::build(b, b.flipped, 1, max_seg, st, nullptr);
     if (rc != TOHIP_OK) return rc;
     int* total = b.ctrl + hull::kCtrlChanged;
     rc = hull::compact(b, b.idx_all, b.m1, total, st);
