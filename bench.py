@@ -137,6 +137,9 @@ def main():
     ap.add_argument("--cameras", type=int, default=1,
                     help="cameras per waypoint (BASELINE.json configs[4]: 5, with --wps-per-gpu 32); each (camera, "
                          "waypoint) pair is one virtual waypoint with its own min-max normalisation")
+    ap.add_argument("--graph", choices=["on", "off"], default="off",
+                    help="replay the step's launches from a HIP graph in the timed region (measured SLOWER on ROCm 7.2: 0.151 vs "
+                         "0.139 ms dense, 0.079 vs 0.075 culled - graph kernel nodes cost more than the queue they replace)")
     ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dump", default=None, help="write the last dense step's outputs (scalars, gradient rows, rewards) to this .npz "
                                                  "(rank 0): tests compare runs at different N")
@@ -198,15 +201,41 @@ def main():
     ms = (ctypes.c_double * 5)()
     cnt = (ctypes.c_int64 * 5)()
 
+    use_graph = args.graph == "on" and shard is None
+
+    def captured(flags):
+        """The step's seven launches captured once into a HIP graph (torch.cuda.CUDAGraph on ROCm): a replay enqueues the same
+        kernels with the same arguments from one host call, so the ~50 us of Python + ctypes per step cannot starve the queue."""
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step(flags)
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            o = step(flags)
+        return g, o
+
     def timed(flags):
         """W warm-up steps, then exactly K steps between two (barrier + synchronize) fences; MAX over ranks.
         No instrumentation inside: the library's per-kernel HIP events cost ~0.06 ms per step."""
+        if use_graph:
+            g, o = captured(flags)
+            run = g.replay
+        else:
+            o = None
+            run = None
         for _ in range(args.warmup):
-            step(flags)
+            run() if run else step(flags)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            o = step(flags)
+            if run:
+                run()
+            else:
+                o = step(flags)
         fence()
         dt = time.perf_counter() - t0
         if n_gpus > 1 or forced:
@@ -286,6 +315,7 @@ def main():
                                    ", fwd + bwd (x,y,z,quaternion) gradients",
                        "n_points": args.points, "waypoints_total": w_total, "cameras": args.cameras,
                        "parallelism": f"waypoint-shard x{n_gpus}" if n_gpus > 1 else "single GPU",
+                       "launch": "HIP graph replay of the step's launches" if use_graph else "one host call per library entry point",
                        "mode": "dense: every (point, waypoint) pair evaluated, no data-dependent skipping; the 0.7 % of "
                                "(256-point slot, waypoint) pairs that can contribute are then revisited by the sparse kernels",
                        "loss_vis": float(out[0][1].item())},

@@ -426,7 +426,8 @@ template <bool FAST>
 __global__ void __launch_bounds__(TO_SELECT_THREADS)
 k_traj_select(const float2* __restrict__ part, int nslots, int V, WayRec* __restrict__ rec, int cull, float* __restrict__ minmax,
               unsigned long long* __restrict__ fv, int fv_words, unsigned long long* __restrict__ ft, int vwords,
-              int* __restrict__ vlist, int* __restrict__ vcnt, TieRec* __restrict__ ties, float* __restrict__ lo_sum, int64_t npad) {
+              int* __restrict__ vlist, int* __restrict__ vcnt, TieRec* __restrict__ ties, float* __restrict__ lo_sum, int64_t npad,
+              int* __restrict__ sflag, int* __restrict__ slist) {
     __shared__ float smn[TO_SELECT_THREADS / 64], smx[TO_SELECT_THREADS / 64];
     __shared__ float s_a, s_pmax;
     __shared__ int s_nmax, s_nmin, s_npairs, s_maxrow[TO_TIE_CAP], s_minrow[TO_TIE_CAP];
@@ -512,9 +513,19 @@ k_traj_select(const float2* __restrict__ part, int nslots, int V, WayRec* __rest
             int base = 0;
             if (lane == 0) base = atomicAdd(&s_npairs, __popcll(b));   // LDS: one reservation per wave
             base = __shfl(base, 0);
+            bool first = false;
             if (flag) {
                 myl[base + __popcll(b & ((1ull << lane) - 1ull))] = s;
-                atomicOr(&ft[(int64_t)s * vwords + (v >> 6)], 1ull << (v & 63));
+                // the slot's first flag (of any waypoint) puts it on the list k_traj_lo_sparse walks: a zero word before this bit
+                // is necessary, the exchange on the slot's own marker decides (other words, other blocks)
+                if (atomicOr(&ft[(int64_t)s * vwords + (v >> 6)], 1ull << (v & 63)) == 0ull) first = atomicExch(&sflag[s], 1) == 0;
+            }
+            const unsigned long long fb = __ballot(first);
+            if (fb) {   // one counter update per wave
+                int at = 0;
+                if (lane == 0) at = atomicAdd(&sflag[nslots], __popcll(fb));
+                at = __shfl(at, 0);
+                if (first) slist[at + __popcll(fb & ((1ull << lane) - 1ull))] = s;
             }
         }
     };
@@ -565,20 +576,20 @@ __device__ __forceinline__ float log_odds(const EvalK& k, const WayRec& r, float
 __global__ void __launch_bounds__(1024)
 k_traj_lo_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const unsigned long long* __restrict__ ft, int vwords,
                  float* __restrict__ lo_sum, const uint32_t* __restrict__ occ, int64_t occw, const int* __restrict__ toff, int n_traj,
-                 int C) {
-    // block per slot; the unflagged ones (94 % on the BASELINE workloads) leave after one scalar load of their flag words — a
-    // block's life is that latency, and only two 1024-thread blocks fit a CU.  The sum is ADDED to what lo_sum holds: zero from
+                 int C, const int* __restrict__ slist, const int* __restrict__ nlisted) {
+    // blocks walk the list of flagged slots k_traj_select made (6 % of the slots on the BASELINE workloads; a block per SLOT
+    // spent 9 of its 13 us on 3 700 blocks that read their flag words and left, two 1024-thread blocks to a CU).  The list's
+    // order is arrival order; a slot's sum does not depend on it.  The sum is ADDED to what lo_sum holds: zero from
     // pass 1, or the NaN k_traj_select stored everywhere for a degenerate waypoint (the reference divides 0/0 for every point
     // then, model.py:227).  Several trajectories (toff: their n_traj + 1 body-waypoint offsets; C cameras each): each has its own vector and
     // its own rank count, so its sum is the one a run of that trajectory alone produces.
     __shared__ float spart[3][TO_SLOT];
-    const int s = blockIdx.x;
     const int pt = threadIdx.x & (TO_SLOT - 1), g = threadIdx.x >> 8;
+    const int nl = *nlisted;
+  for (int li = blockIdx.x; li < nl; li += gridDim.x) {   // block-uniform
+    const int s = slist[li];
     const int64_t i = (int64_t)s * TO_SLOT + pt;
     const unsigned long long* fts = ft + (int64_t)s * vwords;
-    unsigned long long any = fts[0];
-    for (int w = 1; w < vwords; ++w) any |= fts[w];
-    if (!any) return;
     const float x = cv.soa[i], y = cv.soa[cv.npad + i], z = cv.soa[2 * cv.npad + i];
     float acc = 0.f;
     int rank = 0, cur = 0, v_next = toff ? toff[1] * C : 0x7fffffff;
@@ -611,6 +622,7 @@ k_traj_lo_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const un
         }
     }
     if (open_) flush();
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1091,7 +1103,8 @@ struct TrajPlan {
     int fv_words;  // (nslots + 63) / 64
     int vwords;    // (V + 63) / 64
     int V;
-    size_t off_ctl, off_rec, off_cold, off_part, off_fv, off_ft, off_vcnt, off_vlist, off_ties, off_bpart, off_vgrad, total;
+    size_t off_ctl, off_rec, off_cold, off_part, off_fv, off_ft, off_sflag, off_slist, off_vcnt, off_vlist, off_ties, off_bpart, off_vgrad, total;
+    int64_t ft_zero_words;   // ft and, right behind it, one int per slot ("listed") + the slot list's counter: cleared together
 };
 
 inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
@@ -1108,7 +1121,10 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
     p.off_cold = o;  o += align_up((size_t)W * sizeof(WayCold), 256);
     p.off_part = o;  o += align_up((size_t)V * (size_t)p.nslots * sizeof(float2), 256);
     p.off_fv = o;    o += align_up((size_t)V * (size_t)p.fv_words * sizeof(unsigned long long), 256);
-    p.off_ft = o;    o += align_up((size_t)p.nslots * (size_t)p.vwords * sizeof(unsigned long long), 256);
+    p.off_ft = o;    o += (size_t)p.nslots * (size_t)p.vwords * sizeof(unsigned long long);
+    p.off_sflag = o; o += align_up(((size_t)p.nslots + 2) * sizeof(int), 256);   // [nslots] listed?  [nslots] = entries of slist
+    p.ft_zero_words = (int64_t)((o - p.off_ft) / sizeof(unsigned long long));
+    p.off_slist = o; o += align_up((size_t)p.nslots * sizeof(int), 256);
     p.off_vcnt = o;  o += align_up((size_t)V * sizeof(int), 256);
     p.off_vlist = o; o += align_up((size_t)V * (size_t)p.nslots * sizeof(int), 256);
     p.off_ties = o;  o += align_up((size_t)V * sizeof(TieRec), 256);
@@ -1193,7 +1209,9 @@ extern "C" int tohip_traj_forward_multi(const void* packed, int64_t n, const flo
     const bool cull = !(flags & TOHIP_TRAJ_DENSE);
     const float* rq = (C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
     const float* rt = rq ? rig->rig_trans : nullptr;
-    const int64_t ft_words = (int64_t)pl.nslots * pl.vwords;
+    const int64_t ft_words = pl.ft_zero_words;   // the flag words and the slot list's markers + counter behind them
+    int* sflag = (int*)(ws + pl.off_sflag);
+    int* slist = (int*)(ws + pl.off_slist);
     const int64_t occw = cv.npad / 32;
     const int* toff = n_traj > 1 ? traj_offsets : nullptr;
     const OutInit oi{lo_sum, rewards_half, cv.npad, n, (int)n_traj};
@@ -1232,15 +1250,16 @@ extern "C" int tohip_traj_forward_multi(const void* packed, int64_t n, const flo
         TO_PROF(TOHIP_PROF_SMALL, st);
         if (pl.nslots <= TO_SELECT_FAST_SLOTS)
             k_traj_select<true><<<(int)V, TO_SELECT_THREADS, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
-                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad);
+                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist);
         else
             k_traj_select<false><<<(int)V, TO_SELECT_THREADS, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
-                                                                       pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad);
+                                                                       pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist);
         TO_HIP_CHECK_LAUNCH();
     }
     {
         TO_PROF(TOHIP_PROF_PASS2, st);
-        k_traj_lo_sparse<<<pl.nslots, 1024, 0, st>>>(cv, rec, k, ft, pl.vwords, lo_sum, occlusion_bits, occw, toff, (int)n_traj, C);
+        k_traj_lo_sparse<<<pl.nslots < 512 ? pl.nslots : 512, 1024, 0, st>>>(cv, rec, k, ft, pl.vwords, lo_sum, occlusion_bits, occw, toff, (int)n_traj, C,
+                                                                          slist, sflag + pl.nslots);
         TO_HIP_CHECK_LAUNCH();
     }
     return TOHIP_OK;
