@@ -22,6 +22,7 @@ so a launch moves ~N*16 B whatever W is (1 % of HBM peak) and is bound by vector
   peak     = 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, max clock)
 """
 import argparse
+import gc
 import ctypes
 import json
 import os
@@ -180,9 +181,13 @@ def main():
         shard.allgather_rows(torch.zeros((args.wps_per_gpu, 7), device=device))
         torch.cuda.synchronize(device)
 
+    rewards_buf = torch.empty(cloud.n, dtype=torch.float32, device=device)   # refilled by every forward
+    lo_buf = torch.empty(cloud.npad, dtype=torch.float32, device=device)
+    mm_buf = torch.empty((n_virtual, 2), dtype=torch.float32, device=device)
+
     def step(flags):
-        rewards = torch.empty(cloud.n, dtype=torch.float32, device=device)
-        lo_sum, minmax = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags, rewards_half=rewards)
+        rewards = rewards_buf
+        lo_sum, minmax = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags, lo_sum=lo_buf, minmax=mm_buf, rewards_half=rewards)
         if shard is not None:
             shard.allreduce_sum(lo_sum)  # the one data-path collective: N floats over xGMI
         rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws, rewards=rewards, prefilled=True)
@@ -230,6 +235,8 @@ def main():
         for _ in range(args.warmup):
             run() if run else step(flags)
         fence()
+        gc_was = gc.isenabled()
+        gc.disable()   # a collector pause in the issuing thread is not part of the path
         t0 = time.perf_counter()
         for _ in range(args.steps):
             if run:
@@ -238,6 +245,8 @@ def main():
                 o = step(flags)
         fence()
         dt = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
         if n_gpus > 1 or forced:
             t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
