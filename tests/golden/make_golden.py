@@ -210,6 +210,17 @@ def gen_traj():
     save("traj_synth_dense", **d)
 
 
+def gen_ties():
+    """Three- and five-fold copies of a block of points: every waypoint's argmax (and the other extremal / active points of
+    the block) is a tie set of >= 3 elements — what torch.max / torch.min do with the gradient there (model.py:226-227)."""
+    cloud = synth.make_cloud(1500, seed=23)
+    cloud = np.concatenate([cloud, cloud[:400], cloud[:400], cloud[100:200], cloud[100:200]], axis=0)   # 3x [0,400), 5x [100,200)
+    p, q = synth.make_path(5, optical=True, jitter_seed=23)
+    d = run_traj(cloud, p, q, 0.0)
+    d.update(run_traj_visonly(cloud, p, q))
+    save("traj_synth_ties3", **d)
+
+
 def gen_clip():
     """Non-default pc_clip_limits (min_dist, max_dist): the Gaussian of get_dist_mask moves to (0.5+8)/2 = 4.25 with
     std 3.75 (model.py:18-21).  python tests/golden/make_golden.py clip"""
@@ -454,6 +465,6 @@ def gen_timing():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["traj", "adam", "pose", "funcs", "hard", "ingest"]
+    which = sys.argv[1:] or ["traj", "ties", "adam", "pose", "funcs", "hard", "ingest"]
     for w in which:
         globals()["gen_" + w]()

@@ -67,7 +67,7 @@ def test_packed_cloud_is_a_permutation(dev):
 
 
 GOLD = ["traj_bundled_tilted_all", "traj_synth_1000x3", "traj_synth_10000x8", "traj_synth_20000x32",
-        "traj_synth_ties", "traj_synth_dense", "traj_synth_clip"]
+        "traj_synth_ties", "traj_synth_ties3", "traj_synth_dense", "traj_synth_clip"]
 
 
 @pytest.mark.parametrize("name", GOLD)
@@ -83,7 +83,7 @@ def test_c_abi_vs_golden(dev, name):
     assert rel_inf(r["qg"], d["vis_quats_grad"]) < GRAD_TOL
 
 
-@pytest.mark.parametrize("name", ["traj_synth_ties", "traj_synth_dense", "traj_synth_20000x32", "traj_bundled_tilted_all"])
+@pytest.mark.parametrize("name", ["traj_synth_ties", "traj_synth_ties3", "traj_synth_dense", "traj_synth_20000x32", "traj_bundled_tilted_all"])
 def test_culling_is_bitwise_exact(dev, name):
     """The default path skips pairs that provably contribute nothing; TOHIP_TRAJ_DENSE evaluates every pair.
     Same bits out (fixtures incl. ties at the max and a dense cloud with min p > 0)."""

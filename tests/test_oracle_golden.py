@@ -16,7 +16,7 @@ def _wps_step(d):
 
 
 TRAJ = ["traj_bundled_default", "traj_bundled_tilted_all", "traj_synth_1000x3", "traj_synth_10000x8",
-        "traj_synth_20000x32", "traj_synth_ties", "traj_synth_dense", "traj_synth_clip"]
+        "traj_synth_20000x32", "traj_synth_ties", "traj_synth_ties3", "traj_synth_dense", "traj_synth_clip"]
 
 
 def _clip(d):
