@@ -1011,9 +1011,10 @@ __global__ void __launch_bounds__(TO_BLOCK) k_seg_faces(Bufs b, int* __restrict_
 
 constexpr int kAssignPts = 8, kAssignTile = 256;
 __global__ void __launch_bounds__(TO_BLOCK) k_assign_all(Bufs b, const int* __restrict__ off, const int* __restrict__ list) {
-    struct Plane { double nx, ny, nz, x0, y0, z0; };
+    // per face: the plane as n.p - c with c = n.p0 LOWERED by a bound of both expressions' rounding (a filter: 3 FMAs), and the
+    // record of the kernels' own distance expression (plane_dist) for the pairs that pass it
+    struct Plane { double nx, ny, nz, cm, x0, y0, z0; int f; int pad; };
     __shared__ Plane pl[kAssignTile];
-    __shared__ int pf[kAssignTile];
     __shared__ FaceMaxTable tab;
     face_max_init(tab);
     const int sg = blockIdx.y, lo = b.seg_off[sg], hi = b.seg_off[sg + 1];
@@ -1022,6 +1023,9 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign_all(Bufs b, const int* __re
     // is rounding noise, not a conflict)
     const int fb = 4 * sg;
     const int c0 = b.fv[3 * fb], c1 = b.fv[3 * fb + 1], c2 = b.fv[3 * fb + 2], c3 = b.fv[3 * fb + 5];
+    // largest coordinate magnitude of the segment (its bounding box)
+    double rmax = 0.0;
+    for (int k = 0; k < 6; ++k) rmax = fmax(rmax, fabs((double)fkey_inv(b.seg_bbox[6 * sg + k])));
     const int chunk = TO_BLOCK * kAssignPts;
     for (int base = lo + blockIdx.x * chunk; base < hi; base += gridDim.x * chunk) {  // block-uniform
         double x[kAssignPts], y[kAssignPts], z[kAssignPts], best[kAssignPts];
@@ -1029,9 +1033,10 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign_all(Bufs b, const int* __re
         bool mine[kAssignPts];
         for (int k = 0; k < kAssignPts; ++k) {
             const int j = base + k * TO_BLOCK + threadIdx.x;
-            mine[k] = j < hi && j % b.sub != 0 && j != c0 && j != c1 && j != c2 && j != c3;  // the sample's points have their faces (or have retired) already
+            // the sample's points have their faces (or have retired) already
+            mine[k] = j < hi && j % b.sub != 0 && j != c0 && j != c1 && j != c2 && j != c3;
             x[k] = mine[k] ? b.px[j] : 0.0; y[k] = mine[k] ? b.py[j] : 0.0; z[k] = mine[k] ? b.pz[j] : 0.0;
-            best[k] = 0.0; bf[k] = kNone;
+            best[k] = mine[k] ? 0.0 : INFINITY; bf[k] = kNone;   // (nothing beats infinity: the other lanes never ask for a test)
         }
         for (int t0 = f0; t0 < f1; t0 += kAssignTile) {
             const int nt = min(kAssignTile, f1 - t0);
@@ -1039,16 +1044,26 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign_all(Bufs b, const int* __re
             if ((int)threadIdx.x < nt) {
                 const int f = list[t0 + threadIdx.x];
                 const FaceRec r = b.frec[f];
-                pl[threadIdx.x] = Plane{r.nx, r.ny, r.nz, r.x0, r.y0, r.z0};
-                pf[threadIdx.x] = f;
+                const double c = r.nx * r.x0 + r.ny * r.y0 + r.nz * r.z0;
+                // |n.p - c - plane_dist| <= ~8u (|nx|+|ny|+|nz|)(rmax + |p0|): 2e-15 covers 16u
+                const double m = 2e-15 * ((fabs(r.nx) + fabs(r.ny) + fabs(r.nz)) * (2.0 * rmax) + fabs(c));
+                pl[threadIdx.x] = Plane{r.nx, r.ny, r.nz, c - m, r.x0, r.y0, r.z0, f, 0};
             }
             __syncthreads();
             for (int q = 0; q < nt; ++q) {
-                const Plane P = pl[q];
-                const int f = pf[q];
-                FaceRec r;  // the same expression as every other distance test (plane_dist)
-                r.nx = P.nx; r.ny = P.ny; r.nz = P.nz; r.x0 = P.x0; r.y0 = P.y0; r.z0 = P.z0;
+                const double nx = pl[q].nx, ny = pl[q].ny, nz = pl[q].nz, cm = pl[q].cm;
+                bool any = false;
+                bool need[kAssignPts];
                 for (int k = 0; k < kAssignPts; ++k) {
+                    need[k] = fma(nx, x[k], fma(ny, y[k], fma(nz, z[k], -cm))) > best[k];  // an upper bound of the distance
+                    any |= need[k];
+                }
+                if (!__any(any)) continue;
+                FaceRec r;  // the same expression as every other distance test
+                r.nx = nx; r.ny = ny; r.nz = nz; r.x0 = pl[q].x0; r.y0 = pl[q].y0; r.z0 = pl[q].z0;
+                const int f = pl[q].f;
+                for (int k = 0; k < kAssignPts; ++k) {
+                    if (!need[k]) continue;
                     const double d = plane_dist(r, x[k], y[k], z[k]);
                     if (d > best[k]) { best[k] = d; bf[k] = f; }
                 }
@@ -1057,7 +1072,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign_all(Bufs b, const int* __re
         for (int k = 0; k < kAssignPts; ++k) {
             const int j = base + k * TO_BLOCK + threadIdx.x;
             if (mine[k]) b.pface[j] = bf[k];
-            wave_face_max(b, tab, mine[k] ? bf[k] : kNone, dkey(best[k]));
+            wave_face_max(b, tab, mine[k] ? bf[k] : kNone, dkey(mine[k] ? best[k] : 0.0));
         }
     }
     face_max_flush(b, tab);
