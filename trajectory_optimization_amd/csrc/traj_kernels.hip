@@ -15,7 +15,7 @@
 //                                rows that hold the extrema (tie sets)
 //   k_traj_lo_sparse             block per flagged slot: log-odds of its flagged waypoints, summed in a fixed order
 //   k_traj_reward                rewards = sigmoid(lo_sum) in the caller's order, mean, visibility loss (one launch)
-//   k_traj_bwd_sparse            block per flagged pair: the 14 gradient sums of its 256 points
+//   k_traj_bwd_sparse            wave per flagged pair: the 14 gradient sums of its 256 points
 //   k_traj_bwd_finish            block per waypoint: partials in slot order (f64), argmin/argmax shares from the
 //                                recorded rows (deterministic: no float atomics), chain to (position, quaternion)
 //
@@ -40,6 +40,7 @@
 //
 // The forward leaves its state (records, flags, lists) in the workspace; the backward reads it there: the workspace
 // must not be touched between tohip_traj_forward and tohip_traj_backward of the same step.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -427,7 +428,7 @@ __global__ void __launch_bounds__(TO_SELECT_THREADS)
 k_traj_select(const float2* __restrict__ part, int nslots, int V, WayRec* __restrict__ rec, int cull, float* __restrict__ minmax,
               unsigned long long* __restrict__ fv, int fv_words, unsigned long long* __restrict__ ft, int vwords,
               int* __restrict__ vlist, int* __restrict__ vcnt, TieRec* __restrict__ ties, float* __restrict__ lo_sum, int64_t npad,
-              int* __restrict__ sflag, int* __restrict__ slist) {
+              int* __restrict__ sflag, int* __restrict__ slist, int64_t nmark, const int* __restrict__ toff, int C) {
     __shared__ float smn[TO_SELECT_THREADS / 64], smx[TO_SELECT_THREADS / 64];
     __shared__ float s_a, s_pmax;
     __shared__ int s_nmax, s_nmin, s_npairs, s_maxrow[TO_TIE_CAP], s_minrow[TO_TIE_CAP];
@@ -499,6 +500,14 @@ k_traj_select(const float2* __restrict__ part, int nslots, int V, WayRec* __rest
         for (int64_t i = t; i < npad; i += TO_SELECT_THREADS) lo_t[i] = nanv;
     }
     int* myl = vlist + (int64_t)v * nslots;
+    // the waypoint's trajectory and that trajectory's bits of this waypoint's flag word
+    const int seg = rec[v].seg;
+    unsigned long long seg_mask = ~0ull;
+    if (toff != nullptr) {
+        const int v_lo = toff[seg] * C, v_hi = toff[seg + 1] * C, w0 = (v >> 6) * 64;
+        if (w0 < v_lo) seg_mask &= ~0ull << (v_lo - w0);
+        if (v_hi - w0 < 64) seg_mask &= (1ull << (v_hi - w0)) - 1ull;
+    }
     auto sweep2 = [&](const float2 qq, const int s0) {
         const int s = s0 + t;
         bool flag = false;
@@ -518,14 +527,19 @@ k_traj_select(const float2* __restrict__ part, int nslots, int V, WayRec* __rest
                 myl[base + __popcll(b & ((1ull << lane) - 1ull))] = s;
                 // the slot's first flag (of any waypoint) puts it on the list k_traj_lo_sparse walks: a zero word before this bit
                 // is necessary, the exchange on the slot's own marker decides (other words, other blocks)
-                if (atomicOr(&ft[(int64_t)s * vwords + (v >> 6)], 1ull << (v & 63)) == 0ull) first = atomicExch(&sflag[s], 1) == 0;
+                // (the word may hold other trajectories' bits: a zero word is only the cheap way out for the common case)
+                const unsigned long long old = atomicOr(&ft[(int64_t)s * vwords + (v >> 6)], 1ull << (v & 63));
+                if ((old & seg_mask) == 0ull) first = atomicExch(&sflag[(int64_t)seg * nslots + s], 1) == 0;
             }
             const unsigned long long fb = __ballot(first);
             if (fb) {   // one counter update per wave
                 int at = 0;
-                if (lane == 0) at = atomicAdd(&sflag[nslots], __popcll(fb));
+                if (lane == 0) at = atomicAdd(&sflag[nmark], __popcll(fb));
                 at = __shfl(at, 0);
-                if (first) slist[at + __popcll(fb & ((1ull << lane) - 1ull))] = s;
+                if (first) {
+                    const int e = at + __popcll(fb & ((1ull << lane) - 1ull));
+                    slist[2 * e] = s; slist[2 * e + 1] = seg;
+                }
             }
         }
     };
@@ -577,7 +591,7 @@ __global__ void __launch_bounds__(1024)
 k_traj_lo_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const unsigned long long* __restrict__ ft, int vwords,
                  float* __restrict__ lo_sum, const uint32_t* __restrict__ occ, int64_t occw, const int* __restrict__ toff, int n_traj,
                  int C, const int* __restrict__ slist, const int* __restrict__ nlisted) {
-    // blocks walk the list of flagged slots k_traj_select made (6 % of the slots on the BASELINE workloads; a block per SLOT
+    // blocks walk the list of flagged (slot, trajectory) pairs k_traj_select made (6 % of the slots on the BASELINE workloads; a block per SLOT
     // spent 9 of its 13 us on 3 700 blocks that read their flag words and left, two 1024-thread blocks to a CU).  The list's
     // order is arrival order; a slot's sum does not depend on it.  The sum is ADDED to what lo_sum holds: zero from
     // pass 1, or the NaN k_traj_select stored everywhere for a degenerate waypoint (the reference divides 0/0 for every point
@@ -586,43 +600,37 @@ k_traj_lo_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const un
     __shared__ float spart[3][TO_SLOT];
     const int pt = threadIdx.x & (TO_SLOT - 1), g = threadIdx.x >> 8;
     const int nl = *nlisted;
-  for (int li = blockIdx.x; li < nl; li += gridDim.x) {   // block-uniform
-    const int s = slist[li];
-    const int64_t i = (int64_t)s * TO_SLOT + pt;
-    const unsigned long long* fts = ft + (int64_t)s * vwords;
-    const float x = cv.soa[i], y = cv.soa[cv.npad + i], z = cv.soa[2 * cv.npad + i];
-    float acc = 0.f;
-    int rank = 0, cur = 0, v_next = toff ? toff[1] * C : 0x7fffffff;
-    bool open_ = false;   // the current trajectory has a flagged waypoint in this slot (uniform)
-    auto flush = [&]() {
+    // a list entry = (slot, trajectory): that trajectory's waypoints [v_lo, v_hi) only, its own log-odds vector — the trajectories
+    // of a slot run side by side, and nobody looks at a (slot, trajectory) pair without a flag
+    for (int li = blockIdx.x; li < nl; li += gridDim.x) {   // block-uniform
+        const int s = slist[2 * li], tr = slist[2 * li + 1];
+        const int v_lo = toff ? toff[tr] * C : 0, v_hi = toff ? toff[tr + 1] * C : 0x7fffffff;
+        const unsigned long long* fts = ft + (int64_t)s * vwords;
+        const int64_t i = (int64_t)s * TO_SLOT + pt;
+        const float x = cv.soa[i], y = cv.soa[cv.npad + i], z = cv.soa[2 * cv.npad + i];
+        float acc = 0.f;
+        int rank = 0;
+        for (int w = v_lo >> 6; w < vwords && w * 64 < v_hi; ++w) {
+            unsigned long long bits = fts[w];
+            if (w * 64 < v_lo) bits &= ~0ull << (v_lo - w * 64);
+            if (v_hi - w * 64 < 64) bits &= (1ull << (v_hi - w * 64)) - 1ull;
+            while (bits) {
+                const int v = w * 64 + __builtin_ctzll(bits);
+                bits &= bits - 1ull;
+                if (((rank++) & 3) == g) {
+                    const WayRec& r = rec[v];
+                    acc += log_odds(k, r, vis_p(r, k, x, y, z) * occ_one(occ, occw, v, i));
+                }
+            }
+        }
         if (g) spart[g - 1][pt] = acc;
         __syncthreads();
         if (!g) {
-            float* dst = lo_sum + (int64_t)cur * cv.npad + i;
+            float* dst = lo_sum + (int64_t)tr * cv.npad + i;
             *dst = *dst + (((acc + spart[0][pt]) + spart[1][pt]) + spart[2][pt]);
         }
         __syncthreads();
-        acc = 0.f; rank = 0; open_ = false;
-    };
-    for (int w = 0; w < vwords; ++w) {
-        unsigned long long bits = fts[w];
-        while (bits) {
-            const int v = w * 64 + __builtin_ctzll(bits);
-            bits &= bits - 1ull;
-            if (v >= v_next) {   // the walk enters a later trajectory
-                if (open_) flush();
-                while (cur + 1 < n_traj && v >= toff[cur + 1] * C) ++cur;
-                v_next = cur + 1 < n_traj ? toff[cur + 1] * C : 0x7fffffff;
-            }
-            open_ = true;
-            if (((rank++) & 3) == g) {
-                const WayRec& r = rec[v];
-                acc += log_odds(k, r, vis_p(r, k, x, y, z) * occ_one(occ, occw, v, i));
-            }
-        }
     }
-    if (open_) flush();
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -705,72 +713,73 @@ k_traj_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, in
 // Per flagged pair 14 sums, bpart[(v*nslots+slot)*16 ..]:
 //   [0..2] sum w gy   [3..11] sum w y (x) gy   [12] S1   [13] S2        (w = G/M, gy = dp/dy, y = x - t)
 
-#define TO_BWD_GX 32   // blocks per waypoint: block (x, v) takes the flagged slots vlist[v][x], [x + 32], ...
+#define TO_BWD_GX 8    // blocks per waypoint; wave (x, w) of a waypoint takes the flagged slots vlist[v][4x + w], [.. + 32], ...
+// One WAVE per flagged pair, four points per lane (point lane + 64 j of the slot): the 14 sums are added per lane over its four
+// points, then once across the wave (DPP tree, total in lane 63) — a quarter of the cross-lane work a 256-thread block with one
+// point per thread spent, no LDS and no block barrier.  A fixed order that depends on nothing but the pair.
 __global__ void __launch_bounds__(TO_SLOT)
 k_traj_bwd_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const int* __restrict__ vlist, const int* __restrict__ vcnt,
                   int nslots, const float* __restrict__ lo_sum, const float* __restrict__ grad_rewards,
                   const float* __restrict__ scalars, const float* __restrict__ gout, float* __restrict__ bpart,
                   const uint32_t* __restrict__ occ, int64_t occw) {
-    __shared__ float swave[TO_SLOT / 64][TO_BWD_NSUM];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * (TO_SLOT / 64) + (threadIdx.x >> 6), nwv = gridDim.x * (TO_SLOT / 64);
     const int v = blockIdx.y;
     const int npairs = vcnt[v];
-    if ((int)blockIdx.x >= npairs) return;
+    if (wv >= npairs) return;
     // the waypoint's trajectory: its log-odds vector, upstream gradient and loss scalars
     const int seg = rec[v].seg;
     lo_sum += (int64_t)seg * cv.npad;
     if (grad_rewards) grad_rewards += (int64_t)seg * cv.n;
     const float coef = grad_rewards ? 0.f : scalars[4 * seg + 2] * gout[seg];
-    for (int it = blockIdx.x; it < npairs; it += gridDim.x) {
+    const WayRec& r = rec[v];
+    for (int it = wv; it < npairs; it += nwv) {
         const int s = vlist[(int64_t)v * nslots + it];
-        const int64_t i = (int64_t)s * TO_SLOT + t;
-        const float x = cv.soa[i], y = cv.soa[cv.npad + i], z = cv.soa[2 * cv.npad + i];
-        // dL/d lo_sum_n: through the caller's dL/d rewards vector (general criterion) or the fused visibility loss
-        float gn = 0.f;
-        if (i < cv.n) {
-            const float lo = lo_sum[i];
-            float rw = to_rcp(1.0f + to_exp(-lo));  // == k_traj_reward's value of rewards[perm[i]]
-            if (lo != lo) rw = lo;
-            const float gr = grad_rewards ? grad_rewards[cv.perm[i]] : coef;
-            gn = gr * rw * (1.0f - rw);
-        }
-        const WayRec& r = rec[v];
-        VisGrad vg;
-        const float p = vis_p(r, k, x, y, z, &vg) * occ_one(occ, occw, v, i);
-        const float ph = (p - r.a) * r.invM;
-        const bool act = (ph >= 0.5f) && (ph <= k.clip_hi);
         float acc[TO_BWD_NSUM];
 #pragma unroll
         for (int j = 0; j < TO_BWD_NSUM; ++j) acc[j] = 0.f;
-        if (act) {
-            float g[3];
-            dvis_dy(r, k, p, vg, g);
-            const float G = gn * to_rcp(ph * (1.0f - ph));
-            const float wgt = G * r.invM;
-            acc[12] = wgt * (ph - 1.0f);
-            acc[13] = -wgt * ph;
-            const float w0 = wgt * g[0], w1 = wgt * g[1], w2 = wgt * g[2];
-            acc[0] = w0; acc[1] = w1; acc[2] = w2;
-            acc[3] = vg.y0 * w0; acc[4] = vg.y0 * w1; acc[5] = vg.y0 * w2;
-            acc[6] = vg.y1 * w0; acc[7] = vg.y1 * w1; acc[8] = vg.y1 * w2;
-            acc[9] = vg.y2 * w0; acc[10] = vg.y2 * w1; acc[11] = vg.y2 * w2;
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < TO_SLOT / 64; ++q) {
+            const int64_t i = (int64_t)s * TO_SLOT + q * 64 + lane;
+            const float x = cv.soa[i], y = cv.soa[cv.npad + i], z = cv.soa[2 * cv.npad + i];
+            // dL/d lo_sum_n: through the caller's dL/d rewards vector (general criterion) or the fused visibility loss
+            float gn = 0.f;
+            if (i < cv.n) {
+                const float lo = lo_sum[i];
+                float rw = to_rcp(1.0f + to_exp(-lo));  // == k_traj_reward's value of rewards[perm[i]]
+                if (lo != lo) rw = lo;
+                const float gr = grad_rewards ? grad_rewards[cv.perm[i]] : coef;
+                gn = gr * rw * (1.0f - rw);
+            }
+            VisGrad vg;
+            const float p = vis_p(r, k, x, y, z, &vg) * occ_one(occ, occw, v, i);
+            const float ph = (p - r.a) * r.invM;
+            const bool act = (ph >= 0.5f) && (ph <= k.clip_hi);
+            if (act) {
+                float g[3];
+                dvis_dy(r, k, p, vg, g);
+                const float G = gn * to_rcp(ph * (1.0f - ph));
+                const float wgt = G * r.invM;
+                acc[12] += wgt * (ph - 1.0f);
+                acc[13] += -wgt * ph;
+                const float w0 = wgt * g[0], w1 = wgt * g[1], w2 = wgt * g[2];
+                acc[0] += w0; acc[1] += w1; acc[2] += w2;
+                acc[3] += vg.y0 * w0; acc[4] += vg.y0 * w1; acc[5] += vg.y0 * w2;
+                acc[6] += vg.y1 * w0; acc[7] += vg.y1 * w1; acc[8] += vg.y1 * w2;
+                acc[9] += vg.y2 * w0; acc[10] += vg.y2 * w1; acc[11] += vg.y2 * w2;
+                any = true;
+            }
         }
-        // fixed-order block sum: DPP tree inside each wave, then the four wave totals in wave order
-        if (__any(act)) {
+        if (__any(any)) {
 #pragma unroll
             for (int j = 0; j < TO_BWD_NSUM; ++j) acc[j] = wave_sum63(acc[j]);
         }
         if (lane == 63) {
+            float* dst = bpart + ((int64_t)v * nslots + s) * 16;
 #pragma unroll
-            for (int j = 0; j < TO_BWD_NSUM; ++j) swave[wave][j] = acc[j];
+            for (int j = 0; j < TO_BWD_NSUM; ++j) dst[j] = acc[j];
+            dst[14] = 0.f; dst[15] = 0.f;   // the finish kernel adds all 16 columns of a row
         }
-        __syncthreads();
-        if (t < 16) {
-            float q = 0.f;
-            if (t < TO_BWD_NSUM) q = ((swave[0][t] + swave[1][t]) + swave[2][t]) + swave[3][t];
-            bpart[((int64_t)v * nslots + s) * 16 + t] = q;
-        }
-        __syncthreads();
     }
 }
 
@@ -1104,6 +1113,7 @@ struct TrajPlan {
     int vwords;    // (V + 63) / 64
     int V;
     size_t off_ctl, off_rec, off_cold, off_part, off_fv, off_ft, off_sflag, off_slist, off_vcnt, off_vlist, off_ties, off_bpart, off_vgrad, total;
+    int64_t nmark;           // (trajectory, slot) markers = capacity of the pair list
     int64_t ft_zero_words;   // ft and, right behind it, one int per slot ("listed") + the slot list's counter: cleared together
 };
 
@@ -1122,9 +1132,11 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
     p.off_part = o;  o += align_up((size_t)V * (size_t)p.nslots * sizeof(float2), 256);
     p.off_fv = o;    o += align_up((size_t)V * (size_t)p.fv_words * sizeof(unsigned long long), 256);
     p.off_ft = o;    o += (size_t)p.nslots * (size_t)p.vwords * sizeof(unsigned long long);
-    p.off_sflag = o; o += align_up(((size_t)p.nslots + 2) * sizeof(int), 256);   // [nslots] listed?  [nslots] = entries of slist
+    const size_t nmark = (size_t)p.nslots * (size_t)(n_traj < 1 ? 1 : n_traj);   // one marker per (trajectory, slot)
+    p.nmark = (int64_t)nmark;
+    p.off_sflag = o; o += align_up((nmark + 2) * sizeof(int), 256);   // [nmark] listed?  [nmark] = entries of slist
     p.ft_zero_words = (int64_t)((o - p.off_ft) / sizeof(unsigned long long));
-    p.off_slist = o; o += align_up((size_t)p.nslots * sizeof(int), 256);
+    p.off_slist = o; o += align_up(nmark * 2 * sizeof(int), 256);     // (slot, trajectory) pairs
     p.off_vcnt = o;  o += align_up((size_t)V * sizeof(int), 256);
     p.off_vlist = o; o += align_up((size_t)V * (size_t)p.nslots * sizeof(int), 256);
     p.off_ties = o;  o += align_up((size_t)V * sizeof(TieRec), 256);
@@ -1186,7 +1198,7 @@ extern "C" int tohip_traj_forward_multi(const void* packed, int64_t n, const flo
                                         const int32_t* traj_offsets, int64_t n_traj, const tohip_camera* cam, const tohip_rig* rig,
                                         int flags, const uint32_t* occlusion_bits, float* lo_sum, float* minmax, float* rewards_half,
                                         void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!packed || !poses || !quats || !cam || !lo_sum || !minmax || !workspace || n <= 0 || W <= 0 || n_traj <= 0 ||
+    if (!packed || !poses || !quats || !cam || !lo_sum || !minmax || !workspace || n <= 0 || W <= 0 || n_traj <= 0 || n_traj > 65535 ||
         (n_traj > 1 && !traj_offsets))
         return TOHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
@@ -1250,16 +1262,17 @@ extern "C" int tohip_traj_forward_multi(const void* packed, int64_t n, const flo
         TO_PROF(TOHIP_PROF_SMALL, st);
         if (pl.nslots <= TO_SELECT_FAST_SLOTS)
             k_traj_select<true><<<(int)V, TO_SELECT_THREADS, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
-                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist);
+                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C);
         else
             k_traj_select<false><<<(int)V, TO_SELECT_THREADS, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
-                                                                       pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist);
+                                                                       pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C);
         TO_HIP_CHECK_LAUNCH();
     }
     {
         TO_PROF(TOHIP_PROF_PASS2, st);
-        k_traj_lo_sparse<<<pl.nslots < 512 ? pl.nslots : 512, 1024, 0, st>>>(cv, rec, k, ft, pl.vwords, lo_sum, occlusion_bits, occw, toff, (int)n_traj, C,
-                                                                          slist, sflag + pl.nslots);
+        const int64_t lob = std::min<int64_t>(pl.nmark, 512 * n_traj);   // blocks: the expected number of listed pairs, each a chain of its own
+        k_traj_lo_sparse<<<(int)std::min<int64_t>(lob, 4096), 1024, 0, st>>>(cv, rec, k, ft, pl.vwords, lo_sum, occlusion_bits, occw, toff, (int)n_traj, C,
+                                                                           slist, sflag + pl.nmark);
         TO_HIP_CHECK_LAUNCH();
     }
     return TOHIP_OK;
