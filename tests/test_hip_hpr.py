@@ -242,3 +242,23 @@ def test_hpr_batched_large_and_degenerate_segments_sample_phase(dev):
         else:
             ref, _ = oracle.hidden_pts_removal(pts)
             assert np.array_equal(got, ref), f"segment {s}"
+
+
+def test_hull_with_exact_copies_of_points(dev):
+    """Duplicated rows (a copy of a hull vertex lies ON the hull whatever the rounding of its plane distance says): as many
+    vertices as Qhull finds, at the same coordinates — which of two identical rows carries the vertex is the library's choice
+    (the lower index in a build without the sample phase)."""
+    from scipy.spatial import ConvexHull
+    from trajectory_optimization_amd import ops
+    for n, seed in ((20_000, 61), (120_000, 62)):   # the larger one goes through the sample phase of the build
+        base = synth.make_cloud(n, seed=seed)
+        ref0 = np.sort(ConvexHull(base.astype(np.float64)).vertices)
+        rng = np.random.default_rng(seed)
+        dup = np.concatenate([ref0[rng.integers(0, len(ref0), 300)], rng.integers(0, n, 300)])   # copies of vertices and of others
+        pts = np.concatenate([base, base[dup], base[dup[:100]]]).astype(np.float32)
+        got = ops.hull_vertices_with_origin(torch.from_numpy(pts).to(dev), False).cpu().numpy().astype(np.int64)
+        ref = ConvexHull(pts.astype(np.float64)).vertices
+        assert len(got) == len(ref) == len(ref0)
+        assert np.array_equal(np.unique(pts[got], axis=0), np.unique(pts[ref], axis=0))
+        if n < 32768:   # (the sample phase of a large build may meet the copy first)
+            assert np.array_equal(got, ref0)   # every vertex is reported at its first row

@@ -98,6 +98,7 @@ struct Bufs {
     int m1;
     int fcap;
     int nseg;
+    int origin;            // 1: the last slot of a segment is the appended origin; 0: it repeats the segment's first point and never takes part
     int sub;               // > 1 while only every sub-th point (in Morton order) takes part: the first rounds of a large build
 };
 
@@ -162,7 +163,7 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                              (const int*)nullptr, (int*)nullptr, (int)m1, 0, 64, (hipStream_t)0);
     p = take(tmp); if (b) { b->sort_tmp = p; b->sort_tmp_bytes = tmp; }
-    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; }
+    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; b->origin = 1; }
     return o;
 }
 
@@ -199,6 +200,16 @@ __device__ __forceinline__ double plane_dist(const FaceRec& r, double x, double 
     return r.nx * dx + r.ny * dy + r.nz * dz;
 }
 __device__ __forceinline__ double fdist(const Bufs& b, int f, int i) { return plane_dist(b.frec[f], b.px[i], b.py[i], b.pz[i]); }
+
+// A point with the coordinates of one of the face's vertices lies ON the face whatever the rounding of its distance says (exact
+// copies of a hull vertex: duplicated input rows, and the slot that repeats a segment's first point when no origin is appended)
+__device__ __forceinline__ bool on_a_vertex(const Bufs& b, int f, double x, double y, double z) {
+    for (int k = 0; k < 3; ++k) {
+        const int v = b.fv[3 * f + k];
+        if (b.px[v] == x && b.py[v] == y && b.pz[v] == z) return true;
+    }
+    return false;
+}
 
 __device__ __forceinline__ void set_plane(const Bufs& b, int f) {
     const int a = b.fv[3 * f], c1 = b.fv[3 * f + 1], c2 = b.fv[3 * f + 2];
@@ -634,10 +645,14 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
         const int i = blockIdx.x * TO_BLOCK + threadIdx.x + it * stride;
         double best = 0.0; int bf = kNone;
         if (i < b.m1) {
-            const int fb = 4 * find_seg(b, i);
+            const int sgi = find_seg(b, i), fb = 4 * sgi;
             // the tetrahedron's corners: faces fb and fb+1 are (a,c1,c2) and (c1,a,d)
-            if ((b.fflags[fb] & 1) && i % b.sub == 0 && !(i == b.fv[3 * fb] || i == b.fv[3 * fb + 1] || i == b.fv[3 * fb + 2] || i == b.fv[3 * fb + 5])) {
-                for (int f = fb; f < fb + 4; ++f) { const double d = fdist(b, f, i); if (d > best) { best = d; bf = f; } }
+            const bool filler = !b.origin && b.perm[i] == b.seg_off[sgi + 1] - 1;
+            if ((b.fflags[fb] & 1) && i % b.sub == 0 && !filler && !(i == b.fv[3 * fb] || i == b.fv[3 * fb + 1] || i == b.fv[3 * fb + 2] || i == b.fv[3 * fb + 5])) {
+                for (int f = fb; f < fb + 4; ++f) {
+                    const double d = fdist(b, f, i);
+                    if (d > best && !on_a_vertex(b, f, b.px[i], b.py[i], b.pz[i])) { best = d; bf = f; }
+                }
                 b.pface[i] = bf;
             }
         }
@@ -905,9 +920,11 @@ __device__ __forceinline__ void reassign_points(const Bufs& b, FaceMaxTable& tab
         const int g = j < nlive ? b.pface[i] : kNone;
         if (g >= 0 && (b.fflags[g] & 4)) {
             const int o = b.fowner[g];
-            if (b.perm[i] != b.fapex[o]) {
+            const int ap = b.inv[b.fapex[o]];
+            const double x = b.px[i], y = b.py[i], z = b.pz[i];
+            // (every new face has the apex as a vertex and two older ones, whose copies retired when THEY went in)
+            if (i != ap && !(x == b.px[ap] && y == b.py[ap] && z == b.pz[ap])) {
                 int steps = 0;
-                const double x = b.px[i], y = b.py[i], z = b.pz[i];
                 for (int f = b.nfhead[o]; f >= 0 && steps < (1 << 20); ++steps) {
                     const FaceRec r = b.frec[f];  // one line per step of the list: plane, anchor and link
                     const double d = plane_dist(r, x, y, z);
@@ -1034,7 +1051,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign_all(Bufs b, const int* __re
         for (int k = 0; k < kAssignPts; ++k) {
             const int j = base + k * TO_BLOCK + threadIdx.x;
             // the sample's points have their faces (or have retired) already
-            mine[k] = j < hi && j % b.sub != 0 && j != c0 && j != c1 && j != c2 && j != c3;
+            mine[k] = j < hi && j % b.sub != 0 && j != c0 && j != c1 && j != c2 && j != c3 && (b.origin || b.perm[j] != hi - 1);
             x[k] = mine[k] ? b.px[j] : 0.0; y[k] = mine[k] ? b.py[j] : 0.0; z[k] = mine[k] ? b.pz[j] : 0.0;
             best[k] = mine[k] ? 0.0 : INFINITY; bf[k] = kNone;   // (nothing beats infinity: the other lanes never ask for a test)
         }
@@ -1065,7 +1082,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign_all(Bufs b, const int* __re
                 for (int k = 0; k < kAssignPts; ++k) {
                     if (!need[k]) continue;
                     const double d = plane_dist(r, x[k], y[k], z[k]);
-                    if (d > best[k]) { best[k] = d; bf[k] = f; }
+                    if (d > best[k] && !on_a_vertex(b, f, x[k], y[k], z[k])) { best[k] = d; bf[k] = f; }
                 }
             }
         }
@@ -1199,6 +1216,7 @@ inline int nblocks(int64_t n, int cap = 2048) {
 // b.seg_off must already be on the device (k_single_segment for one hull).
 static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t max_seg_points, hipStream_t st, int* rounds_out) {
     Bufs b = b_in;  // local copy: the two live-point buffers swap roles at every compaction
+    b.origin = with_origin ? 1 : 0;
     {
         // large segments: the first rounds on a sample (see k_assign_all)
         static const int force_sub = getenv("TOHIP_HULL_SUB") ? atoi(getenv("TOHIP_HULL_SUB")) : 0;  // experiments: 1 = off
