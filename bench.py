@@ -73,10 +73,10 @@ def pmc_figures(kernel):
     try:
         for name, v in d["kernels"].items():
             if kernel in name and "hbm_bytes_per_launch_corrected" in v:
-                return float(v["hbm_bytes_per_launch_corrected"]), v.get("valu_busy_fraction")
+                return float(v["hbm_bytes_per_launch_corrected"]), v.get("valu_busy_fraction"), v.get("valu_busy_while_resident")
     except (TypeError, KeyError, ValueError):
         pass
-    return None, None
+    return None, None, None
 
 
 def cpu_baseline(points, poses, quats, n_wps_sample, budget_s=12.0):
@@ -313,7 +313,7 @@ def main():
         issue_cycles = cyc_per_iter * local_evals / evals_per_iter
         achieved = issue_cycles / (p1_ms * 1e-3) / 1e9           # G issue-cycles/s
         peak = N_SIMDS * CLOCK_GHZ
-        traffic, valu_busy = pmc_figures(PASS1)
+        traffic, valu_busy, valu_busy_res = pmc_figures(PASS1)
         step_ms = 1e3 * dt / args.steps
         line = {
             "metric": "point-visibility evals/sec (fwd+bwd)", "value": value, "unit": "evals/s",
@@ -336,6 +336,10 @@ def main():
                          "peak_note": f"{N_SIMDS} SIMDs x {CLOCK_GHZ} GHz; frac is a lower bound of the SIMDs' VALU-busy fraction "
                                       "(the chip clocks 2.2-2.4 GHz under this load; packed f32 measures 4.0-4.4 cycles)",
                          "valu_busy_pmc": valu_busy,
+                         "valu_busy_while_resident_pmc": valu_busy_res,
+                         "valu_busy_note": "SQ_ACTIVE_INST_VALU x 4 over the SIMD cycles of the whole dispatch (GRBM_GUI_ACTIVE), and over the "
+                                           "cycles the shader engines hold the kernel's waves (SQ_BUSY_CYCLES / 32 SEs): the difference, "
+                                           "~12 % of a 100 us dispatch, is the kernel boundary (launch, cache invalidate / write-back, drain)",
                          "in_kernel": None if span_ms is None else {
                              "span_ms": span_ms, "clock_ghz": clock_ghz,
                              "frac_of_peak": issue_cycles / (span_ms * 1e-3) / 1e9 / peak,

@@ -70,6 +70,12 @@ def main():
             e["valu_issue_cycles_per_launch"] = 4.0 * e["SQ_ACTIVE_INST_VALU_mean_per_launch"]
             e["valu_busy_fraction"] = e["SQ_ACTIVE_INST_VALU_mean_per_launch"] / (32.0 * e["GRBM_GUI_ACTIVE_mean_per_launch"])
             e["clock_ghz_from_grbm"] = e["GRBM_GUI_ACTIVE_mean_per_launch"] / 8.0 / e["duration_ns_mean_pmc_sq"]
+            if e.get("SQ_BUSY_CYCLES_mean_per_launch"):
+                # SQ_BUSY_CYCLES: cycles a shader engine's sequencer holds waves, summed over the 32 SEs (8 XCDs x 4).  VALU issue
+                # over THOSE cycles = how busy the SIMDs are while the kernel's waves are resident; the rest of GRBM_GUI_ACTIVE
+                # is the dispatch's boundary (launch, cache invalidate / write-back, drain)
+                e["sq_busy_share_of_dispatch"] = e["SQ_BUSY_CYCLES_mean_per_launch"] / 32.0 / (e["GRBM_GUI_ACTIVE_mean_per_launch"] / 8.0)
+                e["valu_busy_while_resident"] = 4.0 * e["SQ_ACTIVE_INST_VALU_mean_per_launch"] / 1024.0 / (e["SQ_BUSY_CYCLES_mean_per_launch"] / 32.0)
     with open(os.path.join(dst, f"{tag}_bench_dense_pmc.json"), "w") as f:
         json.dump(out, f, indent=1)
     for k, e in ks.items():
