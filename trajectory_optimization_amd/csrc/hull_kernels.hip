@@ -49,7 +49,8 @@ constexpr int kErrCapacity = 1, kErrFlat = 2, kErrTopology = 4, kErrNaN = 8;
 struct __attribute__((aligned(64))) FaceRec {
     double nx, ny, nz, x0, y0, z0;
     int next;
-    int pad[3];
+    float inv_norm;        // 1 / |n|: heights (distance in length units) rank the candidates
+    int pad[2];
 };
 
 struct Bufs {
@@ -61,6 +62,7 @@ struct Bufs {
     unsigned long long* fmax;  // fcap
     int* fapex;            // fcap   apex candidate as an EXPANDED index (ties go to the caller's lowest index); 0x7fffffff = none
     int* fowner;           // fcap
+    unsigned long long* fprio;  // fcap   rank of a candidate this round (smaller = better), written by the previous round's tail
     int* fflags;           // fcap   bit0 alive, bit1 candidate / accepted, bit2 dies at the end of this round
     int* nfhead;           // fcap
     int* newface;          // 3 * fcap
@@ -98,6 +100,7 @@ struct Bufs {
     int m1;
     int fcap;
     int nseg;
+    int hbits;             // bits of the apex height in a candidate's rank (make_prio)
     int origin;            // 1: the last slot of a segment is the appended origin; 0: it repeats the segment's first point and never takes part
     int sub;               // > 1 while only every sub-th point (in Morton order) takes part: the first rounds of a large build
 };
@@ -108,8 +111,8 @@ __host__ inline size_t seg(size_t bytes) { return align_up(bytes, 256); }
 // The default suits clouds whose hull is a small fraction of the points (HPR of a scene: 2-5 %); a build that runs out
 // returns TOHIP_ENOSPC and the caller retries with a larger workspace — every byte beyond the fixed part is used for
 // faces (faces_for_bytes), up to the never-exceeded-in-practice 8 per point.
-constexpr size_t kBytesPerFace = 16 * sizeof(int) + sizeof(double) + 64;  // the per-face arrays carved below
-constexpr int kFaceArrays = 12;
+constexpr size_t kBytesPerFace = 16 * sizeof(int) + 2 * sizeof(double) + 64;  // the per-face arrays carved below
+constexpr int kFaceArrays = 13;
 
 __host__ inline int default_face_capacity(int64_t m1, int64_t nseg) {
     int64_t c = m1 / 2 + 64 * nseg + 4096;
@@ -133,6 +136,7 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(unsigned long long) * (size_t)fcap); if (b) b->fmax = (unsigned long long*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->fapex = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->fowner = (int*)p;
+    p = take(sizeof(unsigned long long) * (size_t)fcap); if (b) b->fprio = (unsigned long long*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->fflags = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->nfhead = (int*)p;
     p = take(sizeof(int) * 3 * (size_t)fcap); if (b) b->newface = (int*)p;
@@ -163,7 +167,7 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                              (const int*)nullptr, (int*)nullptr, (int)m1, 0, 64, (hipStream_t)0);
     p = take(tmp); if (b) { b->sort_tmp = p; b->sort_tmp_bytes = tmp; }
-    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; b->origin = 1; }
+    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; b->origin = 1; b->hbits = 0; }
     return o;
 }
 
@@ -190,9 +194,17 @@ __device__ __forceinline__ unsigned hash32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ unsigned long long prio(int f, int round) {
-    return ((unsigned long long)hash32((unsigned)f * 0x9E3779B9u + (unsigned)round) << 32) | (unsigned)f;
+// Rank of candidate face f in round `round` (smaller = better): the top `hbits` bits of its apex's HEIGHT above the face
+// (float: exponent first — higher apexes first, they bury more of the others), then a hash salted per round, then the id.
+// hbits = 0: the hashed total order alone.
+__device__ __forceinline__ unsigned long long make_prio(int f, int round, float height, int hbits) {
+    const unsigned h = hash32((unsigned)f * 0x9E3779B9u + (unsigned)round);
+    if (hbits <= 0) return ((unsigned long long)h << 32) | (unsigned)f;
+    const unsigned hb = (__float_as_uint(height) & 0x7fffffffu) >> (31 - hbits);
+    const unsigned inv = ((1u << hbits) - 1u) - hb;
+    return ((unsigned long long)inv << 48) | ((unsigned long long)(h & 0xffffu) << 32) | (unsigned)f;
 }
+__device__ __forceinline__ double dkey_inv_pos(unsigned long long k) { return __longlong_as_double((long long)(k & 0x7fffffffffffffffull)); }
 
 // signed (unnormalised) distance of point i from the plane of face f; > 0 = strictly outside
 __device__ __forceinline__ double plane_dist(const FaceRec& r, double x, double y, double z) {
@@ -222,6 +234,7 @@ __device__ __forceinline__ void set_plane(const Bufs& b, int f) {
     r.nz = ux * vy - uy * vx;
     r.x0 = ax; r.y0 = ay; r.z0 = az;
     r.next = kNone;
+    r.inv_norm = (float)(1.0 / sqrt(r.nx * r.nx + r.ny * r.ny + r.nz * r.nz));
 }
 
 // Per-face maximum of `key` over many points.  Early rounds aim a million points at a handful of faces, and
@@ -468,7 +481,7 @@ __device__ void init_tetrahedron(const Bufs& b, int sg, bool enough, bool has_na
             // no hull for this segment: its four face slots stay dead (never candidates, never neighbours of a live face)
             for (int f = fb; f < fb + 4; ++f) {
                 for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = lo; b.fn[3 * f + k] = f; }
-                b.frec[f] = FaceRec{0.0, 0.0, 0.0, b.px[lo], b.py[lo], b.pz[lo], kNone, {0, 0, 0}};
+                b.frec[f] = FaceRec{0.0, 0.0, 0.0, b.px[lo], b.py[lo], b.pz[lo], kNone, 0.f, {0, 0}};
                 b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = 0x7fffffff; b.nfhead[f] = kNone;
                 b.newface[3 * f] = kNone;
             }
@@ -725,7 +738,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
             continue;
         }
         if (__hip_atomic_load(&b.fowner[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != o) continue;  // taken by a better one
-        const unsigned long long po = prio(o, round);
+        const unsigned long long po = b.fprio[o];
         const int apex = b.inv[ax];
         const double px = b.px[apex], py = b.py[apex], pz = b.pz[apex];
         int cur = 0, ncur = 1, claimed = 0;
@@ -741,12 +754,12 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
                     n = b.fn[3 * cg + t % 3];
                     int co = __hip_atomic_load(&b.fowner[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const bool sees = plane_dist(b.frec[n], px, py, pz) > 0.0;  // loaded alongside the owner, not after it
-                    if (sees && !(co == o || (co >= 0 && prio(co, round) <= po))) {
+                    if (sees && !(co == o || (co >= 0 && b.fprio[co] <= po))) {
                         while (true) {
                             const int old = atomicCAS(&b.fowner[n], co, o);
                             if (old == co) { mine = true; break; }  // two lanes on the same face: the second finds `o` there
                             co = old;
-                            if (co == o || (co >= 0 && prio(co, round) <= po)) break;
+                            if (co == o || (co >= 0 && b.fprio[co] <= po)) break;
                         }
                     }
                 }
@@ -777,11 +790,11 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b, int round) {
         if (!(b.fflags[g] & 1)) continue;
         int best = b.fowner[g];
         if (best == g && b.fapex[g] == 0x7fffffff) { b.fowner[g] = kNone; atomicAnd(&b.fflags[g], ~2); continue; }
-        unsigned long long bp = best >= 0 ? prio(best, round) : ~0ull;
+        unsigned long long bp = best >= 0 ? b.fprio[best] : ~0ull;
         for (int k = 0; k < 3; ++k) {
             const int o = b.fowner[b.fn[3 * g + k]];
             if (o < 0 || o == best || b.fapex[o] == 0x7fffffff) continue;
-            const unsigned long long op = prio(o, round);
+            const unsigned long long op = b.fprio[o];
             if (op < bp && fdist(b, g, b.inv[b.fapex[o]]) > 0.0) { best = o; bp = op; }
         }
         if (best != b.fowner[g]) { b.fowner[g] = best; changed = true; }
@@ -827,7 +840,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_accept(Bufs b, int round, int par)
             const int on = b.fowner[n];
             if (on == o) continue;
             if (fdist(b, n, apex) > 0.0) ok = false;                                  // visible but not ours
-            else if (on >= 0 && prio(on, round) < prio(o, round)) ok = false;          // adjacent to a better region
+            else if (on >= 0 && b.fprio[on] < b.fprio[o]) ok = false;                 // adjacent to a better region
         }
         if (!ok) atomicAnd(&b.fflags[o], ~2);
     }
@@ -951,7 +964,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_link_reassign(Bufs b, int par, int
 // regions' faces die and the round's ownership is cleared; the candidates that are still alive and the new faces with points
 // outside them enter the next round's candidate list as their own owners.  Also run once after the initial tetrahedra
 // (no lists yet; every face is new).  Needs a grid that is a multiple of kSubLists.
-__global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int with_far_arg) {
+__global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int with_far_arg, int next_round) {
     if (with_far_arg) far_arg_points(b, b.ctrl[kCtrlNFaces], blockIdx.x, gridDim.x);
     const int sl = blockIdx.x % kSubLists, cap = sub_cap(b);
     int* __restrict__ next = b.cand[par ^ 1] + (size_t)sl * cap;
@@ -975,6 +988,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int wi
             b.fowner[f] = cand ? f : kNone;
             b.fflags[f] = alive | (cand ? 2 : 0);
             if (from_cand) b.nfhead[f] = kNone;
+            if (cand && from_cand) b.fprio[f] = make_prio(f, next_round, (float)dkey_inv_pos(b.fmax[f]) * b.frec[f].inv_norm, b.hbits);
         }
         enter(f, cand && from_cand);  // a candidate enters through its own entry, not through a claim's
     }
@@ -985,7 +999,10 @@ __global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int wi
         // consecutive faces to consecutive blocks: a round's few hundred new faces spread over all sub-lists
         const int f = f_lo + (it * TO_BLOCK + threadIdx.x) * gridDim.x + blockIdx.x;
         const bool cand = f < nf && (b.fflags[f] & 1) && b.fmax[f] != 0ull;
-        if (cand) { b.fowner[f] = f; b.fflags[f] = 3; }
+        if (cand) {
+            b.fowner[f] = f; b.fflags[f] = 3;
+            b.fprio[f] = make_prio(f, next_round, (float)dkey_inv_pos(b.fmax[f]) * b.frec[f].inv_norm, b.hbits);
+        }
         enter(f, cand);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlOverflow] = 0;  // read by k_accept only
@@ -1096,7 +1113,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign_all(Bufs b, const int* __re
 }
 
 // the candidate list of parity `par` from scratch: every alive face with points outside it, as its own owner
-__global__ void __launch_bounds__(TO_BLOCK) k_rebuild_candidates(Bufs b, int par) {
+__global__ void __launch_bounds__(TO_BLOCK) k_rebuild_candidates(Bufs b, int par, int next_round) {
     const int sl = blockIdx.x % kSubLists, cap = sub_cap(b);
     int* __restrict__ next = b.cand[par] + (size_t)sl * cap;
     int* next_n = ccnt(b, par, sl);
@@ -1108,6 +1125,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_rebuild_candidates(Bufs b, int par
         const bool alive = f < nf && (b.fflags[f] & 1);
         const bool cand = alive && b.fmax[f] != 0ull;
         if (alive) { b.fowner[f] = cand ? f : kNone; b.fflags[f] = 1 | (cand ? 2 : 0); b.nfhead[f] = kNone; }
+        if (cand) b.fprio[f] = make_prio(f, next_round, (float)dkey_inv_pos(b.fmax[f]) * b.frec[f].inv_norm, b.hbits);
         const int slot = block_alloc(next_n, cand ? 1 : 0);
         if (cand) {
             if (slot < cap) next[slot] = f;
@@ -1218,6 +1236,12 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     Bufs b = b_in;  // local copy: the two live-point buffers swap roles at every compaction
     b.origin = with_origin ? 1 : 0;
     {
+        // 9 = exponent + one mantissa bit: apexes more than ~1.4x higher go first, the hash decides among the rest.  Measured
+        // (tools/hpr_sweep.sh): 0 bits (hash only) 177 rounds / 10.7 ms at 1 M points, 6: 116 / 7.0, 9: 106 / 6.2, 12: 120 / 6.7, 16: 129 / 7.2
+        static const int hb = getenv("TOHIP_HULL_HBITS") ? atoi(getenv("TOHIP_HULL_HBITS")) : 9;  // experiments
+        b.hbits = hb < 0 ? 0 : (hb > 16 ? 16 : hb);
+    }
+    {
         // large segments: the first rounds on a sample (see k_assign_all)
         static const int force_sub = getenv("TOHIP_HULL_SUB") ? atoi(getenv("TOHIP_HULL_SUB")) : 0;  // experiments: 1 = off
         const int64_t avg = b.m1 / b.nseg;
@@ -1255,7 +1279,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     if (b.sub > 1) k_live_stride<<<nblocks((b.m1 + b.sub - 1) / b.sub), TO_BLOCK, 0, st>>>(b);
     k_assign0<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
     k_far_arg_all<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);
-    k_round_tail<<<kSubLists, TO_BLOCK, 0, st>>>(b, 1, 0);  // round 0's candidates: the tetrahedra's faces with points outside
+    k_round_tail<<<kSubLists, TO_BLOCK, 0, st>>>(b, 1, 0, 0);  // round 0's candidates: the tetrahedra's faces with points outside
     TO_HIP_CHECK_LAUNCH();
     // One readback = the scalars and the candidate counters of both parities, into pinned memory behind an event: the host
     // keeps ONE batch of rounds enqueued ahead of the readback it is waiting for, so the GPU never idles while the host looks
@@ -1304,7 +1328,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     static const bool always_careful = getenv("TOHIP_HULL_CAREFUL") != nullptr;                   // experiments: the slow path only
     static const int compact_every = getenv("TOHIP_HULL_COMPACT") ? atoi(getenv("TOHIP_HULL_COMPACT")) : 2;
     static const bool trace = getenv("TOHIP_HULL_TRACE") != nullptr;   // experiments: the build's progress, one line per readback
-    static const int join_faces = getenv("TOHIP_HULL_JOIN_FACES") ? atoi(getenv("TOHIP_HULL_JOIN_FACES")) : 1536;  // experiments
+    static const int join_faces = getenv("TOHIP_HULL_JOIN_FACES") ? atoi(getenv("TOHIP_HULL_JOIN_FACES")) : 192;  // experiments
 
     // `careful`: ownership propagated to convergence with the host checking (after a batch that accepted nobody)
     auto enqueue_rounds_inner = [&](int nrounds, bool careful) -> int {
@@ -1338,7 +1362,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
             k_new_faces<<<gl, TO_BLOCK, 0, st>>>(b, par);
             k_link_reassign<<<gl + gr, TO_BLOCK, 0, st>>>(b, par, gl);
             const int gt = std::max(gl, std::min(2048, (nblocks(live_bound) + kSubLists - 1) / kSubLists * kSubLists));
-            k_round_tail<<<gt, TO_BLOCK, 0, st>>>(b, par, 1);
+            k_round_tail<<<gt, TO_BLOCK, 0, st>>>(b, par, 1, round + 1);
             TO_HIP_CHECK_LAUNCH();
         }
         return TOHIP_OK;
@@ -1383,7 +1407,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         const int par = round & 1;
         ej = hipMemsetAsync(b.ctrl + kCtrlInts + par * kSubLists * kCntStride, 0, sizeof(int) * kSubLists * kCntStride, st);
         if (ej != hipSuccess) return (int)ej;
-        k_rebuild_candidates<<<kSubLists * (int)std::min<int64_t>(16, std::max<int64_t>(1, cdiv(nf, kSubLists * TO_BLOCK))), TO_BLOCK, 0, st>>>(b, par);
+        k_rebuild_candidates<<<kSubLists * (int)std::min<int64_t>(16, std::max<int64_t>(1, cdiv(nf, kSubLists * TO_BLOCK))), TO_BLOCK, 0, st>>>(b, par, round);
         TO_HIP_CHECK_LAUNCH();
         b.sub = 1;
         return TOHIP_OK;
