@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(TO_SELECT_THREADS)
 k_traj_select(const float2* __restrict__ part, int nslots, int V, WayRec* __restrict__ rec, int cull, float* __restrict__ minmax,
               unsigned long long* __restrict__ fv, int fv_words, unsigned long long* __restrict__ ft, int vwords,
               int* __restrict__ vlist, int* __restrict__ vcnt, TieRec* __restrict__ ties, float* __restrict__ lo_sum, int64_t npad,
-              int* __restrict__ sflag, int* __restrict__ slist, int64_t nmark, const int* __restrict__ toff, int C) {
+              int* __restrict__ sflag, int* __restrict__ slist, int64_t nmark, const int* __restrict__ toff, int C, float inv_var) {
     __shared__ float smn[TO_SELECT_THREADS / 64], smx[TO_SELECT_THREADS / 64];
     __shared__ float s_a, s_pmax;
     __shared__ int s_nmax, s_nmin, s_npairs, s_maxrow[TO_TIE_CAP], s_minrow[TO_TIE_CAP];
@@ -482,6 +482,13 @@ k_traj_select(const float2* __restrict__ part, int nslots, int V, WayRec* __rest
             rec[v].a = a;
             rec[v].invM = 1.0f / M;
             rec[v].M = M;
+            // the probe's bound has done its work (pass 1); from here on thr1 serves the sparse kernels: a point farther than this
+            // from the Gaussian's centre has p < a + M/2, i.e. p_hat < 1/2 — no log-odds, no gradient (a whole wave of such points
+            // is skipped).  Degenerate waypoints (NaN, M <= 0) keep every point.
+            float thr2 = INFINITY, sthr2 = INFINITY;
+            if (M > 0.f && M < INFINITY) cull_bound(a + 0.5f * M, inv_var, &thr2, &sthr2);
+            rec[v].thr1 = thr2;
+            rec[v].sthr1 = sthr2;
             minmax[2 * v] = a;
             minmax[2 * v + 1] = M;
             s_a = a;
@@ -619,7 +626,8 @@ k_traj_lo_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const un
                 bits &= bits - 1ull;
                 if (((rank++) & 3) == g) {
                     const WayRec& r = rec[v];
-                    acc += log_odds(k, r, vis_p(r, k, x, y, z) * occ_one(occ, occw, v, i));
+                    // a wave (64 neighbouring points) none of whose points can reach p_hat = 1/2 adds exact zeros
+                    if (__any(!(dist2_sp(r, x, y, z) > r.thr1))) acc += log_odds(k, r, vis_p(r, k, x, y, z) * occ_one(occ, occw, v, i));
                 }
             }
         }
@@ -742,6 +750,7 @@ k_traj_bwd_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const i
         for (int q = 0; q < TO_SLOT / 64; ++q) {
             const int64_t i = (int64_t)s * TO_SLOT + q * 64 + lane;
             const float x = cv.soa[i], y = cv.soa[cv.npad + i], z = cv.soa[2 * cv.npad + i];
+            if (!__any(!(dist2_sp(r, x, y, z) > r.thr1))) continue;   // none of these 64 points can reach p_hat = 1/2 (k_traj_select)
             // dL/d lo_sum_n: through the caller's dL/d rewards vector (general criterion) or the fused visibility loss
             float gn = 0.f;
             if (i < cv.n) {
@@ -1262,10 +1271,10 @@ extern "C" int tohip_traj_forward_multi(const void* packed, int64_t n, const flo
         TO_PROF(TOHIP_PROF_SMALL, st);
         if (pl.nslots <= TO_SELECT_FAST_SLOTS)
             k_traj_select<true><<<(int)V, TO_SELECT_THREADS, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
-                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C);
+                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C, k.inv_var);
         else
             k_traj_select<false><<<(int)V, TO_SELECT_THREADS, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
-                                                                       pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C);
+                                                                       pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C, k.inv_var);
         TO_HIP_CHECK_LAUNCH();
     }
     {
