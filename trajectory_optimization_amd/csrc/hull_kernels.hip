@@ -1245,7 +1245,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         // large segments: the first rounds on a sample (see k_assign_all)
         static const int force_sub = getenv("TOHIP_HULL_SUB") ? atoi(getenv("TOHIP_HULL_SUB")) : 0;  // experiments: 1 = off
         const int64_t avg = b.m1 / b.nseg;
-        b.sub = (avg >= 32768 && b.nseg <= 65535) ? (int)std::min<int64_t>(256, std::max<int64_t>(2, avg / 512)) : 1;
+        b.sub = (avg >= 32768 && b.nseg <= 65535) ? (int)std::min<int64_t>(128, std::max<int64_t>(2, avg / 1024)) : 1;
         if (force_sub > 0) b.sub = force_sub;
     }
     hipError_t e = hipMemsetAsync(b.ctrl, 0, sizeof(int) * kCtrlTotal, st);
