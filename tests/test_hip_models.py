@@ -574,8 +574,8 @@ def test_occlusion_rows_do_not_depend_on_the_chunking(dev, monkeypatch):
     assert 0 < int((a != -1).sum())   # something is occluded
 
 
-@pytest.mark.parametrize("dense", [False, True])
-def test_several_trajectories_in_one_pass_equal_separate_calls(dev, dense):
+@pytest.mark.parametrize("dense,lens", [(False, [9, 17, 5]), (True, [9, 17, 5]), (False, [40, 50, 23]), (True, [33, 1, 64])])
+def test_several_trajectories_in_one_pass_equal_separate_calls(dev, dense, lens):
     """tohip_traj_*_multi: B trajectories' waypoints as one batch of virtual waypoints, each with its own log-odds vector,
     rewards, loss scalars and gradients — bit for bit what B separate calls give (unequal lengths, a rig, both modes)."""
     from trajectory_optimization_amd import ops
@@ -585,7 +585,7 @@ def test_several_trajectories_in_one_pass_equal_separate_calls(dev, dense):
     cam = ops.Camera(K, IW, IH)
     flags = ops.DENSE if dense else 0
     rg = ops.CameraRig(*synth.camera_rig(2), dev)
-    lens = [9, 17, 5]
+    # (with two cameras each: the longer sets put trajectories across the 64-waypoint words of the flag rows)
     paths = [synth.make_path(w, optical=True, jitter_seed=70 + i) for i, w in enumerate(lens)]
     # move the second and third path so that the three see different parts of the cloud (and share some slots)
     paths[1] = (paths[1][0] + np.float32([0.0, 4.0, 0.0]), paths[1][1])
