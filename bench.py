@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--cameras", type=int, default=1,
                     help="cameras per waypoint (BASELINE.json configs[4]: 5, with --wps-per-gpu 32); each (camera, "
                          "waypoint) pair is one virtual waypoint with its own min-max normalisation")
+    ap.add_argument("--fused-reward", choices=["on", "off"], default="on",
+                    help="on: tohip_traj_reward_backward (6 launches per step); off: tohip_traj_reward then tohip_traj_backward (7)")
     ap.add_argument("--graph", choices=["on", "off"], default="off",
                     help="replay the step's launches from a HIP graph in the timed region (measured SLOWER on ROCm 7.2: 0.151 vs "
                          "0.139 ms dense, 0.079 vs 0.075 culled - graph kernel nodes cost more than the queue they replace)")
@@ -190,8 +192,13 @@ def main():
         lo_sum, minmax = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags, lo_sum=lo_buf, minmax=mm_buf, rewards_half=rewards)
         if shard is not None:
             shard.allreduce_sum(lo_sum)  # the one data-path collective: N floats over xGMI
-        rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws, rewards=rewards, prefilled=True)
-        pg, qg = ops.traj_backward(cloud, args.wps_per_gpu, cam, ws, lo_sum, scalars=scalars, gout=gout, rig=rig, flags=flags)
+        if args.fused_reward == "on":
+            # rewards, mean and loss share the backward's first launch (tohip_traj_reward_backward: two launches instead of three)
+            rewards, scalars, pg, qg = ops.traj_reward_backward(cloud, args.wps_per_gpu, cam, ws, lo_sum, gout, rewards=rewards,
+                                                               prefilled=True, rig=rig, flags=flags)
+        else:
+            rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws, rewards=rewards, prefilled=True)
+            pg, qg = ops.traj_backward(cloud, args.wps_per_gpu, cam, ws, lo_sum, scalars=scalars, gout=gout, rig=rig, flags=flags)
         if shard is not None:
             g = shard.allgather_rows(torch.cat([pg, qg], dim=1))  # (W_total, 7) floats: every rank can step the optimiser
             pg, qg = g[:, :3], g[:, 3:]

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOHIP_ABI_VERSION 6
+#define TOHIP_ABI_VERSION 7
 
 #define TOHIP_OK 0
 #define TOHIP_EINVAL (-1)   /* bad size / null pointer */
@@ -153,6 +153,22 @@ int tohip_traj_backward_multi(const void *packed, int64_t n_points, int64_t n_wp
                               const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits, const float *lo_sum,
                               const float *grad_rewards, const float *scalars, const float *gout, float *poses_grad,
                               float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
+
+/* tohip_traj_reward + tohip_traj_backward of the fused visibility loss (model.py:237,246 and loss.backward() through them) in two
+ * launches instead of three: the rewards / mean / loss scalars and the gradient sums both need only the complete log-odds vector,
+ * so they share a launch (the sums are taken with unit dL/d reward and scaled by scalars[2] * gout afterwards: they are linear in
+ * it).  Arguments as in the two separate calls; `scalars` and `rewards` are outputs.  rewards and scalars are bitwise those of
+ * tohip_traj_reward; the gradients agree with tohip_traj_backward's to rounding (the scale factor is applied once per waypoint
+ * in f64 instead of once per point in f32). */
+int tohip_traj_reward_backward(const void *packed, int64_t n_points, int64_t n_wps, const tohip_camera *cam_host,
+                               const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits, const float *lo_sum, float eps,
+                               int prefilled, float *rewards, float *scalars, const float *gout, float *poses_grad,
+                               float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
+int tohip_traj_reward_backward_multi(const void *packed, int64_t n_points, int64_t n_wps, int64_t n_traj,
+                                     const tohip_camera *cam_host, const tohip_rig *rig_host, int flags,
+                                     const uint32_t *occlusion_bits, const float *lo_sum, float eps, int prefilled, float *rewards,
+                                     float *scalars, const float *gout, float *poses_grad, float *quats_grad, void *workspace,
+                                     size_t workspace_bytes, void *stream);
 
 /* ---- ModelPose (model.py:98-127) -------------------------------------------------------------- */
 size_t tohip_pose_workspace_bytes(int64_t n_points);

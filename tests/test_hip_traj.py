@@ -391,3 +391,32 @@ def test_prefilled_rewards_equal_the_scattered_ones(dev, n, w):
     assert float(rew_a.min()) >= 0.5 and float(rew_a.max()) > 0.5
     # the mean is the f64 mean of the rewards
     assert abs(float(sc_a[0]) - float(rew_a.double().mean())) <= 1e-7
+
+
+@pytest.mark.parametrize("name", ["traj_synth_20000x32", "traj_synth_ties3", "traj_bundled_tilted_all"])
+def test_fused_reward_backward_equals_the_two_calls(dev, name):
+    """tohip_traj_reward_backward: rewards + scalars in the backward's first launch.  rewards / scalars bitwise those of
+    tohip_traj_reward; the gradients those of tohip_traj_backward to rounding (dL/d reward applied per waypoint in f64 instead
+    of per point in f32)."""
+    ops = _ops()
+    d = load_golden(name)
+    cloud = ops.PackedCloud(torch.from_numpy(d["points"]).to(dev))
+    cam = ops.Camera(K, IW, IH)
+    p = torch.from_numpy(d["poses"]).to(dev)   # (these fixtures evaluate every waypoint)
+    q = torch.from_numpy(d["quats"]).to(dev)
+    ws = ops.TrajWorkspace(cloud, p.shape[0])
+    gout = torch.tensor([0.7], device=dev)
+    for flags in (0, ops.DENSE):
+        half = torch.empty(cloud.n, device=dev)
+        lo, _ = ops.traj_forward(cloud, p, q, cam, ws, flags=flags, rewards_half=half)
+        rew, sc = ops.traj_reward(cloud, lo, cam, ws, rewards=half.clone(), prefilled=True)
+        pg, qg = ops.traj_backward(cloud, p.shape[0], cam, ws, lo, scalars=sc, gout=gout, flags=flags)
+        rew2, sc2, pg2, qg2 = ops.traj_reward_backward(cloud, p.shape[0], cam, ws, lo, gout, rewards=half, prefilled=True, flags=flags)
+        assert torch.equal(rew, rew2) and torch.equal(sc, sc2)
+        assert rel_inf(pg2.cpu().numpy(), pg.cpu().numpy()) < 1e-6 and rel_inf(qg2.cpu().numpy(), qg.cpu().numpy()) < 1e-6
+    # dense and culled agree bitwise through the fused entry point too
+    outs = []
+    for flags in (0, ops.DENSE):
+        lo, _ = ops.traj_forward(cloud, p, q, cam, ws, flags=flags)
+        outs.append(ops.traj_reward_backward(cloud, p.shape[0], cam, ws, lo, gout, flags=flags))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))

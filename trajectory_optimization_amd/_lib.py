@@ -45,6 +45,10 @@ SIGNATURES = {
     "tohip_traj_reward_multi": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_f, ctypes.c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_traj_backward_multi": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig), ctypes.c_int,
                                                   c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_traj_reward_backward_multi": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig), ctypes.c_int,
+                                                         c_vp, c_vp, c_f, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_traj_reward_backward": (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig), ctypes.c_int,
+                                                   c_vp, c_vp, c_f, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_traj_step_tail_multi": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_vp, c_vp,
                                                    c_vp, c_vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_vp, c_i64, c_vp,
                                                    c_vp]),
@@ -142,7 +146,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 6  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
+ABI_VERSION = 7  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
 ENOSPC = -2  # TOHIP_ENOSPC
 ENAN = -4    # TOHIP_ENAN
 

@@ -662,18 +662,17 @@ __device__ __forceinline__ double wave_sum_double(double v) {
 // most 128 roundings of 2^-(shift+1) on a sum of >= n/2 (1 M points: 5e-13 relative).  acc: zero before and after the launch.
 #define TO_REWARD_THREADS 1024
 #define TO_REWARD_BLOCKS 128
-__global__ void __launch_bounds__(TO_REWARD_THREADS)
-k_traj_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, int64_t n, int64_t npad, float eps, int shift, int prefilled,
-              float* __restrict__ rewards, unsigned long long* __restrict__ acc, float* __restrict__ scalars) {
-    __shared__ double lds[TO_REWARD_THREADS / 64];
-    // blockIdx.y = trajectory: its own log-odds vector, rewards vector, accumulator word and scalars
-    lo_sum += (int64_t)blockIdx.y * npad;
-    rewards += (int64_t)blockIdx.y * n;
-    acc += blockIdx.y;
-    scalars += 4 * blockIdx.y;
+// block bx of nbx of trajectory `traj` (its own log-odds vector, rewards vector, accumulator word and scalars)
+__device__ __forceinline__ void reward_block(const float* __restrict__ lo_sum, const int* __restrict__ perm, int64_t n, int64_t npad, float eps,
+                                             int shift, int prefilled, float* __restrict__ rewards, unsigned long long* __restrict__ acc,
+                                             float* __restrict__ scalars, int bx, int nbx, int traj, double* lds) {
+    lo_sum += (int64_t)traj * npad;
+    rewards += (int64_t)traj * n;
+    acc += traj;
+    scalars += 4 * traj;
     double s = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * TO_REWARD_THREADS * 4;
-    for (int64_t i0 = ((int64_t)blockIdx.x * TO_REWARD_THREADS + threadIdx.x) * 4; i0 < n; i0 += stride) {
+    const int64_t stride = (int64_t)nbx * TO_REWARD_THREADS * 4;
+    for (int64_t i0 = ((int64_t)bx * TO_REWARD_THREADS + threadIdx.x) * 4; i0 < n; i0 += stride) {
         const float4 lo4 = *reinterpret_cast<const float4*>(lo_sum + i0);   // npad is a multiple of 2048: aligned, in bounds
         const float lo[4] = {lo4.x, lo4.y, lo4.z, lo4.w};
         const bool all0 = (lo4.x == 0.f) & (lo4.y == 0.f) & (lo4.z == 0.f) & (lo4.w == 0.f);
@@ -701,7 +700,7 @@ k_traj_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, in
     const unsigned long long fixed = isnan_ ? 0ull : (unsigned long long)__double2ll_rn(ldexp(tot, shift));
     const unsigned long long word = (1ull << 56) | (isnan_ ? (1ull << 48) : 0ull) | fixed;
     const unsigned long long old = __hip_atomic_fetch_add(acc, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((int)(old >> 56) != (int)gridDim.x - 1) return;
+    if ((int)(old >> 56) != nbx - 1) return;
     const unsigned long long all = old + word;
     __hip_atomic_store(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     const bool anynan = ((all >> 48) & 0xffull) != 0ull;
@@ -712,6 +711,13 @@ k_traj_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, in
     scalars[1] = vis;
     scalars[2] = (float)(-(double)vis * (double)vis / (double)n);
     scalars[3] = 0.f;  // reserved; written so that callers need not clear the vector
+}
+
+__global__ void __launch_bounds__(TO_REWARD_THREADS)
+k_traj_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, int64_t n, int64_t npad, float eps, int shift, int prefilled,
+              float* __restrict__ rewards, unsigned long long* __restrict__ acc, float* __restrict__ scalars) {
+    __shared__ double lds[TO_REWARD_THREADS / 64];
+    reward_block(lo_sum, perm, n, npad, eps, shift, prefilled, rewards, acc, scalars, blockIdx.x, gridDim.x, blockIdx.y, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -725,20 +731,21 @@ k_traj_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, in
 // One WAVE per flagged pair, four points per lane (point lane + 64 j of the slot): the 14 sums are added per lane over its four
 // points, then once across the wave (DPP tree, total in lane 63) — a quarter of the cross-lane work a 256-thread block with one
 // point per thread spent, no LDS and no block barrier.  A fixed order that depends on nothing but the pair.
-__global__ void __launch_bounds__(TO_SLOT)
-k_traj_bwd_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const int* __restrict__ vlist, const int* __restrict__ vcnt,
-                  int nslots, const float* __restrict__ lo_sum, const float* __restrict__ grad_rewards,
-                  const float* __restrict__ scalars, const float* __restrict__ gout, float* __restrict__ bpart,
-                  const uint32_t* __restrict__ occ, int64_t occw) {
-    const int lane = threadIdx.x & 63, wv = blockIdx.x * (TO_SLOT / 64) + (threadIdx.x >> 6), nwv = gridDim.x * (TO_SLOT / 64);
-    const int v = blockIdx.y;
+// wave wv of nwv of waypoint v.  scalars == NULL (and no grad_rewards): the sums are taken with dL/d reward = 1 and the finish kernel
+// scales them (they are linear in it) — so that this work does not have to wait for the mean of the rewards.
+__device__ __forceinline__ void bwd_pairs(const CloudView& cv, const WayRec* __restrict__ rec, const EvalK& k, const int* __restrict__ vlist,
+                                          const int* __restrict__ vcnt, int nslots, const float* __restrict__ lo_sum,
+                                          const float* __restrict__ grad_rewards, const float* __restrict__ scalars,
+                                          const float* __restrict__ gout, float* __restrict__ bpart, const uint32_t* __restrict__ occ,
+                                          int64_t occw, int v, int wv, int nwv) {
+    const int lane = threadIdx.x & 63;
     const int npairs = vcnt[v];
     if (wv >= npairs) return;
     // the waypoint's trajectory: its log-odds vector, upstream gradient and loss scalars
     const int seg = rec[v].seg;
     lo_sum += (int64_t)seg * cv.npad;
     if (grad_rewards) grad_rewards += (int64_t)seg * cv.n;
-    const float coef = grad_rewards ? 0.f : scalars[4 * seg + 2] * gout[seg];
+    const float coef = grad_rewards ? 0.f : (scalars ? scalars[4 * seg + 2] * gout[seg] : 1.0f);
     const WayRec& r = rec[v];
     for (int it = wv; it < npairs; it += nwv) {
         const int s = vlist[(int64_t)v * nslots + it];
@@ -790,6 +797,33 @@ k_traj_bwd_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const i
             dst[14] = 0.f; dst[15] = 0.f;   // the finish kernel adds all 16 columns of a row
         }
     }
+}
+
+__global__ void __launch_bounds__(TO_SLOT)
+k_traj_bwd_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const int* __restrict__ vlist, const int* __restrict__ vcnt,
+                  int nslots, const float* __restrict__ lo_sum, const float* __restrict__ grad_rewards,
+                  const float* __restrict__ scalars, const float* __restrict__ gout, float* __restrict__ bpart,
+                  const uint32_t* __restrict__ occ, int64_t occw) {
+    bwd_pairs(cv, rec, k, vlist, vcnt, nslots, lo_sum, grad_rewards, scalars, gout, bpart, occ, occw, blockIdx.y,
+              blockIdx.x * (TO_SLOT / 64) + (threadIdx.x >> 6), gridDim.x * (TO_SLOT / 64));
+}
+
+// rewards + mean + loss (the first nbx * n_traj blocks) and the gradient sums with unit upstream gradient (the other blocks, 16
+// waves each = half a waypoint's 32) in ONE launch: both need the complete log-odds vector and nothing of each other.
+__global__ void __launch_bounds__(TO_REWARD_THREADS)
+k_traj_reward_bwd(const float* __restrict__ lo_sum, int64_t n, float eps, int shift, int prefilled, float* __restrict__ rewards,
+                  unsigned long long* __restrict__ acc, float* __restrict__ scalars, int nbx, int n_traj,
+                  CloudView cv, const WayRec* __restrict__ rec, EvalK k, const int* __restrict__ vlist, const int* __restrict__ vcnt,
+                  int nslots, float* __restrict__ bpart, const uint32_t* __restrict__ occ, int64_t occw, int V) {
+    __shared__ double lds[TO_REWARD_THREADS / 64];
+    const int R = nbx * n_traj;
+    if ((int)blockIdx.x < R) {
+        reward_block(lo_sum, cv.perm, n, cv.npad, eps, shift, prefilled, rewards, acc, scalars, blockIdx.x % nbx, nbx, blockIdx.x / nbx, lds);
+        return;
+    }
+    const int64_t gw = ((int64_t)blockIdx.x - R) * (TO_REWARD_THREADS / 64) + (threadIdx.x >> 6);
+    const int v = (int)(gw >> 5);
+    if (v < V) bwd_pairs(cv, rec, k, vlist, vcnt, nslots, lo_sum, nullptr, nullptr, nullptr, bpart, occ, occw, v, (int)(gw & 31), 32);
 }
 
 // thread per body waypoint: rig composition, dL/dt = -R sum dL/dc, dL/dR = sum y (x) dL/dc,
@@ -880,7 +914,8 @@ __global__ void __launch_bounds__(TO_FINISH_THREADS)
 k_traj_bwd_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const unsigned long long* __restrict__ fv, int fv_words,
                   const WayRec* __restrict__ rec, EvalK k, const TieRec* __restrict__ ties, const float2* __restrict__ part,
                   const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ vgrad,
-                  const WayCold* __restrict__ cold, int single, float* __restrict__ poses_grad, float* __restrict__ quats_grad) {
+                  const WayCold* __restrict__ cold, int single, float* __restrict__ poses_grad, float* __restrict__ quats_grad,
+                  const float* __restrict__ post_scalars, const float* __restrict__ post_gout) {
     __shared__ double sgrp[64][16];
     __shared__ double stie[2][13];   // [0] argmin set, [1] argmax set: 12 sums + count
     const int v = blockIdx.x, t = threadIdx.x, kq = t & 15, g = t >> 4;
@@ -950,6 +985,8 @@ k_traj_bwd_finish(CloudView cv, const float* __restrict__ bpart, int nslots, con
     if (t < 16) {
         double q = 0.0;
         for (int gg = 0; gg < 64; ++gg) q += sgrp[gg][t];
+        // sums taken with unit upstream gradient (k_traj_reward_bwd) get the trajectory's dL/d reward here: they are linear in it
+        if (post_scalars != nullptr) q *= (double)(post_scalars[4 * r.seg + 2] * post_gout[r.seg]);
         stot[t] = q;
     }
     __syncthreads();
@@ -1318,13 +1355,18 @@ extern "C" int tohip_traj_reward(const void* packed, const float* lo_sum, int64_
     return tohip_traj_reward_multi(packed, lo_sum, n, 1, eps, prefilled, rewards, scalars, workspace, workspace_bytes, stream_);
 }
 
-extern "C" int tohip_traj_backward_multi(const void* packed, int64_t n, int64_t W, int64_t n_traj, const tohip_camera* cam,
-                                         const tohip_rig* rig, int flags, const uint32_t* occlusion_bits, const float* lo_sum,
-                                         const float* grad_rewards, const float* scalars, const float* gout, float* poses_grad,
-                                         float* quats_grad, void* workspace, size_t workspace_bytes, void* stream_) {
+namespace {
+// backward of the step; with `fused` also the rewards, their mean and the loss scalars (tohip_traj_reward's work) in the
+// backward's first launch
+struct FusedReward { float eps; int prefilled; float* rewards; float* scalars; };
+int traj_backward_impl(const void* packed, int64_t n, int64_t W, int64_t n_traj, const tohip_camera* cam,
+                       const tohip_rig* rig, int flags, const uint32_t* occlusion_bits, const float* lo_sum,
+                       const float* grad_rewards, const float* scalars, const float* gout, float* poses_grad,
+                       float* quats_grad, void* workspace, size_t workspace_bytes, void* stream_, const FusedReward* fused) {
     if (!packed || !cam || !lo_sum || !poses_grad || !quats_grad || !workspace || n <= 0 || W <= 0 || n_traj <= 0 ||
-        (!grad_rewards && (!scalars || !gout)))
+        (!grad_rewards && (!scalars || !gout)) || n_traj > 65535)
         return TOHIP_EINVAL;
+    const float* fused_scalars = fused ? scalars : nullptr;
     hipStream_t st = (hipStream_t)stream_;
     const int C = rig_cams(rig);
     const int64_t V = W * C;
@@ -1346,7 +1388,19 @@ extern "C" int tohip_traj_backward_multi(const void* packed, int64_t n, int64_t 
     const float* rt = rq ? rig->rig_trans : nullptr;
     const int64_t occw = cv.npad / 32;
     (void)flags;
-    {
+    if (fused) {
+        TO_PROF(TOHIP_PROF_BWD, st);
+        int nbx = (int)((n + 4 * TO_REWARD_THREADS - 1) / (4 * TO_REWARD_THREADS));
+        if (nbx > TO_REWARD_BLOCKS) nbx = TO_REWARD_BLOCKS;
+        int lg = 0;
+        while (((int64_t)1 << lg) < n) ++lg;
+        const int64_t blocks = (int64_t)nbx * n_traj + (V * 32 + TO_REWARD_THREADS / 64 - 1) / (TO_REWARD_THREADS / 64);
+        if (blocks > 0x7fffffff) return TOHIP_EINVAL;
+        k_traj_reward_bwd<<<(int)blocks, TO_REWARD_THREADS, 0, st>>>(lo_sum, n, fused->eps, 47 - lg, fused->prefilled ? 1 : 0, fused->rewards,
+                                                                     (unsigned long long*)workspace, fused->scalars, nbx, (int)n_traj, cv, rec, k,
+                                                                     vlist, vcnt, pl.nslots, bpart, occlusion_bits, occw, (int)V);
+        TO_HIP_CHECK_LAUNCH();
+    } else {
         TO_PROF(TOHIP_PROF_BWD, st);
         for (int64_t v0 = 0; v0 < V; v0 += 65535) {  // grid.y limit
             const int nv = (int)(V - v0 < 65535 ? V - v0 : 65535);
@@ -1359,13 +1413,43 @@ extern "C" int tohip_traj_backward_multi(const void* packed, int64_t n, int64_t 
     TO_PROF(TOHIP_PROF_SMALL, st);
     const bool single = C == 1 && rq == nullptr;
     k_traj_bwd_finish<<<(int)V, TO_FINISH_THREADS, 0, st>>>(cv, bpart, pl.nslots, fv, pl.fv_words, rec, k, ties, part,
-                                                            occlusion_bits, occw, vgrad, cold, single ? 1 : 0, poses_grad, quats_grad);
+                                                            occlusion_bits, occw, vgrad, cold, single ? 1 : 0, poses_grad, quats_grad,
+                                                            fused_scalars, fused_scalars ? gout : nullptr);
     TO_HIP_CHECK_LAUNCH();
     if (!single) {
         k_traj_bwd_finish2<<<(int)((W + 63) / 64), 64, 0, st>>>(vgrad, rec, cold, (int)W, C, rq, rt, poses_grad, quats_grad);
         TO_HIP_CHECK_LAUNCH();
     }
     return TOHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int tohip_traj_backward_multi(const void* packed, int64_t n, int64_t W, int64_t n_traj, const tohip_camera* cam,
+                                         const tohip_rig* rig, int flags, const uint32_t* occlusion_bits, const float* lo_sum,
+                                         const float* grad_rewards, const float* scalars, const float* gout, float* poses_grad,
+                                         float* quats_grad, void* workspace, size_t workspace_bytes, void* stream_) {
+    return traj_backward_impl(packed, n, W, n_traj, cam, rig, flags, occlusion_bits, lo_sum, grad_rewards, scalars, gout, poses_grad, quats_grad,
+                              workspace, workspace_bytes, stream_, nullptr);
+}
+
+extern "C" int tohip_traj_reward_backward_multi(const void* packed, int64_t n, int64_t W, int64_t n_traj, const tohip_camera* cam,
+                                                const tohip_rig* rig, int flags, const uint32_t* occlusion_bits, const float* lo_sum,
+                                                float eps, int prefilled, float* rewards, float* scalars, const float* gout,
+                                                float* poses_grad, float* quats_grad, void* workspace, size_t workspace_bytes,
+                                                void* stream_) {
+    if (!rewards || !scalars || !gout) return TOHIP_EINVAL;
+    const FusedReward f{eps, prefilled, rewards, scalars};
+    return traj_backward_impl(packed, n, W, n_traj, cam, rig, flags, occlusion_bits, lo_sum, nullptr, scalars, gout, poses_grad, quats_grad,
+                              workspace, workspace_bytes, stream_, &f);
+}
+
+extern "C" int tohip_traj_reward_backward(const void* packed, int64_t n, int64_t W, const tohip_camera* cam, const tohip_rig* rig, int flags,
+                                          const uint32_t* occlusion_bits, const float* lo_sum, float eps, int prefilled, float* rewards,
+                                          float* scalars, const float* gout, float* poses_grad, float* quats_grad, void* workspace,
+                                          size_t workspace_bytes, void* stream_) {
+    return tohip_traj_reward_backward_multi(packed, n, W, 1, cam, rig, flags, occlusion_bits, lo_sum, eps, prefilled, rewards, scalars, gout,
+                                            poses_grad, quats_grad, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int tohip_traj_backward(const void* packed, int64_t n, int64_t W, const tohip_camera* cam, const tohip_rig* rig,

@@ -135,6 +135,38 @@ def traj_backward(cloud, n_wps, cam, ws, lo_sum, grad_rewards=None, scalars=None
     return pg, qg
 
 
+def traj_reward_backward(cloud, n_wps, cam, ws, lo_sum, gout, rewards=None, prefilled=False, rig=None, flags=0, occ=None):
+    """traj_reward + traj_backward of the fused visibility loss in two launches instead of three.
+    -> (rewards[N], scalars[4], poses_grad (n_wps,3), quats_grad (n_wps,4))."""
+    if rewards is None:
+        rewards = torch.empty(cloud.n, dtype=torch.float32, device=cloud.device)
+    scalars = torch.empty(4, dtype=torch.float32, device=cloud.device)
+    pg = torch.empty((n_wps, 3), dtype=torch.float32, device=cloud.device)
+    qg = torch.empty((n_wps, 4), dtype=torch.float32, device=cloud.device)
+    with torch.cuda.device(cloud.device):
+        check(_lib.lib().tohip_traj_reward_backward(ptr(cloud.blob), cloud.n, n_wps, cam.ref(), rig.ref() if rig is not None else _NULL_RIG,
+                                                    int(flags), ptr(occ), ptr(lo_sum), cam.eps, int(bool(prefilled)), ptr(rewards),
+                                                    ptr(scalars), ptr(gout), ptr(pg), ptr(qg), ptr(ws.buf), ws.bytes, stream_ptr()),
+              "tohip_traj_reward_backward")
+    return rewards, scalars, pg, qg
+
+
+def traj_reward_backward_multi(cloud, n_wps, n_traj, cam, ws, lo_sum, gout, rewards=None, prefilled=False, rig=None, flags=0):
+    """-> (rewards (B,N), scalars (B,4), poses_grad (W,3), quats_grad (W,4)) of B trajectories (traj_forward_multi's lo_sum)."""
+    if rewards is None:
+        rewards = torch.empty((n_traj, cloud.n), dtype=torch.float32, device=cloud.device)
+    scalars = torch.empty((n_traj, 4), dtype=torch.float32, device=cloud.device)
+    pg = torch.empty((n_wps, 3), dtype=torch.float32, device=cloud.device)
+    qg = torch.empty((n_wps, 4), dtype=torch.float32, device=cloud.device)
+    with torch.cuda.device(cloud.device):
+        check(_lib.lib().tohip_traj_reward_backward_multi(ptr(cloud.blob), cloud.n, n_wps, n_traj, cam.ref(),
+                                                          rig.ref() if rig is not None else _NULL_RIG, int(flags), None, ptr(lo_sum),
+                                                          cam.eps, int(bool(prefilled)), ptr(rewards), ptr(scalars), ptr(gout), ptr(pg),
+                                                          ptr(qg), ptr(ws.buf), ws.bytes, stream_ptr()),
+              "tohip_traj_reward_backward_multi")
+    return rewards, scalars, pg, qg
+
+
 def traj_forward_multi(cloud, poses, quats, traj_offsets, cam, ws, rig=None, flags=0, lo_sum=None, minmax=None, rewards_half=None):
     """Several trajectories over one cloud in one pass: `poses` (W,3) / `quats` (W,4) hold their waypoints end to end,
     `traj_offsets` (B+1 int32 on the device) where each starts.  -> (lo_sum (B, npad), minmax (V, 2)); ws = TrajWorkspace(cloud, V, B)."""

@@ -77,12 +77,15 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
         else:
             lo_sum.zero_()
         model._shard.allreduce_sum(lo_sum)
-        check(L.tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, 1 if n_loc > 0 else 0, ptr(rewards), ptr(scalars),
-                                  ptr(ws.buf), ws.bytes, s), "reward")
         tgt_p, tgt_q = (pg_loc, qg_loc) if sharded else (pg_e, qg_e)
         if n_loc > 0:
-            check(L.tohip_traj_backward(ptr(cloud.blob), cloud.n, n_loc, cam.ref(), rig_ref, model._flags, ptr(occ), ptr(lo_sum),
-                                        None, ptr(scalars), ptr(gout), ptr(tgt_p), ptr(tgt_q), ptr(ws.buf), ws.bytes, s), "backward")
+            # rewards, their mean and the loss scalars share the backward's first launch
+            check(L.tohip_traj_reward_backward(ptr(cloud.blob), cloud.n, n_loc, cam.ref(), rig_ref, model._flags, ptr(occ), ptr(lo_sum),
+                                               cam.eps, 1, ptr(rewards), ptr(scalars), ptr(gout), ptr(tgt_p), ptr(tgt_q), ptr(ws.buf),
+                                               ws.bytes, s), "reward + backward")
+        else:
+            check(L.tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, 0, ptr(rewards), ptr(scalars), ptr(ws.buf), ws.bytes, s),
+                  "reward")
         if sharded:
             # assemble every rank's gradient rows: ONE (n_eval, 7) all-reduce, then the replicated remainder of the step
             if n_loc > 0:
@@ -170,10 +173,9 @@ def optimize_trajectories(models, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewa
             check(L.tohip_traj_forward_multi(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), B * n_eval, ptr(toff), B, cam.ref(), rig_ref,
                                              m0._flags, None, ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(ws.buf), ws.bytes, s), "forward")
             ws.generation += 1
-            check(L.tohip_traj_reward_multi(ptr(cloud.blob), ptr(lo_sum), cloud.n, B, cam.eps, 1, ptr(rewards), ptr(scalars), ptr(ws.buf),
-                                            ws.bytes, s), "reward")
-            check(L.tohip_traj_backward_multi(ptr(cloud.blob), cloud.n, B * n_eval, B, cam.ref(), rig_ref, m0._flags, None, ptr(lo_sum), None,
-                                              ptr(scalars), ptr(gout), ptr(pg_e), ptr(qg_e), ptr(ws.buf), ws.bytes, s), "backward")
+            check(L.tohip_traj_reward_backward_multi(ptr(cloud.blob), cloud.n, B * n_eval, B, cam.ref(), rig_ref, m0._flags, None, ptr(lo_sum),
+                                                     cam.eps, 1, ptr(rewards), ptr(scalars), ptr(gout), ptr(pg_e), ptr(qg_e), ptr(ws.buf),
+                                                     ws.bytes, s), "reward + backward")
             check(L.tohip_traj_step_tail_multi(ptr(poses), ptr(quats), ptr(poses0), W, B, ptr(pg_e), ptr(qg_e), n_eval, step_w, ptr(pg), ptr(qg),
                                                ptr(mp), ptr(vp), ptr(mq), ptr(vq), float(m0.smoothness_weight), float(m0.traj_length_weight),
                                                float(m0.eps), float(lr_pose), float(lr_quat), betas[0], betas[1], adam_eps, float(rewards_th),
