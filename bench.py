@@ -216,7 +216,7 @@ def main():
     use_graph = args.graph == "on" and shard is None
 
     def captured(flags):
-        """The step's seven launches captured once into a HIP graph (torch.cuda.CUDAGraph on ROCm): a replay enqueues the same
+        """The step's launches captured once into a HIP graph (torch.cuda.CUDAGraph on ROCm): a replay enqueues the same
         kernels with the same arguments from one host call, so the ~50 us of Python + ctypes per step cannot starve the queue."""
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
