@@ -5,7 +5,7 @@ from trajectory_optimization_amd import synth
 from trajectory_optimization_amd.model import ModelTraj
 from trajectory_optimization_amd.optimizer import optimize_trajectories, optimize_trajectory
 dev = torch.device("cuda:0")
-n, w, B, steps = int(os.environ.get("N", 1_000_000)), int(os.environ.get("W", 128)), int(os.environ.get("B", 8)), 20
+n, w, B, steps = int(os.environ.get("N", 1_000_000)), int(os.environ.get("W", 128)), int(os.environ.get("B", 8)), int(os.environ.get("STEPS", 20))
 pts = torch.from_numpy(synth.make_cloud(n, seed=0))
 K = torch.from_numpy(synth.K_INTRINS)
 paths = []
