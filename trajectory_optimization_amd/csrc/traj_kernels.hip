@@ -903,35 +903,46 @@ __global__ void k_bwd_finish2(const float* __restrict__ vgrad, const WayHot* __r
     if (w < W) finish_waypoint(w, vgrad, HotRows{hot}, cold, C, rig_q, rig_t, poses_grad, quats_grad);
 }
 
-// block per virtual waypoint (1024 threads = 16 sums x 64 slot groups): adds the partials of the flagged slots — group g
-// takes the slots s = g (mod 64), i.e. bit g of every flag word, in ascending order; the 64 group sums are then added in
-// group order (double) — and the shares of the extremal points: the rows recorded by k_traj_select are re-evaluated by
+// block per virtual waypoint: adds the partials of the flagged slots in 16 sums x 64 slot groups — group g takes the slots
+// s = g (mod 64), i.e. bit g of every flag word, in ascending order; the 64 group sums are then added in group order (double).
+// THREADS = 1024: a thread per (sum, group), the shortest chain (up to a few hundred waypoints).  THREADS = 256: a thread keeps
+// four groups (g, g + 16, g + 32, g + 48) — the same 64 sums in the same order, bit for bit — and eight blocks share a CU where
+// two 1024-thread blocks made the 1 024 waypoints of eight concurrent trajectories queue (32 -> 13 us) — and the shares of the extremal points: the rows recorded by k_traj_select are re-evaluated by
 // wave 0 in ascending row order with a fixed DPP tree, so the result does not depend on any arrival order (torch splits the
 // gradient of min()/max() evenly among ties, model.py:226-227).
 //   vgrad[v*12 ..] = (sum dL/dc [3], sum y (x) dL/dc [9]) with c = R^T y:  R^T gy,  (y (x) gy) R.
-#define TO_FINISH_THREADS 1024
-__global__ void __launch_bounds__(TO_FINISH_THREADS)
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
 k_traj_bwd_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const unsigned long long* __restrict__ fv, int fv_words,
                   const WayRec* __restrict__ rec, EvalK k, const TieRec* __restrict__ ties, const float2* __restrict__ part,
                   const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ vgrad,
                   const WayCold* __restrict__ cold, int single, float* __restrict__ poses_grad, float* __restrict__ quats_grad,
                   const float* __restrict__ post_scalars, const float* __restrict__ post_gout) {
+    constexpr int NG = THREADS / 16, PER = 64 / NG;   // groups per pass, groups per thread
     __shared__ double sgrp[64][16];
     __shared__ double stie[2][13];   // [0] argmin set, [1] argmax set: 12 sums + count
     const int v = blockIdx.x, t = threadIdx.x, kq = t & 15, g = t >> 4;
     const WayRec& r = rec[v];
     // the waypoint's flag words first (one parallel load), then each group's bit of every word
     __shared__ unsigned long long sfv[1024];
-    double acc = 0.0;
+    double acc[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) acc[j] = 0.0;
     for (int w0 = 0; w0 < fv_words; w0 += 1024) {
         const int nw = min(1024, fv_words - w0);
         __syncthreads();
-        if (t < nw) sfv[t] = fv[(int64_t)v * fv_words + w0 + t];
+        for (int j = t; j < nw; j += THREADS) sfv[j] = fv[(int64_t)v * fv_words + w0 + j];
         __syncthreads();
-        for (int w = 0; w < nw; ++w)
-            if ((sfv[w] >> g) & 1ull) acc += (double)bpart[((int64_t)v * nslots + ((w0 + w) * 64 + g)) * 16 + kq];
+        for (int w = 0; w < nw; ++w) {
+            const unsigned long long word = sfv[w];
+            if (word == 0ull) continue;
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if ((word >> (g + NG * j)) & 1ull) acc[j] += (double)bpart[((int64_t)v * nslots + ((w0 + w) * 64 + g + NG * j)) * 16 + kq];
+        }
     }
-    sgrp[g][kq] = acc;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) sgrp[g + NG * j][kq] = acc[j];
     // ---- argmin / argmax sets: waves 0..3 take a quarter (64 points) of every recorded slot each ----
     __shared__ double stie4[2][4][13];
     if (t < 256) {
@@ -1412,9 +1423,12 @@ int traj_backward_impl(const void* packed, int64_t n, int64_t W, int64_t n_traj,
     }
     TO_PROF(TOHIP_PROF_SMALL, st);
     const bool single = C == 1 && rq == nullptr;
-    k_traj_bwd_finish<<<(int)V, TO_FINISH_THREADS, 0, st>>>(cv, bpart, pl.nslots, fv, pl.fv_words, rec, k, ties, part,
-                                                            occlusion_bits, occw, vgrad, cold, single ? 1 : 0, poses_grad, quats_grad,
-                                                            fused_scalars, fused_scalars ? gout : nullptr);
+    if (V <= 512)
+        k_traj_bwd_finish<1024><<<(int)V, 1024, 0, st>>>(cv, bpart, pl.nslots, fv, pl.fv_words, rec, k, ties, part, occlusion_bits, occw, vgrad,
+                                                         cold, single ? 1 : 0, poses_grad, quats_grad, fused_scalars, fused_scalars ? gout : nullptr);
+    else
+        k_traj_bwd_finish<256><<<(int)V, 256, 0, st>>>(cv, bpart, pl.nslots, fv, pl.fv_words, rec, k, ties, part, occlusion_bits, occw, vgrad,
+                                                       cold, single ? 1 : 0, poses_grad, quats_grad, fused_scalars, fused_scalars ? gout : nullptr);
     TO_HIP_CHECK_LAUNCH();
     if (!single) {
         k_traj_bwd_finish2<<<(int)((W + 63) / 64), 64, 0, st>>>(vgrad, rec, cold, (int)W, C, rq, rt, poses_grad, quats_grad);
