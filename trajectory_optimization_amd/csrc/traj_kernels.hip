@@ -228,7 +228,9 @@ __device__ inline void cull_bound(float tau, float inv_var, float* thr, float* s
 //   azero = some sample has p == 0 exactly  =>  min_n p == 0 (p is never negative)
 // The block first builds its waypoint's record (k_traj_prep's work: one launch less), and it is 1024 threads wide:
 // the samples are scattered single loads, so the kernel is as long as one thread's chain of them.
-#define TO_PROBE_THREADS 1024
+// THREADS = 1024 for up to a few hundred waypoints (the shortest chain); 256 beyond (eight blocks to a CU instead of two: the
+// 1 024 waypoints of eight concurrent trajectories no longer queue).  Maximum and "some p is zero" do not depend on the order.
+template <int TO_PROBE_THREADS>
 __global__ void __launch_bounds__(TO_PROBE_THREADS)
 k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restrict__ quats, int C,
              const float* __restrict__ rig_q, const float* __restrict__ rig_t, EvalK k, WayRec* __restrict__ rec,
@@ -240,7 +242,7 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
     clear_select_state(ft, ft_words);
     // the samples (a contiguous copy of every step-th sorted point, made at pack time) are requested first, the record is
     // built meanwhile
-    constexpr int kBatch = TO_PROBE_MAX / TO_PROBE_THREADS;
+    constexpr int kBatch = 8, kRounds = TO_PROBE_MAX / (TO_PROBE_THREADS * kBatch);
     float px[kBatch], py[kBatch], pz[kBatch];
 #pragma unroll
     for (int j = 0; j < kBatch; ++j) {
@@ -253,13 +255,23 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
     const WayRec r = rec[v];
     float mx = 0.f;
     int zero = 0;
+    for (int rd = 0; rd < kRounds; ++rd) {
+        if (rd > 0) {
 #pragma unroll
-    for (int j = 0; j < kBatch; ++j) {
-        const int sj = t + j * TO_PROBE_THREADS;
-        if (sj < cv.nsamples) {
-            const float p = vis_p(r, k, px[j], py[j], pz[j]) * occ_one(occ, occw, v, (int64_t)sj * cv.sample_step);
-            mx = fmaxf(mx, p);
-            zero |= (p == 0.f);
+            for (int j = 0; j < kBatch; ++j) {
+                const int sj = t + (rd * kBatch + j) * TO_PROBE_THREADS;
+                const int sc = sj < cv.nsamples ? sj : 0;
+                px[j] = cv.samples[sc]; py[j] = cv.samples[TO_PROBE_MAX + sc]; pz[j] = cv.samples[2 * TO_PROBE_MAX + sc];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int sj = t + (rd * kBatch + j) * TO_PROBE_THREADS;
+            if (sj < cv.nsamples) {
+                const float p = vis_p(r, k, px[j], py[j], pz[j]) * occ_one(occ, occw, v, (int64_t)sj * cv.sample_step);
+                mx = fmaxf(mx, p);
+                zero |= (p == 0.f);
+            }
         }
     }
     for (int s = 32; s > 0; s >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, s)); zero |= __shfl_xor(zero, s); }
@@ -421,9 +433,10 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile
 // Flags: fv[v][slot word] (finish kernel), ft[slot][v word] (forward); vlist[v][0..vcnt[v]) = the flagged slots of v
 // (backward).  Everything a block appends to is its own: the only global atomics are the ft bits, fire and forget.
 
-#define TO_SELECT_THREADS 1024
-#define TO_SELECT_FAST_SLOTS (4 * TO_SELECT_THREADS)   // up to this many slots (1 M points) a thread keeps its slots' partials in registers
-template <bool FAST>
+#define TO_SELECT_FAST_SLOTS 4096   // up to this many slots (1 M points) a thread keeps its slots' partials in registers
+// TO_SELECT_THREADS = 1024 for up to a few hundred waypoints, 256 beyond (eight blocks to a CU instead of two); minima, maxima, flags
+// and the sorted tie rows do not depend on it
+template <bool FAST, int TO_SELECT_THREADS>
 __global__ void __launch_bounds__(TO_SELECT_THREADS)
 k_traj_select(const float2* __restrict__ part, int nslots, int V, WayRec* __restrict__ rec, int cull, float* __restrict__ minmax,
               unsigned long long* __restrict__ fv, int fv_words, unsigned long long* __restrict__ ft, int vwords,
@@ -436,15 +449,16 @@ k_traj_select(const float2* __restrict__ part, int nslots, int V, WayRec* __rest
     const float2* pv = part + (int64_t)v * nslots;
     float mn = INFINITY, mx = -INFINITY;
     bool nan = false;
-    float2 q[4];   // FAST: thread t owns slots t, t + 1024, ...: requested at once, kept for sweep 2
+    constexpr int NQ = TO_SELECT_FAST_SLOTS / TO_SELECT_THREADS;
+    float2 q[NQ];   // FAST: thread t owns slots t, t + THREADS, ...: requested at once, kept for sweep 2
     if constexpr (FAST) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < NQ; ++kk) {
             const int s = t + kk * TO_SELECT_THREADS;
             q[kk] = s < nslots ? pv[s] : make_float2(INFINITY, -INFINITY);
         }
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < NQ; ++kk) {
             mn = fminf(mn, q[kk].x);
             mx = fmaxf(mx, q[kk].y);
             nan |= (q[kk].y != q[kk].y);   // a NaN p wins the max in pass 1 (integer order): the reference's max() is NaN too
@@ -552,7 +566,7 @@ k_traj_select(const float2* __restrict__ part, int nslots, int V, WayRec* __rest
     };
     if constexpr (FAST) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < NQ; ++kk)
             if (kk * TO_SELECT_THREADS < nslots) sweep2(q[kk], kk * TO_SELECT_THREADS);
     } else {
         for (int s0 = 0; s0 < nslots; s0 += TO_SELECT_THREADS) sweep2(s0 + t < nslots ? pv[s0 + t] : make_float2(0.f, 0.f), s0);
@@ -1288,8 +1302,12 @@ extern "C" int tohip_traj_forward_multi(const void* packed, int64_t n, const flo
     {
         TO_PROF(TOHIP_PROF_SMALL, st);
         if (cull) {
-            k_traj_probe<<<(int)V, TO_PROBE_THREADS, 0, st>>>(cv, poses, quats, C, rq, rt, k, rec, cold, occlusion_bits, occw,
-                                                              ft, ft_words, toff, (int)n_traj);
+            if (V <= 512)
+                k_traj_probe<1024><<<(int)V, 1024, 0, st>>>(cv, poses, quats, C, rq, rt, k, rec, cold, occlusion_bits, occw, ft, ft_words, toff,
+                                                            (int)n_traj);
+            else
+                k_traj_probe<256><<<(int)V, 256, 0, st>>>(cv, poses, quats, C, rq, rt, k, rec, cold, occlusion_bits, occw, ft, ft_words, toff,
+                                                          (int)n_traj);
         } else {
             int nb = (int)((V + 255) / 256);
             const int want = (int)((ft_words + 255) / 256);
@@ -1317,12 +1335,18 @@ extern "C" int tohip_traj_forward_multi(const void* packed, int64_t n, const flo
     }
     {
         TO_PROF(TOHIP_PROF_SMALL, st);
-        if (pl.nslots <= TO_SELECT_FAST_SLOTS)
-            k_traj_select<true><<<(int)V, TO_SELECT_THREADS, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
+        const bool fast = pl.nslots <= TO_SELECT_FAST_SLOTS;
+        if (V <= 512) {
+            if (fast) k_traj_select<true, 1024><<<(int)V, 1024, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
                                                                       pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C, k.inv_var);
-        else
-            k_traj_select<false><<<(int)V, TO_SELECT_THREADS, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
-                                                                       pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C, k.inv_var);
+            else k_traj_select<false, 1024><<<(int)V, 1024, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
+                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C, k.inv_var);
+        } else {
+            if (fast) k_traj_select<true, 256><<<(int)V, 256, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
+                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C, k.inv_var);
+            else k_traj_select<false, 256><<<(int)V, 256, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
+                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C, k.inv_var);
+        }
         TO_HIP_CHECK_LAUNCH();
     }
     {
