@@ -771,11 +771,12 @@ __device__ __forceinline__ void bwd_pairs(const CloudView& cv, const WayRec* __r
         for (int q = 0; q < TO_SLOT / 64; ++q) {
             const int64_t i = (int64_t)s * TO_SLOT + q * 64 + lane;
             const float x = cv.soa[i], y = cv.soa[cv.npad + i], z = cv.soa[2 * cv.npad + i];
+            const float lo_i = lo_sum[i];   // (npad floats per vector) requested with the coordinates, not after the distance test
             if (!__any(!(dist2_sp(r, x, y, z) > r.thr1))) continue;   // none of these 64 points can reach p_hat = 1/2 (k_traj_select)
             // dL/d lo_sum_n: through the caller's dL/d rewards vector (general criterion) or the fused visibility loss
             float gn = 0.f;
             if (i < cv.n) {
-                const float lo = lo_sum[i];
+                const float lo = lo_i;
                 float rw = to_rcp(1.0f + to_exp(-lo));  // == k_traj_reward's value of rewards[perm[i]]
                 if (lo != lo) rw = lo;
                 const float gr = grad_rewards ? grad_rewards[cv.perm[i]] : coef;
