@@ -443,7 +443,8 @@ __global__ void __launch_bounds__(TO_BLOCK) k_sort_keys(Bufs b, const float* __r
             q[k] = t >= 0.0f ? (t < 1023.0f ? (unsigned)t : 1023u) : 0u;
         }
         const unsigned m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
-        b.keys[e] = ((unsigned long long)(unsigned)sg << 30) | m;
+        if (b.nseg == 1) reinterpret_cast<unsigned*>(b.keys)[e] = m;   // one hull: 32-bit keys sort in half the time
+        else b.keys[e] = ((unsigned long long)(unsigned)sg << 30) | m;
         b.vals[e] = e;
     }
 }
@@ -1259,8 +1260,11 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         int seg_bits = 0;
         while ((1 << seg_bits) < b.nseg) ++seg_bits;
         size_t tmp = b.sort_tmp_bytes;
-        const hipError_t es = hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, tmp, b.keys, b.keys2, b.vals, b.perm, b.m1, 0,
-                                                                 30 + seg_bits, st);  // stable: equal cells keep the caller's order
+        // stable: equal cells keep the caller's order
+        const hipError_t es = b.nseg == 1
+            ? hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, tmp, reinterpret_cast<const unsigned*>(b.keys), reinterpret_cast<unsigned*>(b.keys2),
+                                                 b.vals, b.perm, b.m1, 0, 30, st)
+            : hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, tmp, b.keys, b.keys2, b.vals, b.perm, b.m1, 0, 30 + seg_bits, st);
         if (es != hipSuccess) return (int)es;
     }
     k_load<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, pts, with_origin);
