@@ -262,3 +262,19 @@ def test_hull_with_exact_copies_of_points(dev):
         assert np.array_equal(np.unique(pts[got], axis=0), np.unique(pts[ref], axis=0))
         if n < 32768:   # (the sample phase of a large build may meet the copy first)
             assert np.array_equal(got, ref0)   # every vertex is reported at its first row
+
+
+def test_hull_builds_repeat(dev):
+    """The order in which concurrent claims land differs from build to build (and with it face ids and the number of rounds); the
+    vertex set must not: twelve builds of two fixtures, every one equal to Qhull's."""
+    from trajectory_optimization_amd.tools import convexHull, sphericalFlip
+    for name in ("hpr_synth_outside", "hpr_synth_100k"):
+        d = load_golden(name)
+        pts = torch.from_numpy(d["points"]).to(dev)
+        for _ in range(12):
+            if "hull_vertices" in d:
+                assert np.array_equal(convexHull(sphericalFlip(pts, dev, 2), dev).vertices.cpu().numpy(), d["hull_vertices"])
+            else:
+                from trajectory_optimization_amd.tools import hidden_pts_removal
+                _, mask = hidden_pts_removal(pts, dev)
+                assert np.array_equal(np.flatnonzero(mask.cpu().numpy()), d["visible_idx"])
