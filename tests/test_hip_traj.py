@@ -420,3 +420,23 @@ def test_fused_reward_backward_equals_the_two_calls(dev, name):
         lo, _ = ops.traj_forward(cloud, p, q, cam, ws, flags=flags)
         outs.append(ops.traj_reward_backward(cloud, p.shape[0], cam, ws, lo, gout, flags=flags))
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+@pytest.mark.parametrize("n,w,cams,occ", [(200_000, 70, 1, True), (60_000, 9, 3, False), (300_000, 130, 1, False)])
+def test_fused_reward_backward_with_rig_and_occlusion(dev, n, w, cams, occ):
+    """tohip_traj_reward_backward on the cases the fixtures do not have: occlusion rows, a camera rig (k_traj_bwd_finish2),
+    more than 128 waypoints; against the two separate calls and the f64 oracle."""
+    from oracle import oracle
+    ops = _ops()
+    c = _setup(dev, n, w, cams, occ)
+    gout = torch.tensor([1.0], device=dev)
+    lo, _ = ops.traj_forward(c["cloud"], c["p"], c["q"], c["cam"], c["ws"], c["rig"], occ=c["occ"])
+    rew, sc = ops.traj_reward(c["cloud"], lo, c["cam"], c["ws"])
+    pg, qg = ops.traj_backward(c["cloud"], w, c["cam"], c["ws"], lo, scalars=sc, gout=gout, rig=c["rig"], occ=c["occ"])
+    rew2, sc2, pg2, qg2 = ops.traj_reward_backward(c["cloud"], w, c["cam"], c["ws"], lo, gout, rig=c["rig"], occ=c["occ"])
+    assert torch.equal(rew, rew2) and torch.equal(sc, sc2)
+    assert rel_inf(pg2.cpu().numpy(), pg.cpu().numpy()) < 1e-6 and rel_inf(qg2.cpu().numpy(), qg.cpu().numpy()) < 1e-6
+    if cams == 1 and not occ:
+        f = oracle.traj_forward(c["pts"], c["poses"], c["quats"], K, IW, IH, prec="f64")
+        pgo, qgo = oracle.traj_backward(c["pts"], c["poses"], c["quats"], K, IW, IH, f, prec="f64")
+        assert rel_inf(pg2.cpu().numpy(), pgo) < GRAD_TOL and rel_inf(qg2.cpu().numpy(), qgo) < GRAD_TOL
