@@ -101,6 +101,7 @@ struct Bufs {
     int fcap;
     int nseg;
     int hbits;             // bits of the apex height in a candidate's rank (make_prio)
+    int early_out;         // k_owner_claim: candidates beaten by a neighbouring candidate do not walk
     int origin;            // 1: the last slot of a segment is the appended origin; 0: it repeats the segment's first point and never takes part
     int sub;               // > 1 while only every sub-th point (in Morton order) takes part: the first rounds of a large build
 };
@@ -167,7 +168,7 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                              (const int*)nullptr, (int*)nullptr, (int)m1, 0, 64, (hipStream_t)0);
     p = take(tmp); if (b) { b->sort_tmp = p; b->sort_tmp_bytes = tmp; }
-    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; b->origin = 1; b->hbits = 0; }
+    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; b->origin = 1; b->hbits = 0; b->early_out = 0; }
     return o;
 }
 
@@ -740,6 +741,23 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
         }
         if (__hip_atomic_load(&b.fowner[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != o) continue;  // taken by a better one
         const unsigned long long po = b.fprio[o];
+        {
+            // A candidate whose own face is seen by the apex of a BETTER candidate next door has lost before it starts: that
+            // neighbour's walk takes this face at its first level.  Not walking keeps its claims off the faces that worse
+            // candidates need (experiments: TOHIP_HULL_EARLY_OUT=0 switches it off)
+            bool doomed = false;
+            if (b.early_out && lane < 3) {
+                const int n = b.fn[3 * o + lane];
+                if ((b.fflags[n] & 3) == 3 && b.fprio[n] < po) {
+                    const int an = b.fapex[n];
+                    if (an != 0x7fffffff) {
+                        const int pa = b.inv[an];
+                        doomed = plane_dist(b.frec[o], b.px[pa], b.py[pa], b.pz[pa]) > 0.0;
+                    }
+                }
+            }
+            if (__any(doomed)) continue;
+        }
         const int apex = b.inv[ax];
         const double px = b.px[apex], py = b.py[apex], pz = b.pz[apex];
         int cur = 0, ncur = 1, claimed = 0;
@@ -1241,6 +1259,8 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         // (tools/hpr_sweep.sh): 0 bits (hash only) 177 rounds / 10.7 ms at 1 M points, 6: 116 / 7.0, 9: 106 / 6.2, 12: 120 / 6.7, 16: 129 / 7.2
         static const int hb = getenv("TOHIP_HULL_HBITS") ? atoi(getenv("TOHIP_HULL_HBITS")) : 9;  // experiments
         b.hbits = hb < 0 ? 0 : (hb > 16 ? 16 : hb);
+        static const int eo = getenv("TOHIP_HULL_EARLY_OUT") ? atoi(getenv("TOHIP_HULL_EARLY_OUT")) : 1;  // experiments
+        b.early_out = eo;
     }
     {
         // large segments: the first rounds on a sample (see k_assign_all)
