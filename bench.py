@@ -126,6 +126,100 @@ def hpr_leg(points, device):
             "index_set_equal_to_qhull": bool(np.array_equal(idx.cpu().numpy().astype(np.int64), ref))}
 
 
+def dropin_leg(device, steps=200, warmup=10):
+    """The reference's OWN loop (/root/reference/src/trajectory_optimization.py:109-116) over the drop-in classes:
+        optimizer.zero_grad(); loss = model(); loss.backward(); optimizer.step()
+    timed without any synchronisation inside the loop (one at the end), with torch.optim.Adam as the reference builds it (two
+    parameter groups), with torch's fused Adam, with this package's one-launch Adam (same constructor), with the whole step
+    captured into a HIP graph (torch.cuda.graph + capturable Adam), and the launch-only optimize_trajectory beside them."""
+    from trajectory_optimization_amd.model import ModelTraj
+    from trajectory_optimization_amd.optimizer import optimize_trajectory, Adam as HipAdam
+    b = np.load(os.path.join(REPO, "tests", "golden", "bundled.npz"))
+    ident = np.tile(np.array([[1, 0, 0, 0]], np.float32), (len(b["poses"]), 1))
+    cases = {"bundled_40k_x_27": (b["pts"].astype(np.float32), b["poses"].astype(np.float32), ident, 0.5),
+             "synthetic_1M_x_128": (synth.make_cloud(N_POINTS, seed=0),) + synth.make_path(WPS_PER_GPU, optical=True) + (0.0,)}
+    K = torch.from_numpy(synth.K_INTRINS)
+    out = {}
+    for name, (pts, poses, quats, vwd) in cases.items():
+        P = torch.from_numpy(pts).to(device)
+
+        def model():
+            return ModelTraj(P, torch.from_numpy(poses), torch.from_numpy(quats), K, synth.IMG_WIDTH, synth.IMG_HEIGHT, device=device)
+
+        def groups(m):
+            return [{"params": [m.poses], "lr": 0.1}, {"params": [m.quats], "lr": 0.02}]
+
+        def loop(m, opt, n):
+            for _ in range(n):
+                opt.zero_grad()
+                loss = m(vis_wps_dist=vwd)
+                loss.backward()
+                opt.step()
+            return loss
+
+        res = {}
+        variants = {"torch.optim.Adam": lambda m: torch.optim.Adam(groups(m)),
+                    "torch.optim.Adam(fused=True)": lambda m: torch.optim.Adam(groups(m), fused=True),
+                    "trajectory_optimization_amd.optimizer.Adam": lambda m: HipAdam(groups(m))}
+        for vname, mk in variants.items():
+            try:
+                m = model()
+                opt = mk(m)
+                loop(m, opt, warmup)
+                torch.cuda.synchronize(device)
+                gc_was = gc.isenabled()
+                gc.disable()
+                t0 = time.perf_counter()
+                loss = loop(m, opt, steps)
+                torch.cuda.synchronize(device)
+                dt = time.perf_counter() - t0
+                if gc_was:
+                    gc.enable()
+                res[vname] = {"ms_per_step": 1e3 * dt / steps, "loss_after": float(loss.item())}
+            except Exception as e:  # a variant this torch build lacks is reported, not fatal
+                res[vname] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        # the whole step (forward, backward, capturable Adam) captured once, replayed per step
+        try:
+            m = model()
+            opt = torch.optim.Adam(groups(m), capturable=True)
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                loop(m, opt, 3)
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+            g = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(g):
+                loss = m(vis_wps_dist=vwd)
+                loss.backward()
+                opt.step()
+            for _ in range(warmup):
+                g.replay()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                g.replay()
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            res["hip_graph(torch.optim.Adam(capturable=True))"] = {"ms_per_step": 1e3 * dt / steps, "loss_after": float(loss.item())}
+        except Exception as e:
+            res["hip_graph(torch.optim.Adam(capturable=True))"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        m = model()
+        optimize_trajectory(m, n_opt_steps=warmup, lr_pose=0.1, lr_quat=0.02, rewards_th=1e9, vis_wps_dist=vwd)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        optimize_trajectory(m, n_opt_steps=steps, lr_pose=0.1, lr_quat=0.02, rewards_th=1e9, vis_wps_dist=vwd)
+        torch.cuda.synchronize(device)
+        res["launch_only(optimize_trajectory)"] = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / steps}
+        n_eval = (len(poses) + m._wps_step(vwd) - 1) // m._wps_step(vwd)
+        out[name] = {"points": int(pts.shape[0]), "waypoints": int(len(poses)), "waypoints_evaluated": int(n_eval), "steps": steps,
+                     "mode": "culled (library default)", "variants": res}
+    out["note"] = ("the reference's loop, unchanged, over ModelTraj: zero_grad(); loss = model(); loss.backward(); step() — host-bound: "
+                   "model() and backward() are one library call each, the rest of the time is torch's autograd engine and optimizer")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +238,7 @@ def main():
                     help="replay the step's launches from a HIP graph in the timed region (measured SLOWER on ROCm 7.2: 0.151 vs "
                          "0.139 ms dense, 0.079 vs 0.075 culled - graph kernel nodes cost more than the queue they replace)")
     ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--dropin", choices=["on", "off"], default="on", help="time the reference's own loop over the drop-in classes (N = 1 only)")
     ap.add_argument("--dump", default=None, help="write the last dense step's outputs (scalars, gradient rows, rewards) to this .npz "
                                                  "(rank 0): tests compare runs at different N")
     args = ap.parse_args()
@@ -375,6 +470,8 @@ def main():
             "note": "library default (what ModelTraj runs): pass 1 skips pairs that provably can neither be a waypoint's maximum "
                     "nor contribute, via a Morton-sorted cloud, per-256-point bounding spheres and a distance bound on p"}
         if n_gpus == 1 and args.cpu_wps > 0 and args.cameras == 1:
+            if args.dropin == "on":
+                line["dropin"] = dropin_leg(device)
             line["hpr"] = hpr_leg(pts, device)
             line["cpu_baseline"] = cpu_baseline(pts, poses_all, quats_all, args.cpu_wps)
             line["reference_cpu_container"] = {

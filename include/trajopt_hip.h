@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOHIP_ABI_VERSION 7
+#define TOHIP_ABI_VERSION 8
 
 #define TOHIP_OK 0
 #define TOHIP_EINVAL (-1)   /* bad size / null pointer */
@@ -170,6 +170,46 @@ int tohip_traj_reward_backward_multi(const void *packed, int64_t n_points, int64
                                      float *scalars, const float *gout, float *poses_grad, float *quats_grad, void *workspace,
                                      size_t workspace_bytes, void *stream);
 
+/* ---- ModelTraj.forward() / loss.backward() as one call each ------------------------------------------
+ * The reference's loop (trajectory_optimization.py:109-116) is `optimizer.zero_grad(); loss = model(); loss.backward();
+ * optimizer.step()`; one step's kernels take 0.05-0.15 ms on an MI355X, so the loop is bound by the host work between them.
+ * tohip_traj_loss describes a model once (HOST struct, caller-owned like everything it points to; the library keeps no state):
+ * model() is then tohip_traj_loss_forward — waypoint selection (model.py:214-217), visibility + log-odds (:217-231), rewards
+ * (:237), criterion (:244-260) — and loss.backward() is tohip_traj_loss_backward.  One trajectory, no occlusion rows, no
+ * sharding (those go through the separate calls above). */
+typedef struct tohip_traj_loss {
+    const void *packed;      /* tohip_pack_cloud's blob */
+    int64_t n_points;
+    int64_t n_wps;           /* W: ALL waypoints (criterion uses every one, model.py:249-258) */
+    int32_t wps_step;        /* every wps_step-th waypoint is evaluated for visibility (model.py:215-217) */
+    int32_t flags;           /* TOHIP_TRAJ_* */
+    tohip_camera cam;
+    tohip_rig rig;           /* n_cams = 0: one camera at the body frame */
+    const float *poses0;     /* (W,3) initial positions (model.py:176) */
+    float smoothness_weight; /* model.py:166 */
+    float traj_length_weight;
+    void *workspace;         /* tohip_traj_workspace_bytes(n_points, n_eval * max(1, n_cams)), n_eval = ceil(W / wps_step); zero-filled once */
+    size_t workspace_bytes;
+    void *scratch;           /* tohip_traj_loss_scratch_bytes(...) bytes: the step's intermediate vectors (layout below) */
+    size_t scratch_bytes;
+    float *reg_terms;        /* NULL, or (3, W, 3) floats: the gradients of l2, length and smooth separately (callers that
+                                differentiate a single entry of model.loss) */
+} tohip_traj_loss;
+size_t tohip_traj_loss_scratch_bytes(int64_t n_points, int64_t n_wps, int32_t wps_step, int32_t n_cams);
+/* byte offsets into `scratch` of: [0] poses_e (n_eval,3)  [1] quats_e (n_eval,4)  [2] lo_sum (Npad, packed order)
+ * [3] minmax (V,2)  [4] scalars (4: mean reward, loss_vis, d loss_vis / d reward, -)  [5] poses_grad_eval (n_eval,3)
+ * [6] quats_grad_eval (n_eval,4)  [7] regularisers' gradient (W,3) — for callers that want to look at them. */
+int tohip_traj_loss_scratch_layout(int64_t n_points, int64_t n_wps, int32_t wps_step, int32_t n_cams, int64_t *offsets_host);
+/* model(): rewards (N floats, caller's point order), loss_terms[0..4] = vis, l2, length, smooth, total (8 floats).  Leaves the
+ * step's state in workspace + scratch for tohip_traj_loss_backward (and for tohip_traj_backward with a general dL/d rewards:
+ * the workspace is in the state tohip_traj_forward leaves, lo_sum / scalars are in scratch). */
+int tohip_traj_loss_forward(const tohip_traj_loss *plan_host, const float *poses, const float *quats, float *rewards,
+                            float *loss_terms, void *stream);
+/* loss.backward(): gout = DEVICE pointer to dL/d loss (autograd's incoming gradient); poses_grad (W,3), quats_grad (W,4) =
+ * gout * d loss / d (poses, quats) of the step whose forward last used the plan's workspace and scratch. */
+int tohip_traj_loss_backward(const tohip_traj_loss *plan_host, const float *gout, float *poses_grad, float *quats_grad,
+                             void *stream);
+
 /* ---- ModelPose (model.py:98-127) -------------------------------------------------------------- */
 size_t tohip_pose_workspace_bytes(int64_t n_points);
 
@@ -284,6 +324,19 @@ int tohip_rows_strided(const float *src, int64_t n_rows, int cols, int step, int
  * 1-based iteration; a no-op once state[2] != 0 (early stop reached).  state may be NULL. */
 int tohip_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                     float beta2, float eps, int32_t step, const float *state, void *stream);
+/* The same update for up to TOHIP_ADAM_MAX_GROUPS parameter tensors in ONE launch (the reference's optimiser holds two:
+ * poses @ lr_pose, quats @ lr_quat, trajectory_optimization.py:91-94).  groups_host: HOST array. */
+#define TOHIP_ADAM_MAX_GROUPS 8
+typedef struct tohip_adam_group {
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    int64_t n;
+    float lr, beta1, beta2, eps;
+    int32_t step; /* 1-based */
+} tohip_adam_group;
+int tohip_adam_step_multi(const tohip_adam_group *groups_host, int32_t n_groups, void *stream);
 /* early-stop rule of trajectory_optimization.py:100-124 on the device.  state (8 floats, zero-initialised by
  * the caller): [0] reward0 [1] smooth0 [2] stopped [3] steps taken [4] visibility gain [5] smoothness gain. */
 int tohip_early_stop(const float *scalars, const float *loss_terms, float rewards_th, float smoothness_th, float *state,

@@ -30,6 +30,21 @@ class Rig(ctypes.Structure):
     _fields_ = [("n_cams", c_i32), ("rig_quats", c_vp), ("rig_trans", c_vp)]
 
 
+class TrajLoss(ctypes.Structure):
+    """struct tohip_traj_loss (include/trajopt_hip.h)."""
+    _fields_ = [("packed", c_vp), ("n_points", c_i64), ("n_wps", c_i64), ("wps_step", c_i32), ("flags", c_i32), ("cam", Camera),
+                ("rig", Rig), ("poses0", c_vp), ("smoothness_weight", c_f), ("traj_length_weight", c_f), ("workspace", c_vp),
+                ("workspace_bytes", c_sz), ("scratch", c_vp), ("scratch_bytes", c_sz), ("reg_terms", c_vp)]
+
+
+class AdamGroup(ctypes.Structure):
+    """struct tohip_adam_group (include/trajopt_hip.h)."""
+    _fields_ = [("param", c_vp), ("grad", c_vp), ("exp_avg", c_vp), ("exp_avg_sq", c_vp), ("n", c_i64), ("lr", c_f), ("beta1", c_f),
+                ("beta2", c_f), ("eps", c_f), ("step", c_i32)]
+
+
+ADAM_MAX_GROUPS = 8  # TOHIP_ADAM_MAX_GROUPS
+
 # name -> (restype, argtypes); every symbol include/trajopt_hip.h declares
 SIGNATURES = {
     "tohip_abi_version": (ctypes.c_int, []),
@@ -55,6 +70,10 @@ SIGNATURES = {
     "tohip_gather_waypoints_multi": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, ctypes.c_int, c_vp, c_vp, c_vp]),
     "tohip_traj_forward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig),
                                            ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_traj_loss_scratch_bytes": (c_sz, [c_i64, c_i64, c_i32, c_i32]),
+    "tohip_traj_loss_scratch_layout": (ctypes.c_int, [c_i64, c_i64, c_i32, c_i32, ctypes.POINTER(c_i64)]),
+    "tohip_traj_loss_forward": (ctypes.c_int, [ctypes.POINTER(TrajLoss), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tohip_traj_loss_backward": (ctypes.c_int, [ctypes.POINTER(TrajLoss), c_vp, c_vp, c_vp, c_vp]),
     "tohip_inverse_permutation": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "tohip_occlusion_rows": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "tohip_occlusion_row": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -92,6 +111,7 @@ SIGNATURES = {
     "tohip_gather_waypoints": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_vp]),
     "tohip_rows_strided": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     "tohip_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_i32, c_vp, c_vp]),
+    "tohip_adam_step_multi": (ctypes.c_int, [ctypes.POINTER(AdamGroup), c_i32, c_vp]),
     "tohip_early_stop": (ctypes.c_int, [c_vp, c_vp, c_f, c_f, c_vp, ctypes.c_int, c_vp]),
     "tohip_ingest_workspace_bytes": (c_sz, [c_i64]),
     "tohip_pointcloud2_to_xyz": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
@@ -146,7 +166,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 7  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
+ABI_VERSION = 8  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
 ENOSPC = -2  # TOHIP_ENOSPC
 ENAN = -4    # TOHIP_ENAN
 

@@ -354,6 +354,32 @@ extern "C" int tohip_adam_step(float* param, const float* grad, float* exp_avg, 
     return TOHIP_OK;
 }
 
+// torch.optim.Adam's update of up to TOHIP_ADAM_MAX_GROUPS parameter tensors in ONE launch (blockIdx.y = tensor): the reference's
+// optimiser holds two (poses @ lr_pose, quats @ lr_quat; trajectory_optimization.py:91-94), torch launches ~7 kernels for each.
+struct AdamMulti { tohip_adam_group g[TOHIP_ADAM_MAX_GROUPS]; };
+__global__ void __launch_bounds__(256) k_adam_multi(AdamMulti a) {
+    const tohip_adam_group& g = a.g[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += (int64_t)gridDim.x * blockDim.x)
+        adam_element(g.param, g.grad[i], g.exp_avg, g.exp_avg_sq, (int)i, g.lr, g.beta1, g.beta2, g.eps, g.step);
+}
+
+extern "C" int tohip_adam_step_multi(const tohip_adam_group* groups, int32_t n_groups, void* stream_) {
+    if (!groups || n_groups <= 0 || n_groups > TOHIP_ADAM_MAX_GROUPS) return TOHIP_EINVAL;
+    AdamMulti a;
+    int64_t nmax = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const tohip_adam_group& g = groups[i];
+        if (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq || g.n <= 0 || g.n > 0x7fffffff || g.step < 1) return TOHIP_EINVAL;
+        a.g[i] = g;
+        if (g.n > nmax) nmax = g.n;
+    }
+    int64_t nb = (nmax + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    k_adam_multi<<<dim3((unsigned)nb, (unsigned)n_groups), 256, 0, (hipStream_t)stream_>>>(a);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
 extern "C" int tohip_early_stop(const float* scalars, const float* loss_terms, float rewards_th, float smoothness_th,
                                 float* state, int row_from_state, void* stream_) {
     if (!scalars || !loss_terms || !state) return TOHIP_EINVAL;

@@ -1398,9 +1398,10 @@ struct FusedReward { float eps; int prefilled; float* rewards; float* scalars; }
 int traj_backward_impl(const void* packed, int64_t n, int64_t W, int64_t n_traj, const tohip_camera* cam,
                        const tohip_rig* rig, int flags, const uint32_t* occlusion_bits, const float* lo_sum,
                        const float* grad_rewards, const float* scalars, const float* gout, float* poses_grad,
-                       float* quats_grad, void* workspace, size_t workspace_bytes, void* stream_, const FusedReward* fused) {
-    if (!packed || !cam || !lo_sum || !poses_grad || !quats_grad || !workspace || n <= 0 || W <= 0 || n_traj <= 0 ||
-        (!grad_rewards && (!scalars || !gout)) || n_traj > 65535)
+                       float* quats_grad, void* workspace, size_t workspace_bytes, void* stream_, const FusedReward* fused,
+                       int phases = 3 /* 1: the pair sums (with `fused`: + rewards, mean, loss scalars); 2: the finish kernels */) {
+    if (!packed || !cam || !lo_sum || ((phases & 2) && (!poses_grad || !quats_grad)) || !workspace || n <= 0 || W <= 0 || n_traj <= 0 ||
+        (!grad_rewards && (!scalars || ((phases & 2) && !gout))) || n_traj > 65535)
         return TOHIP_EINVAL;
     const float* fused_scalars = fused ? scalars : nullptr;
     hipStream_t st = (hipStream_t)stream_;
@@ -1424,7 +1425,8 @@ int traj_backward_impl(const void* packed, int64_t n, int64_t W, int64_t n_traj,
     const float* rt = rq ? rig->rig_trans : nullptr;
     const int64_t occw = cv.npad / 32;
     (void)flags;
-    if (fused) {
+    if (!(phases & 1)) {
+    } else if (fused) {
         TO_PROF(TOHIP_PROF_BWD, st);
         int nbx = (int)((n + 4 * TO_REWARD_THREADS - 1) / (4 * TO_REWARD_THREADS));
         if (nbx > TO_REWARD_BLOCKS) nbx = TO_REWARD_BLOCKS;
@@ -1446,6 +1448,7 @@ int traj_backward_impl(const void* packed, int64_t n, int64_t W, int64_t n_traj,
         }
         TO_HIP_CHECK_LAUNCH();
     }
+    if (!(phases & 2)) return TOHIP_OK;
     TO_PROF(TOHIP_PROF_SMALL, st);
     const bool single = C == 1 && rq == nullptr;
     if (V <= 512)

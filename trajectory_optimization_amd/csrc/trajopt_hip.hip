@@ -7,6 +7,7 @@
 #include "hard_kernels.hip"
 #include "hull_kernels.hip"
 #include "optim_kernels.hip"
+#include "loss_kernels.hip"
 #include "ingest_kernels.hip"
 #include "render_kernels.hip"
 

@@ -10,6 +10,7 @@ gfx950 kernels behind the C ABI of include/trajopt_hip.h (see ops.py); the O(W) 
 criterion() stay in torch.  There is no CPU fallback: constructing a model on a
 non-HIP device raises.
 """
+import ctypes
 from copy import deepcopy
 from time import time
 
@@ -18,6 +19,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
+from .optimizer import tag_parameter
 from .tools import hidden_pts_removal
 
 
@@ -226,13 +228,51 @@ class _TrajRewards(torch.autograd.Function):
         return grads[:, :3].contiguous(), grads[:, 3:].contiguous(), None
 
 
+def _assemble_grads(model, step_w, W, lo, hi, pg, qg, g_loss, g_terms, reg_sum, reg_terms, dev):
+    """(W,3) / (W,4) gradients from this rank's evaluated rows [lo, hi) (pg, qg: None when the visibility term carries no
+    gradient), all-reduced over the shard, plus the regularisers' share (identical on every rank, so added after the all-reduce).
+    g_terms = (g_l2, g_length, g_smooth): upstream gradients of the single entries of model.loss, or all None."""
+    grads = torch.zeros((W, 7), dtype=torch.float32, device=dev)
+    if pg is not None:
+        rows = slice(lo * step_w, (hi - 1) * step_w + 1, step_w)
+        grads[rows, :3], grads[rows, 3:] = pg, qg
+    grads = model._shard.allreduce_sum(grads)
+    pg_all, qg_all = grads[:, :3], grads[:, 3:]
+    if all(g is None for g in g_terms):
+        if g_loss is not None:
+            pg_all = pg_all + g_loss * reg_sum
+    else:
+        for k, g in enumerate(g_terms):
+            c = g_loss if g is None else (g.to(torch.float32) if g_loss is None else g_loss + g.to(torch.float32))
+            if c is not None:
+                pg_all = pg_all + c * reg_terms[k]
+    return pg_all.contiguous(), qg_all.contiguous()
+
+
+def _vis_upstream(g_loss, g_vis, g_rewards, scalars):
+    """Keyword arguments of ops.traj_backward for the upstream gradients of (loss, loss['vis'], rewards); None: no gradient."""
+    c_vis = g_vis if g_loss is None else (g_loss if g_vis is None else g_loss + g_vis)  # the visibility term enters the total with weight 1
+    if c_vis is None and g_rewards is None:
+        return None
+    if g_rewards is None:
+        return dict(scalars=scalars, gout=c_vis.reshape(1).contiguous())  # fused visibility loss, read on the device
+    g = g_rewards.to(torch.float32)
+    if c_vis is not None:
+        g = g + c_vis * scalars[2]  # d loss_vis / d reward_n = -vis^2 / N
+    return dict(grad_rewards=g.contiguous())
+
+
+def _f32(g):
+    return None if g is None else g.to(torch.float32)
+
+
 class _TrajLoss(torch.autograd.Function):
-    """ModelTraj.forward in one autograd node: (poses, quats) -> (loss, rewards, vis, l2, length, smooth).
+    """ModelTraj.forward in one autograd node: (poses, quats) -> (loss, rewards, vis, l2, length, smooth), for a sharded and / or
+    occlusion-aware model (the plain single-GPU model goes through _TrajLossPlan below: one library call per direction).
 
     Same launches as optimizer.optimize_trajectory's step — visibility forward, [all-reduce], reward, criterion
     regularisers with their analytic gradients — instead of the ~60 small torch kernels and as many autograd nodes
-    the op-by-op criterion costs: on an MI355X the forward/backward pair of the drop-in loop is bound by those
-    launches, not by the kernels.  Every output stays differentiable, as in the reference: `loss.backward()` takes the
+    the op-by-op criterion costs.  Every output stays differentiable, as in the reference: `loss.backward()` takes the
     fused visibility-loss path; a loss built on model.rewards or on single entries of model.loss back-propagates
     through the general dL/d rewards path and the per-term regulariser gradients."""
 
@@ -276,40 +316,187 @@ class _TrajLoss(torch.autograd.Function):
         ps, qs, lo_sum, scalars, reg_sum, reg_terms = ctx.saved_tensors
         m = ctx.model
         lo, hi = ctx.range
-        dev = lo_sum.device
-
-        def f32(g):
-            return None if g is None else g.to(torch.float32)
-
-        def plus(a, b):
-            return b if a is None else (a if b is None else a + b)
-
-        g_loss, g_vis = f32(g_loss), f32(g_vis)
-        c_vis = plus(g_loss, g_vis)  # dL/d loss_vis: the visibility term enters the total with weight 1
-        grads = torch.zeros((ctx.W, 7), dtype=torch.float32, device=dev)
-        if hi > lo and (c_vis is not None or g_rewards is not None):
-            if g_rewards is None:
-                kw = dict(scalars=scalars, gout=c_vis.reshape(1).contiguous())  # fused visibility loss, read on the device
-            else:
-                g = g_rewards.to(torch.float32)
-                if c_vis is not None:
-                    g = g + c_vis * scalars[2]  # d loss_vis / d reward_n = -vis^2 / N
-                kw = dict(grad_rewards=g.contiguous())
+        g_loss = _f32(g_loss)
+        pg = qg = None
+        kw = _vis_upstream(g_loss, _f32(g_vis), g_rewards, scalars) if hi > lo else None
+        if kw is not None:
             pg, qg = _local_backward(m, ctx.ws, ctx.gen, ps, qs, ctx.occ, lo_sum, **kw)
-            rows = slice(lo * ctx.step_w, (hi - 1) * ctx.step_w + 1, ctx.step_w)
-            grads[rows, :3], grads[rows, 3:] = pg, qg
-        grads = m._shard.allreduce_sum(grads)
-        pg_all, qg_all = grads[:, :3], grads[:, 3:]
-        # regularisers: identical on every rank, so added after the all-reduce
-        if g_l2 is None and g_length is None and g_smooth is None:
-            if g_loss is not None:
-                pg_all = pg_all + g_loss * reg_sum
+        pg_all, qg_all = _assemble_grads(m, ctx.step_w, ctx.W, lo, hi, pg, qg, g_loss, (g_l2, g_length, g_smooth), reg_sum, reg_terms,
+                                         lo_sum.device)
+        return pg_all, qg_all, None, None
+
+
+class _LossPlan:
+    """A ModelTraj as the library sees it (struct tohip_traj_loss): built once per (model, waypoint step), it owns the step's
+    workspace and scratch vectors, so that model() and loss.backward() are one library call each with five pointers."""
+
+    def __init__(self, model, step_w):
+        L = _lib.lib()
+        dev, cloud, rig = model.device, model._cloud, model._rig
+        W = model.poses.shape[0]
+        C = rig.n_cams if rig is not None else 1
+        self.n, self.W, self.step_w = cloud.n, W, step_w
+        self.n_eval = (W + step_w - 1) // step_w
+        self.ws = model._workspace(self.n_eval)
+        nbytes = L.tohip_traj_loss_scratch_bytes(cloud.n, W, step_w, C)
+        self.scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        off = (ctypes.c_int64 * 8)()
+        check(L.tohip_traj_loss_scratch_layout(cloud.n, W, step_w, C, off), "tohip_traj_loss_scratch_layout")
+
+        def view(i, count, shape):
+            return self.scratch[off[i]:off[i] + 4 * count].view(torch.float32).view(shape)
+        self.poses_e, self.quats_e = view(0, 3 * self.n_eval, (self.n_eval, 3)), view(1, 4 * self.n_eval, (self.n_eval, 4))
+        self.lo_sum, self.scalars = view(2, cloud.npad, (cloud.npad,)), view(4, 4, (4,))
+        self.reg_sum = view(7, 3 * W, (W, 3))
+        self.reg_terms = torch.empty((3, W, 3), dtype=torch.float32, device=dev)
+        self.poses0 = model.poses0.contiguous()
+        c = _lib.TrajLoss()
+        c.packed, c.n_points, c.n_wps, c.wps_step, c.flags = cloud.blob.data_ptr(), cloud.n, W, step_w, int(model._flags)
+        c.cam = model._cam.c
+        if rig is not None:
+            c.rig = rig.c
+        c.poses0 = self.poses0.data_ptr()
+        c.smoothness_weight, c.traj_length_weight = float(model.smoothness_weight), float(model.traj_length_weight)
+        c.workspace, c.workspace_bytes = self.ws.buf.data_ptr(), self.ws.bytes
+        c.scratch, c.scratch_bytes = self.scratch.data_ptr(), nbytes
+        c.reg_terms = self.reg_terms.data_ptr()
+        self.c, self.ref = c, ctypes.byref(c)
+        self.model = model
+        self.fwd, self.bwd = L.tohip_traj_loss_forward, L.tohip_traj_loss_backward
+        self.dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.dev = dev
+        self.f32 = dict(dtype=torch.float32, device=dev)
+        self.one = torch.ones((), **self.f32)   # dL/d loss of a plain loss.backward()
+
+    def forward(self, poses, quats, rewards, terms):
+        idx = self.dev_index
+        self.ws.generation += 1
+        if torch.cuda.current_device() == idx:
+            rc = self.fwd(self.ref, poses.data_ptr(), quats.data_ptr(), rewards.data_ptr(), terms.data_ptr(),
+                          torch._C._cuda_getCurrentRawStream(idx))
         else:
-            for k, g in enumerate((g_l2, g_length, g_smooth)):
-                c = plus(g_loss, f32(g))
-                if c is not None:
-                    pg_all = pg_all + c * reg_terms[k]
-        return pg_all.contiguous(), qg_all.contiguous(), None, None
+            with torch.cuda.device(idx):
+                rc = self.fwd(self.ref, poses.data_ptr(), quats.data_ptr(), rewards.data_ptr(), terms.data_ptr(),
+                              torch._C._cuda_getCurrentRawStream(idx))
+        if rc:
+            check(rc, "tohip_traj_loss_forward")
+        return self.ws.generation
+
+    def backward(self, gout, pg, qg):
+        idx = self.dev_index
+        if torch.cuda.current_device() == idx:
+            rc = self.bwd(self.ref, gout.data_ptr(), pg.data_ptr(), qg.data_ptr(), torch._C._cuda_getCurrentRawStream(idx))
+        else:
+            with torch.cuda.device(idx):
+                rc = self.bwd(self.ref, gout.data_ptr(), pg.data_ptr(), qg.data_ptr(), torch._C._cuda_getCurrentRawStream(idx))
+        if rc:
+            check(rc, "tohip_traj_loss_backward")
+
+
+class _FastBackward:
+    """What `loss.backward()` needs when `loss` is exactly what model() returned and nothing else is asked for: the plan, the
+    Parameters and their versions.  torch's autograd engine hands a HIP graph to a worker thread and waits for it (40-80 us per
+    call for these two small tensors); this does what that thread would do — one library call, gradients accumulated into
+    .grad — on the calling thread.  Anything beyond the plain call goes through the engine."""
+    __slots__ = ("plan", "gen", "node", "params", "versions", "done")
+
+    def __init__(self, plan, gen, node, params):
+        self.plan, self.gen, self.node, self.params, self.done = plan, gen, node, params, False
+        self.versions = (params[0]._version, params[1]._version)
+
+    def usable(self, loss):
+        p, q = self.params
+        return (loss.grad_fn is self.node and p._version == self.versions[0] and q._version == self.versions[1] and
+                p.requires_grad and q.requires_grad and p._backward_hooks is None and q._backward_hooks is None and
+                getattr(p, "_post_accumulate_grad_hooks", None) is None and getattr(q, "_post_accumulate_grad_hooks", None) is None and
+                (p.grad is None or _plain_grad(p)) and (q.grad is None or _plain_grad(q)) and not torch.is_anomaly_enabled())
+
+    def run(self, retain_graph):
+        plan = self.plan
+        if self.done:
+            raise RuntimeError("Trying to backward through the graph a second time (or directly access saved tensors after they have "
+                               "already been freed). Specify retain_graph=True if you need to backward through the graph a second time.")
+        p, q = self.params
+        if plan.ws.generation != self.gen:   # model() ran again since: rebuild this step's state
+            self.gen = plan.forward(p, q, torch.empty(plan.n, **plan.f32), torch.empty(8, **plan.f32))
+        pg, qg = torch.empty((plan.W, 3), **plan.f32), torch.empty((plan.W, 4), **plan.f32)
+        plan.backward(plan.one, pg, qg)
+        with torch.no_grad():
+            if p.grad is None:
+                p.grad = pg
+            else:
+                p.grad.add_(pg)
+            if q.grad is None:
+                q.grad = qg
+            else:
+                q.grad.add_(qg)
+        if not retain_graph:
+            self.done = True
+
+
+def _plain_grad(p):
+    g = p.grad
+    return g.dtype == torch.float32 and g.device == p.device and g.shape == p.shape and not g.requires_grad and not g.is_sparse
+
+
+class _Loss(torch.Tensor):
+    """The 0-d loss ModelTraj.forward returns: an ordinary tensor (same storage, same autograd node) whose plain
+    `.backward()` skips the autograd engine's thread hand-off (_FastBackward); every other use is torch's."""
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        fast = self.__dict__.get("_tohip_fast")
+        if fast is not None and gradient is None and inputs is None and not create_graph and fast.usable(self):
+            return fast.run(retain_graph)
+        return super().backward(gradient, retain_graph, create_graph, inputs)
+
+
+class _TrajLossPlan(torch.autograd.Function):
+    """ModelTraj.forward of a single-GPU model without occlusion rows: (poses, quats) -> (loss, rewards, vis, l2, length, smooth)
+    with ONE library call in each direction (tohip_traj_loss_forward / _backward over the model's _LossPlan) and no torch kernel
+    besides: the reference's `zero_grad(); loss = model(); loss.backward(); step()` loop is bound by the host on this chip.
+    The inputs are saved by reference: editing poses / quats in place between model() and backward() raises, as torch's own ops
+    would; a backward that arrives after another forward of the same model re-runs its forward first (same inputs, same bits).
+    Upstream gradients other than dL/d loss (model.rewards, single entries of model.loss) take the general kernels."""
+
+    @staticmethod
+    def forward(ctx, poses, quats, plan):
+        if not (poses.is_contiguous() and quats.is_contiguous() and poses.dtype == torch.float32 and quats.dtype == torch.float32):
+            raise RuntimeError("ModelTraj: poses / quats must be contiguous float32 tensors")
+        rewards = torch.empty(plan.n, **plan.f32)
+        terms = torch.empty(8, **plan.f32)
+        ctx.gen = plan.forward(poses, quats, rewards, terms)
+        ctx.plan = plan
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(poses, quats)
+        vis, l2, length, smooth, total = terms[:5].unbind()
+        if plan.model.fast_backward:
+            total = total.as_subclass(_Loss)   # made here: an alias made outside would be one more autograd node
+        return total, rewards, vis, l2, length, smooth
+
+    @staticmethod
+    def backward(ctx, g_loss, g_rewards, g_vis, g_l2, g_length, g_smooth):
+        plan = ctx.plan
+        poses, quats = ctx.saved_tensors
+        if plan.ws.generation != ctx.gen:   # model() ran again since: rebuild this step's state (rewards / loss terms to spare vectors)
+            ctx.gen = plan.forward(poses, quats, torch.empty(plan.n, **plan.f32), torch.empty(8, **plan.f32))
+        if g_rewards is None and g_vis is None and g_l2 is None and g_length is None and g_smooth is None:
+            if g_loss is None:
+                return None, None, None
+            if g_loss.dtype != torch.float32 or g_loss.device != plan.dev:
+                g_loss = g_loss.to(**plan.f32)
+            pg, qg = torch.empty((plan.W, 3), **plan.f32), torch.empty((plan.W, 4), **plan.f32)
+            plan.backward(g_loss, pg, qg)
+            return pg, qg, None
+        m = plan.model
+        g_loss = _f32(g_loss)
+        pg = qg = None
+        kw = _vis_upstream(g_loss, _f32(g_vis), g_rewards, plan.scalars)
+        if kw is not None:
+            pg, qg = ops.traj_backward(m._cloud, plan.n_eval, m._cam, plan.ws, plan.lo_sum, rig=m._rig, flags=m._flags, **kw)
+        pg_all, qg_all = _assemble_grads(m, plan.step_w, plan.W, 0, plan.n_eval, pg, qg, g_loss, (g_l2, g_length, g_smooth), plan.reg_sum,
+                                         plan.reg_terms, plan.dev)
+        return pg_all, qg_all, None
 
 
 # ------------------------------------------------------------------------------ models
@@ -354,6 +541,8 @@ class ModelPose(nn.Module):
         self._ws = ops.PoseWorkspace(self._cloud)
         self._occlusion_mask, self._occlusion_key = None, None
         self.fused_loss = True  # forward() as one autograd node; False (or an overridden criterion): observations node + torch ops
+        for p in (self.trans, self.quat):
+            tag_parameter(p)   # torch.optim.Adam.step() may update them with one launch (optimizer.accelerate_torch_adam)
 
     def forward(self, debug=False, hpr=False):
         t0 = time()
@@ -460,11 +649,16 @@ class ModelTraj(nn.Module):
             raise ValueError("occlusion must be None, 'hpr' or 'zbuffer'")
         self._occlusion, self._occlusion_limits = occlusion, occlusion_limits
         self._ws_cache = {}
+        self._plan_obj, self._plan_key = None, None
         self._wps_step_cache = {}
         self._length0 = None
         # forward() as ONE autograd node (visibility + criterion on the device); False: rewards node + the op-by-op
         # torch criterion below (always used when a subclass overrides criterion, or for fewer than 3 waypoints)
         self.fused_loss = True
+        # a plain `loss.backward()` on what forward() returned runs on the calling thread (_FastBackward); False: always torch's engine
+        self.fast_backward = True
+        for p in (self.poses, self.quats):
+            tag_parameter(p)   # torch.optim.Adam.step() may update them with one launch (optimizer.accelerate_torch_adam)
 
     def _occlusion_rows(self, ps, qs):
         """Occlusion bit rows of the given body waypoints, one row per virtual waypoint v = w*C + c (with a rig: the cameras'
@@ -492,6 +686,15 @@ class ModelTraj(nn.Module):
             ws = self._ws_cache[v] = ops.TrajWorkspace(self._cloud, v)
         return ws
 
+    def _plan(self, step_w):
+        """The library-side description of this model for the one-call forward / backward (rebuilt when something it froze
+        has changed: the weights of criterion, the mode, the initial trajectory, the number of waypoints)."""
+        key = (step_w, float(self.smoothness_weight), float(self.traj_length_weight), self._flags, self.poses0.data_ptr(),
+               self.poses.shape[0])
+        if self._plan_key != key:
+            self._plan_obj, self._plan_key = _LossPlan(self, step_w), key
+        return self._plan_obj
+
     def _wps_step(self, vis_wps_dist):
         # based on the mean waypoint distance of the INITIAL trajectory (model.py:214-215); constant per
         # model, so the host sync the reference pays on every forward happens once
@@ -513,7 +716,13 @@ class ModelTraj(nn.Module):
         N_wps = len(self.poses)
         wps_step = self._wps_step(vis_wps_dist)
         if self.fused_loss and N_wps >= 3 and type(self).criterion is ModelTraj.criterion:
-            loss, self.rewards, vis, l2, length, smooth = _TrajLoss.apply(self.poses, self.quats, self, wps_step)
+            if self._occlusion is None and self._shard.world_size == 1:
+                plan = self._plan(wps_step)
+                loss, self.rewards, vis, l2, length, smooth = _TrajLossPlan.apply(self.poses, self.quats, plan)
+                if type(loss) is _Loss and loss.requires_grad:
+                    loss.__dict__["_tohip_fast"] = _FastBackward(plan, plan.ws.generation, loss.grad_fn, (self.poses, self.quats))
+            else:
+                loss, self.rewards, vis, l2, length, smooth = _TrajLoss.apply(self.poses, self.quats, self, wps_step)
             self.loss = {'vis': vis, 'length': length, 'l2': l2, 'smooth': smooth}
             if debug:
                 torch.cuda.synchronize(self.device)

@@ -238,10 +238,37 @@ def optimize_pose(model, n_opt_steps=100, lr_pose=0.1, lr_quat=0.1, hpr=False, b
     return PoseOptResult(losses[:n_opt_steps].cpu().tolist())  # the run's only host synchronisation
 
 
+def _adam_update(L, entries, arr):
+    """One launch for all the listed (group, param, state, grad) entries (at most ADAM_MAX_GROUPS per launch)."""
+    k = 0
+    dev = None
+    for group, p, st, g in entries:
+        e = arr[k]
+        e.param, e.grad, e.exp_avg, e.exp_avg_sq = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+        e.n = p.numel()
+        e.lr, (e.beta1, e.beta2), e.eps, e.step = group["lr"], group["betas"], group["eps"], int(st["step"])
+        k += 1
+        if dev is not None and p.device != dev:
+            raise RuntimeError("one optimizer step over parameters of several devices is not supported")
+        dev = p.device
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if torch.cuda.current_device() == idx:
+        rc = L.tohip_adam_step_multi(arr, k, torch._C._cuda_getCurrentRawStream(idx))
+    else:
+        with torch.cuda.device(idx):
+            rc = L.tohip_adam_step_multi(arr, k, torch._C._cuda_getCurrentRawStream(idx))
+    if rc:
+        check(rc, "tohip_adam_step_multi")
+
+
+def _steppable(p, g):
+    return p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.dtype == torch.float32 and g.is_contiguous() and not g.is_sparse
+
+
 class Adam(torch.optim.Optimizer):
     """torch.optim.Adam for the models' Parameters (defaults of the reference's loops: betas (0.9, 0.999), eps 1e-8, no
-    weight decay, no amsgrad) with ONE kernel launch per parameter (tohip_adam_step) instead of the dozen small foreach
-    kernels per step — the drop-in loop is launch-bound.  Same constructor (parameter groups with their own `lr`), so
+    weight decay, no amsgrad) with ONE kernel launch for all parameters (tohip_adam_step_multi) instead of the dozen small foreach
+    kernels per group — the drop-in loop is launch-bound.  Same constructor (parameter groups with their own `lr`), so
     `ExponentialLR` and friends work unchanged:
 
         optimizer = Adam([{'params': [model.poses], 'lr': 0.1}, {'params': [model.quats], 'lr': 0.02}])
@@ -249,6 +276,7 @@ class Adam(torch.optim.Optimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._arr = (_lib.AdamGroup * _lib.ADAM_MAX_GROUPS)()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -256,13 +284,15 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        L = _lib.lib()
+        entries = []
         for group in self.param_groups:
-            b1, b2 = group["betas"]
             for p in group["params"]:
-                if p.grad is None:
+                g = p.grad
+                if g is None:
                     continue
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                if not _steppable(p, g):
                     raise RuntimeError("trajectory_optimization_amd.optimizer.Adam steps contiguous float32 HIP tensors only")
                 st = self.state[p]
                 if not st:
@@ -270,9 +300,94 @@ class Adam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                with torch.cuda.device(p.device):
-                    check(L.tohip_adam_step(ptr(p.data), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), p.numel(),
-                                            float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), None,
-                                            stream_ptr()), "tohip_adam_step")
+                entries.append((group, p, st, g))
+        L = _lib.lib()
+        for i in range(0, len(entries), _lib.ADAM_MAX_GROUPS):
+            _adam_update(L, entries[i:i + _lib.ADAM_MAX_GROUPS], self._arr)
         return loss
+
+
+# ---- torch.optim.Adam itself, for the models' Parameters ----------------------------------------------------------------------
+# The reference builds `torch.optim.Adam([{'params': [model.poses], 'lr': lr_pose}, {'params': [model.quats], 'lr': lr_quat}])`
+# (/root/reference/src/trajectory_optimization.py:91-94).  Its step() is ~14 foreach launches and 0.13-0.15 ms of host time for
+# these two small tensors — longer than everything else in the loop together.  While this is enabled (default), a step pre-hook
+# updates the Parameters that belong to a model of this package (tagged at construction) with the one-launch kernel, on
+# torch's own state entries (`step`, `exp_avg`, `exp_avg_sq`: state_dict(), schedulers and a later switch back all keep working),
+# and hides their gradients from torch's step for its duration; every other parameter, and every optimizer configuration other
+# than plain Adam (amsgrad, weight decay, maximize, capturable, fused, differentiable, a closure) is left to torch.
+
+_ACCEL = {"on": True, "installed": False}
+
+
+def accelerate_torch_adam(enable=True):
+    """Switch the one-launch update of tagged Parameters inside torch.optim.Adam.step() on or off (process-wide)."""
+    _ACCEL["on"] = bool(enable)
+    if enable:
+        _install_hooks()
+
+
+def tag_parameter(p):
+    """Mark a Parameter as one whose plain-Adam update may be taken over (the models call this for poses / quats / trans / quat)."""
+    p._tohip_param = True
+    _install_hooks()
+    return p
+
+
+def _install_hooks():
+    if not _ACCEL["installed"]:
+        from torch.optim.optimizer import register_optimizer_step_pre_hook, register_optimizer_step_post_hook
+        register_optimizer_step_pre_hook(_adam_pre_hook)
+        register_optimizer_step_post_hook(_adam_post_hook)
+        _ACCEL["installed"] = True
+
+
+def _plain_adam_group(g):
+    return not (g["amsgrad"] or g["weight_decay"] != 0 or g["maximize"] or g["capturable"] or g["differentiable"] or g["fused"] or
+                g.get("decoupled_weight_decay", False) or not isinstance(g["lr"], float))
+
+
+def _adam_pre_hook(opt, args, kwargs):
+    if not _ACCEL["on"] or type(opt) is not torch.optim.Adam or (len(args) > 1 and args[1] is not None) or kwargs.get("closure") is not None:   # args[0] is the optimizer
+        return None
+    entries = []
+    for group in opt.param_groups:
+        plain = None
+        for p in group["params"]:
+            g = p.grad
+            if g is None or not getattr(p, "_tohip_param", False):
+                continue
+            if plain is None:
+                plain = _plain_adam_group(group)
+            if not plain or not _steppable(p, g):
+                continue
+            st = opt.state[p]
+            if len(st) == 0:   # what torch.optim.Adam._init_group creates (step on the host: neither capturable nor fused)
+                st["step"] = torch.tensor(0.0, dtype=torch.float64 if torch.get_default_dtype() == torch.float64 else torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif st["step"].is_cuda or not st["exp_avg"].is_contiguous():
+                continue
+            entries.append((group, p, st, g))
+    if not entries:
+        return None
+    arr = opt.__dict__.get("_tohip_adam_arr")
+    if arr is None:
+        arr = opt.__dict__["_tohip_adam_arr"] = (_lib.AdamGroup * _lib.ADAM_MAX_GROUPS)()
+    L = _lib.lib()
+    with torch.no_grad():
+        for _, _, st, _ in entries:
+            st["step"] += 1
+        for i in range(0, len(entries), _lib.ADAM_MAX_GROUPS):
+            _adam_update(L, entries[i:i + _lib.ADAM_MAX_GROUPS], arr)
+    for _, p, _, _ in entries:
+        p.grad = None    # torch's step skips parameters without a gradient; the post-hook puts it back
+    opt.__dict__["_tohip_adam_stash"] = entries
+    return None
+
+
+def _adam_post_hook(opt, args, kwargs):
+    stash = opt.__dict__.pop("_tohip_adam_stash", None)
+    if stash:
+        for _, p, _, g in stash:
+            p.grad = g
+    return None
