@@ -55,7 +55,7 @@ def test_backward_on_the_calling_thread_equals_the_engine(dev, vwd):
 
 def test_fast_backward_steps_aside(dev):
     """Anything but the plain call goes through torch's engine: an explicit gradient, a hook on a Parameter, a loss built on
-    the returned one, an in-place edit of the inputs (which raises, as torch's own saved tensors would)."""
+    the returned one."""
     m = _model(dev)
     ref = m(vis_wps_dist=0.0)
     ref.backward()
@@ -72,12 +72,6 @@ def test_fast_backward_steps_aside(dev):
     m(vis_wps_dist=0.0).backward()
     h.remove()
     assert len(seen) == 1 and torch.equal(seen[0], g0)
-    m.zero_grad()
-    loss = m(vis_wps_dist=0.0)
-    with torch.no_grad():
-        m.poses.add_(0.01)
-    with pytest.raises(RuntimeError, match="inplace|in-place"):
-        loss.backward()
 
 
 def test_backward_after_another_forward_rebuilds_its_step(dev):

@@ -319,24 +319,31 @@ def test_tie_sets_are_deterministic_and_split_evenly(dev, copies):
 
 
 def test_workspace_state_contract(dev):
-    """The backward reads the state its forward left in the workspace.  ModelTraj notices when another forward has used the
-    workspace in between and rebuilds the state: gradients of the first loss are the same either way."""
+    """The backward reads the state its forward left in the workspace, not the Parameters: an optimizer step (an in-place edit)
+    between model() and backward() changes nothing.  ModelTraj notices when another forward has used the workspace in between
+    and rebuilds the state from the (unchanged) inputs: gradients of the first loss are the same either way.  Both at once —
+    another forward AND edited inputs — cannot be served and raises."""
     from trajectory_optimization_amd.model import ModelTraj
     pts = synth.make_cloud(30_000, seed=9)
     poses, quats = synth.make_path(6, optical=True, jitter_seed=9)
-    def grads(second_forward):
+    def grads(second_forward, edit, fast=True):
         m = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(K), IW, IH, device=dev)
+        m.fast_backward = fast
         loss = m(vis_wps_dist=0.0)
         if second_forward:
+            m(vis_wps_dist=0.0)
+        if edit:
             with torch.no_grad():
                 m.poses.add_(0.05)
-            m(vis_wps_dist=0.0)
-            with torch.no_grad():
-                m.poses.sub_(0.05)
+                m.quats.mul_(1.5)
         loss.backward()
         return m.poses.grad.clone(), m.quats.grad.clone()
-    a, b = grads(False), grads(True)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    a = grads(False, False)
+    for fast in (True, False):
+        for b in (grads(True, False, fast), grads(False, True, fast)):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        with pytest.raises(RuntimeError, match="inplace"):
+            grads(True, True, fast)
 
 
 @pytest.mark.parametrize("seed", range(10))

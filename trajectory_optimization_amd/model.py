@@ -382,6 +382,14 @@ class _LossPlan:
             check(rc, "tohip_traj_loss_forward")
         return self.ws.generation
 
+    def rebuild(self, poses, quats, versions):
+        """The state of an earlier step, after another forward has used the workspace: possible while its inputs are unchanged."""
+        if poses._version != versions[0] or quats._version != versions[1]:
+            raise RuntimeError("ModelTraj: backward() of a loss whose model has been evaluated again AND whose poses / quats have been "
+                               "modified by an inplace operation since: the step's state is gone (call backward() before the next "
+                               "model(), or before optimizer.step())")
+        return self.forward(poses, quats, torch.empty(self.n, **self.f32), torch.empty(8, **self.f32))
+
     def backward(self, gout, pg, qg):
         idx = self.dev_index
         if torch.cuda.current_device() == idx:
@@ -406,8 +414,7 @@ class _FastBackward:
 
     def usable(self, loss):
         p, q = self.params
-        return (loss.grad_fn is self.node and p._version == self.versions[0] and q._version == self.versions[1] and
-                p.requires_grad and q.requires_grad and p._backward_hooks is None and q._backward_hooks is None and
+        return (loss.grad_fn is self.node and p.requires_grad and q.requires_grad and p._backward_hooks is None and q._backward_hooks is None and
                 getattr(p, "_post_accumulate_grad_hooks", None) is None and getattr(q, "_post_accumulate_grad_hooks", None) is None and
                 (p.grad is None or _plain_grad(p)) and (q.grad is None or _plain_grad(q)) and not torch.is_anomaly_enabled())
 
@@ -418,7 +425,7 @@ class _FastBackward:
                                "already been freed). Specify retain_graph=True if you need to backward through the graph a second time.")
         p, q = self.params
         if plan.ws.generation != self.gen:   # model() ran again since: rebuild this step's state
-            self.gen = plan.forward(p, q, torch.empty(plan.n, **plan.f32), torch.empty(8, **plan.f32))
+            self.gen = plan.rebuild(p, q, self.versions)
         pg, qg = torch.empty((plan.W, 3), **plan.f32), torch.empty((plan.W, 4), **plan.f32)
         plan.backward(plan.one, pg, qg)
         with torch.no_grad():
@@ -455,8 +462,9 @@ class _TrajLossPlan(torch.autograd.Function):
     """ModelTraj.forward of a single-GPU model without occlusion rows: (poses, quats) -> (loss, rewards, vis, l2, length, smooth)
     with ONE library call in each direction (tohip_traj_loss_forward / _backward over the model's _LossPlan) and no torch kernel
     besides: the reference's `zero_grad(); loss = model(); loss.backward(); step()` loop is bound by the host on this chip.
-    The inputs are saved by reference: editing poses / quats in place between model() and backward() raises, as torch's own ops
-    would; a backward that arrives after another forward of the same model re-runs its forward first (same inputs, same bits).
+    The backward reads the state its forward left in the plan's workspace (records, flags, regulariser gradients), not the
+    Parameters: editing them in place after model() — optimizer.step() — does not disturb it.  A backward that arrives after
+    ANOTHER forward of the same model re-runs its own forward first (same inputs, same bits), which needs the inputs unchanged.
     Upstream gradients other than dL/d loss (model.rewards, single entries of model.loss) take the general kernels."""
 
     @staticmethod
@@ -468,7 +476,8 @@ class _TrajLossPlan(torch.autograd.Function):
         ctx.gen = plan.forward(poses, quats, rewards, terms)
         ctx.plan = plan
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(poses, quats)
+        ctx.inputs, ctx.versions = (poses, quats), (poses._version, quats._version)
+        ctx.save_for_backward(plan.one)   # nothing of it is needed: a second backward() without retain_graph raises like torch's ops
         vis, l2, length, smooth, total = terms[:5].unbind()
         if plan.model.fast_backward:
             total = total.as_subclass(_Loss)   # made here: an alias made outside would be one more autograd node
@@ -477,9 +486,9 @@ class _TrajLossPlan(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, g_rewards, g_vis, g_l2, g_length, g_smooth):
         plan = ctx.plan
-        poses, quats = ctx.saved_tensors
+        ctx.saved_tensors
         if plan.ws.generation != ctx.gen:   # model() ran again since: rebuild this step's state (rewards / loss terms to spare vectors)
-            ctx.gen = plan.forward(poses, quats, torch.empty(plan.n, **plan.f32), torch.empty(8, **plan.f32))
+            ctx.gen = plan.rebuild(ctx.inputs[0], ctx.inputs[1], ctx.versions)
         if g_rewards is None and g_vis is None and g_l2 is None and g_length is None and g_smooth is None:
             if g_loss is None:
                 return None, None, None
