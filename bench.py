@@ -234,6 +234,9 @@ def main():
                          "waypoint) pair is one virtual waypoint with its own min-max normalisation")
     ap.add_argument("--fused-reward", choices=["on", "off"], default="on",
                     help="on: tohip_traj_reward_backward (6 launches per step); off: tohip_traj_reward then tohip_traj_backward (7)")
+    ap.add_argument("--fused-step", choices=["on", "off"], default="on",
+                    help="N = 1: tohip_traj_forward_backward (4 launches); off: tohip_traj_forward then tohip_traj_reward_backward (5), the "
+                         "split that a waypoint-sharded run needs around its all-reduce")
     ap.add_argument("--graph", choices=["on", "off"], default="off",
                     help="replay the step's launches from a HIP graph in the timed region (measured SLOWER on ROCm 7.2: 0.151 vs "
                          "0.139 ms dense, 0.079 vs 0.075 culled - graph kernel nodes cost more than the queue they replace)")
@@ -284,6 +287,11 @@ def main():
 
     def step(flags):
         rewards = rewards_buf
+        if shard is None and args.fused_step == "on":
+            # no collective between forward and backward: the whole step is ONE library call, four launches
+            rewards, scalars, pg, qg, _, _ = ops.traj_forward_backward(cloud, poses, quats, cam, ws, gout, rig=rig, flags=flags, lo_sum=lo_buf,
+                                                                       minmax=mm_buf, rewards=rewards)
+            return scalars, pg, qg, rewards
         lo_sum, minmax = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags, lo_sum=lo_buf, minmax=mm_buf, rewards_half=rewards)
         if shard is not None:
             shard.allreduce_sum(lo_sum)  # the one data-path collective: N floats over xGMI
@@ -371,7 +379,7 @@ def main():
         """Diagnostic, outside every timed region: the dense kernel's blocks stamp s_memrealtime (100 MHz) at their start and end
         (tohip_profile_clock); first start -> last end per XCD (each XCD has its own counter), the longest of the eight.
         rocprofv3 / HIP-event durations of back-to-back launches also contain the queueing behind the previous kernel."""
-        nb = L.tohip_profile_clock_blocks(cloud.n, n_virtual, flags)
+        nb = L.tohip_profile_clock_blocks(cloud.n, n_virtual, flags, 0)
         if nb <= 0:
             return None, None
         buf = torch.zeros(6 * nb, dtype=torch.int64, device=device)

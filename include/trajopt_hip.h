@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOHIP_ABI_VERSION 8
+#define TOHIP_ABI_VERSION 9
 
 #define TOHIP_OK 0
 #define TOHIP_EINVAL (-1)   /* bad size / null pointer */
@@ -169,6 +169,23 @@ int tohip_traj_reward_backward_multi(const void *packed, int64_t n_points, int64
                                      const uint32_t *occlusion_bits, const float *lo_sum, float eps, int prefilled, float *rewards,
                                      float *scalars, const float *gout, float *poses_grad, float *quats_grad, void *workspace,
                                      size_t workspace_bytes, void *stream);
+
+/* The whole step when NO collective sits between forward and backward (one GPU, or every rank holding all waypoints):
+ * tohip_traj_forward + tohip_traj_reward + tohip_traj_backward of the fused visibility loss in FOUR launches — records + probe,
+ * pass 1, one sparse kernel (log-odds, rewards, their sum, the gradient sums of the flagged pairs), the per-waypoint finish.
+ * Outputs as in the separate calls (lo_sum, minmax, rewards, scalars, poses_grad, quats_grad); gout = device pointer(s) to
+ * dL/d loss_vis.  rewards, scalars and lo_sum are bitwise those of the separate calls; the gradients agree to rounding (the
+ * dL/d reward factor is applied once per waypoint in f64 instead of once per point in f32).  replaces model.py:217-231,:237,:246
+ * and loss.backward() through them. */
+int tohip_traj_forward_backward(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
+                                const tohip_camera *cam_host, const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits,
+                                float *lo_sum, float *minmax, float *rewards, float *scalars, const float *gout,
+                                float *poses_grad, float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
+int tohip_traj_forward_backward_multi(const void *packed, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
+                                      const int32_t *traj_offsets, int64_t n_traj, const tohip_camera *cam_host,
+                                      const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits, float *lo_sum,
+                                      float *minmax, float *rewards, float *scalars, const float *gout, float *poses_grad,
+                                      float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- ModelTraj.forward() / loss.backward() as one call each ------------------------------------------
  * The reference's loop (trajectory_optimization.py:109-116) is `optimizer.zero_grad(); loss = model(); loss.backward();
@@ -407,11 +424,12 @@ int tohip_profile_enable(int on);
 const char *tohip_profile_name(int id);
 int tohip_profile_read(double *ms_sum_host, int64_t *counts_host);
 /* Diagnostic: while a device buffer is set, every block of k_traj_pass1 (the dense kernel) stores two 64-bit words — its
- * lifetime in shader-clock ticks (s_memtime) and in 100 MHz ticks (s_memrealtime) — at [2*block], capacity
- * tohip_profile_clock_blocks(n_points, n_virtual, flags) blocks; NULL switches it off.  Their quotient x 100 MHz is the clock
+ * lifetime in shader-clock ticks (s_memtime) and in 100 MHz ticks (s_memrealtime) — at [2*block], then four words per block
+ * (start, end, HW_ID, XCC_ID) from [2*grid]; grid = tohip_profile_clock_blocks(n_points, n_virtual, flags, with_occlusion) blocks
+ * (6 words each); NULL switches it off.  Their quotient x 100 MHz is the clock
  * the chip actually holds under this kernel (it gives clock back under load).  Never set during a timed pass. */
 int tohip_profile_clock(void *device_buffer);
-int64_t tohip_profile_clock_blocks(int64_t n_points, int64_t n_virtual, int flags);
+int64_t tohip_profile_clock_blocks(int64_t n_points, int64_t n_virtual, int flags, int with_occlusion);
 
 /* ---- self tests of cross-lane primitives (used by tests/, cheap) -------------------------------- */
 int tohip_selftest_wave_reduce(const float *in64xK, int32_t k, float *out_sum, float *out_min, float *out_max,

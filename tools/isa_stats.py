@@ -88,7 +88,7 @@ def main():
             json.dump(out, f, indent=1)
         print(json.dumps({k: out[k] for k in ("packed_f32", "transcendental", "other_valu", "salu_smem", "vmem")}))
         return
-    pats = args or ["k_traj_pass1_dense", "k_traj_pass1_cull", "k_traj_lo_sparse", "k_traj_bwd_sparse", "k_traj_select"]
+    pats = args or ["k_traj_pass1_dense", "k_traj_pass1_cull", "k_traj_sparse", "k_traj_finish", "k_traj_probe"]
     for name, (ins, loop, _) in ks.items():
         if not any(p in name for p in pats):
             continue

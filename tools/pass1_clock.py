@@ -12,7 +12,7 @@ p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
 ws = ops.TrajWorkspace(cloud, w)
 L = _lib.lib()
 for name, flags in (("dense", ops.DENSE),):
-    nb = L.tohip_profile_clock_blocks(n, w, flags)
+    nb = L.tohip_profile_clock_blocks(n, w, flags, 0)
     buf = torch.zeros(6 * nb, dtype=torch.int64, device=dev)
     t_end = time.time() + 2.0           # >= 2 s of back-to-back launches first (the guide's recipe)
     while time.time() < t_end:

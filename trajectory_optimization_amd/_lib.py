@@ -70,6 +70,11 @@ SIGNATURES = {
     "tohip_gather_waypoints_multi": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, ctypes.c_int, c_vp, c_vp, c_vp]),
     "tohip_traj_forward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig),
                                            ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_traj_forward_backward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig), ctypes.c_int,
+                                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_traj_forward_backward_multi": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, ctypes.POINTER(Camera),
+                                                          ctypes.POINTER(Rig), ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                          c_vp, c_sz, c_vp]),
     "tohip_traj_loss_scratch_bytes": (c_sz, [c_i64, c_i64, c_i32, c_i32]),
     "tohip_traj_loss_scratch_layout": (ctypes.c_int, [c_i64, c_i64, c_i32, c_i32, ctypes.POINTER(c_i64)]),
     "tohip_traj_loss_forward": (ctypes.c_int, [ctypes.POINTER(TrajLoss), c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -128,7 +133,7 @@ SIGNATURES = {
     "tohip_profile_name": (ctypes.c_char_p, [ctypes.c_int]),
     "tohip_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "tohip_profile_clock": (ctypes.c_int, [c_vp]),
-    "tohip_profile_clock_blocks": (c_i64, [c_i64, c_i64, ctypes.c_int]),
+    "tohip_profile_clock_blocks": (c_i64, [c_i64, c_i64, ctypes.c_int, ctypes.c_int]),
     "tohip_selftest_wave_reduce": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
 }
 
@@ -166,7 +171,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 8  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
+ABI_VERSION = 9  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
 ENOSPC = -2  # TOHIP_ENOSPC
 ENAN = -4    # TOHIP_ENAN
 

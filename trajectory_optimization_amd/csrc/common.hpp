@@ -431,23 +431,41 @@ __host__ __device__ inline void quat_to_R(const float q[4], float R[9]) {
 #define TO_L2E 1.4426950408889634
 
 // 128 bytes = two 64-byte lines per virtual waypoint; line 0 is all a plain evaluation reads (one s_load_dwordx16).
+// L and U are the probe's results: attained values of p (maximum and minimum over a sample of the cloud).  Pass 1 folds a
+// wave's (min, max) into the waypoint's running extrema (Extrema, integer atomics) only when it improves on them, which a
+// handful of waves per waypoint do, and lists a slot as a CANDIDATE when its maximum reaches Lh for some waypoint: with
+// min p = 0 (U == 0) a flagged pair has max >= M/2 (1 - 2^-22) > 0.49 M >= 0.49 L; while the minimum is unknown every slot is one.
 struct __attribute__((aligned(128))) WayRec {
     float t[3];    //  0..2   translation of the virtual waypoint
     float f0[3];   //  3..5
     float f1[3];   //  6..8
     float f2[3];   //  9..11
     float sp[3];   // 12..14
-    float a;       // 15      min_n p                      (k_select)
-    float invM;    // 16      1 / max_n (p - a)            (k_select)
-    float M;       // 17      max_n (p - a)
-    float L;       // 18      probe: an attained value of p (lower bound of the max); 0 = none
-    float thr1;    // 19      probe: squared-distance bound, d2 > thr1  =>  p < L/2  (+inf = never cull)
-    float sthr1;   // 20      sqrt(thr1), rounded up
-    float azero;   // 21      probe: 1 = a point with p == 0 was exhibited, hence min_n p == 0 exactly
+    float Lh;      // 15      0.49 L (0 while the minimum is not known to be zero): a slot whose maximum stays below it cannot be flagged
+    float L;       // 16      probe: max of p over the sample (a lower bound of the max)
+    float U;       // 17      probe: min of p over the sample (an upper bound of the min)
+    float thr1;    // 18      probe: squared-distance bound, d2 > thr1  =>  p < L/2  (+inf = never cull)
+    float sthr1;   // 19      sqrt(thr1), rounded up
+    float azero;   // 20      probe: 1 = U == 0, hence min_n p == 0 exactly (p is never negative)
+    float pad;     // 21
     float m[9];    // 22..30  m[3*i+j] = R[j][i]: c = m y (the gradient chain wants R)
     int seg;       // 31      trajectory the waypoint belongs to (several trajectories evaluated in one pass; else 0)
 };
 static_assert(sizeof(WayRec) == 128, "WayRec is two 64-byte lines");
+
+// Per-waypoint extrema of p as bit patterns (p >= +0: the integer order is the float order; a NaN sorts above +inf).
+// Initialised by the probe with (U, L), improved by pass 1 with atomicMin / atomicMax — order independent, hence
+// deterministic.  a = min p, M = max p - a, p_hat = (p - a) / M  (model.py:226-227).
+struct __attribute__((aligned(16))) Extrema {
+    int mn, mx;
+    int pad[2];
+};
+__device__ __forceinline__ void load_norm(const Extrema& e, float& a, float& pmax, float& M, float& invM) {
+    a = __builtin_bit_cast(float, e.mn);
+    pmax = __builtin_bit_cast(float, e.mx);
+    M = pmax - a;          // == max(p - a): rounding is monotone
+    invM = 1.0f / M;
+}
 
 struct EvalK {
     float eps, cw, ch, cd;
@@ -502,7 +520,8 @@ __device__ __forceinline__ float vis_p(const WayRec& r, const EvalK& k, float x,
     return S * E;
 }
 
-__device__ __forceinline__ f2 vis_p_pk(const WayRec& r, const EvalK& k, f2 x, f2 y, f2 z) {
+template <class Rec>
+__device__ __forceinline__ f2 vis_p_pk(const Rec& r, const EvalK& k, f2 x, f2 y, f2 z) {
     const f2 y0 = x - pk_splat(r.t[0]), y1 = y - pk_splat(r.t[1]), y2 = z - pk_splat(r.t[2]);
     const f2 g0 = pk_fma(pk_splat(r.f0[2]), y2, pk_fma(pk_splat(r.f0[1]), y1, pk_splat(r.f0[0]) * y0));
     const f2 g1 = pk_fma(pk_splat(r.f1[2]), y2, pk_fma(pk_splat(r.f1[1]), y1, pk_splat(r.f1[0]) * y0));
@@ -533,6 +552,46 @@ __device__ __forceinline__ void dvis_dy(const WayRec& r, const EvalK& k, float p
         const float w1 = fmaf(-q1, r.f2[i], r.f1[i]);
         const float dA = fmaf(s.rz, fmaf(s.av, w1, s.au * w0), k.cd * dk[i]);   // (dA/dy)/2
         g[i] = live ? p * fmaf(-c2, dA, oneS * r.f2[i]) : 0.0f;
+    }
+}
+
+// packed twins (two points per lane) of vis_p with its by-products and of dvis_dy: per element the operation sequence of the
+// scalar functions, so p compares equal (==) with what pass 1 saw
+struct VisGrad2 {
+    f2 y0, y1, y2, d0, d1, d2, g0, g1, rz, au, av, S;
+};
+
+template <class Rec>
+__device__ __forceinline__ f2 vis_p_pk_grad(const Rec& r, const EvalK& k, f2 x, f2 y, f2 z, VisGrad2& o) {
+    const f2 y0 = x - pk_splat(r.t[0]), y1 = y - pk_splat(r.t[1]), y2 = z - pk_splat(r.t[2]);
+    const f2 g0 = pk_fma(pk_splat(r.f0[2]), y2, pk_fma(pk_splat(r.f0[1]), y1, pk_splat(r.f0[0]) * y0));
+    const f2 g1 = pk_fma(pk_splat(r.f1[2]), y2, pk_fma(pk_splat(r.f1[1]), y1, pk_splat(r.f1[0]) * y0));
+    const f2 zz = pk_fma(pk_splat(r.f2[2]), y2, pk_fma(pk_splat(r.f2[1]), y1, pk_fma(pk_splat(r.f2[0]), y0, pk_splat(k.eps))));
+    const f2 d0 = y0 - pk_splat(r.sp[0]), d1 = y1 - pk_splat(r.sp[1]), d2 = y2 - pk_splat(r.sp[2]);
+    const f2 dd = pk_fma(d2, d2, pk_fma(d1, d1, d0 * d0));
+    const f2 rz = pk_rcp(zz);
+    const f2 au = pk_fma(g0, rz, pk_splat(-k.cw)), av = pk_fma(g1, rz, pk_splat(-k.ch));
+    const f2 A = pk_fma(av, av, pk_fma(au, au, dd * pk_splat(k.cd)));
+    const f2 E = f2{to_exp2(-A.x), to_exp2(-A.y)};
+    const f2 ea = pk_fma(zz, pk_splat(k.nl2e), pk_splat(k.l2e_eps));
+    const f2 S = pk_rcp(pk_splat(1.0f) + f2{to_exp2(ea.x), to_exp2(ea.y)});
+    o.y0 = y0; o.y1 = y1; o.y2 = y2; o.d0 = d0; o.d1 = d1; o.d2 = d2; o.g0 = g0; o.g1 = g1; o.rz = rz; o.au = au; o.av = av; o.S = S;
+    return S * E;
+}
+
+template <class Rec>
+__device__ __forceinline__ void dvis_dy_pk(const Rec& r, const EvalK& k, f2 p, const VisGrad2& s, f2 g[3]) {
+    const f2 q0 = s.g0 * s.rz, q1 = s.g1 * s.rz;
+    const f2 oneS = pk_splat(1.0f) - s.S;
+    const float c2 = 2.0f * 0.693147180559945f;
+    const f2 dk[3] = {s.d0, s.d1, s.d2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const f2 w0 = pk_fma(-q0, pk_splat(r.f2[i]), pk_splat(r.f0[i]));
+        const f2 w1 = pk_fma(-q1, pk_splat(r.f2[i]), pk_splat(r.f1[i]));
+        const f2 dA = pk_fma(s.rz, pk_fma(s.av, w1, s.au * w0), pk_splat(k.cd) * dk[i]);
+        const f2 gi = p * pk_fma(pk_splat(-c2), dA, oneS * pk_splat(r.f2[i]));
+        g[i] = f2{p.x > 0.0f ? gi.x : 0.0f, p.y > 0.0f ? gi.y : 0.0f};
     }
 }
 

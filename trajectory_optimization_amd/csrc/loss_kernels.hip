@@ -102,16 +102,15 @@ extern "C" int tohip_traj_loss_forward(const tohip_traj_loss* p, const float* po
         pev = pe; qev = qe;
     }
     const tohip_rig* rig = C > 1 || p->rig.rig_quats ? &p->rig : nullptr;
-    int rc = tohip_traj_forward(p->packed, p->n_points, pev, qev, l.n_eval, &p->cam, rig, p->flags, nullptr, lo, mm, rewards, p->workspace,
-                                p->workspace_bytes, st);
+    // probe, pass 1, k_traj_sparse<FUSED>: log-odds, rewards, their integer sum, the pair sums with unit upstream gradient
+    TrajStep s;
+    int rc = traj_step_init(s, p->packed, p->n_points, l.n_eval, 1, nullptr, &p->cam, rig, p->flags, nullptr, p->workspace, p->workspace_bytes, st, true);
     if (rc != TOHIP_OK) return rc;
-    // rewards, mean, visibility loss + the pair sums with unit upstream gradient: the first launch of tohip_traj_reward_backward
-    const FusedReward f{p->cam.eps, 1, rewards, scal};
-    rc = traj_backward_impl(p->packed, p->n_points, l.n_eval, 1, &p->cam, rig, p->flags, nullptr, lo, nullptr, scal, nullptr, nullptr, nullptr,
-                            p->workspace, p->workspace_bytes, st, &f, 1);
+    rc = traj_fused_forward(s, pev, qev, lo, mm, rewards);
     if (rc != TOHIP_OK) return rc;
+    // criterion: the scalars of the visibility term come out of the integer reward sum first
     k_traj_regularizers<<<1, TO_BLOCK, 0, st>>>(poses, p->poses0, (int)p->n_wps, p->smoothness_weight, p->traj_length_weight, p->cam.eps,
-                                                scal, loss_terms, reg, 0, nullptr, p->reg_terms);
+                                                scal, loss_terms, reg, 0, nullptr, p->reg_terms, s.acc, p->n_points, s.shift);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
@@ -123,15 +122,14 @@ extern "C" int tohip_traj_loss_backward(const tohip_traj_loss* p, const float* g
     if (p->scratch_bytes < l.total) return TOHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream_;
     char* sc = (char*)p->scratch;
-    float* lo = (float*)(sc + l.off_lo);
-    float* scal = (float*)(sc + l.off_sc);
     float* pge = (float*)(sc + l.off_pge);
     float* qge = (float*)(sc + l.off_qge);
     const float* reg = (const float*)(sc + l.off_reg);
     const tohip_rig* rig = C > 1 || p->rig.rig_quats ? &p->rig : nullptr;
-    const FusedReward f{p->cam.eps, 1, nullptr, scal};
-    const int rc = traj_backward_impl(p->packed, p->n_points, l.n_eval, 1, &p->cam, rig, p->flags, nullptr, lo, nullptr, scal, gout, pge, qge,
-                                      p->workspace, p->workspace_bytes, st, &f, 2);
+    TrajStep s;
+    int rc = traj_step_init(s, p->packed, p->n_points, l.n_eval, 1, nullptr, &p->cam, rig, p->flags, nullptr, p->workspace, p->workspace_bytes, st, false);
+    if (rc != TOHIP_OK) return rc;
+    rc = launch_finish(s, finish_post(s, 2, nullptr, gout, nullptr, p->cam.eps), pge, qge);
     if (rc != TOHIP_OK) return rc;
     const int n = (int)(p->n_wps * 4);
     k_traj_loss_grad<<<(n + 255) / 256, 256, 0, st>>>(pge, qge, reg, gout, (int)p->n_wps, (int)l.n_eval, p->wps_step, poses_grad, quats_grad);

@@ -132,9 +132,18 @@ __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_regularizers(const float* __restrict__ poses, const float* __restrict__ poses0, int W, float smooth_w,
                     float length_w, float eps, const float* __restrict__ scalars, float* __restrict__ loss_terms,
                     float* __restrict__ grad_poses, int accumulate, const float* __restrict__ state,
-                    float* __restrict__ grad_terms) {
+                    float* __restrict__ grad_terms, const RewardAcc* __restrict__ acc = nullptr, int64_t n_points = 0, int shift = 0) {
     __shared__ double lds[TO_BLOCK];
     __shared__ double sh[4];
+    if (acc != nullptr) {   // a fused step: the visibility scalars are still an integer sum (k_traj_sparse<FUSED>); `scalars` receives them
+        float* sc = const_cast<float*>(scalars);
+        if (threadIdx.x == 0) {
+            float out[4];
+            reward_scalars_from_a(acc, n_points, shift, eps, out);
+            sc[0] = out[0]; sc[1] = out[1]; sc[2] = out[2]; sc[3] = out[3];
+        }
+        __syncthreads();
+    }
     regularizers_block(poses, poses0, W, smooth_w, length_w, eps, scalars, loss_terms, grad_poses, accumulate, state,
                        grad_terms, lds, sh);
 }

@@ -3,42 +3,46 @@
 // Replaces the per-waypoint Python loop of /root/reference/src/model.py:217-231 (forward),
 // :237/:246 (rewards, visibility loss) and its torch-autograd backward (SURVEY.md §8a rows A-C,E,G).
 //
-// Every (point, waypoint) pair is evaluated ONCE, in pass 1, which only keeps the per-waypoint extrema; everything
-// after it works on the few pairs that can contribute:
+// Every (point, waypoint) pair is evaluated ONCE, in pass 1, which keeps the extrema only; everything after it works on
+// the few pairs that can contribute.  A step is FOUR launches:
 //
-//   k_traj_prep / k_traj_probe   waypoint records (WayRec, common.hpp); the probe (CULL mode) also samples the cloud
-//   k_traj_pass1                 p of every pair -> (min, max) per (waypoint, wave of 256 points)   the dense kernel
-//   k_traj_select                block per waypoint: a = min p, M = max (p - a); a (256-point slot, waypoint) pair
-//                                is FLAGGED when its maximum reaches p_hat >= 1/2 (or it holds an argmin point and
-//                                a > 0): only flagged pairs have a non-zero log-odds term or a gradient.  Flags in
-//                                both orientations, the list of flagged slots, the list of flagged pairs, and the
-//                                rows that hold the extrema (tie sets)
-//   k_traj_lo_sparse             block per flagged slot: log-odds of its flagged waypoints, summed in a fixed order
-//   k_traj_reward                rewards = sigmoid(lo_sum) in the caller's order, mean, visibility loss (one launch)
-//   k_traj_bwd_sparse            wave per flagged pair: the 14 gradient sums of its 256 points
-//   k_traj_bwd_finish            block per waypoint: partials in slot order (f64), argmin/argmax shares from the
-//                                recorded rows (deterministic: no float atomics), chain to (position, quaternion)
+//   k_traj_probe    block per waypoint: its record (WayRec, common.hpp), the extrema of p over a sample of the cloud
+//                   (attained values: L <= max p, U >= min p; CULL mode skips with them), and the reset of what the step
+//                   accumulates into (running extrema, flag rows, tie lists, the reward sum)
+//   k_traj_pass1    p of every pair -> (min, max) per (256-point slot, waypoint) in `part`, and the waypoint's running
+//                   extrema by integer atomicMin / atomicMax (order independent) from the few waves that improve on (U, L)
+//   k_traj_sparse   block per slot: which waypoints are FLAGGED for it — slot maximum reaches p_hat >= 1/2, or it holds an
+//                   argmin point while min p > 0: only flagged pairs have a non-zero log-odds term or a gradient — then the
+//                   log-odds of its 256 points over the flagged waypoints (fixed order), the rewards, their fixed-point sum,
+//                   and the 14 gradient sums of every flagged pair.  Packed f32 throughout (two points per register pair).
+//                   Three builds: FUSED (all of it: no collective between forward and backward), FWD (up to lo_sum: the
+//                   all-reduce of a waypoint-sharded run comes next), BWD (gradient sums from a complete lo_sum)
+//   k_traj_finish   block per waypoint: its flagged slots' partials in slot order (f64), argmin/argmax shares from the
+//                   recorded slots (deterministic: no float atomics), scale by dL/d reward, chain to (position, quaternion)
 //
-// About 0.7 % of the (slot, waypoint) pairs are flagged on the BASELINE workloads (1 M x 128: 3 546 of 500 224), so
-// the sparse kernels are launch-latency sized and pass 1 is the whole cost: ~N*16 B of HBM traffic per launch, bound
-// by VALU issue (26 FMA-class + 4 transcendental instructions per evaluation, common.hpp).
+// About 0.7 % of the (slot, waypoint) pairs are flagged on the BASELINE workloads (1 M x 128: 3 546 of 500 224); a dense
+// indoor cloud flags 10-20 %.  Pass 1 moves ~N*16 B per launch whatever W is and is bound by VALU issue (26 FMA-class + 4
+// transcendental instructions per evaluation, common.hpp); the sparse kernel costs in proportion to the flagged pairs.
 //
 // Data layout in HBM
 //   cloud     Morton-sorted SoA x|y|z (npad each) + permutation + one bounding sphere per 256 points
 //             (packed once, tohip_pack_cloud)                                          16 B/point
 //   WayRec    two 64-B lines per virtual waypoint; line 0 -> SGPRs by one s_load_dwordx16
+//   Extrema   16 B per virtual waypoint: (min p, max p) as integers
 //   lo_sum (sorted order) / rewards (original order)                                    4 B/point each
-//   part      [virtual waypoint][slot]: (min, max) of p over the 256 points of a wave       8 B
+//   part      [slot][virtual waypoint]: (min, max) of p over the slot's 256 points         8 B
+//   ft / fv   flag bits, [slot][waypoint word] (the backward of a split step reads its row) and [waypoint][slot word]
+//             (k_traj_finish walks it)
 //   bpart     [virtual waypoint][slot]: 14 gradient sums of a flagged pair                 64 B (written where flagged)
 //
 // Two evaluation modes with bitwise identical results:
 //   DENSE  pass 1 evaluates every (point, waypoint) pair (the streaming reference semantics; bench headline)
 //   CULL   pass 1 skips pairs that provably can neither be a waypoint's maximum nor be flagged: p <= 2^(-cd d2)
 //          bounds p by the squared distance d2 = |y - sp|^2; a wave tests its tile's bounding sphere against
-//          64 waypoints at once, then the per-point d2.  The bound is L/2 with L an attained value of p found by a
-//          strided probe, which also proves min p == 0 by exhibiting a zero (else that waypoint is searched densely).
+//          64 waypoints at once.  The bound is L/2; waypoints whose sample did not exhibit p == 0 (U > 0: the minimum
+//          is not known to be zero) are searched densely.
 //
-// The forward leaves its state (records, flags, lists) in the workspace; the backward reads it there: the workspace
+// The forward leaves its state (records, extrema, flags) in the workspace; the backward reads it there: the workspace
 // must not be touched between tohip_traj_forward and tohip_traj_backward of the same step.
 #include <algorithm>
 #include <cstdlib>
@@ -50,21 +54,55 @@
 #define TO_SLOT 256            // points per flag slot (= bounding-sphere tile)
 #define TO_TIE_CAP 7           // recorded slots per extremum and waypoint; more -> the finish kernel scans all slots
 #define TO_BWD_NSUM 14
+#define TO_SP_MAXW 1024        // flag words of one slot held in LDS by k_traj_sparse: at most 65 536 virtual waypoints
 
 // ---------------------------------------------------------------------------------------------
-// workspace control block
+// workspace control block, per trajectory: the sum of the rewards as integers.  Every reward enters as rn(r * 2^shift)
+// (exact for r in [1/2, 1): a reward is sigmoid of a non-negative log-odds sum), so the total is the same whatever kernel,
+// block or order added it up: scalars are bitwise reproducible across the fused and the split step.
+//   a[0..7]   k_traj_sparse<FUSED>: eight partial sums of r - 1/2 over the points it touches, one 128-byte line each
+//             (blockIdx & 7 picks one: an address takes ~90 atomics / us); cleared by the next k_traj_probe, read by
+//             k_traj_finish / the criterion kernel
+//   b         k_traj_reward: ONE word — the sum (bits 0..47), the blocks that met a NaN (48..55), the blocks that have
+//             arrived (56..63) — so that one relaxed atomic per block both adds and counts: the block whose add returns the
+//             last arrival has the total in hand.  Zero between launches (that block clears it).
+struct __attribute__((aligned(128))) RewardAcc {
+    struct __attribute__((aligned(128))) Line { long long sum; unsigned nan; unsigned pad[29]; } a[8];
+    struct __attribute__((aligned(128))) { unsigned long long word; unsigned long long pad[15]; } b;
+};
+static_assert(sizeof(RewardAcc) == 9 * 128, "RewardAcc is nine lines");
+#define TO_REWARD_BLOCKS 128   // arrivals and NaN marks are 8-bit fields
 
-// head of the workspace: k_traj_reward's accumulators, one 64-bit word per trajectory (arrivals | NaN marks | fixed-point
-// sum); zero between launches
+__host__ __device__ inline int reward_shift(int64_t n) {
+    int lg = 0;
+    while (((int64_t)1 << lg) < n) ++lg;
+    return 47 - lg;   // n * 2^shift <= 2^47: the sum stays below bit 48
+}
+__device__ __forceinline__ long long reward_fixed(float r, int shift) { return __double2ll_rn(ldexp((double)r, shift)); }
+// scalars[0] = mean(rewards), [1] = loss_vis = 1/(mean+eps) (model.py:246), [2] = d loss_vis / d reward_n, [3] reserved
+__device__ __forceinline__ void reward_scalars(long long total, bool anynan, int64_t n, int shift, float eps, float out[4]) {
+    const float mean = anynan ? __builtin_nanf("") : (float)(ldexp((double)total, -shift) / (double)n);
+    const float vis = 1.0f / (mean + eps);
+    out[0] = mean;
+    out[1] = vis;
+    out[2] = (float)(-(double)vis * (double)vis / (double)n);
+    out[3] = 0.f;
+}
+__device__ __forceinline__ void reward_scalars_from_a(const RewardAcc* acc, int64_t n, int shift, float eps, float out[4]) {
+    long long s = 0;
+    unsigned nan = 0;
+    for (int i = 0; i < 8; ++i) { s += acc->a[i].sum; nan |= acc->a[i].nan; }
+    reward_scalars((long long)n * (1ll << (shift - 1)) + s, nan != 0, n, shift, eps, out);   // the untouched points hold 1/2
+}
 
-struct TieRec {            // slots (ascending) whose max equals the waypoint's max / whose min equals its min (a > 0)
+struct TieRec {            // slots whose max equals the waypoint's max / whose min equals its min (a > 0), in arrival order
     int nmax, nmin;        // counts; > TO_TIE_CAP: overflow, scan every slot
     int maxrow[TO_TIE_CAP];
     int minrow[TO_TIE_CAP];
 };
 
 // ---------------------------------------------------------------------------------------------
-// virtual waypoint records: thread per virtual waypoint v = w*C + c.  F.normalize (model.py:53), rig composition
+// virtual waypoint records: v = w*C + c.  F.normalize (model.py:53), rig composition
 // R_v = R(qn_w) R(q_c), t_v = t_w + R(qn_w) l_c, then the three projection rows and the Gaussian's centre.
 
 // traj_off (optional): n_traj + 1 ascending body-waypoint offsets of several trajectories laid end to end
@@ -126,23 +164,8 @@ __device__ __forceinline__ void prep_wayrec(int v, const float* __restrict__ pos
         r.f2[kk] = (float)h2;
         r.sp[kk] = (float)((double)k.mean * s);
     }
-    r.a = 0.f; r.invM = 1.f; r.M = 1.f; r.L = 0.f; r.thr1 = INFINITY; r.sthr1 = INFINITY; r.azero = 0.f; r.seg = seg;
+    r.Lh = 0.f; r.L = 0.f; r.U = INFINITY; r.thr1 = INFINITY; r.sthr1 = INFINITY; r.azero = 0.f; r.pad = 0.f; r.seg = seg;
     rec[v] = r;
-}
-
-// clears what k_traj_select accumulates into (the slot-major flags)
-__device__ __forceinline__ void clear_select_state(unsigned long long* __restrict__ ft, int64_t ft_words) {
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = tid; i < ft_words; i += nth) ft[i] = 0ull;
-}
-
-__global__ void __launch_bounds__(256)
-k_traj_prep(const float* __restrict__ poses, const float* __restrict__ quats, int V, int C, const float* __restrict__ rig_q,
-            const float* __restrict__ rig_t, EvalK k, WayRec* __restrict__ rec, WayCold* __restrict__ cold,
-            unsigned long long* __restrict__ ft, int64_t ft_words, const int* __restrict__ traj_off, int n_traj) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < V) prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, rec, cold, traj_off, n_traj);
-    clear_select_state(ft, ft_words);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -192,12 +215,6 @@ __device__ __forceinline__ float4 wave_tile_bound(const CloudView& cv, int64_t b
     return b;
 }
 
-// squared distance of a world point from the Gaussian's centre of record r — the expression vis_p uses
-__device__ __forceinline__ float dist2_sp(const WayRec& r, float x, float y, float z) {
-    const float d0 = (x - r.t[0]) - r.sp[0], d1 = (y - r.t[1]) - r.sp[1], d2 = (z - r.t[2]) - r.sp[2];
-    return fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
-}
-
 // (tile, waypoint) liveness for 64 waypoints at once: lane l tests waypoint vc + l against the wave's tile; the ballot is
 // the set of waypoints whose sphere {d2 <= thr1} may reach the tile.  Waypoints without the probe's "min is zero" proof
 // always survive (they are searched densely).
@@ -206,12 +223,12 @@ __device__ __forceinline__ unsigned long long tile_survivors(const WayRec* __res
     bool ok = false;
     if (v < v1) {
         const float4* rp = reinterpret_cast<const float4*>(rec + v);
-        const float4 q0 = rp[0], q3 = rp[3], q4 = rp[4], q5 = rp[5];  // t0 t1 t2 f00 | sp0 sp1 sp2 a | invM M L thr1 | sthr1 azero ..
+        const float4 q0 = rp[0], q3 = rp[3], q4 = rp[4], q5 = rp[5];  // t0 t1 t2 f00 | sp0 sp1 sp2 Lh | L U thr1 sthr1 | azero ..
         const float d0 = (tb.x - q0.x) - q3.x, d1 = (tb.y - q0.y) - q3.y, d2 = (tb.z - q0.z) - q3.z;
         const float D2 = fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
-        const float thr = q4.w, sthr = q5.x;
+        const float thr = q4.z, sthr = q4.w;
         const float bound = fmaf(tb.w, fmaf(2.0f, sthr, tb.w), thr) * 1.00001f;  // (sthr + r)^2, rounded up
-        ok = (q5.y == 0.f) || !(D2 > bound);
+        ok = (q5.x == 0.f) || !(D2 > bound);
     }
     return __ballot(ok);
 }
@@ -223,23 +240,30 @@ __device__ inline void cull_bound(float tau, float inv_var, float* thr, float* s
 }
 
 // ---------------------------------------------------------------------------------------------
-// probe (CULL mode): block per virtual waypoint evaluates a strided sample of the sorted cloud.
-//   L     = max p over the sample  (a lower bound of the true max: an attained value of p)
-//   azero = some sample has p == 0 exactly  =>  min_n p == 0 (p is never negative)
-// The block first builds its waypoint's record (k_traj_prep's work: one launch less), and it is 1024 threads wide:
-// the samples are scattered single loads, so the kernel is as long as one thread's chain of them.
-// THREADS = 1024 for up to a few hundred waypoints (the shortest chain); 256 beyond (eight blocks to a CU instead of two: the
-// 1 024 waypoints of eight concurrent trajectories no longer queue).  Maximum and "some p is zero" do not depend on the order.
+// probe: block per virtual waypoint.  Builds the waypoint's record, evaluates a strided sample of the sorted cloud
+//   L = max p over the sample  (a lower bound of the true max: an attained value of p)
+//   U = min p over the sample  (an upper bound of the true min; U == 0  =>  min_n p == 0: p is never negative)
+// and resets what the step accumulates into: the waypoint's running extrema := (U, L), its tie lists, its row of the
+// waypoint-major flag bits, and (block 0) the trajectories' reward sums.
+// THREADS = 1024 for up to a few hundred waypoints (the samples are scattered single loads: the kernel is as long as one
+// thread's chain of them); 256 beyond (eight blocks to a CU instead of two: the 1 024 waypoints of eight concurrent
+// trajectories no longer queue).  Maximum and minimum do not depend on the order.
 template <int TO_PROBE_THREADS>
 __global__ void __launch_bounds__(TO_PROBE_THREADS)
 k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restrict__ quats, int C,
              const float* __restrict__ rig_q, const float* __restrict__ rig_t, EvalK k, WayRec* __restrict__ rec,
-             WayCold* __restrict__ cold, const uint32_t* __restrict__ occ, int64_t occw,
-             unsigned long long* __restrict__ ft, int64_t ft_words, const int* __restrict__ traj_off, int n_traj) {
-    __shared__ float smx[TO_PROBE_THREADS / 64];
-    __shared__ int szero[TO_PROBE_THREADS / 64];
+             WayCold* __restrict__ cold, Extrema* __restrict__ ext, TieRec* __restrict__ ties, const uint32_t* __restrict__ occ,
+             int64_t occw, unsigned long long* __restrict__ fv, int fv_words, RewardAcc* __restrict__ acc,
+             const int* __restrict__ traj_off, int* __restrict__ traj_off_ws, int n_traj, int* __restrict__ cand, int ncand_words) {
+    __shared__ float smx[TO_PROBE_THREADS / 64], smn[TO_PROBE_THREADS / 64];
     const int v = blockIdx.x, t = threadIdx.x;
-    clear_select_state(ft, ft_words);
+    for (int j = t; j < fv_words; j += TO_PROBE_THREADS) fv[(int64_t)v * fv_words + j] = 0ull;
+    for (int j = v * TO_PROBE_THREADS + t; j < ncand_words; j += gridDim.x * TO_PROBE_THREADS) cand[j] = 0;   // slot marks + the list's counter
+    if (v == 0) {
+        for (int j = t; j < n_traj * 8; j += TO_PROBE_THREADS) { acc[j >> 3].a[j & 7].sum = 0; acc[j >> 3].a[j & 7].nan = 0u; }
+        if (traj_off != nullptr)   // the calls that follow the forward (backward, finish) take no offsets: they read this copy
+            for (int j = t; j <= n_traj; j += TO_PROBE_THREADS) traj_off_ws[j] = traj_off[j];
+    }
     // the samples (a contiguous copy of every step-th sorted point, made at pack time) are requested first, the record is
     // built meanwhile
     constexpr int kBatch = 8, kRounds = TO_PROBE_MAX / (TO_PROBE_THREADS * kBatch);
@@ -253,8 +277,7 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
     if (t == 0) prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, rec, cold, traj_off, n_traj);
     __syncthreads();
     const WayRec r = rec[v];
-    float mx = 0.f;
-    int zero = 0;
+    float mx = 0.f, mn = INFINITY;
     for (int rd = 0; rd < kRounds; ++rd) {
         if (rd > 0) {
 #pragma unroll
@@ -270,29 +293,63 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
             if (sj < cv.nsamples) {
                 const float p = vis_p(r, k, px[j], py[j], pz[j]) * occ_one(occ, occw, v, (int64_t)sj * cv.sample_step);
                 mx = fmaxf(mx, p);
-                zero |= (p == 0.f);
+                mn = fminf(mn, p);
             }
         }
     }
-    for (int s = 32; s > 0; s >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, s)); zero |= __shfl_xor(zero, s); }
-    if ((t & 63) == 0) { smx[t >> 6] = mx; szero[t >> 6] = zero; }
+    for (int s = 32; s > 0; s >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, s)); mn = fminf(mn, __shfl_xor(mn, s)); }
+    if ((t & 63) == 0) { smx[t >> 6] = mx; smn[t >> 6] = mn; }
     __syncthreads();
     if (t == 0) {
-        for (int w = 1; w < TO_PROBE_THREADS / 64; ++w) { mx = fmaxf(mx, smx[w]); zero |= szero[w]; }
+        for (int w = 1; w < TO_PROBE_THREADS / 64; ++w) { mx = fmaxf(mx, smx[w]); mn = fminf(mn, smn[w]); }
+        if (!(mn <= mx)) { mx = 0.f; mn = INFINITY; }   // a NaN among the sampled p (fmax/fmin drop it): no usable bound
         float thr, sthr;
         cull_bound(0.5f * mx, k.inv_var, &thr, &sthr);   // d2 > thr  =>  p < L/2 <= M/2: neither the max nor flagged
+        rec[v].Lh = (mn == 0.f) ? 0.49f * mx : 0.f;
         rec[v].L = mx;
+        rec[v].U = mn;
         rec[v].thr1 = thr;
         rec[v].sthr1 = sthr;
-        rec[v].azero = zero ? 1.f : 0.f;
+        rec[v].azero = (mn == 0.f) ? 1.f : 0.f;
+        Extrema e;
+        e.mn = __builtin_bit_cast(int, mn);
+        e.mx = __builtin_bit_cast(int, mx);
+        e.pad[0] = e.pad[1] = 0;
+        ext[v] = e;
+        ties[v].nmax = 0;
+        ties[v].nmin = 0;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// pass 1: p of every (point, waypoint) pair of the block's tile -> per-wave (min, max).  grid = (point blocks, waypoint
-// tiles).  A lane owns 4 consecutive sorted points, a wave one 256-point slot; part[v * nslots + slot] = (min, max).
+// pass 1: p of every (point, waypoint) pair -> part[slot * V + v] = (min, max) over the slot's 256 points, and the
+// waypoint's running extrema.  Only a wave whose value improves on the probe's (U, L) issues an atomic: the number of
+// points above a 4 096-sample maximum is ~n/4096, in a few dozen slots per waypoint.
 
-#define TO_P 4   // points per lane: a wave is one slot (and one bounding-sphere tile)
+#define TO_P 4   // points per lane of the culled kernel: a wave is one slot (and one bounding-sphere tile)
+
+// What the lane holding a slot's (min, max) of waypoint v does with them besides storing them: a slot whose maximum reaches Lh is
+// a candidate (-> returns true; the common case is ONE compare), and only a candidate can improve on L; the minimum needs a look
+// only while the probe has not exhibited a zero (U != 0: a wave-uniform branch).
+__device__ __forceinline__ bool fold_extrema(Extrema* __restrict__ ext, int v, float mn, float mx, const WayRec& r) {
+    bool cand = false;
+    if (!(mx < r.Lh)) {
+        cand = true;
+        const int mxb = __builtin_bit_cast(int, mx);
+        if (mxb > __builtin_bit_cast(int, r.L)) atomicMax(&ext[v].mx, mxb);
+    }
+    const int Ub = __builtin_bit_cast(int, r.U);
+    if (Ub != 0) {
+        const int mnb = __builtin_bit_cast(int, mn);
+        if (mnb < Ub) atomicMin(&ext[v].mn, mnb);
+    }
+    return cand;
+}
+
+// a candidate slot enters the list k_traj_sparse walks, once (the exchange on its mark decides); arrival order
+__device__ __forceinline__ void list_candidate(int* __restrict__ cand, int* __restrict__ clist, int nslots, int slot) {
+    if (atomicExch(&cand[slot], 1) == 0) clist[atomicAdd(&cand[nslots], 1)] = slot;
+}
 
 __device__ __forceinline__ void pass1_eval(const EvalK& k, const WayRec& r, const float (&x)[TO_P], const float (&y)[TO_P],
                                            const float (&z)[TO_P], const float (&om)[TO_P], float& mn, float& mx) {
@@ -302,8 +359,8 @@ __device__ __forceinline__ void pass1_eval(const EvalK& k, const WayRec& r, cons
     mx = fmaxf(fmaxf(p0.x, p0.y), fmaxf(p1.x, p1.y));
 }
 
-// the log-odds vector starts from zero (k_traj_lo_sparse fills the flagged slots) and, when the caller asks for it, the rewards
-// vector from sigmoid(0) = 1/2 (k_traj_reward then only stores the others): done by whoever evaluates a point block's first waypoint
+// the log-odds vector starts from zero (k_traj_sparse fills the flagged slots) and, when the caller asks for it, the rewards
+// vector from sigmoid(0) = 1/2 (only the others are stored later): done by whoever evaluates a point block's first waypoint
 typedef float f4v __attribute__((ext_vector_type(4)));
 struct OutInit {   // n_traj log-odds vectors of npad floats (and rewards vectors of n floats) one after the other
     float* lo_zero;
@@ -330,11 +387,13 @@ __device__ __forceinline__ void init_outputs(int64_t base, const OutInit& o) {
 // instruction-level parallelism has to come from inside the wave), a wave two 256-point slots, a block 2048 points.  The
 // (point block, waypoint) pairs are one flat range cut into gridDim.x equal pieces: a block's piece is a run of consecutive
 // waypoints of one point block (seldom two), so every block does the same number of evaluations to within one waypoint, loads
-// its points once (twice), and all blocks end together: no dispatch order, no tail.
+// its points once (twice), and all blocks end together: no dispatch order, no tail.  A lane's (min, max) stores of consecutive
+// waypoints are adjacent in `part`.
 #define TO_PD 8
 template <bool OCC>
 __global__ void __launch_bounds__(TO_BLOCK)
-k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk, EvalK k, float2* __restrict__ part, int nslots,
+k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk, EvalK k, float2* __restrict__ part,
+                   Extrema* __restrict__ ext, int* __restrict__ cand, int* __restrict__ clist, int nslots,
                    const uint32_t* __restrict__ occ, int64_t occw, OutInit oi, unsigned long long* __restrict__ stamps) {
     constexpr int P = TO_PD;
     const int lane = threadIdx.x & 63;
@@ -359,6 +418,8 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
         float x[P], y[P], z[P];
         load_points<P>(cv.soa, cv.npad, base, x, y, z);
         if (v0 == 0) { init_outputs(base, oi); init_outputs(base + 4, oi); }
+        float2* prow = part + (int64_t)slot * V;
+        bool is_cand = false;
         for (int v = v0; v < v1; ++v) {
             const int64_t uu = u + (v - v0);
             if (uu == q1) __builtin_amdgcn_s_setprio(2);
@@ -375,18 +436,22 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
             float mx = fmaxf(fmaxf(fmaxf(p[0].x, p[0].y), fmaxf(p[1].x, p[1].y)), fmaxf(fmaxf(p[2].x, p[2].y), fmaxf(p[3].x, p[3].y)));
             mn = half_min31_nn_fused(mn);
             mx = half_max31_nn_fused(mx);
-            if ((lane & 31) == 31) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
+            if ((lane & 31) == 31) {
+                prow[v] = make_float2(mn, mx);
+                is_cand |= fold_extrema(ext, v, mn, mx, r);
+            }
         }
+        if (is_cand) list_candidate(cand, clist, nslots, slot);
         u += v1 - v0;
     }
     if (stamps != nullptr && threadIdx.x == 0) {
         stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st0;
         stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
-        unsigned long long* ext = stamps + 2 * (int64_t)gridDim.x + 4 * (int64_t)blockIdx.x;   // where and when the block ran
+        unsigned long long* ext_st = stamps + 2 * (int64_t)gridDim.x + 4 * (int64_t)blockIdx.x;   // where and when the block ran
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        ext[0] = sr0; ext[1] = __builtin_amdgcn_s_memrealtime(); ext[2] = hw; ext[3] = xcc;
+        ext_st[0] = sr0; ext_st[1] = __builtin_amdgcn_s_memrealtime(); ext_st[2] = hw; ext_st[3] = xcc;
     }
 }
 
@@ -395,7 +460,8 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
 // save once the tile is live.  The work sits in the few point blocks near the path, hence many short block rows.
 template <bool OCC>
 __global__ void __launch_bounds__(TO_BLOCK)
-k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile, EvalK k, float2* __restrict__ part, int nslots,
+k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile, EvalK k, float2* __restrict__ part,
+                  Extrema* __restrict__ ext, int* __restrict__ cand, int* __restrict__ clist, int nslots,
                   const uint32_t* __restrict__ occ, int64_t occw, OutInit oi) {
     constexpr int P = TO_P;
     const int lane = threadIdx.x & 63;
@@ -409,8 +475,10 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile
     const int v1 = min(V, v0 + vtile);
     const float4 tb = wave_tile_bound(cv, base);
     unsigned long long live = tile_survivors(rec, v0, v1, tb);
+    float2* prow = part + (int64_t)slot * V;
     // waypoints that cannot be affected from this tile: min is the proven 0, max unknown (-inf: never flagged)
-    if (v0 + lane < v1 && !((live >> lane) & 1ull)) part[(int64_t)(v0 + lane) * nslots + slot] = make_float2(0.f, -INFINITY);
+    if (v0 + lane < v1 && !((live >> lane) & 1ull)) prow[v0 + lane] = make_float2(0.f, -INFINITY);
+    bool is_cand = false;
     while (live) {
         const int v = v0 + __builtin_ctzll(live);
         live &= live - 1ull;
@@ -420,280 +488,361 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile
         pass1_eval(k, r, x, y, z, om, mn, mx);
         mn = wave_min63_nn_fused(mn);
         mx = wave_max63_nn_fused(mx);
-        if (lane == 63) part[(int64_t)v * nslots + slot] = make_float2(mn, mx);
+        if (lane == 63) {
+            prow[v] = make_float2(mn, mx);
+            is_cand |= fold_extrema(ext, v, mn, mx, r);
+        }
     }
+    if (is_cand) list_candidate(cand, clist, nslots, slot);
 }
 
 // ---------------------------------------------------------------------------------------------
-// select: block per virtual waypoint.
-//   sweep 1  a = min, pmax = max over the slot partials; M = pmax - a (== max(p - a): rounding is monotone)
-//   sweep 2  thread per 256-point slot: flagged when its maximum has p_hat >= 1/2 — the predicate the sparse kernels
-//            evaluate per point, applied to an attained value — or it holds an argmin point while a > 0 (that set carries
-//            gradient, model.py:226); the slots holding the extrema are recorded for the finish kernel.
-// Flags: fv[v][slot word] (finish kernel), ft[slot][v word] (forward); vlist[v][0..vcnt[v]) = the flagged slots of v
-// (backward).  Everything a block appends to is its own: the only global atomics are the ft bits, fire and forget.
+// sparse: 1024-thread blocks (16 waves) walk the list of candidate slots pass 1 made (6-8 % of the slots on the BASELINE
+// workloads; every slot of a dense indoor cloud).  Every wave holds the slot's 256 points (four consecutive points per lane, as
+// two packed pairs); the slot's flagged waypoints of a trajectory, in ascending order, go round-robin to the waves (rank & 15):
+// a fixed order that depends only on the flag set, which DENSE and CULL share.  The list's order is arrival order; a slot's
+// results do not depend on it.
+//   flags     lane per waypoint: the slot's (min, max) against the waypoint's final extrema — flagged when its maximum
+//             has p_hat >= 1/2 (the predicate applied per point below, on an attained value), or it holds an argmin point
+//             while a > 0 (that set carries gradient, model.py:226); a degenerate waypoint (max == min, or a NaN: the
+//             reference's 0/0 for EVERY point, model.py:227) flags every slot and adds NaN.  Slots holding an extremum
+//             enter the waypoint's tie list.  The flag words go to ft (row of this slot) and fv (bit of this slot).
+//   staging   what an evaluation reads of a flagged waypoint's record, with a and 1/M, goes to LDS in one parallel load per
+//             256 waypoints: a wave's chain is then arithmetic, not a scalar load per waypoint
+//   forward   p_hat = (p - a)/M, clip to [0.5, 1-eps], log-odds (model.py:226-231), summed per wave, the sixteen waves in
+//             order; unflagged pairs contribute exactly 0.  lo_sum[slot] is complete when the block is done with it:
+//   rewards   r = sigmoid(lo) to the caller's order (points with lo == 0 keep the prefilled 1/2), their sum as integers
+//   backward  per flagged pair: G = dL/dp_hat = g_n [0.5 <= p_hat <= 1-eps] / (p_hat (1 - p_hat)), dL/dp = G / M, plus
+//             the shares of the min/max points (S1 = sum G (p_hat - 1)/M -> argmin set, S2 = sum G (-p_hat)/M -> argmax
+//             set; torch splits them evenly among ties).  bpart[(v*nslots+slot)*16 ..]:
+//               [0..2] sum w gy   [3..11] sum w y (x) gy   [12] S1   [13] S2        (w = G/M, gy = dp/dy, y = x - t)
+//             per lane over its four points, then one DPP tree over the wave.  FUSED takes the sums with dL/d reward = 1
+//             (they are linear in it; k_traj_finish scales them once the mean of the rewards is known).
 
-#define TO_SELECT_FAST_SLOTS 4096   // up to this many slots (1 M points) a thread keeps its slots' partials in registers
-// TO_SELECT_THREADS = 1024 for up to a few hundred waypoints, 256 beyond (eight blocks to a CU instead of two); minima, maxima, flags
-// and the sorted tie rows do not depend on it
-template <bool FAST, int TO_SELECT_THREADS>
-__global__ void __launch_bounds__(TO_SELECT_THREADS)
-k_traj_select(const float2* __restrict__ part, int nslots, int V, WayRec* __restrict__ rec, int cull, float* __restrict__ minmax,
-              unsigned long long* __restrict__ fv, int fv_words, unsigned long long* __restrict__ ft, int vwords,
-              int* __restrict__ vlist, int* __restrict__ vcnt, TieRec* __restrict__ ties, float* __restrict__ lo_sum, int64_t npad,
-              int* __restrict__ sflag, int* __restrict__ slist, int64_t nmark, const int* __restrict__ toff, int C, float inv_var) {
-    __shared__ float smn[TO_SELECT_THREADS / 64], smx[TO_SELECT_THREADS / 64];
-    __shared__ float s_a, s_pmax;
-    __shared__ int s_nmax, s_nmin, s_npairs, s_maxrow[TO_TIE_CAP], s_minrow[TO_TIE_CAP];
-    const int v = blockIdx.x, t = threadIdx.x, lane = t & 63;
-    const float2* pv = part + (int64_t)v * nslots;
-    float mn = INFINITY, mx = -INFINITY;
-    bool nan = false;
-    constexpr int NQ = TO_SELECT_FAST_SLOTS / TO_SELECT_THREADS;
-    float2 q[NQ];   // FAST: thread t owns slots t, t + THREADS, ...: requested at once, kept for sweep 2
-    if constexpr (FAST) {
-#pragma unroll
-        for (int kk = 0; kk < NQ; ++kk) {
-            const int s = t + kk * TO_SELECT_THREADS;
-            q[kk] = s < nslots ? pv[s] : make_float2(INFINITY, -INFINITY);
-        }
-#pragma unroll
-        for (int kk = 0; kk < NQ; ++kk) {
-            mn = fminf(mn, q[kk].x);
-            mx = fmaxf(mx, q[kk].y);
-            nan |= (q[kk].y != q[kk].y);   // a NaN p wins the max in pass 1 (integer order): the reference's max() is NaN too
-        }
-    } else {
-        for (int s0 = 0; s0 < nslots; s0 += 4 * TO_SELECT_THREADS) {  // four loads in flight per thread
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int sidx = s0 + j * TO_SELECT_THREADS + t;
-                q[j] = sidx < nslots ? pv[sidx] : make_float2(INFINITY, -INFINITY);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                mn = fminf(mn, q[j].x);
-                mx = fmaxf(mx, q[j].y);
-                nan |= (q[j].y != q[j].y);
-            }
-        }
-    }
-    for (int s = 32; s > 0; s >>= 1) { mn = fminf(mn, __shfl_xor(mn, s)); mx = fmaxf(mx, __shfl_xor(mx, s)); }
-    nan = __any(nan);
-    if (lane == 0) { smn[t >> 6] = mn; smx[t >> 6] = nan ? __builtin_nanf("") : mx; }
-    if (t == 0) { s_nmax = 0; s_nmin = 0; s_npairs = 0; }
-    __syncthreads();
-    if (t < 64) {   // wave 0: the 16 wave results
-        float a = t < TO_SELECT_THREADS / 64 ? smn[t] : INFINITY, pm = t < TO_SELECT_THREADS / 64 ? smx[t] : -INFINITY;
-        bool anynan = pm != pm;
-        for (int s = 8; s > 0; s >>= 1) { a = fminf(a, __shfl_xor(a, s)); pm = fmaxf(pm, __shfl_xor(pm, s)); }
-        anynan = __any(anynan);
-        if (t == 0) {
-            float pmax = pm;
-            if (cull) pmax = fmaxf(pmax, rec[v].L);  // L is an attained value of p (defensive: its tile is never skipped)
-            if (anynan) pmax = __builtin_nanf("");
-            const float M = pmax - a;
-            rec[v].a = a;
-            rec[v].invM = 1.0f / M;
-            rec[v].M = M;
-            // the probe's bound has done its work (pass 1); from here on thr1 serves the sparse kernels: a point farther than this
-            // from the Gaussian's centre has p < a + M/2, i.e. p_hat < 1/2 — no log-odds, no gradient (a whole wave of such points
-            // is skipped).  Degenerate waypoints (NaN, M <= 0) keep every point.
-            float thr2 = INFINITY, sthr2 = INFINITY;
-            if (M > 0.f && M < INFINITY) cull_bound(a + 0.5f * M, inv_var, &thr2, &sthr2);
-            rec[v].thr1 = thr2;
-            rec[v].sthr1 = sthr2;
-            minmax[2 * v] = a;
-            minmax[2 * v + 1] = M;
-            s_a = a;
-            s_pmax = pmax;
-        }
-    }
-    __syncthreads();
-    const float a = s_a, pmax = s_pmax;
-    const float M = pmax - a, invM = 1.0f / M;
-    const bool amin = a > 0.f;
-    if (!(M > 0.f) || !(invM < INFINITY)) {
-        // max == min, or a NaN: the reference's p / max is 0/0 for EVERY point of this waypoint (model.py:227), so every
-        // log-odds sum is NaN.  Rare: this block stores it; k_traj_lo_sparse adds onto it.
-        const float nanv = __builtin_nanf("");
-        float* lo_t = lo_sum + (int64_t)rec[v].seg * npad;   // its trajectory's vector
-        for (int64_t i = t; i < npad; i += TO_SELECT_THREADS) lo_t[i] = nanv;
-    }
-    int* myl = vlist + (int64_t)v * nslots;
-    // the waypoint's trajectory and that trajectory's bits of this waypoint's flag word
-    const int seg = rec[v].seg;
-    unsigned long long seg_mask = ~0ull;
-    if (toff != nullptr) {
-        const int v_lo = toff[seg] * C, v_hi = toff[seg + 1] * C, w0 = (v >> 6) * 64;
-        if (w0 < v_lo) seg_mask &= ~0ull << (v_lo - w0);
-        if (v_hi - w0 < 64) seg_mask &= (1ull << (v_hi - w0)) - 1ull;
-    }
-    auto sweep2 = [&](const float2 qq, const int s0) {
-        const int s = s0 + t;
-        bool flag = false;
-        if (s < nslots) {
-            flag = ((qq.y - a) * invM >= 0.5f) | (amin & (qq.x == a));
-            if (qq.y == pmax && M > 0.f) { const int i = atomicAdd(&s_nmax, 1); if (i < TO_TIE_CAP) s_maxrow[i] = s; }
-            if (amin && qq.x == a) { const int i = atomicAdd(&s_nmin, 1); if (i < TO_TIE_CAP) s_minrow[i] = s; }
-        }
-        const unsigned long long b = __ballot(flag);
-        if (lane == 0 && (s0 + (t & ~63)) < nslots) fv[(int64_t)v * fv_words + ((s0 + t) >> 6)] = b;
-        if (b) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&s_npairs, __popcll(b));   // LDS: one reservation per wave
-            base = __shfl(base, 0);
-            bool first = false;
-            if (flag) {
-                myl[base + __popcll(b & ((1ull << lane) - 1ull))] = s;
-                // the slot's first flag (of any waypoint) puts it on the list k_traj_lo_sparse walks: a zero word before this bit
-                // is necessary, the exchange on the slot's own marker decides (other words, other blocks)
-                // (the word may hold other trajectories' bits: a zero word is only the cheap way out for the common case)
-                const unsigned long long old = atomicOr(&ft[(int64_t)s * vwords + (v >> 6)], 1ull << (v & 63));
-                if ((old & seg_mask) == 0ull) first = atomicExch(&sflag[(int64_t)seg * nslots + s], 1) == 0;
-            }
-            const unsigned long long fb = __ballot(first);
-            if (fb) {   // one counter update per wave
-                int at = 0;
-                if (lane == 0) at = atomicAdd(&sflag[nmark], __popcll(fb));
-                at = __shfl(at, 0);
-                if (first) {
-                    const int e = at + __popcll(fb & ((1ull << lane) - 1ull));
-                    slist[2 * e] = s; slist[2 * e + 1] = seg;
-                }
-            }
-        }
-    };
-    if constexpr (FAST) {
-#pragma unroll
-        for (int kk = 0; kk < NQ; ++kk)
-            if (kk * TO_SELECT_THREADS < nslots) sweep2(q[kk], kk * TO_SELECT_THREADS);
-    } else {
-        for (int s0 = 0; s0 < nslots; s0 += TO_SELECT_THREADS) sweep2(s0 + t < nslots ? pv[s0 + t] : make_float2(0.f, 0.f), s0);
-    }
-    __syncthreads();
-    if (t == 0) {
-        vcnt[v] = s_npairs;
-        // ascending slot order: the tie sums are added in a fixed order (insertion sort of <= 7 entries, in LDS)
-        const int na = min(s_nmax, TO_TIE_CAP), nb = min(s_nmin, TO_TIE_CAP);
-        for (int i = 1; i < na; ++i) {
-            const int x = s_maxrow[i];
-            int j = i - 1;
-            while (j >= 0 && s_maxrow[j] > x) { s_maxrow[j + 1] = s_maxrow[j]; --j; }
-            s_maxrow[j + 1] = x;
-        }
-        for (int i = 1; i < nb; ++i) {
-            const int x = s_minrow[i];
-            int j = i - 1;
-            while (j >= 0 && s_minrow[j] > x) { s_minrow[j + 1] = s_minrow[j]; --j; }
-            s_minrow[j + 1] = x;
-        }
-        int* tp = reinterpret_cast<int*>(ties + v);   // TieRec: nmax, nmin, maxrow[7], minrow[7]
-        tp[0] = s_nmax;
-        tp[1] = s_nmin;
-        for (int i = 0; i < TO_TIE_CAP; ++i) { tp[2 + i] = i < na ? s_maxrow[i] : 0; tp[2 + TO_TIE_CAP + i] = i < nb ? s_minrow[i] : 0; }
-    }
-}
+enum { TO_SP_FWD = 0, TO_SP_BWD = 1, TO_SP_FUSED = 2 };
+#define TO_SP_THREADS 1024
+#define TO_SP_WAVES (TO_SP_THREADS / 64)
+#define TO_SP_CW 4                      // flag words (x 64 waypoints) staged at a time
+#define TO_SP_STAGE (TO_SP_CW * 64)
 
-// ---------------------------------------------------------------------------------------------
-// sparse forward: block per flagged slot, 1024 threads = 256 points x 4 waypoint groups.  Group g takes the slot's flagged
-// waypoints of rank g, g+4, ... (ascending); the four partial sums are added in group order: a fixed summation order that
-// depends only on the flag set, which DENSE and CULL share.
-//   p_hat = (p - a)/M, clip to [0.5, 1-eps], log-odds (model.py:226-231); unflagged pairs contribute exactly 0.
+struct SparseArgs {
+    CloudView cv;
+    const WayRec* rec;
+    const Extrema* ext;
+    EvalK k;
+    const float2* part;
+    int V, nslots, vwords, fv_words;
+    const int* clist;            // candidate slots (pass 1), clist_n[0] of them
+    const int* clist_n;
+    unsigned long long* ft;
+    unsigned long long* fv;
+    TieRec* ties;
+    float* lo_sum;               // n_traj x npad; FWD / FUSED write the flagged slots, BWD reads
+    float* minmax;               // FWD / FUSED: (a, M) per virtual waypoint (block 0 writes it)
+    const uint32_t* occ;
+    int64_t occw;
+    const int* toff;
+    int n_traj, C;
+    float* rewards;              // FUSED: n_traj x n, caller's order
+    int prefilled;               // FUSED: rewards hold 1/2 everywhere
+    RewardAcc* acc;              // FUSED
+    int shift;
+    const float* grad_rewards;   // BWD upstream: dL/d rewards (n_traj x n, caller's order), or
+    const float* scalars;        //               scalars[4*traj+2] * gout[traj], or (all three NULL) 1
+    const float* gout;
+    float* bpart;
+};
 
-__device__ __forceinline__ float log_odds(const EvalK& k, const WayRec& r, float p) {
-    float ph = (p - r.a) * r.invM;
-    ph = __builtin_amdgcn_fmed3f(ph, 0.5f, k.clip_hi);
+// a flagged waypoint as the evaluations read it (LDS): line 0 of its record, its normalisation, its index
+struct __attribute__((aligned(16))) StagedWay {
+    float t[3], f0[3], f1[3], f2[3], sp[3];
+    float a, invM;
+    int v;
+    float pad[2];
+};
+static_assert(sizeof(StagedWay) == 80, "StagedWay is 20 floats");
+
+struct SparseLds {
+    unsigned long long sflag[TO_SP_MAXW];
+    StagedWay stage[TO_SP_STAGE];
+    float4 spart[TO_SP_WAVES][64];
+    int any[TO_SP_WAVES];
+};
+
+__device__ __forceinline__ f2 log_odds_pk(const EvalK& k, float a, float invM, f2 p) {
+    f2 ph = (p - pk_splat(a)) * pk_splat(invM);
+    ph = f2{__builtin_amdgcn_fmed3f(ph.x, 0.5f, k.clip_hi), __builtin_amdgcn_fmed3f(ph.y, 0.5f, k.clip_hi)};
     // log(ph/(1-ph)) as a difference of logs: exactly 0 at ph = 0.5
-    return (to_log2(ph) - to_log2(1.0f - ph)) * 0.693147180559945f;
+    const f2 om = pk_splat(1.0f) - ph;
+    return (f2{to_log2(ph.x), to_log2(ph.y)} - f2{to_log2(om.x), to_log2(om.y)}) * pk_splat(0.693147180559945f);
 }
 
-__global__ void __launch_bounds__(1024)
-k_traj_lo_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const unsigned long long* __restrict__ ft, int vwords,
-                 float* __restrict__ lo_sum, const uint32_t* __restrict__ occ, int64_t occw, const int* __restrict__ toff, int n_traj,
-                 int C, const int* __restrict__ slist, const int* __restrict__ nlisted) {
-    // blocks walk the list of flagged (slot, trajectory) pairs k_traj_select made (6 % of the slots on the BASELINE workloads; a block per SLOT
-    // spent 9 of its 13 us on 3 700 blocks that read their flag words and left, two 1024-thread blocks to a CU).  The list's
-    // order is arrival order; a slot's sum does not depend on it.  The sum is ADDED to what lo_sum holds: zero from
-    // pass 1, or the NaN k_traj_select stored everywhere for a degenerate waypoint (the reference divides 0/0 for every point
-    // then, model.py:227).  Several trajectories (toff: their n_traj + 1 body-waypoint offsets; C cameras each): each has its own vector and
-    // its own rank count, so its sum is the one a run of that trajectory alone produces.
-    __shared__ float spart[3][TO_SLOT];
-    const int pt = threadIdx.x & (TO_SLOT - 1), g = threadIdx.x >> 8;
-    const int nl = *nlisted;
-    // a list entry = (slot, trajectory): that trajectory's waypoints [v_lo, v_hi) only, its own log-odds vector — the trajectories
-    // of a slot run side by side, and nobody looks at a (slot, trajectory) pair without a flag
-    for (int li = blockIdx.x; li < nl; li += gridDim.x) {   // block-uniform
-        const int s = slist[2 * li], tr = slist[2 * li + 1];
-        const int v_lo = toff ? toff[tr] * C : 0, v_hi = toff ? toff[tr + 1] * C : 0x7fffffff;
-        const unsigned long long* fts = ft + (int64_t)s * vwords;
-        const int64_t i = (int64_t)s * TO_SLOT + pt;
-        const float x = cv.soa[i], y = cv.soa[cv.npad + i], z = cv.soa[2 * cv.npad + i];
-        float acc = 0.f;
-        int rank = 0;
-        for (int w = v_lo >> 6; w < vwords && w * 64 < v_hi; ++w) {
-            unsigned long long bits = fts[w];
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// one candidate slot; blockDim.x = TO_SP_THREADS.  Returns with every thread past its last use of the LDS.
+template <int MODE, bool OCC>
+__device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int acc_line, SparseLds& L) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const EvalK& k = a.k;
+    const int64_t base = (int64_t)slot * TO_SLOT + lane * 4;
+    float x[4], y[4], z[4];
+    load_points<4>(a.cv.soa, a.cv.npad, base, x, y, z);
+
+    // ---- flags of this slot, one word per 64 waypoints ----
+    unsigned long long mine = 0ull;
+    for (int w = wave; w < a.vwords; w += TO_SP_WAVES) {
+        unsigned long long word;
+        if constexpr (MODE == TO_SP_BWD) {
+            word = a.ft[(int64_t)slot * a.vwords + w];
+        } else {
+            const int v = w * 64 + lane;
+            bool flag = false;
+            if (v < a.V) {
+                const float2 q = a.part[(int64_t)slot * a.V + v];
+                float av, pmax, M, invM;
+                load_norm(a.ext[v], av, pmax, M, invM);
+                const bool amin = av > 0.f;
+                const bool degenerate = !(M > 0.f) || !(invM < INFINITY);
+                flag = ((q.y - av) * invM >= 0.5f) | (amin & (q.x == av)) | degenerate;
+                if (q.y == pmax && M > 0.f) { const int i = atomicAdd(&a.ties[v].nmax, 1); if (i < TO_TIE_CAP) a.ties[v].maxrow[i] = slot; }
+                if (amin && q.x == av) { const int i = atomicAdd(&a.ties[v].nmin, 1); if (i < TO_TIE_CAP) a.ties[v].minrow[i] = slot; }
+                if (flag) atomicOr(&a.fv[(int64_t)v * a.fv_words + (slot >> 6)], 1ull << (slot & 63));
+            }
+            word = __ballot(flag);
+            if (lane == 0) a.ft[(int64_t)slot * a.vwords + w] = word;
+        }
+        if (lane == 0) L.sflag[w] = word;
+        mine |= word;
+    }
+    if (lane == 0) L.any[wave] = mine != 0ull;
+    __syncthreads();
+    bool anyf = false;
+#pragma unroll
+    for (int w = 0; w < TO_SP_WAVES; ++w) anyf |= L.any[w] != 0;
+    if (!anyf) { __syncthreads(); return; }   // a candidate that is not flagged after all: lo_sum 0, rewards 1/2 (pass 1 wrote them)
+
+    for (int tr = 0; tr < a.n_traj; ++tr) {
+        // the trajectory's virtual waypoints [v_lo, v_hi): its own log-odds vector, rewards, sums and rank count, so that its
+        // results are the ones a run of that trajectory alone produces
+        const int v_lo = a.toff ? a.toff[tr] * a.C : 0, v_hi = a.toff ? a.toff[tr + 1] * a.C : a.V;
+        const int w_lo = v_lo >> 6, w_hi = min(a.vwords, (v_hi + 63) >> 6);
+        auto flagged = [&](int w) {
+            unsigned long long bits = uniform_u64(L.sflag[w]);
             if (w * 64 < v_lo) bits &= ~0ull << (v_lo - w * 64);
             if (v_hi - w * 64 < 64) bits &= (1ull << (v_hi - w * 64)) - 1ull;
-            while (bits) {
-                const int v = w * 64 + __builtin_ctzll(bits);
-                bits &= bits - 1ull;
-                if (((rank++) & 3) == g) {
-                    const WayRec& r = rec[v];
-                    // a wave (64 neighbouring points) none of whose points can reach p_hat = 1/2 adds exact zeros
-                    if (__any(!(dist2_sp(r, x, y, z) > r.thr1))) acc += log_odds(k, r, vis_p(r, k, x, y, z) * occ_one(occ, occw, v, i));
+            return bits;
+        };
+        bool any = false;
+        for (int w = w_lo; w < w_hi; ++w) any |= flagged(w) != 0ull;
+        if (!any) continue;   // block-uniform
+        const bool one_chunk = (w_hi - w_lo) <= TO_SP_CW;
+        // stage the flagged waypoints of words [wc, wc + CW): entry = rank inside the chunk; returns their number
+        auto stage_chunk = [&](int wc) {
+            int cnt = 0, my_rank = -1, my_v = -1;
+#pragma unroll
+            for (int j = 0; j < TO_SP_CW; ++j) {
+                const int w = wc + j;
+                const unsigned long long bits = w < w_hi ? flagged(w) : 0ull;
+                if ((t >> 6) == j && ((bits >> lane) & 1ull)) { my_rank = cnt + __popcll(bits & ((1ull << lane) - 1ull)); my_v = w * 64 + lane; }
+                cnt += __popcll(bits);
+            }
+            if (my_rank >= 0) {   // threads 0 .. 255: one flagged waypoint each
+                const WayRec& r = a.rec[my_v];
+                StagedWay sw;
+                for (int i = 0; i < 3; ++i) { sw.t[i] = r.t[i]; sw.f0[i] = r.f0[i]; sw.f1[i] = r.f1[i]; sw.f2[i] = r.f2[i]; sw.sp[i] = r.sp[i]; }
+                float pmax, M;
+                load_norm(a.ext[my_v], sw.a, pmax, M, sw.invM);
+                if (!(M > 0.f) || !(sw.invM < INFINITY)) sw.invM = __builtin_nanf("");   // degenerate: every log-odds is NaN (0/0 in the reference)
+                sw.v = my_v;
+                sw.pad[0] = sw.pad[1] = 0.f;
+                L.stage[my_rank] = sw;
+            }
+            __syncthreads();
+            return cnt;
+        };
+        float lo[4];
+        if constexpr (MODE != TO_SP_BWD) {
+            f2 acc0 = pk_splat(0.f), acc1 = pk_splat(0.f);
+            int rank0 = 0;
+            for (int wc = w_lo; wc < w_hi; wc += TO_SP_CW) {
+                const int cnt = stage_chunk(wc);
+                for (int e = ((wave - rank0) & (TO_SP_WAVES - 1)); e < cnt; e += TO_SP_WAVES) {   // rank0 + e == wave (mod 16)
+                    const StagedWay& r = L.stage[e];
+                    float om[4];
+                    load_occ<4, OCC>(a.occ, a.occw, r.v, base, om);
+                    const f2 p0 = vis_p_pk(r, k, f2{x[0], x[1]}, f2{y[0], y[1]}, f2{z[0], z[1]}) * f2{om[0], om[1]};
+                    const f2 p1 = vis_p_pk(r, k, f2{x[2], x[3]}, f2{y[2], y[3]}, f2{z[2], z[3]}) * f2{om[2], om[3]};
+                    // a degenerate waypoint (staged with 1/M = NaN) makes every log-odds NaN, whatever med3 does with one; else + 0
+                    const f2 poison = pk_splat(r.invM != r.invM ? __builtin_nanf("") : 0.f);
+                    acc0 = acc0 + (log_odds_pk(k, r.a, r.invM, p0) + poison);
+                    acc1 = acc1 + (log_odds_pk(k, r.a, r.invM, p1) + poison);
+                }
+                rank0 += cnt;
+                if (!one_chunk) __syncthreads();   // the stage is rewritten by the next chunk
+            }
+            L.spart[wave][lane] = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
+            __syncthreads();
+            float4 s = L.spart[0][lane];
+#pragma unroll
+            for (int w = 1; w < TO_SP_WAVES; ++w) {
+                const float4 q = L.spart[w][lane];
+                s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+            }
+            lo[0] = s.x; lo[1] = s.y; lo[2] = s.z; lo[3] = s.w;
+            if (wave == 0) *reinterpret_cast<float4*>(a.lo_sum + (int64_t)tr * a.cv.npad + base) = s;
+        } else {
+            const float4 l4 = *reinterpret_cast<const float4*>(a.lo_sum + (int64_t)tr * a.cv.npad + base);
+            lo[0] = l4.x; lo[1] = l4.y; lo[2] = l4.z; lo[3] = l4.w;
+        }
+        if constexpr (MODE == TO_SP_FWD) { __syncthreads(); continue; }   // spart and the stage are free for the next trajectory
+
+        // ---- rewards of the slot's points, dL/d lo_sum_n ----
+        float gn[4];
+        {
+            const float coef = (MODE == TO_SP_BWD && a.scalars) ? a.scalars[4 * tr + 2] * a.gout[tr] : 1.0f;
+            int4 o4 = make_int4(0, 0, 0, 0);
+            if (MODE == TO_SP_FUSED ? wave == 0 : a.grad_rewards != nullptr) o4 = *reinterpret_cast<const int4*>(a.cv.perm + base);
+            const int o[4] = {o4.x, o4.y, o4.z, o4.w};
+            long long fsum = 0;
+            bool fnan = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float rw = to_rcp(1.0f + to_exp(-lo[j]));   // == k_traj_reward's value of rewards[perm[i]]
+                if (lo[j] != lo[j]) rw = lo[j];
+                const bool valid = base + j < a.cv.n;        // pads are not points
+                float gr = coef;
+                if (MODE == TO_SP_BWD && a.grad_rewards != nullptr) gr = valid ? a.grad_rewards[(int64_t)tr * a.cv.n + o[j]] : 0.f;
+                gn[j] = valid ? gr * rw * (1.0f - rw) : 0.f;
+                if (MODE == TO_SP_FUSED && wave == 0 && valid) {
+                    if (!a.prefilled || lo[j] != 0.f) a.rewards[(int64_t)tr * a.cv.n + o[j]] = rw;
+                    if (rw != rw) fnan = true;
+                    else fsum += reward_fixed(rw, a.shift) - (1ll << (a.shift - 1));
+                }
+            }
+            if (MODE == TO_SP_FUSED && wave == 0) {
+                for (int s = 32; s > 0; s >>= 1) fsum += __shfl_xor(fsum, s);
+                fnan = __any(fnan);
+                if (lane == 0) {
+                    if (fsum != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&a.acc[tr].a[acc_line].sum), (unsigned long long)fsum);
+                    if (fnan) atomicOr(&a.acc[tr].a[acc_line].nan, 1u);
                 }
             }
         }
-        if (g) spart[g - 1][pt] = acc;
-        __syncthreads();
-        if (!g) {
-            float* dst = lo_sum + (int64_t)tr * cv.npad + i;
-            *dst = *dst + (((acc + spart[0][pt]) + spart[1][pt]) + spart[2][pt]);
+
+        // ---- gradient sums of the flagged pairs ----
+        int rank0 = 0;
+        for (int wc = w_lo; wc < w_hi; wc += TO_SP_CW) {
+            int cnt;
+            if (MODE == TO_SP_FUSED && one_chunk) {   // still staged by the forward sweep
+                cnt = 0;
+                for (int w = w_lo; w < w_hi; ++w) cnt += __popcll(flagged(w));
+            } else {
+                cnt = stage_chunk(wc);
+            }
+            for (int e = ((wave - rank0) & (TO_SP_WAVES - 1)); e < cnt; e += TO_SP_WAVES) {
+                const StagedWay& r = L.stage[e];
+                const float av = r.a, invM = r.invM;
+                float om[4];
+                load_occ<4, OCC>(a.occ, a.occw, r.v, base, om);
+                f2 acc[TO_BWD_NSUM];
+#pragma unroll
+                for (int j = 0; j < TO_BWD_NSUM; ++j) acc[j] = pk_splat(0.f);
+                bool any_act = false;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    VisGrad2 vg;
+                    const f2 p = vis_p_pk_grad(r, k, f2{x[2 * h], x[2 * h + 1]}, f2{y[2 * h], y[2 * h + 1]}, f2{z[2 * h], z[2 * h + 1]}, vg) *
+                                 f2{om[2 * h], om[2 * h + 1]};
+                    const f2 ph = (p - pk_splat(av)) * pk_splat(invM);
+                    const bool act0 = (ph.x >= 0.5f) && (ph.x <= k.clip_hi), act1 = (ph.y >= 0.5f) && (ph.y <= k.clip_hi);
+                    if (act0 | act1) {
+                        f2 g[3];
+                        dvis_dy_pk(r, k, p, vg, g);
+                        const f2 G = f2{gn[2 * h], gn[2 * h + 1]} * pk_rcp(ph * (pk_splat(1.0f) - ph));
+                        f2 wgt = G * pk_splat(invM);
+                        wgt = f2{act0 ? wgt.x : 0.f, act1 ? wgt.y : 0.f};
+                        acc[12] = acc[12] + wgt * (ph - pk_splat(1.0f));
+                        acc[13] = acc[13] + (-wgt) * ph;
+                        const f2 w0 = wgt * g[0], w1 = wgt * g[1], w2 = wgt * g[2];
+                        acc[0] = acc[0] + w0; acc[1] = acc[1] + w1; acc[2] = acc[2] + w2;
+                        acc[3] = acc[3] + vg.y0 * w0; acc[4] = acc[4] + vg.y0 * w1; acc[5] = acc[5] + vg.y0 * w2;
+                        acc[6] = acc[6] + vg.y1 * w0; acc[7] = acc[7] + vg.y1 * w1; acc[8] = acc[8] + vg.y1 * w2;
+                        acc[9] = acc[9] + vg.y2 * w0; acc[10] = acc[10] + vg.y2 * w1; acc[11] = acc[11] + vg.y2 * w2;
+                        any_act = true;
+                    }
+                }
+                float sum[TO_BWD_NSUM];
+#pragma unroll
+                for (int j = 0; j < TO_BWD_NSUM; ++j) sum[j] = acc[j].x + acc[j].y;
+                if (__any(any_act)) {
+#pragma unroll
+                    for (int j = 0; j < TO_BWD_NSUM; ++j) sum[j] = wave_sum63(sum[j]);
+                }
+                if (lane == 63) {
+                    float4* dst = reinterpret_cast<float4*>(a.bpart + ((int64_t)r.v * a.nslots + slot) * 16);
+                    dst[0] = make_float4(sum[0], sum[1], sum[2], sum[3]);
+                    dst[1] = make_float4(sum[4], sum[5], sum[6], sum[7]);
+                    dst[2] = make_float4(sum[8], sum[9], sum[10], sum[11]);
+                    dst[3] = make_float4(sum[12], sum[13], 0.f, 0.f);   // the finish kernel adds all 16 columns of a row
+                }
+            }
+            rank0 += cnt;
+            __syncthreads();   // the stage (and spart) are free again
         }
-        __syncthreads();
     }
+    __syncthreads();   // the flag words are free for the block's next slot
+}
+
+// (a, M) per virtual waypoint for the caller (tohip_traj_forward's minmax output): block 0, before its first slot
+__device__ __forceinline__ void write_minmax(const SparseArgs& a) {
+    if (a.minmax == nullptr) return;
+    for (int v = threadIdx.x; v < a.V; v += blockDim.x) {
+        float av, pmax, M, invM;
+        load_norm(a.ext[v], av, pmax, M, invM);
+        a.minmax[2 * v] = av;
+        a.minmax[2 * v + 1] = M;
+    }
+}
+
+template <int MODE, bool OCC>
+__global__ void __launch_bounds__(TO_SP_THREADS) k_traj_sparse(SparseArgs a) {
+    __shared__ SparseLds L;
+    if (MODE != TO_SP_BWD && blockIdx.x == 0) write_minmax(a);
+    const int n = *a.clist_n;
+    for (int li = blockIdx.x; li < n; li += gridDim.x) sparse_slot<MODE, OCC>(a, a.clist[li], (int)(blockIdx.x & 7), L);
 }
 
 // ---------------------------------------------------------------------------------------------
 // rewards = sigmoid(lo_sum) (model.py:237) scattered back to the caller's point order, mean and
-// visibility loss (model.py:246).
-
-// f64 sum of one value per lane in a fixed order (xor butterfly); every lane gets the result
-__device__ __forceinline__ double wave_sum_double(double v) {
-    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
-    return v;
-}
-
+// visibility loss (model.py:246) — the split step (a collective sits between forward and backward) and callers that hand
+// in a log-odds vector of their own.
 // One launch, thread per PACKED position: lo_sum and the permutation are read coalesced, the reward goes to the caller's
 // order with a scattered 4-byte store — which is skipped for the points whose log-odds is exactly 0 when the caller says the
 // rewards vector already holds sigmoid(0) = 1/2 everywhere (`prefilled`: tohip_traj_forward's rewards_half output; 98 % of the
-// points on the BASELINE workloads).
-// The mean needs one more dependent step only: every block adds ONE 64-bit word to an accumulator — its f64 partial as a
-// fixed-point integer (bits 0..47), a NaN mark (bits 48..55) and its arrival (bits 56..63).  Integer addition commutes, so the
-// total does not depend on the arrival order; the block whose add returns the last arrival has the complete sum in hand
-// (returned value + its own word) and writes the scalars.  The fixed-point step is 2^-shift with shift = 47 - ceil(log2 n): at
-// most 128 roundings of 2^-(shift+1) on a sum of >= n/2 (1 M points: 5e-13 relative).  acc: zero before and after the launch.
-#define TO_REWARD_THREADS 1024
-#define TO_REWARD_BLOCKS 128
-// block bx of nbx of trajectory `traj` (its own log-odds vector, rewards vector, accumulator word and scalars)
+// points on the BASELINE workloads).  Every block adds its integer sum to the trajectory's accumulator; the block whose
+// arrival completes the count has the total (integer addition commutes: no dependence on the order), writes the scalars and
+// clears the accumulator for the next launch.
+// block bx of nbx of trajectory `traj` (its own log-odds vector, rewards vector, accumulator and scalars); blockDim.x = 1024
 __device__ __forceinline__ void reward_block(const float* __restrict__ lo_sum, const int* __restrict__ perm, int64_t n, int64_t npad, float eps,
-                                             int shift, int prefilled, float* __restrict__ rewards, unsigned long long* __restrict__ acc,
-                                             float* __restrict__ scalars, int bx, int nbx, int traj, double* lds) {
+                                             int shift, int prefilled, float* __restrict__ rewards, RewardAcc* __restrict__ acc,
+                                             float* __restrict__ scalars, int bx, int nbx, int traj, long long* lds) {
     lo_sum += (int64_t)traj * npad;
     rewards += (int64_t)traj * n;
     acc += traj;
     scalars += 4 * traj;
-    double s = 0.0;
-    const int64_t stride = (int64_t)nbx * TO_REWARD_THREADS * 4;
-    for (int64_t i0 = ((int64_t)bx * TO_REWARD_THREADS + threadIdx.x) * 4; i0 < n; i0 += stride) {
+    long long s = 0;
+    bool anynan = false;
+    const long long half = 1ll << (shift - 1);
+    const int64_t stride = (int64_t)nbx * TO_SP_THREADS * 4;
+    for (int64_t i0 = ((int64_t)bx * TO_SP_THREADS + threadIdx.x) * 4; i0 < n; i0 += stride) {
         const float4 lo4 = *reinterpret_cast<const float4*>(lo_sum + i0);   // npad is a multiple of 2048: aligned, in bounds
         const float lo[4] = {lo4.x, lo4.y, lo4.z, lo4.w};
         const bool all0 = (lo4.x == 0.f) & (lo4.y == 0.f) & (lo4.z == 0.f) & (lo4.w == 0.f);
-        if (prefilled && all0) {
-            // sigmoid(0) evaluated as below is exactly 0.5: rcp(1 + 1)
-            const int cnt = (int)min((int64_t)4, n - i0);
-            s += 0.5 * (double)cnt;
+        if (all0 && prefilled) {   // sigmoid(0) evaluated as below is exactly 0.5
+            s += half * min((int64_t)4, n - i0);
             continue;
         }
         const int4 o4 = *reinterpret_cast<const int4*>(perm + i0);
@@ -704,141 +853,52 @@ __device__ __forceinline__ void reward_block(const float* __restrict__ lo_sum, c
                 float r = to_rcp(1.0f + to_exp(-lo[j]));
                 if (lo[j] != lo[j]) r = lo[j];  // a degenerate waypoint (max == min) makes the reference's rewards NaN: propagate
                 if (!prefilled || lo[j] != 0.f) rewards[o[j]] = r;
-                s += (double)r;
+                if (r != r) anynan = true;
+                else s += reward_fixed(r, shift);
             }
         }
     }
-    const double tot = block_sum_double(s, lds);
+    for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+    anynan = __any(anynan);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { lds[wave] = s; lds[TO_SP_WAVES + wave] = anynan ? 1ll : 0ll; }
+    __syncthreads();
     if (threadIdx.x != 0) return;
-    const bool isnan_ = tot != tot;
-    const unsigned long long fixed = isnan_ ? 0ull : (unsigned long long)__double2ll_rn(ldexp(tot, shift));
-    const unsigned long long word = (1ull << 56) | (isnan_ ? (1ull << 48) : 0ull) | fixed;
-    const unsigned long long old = __hip_atomic_fetch_add(acc, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    long long tot = 0;
+    bool nan_ = false;
+    for (int w = 0; w < TO_SP_WAVES; ++w) { tot += lds[w]; nan_ |= lds[TO_SP_WAVES + w] != 0ll; }
+    const unsigned long long word = (1ull << 56) | (nan_ ? (1ull << 48) : 0ull) | ((unsigned long long)tot & 0xffffffffffffull);
+    const unsigned long long old = __hip_atomic_fetch_add(&acc->b.word, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((int)(old >> 56) != nbx - 1) return;
     const unsigned long long all = old + word;
-    __hip_atomic_store(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-    const bool anynan = ((all >> 48) & 0xffull) != 0ull;
-    const double sum = ldexp((double)(all & 0xffffffffffffull), -shift);
-    const float mean = anynan ? __builtin_nanf("") : (float)(sum / (double)n);
-    const float vis = 1.0f / (mean + eps);
-    scalars[0] = mean;
-    scalars[1] = vis;
-    scalars[2] = (float)(-(double)vis * (double)vis / (double)n);
-    scalars[3] = 0.f;  // reserved; written so that callers need not clear the vector
+    __hip_atomic_store(&acc->b.word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    float out[4];
+    reward_scalars((long long)(all & 0xffffffffffffull), ((all >> 48) & 0xffull) != 0ull, n, shift, eps, out);
+    scalars[0] = out[0]; scalars[1] = out[1]; scalars[2] = out[2]; scalars[3] = out[3];
 }
 
-__global__ void __launch_bounds__(TO_REWARD_THREADS)
+__global__ void __launch_bounds__(TO_SP_THREADS)
 k_traj_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, int64_t n, int64_t npad, float eps, int shift, int prefilled,
-              float* __restrict__ rewards, unsigned long long* __restrict__ acc, float* __restrict__ scalars) {
-    __shared__ double lds[TO_REWARD_THREADS / 64];
+              float* __restrict__ rewards, RewardAcc* __restrict__ acc, float* __restrict__ scalars) {
+    __shared__ long long lds[2 * TO_SP_WAVES];
     reward_block(lo_sum, perm, n, npad, eps, shift, prefilled, rewards, acc, scalars, blockIdx.x, gridDim.x, blockIdx.y, lds);
 }
 
-// ---------------------------------------------------------------------------------------------
-// backward.  Per (point, waypoint): G = dL/dp_hat = g_n [0.5 <= p_hat <= 1-eps] / (p_hat (1 - p_hat)),
-// dL/dp = G / M, plus the shares of the min/max points (torch splits them evenly among ties):
-//   S1 = sum G (p_hat - 1)/M  -> argmin set,   S2 = sum G (-p_hat)/M -> argmax set.
-// Per flagged pair 14 sums, bpart[(v*nslots+slot)*16 ..]:
-//   [0..2] sum w gy   [3..11] sum w y (x) gy   [12] S1   [13] S2        (w = G/M, gy = dp/dy, y = x - t)
-
-#define TO_BWD_GX 8    // blocks per waypoint; wave (x, w) of a waypoint takes the flagged slots vlist[v][4x + w], [.. + 32], ...
-// One WAVE per flagged pair, four points per lane (point lane + 64 j of the slot): the 14 sums are added per lane over its four
-// points, then once across the wave (DPP tree, total in lane 63) — a quarter of the cross-lane work a 256-thread block with one
-// point per thread spent, no LDS and no block barrier.  A fixed order that depends on nothing but the pair.
-// wave wv of nwv of waypoint v.  scalars == NULL (and no grad_rewards): the sums are taken with dL/d reward = 1 and the finish kernel
-// scales them (they are linear in it) — so that this work does not have to wait for the mean of the rewards.
-__device__ __forceinline__ void bwd_pairs(const CloudView& cv, const WayRec* __restrict__ rec, const EvalK& k, const int* __restrict__ vlist,
-                                          const int* __restrict__ vcnt, int nslots, const float* __restrict__ lo_sum,
-                                          const float* __restrict__ grad_rewards, const float* __restrict__ scalars,
-                                          const float* __restrict__ gout, float* __restrict__ bpart, const uint32_t* __restrict__ occ,
-                                          int64_t occw, int v, int wv, int nwv) {
-    const int lane = threadIdx.x & 63;
-    const int npairs = vcnt[v];
-    if (wv >= npairs) return;
-    // the waypoint's trajectory: its log-odds vector, upstream gradient and loss scalars
-    const int seg = rec[v].seg;
-    lo_sum += (int64_t)seg * cv.npad;
-    if (grad_rewards) grad_rewards += (int64_t)seg * cv.n;
-    const float coef = grad_rewards ? 0.f : (scalars ? scalars[4 * seg + 2] * gout[seg] : 1.0f);
-    const WayRec& r = rec[v];
-    for (int it = wv; it < npairs; it += nwv) {
-        const int s = vlist[(int64_t)v * nslots + it];
-        float acc[TO_BWD_NSUM];
-#pragma unroll
-        for (int j = 0; j < TO_BWD_NSUM; ++j) acc[j] = 0.f;
-        bool any = false;
-#pragma unroll
-        for (int q = 0; q < TO_SLOT / 64; ++q) {
-            const int64_t i = (int64_t)s * TO_SLOT + q * 64 + lane;
-            const float x = cv.soa[i], y = cv.soa[cv.npad + i], z = cv.soa[2 * cv.npad + i];
-            const float lo_i = lo_sum[i];   // (npad floats per vector) requested with the coordinates, not after the distance test
-            if (!__any(!(dist2_sp(r, x, y, z) > r.thr1))) continue;   // none of these 64 points can reach p_hat = 1/2 (k_traj_select)
-            // dL/d lo_sum_n: through the caller's dL/d rewards vector (general criterion) or the fused visibility loss
-            float gn = 0.f;
-            if (i < cv.n) {
-                const float lo = lo_i;
-                float rw = to_rcp(1.0f + to_exp(-lo));  // == k_traj_reward's value of rewards[perm[i]]
-                if (lo != lo) rw = lo;
-                const float gr = grad_rewards ? grad_rewards[cv.perm[i]] : coef;
-                gn = gr * rw * (1.0f - rw);
-            }
-            VisGrad vg;
-            const float p = vis_p(r, k, x, y, z, &vg) * occ_one(occ, occw, v, i);
-            const float ph = (p - r.a) * r.invM;
-            const bool act = (ph >= 0.5f) && (ph <= k.clip_hi);
-            if (act) {
-                float g[3];
-                dvis_dy(r, k, p, vg, g);
-                const float G = gn * to_rcp(ph * (1.0f - ph));
-                const float wgt = G * r.invM;
-                acc[12] += wgt * (ph - 1.0f);
-                acc[13] += -wgt * ph;
-                const float w0 = wgt * g[0], w1 = wgt * g[1], w2 = wgt * g[2];
-                acc[0] += w0; acc[1] += w1; acc[2] += w2;
-                acc[3] += vg.y0 * w0; acc[4] += vg.y0 * w1; acc[5] += vg.y0 * w2;
-                acc[6] += vg.y1 * w0; acc[7] += vg.y1 * w1; acc[8] += vg.y1 * w2;
-                acc[9] += vg.y2 * w0; acc[10] += vg.y2 * w1; acc[11] += vg.y2 * w2;
-                any = true;
-            }
-        }
-        if (__any(any)) {
-#pragma unroll
-            for (int j = 0; j < TO_BWD_NSUM; ++j) acc[j] = wave_sum63(acc[j]);
-        }
-        if (lane == 63) {
-            float* dst = bpart + ((int64_t)v * nslots + s) * 16;
-#pragma unroll
-            for (int j = 0; j < TO_BWD_NSUM; ++j) dst[j] = acc[j];
-            dst[14] = 0.f; dst[15] = 0.f;   // the finish kernel adds all 16 columns of a row
-        }
-    }
-}
-
-__global__ void __launch_bounds__(TO_SLOT)
-k_traj_bwd_sparse(CloudView cv, const WayRec* __restrict__ rec, EvalK k, const int* __restrict__ vlist, const int* __restrict__ vcnt,
-                  int nslots, const float* __restrict__ lo_sum, const float* __restrict__ grad_rewards,
-                  const float* __restrict__ scalars, const float* __restrict__ gout, float* __restrict__ bpart,
-                  const uint32_t* __restrict__ occ, int64_t occw) {
-    bwd_pairs(cv, rec, k, vlist, vcnt, nslots, lo_sum, grad_rewards, scalars, gout, bpart, occ, occw, blockIdx.y,
-              blockIdx.x * (TO_SLOT / 64) + (threadIdx.x >> 6), gridDim.x * (TO_SLOT / 64));
-}
-
-// rewards + mean + loss (the first nbx * n_traj blocks) and the gradient sums with unit upstream gradient (the other blocks, 16
-// waves each = half a waypoint's 32) in ONE launch: both need the complete log-odds vector and nothing of each other.
-__global__ void __launch_bounds__(TO_REWARD_THREADS)
-k_traj_reward_bwd(const float* __restrict__ lo_sum, int64_t n, float eps, int shift, int prefilled, float* __restrict__ rewards,
-                  unsigned long long* __restrict__ acc, float* __restrict__ scalars, int nbx, int n_traj,
-                  CloudView cv, const WayRec* __restrict__ rec, EvalK k, const int* __restrict__ vlist, const int* __restrict__ vcnt,
-                  int nslots, float* __restrict__ bpart, const uint32_t* __restrict__ occ, int64_t occw, int V) {
-    __shared__ double lds[TO_REWARD_THREADS / 64];
-    const int R = nbx * n_traj;
+// rewards + mean + loss (the first nbx * n_traj blocks) and the gradient sums with unit upstream gradient (the other blocks:
+// k_traj_sparse<BWD>'s list walkers) in ONE launch: both need the complete log-odds vector and nothing of each other.
+template <bool OCC>
+__global__ void __launch_bounds__(TO_SP_THREADS)
+k_traj_reward_bwd(const float* __restrict__ lo_sum, int64_t n, float eps, int prefilled, float* __restrict__ rewards,
+                  float* __restrict__ scalars, int nbx, SparseArgs a) {
+    __shared__ SparseLds L;
+    const int R = nbx * a.n_traj;
     if ((int)blockIdx.x < R) {
-        reward_block(lo_sum, cv.perm, n, cv.npad, eps, shift, prefilled, rewards, acc, scalars, blockIdx.x % nbx, nbx, blockIdx.x / nbx, lds);
+        reward_block(lo_sum, a.cv.perm, n, a.cv.npad, eps, a.shift, prefilled, rewards, a.acc, scalars, blockIdx.x % nbx, nbx, blockIdx.x / nbx,
+                     reinterpret_cast<long long*>(L.sflag));
         return;
     }
-    const int64_t gw = ((int64_t)blockIdx.x - R) * (TO_REWARD_THREADS / 64) + (threadIdx.x >> 6);
-    const int v = (int)(gw >> 5);
-    if (v < V) bwd_pairs(cv, rec, k, vlist, vcnt, nslots, lo_sum, nullptr, nullptr, nullptr, bpart, occ, occw, v, (int)(gw & 31), 32);
+    const int nl = *a.clist_n, bid = (int)blockIdx.x - R, nb = (int)gridDim.x - R;
+    for (int li = bid; li < nl; li += nb) sparse_slot<TO_SP_BWD, OCC>(a, a.clist[li], bid & 7, L);
 }
 
 // thread per body waypoint: rig composition, dL/dt = -R sum dL/dc, dL/dR = sum y (x) dL/dc,
@@ -918,26 +978,60 @@ __global__ void k_bwd_finish2(const float* __restrict__ vgrad, const WayHot* __r
     if (w < W) finish_waypoint(w, vgrad, HotRows{hot}, cold, C, rig_q, rig_t, poses_grad, quats_grad);
 }
 
+
 // block per virtual waypoint: adds the partials of the flagged slots in 16 sums x 64 slot groups — group g takes the slots
 // s = g (mod 64), i.e. bit g of every flag word, in ascending order; the 64 group sums are then added in group order (double).
 // THREADS = 1024: a thread per (sum, group), the shortest chain (up to a few hundred waypoints).  THREADS = 256: a thread keeps
 // four groups (g, g + 16, g + 32, g + 48) — the same 64 sums in the same order, bit for bit — and eight blocks share a CU where
-// two 1024-thread blocks made the 1 024 waypoints of eight concurrent trajectories queue (32 -> 13 us) — and the shares of the extremal points: the rows recorded by k_traj_select are re-evaluated by
-// wave 0 in ascending row order with a fixed DPP tree, so the result does not depend on any arrival order (torch splits the
-// gradient of min()/max() evenly among ties, model.py:226-227).
+// two 1024-thread blocks made the 1 024 waypoints of eight concurrent trajectories queue (32 -> 13 us) — and the shares of the
+// extremal points: the slots recorded by k_traj_sparse (arrival order: sorted here) are re-evaluated by waves 0..3 in ascending
+// slot order with a fixed DPP tree, so the result does not depend on any arrival order (torch splits the gradient of min()/max()
+// evenly among ties, model.py:226-227).
 //   vgrad[v*12 ..] = (sum dL/dc [3], sum y (x) dL/dc [9]) with c = R^T y:  R^T gy,  (y (x) gy) R.
+// The sums of a FUSED step were taken with unit dL/d reward: post = 1 scales them by scalars[4*seg+2] * gout[seg] (scalars
+// written by k_traj_reward in the same step), post = 2 by the same factor computed here from the integer reward sum
+// (RewardAcc::a), which the first block of each trajectory also turns into that trajectory's scalars.
+struct FinishPost {
+    int mode;                  // 0: none   1: scalars + gout   2: acc + gout (+ scalars_out)
+    const float* scalars;
+    const float* gout;
+    const RewardAcc* acc;
+    float* scalars_out;
+    int64_t n;
+    int shift;
+    float eps;
+    const int* toff;
+    int C;
+};
+
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS)
-k_traj_bwd_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const unsigned long long* __restrict__ fv, int fv_words,
-                  const WayRec* __restrict__ rec, EvalK k, const TieRec* __restrict__ ties, const float2* __restrict__ part,
-                  const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ vgrad,
-                  const WayCold* __restrict__ cold, int single, float* __restrict__ poses_grad, float* __restrict__ quats_grad,
-                  const float* __restrict__ post_scalars, const float* __restrict__ post_gout) {
+k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const unsigned long long* __restrict__ fv, int fv_words,
+              const WayRec* __restrict__ rec, const Extrema* __restrict__ ext, EvalK k, const TieRec* __restrict__ ties,
+              const float2* __restrict__ part, int V, const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ vgrad,
+              const WayCold* __restrict__ cold, int single, float* __restrict__ poses_grad, float* __restrict__ quats_grad,
+              FinishPost post) {
     constexpr int NG = THREADS / 16, PER = 64 / NG;   // groups per pass, groups per thread
     __shared__ double sgrp[64][16];
     __shared__ double stie[2][13];   // [0] argmin set, [1] argmax set: 12 sums + count
+    __shared__ int srow[2][TO_TIE_CAP];
     const int v = blockIdx.x, t = threadIdx.x, kq = t & 15, g = t >> 4;
     const WayRec& r = rec[v];
+    float a, pmax, M, invM;
+    load_norm(ext[v], a, pmax, M, invM);
+    // the recorded tie slots in ascending order: the tie sums are added in a fixed order (insertion sort of <= 7 entries)
+    if (t < 2) {
+        const int* tp = reinterpret_cast<const int*>(ties + v);   // TieRec: nmax, nmin, maxrow[7], minrow[7]
+        const int cnt = min(t ? tp[0] : tp[1], TO_TIE_CAP);
+        const int* src = tp + 2 + (t ? 0 : TO_TIE_CAP);
+        int* dst = srow[t];
+        for (int i = 0; i < cnt; ++i) {
+            const int xv = src[i];
+            int j = i - 1;
+            while (j >= 0 && dst[j] > xv) { dst[j + 1] = dst[j]; --j; }
+            dst[j + 1] = xv;
+        }
+    }
     // the waypoint's flag words first (one parallel load), then each group's bit of every word
     __shared__ unsigned long long sfv[1024];
     double acc[PER];
@@ -960,10 +1054,10 @@ k_traj_bwd_finish(CloudView cv, const float* __restrict__ bpart, int nslots, con
     for (int j = 0; j < PER; ++j) sgrp[g + NG * j][kq] = acc[j];
     // ---- argmin / argmax sets: waves 0..3 take a quarter (64 points) of every recorded slot each ----
     __shared__ double stie4[2][4][13];
+    __syncthreads();   // srow
     if (t < 256) {
         const int wq = t >> 6, ln = t & 63;
-        const int* tp = reinterpret_cast<const int*>(ties + v);   // TieRec: nmax, nmin, maxrow[7], minrow[7]
-        const float a = r.a, M = r.M;
+        const int* tp = reinterpret_cast<const int*>(ties + v);
         for (int set = 0; set < 2; ++set) {
             const int cnt = set ? tp[0] : tp[1];
             double tot[13];
@@ -989,11 +1083,11 @@ k_traj_bwd_finish(CloudView cv, const float* __restrict__ bpart, int nslots, con
                 for (int j = 0; j < 13; ++j) tot[j] += (double)wave_sum63(gq[j]);  // valid in lane 63
             };
             if (cnt <= TO_TIE_CAP) {
-                for (int q = 0; q < cnt; ++q) do_slot(tp[2 + (set ? 0 : TO_TIE_CAP) + q]);
+                for (int q = 0; q < cnt; ++q) do_slot(srow[set][q]);
             } else {
                 // more slots hold the extremum than were recorded: walk every slot partial (rare: many exact duplicates)
                 for (int rr = 0; rr < nslots; ++rr) {
-                    const float2 q = part[(int64_t)v * nslots + rr];
+                    const float2 q = part[(int64_t)rr * V + v];
                     const bool hit = set ? (q.y - a == M) : (q.x == a);
                     if (hit) do_slot(rr);
                 }
@@ -1011,8 +1105,18 @@ k_traj_bwd_finish(CloudView cv, const float* __restrict__ bpart, int nslots, con
     if (t < 16) {
         double q = 0.0;
         for (int gg = 0; gg < 64; ++gg) q += sgrp[gg][t];
-        // sums taken with unit upstream gradient (k_traj_reward_bwd) get the trajectory's dL/d reward here: they are linear in it
-        if (post_scalars != nullptr) q *= (double)(post_scalars[4 * r.seg + 2] * post_gout[r.seg]);
+        // sums taken with unit upstream gradient get the trajectory's dL/d reward here: they are linear in it
+        if (post.mode == 1) q *= (double)(post.scalars[4 * r.seg + 2] * post.gout[r.seg]);
+        if (post.mode == 2) {
+            float sc[4];
+            reward_scalars_from_a(post.acc + r.seg, post.n, post.shift, post.eps, sc);
+            q *= (double)(sc[2] * post.gout[r.seg]);
+            const int v_first = post.toff ? post.toff[r.seg] * post.C : 0;
+            if (t == 0 && v == v_first && post.scalars_out) {
+                float* so = post.scalars_out + 4 * r.seg;
+                so[0] = sc[0]; so[1] = sc[1]; so[2] = sc[2]; so[3] = sc[3];
+            }
+        }
         stot[t] = q;
     }
     __syncthreads();
@@ -1179,14 +1283,12 @@ inline unsigned long long*& clock_stamps() { static unsigned long long* p = null
 
 struct TrajPlan {
     int64_t npad;
-    int nblk;      // pass-1 point blocks (1024 points each)
+    int nblk;      // culled pass-1 point blocks (1024 points each)
     int nslots;    // npad / 256
     int fv_words;  // (nslots + 63) / 64
     int vwords;    // (V + 63) / 64
     int V;
-    size_t off_ctl, off_rec, off_cold, off_part, off_fv, off_ft, off_sflag, off_slist, off_vcnt, off_vlist, off_ties, off_bpart, off_vgrad, total;
-    int64_t nmark;           // (trajectory, slot) markers = capacity of the pair list
-    int64_t ft_zero_words;   // ft and, right behind it, one int per slot ("listed") + the slot list's counter: cleared together
+    size_t off_ctl, off_toff, off_rec, off_cold, off_ext, off_cand, off_clist, off_part, off_fv, off_ft, off_ties, off_bpart, off_vgrad, total;
 };
 
 inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
@@ -1198,19 +1300,16 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
     p.vwords = (int)((V + 63) / 64);
     p.V = (int)V;
     size_t o = 0;
-    p.off_ctl = o;   o += align_up(sizeof(unsigned long long) * (size_t)(n_traj < 1 ? 1 : n_traj), 256);   // first: all tohip_traj_reward uses
+    p.off_ctl = o;   o += sizeof(RewardAcc) * (size_t)(n_traj < 1 ? 1 : n_traj);   // first: all tohip_traj_reward uses
+    p.off_toff = o;  o += align_up(sizeof(int) * (size_t)((n_traj < 1 ? 1 : n_traj) + 1), 256);   // the forward's copy of the trajectory offsets
     p.off_rec = o;   o += align_up((size_t)V * sizeof(WayRec), 256);
     p.off_cold = o;  o += align_up((size_t)W * sizeof(WayCold), 256);
+    p.off_ext = o;   o += align_up((size_t)V * sizeof(Extrema), 256);
+    p.off_cand = o;  o += align_up(((size_t)p.nslots + 1) * sizeof(int), 256);   // a mark per slot, then the candidate list's counter
+    p.off_clist = o; o += align_up((size_t)p.nslots * sizeof(int), 256);
     p.off_part = o;  o += align_up((size_t)V * (size_t)p.nslots * sizeof(float2), 256);
     p.off_fv = o;    o += align_up((size_t)V * (size_t)p.fv_words * sizeof(unsigned long long), 256);
-    p.off_ft = o;    o += (size_t)p.nslots * (size_t)p.vwords * sizeof(unsigned long long);
-    const size_t nmark = (size_t)p.nslots * (size_t)(n_traj < 1 ? 1 : n_traj);   // one marker per (trajectory, slot)
-    p.nmark = (int64_t)nmark;
-    p.off_sflag = o; o += align_up((nmark + 2) * sizeof(int), 256);   // [nmark] listed?  [nmark] = entries of slist
-    p.ft_zero_words = (int64_t)((o - p.off_ft) / sizeof(unsigned long long));
-    p.off_slist = o; o += align_up(nmark * 2 * sizeof(int), 256);     // (slot, trajectory) pairs
-    p.off_vcnt = o;  o += align_up((size_t)V * sizeof(int), 256);
-    p.off_vlist = o; o += align_up((size_t)V * (size_t)p.nslots * sizeof(int), 256);
+    p.off_ft = o;    o += align_up((size_t)p.nslots * (size_t)p.vwords * sizeof(unsigned long long), 256);
     p.off_ties = o;  o += align_up((size_t)V * sizeof(TieRec), 256);
     p.off_bpart = o; o += align_up((size_t)V * (size_t)p.nslots * 16 * sizeof(float), 256);
     p.off_vgrad = o; o += align_up((size_t)V * 12 * sizeof(float), 256);
@@ -1256,6 +1355,159 @@ inline int dense_blocks(int nblk, int V, bool occ) {
 
 inline int rig_cams(const tohip_rig* rig) { return (rig && rig->n_cams > 0 && rig->rig_quats) ? rig->n_cams : 1; }
 
+// everything the launches of one step share
+struct TrajStep {
+    hipStream_t st;
+    TrajPlan pl;
+    CloudView cv;
+    EvalK k;
+    int C;
+    int64_t n, W, V, n_traj;
+    const float *rq, *rt;
+    const int* toff;     // trajectory offsets (NULL: one trajectory)
+    int* toff_ws;        // their copy in the workspace: the calls after the forward take none
+    const uint32_t* occ;
+    int64_t occw;
+    bool cull;
+    RewardAcc* acc;
+    WayRec* rec;
+    WayCold* cold;
+    Extrema* ext;
+    int *cand, *clist;
+    float2* part;
+    unsigned long long *fv, *ft;
+    TieRec* ties;
+    float *bpart, *vgrad;
+    int shift;
+};
+
+inline int traj_step_init(TrajStep& s, const void* packed, int64_t n, int64_t W, int64_t n_traj, const int32_t* traj_offsets,
+                          const tohip_camera* cam, const tohip_rig* rig, int flags, const uint32_t* occ, void* workspace,
+                          size_t workspace_bytes, void* stream_, bool forward) {
+    if (!packed || !cam || !workspace || n <= 0 || W <= 0 || n_traj <= 0 || n_traj > 65535 || (forward && n_traj > 1 && !traj_offsets)) return TOHIP_EINVAL;
+    s.st = (hipStream_t)stream_;
+    s.C = rig_cams(rig);
+    s.n = n; s.W = W; s.V = W * s.C; s.n_traj = n_traj;
+    if (s.V > 64 * TO_SP_MAXW) return TOHIP_EINVAL;
+    s.pl = make_plan(n, s.V, W, n_traj);
+    if (workspace_bytes < s.pl.total) return TOHIP_ENOSPC;
+    char* ws = (char*)workspace;
+    s.acc = (RewardAcc*)(ws + s.pl.off_ctl);
+    s.rec = (WayRec*)(ws + s.pl.off_rec);
+    s.cold = (WayCold*)(ws + s.pl.off_cold);
+    s.ext = (Extrema*)(ws + s.pl.off_ext);
+    s.cand = (int*)(ws + s.pl.off_cand);
+    s.clist = (int*)(ws + s.pl.off_clist);
+    s.part = (float2*)(ws + s.pl.off_part);
+    s.fv = (unsigned long long*)(ws + s.pl.off_fv);
+    s.ft = (unsigned long long*)(ws + s.pl.off_ft);
+    s.ties = (TieRec*)(ws + s.pl.off_ties);
+    s.bpart = (float*)(ws + s.pl.off_bpart);
+    s.vgrad = (float*)(ws + s.pl.off_vgrad);
+    s.k = make_evalk(cam);
+    s.cv = cloud_view(packed, n);
+    s.cull = !(flags & TOHIP_TRAJ_DENSE);
+    s.rq = (s.C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
+    s.rt = s.rq ? rig->rig_trans : nullptr;
+    s.toff_ws = (int*)(ws + s.pl.off_toff);
+    s.toff = n_traj > 1 ? (forward ? traj_offsets : s.toff_ws) : nullptr;
+    s.occ = occ;
+    s.occw = s.cv.npad / 32;
+    s.shift = reward_shift(n);
+    return TOHIP_OK;
+}
+
+// launches 1 and 2 of a step: records + probe, pass 1
+inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float* quats, float* lo_sum, float* rewards_half) {
+    const int V = (int)s.V;
+    {
+        TO_PROF(TOHIP_PROF_SMALL, s.st);
+        if (V <= 512)
+            k_traj_probe<1024><<<V, 1024, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
+                                                     s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cand, s.pl.nslots + 1);
+        else
+            k_traj_probe<256><<<V, 256, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
+                                                   s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cand, s.pl.nslots + 1);
+        TO_HIP_CHECK_LAUNCH();
+    }
+    const OutInit oi{lo_sum, rewards_half, s.cv.npad, s.n, (int)s.n_traj};
+    {
+        TO_PROF(TOHIP_PROF_PASS1, s.st);
+        const bool occ = s.occ != nullptr;
+        if (s.cull) {
+            int vtile, ntiles;
+            cull_tiles(V, &vtile, &ntiles);
+            const dim3 grid(s.pl.nblk, ntiles);
+            if (occ) k_traj_pass1_cull<true><<<grid, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, vtile, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.occ, s.occw, oi);
+            else k_traj_pass1_cull<false><<<grid, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, vtile, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.occ, s.occw, oi);
+        } else {
+            const int nblk8 = (int)(s.pl.npad / (TO_BLOCK * TO_PD));
+            const int nb = dense_blocks(nblk8, V, occ);
+            if (occ) k_traj_pass1_dense<true><<<nb, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, nblk8, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.occ, s.occw, oi, clock_stamps());
+            else k_traj_pass1_dense<false><<<nb, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, nblk8, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.occ, s.occw, oi, clock_stamps());
+        }
+        TO_HIP_CHECK_LAUNCH();
+    }
+    return TOHIP_OK;
+}
+
+inline SparseArgs sparse_args(const TrajStep& s, float* lo_sum) {
+    SparseArgs a;
+    a.cv = s.cv; a.rec = s.rec; a.ext = s.ext; a.k = s.k; a.part = s.part;
+    a.V = (int)s.V; a.nslots = s.pl.nslots; a.vwords = s.pl.vwords; a.fv_words = s.pl.fv_words; a.clist = s.clist; a.clist_n = s.cand + s.pl.nslots;
+    a.ft = s.ft; a.fv = s.fv; a.ties = s.ties; a.lo_sum = lo_sum; a.minmax = nullptr; a.occ = s.occ; a.occw = s.occw;
+    a.toff = s.toff; a.n_traj = (int)s.n_traj; a.C = s.C;
+    a.rewards = nullptr; a.prefilled = 0; a.acc = s.acc; a.shift = s.shift;
+    a.grad_rewards = nullptr; a.scalars = nullptr; a.gout = nullptr; a.bpart = s.bpart;
+    return a;
+}
+
+// list walkers: the expected number of candidate slots on the workloads this is tuned for (6-8 % of the slots), each a chain
+// of its own; a dense cloud lists every slot and the blocks loop
+inline int sparse_blocks(const TrajStep& s) {
+    int64_t nb = std::min<int64_t>(s.pl.nslots, 512 * s.n_traj);
+    return (int)std::min<int64_t>(nb, 4096);
+}
+
+template <int MODE>
+inline int launch_sparse(const TrajStep& s, const SparseArgs& a) {
+    const int grid = sparse_blocks(s);
+    if (s.occ) k_traj_sparse<MODE, true><<<grid, TO_SP_THREADS, 0, s.st>>>(a);
+    else k_traj_sparse<MODE, false><<<grid, TO_SP_THREADS, 0, s.st>>>(a);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+inline int launch_finish(const TrajStep& s, const FinishPost& post, float* poses_grad, float* quats_grad) {
+    TO_PROF(TOHIP_PROF_SMALL, s.st);
+    const bool single = s.C == 1 && s.rq == nullptr;
+    const int V = (int)s.V;
+    if (V <= 512)
+        k_traj_finish<1024><<<V, 1024, 0, s.st>>>(s.cv, s.bpart, s.pl.nslots, s.fv, s.pl.fv_words, s.rec, s.ext, s.k, s.ties, s.part, V, s.occ, s.occw,
+                                                  s.vgrad, s.cold, single ? 1 : 0, poses_grad, quats_grad, post);
+    else
+        k_traj_finish<256><<<V, 256, 0, s.st>>>(s.cv, s.bpart, s.pl.nslots, s.fv, s.pl.fv_words, s.rec, s.ext, s.k, s.ties, s.part, V, s.occ, s.occw,
+                                                s.vgrad, s.cold, single ? 1 : 0, poses_grad, quats_grad, post);
+    TO_HIP_CHECK_LAUNCH();
+    if (!single) {
+        k_traj_bwd_finish2<<<(int)((s.W + 63) / 64), 64, 0, s.st>>>(s.vgrad, s.rec, s.cold, (int)s.W, s.C, s.rq, s.rt, poses_grad, quats_grad);
+        TO_HIP_CHECK_LAUNCH();
+    }
+    return TOHIP_OK;
+}
+
+inline FinishPost finish_post(const TrajStep& s, int mode, const float* scalars, const float* gout, float* scalars_out, float eps) {
+    FinishPost p;
+    p.mode = mode; p.scalars = scalars; p.gout = gout; p.acc = s.acc; p.scalars_out = scalars_out; p.n = s.n; p.shift = s.shift; p.eps = eps;
+    p.toff = s.toff; p.C = s.C;
+    return p;
+}
+
+inline int reward_blocks(int64_t n) {
+    int64_t nb = (n + 4 * TO_SP_THREADS - 1) / (4 * TO_SP_THREADS);
+    return (int)(nb > TO_REWARD_BLOCKS ? TO_REWARD_BLOCKS : nb);
+}
+
 }  // namespace
 
 extern "C" size_t tohip_traj_workspace_bytes_multi(int64_t n_points, int64_t n_virtual, int64_t n_traj) {
@@ -1270,94 +1522,16 @@ extern "C" int tohip_traj_forward_multi(const void* packed, int64_t n, const flo
                                         const int32_t* traj_offsets, int64_t n_traj, const tohip_camera* cam, const tohip_rig* rig,
                                         int flags, const uint32_t* occlusion_bits, float* lo_sum, float* minmax, float* rewards_half,
                                         void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!packed || !poses || !quats || !cam || !lo_sum || !minmax || !workspace || n <= 0 || W <= 0 || n_traj <= 0 || n_traj > 65535 ||
-        (n_traj > 1 && !traj_offsets))
-        return TOHIP_EINVAL;
-    hipStream_t st = (hipStream_t)stream_;
-    const int C = rig_cams(rig);
-    const int64_t V = W * C;
-    if (V > (1 << 24)) return TOHIP_EINVAL;
-    const TrajPlan pl = make_plan(n, V, W, n_traj);
-    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
-    char* ws = (char*)workspace;
-    WayRec* rec = (WayRec*)(ws + pl.off_rec);
-    WayCold* cold = (WayCold*)(ws + pl.off_cold);
-    float2* part = (float2*)(ws + pl.off_part);
-    unsigned long long* fv = (unsigned long long*)(ws + pl.off_fv);
-    unsigned long long* ft = (unsigned long long*)(ws + pl.off_ft);
-    int* vcnt = (int*)(ws + pl.off_vcnt);
-    int* vlist = (int*)(ws + pl.off_vlist);
-    TieRec* ties = (TieRec*)(ws + pl.off_ties);
-    const EvalK k = make_evalk(cam);
-    const CloudView cv = cloud_view(packed, n);
-    const bool cull = !(flags & TOHIP_TRAJ_DENSE);
-    const float* rq = (C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
-    const float* rt = rq ? rig->rig_trans : nullptr;
-    const int64_t ft_words = pl.ft_zero_words;   // the flag words and the slot list's markers + counter behind them
-    int* sflag = (int*)(ws + pl.off_sflag);
-    int* slist = (int*)(ws + pl.off_slist);
-    const int64_t occw = cv.npad / 32;
-    const int* toff = n_traj > 1 ? traj_offsets : nullptr;
-    const OutInit oi{lo_sum, rewards_half, cv.npad, n, (int)n_traj};
-
-    {
-        TO_PROF(TOHIP_PROF_SMALL, st);
-        if (cull) {
-            if (V <= 512)
-                k_traj_probe<1024><<<(int)V, 1024, 0, st>>>(cv, poses, quats, C, rq, rt, k, rec, cold, occlusion_bits, occw, ft, ft_words, toff,
-                                                            (int)n_traj);
-            else
-                k_traj_probe<256><<<(int)V, 256, 0, st>>>(cv, poses, quats, C, rq, rt, k, rec, cold, occlusion_bits, occw, ft, ft_words, toff,
-                                                          (int)n_traj);
-        } else {
-            int nb = (int)((V + 255) / 256);
-            const int want = (int)((ft_words + 255) / 256);
-            if (nb < want) nb = want > 256 ? 256 : want;
-            k_traj_prep<<<nb, 256, 0, st>>>(poses, quats, (int)V, C, rq, rt, k, rec, cold, ft, ft_words, toff, (int)n_traj);
-        }
-        TO_HIP_CHECK_LAUNCH();
-    }
-    {
-        TO_PROF(TOHIP_PROF_PASS1, st);
-        const bool occ = occlusion_bits != nullptr;
-        if (cull) {
-            int vtile, ntiles;
-            cull_tiles((int)V, &vtile, &ntiles);
-            const dim3 grid(pl.nblk, ntiles);
-            if (occ) k_traj_pass1_cull<true><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, oi);
-            else k_traj_pass1_cull<false><<<grid, TO_BLOCK, 0, st>>>(cv, rec, (int)V, vtile, k, part, pl.nslots, occlusion_bits, occw, oi);
-        } else {
-            const int nblk8 = (int)(pl.npad / (TO_BLOCK * TO_PD));
-            const int nb = dense_blocks(nblk8, (int)V, occ);
-            if (occ) k_traj_pass1_dense<true><<<nb, TO_BLOCK, 0, st>>>(cv, rec, (int)V, nblk8, k, part, pl.nslots, occlusion_bits, occw, oi, clock_stamps());
-            else k_traj_pass1_dense<false><<<nb, TO_BLOCK, 0, st>>>(cv, rec, (int)V, nblk8, k, part, pl.nslots, occlusion_bits, occw, oi, clock_stamps());
-        }
-        TO_HIP_CHECK_LAUNCH();
-    }
-    {
-        TO_PROF(TOHIP_PROF_SMALL, st);
-        const bool fast = pl.nslots <= TO_SELECT_FAST_SLOTS;
-        if (V <= 512) {
-            if (fast) k_traj_select<true, 1024><<<(int)V, 1024, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
-                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C, k.inv_var);
-            else k_traj_select<false, 1024><<<(int)V, 1024, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
-                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C, k.inv_var);
-        } else {
-            if (fast) k_traj_select<true, 256><<<(int)V, 256, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
-                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C, k.inv_var);
-            else k_traj_select<false, 256><<<(int)V, 256, 0, st>>>(part, pl.nslots, (int)V, rec, cull ? 1 : 0, minmax, fv, pl.fv_words, ft,
-                                                                      pl.vwords, vlist, vcnt, ties, lo_sum, cv.npad, sflag, slist, pl.nmark, toff, C, k.inv_var);
-        }
-        TO_HIP_CHECK_LAUNCH();
-    }
-    {
-        TO_PROF(TOHIP_PROF_PASS2, st);
-        const int64_t lob = std::min<int64_t>(pl.nmark, 512 * n_traj);   // blocks: the expected number of listed pairs, each a chain of its own
-        k_traj_lo_sparse<<<(int)std::min<int64_t>(lob, 4096), 1024, 0, st>>>(cv, rec, k, ft, pl.vwords, lo_sum, occlusion_bits, occw, toff, (int)n_traj, C,
-                                                                           slist, sflag + pl.nmark);
-        TO_HIP_CHECK_LAUNCH();
-    }
-    return TOHIP_OK;
+    if (!poses || !quats || !lo_sum || !minmax) return TOHIP_EINVAL;
+    TrajStep s;
+    int rc = traj_step_init(s, packed, n, W, n_traj, traj_offsets, cam, rig, flags, occlusion_bits, workspace, workspace_bytes, stream_, true);
+    if (rc != TOHIP_OK) return rc;
+    rc = launch_probe_pass1(s, poses, quats, lo_sum, rewards_half);
+    if (rc != TOHIP_OK) return rc;
+    TO_PROF(TOHIP_PROF_PASS2, s.st);
+    SparseArgs a = sparse_args(s, lo_sum);
+    a.minmax = minmax;
+    return launch_sparse<TO_SP_FWD>(s, a);
 }
 
 extern "C" int tohip_traj_forward(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
@@ -1372,16 +1546,12 @@ extern "C" int tohip_traj_reward_multi(const void* packed, const float* lo_sum, 
                                        float* rewards, float* scalars, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!packed || !lo_sum || !rewards || !scalars || !workspace || n <= 0 || n_traj <= 0 || n_traj > 65535) return TOHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
-    if (workspace_bytes < sizeof(unsigned long long) * (size_t)n_traj) return TOHIP_ENOSPC;
-    unsigned long long* acc = (unsigned long long*)workspace;   // TrajPlan::off_ctl == 0
+    if (workspace_bytes < sizeof(RewardAcc) * (size_t)n_traj) return TOHIP_ENOSPC;
+    RewardAcc* acc = (RewardAcc*)workspace;   // TrajPlan::off_ctl == 0
     const CloudView cv = cloud_view(packed, n);
-    int nb = (int)((n + 4 * TO_REWARD_THREADS - 1) / (4 * TO_REWARD_THREADS));
-    if (nb > TO_REWARD_BLOCKS) nb = TO_REWARD_BLOCKS;
-    int lg = 0;
-    while (((int64_t)1 << lg) < n) ++lg;
     TO_PROF(TOHIP_PROF_REWARD, st);
-    k_traj_reward<<<dim3(nb, (unsigned)n_traj), TO_REWARD_THREADS, 0, st>>>(lo_sum, cv.perm, n, cv.npad, eps, 47 - lg, prefilled ? 1 : 0, rewards,
-                                                                            acc, scalars);
+    k_traj_reward<<<dim3(reward_blocks(n), (unsigned)n_traj), TO_SP_THREADS, 0, st>>>(lo_sum, cv.perm, n, cv.npad, eps, reward_shift(n), prefilled ? 1 : 0,
+                                                                                 rewards, acc, scalars);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
@@ -1392,77 +1562,36 @@ extern "C" int tohip_traj_reward(const void* packed, const float* lo_sum, int64_
 }
 
 namespace {
-// backward of the step; with `fused` also the rewards, their mean and the loss scalars (tohip_traj_reward's work) in the
-// backward's first launch
+// backward of a split step (a complete lo_sum comes in); with `fused` also the rewards, their mean and the loss scalars
+// (tohip_traj_reward's work) in the backward's first launch.  phases: 1 = the pair sums (with `fused`: + rewards), 2 = the finish.
 struct FusedReward { float eps; int prefilled; float* rewards; float* scalars; };
 int traj_backward_impl(const void* packed, int64_t n, int64_t W, int64_t n_traj, const tohip_camera* cam,
-                       const tohip_rig* rig, int flags, const uint32_t* occlusion_bits, const float* lo_sum,
+                       const tohip_rig* rig, int flags, const uint32_t* occlusion_bits, float* lo_sum,
                        const float* grad_rewards, const float* scalars, const float* gout, float* poses_grad,
-                       float* quats_grad, void* workspace, size_t workspace_bytes, void* stream_, const FusedReward* fused,
-                       int phases = 3 /* 1: the pair sums (with `fused`: + rewards, mean, loss scalars); 2: the finish kernels */) {
-    if (!packed || !cam || !lo_sum || ((phases & 2) && (!poses_grad || !quats_grad)) || !workspace || n <= 0 || W <= 0 || n_traj <= 0 ||
-        (!grad_rewards && (!scalars || ((phases & 2) && !gout))) || n_traj > 65535)
-        return TOHIP_EINVAL;
-    const float* fused_scalars = fused ? scalars : nullptr;
-    hipStream_t st = (hipStream_t)stream_;
-    const int C = rig_cams(rig);
-    const int64_t V = W * C;
-    const TrajPlan pl = make_plan(n, V, W, n_traj);
-    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
-    char* ws = (char*)workspace;
-    WayRec* rec = (WayRec*)(ws + pl.off_rec);
-    WayCold* cold = (WayCold*)(ws + pl.off_cold);
-    float2* part = (float2*)(ws + pl.off_part);
-    unsigned long long* fv = (unsigned long long*)(ws + pl.off_fv);
-    const int* vcnt = (const int*)(ws + pl.off_vcnt);
-    const int* vlist = (const int*)(ws + pl.off_vlist);
-    TieRec* ties = (TieRec*)(ws + pl.off_ties);
-    float* bpart = (float*)(ws + pl.off_bpart);
-    float* vgrad = (float*)(ws + pl.off_vgrad);
-    const EvalK k = make_evalk(cam);
-    const CloudView cv = cloud_view(packed, n);
-    const float* rq = (C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
-    const float* rt = rq ? rig->rig_trans : nullptr;
-    const int64_t occw = cv.npad / 32;
-    (void)flags;
-    if (!(phases & 1)) {
-    } else if (fused) {
-        TO_PROF(TOHIP_PROF_BWD, st);
-        int nbx = (int)((n + 4 * TO_REWARD_THREADS - 1) / (4 * TO_REWARD_THREADS));
-        if (nbx > TO_REWARD_BLOCKS) nbx = TO_REWARD_BLOCKS;
-        int lg = 0;
-        while (((int64_t)1 << lg) < n) ++lg;
-        const int64_t blocks = (int64_t)nbx * n_traj + (V * 32 + TO_REWARD_THREADS / 64 - 1) / (TO_REWARD_THREADS / 64);
-        if (blocks > 0x7fffffff) return TOHIP_EINVAL;
-        k_traj_reward_bwd<<<(int)blocks, TO_REWARD_THREADS, 0, st>>>(lo_sum, n, fused->eps, 47 - lg, fused->prefilled ? 1 : 0, fused->rewards,
-                                                                     (unsigned long long*)workspace, fused->scalars, nbx, (int)n_traj, cv, rec, k,
-                                                                     vlist, vcnt, pl.nslots, bpart, occlusion_bits, occw, (int)V);
+                       float* quats_grad, void* workspace, size_t workspace_bytes, void* stream_, const FusedReward* fused) {
+    if (!lo_sum || !poses_grad || !quats_grad || (!grad_rewards && (!scalars || !gout))) return TOHIP_EINVAL;
+    TrajStep s;
+    int rc = traj_step_init(s, packed, n, W, n_traj, nullptr, cam, rig, flags, occlusion_bits, workspace, workspace_bytes, stream_, false);
+    if (rc != TOHIP_OK) return rc;
+    SparseArgs a = sparse_args(s, lo_sum);
+    if (fused) {
+        TO_PROF(TOHIP_PROF_BWD, s.st);
+        const int nbx = reward_blocks(n);
+        const int64_t blocks = (int64_t)nbx * n_traj + sparse_blocks(s);
+        if (s.occ) k_traj_reward_bwd<true><<<(int)blocks, TO_SP_THREADS, 0, s.st>>>(lo_sum, n, fused->eps, fused->prefilled ? 1 : 0, fused->rewards, fused->scalars, nbx, a);
+        else k_traj_reward_bwd<false><<<(int)blocks, TO_SP_THREADS, 0, s.st>>>(lo_sum, n, fused->eps, fused->prefilled ? 1 : 0, fused->rewards, fused->scalars, nbx, a);
         TO_HIP_CHECK_LAUNCH();
-    } else {
-        TO_PROF(TOHIP_PROF_BWD, st);
-        for (int64_t v0 = 0; v0 < V; v0 += 65535) {  // grid.y limit
-            const int nv = (int)(V - v0 < 65535 ? V - v0 : 65535);
-            k_traj_bwd_sparse<<<dim3(TO_BWD_GX, nv), TO_SLOT, 0, st>>>(cv, rec + v0, k, vlist + v0 * pl.nslots, vcnt + v0, pl.nslots, lo_sum,
-                                                                        grad_rewards, scalars, gout, bpart + v0 * pl.nslots * 16,
-                                                                        occlusion_bits ? occlusion_bits + v0 * occw : nullptr, occw);
-        }
-        TO_HIP_CHECK_LAUNCH();
+        return launch_finish(s, finish_post(s, 1, scalars, gout, nullptr, fused->eps), poses_grad, quats_grad);
     }
-    if (!(phases & 2)) return TOHIP_OK;
-    TO_PROF(TOHIP_PROF_SMALL, st);
-    const bool single = C == 1 && rq == nullptr;
-    if (V <= 512)
-        k_traj_bwd_finish<1024><<<(int)V, 1024, 0, st>>>(cv, bpart, pl.nslots, fv, pl.fv_words, rec, k, ties, part, occlusion_bits, occw, vgrad,
-                                                         cold, single ? 1 : 0, poses_grad, quats_grad, fused_scalars, fused_scalars ? gout : nullptr);
-    else
-        k_traj_bwd_finish<256><<<(int)V, 256, 0, st>>>(cv, bpart, pl.nslots, fv, pl.fv_words, rec, k, ties, part, occlusion_bits, occw, vgrad,
-                                                       cold, single ? 1 : 0, poses_grad, quats_grad, fused_scalars, fused_scalars ? gout : nullptr);
-    TO_HIP_CHECK_LAUNCH();
-    if (!single) {
-        k_traj_bwd_finish2<<<(int)((W + 63) / 64), 64, 0, st>>>(vgrad, rec, cold, (int)W, C, rq, rt, poses_grad, quats_grad);
-        TO_HIP_CHECK_LAUNCH();
+    {
+        TO_PROF(TOHIP_PROF_BWD, s.st);
+        a.grad_rewards = grad_rewards;
+        a.scalars = grad_rewards ? nullptr : scalars;
+        a.gout = grad_rewards ? nullptr : gout;
+        rc = launch_sparse<TO_SP_BWD>(s, a);
+        if (rc != TOHIP_OK) return rc;
     }
-    return TOHIP_OK;
+    return launch_finish(s, finish_post(s, 0, nullptr, nullptr, nullptr, 0.f), poses_grad, quats_grad);
 }
 
 }  // namespace
@@ -1471,8 +1600,8 @@ extern "C" int tohip_traj_backward_multi(const void* packed, int64_t n, int64_t 
                                          const tohip_rig* rig, int flags, const uint32_t* occlusion_bits, const float* lo_sum,
                                          const float* grad_rewards, const float* scalars, const float* gout, float* poses_grad,
                                          float* quats_grad, void* workspace, size_t workspace_bytes, void* stream_) {
-    return traj_backward_impl(packed, n, W, n_traj, cam, rig, flags, occlusion_bits, lo_sum, grad_rewards, scalars, gout, poses_grad, quats_grad,
-                              workspace, workspace_bytes, stream_, nullptr);
+    return traj_backward_impl(packed, n, W, n_traj, cam, rig, flags, occlusion_bits, const_cast<float*>(lo_sum), grad_rewards, scalars, gout,
+                              poses_grad, quats_grad, workspace, workspace_bytes, stream_, nullptr);
 }
 
 extern "C" int tohip_traj_reward_backward_multi(const void* packed, int64_t n, int64_t W, int64_t n_traj, const tohip_camera* cam,
@@ -1482,8 +1611,8 @@ extern "C" int tohip_traj_reward_backward_multi(const void* packed, int64_t n, i
                                                 void* stream_) {
     if (!rewards || !scalars || !gout) return TOHIP_EINVAL;
     const FusedReward f{eps, prefilled, rewards, scalars};
-    return traj_backward_impl(packed, n, W, n_traj, cam, rig, flags, occlusion_bits, lo_sum, nullptr, scalars, gout, poses_grad, quats_grad,
-                              workspace, workspace_bytes, stream_, &f);
+    return traj_backward_impl(packed, n, W, n_traj, cam, rig, flags, occlusion_bits, const_cast<float*>(lo_sum), nullptr, scalars, gout, poses_grad,
+                              quats_grad, workspace, workspace_bytes, stream_, &f);
 }
 
 extern "C" int tohip_traj_reward_backward(const void* packed, int64_t n, int64_t W, const tohip_camera* cam, const tohip_rig* rig, int flags,
@@ -1502,17 +1631,54 @@ extern "C" int tohip_traj_backward(const void* packed, int64_t n, int64_t W, con
                                      quats_grad, workspace, workspace_bytes, stream_);
 }
 
+namespace {
+// the fused step, launches 1-3: probe, pass 1, k_traj_sparse<FUSED> (log-odds, rewards, their integer sum, the pair sums with
+// unit upstream gradient).  The finish (launch 4) needs dL/d loss_vis and may follow later (loss_kernels.hip).
+int traj_fused_forward(TrajStep& s, const float* poses, const float* quats, float* lo_sum, float* minmax, float* rewards) {
+    int rc = launch_probe_pass1(s, poses, quats, lo_sum, rewards);
+    if (rc != TOHIP_OK) return rc;
+    TO_PROF(TOHIP_PROF_PASS2, s.st);
+    SparseArgs a = sparse_args(s, lo_sum);
+    a.minmax = minmax;
+    a.rewards = rewards;
+    a.prefilled = 1;
+    return launch_sparse<TO_SP_FUSED>(s, a);
+}
+}  // namespace
+
+extern "C" int tohip_traj_forward_backward_multi(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
+                                                 const int32_t* traj_offsets, int64_t n_traj, const tohip_camera* cam,
+                                                 const tohip_rig* rig, int flags, const uint32_t* occlusion_bits, float* lo_sum,
+                                                 float* minmax, float* rewards, float* scalars, const float* gout, float* poses_grad,
+                                                 float* quats_grad, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!poses || !quats || !lo_sum || !minmax || !rewards || !scalars || !gout || !poses_grad || !quats_grad) return TOHIP_EINVAL;
+    TrajStep s;
+    int rc = traj_step_init(s, packed, n, W, n_traj, traj_offsets, cam, rig, flags, occlusion_bits, workspace, workspace_bytes, stream_, true);
+    if (rc != TOHIP_OK) return rc;
+    rc = traj_fused_forward(s, poses, quats, lo_sum, minmax, rewards);
+    if (rc != TOHIP_OK) return rc;
+    return launch_finish(s, finish_post(s, 2, nullptr, gout, scalars, cam->eps), poses_grad, quats_grad);
+}
+
+extern "C" int tohip_traj_forward_backward(const void* packed, int64_t n, const float* poses, const float* quats, int64_t W,
+                                           const tohip_camera* cam, const tohip_rig* rig, int flags, const uint32_t* occlusion_bits,
+                                           float* lo_sum, float* minmax, float* rewards, float* scalars, const float* gout,
+                                           float* poses_grad, float* quats_grad, void* workspace, size_t workspace_bytes, void* stream_) {
+    return tohip_traj_forward_backward_multi(packed, n, poses, quats, W, nullptr, 1, cam, rig, flags, occlusion_bits, lo_sum, minmax, rewards,
+                                             scalars, gout, poses_grad, quats_grad, workspace, workspace_bytes, stream_);
+}
+
 // Diagnostic (bench.py's roofline leg, never on in a timed pass): k_traj_pass1 stamps s_memtime / s_memrealtime per block into
-// `buffer` (16 bytes per block; capacity for grid.x * grid.y blocks: tohip_profile_clock_blocks) while it is set; NULL turns it off.
+// `buffer` (48 bytes per block; capacity: tohip_profile_clock_blocks) while it is set; NULL turns it off.
 // The in-kernel clock is d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).
 extern "C" int tohip_profile_clock(void* buffer) {
     clock_stamps() = (unsigned long long*)buffer;
     return TOHIP_OK;
 }
-extern "C" int64_t tohip_profile_clock_blocks(int64_t n_points, int64_t n_virtual, int flags) {
+// the dense kernel's grid for this problem (with_occlusion selects the build it is asked about)
+extern "C" int64_t tohip_profile_clock_blocks(int64_t n_points, int64_t n_virtual, int flags, int with_occlusion) {
     if (n_points <= 0 || n_virtual <= 0 || !(flags & TOHIP_TRAJ_DENSE)) return 0;   // only the dense kernel stamps
     const TrajPlan pl = make_plan(n_points, n_virtual, n_virtual);
     const int nblk8 = (int)(pl.npad / (TO_BLOCK * TO_PD));
-    return dense_blocks(nblk8, (int)n_virtual, true) > dense_blocks(nblk8, (int)n_virtual, false)
-               ? dense_blocks(nblk8, (int)n_virtual, true) : dense_blocks(nblk8, (int)n_virtual, false);
+    return dense_blocks(nblk8, (int)n_virtual, with_occlusion != 0);
 }
