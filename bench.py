@@ -220,6 +220,42 @@ def dropin_leg(device, steps=200, warmup=10):
     return out
 
 
+def density_leg(device, steps=20, warmup=3):
+    """The same 1 M points x 128 waypoints in ever smaller rooms (the path scaled with the room): the headline workload flags
+    0.7 % of the (256-point slot, waypoint) pairs; an indoor cloud flags 10-20 %, and the kernels after pass 1 cost in proportion.
+    Per extent: flagged fraction, dense and culled ms/step (tohip_traj_forward_backward, off the timed headline), bitwise equality
+    of the two modes."""
+    from trajectory_optimization_amd import ops
+    out = []
+    cam = ops.Camera(synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT)
+    gout = torch.ones(1, device=device)
+    for ext in ((40.0, 40.0, 4.0), (20.0, 20.0, 4.0), (10.0, 10.0, 4.0), (6.0, 6.0, 3.0)):
+        pts = synth.make_cloud(N_POINTS, seed=0, extent=ext)
+        poses, quats = synth.make_path(WPS_PER_GPU, optical=True, scale=ext[0] / 40.0)
+        cloud = ops.PackedCloud(torch.from_numpy(pts).to(device))
+        p, q = torch.from_numpy(poses).to(device), torch.from_numpy(quats).to(device)
+        ws = ops.TrajWorkspace(cloud, WPS_PER_GPU)
+        row = {"extent_m": list(ext)}
+        outs = {}
+        for name, flags in (("dense", ops.DENSE), ("culled", 0)):
+            for _ in range(warmup):
+                o = ops.traj_forward_backward(cloud, p, q, cam, ws, gout, flags=flags)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                o = ops.traj_forward_backward(cloud, p, q, cam, ws, gout, flags=flags)
+            torch.cuda.synchronize(device)
+            row[f"{name}_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / steps
+            outs[name] = o
+        st = ops.traj_step_stats(cloud, ws)
+        row.update(flagged_fraction=st["flagged_fraction"], flagged_pairs=st["flagged_pairs"], candidate_slots=st["candidate_slots"],
+                   slots=st["slots"], mean_reward=float(outs["dense"][1][0].item()),
+                   dense_equals_culled_bitwise=bool(all(torch.equal(a, b) for a, b in zip(outs["dense"][:5], outs["culled"][:5]))))
+        out.append(row)
+        del cloud, ws
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,6 +278,7 @@ def main():
                          "0.139 ms dense, 0.079 vs 0.075 culled - graph kernel nodes cost more than the queue they replace)")
     ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dropin", choices=["on", "off"], default="on", help="time the reference's own loop over the drop-in classes (N = 1 only)")
+    ap.add_argument("--density", choices=["on", "off"], default="on", help="step time versus flagged fraction: 1 M points in ever smaller rooms (N = 1 only)")
     ap.add_argument("--dump", default=None, help="write the last dense step's outputs (scalars, gradient rows, rewards) to this .npz "
                                                  "(rank 0): tests compare runs at different N")
     args = ap.parse_args()
@@ -480,6 +517,8 @@ def main():
         if n_gpus == 1 and args.cpu_wps > 0 and args.cameras == 1:
             if args.dropin == "on":
                 line["dropin"] = dropin_leg(device)
+            if args.density == "on":
+                line["density_sweep"] = density_leg(device)
             line["hpr"] = hpr_leg(pts, device)
             line["cpu_baseline"] = cpu_baseline(pts, poses_all, quats_all, args.cpu_wps)
             line["reference_cpu_container"] = {

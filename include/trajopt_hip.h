@@ -431,6 +431,12 @@ int tohip_profile_read(double *ms_sum_host, int64_t *counts_host);
 int tohip_profile_clock(void *device_buffer);
 int64_t tohip_profile_clock_blocks(int64_t n_points, int64_t n_virtual, int flags, int with_occlusion);
 
+/* Diagnostic: what the last forward over `workspace` found.  stats (DEVICE int64 x 4, zero-filled by the caller):
+ * [0] flagged (256-point slot, virtual waypoint) pairs — the pairs with a non-zero log-odds term or a gradient;
+ * [1] candidate slots listed by pass 1; [2] slots; [3] virtual waypoints. */
+int tohip_traj_step_stats(int64_t n_points, int64_t n_virtual, int64_t n_traj, const void *workspace, size_t workspace_bytes,
+                          int64_t *stats, void *stream);
+
 /* ---- self tests of cross-lane primitives (used by tests/, cheap) -------------------------------- */
 int tohip_selftest_wave_reduce(const float *in64xK, int32_t k, float *out_sum, float *out_min, float *out_max,
                                void *stream);

@@ -129,6 +129,7 @@ SIGNATURES = {
     "tohip_render_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "tohip_render_points": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(c_f), c_i32, c_i32, c_f, c_f, c_f, c_f, c_vp, c_vp,
                                             c_vp, c_vp, c_sz, c_vp]),
+    "tohip_traj_step_stats": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_sz, c_vp, c_vp]),
     "tohip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "tohip_profile_name": (ctypes.c_char_p, [ctypes.c_int]),
     "tohip_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),

@@ -601,15 +601,17 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int a
             const int v = w * 64 + lane;
             bool flag = false;
             if (v < a.V) {
-                const float2 q = a.part[(int64_t)slot * a.V + v];
+                const float2 pq = a.part[(int64_t)slot * a.V + v];
                 float av, pmax, M, invM;
                 load_norm(a.ext[v], av, pmax, M, invM);
                 const bool amin = av > 0.f;
                 const bool degenerate = !(M > 0.f) || !(invM < INFINITY);
-                flag = ((q.y - av) * invM >= 0.5f) | (amin & (q.x == av)) | degenerate;
-                if (q.y == pmax && M > 0.f) { const int i = atomicAdd(&a.ties[v].nmax, 1); if (i < TO_TIE_CAP) a.ties[v].maxrow[i] = slot; }
-                if (amin && q.x == av) { const int i = atomicAdd(&a.ties[v].nmin, 1); if (i < TO_TIE_CAP) a.ties[v].minrow[i] = slot; }
-                if (flag) atomicOr(&a.fv[(int64_t)v * a.fv_words + (slot >> 6)], 1ull << (slot & 63));
+                flag = ((pq.y - av) * invM >= 0.5f) | (amin & (pq.x == av)) | degenerate;
+                {
+                    if (pq.y == pmax && M > 0.f) { const int i = atomicAdd(&a.ties[v].nmax, 1); if (i < TO_TIE_CAP) a.ties[v].maxrow[i] = slot; }
+                    if (amin && pq.x == av) { const int i = atomicAdd(&a.ties[v].nmin, 1); if (i < TO_TIE_CAP) a.ties[v].minrow[i] = slot; }
+                    if (flag) atomicOr(&a.fv[(int64_t)v * a.fv_words + (slot >> 6)], 1ull << (slot & 63));
+                }
             }
             word = __ballot(flag);
             if (lane == 0) a.ft[(int64_t)slot * a.vwords + w] = word;
@@ -764,13 +766,13 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int a
                         const f2 G = f2{gn[2 * h], gn[2 * h + 1]} * pk_rcp(ph * (pk_splat(1.0f) - ph));
                         f2 wgt = G * pk_splat(invM);
                         wgt = f2{act0 ? wgt.x : 0.f, act1 ? wgt.y : 0.f};
-                        acc[12] = acc[12] + wgt * (ph - pk_splat(1.0f));
-                        acc[13] = acc[13] + (-wgt) * ph;
+                        acc[12] = pk_fma(wgt, ph - pk_splat(1.0f), acc[12]);
+                        acc[13] = pk_fma(-wgt, ph, acc[13]);
                         const f2 w0 = wgt * g[0], w1 = wgt * g[1], w2 = wgt * g[2];
                         acc[0] = acc[0] + w0; acc[1] = acc[1] + w1; acc[2] = acc[2] + w2;
-                        acc[3] = acc[3] + vg.y0 * w0; acc[4] = acc[4] + vg.y0 * w1; acc[5] = acc[5] + vg.y0 * w2;
-                        acc[6] = acc[6] + vg.y1 * w0; acc[7] = acc[7] + vg.y1 * w1; acc[8] = acc[8] + vg.y1 * w2;
-                        acc[9] = acc[9] + vg.y2 * w0; acc[10] = acc[10] + vg.y2 * w1; acc[11] = acc[11] + vg.y2 * w2;
+                        acc[3] = pk_fma(vg.y0, w0, acc[3]); acc[4] = pk_fma(vg.y0, w1, acc[4]); acc[5] = pk_fma(vg.y0, w2, acc[5]);
+                        acc[6] = pk_fma(vg.y1, w0, acc[6]); acc[7] = pk_fma(vg.y1, w1, acc[7]); acc[8] = pk_fma(vg.y1, w2, acc[8]);
+                        acc[9] = pk_fma(vg.y2, w0, acc[9]); acc[10] = pk_fma(vg.y2, w1, acc[10]); acc[11] = pk_fma(vg.y2, w2, acc[11]);
                         any_act = true;
                     }
                 }
@@ -807,12 +809,18 @@ __device__ __forceinline__ void write_minmax(const SparseArgs& a) {
     }
 }
 
+// block b of nb walks the candidate list with stride nb (one 16-wave block is resident per CU at this kernel's register count)
+template <int MODE, bool OCC>
+__device__ __forceinline__ void sparse_walk(const SparseArgs& a, int b, int nb, SparseLds& L) {
+    const int n = *a.clist_n;
+    for (int li = b; li < n; li += nb) sparse_slot<MODE, OCC>(a, a.clist[li], b & 7, L);
+}
+
 template <int MODE, bool OCC>
 __global__ void __launch_bounds__(TO_SP_THREADS) k_traj_sparse(SparseArgs a) {
     __shared__ SparseLds L;
     if (MODE != TO_SP_BWD && blockIdx.x == 0) write_minmax(a);
-    const int n = *a.clist_n;
-    for (int li = blockIdx.x; li < n; li += gridDim.x) sparse_slot<MODE, OCC>(a, a.clist[li], (int)(blockIdx.x & 7), L);
+    sparse_walk<MODE, OCC>(a, (int)blockIdx.x, (int)gridDim.x, L);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -897,8 +905,7 @@ k_traj_reward_bwd(const float* __restrict__ lo_sum, int64_t n, float eps, int pr
                      reinterpret_cast<long long*>(L.sflag));
         return;
     }
-    const int nl = *a.clist_n, bid = (int)blockIdx.x - R, nb = (int)gridDim.x - R;
-    for (int li = bid; li < nl; li += nb) sparse_slot<TO_SP_BWD, OCC>(a, a.clist[li], bid & 7, L);
+    sparse_walk<TO_SP_BWD, OCC>(a, (int)blockIdx.x - R, (int)gridDim.x - R, L);
 }
 
 // thread per body waypoint: rig composition, dL/dt = -R sum dL/dc, dL/dR = sum y (x) dL/dc,
@@ -1465,7 +1472,7 @@ inline SparseArgs sparse_args(const TrajStep& s, float* lo_sum) {
 // list walkers: the expected number of candidate slots on the workloads this is tuned for (6-8 % of the slots), each a chain
 // of its own; a dense cloud lists every slot and the blocks loop
 inline int sparse_blocks(const TrajStep& s) {
-    int64_t nb = std::min<int64_t>(s.pl.nslots, 512 * s.n_traj);
+    int64_t nb = std::min<int64_t>(s.pl.nslots, 512 * s.n_traj);   // two 1024-thread blocks to a CU: all resident at once
     return (int)std::min<int64_t>(nb, 4096);
 }
 
@@ -1666,6 +1673,32 @@ extern "C" int tohip_traj_forward_backward(const void* packed, int64_t n, const 
                                            float* poses_grad, float* quats_grad, void* workspace, size_t workspace_bytes, void* stream_) {
     return tohip_traj_forward_backward_multi(packed, n, poses, quats, W, nullptr, 1, cam, rig, flags, occlusion_bits, lo_sum, minmax, rewards,
                                              scalars, gout, poses_grad, quats_grad, workspace, workspace_bytes, stream_);
+}
+
+// Diagnostic: what the last forward over `workspace` found — stats[0] = flagged (slot, waypoint) pairs, stats[1] = candidate slots
+// listed by pass 1, stats[2] = slots, stats[3] = virtual waypoints (device int64 x 4; the caller zero-fills it).
+__global__ void k_traj_stats(const int* __restrict__ clist, const int* __restrict__ clist_n, const unsigned long long* __restrict__ ft,
+                             int vwords, int nslots, int V, unsigned long long* __restrict__ stats) {
+    const int n = *clist_n;
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)n * vwords; i += (int64_t)gridDim.x * blockDim.x)
+        c += __popcll(ft[(int64_t)clist[i / vwords] * vwords + (i % vwords)]);
+    for (int s = 32; s > 0; s >>= 1) c += __shfl_xor(c, s);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&stats[0], c);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[1] = (unsigned long long)n; stats[2] = (unsigned long long)nslots; stats[3] = (unsigned long long)V; }
+}
+
+extern "C" int tohip_traj_step_stats(int64_t n_points, int64_t n_virtual, int64_t n_traj, const void* workspace, size_t workspace_bytes,
+                                     int64_t* stats, void* stream_) {
+    if (n_points <= 0 || n_virtual <= 0 || n_traj <= 0 || !workspace || !stats) return TOHIP_EINVAL;
+    const TrajPlan pl = make_plan(n_points, n_virtual, n_virtual, n_traj);
+    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
+    const char* ws = (const char*)workspace;
+    const int* cand = (const int*)(ws + pl.off_cand);
+    k_traj_stats<<<256, 256, 0, (hipStream_t)stream_>>>((const int*)(ws + pl.off_clist), cand + pl.nslots, (const unsigned long long*)(ws + pl.off_ft),
+                                                        pl.vwords, pl.nslots, (int)n_virtual, (unsigned long long*)stats);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
 }
 
 // Diagnostic (bench.py's roofline leg, never on in a timed pass): k_traj_pass1 stamps s_memtime / s_memrealtime per block into

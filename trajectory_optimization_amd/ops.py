@@ -233,6 +233,15 @@ def traj_backward_multi(cloud, n_wps, n_traj, cam, ws, lo_sum, grad_rewards=None
     return pg, qg
 
 
+def traj_step_stats(cloud, ws):
+    """What the last forward over `ws` found -> dict(flagged_pairs, candidate_slots, slots, virtual_waypoints, flagged_fraction)."""
+    st = torch.zeros(4, dtype=torch.int64, device=cloud.device)
+    with torch.cuda.device(cloud.device):
+        check(_lib.lib().tohip_traj_step_stats(cloud.n, ws.n_virtual, ws.n_traj, ptr(ws.buf), ws.bytes, ptr(st), stream_ptr()), "tohip_traj_step_stats")
+    f, c, s, v = (int(x) for x in st.cpu())
+    return dict(flagged_pairs=f, candidate_slots=c, slots=s, virtual_waypoints=v, flagged_fraction=f / max(1, s * v))
+
+
 class PoseWorkspace:
     def __init__(self, cloud):
         self.bytes = _lib.lib().tohip_pose_workspace_bytes(cloud.n)

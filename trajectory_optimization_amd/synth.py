@@ -41,8 +41,8 @@ def make_cloud(n_points, seed=0, extent=(40.0, 40.0, 4.0)):
     return pts.astype(np.float32)
 
 
-def make_path(n_wps, optical=True, jitter_seed=None):
-    """Smooth curve t=(-10+20s, 3 sin 6s, 0), yaw 0.5 cos 6s, wxyz quats.
+def make_path(n_wps, optical=True, jitter_seed=None, scale=1.0):
+    """Smooth curve t=scale*(-10+20s, 3 sin 6s, 0), yaw 0.5 cos 6s, wxyz quats.
 
     With `optical` the yaw rotation is composed with the body->optical
     rotation so the camera +Z axis looks along the path.  `jitter_seed`
@@ -53,7 +53,7 @@ def make_path(n_wps, optical=True, jitter_seed=None):
         s = np.zeros(1)
     else:
         s = np.arange(n_wps, dtype=np.float64) / (n_wps - 1)
-    pos = np.stack([-10.0 + 20.0 * s, 3.0 * np.sin(6.0 * s), np.zeros_like(s)], axis=1)
+    pos = scale * np.stack([-10.0 + 20.0 * s, 3.0 * np.sin(6.0 * s), np.zeros_like(s)], axis=1)
     yaw = 0.5 * np.cos(6.0 * s)
     q = np.stack([np.cos(yaw / 2), np.zeros_like(s), np.zeros_like(s), np.sin(yaw / 2)], axis=1)
     if optical:
