@@ -447,3 +447,56 @@ def test_fused_reward_backward_with_rig_and_occlusion(dev, n, w, cams, occ):
         f = oracle.traj_forward(c["pts"], c["poses"], c["quats"], K, IW, IH, prec="f64")
         pgo, qgo = oracle.traj_backward(c["pts"], c["poses"], c["quats"], K, IW, IH, f, prec="f64")
         assert rel_inf(pg2.cpu().numpy(), pgo) < GRAD_TOL and rel_inf(qg2.cpu().numpy(), qgo) < GRAD_TOL
+
+
+@pytest.mark.parametrize("n,w,cams,occ", [(200_000, 70, 1, True), (60_000, 9, 3, False), (300_000, 130, 1, False), (3000, 5, 1, False),
+                                          (1_000_003, 17, 1, False)])
+def test_fused_step_equals_the_split_calls(dev, n, w, cams, occ):
+    """tohip_traj_forward_backward (four launches, no collective between forward and backward): log-odds, minmax, rewards and
+    scalars are bitwise those of tohip_traj_forward + tohip_traj_reward (the reward sum is an integer sum: no order to depend
+    on); the gradients those of tohip_traj_backward to rounding (the dL/d reward factor is applied per waypoint in f64 instead
+    of per point in f32).  Dense and culled agree bitwise through it; two runs agree bitwise."""
+    ops = _ops()
+    c = _setup(dev, n, w, cams, occ)
+    gout = torch.tensor([0.7], device=dev)
+    outs = []
+    for flags in (0, ops.DENSE):
+        half = torch.empty(c["cloud"].n, device=dev)
+        lo, mm = ops.traj_forward(c["cloud"], c["p"], c["q"], c["cam"], c["ws"], c["rig"], flags=flags, occ=c["occ"], rewards_half=half)
+        rew, sc = ops.traj_reward(c["cloud"], lo, c["cam"], c["ws"], rewards=half, prefilled=True)
+        pg, qg = ops.traj_backward(c["cloud"], w, c["cam"], c["ws"], lo, scalars=sc, gout=gout, rig=c["rig"], flags=flags, occ=c["occ"])
+        lo, mm = lo.clone(), mm.clone()
+        f = ops.traj_forward_backward(c["cloud"], c["p"], c["q"], c["cam"], c["ws"], gout, rig=c["rig"], flags=flags, occ=c["occ"])
+        assert torch.equal(f[0], rew) and torch.equal(f[1], sc) and torch.equal(f[4][:c["cloud"].n], lo[:c["cloud"].n]) and torch.equal(f[5], mm)
+        assert rel_inf(f[2].cpu().numpy(), pg.cpu().numpy()) < 1e-6 and rel_inf(f[3].cpu().numpy(), qg.cpu().numpy()) < 1e-6
+        g = ops.traj_forward_backward(c["cloud"], c["p"], c["q"], c["cam"], c["ws"], gout, rig=c["rig"], flags=flags, occ=c["occ"])
+        assert all(torch.equal(a, b) for a, b in zip(f[:4], g[:4]))
+        outs.append(f)
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][:4], outs[1][:4]))
+
+
+def test_fused_step_of_several_trajectories_equals_single_calls(dev):
+    """tohip_traj_forward_backward_multi: each trajectory's rewards, scalars and gradient rows are, bit for bit, those of a call
+    with that trajectory alone."""
+    ops = _ops()
+    pts = synth.make_cloud(120_000, seed=21)
+    cloud = ops.PackedCloud(torch.from_numpy(pts).to(dev))
+    cam = ops.Camera(K, IW, IH)
+    lens = [7, 19, 3]
+    ps, qs = [], []
+    for i, n in enumerate(lens):
+        p, q = synth.make_path(n, optical=True, jitter_seed=40 + i)
+        p[:, 1] += 0.7 * i
+        ps.append(p); qs.append(q)
+    P, Q = torch.from_numpy(np.concatenate(ps)).to(dev), torch.from_numpy(np.concatenate(qs)).to(dev)
+    toff = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=dev)
+    gout = torch.tensor([1.0, 0.5, 2.0], device=dev)
+    ws = ops.TrajWorkspace(cloud, sum(lens), len(lens))
+    rew, sc, pg, qg, lo, mm = ops.traj_forward_backward_multi(cloud, P, Q, toff, cam, ws, gout)
+    o = 0
+    for b, n in enumerate(lens):
+        ws1 = ops.TrajWorkspace(cloud, n)
+        r1, s1, pg1, qg1, lo1, mm1 = ops.traj_forward_backward(cloud, P[o:o + n].contiguous(), Q[o:o + n].contiguous(), cam, ws1, gout[b:b + 1])
+        assert torch.equal(rew[b], r1) and torch.equal(sc[b], s1) and torch.equal(lo[b, :cloud.n], lo1[:cloud.n]) and torch.equal(mm[o:o + n], mm1)
+        assert torch.equal(pg[o:o + n], pg1) and torch.equal(qg[o:o + n], qg1)
+        o += n

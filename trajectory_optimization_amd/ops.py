@@ -175,6 +175,30 @@ def traj_forward_backward(cloud, poses, quats, cam, ws, gout, rig=None, flags=0,
     return rewards, scalars, pg, qg, lo_sum, minmax
 
 
+def traj_forward_backward_multi(cloud, poses, quats, traj_offsets, cam, ws, gout, rig=None, flags=0, lo_sum=None, minmax=None, rewards=None):
+    """traj_forward_backward for B trajectories laid end to end (traj_forward_multi's layout; gout: (B,) dL/d loss_vis each).
+    -> (rewards (B,N), scalars (B,4), poses_grad (W,3), quats_grad (W,4), lo_sum (B,npad), minmax (V,2))."""
+    W, B = poses.shape[0], traj_offsets.numel() - 1
+    C = rig.n_cams if rig is not None else 1
+    dev = cloud.device
+    if lo_sum is None:
+        lo_sum = torch.empty((B, cloud.npad), dtype=torch.float32, device=dev)
+    if minmax is None:
+        minmax = torch.empty((W * C, 2), dtype=torch.float32, device=dev)
+    if rewards is None:
+        rewards = torch.empty((B, cloud.n), dtype=torch.float32, device=dev)
+    scalars = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    pg = torch.empty((W, 3), dtype=torch.float32, device=dev)
+    qg = torch.empty((W, 4), dtype=torch.float32, device=dev)
+    ws.generation += 1
+    with torch.cuda.device(dev):
+        check(_lib.lib().tohip_traj_forward_backward_multi(ptr(cloud.blob), cloud.n, ptr(poses), ptr(quats), W, ptr(traj_offsets), B, cam.ref(),
+                                                           rig.ref() if rig is not None else _NULL_RIG, int(flags), None, ptr(lo_sum), ptr(minmax),
+                                                           ptr(rewards), ptr(scalars), ptr(gout), ptr(pg), ptr(qg), ptr(ws.buf), ws.bytes,
+                                                           stream_ptr()), "tohip_traj_forward_backward_multi")
+    return rewards, scalars, pg, qg, lo_sum, minmax
+
+
 def traj_reward_backward_multi(cloud, n_wps, n_traj, cam, ws, lo_sum, gout, rewards=None, prefilled=False, rig=None, flags=0):
     """-> (rewards (B,N), scalars (B,4), poses_grad (W,3), quats_grad (W,4)) of B trajectories (traj_forward_multi's lo_sum)."""
     if rewards is None:

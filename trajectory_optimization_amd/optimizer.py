@@ -69,23 +69,30 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
         occ = None
         if occluded and n_loc > 0:
             occ = model._occlusion_rows(p_loc, q_loc)
-        if n_loc > 0:
-            check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref,
-                                       model._flags, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(ws.buf), ws.bytes, s),
-                  "forward")
+        tgt_p, tgt_q = (pg_loc, qg_loc) if sharded else (pg_e, qg_e)
+        if not sharded:
+            # no collective between forward and backward: the whole visibility step is ONE call, four launches
+            check(L.tohip_traj_forward_backward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref, model._flags,
+                                                ptr(occ), ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(scalars), ptr(gout), ptr(tgt_p),
+                                                ptr(tgt_q), ptr(ws.buf), ws.bytes, s), "forward + backward")
             ws.generation += 1
         else:
-            lo_sum.zero_()
-        model._shard.allreduce_sum(lo_sum)
-        tgt_p, tgt_q = (pg_loc, qg_loc) if sharded else (pg_e, qg_e)
-        if n_loc > 0:
-            # rewards, their mean and the loss scalars share the backward's first launch
-            check(L.tohip_traj_reward_backward(ptr(cloud.blob), cloud.n, n_loc, cam.ref(), rig_ref, model._flags, ptr(occ), ptr(lo_sum),
-                                               cam.eps, 1, ptr(rewards), ptr(scalars), ptr(gout), ptr(tgt_p), ptr(tgt_q), ptr(ws.buf),
-                                               ws.bytes, s), "reward + backward")
-        else:
-            check(L.tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, 0, ptr(rewards), ptr(scalars), ptr(ws.buf), ws.bytes, s),
-                  "reward")
+            if n_loc > 0:
+                check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref,
+                                           model._flags, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(ws.buf), ws.bytes, s),
+                      "forward")
+                ws.generation += 1
+            else:
+                lo_sum.zero_()
+            model._shard.allreduce_sum(lo_sum)
+            if n_loc > 0:
+                # rewards, their mean and the loss scalars share the backward's first launch
+                check(L.tohip_traj_reward_backward(ptr(cloud.blob), cloud.n, n_loc, cam.ref(), rig_ref, model._flags, ptr(occ), ptr(lo_sum),
+                                                   cam.eps, 1, ptr(rewards), ptr(scalars), ptr(gout), ptr(tgt_p), ptr(tgt_q), ptr(ws.buf),
+                                                   ws.bytes, s), "reward + backward")
+            else:
+                check(L.tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, 0, ptr(rewards), ptr(scalars), ptr(ws.buf), ws.bytes, s),
+                      "reward")
         if sharded:
             # assemble every rank's gradient rows: ONE (n_eval, 7) all-reduce, then the replicated remainder of the step
             if n_loc > 0:
@@ -170,12 +177,10 @@ def optimize_trajectories(models, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewa
         for _ in range(n_opt_steps):
             s = stream_ptr()
             check(L.tohip_gather_waypoints_multi(ptr(poses), ptr(quats), W, B, n_eval, step_w, ptr(poses_e), ptr(quats_e), s), "gather")
-            check(L.tohip_traj_forward_multi(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), B * n_eval, ptr(toff), B, cam.ref(), rig_ref,
-                                             m0._flags, None, ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(ws.buf), ws.bytes, s), "forward")
+            check(L.tohip_traj_forward_backward_multi(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), B * n_eval, ptr(toff), B, cam.ref(),
+                                                      rig_ref, m0._flags, None, ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(scalars), ptr(gout),
+                                                      ptr(pg_e), ptr(qg_e), ptr(ws.buf), ws.bytes, s), "forward + backward")
             ws.generation += 1
-            check(L.tohip_traj_reward_backward_multi(ptr(cloud.blob), cloud.n, B * n_eval, B, cam.ref(), rig_ref, m0._flags, None, ptr(lo_sum),
-                                                     cam.eps, 1, ptr(rewards), ptr(scalars), ptr(gout), ptr(pg_e), ptr(qg_e), ptr(ws.buf),
-                                                     ws.bytes, s), "reward + backward")
             check(L.tohip_traj_step_tail_multi(ptr(poses), ptr(quats), ptr(poses0), W, B, ptr(pg_e), ptr(qg_e), n_eval, step_w, ptr(pg), ptr(qg),
                                                ptr(mp), ptr(vp), ptr(mq), ptr(vq), float(m0.smoothness_weight), float(m0.traj_length_weight),
                                                float(m0.eps), float(lr_pose), float(lr_quat), betas[0], betas[1], adam_eps, float(rewards_th),
