@@ -5,8 +5,9 @@ For N>1 the driver launches it under torch.distributed.run, one rank per GPU (RC
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): a 1 M-point synthetic
 cloud x 128 waypoints per GPU, full forward + backward to (x,y,z) and quaternion gradients, through the
-C ABI of include/trajopt_hip.h.  One "step" = tohip_traj_forward -> [all-reduce of the log-odds vector when
-N>1] -> tohip_traj_reward -> tohip_traj_backward [-> all-gather of the (W,7) gradient rows when N>1].  With N
+C ABI of include/trajopt_hip.h.  One "step" at N = 1 = tohip_traj_forward_backward (four launches); with N > 1 a collective sits
+between forward and backward: tohip_traj_forward -> all-reduce of the log-odds vector -> tohip_traj_reward_backward -> all-gather of the
+(W,7) gradient rows.  With N
 GPUs the trajectory has 128*N waypoints sharded contiguously over the ranks (weak scaling; N=8 is configs[3],
 1 M x 1024); value = N_points * W_total / time.  Inputs are resident in HBM before the timed region.
 
@@ -16,7 +17,7 @@ Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed on 
 The roofline is a VALU-ISSUE roofline: the kernels keep points in registers and stream waypoint records through SGPRs,
 so a launch moves ~N*16 B whatever W is (1 % of HBM peak) and is bound by vector-instruction issue.
   achieved = issue cycles the launch's instruction stream needs / kernel time
-             (instruction mix of the compiled inner loop: profiles/r02_pass1_isa_mix.json, from tools/isa_stats.py;
+             (instruction mix of the compiled inner loop: profiles/r03_pass1_isa_mix.json, from tools/isa_stats.py;
               prices per wave64 instruction measured on this chip: profiles/r02_valu_peak.json, tools/valu_peak.hip —
               packed f32 4, transcendental 8, other VALU 4 cycles)
   peak     = 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, max clock)
@@ -41,7 +42,7 @@ N_POINTS = 1_000_000
 WPS_PER_GPU = 128
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_SIMDS = 1024          # 256 CUs x 4 SIMDs
-CLOCK_GHZ = 2.4         # max clock (the chip holds 2.2-2.4 GHz under this load: profiles/r02_valu_peak.json)
+CLOCK_GHZ = 2.4         # max clock (the chip holds 2.1-2.4 GHz under this load: profiles/r02_valu_peak.json)
 ISSUE_CYCLES = {"packed_f32": 4.0, "transcendental": 8.0, "other_valu": 4.0}  # per wave64 instruction, measured
 # algorithmic bytes per evaluation of a STREAMING implementation of the reference's loop: kept as a named
 # secondary figure only — the kernels do not stream, so it exceeds the HBM peak
@@ -57,19 +58,31 @@ def _profile_json(name):
         return None
 
 
+def source_hash():
+    """sha256 of the sources the dense loop is compiled from (tools/isa_stats.py stores it with the mix it counted)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("common.hpp", "traj_kernels.hip"):
+        with open(os.path.join(REPO, "trajectory_optimization_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def isa_mix():
-    """VALU instructions of one (wave, waypoint) iteration of k_traj_pass1's dense inner loop (= 64*P evaluations), by class."""
-    d = _profile_json("r02_pass1_isa_mix.json")
+    """VALU instructions of one (wave, waypoint) iteration of k_traj_pass1's dense inner loop (= 64*P evaluations), by class.
+    The mix is a checked-in count of the compiled loop: it is only valid for the sources it was counted on."""
+    d = _profile_json("r03_pass1_isa_mix.json")
     if d is None:
-        raise SystemExit("profiles/r02_pass1_isa_mix.json is missing (tools/isa_stats.py --json writes it)")
+        raise SystemExit("profiles/r03_pass1_isa_mix.json is missing (tools/isa_stats.py --json writes it)")
+    d["stale"] = d.get("source_hash") != source_hash()
     return d
 
 
 def pmc_figures(kernel):
     """(HBM bytes per launch, VALU busy fraction) of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r02_bench_dense_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes; SQ_ACTIVE_INST_VALU x4 over the SIMD
-    cycles of the kernel), or (None, None)."""
-    d = _profile_json("r02_bench_dense_pmc.json")
+    (profiles/r03_bench_dense_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes; SQ_ACTIVE_INST_VALU x4 over the SIMD
+    cycles of the kernel), or (None, None, None)."""
+    d = _profile_json("r03_bench_dense_pmc.json")
     try:
         for name, v in d["kernels"].items():
             if kernel in name and "hbm_bytes_per_launch_corrected" in v:
@@ -400,6 +413,50 @@ def main():
             dt = float(t.item())
         return dt, o
 
+    def windows(flags, n_windows=5):
+        """ms per step of n further windows of K steps each (same fences): the spread of the one timed window."""
+        out = []
+        for _ in range(n_windows):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step(flags)
+            fence()
+            out.append(1e3 * (time.perf_counter() - t0) / args.steps)
+        return sorted(out)
+
+    def comm_leg(flags):
+        """N > 1: where the step's time goes.  The same K steps with events around the two collectives (on the compute stream,
+        which waits for RCCL's), and K steps of the same launches with the collectives left out."""
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+        fence()
+        for e in ev:
+            lo_sum, _ = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags, lo_sum=lo_buf, minmax=mm_buf, rewards_half=rewards_buf)
+            e[0].record()
+            shard.allreduce_sum(lo_sum)
+            e[1].record()
+            _, _, pg, qg = ops.traj_reward_backward(cloud, args.wps_per_gpu, cam, ws, lo_sum, gout, rewards=rewards_buf, prefilled=True, rig=rig,
+                                                    flags=flags)
+            g = torch.cat([pg, qg], dim=1)
+            e[2].record()
+            shard.allgather_rows(g)
+            e[3].record()
+        fence()
+        ar = sorted(e[0].elapsed_time(e[1]) for e in ev)
+        ag = sorted(e[2].elapsed_time(e[3]) for e in ev)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lo_sum, _ = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags, lo_sum=lo_buf, minmax=mm_buf, rewards_half=rewards_buf)
+            ops.traj_reward_backward(cloud, args.wps_per_gpu, cam, ws, lo_sum, gout, rewards=rewards_buf, prefilled=True, rig=rig, flags=flags)
+        fence()
+        no_comm = 1e3 * (time.perf_counter() - t0) / args.steps
+        return {"allreduce_ms_median": ar[len(ar) // 2], "allreduce_ms_max": ar[-1], "allreduce_bytes": int(cloud.npad * 4),
+                "allgather_ms_median": ag[len(ag) // 2], "allgather_bytes_per_rank": int(args.wps_per_gpu * 7 * 4),
+                "step_without_collectives_ms": no_comm, "backend": dist.get_backend(),
+                "note": "rank 0's view; events on the compute stream around each collective (it waits for RCCL's stream), "
+                        "and the same launches with the collectives left out"}
+
     def kernel_times(flags):
         """The same K steps once more with HIP events recorded around every kernel on the launch stream
         (tohip_profile_*): mean duration per launch, for the roofline object."""
@@ -437,15 +494,20 @@ def main():
     dense_flags = ops.DENSE if args.mode != "culled" else 0
     kern = kernel_times(dense_flags)
     dt, out = timed(dense_flags)
+    out = tuple(t.clone() for t in out)   # the step's outputs live in buffers the later legs reuse
     span_ms, clock_ghz = in_kernel_span(dense_flags) if (dense_flags and n_gpus == 1) else (None, None)
     # the library's default path: exact culling (bitwise identical outputs, tests/test_hip_traj.py)
     if args.mode == "both":
         kern_c = kernel_times(0)
         dt_c, out_c = timed(0)
+        out_c = tuple(t.clone() for t in out_c)
     else:
         dt_c, out_c, kern_c = dt, out, kern
     evals_per_step = args.points * w_total * args.cameras
     value = evals_per_step * args.steps / dt
+    win_dense = windows(dense_flags)
+    win_culled = windows(0) if args.mode == "both" else win_dense
+    comm = comm_leg(dense_flags) if shard is not None else None
 
     if rank == 0 and args.dump:
         np.savez(args.dump, scalars=out[0].cpu().numpy(), pg=out[1].cpu().numpy(), qg=out[2].cpu().numpy(), rewards=out[3].cpu().numpy())
@@ -465,18 +527,24 @@ def main():
         line = {
             "metric": "point-visibility evals/sec (fwd+bwd)", "value": value, "unit": "evals/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+            "ms_per_step_windows": {"median": win_dense[len(win_dense) // 2], "min": win_dense[0], "max": win_dense[-1], "windows": len(win_dense),
+                                    "note": "further windows of K steps each after the timed one (rank 0's clock)"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.points}-point cloud x {args.wps_per_gpu} waypoints per GPU "
                                    f"({w_total} total)" + (f" x {args.cameras} cameras" if args.cameras > 1 else "") +
                                    ", fwd + bwd (x,y,z,quaternion) gradients",
                        "n_points": args.points, "waypoints_total": w_total, "cameras": args.cameras,
                        "parallelism": f"waypoint-shard x{n_gpus}" if n_gpus > 1 else "single GPU",
-                       "launch": "HIP graph replay of the step's launches" if use_graph else "one host call per library entry point",
+                       "launch": "HIP graph replay of the step's launches" if use_graph else
+                                 ("tohip_traj_forward_backward: one host call, four launches" if (shard is None and args.fused_step == "on") else
+                                  "tohip_traj_forward -> [all-reduce] -> tohip_traj_reward_backward [-> all-gather]: five launches"),
                        "mode": "dense: every (point, waypoint) pair evaluated, no data-dependent skipping; the 0.7 % of "
-                               "(256-point slot, waypoint) pairs that can contribute are then revisited by the sparse kernels",
+                               "(256-point slot, waypoint) pairs that can contribute are then revisited by the sparse kernel",
                        "loss_vis": float(out[0][1].item())},
             "roofline": {"bound": "valu", "kernel": PASS1, "achieved": achieved, "peak": peak, "unit": "G VALU-issue-cycles/s",
                          "frac": achieved / peak, "traffic": traffic,
+                         "isa_mix_stale": bool(mix.get("stale")),   # True: the kernels' sources changed after the mix was counted
+                         "kernel_ms_per_step_sum": sum(v[0] for v in kern.values()) / args.steps,
                          "kernel_ms_per_launch": p1_ms, "kernel_share_of_step": p1_ms / step_ms,
                          "issue_cycles_per_launch": issue_cycles,
                          "isa_mix_per_wave_iteration": mix, "issue_cycles_per_instruction": ISSUE_CYCLES,
@@ -495,7 +563,7 @@ def main():
                                      "diagnostic pass): what the blocks themselves take; kernel_ms_per_launch also holds the "
                                      "launch / queueing share of a back-to-back dependent launch"},
                          "hbm_counter_frac": (traffic / (p1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "traffic_note": "HBM bytes per launch from profiles/r02_bench_dense_pmc.json (separate --pmc passes of "
+                         "traffic_note": "HBM bytes per launch from profiles/r03_bench_dense_pmc.json (separate --pmc passes of "
                                          "this command: 2 x FETCH_SIZE + WRITE_SIZE); a few per cent of the HBM peak: points live "
                                          "in registers, waypoints stream through SGPRs, the 8-byte (min, max) stores go out as "
                                          "32-byte sectors",
@@ -511,6 +579,7 @@ def main():
         line["culled_exact"] = {
             "value": evals_per_step * args.steps / dt_c, "unit": "evals/s", "ms_per_step": 1e3 * dt_c / args.steps,
             "bitwise_identical_to_dense": bool(same),
+            "ms_per_step_windows": {"median": win_culled[len(win_culled) // 2], "min": win_culled[0], "max": win_culled[-1]},
             "kernel_ms": {k: v[0] / args.steps for k, v in kern_c.items()},
             "note": "library default (what ModelTraj runs): pass 1 skips pairs that provably can neither be a waypoint's maximum "
                     "nor contribute, via a Morton-sorted cloud, per-256-point bounding spheres and a distance bound on p"}
@@ -525,6 +594,8 @@ def main():
                 "value": 1.3e7, "unit": "evals/s", "cores": 8,
                 "note": "the reference ITSELF (torch CPU, fwd+bwd, 1 M x 16) timed in the build container — it cannot travel to the "
                         "GPU box; profiles/r01_reference_cpu_timing.txt"}
+        if comm is not None:
+            line["comm"] = comm
         print(json.dumps(line), flush=True)
     if n_gpus > 1 or forced:
         dist.barrier()

@@ -4,12 +4,12 @@
 #   (FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ_* in a third), as MI355X_MICROARCH.md prescribes.
 # Afterwards, here:  python tools/summarize_profiles.py gpurun_out/prof_<tag> rNN   -> profiles/rNN_*
 set -euo pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-common="--steps 5 --warmup 1 --cpu-wps 0"
+common="--steps 20 --warmup 5 --cpu-wps 0 --dropin off --density off"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/dense" -o dense -- python3 "$root/bench.py" $common --mode dense > "$out/dense.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/culled" -o culled -- python3 "$root/bench.py" $common --mode culled > "$out/culled.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -o pmc -- python3 "$root/bench.py" $common --mode dense > "$out/pmc_fetch.log" 2>&1

@@ -21,6 +21,16 @@ DENSE_PASS1 = "k_traj_pass1_denseILb0E"   # <OCC = false>
 TRANS = re.compile(r"v_(exp|log|rcp|rsq|sqrt|sin|cos)_")
 
 
+def source_hash():
+    """sha256 of the sources the dense loop is compiled from: bench.py refuses a mix that was counted on other code."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("common.hpp", "traj_kernels.hip"):
+        with open(os.path.join(REPO, "trajectory_optimization_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def disassemble():
     out = os.path.join(tempfile.gettempdir(), "trajopt_isa.s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17",
@@ -59,6 +69,46 @@ def kernels(text):
     return res
 
 
+def hot_loop_ops(text, kernel_prefix, marker="s_load_dwordx16"):
+    """Mnemonics of the innermost loop of `kernel_prefix` that contains `marker`, WITHOUT its cold regions: a region skipped by an
+    `s_cbranch_execz` that holds a global atomic and no store (pass 1 folds a wave's extrema into the waypoint's running ones and
+    lists a candidate slot only when the probe's bounds are beaten: a few dozen times per waypoint and launch)."""
+    i = next(k for k, l in enumerate(text) if l.startswith(kernel_prefix))
+    j = i
+    while "s_endpgm" not in text[j]:
+        j += 1
+    body = text[i:j]
+    k = next(n for n, l in enumerate(body) if marker in l)
+    hdr = None
+    for n in range(k, -1, -1):
+        m = re.search(r"in Loop: Header=BB(\w+)", body[n])
+        if m:
+            hdr = m.group(1)
+            break
+    lines = [l.strip() for l in body if l.strip()]
+    # the loop's blocks, in layout order
+    sel, keep = [], False
+    for l in lines:
+        if re.match(r"^(\.LBB\w+:|; %bb\.\d+:)", l):
+            keep = f"Header=BB{hdr} " in l + " " or l.startswith(f".LBB{hdr}:")
+            sel.append(("label", l.split(":")[0]))
+            continue
+        if keep and not l.startswith((".", ";", "/")) and not l.endswith(":"):
+            sel.append(("op", l))
+    cold = [False] * len(sel)
+    for a, (kind, l) in enumerate(sel):
+        if kind == "op" and l.startswith("s_cbranch_execz"):
+            tgt = l.split()[1]
+            b = next((n for n in range(a + 1, len(sel)) if sel[n] == ("label", tgt)), None)
+            if b is None:
+                continue
+            region = [x for kk, x in sel[a + 1:b] if kk == "op"]
+            if any(x.startswith("global_atomic") for x in region) and not any(x.startswith("global_store") for x in region):
+                for n in range(a + 1, b):
+                    cold[n] = True
+    return [l.split()[0] for n, (kind, l) in enumerate(sel) if kind == "op" and not cold[n]], sum(1 for n, (kind, _) in enumerate(sel) if kind == "op" and cold[n])
+
+
 def classes(ops):
     c = collections.Counter(ops)
     trans = sum(v for k, v in c.items() if TRANS.match(k))
@@ -72,17 +122,20 @@ def classes(ops):
 
 def main():
     args = sys.argv[1:]
-    ks = kernels(disassemble())
+    text = disassemble()
+    ks = kernels(text)
     if args and args[0] == "--json":
         name = next(n for n in ks if DENSE_PASS1 in n)
-        # the waypoint loop: the one that loads a waypoint record (s_load_dwordx16)
-        body = next(ops for ops in ks[name][2].values() if "s_load_dwordx16" in ops)
+        # the waypoint loop: the one that loads a waypoint record (s_load_dwordx16), without its cold regions
+        body, n_cold = hot_loop_ops(text, name)
         c, cl = classes(body)
         out = dict(kernel=name, points_per_lane=8, evaluations_per_iteration=512,
                    packed_f32=cl["packed_f32"], transcendental=cl["transcendental"], other_valu=cl["other_valu"],
-                   salu_smem=cl["salu_smem"], vmem=cl["vmem"],
+                   salu_smem=cl["salu_smem"], vmem=cl["vmem"], cold_instructions_excluded=n_cold, source_hash=source_hash(),
                    note="VALU instructions of one (wave, waypoint) iteration of the dense inner loop (hipcc -O3 --offload-arch=gfx950, "
-                        "ROCm 7.2); a lane owns 8 points = 4 packed pairs; per evaluation: 26 FMA-class operations (13 packed instructions per pair), 4 transcendentals",
+                        "ROCm 7.2); a lane owns 8 points = 4 packed pairs; per evaluation: 26 FMA-class operations (13 packed instructions per pair), 4 transcendentals; "
+                        "the regions a wave enters only when its slot beats the probe's bounds (atomicMin / atomicMax of the running extrema: a few dozen "
+                        "times per waypoint and launch) are not counted",
                    mnemonics=dict(c.most_common()))
         with open(args[1], "w") as f:
             json.dump(out, f, indent=1)

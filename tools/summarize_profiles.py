@@ -42,8 +42,8 @@ def main():
         shutil.copy(os.path.join(src, "hpr", "hpr_kernel_stats.csv"), os.path.join(dst, f"{tag}_hpr_batched_kernel_stats.csv"))
     if os.path.exists(os.path.join(src, "hpr1m", "hpr1m_kernel_stats.csv")):
         shutil.copy(os.path.join(src, "hpr1m", "hpr1m_kernel_stats.csv"), os.path.join(dst, f"{tag}_hpr_1m_kernel_stats.csv"))
-    out = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --kernel-trace -- python3 bench.py --steps 5 --warmup 1 "
-                      "--cpu-wps 0 --mode dense   (three separate runs, tools/collect_profiles.sh)",
+    out = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --kernel-trace -- python3 bench.py --steps 20 --warmup 5 "
+                      "--cpu-wps 0 --dropin off --density off --mode dense   (three separate runs, tools/collect_profiles.sh)",
            "units": "FETCH_SIZE/WRITE_SIZE in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)",
            "kernels": {}}
     ks = out["kernels"]
