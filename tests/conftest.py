@@ -25,8 +25,19 @@ def load_golden(name):
                                extent=(30.0, 30.0, 30.0) if name.startswith("frustum") else (40.0, 40.0, 4.0))
         if "centre" in d:
             pts = pts - d["centre"].astype(np.float32)
+        if "dup" in d:   # exact duplicate rows: the generator's recipe (tests/golden/make_golden.py)
+            pts, d["source_row"] = synth.with_duplicate_rows(pts, d["dup"], int(d["seed"]) + 1000)
+            assert len(pts) == int(d["n_rows"])
         d["points"] = pts
     return d
+
+
+def lowest_identical_rows(points, idx):
+    """idx with every row replaced by the lowest-index row of `points` that has the same coordinates (ascending, unique): the
+    rule the GPU hull reports duplicated rows by."""
+    pts = np.ascontiguousarray(points)
+    _, first, inverse = np.unique(pts.view([("", pts.dtype)] * 3).ravel(), return_index=True, return_inverse=True)
+    return np.unique(first[inverse.ravel()[np.asarray(idx)]])
 
 
 def rel_inf(a, b):

@@ -376,6 +376,21 @@ def gen_hard():
              hull_vertices=hull.vertices.astype(np.int32),
              origin_is_vertex=np.bool_(hull.vertices[-1] == n),
              flipped_head=flipped[:64])
+    # exact duplicate rows (raw lidar clouds have them), below and above the size at which the GPU build starts on a sample
+    for name, n, seed in [("hpr_synth_dups_20k", 20000, 11), ("hpr_synth_dups_120k", 120000, 12)]:
+        centre = np.asarray((30.0, 5.0, 1.0), dtype=np.float32)
+        base = synth.make_cloud(n, seed=seed) - centre
+        _, m0 = ref_tools.hidden_pts_removal(torch.from_numpy(base), CPU)
+        vis0 = np.flatnonzero(m0.numpy())
+        rng = np.random.default_rng(seed + 500)
+        dup = np.concatenate([vis0[rng.integers(0, len(vis0), 300)], rng.integers(0, n, 300)])   # copies of visible points and of others
+        pts, src = synth.with_duplicate_rows(base, dup, seed + 1000)
+        C = torch.from_numpy(pts)
+        hull = ref_tools.convexHull(ref_tools.sphericalFlip(C, CPU, 2), CPU)
+        vis, mask = ref_tools.hidden_pts_removal(C, CPU)
+        save(name, seed=seed, n=n, centre=centre, dup=dup.astype(np.int32), n_rows=np.int64(len(pts)),
+             visible_idx=np.flatnonzero(mask.numpy()).astype(np.int32), hull_vertices=hull.vertices.astype(np.int32),
+             origin_is_vertex=np.bool_(hull.vertices[-1] == len(pts)))
     # origin strictly interior: a shell of points around the viewpoint
     rng = np.random.default_rng(9)
     d = rng.standard_normal((5000, 3))

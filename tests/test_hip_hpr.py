@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_inf
+from conftest import load_golden, lowest_identical_rows, rel_inf
 from trajectory_optimization_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -246,11 +246,11 @@ def test_hpr_batched_large_and_degenerate_segments_sample_phase(dev):
 
 def test_hull_with_exact_copies_of_points(dev):
     """Duplicated rows (a copy of a hull vertex lies ON the hull whatever the rounding of its plane distance says): as many
-    vertices as Qhull finds, at the same coordinates — which of two identical rows carries the vertex is the library's choice
-    (the lower index in a build without the sample phase)."""
+    vertices as Qhull finds, at the same coordinates, each reported at the LOWEST row that has its coordinates — with and without
+    the sample phase of the build (the larger cloud goes through it)."""
     from scipy.spatial import ConvexHull
     from trajectory_optimization_amd import ops
-    for n, seed in ((20_000, 61), (120_000, 62)):   # the larger one goes through the sample phase of the build
+    for n, seed in ((20_000, 61), (120_000, 62)):
         base = synth.make_cloud(n, seed=seed)
         ref0 = np.sort(ConvexHull(base.astype(np.float64)).vertices)
         rng = np.random.default_rng(seed)
@@ -260,8 +260,31 @@ def test_hull_with_exact_copies_of_points(dev):
         ref = ConvexHull(pts.astype(np.float64)).vertices
         assert len(got) == len(ref) == len(ref0)
         assert np.array_equal(np.unique(pts[got], axis=0), np.unique(pts[ref], axis=0))
-        if n < 32768:   # (the sample phase of a large build may meet the copy first)
-            assert np.array_equal(got, ref0)   # every vertex is reported at its first row
+        assert np.array_equal(got, ref0)   # every vertex is reported at its first row (the copies were appended)
+        assert np.array_equal(got, lowest_identical_rows(pts, ref))
+
+
+@pytest.mark.parametrize("name", ["hpr_synth_dups_20k", "hpr_synth_dups_120k"])
+def test_hpr_with_duplicate_rows_vs_reference(dev, name):
+    """The reference's hidden_pts_removal (/root/reference/src/tools.py:67-85) on clouds with exact duplicate rows, copies before
+    and after their originals (fixtures from the reference itself, 20 k and 120 k rows: without and with the sample phase of the
+    GPU build).  Which of several identical rows Qhull reports follows its insertion history (the first copy in ~70 % of the
+    cases, the last in the others) and no parallel build can reproduce it; what is pinned: the SAME visible points — count and
+    coordinates — each reported at the lowest row with its coordinates, i.e. Qhull's set mapped through that rule, exactly."""
+    from trajectory_optimization_amd.tools import hidden_pts_removal, convexHull, sphericalFlip
+    d = load_golden(name)
+    assert bool(d["origin_is_vertex"])   # (else the reference's drop-last quirk would pick between copies)
+    pts = torch.from_numpy(d["points"]).to(dev)
+    for _ in range(3):   # claims land in a different order from build to build; the result must not move
+        vis, mask = hidden_pts_removal(pts, dev)
+        got = np.flatnonzero(mask.cpu().numpy())
+        ref = d["visible_idx"]
+        assert len(got) == len(ref)
+        assert np.array_equal(np.unique(d["points"][got], axis=0), np.unique(d["points"][ref], axis=0))
+        assert np.array_equal(got, lowest_identical_rows(d["points"], ref))
+        hull = convexHull(sphericalFlip(pts, dev, 2), dev).vertices.cpu().numpy()
+        assert np.array_equal(hull[:-1], got) and hull[-1] == len(d["points"])
+    assert int((got != ref).sum()) > 0   # the fixture does exercise the difference between the two rules
 
 
 def test_hull_builds_repeat(dev):

@@ -116,7 +116,7 @@ def test_hard_pipeline_bit_exact():
 
 
 @pytest.mark.parametrize("name", ["hpr_bundled_world", "hpr_synth_10k", "hpr_synth_100k", "hpr_synth_outside",
-                                  "hpr_shell_origin_inside"])
+                                  "hpr_shell_origin_inside", "hpr_synth_dups_20k", "hpr_synth_dups_120k"])
 def test_hpr_index_sets(name):
     d = load_golden(name)
     vis, mask = oracle.hidden_pts_removal(d["points"])

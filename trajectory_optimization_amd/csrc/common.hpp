@@ -7,6 +7,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "../../include/trajopt_hip.h"
 
 #define TO_WAVE 64
@@ -84,6 +88,14 @@ struct CloudView {
 static inline int probe_step(int64_t n) { const int64_t s = n / 4096; return (int)(s < 1 ? 1 : s); }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// LSD radix sort of (key, value) pairs on bits [begin_bit, end_bit) — rocPRIM's device primitive, stable (equal keys keep their
+// order: the Morton sorts rely on it for determinism).  tmp == NULL: only the scratch size is returned in `bytes`.
+template <class Key, class Val>
+static inline hipError_t sort_pairs(void* tmp, size_t& bytes, const Key* keys_in, Key* keys_out, const Val* vals_in, Val* vals_out, int n,
+                                    int begin_bit, int end_bit, hipStream_t st) {
+    return rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, (unsigned)n, (unsigned)begin_bit, (unsigned)end_bit, st);
+}
 
 // Packed cloud blob (tohip_pack_cloud): [x|y|z f32, 3*npad] [perm i32, npad] [bounds float4, npad/256] [inv i32, npad]
 // [samples x|y|z f32, 3*TO_PROBE_MAX]

@@ -8,7 +8,6 @@
 // These produce index sets that must equal the reference's bit for bit, so the arithmetic is the
 // reference CPU path's, operation by operation: K @ points as the k-ordered FMA chain of its 3x3 sgemm,
 // IEEE division, torch.linalg.norm's FMA chain (all pinned on fixtures, tests/test_oracle_golden.py).
-#include <hipcub/hipcub.hpp>
 
 #include "common.hpp"
 
@@ -145,7 +144,7 @@ inline PackPlan pack_plan(int64_t n) {
     p.off_vals2 = o; o += align_up(sizeof(int) * (size_t)n, 256);
     p.off_bbox = o;  o += 256;
     size_t tmp = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
+    (void)sort_pairs(nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
                                              (int*)nullptr, (int)n, 0, 30, (hipStream_t)0);
     p.tmp_bytes = tmp;
     p.off_tmp = o;   o += align_up(tmp, 256);
@@ -182,7 +181,7 @@ extern "C" int tohip_pack_cloud(const float* xyz, int64_t n, int sort, void* pac
         k_morton<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, bbox, keys, vals);
         TO_HIP_CHECK_LAUNCH();
         size_t tmp = pl.tmp_bytes;
-        e = hipcub::DeviceRadixSort::SortPairs(ws + pl.off_tmp, tmp, keys, keys2, vals, vals2, (int)n, 0, 30, st);
+        e = sort_pairs(ws + pl.off_tmp, tmp, keys, keys2, vals, vals2, (int)n, 0, 30, st);
         if (e != hipSuccess) return (int)e;
         order = vals2;  // radix sort is stable: equal cells keep the caller's order (deterministic)
     } else {

@@ -27,6 +27,9 @@
 #include <cstdlib>
 #include <vector>
 
+#include <map>
+#include <memory>
+
 #include "common.hpp"
 
 namespace hull {
@@ -165,8 +168,13 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * m1); if (b) b->vals = (int*)p;
     p = take(sizeof(unsigned) * 6 * nseg); if (b) b->seg_bbox = (unsigned*)p;
     size_t tmp = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                             (const int*)nullptr, (int*)nullptr, (int)m1, 0, 64, (hipStream_t)0);
+    (void)sort_pairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int*)nullptr, (int)m1, 0, 64,
+                     (hipStream_t)0);
+    {
+        size_t tmp32 = 0;   // a single segment sorts 30-bit keys as 32-bit words
+        (void)sort_pairs(nullptr, tmp32, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (int)m1, 0, 30, (hipStream_t)0);
+        if (tmp32 > tmp) tmp = tmp32;
+    }
     p = take(tmp); if (b) { b->sort_tmp = p; b->sort_tmp_bytes = tmp; }
     if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; b->origin = 1; b->hbits = 0; b->early_out = 0; }
     return o;
@@ -1153,12 +1161,42 @@ __global__ void __launch_bounds__(TO_BLOCK) k_rebuild_candidates(Bufs b, int par
     }
 }
 
+// the 30-bit Morton cell of sorted position j — what k_sort_keys computed for it (same operations on the same floats)
+__device__ __forceinline__ unsigned morton_cell(const Bufs& b, int j, int sg) {
+    const float c[3] = {(float)b.px[j], (float)b.py[j], (float)b.pz[j]};
+    unsigned q[3];
+    for (int k = 0; k < 3; ++k) {
+        const float lo = fkey_inv(b.seg_bbox[6 * sg + k]), hi = fkey_inv(b.seg_bbox[6 * sg + 3 + k]);
+        const float t = (c[k] - lo) / (hi - lo) * 1023.0f;
+        q[k] = t >= 0.0f ? (t < 1023.0f ? (unsigned)t : 1023u) : 0u;
+    }
+    return spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+}
+
+// Which of several IDENTICAL rows carries a hull vertex is the build's business (copies of a vertex are treated as lying on the
+// hull), and it depends on the schedule (a large build's sample may meet a later copy first).  Reported is always the row with
+// the LOWEST original index: identical rows share a Morton cell, the sort is stable, so inside the run of equal cells around the
+// vertex the first row with its coordinates is that one.  (Qhull's own choice among identical rows follows its insertion history
+// — the first copy in ~70 % of the cases, the last in the others — and cannot be reproduced by a parallel build.)
+__device__ __forceinline__ int lowest_identical_row(const Bufs& b, int j) {
+    const int e = b.perm[j];
+    const int sg = find_seg(b, e);
+    const int lo = b.seg_off[sg], hi = b.seg_off[sg + 1];
+    const unsigned cell = morton_cell(b, j, sg);
+    const double x = b.px[j], y = b.py[j], z = b.pz[j];
+    int first = j;
+    for (int i = j - 1; i >= lo && morton_cell(b, i, sg) == cell; --i)
+        if (b.px[i] == x && b.py[i] == y && b.pz[i] == z) first = i;
+    (void)hi;
+    return first;
+}
+
 __global__ void __launch_bounds__(TO_BLOCK) k_mark_vertices(Bufs b) {
     const int nf = min(b.ctrl[kCtrlNFaces + 8], b.fcap);  // every face created (the published count lags by the last round)
     const int stride = gridDim.x * TO_BLOCK;
     for (int f = blockIdx.x * TO_BLOCK + threadIdx.x; f < nf; f += stride)
         if (b.fflags[f] & 1)
-            for (int k = 0; k < 3; ++k) b.vflag[b.perm[b.fv[3 * f + k]]] = 1;  // flags in the caller's (expanded) numbering
+            for (int k = 0; k < 3; ++k) b.vflag[b.perm[lowest_identical_row(b, b.fv[3 * f + k])]] = 1;  // flags in the caller's (expanded) numbering
 }
 
 // ---- compaction of the live-point list (ordered: the Morton locality stays) -----------------------
@@ -1282,9 +1320,9 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         size_t tmp = b.sort_tmp_bytes;
         // stable: equal cells keep the caller's order
         const hipError_t es = b.nseg == 1
-            ? hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, tmp, reinterpret_cast<const unsigned*>(b.keys), reinterpret_cast<unsigned*>(b.keys2),
+            ? sort_pairs(b.sort_tmp, tmp, reinterpret_cast<const unsigned*>(b.keys), reinterpret_cast<unsigned*>(b.keys2),
                                                  b.vals, b.perm, b.m1, 0, 30, st)
-            : hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, tmp, b.keys, b.keys2, b.vals, b.perm, b.m1, 0, 30 + seg_bits, st);
+            : sort_pairs(b.sort_tmp, tmp, b.keys, b.keys2, b.vals, b.perm, b.m1, 0, 30 + seg_bits, st);
         if (es != hipSuccess) return (int)es;
     }
     k_load<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, pts, with_origin);
@@ -1314,12 +1352,28 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         int* buf[2] = {nullptr, nullptr};
         hipEvent_t ev[2] = {nullptr, nullptr};
         bool ok = false;
-        Pinned() {
-            ok = hipHostMalloc((void**)&buf[0], sizeof(int) * kRead) == hipSuccess && hipHostMalloc((void**)&buf[1], sizeof(int) * kRead) == hipSuccess &&
+        Pinned() {   // on the device that is current: events belong to a device; portable pinned memory is usable from all
+            ok = hipHostMalloc((void**)&buf[0], sizeof(int) * kRead, hipHostMallocPortable) == hipSuccess &&
+                 hipHostMalloc((void**)&buf[1], sizeof(int) * kRead, hipHostMallocPortable) == hipSuccess &&
                  hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
         }
+        ~Pinned() {
+            for (int i = 0; i < 2; ++i) {
+                if (buf[i]) (void)hipHostFree(buf[i]);
+                if (ev[i]) (void)hipEventDestroy(ev[i]);
+            }
+        }
+        Pinned(const Pinned&) = delete;
+        Pinned& operator=(const Pinned&) = delete;
     };
-    static thread_local Pinned pin;  // lives as long as the thread: a build must not pay two pinned allocations
+    // one set per (thread, device): it lives as long as the thread (a build must not pay two pinned allocations), and a build on
+    // another GPU of the same process gets events of ITS device (an event recorded on a stream of another device is an error)
+    static thread_local std::map<int, std::unique_ptr<Pinned>> pins;
+    int cur_dev = 0;
+    if (hipGetDevice(&cur_dev) != hipSuccess) return TOHIP_EINVAL;
+    std::unique_ptr<Pinned>& pin_slot = pins[cur_dev];
+    if (!pin_slot) pin_slot.reset(new Pinned());
+    Pinned& pin = *pin_slot;
     if (!pin.ok) return TOHIP_EINVAL;
     const int* h = pin.buf[0];
     int wslot = 0, rslot = 0, inflight = 0;
@@ -1505,7 +1559,10 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
             k_live_count<<<ntl, TO_BLOCK, 0, st>>>(b, nlive, b.tile_cnt);
             k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(b.tile_cnt, ntl, b.tile_off, b.ctrl + kCtrlNLive);
             k_live_write<<<ntl, TO_BLOCK, 0, st>>>(b, nlive, b.tile_off);
-            TO_HIP_CHECK_LAUNCH();
+            {
+                const hipError_t el = hipGetLastError();   // a readback may be in flight on the shared pinned buffers: drain before leaving
+                if (el != hipSuccess) return drain((int)el);
+            }
             int* t = b.live; b.live = b.live2; b.live2 = t;
             batches_since_compaction = 0;
             live_bound = nlive;  // the new count is on the device only; this bounds it

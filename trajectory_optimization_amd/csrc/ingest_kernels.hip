@@ -7,7 +7,6 @@
 //                                                          algorithm: field filter -> voxel keys -> centroid per voxel,
 //                                                          output in ascending voxel-key order)
 //   pc_to_voxel occupancy grid                              /root/reference/src/pointcloud_utils.py:279-288
-#include <hipcub/hipcub.hpp>
 
 #include "common.hpp"
 
@@ -233,7 +232,7 @@ inline VoxPlan vox_plan(int64_t n) {
     p.off_toff = o;  o += align_up(sizeof(int) * ntiles, 256);
     p.off_ctrl = o;  o += 256;
     size_t tmp = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+    (void)sort_pairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                              (const int*)nullptr, (int*)nullptr, (int)n, 0, 64, (hipStream_t)0);
     p.tmp_bytes = tmp;
     p.off_tmp = o;   o += align_up(tmp, 256);
@@ -285,7 +284,7 @@ extern "C" int tohip_voxel_grid(const float* xyz, int64_t n, float leaf_x, float
     k_vox_keys<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, vp, ctrl, keys, vals);
     TO_HIP_CHECK_LAUNCH();
     size_t tmp = pl.tmp_bytes;
-    e = hipcub::DeviceRadixSort::SortPairs(ws + pl.off_tmp, tmp, keys, keys2, vals, vals2, (int)n, 0, 64, st);
+    e = sort_pairs(ws + pl.off_tmp, tmp, keys, keys2, vals, vals2, (int)n, 0, 64, st);
     if (e != hipSuccess) return (int)e;
     k_vox_heads<<<(int)nb, TO_BLOCK, 0, st>>>(keys2, n, head);
     TO_HIP_CHECK_LAUNCH();

@@ -514,10 +514,10 @@ class ModelPose(nn.Module):
     """Single camera pose optimisation model (/root/reference/src/model.py:65-127)."""
 
     def __init__(self,
-                 points: torch.tensor,
-                 trans0: torch.tensor,  # t = (x, y, z), example: torch.tensor([[0., 0., 0.]])
-                 q0: torch.tensor,  # q = (w, x, y, z), example: torch.tensor([[1., 0., 0., 0.]])
-                 intrins: torch.tensor,  # torch.tensor, size=(3, 3)
+                 points: torch.tensor,   # the cloud, (N, 3), world frame
+                 trans0: torch.tensor,   # initial camera position, shape (1, 3)
+                 q0: torch.tensor,       # initial camera orientation, shape (1, 4), scalar part first
+                 intrins: torch.tensor,  # pinhole matrix K, shape (3, 3)
                  img_width, img_height,
                  min_dist=1.0, max_dist=5.0,
                  device=torch.device('cuda:0')):
@@ -542,7 +542,7 @@ class ModelPose(nn.Module):
         self.K = torch.as_tensor(intrins, dtype=torch.float32).to(self.device)
         self.img_width, self.img_height = float(img_width), float(img_height)
         self.eps = 1e-6
-        self.pc_clip_limits = [min_dist, max_dist]  # [m]
+        self.pc_clip_limits = [min_dist, max_dist]  # near / far range of the distance mask, metres
 
         self.to(self.device)
         self._cloud = ops.PackedCloud(self.points)
@@ -578,7 +578,7 @@ class ModelPose(nn.Module):
         return loss
 
     def criterion(self, observations):
-        # transform observations to loss function
+        # the more (softly) observed points, the smaller the loss: reciprocal of their sum (/root/reference/src/model.py:124-127)
         loss = 1. / (torch.sum(observations) + self.eps)
         return loss
 
@@ -610,10 +610,10 @@ class ModelTraj(nn.Module):
     """
 
     def __init__(self,
-                 points: torch.tensor,
-                 wps_poses: torch.tensor,  # (N, 3): [[[x0, y0, z0]], [[x1, y1, z1]], ...]
-                 wps_quats: torch.tensor,  # (N, 4): torch.tensor: [w, x, y, z]-format
-                 intrins: torch.tensor,  # torch.tensor, size=(3, 3)
+                 points: torch.tensor,     # the cloud, (N, 3), world frame
+                 wps_poses: torch.tensor,  # waypoint positions, (W, 3), one row per waypoint
+                 wps_quats: torch.tensor,  # waypoint orientations, (W, 4), scalar part first
+                 intrins: torch.tensor,    # pinhole matrix K, shape (3, 3)
                  img_width, img_height,
                  min_dist=1.0, max_dist=5.0,
                  smoothness_weight=14.0, traj_length_weight=0.02,
@@ -628,10 +628,10 @@ class ModelTraj(nn.Module):
         self.points = torch.as_tensor(points, dtype=torch.float32).to(self.device)
         self.rewards = None
         self.observations = None
-        self.lo_sum = 0.0  # log odds sum for the entire point cloud for the whole trajectory
+        self.lo_sum = 0.0  # attribute kept for the reference's surface (its accumulated log-odds); the kernels hold theirs in packed order
 
-        self.poses0 = torch.as_tensor(wps_poses, dtype=torch.float32).to(self.device)  # (N, 3)
-        self.quats0 = torch.as_tensor(wps_quats, dtype=torch.float32).to(self.device)  # (N, 4)
+        self.poses0 = torch.as_tensor(wps_poses, dtype=torch.float32).to(self.device)  # the trajectory as given: criterion measures against it
+        self.quats0 = torch.as_tensor(wps_quats, dtype=torch.float32).to(self.device)
 
         self.poses = nn.Parameter(deepcopy(self.poses0))
         self.quats = nn.Parameter(deepcopy(self.quats0))
@@ -639,7 +639,7 @@ class ModelTraj(nn.Module):
         self.K = torch.as_tensor(intrins, dtype=torch.float32).to(self.device)
         self.img_width, self.img_height = float(img_width), float(img_height)
         self.eps = 1e-6
-        self.pc_clip_limits = [min_dist, max_dist]  # [m]
+        self.pc_clip_limits = [min_dist, max_dist]  # near / far range of the distance mask, metres
 
         self.loss = {'vis': float('inf'),
                      'length': float('inf'),
@@ -715,12 +715,10 @@ class ModelTraj(nn.Module):
         return step
 
     def forward(self,
-                vis_wps_dist=0.5,  # distance between neighbor waypoints to estimate visibility
+                vis_wps_dist=0.5,  # metres between the waypoints whose visibility is evaluated (every wps_step-th one)
                 debug=False):
-        """
-        Trajectory evaluation based on visibility estimation from its waypoints.
-        traj_score = log_odds_sum([visibility_estimation(wp) for wp in traj_waypoints])
-        """
+        """/root/reference/src/model.py:200-242: soft visibility of every point from every wps_step-th waypoint, normalised per
+        waypoint, clipped, turned into log-odds and summed over the waypoints; rewards = sigmoid of the sum; returns criterion()."""
         t0 = time()
         N_wps = len(self.poses)
         wps_step = self._wps_step(vis_wps_dist)
@@ -750,16 +748,17 @@ class ModelTraj(nn.Module):
         return loss
 
     def criterion(self, rewards):
-        # transform observations to loss function: loss = 1 / mean(prob(observed))
+        # the four terms of /root/reference/src/model.py:244-260, op by op (the fused node computes the same on the device)
+        # visibility: reciprocal of the mean reward
         self.loss['vis'] = 1. / (torch.mean(rewards) + self.eps)
 
-        # penalties for being far from initial waypoints
+        # the first waypoint should stay where the trajectory started
         self.loss['l2'] = torch.linalg.norm(self.poses[0] - self.poses0[0])
 
-        # smoothness estimation based on average angles between waypoints: the bigger the angle the better
+        # straighter is better: weight over the mean interior angle of the polyline
         self.loss['smooth'] = self.smoothness_weight / (mean_angle_calc(self.poses, self.eps) + self.eps)
 
-        # penalty for trajectory length (compared to initial one)
+        # the path should keep its initial length
         if self._length0 is None:
             self._length0 = length_calc(self.poses0)
         self.loss['length'] = self.traj_length_weight * torch.abs(length_calc(self.poses) - self._length0)

@@ -153,6 +153,10 @@ def optimize_trajectories(models, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewa
             raise ValueError("optimize_trajectories: the models must share the cloud, camera, rig, mode, waypoint count and step")
         if m is not m0 and m.points.data_ptr() != m0.points.data_ptr() and not torch.equal(m.points, m0.points):
             raise ValueError("optimize_trajectories: the models must be built on the same points")
+        if m is not m0 and (m.device != m0.device or float(m.eps) != float(m0.eps)):
+            raise ValueError("optimize_trajectories: the models must live on one device and share eps")
+        if m is not m0 and rig is not None and (m._rig.n_cams != rig.n_cams or not torch.equal(m._rig.q, rig.q) or not torch.equal(m._rig.t, rig.t)):
+            raise ValueError("optimize_trajectories: the models must share the camera rig (extrinsics differ)")
     n_eval = (W + step_w - 1) // step_w
     C = rig.n_cams if rig else 1
     f32 = dict(dtype=torch.float32, device=dev)

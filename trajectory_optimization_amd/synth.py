@@ -72,3 +72,12 @@ def camera_rig(n_cams=5):
     offs = np.deg2rad(np.array([0.0, 72.0, -72.0, 144.0, -144.0][:n_cams]))
     q = np.stack([np.cos(offs / 2), np.zeros_like(offs), np.zeros_like(offs), np.sin(offs / 2)], axis=1)
     return q.astype(np.float32), np.zeros((n_cams, 3), dtype=np.float32)
+
+
+def with_duplicate_rows(base, dup, seed):
+    """`base` (n,3) plus copies of its rows `dup` (and of dup[:len(dup)//6] once more), all rows then shuffled (PCG64(seed)): a cloud
+    with exact duplicate rows whose copies sit before and after their originals.  -> (points, source row of each point)."""
+    src = np.concatenate([np.arange(len(base)), np.asarray(dup), np.asarray(dup)[:len(dup) // 6]])
+    order = np.random.default_rng(seed).permutation(len(src))
+    src = src[order]
+    return base[src].astype(np.float32), src
