@@ -228,6 +228,39 @@ def dropin_leg(device, steps=200, warmup=10):
         n_eval = (len(poses) + m._wps_step(vwd) - 1) // m._wps_step(vwd)
         out[name] = {"points": int(pts.shape[0]), "waypoints": int(len(poses)), "waypoints_evaluated": int(n_eval), "steps": steps,
                      "mode": "culled (library default)", "variants": res}
+    # the pose loop (/root/reference/src/pose_optimization.py:93-97,124-141) on the bundled cloud: ModelPose, two Adam groups
+    from trajectory_optimization_amd.model import ModelPose
+    from trajectory_optimization_amd.optimizer import optimize_pose
+    Pb = torch.from_numpy(b["pts"].astype(np.float32)).to(device)
+
+    def pose_model():
+        return ModelPose(Pb, torch.tensor([[6.0, 2.0, 0.0]]), torch.tensor([[1.0, 0.0, 0.0, 0.0]]), K, synth.IMG_WIDTH, synth.IMG_HEIGHT, device=device)
+    res = {}
+    for vname, mk in (("torch.optim.Adam", torch.optim.Adam), ("trajectory_optimization_amd.optimizer.Adam", HipAdam)):
+        m = pose_model()
+        opt = mk([{"params": [m.trans], "lr": 0.1}, {"params": [m.quat], "lr": 0.1}])
+
+        def ploop(n):
+            for _ in range(n):
+                opt.zero_grad()
+                loss = m()
+                loss.backward()
+                opt.step()
+            return loss
+        ploop(warmup)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        loss = ploop(steps)
+        torch.cuda.synchronize(device)
+        res[vname] = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / steps, "loss_after": float(loss.item())}
+    m = pose_model()
+    optimize_pose(m, n_opt_steps=warmup)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    optimize_pose(m, n_opt_steps=steps)
+    torch.cuda.synchronize(device)
+    res["launch_only(optimize_pose)"] = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / steps}
+    out["pose_bundled_40k"] = {"points": int(Pb.shape[0]), "steps": steps, "variants": res}
     out["note"] = ("the reference's loop, unchanged, over ModelTraj: zero_grad(); loss = model(); loss.backward(); step() — host-bound: "
                    "model() and backward() are one library call each, the rest of the time is torch's autograd engine and optimizer")
     return out

@@ -187,3 +187,26 @@ def test_captured_step_equals_the_eager_loop(dev):
     assert torch.equal(mg.poses.detach(), me.poses.detach()) and torch.equal(mg.quats.detach(), me.quats.detach())
     assert torch.equal(mg.rewards.detach(), me.rewards.detach())
     assert torch.equal(mg.poses.grad, me.poses.grad)
+
+
+@pytest.mark.parametrize("hpr", [False, True])
+def test_pose_backward_on_the_calling_thread_equals_the_engine(dev, hpr):
+    """ModelPose (/root/reference/src/pose_optimization.py:130-136): loss.backward() of the returned loss without the engine ==
+    through the engine, bit for bit; an in-place edit of the pose before backward() raises like torch's saved tensors."""
+    from trajectory_optimization_amd.model import ModelPose
+    pts = torch.from_numpy(synth.make_cloud(30_000, seed=8))
+    out = []
+    for fast in (True, False):
+        m = ModelPose(pts, torch.tensor([[1.0, 0.5, 0.0]]), torch.tensor([[0.9, 0.1, -0.3, 0.2]]), torch.from_numpy(K), IW, IH, device=dev)
+        m.fast_backward = fast
+        loss = m(hpr=hpr)
+        assert (type(loss) is not torch.Tensor) == fast
+        loss.backward()
+        m(hpr=hpr).backward()   # accumulates
+        out.append((loss.detach().clone(), m.trans.grad.clone(), m.quat.grad.clone(), m.observations.detach().clone()))
+        loss = m(hpr=hpr)
+        with torch.no_grad():
+            m.trans.add_(0.01)
+        with pytest.raises(RuntimeError, match="inplace|in-place"):
+            loss.backward()
+    assert all(torch.equal(a, b) for a, b in zip(*out))

@@ -346,9 +346,17 @@ __device__ __forceinline__ bool fold_extrema(Extrema* __restrict__ ext, int v, f
     return cand;
 }
 
-// a candidate slot enters the list k_traj_sparse walks, once (the exchange on its mark decides); arrival order
-__device__ __forceinline__ void list_candidate(int* __restrict__ cand, int* __restrict__ clist, int nslots, int slot) {
-    if (atomicExch(&cand[slot], 1) == 0) clist[atomicAdd(&cand[nslots], 1)] = slot;
+// A candidate slot enters the list k_traj_sparse walks, once: the exchange on its mark decides, issued when the slot's first
+// candidate waypoint turns up (claim) so that its round trip runs under the remaining waypoints; the append follows at the end.
+struct CandClaim {
+    int old = 1;          // the mark before this lane's exchange (0: this lane claimed the slot)
+    bool issued = false;
+};
+__device__ __forceinline__ void claim_candidate(CandClaim& c, int* __restrict__ cand, int slot) {
+    if (!c.issued) { c.old = atomicExch(&cand[slot], 1); c.issued = true; }
+}
+__device__ __forceinline__ void list_candidate(const CandClaim& c, int* __restrict__ cand, int* __restrict__ clist, int nslots, int slot) {
+    if (c.issued && c.old == 0) clist[atomicAdd(&cand[nslots], 1)] = slot;
 }
 
 __device__ __forceinline__ void pass1_eval(const EvalK& k, const WayRec& r, const float (&x)[TO_P], const float (&y)[TO_P],
@@ -419,7 +427,7 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
         load_points<P>(cv.soa, cv.npad, base, x, y, z);
         if (v0 == 0) { init_outputs(base, oi); init_outputs(base + 4, oi); }
         float2* prow = part + (int64_t)slot * V;
-        bool is_cand = false;
+        CandClaim claim;
         for (int v = v0; v < v1; ++v) {
             const int64_t uu = u + (v - v0);
             if (uu == q1) __builtin_amdgcn_s_setprio(2);
@@ -438,10 +446,10 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
             mx = half_max31_nn_fused(mx);
             if ((lane & 31) == 31) {
                 prow[v] = make_float2(mn, mx);
-                is_cand |= fold_extrema(ext, v, mn, mx, r);
+                if (fold_extrema(ext, v, mn, mx, r)) claim_candidate(claim, cand, slot);
             }
         }
-        if (is_cand) list_candidate(cand, clist, nslots, slot);
+        list_candidate(claim, cand, clist, nslots, slot);
         u += v1 - v0;
     }
     if (stamps != nullptr && threadIdx.x == 0) {
@@ -478,7 +486,7 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile
     float2* prow = part + (int64_t)slot * V;
     // waypoints that cannot be affected from this tile: min is the proven 0, max unknown (-inf: never flagged)
     if (v0 + lane < v1 && !((live >> lane) & 1ull)) prow[v0 + lane] = make_float2(0.f, -INFINITY);
-    bool is_cand = false;
+    CandClaim claim;
     while (live) {
         const int v = v0 + __builtin_ctzll(live);
         live &= live - 1ull;
@@ -490,10 +498,10 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile
         mx = wave_max63_nn_fused(mx);
         if (lane == 63) {
             prow[v] = make_float2(mn, mx);
-            is_cand |= fold_extrema(ext, v, mn, mx, r);
+            if (fold_extrema(ext, v, mn, mx, r)) claim_candidate(claim, cand, slot);
         }
     }
-    if (is_cand) list_candidate(cand, clist, nslots, slot);
+    list_candidate(claim, cand, clist, nslots, slot);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -812,8 +820,12 @@ __device__ __forceinline__ void write_minmax(const SparseArgs& a) {
 // block b of nb walks the candidate list with stride nb (one 16-wave block is resident per CU at this kernel's register count)
 template <int MODE, bool OCC>
 __device__ __forceinline__ void sparse_walk(const SparseArgs& a, int b, int nb, SparseLds& L) {
+    int slot = a.clist[b];   // requested with the list's length, not after it (the list's buffer holds one int per slot >= blocks)
     const int n = *a.clist_n;
-    for (int li = b; li < n; li += nb) sparse_slot<MODE, OCC>(a, a.clist[li], b & 7, L);
+    for (int li = b; li < n; li += nb) {
+        sparse_slot<MODE, OCC>(a, slot, b & 7, L);
+        if (li + nb < n) slot = a.clist[li + nb];
+    }
 }
 
 template <int MODE, bool OCC>

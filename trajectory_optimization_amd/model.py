@@ -145,28 +145,35 @@ class _PoseLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, trans, quat, model, mask):
-        t = trans.detach().contiguous()
-        q = quat.detach().contiguous()
-        obs, scalars = ops.pose_forward(model._cloud, t, q, model._cam, model._ws, mask)
+        if not (trans.is_contiguous() and quat.is_contiguous() and trans.dtype == torch.float32 and quat.dtype == torch.float32):
+            raise RuntimeError("ModelPose: trans / quat must be contiguous float32 tensors")
+        plan = model._plan
+        obs = torch.empty(plan.n, **plan.f32)
+        scalars = torch.empty(4, **plan.f32)
+        plan.forward(trans, quat, mask, obs, scalars)
         ctx.model, ctx.mask = model, mask
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(t, q, scalars)
-        return scalars[1].clone(), obs
+        ctx.save_for_backward(trans, quat, scalars)   # by reference: an in-place edit before backward() raises, as for torch's ops
+        loss = scalars[1]
+        if model.fast_backward:
+            loss = loss.as_subclass(_Loss)
+        return loss, obs, scalars
 
     @staticmethod
-    def backward(ctx, g_loss, g_obs):
+    def backward(ctx, g_loss, g_obs, _g_scalars):
         t, q, scalars = ctx.saved_tensors
         m = ctx.model
         if g_loss is None and g_obs is None:
             return None, None, None, None
         if g_obs is None:
-            kw = dict(scalars=scalars, gout=g_loss.to(torch.float32).reshape(1).contiguous())
-        else:
-            g = g_obs.to(torch.float32)
-            if g_loss is not None:
-                g = g - g_loss.to(torch.float32) * scalars[1] * scalars[1]  # d loss / d observation_n = -loss^2
-            kw = dict(grad_obs=g.contiguous())
-        tg, qg = ops.pose_backward(m._cloud, t, q, m._cam, m._ws, ctx.mask, **kw)
+            plan = m._plan
+            tg, qg = torch.empty((1, 3), **plan.f32), torch.empty((1, 4), **plan.f32)
+            plan.backward(t, q, ctx.mask, scalars, g_loss.to(**plan.f32).reshape(1), tg, qg)
+            return tg, qg, None, None
+        g = g_obs.to(torch.float32)
+        if g_loss is not None:
+            g = g - g_loss.to(torch.float32) * scalars[1] * scalars[1]  # d loss / d observation_n = -loss^2
+        tg, qg = ops.pose_backward(m._cloud, t, q, m._cam, m._ws, ctx.mask, grad_obs=g.contiguous())
         return tg, qg, None, None
 
 
@@ -418,16 +425,22 @@ class _FastBackward:
                 getattr(p, "_post_accumulate_grad_hooks", None) is None and getattr(q, "_post_accumulate_grad_hooks", None) is None and
                 (p.grad is None or _plain_grad(p)) and (q.grad is None or _plain_grad(q)) and not torch.is_anomaly_enabled())
 
-    def run(self, retain_graph):
+    def compute(self):
+        """-> the two gradients for dL/d loss = 1 (ModelTraj)."""
         plan = self.plan
-        if self.done:
-            raise RuntimeError("Trying to backward through the graph a second time (or directly access saved tensors after they have "
-                               "already been freed). Specify retain_graph=True if you need to backward through the graph a second time.")
         p, q = self.params
         if plan.ws.generation != self.gen:   # model() ran again since: rebuild this step's state
             self.gen = plan.rebuild(p, q, self.versions)
         pg, qg = torch.empty((plan.W, 3), **plan.f32), torch.empty((plan.W, 4), **plan.f32)
         plan.backward(plan.one, pg, qg)
+        return pg, qg
+
+    def run(self, retain_graph):
+        if self.done:
+            raise RuntimeError("Trying to backward through the graph a second time (or directly access saved tensors after they have "
+                               "already been freed). Specify retain_graph=True if you need to backward through the graph a second time.")
+        p, q = self.params
+        pg, qg = self.compute()
         with torch.no_grad():
             if p.grad is None:
                 p.grad = pg
@@ -439,6 +452,61 @@ class _FastBackward:
                 q.grad.add_(qg)
         if not retain_graph:
             self.done = True
+
+
+class _FastBackwardPose(_FastBackward):
+    """The same for ModelPose: its backward kernels read the camera from the Parameters again, so the short cut is only taken
+    while they are what the forward saw (else torch's engine raises its in-place error)."""
+    __slots__ = ("mask", "scalars")
+
+    def __init__(self, plan, node, params, mask, scalars):
+        super().__init__(plan, 0, node, params)
+        self.mask, self.scalars = mask, scalars
+
+    def usable(self, loss):
+        p, q = self.params
+        return p._version == self.versions[0] and q._version == self.versions[1] and super().usable(loss)
+
+    def compute(self):
+        plan = self.plan
+        tg, qg = torch.empty((1, 3), **plan.f32), torch.empty((1, 4), **plan.f32)
+        plan.backward(self.params[0], self.params[1], self.mask, self.scalars, plan.one, tg, qg)
+        return tg, qg
+
+
+class _PosePlan:
+    """ModelPose's two library calls with everything constant converted once (the loop is host-bound)."""
+
+    def __init__(self, model):
+        L = _lib.lib()
+        self.fwd, self.bwd = L.tohip_pose_forward, L.tohip_pose_backward
+        self.blob, self.n = model._cloud.blob.data_ptr(), model._cloud.n
+        self.cam = model._cam.ref()
+        self.ws, self.wsb = model._ws.buf.data_ptr(), model._ws.bytes
+        dev = model.device
+        self.dev, self.dev_index = dev, (dev.index if dev.index is not None else torch.cuda.current_device())
+        self.f32 = dict(dtype=torch.float32, device=dev)
+        self.one = torch.ones(1, **self.f32)
+        self.model = model
+
+    def _call(self, fn, *args):
+        idx = self.dev_index
+        if torch.cuda.current_device() == idx:
+            return fn(*args, self.ws, self.wsb, torch._C._cuda_getCurrentRawStream(idx))
+        with torch.cuda.device(idx):
+            return fn(*args, self.ws, self.wsb, torch._C._cuda_getCurrentRawStream(idx))
+
+    def forward(self, t, q, mask, obs, scalars):
+        rc = self._call(self.fwd, self.blob, self.n, t.data_ptr(), q.data_ptr(), self.cam, mask.data_ptr() if mask is not None else None,
+                        obs.data_ptr(), scalars.data_ptr())
+        if rc:
+            check(rc, "tohip_pose_forward")
+
+    def backward(self, t, q, mask, scalars, gout, tg, qg):
+        rc = self._call(self.bwd, self.blob, self.n, t.data_ptr(), q.data_ptr(), self.cam, mask.data_ptr() if mask is not None else None, None,
+                        scalars.data_ptr(), gout.data_ptr(), tg.data_ptr(), qg.data_ptr())
+        if rc:
+            check(rc, "tohip_pose_backward")
 
 
 def _plain_grad(p):
@@ -550,6 +618,8 @@ class ModelPose(nn.Module):
         self._ws = ops.PoseWorkspace(self._cloud)
         self._occlusion_mask, self._occlusion_key = None, None
         self.fused_loss = True  # forward() as one autograd node; False (or an overridden criterion): observations node + torch ops
+        self.fast_backward = True   # a plain `loss.backward()` on what forward() returned runs on the calling thread
+        self._plan = _PosePlan(self)
         for p in (self.trans, self.quat):
             tag_parameter(p)   # torch.optim.Adam.step() may update them with one launch (optimizer.accelerate_torch_adam)
 
@@ -566,7 +636,9 @@ class ModelPose(nn.Module):
             mask = self._occlusion_mask
         fused = self.fused_loss and type(self).criterion is ModelPose.criterion
         if fused:
-            loss, self.observations = _PoseLoss.apply(self.trans, self.quat, self, mask)
+            loss, self.observations, scalars = _PoseLoss.apply(self.trans, self.quat, self, mask)
+            if type(loss) is _Loss and loss.requires_grad:
+                loss.__dict__["_tohip_fast"] = _FastBackwardPose(self._plan, loss.grad_fn, (self.trans, self.quat), mask, scalars.detach())
         else:
             self.observations = _PoseObservations.apply(self.trans, self.quat, self, mask)
         if debug:
