@@ -106,6 +106,17 @@ def hot_loop_ops(text, kernel_prefix, marker="s_load_dwordx16"):
             if any(x.startswith("global_atomic") for x in region) and not any(x.startswith("global_store") for x in region):
                 for n in range(a + 1, b):
                     cold[n] = True
+        if kind == "op" and l.startswith("s_cbranch_scc"):
+            # the slot's MINIMUM: computed only while the probe has not exhibited a zero (a waypoint-uniform branch around a
+            # region of v_min instructions); with one exact zero in the cloud — every BASELINE workload — it is never entered
+            tgt = l.split()[1]
+            b = next((n for n in range(a + 1, len(sel)) if sel[n] == ("label", tgt)), None)
+            if b is None:
+                continue
+            region = [x for kk, x in sel[a + 1:b] if kk == "op"]
+            if any(x.startswith("v_min_i32_dpp") for x in region) and not any(x.startswith(("v_max_i32_dpp", "global_", "v_pk_")) for x in region):
+                for n in range(a + 1, b):
+                    cold[n] = True
     return [l.split()[0] for n, (kind, l) in enumerate(sel) if kind == "op" and not cold[n]], sum(1 for n, (kind, _) in enumerate(sel) if kind == "op" and cold[n])
 
 
@@ -133,9 +144,10 @@ def main():
                    packed_f32=cl["packed_f32"], transcendental=cl["transcendental"], other_valu=cl["other_valu"],
                    salu_smem=cl["salu_smem"], vmem=cl["vmem"], cold_instructions_excluded=n_cold, source_hash=source_hash(),
                    note="VALU instructions of one (wave, waypoint) iteration of the dense inner loop (hipcc -O3 --offload-arch=gfx950, "
-                        "ROCm 7.2); a lane owns 8 points = 4 packed pairs; per evaluation: 26 FMA-class operations (13 packed instructions per pair), 4 transcendentals; "
+                        "ROCm 7.2); a lane owns 8 points = 4 packed pairs; per evaluation: 25 FMA-class operations, 4 transcendentals; "
                         "the regions a wave enters only when its slot beats the probe's bounds (atomicMin / atomicMax of the running extrema: a few dozen "
-                        "times per waypoint and launch) are not counted",
+                        "times per waypoint and launch) and the slot-minimum region (entered only for a waypoint whose sample held no exact zero: none "
+                        "on the BASELINE workloads) are not counted; 25 FMA-class operations per evaluation since r03",
                    mnemonics=dict(c.most_common()))
         with open(args[1], "w") as f:
             json.dump(out, f, indent=1)

@@ -433,10 +433,11 @@ __host__ __device__ inline void quat_to_R(const float q[4], float R[9]) {
 //   p = sigmoid(h2) * exp(-1/2 (|c - mu|^2/sigma^2 + ((u - W/2)/W)^2 + ((v - H/2)/H)^2))      model.py:13-47,:223
 // Everything the camera contributes is linear in y = x - t, so the per-waypoint record holds three row vectors
 //   g0 = f0 . y,  g1 = f1 . y,  z = f2 . y + eps       f0 = sqrt(L2E/2)/W * K[0,:] R^T,  f1 likewise,  f2 = K[2,:] R^T
-// and the world-aligned offset of the Gaussian's centre, sp = R mu (|c - mu| = |y - sp|: rotations keep lengths).
-// With cd = L2E/(2 sigma^2), cw = ch = sqrt(L2E/2)/2 the exponent arrives in base 2 without further scaling:
-//   A = cd |y - sp|^2 + (g0/z - cw)^2 + (g1/z - ch)^2,    p = 2^-A / (1 + 2^(-L2E (z - eps)))
-// 26 FMA-class operations and 4 transcendentals (v_rcp x2, v_exp x2) per evaluation; any K (no pinhole special case).
+// and the world-aligned offset of the Gaussian's centre, R mu (|c - mu| = |y - R mu|: rotations keep lengths), pre-scaled:
+// sp = -sqrt(cd) R mu with cd = L2E/(2 sigma^2), so that d = sqrt(cd) y + sp = sqrt(cd) (y - R mu) is one FMA per axis and
+// the exponent arrives in base 2 without further scaling (cw = ch = sqrt(L2E/2)/2):
+//   A = |d|^2 + (g0/z - cw)^2 + (g1/z - ch)^2,    p = 2^-A / (1 + 2^(-L2E (z - eps)))
+// 25 FMA-class operations and 4 transcendentals (v_rcp x2, v_exp x2) per evaluation; any K (no pinhole special case).
 // The scalar and the packed function apply the same IEEE operations per element, so pass 1 (packed) and the sparse
 // kernels (scalar) see bit-identical p — they compare it with == against the per-waypoint extrema.
 
@@ -452,7 +453,7 @@ struct __attribute__((aligned(128))) WayRec {
     float f0[3];   //  3..5
     float f1[3];   //  6..8
     float f2[3];   //  9..11
-    float sp[3];   // 12..14
+    float sp[3];   // 12..14  -sqrt(cd) R mu
     float Lh;      // 15      0.49 L (0 while the minimum is not known to be zero): a slot whose maximum stays below it cannot be flagged
     float L;       // 16      probe: max of p over the sample (a lower bound of the max)
     float U;       // 17      probe: min of p over the sample (an upper bound of the min)
@@ -480,7 +481,7 @@ __device__ __forceinline__ void load_norm(const Extrema& e, float& a, float& pma
 }
 
 struct EvalK {
-    float eps, cw, ch, cd;
+    float eps, cw, ch, scd;   // scd = sqrt(cd), cd = L2E/(2 sigma^2)
     float nl2e;      // -L2E
     float l2e_eps;   //  L2E * eps
     float clip_hi;   // float32(1 - 1e-6)                                   model.py:229
@@ -496,7 +497,7 @@ static inline EvalK make_evalk(const tohip_camera* c) {
     const double s = sqrt(TO_L2E * 0.5);
     k.eps = c->eps;
     k.cw = k.ch = (float)(0.5 * s);
-    k.cd = (float)(TO_L2E * 0.5 / (sd * sd));
+    k.scd = (float)sqrt(TO_L2E * 0.5 / (sd * sd));
     k.nl2e = (float)(-TO_L2E);
     k.l2e_eps = (float)(TO_L2E * (double)c->eps);
     k.clip_hi = (float)(1.0 - (double)c->eps);
@@ -520,11 +521,11 @@ __device__ __forceinline__ float vis_p(const WayRec& r, const EvalK& k, float x,
     const float g0 = fmaf(r.f0[2], y2, fmaf(r.f0[1], y1, r.f0[0] * y0));
     const float g1 = fmaf(r.f1[2], y2, fmaf(r.f1[1], y1, r.f1[0] * y0));
     const float zz = fmaf(r.f2[2], y2, fmaf(r.f2[1], y1, fmaf(r.f2[0], y0, k.eps)));
-    const float d0 = y0 - r.sp[0], d1 = y1 - r.sp[1], d2 = y2 - r.sp[2];
+    const float d0 = fmaf(y0, k.scd, r.sp[0]), d1 = fmaf(y1, k.scd, r.sp[1]), d2 = fmaf(y2, k.scd, r.sp[2]);   // sqrt(cd) (y - R mu)
     const float dd = fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
     const float rz = to_rcp(zz);
     const float au = fmaf(g0, rz, -k.cw), av = fmaf(g1, rz, -k.ch);
-    const float A = fmaf(av, av, fmaf(au, au, dd * k.cd));
+    const float A = fmaf(av, av, fmaf(au, au, dd));
     const float E = to_exp2(-A);
     const float e = to_exp2(fmaf(zz, k.nl2e, k.l2e_eps));
     const float S = to_rcp(1.0f + e);
@@ -538,11 +539,12 @@ __device__ __forceinline__ f2 vis_p_pk(const Rec& r, const EvalK& k, f2 x, f2 y,
     const f2 g0 = pk_fma(pk_splat(r.f0[2]), y2, pk_fma(pk_splat(r.f0[1]), y1, pk_splat(r.f0[0]) * y0));
     const f2 g1 = pk_fma(pk_splat(r.f1[2]), y2, pk_fma(pk_splat(r.f1[1]), y1, pk_splat(r.f1[0]) * y0));
     const f2 zz = pk_fma(pk_splat(r.f2[2]), y2, pk_fma(pk_splat(r.f2[1]), y1, pk_fma(pk_splat(r.f2[0]), y0, pk_splat(k.eps))));
-    const f2 d0 = y0 - pk_splat(r.sp[0]), d1 = y1 - pk_splat(r.sp[1]), d2 = y2 - pk_splat(r.sp[2]);
+    const f2 d0 = pk_fma(y0, pk_splat(k.scd), pk_splat(r.sp[0])), d1 = pk_fma(y1, pk_splat(k.scd), pk_splat(r.sp[1])),
+             d2 = pk_fma(y2, pk_splat(k.scd), pk_splat(r.sp[2]));
     const f2 dd = pk_fma(d2, d2, pk_fma(d1, d1, d0 * d0));
     const f2 rz = pk_rcp(zz);
     const f2 au = pk_fma(g0, rz, pk_splat(-k.cw)), av = pk_fma(g1, rz, pk_splat(-k.ch));
-    const f2 A = pk_fma(av, av, pk_fma(au, au, dd * pk_splat(k.cd)));
+    const f2 A = pk_fma(av, av, pk_fma(au, au, dd));
     const f2 E = f2{to_exp2(-A.x), to_exp2(-A.y)};
     const f2 ea = pk_fma(zz, pk_splat(k.nl2e), pk_splat(k.l2e_eps));
     const f2 S = pk_rcp(pk_splat(1.0f) + f2{to_exp2(ea.x), to_exp2(ea.y)});
@@ -562,7 +564,7 @@ __device__ __forceinline__ void dvis_dy(const WayRec& r, const EvalK& k, float p
     for (int i = 0; i < 3; ++i) {
         const float w0 = fmaf(-q0, r.f2[i], r.f0[i]);   // f0 - g0 rz f2
         const float w1 = fmaf(-q1, r.f2[i], r.f1[i]);
-        const float dA = fmaf(s.rz, fmaf(s.av, w1, s.au * w0), k.cd * dk[i]);   // (dA/dy)/2
+        const float dA = fmaf(s.rz, fmaf(s.av, w1, s.au * w0), k.scd * dk[i]);   // (dA/dy)/2: cd (y - R mu) = sqrt(cd) d
         g[i] = live ? p * fmaf(-c2, dA, oneS * r.f2[i]) : 0.0f;
     }
 }
@@ -579,11 +581,12 @@ __device__ __forceinline__ f2 vis_p_pk_grad(const Rec& r, const EvalK& k, f2 x, 
     const f2 g0 = pk_fma(pk_splat(r.f0[2]), y2, pk_fma(pk_splat(r.f0[1]), y1, pk_splat(r.f0[0]) * y0));
     const f2 g1 = pk_fma(pk_splat(r.f1[2]), y2, pk_fma(pk_splat(r.f1[1]), y1, pk_splat(r.f1[0]) * y0));
     const f2 zz = pk_fma(pk_splat(r.f2[2]), y2, pk_fma(pk_splat(r.f2[1]), y1, pk_fma(pk_splat(r.f2[0]), y0, pk_splat(k.eps))));
-    const f2 d0 = y0 - pk_splat(r.sp[0]), d1 = y1 - pk_splat(r.sp[1]), d2 = y2 - pk_splat(r.sp[2]);
+    const f2 d0 = pk_fma(y0, pk_splat(k.scd), pk_splat(r.sp[0])), d1 = pk_fma(y1, pk_splat(k.scd), pk_splat(r.sp[1])),
+             d2 = pk_fma(y2, pk_splat(k.scd), pk_splat(r.sp[2]));
     const f2 dd = pk_fma(d2, d2, pk_fma(d1, d1, d0 * d0));
     const f2 rz = pk_rcp(zz);
     const f2 au = pk_fma(g0, rz, pk_splat(-k.cw)), av = pk_fma(g1, rz, pk_splat(-k.ch));
-    const f2 A = pk_fma(av, av, pk_fma(au, au, dd * pk_splat(k.cd)));
+    const f2 A = pk_fma(av, av, pk_fma(au, au, dd));
     const f2 E = f2{to_exp2(-A.x), to_exp2(-A.y)};
     const f2 ea = pk_fma(zz, pk_splat(k.nl2e), pk_splat(k.l2e_eps));
     const f2 S = pk_rcp(pk_splat(1.0f) + f2{to_exp2(ea.x), to_exp2(ea.y)});
@@ -601,7 +604,7 @@ __device__ __forceinline__ void dvis_dy_pk(const Rec& r, const EvalK& k, f2 p, c
     for (int i = 0; i < 3; ++i) {
         const f2 w0 = pk_fma(-q0, pk_splat(r.f2[i]), pk_splat(r.f0[i]));
         const f2 w1 = pk_fma(-q1, pk_splat(r.f2[i]), pk_splat(r.f1[i]));
-        const f2 dA = pk_fma(s.rz, pk_fma(s.av, w1, s.au * w0), pk_splat(k.cd) * dk[i]);
+        const f2 dA = pk_fma(s.rz, pk_fma(s.av, w1, s.au * w0), pk_splat(k.scd) * dk[i]);
         const f2 gi = p * pk_fma(pk_splat(-c2), dA, oneS * pk_splat(r.f2[i]));
         g[i] = f2{p.x > 0.0f ? gi.x : 0.0f, p.y > 0.0f ? gi.y : 0.0f};
     }

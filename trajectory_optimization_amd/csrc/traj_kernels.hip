@@ -162,7 +162,7 @@ __device__ __forceinline__ void prep_wayrec(int v, const float* __restrict__ pos
         r.f0[kk] = (float)((double)k.su * h0);
         r.f1[kk] = (float)((double)k.sv * h1);
         r.f2[kk] = (float)h2;
-        r.sp[kk] = (float)((double)k.mean * s);
+        r.sp[kk] = (float)(-(double)k.scd * (double)k.mean * s);
     }
     r.Lh = 0.f; r.L = 0.f; r.U = INFINITY; r.thr1 = INFINITY; r.sthr1 = INFINITY; r.azero = 0.f; r.pad = 0.f; r.seg = seg;
     rec[v] = r;
@@ -218,13 +218,14 @@ __device__ __forceinline__ float4 wave_tile_bound(const CloudView& cv, int64_t b
 // (tile, waypoint) liveness for 64 waypoints at once: lane l tests waypoint vc + l against the wave's tile; the ballot is
 // the set of waypoints whose sphere {d2 <= thr1} may reach the tile.  Waypoints without the probe's "min is zero" proof
 // always survive (they are searched densely).
-__device__ __forceinline__ unsigned long long tile_survivors(const WayRec* __restrict__ rec, int vc, int v1, const float4& tb) {
+__device__ __forceinline__ unsigned long long tile_survivors(const WayRec* __restrict__ rec, int vc, int v1, const float4& tb, float inv_scd) {
     const int v = vc + (int)(threadIdx.x & 63);
     bool ok = false;
     if (v < v1) {
         const float4* rp = reinterpret_cast<const float4*>(rec + v);
         const float4 q0 = rp[0], q3 = rp[3], q4 = rp[4], q5 = rp[5];  // t0 t1 t2 f00 | sp0 sp1 sp2 Lh | L U thr1 sthr1 | azero ..
-        const float d0 = (tb.x - q0.x) - q3.x, d1 = (tb.y - q0.y) - q3.y, d2 = (tb.z - q0.z) - q3.z;
+        // the sphere's centre from the Gaussian's, in metres: (c - t) - R mu, with R mu = -sp / sqrt(cd)
+        const float d0 = fmaf(q3.x, inv_scd, tb.x - q0.x), d1 = fmaf(q3.y, inv_scd, tb.y - q0.y), d2 = fmaf(q3.z, inv_scd, tb.z - q0.z);
         const float D2 = fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
         const float thr = q4.z, sthr = q4.w;
         const float bound = fmaf(tb.w, fmaf(2.0f, sthr, tb.w), thr) * 1.00001f;  // (sthr + r)^2, rounded up
@@ -363,8 +364,9 @@ __device__ __forceinline__ void pass1_eval(const EvalK& k, const WayRec& r, cons
                                            const float (&z)[TO_P], const float (&om)[TO_P], float& mn, float& mx) {
     const f2 p0 = vis_p_pk(r, k, f2{x[0], x[1]}, f2{y[0], y[1]}, f2{z[0], z[1]}) * f2{om[0], om[1]};
     const f2 p1 = vis_p_pk(r, k, f2{x[2], x[3]}, f2{y[2], y[3]}, f2{z[2], z[3]}) * f2{om[2], om[3]};
-    mn = fminf(fminf(p0.x, p0.y), fminf(p1.x, p1.y));   // p >= +0 always
-    mx = fmaxf(fmaxf(p0.x, p0.y), fmaxf(p1.x, p1.y));
+    mx = wave_max63_nn_fused(fmaxf(fmaxf(p0.x, p0.y), fmaxf(p1.x, p1.y)));
+    mn = 0.f;   // wanted only while the probe has not exhibited a zero (see the dense kernel)
+    if (__builtin_bit_cast(int, r.U) != 0) mn = wave_min63_nn_fused(fminf(fminf(p0.x, p0.y), fminf(p1.x, p1.y)));   // p >= +0 always
 }
 
 // the log-odds vector starts from zero (k_traj_sparse fills the flagged slots) and, when the caller asks for it, the rewards
@@ -440,10 +442,15 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
 #pragma unroll
             for (int i = 0; i < P; i += 2)
                 p[i / 2] = vis_p_pk(r, k, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}) * f2{om[i], om[i + 1]};
-            float mn = fminf(fminf(fminf(p[0].x, p[0].y), fminf(p[1].x, p[1].y)), fminf(fminf(p[2].x, p[2].y), fminf(p[3].x, p[3].y)));
             float mx = fmaxf(fmaxf(fmaxf(p[0].x, p[0].y), fmaxf(p[1].x, p[1].y)), fmaxf(fmaxf(p[2].x, p[2].y), fmaxf(p[3].x, p[3].y)));
-            mn = half_min31_nn_fused(mn);
             mx = half_max31_nn_fused(mx);
+            // the minimum is wanted only while the probe has not exhibited a zero (U != 0, wave-uniform): p is never negative, so
+            // with one zero in the cloud min p = 0 whatever this slot holds, and nothing downstream looks at a slot's minimum then
+            float mn = 0.f;
+            if (__builtin_bit_cast(int, r.U) != 0) {
+                mn = fminf(fminf(fminf(p[0].x, p[0].y), fminf(p[1].x, p[1].y)), fminf(fminf(p[2].x, p[2].y), fminf(p[3].x, p[3].y)));
+                mn = half_min31_nn_fused(mn);
+            }
             if ((lane & 31) == 31) {
                 prow[v] = make_float2(mn, mx);
                 if (fold_extrema(ext, v, mn, mx, r)) claim_candidate(claim, cand, slot);
@@ -482,7 +489,7 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile
     const int v0 = blockIdx.y * vtile;
     const int v1 = min(V, v0 + vtile);
     const float4 tb = wave_tile_bound(cv, base);
-    unsigned long long live = tile_survivors(rec, v0, v1, tb);
+    unsigned long long live = tile_survivors(rec, v0, v1, tb, 1.0f / k.scd);
     float2* prow = part + (int64_t)slot * V;
     // waypoints that cannot be affected from this tile: min is the proven 0, max unknown (-inf: never flagged)
     if (v0 + lane < v1 && !((live >> lane) & 1ull)) prow[v0 + lane] = make_float2(0.f, -INFINITY);
@@ -494,8 +501,6 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile
         float mn, mx, om[P];
         load_occ<P, OCC>(occ, occw, v, base, om);
         pass1_eval(k, r, x, y, z, om, mn, mx);
-        mn = wave_min63_nn_fused(mn);
-        mx = wave_max63_nn_fused(mx);
         if (lane == 63) {
             prow[v] = make_float2(mn, mx);
             if (fold_extrema(ext, v, mn, mx, r)) claim_candidate(claim, cand, slot);
