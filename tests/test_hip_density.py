@@ -1,0 +1,57 @@
+"""The dense-scene end of the workload: 1 M points in a small room flag ~6x the (slot, waypoint) pairs of the BASELINE slab, and
+the kernels after pass 1 do ~6x the work (bench.py's density_sweep times it).  Parity there: the densest setting of the sweep against
+the f64 oracle, the fused step against the split calls, dense == culled bitwise."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_inf
+from test_hip_conditioning import MARGIN, _margins
+from trajectory_optimization_amd import synth
+
+pytestmark = pytest.mark.gpu
+K, IW, IH = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
+
+
+@pytest.mark.parametrize("extent,w", [((6.0, 6.0, 3.0), 128), ((10.0, 10.0, 4.0), 48)])
+def test_dense_room_against_the_oracle(extent, w):
+    from oracle import oracle
+    from trajectory_optimization_amd import ops
+    dev = torch.device("cuda:0")
+    n = 1_000_000
+    pts = synth.make_cloud(n, seed=0, extent=extent)
+    poses, quats = synth.make_path(w, optical=True, scale=extent[0] / 40.0)
+    cloud = ops.PackedCloud(torch.from_numpy(pts).to(dev))
+    cam = ops.Camera(K, IW, IH)
+    p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
+    ws = ops.TrajWorkspace(cloud, w)
+    gout = torch.ones(1, device=dev)
+    outs = {}
+    for name, flags in (("culled", 0), ("dense", ops.DENSE)):
+        outs[name] = ops.traj_forward_backward(cloud, p, q, cam, ws, gout, flags=flags)
+    st = ops.traj_step_stats(cloud, ws)
+    assert st["flagged_fraction"] > 0.03, st   # the setting is what it claims to be: > 4x the BASELINE slab's 0.7 %
+    assert all(torch.equal(a, b) for a, b in zip(outs["dense"][:5], outs["culled"][:5]))
+    # the split calls (what a sharded run does around its all-reduce) give the same rewards / scalars bit for bit
+    lo, _ = ops.traj_forward(cloud, p, q, cam, ws)
+    rew, sc, pg2, qg2 = ops.traj_reward_backward(cloud, w, cam, ws, lo, gout)
+    rewards, scalars, pg, qg = (t.cpu().numpy() for t in outs["culled"][:4])
+    assert np.array_equal(rew.cpu().numpy(), rewards) and np.array_equal(sc.cpu().numpy(), scalars)
+    assert rel_inf(pg2.cpu().numpy(), pg) < 1e-6 and rel_inf(qg2.cpu().numpy(), qg) < 1e-6
+    f = oracle.traj_forward(pts, poses, quats, K, IW, IH, prec="f64")
+    pgo, qgo = oracle.traj_backward(pts, poses, quats, K, IW, IH, f, prec="f64")
+    np.testing.assert_allclose(rewards, f["rewards"], rtol=1e-5, atol=0)   # north star: rewards within 1e-5 relative
+    assert abs(scalars[1] - f["loss_vis"]) <= 2e-6 * f["loss_vis"]
+    # gradients: the 1e-5 bar on every waypoint none of whose points sits within f32 rounding of a threshold of the clipped
+    # log-odds (tests/test_hip_conditioning.py): 9 000 points per cubic metre put ~1e5 points per waypoint between p_hat 0.4 and 0.6,
+    # so a fair share of the waypoints has one within 3e-7 of 1/2 — one point's on/off is 1e-5 .. 1e-4 of a waypoint's gradient
+    keep = _margins(pts, poses, quats, (1.0, 5.0)) > MARGIN
+    ep = np.abs(pg - pgo).max(axis=1) / np.abs(pgo).max()
+    eq = np.abs(qg - qgo).max(axis=1) / np.abs(qgo).max()
+    assert keep.sum() >= w // 2, keep.sum()
+    assert (ep[keep] < 1e-5).all() and (eq[keep] < 1e-5).all(), (ep[keep].max(), eq[keep].max())
+    assert ep.max() < 1e-3 and eq.max() < 1e-3   # and the others are off by single points, not by anything systematic
+    warnings.warn(f"dense room {extent}: {int((~keep).sum())} of {w} waypoints have a point within {MARGIN:g} of a threshold and were excluded from "
+                  f"the 1e-5 gradient bar (worst of them {max(ep.max(), eq.max()):.1e}); worst among the others {max(ep[keep].max(), eq[keep].max()):.1e}")
