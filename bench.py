@@ -319,6 +319,9 @@ def main():
     ap.add_argument("--fused-step", choices=["on", "off"], default="on",
                     help="N = 1: tohip_traj_forward_backward (4 launches); off: tohip_traj_forward then tohip_traj_reward_backward (5), the "
                          "split that a waypoint-sharded run needs around its all-reduce")
+    ap.add_argument("--compact-allreduce", choices=["on", "off"], default="off",
+                    help="N > 1: all-reduce only the slots some rank lists as candidates (a flag per slot MAX-reduced first; one host read of "
+                         "the union's size per step) instead of the whole N-float log-odds vector")
     ap.add_argument("--graph", choices=["on", "off"], default="off",
                     help="replay the step's launches from a HIP graph in the timed region (measured SLOWER on ROCm 7.2: 0.151 vs "
                          "0.139 ms dense, 0.079 vs 0.075 culled - graph kernel nodes cost more than the queue they replace)")
@@ -355,7 +358,7 @@ def main():
     ws = ops.TrajWorkspace(cloud, n_virtual)
     gout = torch.ones(1, device=device)
     forced = os.environ.get("TOHIP_DIST_FORCE_INIT") == "1"   # one-rank process group: the RCCL calls of the N>1 step on one GPU
-    shard = WaypointShard(force_collectives=forced) if (n_gpus > 1 or forced) else None
+    shard = WaypointShard(force_collectives=forced, compact=args.compact_allreduce == "on") if (n_gpus > 1 or forced) else None
 
     if shard is not None:
         # communicator set-up (RCCL rings over xGMI) happens on the first collective of each kind: keep it out of the timed
@@ -377,7 +380,7 @@ def main():
             return scalars, pg, qg, rewards
         lo_sum, minmax = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags, lo_sum=lo_buf, minmax=mm_buf, rewards_half=rewards)
         if shard is not None:
-            shard.allreduce_sum(lo_sum)  # the one data-path collective: N floats over xGMI
+            ops.allreduce_log_odds(shard, cloud, ws, lo_sum)  # the one data-path collective: N floats over xGMI (or the union's slots)
         if args.fused_reward == "on":
             # rewards, mean and loss share the backward's first launch (tohip_traj_reward_backward: two launches instead of three)
             rewards, scalars, pg, qg = ops.traj_reward_backward(cloud, args.wps_per_gpu, cam, ws, lo_sum, gout, rewards=rewards,
@@ -466,7 +469,7 @@ def main():
         for e in ev:
             lo_sum, _ = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags, lo_sum=lo_buf, minmax=mm_buf, rewards_half=rewards_buf)
             e[0].record()
-            shard.allreduce_sum(lo_sum)
+            ops.allreduce_log_odds(shard, cloud, ws, lo_sum)
             e[1].record()
             _, _, pg, qg = ops.traj_reward_backward(cloud, args.wps_per_gpu, cam, ws, lo_sum, gout, rewards=rewards_buf, prefilled=True, rig=rig,
                                                     flags=flags)
@@ -484,7 +487,21 @@ def main():
             ops.traj_reward_backward(cloud, args.wps_per_gpu, cam, ws, lo_sum, gout, rewards=rewards_buf, prefilled=True, rig=rig, flags=flags)
         fence()
         no_comm = 1e3 * (time.perf_counter() - t0) / args.steps
-        return {"allreduce_ms_median": ar[len(ar) // 2], "allreduce_ms_max": ar[-1], "allreduce_bytes": int(cloud.npad * 4),
+        # the other kind of all-reduce of the log-odds vector (full N floats <-> the union of the ranks' candidate slots), for comparison
+        other = WaypointShard(force_collectives=forced, compact=not shard.compact)
+        ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
+        fence()
+        for e in ev2:
+            lo_sum, _ = ops.traj_forward(cloud, poses, quats, cam, ws, rig=rig, flags=flags, lo_sum=lo_buf, minmax=mm_buf, rewards_half=rewards_buf)
+            e[0].record()
+            ops.allreduce_log_odds(other, cloud, ws, lo_sum)
+            e[1].record()
+        fence()
+        ar2 = sorted(e[0].elapsed_time(e[1]) for e in ev2)
+        return {"allreduce_ms_median": ar[len(ar) // 2], "allreduce_ms_max": ar[-1], "allreduce_bytes": int(cloud.npad * 4), "compact_allreduce": bool(shard.compact),
+                "other_allreduce": {"compact": bool(other.compact), "ms_median": ar2[len(ar2) // 2], "ms_max": ar2[-1],
+                                    "note": "the same K forwards followed by the OTHER kind of all-reduce (compact: a 0/1 flag per slot MAX-reduced, one "
+                                            "host read of the union's size, pack, sum of the union's slots, unpack), events around it"},
                 "allgather_ms_median": ag[len(ag) // 2], "allgather_bytes_per_rank": int(args.wps_per_gpu * 7 * 4),
                 "step_without_collectives_ms": no_comm, "backend": dist.get_backend(),
                 "note": "rank 0's view; events on the compute stream around each collective (it waits for RCCL's stream), "

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOHIP_ABI_VERSION 9
+#define TOHIP_ABI_VERSION 10
 
 #define TOHIP_OK 0
 #define TOHIP_EINVAL (-1)   /* bad size / null pointer */
@@ -186,6 +186,20 @@ int tohip_traj_forward_backward_multi(const void *packed, int64_t n_points, cons
                                       const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits, float *lo_sum,
                                       float *minmax, float *rewards, float *scalars, const float *gout, float *poses_grad,
                                       float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- a waypoint-sharded step's all-reduce, compacted (the one data-path collective) ------------------------------
+ * A rank's partial log-odds vector is exactly zero outside the 256-point slots its forward listed as candidates (6-8 % of the
+ * slots on the BASELINE workloads).  Instead of all-reducing N floats: (1) tohip_traj_candidate_flags -> one 0/1 int32 per slot
+ * of this rank's last forward (Npad/256 of them, device); the ranks MAX-reduce them (RCCL has no OR); (2) tohip_slot_flags_prefix
+ * -> prefix[s] = set flags below slot s, prefix[nslots] = their number = the union's slots (nslots + 1 int32, device); (3)
+ * tohip_slots_pack(pack = 1) gathers the union's slots of lo_sum into `compact` (256 floats each, in slot order; at most
+ * capacity_slots of them); the ranks sum-reduce compact[0 .. 256 * count); (4) tohip_slots_pack(pack = 0) scatters it back.  The
+ * slots outside the union are zero on every rank and are not touched. */
+int tohip_traj_candidate_flags(int64_t n_points, int64_t n_virtual, int64_t n_traj, const void *workspace, size_t workspace_bytes,
+                               int32_t *slot_flags, void *stream);
+int tohip_slot_flags_prefix(const int32_t *slot_flags, int64_t n_points, int32_t *prefix, void *stream);
+int tohip_slots_pack(const int32_t *slot_flags, const int32_t *prefix, int64_t n_points, float *lo_sum, float *compact,
+                     int64_t capacity_slots, int pack, void *stream);
 
 /* ---- ModelTraj.forward() / loss.backward() as one call each ------------------------------------------
  * The reference's loop (trajectory_optimization.py:109-116) is `optimizer.zero_grad(); loss = model(); loss.backward();

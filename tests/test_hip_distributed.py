@@ -40,9 +40,16 @@ def _worker(rank, world, port, out_dir):
     m2 = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(synth.K_INTRINS),
                    synth.IMG_WIDTH, synth.IMG_HEIGHT, device=device, shard=WaypointShard())
     res = optimize_trajectory(m2, n_opt_steps=4, lr_pose=0.05, lr_quat=0.01, rewards_th=1e9, vis_wps_dist=0.0)
+    # the compact all-reduce (a bit per slot OR-reduced, then only the union's slots summed) gives the full one's bits
+    mc = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(synth.K_INTRINS),
+                   synth.IMG_WIDTH, synth.IMG_HEIGHT, device=device, shard=WaypointShard(compact=True))
+    lc = mc(vis_wps_dist=0.0)
+    lc.backward()
+    compact_same = bool(torch.equal(lc.detach(), loss.detach()) and torch.equal(mc.rewards.detach(), m.rewards.detach()) and
+                        torch.equal(mc.poses.grad, m.poses.grad) and torch.equal(mc.quats.grad, m.quats.grad))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=loss.item(), rewards=m.rewards.detach().cpu().numpy(),
              pg=m.poses.grad.cpu().numpy(), qg=m.quats.grad.cpu().numpy(), opt_poses=m2.poses.detach().cpu().numpy(),
-             opt_quats=m2.quats.detach().cpu().numpy(), opt_losses=np.asarray(res.losses))
+             opt_quats=m2.quats.detach().cpu().numpy(), opt_losses=np.asarray(res.losses), compact_same=compact_same)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,6 +63,7 @@ def test_sharded_model_equals_single_process(tmp_path):
     r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in range(world))
     for k in ("loss", "rewards", "pg", "qg", "opt_poses", "opt_quats", "opt_losses"):
         assert np.array_equal(r0[k], r1[k]), k  # replicated state identical on both ranks
+    assert bool(r0["compact_same"]) and bool(r1["compact_same"])
     dev = torch.device("cuda:0")
     pts = synth.make_cloud(60_000, seed=9)
     poses, quats = synth.make_path(9, optical=True, jitter_seed=9)
@@ -134,3 +142,13 @@ def test_bench_step_through_rccl_on_one_rank(bench_one_rank, tmp_path):
     a, b = bench_one_rank, np.load(tmp_path / "rccl.npz")
     for k in ("scalars", "pg", "qg", "rewards"):
         assert np.array_equal(a[k], b[k]), k
+    # and with the compact all-reduce (OR-reduce of the slot mask + sum of the union's slots, both through RCCL)
+    out = _run([sys.executable, "bench.py", "--gpus", "1", "--wps-per-gpu", "64", "--compact-allreduce", "on", "--dump", str(tmp_path / "rcclc.npz")]
+               + _BENCH_COMMON,
+               {"TOHIP_DIST_FORCE_INIT": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(_free_port())})
+    line = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+    assert line["comm"]["compact_allreduce"] is True
+    c = np.load(tmp_path / "rcclc.npz")
+    for k in ("scalars", "pg", "qg", "rewards"):
+        assert np.array_equal(a[k], c[k]), k

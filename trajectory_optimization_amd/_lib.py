@@ -129,6 +129,9 @@ SIGNATURES = {
     "tohip_render_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "tohip_render_points": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(c_f), c_i32, c_i32, c_f, c_f, c_f, c_f, c_vp, c_vp,
                                             c_vp, c_vp, c_sz, c_vp]),
+    "tohip_traj_candidate_flags": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_sz, c_vp, c_vp]),
+    "tohip_slot_flags_prefix": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "tohip_slots_pack": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.c_int, c_vp]),
     "tohip_traj_step_stats": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_sz, c_vp, c_vp]),
     "tohip_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "tohip_profile_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -172,7 +175,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 9  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
+ABI_VERSION = 10  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
 ENOSPC = -2  # TOHIP_ENOSPC
 ENAN = -4    # TOHIP_ENAN
 

@@ -603,6 +603,9 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int a
     const int64_t base = (int64_t)slot * TO_SLOT + lane * 4;
     float x[4], y[4], z[4];
     load_points<4>(a.cv.soa, a.cv.npad, base, x, y, z);
+    // where the slot's points live in the caller's order (rewards / upstream gradients): requested now, wanted after the forward
+    int4 o4 = make_int4(0, 0, 0, 0);
+    if (MODE == TO_SP_FUSED ? wave == 0 : (MODE == TO_SP_BWD && a.grad_rewards != nullptr)) o4 = *reinterpret_cast<const int4*>(a.cv.perm + base);
 
     // ---- flags of this slot, one word per 64 waypoints ----
     unsigned long long mine = 0ull;
@@ -718,8 +721,6 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int a
         float gn[4];
         {
             const float coef = (MODE == TO_SP_BWD && a.scalars) ? a.scalars[4 * tr + 2] * a.gout[tr] : 1.0f;
-            int4 o4 = make_int4(0, 0, 0, 0);
-            if (MODE == TO_SP_FUSED ? wave == 0 : a.grad_rewards != nullptr) o4 = *reinterpret_cast<const int4*>(a.cv.perm + base);
             const int o[4] = {o4.x, o4.y, o4.z, o4.w};
             long long fsum = 0;
             bool fnan = false;
@@ -1690,6 +1691,85 @@ extern "C" int tohip_traj_forward_backward(const void* packed, int64_t n, const 
                                            float* poses_grad, float* quats_grad, void* workspace, size_t workspace_bytes, void* stream_) {
     return tohip_traj_forward_backward_multi(packed, n, poses, quats, W, nullptr, 1, cam, rig, flags, occlusion_bits, lo_sum, minmax, rewards,
                                              scalars, gout, poses_grad, quats_grad, workspace, workspace_bytes, stream_);
+}
+
+// ---- the log-odds vector of a waypoint-sharded step, compacted for its all-reduce ---------------------------------------------
+// A rank's partial log-odds vector is exactly zero outside the slots its pass 1 listed as candidates (6-8 % of the slots on the
+// BASELINE workloads).  The ranks MAX-reduce a 0/1 flag per slot (16 KB at 1 M points), pack the slots of the union — the same
+// set on every rank — into one contiguous buffer, all-reduce that, and unpack: the slots outside the union are zero on every
+// rank and stay untouched.
+
+// flag[s] = 1 when slot s is a candidate of this rank's last forward, else 0 (one int32 per slot: RCCL reduces with MAX, it has no OR)
+__global__ void k_candidate_flags(const int* __restrict__ clist, const int* __restrict__ clist_n, int* __restrict__ flag) {
+    const int n = *clist_n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) flag[clist[i]] = 1;
+}
+
+// prefix[s] = number of set flags below slot s; prefix[nslots] = their total (one block)
+__global__ void __launch_bounds__(1024) k_flag_prefix(const int* __restrict__ flag, int nslots, int* __restrict__ prefix) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (nslots + 1023) / 1024;
+    int c = 0;
+    for (int j = 0; j < per; ++j) { const int s = t * per + j; if (s < nslots) c += flag[s] != 0; }
+    part[t] = c;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {   // inclusive scan
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = t ? part[t - 1] : 0;
+    for (int j = 0; j < per; ++j) {
+        const int s = t * per + j;
+        if (s < nslots) { prefix[s] = run; run += flag[s] != 0; }
+    }
+    if (t == 1023) prefix[nslots] = part[1023];
+}
+
+// block per slot of the union: its 256-float block <-> block prefix[s] of the compact buffer (pack = 1: gather, 0: scatter)
+__global__ void __launch_bounds__(TO_SLOT)
+k_slots_move(const int* __restrict__ flag, const int* __restrict__ prefix, int nslots, float* __restrict__ lo_sum,
+             float* __restrict__ compact, int64_t capacity_slots, int pack) {
+    for (int s = blockIdx.x; s < nslots; s += gridDim.x) {
+        if (!flag[s]) continue;
+        const int e = prefix[s];
+        if (e >= capacity_slots) continue;
+        if (pack) compact[(int64_t)e * TO_SLOT + threadIdx.x] = lo_sum[(int64_t)s * TO_SLOT + threadIdx.x];
+        else lo_sum[(int64_t)s * TO_SLOT + threadIdx.x] = compact[(int64_t)e * TO_SLOT + threadIdx.x];
+    }
+}
+
+extern "C" int tohip_traj_candidate_flags(int64_t n_points, int64_t n_virtual, int64_t n_traj, const void* workspace, size_t workspace_bytes,
+                                          int32_t* slot_flags, void* stream_) {
+    if (n_points <= 0 || n_virtual <= 0 || n_traj <= 0 || !workspace || !slot_flags) return TOHIP_EINVAL;
+    const TrajPlan pl = make_plan(n_points, n_virtual, n_virtual, n_traj);
+    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream_;
+    const char* ws = (const char*)workspace;
+    const hipError_t e = hipMemsetAsync(slot_flags, 0, sizeof(int32_t) * (size_t)pl.nslots, st);
+    if (e != hipSuccess) return (int)e;
+    k_candidate_flags<<<16, 256, 0, st>>>((const int*)(ws + pl.off_clist), (const int*)(ws + pl.off_cand) + pl.nslots, slot_flags);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+extern "C" int tohip_slot_flags_prefix(const int32_t* slot_flags, int64_t n_points, int32_t* prefix, void* stream_) {
+    if (!slot_flags || !prefix || n_points <= 0) return TOHIP_EINVAL;
+    const int nslots = (int)(tohip_padded_points(n_points) / TO_SLOT);
+    k_flag_prefix<<<1, 1024, 0, (hipStream_t)stream_>>>(slot_flags, nslots, prefix);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+extern "C" int tohip_slots_pack(const int32_t* slot_flags, const int32_t* prefix, int64_t n_points, float* lo_sum, float* compact,
+                                int64_t capacity_slots, int pack, void* stream_) {
+    if (!slot_flags || !prefix || !lo_sum || !compact || n_points <= 0 || capacity_slots < 0) return TOHIP_EINVAL;
+    const int nslots = (int)(tohip_padded_points(n_points) / TO_SLOT);
+    k_slots_move<<<nslots < 2048 ? nslots : 2048, TO_SLOT, 0, (hipStream_t)stream_>>>(slot_flags, prefix, nslots, lo_sum, compact, capacity_slots, pack);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
 }
 
 // Diagnostic: what the last forward over `workspace` found — stats[0] = flagged (slot, waypoint) pairs, stats[1] = candidate slots

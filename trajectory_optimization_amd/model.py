@@ -213,7 +213,7 @@ class _TrajRewards(torch.autograd.Function):
             lo_sum, half, ws, gen = _local_forward(model, ps, qs, occ)
         else:
             lo_sum = torch.zeros(model._cloud.npad, device=p.device)
-        lo_sum = sh.allreduce_sum(lo_sum)
+        lo_sum = ops.allreduce_log_odds(sh, model._cloud, model._workspace(max(hi - lo, 1)), lo_sum, local=hi > lo)
         rewards, _ = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)), rewards=half,
                                      prefilled=half is not None)
         ctx.model, ctx.range, ctx.n_wps, ctx.occ, ctx.ws, ctx.gen = model, (lo, hi), p.shape[0], occ, ws, gen
@@ -302,7 +302,7 @@ class _TrajLoss(torch.autograd.Function):
             lo_sum, half, ws, gen = _local_forward(model, ps, qs, occ)
         else:
             lo_sum = torch.zeros(model._cloud.npad, device=dev)
-        lo_sum = sh.allreduce_sum(lo_sum)
+        lo_sum = ops.allreduce_log_odds(sh, model._cloud, model._workspace(max(hi - lo, 1)), lo_sum, local=hi > lo)
         rewards, scalars = ops.traj_reward(model._cloud, lo_sum, model._cam, model._workspace(max(hi - lo, 1)), rewards=half,
                                            prefilled=half is not None)
         terms = torch.empty(8, dtype=torch.float32, device=dev)

@@ -257,6 +257,35 @@ def traj_backward_multi(cloud, n_wps, n_traj, cam, ws, lo_sum, grad_rewards=None
     return pg, qg
 
 
+def allreduce_log_odds(shard, cloud, ws, lo_sum, local=True):
+    """The one data-path collective of a waypoint-sharded step: the sum of the ranks' partial log-odds vectors, in
+    place.  With shard.compact only the slots some rank's forward listed as candidates travel (tohip_traj_candidate_flags ...
+    tohip_slots_pack): the vector is exactly zero elsewhere on every rank.  local=False: this rank ran no forward over `ws` (it
+    holds no waypoint): its vector is zero and it lists nothing."""
+    if not getattr(shard, "compact", False) or shard.world_size == 1 and not shard._always:
+        return shard.allreduce_sum(lo_sum)
+    L = _lib.lib()
+    dev = cloud.device
+    nslots = cloud.npad // 256
+    flags = torch.zeros(nslots, dtype=torch.int32, device=dev)
+    prefix = torch.empty(nslots + 1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        if local:
+            check(L.tohip_traj_candidate_flags(cloud.n, ws.n_virtual, ws.n_traj, ptr(ws.buf), ws.bytes, ptr(flags), stream_ptr()), "tohip_traj_candidate_flags")
+        shard.allreduce_max(flags)
+        check(L.tohip_slot_flags_prefix(ptr(flags), cloud.n, ptr(prefix), stream_ptr()), "tohip_slot_flags_prefix")
+        count = int(prefix[nslots].item())   # the step's one host read: the union's size is the message's
+        if count == 0:
+            return lo_sum
+        buf = getattr(ws, "_compact", None)
+        if buf is None or buf.numel() < count * 256:
+            buf = ws._compact = torch.empty(max(count * 256 * 2, 1 << 16), dtype=torch.float32, device=dev)
+        check(L.tohip_slots_pack(ptr(flags), ptr(prefix), cloud.n, ptr(lo_sum), ptr(buf), count, 1, stream_ptr()), "tohip_slots_pack")
+        shard.allreduce_sum(buf[:count * 256])
+        check(L.tohip_slots_pack(ptr(flags), ptr(prefix), cloud.n, ptr(lo_sum), ptr(buf), count, 0, stream_ptr()), "tohip_slots_pack")
+    return lo_sum
+
+
 def traj_step_stats(cloud, ws):
     """What the last forward over `ws` found -> dict(flagged_pairs, candidate_slots, slots, virtual_waypoints, flagged_fraction)."""
     st = torch.zeros(4, dtype=torch.int64, device=cloud.device)

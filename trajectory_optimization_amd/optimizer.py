@@ -84,7 +84,7 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
                 ws.generation += 1
             else:
                 lo_sum.zero_()
-            model._shard.allreduce_sum(lo_sum)
+            ops.allreduce_log_odds(model._shard, cloud, ws, lo_sum, local=n_loc > 0)
             if n_loc > 0:
                 # rewards, their mean and the loss scalars share the backward's first launch
                 check(L.tohip_traj_reward_backward(ptr(cloud.blob), cloud.n, n_loc, cam.ref(), rig_ref, model._flags, ptr(occ), ptr(lo_sum),
