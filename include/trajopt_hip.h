@@ -77,10 +77,11 @@ int tohip_pack_cloud(const float *xyz, int64_t n_points, int sort, void *packed,
                      size_t workspace_bytes, void *stream);
 
 /* ---- ModelTraj (model.py:200-242 forward, :246 visibility term, autograd backward) ----------
- * Workspace bytes needed by the three calls below for n_points and n_virtual = W * max(1,n_cams).
- * THE WORKSPACE MUST BE ZERO-FILLED ONCE BEFORE ITS FIRST USE (hipMemset); the calls keep that invariant.  The forward
- * leaves its state there (waypoint records, per-waypoint extrema, the flags and lists of the pairs that contribute) and
- * the backward of the same step reads it: do not touch the workspace between the two. */
+ * Workspace bytes needed by the calls below for n_points and n_virtual = W * max(1,n_cams) (at most 65 536 virtual waypoints).
+ * THE WORKSPACE MUST BE ZERO-FILLED ONCE BEFORE ITS FIRST USE (hipMemset): tohip_traj_reward's accumulator word is expected
+ * zero and left zero; every forward resets what a step accumulates into, that word included.  The forward leaves its state
+ * there (waypoint records, per-waypoint extrema, the flags of the pairs that contribute, the candidate slots) and the backward
+ * of the same step reads it: do not touch the workspace between the two. */
 size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual);
 
 /* flags */

@@ -8,9 +8,9 @@
 // loss.backward() computes, over a caller-owned description of the model (tohip_traj_loss: pointers and constants only; the
 // library keeps no state).
 //
-//   tohip_traj_loss_forward    gather of the evaluated waypoints -> tohip_traj_forward's launches -> rewards, their mean, the
-//                              visibility loss and (same launch) the gradient sums of the flagged pairs with unit upstream
-//                              gradient -> criterion's regularisers with their analytic gradients
+//   tohip_traj_loss_forward    probe (every wps_step-th waypoint, read in place), pass 1, the fused sparse kernel (log-odds,
+//                              rewards, their sum, the gradient sums of the flagged pairs with unit upstream gradient) ->
+//                              criterion's regularisers with their analytic gradients and the visibility scalars
 //   tohip_traj_loss_backward   the per-waypoint finish of the visibility gradient (scaled by dL/d loss, read on the device)
 //                              -> full (W,3) / (W,4) gradients: evaluated rows scattered, the regularisers' gradient on top
 #include "common.hpp"
@@ -88,25 +88,17 @@ extern "C" int tohip_traj_loss_forward(const tohip_traj_loss* p, const float* po
     if (p->scratch_bytes < l.total) return TOHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream_;
     char* sc = (char*)p->scratch;
-    float* pe = (float*)(sc + l.off_pe);
-    float* qe = (float*)(sc + l.off_qe);
     float* lo = (float*)(sc + l.off_lo);
     float* mm = (float*)(sc + l.off_mm);
     float* scal = (float*)(sc + l.off_sc);
     float* reg = (float*)(sc + l.off_reg);
-    const float *pev = poses, *qev = quats;
-    if (p->wps_step > 1) {
-        const int n = (int)(l.n_eval * 4);
-        k_gather_waypoints<<<(n + 255) / 256, 256, 0, st>>>(poses, quats, (int)l.n_eval, p->wps_step, pe, qe);
-        TO_HIP_CHECK_LAUNCH();
-        pev = pe; qev = qe;
-    }
     const tohip_rig* rig = C > 1 || p->rig.rig_quats ? &p->rig : nullptr;
     // probe, pass 1, k_traj_sparse<FUSED>: log-odds, rewards, their integer sum, the pair sums with unit upstream gradient
     TrajStep s;
     int rc = traj_step_init(s, p->packed, p->n_points, l.n_eval, 1, nullptr, &p->cam, rig, p->flags, nullptr, p->workspace, p->workspace_bytes, st, true);
     if (rc != TOHIP_OK) return rc;
-    rc = traj_fused_forward(s, pev, qev, lo, mm, rewards);
+    s.wp_stride = p->wps_step;   // every wps_step-th waypoint is evaluated (model.py:215-217): the probe reads them in place
+    rc = traj_fused_forward(s, poses, quats, lo, mm, rewards);
     if (rc != TOHIP_OK) return rc;
     // criterion: the scalars of the visibility term come out of the integer reward sum first
     k_traj_regularizers<<<1, TO_BLOCK, 0, st>>>(poses, p->poses0, (int)p->n_wps, p->smoothness_weight, p->traj_length_weight, p->cam.eps,

@@ -109,11 +109,14 @@ struct TieRec {            // slots whose max equals the waypoint's max / whose 
 __device__ __forceinline__ void prep_wayrec(int v, const float* __restrict__ poses, const float* __restrict__ quats, int C,
                                             const float* __restrict__ rig_q, const float* __restrict__ rig_t,
                                             const EvalK& k, WayRec* __restrict__ rec, WayCold* __restrict__ cold,
-                                            const int* __restrict__ traj_off, int n_traj) {
+                                            const int* __restrict__ traj_off, int n_traj, int wp_stride = 1) {
     const int w = v / C, c = v - w * C;
     int seg = 0;
     if (traj_off != nullptr)
         while (seg + 1 < n_traj && w >= traj_off[seg + 1]) ++seg;
+    // wp_stride > 1: the evaluated waypoints are every wp_stride-th row of the caller's arrays (model.py:215-217), read in place
+    poses += (int64_t)3 * w * (wp_stride - 1);
+    quats += (int64_t)4 * w * (wp_stride - 1);
     float q[4] = {quats[4 * w], quats[4 * w + 1], quats[4 * w + 2], quats[4 * w + 3]};
     float ss = q[0] * q[0];
     ss = ss + q[1] * q[1];
@@ -255,13 +258,15 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
              const float* __restrict__ rig_q, const float* __restrict__ rig_t, EvalK k, WayRec* __restrict__ rec,
              WayCold* __restrict__ cold, Extrema* __restrict__ ext, TieRec* __restrict__ ties, const uint32_t* __restrict__ occ,
              int64_t occw, unsigned long long* __restrict__ fv, int fv_words, RewardAcc* __restrict__ acc,
-             const int* __restrict__ traj_off, int* __restrict__ traj_off_ws, int n_traj, int* __restrict__ cand, int ncand_words) {
+             const int* __restrict__ traj_off, int* __restrict__ traj_off_ws, int n_traj, int* __restrict__ cand, int ncand_words,
+             int wp_stride) {
     __shared__ float smx[TO_PROBE_THREADS / 64], smn[TO_PROBE_THREADS / 64];
     const int v = blockIdx.x, t = threadIdx.x;
     for (int j = t; j < fv_words; j += TO_PROBE_THREADS) fv[(int64_t)v * fv_words + j] = 0ull;
     for (int j = v * TO_PROBE_THREADS + t; j < ncand_words; j += gridDim.x * TO_PROBE_THREADS) cand[j] = 0;   // slot marks + the list's counter
     if (v == 0) {
         for (int j = t; j < n_traj * 8; j += TO_PROBE_THREADS) { acc[j >> 3].a[j & 7].sum = 0; acc[j >> 3].a[j & 7].nan = 0u; }
+        for (int j = t; j < n_traj; j += TO_PROBE_THREADS) acc[j].b.word = 0ull;   // (k_traj_reward leaves it zero; a launch that was cut short may not have)
         if (traj_off != nullptr)   // the calls that follow the forward (backward, finish) take no offsets: they read this copy
             for (int j = t; j <= n_traj; j += TO_PROBE_THREADS) traj_off_ws[j] = traj_off[j];
     }
@@ -275,7 +280,7 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
         const int sc = sj < cv.nsamples ? sj : 0;
         px[j] = cv.samples[sc]; py[j] = cv.samples[TO_PROBE_MAX + sc]; pz[j] = cv.samples[2 * TO_PROBE_MAX + sc];
     }
-    if (t == 0) prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, rec, cold, traj_off, n_traj);
+    if (t == 0) prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, rec, cold, traj_off, n_traj, wp_stride);
     __syncthreads();
     const WayRec r = rec[v];
     float mx = 0.f, mn = INFINITY;
@@ -1394,6 +1399,7 @@ struct TrajStep {
     const uint32_t* occ;
     int64_t occw;
     bool cull;
+    int wp_stride = 1;   // rows between two evaluated waypoints in the arrays handed to the probe
     RewardAcc* acc;
     WayRec* rec;
     WayCold* cold;
@@ -1449,10 +1455,10 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
         TO_PROF(TOHIP_PROF_SMALL, s.st);
         if (V <= 512)
             k_traj_probe<1024><<<V, 1024, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
-                                                     s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cand, s.pl.nslots + 1);
+                                                     s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cand, s.pl.nslots + 1, s.wp_stride);
         else
             k_traj_probe<256><<<V, 256, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
-                                                   s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cand, s.pl.nslots + 1);
+                                                   s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cand, s.pl.nslots + 1, s.wp_stride);
         TO_HIP_CHECK_LAUNCH();
     }
     const OutInit oi{lo_sum, rewards_half, s.cv.npad, s.n, (int)s.n_traj};
