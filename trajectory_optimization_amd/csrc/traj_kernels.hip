@@ -1064,30 +1064,11 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
     }
     // the waypoint's flag words first (one parallel load), then each group's bit of every word
     __shared__ unsigned long long sfv[1024];
-    double acc[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) acc[j] = 0.0;
-    for (int w0 = 0; w0 < fv_words; w0 += 1024) {
-        const int nw = min(1024, fv_words - w0);
-        __syncthreads();
-        for (int j = t; j < nw; j += THREADS) sfv[j] = fv[(int64_t)v * fv_words + w0 + j];
-        __syncthreads();
-        for (int w = 0; w < nw; ++w) {
-            const unsigned long long word = sfv[w];
-            if (word == 0ull) continue;
-#pragma unroll
-            for (int j = 0; j < PER; ++j)
-                if ((word >> (g + NG * j)) & 1ull) acc[j] += (double)bpart[((int64_t)v * nslots + ((w0 + w) * 64 + g + NG * j)) * 16 + kq];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < PER; ++j) sgrp[g + NG * j][kq] = acc[j];
-    // ---- argmin / argmax sets: waves 0..3 take a quarter (64 points) of every recorded slot each ----
     __shared__ double stie4[2][4][13];
-    __syncthreads();   // srow
-    if (t < 256) {
+    const int* tp = reinterpret_cast<const int*>(ties + v);
+    // ---- argmin / argmax sets: waves 0..3 take a quarter (64 points) of every recorded slot each ----
+    auto tie_sets = [&]() {
         const int wq = t >> 6, ln = t & 63;
-        const int* tp = reinterpret_cast<const int*>(ties + v);
         for (int set = 0; set < 2; ++set) {
             const int cnt = set ? tp[0] : tp[1];
             double tot[13];
@@ -1125,6 +1106,48 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
             if (ln == 63)
                 for (int j = 0; j < 13; ++j) stie4[set][wq][j] = tot[j];
         }
+    };
+    if (THREADS == 1024 && fv_words <= 1024) {
+        // The common shape: the two jobs run side by side.  Waves 0..3 re-evaluate the tie slots; waves 4..15 add the partials —
+        // 1024 (group, column) items on 768 threads, a third of them two — into the same 64 x 16 group sums, each in ascending slot order.
+        for (int j = t; j < fv_words; j += THREADS) sfv[j] = fv[(int64_t)v * fv_words + j];
+        __syncthreads();   // the flag words and the sorted tie slots
+        if (t < 256) {
+            tie_sets();
+        } else {
+            const int i0 = t - 256, i1 = i0 < 256 ? 768 + i0 : -1;
+            const int g0 = i0 >> 4, k0 = i0 & 15, g1 = i1 >> 4, k1 = i1 & 15;
+            double acc0 = 0.0, acc1 = 0.0;
+            for (int w = 0; w < fv_words; ++w) {
+                const unsigned long long word = sfv[w];
+                if (word == 0ull) continue;
+                if ((word >> g0) & 1ull) acc0 += (double)bpart[((int64_t)v * nslots + (w * 64 + g0)) * 16 + k0];
+                if (i1 >= 0 && ((word >> g1) & 1ull)) acc1 += (double)bpart[((int64_t)v * nslots + (w * 64 + g1)) * 16 + k1];
+            }
+            sgrp[g0][k0] = acc0;
+            if (i1 >= 0) sgrp[g1][k1] = acc1;
+        }
+    } else {
+        double acc[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) acc[j] = 0.0;
+        for (int w0 = 0; w0 < fv_words; w0 += 1024) {
+            const int nw = min(1024, fv_words - w0);
+            __syncthreads();
+            for (int j = t; j < nw; j += THREADS) sfv[j] = fv[(int64_t)v * fv_words + w0 + j];
+            __syncthreads();
+            for (int w = 0; w < nw; ++w) {
+                const unsigned long long word = sfv[w];
+                if (word == 0ull) continue;
+#pragma unroll
+                for (int j = 0; j < PER; ++j)
+                    if ((word >> (g + NG * j)) & 1ull) acc[j] += (double)bpart[((int64_t)v * nslots + ((w0 + w) * 64 + g + NG * j)) * 16 + kq];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) sgrp[g + NG * j][kq] = acc[j];
+        __syncthreads();   // srow
+        if (t < 256) tie_sets();
     }
     __syncthreads();
     if (t < 26) {   // ascending slot order inside a quarter, quarters in order: a fixed summation order
