@@ -280,9 +280,10 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
         const int sc = sj < cv.nsamples ? sj : 0;
         px[j] = cv.samples[sc]; py[j] = cv.samples[TO_PROBE_MAX + sc]; pz[j] = cv.samples[2 * TO_PROBE_MAX + sc];
     }
-    if (t == 0) prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, rec, cold, traj_off, n_traj, wp_stride);
+    __shared__ WayRec srec;   // the block's record: built by thread 0, read by everybody from LDS (not back from global memory)
+    if (t == 0) { prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, &srec - v, cold, traj_off, n_traj, wp_stride); rec[v] = srec; }
     __syncthreads();
-    const WayRec r = rec[v];
+    const WayRec r = srec;
     float mx = 0.f, mn = INFINITY;
     for (int rd = 0; rd < kRounds; ++rd) {
         if (rd > 0) {
