@@ -1,5 +1,6 @@
 // A host with no Python and no torch in it: the visibility forward + reward + backward of a small trajectory through
-// the C ABI of include/trajopt_hip.h — what a C or C++ caller links against.
+// the C ABI of include/trajopt_hip.h — what a C or C++ caller links against — as the three separate calls a sharded run
+// makes around its all-reduce, and as the one fused call of a single GPU.
 //
 //   hipcc --offload-arch=gfx950 -O2 -Iinclude examples/c_host.cpp -Ltrajectory_optimization_amd -ltrajopt_hip
 //         -Wl,-rpath,$PWD/trajectory_optimization_amd -o c_host && ./c_host [n_points] [n_wps]
@@ -75,6 +76,24 @@ int main(int argc, char** argv) {
     TO_OK(tohip_traj_backward(d_packed, n, W, &cam, nullptr, 0, nullptr, d_lo, nullptr, d_scalars, d_gout, d_pg, d_qg, d_ws, traj_ws,
                               st));
     HIP_OK(hipStreamSynchronize(st));
+    // the same step as ONE call (four launches): what a single-GPU caller uses, no collective between forward and backward
+    float* d_pg2 = dev_alloc<float>(3 * W);
+    float* d_qg2 = dev_alloc<float>(4 * W);
+    float* d_scalars2 = dev_alloc<float>(4);
+    float* d_rewards2 = dev_alloc<float>(n);
+    if (!d_pg2 || !d_qg2 || !d_scalars2 || !d_rewards2) return 2;
+    TO_OK(tohip_traj_forward_backward(d_packed, n, d_poses, d_quats, W, &cam, nullptr, 0, nullptr, d_lo, d_minmax, d_rewards2, d_scalars2, d_gout,
+                                      d_pg2, d_qg2, d_ws, traj_ws, st));
+    HIP_OK(hipStreamSynchronize(st));
+    float scalars2[4];
+    std::vector<float> pg2(3 * W), qg2(4 * W), r1(n), r2(n);
+    HIP_OK(hipMemcpy(scalars2, d_scalars2, sizeof(scalars2), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(pg2.data(), d_pg2, pg2.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(qg2.data(), d_qg2, qg2.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(r1.data(), d_rewards, r1.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(r2.data(), d_rewards2, r2.size() * sizeof(float), hipMemcpyDeviceToHost));
+    bool fused_rewards_equal = scalars2[0] == 0.f ? false : true;
+    for (int64_t i = 0; i < n; ++i) fused_rewards_equal = fused_rewards_equal && r1[i] == r2[i];
 
     float scalars[4];
     std::vector<float> pg(3 * W), qg(4 * W);
@@ -86,6 +105,11 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < pg.size(); ++i) std::printf("%s%.9g", i ? ", " : "", pg[i]);
     std::printf("], \"quats_grad\": [");
     for (size_t i = 0; i < qg.size(); ++i) std::printf("%s%.9g", i ? ", " : "", qg[i]);
-    std::printf("]}\n");
+    std::printf("], \"fused\": {\"mean_reward\": %.9g, \"loss_vis\": %.9g, \"rewards_equal\": %s, \"poses_grad\": [", scalars2[0], scalars2[1],
+                fused_rewards_equal ? "true" : "false");
+    for (size_t i = 0; i < pg2.size(); ++i) std::printf("%s%.9g", i ? ", " : "", pg2[i]);
+    std::printf("], \"quats_grad\": [");
+    for (size_t i = 0; i < qg2.size(); ++i) std::printf("%s%.9g", i ? ", " : "", qg2[i]);
+    std::printf("]}}\n");
     return 0;
 }

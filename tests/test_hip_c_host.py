@@ -53,3 +53,9 @@ def test_cpp_host_matches_python_path(tmp_path):
     assert np.array_equal(np.asarray(out["poses_grad"], np.float32).reshape(W, 3), pg.cpu().numpy())
     assert np.array_equal(np.asarray(out["quats_grad"], np.float32).reshape(W, 4), qg.cpu().numpy())
     assert 0.5 < out["mean_reward"] < 1.0 and np.abs(pg.cpu().numpy()).max() > 0
+    # the fused call of the same host: rewards and scalars bitwise the separate calls', gradients those of the Python fused path
+    f = out["fused"]
+    assert f["rewards_equal"] is True and np.float32(f["mean_reward"]) == scalars[0].item() and np.float32(f["loss_vis"]) == scalars[1].item()
+    r2 = ops.traj_forward_backward(cloud, p, q, cam, ws, torch.ones(1, device=dev))
+    assert np.array_equal(np.asarray(f["poses_grad"], np.float32).reshape(W, 3), r2[2].cpu().numpy())
+    assert np.array_equal(np.asarray(f["quats_grad"], np.float32).reshape(W, 4), r2[3].cpu().numpy())
