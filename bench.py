@@ -5,7 +5,7 @@ For N>1 the driver launches it under torch.distributed.run, one rank per GPU (RC
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): a 1 M-point synthetic
 cloud x 128 waypoints per GPU, full forward + backward to (x,y,z) and quaternion gradients, through the
-C ABI of include/trajopt_hip.h.  One "step" at N = 1 = tohip_traj_forward_backward (four launches); with N > 1 a collective sits
+C ABI of include/trajopt_hip.h.  One "step" at N = 1 = tohip_traj_forward_backward (five launches); with N > 1 a collective sits
 between forward and backward: tohip_traj_forward -> all-reduce of the log-odds vector -> tohip_traj_reward_backward -> all-gather of the
 (W,7) gradient rows.  With N
 GPUs the trajectory has 128*N waypoints sharded contiguously over the ranks (weak scaling; N=8 is configs[3],
@@ -315,9 +315,9 @@ def main():
                     help="cameras per waypoint (BASELINE.json configs[4]: 5, with --wps-per-gpu 32); each (camera, "
                          "waypoint) pair is one virtual waypoint with its own min-max normalisation")
     ap.add_argument("--fused-reward", choices=["on", "off"], default="on",
-                    help="on: tohip_traj_reward_backward (6 launches per step); off: tohip_traj_reward then tohip_traj_backward (7)")
+                    help="on: tohip_traj_reward_backward (5 launches per step); off: tohip_traj_reward then tohip_traj_backward (6)")
     ap.add_argument("--fused-step", choices=["on", "off"], default="on",
-                    help="N = 1: tohip_traj_forward_backward (4 launches); off: tohip_traj_forward then tohip_traj_reward_backward (5), the "
+                    help="N = 1: tohip_traj_forward_backward (5 launches); off: tohip_traj_forward then tohip_traj_reward_backward (5), the "
                          "split that a waypoint-sharded run needs around its all-reduce")
     ap.add_argument("--compact-allreduce", choices=["on", "off"], default="off",
                     help="N > 1: all-reduce only the slots some rank lists as candidates (a flag per slot MAX-reduced first; one host read of "
@@ -374,7 +374,7 @@ def main():
     def step(flags):
         rewards = rewards_buf
         if shard is None and args.fused_step == "on":
-            # no collective between forward and backward: the whole step is ONE library call, four launches
+            # no collective between forward and backward: the whole step is ONE library call, five launches
             rewards, scalars, pg, qg, _, _ = ops.traj_forward_backward(cloud, poses, quats, cam, ws, gout, rig=rig, flags=flags, lo_sum=lo_buf,
                                                                        minmax=mm_buf, rewards=rewards)
             return scalars, pg, qg, rewards
@@ -586,7 +586,7 @@ def main():
                        "n_points": args.points, "waypoints_total": w_total, "cameras": args.cameras,
                        "parallelism": f"waypoint-shard x{n_gpus}" if n_gpus > 1 else "single GPU",
                        "launch": "HIP graph replay of the step's launches" if use_graph else
-                                 ("tohip_traj_forward_backward: one host call, four launches" if (shard is None and args.fused_step == "on") else
+                                 ("tohip_traj_forward_backward: one host call, five launches" if (shard is None and args.fused_step == "on") else
                                   "tohip_traj_forward -> [all-reduce] -> tohip_traj_reward_backward [-> all-gather]: five launches"),
                        "mode": "dense: every (point, waypoint) pair evaluated, no data-dependent skipping; the 0.7 % of "
                                "(256-point slot, waypoint) pairs that can contribute are then revisited by the sparse kernel",

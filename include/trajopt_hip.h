@@ -80,7 +80,7 @@ int tohip_pack_cloud(const float *xyz, int64_t n_points, int sort, void *packed,
  * Workspace bytes needed by the calls below for n_points and n_virtual = W * max(1,n_cams) (at most 65 536 virtual waypoints).
  * THE WORKSPACE MUST BE ZERO-FILLED ONCE BEFORE ITS FIRST USE (hipMemset): tohip_traj_reward's accumulator word is expected
  * zero and left zero; every forward resets what a step accumulates into, that word included.  The forward leaves its state
- * there (waypoint records, per-waypoint extrema, the flags of the pairs that contribute, the candidate slots) and the backward
+ * there (waypoint records, per-waypoint extrema, the list of the pairs that contribute, the candidate slots) and the backward
  * of the same step reads it: do not touch the workspace between the two. */
 size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual);
 
@@ -172,8 +172,9 @@ int tohip_traj_reward_backward_multi(const void *packed, int64_t n_points, int64
                                      size_t workspace_bytes, void *stream);
 
 /* The whole step when NO collective sits between forward and backward (one GPU, or every rank holding all waypoints):
- * tohip_traj_forward + tohip_traj_reward + tohip_traj_backward of the fused visibility loss in FOUR launches — records + probe,
- * pass 1, one sparse kernel (log-odds, rewards, their sum, the gradient sums of the flagged pairs), the per-waypoint finish.
+ * tohip_traj_forward + tohip_traj_reward + tohip_traj_backward of the fused visibility loss in FIVE launches — records + probe,
+ * pass 1, the sparse kernel (flags, log-odds, rewards, their sum; a block per candidate slot), the gradient sums of the flagged
+ * (slot, waypoint) pairs (a wave per pair, dealt evenly to the whole chip), the per-waypoint finish.
  * Outputs as in the separate calls (lo_sum, minmax, rewards, scalars, poses_grad, quats_grad); gout = device pointer(s) to
  * dL/d loss_vis.  rewards, scalars and lo_sum are bitwise those of the separate calls; the gradients agree to rounding (the
  * dL/d reward factor is applied once per waypoint in f64 instead of once per point in f32).  replaces model.py:217-231,:237,:246
@@ -448,7 +449,7 @@ int64_t tohip_profile_clock_blocks(int64_t n_points, int64_t n_virtual, int flag
 
 /* Diagnostic: what the last forward over `workspace` found.  stats (DEVICE int64 x 4, zero-filled by the caller):
  * [0] flagged (256-point slot, virtual waypoint) pairs — the pairs with a non-zero log-odds term or a gradient;
- * [1] candidate slots listed by pass 1; [2] slots; [3] virtual waypoints. */
+ * [1] candidate (slot, trajectory) items listed by pass 1; [2] slots; [3] virtual waypoints. */
 int tohip_traj_step_stats(int64_t n_points, int64_t n_virtual, int64_t n_traj, const void *workspace, size_t workspace_bytes,
                           int64_t *stats, void *stream);
 

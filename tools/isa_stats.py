@@ -117,6 +117,27 @@ def hot_loop_ops(text, kernel_prefix, marker="s_load_dwordx16"):
             if any(x.startswith("v_min_i32_dpp") for x in region) and not any(x.startswith(("v_max_i32_dpp", "global_", "v_pk_")) for x in region):
                 for n in range(a + 1, b):
                     cold[n] = True
+    # blocks laid out after the loop's back edge that only cold code jumps to (the compiler moves a cold region's inner
+    # branches out of line): cold too.  A block = a label's ops up to the next label; it is cold when the op before it does not
+    # fall through into it (an unconditional s_branch, or cold) and every branch to its label is cold (a block without a label
+    # of its own is entered by falling through only).
+    changed = True
+    while changed:
+        changed = False
+        for a, (kind, l) in enumerate(sel):
+            if kind != "label":
+                continue
+            b = next((n for n in range(a + 1, len(sel)) if sel[n][0] == "label"), len(sel))
+            if b == a + 1 or all(cold[a + 1:b]):
+                continue
+            prev = next((n for n in range(a - 1, -1, -1) if sel[n][0] == "op"), None)
+            falls = prev is not None and not (cold[prev] or sel[prev][1].startswith("s_branch"))
+            srcs = [n for n, (kk, x) in enumerate(sel) if kk == "op" and x.startswith(("s_cbranch", "s_branch")) and x.split()[1] == l]
+            entered = bool(srcs) or (prev is not None and cold[prev] and not sel[prev][1].startswith("s_branch"))
+            if not falls and entered and all(cold[n] for n in srcs):
+                for n in range(a + 1, b):
+                    cold[n] = True
+                changed = True
     return [l.split()[0] for n, (kind, l) in enumerate(sel) if kind == "op" and not cold[n]], sum(1 for n, (kind, _) in enumerate(sel) if kind == "op" and cold[n])
 
 

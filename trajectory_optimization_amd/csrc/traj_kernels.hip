@@ -353,17 +353,23 @@ __device__ __forceinline__ bool fold_extrema(Extrema* __restrict__ ext, int v, f
     return cand;
 }
 
-// A candidate slot enters the list k_traj_sparse walks, once: the exchange on its mark decides, issued when the slot's first
-// candidate waypoint turns up (claim) so that its round trip runs under the remaining waypoints; the append follows at the end.
+// A candidate (slot, trajectory) enters the list k_traj_sparse walks, once, as item trajectory * nslots + slot: the exchange on
+// its mark decides, issued when its first candidate waypoint turns up (claim) so that its round trip runs under the remaining
+// waypoints; the append follows when the lane moves on to another trajectory's waypoints, or at the end.  nitems = nslots *
+// trajectories: the marks, then the list's counter.
 struct CandClaim {
-    int old = 1;          // the mark before this lane's exchange (0: this lane claimed the slot)
+    int old = 1;          // the mark before this lane's exchange (0: this lane claimed the item)
+    int item = 0;
     bool issued = false;
 };
-__device__ __forceinline__ void claim_candidate(CandClaim& c, int* __restrict__ cand, int slot) {
-    if (!c.issued) { c.old = atomicExch(&cand[slot], 1); c.issued = true; }
+__device__ __forceinline__ void list_candidate(CandClaim& c, int* __restrict__ cand, int* __restrict__ clist, int nitems) {
+    if (c.issued && c.old == 0) clist[atomicAdd(&cand[nitems], 1)] = c.item;
+    c.issued = false;
 }
-__device__ __forceinline__ void list_candidate(const CandClaim& c, int* __restrict__ cand, int* __restrict__ clist, int nslots, int slot) {
-    if (c.issued && c.old == 0) clist[atomicAdd(&cand[nslots], 1)] = slot;
+__device__ __forceinline__ void claim_candidate(CandClaim& c, int* __restrict__ cand, int* __restrict__ clist, int nslots, int nitems, int slot, int seg) {
+    const int item = seg * nslots + slot;
+    if (c.issued && c.item != item) list_candidate(c, cand, clist, nitems);
+    if (!c.issued) { c.old = atomicExch(&cand[item], 1); c.item = item; c.issued = true; }
 }
 
 __device__ __forceinline__ void pass1_eval(const EvalK& k, const WayRec& r, const float (&x)[TO_P], const float (&y)[TO_P],
@@ -409,7 +415,7 @@ __device__ __forceinline__ void init_outputs(int64_t base, const OutInit& o) {
 template <bool OCC>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk, EvalK k, float2* __restrict__ part,
-                   Extrema* __restrict__ ext, int* __restrict__ cand, int* __restrict__ clist, int nslots,
+                   Extrema* __restrict__ ext, int* __restrict__ cand, int* __restrict__ clist, int nslots, int nitems,
                    const uint32_t* __restrict__ occ, int64_t occw, OutInit oi, unsigned long long* __restrict__ stamps) {
     constexpr int P = TO_PD;
     const int lane = threadIdx.x & 63;
@@ -459,10 +465,10 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
             }
             if ((lane & 31) == 31) {
                 prow[v] = make_float2(mn, mx);
-                if (fold_extrema(ext, v, mn, mx, r)) claim_candidate(claim, cand, slot);
+                if (fold_extrema(ext, v, mn, mx, r)) claim_candidate(claim, cand, clist, nslots, nitems, slot, r.seg);
             }
         }
-        list_candidate(claim, cand, clist, nslots, slot);
+        list_candidate(claim, cand, clist, nitems);
         u += v1 - v0;
     }
     if (stamps != nullptr && threadIdx.x == 0) {
@@ -482,7 +488,7 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
 template <bool OCC>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile, EvalK k, float2* __restrict__ part,
-                  Extrema* __restrict__ ext, int* __restrict__ cand, int* __restrict__ clist, int nslots,
+                  Extrema* __restrict__ ext, int* __restrict__ cand, int* __restrict__ clist, int nslots, int nitems,
                   const uint32_t* __restrict__ occ, int64_t occw, OutInit oi) {
     constexpr int P = TO_P;
     const int lane = threadIdx.x & 63;
@@ -509,10 +515,10 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile
         pass1_eval(k, r, x, y, z, om, mn, mx);
         if (lane == 63) {
             prow[v] = make_float2(mn, mx);
-            if (fold_extrema(ext, v, mn, mx, r)) claim_candidate(claim, cand, slot);
+            if (fold_extrema(ext, v, mn, mx, r)) claim_candidate(claim, cand, clist, nslots, nitems, slot, r.seg);
         }
     }
-    list_candidate(claim, cand, clist, nslots, slot);
+    list_candidate(claim, cand, clist, nitems);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -538,7 +544,7 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile
 //             per lane over its four points, then one DPP tree over the wave.  FUSED takes the sums with dL/d reward = 1
 //             (they are linear in it; k_traj_finish scales them once the mean of the rewards is known).
 
-enum { TO_SP_FWD = 0, TO_SP_BWD = 1, TO_SP_FUSED = 2 };
+enum { TO_SP_FWD = 0, TO_SP_FUSED = 2 };
 #define TO_SP_THREADS 1024
 #define TO_SP_WAVES (TO_SP_THREADS / 64)
 #define TO_SP_CW 4                      // flag words (x 64 waypoints) staged at a time
@@ -553,7 +559,8 @@ struct SparseArgs {
     int V, nslots, vwords, fv_words;
     const int* clist;            // candidate slots (pass 1), clist_n[0] of them
     const int* clist_n;
-    unsigned long long* ft;
+    int2* plist;                 // the step's flagged (slot, waypoint) pairs, *npairs of them, in no particular order
+    int* npairs;                 //   (FWD / FUSED append, the pair kernel reads)
     unsigned long long* fv;
     TieRec* ties;
     float* lo_sum;               // n_traj x npad; FWD / FUSED write the flagged slots, BWD reads
@@ -586,6 +593,7 @@ struct SparseLds {
     StagedWay stage[TO_SP_STAGE];
     float4 spart[TO_SP_WAVES][64];
     int any[TO_SP_WAVES];
+    int pbase;
 };
 
 __device__ __forceinline__ f2 log_odds_pk(const EvalK& k, float a, float invM, f2 p) {
@@ -601,68 +609,60 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// one candidate slot; blockDim.x = TO_SP_THREADS.  Returns with every thread past its last use of the LDS.
+// one candidate slot for trajectory tr — its virtual waypoints [v_lo, v_hi), its own log-odds vector, rewards, sums and rank
+// count, so that its results are the ones a run of that trajectory alone produces; blockDim.x = TO_SP_THREADS.  Returns with
+// every thread past its last use of the LDS.
 template <int MODE, bool OCC>
-__device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int acc_line, SparseLds& L) {
+__device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int tr, int acc_line, SparseLds& L) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const EvalK& k = a.k;
     const int64_t base = (int64_t)slot * TO_SLOT + lane * 4;
     float x[4], y[4], z[4];
     load_points<4>(a.cv.soa, a.cv.npad, base, x, y, z);
-    // where the slot's points live in the caller's order (rewards / upstream gradients): requested now, wanted after the forward
+    // where the slot's points live in the caller's order (rewards): requested now, wanted after the forward
     int4 o4 = make_int4(0, 0, 0, 0);
-    if (MODE == TO_SP_FUSED ? wave == 0 : (MODE == TO_SP_BWD && a.grad_rewards != nullptr)) o4 = *reinterpret_cast<const int4*>(a.cv.perm + base);
+    if (MODE == TO_SP_FUSED && wave == 0) o4 = *reinterpret_cast<const int4*>(a.cv.perm + base);
 
+    const int v_lo = a.toff ? a.toff[tr] * a.C : 0, v_hi = a.toff ? a.toff[tr + 1] * a.C : a.V;
+    const int w_lo = v_lo >> 6, w_hi = min(a.vwords, (v_hi + 63) >> 6);
     // ---- flags of this slot, one word per 64 waypoints ----
-    unsigned long long mine = 0ull;
-    for (int w = wave; w < a.vwords; w += TO_SP_WAVES) {
-        unsigned long long word;
-        if constexpr (MODE == TO_SP_BWD) {
-            word = a.ft[(int64_t)slot * a.vwords + w];
-        } else {
-            const int v = w * 64 + lane;
-            bool flag = false;
-            if (v < a.V) {
-                const float2 pq = a.part[(int64_t)slot * a.V + v];
-                float av, pmax, M, invM;
-                load_norm(a.ext[v], av, pmax, M, invM);
-                const bool amin = av > 0.f;
-                const bool degenerate = !(M > 0.f) || !(invM < INFINITY);
-                flag = ((pq.y - av) * invM >= 0.5f) | (amin & (pq.x == av)) | degenerate;
-                {
-                    if (pq.y == pmax && M > 0.f) { const int i = atomicAdd(&a.ties[v].nmax, 1); if (i < TO_TIE_CAP) a.ties[v].maxrow[i] = slot; }
-                    if (amin && pq.x == av) { const int i = atomicAdd(&a.ties[v].nmin, 1); if (i < TO_TIE_CAP) a.ties[v].minrow[i] = slot; }
-                    if (flag) atomicOr(&a.fv[(int64_t)v * a.fv_words + (slot >> 6)], 1ull << (slot & 63));
-                }
-            }
-            word = __ballot(flag);
-            if (lane == 0) a.ft[(int64_t)slot * a.vwords + w] = word;
+    int mine = 0;
+    for (int w = w_lo + wave; w < w_hi; w += TO_SP_WAVES) {
+        const int v = w * 64 + lane;
+        bool flag = false;
+        if (v >= v_lo && v < v_hi) {
+            const float2 pq = a.part[(int64_t)slot * a.V + v];
+            float av, pmax, M, invM;
+            load_norm(a.ext[v], av, pmax, M, invM);
+            const bool amin = av > 0.f;
+            const bool degenerate = !(M > 0.f) || !(invM < INFINITY);
+            flag = ((pq.y - av) * invM >= 0.5f) | (amin & (pq.x == av)) | degenerate;
+            if (pq.y == pmax && M > 0.f) { const int i = atomicAdd(&a.ties[v].nmax, 1); if (i < TO_TIE_CAP) a.ties[v].maxrow[i] = slot; }
+            if (amin && pq.x == av) { const int i = atomicAdd(&a.ties[v].nmin, 1); if (i < TO_TIE_CAP) a.ties[v].minrow[i] = slot; }
+            if (flag) atomicOr(&a.fv[(int64_t)v * a.fv_words + (slot >> 6)], 1ull << (slot & 63));
         }
+        const unsigned long long word = __ballot(flag);
         if (lane == 0) L.sflag[w] = word;
-        mine |= word;
+        mine += __popcll(word);
     }
-    if (lane == 0) L.any[wave] = mine != 0ull;
+    if (lane == 0) L.any[wave] = mine;
     __syncthreads();
-    bool anyf = false;
+    int npairs = 0;
 #pragma unroll
-    for (int w = 0; w < TO_SP_WAVES; ++w) anyf |= L.any[w] != 0;
-    if (!anyf) { __syncthreads(); return; }   // a candidate that is not flagged after all: lo_sum 0, rewards 1/2 (pass 1 wrote them)
+    for (int w = 0; w < TO_SP_WAVES; ++w) npairs += L.any[w];
+    if (npairs == 0) { __syncthreads(); return; }   // a candidate that is not flagged after all: lo_sum 0, rewards 1/2 (pass 1 wrote them)
+    // room for the slot's pairs in the step's pair list: asked for by a thread with no other load in flight, wanted at the end
+    // (an offset the compiler cannot see through keeps the add a plain one-lane atomic: the wave-aggregated form it would build
+    // for a uniform address waits for the result on the spot)
+    int pbase = 0;
+    if (t == TO_SP_THREADS - 1) {
+        int zero = 0;
+        asm volatile("" : "+v"(zero));
+        pbase = atomicAdd(a.npairs + zero, npairs);
+    }
 
-    for (int tr = 0; tr < a.n_traj; ++tr) {
-        // the trajectory's virtual waypoints [v_lo, v_hi): its own log-odds vector, rewards, sums and rank count, so that its
-        // results are the ones a run of that trajectory alone produces
-        const int v_lo = a.toff ? a.toff[tr] * a.C : 0, v_hi = a.toff ? a.toff[tr + 1] * a.C : a.V;
-        const int w_lo = v_lo >> 6, w_hi = min(a.vwords, (v_hi + 63) >> 6);
-        auto flagged = [&](int w) {
-            unsigned long long bits = uniform_u64(L.sflag[w]);
-            if (w * 64 < v_lo) bits &= ~0ull << (v_lo - w * 64);
-            if (v_hi - w * 64 < 64) bits &= (1ull << (v_hi - w * 64)) - 1ull;
-            return bits;
-        };
-        bool any = false;
-        for (int w = w_lo; w < w_hi; ++w) any |= flagged(w) != 0ull;
-        if (!any) continue;   // block-uniform
-        const bool one_chunk = (w_hi - w_lo) <= TO_SP_CW;
+    {
+        auto flagged = [&](int w) { return uniform_u64(L.sflag[w]); };
         // stage the flagged waypoints of words [wc, wc + CW): entry = rank inside the chunk; returns their number
         auto stage_chunk = [&](int wc) {
             int cnt = 0, my_rank = -1, my_v = -1;
@@ -688,7 +688,7 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int a
             return cnt;
         };
         float lo[4];
-        if constexpr (MODE != TO_SP_BWD) {
+        {
             f2 acc0 = pk_splat(0.f), acc1 = pk_splat(0.f);
             int rank0 = 0;
             for (int wc = w_lo; wc < w_hi; wc += TO_SP_CW) {
@@ -705,7 +705,7 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int a
                     acc1 = acc1 + (log_odds_pk(k, r.a, r.invM, p1) + poison);
                 }
                 rank0 += cnt;
-                if (!one_chunk) __syncthreads();   // the stage is rewritten by the next chunk
+                if (wc + TO_SP_CW < w_hi) __syncthreads();   // the stage is rewritten by the next chunk
             }
             L.spart[wave][lane] = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
             __syncthreads();
@@ -717,16 +717,10 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int a
             }
             lo[0] = s.x; lo[1] = s.y; lo[2] = s.z; lo[3] = s.w;
             if (wave == 0) *reinterpret_cast<float4*>(a.lo_sum + (int64_t)tr * a.cv.npad + base) = s;
-        } else {
-            const float4 l4 = *reinterpret_cast<const float4*>(a.lo_sum + (int64_t)tr * a.cv.npad + base);
-            lo[0] = l4.x; lo[1] = l4.y; lo[2] = l4.z; lo[3] = l4.w;
         }
-        if constexpr (MODE == TO_SP_FWD) { __syncthreads(); continue; }   // spart and the stage are free for the next trajectory
 
-        // ---- rewards of the slot's points, dL/d lo_sum_n ----
-        float gn[4];
-        {
-            const float coef = (MODE == TO_SP_BWD && a.scalars) ? a.scalars[4 * tr + 2] * a.gout[tr] : 1.0f;
+        // ---- rewards of the slot's points (wave 0) ----
+        if (MODE == TO_SP_FUSED && wave == 0) {
             const int o[4] = {o4.x, o4.y, o4.z, o4.w};
             long long fsum = 0;
             bool fnan = false;
@@ -734,88 +728,34 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int a
             for (int j = 0; j < 4; ++j) {
                 float rw = to_rcp(1.0f + to_exp(-lo[j]));   // == k_traj_reward's value of rewards[perm[i]]
                 if (lo[j] != lo[j]) rw = lo[j];
-                const bool valid = base + j < a.cv.n;        // pads are not points
-                float gr = coef;
-                if (MODE == TO_SP_BWD && a.grad_rewards != nullptr) gr = valid ? a.grad_rewards[(int64_t)tr * a.cv.n + o[j]] : 0.f;
-                gn[j] = valid ? gr * rw * (1.0f - rw) : 0.f;
-                if (MODE == TO_SP_FUSED && wave == 0 && valid) {
+                if (base + j < a.cv.n) {                      // pads are not points
                     if (!a.prefilled || lo[j] != 0.f) a.rewards[(int64_t)tr * a.cv.n + o[j]] = rw;
                     if (rw != rw) fnan = true;
                     else fsum += reward_fixed(rw, a.shift) - (1ll << (a.shift - 1));
                 }
             }
-            if (MODE == TO_SP_FUSED && wave == 0) {
-                for (int s = 32; s > 0; s >>= 1) fsum += __shfl_xor(fsum, s);
-                fnan = __any(fnan);
-                if (lane == 0) {
-                    if (fsum != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&a.acc[tr].a[acc_line].sum), (unsigned long long)fsum);
-                    if (fnan) atomicOr(&a.acc[tr].a[acc_line].nan, 1u);
-                }
+            for (int s = 32; s > 0; s >>= 1) fsum += __shfl_xor(fsum, s);
+            fnan = __any(fnan);
+            if (lane == 0) {
+                if (fsum != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&a.acc[tr].a[acc_line].sum), (unsigned long long)fsum);
+                if (fnan) atomicOr(&a.acc[tr].a[acc_line].nan, 1u);
             }
         }
-
-        // ---- gradient sums of the flagged pairs ----
-        int rank0 = 0;
-        for (int wc = w_lo; wc < w_hi; wc += TO_SP_CW) {
-            int cnt;
-            if (MODE == TO_SP_FUSED && one_chunk) {   // still staged by the forward sweep
-                cnt = 0;
-                for (int w = w_lo; w < w_hi; ++w) cnt += __popcll(flagged(w));
-            } else {
-                cnt = stage_chunk(wc);
-            }
-            for (int e = ((wave - rank0) & (TO_SP_WAVES - 1)); e < cnt; e += TO_SP_WAVES) {
-                const StagedWay& r = L.stage[e];
-                const float av = r.a, invM = r.invM;
-                float om[4];
-                load_occ<4, OCC>(a.occ, a.occw, r.v, base, om);
-                f2 acc[TO_BWD_NSUM];
+        if (t == TO_SP_THREADS - 1) L.pbase = pbase;   // (a device-scope atomic's answer takes microseconds: first read here)
+        __syncthreads();
+    }
+    // the slot's pairs: a position each (the waves' counts, then the wave's words in its order, then the bit's rank)
+    {
+        int at = L.pbase;
 #pragma unroll
-                for (int j = 0; j < TO_BWD_NSUM; ++j) acc[j] = pk_splat(0.f);
-                bool any_act = false;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    VisGrad2 vg;
-                    const f2 p = vis_p_pk_grad(r, k, f2{x[2 * h], x[2 * h + 1]}, f2{y[2 * h], y[2 * h + 1]}, f2{z[2 * h], z[2 * h + 1]}, vg) *
-                                 f2{om[2 * h], om[2 * h + 1]};
-                    const f2 ph = (p - pk_splat(av)) * pk_splat(invM);
-                    const bool act0 = (ph.x >= 0.5f) && (ph.x <= k.clip_hi), act1 = (ph.y >= 0.5f) && (ph.y <= k.clip_hi);
-                    if (act0 | act1) {
-                        f2 g[3];
-                        dvis_dy_pk(r, k, p, vg, g);
-                        const f2 G = f2{gn[2 * h], gn[2 * h + 1]} * pk_rcp(ph * (pk_splat(1.0f) - ph));
-                        f2 wgt = G * pk_splat(invM);
-                        wgt = f2{act0 ? wgt.x : 0.f, act1 ? wgt.y : 0.f};
-                        acc[12] = pk_fma(wgt, ph - pk_splat(1.0f), acc[12]);
-                        acc[13] = pk_fma(-wgt, ph, acc[13]);
-                        const f2 w0 = wgt * g[0], w1 = wgt * g[1], w2 = wgt * g[2];
-                        acc[0] = acc[0] + w0; acc[1] = acc[1] + w1; acc[2] = acc[2] + w2;
-                        acc[3] = pk_fma(vg.y0, w0, acc[3]); acc[4] = pk_fma(vg.y0, w1, acc[4]); acc[5] = pk_fma(vg.y0, w2, acc[5]);
-                        acc[6] = pk_fma(vg.y1, w0, acc[6]); acc[7] = pk_fma(vg.y1, w1, acc[7]); acc[8] = pk_fma(vg.y1, w2, acc[8]);
-                        acc[9] = pk_fma(vg.y2, w0, acc[9]); acc[10] = pk_fma(vg.y2, w1, acc[10]); acc[11] = pk_fma(vg.y2, w2, acc[11]);
-                        any_act = true;
-                    }
-                }
-                float sum[TO_BWD_NSUM];
-#pragma unroll
-                for (int j = 0; j < TO_BWD_NSUM; ++j) sum[j] = acc[j].x + acc[j].y;
-                if (__any(any_act)) {
-#pragma unroll
-                    for (int j = 0; j < TO_BWD_NSUM; ++j) sum[j] = wave_sum63(sum[j]);
-                }
-                if (lane == 63) {
-                    float4* dst = reinterpret_cast<float4*>(a.bpart + ((int64_t)r.v * a.nslots + slot) * 16);
-                    dst[0] = make_float4(sum[0], sum[1], sum[2], sum[3]);
-                    dst[1] = make_float4(sum[4], sum[5], sum[6], sum[7]);
-                    dst[2] = make_float4(sum[8], sum[9], sum[10], sum[11]);
-                    dst[3] = make_float4(sum[12], sum[13], 0.f, 0.f);   // the finish kernel adds all 16 columns of a row
-                }
-            }
-            rank0 += cnt;
-            __syncthreads();   // the stage (and spart) are free again
+        for (int w = 0; w < TO_SP_WAVES; ++w) at += w < wave ? L.any[w] : 0;
+        for (int w = w_lo + wave; w < w_hi; w += TO_SP_WAVES) {
+            const unsigned long long word = uniform_u64(L.sflag[w]);
+            if ((word >> lane) & 1ull) a.plist[at + __popcll(word & ((1ull << lane) - 1ull))] = make_int2(slot, w * 64 + lane);
+            at += __popcll(word);
         }
     }
-    __syncthreads();   // the flag words are free for the block's next slot
+    __syncthreads();   // the flag words are free for the block's next item
 }
 
 // (a, M) per virtual waypoint for the caller (tohip_traj_forward's minmax output): block 0, before its first slot
@@ -829,22 +769,130 @@ __device__ __forceinline__ void write_minmax(const SparseArgs& a) {
     }
 }
 
-// block b of nb walks the candidate list with stride nb (one 16-wave block is resident per CU at this kernel's register count)
+// block b of nb walks the list of candidate (slot, trajectory) items with stride nb (one 16-wave block is resident per CU at
+// this kernel's register count)
 template <int MODE, bool OCC>
 __device__ __forceinline__ void sparse_walk(const SparseArgs& a, int b, int nb, SparseLds& L) {
-    int slot = a.clist[b];   // requested with the list's length, not after it (the list's buffer holds one int per slot >= blocks)
+    int item = a.clist[b];   // requested with the list's length, not after it (the list's buffer holds one int per item >= blocks)
     const int n = *a.clist_n;
     for (int li = b; li < n; li += nb) {
-        sparse_slot<MODE, OCC>(a, slot, b & 7, L);
-        if (li + nb < n) slot = a.clist[li + nb];
+        const int tr = item / a.nslots;
+        sparse_slot<MODE, OCC>(a, item - tr * a.nslots, tr, b & 7, L);
+        if (li + nb < n) item = a.clist[li + nb];
     }
 }
 
 template <int MODE, bool OCC>
 __global__ void __launch_bounds__(TO_SP_THREADS) k_traj_sparse(SparseArgs a) {
     __shared__ SparseLds L;
-    if (MODE != TO_SP_BWD && blockIdx.x == 0) write_minmax(a);
+    if (blockIdx.x == 0) write_minmax(a);
     sparse_walk<MODE, OCC>(a, (int)blockIdx.x, (int)gridDim.x, L);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The gradient sums of the flagged (slot, waypoint) pairs, one WAVE per pair, the pairs dealt round-robin to every wave of the
+// grid: a slot seen by forty waypoints and one seen by a single waypoint cost their blocks the same in k_traj_sparse, and
+// the chip is evenly loaded here whatever the pairs' distribution over the slots (a dense indoor cloud flags 6x the pairs of the
+// BASELINE slab in a third of the slots).  The pairs come from the list k_traj_sparse appended them to (their order there is
+// arrival order; a pair's row does not depend on it).  A wave reads its pair's waypoint record with scalar loads (the index is
+// uniform), the slot's four points per lane, their log-odds and, when the upstream gradient is per point, its entries.
+//   per flagged pair: G = dL/dp_hat = g_n [0.5 <= p_hat <= 1-eps] / (p_hat (1 - p_hat)), dL/dp = G / M, plus
+//   the shares of the min/max points (S1 = sum G (p_hat - 1)/M -> argmin set, S2 = sum G (-p_hat)/M -> argmax
+//   set; torch splits them evenly among ties).  bpart[(v*nslots+slot)*16 ..]:
+//     [0..2] sum w gy   [3..11] sum w y (x) gy   [12] S1   [13] S2        (w = G/M, gy = dp/dy, y = x - t)
+//   per lane over its four points, then one DPP tree over the wave.  The fused step takes the sums with dL/d reward = 1
+//   (they are linear in it; k_traj_finish scales them once the mean of the rewards is known).
+template <bool OCC>
+__device__ __forceinline__ void pair_sums(const SparseArgs& a, int slot, int v, int lane) {
+    const EvalK& k = a.k;
+    const WayRec& r = a.rec[v];
+    const int tr = a.toff ? r.seg : 0;
+    const int64_t base = (int64_t)slot * TO_SLOT + lane * 4;
+    float x[4], y[4], z[4];
+    load_points<4>(a.cv.soa, a.cv.npad, base, x, y, z);
+    const float4 l4 = *reinterpret_cast<const float4*>(a.lo_sum + (int64_t)tr * a.cv.npad + base);
+    int4 o4 = make_int4(0, 0, 0, 0);
+    if (a.grad_rewards != nullptr) o4 = *reinterpret_cast<const int4*>(a.cv.perm + base);
+    float om[4];
+    load_occ<4, OCC>(a.occ, a.occw, v, base, om);
+    float av, pmax, M, invM;
+    load_norm(a.ext[v], av, pmax, M, invM);
+    if (!(M > 0.f) || !(invM < INFINITY)) invM = __builtin_nanf("");   // degenerate: nothing is active (NaN compares false)
+    const float coef = a.scalars ? a.scalars[4 * tr + 2] * a.gout[tr] : 1.0f;
+    const float lo[4] = {l4.x, l4.y, l4.z, l4.w};
+    const int o[4] = {o4.x, o4.y, o4.z, o4.w};
+    float gn[4];   // dL/d lo_sum_n
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float rw = to_rcp(1.0f + to_exp(-lo[j]));
+        if (lo[j] != lo[j]) rw = lo[j];
+        const bool valid = base + j < a.cv.n;        // pads are not points
+        float gr = coef;
+        if (a.grad_rewards != nullptr) gr = valid ? a.grad_rewards[(int64_t)tr * a.cv.n + o[j]] : 0.f;
+        gn[j] = valid ? gr * rw * (1.0f - rw) : 0.f;
+    }
+    f2 acc[TO_BWD_NSUM];
+#pragma unroll
+    for (int j = 0; j < TO_BWD_NSUM; ++j) acc[j] = pk_splat(0.f);
+    bool any_act = false;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        VisGrad2 vg;
+        const f2 p = vis_p_pk_grad(r, k, f2{x[2 * h], x[2 * h + 1]}, f2{y[2 * h], y[2 * h + 1]}, f2{z[2 * h], z[2 * h + 1]}, vg) *
+                     f2{om[2 * h], om[2 * h + 1]};
+        const f2 ph = (p - pk_splat(av)) * pk_splat(invM);
+        const bool act0 = (ph.x >= 0.5f) && (ph.x <= k.clip_hi), act1 = (ph.y >= 0.5f) && (ph.y <= k.clip_hi);
+        if (act0 | act1) {
+            f2 g[3];
+            dvis_dy_pk(r, k, p, vg, g);
+            const f2 G = f2{gn[2 * h], gn[2 * h + 1]} * pk_rcp(ph * (pk_splat(1.0f) - ph));
+            f2 wgt = G * pk_splat(invM);
+            wgt = f2{act0 ? wgt.x : 0.f, act1 ? wgt.y : 0.f};
+            acc[12] = pk_fma(wgt, ph - pk_splat(1.0f), acc[12]);
+            acc[13] = pk_fma(-wgt, ph, acc[13]);
+            const f2 w0 = wgt * g[0], w1 = wgt * g[1], w2 = wgt * g[2];
+            acc[0] = acc[0] + w0; acc[1] = acc[1] + w1; acc[2] = acc[2] + w2;
+            acc[3] = pk_fma(vg.y0, w0, acc[3]); acc[4] = pk_fma(vg.y0, w1, acc[4]); acc[5] = pk_fma(vg.y0, w2, acc[5]);
+            acc[6] = pk_fma(vg.y1, w0, acc[6]); acc[7] = pk_fma(vg.y1, w1, acc[7]); acc[8] = pk_fma(vg.y1, w2, acc[8]);
+            acc[9] = pk_fma(vg.y2, w0, acc[9]); acc[10] = pk_fma(vg.y2, w1, acc[10]); acc[11] = pk_fma(vg.y2, w2, acc[11]);
+            any_act = true;
+        }
+    }
+    float sum[TO_BWD_NSUM];
+#pragma unroll
+    for (int j = 0; j < TO_BWD_NSUM; ++j) sum[j] = acc[j].x + acc[j].y;
+    if (__any(any_act)) {
+#pragma unroll
+        for (int j = 0; j < TO_BWD_NSUM; ++j) sum[j] = wave_sum63(sum[j]);
+    }
+    if (lane == 63) {
+        float4* dst = reinterpret_cast<float4*>(a.bpart + ((int64_t)v * a.nslots + slot) * 16);
+        dst[0] = make_float4(sum[0], sum[1], sum[2], sum[3]);
+        dst[1] = make_float4(sum[4], sum[5], sum[6], sum[7]);
+        dst[2] = make_float4(sum[8], sum[9], sum[10], sum[11]);
+        dst[3] = make_float4(sum[12], sum[13], 0.f, 0.f);   // the finish kernel adds all 16 columns of a row
+    }
+}
+
+// block b of nb (TO_SP_THREADS threads each): wave gw = 16 b + wave of 16 nb takes the pairs gw, gw + 16 nb, ...
+template <bool OCC>
+__device__ __forceinline__ void pair_walk(const SparseArgs& a, int b, int nb) {
+    const int lane = threadIdx.x & 63;
+    const int gw = __builtin_amdgcn_readfirstlane(b * TO_SP_WAVES + (int)(threadIdx.x >> 6)), GW = nb * TO_SP_WAVES;
+    // the wave's first pair is requested with the list's length, not after it (an entry beyond the length is last step's: unused)
+    const int64_t cap = (int64_t)a.V * a.nslots;
+    int2 next = gw < cap ? a.plist[gw] : make_int2(0, 0);
+    const int P = *a.npairs;
+    for (int p = gw; p < P; p += GW) {
+        const int2 cur = next;
+        if (p + GW < P) next = a.plist[p + GW];
+        pair_sums<OCC>(a, __builtin_amdgcn_readfirstlane(cur.x), __builtin_amdgcn_readfirstlane(cur.y), lane);
+    }
+}
+
+template <bool OCC>
+__global__ void __launch_bounds__(TO_SP_THREADS) k_traj_pairs(SparseArgs a) {
+    pair_walk<OCC>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -917,19 +965,18 @@ k_traj_reward(const float* __restrict__ lo_sum, const int* __restrict__ perm, in
 }
 
 // rewards + mean + loss (the first nbx * n_traj blocks) and the gradient sums with unit upstream gradient (the other blocks:
-// k_traj_sparse<BWD>'s list walkers) in ONE launch: both need the complete log-odds vector and nothing of each other.
+// k_traj_pairs' waves) in ONE launch: both need the complete log-odds vector and nothing of each other.
 template <bool OCC>
 __global__ void __launch_bounds__(TO_SP_THREADS)
 k_traj_reward_bwd(const float* __restrict__ lo_sum, int64_t n, float eps, int prefilled, float* __restrict__ rewards,
                   float* __restrict__ scalars, int nbx, SparseArgs a) {
-    __shared__ SparseLds L;
+    __shared__ long long lds[2 * TO_SP_WAVES];
     const int R = nbx * a.n_traj;
     if ((int)blockIdx.x < R) {
-        reward_block(lo_sum, a.cv.perm, n, a.cv.npad, eps, a.shift, prefilled, rewards, a.acc, scalars, blockIdx.x % nbx, nbx, blockIdx.x / nbx,
-                     reinterpret_cast<long long*>(L.sflag));
+        reward_block(lo_sum, a.cv.perm, n, a.cv.npad, eps, a.shift, prefilled, rewards, a.acc, scalars, blockIdx.x % nbx, nbx, blockIdx.x / nbx, lds);
         return;
     }
-    sparse_walk<TO_SP_BWD, OCC>(a, (int)blockIdx.x - R, (int)gridDim.x - R, L);
+    pair_walk<OCC>(a, (int)blockIdx.x - R, (int)gridDim.x - R);
 }
 
 // thread per body waypoint: rig composition, dL/dt = -R sum dL/dc, dL/dR = sum y (x) dL/dc,
@@ -1339,10 +1386,11 @@ struct TrajPlan {
     int64_t npad;
     int nblk;      // culled pass-1 point blocks (1024 points each)
     int nslots;    // npad / 256
+    int nitems;    // nslots x trajectories: the (slot, trajectory) items pass 1 may list
     int fv_words;  // (nslots + 63) / 64
     int vwords;    // (V + 63) / 64
     int V;
-    size_t off_ctl, off_toff, off_rec, off_cold, off_ext, off_cand, off_clist, off_part, off_fv, off_ft, off_ties, off_bpart, off_vgrad, total;
+    size_t off_ctl, off_toff, off_rec, off_cold, off_ext, off_cand, off_clist, off_part, off_fv, off_plist, off_ties, off_bpart, off_vgrad, total;
 };
 
 inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
@@ -1350,6 +1398,7 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
     p.npad = tohip_padded_points(n);
     p.nblk = (int)(p.npad / (TO_BLOCK * TO_P));
     p.nslots = (int)(p.npad / TO_SLOT);
+    p.nitems = (int)((int64_t)p.nslots * (n_traj < 1 ? 1 : n_traj));
     p.fv_words = (p.nslots + 63) / 64;
     p.vwords = (int)((V + 63) / 64);
     p.V = (int)V;
@@ -1359,11 +1408,11 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
     p.off_rec = o;   o += align_up((size_t)V * sizeof(WayRec), 256);
     p.off_cold = o;  o += align_up((size_t)W * sizeof(WayCold), 256);
     p.off_ext = o;   o += align_up((size_t)V * sizeof(Extrema), 256);
-    p.off_cand = o;  o += align_up(((size_t)p.nslots + 1) * sizeof(int), 256);   // a mark per slot, then the candidate list's counter
-    p.off_clist = o; o += align_up((size_t)p.nslots * sizeof(int), 256);
+    p.off_cand = o;  o += align_up(((size_t)p.nitems + 2) * sizeof(int), 256);   // a mark per item, then the candidate list's and the pair list's counters
+    p.off_clist = o; o += align_up((size_t)p.nitems * sizeof(int), 256);
     p.off_part = o;  o += align_up((size_t)V * (size_t)p.nslots * sizeof(float2), 256);
     p.off_fv = o;    o += align_up((size_t)V * (size_t)p.fv_words * sizeof(unsigned long long), 256);
-    p.off_ft = o;    o += align_up((size_t)p.nslots * (size_t)p.vwords * sizeof(unsigned long long), 256);
+    p.off_plist = o; o += align_up((size_t)V * (size_t)p.nslots * sizeof(int2), 256);   // every pair flagged: the same bytes as part
     p.off_ties = o;  o += align_up((size_t)V * sizeof(TieRec), 256);
     p.off_bpart = o; o += align_up((size_t)V * (size_t)p.nslots * 16 * sizeof(float), 256);
     p.off_vgrad = o; o += align_up((size_t)V * 12 * sizeof(float), 256);
@@ -1429,8 +1478,9 @@ struct TrajStep {
     WayCold* cold;
     Extrema* ext;
     int *cand, *clist;
+    int2* plist;
     float2* part;
-    unsigned long long *fv, *ft;
+    unsigned long long* fv;
     TieRec* ties;
     float *bpart, *vgrad;
     int shift;
@@ -1443,7 +1493,7 @@ inline int traj_step_init(TrajStep& s, const void* packed, int64_t n, int64_t W,
     s.st = (hipStream_t)stream_;
     s.C = rig_cams(rig);
     s.n = n; s.W = W; s.V = W * s.C; s.n_traj = n_traj;
-    if (s.V > 64 * TO_SP_MAXW) return TOHIP_EINVAL;
+    if (s.V > 64 * TO_SP_MAXW || (int64_t)(tohip_padded_points(n) / TO_SLOT) * n_traj > (int64_t)1 << 30) return TOHIP_EINVAL;
     s.pl = make_plan(n, s.V, W, n_traj);
     if (workspace_bytes < s.pl.total) return TOHIP_ENOSPC;
     char* ws = (char*)workspace;
@@ -1453,9 +1503,9 @@ inline int traj_step_init(TrajStep& s, const void* packed, int64_t n, int64_t W,
     s.ext = (Extrema*)(ws + s.pl.off_ext);
     s.cand = (int*)(ws + s.pl.off_cand);
     s.clist = (int*)(ws + s.pl.off_clist);
+    s.plist = (int2*)(ws + s.pl.off_plist);
     s.part = (float2*)(ws + s.pl.off_part);
     s.fv = (unsigned long long*)(ws + s.pl.off_fv);
-    s.ft = (unsigned long long*)(ws + s.pl.off_ft);
     s.ties = (TieRec*)(ws + s.pl.off_ties);
     s.bpart = (float*)(ws + s.pl.off_bpart);
     s.vgrad = (float*)(ws + s.pl.off_vgrad);
@@ -1479,10 +1529,10 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
         TO_PROF(TOHIP_PROF_SMALL, s.st);
         if (V <= 512)
             k_traj_probe<1024><<<V, 1024, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
-                                                     s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cand, s.pl.nslots + 1, s.wp_stride);
+                                                     s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cand, s.pl.nitems + 2, s.wp_stride);
         else
             k_traj_probe<256><<<V, 256, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
-                                                   s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cand, s.pl.nslots + 1, s.wp_stride);
+                                                   s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cand, s.pl.nitems + 2, s.wp_stride);
         TO_HIP_CHECK_LAUNCH();
     }
     const OutInit oi{lo_sum, rewards_half, s.cv.npad, s.n, (int)s.n_traj};
@@ -1493,13 +1543,13 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
             int vtile, ntiles;
             cull_tiles(V, &vtile, &ntiles);
             const dim3 grid(s.pl.nblk, ntiles);
-            if (occ) k_traj_pass1_cull<true><<<grid, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, vtile, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.occ, s.occw, oi);
-            else k_traj_pass1_cull<false><<<grid, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, vtile, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.occ, s.occw, oi);
+            if (occ) k_traj_pass1_cull<true><<<grid, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, vtile, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.pl.nitems, s.occ, s.occw, oi);
+            else k_traj_pass1_cull<false><<<grid, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, vtile, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.pl.nitems, s.occ, s.occw, oi);
         } else {
             const int nblk8 = (int)(s.pl.npad / (TO_BLOCK * TO_PD));
             const int nb = dense_blocks(nblk8, V, occ);
-            if (occ) k_traj_pass1_dense<true><<<nb, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, nblk8, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.occ, s.occw, oi, clock_stamps());
-            else k_traj_pass1_dense<false><<<nb, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, nblk8, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.occ, s.occw, oi, clock_stamps());
+            if (occ) k_traj_pass1_dense<true><<<nb, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, nblk8, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.pl.nitems, s.occ, s.occw, oi, clock_stamps());
+            else k_traj_pass1_dense<false><<<nb, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, nblk8, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.pl.nitems, s.occ, s.occw, oi, clock_stamps());
         }
         TO_HIP_CHECK_LAUNCH();
     }
@@ -1509,8 +1559,8 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
 inline SparseArgs sparse_args(const TrajStep& s, float* lo_sum) {
     SparseArgs a;
     a.cv = s.cv; a.rec = s.rec; a.ext = s.ext; a.k = s.k; a.part = s.part;
-    a.V = (int)s.V; a.nslots = s.pl.nslots; a.vwords = s.pl.vwords; a.fv_words = s.pl.fv_words; a.clist = s.clist; a.clist_n = s.cand + s.pl.nslots;
-    a.ft = s.ft; a.fv = s.fv; a.ties = s.ties; a.lo_sum = lo_sum; a.minmax = nullptr; a.occ = s.occ; a.occw = s.occw;
+    a.V = (int)s.V; a.nslots = s.pl.nslots; a.vwords = s.pl.vwords; a.fv_words = s.pl.fv_words; a.clist = s.clist; a.clist_n = s.cand + s.pl.nitems; a.plist = s.plist; a.npairs = s.cand + s.pl.nitems + 1;
+    a.fv = s.fv; a.ties = s.ties; a.lo_sum = lo_sum; a.minmax = nullptr; a.occ = s.occ; a.occw = s.occw;
     a.toff = s.toff; a.n_traj = (int)s.n_traj; a.C = s.C;
     a.rewards = nullptr; a.prefilled = 0; a.acc = s.acc; a.shift = s.shift;
     a.grad_rewards = nullptr; a.scalars = nullptr; a.gout = nullptr; a.bpart = s.bpart;
@@ -1520,7 +1570,7 @@ inline SparseArgs sparse_args(const TrajStep& s, float* lo_sum) {
 // list walkers: the expected number of candidate slots on the workloads this is tuned for (6-8 % of the slots), each a chain
 // of its own; a dense cloud lists every slot and the blocks loop
 inline int sparse_blocks(const TrajStep& s) {
-    int64_t nb = std::min<int64_t>(s.pl.nslots, 512 * s.n_traj);   // two 1024-thread blocks to a CU: all resident at once
+    int64_t nb = std::min<int64_t>(s.pl.nitems, 512 * s.n_traj);
     return (int)std::min<int64_t>(nb, 4096);
 }
 
@@ -1529,6 +1579,24 @@ inline int launch_sparse(const TrajStep& s, const SparseArgs& a) {
     const int grid = sparse_blocks(s);
     if (s.occ) k_traj_sparse<MODE, true><<<grid, TO_SP_THREADS, 0, s.st>>>(a);
     else k_traj_sparse<MODE, false><<<grid, TO_SP_THREADS, 0, s.st>>>(a);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+// one 16-wave block per CU, all resident: the pairs are dealt to the grid's waves
+inline int pair_blocks() {
+    static const int cus = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) return prop.multiProcessorCount;
+        return 256;
+    }();
+    return cus;
+}
+
+inline int launch_pairs(const TrajStep& s, const SparseArgs& a) {
+    if (s.occ) k_traj_pairs<true><<<pair_blocks(), TO_SP_THREADS, 0, s.st>>>(a);
+    else k_traj_pairs<false><<<pair_blocks(), TO_SP_THREADS, 0, s.st>>>(a);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
@@ -1632,7 +1700,7 @@ int traj_backward_impl(const void* packed, int64_t n, int64_t W, int64_t n_traj,
     if (fused) {
         TO_PROF(TOHIP_PROF_BWD, s.st);
         const int nbx = reward_blocks(n);
-        const int64_t blocks = (int64_t)nbx * n_traj + sparse_blocks(s);
+        const int64_t blocks = (int64_t)nbx * n_traj + pair_blocks();
         if (s.occ) k_traj_reward_bwd<true><<<(int)blocks, TO_SP_THREADS, 0, s.st>>>(lo_sum, n, fused->eps, fused->prefilled ? 1 : 0, fused->rewards, fused->scalars, nbx, a);
         else k_traj_reward_bwd<false><<<(int)blocks, TO_SP_THREADS, 0, s.st>>>(lo_sum, n, fused->eps, fused->prefilled ? 1 : 0, fused->rewards, fused->scalars, nbx, a);
         TO_HIP_CHECK_LAUNCH();
@@ -1643,7 +1711,7 @@ int traj_backward_impl(const void* packed, int64_t n, int64_t W, int64_t n_traj,
         a.grad_rewards = grad_rewards;
         a.scalars = grad_rewards ? nullptr : scalars;
         a.gout = grad_rewards ? nullptr : gout;
-        rc = launch_sparse<TO_SP_BWD>(s, a);
+        rc = launch_pairs(s, a);
         if (rc != TOHIP_OK) return rc;
     }
     return launch_finish(s, finish_post(s, 0, nullptr, nullptr, nullptr, 0.f), poses_grad, quats_grad);
@@ -1697,7 +1765,9 @@ int traj_fused_forward(TrajStep& s, const float* poses, const float* quats, floa
     a.minmax = minmax;
     a.rewards = rewards;
     a.prefilled = 1;
-    return launch_sparse<TO_SP_FUSED>(s, a);
+    rc = launch_sparse<TO_SP_FUSED>(s, a);
+    if (rc != TOHIP_OK) return rc;
+    return launch_pairs(s, a);
 }
 }  // namespace
 
@@ -1730,9 +1800,9 @@ extern "C" int tohip_traj_forward_backward(const void* packed, int64_t n, const 
 // rank and stay untouched.
 
 // flag[s] = 1 when slot s is a candidate of this rank's last forward, else 0 (one int32 per slot: RCCL reduces with MAX, it has no OR)
-__global__ void k_candidate_flags(const int* __restrict__ clist, const int* __restrict__ clist_n, int* __restrict__ flag) {
+__global__ void k_candidate_flags(const int* __restrict__ clist, const int* __restrict__ clist_n, int nslots, int* __restrict__ flag) {
     const int n = *clist_n;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) flag[clist[i]] = 1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) flag[clist[i] % nslots] = 1;   // of any trajectory
 }
 
 // prefix[s] = number of set flags below slot s; prefix[nslots] = their total (one block)
@@ -1780,7 +1850,7 @@ extern "C" int tohip_traj_candidate_flags(int64_t n_points, int64_t n_virtual, i
     const char* ws = (const char*)workspace;
     const hipError_t e = hipMemsetAsync(slot_flags, 0, sizeof(int32_t) * (size_t)pl.nslots, st);
     if (e != hipSuccess) return (int)e;
-    k_candidate_flags<<<16, 256, 0, st>>>((const int*)(ws + pl.off_clist), (const int*)(ws + pl.off_cand) + pl.nslots, slot_flags);
+    k_candidate_flags<<<16, 256, 0, st>>>((const int*)(ws + pl.off_clist), (const int*)(ws + pl.off_cand) + pl.nitems, pl.nslots, slot_flags);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
@@ -1804,15 +1874,11 @@ extern "C" int tohip_slots_pack(const int32_t* slot_flags, const int32_t* prefix
 
 // Diagnostic: what the last forward over `workspace` found — stats[0] = flagged (slot, waypoint) pairs, stats[1] = candidate slots
 // listed by pass 1, stats[2] = slots, stats[3] = virtual waypoints (device int64 x 4; the caller zero-fills it).
-__global__ void k_traj_stats(const int* __restrict__ clist, const int* __restrict__ clist_n, const unsigned long long* __restrict__ ft,
-                             int vwords, int nslots, int V, unsigned long long* __restrict__ stats) {
-    const int n = *clist_n;
-    unsigned long long c = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)n * vwords; i += (int64_t)gridDim.x * blockDim.x)
-        c += __popcll(ft[(int64_t)clist[i / vwords] * vwords + (i % vwords)]);
-    for (int s = 32; s > 0; s >>= 1) c += __shfl_xor(c, s);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&stats[0], c);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[1] = (unsigned long long)n; stats[2] = (unsigned long long)nslots; stats[3] = (unsigned long long)V; }
+__global__ void k_traj_stats(const int* __restrict__ counters, int nslots, int V, unsigned long long* __restrict__ stats) {
+    stats[0] = (unsigned long long)counters[1];
+    stats[1] = (unsigned long long)counters[0];
+    stats[2] = (unsigned long long)nslots;
+    stats[3] = (unsigned long long)V;
 }
 
 extern "C" int tohip_traj_step_stats(int64_t n_points, int64_t n_virtual, int64_t n_traj, const void* workspace, size_t workspace_bytes,
@@ -1822,8 +1888,7 @@ extern "C" int tohip_traj_step_stats(int64_t n_points, int64_t n_virtual, int64_
     if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
     const char* ws = (const char*)workspace;
     const int* cand = (const int*)(ws + pl.off_cand);
-    k_traj_stats<<<256, 256, 0, (hipStream_t)stream_>>>((const int*)(ws + pl.off_clist), cand + pl.nslots, (const unsigned long long*)(ws + pl.off_ft),
-                                                        pl.vwords, pl.nslots, (int)n_virtual, (unsigned long long*)stats);
+    k_traj_stats<<<1, 1, 0, (hipStream_t)stream_>>>(cand + pl.nitems, pl.nslots, (int)n_virtual, (unsigned long long*)stats);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }

@@ -153,7 +153,7 @@ def traj_reward_backward(cloud, n_wps, cam, ws, lo_sum, gout, rewards=None, pref
 
 def traj_forward_backward(cloud, poses, quats, cam, ws, gout, rig=None, flags=0, occ=None, lo_sum=None, minmax=None, rewards=None):
     """The whole step of the fused visibility loss when no collective sits between forward and backward (tohip_traj_forward_backward,
-    four launches).  -> (rewards[N], scalars[4], poses_grad (W,3), quats_grad (W,4), lo_sum[npad] packed order, minmax[V,2])."""
+    five launches).  -> (rewards[N], scalars[4], poses_grad (W,3), quats_grad (W,4), lo_sum[npad] packed order, minmax[V,2])."""
     W = poses.shape[0]
     C = rig.n_cams if rig is not None else 1
     dev = cloud.device
