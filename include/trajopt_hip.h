@@ -447,9 +447,10 @@ int tohip_profile_read(double *ms_sum_host, int64_t *counts_host);
 int tohip_profile_clock(void *device_buffer);
 int64_t tohip_profile_clock_blocks(int64_t n_points, int64_t n_virtual, int flags, int with_occlusion);
 
-/* Diagnostic: what the last forward over `workspace` found.  stats (DEVICE int64 x 4, zero-filled by the caller):
+/* Diagnostic: what the last forward over `workspace` found.  stats (DEVICE int64 x 5, zero-filled by the caller):
  * [0] flagged (256-point slot, virtual waypoint) pairs — the pairs with a non-zero log-odds term or a gradient;
- * [1] candidate (slot, trajectory) items listed by pass 1; [2] slots; [3] virtual waypoints. */
+ * [1] candidate (slot, trajectory) items of pass 1; [2] slots; [3] virtual waypoints; [4] the (slot, waypoint) pairs the last
+ * culled pass 1 evaluated (stale after a dense one). */
 int tohip_traj_step_stats(int64_t n_points, int64_t n_virtual, int64_t n_traj, const void *workspace, size_t workspace_bytes,
                           int64_t *stats, void *stream);
 

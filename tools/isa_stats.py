@@ -101,6 +101,9 @@ def hot_loop_ops(text, kernel_prefix, marker="s_load_dwordx16"):
             tgt = l.split()[1]
             b = next((n for n in range(a + 1, len(sel)) if sel[n] == ("label", tgt)), None)
             if b is None:
+                # the skip target lies earlier in the layout (the loop's latch): the region runs to its own jump there
+                b = next((n + 1 for n in range(a + 1, len(sel)) if sel[n] == ("op", "s_branch " + tgt)), None)
+            if b is None:
                 continue
             region = [x for kk, x in sel[a + 1:b] if kk == "op"]
             if any(x.startswith("global_atomic") for x in region) and not any(x.startswith("global_store") for x in region):

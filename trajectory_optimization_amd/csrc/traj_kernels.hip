@@ -54,6 +54,10 @@
 #define TO_SLOT 256            // points per flag slot (= bounding-sphere tile)
 #define TO_TIE_CAP 7           // recorded slots per extremum and waypoint; more -> the finish kernel scans all slots
 #define TO_BWD_NSUM 14
+#define TO_SP_THREADS 1024     // the block of the kernels that walk slot lists (culled pass 1, sparse, pairs)
+#define TO_SP_WAVES (TO_SP_THREADS / 64)
+#define TO_CBIT_STRIDE 16      // words between two words of the candidate bits: one to a 128-byte line (mark_candidate)
+#define TO_PROBE_MAXFW 1024   // words of a `live` row the probe holds in LDS: culling up to 65 536 slots (16.7 M points), dense beyond
 #define TO_SP_MAXW 1024        // flag words of one slot held in LDS by k_traj_sparse: at most 65 536 virtual waypoints
 
 // ---------------------------------------------------------------------------------------------
@@ -207,34 +211,15 @@ __device__ __forceinline__ float occ_one(const uint32_t* __restrict__ occ, int64
     return ((occ[(int64_t)v * occw + (i >> 5)] >> (unsigned)(i & 31)) & 1u) ? 1.0f : 0.0f;
 }
 
-// wave-uniform bounding sphere of the 256-point tile this wave's points belong to (P = 4: one tile per wave)
-__device__ __forceinline__ float4 wave_tile_bound(const CloudView& cv, int64_t base) {
-    const int tile = __builtin_amdgcn_readfirstlane((int)(base >> 8));
-    float4 b = cv.bounds[tile];
-    b.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b.x)));
-    b.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b.y)));
-    b.z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b.z)));
-    b.w = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b.w)));
-    return b;
-}
-
-// (tile, waypoint) liveness for 64 waypoints at once: lane l tests waypoint vc + l against the wave's tile; the ballot is
-// the set of waypoints whose sphere {d2 <= thr1} may reach the tile.  Waypoints without the probe's "min is zero" proof
-// always survive (they are searched densely).
-__device__ __forceinline__ unsigned long long tile_survivors(const WayRec* __restrict__ rec, int vc, int v1, const float4& tb, float inv_scd) {
-    const int v = vc + (int)(threadIdx.x & 63);
-    bool ok = false;
-    if (v < v1) {
-        const float4* rp = reinterpret_cast<const float4*>(rec + v);
-        const float4 q0 = rp[0], q3 = rp[3], q4 = rp[4], q5 = rp[5];  // t0 t1 t2 f00 | sp0 sp1 sp2 Lh | L U thr1 sthr1 | azero ..
-        // the sphere's centre from the Gaussian's, in metres: (c - t) - R mu, with R mu = -sp / sqrt(cd)
-        const float d0 = fmaf(q3.x, inv_scd, tb.x - q0.x), d1 = fmaf(q3.y, inv_scd, tb.y - q0.y), d2 = fmaf(q3.z, inv_scd, tb.z - q0.z);
-        const float D2 = fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
-        const float thr = q4.z, sthr = q4.w;
-        const float bound = fmaf(tb.w, fmaf(2.0f, sthr, tb.w), thr) * 1.00001f;  // (sthr + r)^2, rounded up
-        ok = (q5.x == 0.f) || !(D2 > bound);
-    }
-    return __ballot(ok);
+// (tile, waypoint) liveness: may the waypoint's sphere {d2 <= thr1} reach the tile (bounding sphere tb)?  Waypoints without the
+// probe's "min is zero" proof (azero == 0) are searched densely: every tile is live for them.
+// t = the waypoint's position, sp = -sqrt(cd) R mu (the record's fields)
+__device__ __forceinline__ bool tile_live(const float (&t)[3], const float (&sp)[3], float thr, float sthr, float azero, const float4& tb, float inv_scd) {
+    // the sphere's centre from the Gaussian's, in metres: (c - t) - R mu, with R mu = -sp / sqrt(cd)
+    const float d0 = fmaf(sp[0], inv_scd, tb.x - t[0]), d1 = fmaf(sp[1], inv_scd, tb.y - t[1]), d2 = fmaf(sp[2], inv_scd, tb.z - t[2]);
+    const float D2 = fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
+    const float bound = fmaf(tb.w, fmaf(2.0f, sthr, tb.w), thr) * 1.00001f;  // (sthr + r)^2, rounded up
+    return (azero == 0.f) || !(D2 > bound);
 }
 
 // Squared-distance bound thr such that  d2 > thr  =>  2^(-cd d2) < tau * (1 - 1e-4): p = S * 2^-A <= 2^(-cd d2) cannot
@@ -242,6 +227,39 @@ __device__ __forceinline__ unsigned long long tile_survivors(const WayRec* __res
 __device__ inline void cull_bound(float tau, float inv_var, float* thr, float* sthr) {
     cull_threshold(tau, inv_var, thr, sthr);
 }
+
+// the log-odds vector starts from zero (k_traj_sparse fills the flagged slots) and, when the caller asks for it, the rewards
+// vector from sigmoid(0) = 1/2 (only the others are stored later): done by whoever evaluates a point block's first waypoint
+typedef float f4v __attribute__((ext_vector_type(4)));
+struct OutInit {   // n_traj log-odds vectors of npad floats (and rewards vectors of n floats) one after the other
+    float* lo_zero;
+    float* rewards_half;
+    int64_t npad, n;
+    int n_traj;
+};
+__device__ __forceinline__ void init_outputs(int64_t base, const OutInit& o) {
+    // streaming stores: nothing of this is read again by this kernel
+    for (int b = 0; b < o.n_traj; ++b) {
+        __builtin_nontemporal_store(f4v{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4v*>(o.lo_zero + (int64_t)b * o.npad + base));
+        if (o.rewards_half != nullptr && base < o.n) {
+            float* rh = o.rewards_half + (int64_t)b * o.n;
+            if (base + 4 <= o.n && ((((int64_t)b * o.n) & 3) == 0))   // (n need not be a multiple of 4: a later vector may start unaligned)
+                __builtin_nontemporal_store(f4v{0.5f, 0.5f, 0.5f, 0.5f}, reinterpret_cast<f4v*>(rh + base));
+            else
+                for (int64_t i = base; i < base + 4 && i < o.n; ++i) rh[i] = 0.5f;
+        }
+    }
+}
+
+// what the probe does besides for the culled pass 1
+struct ProbeCull {
+    int on;
+    int nslots;
+    unsigned long long* live;      // V x fv_words: bit s of row v = slot s may hold a point waypoint v sees at all
+    int* plive;                    // V x nslots: the same as lists of slots
+    int* nlive;                    // V: their lengths
+    OutInit oi;
+};
 
 // ---------------------------------------------------------------------------------------------
 // probe: block per virtual waypoint.  Builds the waypoint's record, evaluates a strided sample of the sorted cloud
@@ -258,18 +276,23 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
              const float* __restrict__ rig_q, const float* __restrict__ rig_t, EvalK k, WayRec* __restrict__ rec,
              WayCold* __restrict__ cold, Extrema* __restrict__ ext, TieRec* __restrict__ ties, const uint32_t* __restrict__ occ,
              int64_t occw, unsigned long long* __restrict__ fv, int fv_words, RewardAcc* __restrict__ acc,
-             const int* __restrict__ traj_off, int* __restrict__ traj_off_ws, int n_traj, int* __restrict__ cand, int ncand_words,
-             int wp_stride) {
+             const int* __restrict__ traj_off, int* __restrict__ traj_off_ws, int n_traj, unsigned long long* __restrict__ cbits,
+             int ncbits, int* __restrict__ ctr, int wp_stride, ProbeCull pc) {
     __shared__ float smx[TO_PROBE_THREADS / 64], smn[TO_PROBE_THREADS / 64];
+    __shared__ float scull[4];
     const int v = blockIdx.x, t = threadIdx.x;
     for (int j = t; j < fv_words; j += TO_PROBE_THREADS) fv[(int64_t)v * fv_words + j] = 0ull;
-    for (int j = v * TO_PROBE_THREADS + t; j < ncand_words; j += gridDim.x * TO_PROBE_THREADS) cand[j] = 0;   // slot marks + the list's counter
+    for (int j = v * TO_PROBE_THREADS + t; j < ncbits; j += gridDim.x * TO_PROBE_THREADS) cbits[(int64_t)j * TO_CBIT_STRIDE] = 0ull;   // the candidate (slot, trajectory) bits
+    if (v == 0 && t == 0) ctr[0] = 0;   // the pair list's length
     if (v == 0) {
         for (int j = t; j < n_traj * 8; j += TO_PROBE_THREADS) { acc[j >> 3].a[j & 7].sum = 0; acc[j >> 3].a[j & 7].nan = 0u; }
         for (int j = t; j < n_traj; j += TO_PROBE_THREADS) acc[j].b.word = 0ull;   // (k_traj_reward leaves it zero; a launch that was cut short may not have)
         if (traj_off != nullptr)   // the calls that follow the forward (backward, finish) take no offsets: they read this copy
             for (int j = t; j <= n_traj; j += TO_PROBE_THREADS) traj_off_ws[j] = traj_off[j];
     }
+    // CULL: the outputs' start values (the dense pass 1 sets them itself): stores nobody here waits for
+    if (pc.on)
+        for (int64_t i = ((int64_t)v * TO_PROBE_THREADS + t) * 4; i < pc.oi.npad; i += (int64_t)gridDim.x * TO_PROBE_THREADS * 4) init_outputs(i, pc.oi);
     // the samples (a contiguous copy of every step-th sorted point, made at pack time) are requested first, the record is
     // built meanwhile
     constexpr int kBatch = 8, kRounds = TO_PROBE_MAX / (TO_PROBE_THREADS * kBatch);
@@ -318,6 +341,7 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
         rec[v].thr1 = thr;
         rec[v].sthr1 = sthr;
         rec[v].azero = (mn == 0.f) ? 1.f : 0.f;
+        scull[0] = thr; scull[1] = sthr; scull[2] = (mn == 0.f) ? 1.f : 0.f;
         Extrema e;
         e.mn = __builtin_bit_cast(int, mn);
         e.mx = __builtin_bit_cast(int, mx);
@@ -325,6 +349,43 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
         ext[v] = e;
         ties[v].nmax = 0;
         ties[v].nmin = 0;
+    }
+    if (!pc.on) return;
+    // CULL: which 256-point slots can waypoint v reach at all — row v of `live` (a bit per slot: k_traj_sparse asks it whether a
+    // pair was evaluated) and the same as a list, plive[v * nslots ..] with nlive[v] entries in slot order (the culled pass 1
+    // deals it to its waves)
+    __shared__ unsigned long long swords[TO_PROBE_MAXFW];
+    __shared__ int spre[TO_PROBE_MAXFW];
+    __syncthreads();
+    const float thr = scull[0], sthr = scull[1], azero = scull[2], inv_scd = 1.0f / k.scd;
+    const int lane = t & 63;
+    for (int w = t >> 6; w < fv_words; w += TO_PROBE_THREADS / 64) {
+        const int sl = w * 64 + lane;
+        bool ok = false;
+        if (sl < pc.nslots) ok = tile_live(r.t, r.sp, thr, sthr, azero, cv.bounds[sl], inv_scd);
+        const unsigned long long word = __ballot(ok);
+        if (lane == 0) { pc.live[(int64_t)v * fv_words + w] = word; swords[w] = word; }
+    }
+    __syncthreads();
+    if (t < 64) {   // exclusive prefix of the words' popcounts, 64 words at a time
+        int carry = 0;
+        for (int w0 = 0; w0 < fv_words; w0 += 64) {
+            const int c = (w0 + lane < fv_words) ? __popcll(swords[w0 + lane]) : 0;
+            int incl = c;
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                const int up = __shfl_up(incl, sh);
+                if (lane >= sh) incl += up;
+            }
+            if (w0 + lane < fv_words) spre[w0 + lane] = carry + incl - c;
+            carry += __shfl(incl, 63);
+        }
+        if (lane == 0) pc.nlive[v] = carry;
+    }
+    __syncthreads();
+    for (int w = t >> 6; w < fv_words; w += TO_PROBE_THREADS / 64) {
+        const unsigned long long word = swords[w];
+        if ((word >> lane) & 1ull) pc.plive[(int64_t)v * pc.nslots + spre[w] + __popcll(word & ((1ull << lane) - 1ull))] = w * 64 + lane;
     }
 }
 
@@ -353,23 +414,14 @@ __device__ __forceinline__ bool fold_extrema(Extrema* __restrict__ ext, int v, f
     return cand;
 }
 
-// A candidate (slot, trajectory) enters the list k_traj_sparse walks, once, as item trajectory * nslots + slot: the exchange on
-// its mark decides, issued when its first candidate waypoint turns up (claim) so that its round trip runs under the remaining
-// waypoints; the append follows when the lane moves on to another trajectory's waypoints, or at the end.  nitems = nslots *
-// trajectories: the marks, then the list's counter.
-struct CandClaim {
-    int old = 1;          // the mark before this lane's exchange (0: this lane claimed the item)
-    int item = 0;
-    bool issued = false;
-};
-__device__ __forceinline__ void list_candidate(CandClaim& c, int* __restrict__ cand, int* __restrict__ clist, int nitems) {
-    if (c.issued && c.old == 0) clist[atomicAdd(&cand[nitems], 1)] = c.item;
-    c.issued = false;
+// A candidate (slot, trajectory) sets its bit — bit `slot` of the trajectory's row of fv_words words; k_traj_sparse walks the
+// set bits.  No answer is waited for.  The words sit TO_CBIT_STRIDE words apart, one to a 128-byte line: device-scope atomics on
+// one line are served one after the other (~80 ns each, measured), and a step sets thousands of these bits.
+__device__ __forceinline__ unsigned long long* cbit_word(unsigned long long* cbits, int fv_words, int seg, int w) {
+    return cbits + ((int64_t)seg * fv_words + w) * TO_CBIT_STRIDE;
 }
-__device__ __forceinline__ void claim_candidate(CandClaim& c, int* __restrict__ cand, int* __restrict__ clist, int nslots, int nitems, int slot, int seg) {
-    const int item = seg * nslots + slot;
-    if (c.issued && c.item != item) list_candidate(c, cand, clist, nitems);
-    if (!c.issued) { c.old = atomicExch(&cand[item], 1); c.item = item; c.issued = true; }
+__device__ __forceinline__ void mark_candidate(unsigned long long* __restrict__ cbits, int fv_words, int slot, int seg) {
+    atomicOr(cbit_word(cbits, fv_words, seg, slot >> 6), 1ull << (slot & 63));
 }
 
 __device__ __forceinline__ void pass1_eval(const EvalK& k, const WayRec& r, const float (&x)[TO_P], const float (&y)[TO_P],
@@ -379,29 +431,6 @@ __device__ __forceinline__ void pass1_eval(const EvalK& k, const WayRec& r, cons
     mx = wave_max63_nn_fused(fmaxf(fmaxf(p0.x, p0.y), fmaxf(p1.x, p1.y)));
     mn = 0.f;   // wanted only while the probe has not exhibited a zero (see the dense kernel)
     if (__builtin_bit_cast(int, r.U) != 0) mn = wave_min63_nn_fused(fminf(fminf(p0.x, p0.y), fminf(p1.x, p1.y)));   // p >= +0 always
-}
-
-// the log-odds vector starts from zero (k_traj_sparse fills the flagged slots) and, when the caller asks for it, the rewards
-// vector from sigmoid(0) = 1/2 (only the others are stored later): done by whoever evaluates a point block's first waypoint
-typedef float f4v __attribute__((ext_vector_type(4)));
-struct OutInit {   // n_traj log-odds vectors of npad floats (and rewards vectors of n floats) one after the other
-    float* lo_zero;
-    float* rewards_half;
-    int64_t npad, n;
-    int n_traj;
-};
-__device__ __forceinline__ void init_outputs(int64_t base, const OutInit& o) {
-    // streaming stores: nothing of this is read again by this kernel
-    for (int b = 0; b < o.n_traj; ++b) {
-        __builtin_nontemporal_store(f4v{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4v*>(o.lo_zero + (int64_t)b * o.npad + base));
-        if (o.rewards_half != nullptr && base < o.n) {
-            float* rh = o.rewards_half + (int64_t)b * o.n;
-            if (base + 4 <= o.n && ((((int64_t)b * o.n) & 3) == 0))   // (n need not be a multiple of 4: a later vector may start unaligned)
-                __builtin_nontemporal_store(f4v{0.5f, 0.5f, 0.5f, 0.5f}, reinterpret_cast<f4v*>(rh + base));
-            else
-                for (int64_t i = base; i < base + 4 && i < o.n; ++i) rh[i] = 0.5f;
-        }
-    }
 }
 
 // DENSE: persistent blocks, as many as the chip holds at once (host: occupancy x CUs).  A lane owns EIGHT consecutive points
@@ -415,7 +444,7 @@ __device__ __forceinline__ void init_outputs(int64_t base, const OutInit& o) {
 template <bool OCC>
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk, EvalK k, float2* __restrict__ part,
-                   Extrema* __restrict__ ext, int* __restrict__ cand, int* __restrict__ clist, int nslots, int nitems,
+                   Extrema* __restrict__ ext, unsigned long long* __restrict__ cbits, int fv_words,
                    const uint32_t* __restrict__ occ, int64_t occw, OutInit oi, unsigned long long* __restrict__ stamps) {
     constexpr int P = TO_PD;
     const int lane = threadIdx.x & 63;
@@ -441,7 +470,6 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
         load_points<P>(cv.soa, cv.npad, base, x, y, z);
         if (v0 == 0) { init_outputs(base, oi); init_outputs(base + 4, oi); }
         float2* prow = part + (int64_t)slot * V;
-        CandClaim claim;
         for (int v = v0; v < v1; ++v) {
             const int64_t uu = u + (v - v0);
             if (uu == q1) __builtin_amdgcn_s_setprio(2);
@@ -465,10 +493,9 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
             }
             if ((lane & 31) == 31) {
                 prow[v] = make_float2(mn, mx);
-                if (fold_extrema(ext, v, mn, mx, r)) claim_candidate(claim, cand, clist, nslots, nitems, slot, r.seg);
+                if (fold_extrema(ext, v, mn, mx, r)) mark_candidate(cbits, fv_words, slot, r.seg);
             }
         }
-        list_candidate(claim, cand, clist, nitems);
         u += v1 - v0;
     }
     if (stamps != nullptr && threadIdx.x == 0) {
@@ -482,43 +509,85 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
     }
 }
 
-// CULL: grid = (point blocks, waypoint tiles of <= 64): one ballot covers the block row's waypoints.  A live (tile, waypoint)
-// pair is evaluated like in the dense kernel (packed, every point of the wave): per-point distance tests cost as much as they
-// save once the tile is live.  The work sits in the few point blocks near the path, hence many short block rows.
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// CULL: most (slot, waypoint) pairs cannot contribute — on the BASELINE slab a waypoint reaches 2.5 % of the slots — and the
+// probe has listed, per waypoint, the slots it can reach.  grid = (TO_CULL_GX, V) blocks of sixteen waves: the waves of row v
+// deal the waypoint's list among themselves, one (slot, waypoint) pair at a time — the record sits in scalar registers for the
+// wave's whole life, the next pair's points are requested before the current pair is evaluated; every pair costs the same, so
+// the chip is evenly loaded whatever the pairs' distribution over the slots.  The waypoint's extrema and its candidates' bits
+// are combined in LDS and leave the block as ONE atomic per word: thousands of device-scope atomics on a few lines, one per
+// pair, were what the kernel's time consisted of.  A pair that is not listed is not written: k_traj_sparse takes (min, max) =
+// (the proven 0, -inf: never flagged) for it from the `live` bit.
+#define TO_CULL_GX 2
+struct CullLds {
+    unsigned long long cand[TO_PROBE_MAXFW];
+    int mx[TO_SP_WAVES], mn[TO_SP_WAVES];
+};
+
 template <bool OCC>
-__global__ void __launch_bounds__(TO_BLOCK)
-k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile, EvalK k, float2* __restrict__ part,
-                  Extrema* __restrict__ ext, int* __restrict__ cand, int* __restrict__ clist, int nslots, int nitems,
-                  const uint32_t* __restrict__ occ, int64_t occw, OutInit oi) {
+__global__ void __launch_bounds__(TO_SP_THREADS)
+k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, float2* __restrict__ part, Extrema* __restrict__ ext,
+                  unsigned long long* __restrict__ cbits, int fv_words, int nslots, const int* __restrict__ plive,
+                  const int* __restrict__ nlive, const uint32_t* __restrict__ occ, int64_t occw) {
     constexpr int P = TO_P;
-    const int lane = threadIdx.x & 63;
-    const int gthread = blockIdx.x * TO_BLOCK + threadIdx.x;
-    const int64_t base = (int64_t)gthread * P;
-    const int slot = gthread >> 6;
-    float x[P], y[P], z[P];
-    load_points<P>(cv.soa, cv.npad, base, x, y, z);
-    if (blockIdx.y == 0) init_outputs(base, oi);
-    const int v0 = blockIdx.y * vtile;
-    const int v1 = min(V, v0 + vtile);
-    const float4 tb = wave_tile_bound(cv, base);
-    unsigned long long live = tile_survivors(rec, v0, v1, tb, 1.0f / k.scd);
-    float2* prow = part + (int64_t)slot * V;
-    // waypoints that cannot be affected from this tile: min is the proven 0, max unknown (-inf: never flagged)
-    if (v0 + lane < v1 && !((live >> lane) & 1ull)) prow[v0 + lane] = make_float2(0.f, -INFINITY);
-    CandClaim claim;
-    while (live) {
-        const int v = v0 + __builtin_ctzll(live);
-        live &= live - 1ull;
-        const WayRec& r = rec[v];
-        float mn, mx, om[P];
-        load_occ<P, OCC>(occ, occw, v, base, om);
-        pass1_eval(k, r, x, y, z, om, mn, mx);
-        if (lane == 63) {
-            prow[v] = make_float2(mn, mx);
-            if (fold_extrema(ext, v, mn, mx, r)) claim_candidate(claim, cand, clist, nslots, nitems, slot, r.seg);
+    __shared__ CullLds L;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int v = blockIdx.y;
+    const int wr = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * TO_SP_WAVES) + wave), WR = TO_CULL_GX * TO_SP_WAVES;
+    const int* list = plive + (int64_t)v * nslots;
+    int slot = wr < nslots ? list[wr] : 0;   // requested with the list's length, not after it
+    const int n = nlive[v];
+    if ((int)(blockIdx.x * TO_SP_WAVES) >= n) return;   // block-uniform
+    for (int w = t; w < fv_words; w += TO_SP_THREADS) L.cand[w] = 0ull;
+    __syncthreads();
+    const WayRec& r = rec[v];
+    int bmx = __builtin_bit_cast(int, r.L), bmn = __builtin_bit_cast(int, r.U);   // p >= +0: the bit patterns order like the values
+    if (wr < n) {
+        float x[P], y[P], z[P];
+        load_points<P>(cv.soa, cv.npad, (int64_t)slot * TO_SLOT + lane * P, x, y, z);
+        for (int j = wr; j < n; j += WR) {
+            const int cur = slot;
+            const int64_t base = (int64_t)cur * TO_SLOT + lane * P;
+            float nx[P], ny[P], nz[P];
+            const bool more = j + WR < n;
+            if (more) {
+                slot = __builtin_amdgcn_readfirstlane(list[j + WR]);
+                load_points<P>(cv.soa, cv.npad, (int64_t)slot * TO_SLOT + lane * P, nx, ny, nz);
+            }
+            float mn, mx, om[P];
+            load_occ<P, OCC>(occ, occw, v, base, om);
+            pass1_eval(k, r, x, y, z, om, mn, mx);
+            if (lane == 63) {
+                part[(int64_t)cur * V + v] = make_float2(mn, mx);
+                // what fold_extrema does with atomics, on the wave's own running values
+                if (!(mx < r.Lh)) {
+                    atomicOr(&L.cand[cur >> 6], 1ull << (cur & 63));
+                    bmx = max(bmx, __builtin_bit_cast(int, mx));
+                }
+                if (__builtin_bit_cast(int, r.U) != 0) bmn = min(bmn, __builtin_bit_cast(int, mn));
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) { x[i] = nx[i]; y[i] = ny[i]; z[i] = nz[i]; }
+            }
         }
     }
-    list_candidate(claim, cand, clist, nitems);
+    if (lane == 63) { L.mx[wave] = bmx; L.mn[wave] = bmn; }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < TO_SP_WAVES; ++w) { bmx = max(bmx, L.mx[w]); bmn = min(bmn, L.mn[w]); }
+        bmx = max(bmx, L.mx[0]); bmn = min(bmn, L.mn[0]);
+        if (bmx > __builtin_bit_cast(int, r.L)) atomicMax(&ext[v].mx, bmx);
+        if (bmn < __builtin_bit_cast(int, r.U)) atomicMin(&ext[v].mn, bmn);
+    }
+    for (int w = t; w < fv_words; w += TO_SP_THREADS) {
+        const unsigned long long word = L.cand[w];
+        if (word) atomicOr(cbit_word(cbits, fv_words, r.seg, w), word);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -545,8 +614,6 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, int vtile
 //             (they are linear in it; k_traj_finish scales them once the mean of the rewards is known).
 
 enum { TO_SP_FWD = 0, TO_SP_FUSED = 2 };
-#define TO_SP_THREADS 1024
-#define TO_SP_WAVES (TO_SP_THREADS / 64)
 #define TO_SP_CW 4                      // flag words (x 64 waypoints) staged at a time
 #define TO_SP_STAGE (TO_SP_CW * 64)
 
@@ -557,8 +624,8 @@ struct SparseArgs {
     EvalK k;
     const float2* part;
     int V, nslots, vwords, fv_words;
-    const int* clist;            // candidate slots (pass 1), clist_n[0] of them
-    const int* clist_n;
+    const unsigned long long* cbits;   // candidate (slot, trajectory) bits (pass 1): n_traj rows of fv_words words
+    const unsigned long long* live;    // culled pass 1: bit (v, slot) = the pair was evaluated (part holds it); NULL: all were
     int2* plist;                 // the step's flagged (slot, waypoint) pairs, *npairs of them, in no particular order
     int* npairs;                 //   (FWD / FUSED append, the pair kernel reads)
     unsigned long long* fv;
@@ -604,11 +671,6 @@ __device__ __forceinline__ f2 log_odds_pk(const EvalK& k, float a, float invM, f
     return (f2{to_log2(ph.x), to_log2(ph.y)} - f2{to_log2(om.x), to_log2(om.y)}) * pk_splat(0.693147180559945f);
 }
 
-__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 // one candidate slot for trajectory tr — its virtual waypoints [v_lo, v_hi), its own log-odds vector, rewards, sums and rank
 // count, so that its results are the ones a run of that trajectory alone produces; blockDim.x = TO_SP_THREADS.  Returns with
 // every thread past its last use of the LDS.
@@ -631,7 +693,9 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
         const int v = w * 64 + lane;
         bool flag = false;
         if (v >= v_lo && v < v_hi) {
-            const float2 pq = a.part[(int64_t)slot * a.V + v];
+            float2 pq = a.part[(int64_t)slot * a.V + v];
+            // a pair the culled pass 1 did not evaluate: min is the proven 0, max unknown (-inf: never flagged)
+            if (a.live != nullptr && !((a.live[(int64_t)v * a.fv_words + (slot >> 6)] >> (slot & 63)) & 1ull)) pq = make_float2(0.f, -INFINITY);
             float av, pmax, M, invM;
             load_norm(a.ext[v], av, pmax, M, invM);
             const bool amin = av > 0.f;
@@ -769,16 +833,37 @@ __device__ __forceinline__ void write_minmax(const SparseArgs& a) {
     }
 }
 
-// block b of nb walks the list of candidate (slot, trajectory) items with stride nb (one 16-wave block is resident per CU at
-// this kernel's register count)
+// block b of nb takes the b-th, (b + nb)-th, ... set bit of the candidate bits (bit s of row tr = slot s for trajectory tr):
+// every wave finds them from the same popcount prefix, 64 words at a time (one 16-wave block is resident per CU at this kernel's
+// register count)
 template <int MODE, bool OCC>
 __device__ __forceinline__ void sparse_walk(const SparseArgs& a, int b, int nb, SparseLds& L) {
-    int item = a.clist[b];   // requested with the list's length, not after it (the list's buffer holds one int per item >= blocks)
-    const int n = *a.clist_n;
-    for (int li = b; li < n; li += nb) {
-        const int tr = item / a.nslots;
-        sparse_slot<MODE, OCC>(a, item - tr * a.nslots, tr, b & 7, L);
-        if (li + nb < n) item = a.clist[li + nb];
+    const int lane = threadIdx.x & 63;
+    const int nwords = a.n_traj * a.fv_words;
+    int carry = 0, next = b;
+    for (int c0 = 0; c0 < nwords; c0 += 64) {
+        const unsigned long long word = (c0 + lane < nwords) ? a.cbits[(int64_t)(c0 + lane) * TO_CBIT_STRIDE] : 0ull;
+        const int pc = __popcll(word);
+        int incl = pc;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const int up = __shfl_up(incl, sh);
+            if (lane >= sh) incl += up;
+        }
+        const int tot = __shfl(incl, 63);
+        while (next < carry + tot) {   // wave- and block-uniform
+            const int rnk = next - carry;
+            const int f = __builtin_ctzll(__ballot(incl > rnk));
+            const int rr = rnk - __shfl(incl - pc, f);
+            const unsigned long long wf = uniform_u64((unsigned long long)__shfl((long long)word, f));
+            const bool hit = ((wf >> lane) & 1ull) && __popcll(wf & ((1ull << lane) - 1ull)) == rr;
+            const int wi = c0 + f;                       // word index: trajectory wi / fv_words, slots 64 (wi % fv_words) ..
+            const int tr = wi / a.fv_words;
+            const int slot = (wi - tr * a.fv_words) * 64 + __builtin_ctzll(__ballot(hit));
+            sparse_slot<MODE, OCC>(a, slot, tr, b & 7, L);
+            next += nb;
+        }
+        carry += tot;
     }
 }
 
@@ -1386,11 +1471,11 @@ struct TrajPlan {
     int64_t npad;
     int nblk;      // culled pass-1 point blocks (1024 points each)
     int nslots;    // npad / 256
-    int nitems;    // nslots x trajectories: the (slot, trajectory) items pass 1 may list
+    int ncbits;    // trajectories x fv_words: the words of the candidate (slot, trajectory) bits
     int fv_words;  // (nslots + 63) / 64
     int vwords;    // (V + 63) / 64
     int V;
-    size_t off_ctl, off_toff, off_rec, off_cold, off_ext, off_cand, off_clist, off_part, off_fv, off_plist, off_ties, off_bpart, off_vgrad, total;
+    size_t off_ctl, off_toff, off_rec, off_cold, off_ext, off_cbits, off_ctr, off_part, off_fv, off_live, off_plive, off_nlive, off_plist, off_ties, off_bpart, off_vgrad, total;
 };
 
 inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
@@ -1398,8 +1483,8 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
     p.npad = tohip_padded_points(n);
     p.nblk = (int)(p.npad / (TO_BLOCK * TO_P));
     p.nslots = (int)(p.npad / TO_SLOT);
-    p.nitems = (int)((int64_t)p.nslots * (n_traj < 1 ? 1 : n_traj));
     p.fv_words = (p.nslots + 63) / 64;
+    p.ncbits = (int)((int64_t)p.fv_words * (n_traj < 1 ? 1 : n_traj));
     p.vwords = (int)((V + 63) / 64);
     p.V = (int)V;
     size_t o = 0;
@@ -1408,27 +1493,19 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
     p.off_rec = o;   o += align_up((size_t)V * sizeof(WayRec), 256);
     p.off_cold = o;  o += align_up((size_t)W * sizeof(WayCold), 256);
     p.off_ext = o;   o += align_up((size_t)V * sizeof(Extrema), 256);
-    p.off_cand = o;  o += align_up(((size_t)p.nitems + 2) * sizeof(int), 256);   // a mark per item, then the candidate list's and the pair list's counters
-    p.off_clist = o; o += align_up((size_t)p.nitems * sizeof(int), 256);
+    p.off_cbits = o; o += align_up((size_t)p.ncbits * TO_CBIT_STRIDE * sizeof(unsigned long long), 256);   // a bit per (trajectory, slot): pass 1's candidates
+    p.off_ctr = o;   o += 256;                                                             // [0] the pair list's length
     p.off_part = o;  o += align_up((size_t)V * (size_t)p.nslots * sizeof(float2), 256);
     p.off_fv = o;    o += align_up((size_t)V * (size_t)p.fv_words * sizeof(unsigned long long), 256);
+    p.off_live = o;  o += align_up((size_t)V * (size_t)p.fv_words * sizeof(unsigned long long), 256);   // culled pass 1: the slots a waypoint can reach, as bits
+    p.off_plive = o; o += align_up((size_t)V * (size_t)p.nslots * sizeof(int), 256);                    //   and as lists,
+    p.off_nlive = o; o += align_up((size_t)V * sizeof(int), 256);                                       //   with their lengths
     p.off_plist = o; o += align_up((size_t)V * (size_t)p.nslots * sizeof(int2), 256);   // every pair flagged: the same bytes as part
     p.off_ties = o;  o += align_up((size_t)V * sizeof(TieRec), 256);
     p.off_bpart = o; o += align_up((size_t)V * (size_t)p.nslots * 16 * sizeof(float), 256);
     p.off_vgrad = o; o += align_up((size_t)V * 12 * sizeof(float), 256);
     p.total = o;
     return p;
-}
-
-// culled pass 1: block rows of at most this many waypoints (one ballot; a wave walks its live waypoints one after the other)
-inline void cull_tiles(int V, int* vtile, int* ntiles) {
-    static const int cvt = [] { const char* e = getenv("TOHIP_CULL_VTILE"); return e ? atoi(e) : 0; }();  // experiments
-    int vt = cvt > 0 ? cvt : 32;
-    if (vt > 64) vt = 64;
-    if (vt > V) vt = V;
-    if (vt < 1) vt = 1;
-    *vtile = vt;
-    *ntiles = (V + vt - 1) / vt;
 }
 
 // dense pass 1: as many persistent blocks as are resident at once (never more than one per (point block, waypoint) pair)
@@ -1477,10 +1554,11 @@ struct TrajStep {
     WayRec* rec;
     WayCold* cold;
     Extrema* ext;
-    int *cand, *clist;
+    unsigned long long* cbits;
+    int *ctr, *plive, *nlive;
     int2* plist;
     float2* part;
-    unsigned long long* fv;
+    unsigned long long *fv, *live;
     TieRec* ties;
     float *bpart, *vgrad;
     int shift;
@@ -1493,7 +1571,7 @@ inline int traj_step_init(TrajStep& s, const void* packed, int64_t n, int64_t W,
     s.st = (hipStream_t)stream_;
     s.C = rig_cams(rig);
     s.n = n; s.W = W; s.V = W * s.C; s.n_traj = n_traj;
-    if (s.V > 64 * TO_SP_MAXW || (int64_t)(tohip_padded_points(n) / TO_SLOT) * n_traj > (int64_t)1 << 30) return TOHIP_EINVAL;
+    if (s.V > 64 * TO_SP_MAXW || (int64_t)(tohip_padded_points(n) / TO_SLOT / 64 + 1) * n_traj > (int64_t)1 << 30) return TOHIP_EINVAL;
     s.pl = make_plan(n, s.V, W, n_traj);
     if (workspace_bytes < s.pl.total) return TOHIP_ENOSPC;
     char* ws = (char*)workspace;
@@ -1501,9 +1579,12 @@ inline int traj_step_init(TrajStep& s, const void* packed, int64_t n, int64_t W,
     s.rec = (WayRec*)(ws + s.pl.off_rec);
     s.cold = (WayCold*)(ws + s.pl.off_cold);
     s.ext = (Extrema*)(ws + s.pl.off_ext);
-    s.cand = (int*)(ws + s.pl.off_cand);
-    s.clist = (int*)(ws + s.pl.off_clist);
+    s.cbits = (unsigned long long*)(ws + s.pl.off_cbits);
+    s.ctr = (int*)(ws + s.pl.off_ctr);
+    s.plive = (int*)(ws + s.pl.off_plive);
+    s.nlive = (int*)(ws + s.pl.off_nlive);
     s.plist = (int2*)(ws + s.pl.off_plist);
+    s.live = (unsigned long long*)(ws + s.pl.off_live);
     s.part = (float2*)(ws + s.pl.off_part);
     s.fv = (unsigned long long*)(ws + s.pl.off_fv);
     s.ties = (TieRec*)(ws + s.pl.off_ties);
@@ -1511,7 +1592,7 @@ inline int traj_step_init(TrajStep& s, const void* packed, int64_t n, int64_t W,
     s.vgrad = (float*)(ws + s.pl.off_vgrad);
     s.k = make_evalk(cam);
     s.cv = cloud_view(packed, n);
-    s.cull = !(flags & TOHIP_TRAJ_DENSE);
+    s.cull = !(flags & TOHIP_TRAJ_DENSE) && s.pl.fv_words <= TO_PROBE_MAXFW;   // (beyond 16.7 M points every pair is evaluated)
     s.rq = (s.C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
     s.rt = s.rq ? rig->rig_trans : nullptr;
     s.toff_ws = (int*)(ws + s.pl.off_toff);
@@ -1525,31 +1606,30 @@ inline int traj_step_init(TrajStep& s, const void* packed, int64_t n, int64_t W,
 // launches 1 and 2 of a step: records + probe, pass 1
 inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float* quats, float* lo_sum, float* rewards_half) {
     const int V = (int)s.V;
+    const OutInit oi{lo_sum, rewards_half, s.cv.npad, s.n, (int)s.n_traj};
     {
         TO_PROF(TOHIP_PROF_SMALL, s.st);
+        const ProbeCull pc{s.cull ? 1 : 0, s.pl.nslots, s.live, s.plive, s.nlive, oi};
         if (V <= 512)
             k_traj_probe<1024><<<V, 1024, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
-                                                     s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cand, s.pl.nitems + 2, s.wp_stride);
+                                                     s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cbits, s.pl.ncbits, s.ctr, s.wp_stride, pc);
         else
             k_traj_probe<256><<<V, 256, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
-                                                   s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cand, s.pl.nitems + 2, s.wp_stride);
+                                                   s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cbits, s.pl.ncbits, s.ctr, s.wp_stride, pc);
         TO_HIP_CHECK_LAUNCH();
     }
-    const OutInit oi{lo_sum, rewards_half, s.cv.npad, s.n, (int)s.n_traj};
     {
         TO_PROF(TOHIP_PROF_PASS1, s.st);
         const bool occ = s.occ != nullptr;
         if (s.cull) {
-            int vtile, ntiles;
-            cull_tiles(V, &vtile, &ntiles);
-            const dim3 grid(s.pl.nblk, ntiles);
-            if (occ) k_traj_pass1_cull<true><<<grid, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, vtile, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.pl.nitems, s.occ, s.occw, oi);
-            else k_traj_pass1_cull<false><<<grid, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, vtile, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.pl.nitems, s.occ, s.occw, oi);
+            const dim3 grid(TO_CULL_GX, V);
+            if (occ) k_traj_pass1_cull<true><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.pl.nslots, s.plive, s.nlive, s.occ, s.occw);
+            else k_traj_pass1_cull<false><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.pl.nslots, s.plive, s.nlive, s.occ, s.occw);
         } else {
             const int nblk8 = (int)(s.pl.npad / (TO_BLOCK * TO_PD));
             const int nb = dense_blocks(nblk8, V, occ);
-            if (occ) k_traj_pass1_dense<true><<<nb, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, nblk8, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.pl.nitems, s.occ, s.occw, oi, clock_stamps());
-            else k_traj_pass1_dense<false><<<nb, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, nblk8, s.k, s.part, s.ext, s.cand, s.clist, s.pl.nslots, s.pl.nitems, s.occ, s.occw, oi, clock_stamps());
+            if (occ) k_traj_pass1_dense<true><<<nb, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, nblk8, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.occ, s.occw, oi, clock_stamps());
+            else k_traj_pass1_dense<false><<<nb, TO_BLOCK, 0, s.st>>>(s.cv, s.rec, V, nblk8, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.occ, s.occw, oi, clock_stamps());
         }
         TO_HIP_CHECK_LAUNCH();
     }
@@ -1559,7 +1639,7 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
 inline SparseArgs sparse_args(const TrajStep& s, float* lo_sum) {
     SparseArgs a;
     a.cv = s.cv; a.rec = s.rec; a.ext = s.ext; a.k = s.k; a.part = s.part;
-    a.V = (int)s.V; a.nslots = s.pl.nslots; a.vwords = s.pl.vwords; a.fv_words = s.pl.fv_words; a.clist = s.clist; a.clist_n = s.cand + s.pl.nitems; a.plist = s.plist; a.npairs = s.cand + s.pl.nitems + 1;
+    a.V = (int)s.V; a.nslots = s.pl.nslots; a.vwords = s.pl.vwords; a.fv_words = s.pl.fv_words; a.cbits = s.cbits; a.live = s.cull ? s.live : nullptr; a.plist = s.plist; a.npairs = s.ctr;
     a.fv = s.fv; a.ties = s.ties; a.lo_sum = lo_sum; a.minmax = nullptr; a.occ = s.occ; a.occw = s.occw;
     a.toff = s.toff; a.n_traj = (int)s.n_traj; a.C = s.C;
     a.rewards = nullptr; a.prefilled = 0; a.acc = s.acc; a.shift = s.shift;
@@ -1570,7 +1650,7 @@ inline SparseArgs sparse_args(const TrajStep& s, float* lo_sum) {
 // list walkers: the expected number of candidate slots on the workloads this is tuned for (6-8 % of the slots), each a chain
 // of its own; a dense cloud lists every slot and the blocks loop
 inline int sparse_blocks(const TrajStep& s) {
-    int64_t nb = std::min<int64_t>(s.pl.nitems, 512 * s.n_traj);
+    int64_t nb = std::min<int64_t>((int64_t)s.pl.nslots * s.n_traj, 512 * s.n_traj);
     return (int)std::min<int64_t>(nb, 4096);
 }
 
@@ -1800,9 +1880,12 @@ extern "C" int tohip_traj_forward_backward(const void* packed, int64_t n, const 
 // rank and stay untouched.
 
 // flag[s] = 1 when slot s is a candidate of this rank's last forward, else 0 (one int32 per slot: RCCL reduces with MAX, it has no OR)
-__global__ void k_candidate_flags(const int* __restrict__ clist, const int* __restrict__ clist_n, int nslots, int* __restrict__ flag) {
-    const int n = *clist_n;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) flag[clist[i] % nslots] = 1;   // of any trajectory
+__global__ void k_candidate_flags(const unsigned long long* __restrict__ cbits, int fv_words, int n_traj, int nslots, int* __restrict__ flag) {
+    for (int sl = blockIdx.x * blockDim.x + threadIdx.x; sl < nslots; sl += gridDim.x * blockDim.x) {
+        unsigned long long any = 0ull;
+        for (int tr = 0; tr < n_traj; ++tr) any |= cbits[((int64_t)tr * fv_words + (sl >> 6)) * TO_CBIT_STRIDE];   // of any trajectory
+        flag[sl] = (int)((any >> (sl & 63)) & 1ull);
+    }
 }
 
 // prefix[s] = number of set flags below slot s; prefix[nslots] = their total (one block)
@@ -1848,9 +1931,7 @@ extern "C" int tohip_traj_candidate_flags(int64_t n_points, int64_t n_virtual, i
     if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream_;
     const char* ws = (const char*)workspace;
-    const hipError_t e = hipMemsetAsync(slot_flags, 0, sizeof(int32_t) * (size_t)pl.nslots, st);
-    if (e != hipSuccess) return (int)e;
-    k_candidate_flags<<<16, 256, 0, st>>>((const int*)(ws + pl.off_clist), (const int*)(ws + pl.off_cand) + pl.nitems, pl.nslots, slot_flags);
+    k_candidate_flags<<<16, 256, 0, st>>>((const unsigned long long*)(ws + pl.off_cbits), pl.fv_words, (int)n_traj, pl.nslots, slot_flags);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
@@ -1873,12 +1954,17 @@ extern "C" int tohip_slots_pack(const int32_t* slot_flags, const int32_t* prefix
 }
 
 // Diagnostic: what the last forward over `workspace` found — stats[0] = flagged (slot, waypoint) pairs, stats[1] = candidate slots
-// listed by pass 1, stats[2] = slots, stats[3] = virtual waypoints (device int64 x 4; the caller zero-fills it).
-__global__ void k_traj_stats(const int* __restrict__ counters, int nslots, int V, unsigned long long* __restrict__ stats) {
-    stats[0] = (unsigned long long)counters[1];
-    stats[1] = (unsigned long long)counters[0];
-    stats[2] = (unsigned long long)nslots;
-    stats[3] = (unsigned long long)V;
+// of pass 1, stats[2] = slots, stats[3] = virtual waypoints, stats[4] = the pairs the last CULLED pass 1 evaluated (device int64 x 5; the
+// caller zero-fills it).
+__global__ void k_traj_stats(const unsigned long long* __restrict__ cbits, int ncbits, const int* __restrict__ ctr, int nslots, int V,
+                             const int* __restrict__ nlive, unsigned long long* __restrict__ stats) {
+    unsigned long long c = 0, e = 0;
+    for (int i = threadIdx.x; i < ncbits; i += blockDim.x) c += __popcll(cbits[(int64_t)i * TO_CBIT_STRIDE]);
+    for (int i = threadIdx.x; i < V; i += blockDim.x) e += (unsigned long long)nlive[i];
+    for (int s = 32; s > 0; s >>= 1) { c += __shfl_xor(c, s); e += __shfl_xor(e, s); }
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&stats[1], c);
+    if ((threadIdx.x & 63) == 0 && e) atomicAdd(&stats[4], e);
+    if (threadIdx.x == 0) { stats[0] = (unsigned long long)ctr[0]; stats[2] = (unsigned long long)nslots; stats[3] = (unsigned long long)V; }
 }
 
 extern "C" int tohip_traj_step_stats(int64_t n_points, int64_t n_virtual, int64_t n_traj, const void* workspace, size_t workspace_bytes,
@@ -1887,8 +1973,8 @@ extern "C" int tohip_traj_step_stats(int64_t n_points, int64_t n_virtual, int64_
     const TrajPlan pl = make_plan(n_points, n_virtual, n_virtual, n_traj);
     if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
     const char* ws = (const char*)workspace;
-    const int* cand = (const int*)(ws + pl.off_cand);
-    k_traj_stats<<<1, 1, 0, (hipStream_t)stream_>>>(cand + pl.nitems, pl.nslots, (int)n_virtual, (unsigned long long*)stats);
+    k_traj_stats<<<1, 1024, 0, (hipStream_t)stream_>>>((const unsigned long long*)(ws + pl.off_cbits), pl.ncbits, (const int*)(ws + pl.off_ctr), pl.nslots,
+                                                       (int)n_virtual, (const int*)(ws + pl.off_nlive), (unsigned long long*)stats);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }

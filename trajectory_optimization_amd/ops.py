@@ -287,12 +287,13 @@ def allreduce_log_odds(shard, cloud, ws, lo_sum, local=True):
 
 
 def traj_step_stats(cloud, ws):
-    """What the last forward over `ws` found -> dict(flagged_pairs, candidate_slots, slots, virtual_waypoints, flagged_fraction)."""
-    st = torch.zeros(4, dtype=torch.int64, device=cloud.device)
+    """What the last forward over `ws` found -> dict(flagged_pairs, candidate_slots, slots, virtual_waypoints, flagged_fraction,
+    evaluated_pairs: those the last culled pass 1 evaluated)."""
+    st = torch.zeros(5, dtype=torch.int64, device=cloud.device)
     with torch.cuda.device(cloud.device):
         check(_lib.lib().tohip_traj_step_stats(cloud.n, ws.n_virtual, ws.n_traj, ptr(ws.buf), ws.bytes, ptr(st), stream_ptr()), "tohip_traj_step_stats")
-    f, c, s, v = (int(x) for x in st.cpu())
-    return dict(flagged_pairs=f, candidate_slots=c, slots=s, virtual_waypoints=v, flagged_fraction=f / max(1, s * v))
+    f, c, s, v, e = (int(x) for x in st.cpu())
+    return dict(flagged_pairs=f, candidate_slots=c, slots=s, virtual_waypoints=v, flagged_fraction=f / max(1, s * v), evaluated_pairs=e)
 
 
 class PoseWorkspace:
