@@ -258,7 +258,6 @@ struct ProbeCull {
     unsigned long long* live;      // V x fv_words: bit s of row v = slot s may hold a point waypoint v sees at all
     int* plive;                    // V x nslots: the same as lists of slots
     int* nlive;                    // V: their lengths
-    OutInit oi;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -290,9 +289,16 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
         if (traj_off != nullptr)   // the calls that follow the forward (backward, finish) take no offsets: they read this copy
             for (int j = t; j <= n_traj; j += TO_PROBE_THREADS) traj_off_ws[j] = traj_off[j];
     }
-    // CULL: the outputs' start values (the dense pass 1 sets them itself): stores nobody here waits for
-    if (pc.on)
-        for (int64_t i = ((int64_t)v * TO_PROBE_THREADS + t) * 4; i < pc.oi.npad; i += (int64_t)gridDim.x * TO_PROBE_THREADS * 4) init_outputs(i, pc.oi);
+    // CULL: the bounding spheres of the first slots this wave will test, requested now
+    constexpr int kPre = 4, kWaves = TO_PROBE_THREADS / 64;
+    float4 tb[kPre];
+    if (pc.on) {
+#pragma unroll
+        for (int i = 0; i < kPre; ++i) {
+            const int sl = ((t >> 6) + i * kWaves) * 64 + (t & 63);
+            tb[i] = cv.bounds[sl < pc.nslots ? sl : 0];
+        }
+    }
     // the samples (a contiguous copy of every step-th sorted point, made at pack time) are requested first, the record is
     // built meanwhile
     constexpr int kBatch = 8, kRounds = TO_PROBE_MAX / (TO_PROBE_THREADS * kBatch);
@@ -359,12 +365,23 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
     __syncthreads();
     const float thr = scull[0], sthr = scull[1], azero = scull[2], inv_scd = 1.0f / k.scd;
     const int lane = t & 63;
-    for (int w = t >> 6; w < fv_words; w += TO_PROBE_THREADS / 64) {
+    auto test_word = [&](int w, const float4& b) {
         const int sl = w * 64 + lane;
-        bool ok = false;
-        if (sl < pc.nslots) ok = tile_live(r.t, r.sp, thr, sthr, azero, cv.bounds[sl], inv_scd);
-        const unsigned long long word = __ballot(ok);
+        const unsigned long long word = __ballot(sl < pc.nslots && tile_live(r.t, r.sp, thr, sthr, azero, b, inv_scd));
         if (lane == 0) { pc.live[(int64_t)v * fv_words + w] = word; swords[w] = word; }
+    };
+#pragma unroll
+    for (int i = 0; i < kPre; ++i)
+        if ((t >> 6) + i * kWaves < fv_words) test_word((t >> 6) + i * kWaves, tb[i]);
+    for (int w0 = (t >> 6) + kPre * kWaves; w0 < fv_words; w0 += kPre * kWaves) {   // the rest, kPre loads in flight at a time
+#pragma unroll
+        for (int i = 0; i < kPre; ++i) {
+            const int sl = (w0 + i * kWaves) * 64 + lane;
+            tb[i] = cv.bounds[sl < pc.nslots ? sl : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < kPre; ++i)
+            if (w0 + i * kWaves < fv_words) test_word(w0 + i * kWaves, tb[i]);
     }
     __syncthreads();
     if (t < 64) {   // exclusive prefix of the words' popcounts, 64 words at a time
@@ -515,14 +532,13 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 }
 
 // CULL: most (slot, waypoint) pairs cannot contribute — on the BASELINE slab a waypoint reaches 2.5 % of the slots — and the
-// probe has listed, per waypoint, the slots it can reach.  grid = (TO_CULL_GX, V) blocks of sixteen waves: the waves of row v
+// probe has listed, per waypoint, the slots it can reach.  grid = (2 or 1, V) blocks of sixteen waves: the waves of row v
 // deal the waypoint's list among themselves, one (slot, waypoint) pair at a time — the record sits in scalar registers for the
 // wave's whole life, the next pair's points are requested before the current pair is evaluated; every pair costs the same, so
 // the chip is evenly loaded whatever the pairs' distribution over the slots.  The waypoint's extrema and its candidates' bits
 // are combined in LDS and leave the block as ONE atomic per word: thousands of device-scope atomics on a few lines, one per
 // pair, were what the kernel's time consisted of.  A pair that is not listed is not written: k_traj_sparse takes (min, max) =
 // (the proven 0, -inf: never flagged) for it from the `live` bit.
-#define TO_CULL_GX 2
 struct CullLds {
     unsigned long long cand[TO_PROBE_MAXFW];
     int mx[TO_SP_WAVES], mn[TO_SP_WAVES];
@@ -532,12 +548,15 @@ template <bool OCC>
 __global__ void __launch_bounds__(TO_SP_THREADS)
 k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, float2* __restrict__ part, Extrema* __restrict__ ext,
                   unsigned long long* __restrict__ cbits, int fv_words, int nslots, const int* __restrict__ plive,
-                  const int* __restrict__ nlive, const uint32_t* __restrict__ occ, int64_t occw) {
+                  const int* __restrict__ nlive, const uint32_t* __restrict__ occ, int64_t occw, OutInit oi) {
     constexpr int P = TO_P;
     __shared__ CullLds L;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int v = blockIdx.y;
-    const int wr = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * TO_SP_WAVES) + wave), WR = TO_CULL_GX * TO_SP_WAVES;
+    // the outputs' start values (the dense pass 1 sets them itself): stores nobody here waits for
+    for (int64_t i = (((int64_t)v * gridDim.x + blockIdx.x) * TO_SP_THREADS + t) * 4; i < oi.npad; i += (int64_t)gridDim.y * gridDim.x * TO_SP_THREADS * 4)
+        init_outputs(i, oi);
+    const int wr = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * TO_SP_WAVES) + wave), WR = (int)gridDim.x * TO_SP_WAVES;
     const int* list = plive + (int64_t)v * nslots;
     int slot = wr < nslots ? list[wr] : 0;   // requested with the list's length, not after it
     const int n = nlive[v];
@@ -833,16 +852,17 @@ __device__ __forceinline__ void write_minmax(const SparseArgs& a) {
     }
 }
 
-// block b of nb takes the b-th, (b + nb)-th, ... set bit of the candidate bits (bit s of row tr = slot s for trajectory tr):
-// every wave finds them from the same popcount prefix, 64 words at a time (one 16-wave block is resident per CU at this kernel's
-// register count)
+// block b of nb works for trajectory b % n_traj: the q-th, (q + S)-th, ... set bit of that trajectory's candidate bits (bit s =
+// slot s), q = b / n_traj, S = nb / n_traj (the host launches a multiple of n_traj blocks).  Every wave finds them from the same
+// popcount prefix, 64 words at a time (one 16-wave block is resident per CU at this kernel's register count).
 template <int MODE, bool OCC>
 __device__ __forceinline__ void sparse_walk(const SparseArgs& a, int b, int nb, SparseLds& L) {
     const int lane = threadIdx.x & 63;
-    const int nwords = a.n_traj * a.fv_words;
-    int carry = 0, next = b;
-    for (int c0 = 0; c0 < nwords; c0 += 64) {
-        const unsigned long long word = (c0 + lane < nwords) ? a.cbits[(int64_t)(c0 + lane) * TO_CBIT_STRIDE] : 0ull;
+    const int tr = b % a.n_traj, S = nb / a.n_traj;
+    const unsigned long long* bits = a.cbits + (int64_t)tr * a.fv_words * TO_CBIT_STRIDE;
+    int carry = 0, next = b / a.n_traj;
+    for (int c0 = 0; c0 < a.fv_words; c0 += 64) {
+        const unsigned long long word = (c0 + lane < a.fv_words) ? bits[(int64_t)(c0 + lane) * TO_CBIT_STRIDE] : 0ull;
         const int pc = __popcll(word);
         int incl = pc;
 #pragma unroll
@@ -857,11 +877,8 @@ __device__ __forceinline__ void sparse_walk(const SparseArgs& a, int b, int nb, 
             const int rr = rnk - __shfl(incl - pc, f);
             const unsigned long long wf = uniform_u64((unsigned long long)__shfl((long long)word, f));
             const bool hit = ((wf >> lane) & 1ull) && __popcll(wf & ((1ull << lane) - 1ull)) == rr;
-            const int wi = c0 + f;                       // word index: trajectory wi / fv_words, slots 64 (wi % fv_words) ..
-            const int tr = wi / a.fv_words;
-            const int slot = (wi - tr * a.fv_words) * 64 + __builtin_ctzll(__ballot(hit));
-            sparse_slot<MODE, OCC>(a, slot, tr, b & 7, L);
-            next += nb;
+            sparse_slot<MODE, OCC>(a, (c0 + f) * 64 + __builtin_ctzll(__ballot(hit)), tr, b & 7, L);
+            next += S;
         }
         carry += tot;
     }
@@ -1609,7 +1626,7 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
     const OutInit oi{lo_sum, rewards_half, s.cv.npad, s.n, (int)s.n_traj};
     {
         TO_PROF(TOHIP_PROF_SMALL, s.st);
-        const ProbeCull pc{s.cull ? 1 : 0, s.pl.nslots, s.live, s.plive, s.nlive, oi};
+        const ProbeCull pc{s.cull ? 1 : 0, s.pl.nslots, s.live, s.plive, s.nlive};
         if (V <= 512)
             k_traj_probe<1024><<<V, 1024, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
                                                      s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cbits, s.pl.ncbits, s.ctr, s.wp_stride, pc);
@@ -1622,9 +1639,9 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
         TO_PROF(TOHIP_PROF_PASS1, s.st);
         const bool occ = s.occ != nullptr;
         if (s.cull) {
-            const dim3 grid(TO_CULL_GX, V);
-            if (occ) k_traj_pass1_cull<true><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.pl.nslots, s.plive, s.nlive, s.occ, s.occw);
-            else k_traj_pass1_cull<false><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.pl.nslots, s.plive, s.nlive, s.occ, s.occw);
+            const dim3 grid(V <= 256 ? 2 : 1, V);   // two blocks to a row while that fills the chip once; a block's fixed cost otherwise
+            if (occ) k_traj_pass1_cull<true><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.pl.nslots, s.plive, s.nlive, s.occ, s.occw, oi);
+            else k_traj_pass1_cull<false><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.pl.nslots, s.plive, s.nlive, s.occ, s.occw, oi);
         } else {
             const int nblk8 = (int)(s.pl.npad / (TO_BLOCK * TO_PD));
             const int nb = dense_blocks(nblk8, V, occ);
@@ -1650,8 +1667,10 @@ inline SparseArgs sparse_args(const TrajStep& s, float* lo_sum) {
 // list walkers: the expected number of candidate slots on the workloads this is tuned for (6-8 % of the slots), each a chain
 // of its own; a dense cloud lists every slot and the blocks loop
 inline int sparse_blocks(const TrajStep& s) {
-    int64_t nb = std::min<int64_t>((int64_t)s.pl.nslots * s.n_traj, 512 * s.n_traj);
-    return (int)std::min<int64_t>(nb, 4096);
+    // per trajectory: as many blocks as a BASELINE step has candidate slots twice over (each a chain of its own); with several
+    // trajectories about 512 blocks in all (a block that finds nothing still costs its launch and its scan)
+    const int64_t per_traj = std::max<int64_t>(1, std::min<int64_t>(s.pl.nslots, 512 / s.n_traj));
+    return (int)(per_traj * s.n_traj);
 }
 
 template <int MODE>
