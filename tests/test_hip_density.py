@@ -55,3 +55,47 @@ def test_dense_room_against_the_oracle(extent, w):
     assert ep.max() < 1e-3 and eq.max() < 1e-3   # and the others are off by single points, not by anything systematic
     warnings.warn(f"dense room {extent}: {int((~keep).sum())} of {w} waypoints have a point within {MARGIN:g} of a threshold and were excluded from "
                   f"the 1e-5 gradient bar (worst of them {max(ep.max(), eq.max()):.1e}); worst among the others {max(ep[keep].max(), eq[keep].max()):.1e}")
+
+
+def test_culled_pass_evaluates_a_few_percent_of_the_pairs():
+    """What the culled pass 1 is for: on the BASELINE slab the probe's lists hold 2-3 % of the (slot, waypoint) pairs, every flagged
+    pair among them (tohip_traj_step_stats), and the candidates the sparse kernel walks are the slots that hold one."""
+    from trajectory_optimization_amd import ops
+    dev = torch.device("cuda:0")
+    n, w = 300_000, 64
+    cloud = ops.PackedCloud(torch.from_numpy(synth.make_cloud(n, seed=3)).to(dev))
+    poses, quats = synth.make_path(w, optical=True)
+    cam = ops.Camera(K, IW, IH)
+    p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
+    ws = ops.TrajWorkspace(cloud, w)
+    gout = torch.ones(1, device=dev)
+    culled = ops.traj_forward_backward(cloud, p, q, cam, ws, gout, flags=0)
+    st = ops.traj_step_stats(cloud, ws)
+    dense = ops.traj_forward_backward(cloud, p, q, cam, ws, gout, flags=ops.DENSE)
+    sd = ops.traj_step_stats(cloud, ws)
+    assert all(torch.equal(a, b) for a, b in zip(dense[:5], culled[:5]))
+    total = st["slots"] * st["virtual_waypoints"]
+    assert st["flagged_pairs"] == sd["flagged_pairs"] and st["candidate_slots"] == sd["candidate_slots"]
+    assert st["flagged_pairs"] <= st["evaluated_pairs"] <= 0.08 * total, st
+    assert 0 < st["candidate_slots"] <= st["slots"]
+
+
+def test_beyond_the_probes_slot_limit_every_pair_is_evaluated():
+    """More than 65 536 slots (16.7 M points): the probe's per-waypoint slot lists do not fit its LDS, and the default mode evaluates
+    every pair like TOHIP_TRAJ_DENSE does — the same results, no failure."""
+    from trajectory_optimization_amd import ops
+    dev = torch.device("cuda:0")
+    n, w = 16_800_000, 2
+    rng = np.random.default_rng(5)
+    pts = torch.from_numpy((rng.random((n, 3), dtype=np.float32) * np.float32([60, 60, 4]) - np.float32([30, 30, 2])))
+    cloud = ops.PackedCloud(pts.to(dev))
+    assert cloud.npad // 256 > 65536
+    poses, quats = synth.make_path(w, optical=True)
+    cam = ops.Camera(K, IW, IH)
+    p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
+    ws = ops.TrajWorkspace(cloud, w)
+    gout = torch.ones(1, device=dev)
+    a = ops.traj_forward_backward(cloud, p, q, cam, ws, gout, flags=0)
+    b = ops.traj_forward_backward(cloud, p, q, cam, ws, gout, flags=ops.DENSE)
+    assert all(torch.equal(x, y) for x, y in zip(a[:5], b[:5]))
+    assert 0.5 < float(a[1][0]) < 0.6 and torch.isfinite(a[2]).all() and float(a[2].abs().max()) > 0
