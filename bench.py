@@ -571,6 +571,13 @@ def main():
         p1_ms = kern[PASS1][0] / kern[PASS1][1]
         issue_cycles = cyc_per_iter * local_evals / evals_per_iter
         achieved = issue_cycles / (p1_ms * 1e-3) / 1e9           # G issue-cycles/s
+        if not dense_flags:
+            # --mode culled: pass 1 evaluates only the pairs a waypoint can reach (2.5 % on this workload); the priced instruction
+            # stream is the dense kernel's, so the roofline of this line is scaled by the evaluated share (tohip_traj_step_stats)
+            st = ops.traj_step_stats(cloud, ws)
+            share = st["evaluated_pairs"] / max(1, st["slots"] * st["virtual_waypoints"])
+            issue_cycles *= share
+            achieved *= share
         peak = N_SIMDS * CLOCK_GHZ
         traffic, valu_busy, valu_busy_res = pmc_figures(PASS1)
         step_ms = 1e3 * dt / args.steps
