@@ -71,7 +71,7 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
             occ = model._occlusion_rows(p_loc, q_loc)
         tgt_p, tgt_q = (pg_loc, qg_loc) if sharded else (pg_e, qg_e)
         if not sharded:
-            # no collective between forward and backward: the whole visibility step is ONE call, four launches
+            # no collective between forward and backward: the whole visibility step is ONE call, five launches
             check(L.tohip_traj_forward_backward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref, model._flags,
                                                 ptr(occ), ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(scalars), ptr(gout), ptr(tgt_p),
                                                 ptr(tgt_q), ptr(ws.buf), ws.bytes, s), "forward + backward")
