@@ -533,22 +533,27 @@ __device__ __forceinline__ float vis_p(const WayRec& r, const EvalK& k, float x,
     return S * E;
 }
 
+// (eps2, l2e2: k.eps and k.l2e_eps in both halves of a register pair — an instruction takes one scalar operand, so a second
+// constant has to sit in vector registers; the dense pass 1 keeps these two there for its whole loop)
 template <class Rec>
-__device__ __forceinline__ f2 vis_p_pk(const Rec& r, const EvalK& k, f2 x, f2 y, f2 z) {
+__device__ __forceinline__ f2 vis_p_pk(const Rec& r, const EvalK& k, f2 x, f2 y, f2 z, f2 eps2, f2 l2e2, f2 scd2) {
     const f2 y0 = x - pk_splat(r.t[0]), y1 = y - pk_splat(r.t[1]), y2 = z - pk_splat(r.t[2]);
     const f2 g0 = pk_fma(pk_splat(r.f0[2]), y2, pk_fma(pk_splat(r.f0[1]), y1, pk_splat(r.f0[0]) * y0));
     const f2 g1 = pk_fma(pk_splat(r.f1[2]), y2, pk_fma(pk_splat(r.f1[1]), y1, pk_splat(r.f1[0]) * y0));
-    const f2 zz = pk_fma(pk_splat(r.f2[2]), y2, pk_fma(pk_splat(r.f2[1]), y1, pk_fma(pk_splat(r.f2[0]), y0, pk_splat(k.eps))));
-    const f2 d0 = pk_fma(y0, pk_splat(k.scd), pk_splat(r.sp[0])), d1 = pk_fma(y1, pk_splat(k.scd), pk_splat(r.sp[1])),
-             d2 = pk_fma(y2, pk_splat(k.scd), pk_splat(r.sp[2]));
+    const f2 zz = pk_fma(pk_splat(r.f2[2]), y2, pk_fma(pk_splat(r.f2[1]), y1, pk_fma(pk_splat(r.f2[0]), y0, eps2)));
+    const f2 d0 = pk_fma(y0, scd2, pk_splat(r.sp[0])), d1 = pk_fma(y1, scd2, pk_splat(r.sp[1])), d2 = pk_fma(y2, scd2, pk_splat(r.sp[2]));
     const f2 dd = pk_fma(d2, d2, pk_fma(d1, d1, d0 * d0));
     const f2 rz = pk_rcp(zz);
     const f2 au = pk_fma(g0, rz, pk_splat(-k.cw)), av = pk_fma(g1, rz, pk_splat(-k.ch));
     const f2 A = pk_fma(av, av, pk_fma(au, au, dd));
     const f2 E = f2{to_exp2(-A.x), to_exp2(-A.y)};
-    const f2 ea = pk_fma(zz, pk_splat(k.nl2e), pk_splat(k.l2e_eps));
+    const f2 ea = pk_fma(zz, pk_splat(k.nl2e), l2e2);
     const f2 S = pk_rcp(pk_splat(1.0f) + f2{to_exp2(ea.x), to_exp2(ea.y)});
     return S * E;
+}
+template <class Rec>
+__device__ __forceinline__ f2 vis_p_pk(const Rec& r, const EvalK& k, f2 x, f2 y, f2 z) {
+    return vis_p_pk(r, k, x, y, z, pk_splat(k.eps), pk_splat(k.l2e_eps), pk_splat(k.scd));
 }
 
 // d p / d y (y = x - t, world-aligned) of the same evaluation; zero where p underflowed or the pair is occluded.

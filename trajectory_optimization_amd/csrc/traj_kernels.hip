@@ -468,6 +468,9 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
     // diagnostic only (tohip_profile_clock): shader-clock and 100 MHz real-time stamps of this block, to a buffer nothing else reads
     unsigned long long st0 = 0, sr0 = 0;
     if (stamps != nullptr && threadIdx.x == 0) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
+    // two of the evaluation's constants live in vector registers for the whole kernel (common.hpp, vis_p_pk)
+    f2 eps2 = pk_splat(k.eps), l2e2 = pk_splat(k.l2e_eps), scd2 = pk_splat(k.scd);
+    asm volatile("" : "+v"(eps2), "+v"(l2e2), "+v"(scd2));
     const int64_t total = (int64_t)nblk * V;
     int64_t u = total * blockIdx.x / gridDim.x;
     const int64_t u_end = total * (blockIdx.x + 1) / gridDim.x;
@@ -498,7 +501,7 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
             f2 p[P / 2];
 #pragma unroll
             for (int i = 0; i < P; i += 2)
-                p[i / 2] = vis_p_pk(r, k, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}) * f2{om[i], om[i + 1]};
+                p[i / 2] = vis_p_pk(r, k, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, eps2, l2e2, scd2) * f2{om[i], om[i + 1]};
             float mx = fmaxf(fmaxf(fmaxf(p[0].x, p[0].y), fmaxf(p[1].x, p[1].y)), fmaxf(fmaxf(p[2].x, p[2].y), fmaxf(p[3].x, p[3].y)));
             mx = half_max31_nn_fused(mx);
             // the minimum is wanted only while the probe has not exhibited a zero (U != 0, wave-uniform): p is never negative, so
