@@ -318,6 +318,35 @@ def test_tie_sets_are_deterministic_and_split_evenly(dev, copies):
     assert rel_inf(runs[0]["pg"], pg) < GRAD_TOL and rel_inf(runs[0]["qg"], qg) < GRAD_TOL
 
 
+def test_more_tie_slots_than_recorded_on_a_used_workspace(dev):
+    """The extremum in more slots than a waypoint's tie record holds (2 500 exact copies of its argmax point: ten slots) sends the
+    finish kernel through every slot's (min, max) of that waypoint.  In the culled mode the pairs pass 1 did not evaluate are not
+    written at all — whatever an earlier step at other poses left there must not be looked at: a workspace that has seen other
+    poses gives the bits of a fresh one, and those of the dense mode."""
+    from oracle import oracle
+    ops = _ops()
+    base = synth.make_cloud(60_000, seed=21)
+    poses, quats = synth.make_path(6, optical=True, jitter_seed=21)
+    pv = oracle.pose_forward(base, poses[2], quats[2], K, IW, IH, prec="f64")[0]
+    pts = np.concatenate([base, np.repeat(base[int(np.argmax(pv))][None], 2500, 0)]).astype(np.float32)
+    pts = pts[np.random.default_rng(1).permutation(len(pts))]
+    cloud = ops.PackedCloud(torch.from_numpy(pts).to(dev))
+    cam = ops.Camera(K, IW, IH)
+    p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
+    gout = torch.ones(1, device=dev)
+    fresh = ops.traj_forward_backward(cloud, p, q, cam, ops.TrajWorkspace(cloud, 6), gout, flags=0)
+    dense = ops.traj_forward_backward(cloud, p, q, cam, ops.TrajWorkspace(cloud, 6), gout, flags=ops.DENSE)
+    used = ops.TrajWorkspace(cloud, 6)
+    for shift in (3.0, -4.0, 1.5):   # other poses first: every slot near them gets written
+        ops.traj_forward_backward(cloud, p + torch.tensor([shift, -shift, 0.0], device=dev), q, cam, used, gout, flags=0)
+    again = ops.traj_forward_backward(cloud, p, q, cam, used, gout, flags=0)
+    for a, b, c in zip(fresh[:5], dense[:5], again[:5]):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    f = oracle.traj_forward(pts, poses, quats, K, IW, IH, prec="f64")
+    pg, qg = oracle.traj_backward(pts, poses, quats, K, IW, IH, f, prec="f64")
+    assert rel_inf(fresh[2].cpu().numpy(), pg) < GRAD_TOL and rel_inf(fresh[3].cpu().numpy(), qg) < GRAD_TOL
+
+
 def test_workspace_state_contract(dev):
     """The backward reads the state its forward left in the workspace, not the Parameters: an optimizer step (an in-place edit)
     between model() and backward() changes nothing.  ModelTraj notices when another forward has used the workspace in between

@@ -1175,6 +1175,7 @@ __global__ void k_bwd_finish2(const float* __restrict__ vgrad, const WayHot* __r
 // written by k_traj_reward in the same step), post = 2 by the same factor computed here from the integer reward sum
 // (RewardAcc::a), which the first block of each trajectory also turns into that trajectory's scalars.
 struct FinishPost {
+    const unsigned long long* live;   // culled pass 1: bit (v, slot) = the pair was evaluated (`part` holds it); NULL: all were
     int mode;                  // 0: none   1: scalars + gout   2: acc + gout (+ scalars_out)
     const float* scalars;
     const float* gout;
@@ -1251,6 +1252,7 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
             } else {
                 // more slots hold the extremum than were recorded: walk every slot partial (rare: many exact duplicates)
                 for (int rr = 0; rr < nslots; ++rr) {
+                    if (post.live != nullptr && !((post.live[(int64_t)v * fv_words + (rr >> 6)] >> (rr & 63)) & 1ull)) continue;   // not evaluated: holds neither
                     const float2 q = part[(int64_t)rr * V + v];
                     const bool hit = set ? (q.y - a == M) : (q.x == a);
                     if (hit) do_slot(rr);
@@ -1723,6 +1725,7 @@ inline int launch_finish(const TrajStep& s, const FinishPost& post, float* poses
 
 inline FinishPost finish_post(const TrajStep& s, int mode, const float* scalars, const float* gout, float* scalars_out, float eps) {
     FinishPost p;
+    p.live = s.cull ? s.live : nullptr;
     p.mode = mode; p.scalars = scalars; p.gout = gout; p.acc = s.acc; p.scalars_out = scalars_out; p.n = s.n; p.shift = s.shift; p.eps = eps;
     p.toff = s.toff; p.C = s.C;
     return p;
