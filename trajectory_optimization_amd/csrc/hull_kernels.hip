@@ -71,6 +71,7 @@ struct Bufs {
     int* newface;          // 3 * fcap
     int* cand[2];          // fcap each: candidate faces of even / odd rounds, kSubLists sub-lists of fcap / kSubLists
     int* olist;            // fcap: faces claimed this round, same sub-list layout
+    int* oclaim;           // fcap: the candidate that claimed each of them (an entry counts while that candidate still owns the face)
     int* ctrl;             // kCtrlInts
     int* vflag;            // M1
     int* tile_cnt;         // ntiles(M1)
@@ -115,8 +116,8 @@ __host__ inline size_t seg(size_t bytes) { return align_up(bytes, 256); }
 // The default suits clouds whose hull is a small fraction of the points (HPR of a scene: 2-5 %); a build that runs out
 // returns TOHIP_ENOSPC and the caller retries with a larger workspace — every byte beyond the fixed part is used for
 // faces (faces_for_bytes), up to the never-exceeded-in-practice 8 per point.
-constexpr size_t kBytesPerFace = 16 * sizeof(int) + 2 * sizeof(double) + 64;  // the per-face arrays carved below
-constexpr int kFaceArrays = 13;
+constexpr size_t kBytesPerFace = 17 * sizeof(int) + 2 * sizeof(double) + 64;  // the per-face arrays carved below
+constexpr int kFaceArrays = 14;
 
 __host__ inline int default_face_capacity(int64_t m1, int64_t nseg) {
     int64_t c = m1 / 2 + 64 * nseg + 4096;
@@ -147,6 +148,7 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * (size_t)fcap); if (b) b->cand[0] = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->cand[1] = (int*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->olist = (int*)p;
+    p = take(sizeof(int) * (size_t)fcap); if (b) b->oclaim = (int*)p;
     p = take(sizeof(int) * kCtrlTotal); if (b) b->ctrl = (int*)p;
     p = take(sizeof(int) * m1); if (b) b->vflag = (int*)p;
     p = take(sizeof(int) * ntiles); if (b) b->tile_cnt = (int*)p;
@@ -333,7 +335,7 @@ __device__ __forceinline__ int sub_cap(const Bufs& b) { return b.fcap / kSubList
 // walks sub-list vb % kSubLists of both, part vb / kSubLists.  A face can show up more than once (a candidate whose face
 // was claimed by a better one; a face claimed twice): the kernels are idempotent or de-duplicate (k_new_faces).
 struct ListWalk {
-    const int *cl, *ol;
+    const int *cl, *ol, *oc;
     int ncand, total, first, step, loops;
 };
 __device__ __forceinline__ ListWalk list_walk(const Bufs& b, int par, int vb, int nvb) {
@@ -341,6 +343,7 @@ __device__ __forceinline__ ListWalk list_walk(const Bufs& b, int par, int vb, in
     const int sl = vb % kSubLists, cap = sub_cap(b);
     w.cl = b.cand[par] + (size_t)sl * cap;
     w.ol = b.olist + (size_t)sl * cap;
+    w.oc = b.oclaim + (size_t)sl * cap;
     w.ncand = min(*ccnt(b, par, sl), cap);
     w.total = w.ncand + min(*ocnt(b, par, sl), cap);  // one index space: the candidates, then the claimed faces
     w.first = (vb / kSubLists) * TO_BLOCK + threadIdx.x;
@@ -348,9 +351,11 @@ __device__ __forceinline__ ListWalk list_walk(const Bufs& b, int par, int vb, in
     w.loops = (w.total + w.step - 1) / w.step;  // the same for every thread of the block
     return w;
 }
-__device__ __forceinline__ int list_face(const ListWalk& w, int it, bool* is_cand = nullptr) {
+// claimer (optional): the candidate whose entry this is — the face itself for a candidate's own entry
+__device__ __forceinline__ int list_face(const ListWalk& w, int it, bool* is_cand = nullptr, int* claimer = nullptr) {
     const int j = w.first + it * w.step;
     if (is_cand) *is_cand = j < w.ncand;
+    if (claimer) *claimer = j < w.ncand ? w.cl[j] : (j < w.total ? w.oc[j - w.ncand] : kNone);
     return j < w.ncand ? w.cl[j] : (j < w.total ? w.ol[j - w.ncand] : kNone);
 }
 
@@ -721,10 +726,12 @@ constexpr int kClaimFront = 128, kClaimMax = 4096, kClaimLog = 192;
 __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int par) {
     __shared__ int fr[TO_WAVES_PER_BLOCK][2][kClaimFront];
     __shared__ int lg[TO_WAVES_PER_BLOCK][kClaimLog];
+    __shared__ int lgc[TO_WAVES_PER_BLOCK][kClaimLog];   // who claimed it
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int sl = blockIdx.x % kSubLists, cap = sub_cap(b);
     const int* __restrict__ cand = b.cand[par] + (size_t)sl * cap;
     int* __restrict__ own = b.olist + (size_t)sl * cap;
+    int* __restrict__ ownc = b.oclaim + (size_t)sl * cap;
     int* own_n = ocnt(b, par, sl);
     const int ncand = min(*ccnt(b, par, sl), cap);
     const int wstep = (gridDim.x / kSubLists) * TO_WAVES_PER_BLOCK;
@@ -735,7 +742,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
         if (lane == 0) base = atomicAdd(own_n, logn);
         base = __shfl(base, 0);
         for (int i = lane; i < logn; i += 64) {
-            if (base + i < cap) own[base + i] = lg[wid][i];
+            if (base + i < cap) { own[base + i] = lg[wid][i]; ownc[base + i] = lgc[wid][i]; }
             else { b.ctrl[kCtrlOverflow] = 1; b.ctrl[kCtrlError] |= kErrCapacity; }  // k_accept turns everybody down; the build ends
         }
         logn = 0;
@@ -793,7 +800,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
                 const unsigned long long bal = __ballot(mine);
                 const int cnt = __popcll(bal), rank = __popcll(bal & ((1ull << lane) - 1ull));
                 if (logn + cnt > kClaimLog) flush();
-                if (mine) lg[wid][logn + rank] = n;
+                if (mine) { lg[wid][logn + rank] = n; lgc[wid][logn + rank] = o; }
                 logn += cnt;
                 if (mine && nnext + rank < kClaimFront) fr[wid][cur ^ 1][nnext + rank] = n;  // beyond: the walk stays incomplete (safe)
                 nnext += cnt;
@@ -839,7 +846,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owned_list(Bufs b, int par) {
         const bool put = g < nf && (b.fflags[g] & 1) && b.fowner[g] >= 0 && b.fowner[g] != g;
         const int slot = block_alloc(ocnt(b, par, sl), put ? 1 : 0);
         if (put) {
-            if (slot < cap) b.olist[(size_t)sl * cap + slot] = g;
+            if (slot < cap) { b.olist[(size_t)sl * cap + slot] = g; b.oclaim[(size_t)sl * cap + slot] = b.fowner[g]; }
             else b.ctrl[kCtrlError] |= kErrCapacity;
         }
     }
@@ -881,15 +888,19 @@ __device__ __forceinline__ bool owned_accepted(const Bufs& b, int g, int* owner)
 }
 
 // one new triangle (u, v, apex) per horizon edge (u, v) of an accepted region; the region's faces get their death mark
-// (bit 2; the alive bit goes in the tail, when nobody looks at the region any more) — which also tells a face's second
-// list entry that the first one has been here
+// (bit 2; the alive bit goes in the tail, when nobody looks at the region any more).  A face can be listed more than once (claimed,
+// then taken by a better candidate): the entry that counts is the one made by the candidate that owns the face now — exactly one
+// (a candidate claims a face at most once), decided without an atomic whose answer the thread would have to wait for.
 __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
     const ListWalk w = list_walk(b, par, blockIdx.x, gridDim.x);
     for (int it = 0; it < w.loops; ++it) {
-        const int g = list_face(w, it);
+        int claimer = kNone;
+        const int g = list_face(w, it, nullptr, &claimer);
         int o = kNone, want = 0;
         bool hor[3] = {false, false, false};
-        if (g >= 0 && (b.fflags[g] & 1) && owned_accepted(b, g, &o) && !(atomicOr(&b.fflags[g], 4) & 4)) {
+        const int fl = g >= 0 ? b.fflags[g] : 0;
+        if (g >= 0 && (fl & 1) && owned_accepted(b, g, &o) && claimer == o) {
+            b.fflags[g] = fl | 4;   // nobody else writes this face's flags in this launch
             for (int k = 0; k < 3; ++k) { hor[k] = b.fowner[b.fn[3 * g + k]] != o; want += hor[k]; }
         } else {
             o = kNone;
@@ -904,14 +915,15 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
             if (id >= b.fcap) { b.ctrl[kCtrlError] |= kErrCapacity; break; }
             const int n = b.fn[3 * g + k];
             const int u = b.fv[3 * g + k], v = b.fv[3 * g + (k + 1) % 3];
+            const int prev = atomicExch(&b.nfhead[o], id);   // the region's list of new faces: asked for first, stored last
             b.fv[3 * id] = u; b.fv[3 * id + 1] = v; b.fv[3 * id + 2] = apex;
             b.fn[3 * id] = n; b.fn[3 * id + 1] = kNone; b.fn[3 * id + 2] = kNone;
             set_plane(b, id);
             b.fflags[id] = 1; b.fowner[id] = kNone; b.fmax[id] = 0ull; b.fapex[id] = 0x7fffffff; b.nfhead[id] = kNone;
             b.newface[3 * g + k] = id;
-            b.frec[id].next = atomicExch(&b.nfhead[o], id);
             for (int j = 0; j < 3; ++j)
                 if (b.fn[3 * n + j] == g) b.fn[3 * n + j] = id;
+            b.frec[id].next = prev;
             ++id;
         }
     }
@@ -996,41 +1008,50 @@ __global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int wi
     const int sl = blockIdx.x % kSubLists, cap = sub_cap(b);
     int* __restrict__ next = b.cand[par ^ 1] + (size_t)sl * cap;
     int* next_n = ccnt(b, par ^ 1, sl);
-    auto enter = [&](int f, bool yes) {  // all threads of the block
-        const int slot = block_alloc(next_n, yes ? 1 : 0);
-        if (yes) {
-            if (slot < cap) next[slot] = f;
-            else b.ctrl[kCtrlError] |= kErrCapacity;
-        }
-    };
+    // One pass over both sources of the next round's candidates — the listed faces (a surviving candidate re-enters through its own
+    // entry) and the faces created this round — with ONE reservation per step for both: an allocation is an atomic whose answer
+    // the whole block waits for.
     const ListWalk w = list_walk(b, par, blockIdx.x, gridDim.x);
-    for (int it = 0; it < w.loops; ++it) {
-        bool from_cand;
-        const int f = list_face(w, it, &from_cand);
-        bool cand = false;
-        if (f >= 0) {
-            const int fl = b.fflags[f];
-            const int alive = (fl & 1) && !(fl & 4);
-            cand = alive && b.fmax[f] != 0ull;  // fmax persists: an outside set is fixed at the face's creation
-            b.fowner[f] = cand ? f : kNone;
-            b.fflags[f] = alive | (cand ? 2 : 0);
-            if (from_cand) b.nfhead[f] = kNone;
-            if (cand && from_cand) b.fprio[f] = make_prio(f, next_round, (float)dkey_inv_pos(b.fmax[f]) * b.frec[f].inv_norm, b.hbits);
-        }
-        enter(f, cand && from_cand);  // a candidate enters through its own entry, not through a claim's
-    }
     const int f_lo = b.ctrl[kCtrlNFaces], nf = min(b.ctrl[kCtrlNFaces + 8], b.fcap);  // final since k_new_faces ended
     const int stride = gridDim.x * TO_BLOCK;
     const int nloop = (nf - f_lo + stride - 1) / stride;
-    for (int it = 0; it < nloop; ++it) {
-        // consecutive faces to consecutive blocks: a round's few hundred new faces spread over all sub-lists
-        const int f = f_lo + (it * TO_BLOCK + threadIdx.x) * gridDim.x + blockIdx.x;
-        const bool cand = f < nf && (b.fflags[f] & 1) && b.fmax[f] != 0ull;
-        if (cand) {
-            b.fowner[f] = f; b.fflags[f] = 3;
-            b.fprio[f] = make_prio(f, next_round, (float)dkey_inv_pos(b.fmax[f]) * b.frec[f].inv_norm, b.hbits);
+    for (int it = 0; it < max(w.loops, nloop); ++it) {
+        int f1 = kNone, f2 = kNone;
+        bool c1 = false, c2 = false;
+        if (it < w.loops) {
+            bool from_cand;
+            f1 = list_face(w, it, &from_cand);
+            bool cand = false;
+            if (f1 >= 0) {
+                const int fl = b.fflags[f1];
+                const int alive = (fl & 1) && !(fl & 4);
+                cand = alive && b.fmax[f1] != 0ull;  // fmax persists: an outside set is fixed at the face's creation
+                b.fowner[f1] = cand ? f1 : kNone;
+                b.fflags[f1] = alive | (cand ? 2 : 0);
+                if (from_cand) b.nfhead[f1] = kNone;
+                if (cand && from_cand) b.fprio[f1] = make_prio(f1, next_round, (float)dkey_inv_pos(b.fmax[f1]) * b.frec[f1].inv_norm, b.hbits);
+            }
+            c1 = cand && from_cand;  // a candidate enters through its own entry, not through a claim's
         }
-        enter(f, cand);
+        if (it < nloop) {
+            // consecutive faces to consecutive blocks: a round's few hundred new faces spread over all sub-lists
+            f2 = f_lo + (it * TO_BLOCK + threadIdx.x) * gridDim.x + blockIdx.x;
+            c2 = f2 < nf && (b.fflags[f2] & 1) && b.fmax[f2] != 0ull;
+            if (c2) {
+                b.fowner[f2] = f2; b.fflags[f2] = 3;
+                b.fprio[f2] = make_prio(f2, next_round, (float)dkey_inv_pos(b.fmax[f2]) * b.frec[f2].inv_norm, b.hbits);
+            }
+        }
+        const int slot = block_alloc(next_n, (c1 ? 1 : 0) + (c2 ? 1 : 0));
+        if (c1) {
+            if (slot < cap) next[slot] = f1;
+            else b.ctrl[kCtrlError] |= kErrCapacity;
+        }
+        if (c2) {
+            const int s2 = slot + (c1 ? 1 : 0);
+            if (s2 < cap) next[s2] = f2;
+            else b.ctrl[kCtrlError] |= kErrCapacity;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) b.ctrl[kCtrlOverflow] = 0;  // read by k_accept only
 }
@@ -1721,7 +1742,7 @@ extern "C" int tohip_convex_hull_vertices(const float* pts, int64_t n, int with_
     if (fcap == 0) return TOHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream_;
     hull::Bufs b;
-    hull::carve(&b, (char*)workspace, n, 1, fcap);
+    if (hull::carve(&b, (char*)workspace, n, 1, fcap) > workspace_bytes) return TOHIP_ENOSPC;   // (faces_for_bytes and carve disagree: a build error)
     hull::k_single_segment<<<1, 1, 0, st>>>(b);
     TO_HIP_CHECK_LAUNCH();
     int rounds = 0;
@@ -1739,7 +1760,7 @@ extern "C" int tohip_hidden_pts_removal(const float* xyz, int64_t n, float param
     if (fcap == 0) return TOHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream_;
     hull::Bufs b;
-    hull::carve(&b, (char*)workspace, n, 1, fcap);
+    if (hull::carve(&b, (char*)workspace, n, 1, fcap) > workspace_bytes) return TOHIP_ENOSPC;   // (faces_for_bytes and carve disagree: a build error)
     hull::k_single_segment<<<1, 1, 0, st>>>(b);
     TO_HIP_CHECK_LAUNCH();
     int rc = launch_flip(xyz, n, param, b.flipped, nullptr, b.flip_max, st);
@@ -1783,7 +1804,7 @@ extern "C" int tohip_hidden_pts_removal_batched(const float* xyz, const int64_t*
     if (fcap == 0) return TOHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream_;
     hull::Bufs b;
-    hull::carve(&b, (char*)workspace, n, n_segments, fcap);
+    if (hull::carve(&b, (char*)workspace, n, n_segments, fcap) > workspace_bytes) return TOHIP_ENOSPC;   // (faces_for_bytes and carve disagree: a build error)
     std::vector<int> off((size_t)n_segments + 1);
     for (int32_t s = 0; s <= n_segments; ++s) off[s] = (int)(seg_offsets_host[s] + s);  // + one origin slot per segment
     hipError_t e = hipMemcpyAsync(b.seg_off, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice, st);
