@@ -63,7 +63,8 @@ struct Bufs {
     int* fn;               // 3 * fcap
     FaceRec* frec;         // fcap
     unsigned long long* fmax;  // fcap
-    int* fapex;            // fcap   apex candidate as an EXPANDED index (ties go to the caller's lowest index); 0x7fffffff = none
+    unsigned long long* fapex;  // fcap   apex candidate: its EXPANDED index (high word: ties go to the caller's lowest index) and its
+                           //        position (low word: what the kernels want, without a trip through `inv`); kNoApex = none
     int* fowner;           // fcap
     unsigned long long* fprio;  // fcap   rank of a candidate this round (smaller = better), written by the previous round's tail
     int* fflags;           // fcap   bit0 alive, bit1 candidate / accepted, bit2 dies at the end of this round
@@ -110,13 +111,16 @@ struct Bufs {
     int sub;               // > 1 while only every sub-th point (in Morton order) takes part: the first rounds of a large build
 };
 
+constexpr unsigned long long kNoApex = ~0ull;
+__device__ __forceinline__ int apex_pos(unsigned long long a) { return (int)(unsigned)(a & 0xffffffffull); }
+
 __host__ inline size_t seg(size_t bytes) { return align_up(bytes, 256); }
 
 // Faces are never recycled within a build, so the capacity bounds the faces ever CREATED (a few per hull vertex).
 // The default suits clouds whose hull is a small fraction of the points (HPR of a scene: 2-5 %); a build that runs out
 // returns TOHIP_ENOSPC and the caller retries with a larger workspace — every byte beyond the fixed part is used for
 // faces (faces_for_bytes), up to the never-exceeded-in-practice 8 per point.
-constexpr size_t kBytesPerFace = 17 * sizeof(int) + 2 * sizeof(double) + 64;  // the per-face arrays carved below
+constexpr size_t kBytesPerFace = 16 * sizeof(int) + 3 * sizeof(double) + 64;  // the per-face arrays carved below
 constexpr int kFaceArrays = 14;
 
 __host__ inline int default_face_capacity(int64_t m1, int64_t nseg) {
@@ -139,7 +143,7 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * 3 * (size_t)fcap); if (b) b->fn = (int*)p;
     p = take(sizeof(FaceRec) * (size_t)fcap); if (b) b->frec = (FaceRec*)p;
     p = take(sizeof(unsigned long long) * (size_t)fcap); if (b) b->fmax = (unsigned long long*)p;
-    p = take(sizeof(int) * (size_t)fcap); if (b) b->fapex = (int*)p;
+    p = take(sizeof(unsigned long long) * (size_t)fcap); if (b) b->fapex = (unsigned long long*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->fowner = (int*)p;
     p = take(sizeof(unsigned long long) * (size_t)fcap); if (b) b->fprio = (unsigned long long*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->fflags = (int*)p;
@@ -497,7 +501,7 @@ __device__ void init_tetrahedron(const Bufs& b, int sg, bool enough, bool has_na
             for (int f = fb; f < fb + 4; ++f) {
                 for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = lo; b.fn[3 * f + k] = f; }
                 b.frec[f] = FaceRec{0.0, 0.0, 0.0, b.px[lo], b.py[lo], b.pz[lo], kNone, 0.f, {0, 0}};
-                b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = 0x7fffffff; b.nfhead[f] = kNone;
+                b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = kNoApex; b.nfhead[f] = kNone;
                 b.newface[3 * f] = kNone;
             }
             return;
@@ -515,7 +519,7 @@ __device__ void init_tetrahedron(const Bufs& b, int sg, bool enough, bool has_na
             b.fflags[f] = 1;
             b.fowner[f] = kNone;
             b.fmax[f] = 0ull;
-            b.fapex[f] = 0x7fffffff;
+            b.fapex[f] = kNoApex;
             b.nfhead[f] = kNone;
             b.newface[3 * f] = kNone;
         }
@@ -707,7 +711,7 @@ __device__ __forceinline__ void far_arg_points(const Bufs& b, int f_lo, int vblo
         const int i = b.live[j];
         const int f = b.pface[i];
         if (f < f_lo) continue;
-        if (dkey(fdist(b, f, i)) == b.fmax[f]) atomicMin(&b.fapex[f], b.perm[i]);
+        if (dkey(fdist(b, f, i)) == b.fmax[f]) atomicMin(&b.fapex[f], ((unsigned long long)(unsigned)b.perm[i] << 32) | (unsigned)i);
     }
 }
 
@@ -749,32 +753,35 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
     };
     for (int c = (blockIdx.x / kSubLists) * TO_WAVES_PER_BLOCK + wid; c < ncand; c += wstep) {
         const int o = cand[c];
-        const int ax = b.fapex[o];
-        if (ax == 0x7fffffff) {  // no apex found for a face with points outside it (never seen): not a candidate
+        const unsigned long long ax = b.fapex[o];
+        const int n0 = (b.early_out && lane < 3) ? b.fn[3 * o + lane] : kNone;   // for the look at the neighbours below: requested with the apex
+        if (ax == kNoApex) {  // no apex found for a face with points outside it (never seen): not a candidate
             if (lane == 0) { b.fowner[o] = kNone; atomicAnd(&b.fflags[o], ~2); }
             continue;
         }
         if (__hip_atomic_load(&b.fowner[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != o) continue;  // taken by a better one
         const unsigned long long po = b.fprio[o];
+        // the apex's coordinates are requested before the look at the neighbours below, not after it: two chains of dependent
+        // loads side by side
+        const int apex = apex_pos(ax);
+        const double px = b.px[apex], py = b.py[apex], pz = b.pz[apex];
         {
             // A candidate whose own face is seen by the apex of a BETTER candidate next door has lost before it starts: that
             // neighbour's walk takes this face at its first level.  Not walking keeps its claims off the faces that worse
             // candidates need (experiments: TOHIP_HULL_EARLY_OUT=0 switches it off)
             bool doomed = false;
-            if (b.early_out && lane < 3) {
-                const int n = b.fn[3 * o + lane];
+            if (n0 >= 0) {
+                const int n = n0;
                 if ((b.fflags[n] & 3) == 3 && b.fprio[n] < po) {
-                    const int an = b.fapex[n];
-                    if (an != 0x7fffffff) {
-                        const int pa = b.inv[an];
+                    const unsigned long long an = b.fapex[n];
+                    if (an != kNoApex) {
+                        const int pa = apex_pos(an);
                         doomed = plane_dist(b.frec[o], b.px[pa], b.py[pa], b.pz[pa]) > 0.0;
                     }
                 }
             }
             if (__any(doomed)) continue;
         }
-        const int apex = b.inv[ax];
-        const double px = b.px[apex], py = b.py[apex], pz = b.pz[apex];
         int cur = 0, ncur = 1, claimed = 0;
         if (lane == 0) fr[wid][0][0] = o;
         while (ncur > 0 && claimed < kClaimMax) {
@@ -823,13 +830,13 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b, int round) {
     for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf; g += stride) {
         if (!(b.fflags[g] & 1)) continue;
         int best = b.fowner[g];
-        if (best == g && b.fapex[g] == 0x7fffffff) { b.fowner[g] = kNone; atomicAnd(&b.fflags[g], ~2); continue; }
+        if (best == g && b.fapex[g] == kNoApex) { b.fowner[g] = kNone; atomicAnd(&b.fflags[g], ~2); continue; }
         unsigned long long bp = best >= 0 ? b.fprio[best] : ~0ull;
         for (int k = 0; k < 3; ++k) {
             const int o = b.fowner[b.fn[3 * g + k]];
-            if (o < 0 || o == best || b.fapex[o] == 0x7fffffff) continue;
+            if (o < 0 || o == best || b.fapex[o] == kNoApex) continue;
             const unsigned long long op = b.fprio[o];
-            if (op < bp && fdist(b, g, b.inv[b.fapex[o]]) > 0.0) { best = o; bp = op; }
+            if (op < bp && fdist(b, g, apex_pos(b.fapex[o])) > 0.0) { best = o; bp = op; }
         }
         if (best != b.fowner[g]) { b.fowner[g] = best; changed = true; }
     }
@@ -867,7 +874,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_accept(Bufs b, int round, int par)
         const int o = b.fowner[g];
         if (o < 0) continue;
         if (b.fowner[o] != o) { continue; }  // o lost its own face: not a candidate (owned_accepted() checks the same)
-        const int apex = b.inv[b.fapex[o]];
+        const int apex = apex_pos(b.fapex[o]);
         bool ok = !overflow;
         for (int k = 0; k < 3; ++k) {
             const int n = b.fn[3 * g + k];
@@ -909,7 +916,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
         if (acc != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&b.ctrl[kCtrlAccepted], __popcll(acc));
         int id = block_alloc(&b.ctrl[kCtrlNFaces + 8], want);
         if (want == 0) continue;
-        const int apex = b.inv[b.fapex[o]];
+        const int apex = apex_pos(b.fapex[o]);
         for (int k = 0; k < 3; ++k) {
             if (!hor[k]) continue;
             if (id >= b.fcap) { b.ctrl[kCtrlError] |= kErrCapacity; break; }
@@ -919,7 +926,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
             b.fv[3 * id] = u; b.fv[3 * id + 1] = v; b.fv[3 * id + 2] = apex;
             b.fn[3 * id] = n; b.fn[3 * id + 1] = kNone; b.fn[3 * id + 2] = kNone;
             set_plane(b, id);
-            b.fflags[id] = 1; b.fowner[id] = kNone; b.fmax[id] = 0ull; b.fapex[id] = 0x7fffffff; b.nfhead[id] = kNone;
+            b.fflags[id] = 1; b.fowner[id] = kNone; b.fmax[id] = 0ull; b.fapex[id] = kNoApex; b.nfhead[id] = kNone;
             b.newface[3 * g + k] = id;
             for (int j = 0; j < 3; ++j)
                 if (b.fn[3 * n + j] == g) b.fn[3 * n + j] = id;
@@ -972,7 +979,7 @@ __device__ __forceinline__ void reassign_points(const Bufs& b, FaceMaxTable& tab
         const int g = j < nlive ? b.pface[i] : kNone;
         if (g >= 0 && (b.fflags[g] & 4)) {
             const int o = b.fowner[g];
-            const int ap = b.inv[b.fapex[o]];
+            const int ap = apex_pos(b.fapex[o]);
             const double x = b.px[i], y = b.py[i], z = b.pz[i];
             // (every new face has the apex as a vertex and two older ones, whose copies retired when THEY went in)
             if (i != ap && !(x == b.px[ap] && y == b.py[ap] && z == b.pz[ap])) {
@@ -1087,7 +1094,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_seg_faces(Bufs b, int* __restrict_
         const int k = atomicAdd(&cnt[sg], 1);
         if (list) list[off[sg] + k] = f;
         // every alive face gets a fresh apex search (k_far_arg_all) once the dormant points have joined its outside set
-        if (list) b.fapex[f] = 0x7fffffff;
+        if (list) b.fapex[f] = kNoApex;
     }
 }
 
