@@ -57,7 +57,7 @@
 #define TO_SP_THREADS 1024     // the block of the kernels that walk slot lists (culled pass 1, sparse, pairs)
 #define TO_SP_WAVES (TO_SP_THREADS / 64)
 #define TO_CBIT_STRIDE 16      // words between two words of the candidate bits: one to a 128-byte line (mark_candidate)
-#define TO_PROBE_MAXFW 1024   // words of a `live` row the probe holds in LDS: culling up to 65 536 slots (16.7 M points), dense beyond
+#define TO_PROBE_MAXFW 1024   // words of a `live` row the culled pass 1 holds in LDS: culling up to 65 536 slots (16.7 M points), dense beyond
 #define TO_SP_MAXW 1024        // flag words of one slot held in LDS by k_traj_sparse: at most 65 536 virtual waypoints
 
 // ---------------------------------------------------------------------------------------------
@@ -256,8 +256,6 @@ struct ProbeCull {
     int on;
     int nslots;
     unsigned long long* live;      // V x fv_words: bit s of row v = slot s may hold a point waypoint v sees at all
-    int* plive;                    // V x nslots: the same as lists of slots
-    int* nlive;                    // V: their lengths
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -357,18 +355,15 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
         ties[v].nmin = 0;
     }
     if (!pc.on) return;
-    // CULL: which 256-point slots can waypoint v reach at all — row v of `live` (a bit per slot: k_traj_sparse asks it whether a
-    // pair was evaluated) and the same as a list, plive[v * nslots ..] with nlive[v] entries in slot order (the culled pass 1
-    // deals it to its waves)
-    __shared__ unsigned long long swords[TO_PROBE_MAXFW];
-    __shared__ int spre[TO_PROBE_MAXFW];
+    // CULL: which 256-point slots can waypoint v reach at all — row v of `live`, a bit per slot: the culled pass 1 deals the set
+    // bits to its waves, k_traj_sparse asks them whether a pair was evaluated
     __syncthreads();
     const float thr = scull[0], sthr = scull[1], azero = scull[2], inv_scd = 1.0f / k.scd;
     const int lane = t & 63;
     auto test_word = [&](int w, const float4& b) {
         const int sl = w * 64 + lane;
         const unsigned long long word = __ballot(sl < pc.nslots && tile_live(r.t, r.sp, thr, sthr, azero, b, inv_scd));
-        if (lane == 0) { pc.live[(int64_t)v * fv_words + w] = word; swords[w] = word; }
+        if (lane == 0) pc.live[(int64_t)v * fv_words + w] = word;
     };
 #pragma unroll
     for (int i = 0; i < kPre; ++i)
@@ -382,27 +377,6 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
 #pragma unroll
         for (int i = 0; i < kPre; ++i)
             if (w0 + i * kWaves < fv_words) test_word(w0 + i * kWaves, tb[i]);
-    }
-    __syncthreads();
-    if (t < 64) {   // exclusive prefix of the words' popcounts, 64 words at a time
-        int carry = 0;
-        for (int w0 = 0; w0 < fv_words; w0 += 64) {
-            const int c = (w0 + lane < fv_words) ? __popcll(swords[w0 + lane]) : 0;
-            int incl = c;
-#pragma unroll
-            for (int sh = 1; sh < 64; sh <<= 1) {
-                const int up = __shfl_up(incl, sh);
-                if (lane >= sh) incl += up;
-            }
-            if (w0 + lane < fv_words) spre[w0 + lane] = carry + incl - c;
-            carry += __shfl(incl, 63);
-        }
-        if (lane == 0) pc.nlive[v] = carry;
-    }
-    __syncthreads();
-    for (int w = t >> 6; w < fv_words; w += TO_PROBE_THREADS / 64) {
-        const unsigned long long word = swords[w];
-        if ((word >> lane) & 1ull) pc.plive[(int64_t)v * pc.nslots + spre[w] + __popcll(word & ((1ull << lane) - 1ull))] = w * 64 + lane;
     }
 }
 
@@ -535,7 +509,7 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 }
 
 // CULL: most (slot, waypoint) pairs cannot contribute — on the BASELINE slab a waypoint reaches 2.5 % of the slots — and the
-// probe has listed, per waypoint, the slots it can reach.  grid = (2 or 1, V) blocks of sixteen waves: the waves of row v
+// probe has marked, per waypoint, the slots it can reach.  grid = (2 or 1, V) blocks of sixteen waves: the waves of row v
 // deal the waypoint's list among themselves, one (slot, waypoint) pair at a time — the record sits in scalar registers for the
 // wave's whole life, the next pair's points are requested before the current pair is evaluated; every pair costs the same, so
 // the chip is evenly loaded whatever the pairs' distribution over the slots.  The waypoint's extrema and its candidates' bits
@@ -543,32 +517,66 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 // pair, were what the kernel's time consisted of.  A pair that is not listed is not written: k_traj_sparse takes (min, max) =
 // (the proven 0, -inf: never flagged) for it from the `live` bit.
 struct CullLds {
-    unsigned long long cand[TO_PROBE_MAXFW];
+    unsigned long long cand[TO_PROBE_MAXFW];   // the candidates this block finds
+    unsigned long long row[TO_PROBE_MAXFW];    // the waypoint's reachable slots (its row of `live`)
+    int pre[TO_PROBE_MAXFW];                   // set bits before each word
     int mx[TO_SP_WAVES], mn[TO_SP_WAVES];
+    int total;
 };
+
+// the j-th reachable slot of the block's waypoint (j < total, wave-uniform): the word by a 64-ary search of the prefix, the bit
+// by its rank inside the word — every lane looks at one candidate
+__device__ __forceinline__ int cull_select(const CullLds& L, int fv_words, int j, int lane) {
+    int lo = 0, hi = fv_words;   // the word is in [lo, hi): pre[lo] <= j
+    while (hi - lo > 1) {
+        const int step = (hi - lo + 63) >> 6;
+        const int idx = lo + lane * step;
+        const int cnt = __popcll(__ballot(idx < hi && L.pre[idx] <= j));   // >= 1
+        lo += (cnt - 1) * step;
+        hi = min(hi, lo + step);
+    }
+    const unsigned long long word = uniform_u64(L.row[lo]);
+    const int r = j - L.pre[lo];
+    const bool hit = ((word >> lane) & 1ull) && __popcll(word & ((1ull << lane) - 1ull)) == r;
+    return lo * 64 + __builtin_ctzll(__ballot(hit));
+}
 
 template <bool OCC>
 __global__ void __launch_bounds__(TO_SP_THREADS)
 k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, float2* __restrict__ part, Extrema* __restrict__ ext,
-                  unsigned long long* __restrict__ cbits, int fv_words, int nslots, const int* __restrict__ plive,
-                  const int* __restrict__ nlive, const uint32_t* __restrict__ occ, int64_t occw, OutInit oi) {
+                  unsigned long long* __restrict__ cbits, int fv_words, const unsigned long long* __restrict__ live,
+                  const uint32_t* __restrict__ occ, int64_t occw, OutInit oi) {
     constexpr int P = TO_P;
     __shared__ CullLds L;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int v = blockIdx.y;
+    for (int w = t; w < fv_words; w += TO_SP_THREADS) { L.row[w] = live[(int64_t)v * fv_words + w]; L.cand[w] = 0ull; }
     // the outputs' start values (the dense pass 1 sets them itself): stores nobody here waits for
     for (int64_t i = (((int64_t)v * gridDim.x + blockIdx.x) * TO_SP_THREADS + t) * 4; i < oi.npad; i += (int64_t)gridDim.y * gridDim.x * TO_SP_THREADS * 4)
         init_outputs(i, oi);
-    const int wr = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * TO_SP_WAVES) + wave), WR = (int)gridDim.x * TO_SP_WAVES;
-    const int* list = plive + (int64_t)v * nslots;
-    int slot = wr < nslots ? list[wr] : 0;   // requested with the list's length, not after it
-    const int n = nlive[v];
-    if ((int)(blockIdx.x * TO_SP_WAVES) >= n) return;   // block-uniform
-    for (int w = t; w < fv_words; w += TO_SP_THREADS) L.cand[w] = 0ull;
     __syncthreads();
+    if (t < 64) {   // exclusive prefix of the words' popcounts, 64 words at a time
+        int carry = 0;
+        for (int w0 = 0; w0 < fv_words; w0 += 64) {
+            const int c = (w0 + lane < fv_words) ? __popcll(L.row[w0 + lane]) : 0;
+            int incl = c;
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                const int up = __shfl_up(incl, sh);
+                if (lane >= sh) incl += up;
+            }
+            if (w0 + lane < fv_words) L.pre[w0 + lane] = carry + incl - c;
+            carry += __shfl(incl, 63);
+        }
+        if (lane == 0) L.total = carry;
+    }
+    __syncthreads();
+    const int n = L.total;
+    const int wr = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * TO_SP_WAVES) + wave), WR = (int)gridDim.x * TO_SP_WAVES;
     const WayRec& r = rec[v];
     int bmx = __builtin_bit_cast(int, r.L), bmn = __builtin_bit_cast(int, r.U);   // p >= +0: the bit patterns order like the values
     if (wr < n) {
+        int slot = cull_select(L, fv_words, wr, lane);
         float x[P], y[P], z[P];
         load_points<P>(cv.soa, cv.npad, (int64_t)slot * TO_SLOT + lane * P, x, y, z);
         for (int j = wr; j < n; j += WR) {
@@ -576,8 +584,8 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
             const int64_t base = (int64_t)cur * TO_SLOT + lane * P;
             float nx[P], ny[P], nz[P];
             const bool more = j + WR < n;
-            if (more) {
-                slot = __builtin_amdgcn_readfirstlane(list[j + WR]);
+            if (more) {   // the next pair's points are in flight while this pair is evaluated
+                slot = cull_select(L, fv_words, j + WR, lane);
                 load_points<P>(cv.soa, cv.npad, (int64_t)slot * TO_SLOT + lane * P, nx, ny, nz);
             }
             float mn, mx, om[P];
@@ -1497,7 +1505,7 @@ struct TrajPlan {
     int fv_words;  // (nslots + 63) / 64
     int vwords;    // (V + 63) / 64
     int V;
-    size_t off_ctl, off_toff, off_rec, off_cold, off_ext, off_cbits, off_ctr, off_part, off_fv, off_live, off_plive, off_nlive, off_plist, off_ties, off_bpart, off_vgrad, total;
+    size_t off_ctl, off_toff, off_rec, off_cold, off_ext, off_cbits, off_ctr, off_part, off_fv, off_live, off_plist, off_ties, off_bpart, off_vgrad, total;
 };
 
 inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
@@ -1520,8 +1528,6 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
     p.off_part = o;  o += align_up((size_t)V * (size_t)p.nslots * sizeof(float2), 256);
     p.off_fv = o;    o += align_up((size_t)V * (size_t)p.fv_words * sizeof(unsigned long long), 256);
     p.off_live = o;  o += align_up((size_t)V * (size_t)p.fv_words * sizeof(unsigned long long), 256);   // culled pass 1: the slots a waypoint can reach, as bits
-    p.off_plive = o; o += align_up((size_t)V * (size_t)p.nslots * sizeof(int), 256);                    //   and as lists,
-    p.off_nlive = o; o += align_up((size_t)V * sizeof(int), 256);                                       //   with their lengths
     p.off_plist = o; o += align_up((size_t)V * (size_t)p.nslots * sizeof(int2), 256);   // every pair flagged: the same bytes as part
     p.off_ties = o;  o += align_up((size_t)V * sizeof(TieRec), 256);
     p.off_bpart = o; o += align_up((size_t)V * (size_t)p.nslots * 16 * sizeof(float), 256);
@@ -1577,7 +1583,7 @@ struct TrajStep {
     WayCold* cold;
     Extrema* ext;
     unsigned long long* cbits;
-    int *ctr, *plive, *nlive;
+    int* ctr;
     int2* plist;
     float2* part;
     unsigned long long *fv, *live;
@@ -1603,8 +1609,6 @@ inline int traj_step_init(TrajStep& s, const void* packed, int64_t n, int64_t W,
     s.ext = (Extrema*)(ws + s.pl.off_ext);
     s.cbits = (unsigned long long*)(ws + s.pl.off_cbits);
     s.ctr = (int*)(ws + s.pl.off_ctr);
-    s.plive = (int*)(ws + s.pl.off_plive);
-    s.nlive = (int*)(ws + s.pl.off_nlive);
     s.plist = (int2*)(ws + s.pl.off_plist);
     s.live = (unsigned long long*)(ws + s.pl.off_live);
     s.part = (float2*)(ws + s.pl.off_part);
@@ -1631,7 +1635,7 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
     const OutInit oi{lo_sum, rewards_half, s.cv.npad, s.n, (int)s.n_traj};
     {
         TO_PROF(TOHIP_PROF_SMALL, s.st);
-        const ProbeCull pc{s.cull ? 1 : 0, s.pl.nslots, s.live, s.plive, s.nlive};
+        const ProbeCull pc{s.cull ? 1 : 0, s.pl.nslots, s.live};
         if (V <= 512)
             k_traj_probe<1024><<<V, 1024, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
                                                      s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cbits, s.pl.ncbits, s.ctr, s.wp_stride, pc);
@@ -1645,8 +1649,8 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
         const bool occ = s.occ != nullptr;
         if (s.cull) {
             const dim3 grid(V <= 256 ? 2 : 1, V);   // two blocks to a row while that fills the chip once; a block's fixed cost otherwise
-            if (occ) k_traj_pass1_cull<true><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.pl.nslots, s.plive, s.nlive, s.occ, s.occw, oi);
-            else k_traj_pass1_cull<false><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.pl.nslots, s.plive, s.nlive, s.occ, s.occw, oi);
+            if (occ) k_traj_pass1_cull<true><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.live, s.occ, s.occw, oi);
+            else k_traj_pass1_cull<false><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.live, s.occ, s.occw, oi);
         } else {
             const int nblk8 = (int)(s.pl.npad / (TO_BLOCK * TO_PD));
             const int nb = dense_blocks(nblk8, V, occ);
@@ -1982,10 +1986,10 @@ extern "C" int tohip_slots_pack(const int32_t* slot_flags, const int32_t* prefix
 // of pass 1, stats[2] = slots, stats[3] = virtual waypoints, stats[4] = the pairs the last CULLED pass 1 evaluated (device int64 x 5; the
 // caller zero-fills it).
 __global__ void k_traj_stats(const unsigned long long* __restrict__ cbits, int ncbits, const int* __restrict__ ctr, int nslots, int V,
-                             const int* __restrict__ nlive, unsigned long long* __restrict__ stats) {
+                             const unsigned long long* __restrict__ live, int nlive_words, unsigned long long* __restrict__ stats) {
     unsigned long long c = 0, e = 0;
     for (int i = threadIdx.x; i < ncbits; i += blockDim.x) c += __popcll(cbits[(int64_t)i * TO_CBIT_STRIDE]);
-    for (int i = threadIdx.x; i < V; i += blockDim.x) e += (unsigned long long)nlive[i];
+    for (int i = threadIdx.x; i < nlive_words; i += blockDim.x) e += (unsigned long long)__popcll(live[i]);
     for (int s = 32; s > 0; s >>= 1) { c += __shfl_xor(c, s); e += __shfl_xor(e, s); }
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&stats[1], c);
     if ((threadIdx.x & 63) == 0 && e) atomicAdd(&stats[4], e);
@@ -1999,7 +2003,7 @@ extern "C" int tohip_traj_step_stats(int64_t n_points, int64_t n_virtual, int64_
     if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
     const char* ws = (const char*)workspace;
     k_traj_stats<<<1, 1024, 0, (hipStream_t)stream_>>>((const unsigned long long*)(ws + pl.off_cbits), pl.ncbits, (const int*)(ws + pl.off_ctr), pl.nslots,
-                                                       (int)n_virtual, (const int*)(ws + pl.off_nlive), (unsigned long long*)stats);
+                                                       (int)n_virtual, (const unsigned long long*)(ws + pl.off_live), (int)(n_virtual * pl.fv_words), (unsigned long long*)stats);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
