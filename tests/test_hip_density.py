@@ -81,7 +81,7 @@ def test_culled_pass_evaluates_a_few_percent_of_the_pairs():
 
 
 def test_beyond_the_probes_slot_limit_every_pair_is_evaluated():
-    """More than 65 536 slots (16.7 M points): the probe's per-waypoint slot lists do not fit its LDS, and the default mode evaluates
+    """More than 65 536 slots (16.7 M points): a waypoint's row of reachable-slot bits does not fit pass 1's LDS, and the default mode evaluates
     every pair like TOHIP_TRAJ_DENSE does — the same results, no failure."""
     from trajectory_optimization_amd import ops
     dev = torch.device("cuda:0")
