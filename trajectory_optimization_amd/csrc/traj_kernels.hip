@@ -4,19 +4,22 @@
 // :237/:246 (rewards, visibility loss) and its torch-autograd backward (SURVEY.md §8a rows A-C,E,G).
 //
 // Every (point, waypoint) pair is evaluated ONCE, in pass 1, which keeps the extrema only; everything after it works on
-// the few pairs that can contribute.  A step is FOUR launches:
+// the few pairs that can contribute.  A step is FIVE launches:
 //
 //   k_traj_probe    block per waypoint: its record (WayRec, common.hpp), the extrema of p over a sample of the cloud
-//                   (attained values: L <= max p, U >= min p; CULL mode skips with them), and the reset of what the step
-//                   accumulates into (running extrema, flag rows, tie lists, the reward sum)
-//   k_traj_pass1    p of every pair -> (min, max) per (256-point slot, waypoint) in `part`, and the waypoint's running
-//                   extrema by integer atomicMin / atomicMax (order independent) from the few waves that improve on (U, L)
-//   k_traj_sparse   block per slot: which waypoints are FLAGGED for it — slot maximum reaches p_hat >= 1/2, or it holds an
-//                   argmin point while min p > 0: only flagged pairs have a non-zero log-odds term or a gradient — then the
-//                   log-odds of its 256 points over the flagged waypoints (fixed order), the rewards, their fixed-point sum,
-//                   and the 14 gradient sums of every flagged pair.  Packed f32 throughout (two points per register pair).
-//                   Three builds: FUSED (all of it: no collective between forward and backward), FWD (up to lo_sum: the
-//                   all-reduce of a waypoint-sharded run comes next), BWD (gradient sums from a complete lo_sum)
+//                   (attained values: L <= max p, U >= min p), the reset of what the step accumulates into (running extrema,
+//                   flag rows, tie lists, candidate bits, the pair list's length); CULL: the slots the waypoint can reach
+//   k_traj_pass1    p of every pair (DENSE) / of the pairs the probe marked reachable (CULL) -> (min, max) per (256-point
+//                   slot, waypoint) in `part`, the waypoint's running extrema by integer atomicMin / atomicMax (order
+//                   independent), and a candidate bit per (trajectory, slot) whose maximum can be flagged
+//   k_traj_sparse   block per candidate (slot, trajectory): which waypoints are FLAGGED for it — slot maximum reaches
+//                   p_hat >= 1/2, or it holds an argmin point while min p > 0: only flagged pairs have a non-zero log-odds term
+//                   or a gradient — then the log-odds of its 256 points over the flagged waypoints (fixed order); FUSED (no
+//                   collective between forward and backward) also the rewards and their fixed-point sum; FWD stops at lo_sum
+//                   (the all-reduce of a waypoint-sharded run comes next).  Appends its flagged pairs to the step's pair list.
+//   k_traj_pairs    wave per flagged (slot, waypoint) pair, dealt evenly to the whole chip: the 14 gradient sums of the pair.
+//                   Packed f32 throughout (two points per register pair).  In a split step it shares its launch with the
+//                   rewards' scan of the complete lo_sum (k_traj_reward_bwd)
 //   k_traj_finish   block per waypoint: its flagged slots' partials in slot order (f64), argmin/argmax shares from the
 //                   recorded slots (deterministic: no float atomics), scale by dL/d reward, chain to (position, quaternion)
 //
@@ -31,16 +34,16 @@
 //   Extrema   16 B per virtual waypoint: (min p, max p) as integers
 //   lo_sum (sorted order) / rewards (original order)                                    4 B/point each
 //   part      [slot][virtual waypoint]: (min, max) of p over the slot's 256 points         8 B
-//   ft / fv   flag bits, [slot][waypoint word] (the backward of a split step reads its row) and [waypoint][slot word]
-//             (k_traj_finish walks it)
+//   fv        flag bits [waypoint][slot word] (k_traj_finish walks its row); plist: the step's flagged (slot, waypoint) pairs
+//   cbits     candidate bits [trajectory][slot word], one word per 128-byte line; live (CULL): reachable-slot bits [waypoint][slot word]
 //   bpart     [virtual waypoint][slot]: 14 gradient sums of a flagged pair                 64 B (written where flagged)
 //
 // Two evaluation modes with bitwise identical results:
 //   DENSE  pass 1 evaluates every (point, waypoint) pair (the streaming reference semantics; bench headline)
 //   CULL   pass 1 skips pairs that provably can neither be a waypoint's maximum nor be flagged: p <= 2^(-cd d2)
-//          bounds p by the squared distance d2 = |y - sp|^2; a wave tests its tile's bounding sphere against
-//          64 waypoints at once.  The bound is L/2; waypoints whose sample did not exhibit p == 0 (U > 0: the minimum
-//          is not known to be zero) are searched densely.
+//          bounds p by the squared distance d2 = |y - sp|^2; the probe tests the waypoint's sphere against every slot's
+//          bounding sphere.  The bound is L/2; waypoints whose sample did not exhibit p == 0 (U > 0: the minimum is not
+//          known to be zero) are searched densely.
 //
 // The forward leaves its state (records, extrema, flags) in the workspace; the backward reads it there: the workspace
 // must not be touched between tohip_traj_forward and tohip_traj_backward of the same step.
@@ -621,27 +624,20 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// sparse: 1024-thread blocks (16 waves) walk the list of candidate slots pass 1 made (6-8 % of the slots on the BASELINE
+// sparse: 1024-thread blocks (16 waves) take the candidate (slot, trajectory) bits pass 1 set (6-8 % of the slots on the BASELINE
 // workloads; every slot of a dense indoor cloud).  Every wave holds the slot's 256 points (four consecutive points per lane, as
 // two packed pairs); the slot's flagged waypoints of a trajectory, in ascending order, go round-robin to the waves (rank & 15):
-// a fixed order that depends only on the flag set, which DENSE and CULL share.  The list's order is arrival order; a slot's
-// results do not depend on it.
+// a fixed order that depends only on the flag set, which DENSE and CULL share.
 //   flags     lane per waypoint: the slot's (min, max) against the waypoint's final extrema — flagged when its maximum
 //             has p_hat >= 1/2 (the predicate applied per point below, on an attained value), or it holds an argmin point
 //             while a > 0 (that set carries gradient, model.py:226); a degenerate waypoint (max == min, or a NaN: the
 //             reference's 0/0 for EVERY point, model.py:227) flags every slot and adds NaN.  Slots holding an extremum
-//             enter the waypoint's tie list.  The flag words go to ft (row of this slot) and fv (bit of this slot).
+//             enter the waypoint's tie list.  The flag bits go to fv (bit of this slot), the flagged pairs to the pair list.
 //   staging   what an evaluation reads of a flagged waypoint's record, with a and 1/M, goes to LDS in one parallel load per
 //             256 waypoints: a wave's chain is then arithmetic, not a scalar load per waypoint
 //   forward   p_hat = (p - a)/M, clip to [0.5, 1-eps], log-odds (model.py:226-231), summed per wave, the sixteen waves in
 //             order; unflagged pairs contribute exactly 0.  lo_sum[slot] is complete when the block is done with it:
 //   rewards   r = sigmoid(lo) to the caller's order (points with lo == 0 keep the prefilled 1/2), their sum as integers
-//   backward  per flagged pair: G = dL/dp_hat = g_n [0.5 <= p_hat <= 1-eps] / (p_hat (1 - p_hat)), dL/dp = G / M, plus
-//             the shares of the min/max points (S1 = sum G (p_hat - 1)/M -> argmin set, S2 = sum G (-p_hat)/M -> argmax
-//             set; torch splits them evenly among ties).  bpart[(v*nslots+slot)*16 ..]:
-//               [0..2] sum w gy   [3..11] sum w y (x) gy   [12] S1   [13] S2        (w = G/M, gy = dp/dy, y = x - t)
-//             per lane over its four points, then one DPP tree over the wave.  FUSED takes the sums with dL/d reward = 1
-//             (they are linear in it; k_traj_finish scales them once the mean of the rewards is known).
 
 enum { TO_SP_FWD = 0, TO_SP_FUSED = 2 };
 #define TO_SP_CW 4                      // flag words (x 64 waypoints) staged at a time
