@@ -99,3 +99,35 @@ def test_beyond_the_probes_slot_limit_every_pair_is_evaluated():
     b = ops.traj_forward_backward(cloud, p, q, cam, ws, gout, flags=ops.DENSE)
     assert all(torch.equal(x, y) for x, y in zip(a[:5], b[:5]))
     assert 0.5 < float(a[1][0]) < 0.6 and torch.isfinite(a[2]).all() and float(a[2].abs().max()) > 0
+
+
+def test_culling_beyond_one_word_block_of_slots():
+    """3 M points = 11 719 slots = 184 words of slot bits: the probe's tests beyond its prefetched batch, the culled pass 1's two-level
+    search of the popcount prefix and the sparse kernel's walk over several 64-word chunks of candidate bits — against the dense mode,
+    bit for bit, and with fewer pairs evaluated."""
+    from trajectory_optimization_amd import ops
+    dev = torch.device("cuda:0")
+    n, w = 3_000_000, 6
+    rng = np.random.default_rng(9)
+    pts = torch.from_numpy((rng.random((n, 3), dtype=np.float32) * np.float32([50, 50, 4]) - np.float32([25, 25, 2])))
+    cloud = ops.PackedCloud(pts.to(dev))
+    assert 64 < (cloud.npad // 256 + 63) // 64 <= 1024
+    poses, quats = synth.make_path(w, optical=True)
+    cam = ops.Camera(K, IW, IH)
+    p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
+    ws = ops.TrajWorkspace(cloud, w)
+    gout = torch.ones(1, device=dev)
+    a = ops.traj_forward_backward(cloud, p, q, cam, ws, gout, flags=0)
+    st = ops.traj_step_stats(cloud, ws)
+    b = ops.traj_forward_backward(cloud, p, q, cam, ws, gout, flags=ops.DENSE)
+    assert all(torch.equal(x, y) for x, y in zip(a[:5], b[:5]))
+    assert 0 < st["flagged_pairs"] <= st["evaluated_pairs"] < 0.1 * st["slots"] * st["virtual_waypoints"], st
+    # and as two trajectories in one pass (candidate bits of two rows of 184 words)
+    toff = torch.tensor([0, 2, w], dtype=torch.int32, device=dev)
+    wsm = ops.TrajWorkspace(cloud, w, 2)
+    m = ops.traj_forward_backward_multi(cloud, p, q, toff, cam, wsm, torch.ones(2, device=dev), flags=0)
+    one0 = ops.traj_forward_backward(cloud, p[:2].contiguous(), q[:2].contiguous(), cam, ops.TrajWorkspace(cloud, 2), gout, flags=0)
+    one1 = ops.traj_forward_backward(cloud, p[2:].contiguous(), q[2:].contiguous(), cam, ops.TrajWorkspace(cloud, w - 2), gout, flags=0)
+    assert torch.equal(m[0][0], one0[0]) and torch.equal(m[0][1], one1[0])          # rewards per trajectory
+    assert torch.equal(m[2][:2], one0[2]) and torch.equal(m[2][2:], one1[2])          # position gradients
+    assert torch.equal(m[3][:2], one0[3]) and torch.equal(m[3][2:], one1[3])
