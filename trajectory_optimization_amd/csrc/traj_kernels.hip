@@ -479,7 +479,9 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
 #pragma unroll
             for (int i = 0; i < P; i += 2)
                 p[i / 2] = vis_p_pk(r, k, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, eps2, l2e2, scd2) * f2{om[i], om[i + 1]};
-            float mx = fmaxf(fmaxf(fmaxf(p[0].x, p[0].y), fmaxf(p[1].x, p[1].y)), fmaxf(fmaxf(p[2].x, p[2].y), fmaxf(p[3].x, p[3].y)));
+            // (three-operand maxima: four instructions for eight values)
+            const float m1 = fmaxf(fmaxf(p[0].x, p[0].y), p[1].x), m2 = fmaxf(fmaxf(p[1].y, p[2].x), p[2].y);
+            float mx = fmaxf(m2, fmaxf(fmaxf(p[3].x, p[3].y), m1));
             mx = half_max31_nn_fused(mx);
             // the minimum is wanted only while the probe has not exhibited a zero (U != 0, wave-uniform): p is never negative, so
             // with one zero in the cloud min p = 0 whatever this slot holds, and nothing downstream looks at a slot's minimum then
