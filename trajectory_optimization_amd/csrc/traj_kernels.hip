@@ -699,6 +699,19 @@ __device__ __forceinline__ f2 log_odds_pk(const EvalK& k, float a, float invM, f
     return (f2{to_log2(ph.x), to_log2(ph.y)} - f2{to_log2(om.x), to_log2(om.y)}) * pk_splat(0.693147180559945f);
 }
 
+// what an evaluation reads of waypoint v, with its final normalisation, into the stage
+__device__ __forceinline__ void stage_way(const SparseArgs& a, int v, StagedWay& dst) {
+    const WayRec& r = a.rec[v];
+    StagedWay sw;
+    for (int i = 0; i < 3; ++i) { sw.t[i] = r.t[i]; sw.f0[i] = r.f0[i]; sw.f1[i] = r.f1[i]; sw.f2[i] = r.f2[i]; sw.sp[i] = r.sp[i]; }
+    float pmax, M;
+    load_norm(a.ext[v], sw.a, pmax, M, sw.invM);
+    if (!(M > 0.f) || !(sw.invM < INFINITY)) sw.invM = __builtin_nanf("");   // degenerate: every log-odds is NaN (0/0 in the reference)
+    sw.v = v;
+    sw.pad[0] = sw.pad[1] = 0.f;
+    dst = sw;
+}
+
 // one candidate slot for trajectory tr — its virtual waypoints [v_lo, v_hi), its own log-odds vector, rewards, sums and rank
 // count, so that its results are the ones a run of that trajectory alone produces; blockDim.x = TO_SP_THREADS.  Returns with
 // every thread past its last use of the LDS.
@@ -715,6 +728,10 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
 
     const int v_lo = a.toff ? a.toff[tr] * a.C : 0, v_hi = a.toff ? a.toff[tr + 1] * a.C : a.V;
     const int w_lo = v_lo >> 6, w_hi = min(a.vwords, (v_hi + 63) >> 6);
+    // A trajectory of up to TO_SP_STAGE virtual waypoints is staged whole, entry v - v_lo, with the block's first loads: which
+    // waypoints are flagged is known two dependent loads later, and what is staged does not depend on it.
+    const bool direct = v_hi - v_lo <= TO_SP_STAGE;   // block-uniform
+    if (direct && t < v_hi - v_lo) stage_way(a, v_lo + t, L.stage[t]);
     // ---- flags of this slot, one word per 64 waypoints ----
     int mine = 0;
     for (int w = w_lo + wave; w < w_hi; w += TO_SP_WAVES) {
@@ -765,37 +782,37 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
                 if ((t >> 6) == j && ((bits >> lane) & 1ull)) { my_rank = cnt + __popcll(bits & ((1ull << lane) - 1ull)); my_v = w * 64 + lane; }
                 cnt += __popcll(bits);
             }
-            if (my_rank >= 0) {   // threads 0 .. 255: one flagged waypoint each
-                const WayRec& r = a.rec[my_v];
-                StagedWay sw;
-                for (int i = 0; i < 3; ++i) { sw.t[i] = r.t[i]; sw.f0[i] = r.f0[i]; sw.f1[i] = r.f1[i]; sw.f2[i] = r.f2[i]; sw.sp[i] = r.sp[i]; }
-                float pmax, M;
-                load_norm(a.ext[my_v], sw.a, pmax, M, sw.invM);
-                if (!(M > 0.f) || !(sw.invM < INFINITY)) sw.invM = __builtin_nanf("");   // degenerate: every log-odds is NaN (0/0 in the reference)
-                sw.v = my_v;
-                sw.pad[0] = sw.pad[1] = 0.f;
-                L.stage[my_rank] = sw;
-            }
+            if (my_rank >= 0) stage_way(a, my_v, L.stage[my_rank]);   // threads 0 .. 255: one flagged waypoint each
             __syncthreads();
             return cnt;
         };
         float lo[4];
         {
             f2 acc0 = pk_splat(0.f), acc1 = pk_splat(0.f);
+            auto add_way = [&](const StagedWay& r) {
+                float om[4];
+                load_occ<4, OCC>(a.occ, a.occw, r.v, base, om);
+                const f2 p0 = vis_p_pk(r, k, f2{x[0], x[1]}, f2{y[0], y[1]}, f2{z[0], z[1]}) * f2{om[0], om[1]};
+                const f2 p1 = vis_p_pk(r, k, f2{x[2], x[3]}, f2{y[2], y[3]}, f2{z[2], z[3]}) * f2{om[2], om[3]};
+                // a degenerate waypoint (staged with 1/M = NaN) makes every log-odds NaN, whatever med3 does with one; else + 0
+                const f2 poison = pk_splat(r.invM != r.invM ? __builtin_nanf("") : 0.f);
+                acc0 = acc0 + (log_odds_pk(k, r.a, r.invM, p0) + poison);
+                acc1 = acc1 + (log_odds_pk(k, r.a, r.invM, p1) + poison);
+            };
             int rank0 = 0;
-            for (int wc = w_lo; wc < w_hi; wc += TO_SP_CW) {
-                const int cnt = stage_chunk(wc);
-                for (int e = ((wave - rank0) & (TO_SP_WAVES - 1)); e < cnt; e += TO_SP_WAVES) {   // rank0 + e == wave (mod 16)
-                    const StagedWay& r = L.stage[e];
-                    float om[4];
-                    load_occ<4, OCC>(a.occ, a.occw, r.v, base, om);
-                    const f2 p0 = vis_p_pk(r, k, f2{x[0], x[1]}, f2{y[0], y[1]}, f2{z[0], z[1]}) * f2{om[0], om[1]};
-                    const f2 p1 = vis_p_pk(r, k, f2{x[2], x[3]}, f2{y[2], y[3]}, f2{z[2], z[3]}) * f2{om[2], om[3]};
-                    // a degenerate waypoint (staged with 1/M = NaN) makes every log-odds NaN, whatever med3 does with one; else + 0
-                    const f2 poison = pk_splat(r.invM != r.invM ? __builtin_nanf("") : 0.f);
-                    acc0 = acc0 + (log_odds_pk(k, r.a, r.invM, p0) + poison);
-                    acc1 = acc1 + (log_odds_pk(k, r.a, r.invM, p1) + poison);
+            if (direct) {   // the flagged waypoints in ascending order, rank r to wave r & 15 — the order of the chunked walk below
+                for (int w = w_lo; w < w_hi; ++w) {
+                    unsigned long long bits = flagged(w);
+                    while (bits) {
+                        const int v = w * 64 + __builtin_ctzll(bits);
+                        bits &= bits - 1ull;
+                        if (((rank0++) & (TO_SP_WAVES - 1)) == wave) add_way(L.stage[v - v_lo]);
+                    }
                 }
+            }
+            for (int wc = w_lo; wc < w_hi && !direct; wc += TO_SP_CW) {
+                const int cnt = stage_chunk(wc);
+                for (int e = ((wave - rank0) & (TO_SP_WAVES - 1)); e < cnt; e += TO_SP_WAVES) add_way(L.stage[e]);   // rank0 + e == wave (mod 16)
                 rank0 += cnt;
                 if (wc + TO_SP_CW < w_hi) __syncthreads();   // the stage is rewritten by the next chunk
             }
