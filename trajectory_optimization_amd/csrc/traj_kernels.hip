@@ -1242,6 +1242,10 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
     // the waypoint's flag words first (one parallel load), then each group's bit of every word
     __shared__ unsigned long long sfv[1024];
     __shared__ double stie4[2][4][13];
+    constexpr int FIN_ROWS = 256;
+    __shared__ int snzw[1024];
+    __shared__ int snz_n;
+    __shared__ float svals[THREADS == 1024 ? FIN_ROWS : 1][16];
     const int* tp = reinterpret_cast<const int*>(ties + v);
     // ---- argmin / argmax sets: waves 0..3 take a quarter (64 points) of every recorded slot each ----
     auto tie_sets = [&]() {
@@ -1290,8 +1294,49 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
         // 1024 (group, column) items on 768 threads, a third of them two — into the same 64 x 16 group sums, each in ascending slot order.
         for (int j = t; j < fv_words; j += THREADS) sfv[j] = fv[(int64_t)v * fv_words + j];
         __syncthreads();   // the flag words and the sorted tie slots
+        // The flagged slots' rows of partials: with up to FIN_ROWS of them (one word chunk of flag bits) every row is requested at
+        // once — row j of the ascending list to svals[j] — and the ordered sums below read LDS; a thread that loaded its group's
+        // rows one after the other paid a memory round trip per row (4.6 of the kernel's 8 us at three or four rows per group).
+        int pre = 0, nflag = 0;   // lane = word: flagged slots in the words before it; all of them
+        unsigned long long myword = 0ull, nz = 0ull;   // lane = word: its flag bits; the words that have any
+        if (fv_words <= 64) {
+            const int lane = t & 63;
+            myword = lane < fv_words ? sfv[lane] : 0ull;
+            nz = __ballot(myword != 0ull);
+            const int c = __popcll(myword);
+            int incl = c;
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                const int up = __shfl_up(incl, sh);
+                if (lane >= sh) incl += up;
+            }
+            pre = incl - c;
+            nflag = __shfl(incl, 63);
+        }
+        const bool rows_in_lds = fv_words <= 64 && nflag <= FIN_ROWS;   // block-uniform
         if (t < 256) {
             tie_sets();
+        } else if (rows_in_lds) {
+            // waves 4..15: thread i takes column i % 16 of row i / 16 of the ascending list (then i + 768, ...): every load of the
+            // block is in flight at once
+            const int lane = t & 63;
+            for (int i0 = (t - 256) & ~63; i0 < nflag * 16; i0 += THREADS - 256) {   // wave-uniform: the ballots below want every lane
+                const int i = i0 + lane;
+                const bool valid = i < nflag * 16;
+                const int j = valid ? i >> 4 : nflag - 1, kcol = i & 15;
+                // row j: the word whose prefix is the last one <= j, then its (j - prefix)-th set bit.  Four rows to a wave: four
+                // ballots (the row is wave-uniform per quarter: ask per quarter)
+                int w = 0;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int jq = __shfl(j, qd * 16);
+                    const int wq = __popcll(__ballot(lane < fv_words && pre <= jq)) - 1;   // pre[0] = 0 <= jq
+                    if ((lane >> 4) == qd) w = wq;
+                }
+                unsigned long long w2 = sfv[w];
+                for (int r = j - __shfl(pre, w); r > 0; --r) w2 &= w2 - 1ull;
+                if (valid) svals[j][kcol] = bpart[((int64_t)v * nslots + (w * 64 + __builtin_ctzll(w2))) * 16 + kcol];
+            }
         } else {
             const int i0 = t - 256, i1 = i0 < 256 ? 768 + i0 : -1;
             const int g0 = i0 >> 4, k0 = i0 & 15, g1 = i1 >> 4, k1 = i1 & 15;
@@ -1305,6 +1350,18 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
             sgrp[g0][k0] = acc0;
             if (i1 >= 0) sgrp[g1][k1] = acc1;
         }
+        if (rows_in_lds) {
+            __syncthreads();   // the rows
+            // thread (group g, column kq): its group's rows in ascending slot order, as before, from LDS
+            double acc0 = 0.0;
+            for (unsigned long long m = nz; m; m &= m - 1ull) {   // the words that hold a flag, in ascending order (a few): a walk over all
+                const int w = __builtin_ctzll(m);                // words is a chain of as many LDS round trips
+                const unsigned long long word = (unsigned long long)__shfl((long long)myword, w);
+                const int pw = __shfl(pre, w);                   // (every lane takes part: m is the same for all)
+                if ((word >> g) & 1ull) acc0 += (double)svals[pw + __popcll(word & ((1ull << g) - 1ull))][kq];
+            }
+            sgrp[g][kq] = acc0;
+        }
     } else {
         double acc[PER];
 #pragma unroll
@@ -1314,9 +1371,22 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
             __syncthreads();
             for (int j = t; j < nw; j += THREADS) sfv[j] = fv[(int64_t)v * fv_words + w0 + j];
             __syncthreads();
-            for (int w = 0; w < nw; ++w) {
+            // the words that hold a flag, in ascending order (a few of many: a walk over all of them is a chain of as many LDS round trips)
+            if (t < 64) {
+                int cnt = 0;
+                for (int c0 = 0; c0 < nw; c0 += 64) {
+                    const bool has = c0 + t < nw && sfv[c0 + t] != 0ull;
+                    const unsigned long long m = __ballot(has);
+                    if (has) snzw[cnt + __popcll(m & ((1ull << t) - 1ull))] = c0 + t;
+                    cnt += __popcll(m);
+                }
+                if (t == 0) snz_n = cnt;
+            }
+            __syncthreads();
+            const int nnz = snz_n;
+            for (int i = 0; i < nnz; ++i) {
+                const int w = snzw[i];
                 const unsigned long long word = sfv[w];
-                if (word == 0ull) continue;
 #pragma unroll
                 for (int j = 0; j < PER; ++j)
                     if ((word >> (g + NG * j)) & 1ull) acc[j] += (double)bpart[((int64_t)v * nslots + ((w0 + w) * 64 + g + NG * j)) * 16 + kq];
