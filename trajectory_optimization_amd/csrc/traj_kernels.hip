@@ -689,7 +689,6 @@ struct SparseLds {
     float4 spart[TO_SP_WAVES][64];
     int any[TO_SP_WAVES];
     int pbase;
-    int wtot, wslot;   // sparse_walk: set bits in the chunk of candidate words, the slot the block takes next
 };
 
 __device__ __forceinline__ f2 log_odds_pk(const EvalK& k, float a, float invM, f2 p) {
@@ -725,7 +724,7 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
     load_points<4>(a.cv.soa, a.cv.npad, base, x, y, z);
     // where the slot's points live in the caller's order (rewards): requested now, wanted after the forward
     int4 o4 = make_int4(0, 0, 0, 0);
-    if (MODE == TO_SP_FUSED && wave < 4) o4.x = a.cv.perm[base + wave];   // waves 0..3: point `wave` of every lane
+    if (MODE == TO_SP_FUSED && wave == 0) o4 = *reinterpret_cast<const int4*>(a.cv.perm + base);
 
     const int v_lo = a.toff ? a.toff[tr] * a.C : 0, v_hi = a.toff ? a.toff[tr + 1] * a.C : a.V;
     const int w_lo = v_lo >> 6, w_hi = min(a.vwords, (v_hi + 63) >> 6);
@@ -829,16 +828,17 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
             if (wave == 0) *reinterpret_cast<float4*>(a.lo_sum + (int64_t)tr * a.cv.npad + base) = s;
         }
 
-        // ---- rewards of the slot's points: waves 0..3 take one of a lane's four points each (every wave holds the sums) ----
-        if (MODE == TO_SP_FUSED && wave < 4) {
+        // ---- rewards of the slot's points (wave 0) ----
+        if (MODE == TO_SP_FUSED && wave == 0) {
+            const int o[4] = {o4.x, o4.y, o4.z, o4.w};
             long long fsum = 0;
             bool fnan = false;
-            {
-                const float l = wave == 0 ? lo[0] : wave == 1 ? lo[1] : wave == 2 ? lo[2] : lo[3];
-                float rw = to_rcp(1.0f + to_exp(-l));   // == k_traj_reward's value of rewards[perm[i]]
-                if (l != l) rw = l;
-                if (base + wave < a.cv.n) {               // pads are not points
-                    if (!a.prefilled || l != 0.f) a.rewards[(int64_t)tr * a.cv.n + o4.x] = rw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float rw = to_rcp(1.0f + to_exp(-lo[j]));   // == k_traj_reward's value of rewards[perm[i]]
+                if (lo[j] != lo[j]) rw = lo[j];
+                if (base + j < a.cv.n) {                      // pads are not points
+                    if (!a.prefilled || lo[j] != 0.f) a.rewards[(int64_t)tr * a.cv.n + o[j]] = rw;
                     if (rw != rw) fnan = true;
                     else fsum += reward_fixed(rw, a.shift) - (1ll << (a.shift - 1));
                 }
@@ -846,9 +846,8 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
             for (int s = 32; s > 0; s >>= 1) fsum += __shfl_xor(fsum, s);
             fnan = __any(fnan);
             if (lane == 0) {
-                const int line = (acc_line + wave) & 7;   // (four waves add for a slot: to four lines)
-                if (fsum != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&a.acc[tr].a[line].sum), (unsigned long long)fsum);
-                if (fnan) atomicOr(&a.acc[tr].a[line].nan, 1u);
+                if (fsum != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&a.acc[tr].a[acc_line].sum), (unsigned long long)fsum);
+                if (fnan) atomicOr(&a.acc[tr].a[acc_line].nan, 1u);
             }
         }
         if (t == TO_SP_THREADS - 1) L.pbase = pbase;   // (a device-scope atomic's answer takes microseconds: first read here)
@@ -884,43 +883,30 @@ __device__ __forceinline__ void write_minmax(const SparseArgs& a) {
 // popcount prefix, 64 words at a time (one 16-wave block is resident per CU at this kernel's register count).
 template <int MODE, bool OCC>
 __device__ __forceinline__ void sparse_walk(const SparseArgs& a, int b, int nb, SparseLds& L) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int tr = b % a.n_traj, S = nb / a.n_traj;
     const unsigned long long* bits = a.cbits + (int64_t)tr * a.fv_words * TO_CBIT_STRIDE;
     int carry = 0, next = b / a.n_traj;
     for (int c0 = 0; c0 < a.fv_words; c0 += 64) {
-        // wave 0 reads the 64 words (one to a line: sixteen waves asking for them cost the block a microsecond) and names the slots
-        unsigned long long word = 0ull;
-        int pc = 0, incl = 0;
-        if (wave == 0) {
-            word = (c0 + lane < a.fv_words) ? bits[(int64_t)(c0 + lane) * TO_CBIT_STRIDE] : 0ull;
-            pc = __popcll(word);
-            incl = pc;
+        const unsigned long long word = (c0 + lane < a.fv_words) ? bits[(int64_t)(c0 + lane) * TO_CBIT_STRIDE] : 0ull;
+        const int pc = __popcll(word);
+        int incl = pc;
 #pragma unroll
-            for (int sh = 1; sh < 64; sh <<= 1) {
-                const int up = __shfl_up(incl, sh);
-                if (lane >= sh) incl += up;
-            }
-            if (lane == 63) L.wtot = incl;
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const int up = __shfl_up(incl, sh);
+            if (lane >= sh) incl += up;
         }
-        __syncthreads();
-        const int tot = L.wtot;
-        while (next < carry + tot) {   // block-uniform
-            if (wave == 0) {
-                const int rnk = next - carry;
-                const int f = __builtin_ctzll(__ballot(incl > rnk));
-                const int rr = rnk - __shfl(incl - pc, f);
-                const unsigned long long wf = uniform_u64((unsigned long long)__shfl((long long)word, f));
-                const bool hit = ((wf >> lane) & 1ull) && __popcll(wf & ((1ull << lane) - 1ull)) == rr;
-                const int slot = (c0 + f) * 64 + __builtin_ctzll(__ballot(hit));
-                if (lane == 0) L.wslot = slot;
-            }
-            __syncthreads();
-            sparse_slot<MODE, OCC>(a, L.wslot, tr, b & 7, L);   // ends with a barrier: wslot is free again
+        const int tot = __shfl(incl, 63);
+        while (next < carry + tot) {   // wave- and block-uniform
+            const int rnk = next - carry;
+            const int f = __builtin_ctzll(__ballot(incl > rnk));
+            const int rr = rnk - __shfl(incl - pc, f);
+            const unsigned long long wf = uniform_u64((unsigned long long)__shfl((long long)word, f));
+            const bool hit = ((wf >> lane) & 1ull) && __popcll(wf & ((1ull << lane) - 1ull)) == rr;
+            sparse_slot<MODE, OCC>(a, (c0 + f) * 64 + __builtin_ctzll(__ballot(hit)), tr, b & 7, L);
             next += S;
         }
         carry += tot;
-        __syncthreads();   // wtot is rewritten by the next chunk
     }
 }
 
