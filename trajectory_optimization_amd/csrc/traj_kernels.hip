@@ -521,10 +521,12 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 // are combined in LDS and leave the block as ONE atomic per word: thousands of device-scope atomics on a few lines, one per
 // pair, were what the kernel's time consisted of.  A pair that is not listed is not written: k_traj_sparse takes (min, max) =
 // (the proven 0, -inf: never flagged) for it from the `live` bit.
+#define TO_CULL_LIST 2048
 struct CullLds {
     unsigned long long cand[TO_PROBE_MAXFW];   // the candidates this block finds
     unsigned long long row[TO_PROBE_MAXFW];    // the waypoint's reachable slots (its row of `live`)
     int pre[TO_PROBE_MAXFW];                   // set bits before each word
+    int list[TO_CULL_LIST];                    // the reachable slots in ascending order, while they fit
     int mx[TO_SP_WAVES], mn[TO_SP_WAVES];
     int total;
 };
@@ -577,11 +579,19 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
     }
     __syncthreads();
     const int n = L.total;
+    const bool listed = n <= TO_CULL_LIST;   // block-uniform: the set bits written out once, a pair is then one LDS read
+    if (listed) {
+        for (int w = wave; w < fv_words; w += TO_SP_WAVES) {
+            const unsigned long long word = L.row[w];
+            if ((word >> lane) & 1ull) L.list[L.pre[w] + __popcll(word & ((1ull << lane) - 1ull))] = w * 64 + lane;
+        }
+        __syncthreads();
+    }
     const int wr = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * TO_SP_WAVES) + wave), WR = (int)gridDim.x * TO_SP_WAVES;
     const WayRec& r = rec[v];
     int bmx = __builtin_bit_cast(int, r.L), bmn = __builtin_bit_cast(int, r.U);   // p >= +0: the bit patterns order like the values
     if (wr < n) {
-        int slot = cull_select(L, fv_words, wr, lane);
+        int slot = listed ? L.list[wr] : cull_select(L, fv_words, wr, lane);
         float x[P], y[P], z[P];
         load_points<P>(cv.soa, cv.npad, (int64_t)slot * TO_SLOT + lane * P, x, y, z);
         for (int j = wr; j < n; j += WR) {
@@ -590,7 +600,7 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
             float nx[P], ny[P], nz[P];
             const bool more = j + WR < n;
             if (more) {   // the next pair's points are in flight while this pair is evaluated
-                slot = cull_select(L, fv_words, j + WR, lane);
+                slot = listed ? L.list[j + WR] : cull_select(L, fv_words, j + WR, lane);
                 load_points<P>(cv.soa, cv.npad, (int64_t)slot * TO_SLOT + lane * P, nx, ny, nz);
             }
             float mn, mx, om[P];
@@ -731,7 +741,9 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
     // A trajectory of up to TO_SP_STAGE virtual waypoints is staged whole, entry v - v_lo, with the block's first loads: which
     // waypoints are flagged is known two dependent loads later, and what is staged does not depend on it.
     const bool direct = v_hi - v_lo <= TO_SP_STAGE;   // block-uniform
-    if (direct && t < v_hi - v_lo) stage_way(a, v_lo + t, L.stage[t]);
+    const bool stager = direct && t < v_hi - v_lo;
+    StagedWay sw;
+    if (stager) stage_way(a, v_lo + t, sw);   // into registers: its loads are in flight beside those of the flags below
     // ---- flags of this slot, one word per 64 waypoints ----
     int mine = 0;
     for (int w = w_lo + wave; w < w_hi; w += TO_SP_WAVES) {
@@ -754,6 +766,7 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
         if (lane == 0) L.sflag[w] = word;
         mine += __popcll(word);
     }
+    if (stager) L.stage[t] = sw;
     if (lane == 0) L.any[wave] = mine;
     __syncthreads();
     int npairs = 0;
@@ -800,14 +813,14 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
                 acc1 = acc1 + (log_odds_pk(k, r.a, r.invM, p1) + poison);
             };
             int rank0 = 0;
-            if (direct) {   // the flagged waypoints in ascending order, rank r to wave r & 15 — the order of the chunked walk below
-                for (int w = w_lo; w < w_hi; ++w) {
+            if (direct) {   // the flagged waypoints in ascending order, rank r to wave r & 15 — the order of the chunked walk below.
+                // A wave goes straight to its ranks (a walk over every flagged bit by every wave was 2 us of a dense cloud's slot)
+                for (int kk = wave; kk < npairs; kk += TO_SP_WAVES) {
+                    int r = kk, w = w_lo;
                     unsigned long long bits = flagged(w);
-                    while (bits) {
-                        const int v = w * 64 + __builtin_ctzll(bits);
-                        bits &= bits - 1ull;
-                        if (((rank0++) & (TO_SP_WAVES - 1)) == wave) add_way(L.stage[v - v_lo]);
-                    }
+                    while (r >= __popcll(bits)) { r -= __popcll(bits); bits = flagged(++w); }   // at most five words
+                    const bool hit = ((bits >> lane) & 1ull) && __popcll(bits & ((1ull << lane) - 1ull)) == r;
+                    add_way(L.stage[w * 64 + __builtin_ctzll(__ballot(hit)) - v_lo]);
                 }
             }
             for (int wc = w_lo; wc < w_hi && !direct; wc += TO_SP_CW) {
@@ -1242,7 +1255,7 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
     // the waypoint's flag words first (one parallel load), then each group's bit of every word
     __shared__ unsigned long long sfv[1024];
     __shared__ double stie4[2][4][13];
-    constexpr int FIN_ROWS = 256;
+    constexpr int FIN_ROWS = 64;
     __shared__ int snzw[1024];
     __shared__ int snz_n;
     __shared__ float svals[THREADS == 1024 ? FIN_ROWS : 1][16];
@@ -1313,6 +1326,8 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
             pre = incl - c;
             nflag = __shfl(incl, 63);
         }
+        // (many rows — a dense indoor cloud flags a few hundred slots per waypoint — are cheaper added from memory by their own
+        // (group, column) threads: every thread has several in flight)
         const bool rows_in_lds = fv_words <= 64 && nflag <= FIN_ROWS;   // block-uniform
         if (t < 256) {
             tie_sets();
@@ -1341,11 +1356,20 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
             const int i0 = t - 256, i1 = i0 < 256 ? 768 + i0 : -1;
             const int g0 = i0 >> 4, k0 = i0 & 15, g1 = i1 >> 4, k1 = i1 & 15;
             double acc0 = 0.0, acc1 = 0.0;
-            for (int w = 0; w < fv_words; ++w) {
-                const unsigned long long word = sfv[w];
-                if (word == 0ull) continue;
+            auto add_word = [&](int w, unsigned long long word) {
                 if ((word >> g0) & 1ull) acc0 += (double)bpart[((int64_t)v * nslots + (w * 64 + g0)) * 16 + k0];
                 if (i1 >= 0 && ((word >> g1) & 1ull)) acc1 += (double)bpart[((int64_t)v * nslots + (w * 64 + g1)) * 16 + k1];
+            };
+            if (fv_words <= 64) {   // the words that hold a flag, from the lanes that hold them (no LDS round trip per word)
+                for (unsigned long long m = nz; m; m &= m - 1ull) {
+                    const int w = __builtin_ctzll(m);
+                    add_word(w, (unsigned long long)__shfl((long long)myword, w));
+                }
+            } else {
+                for (int w = 0; w < fv_words; ++w) {
+                    const unsigned long long word = sfv[w];
+                    if (word != 0ull) add_word(w, word);
+                }
             }
             sgrp[g0][k0] = acc0;
             if (i1 >= 0) sgrp[g1][k1] = acc1;
