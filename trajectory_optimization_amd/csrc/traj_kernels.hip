@@ -64,6 +64,32 @@
 #define TO_SP_MAXW 1024        // flag words of one slot held in LDS by k_traj_sparse: at most 65 536 virtual waypoints
 
 // ---------------------------------------------------------------------------------------------
+// Diagnostic build (-DTOHIP_STAMPS, tools/kernel_timeline.py; never the shipped library): thread 0 of every block notes the
+// 100 MHz real-time counter at a few places of the small kernels — where a 7-12 us kernel of dependent memory accesses spends its
+// time cannot be read off a profile (k_traj_finish's 4.3 us walk over its flag words was found this way).
+#ifdef TOHIP_STAMPS
+#define TO_STAMP_BLOCKS 1024
+#define TO_STAMP_N 12
+enum { TO_STAMP_PROBE = 0, TO_STAMP_CULL, TO_STAMP_SPARSE, TO_STAMP_PAIRS, TO_STAMP_FINISH, TO_STAMP_KERNELS };
+__device__ unsigned long long g_stamps[TO_STAMP_KERNELS][TO_STAMP_BLOCKS][TO_STAMP_N];
+#define TO_STAMP(kern, i)                                                                                            \
+    do {                                                                                                             \
+        const unsigned lb_ = blockIdx.y * gridDim.x + blockIdx.x;                                                    \
+        if (threadIdx.x == 0 && lb_ < TO_STAMP_BLOCKS) g_stamps[kern][lb_][i] = __builtin_amdgcn_s_memrealtime();    \
+    } while (0)
+extern "C" int tohip_stamps_read(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * TO_STAMP_KERNELS * TO_STAMP_BLOCKS * TO_STAMP_N);
+}
+extern "C" int tohip_stamps_clear() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * TO_STAMP_KERNELS * TO_STAMP_BLOCKS * TO_STAMP_N);
+}
+#else
+#define TO_STAMP(kern, i) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // workspace control block, per trajectory: the sum of the rewards as integers.  Every reward enters as rn(r * 2^shift)
 // (exact for r in [1/2, 1): a reward is sigmoid of a non-negative log-odds sum), so the total is the same whatever kernel,
 // block or order added it up: scalars are bitwise reproducible across the fused and the split step.
@@ -281,6 +307,7 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
     __shared__ float smx[TO_PROBE_THREADS / 64], smn[TO_PROBE_THREADS / 64];
     __shared__ float scull[4];
     const int v = blockIdx.x, t = threadIdx.x;
+    TO_STAMP(TO_STAMP_PROBE, 0);
     for (int j = t; j < fv_words; j += TO_PROBE_THREADS) fv[(int64_t)v * fv_words + j] = 0ull;
     for (int j = v * TO_PROBE_THREADS + t; j < ncbits; j += gridDim.x * TO_PROBE_THREADS) cbits[(int64_t)j * TO_CBIT_STRIDE] = 0ull;   // the candidate (slot, trajectory) bits
     if (v == 0 && t == 0) ctr[0] = 0;   // the pair list's length
@@ -313,6 +340,7 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
     __shared__ WayRec srec;   // the block's record: built by thread 0, read by everybody from LDS (not back from global memory)
     if (t == 0) { prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, &srec - v, cold, traj_off, n_traj, wp_stride); rec[v] = srec; }
     __syncthreads();
+    TO_STAMP(TO_STAMP_PROBE, 1);   // record built, samples requested
     const WayRec r = srec;
     float mx = 0.f, mn = INFINITY;
     for (int rd = 0; rd < kRounds; ++rd) {
@@ -337,6 +365,7 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
     for (int s = 32; s > 0; s >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, s)); mn = fminf(mn, __shfl_xor(mn, s)); }
     if ((t & 63) == 0) { smx[t >> 6] = mx; smn[t >> 6] = mn; }
     __syncthreads();
+    TO_STAMP(TO_STAMP_PROBE, 2);   // sample evaluated and reduced
     if (t == 0) {
         for (int w = 1; w < TO_PROBE_THREADS / 64; ++w) { mx = fmaxf(mx, smx[w]); mn = fminf(mn, smn[w]); }
         if (!(mn <= mx)) { mx = 0.f; mn = INFINITY; }   // a NaN among the sampled p (fmax/fmin drop it): no usable bound
@@ -357,6 +386,7 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
         ties[v].nmax = 0;
         ties[v].nmin = 0;
     }
+    TO_STAMP(TO_STAMP_PROBE, 3);   // bounds, cull distance, resets
     if (!pc.on) return;
     // CULL: which 256-point slots can waypoint v reach at all — row v of `live`, a bit per slot: the culled pass 1 deals the set
     // bits to its waves, k_traj_sparse asks them whether a pair was evaluated
@@ -381,6 +411,7 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
         for (int i = 0; i < kPre; ++i)
             if (w0 + i * kWaves < fv_words) test_word(w0 + i * kWaves, tb[i]);
     }
+    TO_STAMP(TO_STAMP_PROBE, 4);   // reachable slots
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -557,11 +588,13 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
     __shared__ CullLds L;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int v = blockIdx.y;
+    TO_STAMP(TO_STAMP_CULL, 0);
     for (int w = t; w < fv_words; w += TO_SP_THREADS) { L.row[w] = live[(int64_t)v * fv_words + w]; L.cand[w] = 0ull; }
     // the outputs' start values (the dense pass 1 sets them itself): stores nobody here waits for
     for (int64_t i = (((int64_t)v * gridDim.x + blockIdx.x) * TO_SP_THREADS + t) * 4; i < oi.npad; i += (int64_t)gridDim.y * gridDim.x * TO_SP_THREADS * 4)
         init_outputs(i, oi);
     __syncthreads();
+    TO_STAMP(TO_STAMP_CULL, 1);   // the waypoint's row of reachable slots is in LDS
     if (t < 64) {   // exclusive prefix of the words' popcounts, 64 words at a time
         int carry = 0;
         for (int w0 = 0; w0 < fv_words; w0 += 64) {
@@ -587,6 +620,7 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
         }
         __syncthreads();
     }
+    TO_STAMP(TO_STAMP_CULL, 2);   // prefix and list
     const int wr = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * TO_SP_WAVES) + wave), WR = (int)gridDim.x * TO_SP_WAVES;
     const WayRec& r = rec[v];
     int bmx = __builtin_bit_cast(int, r.L), bmn = __builtin_bit_cast(int, r.U);   // p >= +0: the bit patterns order like the values
@@ -621,8 +655,10 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
             }
         }
     }
+    TO_STAMP(TO_STAMP_CULL, 3);   // wave 0's pairs evaluated
     if (lane == 63) { L.mx[wave] = bmx; L.mn[wave] = bmn; }
     __syncthreads();
+    TO_STAMP(TO_STAMP_CULL, 4);   // every wave's
     if (t == 0) {
         for (int w = 1; w < TO_SP_WAVES; ++w) { bmx = max(bmx, L.mx[w]); bmn = min(bmn, L.mn[w]); }
         bmx = max(bmx, L.mx[0]); bmn = min(bmn, L.mn[0]);
@@ -633,6 +669,7 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
         const unsigned long long word = L.cand[w];
         if (word) atomicOr(cbit_word(cbits, fv_words, r.seg, w), word);
     }
+    TO_STAMP(TO_STAMP_CULL, 5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -728,6 +765,7 @@ __device__ __forceinline__ void stage_way(const SparseArgs& a, int v, StagedWay&
 template <int MODE, bool OCC>
 __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int tr, int acc_line, SparseLds& L) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    TO_STAMP(TO_STAMP_SPARSE, 1);   // the block's candidate is known
     const EvalK& k = a.k;
     const int64_t base = (int64_t)slot * TO_SLOT + lane * 4;
     float x[4], y[4], z[4];
@@ -769,6 +807,7 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
     if (stager) L.stage[t] = sw;
     if (lane == 0) L.any[wave] = mine;
     __syncthreads();
+    TO_STAMP(TO_STAMP_SPARSE, 2);   // flags, staged records
     int npairs = 0;
 #pragma unroll
     for (int w = 0; w < TO_SP_WAVES; ++w) npairs += L.any[w];
@@ -829,8 +868,10 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
                 rank0 += cnt;
                 if (wc + TO_SP_CW < w_hi) __syncthreads();   // the stage is rewritten by the next chunk
             }
+            TO_STAMP(TO_STAMP_SPARSE, 3);   // wave 0's share of the forward sweep
             L.spart[wave][lane] = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
             __syncthreads();
+            TO_STAMP(TO_STAMP_SPARSE, 4);   // every wave's
             float4 s = L.spart[0][lane];
 #pragma unroll
             for (int w = 1; w < TO_SP_WAVES; ++w) {
@@ -863,8 +904,10 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
                 if (fnan) atomicOr(&a.acc[tr].a[acc_line].nan, 1u);
             }
         }
+        TO_STAMP(TO_STAMP_SPARSE, 5);   // sums, rewards
         if (t == TO_SP_THREADS - 1) L.pbase = pbase;   // (a device-scope atomic's answer takes microseconds: first read here)
         __syncthreads();
+        TO_STAMP(TO_STAMP_SPARSE, 6);   // the pair list's answer
     }
     // the slot's pairs: a position each (the waves' counts, then the wave's words in its order, then the bit's rank)
     {
@@ -926,8 +969,10 @@ __device__ __forceinline__ void sparse_walk(const SparseArgs& a, int b, int nb, 
 template <int MODE, bool OCC>
 __global__ void __launch_bounds__(TO_SP_THREADS) k_traj_sparse(SparseArgs a) {
     __shared__ SparseLds L;
+    TO_STAMP(TO_STAMP_SPARSE, 0);
     if (blockIdx.x == 0) write_minmax(a);
     sparse_walk<MODE, OCC>(a, (int)blockIdx.x, (int)gridDim.x, L);
+    TO_STAMP(TO_STAMP_SPARSE, 7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1019,16 +1064,19 @@ __device__ __forceinline__ void pair_sums(const SparseArgs& a, int slot, int v, 
 template <bool OCC>
 __device__ __forceinline__ void pair_walk(const SparseArgs& a, int b, int nb) {
     const int lane = threadIdx.x & 63;
+    TO_STAMP(TO_STAMP_PAIRS, 0);
     const int gw = __builtin_amdgcn_readfirstlane(b * TO_SP_WAVES + (int)(threadIdx.x >> 6)), GW = nb * TO_SP_WAVES;
     // the wave's first pair is requested with the list's length, not after it (an entry beyond the length is last step's: unused)
     const int64_t cap = (int64_t)a.V * a.nslots;
     int2 next = gw < cap ? a.plist[gw] : make_int2(0, 0);
     const int P = *a.npairs;
+    TO_STAMP(TO_STAMP_PAIRS, 1);   // the list's length and the wave's first pair
     for (int p = gw; p < P; p += GW) {
         const int2 cur = next;
         if (p + GW < P) next = a.plist[p + GW];
         pair_sums<OCC>(a, __builtin_amdgcn_readfirstlane(cur.x), __builtin_amdgcn_readfirstlane(cur.y), lane);
     }
+    TO_STAMP(TO_STAMP_PAIRS, 2);
 }
 
 template <bool OCC>
@@ -1236,6 +1284,7 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
     __shared__ double stie[2][13];   // [0] argmin set, [1] argmax set: 12 sums + count
     __shared__ int srow[2][TO_TIE_CAP];
     const int v = blockIdx.x, t = threadIdx.x, kq = t & 15, g = t >> 4;
+    TO_STAMP(TO_STAMP_FINISH, 0);
     const WayRec& r = rec[v];
     float a, pmax, M, invM;
     load_norm(ext[v], a, pmax, M, invM);
@@ -1307,6 +1356,7 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
         // 1024 (group, column) items on 768 threads, a third of them two — into the same 64 x 16 group sums, each in ascending slot order.
         for (int j = t; j < fv_words; j += THREADS) sfv[j] = fv[(int64_t)v * fv_words + j];
         __syncthreads();   // the flag words and the sorted tie slots
+        TO_STAMP(TO_STAMP_FINISH, 1);
         // The flagged slots' rows of partials: with up to FIN_ROWS of them (one word chunk of flag bits) every row is requested at
         // once — row j of the ascending list to svals[j] — and the ordered sums below read LDS; a thread that loaded its group's
         // rows one after the other paid a memory round trip per row (4.6 of the kernel's 8 us at three or four rows per group).
@@ -1421,7 +1471,9 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
         __syncthreads();   // srow
         if (t < 256) tie_sets();
     }
+    TO_STAMP(TO_STAMP_FINISH, 2);   // wave 0: the tie slots re-evaluated
     __syncthreads();
+    TO_STAMP(TO_STAMP_FINISH, 3);   // every wave: tie slots, rows, group sums
     if (t < 26) {   // ascending slot order inside a quarter, quarters in order: a fixed summation order
         const int set = t / 13, j = t % 13;
         stie[set][j] = ((stie4[set][0][j] + stie4[set][1][j]) + stie4[set][2][j]) + stie4[set][3][j];
@@ -1445,6 +1497,7 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
         stot[t] = q;
     }
     __syncthreads();
+    TO_STAMP(TO_STAMP_FINISH, 4);   // the 64 groups added, the factor dL/d reward
     __shared__ float sgy[12];
     if (t < 12) {
         const double nmin = stie[0][12], nmax = stie[1][12];
@@ -1467,6 +1520,7 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
         __syncthreads();
         if (t == 0) finish_waypoint(v, vgrad, RecRows{rec}, cold, 1, nullptr, nullptr, poses_grad, quats_grad);
     }
+    TO_STAMP(TO_STAMP_FINISH, 5);
 }
 
 // ---------------------------------------------------------------------------------------------
