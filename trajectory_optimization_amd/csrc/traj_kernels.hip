@@ -558,7 +558,7 @@ struct CullLds {
     unsigned long long row[TO_PROBE_MAXFW];    // the waypoint's reachable slots (its row of `live`)
     int pre[TO_PROBE_MAXFW];                   // set bits before each word
     int list[TO_CULL_LIST];                    // the reachable slots in ascending order, while they fit
-    int mx[TO_SP_WAVES], mn[TO_SP_WAVES];
+    int mx[2 * TO_SP_WAVES], mn[2 * TO_SP_WAVES];
     int total;
 };
 
@@ -624,25 +624,46 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
     const int wr = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * TO_SP_WAVES) + wave), WR = (int)gridDim.x * TO_SP_WAVES;
     const WayRec& r = rec[v];
     int bmx = __builtin_bit_cast(int, r.L), bmn = __builtin_bit_cast(int, r.U);   // p >= +0: the bit patterns order like the values
-    if (wr < n) {
-        int slot = listed ? L.list[wr] : cull_select(L, fv_words, wr, lane);
-        float x[P], y[P], z[P];
-        load_points<P>(cv.soa, cv.npad, (int64_t)slot * TO_SLOT + lane * P, x, y, z);
-        for (int j = wr; j < n; j += WR) {
+    // A wave takes TWO reachable slots at a time — lanes 0..31 the one, 32..63 the other, eight points per lane: the dense kernel's
+    // four independent packed chains and half-wave reductions (708 issue cycles for two pairs where one pair alone took 584).
+    const int half = lane >> 5, nunits = (n + 1) >> 1;
+    auto unit_slot = [&](int u) {   // lane's slot of unit u (the second half of a last, odd unit repeats the first: not stored)
+        if (listed) return L.list[min(2 * u + half, n - 1)];
+        const int s0 = cull_select(L, fv_words, 2 * u, lane), s1 = cull_select(L, fv_words, min(2 * u + 1, n - 1), lane);   // (wave-uniform ranks)
+        return half ? s1 : s0;
+    };
+    if (wr < nunits) {
+        constexpr int P8 = TO_PD;
+        int slot = unit_slot(wr);
+        float x[P8], y[P8], z[P8];
+        load_points<P8>(cv.soa, cv.npad, (int64_t)slot * TO_SLOT + (lane & 31) * P8, x, y, z);
+        f2 eps2 = pk_splat(k.eps), l2e2 = pk_splat(k.l2e_eps), scd2 = pk_splat(k.scd);
+        for (int u = wr; u < nunits; u += WR) {
             const int cur = slot;
-            const int64_t base = (int64_t)cur * TO_SLOT + lane * P;
-            float nx[P], ny[P], nz[P];
-            const bool more = j + WR < n;
-            if (more) {   // the next pair's points are in flight while this pair is evaluated
-                slot = listed ? L.list[j + WR] : cull_select(L, fv_words, j + WR, lane);
-                load_points<P>(cv.soa, cv.npad, (int64_t)slot * TO_SLOT + lane * P, nx, ny, nz);
+            const bool valid = 2 * u + half < n;
+            const int64_t base = (int64_t)cur * TO_SLOT + (lane & 31) * P8;
+            float nx[P8], ny[P8], nz[P8];
+            const bool more = u + WR < nunits;
+            if (more) {   // the next unit's points are in flight while this one is evaluated
+                slot = unit_slot(u + WR);
+                load_points<P8>(cv.soa, cv.npad, (int64_t)slot * TO_SLOT + (lane & 31) * P8, nx, ny, nz);
             }
-            float mn, mx, om[P];
-            load_occ<P, OCC>(occ, occw, v, base, om);
-            pass1_eval(k, r, x, y, z, om, mn, mx);
-            if (lane == 63) {
+            float om[P8];
+            load_occ<P8, OCC>(occ, occw, v, base, om);
+            f2 p[P8 / 2];
+#pragma unroll
+            for (int i = 0; i < P8; i += 2)
+                p[i / 2] = vis_p_pk(r, k, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, eps2, l2e2, scd2) * f2{om[i], om[i + 1]};
+            const float m1 = fmaxf(fmaxf(p[0].x, p[0].y), p[1].x), m2 = fmaxf(fmaxf(p[1].y, p[2].x), p[2].y);
+            float mx = half_max31_nn_fused(fmaxf(m2, fmaxf(fmaxf(p[3].x, p[3].y), m1)));
+            float mn = 0.f;   // wanted only while the probe has not exhibited a zero (see the dense kernel)
+            if (__builtin_bit_cast(int, r.U) != 0) {
+                mn = fminf(fminf(fminf(p[0].x, p[0].y), fminf(p[1].x, p[1].y)), fminf(fminf(p[2].x, p[2].y), fminf(p[3].x, p[3].y)));
+                mn = half_min31_nn_fused(mn);
+            }
+            if ((lane & 31) == 31 && valid) {
                 part[(int64_t)cur * V + v] = make_float2(mn, mx);
-                // what fold_extrema does with atomics, on the wave's own running values
+                // what fold_extrema does with atomics, on the half-wave's own running values
                 if (!(mx < r.Lh)) {
                     atomicOr(&L.cand[cur >> 6], 1ull << (cur & 63));
                     bmx = max(bmx, __builtin_bit_cast(int, mx));
@@ -651,17 +672,16 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
             }
             if (more) {
 #pragma unroll
-                for (int i = 0; i < P; ++i) { x[i] = nx[i]; y[i] = ny[i]; z[i] = nz[i]; }
+                for (int i = 0; i < P8; ++i) { x[i] = nx[i]; y[i] = ny[i]; z[i] = nz[i]; }
             }
         }
     }
     TO_STAMP(TO_STAMP_CULL, 3);   // wave 0's pairs evaluated
-    if (lane == 63) { L.mx[wave] = bmx; L.mn[wave] = bmn; }
+    if ((lane & 31) == 31) { L.mx[2 * wave + half] = bmx; L.mn[2 * wave + half] = bmn; }
     __syncthreads();
     TO_STAMP(TO_STAMP_CULL, 4);   // every wave's
     if (t == 0) {
-        for (int w = 1; w < TO_SP_WAVES; ++w) { bmx = max(bmx, L.mx[w]); bmn = min(bmn, L.mn[w]); }
-        bmx = max(bmx, L.mx[0]); bmn = min(bmn, L.mn[0]);
+        for (int w = 0; w < 2 * TO_SP_WAVES; ++w) { bmx = max(bmx, L.mx[w]); bmn = min(bmn, L.mn[w]); }
         if (bmx > __builtin_bit_cast(int, r.L)) atomicMax(&ext[v].mx, bmx);
         if (bmn < __builtin_bit_cast(int, r.U)) atomicMin(&ext[v].mn, bmn);
     }
