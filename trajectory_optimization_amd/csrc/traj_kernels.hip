@@ -419,7 +419,7 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
 // waypoint's running extrema.  Only a wave whose value improves on the probe's (U, L) issues an atomic: the number of
 // points above a 4 096-sample maximum is ~n/4096, in a few dozen slots per waypoint.
 
-#define TO_P 4   // points per lane of the culled kernel: a wave is one slot (and one bounding-sphere tile)
+#define TO_P 4   // points per lane where a wave is one slot (the sparse and the pair kernel; the plan's point blocks)
 
 // What the lane holding a slot's (min, max) of waypoint v does with them besides storing them: a slot whose maximum reaches Lh is
 // a candidate (-> returns true; the common case is ONE compare), and only a candidate can improve on L; the minimum needs a look
@@ -447,15 +447,6 @@ __device__ __forceinline__ unsigned long long* cbit_word(unsigned long long* cbi
 }
 __device__ __forceinline__ void mark_candidate(unsigned long long* __restrict__ cbits, int fv_words, int slot, int seg) {
     atomicOr(cbit_word(cbits, fv_words, seg, slot >> 6), 1ull << (slot & 63));
-}
-
-__device__ __forceinline__ void pass1_eval(const EvalK& k, const WayRec& r, const float (&x)[TO_P], const float (&y)[TO_P],
-                                           const float (&z)[TO_P], const float (&om)[TO_P], float& mn, float& mx) {
-    const f2 p0 = vis_p_pk(r, k, f2{x[0], x[1]}, f2{y[0], y[1]}, f2{z[0], z[1]}) * f2{om[0], om[1]};
-    const f2 p1 = vis_p_pk(r, k, f2{x[2], x[3]}, f2{y[2], y[3]}, f2{z[2], z[3]}) * f2{om[2], om[3]};
-    mx = wave_max63_nn_fused(fmaxf(fmaxf(p0.x, p0.y), fmaxf(p1.x, p1.y)));
-    mn = 0.f;   // wanted only while the probe has not exhibited a zero (see the dense kernel)
-    if (__builtin_bit_cast(int, r.U) != 0) mn = wave_min63_nn_fused(fminf(fminf(p0.x, p0.y), fminf(p1.x, p1.y)));   // p >= +0 always
 }
 
 // DENSE: persistent blocks, as many as the chip holds at once (host: occupancy x CUs).  A lane owns EIGHT consecutive points
@@ -584,7 +575,6 @@ __global__ void __launch_bounds__(TO_SP_THREADS)
 k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, float2* __restrict__ part, Extrema* __restrict__ ext,
                   unsigned long long* __restrict__ cbits, int fv_words, const unsigned long long* __restrict__ live,
                   const uint32_t* __restrict__ occ, int64_t occw, OutInit oi) {
-    constexpr int P = TO_P;
     __shared__ CullLds L;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int v = blockIdx.y;
