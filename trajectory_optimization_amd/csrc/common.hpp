@@ -633,25 +633,11 @@ __device__ __forceinline__ float row_max16_nn(float f) {
     return __builtin_bit_cast(float, v);
 }
 
-// Wave64 min / max of non-negative floats, valid in lane 63: the four in-row steps above, then the two cross-row steps as
-// single instructions (v_max_i32_dpp with dst == src1: the rows outside row_mask keep their value, which is what the step
+// Min / max of non-negative floats over each HALF of the wave (lanes 0..31 and 32..63), valid in lanes 31 and 63 — both pass-1
+// kernels hold two 256-point slots per wave (8 points per lane): the four in-row steps above, then the cross-row step as a
+// single instruction (v_max_i32_dpp with dst == src1: the rows outside row_mask keep their value, which is what the step
 // wants; hipcc emits a v_mov_b32_dpp plus the ALU op for the same thing).  DPP reads a VGPR written by the previous VALU
 // instruction only after two wait states: s_nop 1.
-__device__ __forceinline__ float wave_min63_nn_fused(float f) {
-    int v = __builtin_bit_cast(int, row_min16_nn(f));
-    asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
-    return __builtin_bit_cast(float, v);
-}
-__device__ __forceinline__ float wave_max63_nn_fused(float f) {
-    int v = __builtin_bit_cast(int, row_max16_nn(f));
-    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
-    return __builtin_bit_cast(float, v);
-}
-
-// the same over each HALF of the wave (lanes 0..31 and 32..63): valid in lanes 31 and 63 — the dense pass 1 holds two
-// 256-point slots per wave (8 points per lane)
 __device__ __forceinline__ float half_min31_nn_fused(float f) {
     int v = __builtin_bit_cast(int, row_min16_nn(f));
     asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
