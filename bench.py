@@ -17,7 +17,7 @@ Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed on 
 The roofline is a VALU-ISSUE roofline: the kernels keep points in registers and stream waypoint records through SGPRs,
 so a launch moves ~N*16 B whatever W is (1 % of HBM peak) and is bound by vector-instruction issue.
   achieved = issue cycles the launch's instruction stream needs / kernel time
-             (instruction mix of the compiled inner loop: profiles/r03_pass1_isa_mix.json, from tools/isa_stats.py;
+             (instruction mix of the compiled inner loop: profiles/r04_pass1_isa_mix.json, from tools/isa_stats.py;
               prices per wave64 instruction measured on this chip: profiles/r02_valu_peak.json, tools/valu_peak.hip —
               packed f32 4, transcendental 8, other VALU 4 cycles)
   peak     = 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, max clock)
@@ -71,9 +71,9 @@ def source_hash():
 def isa_mix():
     """VALU instructions of one (wave, waypoint) iteration of k_traj_pass1's dense inner loop (= 64*P evaluations), by class.
     The mix is a checked-in count of the compiled loop: it is only valid for the sources it was counted on."""
-    d = _profile_json("r03_pass1_isa_mix.json")
+    d = _profile_json("r04_pass1_isa_mix.json")
     if d is None:
-        raise SystemExit("profiles/r03_pass1_isa_mix.json is missing (tools/isa_stats.py --json writes it)")
+        raise SystemExit("profiles/r04_pass1_isa_mix.json is missing (tools/isa_stats.py --json writes it)")
     d["stale"] = d.get("source_hash") != source_hash()
     return d
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TOHIP_ABI_VERSION 10
+#define TOHIP_ABI_VERSION 11
 
 #define TOHIP_OK 0
 #define TOHIP_EINVAL (-1)   /* bad size / null pointer */
@@ -87,6 +87,10 @@ size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual);
 /* flags */
 #define TOHIP_TRAJ_DENSE 1 /* evaluate every (point, waypoint) pair; default: skip pairs that provably
                               contribute exactly nothing (bitwise identical results, see traj_kernels.hip) */
+/* bits 8..23 of flags: the waypoint selection of model.py:215-217 as a stride of the forward's reads — with
+ * TOHIP_TRAJ_STRIDE(step) the n_wps evaluated waypoints are rows 0, step, 2 step, ... of poses / quats, read in place (one
+ * trajectory; the backward entry points ignore the bits: gradient rows are compact, one per evaluated waypoint). */
+#define TOHIP_TRAJ_STRIDE(step) ((((step) - 1) & 0xffff) << 8)
 
 /* Forward over the W evaluated waypoints (caller has applied wps_step, model.py:214-217):
  * to_camera_frame -> get_dist_mask * get_fov_mask -> per-waypoint (p-min)/max -> clip -> log-odds,
@@ -235,13 +239,63 @@ size_t tohip_traj_loss_scratch_bytes(int64_t n_points, int64_t n_wps, int32_t wp
 int tohip_traj_loss_scratch_layout(int64_t n_points, int64_t n_wps, int32_t wps_step, int32_t n_cams, int64_t *offsets_host);
 /* model(): rewards (N floats, caller's point order), loss_terms[0..4] = vis, l2, length, smooth, total (8 floats).  Leaves the
  * step's state in workspace + scratch for tohip_traj_loss_backward (and for tohip_traj_backward with a general dL/d rewards:
- * the workspace is in the state tohip_traj_forward leaves, lo_sum / scalars are in scratch). */
+ * the workspace is in the state tohip_traj_forward leaves, lo_sum / scalars are in scratch; see tohip_traj_loss_refresh).
+ * Four launches; loss.backward() is one. */
 int tohip_traj_loss_forward(const tohip_traj_loss *plan_host, const float *poses, const float *quats, float *rewards,
                             float *loss_terms, void *stream);
 /* loss.backward(): gout = DEVICE pointer to dL/d loss (autograd's incoming gradient); poses_grad (W,3), quats_grad (W,4) =
  * gout * d loss / d (poses, quats) of the step whose forward last used the plan's workspace and scratch. */
 int tohip_traj_loss_backward(const tohip_traj_loss *plan_host, const float *gout, float *poses_grad, float *quats_grad,
                              void *stream);
+/* tohip_traj_backward over the plan's workspace (a general dL/d rewards between model() and loss.backward()) OVERWRITES the pair
+ * sums tohip_traj_loss_backward reads: they are then scaled by that call's upstream gradient.  Call this before the next
+ * tohip_traj_loss_backward of the same step: it takes the unit-gradient sums again (one launch; same pairs, same bits). */
+int tohip_traj_loss_refresh(const tohip_traj_loss *plan_host, void *stream);
+
+/* ---- one step of TrajOpt.run (trajectory_optimization.py:100-127) as one call ----------------------------------
+ * `optimizer.zero_grad(); loss = model(); loss.backward(); optimizer.step()` and the early-stop bookkeeping (:119-124) for
+ * n_traj equal-length trajectories over one cloud, in the FIVE launches of tohip_traj_forward_backward: the waypoint selection
+ * (model.py:215-217) is a stride of the first launch's reads, criterion's regularisers (model.py:244-260) with their gradient and
+ * the step's Adam constants are extra blocks of the first launch, and every block of the last launch (one per evaluated waypoint)
+ * updates its waypoint's rows of poses / quats (torch.optim.Adam, two groups: trajectory_optimization.py:91-94) and, for a
+ * trajectory's first waypoint, writes the loss log and the early-stop state.  One camera or a rig; no occlusion rows, no sharding
+ * (those use the separate calls + tohip_traj_step_tail).  HOST struct, caller-owned like everything it points to. */
+typedef struct tohip_traj_opt {
+    const void *packed;        /* tohip_pack_cloud's blob */
+    int64_t n_points;
+    int64_t n_wps;             /* W: waypoints of ONE trajectory */
+    int32_t wps_step;          /* every wps_step-th waypoint is evaluated for visibility */
+    int32_t flags;             /* TOHIP_TRAJ_DENSE or 0 */
+    int32_t n_traj;            /* trajectories laid end to end: rows b * W .. b * W + W - 1 of every per-waypoint array */
+    int32_t n_steps;           /* rows of the logs below */
+    const int32_t *traj_offsets; /* n_traj + 1 device int32: b * ceil(W / wps_step) (NULL when n_traj == 1) */
+    tohip_camera cam;
+    tohip_rig rig;             /* n_cams = 0: one camera at the body frame */
+    float *poses, *quats;      /* (n_traj W, 3), (n_traj W, 4): the parameters, updated in place */
+    const float *poses0;       /* (n_traj W, 3) */
+    float smoothness_weight, traj_length_weight;
+    float lr_pose, lr_quat, beta1, beta2, adam_eps;   /* torch.optim.Adam: two groups, shared betas / eps */
+    float rewards_th, smoothness_th;                  /* trajectory_optimization.py:100 */
+    float *exp_avg_p, *exp_avg_sq_p, *exp_avg_q, *exp_avg_sq_q;   /* Adam moments, zero before the first step */
+    float *poses_grad, *quats_grad;   /* outputs (n_traj W, 3 / 4): the step's full gradients (what .grad would hold) */
+    float *poses_grad_eval, *quats_grad_eval; /* outputs, may be NULL: (n_traj n_eval, 3 / 4) visibility gradient rows */
+    float *lo_sum;             /* n_traj x Npad (packed order) */
+    float *minmax;             /* (V, 2), V = n_traj * n_eval * max(1, n_cams) */
+    float *rewards;            /* n_traj x N, caller's point order */
+    float *scalars;            /* n_traj x 4: mean reward, loss_vis, d loss_vis / d reward, - */
+    float *loss_log;           /* n_traj x n_steps x 8: row s of a trajectory = (vis, l2, length, smooth, total) of its s-th step */
+    float *state_log;          /* n_traj x (n_steps + 1) x 8, row 0 ZERO before the first step: row i = the early-stop state before
+                                  step i ([0] reward0 [1] smooth0 [2] stopped [3] steps taken [4] visibility gain [5] smoothness
+                                  gain); step i reads row i and writes row i + 1; row n_steps is the run's result */
+    void *workspace;           /* tohip_traj_workspace_bytes_multi(n_points, V, n_traj); zero-filled once */
+    size_t workspace_bytes;
+    void *scratch;             /* tohip_traj_opt_scratch_bytes(n_wps, n_traj) */
+    size_t scratch_bytes;
+} tohip_traj_opt;
+size_t tohip_traj_opt_scratch_bytes(int64_t n_wps, int64_t n_traj);
+/* step_index = 0, 1, ... n_steps - 1, in order.  A trajectory that has stopped (state[2]) stays put; its rewards are still
+ * refreshed.  Nothing synchronises. */
+int tohip_traj_opt_step(const tohip_traj_opt *opt_host, int32_t step_index, void *stream);
 
 /* ---- ModelPose (model.py:98-127) -------------------------------------------------------------- */
 size_t tohip_pose_workspace_bytes(int64_t n_points);

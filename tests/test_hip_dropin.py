@@ -88,6 +88,62 @@ def test_backward_after_another_forward_rebuilds_its_step(dev):
     assert torch.equal(m.poses.grad, g[0]) and torch.equal(m.quats.grad, g[1])
 
 
+def test_general_backward_then_fused_backward_of_the_same_step(dev):
+    """model.loss['vis'].backward(retain_graph=True) goes through the general kernels and leaves ITS pair sums in the plan's
+    workspace; the loss.backward() that follows must not read them as the unit-gradient sums (tohip_traj_loss_refresh): the
+    accumulated gradient equals the one of the op-by-op route."""
+    grads = []
+    for fused in (True, False):
+        m = _model(dev)
+        m.fused_loss = fused
+        loss = m(vis_wps_dist=0.0)
+        m.loss["vis"].backward(retain_graph=True)
+        g_vis = (m.poses.grad.clone(), m.quats.grad.clone())
+        loss.backward()
+        grads.append((g_vis, (m.poses.grad.clone(), m.quats.grad.clone())))
+    for k in (0, 1):
+        for j in (0, 1):
+            a, b = grads[0][k][j].cpu().numpy(), grads[1][k][j].cpu().numpy()
+            assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), (k, j)
+    # and the fused backward alone, after the general one, equals a fresh step's to the bit
+    m = _model(dev)
+    m(vis_wps_dist=0.0).backward()
+    g = (m.poses.grad.clone(), m.quats.grad.clone())
+    m.zero_grad()
+    loss = m(vis_wps_dist=0.0)
+    m.rewards.sum().backward(retain_graph=True)
+    m.zero_grad()
+    loss.backward()
+    assert torch.equal(m.poses.grad, g[0]) and torch.equal(m.quats.grad, g[1])
+
+
+def test_backward_after_a_step_and_another_forward_raises(dev):
+    """la = model(); opt.step(); model(); la.backward(): the one-launch Adam writes the Parameters through raw pointers but bumps
+    their version counters, so the rebuild of la's step refuses (its inputs are gone) instead of returning another step's gradient;
+    ModelPose's saved (trans, quat) make torch's own in-place check fire."""
+    from trajectory_optimization_amd.model import ModelPose
+    m = _model(dev)
+    opt = torch.optim.Adam(_groups(m))
+    m(vis_wps_dist=0.0).backward()
+    v0 = m.poses._version
+    opt.step()
+    assert m.poses._version > v0
+    la = m(vis_wps_dist=0.0)
+    la.backward(retain_graph=True)
+    opt.step()
+    m(vis_wps_dist=0.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        la.backward()
+    pts = synth.make_cloud(20_000, seed=9)
+    mp = ModelPose(torch.from_numpy(pts), torch.tensor([[0.0, 0.0, 0.0]]), torch.tensor([[1.0, 0.0, 0.0, 0.0]]), torch.from_numpy(K), IW, IH, device=dev)
+    optp = torch.optim.Adam([{"params": [mp.trans], "lr": 0.1}, {"params": [mp.quat], "lr": 0.1}])
+    lp = mp()
+    lp.backward(retain_graph=True)
+    optp.step()
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        lp.backward()
+
+
 def test_torch_adam_with_the_one_launch_update(dev):
     """torch.optim.Adam over the models' Parameters: with the step pre-hook (one launch, torch's own state entries) and without
     it the trajectories agree to rounding; gradients are back in .grad after step(); the state keeps torch's layout; a

@@ -6,7 +6,10 @@ k_traj_probe / _pass1_cull / _sparse / _pairs / _finish; the shipped library has
 per kernel: the span from its first block's start to its last block's end, how far apart the blocks start, and the timeline of the
 median and of the slowest block (ns from the block's own start).
 
-    python tools/kernel_timeline.py [culled|dense] [extent_xy] > profiles/rNN_small_kernel_timelines.txt
+    python tools/kernel_timeline.py [culled|dense] [extent_xy] [moved_steps] > profiles/rNN_small_kernel_timelines.txt
+
+moved_steps > 0: the trajectory first takes that many optimiser steps (optimize_trajectory, lr 0.1 / 0.02): the step a run ends
+with, not the one it starts with (more flagged pairs in more candidate slots).
 """
 import ctypes
 import os
@@ -39,6 +42,7 @@ BLOCKS, N = 1024, 12
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "culled"
     xy = float(sys.argv[2]) if len(sys.argv) > 2 else 40.0
+    moved = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     so = os.path.join(tempfile.gettempdir(), "libtrajopt_stamps.so")
     subprocess.check_call([_lib.HIPCC] + _lib.HIPCC_FLAGS + ["-DTOHIP_STAMPS", _lib.SRC, "-o", so])
     _lib.LIB_PATH = so   # before the first lib() call: this process runs the diagnostic build
@@ -52,6 +56,12 @@ def main():
     poses, quats = synth.make_path(bench.WPS_PER_GPU, optical=True, scale=xy / 40.0)
     cloud = ops.PackedCloud(torch.from_numpy(pts).to(dev))
     p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
+    if moved > 0:
+        from trajectory_optimization_amd.model import ModelTraj
+        from trajectory_optimization_amd.optimizer import optimize_trajectory
+        m = ModelTraj(torch.from_numpy(pts).to(dev), p, q, torch.from_numpy(synth.K_INTRINS), synth.IMG_WIDTH, synth.IMG_HEIGHT, device=dev)
+        optimize_trajectory(m, n_opt_steps=moved, lr_pose=0.1, lr_quat=0.02, rewards_th=1e9, vis_wps_dist=0.0)
+        p, q = m.poses.data.clone(), m.quats.data.clone()
     ws = ops.TrajWorkspace(cloud, bench.WPS_PER_GPU)
     gout = torch.ones(1, device=dev)
     flags = ops.DENSE if mode == "dense" else 0
@@ -64,7 +74,9 @@ def main():
         L.tohip_stamps_read(buf)
         if it >= 6:
             runs.append(np.array(buf[:], dtype=np.int64).reshape(len(KERNELS), BLOCKS, N))
-    print(f"# {bench.N_POINTS} points x {bench.WPS_PER_GPU} waypoints, {mode}, {xy:g} x {xy:g} x 4 m; ns, 100 MHz counter (10 ns steps); "
+    st = ops.traj_step_stats(cloud, ws)
+    print(f"# {bench.N_POINTS} points x {bench.WPS_PER_GPU} waypoints, {mode}, {xy:g} x {xy:g} x 4 m" + (f", after {moved} optimiser steps" if moved else "") +
+          f" ({st['flagged_pairs']} flagged pairs in {st['candidate_slots']} candidate slots); ns, 100 MHz counter (10 ns steps); "
           f"thread 0 of each block; last of {len(runs)} stamped steps")
     a = runs[-1]
     for ki, name in enumerate(KERNELS):
@@ -80,6 +92,10 @@ def main():
               f"{(s[:, 0].max() - t0) * 10} ns")
         dur = (ends - s[:, 0]) * 10
         order = np.argsort(dur)
+        rel_end = np.sort((ends - t0) * 10)
+        print("    block ends after the kernel's first start, ns: " + ", ".join(f"{int(q * 100)} % {int(rel_end[min(len(rel_end) - 1, int(q * len(rel_end)))])}"
+                                                                                   for q in (0.25, 0.5, 0.75, 0.9, 0.99)) +
+              "; block lifetimes, ns: " + ", ".join(f"{int(q * 100)} % {int(dur[order[min(len(order) - 1, int(q * len(order)))]])}" for q in (0.25, 0.5, 0.75, 0.9, 0.99)))
         for what, b in (("median block", order[len(order) // 2]), ("slowest block", order[-1])):
             r = s[b]
             line = ", ".join(f"{labels[i]} {int((r[i] - r[0]) * 10)}" for i in range(1, len(labels)) if r[i] > 0)

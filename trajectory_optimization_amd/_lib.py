@@ -37,6 +37,18 @@ class TrajLoss(ctypes.Structure):
                 ("workspace_bytes", c_sz), ("scratch", c_vp), ("scratch_bytes", c_sz), ("reg_terms", c_vp)]
 
 
+class TrajOpt(ctypes.Structure):
+    """struct tohip_traj_opt (include/trajopt_hip.h)."""
+    _fields_ = [("packed", c_vp), ("n_points", c_i64), ("n_wps", c_i64), ("wps_step", c_i32), ("flags", c_i32), ("n_traj", c_i32),
+                ("n_steps", c_i32), ("traj_offsets", c_vp), ("cam", Camera), ("rig", Rig), ("poses", c_vp), ("quats", c_vp),
+                ("poses0", c_vp), ("smoothness_weight", c_f), ("traj_length_weight", c_f), ("lr_pose", c_f), ("lr_quat", c_f),
+                ("beta1", c_f), ("beta2", c_f), ("adam_eps", c_f), ("rewards_th", c_f), ("smoothness_th", c_f),
+                ("exp_avg_p", c_vp), ("exp_avg_sq_p", c_vp), ("exp_avg_q", c_vp), ("exp_avg_sq_q", c_vp), ("poses_grad", c_vp),
+                ("quats_grad", c_vp), ("poses_grad_eval", c_vp), ("quats_grad_eval", c_vp), ("lo_sum", c_vp), ("minmax", c_vp),
+                ("rewards", c_vp), ("scalars", c_vp), ("loss_log", c_vp), ("state_log", c_vp), ("workspace", c_vp),
+                ("workspace_bytes", c_sz), ("scratch", c_vp), ("scratch_bytes", c_sz)]
+
+
 class AdamGroup(ctypes.Structure):
     """struct tohip_adam_group (include/trajopt_hip.h)."""
     _fields_ = [("param", c_vp), ("grad", c_vp), ("exp_avg", c_vp), ("exp_avg_sq", c_vp), ("n", c_i64), ("lr", c_f), ("beta1", c_f),
@@ -79,6 +91,9 @@ SIGNATURES = {
     "tohip_traj_loss_scratch_layout": (ctypes.c_int, [c_i64, c_i64, c_i32, c_i32, ctypes.POINTER(c_i64)]),
     "tohip_traj_loss_forward": (ctypes.c_int, [ctypes.POINTER(TrajLoss), c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tohip_traj_loss_backward": (ctypes.c_int, [ctypes.POINTER(TrajLoss), c_vp, c_vp, c_vp, c_vp]),
+    "tohip_traj_loss_refresh": (ctypes.c_int, [ctypes.POINTER(TrajLoss), c_vp]),
+    "tohip_traj_opt_scratch_bytes": (c_sz, [c_i64, c_i64]),
+    "tohip_traj_opt_step": (ctypes.c_int, [ctypes.POINTER(TrajOpt), c_i32, c_vp]),
     "tohip_inverse_permutation": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "tohip_occlusion_rows": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "tohip_occlusion_row": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -175,7 +190,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 10  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
+ABI_VERSION = 11  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
 ENOSPC = -2  # TOHIP_ENOSPC
 ENAN = -4    # TOHIP_ENAN
 

@@ -8,18 +8,22 @@
 // loss.backward() computes, over a caller-owned description of the model (tohip_traj_loss: pointers and constants only; the
 // library keeps no state).
 //
-//   tohip_traj_loss_forward    probe (every wps_step-th waypoint, read in place), pass 1, the fused sparse kernel (log-odds,
-//                              rewards, their sum, the gradient sums of the flagged pairs with unit upstream gradient) ->
-//                              criterion's regularisers with their analytic gradients and the visibility scalars
-//   tohip_traj_loss_backward   the per-waypoint finish of the visibility gradient (scaled by dL/d loss, read on the device)
-//                              -> full (W,3) / (W,4) gradients: evaluated rows scattered, the regularisers' gradient on top
+//   tohip_traj_loss_forward    four launches: probe (every wps_step-th waypoint, read in place; one block more computes
+//                              criterion's regularisers with their analytic gradients: they depend on the positions only),
+//                              pass 1, the fused sparse kernel (log-odds, rewards, their integer sum), the gradient sums of the
+//                              flagged pairs with unit upstream gradient (one block more turns the reward sum and the
+//                              regularisers' terms into model()'s scalars and loss terms)
+//   tohip_traj_loss_backward   one launch: the per-waypoint finish of the visibility gradient (scaled by dL/d loss, read on the
+//                              device); every block also writes its waypoint's rows of the full (W,3) / (W,4) gradients —
+//                              visibility row + dL/d loss x the regularisers' gradient (opt_step.hpp, mode 2)
 #include "common.hpp"
+#include "opt_step.hpp"
 
 namespace {
 
 struct LossLayout {
     int64_t n_eval, V, npad;
-    size_t off_pe, off_qe, off_lo, off_mm, off_sc, off_pge, off_qge, off_reg, total;
+    size_t off_pe, off_qe, off_lo, off_mm, off_sc, off_pge, off_qge, off_reg, off_pro, total;
 };
 
 inline LossLayout loss_layout(int64_t n, int64_t W, int step, int n_cams) {
@@ -36,6 +40,7 @@ inline LossLayout loss_layout(int64_t n, int64_t W, int step, int n_cams) {
     l.off_pge = o; o += align_up((size_t)l.n_eval * 3 * sizeof(float), 256);
     l.off_qge = o; o += align_up((size_t)l.n_eval * 4 * sizeof(float), 256);
     l.off_reg = o; o += align_up((size_t)W * 3 * sizeof(float), 256);
+    l.off_pro = o; o += align_up(sizeof(OptPro), 256);   // the regularisers' terms (prologue -> the pairs' extra block)
     l.total = o;
     return l;
 }
@@ -47,25 +52,19 @@ inline bool loss_plan_ok(const tohip_traj_loss* p, LossLayout* l, int* C) {
     return true;
 }
 
-}  // namespace
-
-// full gradients of the loss: row w of the evaluated waypoints' visibility gradient (already scaled by dL/d loss in the finish
-// kernel) where w is a multiple of `step`, zero elsewhere; the regularisers' gradient, scaled here, on top
-__global__ void k_traj_loss_grad(const float* __restrict__ pg_e, const float* __restrict__ qg_e, const float* __restrict__ reg,
-                                 const float* __restrict__ gout, int W, int n_eval, int step, float* __restrict__ pg,
-                                 float* __restrict__ qg) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const float g = gout[0];
-    if (i < W * 3) {
-        const int j = i / 3, k = i - 3 * j, r = j / step;
-        const float v = (j == r * step && r < n_eval) ? pg_e[3 * r + k] : 0.f;
-        pg[i] = v + g * reg[i];
-    }
-    if (i < W * 4) {
-        const int j = i >> 2, k = i & 3, r = j / step;
-        qg[i] = (j == r * step && r < n_eval) ? qg_e[4 * r + k] : 0.f;
-    }
+// what the prologue / epilogue blocks need of the plan (opt_step.hpp, mode 2)
+inline void loss_opt(OptStep& a, const tohip_traj_loss* p, const LossLayout& l) {
+    char* sc = (char*)p->scratch;
+    a.mode = 2;
+    a.poses0 = p->poses0;
+    a.pro = (OptPro*)(sc + l.off_pro);
+    a.reg = (float*)(sc + l.off_reg);
+    a.reg_terms = p->reg_terms;
+    a.W = (int)p->n_wps; a.n_eval = (int)l.n_eval; a.step = p->wps_step; a.n_traj = 1;
+    a.smooth_w = p->smoothness_weight; a.length_w = p->traj_length_weight; a.eps = p->cam.eps;
 }
+
+}  // namespace
 
 extern "C" size_t tohip_traj_loss_scratch_bytes(int64_t n_points, int64_t n_wps, int32_t wps_step, int32_t n_cams) {
     if (n_points <= 0 || n_wps <= 0 || wps_step < 1) return 0;
@@ -91,20 +90,17 @@ extern "C" int tohip_traj_loss_forward(const tohip_traj_loss* p, const float* po
     float* lo = (float*)(sc + l.off_lo);
     float* mm = (float*)(sc + l.off_mm);
     float* scal = (float*)(sc + l.off_sc);
-    float* reg = (float*)(sc + l.off_reg);
     const tohip_rig* rig = C > 1 || p->rig.rig_quats ? &p->rig : nullptr;
-    // probe, pass 1, k_traj_sparse<FUSED>: log-odds, rewards, their integer sum, the pair sums with unit upstream gradient
+    // probe (+ the regularisers' block), pass 1, k_traj_sparse<FUSED>, the pair sums with unit upstream gradient (+ the scalars' block)
     TrajStep s;
-    int rc = traj_step_init(s, p->packed, p->n_points, l.n_eval, 1, nullptr, &p->cam, rig, p->flags, nullptr, p->workspace, p->workspace_bytes, st, true);
+    int rc = traj_step_init(s, p->packed, p->n_points, l.n_eval, 1, nullptr, &p->cam, rig, p->flags & 0xff, nullptr, p->workspace, p->workspace_bytes, st, true);
     if (rc != TOHIP_OK) return rc;
     s.wp_stride = p->wps_step;   // every wps_step-th waypoint is evaluated (model.py:215-217): the probe reads them in place
-    rc = traj_fused_forward(s, poses, quats, lo, mm, rewards);
-    if (rc != TOHIP_OK) return rc;
-    // criterion: the scalars of the visibility term come out of the integer reward sum first
-    k_traj_regularizers<<<1, TO_BLOCK, 0, st>>>(poses, p->poses0, (int)p->n_wps, p->smoothness_weight, p->traj_length_weight, p->cam.eps,
-                                                scal, loss_terms, reg, 0, nullptr, p->reg_terms, s.acc, p->n_points, s.shift);
-    TO_HIP_CHECK_LAUNCH();
-    return TOHIP_OK;
+    loss_opt(s.opt, p, l);
+    s.opt.poses = const_cast<float*>(poses);
+    s.opt.loss_log = loss_terms;
+    s.opt_scalars = scal;
+    return traj_fused_forward(s, poses, quats, lo, mm, rewards);
 }
 
 extern "C" int tohip_traj_loss_backward(const tohip_traj_loss* p, const float* gout, float* poses_grad, float* quats_grad, void* stream_) {
@@ -116,15 +112,26 @@ extern "C" int tohip_traj_loss_backward(const tohip_traj_loss* p, const float* g
     char* sc = (char*)p->scratch;
     float* pge = (float*)(sc + l.off_pge);
     float* qge = (float*)(sc + l.off_qge);
-    const float* reg = (const float*)(sc + l.off_reg);
     const tohip_rig* rig = C > 1 || p->rig.rig_quats ? &p->rig : nullptr;
     TrajStep s;
-    int rc = traj_step_init(s, p->packed, p->n_points, l.n_eval, 1, nullptr, &p->cam, rig, p->flags, nullptr, p->workspace, p->workspace_bytes, st, false);
+    int rc = traj_step_init(s, p->packed, p->n_points, l.n_eval, 1, nullptr, &p->cam, rig, p->flags & 0xff, nullptr, p->workspace, p->workspace_bytes, st, false);
     if (rc != TOHIP_OK) return rc;
-    rc = launch_finish(s, finish_post(s, 2, nullptr, gout, nullptr, p->cam.eps), pge, qge);
+    loss_opt(s.opt, p, l);
+    s.opt.pg = poses_grad; s.opt.qg = quats_grad; s.opt.gout = gout;
+    return launch_finish(s, finish_post(s, 2, nullptr, gout, nullptr, p->cam.eps), pge, qge);
+}
+
+// tohip_traj_backward (a general dL/d rewards, or the fused loss through the separate kernels) leaves ITS pair sums — scaled by
+// its upstream gradient — where tohip_traj_loss_backward expects the sums taken with unit upstream gradient: this takes those
+// again (the step's pair list, log-odds vector and extrema are untouched by a backward: same pairs, same bits).
+extern "C" int tohip_traj_loss_refresh(const tohip_traj_loss* p, void* stream_) {
+    LossLayout l;
+    int C;
+    if (!loss_plan_ok(p, &l, &C)) return TOHIP_EINVAL;
+    if (p->scratch_bytes < l.total) return TOHIP_ENOSPC;
+    const tohip_rig* rig = C > 1 || p->rig.rig_quats ? &p->rig : nullptr;
+    TrajStep s;
+    int rc = traj_step_init(s, p->packed, p->n_points, l.n_eval, 1, nullptr, &p->cam, rig, p->flags & 0xff, nullptr, p->workspace, p->workspace_bytes, stream_, false);
     if (rc != TOHIP_OK) return rc;
-    const int n = (int)(p->n_wps * 4);
-    k_traj_loss_grad<<<(n + 255) / 256, 256, 0, st>>>(pge, qge, reg, gout, (int)p->n_wps, (int)l.n_eval, p->wps_step, poses_grad, quats_grad);
-    TO_HIP_CHECK_LAUNCH();
-    return TOHIP_OK;
+    return launch_pairs(s, sparse_args(s, (float*)((char*)p->scratch + l.off_lo)));
 }

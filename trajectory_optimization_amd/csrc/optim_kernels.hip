@@ -8,142 +8,27 @@
 //
 // Everything here is a single small block: W is tens to a few thousand waypoints.
 #include "common.hpp"
+#include "opt_step.hpp"
 
-// state[] (floats, device):  [0] reward0 (mean reward of the first step)   [1] smooth0 (smooth loss of the first step)
-//                            [2] stopped (0/1)   [3] steps taken   [4] last visibility gain   [5] last smooth gain
-#define TO_OPT_STATE 8
-
-// loss_terms[0..4] = vis, l2, length, smooth, total.  grad_poses (W,3) receives the regularisers' gradient
-// ADDED to what the visibility backward wrote (pass accumulate = 1), scaled by gout (dL/d total = 1).
+// loss_terms[0..4] = vis, l2, length, smooth, total.  grad_poses (W,3) receives the regularisers' gradient (ADDED to what the
+// visibility backward wrote when accumulate != 0).  state (may be NULL): the loss row written is state[3] (steps taken so far).
 __device__ __forceinline__ void
 regularizers_block(const float* __restrict__ poses, const float* __restrict__ poses0, int W, float smooth_w,
                    float length_w, float eps, const float* __restrict__ scalars /* [1] = loss_vis */,
                    float* __restrict__ loss_terms, float* __restrict__ grad_poses, int accumulate,
-                   const float* __restrict__ state /* may be NULL; else loss row = state[3] (steps taken so far) */,
-                   float* __restrict__ grad_terms /* may be NULL; else (3, W, 3): d l2, d length, d smooth separately */,
-                   double* lds /* TO_BLOCK doubles */, double* sh /* 4 doubles */) {
+                   const float* __restrict__ state, float* __restrict__ grad_terms, double* lds, double* sh) {
     if (state) loss_terms += 8 * (int)state[3];
-    const int t = threadIdx.x;
-    auto P = [&](const float* a, int i, int k) { return (double)a[3 * i + k]; };
-    // ---- forward sums -----------------------------------------------------------------------------
-    double len = 0, len0 = 0, ang = 0;
-    for (int i = t; i < W - 1; i += TO_BLOCK) {
-        double s = 0, s0 = 0;
-        for (int k = 0; k < 3; ++k) {
-            const double d = P(poses, i + 1, k) - P(poses, i, k), d0 = P(poses0, i + 1, k) - P(poses0, i, k);
-            s += d * d; s0 += d0 * d0;
-        }
-        len += sqrt(s); len0 += sqrt(s0);
-    }
-    for (int i = 1 + t; i < W - 1; i += TO_BLOCK) {
-        double ab2 = 0, ac2 = 0, dot = 0;
-        for (int k = 0; k < 3; ++k) {
-            const double ab = P(poses, i - 1, k) - P(poses, i, k), ac = P(poses, i + 1, k) - P(poses, i, k);
-            ab2 += ab * ab; ac2 += ac * ac; dot += ab * ac;
-        }
-        double c = dot / (sqrt(ab2) * sqrt(ac2) + (double)eps);
-        c = fmin(1.0, fmax(-1.0, c));
-        ang += acos(c);
-    }
-    const double L = block_sum_double(len, lds);
-    if (t == 0) sh[0] = L;
-    __syncthreads();
-    const double L0 = block_sum_double(len0, lds);
-    if (t == 0) sh[1] = L0;
-    __syncthreads();
-    const double A = block_sum_double(ang, lds);
-    if (t == 0) sh[2] = A;
-    __syncthreads();
-    const double mean_angle = sh[2] / (double)(W - 2);
-    const double smooth = (double)smooth_w / (mean_angle + (double)eps);
-    const double dlen = sh[0] - sh[1];
-    const double length = (double)length_w * fabs(dlen);
-    double l2sq = 0;
-    for (int k = 0; k < 3; ++k) { const double d = P(poses, 0, k) - P(poses0, 0, k); l2sq += d * d; }
-    const double l2 = sqrt(l2sq);
-    if (t == 0) {
-        const double vis = (double)scalars[1];
-        loss_terms[0] = (float)vis; loss_terms[1] = (float)l2; loss_terms[2] = (float)length; loss_terms[3] = (float)smooth;
-        loss_terms[4] = (float)(vis + l2 + length + smooth);
-    }
-    if (!grad_poses && !grad_terms) return;
-    // ---- gradients: thread per waypoint gathers the terms it appears in ------------------------------
-    const double dsm_dang = -smooth / (mean_angle + (double)eps) / (double)(W - 2);  // d smooth / d phi_i
-    const double dlen_w = (double)length_w * (dlen > 0 ? 1.0 : (dlen < 0 ? -1.0 : 0.0));
-    for (int j = t; j < W; j += TO_BLOCK) {
-        double gl[3] = {0, 0, 0}, g2[3] = {0, 0, 0}, gs[3] = {0, 0, 0};  // length, l2, smooth
-        // length: segments (j-1, j) and (j, j+1)
-        if (j > 0) {
-            double d[3], s = 0;
-            for (int k = 0; k < 3; ++k) { d[k] = P(poses, j, k) - P(poses, j - 1, k); s += d[k] * d[k]; }
-            s = sqrt(s);
-            if (s > 0) for (int k = 0; k < 3; ++k) gl[k] += dlen_w * d[k] / s;
-        }
-        if (j < W - 1) {
-            double d[3], s = 0;
-            for (int k = 0; k < 3; ++k) { d[k] = P(poses, j + 1, k) - P(poses, j, k); s += d[k] * d[k]; }
-            s = sqrt(s);
-            if (s > 0) for (int k = 0; k < 3; ++k) gl[k] -= dlen_w * d[k] / s;
-        }
-        // l2 on the first waypoint
-        if (j == 0 && l2 > 0) for (int k = 0; k < 3; ++k) g2[k] += (P(poses, 0, k) - P(poses0, 0, k)) / l2;
-        // smoothness: waypoint j is the corner of angle j and an end point of angles j-1 and j+1
-        for (int i = j - 1; i <= j + 1; ++i) {
-            if (i < 1 || i > W - 2) continue;
-            double ab[3], ac[3], nab = 0, nac = 0, dot = 0;
-            for (int k = 0; k < 3; ++k) {
-                ab[k] = P(poses, i - 1, k) - P(poses, i, k); ac[k] = P(poses, i + 1, k) - P(poses, i, k);
-                nab += ab[k] * ab[k]; nac += ac[k] * ac[k]; dot += ab[k] * ac[k];
-            }
-            nab = sqrt(nab); nac = sqrt(nac);
-            const double den = nab * nac + (double)eps;
-            const double c = dot / den;
-            if (!(c > -1.0 && c < 1.0)) continue;  // arccos' derivative is unbounded at +-1 (torch: inf/nan)
-            const double dphi_dc = -1.0 / sqrt(1.0 - c * c);
-            // dc/dAB = AC/den - c * nac * AB/(nab*den),  dc/dAC symmetric
-            double dab[3], dac[3];
-            for (int k = 0; k < 3; ++k) {
-                dab[k] = ac[k] / den - (nab > 0 ? c * nac * ab[k] / (nab * den) : 0.0);
-                dac[k] = ab[k] / den - (nac > 0 ? c * nab * ac[k] / (nac * den) : 0.0);
-            }
-            for (int k = 0; k < 3; ++k) {
-                double dc;
-                if (j == i - 1) dc = dab[k];
-                else if (j == i + 1) dc = dac[k];
-                else dc = -dab[k] - dac[k];
-                gs[k] += dsm_dang * dphi_dc * dc;
-            }
-        }
-        for (int k = 0; k < 3; ++k) {
-            if (grad_poses) {
-                const float prev = accumulate ? grad_poses[3 * j + k] : 0.f;
-                grad_poses[3 * j + k] = prev + (float)(gl[k] + g2[k] + gs[k]);
-            }
-            if (grad_terms) {
-                grad_terms[3 * j + k] = (float)g2[k];
-                grad_terms[3 * (W + j) + k] = (float)gl[k];
-                grad_terms[3 * (2 * W + j) + k] = (float)gs[k];
-            }
-        }
-    }
+    const RegOut o = regularizers_eval(poses, poses0, W, smooth_w, length_w, eps, grad_poses, accumulate, grad_terms, lds, sh);
+    if (threadIdx.x == 0) write_loss_terms(loss_terms, (double)scalars[1], o);
 }
 
 __global__ void __launch_bounds__(TO_BLOCK)
 k_traj_regularizers(const float* __restrict__ poses, const float* __restrict__ poses0, int W, float smooth_w,
                     float length_w, float eps, const float* __restrict__ scalars, float* __restrict__ loss_terms,
                     float* __restrict__ grad_poses, int accumulate, const float* __restrict__ state,
-                    float* __restrict__ grad_terms, const RewardAcc* __restrict__ acc = nullptr, int64_t n_points = 0, int shift = 0) {
-    __shared__ double lds[TO_BLOCK];
+                    float* __restrict__ grad_terms) {
+    __shared__ double lds[TO_BLOCK / 64];
     __shared__ double sh[4];
-    if (acc != nullptr) {   // a fused step: the visibility scalars are still an integer sum (k_traj_sparse<FUSED>); `scalars` receives them
-        float* sc = const_cast<float*>(scalars);
-        if (threadIdx.x == 0) {
-            float out[4];
-            reward_scalars_from_a(acc, n_points, shift, eps, out);
-            sc[0] = out[0]; sc[1] = out[1]; sc[2] = out[2]; sc[3] = out[3];
-        }
-        __syncthreads();
-    }
     regularizers_block(poses, poses0, W, smooth_w, length_w, eps, scalars, loss_terms, grad_poses, accumulate, state,
                        grad_terms, lds, sh);
 }
@@ -164,9 +49,6 @@ __global__ void k_gather_rows(const float* __restrict__ src, int n_rows, int col
 
 // torch.optim.Adam (defaults betas=(0.9,0.999), eps=1e-8, no weight decay / amsgrad), one call per parameter group.
 // No-op once state[2] (stopped) is set.  `t` = 1-based step index.
-__device__ __forceinline__ void adam_element(float* __restrict__ param, float g, float* __restrict__ m, float* __restrict__ v,
-                                             int i, float lr, float beta1, float beta2, float eps, int t);
-
 __global__ void k_adam(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
                        int n, float lr, float beta1, float beta2, float eps, int t, const float* __restrict__ state) {
     if (state && state[2] != 0.f) return;
@@ -175,38 +57,17 @@ __global__ void k_adam(float* __restrict__ param, const float* __restrict__ grad
     if (i < n) adam_element(param, grad[i], m, v, i, lr, beta1, beta2, eps, t);
 }
 
-__device__ __forceinline__ void adam_element(float* __restrict__ param, float g, float* __restrict__ m, float* __restrict__ v,
-                                             int i, float lr, float beta1, float beta2, float eps, int t) {
-    const float mi = beta1 * m[i] + (1.0f - beta1) * g;      // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = beta2 * v[i] + (1.0f - beta2) * g * g;   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    m[i] = mi; v[i] = vi;
-    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
-    const float step_size = (float)((double)lr / bc1);
-    const float denom = sqrtf(vi) / (float)sqrt(bc2) + eps;
-    param[i] = param[i] - step_size * (mi / denom);
-}
-
 // The reference's early-stop rule, evaluated after the step: gains relative to the first step's values.
-__device__ __forceinline__ void early_stop_rule(const float* __restrict__ scalars, const float* __restrict__ loss_terms,
-                                                float rewards_th, float smoothness_th, float* __restrict__ state,
-                                                int row_from_state);
-
-__global__ void k_early_stop(const float* __restrict__ scalars /* [0] = mean reward */, const float* __restrict__ loss_terms,
-                             float rewards_th, float smoothness_th, float* __restrict__ state, int row_from_state) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) early_stop_rule(scalars, loss_terms, rewards_th, smoothness_th, state, row_from_state);
-}
-
 __device__ __forceinline__ void early_stop_rule(const float* __restrict__ scalars, const float* __restrict__ loss_terms,
                                                 float rewards_th, float smoothness_th, float* __restrict__ state,
                                                 int row_from_state) {
     if (row_from_state) loss_terms += 8 * (int)state[3];
-    if (state[2] != 0.f) return;
-    const float mean_r = scalars[0], smooth = loss_terms[3];  // loss_terms: this step's row
-    if (state[3] == 0.f) { state[0] = mean_r; state[1] = smooth; }
-    state[3] += 1.f;
-    const float vg = mean_r / state[0], sg = state[1] / smooth;
-    state[4] = vg; state[5] = sg;
-    if (vg > rewards_th && sg > smoothness_th) state[2] = 1.f;
+    early_stop_next(state, state, scalars[0], loss_terms[3], rewards_th, smoothness_th);   // loss_terms: this step's row
+}
+
+__global__ void k_early_stop(const float* __restrict__ scalars /* [0] = mean reward */, const float* __restrict__ loss_terms,
+                             float rewards_th, float smoothness_th, float* __restrict__ state, int row_from_state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) early_stop_rule(scalars, loss_terms, rewards_th, smoothness_th, state, row_from_state);
 }
 
 // One block does the whole O(W) remainder of an optimisation step (optimizer.optimize_trajectory): scatter of the

@@ -52,6 +52,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "opt_step.hpp"
 #include "profile.hpp"
 
 #define TO_SLOT 256            // points per flag slot (= bounding-sphere tile)
@@ -62,6 +63,12 @@
 #define TO_CBIT_STRIDE 16      // words between two words of the candidate bits: one to a 128-byte line (mark_candidate)
 #define TO_PROBE_MAXFW 1024   // words of a `live` row the culled pass 1 holds in LDS: culling up to 65 536 slots (16.7 M points), dense beyond
 #define TO_SP_MAXW 1024        // flag words of one slot held in LDS by k_traj_sparse: at most 65 536 virtual waypoints
+// The step's list of flagged (slot, waypoint) pairs is 64 sub-lists, slot s appending to sub-list s & 63, each with its own length
+// word on its own 128-byte line: a returning atomic on ONE word is served ~88 times per microsecond (MI355X_MICROARCH.md,
+// "dequeue"), and a trajectory that has moved for a hundred optimiser steps has 1 400 candidate slots to append — 16 us of a 24 us
+// kernel with one word.  Sub-list l holds the entries [l * cap, l * cap + length l), cap = ceil(nslots / 64) * V.
+#define TO_PL_SHARDS 64
+#define TO_PL_STRIDE 32        // ints between two length words
 
 // ---------------------------------------------------------------------------------------------
 // Diagnostic build (-DTOHIP_STAMPS, tools/kernel_timeline.py; never the shipped library): thread 0 of every block notes the
@@ -142,14 +149,19 @@ struct TieRec {            // slots whose max equals the waypoint's max / whose 
 __device__ __forceinline__ void prep_wayrec(int v, const float* __restrict__ poses, const float* __restrict__ quats, int C,
                                             const float* __restrict__ rig_q, const float* __restrict__ rig_t,
                                             const EvalK& k, WayRec* __restrict__ rec, WayCold* __restrict__ cold,
-                                            const int* __restrict__ traj_off, int n_traj, int wp_stride = 1) {
+                                            const int* __restrict__ traj_off, int n_traj, int wp_stride = 1, int traj_rows = 0) {
     const int w = v / C, c = v - w * C;
     int seg = 0;
     if (traj_off != nullptr)
         while (seg + 1 < n_traj && w >= traj_off[seg + 1]) ++seg;
-    // wp_stride > 1: the evaluated waypoints are every wp_stride-th row of the caller's arrays (model.py:215-217), read in place
-    poses += (int64_t)3 * w * (wp_stride - 1);
-    quats += (int64_t)4 * w * (wp_stride - 1);
+    // wp_stride > 1: the evaluated waypoints are every wp_stride-th row of the caller's arrays (model.py:215-217), read in place;
+    // traj_rows > 0: every trajectory owns traj_rows rows of them (its evaluated waypoints are rows 0, wp_stride, ... of its own)
+    {
+        const int64_t row = (traj_rows > 0 && traj_off != nullptr) ? (int64_t)seg * traj_rows + (int64_t)(w - traj_off[seg]) * wp_stride
+                                                                   : (int64_t)w * wp_stride;
+        poses += 3 * (row - w);
+        quats += 4 * (row - w);
+    }
     float q[4] = {quats[4 * w], quats[4 * w + 1], quats[4 * w + 2], quats[4 * w + 3]};
     float ss = q[0] * q[0];
     ss = ss + q[1] * q[1];
@@ -303,14 +315,19 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
              WayCold* __restrict__ cold, Extrema* __restrict__ ext, TieRec* __restrict__ ties, const uint32_t* __restrict__ occ,
              int64_t occw, unsigned long long* __restrict__ fv, int fv_words, RewardAcc* __restrict__ acc,
              const int* __restrict__ traj_off, int* __restrict__ traj_off_ws, int n_traj, unsigned long long* __restrict__ cbits,
-             int ncbits, int* __restrict__ ctr, int wp_stride, ProbeCull pc) {
+             int ncbits, int* __restrict__ ctr, int wp_stride, int traj_rows, ProbeCull pc, int V, OptStep os) {
     __shared__ float smx[TO_PROBE_THREADS / 64], smn[TO_PROBE_THREADS / 64];
     __shared__ float scull[4];
     const int v = blockIdx.x, t = threadIdx.x;
+    if (v >= V) {   // the blocks behind the waypoints': a trajectory's regularisers and the step's Adam constants (opt_step.hpp)
+        __shared__ double olds[TO_PROBE_THREADS / 64], osh[4];
+        opt_prologue_block(os, v - V, olds, osh);
+        return;
+    }
     TO_STAMP(TO_STAMP_PROBE, 0);
     for (int j = t; j < fv_words; j += TO_PROBE_THREADS) fv[(int64_t)v * fv_words + j] = 0ull;
-    for (int j = v * TO_PROBE_THREADS + t; j < ncbits; j += gridDim.x * TO_PROBE_THREADS) cbits[(int64_t)j * TO_CBIT_STRIDE] = 0ull;   // the candidate (slot, trajectory) bits
-    if (v == 0 && t == 0) ctr[0] = 0;   // the pair list's length
+    for (int j = v * TO_PROBE_THREADS + t; j < ncbits; j += V * TO_PROBE_THREADS) cbits[(int64_t)j * TO_CBIT_STRIDE] = 0ull;   // the candidate (slot, trajectory) bits
+    if (v == 0 && t < TO_PL_SHARDS) ctr[t * TO_PL_STRIDE] = 0;   // the pair sub-lists' lengths
     if (v == 0) {
         for (int j = t; j < n_traj * 8; j += TO_PROBE_THREADS) { acc[j >> 3].a[j & 7].sum = 0; acc[j >> 3].a[j & 7].nan = 0u; }
         for (int j = t; j < n_traj; j += TO_PROBE_THREADS) acc[j].b.word = 0ull;   // (k_traj_reward leaves it zero; a launch that was cut short may not have)
@@ -338,7 +355,7 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
         px[j] = cv.samples[sc]; py[j] = cv.samples[TO_PROBE_MAX + sc]; pz[j] = cv.samples[2 * TO_PROBE_MAX + sc];
     }
     __shared__ WayRec srec;   // the block's record: built by thread 0, read by everybody from LDS (not back from global memory)
-    if (t == 0) { prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, &srec - v, cold, traj_off, n_traj, wp_stride); rec[v] = srec; }
+    if (t == 0) { prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, &srec - v, cold, traj_off, n_traj, wp_stride, traj_rows); rec[v] = srec; }
     __syncthreads();
     TO_STAMP(TO_STAMP_PROBE, 1);   // record built, samples requested
     const WayRec r = srec;
@@ -711,8 +728,9 @@ struct SparseArgs {
     int V, nslots, vwords, fv_words;
     const unsigned long long* cbits;   // candidate (slot, trajectory) bits (pass 1): n_traj rows of fv_words words
     const unsigned long long* live;    // culled pass 1: bit (v, slot) = the pair was evaluated (part holds it); NULL: all were
-    int2* plist;                 // the step's flagged (slot, waypoint) pairs, *npairs of them, in no particular order
-    int* npairs;                 //   (FWD / FUSED append, the pair kernel reads)
+    int2* plist;                 // the step's flagged (slot, waypoint) pairs: TO_PL_SHARDS sub-lists of plcap entries, in no particular order
+    int* npairs;                 //   their lengths, TO_PL_STRIDE ints apart (FWD / FUSED append, the pair kernel reads)
+    int64_t plcap;
     unsigned long long* fv;
     TieRec* ties;
     float* lo_sum;               // n_traj x npad; FWD / FUSED write the flagged slots, BWD reads
@@ -740,11 +758,14 @@ struct __attribute__((aligned(16))) StagedWay {
 };
 static_assert(sizeof(StagedWay) == 80, "StagedWay is 20 floats");
 
+// NW = waves of the block (16 or 4); SFW = flag words held (TO_SP_MAXW, or 8 where one trajectory of at most TO_SP_STAGE virtual
+// waypoints is all there is: 36 KB instead of 44, four 4-wave blocks to a CU)
+template <int NW, int SFW>
 struct SparseLds {
-    unsigned long long sflag[TO_SP_MAXW];
+    unsigned long long sflag[SFW];
     StagedWay stage[TO_SP_STAGE];
-    float4 spart[TO_SP_WAVES][64];
-    int any[TO_SP_WAVES];
+    float4 spart[TO_SP_WAVES][64];   // the SIXTEEN partial sums of a slot (rank & 15), whatever NW is
+    int any[NW];
     int pbase;
 };
 
@@ -770,10 +791,14 @@ __device__ __forceinline__ void stage_way(const SparseArgs& a, int v, StagedWay&
 }
 
 // one candidate slot for trajectory tr — its virtual waypoints [v_lo, v_hi), its own log-odds vector, rewards, sums and rank
-// count, so that its results are the ones a run of that trajectory alone produces; blockDim.x = TO_SP_THREADS.  Returns with
+// count, so that its results are the ones a run of that trajectory alone produces; blockDim.x = 64 NW.  Returns with
 // every thread past its last use of the LDS.
-template <int MODE, bool OCC>
-__device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int tr, int acc_line, SparseLds& L) {
+// The slot's flagged waypoints, in ascending order, go to SIXTEEN partial sums by rank & 15, added up in the order 0..15: a
+// 16-wave block keeps one per wave, a 4-wave block four per wave (ranks w, w + 4, w + 8, w + 12 mod 16) — the same sixteen sums
+// in the same order, hence the same bits whichever block shape the host picks.
+template <int MODE, bool OCC, int NW, int SFW>
+__device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int tr, int acc_line, SparseLds<NW, SFW>& L) {
+    constexpr int NSET = TO_SP_WAVES / NW;   // partial sums a wave keeps
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     TO_STAMP(TO_STAMP_SPARSE, 1);   // the block's candidate is known
     const EvalK& k = a.k;
@@ -786,6 +811,7 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
 
     const int v_lo = a.toff ? a.toff[tr] * a.C : 0, v_hi = a.toff ? a.toff[tr + 1] * a.C : a.V;
     const int w_lo = v_lo >> 6, w_hi = min(a.vwords, (v_hi + 63) >> 6);
+    const int wb = SFW < TO_SP_MAXW ? w_lo : 0;   // L.sflag[w - wb]: the small array holds the trajectory's own words only
     // A trajectory of up to TO_SP_STAGE virtual waypoints is staged whole, entry v - v_lo, with the block's first loads: which
     // waypoints are flagged is known two dependent loads later, and what is staged does not depend on it.
     const bool direct = v_hi - v_lo <= TO_SP_STAGE;   // block-uniform
@@ -794,7 +820,7 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
     if (stager) stage_way(a, v_lo + t, sw);   // into registers: its loads are in flight beside those of the flags below
     // ---- flags of this slot, one word per 64 waypoints ----
     int mine = 0;
-    for (int w = w_lo + wave; w < w_hi; w += TO_SP_WAVES) {
+    for (int w = w_lo + wave; w < w_hi; w += NW) {
         const int v = w * 64 + lane;
         bool flag = false;
         if (v >= v_lo && v < v_hi) {
@@ -811,7 +837,7 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
             if (flag) atomicOr(&a.fv[(int64_t)v * a.fv_words + (slot >> 6)], 1ull << (slot & 63));
         }
         const unsigned long long word = __ballot(flag);
-        if (lane == 0) L.sflag[w] = word;
+        if (lane == 0) L.sflag[w - wb] = word;
         mine += __popcll(word);
     }
     if (stager) L.stage[t] = sw;
@@ -820,20 +846,20 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
     TO_STAMP(TO_STAMP_SPARSE, 2);   // flags, staged records
     int npairs = 0;
 #pragma unroll
-    for (int w = 0; w < TO_SP_WAVES; ++w) npairs += L.any[w];
+    for (int w = 0; w < NW; ++w) npairs += L.any[w];
     if (npairs == 0) { __syncthreads(); return; }   // a candidate that is not flagged after all: lo_sum 0, rewards 1/2 (pass 1 wrote them)
     // room for the slot's pairs in the step's pair list: asked for by a thread with no other load in flight, wanted at the end
     // (an offset the compiler cannot see through keeps the add a plain one-lane atomic: the wave-aggregated form it would build
     // for a uniform address waits for the result on the spot)
     int pbase = 0;
-    if (t == TO_SP_THREADS - 1) {
+    if (t == NW * 64 - 1) {
         int zero = 0;
         asm volatile("" : "+v"(zero));
-        pbase = atomicAdd(a.npairs + zero, npairs);
+        pbase = atomicAdd(a.npairs + (slot & (TO_PL_SHARDS - 1)) * TO_PL_STRIDE + zero, npairs);
     }
 
     {
-        auto flagged = [&](int w) { return uniform_u64(L.sflag[w]); };
+        auto flagged = [&](int w) { return uniform_u64(L.sflag[w - wb]); };
         // stage the flagged waypoints of words [wc, wc + CW): entry = rank inside the chunk; returns their number
         auto stage_chunk = [&](int wc) {
             int cnt = 0, my_rank = -1, my_v = -1;
@@ -850,36 +876,46 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
         };
         float lo[4];
         {
-            f2 acc0 = pk_splat(0.f), acc1 = pk_splat(0.f);
-            auto add_way = [&](const StagedWay& r) {
+            f2 acc0[NSET], acc1[NSET];
+#pragma unroll
+            for (int q = 0; q < NSET; ++q) { acc0[q] = pk_splat(0.f); acc1[q] = pk_splat(0.f); }
+            auto add_way = [&](const StagedWay& r, f2& s0, f2& s1) {
                 float om[4];
                 load_occ<4, OCC>(a.occ, a.occw, r.v, base, om);
                 const f2 p0 = vis_p_pk(r, k, f2{x[0], x[1]}, f2{y[0], y[1]}, f2{z[0], z[1]}) * f2{om[0], om[1]};
                 const f2 p1 = vis_p_pk(r, k, f2{x[2], x[3]}, f2{y[2], y[3]}, f2{z[2], z[3]}) * f2{om[2], om[3]};
                 // a degenerate waypoint (staged with 1/M = NaN) makes every log-odds NaN, whatever med3 does with one; else + 0
                 const f2 poison = pk_splat(r.invM != r.invM ? __builtin_nanf("") : 0.f);
-                acc0 = acc0 + (log_odds_pk(k, r.a, r.invM, p0) + poison);
-                acc1 = acc1 + (log_odds_pk(k, r.a, r.invM, p1) + poison);
+                s0 = s0 + (log_odds_pk(k, r.a, r.invM, p0) + poison);
+                s1 = s1 + (log_odds_pk(k, r.a, r.invM, p1) + poison);
+            };
+            // the wave's share of rank kk (wave == kk mod NW): partial sum (kk & 15) = set (kk / NW) mod NSET of this wave
+            auto add_rank = [&](const StagedWay& r, int kk) {
+                const int set = (kk / NW) & (NSET - 1);
+#pragma unroll
+                for (int q = 0; q < NSET; ++q)
+                    if (q == set) add_way(r, acc0[q], acc1[q]);
             };
             int rank0 = 0;
-            if (direct) {   // the flagged waypoints in ascending order, rank r to wave r & 15 — the order of the chunked walk below.
+            if (direct) {   // the flagged waypoints in ascending order, rank r to partial sum r & 15 — the order of the chunked walk below.
                 // A wave goes straight to its ranks (a walk over every flagged bit by every wave was 2 us of a dense cloud's slot)
-                for (int kk = wave; kk < npairs; kk += TO_SP_WAVES) {
+                for (int kk = wave; kk < npairs; kk += NW) {
                     int r = kk, w = w_lo;
                     unsigned long long bits = flagged(w);
                     while (r >= __popcll(bits)) { r -= __popcll(bits); bits = flagged(++w); }   // at most five words
                     const bool hit = ((bits >> lane) & 1ull) && __popcll(bits & ((1ull << lane) - 1ull)) == r;
-                    add_way(L.stage[w * 64 + __builtin_ctzll(__ballot(hit)) - v_lo]);
+                    add_rank(L.stage[w * 64 + __builtin_ctzll(__ballot(hit)) - v_lo], kk);
                 }
             }
             for (int wc = w_lo; wc < w_hi && !direct; wc += TO_SP_CW) {
                 const int cnt = stage_chunk(wc);
-                for (int e = ((wave - rank0) & (TO_SP_WAVES - 1)); e < cnt; e += TO_SP_WAVES) add_way(L.stage[e]);   // rank0 + e == wave (mod 16)
+                for (int e = ((wave - rank0) & (NW - 1)); e < cnt; e += NW) add_rank(L.stage[e], rank0 + e);   // rank0 + e == wave (mod NW)
                 rank0 += cnt;
                 if (wc + TO_SP_CW < w_hi) __syncthreads();   // the stage is rewritten by the next chunk
             }
             TO_STAMP(TO_STAMP_SPARSE, 3);   // wave 0's share of the forward sweep
-            L.spart[wave][lane] = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
+#pragma unroll
+            for (int q = 0; q < NSET; ++q) L.spart[wave + NW * q][lane] = make_float4(acc0[q].x, acc0[q].y, acc1[q].x, acc1[q].y);
             __syncthreads();
             TO_STAMP(TO_STAMP_SPARSE, 4);   // every wave's
             float4 s = L.spart[0][lane];
@@ -915,17 +951,17 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
             }
         }
         TO_STAMP(TO_STAMP_SPARSE, 5);   // sums, rewards
-        if (t == TO_SP_THREADS - 1) L.pbase = pbase;   // (a device-scope atomic's answer takes microseconds: first read here)
+        if (t == NW * 64 - 1) L.pbase = pbase;   // (a device-scope atomic's answer takes microseconds: first read here)
         __syncthreads();
         TO_STAMP(TO_STAMP_SPARSE, 6);   // the pair list's answer
     }
     // the slot's pairs: a position each (the waves' counts, then the wave's words in its order, then the bit's rank)
     {
-        int at = L.pbase;
+        int64_t at = (int64_t)(slot & (TO_PL_SHARDS - 1)) * a.plcap + L.pbase;
 #pragma unroll
-        for (int w = 0; w < TO_SP_WAVES; ++w) at += w < wave ? L.any[w] : 0;
-        for (int w = w_lo + wave; w < w_hi; w += TO_SP_WAVES) {
-            const unsigned long long word = uniform_u64(L.sflag[w]);
+        for (int w = 0; w < NW; ++w) at += w < wave ? L.any[w] : 0;
+        for (int w = w_lo + wave; w < w_hi; w += NW) {
+            const unsigned long long word = uniform_u64(L.sflag[w - wb]);
             if ((word >> lane) & 1ull) a.plist[at + __popcll(word & ((1ull << lane) - 1ull))] = make_int2(slot, w * 64 + lane);
             at += __popcll(word);
         }
@@ -947,8 +983,8 @@ __device__ __forceinline__ void write_minmax(const SparseArgs& a) {
 // block b of nb works for trajectory b % n_traj: the q-th, (q + S)-th, ... set bit of that trajectory's candidate bits (bit s =
 // slot s), q = b / n_traj, S = nb / n_traj (the host launches a multiple of n_traj blocks).  Every wave finds them from the same
 // popcount prefix, 64 words at a time (one 16-wave block is resident per CU at this kernel's register count).
-template <int MODE, bool OCC>
-__device__ __forceinline__ void sparse_walk(const SparseArgs& a, int b, int nb, SparseLds& L) {
+template <int MODE, bool OCC, int NW, int SFW>
+__device__ __forceinline__ void sparse_walk(const SparseArgs& a, int b, int nb, SparseLds<NW, SFW>& L) {
     const int lane = threadIdx.x & 63;
     const int tr = b % a.n_traj, S = nb / a.n_traj;
     const unsigned long long* bits = a.cbits + (int64_t)tr * a.fv_words * TO_CBIT_STRIDE;
@@ -969,19 +1005,19 @@ __device__ __forceinline__ void sparse_walk(const SparseArgs& a, int b, int nb, 
             const int rr = rnk - __shfl(incl - pc, f);
             const unsigned long long wf = uniform_u64((unsigned long long)__shfl((long long)word, f));
             const bool hit = ((wf >> lane) & 1ull) && __popcll(wf & ((1ull << lane) - 1ull)) == rr;
-            sparse_slot<MODE, OCC>(a, (c0 + f) * 64 + __builtin_ctzll(__ballot(hit)), tr, b & 7, L);
+            sparse_slot<MODE, OCC, NW, SFW>(a, (c0 + f) * 64 + __builtin_ctzll(__ballot(hit)), tr, b & 7, L);
             next += S;
         }
         carry += tot;
     }
 }
 
-template <int MODE, bool OCC>
-__global__ void __launch_bounds__(TO_SP_THREADS) k_traj_sparse(SparseArgs a) {
-    __shared__ SparseLds L;
+template <int MODE, bool OCC, int NW, int SFW>
+__global__ void __launch_bounds__(NW * 64, (NW == 16 || SFW == 8) ? 4 : 3) k_traj_sparse(SparseArgs a) {   // (4 waves per SIMD: 128 registers; 3 where the LDS allows no more)
+    __shared__ SparseLds<NW, SFW> L;
     TO_STAMP(TO_STAMP_SPARSE, 0);
     if (blockIdx.x == 0) write_minmax(a);
-    sparse_walk<MODE, OCC>(a, (int)blockIdx.x, (int)gridDim.x, L);
+    sparse_walk<MODE, OCC, NW, SFW>(a, (int)blockIdx.x, (int)gridDim.x, L);
     TO_STAMP(TO_STAMP_SPARSE, 7);
 }
 
@@ -1076,22 +1112,49 @@ __device__ __forceinline__ void pair_walk(const SparseArgs& a, int b, int nb) {
     const int lane = threadIdx.x & 63;
     TO_STAMP(TO_STAMP_PAIRS, 0);
     const int gw = __builtin_amdgcn_readfirstlane(b * TO_SP_WAVES + (int)(threadIdx.x >> 6)), GW = nb * TO_SP_WAVES;
-    // the wave's first pair is requested with the list's length, not after it (an entry beyond the length is last step's: unused)
-    const int64_t cap = (int64_t)a.V * a.nslots;
-    int2 next = gw < cap ? a.plist[gw] : make_int2(0, 0);
-    const int P = *a.npairs;
-    TO_STAMP(TO_STAMP_PAIRS, 1);   // the list's length and the wave's first pair
+    // lane l holds sub-list l's length; the step's pairs are numbered through the sub-lists in order (an inclusive scan), and the
+    // grid's waves take the numbers gw, gw + GW, ...: the chip is evenly loaded whatever the sub-lists' lengths
+    const int cnt = a.npairs[lane * TO_PL_STRIDE];
+    int incl = cnt;
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        const int up = __shfl_up(incl, sh);
+        if (lane >= sh) incl += up;
+    }
+    const int excl = incl - cnt;
+    const int P = __shfl(incl, 63);
+    auto entry = [&](int p) {   // the p-th pair: in the first sub-list whose inclusive count exceeds p
+        const int l = __popcll(__ballot(incl <= p));
+        return a.plist[(int64_t)l * a.plcap + (p - __shfl(excl, l))];
+    };
+    int2 next = gw < P ? entry(gw) : make_int2(0, 0);
+    TO_STAMP(TO_STAMP_PAIRS, 1);   // the lists' lengths and the wave's first pair
     for (int p = gw; p < P; p += GW) {
         const int2 cur = next;
-        if (p + GW < P) next = a.plist[p + GW];
+        if (p + GW < P) next = entry(p + GW);
         pair_sums<OCC>(a, __builtin_amdgcn_readfirstlane(cur.x), __builtin_amdgcn_readfirstlane(cur.y), lane);
     }
     TO_STAMP(TO_STAMP_PAIRS, 2);
 }
 
+// os.mode == 2 (model() as one library call, loss_kernels.hip): one block more than the pairs need turns the integer reward sum
+// — complete since k_traj_sparse — and the prologue's regulariser terms into model()'s scalars and loss terms.
 template <bool OCC>
-__global__ void __launch_bounds__(TO_SP_THREADS) k_traj_pairs(SparseArgs a) {
-    pair_walk<OCC>(a, (int)blockIdx.x, (int)gridDim.x);
+__global__ void __launch_bounds__(TO_SP_THREADS) k_traj_pairs(SparseArgs a, OptStep os, float* __restrict__ scalars_out) {
+    const int extra = os.mode == 2 ? 1 : 0;
+    if (extra && blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x == 0) {
+            float sc[4];
+            reward_scalars_from_a(a.acc, a.cv.n, a.shift, os.eps, sc);
+            scalars_out[0] = sc[0]; scalars_out[1] = sc[1]; scalars_out[2] = sc[2]; scalars_out[3] = sc[3];
+            const OptPro p = os.pro[0];
+            RegOut o;
+            o.l2 = p.l2; o.length = p.length; o.smooth = p.smooth;
+            write_loss_terms(os.loss_log, (double)sc[1], o);
+        }
+        return;
+    }
+    pair_walk<OCC>(a, (int)blockIdx.x, (int)gridDim.x - extra);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1183,8 +1246,7 @@ k_traj_reward_bwd(const float* __restrict__ lo_sum, int64_t n, float eps, int pr
 // vgrad[v*12 ..] = (sum dL/dc [3], sum y (x) dL/dc [9]); mrow(v) = the 9 floats m[3*i+j] = R_v[j][i].
 template <typename MRow>
 __device__ void finish_waypoint(int w, const float* __restrict__ vgrad, MRow mrow, const WayCold* __restrict__ cold, int C,
-                                const float* __restrict__ rig_q, const float* __restrict__ rig_t,
-                                float* __restrict__ poses_grad, float* __restrict__ quats_grad) {
+                                const float* __restrict__ rig_q, const float* __restrict__ rig_t, float (&out)[7]) {
     double dt[3] = {0, 0, 0}, A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // A[3*j+i] = dL/dR_w[j][i]
     for (int c = 0; c < C; ++c) {
         const int v = w * C + c;
@@ -1211,7 +1273,7 @@ __device__ void finish_waypoint(int w, const float* __restrict__ vgrad, MRow mro
             for (int kk = 0; kk < 9; ++kk) A[kk] += (double)gv[3 + kk];
         }
     }
-    for (int j = 0; j < 3; ++j) poses_grad[3 * w + j] = (float)dt[j];
+    for (int j = 0; j < 3; ++j) out[j] = (float)dt[j];
     const WayCold cd = cold[w];
     const double qw = cd.qn[0], qx = cd.qn[1], qy = cd.qn[2], qz = cd.qn[3];
 #define AA(j, i) A[3 * (j) + (i)]
@@ -1223,10 +1285,15 @@ __device__ void finish_waypoint(int w, const float* __restrict__ vgrad, MRow mro
 #undef AA
     const double dot = qw * dh[0] + qx * dh[1] + qy * dh[2] + qz * dh[3];
     const double inv = 1.0 / (double)cd.nrm;
-    quats_grad[4 * w + 0] = (float)((dh[0] - qw * dot) * inv);
-    quats_grad[4 * w + 1] = (float)((dh[1] - qx * dot) * inv);
-    quats_grad[4 * w + 2] = (float)((dh[2] - qy * dot) * inv);
-    quats_grad[4 * w + 3] = (float)((dh[3] - qz * dot) * inv);
+    out[3] = (float)((dh[0] - qw * dot) * inv);
+    out[4] = (float)((dh[1] - qx * dot) * inv);
+    out[5] = (float)((dh[2] - qy * dot) * inv);
+    out[6] = (float)((dh[3] - qz * dot) * inv);
+}
+// the gradient row of body waypoint w to the caller's arrays (either may be NULL: the row is wanted in registers only)
+__device__ __forceinline__ void store_grad_row(int w, const float (&o)[7], float* __restrict__ poses_grad, float* __restrict__ quats_grad) {
+    if (poses_grad) { poses_grad[3 * w] = o[0]; poses_grad[3 * w + 1] = o[1]; poses_grad[3 * w + 2] = o[2]; }
+    if (quats_grad) { quats_grad[4 * w] = o[3]; quats_grad[4 * w + 1] = o[4]; quats_grad[4 * w + 2] = o[5]; quats_grad[4 * w + 3] = o[6]; }
 }
 
 struct RecRows {
@@ -1238,12 +1305,24 @@ struct HotRows {
     __device__ const float* operator()(int v) const { return hot[v].m; }
 };
 
+// os.mode != 0: the thread goes on with its waypoint's share of the step's epilogue (opt_step.hpp); scalars: the trajectories'
+// (mean reward, loss_vis, ...) the finish kernel wrote in the launch before
 __global__ void k_traj_bwd_finish2(const float* __restrict__ vgrad, const WayRec* __restrict__ rec,
                                    const WayCold* __restrict__ cold, int W, int C, const float* __restrict__ rig_q,
                                    const float* __restrict__ rig_t, float* __restrict__ poses_grad,
-                                   float* __restrict__ quats_grad) {
+                                   float* __restrict__ quats_grad, OptStep os, const float* __restrict__ scalars) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < W) finish_waypoint(w, vgrad, RecRows{rec}, cold, C, rig_q, rig_t, poses_grad, quats_grad);
+    if (w >= W) return;
+    float o[7];
+    finish_waypoint(w, vgrad, RecRows{rec}, cold, C, rig_q, rig_t, o);
+    store_grad_row(w, o, poses_grad, quats_grad);
+    if (os.mode) {
+        const int b = w / os.n_eval, rr = w - b * os.n_eval;
+        const OptPro p = os.pro[b];
+        const bool stopped = os.mode == 1 && os.state_in[(int64_t)b * os.state_stride + 2] != 0.f;
+        for (int e = 0; e < 7 * os.step; ++e) opt_update_element(os, b, rr, e, o, stopped, p);
+        if (os.mode == 1 && rr == 0) opt_commit(os, b, scalars + 4 * b, p);
+    }
 }
 
 // the ModelPose path keeps its own record type (pose_kernels.hip)
@@ -1252,7 +1331,10 @@ __global__ void k_bwd_finish2(const float* __restrict__ vgrad, const WayHot* __r
                               const float* __restrict__ rig_t, float* __restrict__ poses_grad,
                               float* __restrict__ quats_grad) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < W) finish_waypoint(w, vgrad, HotRows{hot}, cold, C, rig_q, rig_t, poses_grad, quats_grad);
+    if (w >= W) return;
+    float o[7];
+    finish_waypoint(w, vgrad, HotRows{hot}, cold, C, rig_q, rig_t, o);
+    store_grad_row(w, o, poses_grad, quats_grad);
 }
 
 
@@ -1288,13 +1370,24 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
               const WayRec* __restrict__ rec, const Extrema* __restrict__ ext, EvalK k, const TieRec* __restrict__ ties,
               const float2* __restrict__ part, int V, const uint32_t* __restrict__ occ, int64_t occw, float* __restrict__ vgrad,
               const WayCold* __restrict__ cold, int single, float* __restrict__ poses_grad, float* __restrict__ quats_grad,
-              FinishPost post) {
+              FinishPost post, OptStep os) {
     constexpr int NG = THREADS / 16, PER = 64 / NG;   // groups per pass, groups per thread
     __shared__ double sgrp[64][16];
     __shared__ double stie[2][13];   // [0] argmin set, [1] argmax set: 12 sums + count
     __shared__ int srow[2][TO_TIE_CAP];
     const int v = blockIdx.x, t = threadIdx.x, kq = t & 15, g = t >> 4;
     TO_STAMP(TO_STAMP_FINISH, 0);
+    // the step's epilogue (opt_step.hpp) reads nothing this kernel computes: asked for now, used at the end
+    OptElem oel;
+    OptPro opro;
+    bool ostopped = false;
+    oel.at = -1;
+    if (os.mode && single) {
+        const int b = v / os.n_eval;
+        if (t < 7 * os.step) oel = opt_elem_load(os, b, v - b * os.n_eval, t);
+        opro = os.pro[b];
+        ostopped = os.mode == 1 && os.state_in[(int64_t)b * os.state_stride + 2] != 0.f;
+    }
     const WayRec& r = rec[v];
     float a, pmax, M, invM;
     load_norm(ext[v], a, pmax, M, invM);
@@ -1489,6 +1582,7 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
         stie[set][j] = ((stie4[set][0][j] + stie4[set][1][j]) + stie4[set][2][j]) + stie4[set][3][j];
     }
     __shared__ double stot[16];
+    __shared__ float s_sc[4];   // the trajectory's scalars (the step's epilogue wants them)
     if (t < 16) {
         double q = 0.0;
         for (int gg = 0; gg < 64; ++gg) q += sgrp[gg][t];
@@ -1497,8 +1591,9 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
         if (post.mode == 2) {
             float sc[4];
             reward_scalars_from_a(post.acc + r.seg, post.n, post.shift, post.eps, sc);
-            q *= (double)(sc[2] * post.gout[r.seg]);
+            q *= (double)(sc[2] * (post.gout ? post.gout[r.seg] : 1.0f));
             const int v_first = post.toff ? post.toff[r.seg] * post.C : 0;
+            if (t == 0) { s_sc[0] = sc[0]; s_sc[1] = sc[1]; s_sc[2] = sc[2]; s_sc[3] = sc[3]; }
             if (t == 0 && v == v_first && post.scalars_out) {
                 float* so = post.scalars_out + 4 * r.seg;
                 so[0] = sc[0]; so[1] = sc[1]; so[2] = sc[2]; so[3] = sc[3];
@@ -1528,7 +1623,22 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
     }
     if (single) {  // one camera per waypoint: the waypoint's gradient follows at once (k_traj_bwd_finish2's work, no launch)
         __syncthreads();
-        if (t == 0) finish_waypoint(v, vgrad, RecRows{rec}, cold, 1, nullptr, nullptr, poses_grad, quats_grad);
+        __shared__ float s_vis[8];
+        if (t == 0) {
+            float o[7];
+            finish_waypoint(v, vgrad, RecRows{rec}, cold, 1, nullptr, nullptr, o);
+            store_grad_row(v, o, poses_grad, quats_grad);
+            for (int kk = 0; kk < 7; ++kk) s_vis[kk] = o[kk];
+        }
+        if (os.mode) {
+            // the step's epilogue for this waypoint's rows (opt_step.hpp): full gradient, and in an optimisation step Adam; the
+            // block of a trajectory's first waypoint also writes the loss log and the next row of the early-stop state
+            __syncthreads();
+            const int b = v / os.n_eval, rr = v - b * os.n_eval;
+            opt_elem_apply(os, oel, s_vis, ostopped, opro);
+            for (int e = t + THREADS; e < 7 * os.step; e += THREADS) opt_update_element(os, b, rr, e, s_vis, ostopped, opro);   // (a stride beyond 36 waypoints)
+            if (os.mode == 1 && rr == 0 && t == 0) opt_commit(os, b, s_sc, opro);
+        }
     }
     TO_STAMP(TO_STAMP_FINISH, 5);
 }
@@ -1678,6 +1788,7 @@ struct TrajPlan {
     int fv_words;  // (nslots + 63) / 64
     int vwords;    // (V + 63) / 64
     int V;
+    int64_t plcap; // entries of one pair sub-list
     size_t off_ctl, off_toff, off_rec, off_cold, off_ext, off_cbits, off_ctr, off_part, off_fv, off_live, off_plist, off_ties, off_bpart, off_vgrad, total;
 };
 
@@ -1697,11 +1808,12 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
     p.off_cold = o;  o += align_up((size_t)W * sizeof(WayCold), 256);
     p.off_ext = o;   o += align_up((size_t)V * sizeof(Extrema), 256);
     p.off_cbits = o; o += align_up((size_t)p.ncbits * TO_CBIT_STRIDE * sizeof(unsigned long long), 256);   // a bit per (trajectory, slot): pass 1's candidates
-    p.off_ctr = o;   o += 256;                                                             // [0] the pair list's length
+    p.off_ctr = o;   o += (size_t)TO_PL_SHARDS * TO_PL_STRIDE * sizeof(int);                // the pair sub-lists' lengths, one to a 128-byte line
     p.off_part = o;  o += align_up((size_t)V * (size_t)p.nslots * sizeof(float2), 256);
     p.off_fv = o;    o += align_up((size_t)V * (size_t)p.fv_words * sizeof(unsigned long long), 256);
     p.off_live = o;  o += align_up((size_t)V * (size_t)p.fv_words * sizeof(unsigned long long), 256);   // culled pass 1: the slots a waypoint can reach, as bits
-    p.off_plist = o; o += align_up((size_t)V * (size_t)p.nslots * sizeof(int2), 256);   // every pair flagged: the same bytes as part
+    p.plcap = (int64_t)((p.nslots + TO_PL_SHARDS - 1) / TO_PL_SHARDS) * V;   // a sub-list's capacity: every pair of its slots flagged
+    p.off_plist = o; o += align_up((size_t)p.plcap * TO_PL_SHARDS * sizeof(int2), 256);
     p.off_ties = o;  o += align_up((size_t)V * sizeof(TieRec), 256);
     p.off_bpart = o; o += align_up((size_t)V * (size_t)p.nslots * 16 * sizeof(float), 256);
     p.off_vgrad = o; o += align_up((size_t)V * 12 * sizeof(float), 256);
@@ -1751,6 +1863,9 @@ struct TrajStep {
     int64_t occw;
     bool cull;
     int wp_stride = 1;   // rows between two evaluated waypoints in the arrays handed to the probe
+    int traj_rows = 0;   // > 0: rows every trajectory owns in those arrays (its evaluated waypoints are rows 0, wp_stride, ... of its own)
+    OptStep opt = OptStep{};   // mode != 0: the step's prologue / epilogue ride in the probe's, the pairs' and the finish launches (opt_step.hpp)
+    float* opt_scalars = nullptr;   // opt.mode == 2: model()'s scalars (the extra block of the pairs' launch writes them)
     RewardAcc* acc;
     WayRec* rec;
     WayCold* cold;
@@ -1792,6 +1907,8 @@ inline int traj_step_init(TrajStep& s, const void* packed, int64_t n, int64_t W,
     s.k = make_evalk(cam);
     s.cv = cloud_view(packed, n);
     s.cull = !(flags & TOHIP_TRAJ_DENSE) && s.pl.fv_words <= TO_PROBE_MAXFW;   // (beyond 16.7 M points every pair is evaluated)
+    s.wp_stride = ((flags >> 8) & 0xffff) + 1;   // TOHIP_TRAJ_STRIDE(step): the evaluated waypoints are every step-th row of poses / quats
+    if (s.wp_stride > 1 && n_traj > 1) return TOHIP_EINVAL;   // (several trajectories read in place: tohip_traj_opt_step)
     s.rq = (s.C > 1 || (rig && rig->rig_quats)) ? rig->rig_quats : nullptr;
     s.rt = s.rq ? rig->rig_trans : nullptr;
     s.toff_ws = (int*)(ws + s.pl.off_toff);
@@ -1809,12 +1926,15 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
     {
         TO_PROF(TOHIP_PROF_SMALL, s.st);
         const ProbeCull pc{s.cull ? 1 : 0, s.pl.nslots, s.live};
+        const int grid = V + (s.opt.mode ? s.opt.n_traj : 0);   // a block per trajectory behind the waypoints': the step's prologue
         if (V <= 512)
-            k_traj_probe<1024><<<V, 1024, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
-                                                     s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cbits, s.pl.ncbits, s.ctr, s.wp_stride, pc);
+            k_traj_probe<1024><<<grid, 1024, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
+                                                        s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cbits, s.pl.ncbits, s.ctr, s.wp_stride,
+                                                        s.traj_rows, pc, V, s.opt);
         else
-            k_traj_probe<256><<<V, 256, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
-                                                   s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cbits, s.pl.ncbits, s.ctr, s.wp_stride, pc);
+            k_traj_probe<256><<<grid, 256, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
+                                                      s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cbits, s.pl.ncbits, s.ctr, s.wp_stride,
+                                                      s.traj_rows, pc, V, s.opt);
         TO_HIP_CHECK_LAUNCH();
     }
     {
@@ -1838,7 +1958,7 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
 inline SparseArgs sparse_args(const TrajStep& s, float* lo_sum) {
     SparseArgs a;
     a.cv = s.cv; a.rec = s.rec; a.ext = s.ext; a.k = s.k; a.part = s.part;
-    a.V = (int)s.V; a.nslots = s.pl.nslots; a.vwords = s.pl.vwords; a.fv_words = s.pl.fv_words; a.cbits = s.cbits; a.live = s.cull ? s.live : nullptr; a.plist = s.plist; a.npairs = s.ctr;
+    a.V = (int)s.V; a.nslots = s.pl.nslots; a.vwords = s.pl.vwords; a.fv_words = s.pl.fv_words; a.cbits = s.cbits; a.live = s.cull ? s.live : nullptr; a.plist = s.plist; a.npairs = s.ctr; a.plcap = s.pl.plcap;
     a.fv = s.fv; a.ties = s.ties; a.lo_sum = lo_sum; a.minmax = nullptr; a.occ = s.occ; a.occw = s.occw;
     a.toff = s.toff; a.n_traj = (int)s.n_traj; a.C = s.C;
     a.rewards = nullptr; a.prefilled = 0; a.acc = s.acc; a.shift = s.shift;
@@ -1848,18 +1968,34 @@ inline SparseArgs sparse_args(const TrajStep& s, float* lo_sum) {
 
 // list walkers: the expected number of candidate slots on the workloads this is tuned for (6-8 % of the slots), each a chain
 // of its own; a dense cloud lists every slot and the blocks loop
-inline int sparse_blocks(const TrajStep& s) {
-    // per trajectory: as many blocks as a BASELINE step has candidate slots twice over (each a chain of its own); with several
-    // trajectories about 512 blocks in all (a block that finds nothing still costs its launch and its scan)
-    const int64_t per_traj = std::max<int64_t>(1, std::min<int64_t>(s.pl.nslots, 512 / s.n_traj));
+// 4-wave blocks, four to a CU (all resident): a candidate slot is a chain of dependent accesses of ~9 us whatever the block's
+// shape, and a 16-wave block holds a whole CU for it — 1 441 candidates (the BASELINE trajectory after a hundred optimiser steps)
+// were 5.6 rounds of 256 such blocks, 28 us.  Sixteen-wave blocks remain for experiments (TOHIP_SPARSE_WAVES=16).
+inline int sparse_waves() {
+    static const int nw = [] { const char* e = getenv("TOHIP_SPARSE_WAVES"); const int v = e ? atoi(e) : 0; return v == 16 ? 16 : 4; }();
+    return nw;
+}
+inline int sparse_blocks(const TrajStep& s, int nw) {
+    // per trajectory: one block per candidate while they fit on the chip at once (a block that finds nothing still costs its
+    // launch and its scan); with several trajectories that many in all
+    const int64_t resident = nw == 16 ? 512 : 1024;
+    const int64_t per_traj = std::max<int64_t>(1, std::min<int64_t>(s.pl.nslots, resident / s.n_traj));
     return (int)(per_traj * s.n_traj);
+}
+
+template <int MODE, bool OCC, int NW>
+inline void launch_sparse_nw(const TrajStep& s, const SparseArgs& a) {
+    const int grid = sparse_blocks(s, NW);
+    // one trajectory of at most TO_SP_STAGE virtual waypoints: its five flag words are all a block holds
+    if (s.n_traj == 1 && s.V <= TO_SP_STAGE) k_traj_sparse<MODE, OCC, NW, 8><<<grid, NW * 64, 0, s.st>>>(a);
+    else k_traj_sparse<MODE, OCC, NW, TO_SP_MAXW><<<grid, NW * 64, 0, s.st>>>(a);
 }
 
 template <int MODE>
 inline int launch_sparse(const TrajStep& s, const SparseArgs& a) {
-    const int grid = sparse_blocks(s);
-    if (s.occ) k_traj_sparse<MODE, true><<<grid, TO_SP_THREADS, 0, s.st>>>(a);
-    else k_traj_sparse<MODE, false><<<grid, TO_SP_THREADS, 0, s.st>>>(a);
+    const bool w16 = sparse_waves() == 16;
+    if (s.occ) { if (w16) launch_sparse_nw<MODE, true, 16>(s, a); else launch_sparse_nw<MODE, true, 4>(s, a); }
+    else { if (w16) launch_sparse_nw<MODE, false, 16>(s, a); else launch_sparse_nw<MODE, false, 4>(s, a); }
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
@@ -1876,8 +2012,9 @@ inline int pair_blocks() {
 }
 
 inline int launch_pairs(const TrajStep& s, const SparseArgs& a) {
-    if (s.occ) k_traj_pairs<true><<<pair_blocks(), TO_SP_THREADS, 0, s.st>>>(a);
-    else k_traj_pairs<false><<<pair_blocks(), TO_SP_THREADS, 0, s.st>>>(a);
+    const int grid = pair_blocks() + (s.opt.mode == 2 ? 1 : 0);
+    if (s.occ) k_traj_pairs<true><<<grid, TO_SP_THREADS, 0, s.st>>>(a, s.opt, s.opt_scalars);
+    else k_traj_pairs<false><<<grid, TO_SP_THREADS, 0, s.st>>>(a, s.opt, s.opt_scalars);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
@@ -1888,13 +2025,14 @@ inline int launch_finish(const TrajStep& s, const FinishPost& post, float* poses
     const int V = (int)s.V;
     if (V <= 512)
         k_traj_finish<1024><<<V, 1024, 0, s.st>>>(s.cv, s.bpart, s.pl.nslots, s.fv, s.pl.fv_words, s.rec, s.ext, s.k, s.ties, s.part, V, s.occ, s.occw,
-                                                  s.vgrad, s.cold, single ? 1 : 0, poses_grad, quats_grad, post);
+                                                  s.vgrad, s.cold, single ? 1 : 0, poses_grad, quats_grad, post, s.opt);
     else
         k_traj_finish<256><<<V, 256, 0, s.st>>>(s.cv, s.bpart, s.pl.nslots, s.fv, s.pl.fv_words, s.rec, s.ext, s.k, s.ties, s.part, V, s.occ, s.occw,
-                                                s.vgrad, s.cold, single ? 1 : 0, poses_grad, quats_grad, post);
+                                                s.vgrad, s.cold, single ? 1 : 0, poses_grad, quats_grad, post, s.opt);
     TO_HIP_CHECK_LAUNCH();
     if (!single) {
-        k_traj_bwd_finish2<<<(int)((s.W + 63) / 64), 64, 0, s.st>>>(s.vgrad, s.rec, s.cold, (int)s.W, s.C, s.rq, s.rt, poses_grad, quats_grad);
+        k_traj_bwd_finish2<<<(int)((s.W + 63) / 64), 64, 0, s.st>>>(s.vgrad, s.rec, s.cold, (int)s.W, s.C, s.rq, s.rt, poses_grad, quats_grad, s.opt,
+                                                                    post.scalars_out);
         TO_HIP_CHECK_LAUNCH();
     }
     return TOHIP_OK;
@@ -2075,6 +2213,66 @@ extern "C" int tohip_traj_forward_backward(const void* packed, int64_t n, const 
                                              scalars, gout, poses_grad, quats_grad, workspace, workspace_bytes, stream_);
 }
 
+// ---- one step of TrajOpt.run (trajectory_optimization.py:100-127) as ONE call and FIVE launches ------------------------------
+// zero_grad(); loss = model(); loss.backward(); optimizer.step(); early-stop bookkeeping — for n_traj trajectories over one cloud.
+// The waypoint selection is a stride of the probe's reads, the regularisers and the step's Adam constants are extra blocks of
+// the probe's launch, the parameter update and the bookkeeping are the tail of every k_traj_finish block (opt_step.hpp).
+namespace {
+struct OptLayout { size_t off_pro, off_reg, total; };
+inline OptLayout opt_layout(int64_t W, int64_t n_traj) {
+    OptLayout l;
+    size_t o = 0;
+    l.off_pro = o; o += align_up(sizeof(OptPro) * (size_t)n_traj, 256);
+    l.off_reg = o; o += align_up(sizeof(float) * 3 * (size_t)W * (size_t)n_traj, 256);
+    l.total = o;
+    return l;
+}
+}  // namespace
+
+extern "C" size_t tohip_traj_opt_scratch_bytes(int64_t n_wps, int64_t n_traj) {
+    if (n_wps <= 0 || n_traj <= 0) return 0;
+    return opt_layout(n_wps, n_traj).total;
+}
+
+extern "C" int tohip_traj_opt_step(const tohip_traj_opt* o, int32_t step_index, void* stream_) {
+    if (!o || !o->packed || !o->poses || !o->quats || !o->poses0 || !o->exp_avg_p || !o->exp_avg_sq_p || !o->exp_avg_q || !o->exp_avg_sq_q ||
+        !o->poses_grad || !o->quats_grad || !o->lo_sum || !o->minmax || !o->rewards || !o->scalars || !o->loss_log || !o->state_log ||
+        !o->workspace || !o->scratch || o->n_points <= 0 || o->n_wps < 3 || o->wps_step < 1 || o->n_traj < 1 || step_index < 0 ||
+        step_index >= o->n_steps || (o->n_traj > 1 && !o->traj_offsets) || (o->flags >> 8) != 0)
+        return TOHIP_EINVAL;
+    const int64_t W = o->n_wps, B = o->n_traj, n_eval = (W + o->wps_step - 1) / o->wps_step;
+    const OptLayout l = opt_layout(W, B);
+    if (o->scratch_bytes < l.total) return TOHIP_ENOSPC;
+    const tohip_rig* rig = (o->rig.n_cams > 0 && o->rig.rig_quats) ? &o->rig : nullptr;
+    TrajStep s;
+    int rc = traj_step_init(s, o->packed, o->n_points, B * n_eval, B, o->traj_offsets, &o->cam, rig, o->flags, nullptr, o->workspace,
+                            o->workspace_bytes, stream_, true);
+    if (rc != TOHIP_OK) return rc;
+    s.wp_stride = o->wps_step;
+    s.traj_rows = (int)W;
+    OptStep& a = s.opt;
+    a.mode = 1;
+    a.poses = o->poses; a.quats = o->quats; a.poses0 = o->poses0;
+    a.mp = o->exp_avg_p; a.vp = o->exp_avg_sq_p; a.mq = o->exp_avg_q; a.vq = o->exp_avg_sq_q;
+    a.pg = o->poses_grad; a.qg = o->quats_grad;
+    a.pro = (OptPro*)((char*)o->scratch + l.off_pro);
+    a.reg = (float*)((char*)o->scratch + l.off_reg);
+    a.reg_terms = nullptr;
+    a.loss_log = o->loss_log;
+    a.log_stride = (int64_t)o->n_steps * 8;
+    a.state_stride = ((int64_t)o->n_steps + 1) * TO_OPT_STATE;
+    a.state_in = o->state_log + (int64_t)step_index * TO_OPT_STATE;
+    a.state_out = o->state_log + ((int64_t)step_index + 1) * TO_OPT_STATE;
+    a.gout = nullptr;
+    a.W = (int)W; a.n_eval = (int)n_eval; a.step = o->wps_step; a.n_traj = (int)B;
+    a.smooth_w = o->smoothness_weight; a.length_w = o->traj_length_weight; a.eps = o->cam.eps;
+    a.lr_pose = o->lr_pose; a.lr_quat = o->lr_quat; a.beta1 = o->beta1; a.beta2 = o->beta2; a.adam_eps = o->adam_eps;
+    a.rewards_th = o->rewards_th; a.smoothness_th = o->smoothness_th;
+    rc = traj_fused_forward(s, o->poses, o->quats, o->lo_sum, o->minmax, o->rewards);
+    if (rc != TOHIP_OK) return rc;
+    return launch_finish(s, finish_post(s, 2, nullptr, nullptr, o->scalars, o->cam.eps), o->poses_grad_eval, o->quats_grad_eval);
+}
+
 // ---- the log-odds vector of a waypoint-sharded step, compacted for its all-reduce ---------------------------------------------
 // A rank's partial log-odds vector is exactly zero outside the slots its pass 1 listed as candidates (6-8 % of the slots on the
 // BASELINE workloads).  The ranks MAX-reduce a 0/1 flag per slot (16 KB at 1 M points), pack the slots of the union — the same
@@ -2166,7 +2364,12 @@ __global__ void k_traj_stats(const unsigned long long* __restrict__ cbits, int n
     for (int s = 32; s > 0; s >>= 1) { c += __shfl_xor(c, s); e += __shfl_xor(e, s); }
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&stats[1], c);
     if ((threadIdx.x & 63) == 0 && e) atomicAdd(&stats[4], e);
-    if (threadIdx.x == 0) { stats[0] = (unsigned long long)ctr[0]; stats[2] = (unsigned long long)nslots; stats[3] = (unsigned long long)V; }
+    if (threadIdx.x == 0) {
+        unsigned long long np = 0;
+        for (int l = 0; l < TO_PL_SHARDS; ++l) np += (unsigned long long)ctr[l * TO_PL_STRIDE];
+        stats[0] = np;
+    }
+    if (threadIdx.x == 0) { stats[2] = (unsigned long long)nslots; stats[3] = (unsigned long long)V; }
 }
 
 extern "C" int tohip_traj_step_stats(int64_t n_points, int64_t n_virtual, int64_t n_traj, const void* workspace, size_t workspace_bytes,

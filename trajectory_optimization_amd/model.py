@@ -369,7 +369,8 @@ class _LossPlan:
         c.reg_terms = self.reg_terms.data_ptr()
         self.c, self.ref = c, ctypes.byref(c)
         self.model = model
-        self.fwd, self.bwd = L.tohip_traj_loss_forward, L.tohip_traj_loss_backward
+        self.fwd, self.bwd, self.refresh = L.tohip_traj_loss_forward, L.tohip_traj_loss_backward, L.tohip_traj_loss_refresh
+        self.sums_stale = False   # True: a general backward (tohip_traj_backward) has overwritten the unit-gradient pair sums
         self.dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
         self.dev = dev
         self.f32 = dict(dtype=torch.float32, device=dev)
@@ -378,6 +379,7 @@ class _LossPlan:
     def forward(self, poses, quats, rewards, terms):
         idx = self.dev_index
         self.ws.generation += 1
+        self.sums_stale = False
         if torch.cuda.current_device() == idx:
             rc = self.fwd(self.ref, poses.data_ptr(), quats.data_ptr(), rewards.data_ptr(), terms.data_ptr(),
                           torch._C._cuda_getCurrentRawStream(idx))
@@ -399,13 +401,29 @@ class _LossPlan:
 
     def backward(self, gout, pg, qg):
         idx = self.dev_index
-        if torch.cuda.current_device() == idx:
-            rc = self.bwd(self.ref, gout.data_ptr(), pg.data_ptr(), qg.data_ptr(), torch._C._cuda_getCurrentRawStream(idx))
-        else:
-            with torch.cuda.device(idx):
-                rc = self.bwd(self.ref, gout.data_ptr(), pg.data_ptr(), qg.data_ptr(), torch._C._cuda_getCurrentRawStream(idx))
+        with torch.cuda.device(idx) if torch.cuda.current_device() != idx else _NOOP:
+            stream = torch._C._cuda_getCurrentRawStream(idx)
+            if self.sums_stale:
+                # a backward through model.rewards / single loss terms of this step ran before: it left ITS sums (scaled by its
+                # upstream gradient) where this one expects the unit-gradient ones — take them again (same pairs, same bits)
+                rc = self.refresh(self.ref, stream)
+                if rc:
+                    check(rc, "tohip_traj_loss_refresh")
+                self.sums_stale = False
+            rc = self.bwd(self.ref, gout.data_ptr(), pg.data_ptr(), qg.data_ptr(), stream)
         if rc:
             check(rc, "tohip_traj_loss_backward")
+
+
+class _Noop:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOOP = _Noop()
 
 
 class _FastBackward:
@@ -421,7 +439,10 @@ class _FastBackward:
 
     def usable(self, loss):
         p, q = self.params
-        return (loss.grad_fn is self.node and p.requires_grad and q.requires_grad and p._backward_hooks is None and q._backward_hooks is None and
+        # (hooks registered on the Parameters' AccumulateGrad NODES — DDP does that — cannot be seen from Python: set
+        # model.fast_backward = False under such wrappers)
+        return (loss.grad_fn is self.node and loss._backward_hooks is None and not loss.retains_grad and
+                p.requires_grad and q.requires_grad and p._backward_hooks is None and q._backward_hooks is None and
                 getattr(p, "_post_accumulate_grad_hooks", None) is None and getattr(q, "_post_accumulate_grad_hooks", None) is None and
                 (p.grad is None or _plain_grad(p)) and (q.grad is None or _plain_grad(q)) and not torch.is_anomaly_enabled())
 
@@ -571,6 +592,7 @@ class _TrajLossPlan(torch.autograd.Function):
         kw = _vis_upstream(g_loss, _f32(g_vis), g_rewards, plan.scalars)
         if kw is not None:
             pg, qg = ops.traj_backward(m._cloud, plan.n_eval, m._cam, plan.ws, plan.lo_sum, rig=m._rig, flags=m._flags, **kw)
+            plan.sums_stale = True   # the pair sums in the workspace are now scaled by THIS upstream gradient
         pg_all, qg_all = _assemble_grads(m, plan.step_w, plan.W, 0, plan.n_eval, pg, qg, g_loss, (g_l2, g_length, g_smooth), plan.reg_sum,
                                          plan.reg_terms, plan.dev)
         return pg_all, qg_all, None
@@ -795,7 +817,7 @@ class ModelTraj(nn.Module):
         N_wps = len(self.poses)
         wps_step = self._wps_step(vis_wps_dist)
         if self.fused_loss and N_wps >= 3 and type(self).criterion is ModelTraj.criterion:
-            if self._occlusion is None and self._shard.world_size == 1:
+            if self._occlusion is None and self._shard.world_size == 1 and not getattr(self._shard, "_always", False):
                 plan = self._plan(wps_step)
                 loss, self.rewards, vis, l2, length, smooth = _TrajLossPlan.apply(self.poses, self.quats, plan)
                 if type(loss) is _Loss and loss.requires_grad:

@@ -8,6 +8,8 @@ synchronisation until the run ends: the stop flag lives on the device and turns 
 
 The classes in model.py + torch.optim.Adam remain the drop-in path; this module is the launch-only fast path.
 """
+import ctypes
+
 import torch
 
 from . import _lib, ops
@@ -20,18 +22,111 @@ class TrajOptResult:
         self.visibility_gain, self.smoothness_gain = vis_gain, smooth_gain
 
 
+class _OptRun:
+    """One device-resident optimisation run as the library sees it (struct tohip_traj_opt): B equal-length trajectories over one
+    packed cloud, every per-step vector allocated once; step(i) is ONE library call — five launches (tohip_traj_opt_step)."""
+
+    def __init__(self, models, n_opt_steps, lr_pose, lr_quat, rewards_th, smoothness_th, vis_wps_dist, betas, adam_eps):
+        L = _lib.lib()
+        m0 = models[0]
+        self.models, self.B, self.dev, self.n_steps = models, len(models), m0.device, max(int(n_opt_steps), 1)
+        B, dev = self.B, self.dev
+        cloud, rig = m0._cloud, m0._rig
+        W = self.W = m0.poses.shape[0]
+        step_w = m0._wps_step(vis_wps_dist)
+        n_eval = self.n_eval = (W + step_w - 1) // step_w
+        C = rig.n_cams if rig else 1
+        f32 = dict(dtype=torch.float32, device=dev)
+        if B == 1:   # the Parameters themselves are updated in place
+            self.poses, self.quats, self.poses0 = m0.poses.data, m0.quats.data, m0.poses0.contiguous()
+        else:
+            self.poses = torch.cat([m.poses.data for m in models]).contiguous()
+            self.quats = torch.cat([m.quats.data for m in models]).contiguous()
+            self.poses0 = torch.cat([m.poses0 for m in models]).contiguous()
+        if not (self.poses.is_contiguous() and self.quats.is_contiguous() and self.poses.dtype == torch.float32 and self.quats.dtype == torch.float32):
+            raise RuntimeError("optimize_trajectory: poses / quats must be contiguous float32 tensors")
+        self.toff = (torch.arange(B + 1, dtype=torch.int32) * n_eval).to(dev) if B > 1 else None
+        self.ws = m0._workspace(n_eval) if B == 1 else ops.TrajWorkspace(cloud, B * n_eval * C, B)
+        self.pg, self.qg = torch.zeros((B * W, 3), **f32), torch.zeros((B * W, 4), **f32)
+        self.lo_sum = torch.empty((B, cloud.npad), **f32)
+        self.minmax = torch.empty((B * n_eval * C, 2), **f32)
+        self.rewards, self.scalars = torch.empty((B, cloud.n), **f32), torch.zeros((B, 4), **f32)
+        self.loss_log = torch.zeros((B, self.n_steps, 8), **f32)
+        self.state_log = torch.zeros((B, self.n_steps + 1, 8), **f32)
+        self.moments = [torch.zeros((B * W, 3), **f32), torch.zeros((B * W, 3), **f32), torch.zeros((B * W, 4), **f32), torch.zeros((B * W, 4), **f32)]
+        nbytes = L.tohip_traj_opt_scratch_bytes(W, B)
+        self.scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        c = _lib.TrajOpt()
+        c.packed, c.n_points, c.n_wps, c.wps_step, c.flags, c.n_traj, c.n_steps = cloud.blob.data_ptr(), cloud.n, W, step_w, int(m0._flags), B, self.n_steps
+        c.traj_offsets = self.toff.data_ptr() if self.toff is not None else None
+        c.cam = m0._cam.c
+        if rig is not None:
+            c.rig = rig.c
+        c.poses, c.quats, c.poses0 = self.poses.data_ptr(), self.quats.data_ptr(), self.poses0.data_ptr()
+        c.smoothness_weight, c.traj_length_weight = float(m0.smoothness_weight), float(m0.traj_length_weight)
+        c.lr_pose, c.lr_quat, c.beta1, c.beta2, c.adam_eps = float(lr_pose), float(lr_quat), float(betas[0]), float(betas[1]), float(adam_eps)
+        c.rewards_th, c.smoothness_th = float(rewards_th), float(smoothness_th)
+        c.exp_avg_p, c.exp_avg_sq_p, c.exp_avg_q, c.exp_avg_sq_q = (t.data_ptr() for t in self.moments)
+        c.poses_grad, c.quats_grad = self.pg.data_ptr(), self.qg.data_ptr()
+        c.poses_grad_eval = c.quats_grad_eval = None
+        c.lo_sum, c.minmax, c.rewards, c.scalars = self.lo_sum.data_ptr(), self.minmax.data_ptr(), self.rewards.data_ptr(), self.scalars.data_ptr()
+        c.loss_log, c.state_log = self.loss_log.data_ptr(), self.state_log.data_ptr()
+        c.workspace, c.workspace_bytes = self.ws.buf.data_ptr(), self.ws.bytes
+        c.scratch, c.scratch_bytes = self.scratch.data_ptr(), nbytes
+        self.c, self.ref, self.fn = c, ctypes.byref(c), L.tohip_traj_opt_step
+
+    def run(self, n):
+        idx = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(idx):
+            stream = torch._C._cuda_getCurrentRawStream(idx)
+            for i in range(n):
+                rc = self.fn(self.ref, i, stream)
+                if rc:
+                    check(rc, "tohip_traj_opt_step")
+                self.ws.generation += 1
+        for m in self.models:   # the Parameters (or their copies) were written through raw pointers
+            torch.autograd.graph.increment_version(m.poses)
+            torch.autograd.graph.increment_version(m.quats)
+
+    def results(self, n):
+        """The run's only host synchronisation: the final state rows and the loss logs."""
+        st = self.state_log[:, n].cpu()
+        lt = self.loss_log.cpu()
+        out = []
+        for b, m in enumerate(self.models):
+            if self.B > 1:
+                m.poses.data.copy_(self.poses[b * self.W:(b + 1) * self.W])
+                m.quats.data.copy_(self.quats[b * self.W:(b + 1) * self.W])
+            steps = int(st[b, 3].item())
+            row = lt[b, max(steps, 1) - 1]
+            m.rewards = self.rewards[b]
+            m.loss = {"vis": row[0], "l2": row[1], "length": row[2], "smooth": row[3]}
+            out.append(TrajOptResult(steps, bool(st[b, 2].item() != 0), lt[b, :max(steps, 1), 4].tolist(), float(st[b, 4]), float(st[b, 5])))
+        return out
+
+
 @torch.no_grad()
 def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards_th=1.2, smoothness_th=0.9,
-                        vis_wps_dist=0.5, betas=(0.9, 0.999), adam_eps=1e-8, use_graph=False):
+                        vis_wps_dist=0.5, betas=(0.9, 0.999), adam_eps=1e-8):
     """Runs up to n_opt_steps on `model` (a ModelTraj) in place; returns a TrajOptResult (one host sync, at the end).
     model.poses / model.quats hold the optimised trajectory, model.rewards the last rewards, model.loss the last terms.
 
-    use_graph: capture one iteration (≈9 launches, every per-step value read from device state) into a hipGraph and
-    replay it n_opt_steps times (not with waypoint sharding, whose all-reduce stays outside a capture, nor with
-    per-waypoint occlusion, whose hull construction syncs).  Measured on the reference's bundled cloud (40 452 points,
-    14 evaluated waypoints, MI355X): eager launch-only loop 0.124 ms/step, graph replay 0.168 ms/step, the
-    torch.optim.Adam + autograd path of model.py 1.34 ms/step — the step is bound by ≈20 dependent kernel boundaries,
-    which a graph does not remove, so eager is the default."""
+    A step is ONE library call and FIVE launches (tohip_traj_opt_step): the waypoint selection is a stride of the first launch's
+    reads, the regularisers and Adam's constants are one block more of the first launch, the parameter update and the early-stop
+    bookkeeping are the tail of the last launch's blocks.  A waypoint-sharded or occlusion-aware model has a collective or a hull
+    pass inside the step and goes through the separate calls (forward | all-reduce | reward + backward | tohip_traj_step_tail).
+    (A HIP-graph replay of the step was measured slower than issuing its launches — a replay costs 10-16 us of host time by
+    itself, five launches 17 us, and the GPU side is the same — so there is no graph variant.)"""
+    if model._shard.world_size > 1 or getattr(model._shard, "_always", False) or model._occlusion is not None:
+        return _optimize_trajectory_split(model, n_opt_steps, lr_pose, lr_quat, rewards_th, smoothness_th, vis_wps_dist, betas, adam_eps)
+    run = _OptRun([model], n_opt_steps, lr_pose, lr_quat, rewards_th, smoothness_th, vis_wps_dist, betas, adam_eps)
+    run.run(n_opt_steps)
+    return run.results(n_opt_steps)[0]
+
+
+@torch.no_grad()
+def _optimize_trajectory_split(model, n_opt_steps, lr_pose, lr_quat, rewards_th, smoothness_th, vis_wps_dist, betas, adam_eps):
+    """optimize_trajectory with a collective (waypoint sharding) or a hull pass (occlusion rows) inside the step."""
     L = _lib.lib()
     dev = model.device
     cloud, cam, rig = model._cloud, model._cam, model._rig
@@ -44,7 +139,6 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
     n_loc = hi_e - lo_e
     ws = model._workspace(max(n_loc, 1))
     f32 = dict(dtype=torch.float32, device=dev)
-    poses_e, quats_e = torch.empty((n_eval, 3), **f32), torch.empty((n_eval, 4), **f32)
     g_e = torch.zeros((n_eval, 7), **f32)  # rows outside this rank's range stay zero
     pg_e, qg_e = torch.empty((n_eval, 3), **f32), torch.empty((n_eval, 4), **f32)
     pg_loc, qg_loc = torch.empty((max(n_loc, 1), 3), **f32), torch.empty((max(n_loc, 1), 4), **f32)
@@ -59,48 +153,41 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
     mq, vq = torch.zeros((W, 4), **f32), torch.zeros((W, 4), **f32)
     poses, quats = model.poses.data, model.quats.data
     rig_ref = rig.ref() if rig is not None else ops._NULL_RIG
-    sharded = model._shard.world_size > 1
     occluded = model._occlusion is not None
+    # this rank's evaluated waypoints are rows lo_e * step_w, (lo_e + 1) * step_w, ... of the Parameters: read in place
+    # (TOHIP_TRAJ_STRIDE in the flags: no gather launch)
+    flags_fwd = int(model._flags) | (((step_w - 1) & 0xffff) << 8)
+    p_at, q_at = poses[lo_e * step_w:], quats[lo_e * step_w:]
 
     def iteration():
         s = stream_ptr()
-        check(L.tohip_gather_waypoints(ptr(poses), ptr(quats), n_eval, step_w, ptr(poses_e), ptr(quats_e), s), "gather waypoints")
-        p_loc, q_loc = poses_e[lo_e:hi_e], quats_e[lo_e:hi_e]  # contiguous row ranges of the compact arrays
         occ = None
         if occluded and n_loc > 0:
-            occ = model._occlusion_rows(p_loc, q_loc)
-        tgt_p, tgt_q = (pg_loc, qg_loc) if sharded else (pg_e, qg_e)
-        if not sharded:
-            # no collective between forward and backward: the whole visibility step is ONE call, five launches
-            check(L.tohip_traj_forward_backward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref, model._flags,
-                                                ptr(occ), ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(scalars), ptr(gout), ptr(tgt_p),
-                                                ptr(tgt_q), ptr(ws.buf), ws.bytes, s), "forward + backward")
+            occ = model._occlusion_rows(poses[lo_e * step_w:(hi_e - 1) * step_w + 1:step_w].contiguous(),
+                                        quats[lo_e * step_w:(hi_e - 1) * step_w + 1:step_w].contiguous())
+        if n_loc > 0:
+            check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(p_at), ptr(q_at), n_loc, cam.ref(), rig_ref,
+                                       flags_fwd, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(ws.buf), ws.bytes, s),
+                  "forward")
             ws.generation += 1
         else:
-            if n_loc > 0:
-                check(L.tohip_traj_forward(ptr(cloud.blob), cloud.n, ptr(p_loc), ptr(q_loc), n_loc, cam.ref(), rig_ref,
-                                           model._flags, ptr(occ), ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(ws.buf), ws.bytes, s),
-                      "forward")
-                ws.generation += 1
-            else:
-                lo_sum.zero_()
-            ops.allreduce_log_odds(model._shard, cloud, ws, lo_sum, local=n_loc > 0)
-            if n_loc > 0:
-                # rewards, their mean and the loss scalars share the backward's first launch
-                check(L.tohip_traj_reward_backward(ptr(cloud.blob), cloud.n, n_loc, cam.ref(), rig_ref, model._flags, ptr(occ), ptr(lo_sum),
-                                                   cam.eps, 1, ptr(rewards), ptr(scalars), ptr(gout), ptr(tgt_p), ptr(tgt_q), ptr(ws.buf),
-                                                   ws.bytes, s), "reward + backward")
-            else:
-                check(L.tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, 0, ptr(rewards), ptr(scalars), ptr(ws.buf), ws.bytes, s),
-                      "reward")
-        if sharded:
-            # assemble every rank's gradient rows: ONE (n_eval, 7) all-reduce, then the replicated remainder of the step
-            if n_loc > 0:
-                g_e[lo_e:hi_e, :3], g_e[lo_e:hi_e, 3:] = pg_loc, qg_loc
-            model._shard.allreduce_sum(g_e)
-            pg_e.copy_(g_e[:, :3])
-            qg_e.copy_(g_e[:, 3:])
-            g_e.zero_()  # the other ranks' rows must be zero again before the next sum
+            lo_sum.zero_()
+        ops.allreduce_log_odds(model._shard, cloud, ws, lo_sum, local=n_loc > 0)
+        if n_loc > 0:
+            # rewards, their mean and the loss scalars share the backward's first launch
+            check(L.tohip_traj_reward_backward(ptr(cloud.blob), cloud.n, n_loc, cam.ref(), rig_ref, model._flags, ptr(occ), ptr(lo_sum),
+                                               cam.eps, 1, ptr(rewards), ptr(scalars), ptr(gout), ptr(pg_loc), ptr(qg_loc), ptr(ws.buf),
+                                               ws.bytes, s), "reward + backward")
+        else:
+            check(L.tohip_traj_reward(ptr(cloud.blob), ptr(lo_sum), cloud.n, cam.eps, 0, ptr(rewards), ptr(scalars), ptr(ws.buf), ws.bytes, s),
+                  "reward")
+        # assemble every rank's gradient rows: ONE (n_eval, 7) all-reduce, then the replicated remainder of the step
+        if n_loc > 0:
+            g_e[lo_e:hi_e, :3], g_e[lo_e:hi_e, 3:] = pg_loc, qg_loc
+        model._shard.allreduce_sum(g_e)
+        pg_e.copy_(g_e[:, :3])
+        qg_e.copy_(g_e[:, 3:])
+        g_e.zero_()  # the other ranks' rows must be zero again before the next sum
         # the O(W) remainder of the step in one launch: scatter, regularisers, both Adam updates, early stop
         check(L.tohip_traj_step_tail(ptr(poses), ptr(quats), ptr(model.poses0), W, ptr(pg_e), ptr(qg_e), n_eval, step_w,
                                      ptr(pg), ptr(qg), ptr(mp), ptr(vp), ptr(mq), ptr(vq), float(model.smoothness_weight),
@@ -109,19 +196,8 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
                                      ptr(loss_terms), ptr(state), s), "step tail")
 
     with torch.cuda.device(dev):
-        if use_graph and not sharded and not occluded and n_opt_steps > 1:
-            graph = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(graph, stream=side):
-                    iteration()
-                for _ in range(n_opt_steps):
-                    graph.replay()
-            torch.cuda.current_stream().wait_stream(side)
-        else:
-            for _ in range(n_opt_steps):
-                iteration()
+        for _ in range(n_opt_steps):
+            iteration()
     st = state.cpu()  # the run's only host synchronisation
     steps = int(st[3].item())
     lt_host = loss_terms[:max(steps, 1)].cpu()
@@ -139,9 +215,7 @@ def optimize_trajectories(models, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewa
     trajectory that has stopped stays put while the others go on).  Each model ends up exactly — bit for bit — where its own
     `optimize_trajectory` run would have put it.  Models: ModelTraj built on the same points with the same camera, rig and
     mode, equal numbers of waypoints and the same waypoint step; no sharding, no occlusion.  -> [TrajOptResult]."""
-    L = _lib.lib()
     m0 = models[0]
-    B, dev = len(models), m0.device
     cloud, cam, rig = m0._cloud, m0._cam, m0._rig
     W = m0.poses.shape[0]
     step_w = m0._wps_step(vis_wps_dist)
@@ -157,51 +231,9 @@ def optimize_trajectories(models, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewa
             raise ValueError("optimize_trajectories: the models must live on one device and share eps")
         if m is not m0 and rig is not None and (m._rig.n_cams != rig.n_cams or not torch.equal(m._rig.q, rig.q) or not torch.equal(m._rig.t, rig.t)):
             raise ValueError("optimize_trajectories: the models must share the camera rig (extrinsics differ)")
-    n_eval = (W + step_w - 1) // step_w
-    C = rig.n_cams if rig else 1
-    f32 = dict(dtype=torch.float32, device=dev)
-    poses = torch.cat([m.poses.data for m in models]).contiguous()
-    quats = torch.cat([m.quats.data for m in models]).contiguous()
-    poses0 = torch.cat([m.poses0 for m in models]).contiguous()
-    toff = (torch.arange(B + 1, dtype=torch.int32) * n_eval).to(dev)
-    ws = ops.TrajWorkspace(cloud, B * n_eval * C, B)
-    poses_e, quats_e = torch.empty((B * n_eval, 3), **f32), torch.empty((B * n_eval, 4), **f32)
-    pg_e, qg_e = torch.empty((B * n_eval, 3), **f32), torch.empty((B * n_eval, 4), **f32)
-    pg, qg = torch.zeros((B * W, 3), **f32), torch.zeros((B * W, 4), **f32)
-    lo_sum = torch.empty((B, cloud.npad), **f32)
-    minmax = torch.empty((B * n_eval * C, 2), **f32)
-    rewards, scalars = torch.empty((B, cloud.n), **f32), torch.zeros((B, 4), **f32)
-    loss_terms = torch.zeros((B, n_opt_steps + 1, 8), **f32)
-    state = torch.zeros((B, 8), **f32)
-    gout = torch.ones(B, **f32)
-    mp, vp = torch.zeros((B * W, 3), **f32), torch.zeros((B * W, 3), **f32)
-    mq, vq = torch.zeros((B * W, 4), **f32), torch.zeros((B * W, 4), **f32)
-    rig_ref = rig.ref() if rig is not None else ops._NULL_RIG
-    with torch.cuda.device(dev):
-        for _ in range(n_opt_steps):
-            s = stream_ptr()
-            check(L.tohip_gather_waypoints_multi(ptr(poses), ptr(quats), W, B, n_eval, step_w, ptr(poses_e), ptr(quats_e), s), "gather")
-            check(L.tohip_traj_forward_backward_multi(ptr(cloud.blob), cloud.n, ptr(poses_e), ptr(quats_e), B * n_eval, ptr(toff), B, cam.ref(),
-                                                      rig_ref, m0._flags, None, ptr(lo_sum), ptr(minmax), ptr(rewards), ptr(scalars), ptr(gout),
-                                                      ptr(pg_e), ptr(qg_e), ptr(ws.buf), ws.bytes, s), "forward + backward")
-            ws.generation += 1
-            check(L.tohip_traj_step_tail_multi(ptr(poses), ptr(quats), ptr(poses0), W, B, ptr(pg_e), ptr(qg_e), n_eval, step_w, ptr(pg), ptr(qg),
-                                               ptr(mp), ptr(vp), ptr(mq), ptr(vq), float(m0.smoothness_weight), float(m0.traj_length_weight),
-                                               float(m0.eps), float(lr_pose), float(lr_quat), betas[0], betas[1], adam_eps, float(rewards_th),
-                                               float(smoothness_th), ptr(scalars), ptr(loss_terms), (n_opt_steps + 1) * 8, ptr(state), s),
-                  "step tail")
-    st = state.cpu()  # the run's only host synchronisation
-    lt = loss_terms.cpu()
-    results = []
-    for b, m in enumerate(models):
-        m.poses.data.copy_(poses[b * W:(b + 1) * W])
-        m.quats.data.copy_(quats[b * W:(b + 1) * W])
-        steps = int(st[b, 3].item())
-        row = lt[b, max(steps, 1) - 1]
-        m.rewards = rewards[b]
-        m.loss = {"vis": row[0], "l2": row[1], "length": row[2], "smooth": row[3]}
-        results.append(TrajOptResult(steps, bool(st[b, 2].item() != 0), lt[b, :max(steps, 1), 4].tolist(), float(st[b, 4]), float(st[b, 5])))
-    return results
+    run = _OptRun(list(models), n_opt_steps, lr_pose, lr_quat, rewards_th, smoothness_th, vis_wps_dist, betas, adam_eps)
+    run.run(n_opt_steps)
+    return run.results(n_opt_steps)
 
 
 class PoseOptResult:
@@ -268,6 +300,8 @@ def _adam_update(L, entries, arr):
             rc = L.tohip_adam_step_multi(arr, k, torch._C._cuda_getCurrentRawStream(idx))
     if rc:
         check(rc, "tohip_adam_step_multi")
+    for _, q, _, _ in entries:   # the kernel wrote through raw pointers: autograd's in-place guards must still see an update
+        torch.autograd.graph.increment_version(q)
 
 
 def _steppable(p, g):
@@ -351,11 +385,21 @@ def _install_hooks():
 
 
 def _plain_adam_group(g):
-    return not (g["amsgrad"] or g["weight_decay"] != 0 or g["maximize"] or g["capturable"] or g["differentiable"] or g["fused"] or
-                g.get("decoupled_weight_decay", False) or not isinstance(g["lr"], float))
+    return not (g.get("amsgrad", False) or g.get("weight_decay", 0) != 0 or g.get("maximize", False) or g.get("capturable", False) or
+                g.get("differentiable", False) or g.get("fused", False) or g.get("decoupled_weight_decay", False) or
+                not isinstance(g["lr"], float))
+
+
+def _restore_stash(opt):
+    stash = opt.__dict__.pop("_tohip_adam_stash", None)
+    if stash:
+        for _, p, _, g in stash:
+            if p.grad is None:
+                p.grad = g
 
 
 def _adam_pre_hook(opt, args, kwargs):
+    _restore_stash(opt)   # a step() that raised between the two hooks left the gradients hidden: put them back first
     if not _ACCEL["on"] or type(opt) is not torch.optim.Adam or (len(args) > 1 and args[1] is not None) or kwargs.get("closure") is not None:   # args[0] is the optimizer
         return None
     entries = []
@@ -395,8 +439,5 @@ def _adam_pre_hook(opt, args, kwargs):
 
 
 def _adam_post_hook(opt, args, kwargs):
-    stash = opt.__dict__.pop("_tohip_adam_stash", None)
-    if stash:
-        for _, p, _, g in stash:
-            p.grad = g
+    _restore_stash(opt)
     return None
