@@ -328,6 +328,7 @@ def main():
     ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dropin", choices=["on", "off"], default="on", help="time the reference's own loop over the drop-in classes (N = 1 only)")
     ap.add_argument("--density", choices=["on", "off"], default="on", help="step time versus flagged fraction: 1 M points in ever smaller rooms (N = 1 only)")
+    ap.add_argument("--moved", choices=["on", "off"], default="on", help="time the same step on the trajectory after 100 optimiser steps (N = 1 only)")
     ap.add_argument("--dump", default=None, help="write the last dense step's outputs (scalars, gradient rows, rewards) to this .npz "
                                                  "(rank 0): tests compare runs at different N")
     args = ap.parse_args()
@@ -371,8 +372,11 @@ def main():
     lo_buf = torch.empty(cloud.npad, dtype=torch.float32, device=device)
     mm_buf = torch.empty((n_virtual, 2), dtype=torch.float32, device=device)
 
+    at = {"poses": poses, "quats": quats}   # where the timed steps evaluate (moved_leg swaps in the trajectory after an optimisation run)
+
     def step(flags):
         rewards = rewards_buf
+        poses, quats = at["poses"], at["quats"]
         if shard is None and args.fused_step == "on":
             # no collective between forward and backward: the whole step is ONE library call, five launches
             rewards, scalars, pg, qg, _, _ = ops.traj_forward_backward(cloud, poses, quats, cam, ws, gout, rig=rig, flags=flags, lo_sum=lo_buf,
@@ -399,8 +403,8 @@ def main():
         torch.cuda.synchronize(device)
 
     L = _lib.lib()
-    ms = (ctypes.c_double * 5)()
-    cnt = (ctypes.c_int64 * 5)()
+    ms = (ctypes.c_double * 6)()
+    cnt = (ctypes.c_int64 * 6)()
 
     use_graph = args.graph == "on" and shard is None
 
@@ -517,7 +521,41 @@ def main():
         fence()
         _lib.check(L.tohip_profile_read(ms, cnt), "tohip_profile_read")
         L.tohip_profile_enable(0)
-        return {L.tohip_profile_name(i).decode(): (ms[i], cnt[i]) for i in range(5) if cnt[i] > 0}
+        return {L.tohip_profile_name(i).decode(): (ms[i], cnt[i]) for i in range(6) if cnt[i] > 0}
+
+    def moved_leg(opt_steps=100, lr=(0.1, 0.02)):
+        """The SAME step where an optimisation run ends up instead of where it starts: the trajectory after `opt_steps` steps of
+        optimizer.optimize_trajectory (Adam, lr_pose / lr_quat as the drop-in leg, no early stop).  Rewards improve as the
+        waypoints spread out, so more (slot, waypoint) pairs are flagged in more candidate slots and the kernels behind pass 1
+        cost more: K steps of each mode timed like the headline (off the headline), per-kernel HIP-event times, and what the
+        forward found."""
+        from trajectory_optimization_amd.model import ModelTraj
+        from trajectory_optimization_amd.optimizer import optimize_trajectory
+        m = ModelTraj(torch.from_numpy(pts).to(device), torch.from_numpy(poses_all[lo:hi].copy()), torch.from_numpy(quats_all[lo:hi].copy()),
+                      torch.from_numpy(synth.K_INTRINS), synth.IMG_WIDTH, synth.IMG_HEIGHT, device=device)
+        optimize_trajectory(m, n_opt_steps=opt_steps, lr_pose=lr[0], lr_quat=lr[1], rewards_th=1e9, vis_wps_dist=0.0)
+        moved_p, moved_q = m.poses.data.clone(), m.quats.data.clone()
+        disp = (moved_p - poses).norm(dim=1)
+        res = {"optimiser_steps": opt_steps, "lr_pose": lr[0], "lr_quat": lr[1], "mean_waypoint_displacement_m": float(disp.mean().item()),
+               "max_waypoint_displacement_m": float(disp.max().item())}
+        del m
+        at["poses"], at["quats"] = moved_p, moved_q
+        try:
+            outs = {}
+            for name, flags in (("dense", ops.DENSE), ("culled", 0)):
+                k = kernel_times(flags)
+                dt_m, o = timed(flags)
+                outs[name] = tuple(t.clone() for t in o)
+                res[name] = {"ms_per_step": 1e3 * dt_m / args.steps, "kernel_us": {kk: 1e3 * v[0] / v[1] for kk, v in k.items()}}
+            st = ops.traj_step_stats(cloud, ws)
+            res.update(flagged_pairs=st["flagged_pairs"], flagged_fraction=st["flagged_fraction"], candidate_slots=st["candidate_slots"],
+                       slots=st["slots"], evaluated_pairs_culled=st["evaluated_pairs"], loss_vis=float(outs["dense"][0][1].item()),
+                       dense_equals_culled_bitwise=bool(all(torch.equal(a, b) for a, b in zip(outs["dense"], outs["culled"]))))
+        finally:
+            at["poses"], at["quats"] = poses, quats
+        res["note"] = ("the headline's step on the trajectory an optimisation run leaves behind; kernel_us: HIP events on the launch stream "
+                       "(they cost ~5 us per bracket: compare them with each other, ms_per_step is timed without them)")
+        return res
 
     def in_kernel_span(flags):
         """Diagnostic, outside every timed region: the dense kernel's blocks stamp s_memrealtime (100 MHz) at their start and end
@@ -558,6 +596,7 @@ def main():
     win_dense = windows(dense_flags)
     win_culled = windows(0) if args.mode == "both" else win_dense
     comm = comm_leg(dense_flags) if shard is not None else None
+    moved = moved_leg() if (shard is None and args.moved == "on" and args.mode == "both" and args.cameras == 1) else None
 
     if rank == 0 and args.dump:
         np.savez(args.dump, scalars=out[0].cpu().numpy(), pg=out[1].cpu().numpy(), qg=out[2].cpu().numpy(), rewards=out[3].cpu().numpy())
@@ -653,6 +692,8 @@ def main():
                         "GPU box; profiles/r01_reference_cpu_timing.txt"}
         if comm is not None:
             line["comm"] = comm
+        if moved is not None:
+            line["after_optimisation"] = moved
         print(json.dumps(line), flush=True)
     if n_gpus > 1 or forced:
         dist.barrier()

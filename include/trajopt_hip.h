@@ -489,7 +489,7 @@ int tohip_render_points(const float *verts, int64_t n_points, const float *K9_ho
  * When enabled, every launch of the big kernels is bracketed by hipEventRecord on its own stream.
  * tohip_profile_read synchronises on those events and returns, per kernel id < TOHIP_PROF_NKERNELS,
  * the summed milliseconds and the number of launches since the last read (HOST arrays). */
-#define TOHIP_PROF_NKERNELS 5
+#define TOHIP_PROF_NKERNELS 6
 int tohip_profile_enable(int on);
 const char *tohip_profile_name(int id);
 int tohip_profile_read(double *ms_sum_host, int64_t *counts_host);

@@ -63,11 +63,11 @@ for name, flags in (("dense", ops.DENSE), ("cull", 0)):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 20
     outs[name] = [t.cpu().numpy() for t in o]
-    ms = (ctypes.c_double * 5)(); cnt = (ctypes.c_int64 * 5)()
+    ms = (ctypes.c_double * 6)(); cnt = (ctypes.c_int64 * 6)()
     L.tohip_profile_enable(1)
     for _ in range(20): step()
     torch.cuda.synchronize()
     L.tohip_profile_read(ms, cnt)
     L.tohip_profile_enable(0)
-    print(f"1Mx128 {name}: {dt*1e3:.4f} ms/step = {n*w/dt:.3e} evals/s; kernels:", {L.tohip_profile_name(i).decode(): round(ms[i]/20*1e3, 1) for i in range(5)}, "us")
+    print(f"1Mx128 {name}: {dt*1e3:.4f} ms/step = {n*w/dt:.3e} evals/s; kernels:", {L.tohip_profile_name(i).decode(): round(ms[i]/20*1e3, 1) for i in range(6)}, "us")
 print("1M dense == cull:", all(np.array_equal(a, b) for a, b in zip(outs["dense"], outs["cull"])), "vis", outs["dense"][0][1])

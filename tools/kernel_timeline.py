@@ -32,7 +32,7 @@ LABELS = {
                           "end"],
     "k_traj_sparse": ["start", "candidate known", "flags, staged records", "wave 0's share of the forward sweep", "every wave's",
                       "sums, rewards", "pair list's answer", "end"],
-    "k_traj_pairs": ["start", "list length, first pair", "end"],
+    "k_traj_pairs": ["start", "list length, first pair", "end", "the block's last wave"],
     "k_traj_finish": ["start", "flag words, tie slots", "wave 0: tie slots re-evaluated", "every wave: ties, rows, group sums",
                       "64 groups added, factor", "end"],
 }

@@ -27,10 +27,10 @@ for name in modes:
     for _ in range(20): o = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 20
-    ms = (ctypes.c_double * 5)(); cnt = (ctypes.c_int64 * 5)()
+    ms = (ctypes.c_double * 6)(); cnt = (ctypes.c_int64 * 6)()
     L.tohip_profile_enable(1)
     for _ in range(20): step()
     torch.cuda.synchronize()
     L.tohip_profile_read(ms, cnt)
     L.tohip_profile_enable(0)
-    print(f"{n}x{w} {name}: {dt*1e3:.4f} ms/step = {n*w/dt:.3e} evals/s; kernels:", {L.tohip_profile_name(i).decode(): round(ms[i]/20*1e3, 1) for i in range(5)}, "us vis", float(o[0][1]))
+    print(f"{n}x{w} {name}: {dt*1e3:.4f} ms/step = {n*w/dt:.3e} evals/s; kernels:", {L.tohip_profile_name(i).decode(): round(ms[i]/20*1e3, 1) for i in range(6)}, "us vis", float(o[0][1]))

@@ -11,7 +11,7 @@ import subprocess
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrajopt_hip.so")
+LIB_PATH = os.environ.get("TOHIP_LIB") or os.path.join(_HERE, "libtrajopt_hip.so")   # (TOHIP_LIB: a diagnostic build, tools/)
 SRC = os.path.join(_HERE, "csrc", "trajopt_hip.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"]

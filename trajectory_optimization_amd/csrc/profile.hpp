@@ -10,8 +10,9 @@
 #define TOHIP_PROF_PASS2 1
 #define TOHIP_PROF_BWD 2
 #define TOHIP_PROF_REWARD 3
-#define TOHIP_PROF_SMALL 4   /* prep / finish kernels together */
-#define TOHIP_PROF_NKERNELS 5
+#define TOHIP_PROF_PROBE 4
+#define TOHIP_PROF_FINISH 5
+#define TOHIP_PROF_NKERNELS 6
 
 namespace toprof {
 struct Rec { int id; hipEvent_t a, b; };

@@ -84,6 +84,12 @@ __device__ unsigned long long g_stamps[TO_STAMP_KERNELS][TO_STAMP_BLOCKS][TO_STA
         const unsigned lb_ = blockIdx.y * gridDim.x + blockIdx.x;                                                    \
         if (threadIdx.x == 0 && lb_ < TO_STAMP_BLOCKS) g_stamps[kern][lb_][i] = __builtin_amdgcn_s_memrealtime();    \
     } while (0)
+// the same by lane 0 of EVERY wave, the latest kept: when the block's last wave passed the place
+#define TO_STAMP_LAST(kern, i)                                                                                       \
+    do {                                                                                                             \
+        const unsigned lb_ = blockIdx.y * gridDim.x + blockIdx.x;                                                    \
+        if ((threadIdx.x & 63) == 0 && lb_ < TO_STAMP_BLOCKS) atomicMax(&g_stamps[kern][lb_][i], (unsigned long long)__builtin_amdgcn_s_memrealtime()); \
+    } while (0)
 extern "C" int tohip_stamps_read(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * TO_STAMP_KERNELS * TO_STAMP_BLOCKS * TO_STAMP_N);
 }
@@ -94,6 +100,7 @@ extern "C" int tohip_stamps_clear() {
 }
 #else
 #define TO_STAMP(kern, i) do { } while (0)
+#define TO_STAMP_LAST(kern, i) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -1135,6 +1142,7 @@ __device__ __forceinline__ void pair_walk(const SparseArgs& a, int b, int nb) {
         pair_sums<OCC>(a, __builtin_amdgcn_readfirstlane(cur.x), __builtin_amdgcn_readfirstlane(cur.y), lane);
     }
     TO_STAMP(TO_STAMP_PAIRS, 2);
+    TO_STAMP_LAST(TO_STAMP_PAIRS, 3);   // the block's last wave
 }
 
 // os.mode == 2 (model() as one library call, loss_kernels.hip): one block more than the pairs need turns the integer reward sum
@@ -1924,7 +1932,7 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
     const int V = (int)s.V;
     const OutInit oi{lo_sum, rewards_half, s.cv.npad, s.n, (int)s.n_traj};
     {
-        TO_PROF(TOHIP_PROF_SMALL, s.st);
+        TO_PROF(TOHIP_PROF_PROBE, s.st);
         const ProbeCull pc{s.cull ? 1 : 0, s.pl.nslots, s.live};
         const int grid = V + (s.opt.mode ? s.opt.n_traj : 0);   // a block per trajectory behind the waypoints': the step's prologue
         if (V <= 512)
@@ -2020,7 +2028,7 @@ inline int launch_pairs(const TrajStep& s, const SparseArgs& a) {
 }
 
 inline int launch_finish(const TrajStep& s, const FinishPost& post, float* poses_grad, float* quats_grad) {
-    TO_PROF(TOHIP_PROF_SMALL, s.st);
+    TO_PROF(TOHIP_PROF_FINISH, s.st);
     const bool single = s.C == 1 && s.rq == nullptr;
     const int V = (int)s.V;
     if (V <= 512)
@@ -2180,13 +2188,16 @@ namespace {
 int traj_fused_forward(TrajStep& s, const float* poses, const float* quats, float* lo_sum, float* minmax, float* rewards) {
     int rc = launch_probe_pass1(s, poses, quats, lo_sum, rewards);
     if (rc != TOHIP_OK) return rc;
-    TO_PROF(TOHIP_PROF_PASS2, s.st);
     SparseArgs a = sparse_args(s, lo_sum);
     a.minmax = minmax;
     a.rewards = rewards;
     a.prefilled = 1;
-    rc = launch_sparse<TO_SP_FUSED>(s, a);
+    {
+        TO_PROF(TOHIP_PROF_PASS2, s.st);
+        rc = launch_sparse<TO_SP_FUSED>(s, a);
+    }
     if (rc != TOHIP_OK) return rc;
+    TO_PROF(TOHIP_PROF_BWD, s.st);
     return launch_pairs(s, a);
 }
 }  // namespace

@@ -34,8 +34,8 @@ extern "C" int tohip_profile_enable(int on) {
 }
 
 extern "C" const char* tohip_profile_name(int id) {
-    static const char* names[TOHIP_PROF_NKERNELS] = {"k_traj_pass1", "k_traj_sparse", "k_traj_reward_bwd / k_traj_sparse<BWD>", "k_traj_reward",
-                                                      "probe + finish kernels"};
+    static const char* names[TOHIP_PROF_NKERNELS] = {"k_traj_pass1", "k_traj_sparse", "k_traj_pairs / k_traj_reward_bwd", "k_traj_reward",
+                                                      "k_traj_probe", "k_traj_finish"};
     return (id >= 0 && id < TOHIP_PROF_NKERNELS) ? names[id] : "?";
 }
 
