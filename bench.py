@@ -266,6 +266,76 @@ def dropin_leg(device, steps=200, warmup=10):
     return out
 
 
+def aux_leg(device, sizes=(1_000_000, 16_000_000), reps=20):
+    """The HBM-bound kernels around the hot path (the only place BASELINE's "achieved HBM GB/s vs peak" literally
+    applies): ModelPose's pass over the cloud (model.py:98-127), sphericalFlip (tools.py:38-53), the hard frustum cull
+    (tools.py:176-187), the soft masks and to_camera_frame helpers (model.py:13-57), the PointCloud2 unpack
+    (pointcloud_utils.py:197-198).  Per kernel family and cloud size: microseconds per call (HIP events on the launch stream around
+    `reps` back-to-back calls through the C ABI, buffers allocated once), GB/s on the ALGORITHMIC bytes of SURVEY.md 8d (what a
+    perfect streaming implementation must move), and that as a fraction of the 8 TB/s HBM peak."""
+    from trajectory_optimization_amd import _lib, ops
+    from trajectory_optimization_amd._lib import ptr, stream_ptr
+    L = _lib.lib()
+    cam = ops.Camera(synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT)
+    f32 = dict(dtype=torch.float32, device=device)
+    out = {}
+    for n in sizes:
+        pts = torch.from_numpy(synth.make_cloud(n, seed=0)).to(device)
+        cloud = ops.PackedCloud(pts, sort=False)           # ModelPose's layout: the caller's order
+        ws = ops.PoseWorkspace(cloud)
+        trans, quat = torch.tensor([[6.0, 2.0, 0.0]], **f32), torch.tensor([[0.9, 0.1, -0.3, 0.2]], **f32)
+        obs, scal, tg, qg, gout = torch.empty(n, **f32), torch.zeros(4, **f32), torch.empty((1, 3), **f32), torch.empty((1, 4), **f32), torch.ones(1, **f32)
+        cam3 = ops.to_camera_frame_exact(pts, quat, trans, normalize=True, transpose=True)    # (3, N) camera frame
+        camn3 = cam3.t().contiguous()
+        dm, fm = torch.empty(n, dtype=torch.uint8, device=device), torch.empty(n, dtype=torch.uint8, device=device)
+        kept, cnt = torch.empty(n, dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int32, device=device)
+        fws = torch.empty(L.tohip_frustum_workspace_bytes(n), dtype=torch.uint8, device=device)
+        flipped, rad, flws = torch.empty_like(pts), torch.empty(1, **f32), torch.empty(8192, dtype=torch.uint8, device=device)
+        d_m, f_m, out3 = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty((n, 3), **f32)
+        msg = torch.zeros((n, 4), **f32)
+        msg[:, :3] = pts
+        raw = msg.view(torch.uint8).reshape(-1)
+        iws = torch.empty(L.tohip_ingest_workspace_bytes(n), dtype=torch.uint8, device=device)
+        q1, t1 = quat.reshape(4).contiguous(), trans.reshape(3).contiguous()
+        s = stream_ptr()
+        calls = {
+            "pose_forward (k_pose_stream<fwd>)": (16.0, lambda: L.tohip_pose_forward(ptr(cloud.blob), n, ptr(trans), ptr(quat), cam.ref(), None, ptr(obs), ptr(scal), ptr(ws.buf), ws.bytes, s)),
+            "pose_forward_backward (k_pose_stream<fwd, grad>: one pass)": (16.0, lambda: L.tohip_pose_forward_backward(ptr(cloud.blob), n, ptr(trans), ptr(quat), cam.ref(), None, ptr(obs), ptr(scal), None, ptr(tg), ptr(qg), ptr(ws.buf), ws.bytes, s)),
+            "pose_backward (k_pose_stream<grad>)": (12.0, lambda: L.tohip_pose_backward(ptr(cloud.blob), n, ptr(trans), ptr(quat), cam.ref(), None, None, ptr(scal), ptr(gout), ptr(tg), ptr(qg), ptr(ws.buf), ws.bytes, s)),
+            "spherical_flip (k_norm_max + k_flip)": (24.0, lambda: L.tohip_spherical_flip(ptr(pts), n, 2.0, ptr(flipped), ptr(rad), ptr(flws), 8192, s)),
+            "frustum_cull (k_frustum_count + scan + k_frustum_write)": (None, lambda: L.tohip_frustum_cull(ptr(cam3), n, cam.ref(), 1.0, 10.0, ptr(dm), ptr(fm), ptr(kept), ptr(cnt), ptr(fws), fws.numel(), s)),
+            "soft_masks (k_soft_masks)": (20.0, lambda: L.tohip_soft_masks(ptr(camn3), n, cam.ref(), ptr(d_m), ptr(f_m), s)),
+            "to_camera_frame (k_to_camera_frame)": (24.0, lambda: L.tohip_to_camera_frame(ptr(pts), n, ptr(q1), ptr(t1), 1, 0, ptr(out3), s)),
+            "pointcloud2_to_xyz (k_pc2_*: 16-byte xyzi points)": (None, lambda: L.tohip_pointcloud2_to_xyz(ptr(raw), n, 16, 0, 4, 8, 7, 0, 1, ptr(out3), ptr(cnt), ptr(iws), iws.numel(), s)),
+        }
+        rows = {}
+        for name, (bpp, fn) in calls.items():
+            for _ in range(3):
+                rc = fn()
+                if rc:
+                    raise RuntimeError(f"{name}: error {rc}")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / reps
+            if bpp is None:   # output bytes depend on what survives: the count of the last call
+                k = int(cnt.item())
+                bpp = (12.0 + 2.0 + 4.0 * k / n) if name.startswith("frustum") else (16.0 + 12.0 * k / n)
+            gbs = bpp * n / (us * 1e-6) / 1e9
+            rows[name] = {"us_per_call": us, "algorithmic_bytes_per_point": bpp, "GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+        out[f"{n}_points"] = rows
+        del pts, cloud, cam3, camn3, flipped, out3, msg, raw, obs
+        torch.cuda.empty_cache()
+    out["note"] = ("algorithmic bytes per point: pose 12 B read + 4 B written (16), backward alone 12; flip 12 + 12; cull 12 + 2 + 4 per kept point; "
+                   "soft masks 12 + 8; to_camera_frame 12 + 12; PointCloud2 16 in + 12 per finite point.  HIP events over back-to-back calls: a "
+                   "call's launches and their boundaries are part of its time (a 1 M-point call is mostly that).  Peak 8 TB/s; ~6.3 TB/s is "
+                   "what streaming kernels achieve on this chip (MI355X_MICROARCH.md)")
+    return out
+
+
 def density_leg(device, steps=20, warmup=3):
     """The same 1 M points x 128 waypoints in ever smaller rooms (the path scaled with the room): the headline workload flags
     0.7 % of the (256-point slot, waypoint) pairs; an indoor cloud flags 10-20 %, and the kernels after pass 1 cost in proportion.
@@ -328,6 +398,7 @@ def main():
     ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dropin", choices=["on", "off"], default="on", help="time the reference's own loop over the drop-in classes (N = 1 only)")
     ap.add_argument("--density", choices=["on", "off"], default="on", help="step time versus flagged fraction: 1 M points in ever smaller rooms (N = 1 only)")
+    ap.add_argument("--aux", choices=["on", "off"], default="on", help="the HBM-bound kernels around the hot path (ModelPose, flip, cull, masks, ingest) at 1 M and 16 M points")
     ap.add_argument("--moved", choices=["on", "off"], default="on", help="time the same step on the trajectory after 100 optimiser steps (N = 1 only)")
     ap.add_argument("--dump", default=None, help="write the last dense step's outputs (scalars, gradient rows, rewards) to this .npz "
                                                  "(rank 0): tests compare runs at different N")
@@ -684,6 +755,8 @@ def main():
                 line["dropin"] = dropin_leg(device)
             if args.density == "on":
                 line["density_sweep"] = density_leg(device)
+            if args.aux == "on":
+                line["aux"] = aux_leg(device)
             line["hpr"] = hpr_leg(pts, device)
             line["cpu_baseline"] = cpu_baseline(pts, poses_all, quats_all, args.cpu_wps)
             line["reference_cpu_container"] = {

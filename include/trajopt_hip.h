@@ -68,7 +68,8 @@ const char *tohip_error_string(int code);
  * device blob of tohip_packed_cloud_bytes(N) bytes: the points in Morton order as x[Npad] | y[Npad] |
  * z[Npad] (Npad = tohip_padded_points(N); the pad repeats the last sorted point), the permutation back to
  * the caller's order and its inverse, and one bounding sphere per 256 sorted points.  sort = 0 keeps the caller's order
- * (no spatial coherence: the exact culling then rarely fires).  Needs tohip_pack_workspace_bytes(N)
+ * (no spatial coherence: the exact culling then rarely fires — the layout for ModelPose, which culls nothing and then reads
+ * masks and writes observations in place, 16 bytes at a time).  Needs tohip_pack_workspace_bytes(N)
  * bytes of scratch. */
 int64_t tohip_padded_points(int64_t n_points);
 size_t tohip_packed_cloud_bytes(int64_t n_points);
@@ -313,6 +314,23 @@ int tohip_pose_backward(const void *packed, int64_t n_points, const float *trans
                         const float *scalars, const float *gout, float *trans_grad, float *quat_grad, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* tohip_pose_forward + tohip_pose_backward of the fused loss in ONE pass over the cloud (the gradient sums do not depend on the
+ * loss: the pass that writes the observations takes them with unit weights, and the finish scales them by -loss^2 gout once the
+ * sum is known): observations, scalars, and trans_grad (3) / quat_grad (4) = gout x d loss / d (trans, raw quat); gout = device
+ * pointer to dL/d loss, NULL = 1.  Two launches (the pass, its one-block finish).  replaces model.py:98-127 + loss.backward(). */
+int tohip_pose_forward_backward(const void *packed, int64_t n_points, const float *trans, const float *quat,
+                                const tohip_camera *cam_host, const float *occlusion_mask, float *observations, float *scalars,
+                                const float *gout, float *trans_grad, float *quat_grad, void *workspace, size_t workspace_bytes,
+                                void *stream);
+/* One step of PoseOpt's loop (pose_optimization.py:124-141): the call above, then torch.optim.Adam (two groups: trans @ lr_pose,
+ * quat @ lr_quat, pose_optimization.py:93-97) on trans / quat IN PLACE, in the finish launch — still two launches.  step = the
+ * 1-based iteration; loss_log[step - 1] = the loss of this step (before the update); trans_grad / quat_grad may be NULL. */
+int tohip_pose_opt_step(const void *packed, int64_t n_points, float *trans, float *quat, const tohip_camera *cam_host,
+                        const float *occlusion_mask, float *observations, float *scalars, float *trans_grad, float *quat_grad,
+                        float *exp_avg_t, float *exp_avg_sq_t, float *exp_avg_q, float *exp_avg_sq_q, float lr_pose, float lr_quat,
+                        float beta1, float beta2, float adam_eps, int32_t step, float *loss_log, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 /* ---- element-wise helpers of model.py (forward values) ---------------------------------------- */
 /* to_camera_frame (model.py:50-57; normalize=1) / ego_to_cam_torch (pc_processor.py:63-70;
  * normalize=0): bit-identical to the reference's f32 op order.  out_layout 0: (N,3), 1: (3,N). */
@@ -356,7 +374,9 @@ int tohip_gather_points(const float *xyz, int64_t n_points, int in_layout, const
  * n/2 faces (HPR of a scene keeps a few % of the points).  A hull that creates more returns TOHIP_ENOSPC: call again
  * with a larger workspace (4x is what the Python host does; 8 faces per point is never exceeded). */
 size_t tohip_hpr_workspace_bytes(int64_t n_points);
-/* sphericalFlip (tools.py:38-53): flipped (N,3), radius_out[0] = max||p|| * 10^param. Bit-exact. */
+/* sphericalFlip (tools.py:38-53): flipped (N,3), radius_out[0] = max||p|| * 10^param. Bit-exact.  workspace: at least
+ * TOHIP_FLIP_WORKSPACE_BYTES of scratch (the blocks' maxima of the norms). */
+#define TOHIP_FLIP_WORKSPACE_BYTES 8192
 int tohip_spherical_flip(const float *xyz, int64_t n_points, float param, float *flipped, float *radius_out,
                          void *workspace, size_t workspace_bytes, void *stream);
 /* hidden_pts_removal (tools.py:67-85): flip, convex hull of flipped points + origin (double

@@ -61,16 +61,24 @@ def traj_forward(points, poses, quats, K, img_w, img_h, min_dist=1.0, max_dist=5
     return dict(lo_sum=lo, rewards=rew, pmin=pmin, pmax=pmax, mean_reward=mean.value, loss_vis=loss.value, occ=occ)
 
 
-def traj_backward(points, poses, quats, K, img_w, img_h, fwd, gout=1.0, min_dist=1.0, max_dist=5.0, prec="f32"):
+def traj_backward(points, poses, quats, K, img_w, img_h, fwd, gout=1.0, min_dist=1.0, max_dist=5.0, prec="f32", act_shift=0.0):
+    """act_shift != 0 (diagnostic): the lower activity threshold of the clipped log-odds at 1/2 + act_shift instead of 1/2 —
+    the difference of two such gradients is what the points inside the band are worth (tests/test_hip_reference_dense.py)."""
     pts, poses, quats, K = _f32(points), _f32(poses), _f32(quats), _f32(K)
     N, W = pts.shape[0], poses.shape[0]
     dt = _DT[prec]
     pg, qg = np.empty((W, 3), dt), np.empty((W, 4), dt)
     rew = np.ascontiguousarray(fwd["rewards"], dtype=dt)
     fn = getattr(lib(), "oracle_traj_backward_" + prec)
-    rc = fn(_ptr(pts), c_i64(N), _ptr(poses), _ptr(quats), c_i64(W), _ptr(K), c_f(img_w), c_f(img_h),
-            c_f(min_dist), c_f(max_dist), _ptr(fwd.get("occ")), _ptr(rew), c_d(fwd["mean_reward"]), c_d(gout), _ptr(pg),
-            _ptr(qg))
+    setter = getattr(lib(), "oracle_set_act_shift_" + prec)
+    setter.argtypes = [c_d]
+    setter(float(act_shift))
+    try:
+        rc = fn(_ptr(pts), c_i64(N), _ptr(poses), _ptr(quats), c_i64(W), _ptr(K), c_f(img_w), c_f(img_h),
+                c_f(min_dist), c_f(max_dist), _ptr(fwd.get("occ")), _ptr(rew), c_d(fwd["mean_reward"]), c_d(gout), _ptr(pg),
+                _ptr(qg))
+    finally:
+        setter(0.0)
     assert rc == 0
     return pg, qg
 

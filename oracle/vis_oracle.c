@@ -205,26 +205,30 @@ int FN(oracle_traj_forward)(const float *xyz, int64_t N, const float *poses, con
         FN(cam_t) cam;
         FN(make_cam)(&cam, quats + 4 * w, poses + 3 * w, 1);
         REAL a = INFINITY;
-#pragma omp parallel for reduction(min : a) schedule(static)
+        int has_nan = 0;
+#pragma omp parallel for reduction(min : a) reduction(| : has_nan) schedule(static)
         for (int64_t n = 0; n < N; ++n) {
             REAL x[3] = {(REAL)xyz[3 * n], (REAL)xyz[3 * n + 1], (REAL)xyz[3 * n + 2]}, c[3];
             FN(to_cam)(&cam, x, c);
             p[n] = FN(soft_vis)(&k, c, NULL);
             if (occ) p[n] = (REAL)occ[w * N + n] * p[n];
             if (p[n] < a) a = p[n];
+            if (p[n] != p[n]) has_nan = 1;
         }
+        if (has_nan) a = (REAL)NAN; /* torch.min() / max() propagate a NaN (a NaN or inf coordinate in the cloud): model.py:226 */
         REAL M = -INFINITY;
 #pragma omp parallel for reduction(max : M) schedule(static)
         for (int64_t n = 0; n < N; ++n) {
             p[n] = p[n] - a; /* model.py:226 */
             if (p[n] > M) M = p[n];
         }
+        if (has_nan) M = (REAL)NAN;
         pmin[w] = a;
         pmax[w] = M;
 #pragma omp parallel for schedule(static)
         for (int64_t n = 0; n < N; ++n) {
             REAL ph = p[n] / M; /* :227 */
-            ph = ph < (REAL)0.5 ? (REAL)0.5 : (ph > k.clip_hi ? k.clip_hi : ph); /* :229 */
+            ph = ph < (REAL)0.5 ? (REAL)0.5 : (ph > k.clip_hi ? k.clip_hi : ph); /* :229 (a NaN passes through, as in torch.clip) */
             const REAL lo = r_log(ph / ((REAL)1 - ph)); /* :230 */
             lo_sum[n] = lo_sum[n] + lo;                  /* :231 */
         }
@@ -242,6 +246,13 @@ int FN(oracle_traj_forward)(const float *xyz, int64_t N, const float *poses, con
     return 0;
 }
 
+/* Diagnostic knob of the backward below (tests/test_hip_conditioning.py): the lower activity threshold of the clipped log-odds
+ * (model.py:229: p_hat >= 1/2 carries gradient) moved by `shift`.  The gradient with the threshold at 1/2 - d minus the one with
+ * it at 1/2 + d is what the points within d of the threshold are worth — the amount by which two correct f32 evaluations of the
+ * reference's formula may differ on a waypoint that has such a point.  0 = the reference's rule. */
+static double FN(g_act_shift) = 0.0;
+void FN(oracle_set_act_shift)(double shift) { FN(g_act_shift) = shift; }
+
 /* Backward of loss_vis w.r.t. the evaluated waypoints' (poses, quats).  rewards/pmin/pmax from the
  * forward; gout = dL/d loss_vis.  Outputs poses_grad[W*3], quats_grad[W*4]. */
 int FN(oracle_traj_backward)(const float *xyz, int64_t N, const float *poses, const float *quats, int64_t W,
@@ -257,20 +268,24 @@ int FN(oracle_traj_backward)(const float *xyz, int64_t N, const float *poses, co
         FN(cam_t) cam;
         FN(make_cam)(&cam, quats + 4 * w, poses + 3 * w, 1);
         REAL a = INFINITY;
-#pragma omp parallel for reduction(min : a) schedule(static)
+        int has_nan = 0;
+#pragma omp parallel for reduction(min : a) reduction(| : has_nan) schedule(static)
         for (int64_t n = 0; n < N; ++n) {
             REAL x[3] = {(REAL)xyz[3 * n], (REAL)xyz[3 * n + 1], (REAL)xyz[3 * n + 2]}, c[3];
             FN(to_cam)(&cam, x, c);
             p[n] = FN(soft_vis)(&k, c, NULL);
             if (occ) p[n] = (REAL)occ[w * N + n] * p[n];
             if (p[n] < a) a = p[n];
+            if (p[n] != p[n]) has_nan = 1;
         }
+        if (has_nan) a = (REAL)NAN; /* torch.min() / max() propagate a NaN (a NaN or inf coordinate in the cloud): model.py:226 */
         REAL M = -INFINITY;
 #pragma omp parallel for reduction(max : M) schedule(static)
         for (int64_t n = 0; n < N; ++n) {
             const REAL pp = p[n] - a;
             if (pp > M) M = pp;
         }
+        if (has_nan) M = (REAL)NAN;
         /* S1 = sum G (phat-1)/M -> shared by argmin ties ; S2 = sum G (-phat)/M -> argmax ties */
         double S1 = 0, S2 = 0, Gt[3] = {0, 0, 0}, GR[9] = {0};
         double At_min[3] = {0}, AR_min[9] = {0}, At_max[3] = {0}, AR_max[9] = {0};
@@ -284,7 +299,7 @@ int FN(oracle_traj_backward)(const float *xyz, int64_t N, const float *poses, co
                 const REAL pp = p[n] - a;
                 const REAL ph = pp / M;
                 const int is_min = (p[n] == a), is_max = (pp == M);
-                const int act = (ph >= (REAL)0.5 && ph <= k.clip_hi);
+                const int act = ((double)ph >= 0.5 + FN(g_act_shift) && ph <= k.clip_hi);
                 if (!act && !is_min && !is_max) continue;
                 REAL x[3] = {(REAL)xyz[3 * n], (REAL)xyz[3 * n + 1], (REAL)xyz[3 * n + 2]}, c[3], g[3];
                 FN(vis_t) s;
@@ -327,6 +342,10 @@ int FN(oracle_traj_backward)(const float *xyz, int64_t N, const float *poses, co
         for (int i = 0; i < 3; ++i) Gt[i] += wmin * At_min[i] + wmax * At_max[i];
         for (int i = 0; i < 9; ++i) GR[i] += wmin * AR_min[i] + wmax * AR_max[i];
         FN(pose_chain)(&cam, Gt, GR, poses_grad + 3 * w, quats_grad + 4 * w);
+        if (has_nan) { /* autograd through the NaN min / max: every entry of the waypoint's gradient is NaN (probed on the reference) */
+            for (int i = 0; i < 3; ++i) poses_grad[3 * w + i] = (REAL)NAN;
+            for (int i = 0; i < 4; ++i) quats_grad[4 * w + i] = (REAL)NAN;
+        }
     }
     free(p);
     return 0;

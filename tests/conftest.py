@@ -50,3 +50,58 @@ def rel_inf(a, b):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def load_reference_case(name):
+    """A fixture of tests/golden/make_golden.py `dense`: the reference's f32 rewards / visibility gradients for a cloud stored by
+    recipe -> the fixture dict with `points` regenerated (and checked against the stored checksum) and `clip` = (min, max) dist."""
+    from trajectory_optimization_amd import synth
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    if str(d["recipe"]) == "room":
+        pts = synth.make_cloud(int(d["n"]), seed=int(d["seed"]), extent=tuple(float(x) for x in d["extent"]))
+    else:
+        from test_hip_conditioning import configurations
+        pts = next(c[1] for c in configurations() if c[0] == int(d["index"]))
+    assert float(pts.astype(np.float64).sum()) == float(d["points_checksum"]), "the recipe no longer reproduces the fixture's cloud"
+    d["points"], d["clip"] = pts, (float(d["min_dist"]), float(d["max_dist"]))
+    return d
+
+
+def conditional_gradient_report(d, gp, gq, margin, tol=1e-5):
+    """The 1e-5 gradient bar against the REFERENCE's own f32 gradients (d: load_reference_case), with its condition made explicit:
+      kept waypoints (no point within `margin` of a threshold of the clipped log-odds, model.py:229): |g - ref| / max|ref| < tol;
+      excluded waypoints: |g - ref| and |ref - oracle f64| are both bounded by what the points inside the band are worth — the
+      f64 oracle's gradient with the activity threshold at 1/2 - 2 margin minus the one with it at 1/2 + 2 margin — i.e. the
+      reference's own f32 result is as undecided there as the implementation under test.
+    -> dict(kept, excluded, worst_kept, worst_excluded, worst_kept_own_row): the last one measures every kept waypoint against its
+    OWN row's norm instead of the global maximum (a waypoint with a small gradient is not hidden behind a large one)."""
+    from oracle import oracle
+    from test_hip_conditioning import _margins
+    from trajectory_optimization_amd import synth
+    K, IW, IH = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
+    pts, poses, quats, clip = d["points"], d["poses"], d["quats"], d["clip"]
+    keep = _margins(pts, poses, quats, clip) > margin
+    out = dict(kept=int(keep.sum()), excluded=int((~keep).sum()), worst_kept=0.0, worst_excluded=0.0, worst_kept_own_row=0.0)
+    band = None
+    if not keep.all():
+        f = oracle.traj_forward(pts, poses, quats, K, IW, IH, clip[0], clip[1], prec="f64")
+        g64 = oracle.traj_backward(pts, poses, quats, K, IW, IH, f, min_dist=clip[0], max_dist=clip[1], prec="f64")
+        lo = oracle.traj_backward(pts, poses, quats, K, IW, IH, f, min_dist=clip[0], max_dist=clip[1], prec="f64", act_shift=-2 * margin)
+        hi = oracle.traj_backward(pts, poses, quats, K, IW, IH, f, min_dist=clip[0], max_dist=clip[1], prec="f64", act_shift=2 * margin)
+        band = [np.abs(a - b).max(axis=1) for a, b in zip(lo, hi)]
+    for k, (g, ref) in enumerate(((gp, d["vis_poses_grad"]), (gq, d["vis_quats_grad"]))):
+        g, ref = np.asarray(g, np.float64), np.asarray(ref, np.float64)
+        den = np.abs(ref).max()
+        err = np.abs(g - ref).max(axis=1)
+        assert (err[keep] < tol * den).all(), (k, (err[keep] / den).max())
+        out["worst_kept"] = max(out["worst_kept"], float((err[keep] / den).max()))
+        own = np.abs(ref).max(axis=1)
+        big = keep & (own > 1e-3 * den)   # (a row that is numerically zero has no relative error to speak of)
+        out["worst_kept_own_row"] = max(out["worst_kept_own_row"], float((err[big] / own[big]).max()) if big.any() else 0.0)
+        for v in np.flatnonzero(~keep):
+            ref_vs_f64 = np.abs(ref[v] - g64[k][v]).max()
+            assert band[k][v] > 0, "an excluded waypoint must have a point inside the band"
+            assert err[v] <= 1.05 * band[k][v] + tol * den, (k, v, err[v], band[k][v])
+            assert ref_vs_f64 <= 1.05 * band[k][v] + tol * den, (k, v, ref_vs_f64, band[k][v])
+            out["worst_excluded"] = max(out["worst_excluded"], float(err[v] / den), float(ref_vs_f64 / den))
+    return out

@@ -450,6 +450,35 @@ def gen_ingest():
     save("ingest", **out)
 
 
+def gen_dense():
+    """The reference's own f32 results where the 1e-5 gradient bar is conditional (tests/test_hip_reference_dense.py): a dense
+    room — 200 k points in 6 x 6 x 3 m, 8 waypoints, ~1 850 points per cubic metre — and the two configurations of
+    tests/test_hip_conditioning.py's generator in which a waypoint has a point within f32 rounding of p_hat = 1/2
+    (/root/reference/src/model.py:229).  The clouds are stored by recipe (seeded generators of trajectory_optimization_amd.synth)
+    with a checksum.  python tests/golden/make_golden.py dense"""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_hip_conditioning import configurations
+
+    def ref_vis(pts, poses, quats, clip):
+        m = ref_model.ModelTraj(points=torch.from_numpy(pts), wps_poses=torch.from_numpy(poses), wps_quats=torch.from_numpy(quats),
+                                intrins=K, img_width=IMG_W, img_height=IMG_H, device=CPU, min_dist=clip[0], max_dist=clip[1])
+        m(vis_wps_dist=0.0)
+        m.loss["vis"].backward()
+        return dict(loss_vis=m.loss["vis"], rewards=m.rewards, vis_poses_grad=m.poses.grad, vis_quats_grad=m.quats.grad)
+
+    n, w, ext = 200_000, 8, (6.0, 6.0, 3.0)
+    pts = synth.make_cloud(n, seed=0, extent=ext)
+    poses, quats = synth.make_path(w, optical=True, scale=ext[0] / 40.0)
+    save("traj_dense_room_200k", recipe=np.asarray("room"), n=n, seed=0, extent=np.asarray(ext), poses=poses, quats=quats,
+         min_dist=np.float64(1.0), max_dist=np.float64(5.0), points_checksum=np.float64(pts.astype(np.float64).sum()),
+         **ref_vis(pts, poses, quats, (1.0, 5.0)))
+    for it, pts, poses, quats, clip, _dense in configurations():
+        if it in (32, 34):
+            save(f"traj_conditioning_{it}", recipe=np.asarray("conditioning"), index=it, poses=poses, quats=quats,
+                 min_dist=np.float64(clip[0]), max_dist=np.float64(clip[1]), points_checksum=np.float64(pts.astype(np.float64).sum()),
+                 **ref_vis(pts, poses, quats, clip))
+
+
 def gen_timing():
     """Not a fixture: wall time of the reference itself (torch CPU, this container) on the bench workload's shape, for
     the record kept in profiles/r01_reference_cpu_timing.txt.  python tests/golden/make_golden.py timing"""

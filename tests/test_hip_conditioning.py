@@ -38,14 +38,11 @@ def _margins(pts, poses, quats, clip):
     return np.array(out)
 
 
-def test_parity_bar_on_random_configurations_states_its_condition():
-    from oracle import oracle
-    from trajectory_optimization_amd.model import ModelTraj
-    dev = torch.device("cuda:0")
-    rng = np.random.default_rng(2026)
-    n_wps = n_excluded = 0
-    worst = 0.0
-    for it in range(40):
+def configurations(count=40, seed=2026):
+    """The seeded random configurations of the test below (tests/golden/make_golden.py `dense` runs the reference on one of them)
+    -> (index, points, poses, quats, clip limits, dense flag)."""
+    rng = np.random.default_rng(seed)
+    for it in range(count):
         n = int(rng.choice([900, 6000, 30_000, 90_000]))
         w = int(rng.integers(3, 24))
         scale = float(rng.choice([0.3, 1.0, 2.0]))
@@ -53,8 +50,19 @@ def test_parity_bar_on_random_configurations_states_its_condition():
         poses, quats = synth.make_path(w, optical=True, jitter_seed=int(rng.integers(1 << 30)))
         quats = (quats * np.float32(rng.uniform(0.5, 2.0))).astype(np.float32)
         clip = (float(rng.uniform(0.3, 2.0)), float(rng.uniform(3.0, 10.0)))
+        yield it, pts, poses, quats, clip, bool(rng.random() < 0.5)
+
+
+def test_parity_bar_on_random_configurations_states_its_condition():
+    from oracle import oracle
+    from trajectory_optimization_amd.model import ModelTraj
+    dev = torch.device("cuda:0")
+    n_wps = n_excluded = 0
+    worst = 0.0
+    for it, pts, poses, quats, clip, dense in configurations():
+        n, w = len(pts), len(poses)
         m = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(K), IW, IH,
-                      min_dist=clip[0], max_dist=clip[1], device=dev, dense=bool(rng.random() < 0.5))
+                      min_dist=clip[0], max_dist=clip[1], device=dev, dense=dense)
         m(vis_wps_dist=0.0)
         m.loss["vis"].backward()
         f = oracle.traj_forward(pts, poses, quats, K, IW, IH, clip[0], clip[1], prec="f64")

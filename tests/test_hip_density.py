@@ -52,7 +52,16 @@ def test_dense_room_against_the_oracle(extent, w):
     eq = np.abs(qg - qgo).max(axis=1) / np.abs(qgo).max()
     assert keep.sum() >= w // 2, keep.sum()
     assert (ep[keep] < 1e-5).all() and (eq[keep] < 1e-5).all(), (ep[keep].max(), eq[keep].max())
-    assert ep.max() < 1e-3 and eq.max() < 1e-3   # and the others are off by single points, not by anything systematic
+    # and the others are off by single points, not by anything systematic: by no more than the points within 2 MARGIN of p_hat = 1/2
+    # are worth (the f64 oracle with the activity threshold moved down / up by that much; tests/test_hip_reference_dense.py shows on
+    # reference-generated fixtures that the reference's own f32 gradient is as undecided on such waypoints)
+    if not keep.all():
+        lo_g = oracle.traj_backward(pts, poses, quats, K, IW, IH, f, prec="f64", act_shift=-2 * MARGIN)
+        hi_g = oracle.traj_backward(pts, poses, quats, K, IW, IH, f, prec="f64", act_shift=2 * MARGIN)
+        for g, go, a_lo, a_hi in ((pg, pgo, lo_g[0], hi_g[0]), (qg, qgo, lo_g[1], hi_g[1])):
+            band = np.abs(a_lo - a_hi).max(axis=1)
+            err = np.abs(g - go).max(axis=1)
+            assert (err[~keep] <= 1.05 * band[~keep] + 1e-5 * np.abs(go).max()).all(), (err[~keep], band[~keep])
     warnings.warn(f"dense room {extent}: {int((~keep).sum())} of {w} waypoints have a point within {MARGIN:g} of a threshold and were excluded from "
                   f"the 1e-5 gradient bar (worst of them {max(ep.max(), eq.max()):.1e}); worst among the others {max(ep[keep].max(), eq[keep].max()):.1e}")
 

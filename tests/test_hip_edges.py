@@ -108,6 +108,35 @@ def test_cloud_entirely_invisible(dev):
     assert np.isnan(f["rewards"]).all() and np.isnan(r).all()
 
 
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+@pytest.mark.parametrize("n,row", [(5000, 1234), (300_000, 0), (300_000, 299_999)])
+def test_a_nan_or_inf_coordinate_poisons_everything_like_the_reference(dev, bad, n, row):
+    """One NaN / inf coordinate in the cloud: the reference's p is NaN for that point, torch.min() / max() propagate it, and every
+    reward of every waypoint, the loss and every gradient entry are NaN (/root/reference/src/model.py:226-231; probed on the
+    reference itself: 5 000 of 5 000 rewards, 12 + 16 of 12 + 16 gradient entries).  fmax / fmin and the culling would drop such a
+    point silently: tohip_pack_cloud notes it, the probe makes every waypoint degenerate.  Both modes; ModelTraj and the raw calls;
+    ModelPose: its sum, hence its loss."""
+    from trajectory_optimization_amd.model import ModelPose, ModelTraj
+    pts = synth.make_cloud(n, seed=5)
+    pts[row, 1] = bad
+    poses, quats = synth.make_path(4, optical=True, jitter_seed=5)
+    f, opg, oqg = _oracle(pts, poses, quats)
+    assert np.isnan(f["rewards"]).all() and np.isnan(f["loss_vis"]) and np.isnan(opg).all() and np.isnan(oqg).all()
+    for flags in (0, 1):
+        r, sc, pg, qg, _ = _run(dev, pts, poses, quats, flags=flags)
+        assert np.isnan(r).all() and np.isnan(sc[0]) and np.isnan(sc[1])
+        assert np.isnan(pg).all() and np.isnan(qg).all()
+    m = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(K), IW, IH, device=dev)
+    loss = m(vis_wps_dist=0.0)
+    loss.backward()
+    assert torch.isnan(loss) and torch.isnan(m.rewards).all() and torch.isnan(m.poses.grad).all() and torch.isnan(m.quats.grad).all()
+    mp = ModelPose(torch.from_numpy(pts), torch.from_numpy(poses[:1]), torch.from_numpy(quats[:1]), torch.from_numpy(K), IW, IH, device=dev)
+    lp = mp()
+    lp.backward()
+    obs = mp.observations.detach().cpu().numpy()
+    assert torch.isnan(lp) and np.isnan(obs[row]) and np.isfinite(np.delete(obs, row)).all() and torch.isnan(mp.trans.grad).all()
+
+
 def test_pose_model_general_K(dev):
     from oracle import oracle
     from trajectory_optimization_amd.model import ModelPose

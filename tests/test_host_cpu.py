@@ -37,7 +37,7 @@ def test_sizes_and_argument_errors_without_gpu():
     # null pointers / bad sizes are rejected before any launch
     assert L.tohip_pack_cloud(None, 10, 1, None, None, 0, None) == -1
     # x|y|z, perm, bounds, inverse perm, the probe's samples
-    assert L.tohip_packed_cloud_bytes(1000) == 2048 * 16 + 8 * 16 + 2048 * 4 + 8192 * 12
+    assert L.tohip_packed_cloud_bytes(1000) == 2048 * 16 + 8 * 16 + 2048 * 4 + 8192 * 12 + 256   # ... + the header
     cam = _lib.make_camera([1, 0, 0, 0, 1, 0, 0, 0, 1], 10, 10, 1, 5)
     assert L.tohip_traj_forward(None, 10, None, None, 1, ctypes.byref(cam), None, 0, None, None, None, None, None, 0, None) == -1
     assert L.tohip_hidden_pts_removal(None, 2, 2.0, None, None, None, None, 0, None) == -1

@@ -45,6 +45,29 @@ def test_traj_forward_backward(name, prec):
             assert np.all(d["quats_grad"][np.setdiff1d(np.arange(len(d["poses"])), idx)] == 0)
 
 
+REFERENCE_CASES = ["traj_dense_room_200k", "traj_conditioning_32", "traj_conditioning_34"]
+
+
+@pytest.mark.parametrize("name", REFERENCE_CASES)
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_conditional_gradient_bar_against_the_reference(name, prec):
+    """Where the 1e-5 gradient bar is conditional (a point within f32 rounding of p_hat = 1/2, model.py:229) the yardstick is
+    the REFERENCE's own f32 result (tests/golden/make_golden.py dense), not the oracle: kept waypoints meet the bar against it,
+    and on the excluded ones the reference differs from the f64 restatement by no more than the points inside the band are
+    worth — its own result is as undecided as anybody's (conftest.conditional_gradient_report)."""
+    from conftest import conditional_gradient_report, load_reference_case
+    from test_hip_conditioning import MARGIN
+    d = load_reference_case(name)
+    fwd = oracle.traj_forward(d["points"], d["poses"], d["quats"], K, IW, IH, d["clip"][0], d["clip"][1], prec=prec)
+    assert abs(fwd["loss_vis"] - float(d["loss_vis"])) <= 2e-6 * float(d["loss_vis"])
+    np.testing.assert_allclose(fwd["rewards"], d["rewards"], rtol=2e-5, atol=2e-6)
+    pg, qg = oracle.traj_backward(d["points"], d["poses"], d["quats"], K, IW, IH, fwd, min_dist=d["clip"][0], max_dist=d["clip"][1], prec=prec)
+    rep = conditional_gradient_report(d, pg, qg, MARGIN)
+    assert rep["kept"] >= len(d["poses"]) - 2
+    if name.startswith("traj_conditioning"):
+        assert rep["excluded"] >= 1   # the configurations were picked for having such a waypoint
+
+
 def test_known_answers_bundled():
     """SURVEY.md §8c known answers."""
     d = load_golden("traj_bundled_default")

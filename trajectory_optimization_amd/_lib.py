@@ -105,6 +105,10 @@ SIGNATURES = {
                                            c_vp]),
     "tohip_pose_backward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(Camera), c_vp, c_vp, c_vp, c_vp, c_vp,
                                             c_vp, c_vp, c_sz, c_vp]),
+    "tohip_pose_forward_backward": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(Camera), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                    c_vp, c_sz, c_vp]),
+    "tohip_pose_opt_step": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(Camera), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                            c_vp, c_f, c_f, c_f, c_f, c_f, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "tohip_to_camera_frame": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     "tohip_soft_masks": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(Camera), c_vp, c_vp, c_vp]),
     "tohip_soft_masks_backward": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(Camera), c_vp, c_vp, c_vp, c_vp]),

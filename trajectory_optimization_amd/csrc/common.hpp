@@ -79,6 +79,8 @@ struct CloudView {
     const float4* bounds;   // per 256 sorted points: bounding-sphere centre xyz, radius (conservative)
     const int* inv;         // original index -> sorted position (n entries)
     const float* samples;   // every sample_step-th sorted point, x | y | z (TO_PROBE_MAX each): the probe's strided sample, contiguous
+    const int* hdr;         // 64 ints: [0] = 1 when the points are Morton-sorted, 0 when they keep the caller's order (perm = identity);
+                            // [1] != 0 when some coordinate of the cloud is NaN or inf
     int64_t npad;
     int64_t n;
     int nsamples, sample_step;
@@ -98,10 +100,10 @@ static inline hipError_t sort_pairs(void* tmp, size_t& bytes, const Key* keys_in
 }
 
 // Packed cloud blob (tohip_pack_cloud): [x|y|z f32, 3*npad] [perm i32, npad] [bounds float4, npad/256] [inv i32, npad]
-// [samples x|y|z f32, 3*TO_PROBE_MAX]
+// [samples x|y|z f32, 3*TO_PROBE_MAX] [header, 64 i32]
 static inline size_t packed_cloud_bytes(int64_t n) {
     const int64_t npad = tohip_padded_points(n);
-    return (size_t)npad * 16 + (size_t)(npad / 256) * 16 + (size_t)npad * 4 + (size_t)TO_PROBE_MAX * 12;
+    return (size_t)npad * 16 + (size_t)(npad / 256) * 16 + (size_t)npad * 4 + (size_t)TO_PROBE_MAX * 12 + 256;
 }
 static inline CloudView cloud_view(const void* packed, int64_t n) {
     CloudView cv;
@@ -112,6 +114,7 @@ static inline CloudView cloud_view(const void* packed, int64_t n) {
     cv.bounds = (const float4*)((const char*)packed + (size_t)cv.npad * 16);
     cv.inv = (const int*)((const char*)packed + (size_t)cv.npad * 16 + (size_t)(cv.npad / 256) * 16);
     cv.samples = (const float*)((const char*)packed + (size_t)cv.npad * 16 + (size_t)(cv.npad / 256) * 16 + (size_t)cv.npad * 4);
+    cv.hdr = (const int*)((const char*)cv.samples + (size_t)TO_PROBE_MAX * 12);
     cv.sample_step = probe_step(n);
     cv.nsamples = (int)((n + cv.sample_step - 1) / cv.sample_step);
     return cv;

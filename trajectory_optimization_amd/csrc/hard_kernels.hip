@@ -77,11 +77,15 @@ __global__ void __launch_bounds__(TO_BLOCK) k_iota(int* __restrict__ vals, int64
 
 __global__ void __launch_bounds__(TO_BLOCK)
 k_pack_cloud(const float* __restrict__ xyz, const int* __restrict__ order, int64_t n, int64_t npad, float* __restrict__ soa,
-             int* __restrict__ perm, int* __restrict__ inv, float* __restrict__ samples, int sample_step) {
+             int* __restrict__ perm, int* __restrict__ inv, float* __restrict__ samples, int sample_step, int* __restrict__ hdr, int sorted) {
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = sorted;   // (the header was cleared before the launch)
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < npad; i += stride) {
         const int64_t s = order[i < n ? i : n - 1];
         const float px = xyz[3 * s], py = xyz[3 * s + 1], pz = xyz[3 * s + 2];
+        // a NaN / inf coordinate: the reference's min() over p makes every reward of every waypoint NaN (model.py:226) — noted once
+        // here, honoured by k_traj_probe (fmax / fmin and the culling would drop such a point silently)
+        if (i < n && !(isfinite(px) && isfinite(py) && isfinite(pz))) atomicOr(&hdr[1], 1);
         soa[i] = px;
         soa[npad + i] = py;
         soa[2 * npad + i] = pz;
@@ -191,8 +195,12 @@ extern "C" int tohip_pack_cloud(const float* xyz, int64_t n, int sort, void* pac
     const CloudView cv = cloud_view(packed, n);
     int64_t nbp = npad / TO_BLOCK;
     if (nbp > 4096) nbp = 4096;
+    {
+        hipError_t e = hipMemsetAsync((void*)cv.hdr, 0, 256, st);
+        if (e != hipSuccess) return (int)e;
+    }
     k_pack_cloud<<<(int)nbp, TO_BLOCK, 0, st>>>(xyz, order, n, npad, (float*)cv.soa, (int*)cv.perm, (int*)cv.inv, (float*)cv.samples,
-                                                cv.sample_step);
+                                                cv.sample_step, (int*)cv.hdr, sort ? 1 : 0);
     TO_HIP_CHECK_LAUNCH();
     k_tile_bounds<<<(int)(npad / TO_BLOCK), TO_BLOCK, 0, st>>>(cv.soa, npad, (float4*)cv.bounds);
     TO_HIP_CHECK_LAUNCH();
@@ -219,10 +227,11 @@ __device__ __forceinline__ void frustum_pred(const FrustumConsts& f, float X, fl
 
 #define TO_CULL_TILE 1024
 
-// pass A: masks + number of kept points per 1024-point tile
+// pass A: masks + number of kept points per 1024-point tile; the kept points of every 64 as one word (keep[i / 64]): pass C
+// reads those 2 bits per 16 points instead of the points again
 __global__ void __launch_bounds__(TO_BLOCK)
 k_frustum_count(const float* __restrict__ cam, int64_t n, FrustumConsts f, uint8_t* __restrict__ dist_mask,
-                uint8_t* __restrict__ fov_mask, int32_t* __restrict__ tile_count) {
+                uint8_t* __restrict__ fov_mask, int32_t* __restrict__ tile_count, unsigned long long* __restrict__ keep) {
     __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
     const int64_t tile0 = (int64_t)blockIdx.x * TO_CULL_TILE;
     int cnt = 0;
@@ -234,68 +243,87 @@ k_frustum_count(const float* __restrict__ cam, int64_t n, FrustumConsts f, uint8
             if (dist_mask) dist_mask[i] = d ? 1 : 0;
             if (fov_mask) fov_mask[i] = v ? 1 : 0;
         }
-        cnt += __popcll(__ballot(d && v));
+        const unsigned long long b = __ballot(d && v);
+        if ((threadIdx.x & 63) == 0 && tile0 + j * TO_BLOCK + threadIdx.x < n) keep[(tile0 + j * TO_BLOCK + threadIdx.x) >> 6] = b;
+        cnt += __popcll(b);
     }
     if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) tile_count[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
-// pass B: exclusive scan of the tile counts (one block, chunks of 256, in order)
-__global__ void __launch_bounds__(TO_BLOCK)
+// pass B: exclusive scan of the tile counts, one block, in rounds of 4 counts per thread: a 16-byte load (coalesced), the
+// thread's own prefix, a scan of the threads' sums (shuffles inside a wave, the waves' totals through LDS), the running carry.
+// (A 256-wide Hillis-Steele scan per 256 counts — 18 barriers each — took 69 us for the 15 625 tiles of a 16 M-point cloud.)
+__global__ void __launch_bounds__(1024)
 k_scan_tiles(const int32_t* __restrict__ tile_count, int ntiles, int32_t* __restrict__ tile_off,
              int32_t* __restrict__ total) {
-    __shared__ int lds[TO_BLOCK];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < ntiles; c0 += TO_BLOCK) {
-        const int i = c0 + threadIdx.x;
-        const int v = i < ntiles ? tile_count[i] : 0;
-        lds[threadIdx.x] = v;
-        __syncthreads();
-        for (int s = 1; s < TO_BLOCK; s <<= 1) {  // Hillis-Steele inclusive scan
-            const int add = (int)threadIdx.x >= s ? lds[threadIdx.x - s] : 0;
-            __syncthreads();
-            lds[threadIdx.x] += add;
-            __syncthreads();
+    __shared__ int wsum[2][16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = (blockDim.x + 63) >> 6;
+    const bool vec = ((((uintptr_t)tile_count) | ((uintptr_t)tile_off)) & 15) == 0;
+    int carry = 0, buf = 0;
+    for (int c0 = 0; c0 < ntiles; c0 += 4 * (int)blockDim.x, buf ^= 1) {
+        const int i = c0 + 4 * t;
+        int v[4] = {0, 0, 0, 0};
+        if (vec && i + 4 <= ntiles) {
+            const int4 q = *reinterpret_cast<const int4*>(tile_count + i);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            for (int k = 0; k < 4; ++k) if (i + k < ntiles) v[k] = tile_count[i + k];
         }
-        if (i < ntiles) tile_off[i] = carry + lds[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry += lds[TO_BLOCK - 1];
-        __syncthreads();
+        const int s = v[0] + v[1] + v[2] + v[3];
+        int incl = s;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const int up = __shfl_up(incl, sh);
+            if (lane >= sh) incl += up;
+        }
+        if (lane == 63) wsum[buf][wave] = incl;
+        __syncthreads();   // (the two buffers alternate: the next round's writes cannot overtake this round's reads)
+        int base = carry, all = 0;
+        for (int w = 0; w < nw; ++w) { if (w < wave) base += wsum[buf][w]; all += wsum[buf][w]; }
+        int run = base + incl - s;
+        if (vec && i + 4 <= ntiles) {
+            *reinterpret_cast<int4*>(tile_off + i) = make_int4(run, run + v[0], run + v[0] + v[1], run + v[0] + v[1] + v[2]);
+        } else {
+            for (int k = 0; k < 4; ++k) { if (i + k < ntiles) tile_off[i + k] = run; run += v[k]; }
+        }
+        carry += all;
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (t == 0) *total = carry;
+}
+inline void launch_scan_tiles(const int32_t* tile_count, int ntiles, int32_t* tile_off, int32_t* total, hipStream_t st) {
+    k_scan_tiles<<<1, ntiles > 2048 ? 1024 : TO_BLOCK, 0, st>>>(tile_count, ntiles, tile_off, total);
 }
 
 // pass C: ascending indices of kept points
 __global__ void __launch_bounds__(TO_BLOCK)
-k_frustum_write(const float* __restrict__ cam, int64_t n, FrustumConsts f, const int32_t* __restrict__ tile_off,
+k_frustum_write(int64_t n, const unsigned long long* __restrict__ keep, const int32_t* __restrict__ tile_off,
                 int32_t* __restrict__ kept_idx) {
-    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tile0 = (int64_t)blockIdx.x * TO_CULL_TILE;
-    int base = tile_off[blockIdx.x];
-    for (int j = 0; j < TO_CULL_TILE / TO_BLOCK; ++j) {
-        const int64_t i = tile0 + j * TO_BLOCK + threadIdx.x;
-        bool d = false, v = false;
-        if (i < n) frustum_pred(f, cam[i], cam[n + i], cam[2 * n + i], d, v);
-        const bool keep = d && v;
-        const unsigned long long b = __ballot(keep);
-        if (lane == 0) wave_cnt[wave] = __popcll(b);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        if (keep) kept_idx[off + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)i;
-        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
+    const int64_t nwords = (n + 63) >> 6;
+    const int ntiles = (int)((n + TO_CULL_TILE - 1) / TO_CULL_TILE);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // (a block per tile was 15 625 blocks of a few instructions each at 16 M points)
+        const int64_t tile0 = (int64_t)tile * TO_CULL_TILE;
+        // the tile's sixteen keep words (wave w of iteration j holds word 4 j + w), requested at once
+        const int64_t w0 = tile0 >> 6;
+        const unsigned long long mine = (lane < 16 && w0 + lane < nwords) ? keep[w0 + lane] : 0ull;
+        int off = tile_off[tile];
+        for (int q = 0; q < 16; ++q) {   // words in point order; every wave walks them all, its own word is q = 4 j + wave
+            const unsigned long long b = (unsigned long long)__shfl((long long)mine, q);
+            if ((q & 3) == wave) {
+                const int64_t i = tile0 + (int64_t)q * 64 + lane;
+                if ((b >> lane) & 1ull) kept_idx[off + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)i;
+            }
+            off += __popcll(b);
+        }
     }
 }
 
 extern "C" size_t tohip_frustum_workspace_bytes(int64_t n) {
     if (n <= 0) return 256;
     const size_t ntiles = (size_t)((n + TO_CULL_TILE - 1) / TO_CULL_TILE);
-    return 2 * ((ntiles * sizeof(int32_t) + 255) / 256 * 256) + 256;
+    return 2 * ((ntiles * sizeof(int32_t) + 255) / 256 * 256) + 256 + ((size_t)((n + 63) / 64) * 8 + 255) / 256 * 256;   // counts, offsets, total, keep bits
 }
 
 extern "C" int tohip_frustum_cull(const float* cam_3xN, int64_t n, const tohip_camera* cam, float min_dist,
@@ -322,14 +350,15 @@ extern "C" int tohip_frustum_cull(const float* cam_3xN, int64_t n, const tohip_c
     int32_t* tile_count = (int32_t*)workspace;
     int32_t* tile_off = (int32_t*)((char*)workspace + seg);
     int32_t* total_scratch = (int32_t*)((char*)workspace + 2 * seg);
-    k_frustum_count<<<ntiles, TO_BLOCK, 0, st>>>(cam_3xN, n, f, dist_mask, fov_mask, tile_count);
+    unsigned long long* keep = (unsigned long long*)((char*)workspace + 2 * seg + 256);
+    k_frustum_count<<<ntiles, TO_BLOCK, 0, st>>>(cam_3xN, n, f, dist_mask, fov_mask, tile_count, keep);
     TO_HIP_CHECK_LAUNCH();
     if (kept_idx || kept_count) {
-        k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(tile_count, ntiles, tile_off, kept_count ? kept_count : total_scratch);
+        launch_scan_tiles(tile_count, ntiles, tile_off, kept_count ? kept_count : total_scratch, st);
         TO_HIP_CHECK_LAUNCH();
     }
     if (kept_idx) {
-        k_frustum_write<<<ntiles, TO_BLOCK, 0, st>>>(cam_3xN, n, f, tile_off, kept_idx);
+        k_frustum_write<<<ntiles < 2048 ? ntiles : 2048, TO_BLOCK, 0, st>>>(n, keep, tile_off, kept_idx);
         TO_HIP_CHECK_LAUNCH();
     }
     return TOHIP_OK;
@@ -491,10 +520,13 @@ extern "C" int tohip_gather_points(const float* xyz, int64_t n, int in_layout, c
 
 __device__ __forceinline__ float flip_norm(float x, float y, float z) { return sqrtf(fmaf(z, z, fmaf(y, y, x * x))); }
 
-// max of the norms through an integer atomicMax on the float bits: norms are >= 0 so the integer order is
-// the float order, and a NaN (0x7fc00000) sorts above +inf, i.e. propagates like torch.max does.
+// max of the norms on the float bits: norms are >= 0 so the integer order is the float order, and a NaN (0x7fc00000) sorts
+// above +inf, i.e. propagates like torch.max does.  Every block leaves its maximum in parts[block] (no atomics: a few thousand of
+// them on one line would be served one after the other); k_flip's blocks each take the maximum of the parts.
+#define TO_FLIP_PARTS 2048
 __global__ void __launch_bounds__(TO_BLOCK)
-k_norm_max(const float* __restrict__ xyz, int64_t n, int* __restrict__ max_bits) {
+k_norm_max(const float* __restrict__ xyz, int64_t n, int* __restrict__ parts) {
+    __shared__ int sw[TO_WAVES_PER_BLOCK];
     int m = 0;
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
@@ -502,13 +534,21 @@ k_norm_max(const float* __restrict__ xyz, int64_t n, int* __restrict__ max_bits)
         m = max(m, __float_as_int(nr) & 0x7fffffff);
     }
     for (int s = 32; s > 0; s >>= 1) m = max(m, __shfl_xor(m, s));
-    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, m);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) parts[blockIdx.x] = max(max(sw[0], sw[1]), max(sw[2], sw[3]));
 }
 
 __global__ void __launch_bounds__(TO_BLOCK)
-k_flip(const float* __restrict__ xyz, int64_t n, const int* __restrict__ max_bits, float scale,
+k_flip(const float* __restrict__ xyz, int64_t n, const int* __restrict__ parts, int nparts, float scale,
        float* __restrict__ flipped, float* __restrict__ radius_out) {
-    const float radius = __int_as_float(*max_bits) * scale;  // tools.py:45
+    __shared__ int sw[TO_WAVES_PER_BLOCK];
+    int m = 0;
+    for (int i = threadIdx.x; i < nparts; i += TO_BLOCK) m = max(m, parts[i]);
+    for (int s = 32; s > 0; s >>= 1) m = max(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float radius = __int_as_float(max(max(sw[0], sw[1]), max(sw[2], sw[3]))) * scale;  // tools.py:45
     if (radius_out && blockIdx.x == 0 && threadIdx.x == 0) radius_out[0] = radius;
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
@@ -521,16 +561,15 @@ k_flip(const float* __restrict__ xyz, int64_t n, const int* __restrict__ max_bit
     }
 }
 
-static int launch_flip(const float* xyz, int64_t n, float param, float* flipped, float* radius_out, int* max_bits,
+// parts: TO_FLIP_PARTS ints of scratch
+static int launch_flip(const float* xyz, int64_t n, float param, float* flipped, float* radius_out, int* parts,
                        hipStream_t st) {
-    hipError_t e = hipMemsetAsync(max_bits, 0, sizeof(int), st);
-    if (e != hipSuccess) return (int)e;
     int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
-    if (nb > 2048) nb = 2048;
-    k_norm_max<<<(int)(nb < 256 ? nb : 256), TO_BLOCK, 0, st>>>(xyz, n, max_bits);  // one same-address atomic per wave
+    if (nb > TO_FLIP_PARTS) nb = TO_FLIP_PARTS;
+    k_norm_max<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, parts);
     TO_HIP_CHECK_LAUNCH();
     const float scale = (float)pow(10.0, (double)param);
-    k_flip<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, max_bits, scale, flipped, radius_out);
+    k_flip<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, parts, (int)nb, scale, flipped, radius_out);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }

@@ -78,7 +78,7 @@ struct Bufs {
     int* tile_cnt;         // ntiles(M1)
     int* tile_off;         // ntiles(M1)
     float* flipped;        // 3 * M (only used by hidden_pts_removal)
-    int* flip_max;         // nseg
+    int* flip_max;         // max(nseg, TO_FLIP_PARTS): per-viewpoint maxima (batched) / the single cloud's block maxima (launch_flip)
     // segments: independent point sets (one hull each) laid end to end; segment s owns the expanded indices
     // [seg_off[s], seg_off[s+1]) — its points followed by ONE slot for the appended origin — and the faces it
     // grows never reference another segment, so every round kernel below serves all hulls at once
@@ -158,7 +158,7 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * ntiles); if (b) b->tile_cnt = (int*)p;
     p = take(sizeof(int) * ntiles); if (b) b->tile_off = (int*)p;
     p = take(sizeof(float) * 3 * (size_t)n_points); if (b) b->flipped = (float*)p;
-    p = take(sizeof(int) * nseg); if (b) b->flip_max = (int*)p;
+    p = take(sizeof(int) * (nseg > TO_FLIP_PARTS ? nseg : TO_FLIP_PARTS)); if (b) b->flip_max = (int*)p;
     p = take(sizeof(int) * (nseg + 1)); if (b) b->seg_off = (int*)p;
     p = take(sizeof(int) * nseg); if (b) b->seg_status = (int*)p;
     p = take(sizeof(int) * nseg); if (b) b->seg_nan = (int*)p;
@@ -1494,7 +1494,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         hipError_t ej = hipMemsetAsync(b.seg_cnt, 0, sizeof(int) * (size_t)b.nseg, st);
         if (ej != hipSuccess) return (int)ej;
         k_seg_faces<<<nblocks(nf), TO_BLOCK, 0, st>>>(b, b.seg_cnt, nullptr, nullptr);
-        k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(b.seg_cnt, b.nseg, b.seg_start, b.seg_start + b.nseg);
+        launch_scan_tiles(b.seg_cnt, b.nseg, b.seg_start, b.seg_start + b.nseg, st);
         ej = hipMemsetAsync(b.flip_max, 0, sizeof(int) * (size_t)b.nseg, st);  // free since the flip: the scatter's cursors
         if (ej != hipSuccess) return (int)ej;
         k_seg_faces<<<nblocks(nf), TO_BLOCK, 0, st>>>(b, b.flip_max, b.seg_start, b.olist);  // olist is free between two rounds
@@ -1505,7 +1505,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         k_live_all<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);
         const int ntl = (b.m1 + 1023) / 1024;
         k_live_count<<<ntl, TO_BLOCK, 0, st>>>(b, b.m1, b.tile_cnt);
-        k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(b.tile_cnt, ntl, b.tile_off, b.ctrl + kCtrlNLive);
+        launch_scan_tiles(b.tile_cnt, ntl, b.tile_off, b.ctrl + kCtrlNLive, st);
         k_live_write<<<ntl, TO_BLOCK, 0, st>>>(b, b.m1, b.tile_off);
         TO_HIP_CHECK_LAUNCH();
         int* t = b.live; b.live = b.live2; b.live2 = t;
@@ -1585,7 +1585,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
             // drop the points that have retired inside the hull from the list the point kernels walk
             const int nlive = h[kCtrlNLive], ntl = (nlive + 1023) / 1024;
             k_live_count<<<ntl, TO_BLOCK, 0, st>>>(b, nlive, b.tile_cnt);
-            k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(b.tile_cnt, ntl, b.tile_off, b.ctrl + kCtrlNLive);
+            launch_scan_tiles(b.tile_cnt, ntl, b.tile_off, b.ctrl + kCtrlNLive, st);
             k_live_write<<<ntl, TO_BLOCK, 0, st>>>(b, nlive, b.tile_off);
             {
                 const hipError_t el = hipGetLastError();   // a readback may be in flight on the shared pinned buffers: drain before leaving
@@ -1615,7 +1615,7 @@ static int compact(const Bufs& b, int* out, int cap, int* total_dev, hipStream_t
     const int ntiles = (b.m1 + 1023) / 1024;
     k_flag_count<<<ntiles, TO_BLOCK, 0, st>>>(b.vflag, b.m1, b.tile_cnt);
     TO_HIP_CHECK_LAUNCH();
-    k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(b.tile_cnt, ntiles, b.tile_off, total_dev);
+    launch_scan_tiles(b.tile_cnt, ntiles, b.tile_off, total_dev, st);
     TO_HIP_CHECK_LAUNCH();
     k_flag_write<<<ntiles, TO_BLOCK, 0, st>>>(b.vflag, b.m1, b.tile_off, out, cap);
     TO_HIP_CHECK_LAUNCH();
@@ -1736,7 +1736,7 @@ extern "C" size_t tohip_hpr_batched_workspace_bytes(int64_t n_total, int32_t n_s
 extern "C" int tohip_spherical_flip(const float* xyz, int64_t n, float param, float* flipped, float* radius_out,
                                     void* workspace, size_t workspace_bytes, void* stream_) {
     if (!xyz || !flipped || !workspace || n <= 0) return TOHIP_EINVAL;
-    if (workspace_bytes < 256) return TOHIP_ENOSPC;
+    if (workspace_bytes < TOHIP_FLIP_WORKSPACE_BYTES) return TOHIP_ENOSPC;
     return launch_flip(xyz, n, param, flipped, radius_out, (int*)workspace, (hipStream_t)stream_);
 }
 
@@ -1837,7 +1837,7 @@ extern "C" int tohip_hidden_pts_removal_batched(const float* xyz, const int64_t*
     TO_HIP_CHECK_LAUNCH();
     hull::k_seg_counts<<<hull::nblocks(n_segments), TO_BLOCK, 0, st>>>(b);
     TO_HIP_CHECK_LAUNCH();
-    k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(b.seg_cnt, n_segments, seg_visible_offsets, seg_visible_offsets + n_segments);
+    launch_scan_tiles(b.seg_cnt, n_segments, seg_visible_offsets, seg_visible_offsets + n_segments, st);
     TO_HIP_CHECK_LAUNCH();
     if (mask && n > 0) {
         e = hipMemsetAsync(mask, 0, sizeof(float) * (size_t)n, st);

@@ -24,9 +24,33 @@ __device__ __forceinline__ float load_field(const uint8_t* p, int datatype, int 
     return __uint_as_float(u);
 }
 
+// `be` carries the layout class besides the byte order (bit 0): bit 1 = little-endian FLOAT32 fields at 4-byte aligned addresses
+// (point_step, offsets and the buffer all multiples of 4: the layout every ROS driver writes) — one dword load per field instead
+// of four byte loads; bit 2 = the same for FLOAT64 (8-byte aligned).
+#define TO_PC2_F32_ALIGNED 2
+#define TO_PC2_F64_ALIGNED 4
+#define TO_PC2_VEC16 8      // with F32_ALIGNED: 16-byte points at 16-byte aligned addresses (x, y, z, intensity): one 16-byte load
 __device__ __forceinline__ bool unpack_point(const uint8_t* data, int64_t i, int point_step, int xo, int yo, int zo,
                                              int datatype, int be, int remove_nans, float& x, float& y, float& z) {
     const uint8_t* p = data + i * point_step;
+    if (be & TO_PC2_F32_ALIGNED) {
+        if (be & TO_PC2_VEC16) {
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            const float f[4] = {v.x, v.y, v.z, v.w};
+            x = f[xo >> 2]; y = f[yo >> 2]; z = f[zo >> 2];
+        } else {
+            const float* q = reinterpret_cast<const float*>(p);
+            x = q[xo >> 2]; y = q[yo >> 2]; z = q[zo >> 2];
+        }
+        return !remove_nans || (isfinite(x) && isfinite(y) && isfinite(z));
+    }
+    if (be & TO_PC2_F64_ALIGNED) {
+        const double* q = reinterpret_cast<const double*>(p);
+        const double dx = q[xo >> 3], dy = q[yo >> 3], dz = q[zo >> 3];
+        x = (float)dx; y = (float)dy; z = (float)dz;
+        return !remove_nans || (isfinite(dx) && isfinite(dy) && isfinite(dz));   // np.isfinite on the stored f64 values
+    }
+    be &= 1;
     x = load_field(p + xo, datatype, be);
     y = load_field(p + yo, datatype, be);
     z = load_field(p + zo, datatype, be);
@@ -115,12 +139,17 @@ extern "C" int tohip_pointcloud2_to_xyz(const uint8_t* data, int64_t n_points, i
     const size_t sg = align_up((size_t)ntiles * sizeof(int32_t), 256);
     int32_t* tile_count = (int32_t*)workspace;
     int32_t* tile_off = (int32_t*)((char*)workspace + sg);
-    k_pc2_count<<<ntiles, TO_BLOCK, 0, st>>>(data, n_points, point_step, x_off, y_off, z_off, datatype, is_bigendian,
+    int layout = is_bigendian ? 1 : 0;
+    const int al = fsz - 1;
+    if (!is_bigendian && !(((uintptr_t)data | (uintptr_t)point_step | (uintptr_t)x_off | (uintptr_t)y_off | (uintptr_t)z_off) & (uintptr_t)al))
+        layout |= datatype == 8 ? TO_PC2_F64_ALIGNED : TO_PC2_F32_ALIGNED;
+    if ((layout & TO_PC2_F32_ALIGNED) && point_step == 16 && !((uintptr_t)data & 15)) layout |= TO_PC2_VEC16;
+    k_pc2_count<<<ntiles, TO_BLOCK, 0, st>>>(data, n_points, point_step, x_off, y_off, z_off, datatype, layout,
                                               remove_nans, tile_count);
     TO_HIP_CHECK_LAUNCH();
-    k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(tile_count, ntiles, tile_off, out_count);
+    launch_scan_tiles(tile_count, ntiles, tile_off, out_count, st);
     TO_HIP_CHECK_LAUNCH();
-    k_pc2_write<<<ntiles, TO_BLOCK, 0, st>>>(data, n_points, point_step, x_off, y_off, z_off, datatype, is_bigendian,
+    k_pc2_write<<<ntiles, TO_BLOCK, 0, st>>>(data, n_points, point_step, x_off, y_off, z_off, datatype, layout,
                                               remove_nans, tile_off, out_xyz);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
@@ -291,7 +320,7 @@ extern "C" int tohip_voxel_grid(const float* xyz, int64_t n, float leaf_x, float
     const int ntiles = (int)((n + 1023) / 1024);
     hull::k_flag_count<<<ntiles, TO_BLOCK, 0, st>>>(head, (int)n, tcnt);
     TO_HIP_CHECK_LAUNCH();
-    k_scan_tiles<<<1, TO_BLOCK, 0, st>>>(tcnt, ntiles, toff, out_count);
+    launch_scan_tiles(tcnt, ntiles, toff, out_count, st);
     TO_HIP_CHECK_LAUNCH();
     hull::k_flag_write<<<ntiles, TO_BLOCK, 0, st>>>(head, (int)n, toff, hpos, (int)n);
     TO_HIP_CHECK_LAUNCH();

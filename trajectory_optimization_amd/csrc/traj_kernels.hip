@@ -393,9 +393,15 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
     if (t == 0) {
         for (int w = 1; w < TO_PROBE_THREADS / 64; ++w) { mx = fmaxf(mx, smx[w]); mn = fminf(mn, smn[w]); }
         if (!(mn <= mx)) { mx = 0.f; mn = INFINITY; }   // a NaN among the sampled p (fmax/fmin drop it): no usable bound
+        // A NaN / inf coordinate anywhere in the cloud (noted by tohip_pack_cloud): the reference's p is NaN for that point, its
+        // min() and max() over p are NaN (torch propagates it), and with them every reward of every waypoint and every gradient
+        // (model.py:226-231).  The waypoint's maximum is set to NaN here — it sorts above every float in the integer order, so
+        // no atomicMax replaces it — which makes the waypoint degenerate: every slot is searched, flagged, and adds NaN.
+        const bool poisoned = cv.hdr[1] != 0;
+        if (poisoned) { mx = __builtin_nanf(""); mn = INFINITY; }
         float thr, sthr;
         cull_bound(0.5f * mx, k.inv_var, &thr, &sthr);   // d2 > thr  =>  p < L/2 <= M/2: neither the max nor flagged
-        rec[v].Lh = (mn == 0.f) ? 0.49f * mx : 0.f;
+        rec[v].Lh = (mn == 0.f && !poisoned) ? 0.49f * mx : 0.f;
         rec[v].L = mx;
         rec[v].U = mn;
         rec[v].thr1 = thr;
@@ -1617,6 +1623,9 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
         const double wmin = nmin > 0.0 ? stot[12] / nmin : 0.0;
         const double wmax = nmax > 0.0 ? stot[13] / nmax : 0.0;
         sgy[t] = (float)(stot[t] + wmin * stie[0][t] + wmax * stie[1][t]);   // sum gy [3], sum y (x) gy [9], world-aligned
+        // a degenerate waypoint (max == min, or a NaN among its p: the reference's p_hat is 0/0 or NaN for EVERY point, model.py:227):
+        // autograd's gradient through it is NaN in every entry, like the rewards
+        if (!(M > 0.f) || !(invM < INFINITY)) sgy[t] = __builtin_nanf("");
     }
     __syncthreads();
     if (t < 12) {

@@ -139,9 +139,10 @@ class _PoseObservations(torch.autograd.Function):
 
 
 class _PoseLoss(torch.autograd.Function):
-    """ModelPose.forward in one autograd node: (trans, quat) -> (loss, observations).  `loss.backward()` takes the fused
-    path of tohip_pose_backward (dL/d loss read on the device); a loss built on model.observations goes through the
-    general dL/d observations path."""
+    """ModelPose.forward in one autograd node: (trans, quat) -> (loss, observations).  The pass over the cloud that writes the
+    observations also takes the gradient sums of the fused loss (they do not depend on its value; tohip_pose_forward_backward), so
+    `loss.backward()` is a multiplication of seven numbers; a loss built on model.observations goes through the general
+    dL/d observations pass."""
 
     @staticmethod
     def forward(ctx, trans, quat, model, mask):
@@ -150,8 +151,14 @@ class _PoseLoss(torch.autograd.Function):
         plan = model._plan
         obs = torch.empty(plan.n, **plan.f32)
         scalars = torch.empty(4, **plan.f32)
-        plan.forward(trans, quat, mask, obs, scalars)
-        ctx.model, ctx.mask = model, mask
+        want_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        if want_grad:
+            grads = torch.empty(8, **plan.f32)   # d loss / d trans [0:3], d loss / d quat [4:8]
+            plan.forward_backward(trans, quat, mask, obs, scalars, grads)
+        else:
+            grads = None
+            plan.forward(trans, quat, mask, obs, scalars)
+        ctx.model, ctx.mask, ctx.grads = model, mask, grads
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(trans, quat, scalars)   # by reference: an in-place edit before backward() raises, as for torch's ops
         loss = scalars[1]
@@ -166,10 +173,8 @@ class _PoseLoss(torch.autograd.Function):
         if g_loss is None and g_obs is None:
             return None, None, None, None
         if g_obs is None:
-            plan = m._plan
-            tg, qg = torch.empty((1, 3), **plan.f32), torch.empty((1, 4), **plan.f32)
-            plan.backward(t, q, ctx.mask, scalars, g_loss.to(**plan.f32).reshape(1), tg, qg)
-            return tg, qg, None, None
+            g = g_loss.to(torch.float32) * ctx.grads
+            return g[0:3].reshape(1, 3), g[4:8].reshape(1, 4), None, None
         g = g_obs.to(torch.float32)
         if g_loss is not None:
             g = g - g_loss.to(torch.float32) * scalars[1] * scalars[1]  # d loss / d observation_n = -loss^2
@@ -476,23 +481,21 @@ class _FastBackward:
 
 
 class _FastBackwardPose(_FastBackward):
-    """The same for ModelPose: its backward kernels read the camera from the Parameters again, so the short cut is only taken
-    while they are what the forward saw (else torch's engine raises its in-place error)."""
-    __slots__ = ("mask", "scalars")
+    """The same for ModelPose: the forward's pass has taken the gradient of the fused loss already.  The short cut is only taken
+    while the Parameters are what the forward saw (else torch's engine raises its in-place error, as it would for torch's ops)."""
+    __slots__ = ("grads",)
 
-    def __init__(self, plan, node, params, mask, scalars):
+    def __init__(self, plan, node, params, grads):
         super().__init__(plan, 0, node, params)
-        self.mask, self.scalars = mask, scalars
+        self.grads = grads
 
     def usable(self, loss):
         p, q = self.params
-        return p._version == self.versions[0] and q._version == self.versions[1] and super().usable(loss)
+        return self.grads is not None and p._version == self.versions[0] and q._version == self.versions[1] and super().usable(loss)
 
     def compute(self):
-        plan = self.plan
-        tg, qg = torch.empty((1, 3), **plan.f32), torch.empty((1, 4), **plan.f32)
-        plan.backward(self.params[0], self.params[1], self.mask, self.scalars, plan.one, tg, qg)
-        return tg, qg
+        g = self.grads
+        return g[0:3].reshape(1, 3).clone(), g[4:8].reshape(1, 4).clone()
 
 
 class _PosePlan:
@@ -500,7 +503,7 @@ class _PosePlan:
 
     def __init__(self, model):
         L = _lib.lib()
-        self.fwd, self.bwd = L.tohip_pose_forward, L.tohip_pose_backward
+        self.fwd, self.bwd, self.fwdbwd = L.tohip_pose_forward, L.tohip_pose_backward, L.tohip_pose_forward_backward
         self.blob, self.n = model._cloud.blob.data_ptr(), model._cloud.n
         self.cam = model._cam.ref()
         self.ws, self.wsb = model._ws.buf.data_ptr(), model._ws.bytes
@@ -522,6 +525,13 @@ class _PosePlan:
                         obs.data_ptr(), scalars.data_ptr())
         if rc:
             check(rc, "tohip_pose_forward")
+
+    def forward_backward(self, t, q, mask, obs, scalars, grads):
+        gp = grads.data_ptr()
+        rc = self._call(self.fwdbwd, self.blob, self.n, t.data_ptr(), q.data_ptr(), self.cam, mask.data_ptr() if mask is not None else None,
+                        obs.data_ptr(), scalars.data_ptr(), None, gp, gp + 16)
+        if rc:
+            check(rc, "tohip_pose_forward_backward")
 
     def backward(self, t, q, mask, scalars, gout, tg, qg):
         rc = self._call(self.bwd, self.blob, self.n, t.data_ptr(), q.data_ptr(), self.cam, mask.data_ptr() if mask is not None else None, None,
@@ -635,7 +645,7 @@ class ModelPose(nn.Module):
         self.pc_clip_limits = [min_dist, max_dist]  # near / far range of the distance mask, metres
 
         self.to(self.device)
-        self._cloud = ops.PackedCloud(self.points)
+        self._cloud = ops.PackedCloud(self.points, sort=False)   # nothing culls here: the caller's order, masks and observations in place
         self._cam = ops.Camera(self.K, self.img_width, self.img_height, min_dist, max_dist, self.eps)
         self._ws = ops.PoseWorkspace(self._cloud)
         self._occlusion_mask, self._occlusion_key = None, None
@@ -660,7 +670,7 @@ class ModelPose(nn.Module):
         if fused:
             loss, self.observations, scalars = _PoseLoss.apply(self.trans, self.quat, self, mask)
             if type(loss) is _Loss and loss.requires_grad:
-                loss.__dict__["_tohip_fast"] = _FastBackwardPose(self._plan, loss.grad_fn, (self.trans, self.quat), mask, scalars.detach())
+                loss.__dict__["_tohip_fast"] = _FastBackwardPose(self._plan, loss.grad_fn, (self.trans, self.quat), loss.grad_fn.grads)
         else:
             self.observations = _PoseObservations.apply(self.trans, self.quat, self, mask)
         if debug:

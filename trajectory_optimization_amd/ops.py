@@ -312,6 +312,20 @@ def pose_forward(cloud, trans, quat, cam, ws, mask=None):
     return obs, scalars
 
 
+def pose_forward_backward(cloud, trans, quat, cam, ws, mask=None, gout=None):
+    """ModelPose.forward and the backward of its fused loss in ONE pass over the cloud (tohip_pose_forward_backward).
+    -> (observations (N,), scalars (4: sum, loss, -, -), trans_grad (1,3), quat_grad (1,4)); gradients are gout x d loss / d (.)."""
+    dev = cloud.device
+    obs = torch.empty(cloud.n, dtype=torch.float32, device=dev)
+    scalars = torch.empty(4, dtype=torch.float32, device=dev)
+    tg = torch.empty((1, 3), dtype=torch.float32, device=dev)
+    qg = torch.empty((1, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().tohip_pose_forward_backward(ptr(cloud.blob), cloud.n, ptr(trans), ptr(quat), cam.ref(), ptr(mask), ptr(obs), ptr(scalars),
+                                                     ptr(gout), ptr(tg), ptr(qg), ptr(ws.buf), ws.bytes, stream_ptr()), "tohip_pose_forward_backward")
+    return obs, scalars, tg, qg
+
+
 def pose_backward(cloud, trans, quat, cam, ws, mask=None, grad_obs=None, scalars=None, gout=None):
     tg = torch.empty((1, 3), dtype=torch.float32, device=cloud.device)
     qg = torch.empty((1, 4), dtype=torch.float32, device=cloud.device)
@@ -501,9 +515,9 @@ def spherical_flip(points, param=2):
     n = pts.shape[0]
     out = torch.empty_like(pts)
     rad = torch.empty(1, dtype=torch.float32, device=pts.device)
-    ws = torch.empty(256, dtype=torch.uint8, device=pts.device)
+    ws = torch.empty(8192, dtype=torch.uint8, device=pts.device)   # TOHIP_FLIP_WORKSPACE_BYTES
     with torch.cuda.device(pts.device):
-        check(_lib.lib().tohip_spherical_flip(ptr(pts), n, float(param), ptr(out), ptr(rad), ptr(ws), 256, stream_ptr()),
+        check(_lib.lib().tohip_spherical_flip(ptr(pts), n, float(param), ptr(out), ptr(rad), ptr(ws), 8192, stream_ptr()),
               "tohip_spherical_flip")
     return out, rad
 

@@ -245,8 +245,8 @@ class PoseOptResult:
 def optimize_pose(model, n_opt_steps=100, lr_pose=0.1, lr_quat=0.1, hpr=False, betas=(0.9, 0.999), adam_eps=1e-8):
     """The reference's PoseOpt loop (/root/reference/src/pose_optimization.py:93-97,124-141): n_opt_steps of
     `loss = model(hpr); loss.backward(); Adam(trans @ lr_pose, quat @ lr_quat).step()` on a ModelPose, in place, as
-    launches only — forward, fused-loss backward and the two Adam updates per step, the loss of every step logged on the
-    device — with one host synchronisation when the run ends.  model.trans / model.quat hold the optimised pose (the
+    launches only — two per step (tohip_pose_opt_step: ONE pass over the cloud for observations, loss and gradient sums, then a
+    one-block finish with both Adam updates and the loss log) — with one host synchronisation when the run ends.  model.trans / model.quat hold the optimised pose (the
     reference normalises the quaternion only when publishing, :102), model.observations the last observations."""
     L = _lib.lib()
     dev = model.device
@@ -257,24 +257,26 @@ def optimize_pose(model, n_opt_steps=100, lr_pose=0.1, lr_quat=0.1, hpr=False, b
         model(hpr=True)  # builds (and caches) the world-frame occlusion mask of model.py:114
         mask = model._occlusion_mask
     obs, scalars = torch.empty(cloud.n, **f32), torch.zeros(4, **f32)
-    gout = torch.ones(1, **f32)
     tg, qg = torch.empty((1, 3), **f32), torch.empty((1, 4), **f32)
     mt, vt = torch.zeros(3, **f32), torch.zeros(3, **f32)
     mq, vq = torch.zeros(4, **f32), torch.zeros(4, **f32)
     losses = torch.empty(max(n_opt_steps, 1), **f32)
     trans, quat = model.trans.data, model.quat.data
-    with torch.cuda.device(dev):
+    fn = L.tohip_pose_opt_step
+    args = (cloud.blob.data_ptr(), cloud.n, trans.data_ptr(), quat.data_ptr(), cam.ref(), mask.data_ptr() if mask is not None else None,
+            obs.data_ptr(), scalars.data_ptr(), tg.data_ptr(), qg.data_ptr(), mt.data_ptr(), vt.data_ptr(), mq.data_ptr(), vq.data_ptr(),
+            float(lr_pose), float(lr_quat), float(betas[0]), float(betas[1]), float(adam_eps))
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(idx):
+        stream = torch._C._cuda_getCurrentRawStream(idx)
         for i in range(n_opt_steps):
-            s = stream_ptr()
-            check(L.tohip_pose_forward(ptr(cloud.blob), cloud.n, ptr(trans), ptr(quat), cam.ref(), ptr(mask), ptr(obs),
-                                       ptr(scalars), ptr(ws.buf), ws.bytes, s), "pose forward")
-            losses[i:i + 1].copy_(scalars[1:2])
-            check(L.tohip_pose_backward(ptr(cloud.blob), cloud.n, ptr(trans), ptr(quat), cam.ref(), ptr(mask), None,
-                                        ptr(scalars), ptr(gout), ptr(tg), ptr(qg), ptr(ws.buf), ws.bytes, s), "pose backward")
-            check(L.tohip_adam_step(ptr(trans), ptr(tg), ptr(mt), ptr(vt), 3, float(lr_pose), betas[0], betas[1], adam_eps,
-                                    i + 1, None, s), "adam trans")
-            check(L.tohip_adam_step(ptr(quat), ptr(qg), ptr(mq), ptr(vq), 4, float(lr_quat), betas[0], betas[1], adam_eps,
-                                    i + 1, None, s), "adam quat")
+            # one pass over the cloud (observations, their sum, the gradient sums) and its one-block finish (loss, gradient, both
+            # Adam updates, the loss log): two launches per step
+            rc = fn(*args, i + 1, losses.data_ptr(), ws.buf.data_ptr(), ws.bytes, stream)
+            if rc:
+                check(rc, "tohip_pose_opt_step")
+    torch.autograd.graph.increment_version(model.trans)
+    torch.autograd.graph.increment_version(model.quat)
     model.observations = obs
     return PoseOptResult(losses[:n_opt_steps].cpu().tolist())  # the run's only host synchronisation
 
