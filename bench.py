@@ -389,6 +389,11 @@ def main():
     ap.add_argument("--fused-step", choices=["on", "off"], default="on",
                     help="N = 1: tohip_traj_forward_backward (5 launches); off: tohip_traj_forward then tohip_traj_reward_backward (5), the "
                          "split that a waypoint-sharded run needs around its all-reduce")
+    ap.add_argument("--shard", choices=["waypoints", "points"], default="waypoints",
+                    help="N > 1: what the ranks split.  waypoints (the north star's design): 128 waypoints per rank over the whole cloud, "
+                         "one all-reduce of the N-float log-odds vector per step.  points: every rank takes points/N of the cloud and ALL "
+                         "128 N waypoints (the same evaluations per rank); two collectives per step whose size does not depend on the cloud "
+                         "(16 B per waypoint, then 320 B per waypoint)")
     ap.add_argument("--compact-allreduce", choices=["on", "off"], default="off",
                     help="N > 1: all-reduce only the slots some rank lists as candidates (a flag per slot MAX-reduced first; one host read of "
                          "the union's size per step) instead of the whole N-float log-odds vector")
@@ -405,7 +410,7 @@ def main():
     args = ap.parse_args()
 
     from trajectory_optimization_amd import _lib, ops
-    from trajectory_optimization_amd.distributed import init_from_env, WaypointShard
+    from trajectory_optimization_amd.distributed import init_from_env, WaypointShard, PointShard
     import torch.distributed as dist
 
     rank, world, device = init_from_env()
@@ -420,23 +425,37 @@ def main():
     # ---- synthetic inputs (seeded), resident in HBM ------------------------------------
     pts = synth.make_cloud(args.points, seed=0)
     poses_all, quats_all = synth.make_path(w_total, optical=True)
-    lo, hi = rank * args.wps_per_gpu, (rank + 1) * args.wps_per_gpu
-    cloud = ops.PackedCloud(torch.from_numpy(pts).to(device))
+    forced = os.environ.get("TOHIP_DIST_FORCE_INIT") == "1"   # one-rank process group: the RCCL calls of the N>1 step on one GPU
+    by_points = args.shard == "points" and (n_gpus > 1 or forced)
+    if by_points:
+        # this rank's rows of the cloud, every waypoint of the whole trajectory: the same evaluations per rank as a waypoint shard
+        shard = PointShard(force_collectives=forced)
+        p_lo, p_hi = shard.point_bounds(args.points)
+        lo, hi = 0, w_total
+        cloud = ops.PackedCloud(torch.from_numpy(pts[p_lo:p_hi].copy()).to(device))
+    else:
+        lo, hi = rank * args.wps_per_gpu, (rank + 1) * args.wps_per_gpu
+        cloud = ops.PackedCloud(torch.from_numpy(pts).to(device))
+        shard = WaypointShard(force_collectives=forced, compact=args.compact_allreduce == "on") if (n_gpus > 1 or forced) else None
     cam = ops.Camera(synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT)
     poses = torch.from_numpy(poses_all[lo:hi].copy()).to(device)
     quats = torch.from_numpy(quats_all[lo:hi].copy()).to(device)
-    n_virtual = args.wps_per_gpu * args.cameras
+    n_local_wps = hi - lo
+    n_virtual = n_local_wps * args.cameras
     rig = ops.CameraRig(*synth.camera_rig(args.cameras), device) if args.cameras > 1 else None
     ws = ops.TrajWorkspace(cloud, n_virtual)
     gout = torch.ones(1, device=device)
-    forced = os.environ.get("TOHIP_DIST_FORCE_INIT") == "1"   # one-rank process group: the RCCL calls of the N>1 step on one GPU
-    shard = WaypointShard(force_collectives=forced, compact=args.compact_allreduce == "on") if (n_gpus > 1 or forced) else None
+    pstep = {}   # --shard points: one ops.PointShardStep per evaluation mode (its buffers are allocated once)
 
     if shard is not None:
         # communicator set-up (RCCL rings over xGMI) happens on the first collective of each kind: keep it out of the timed
         # region whatever --warmup says
-        shard.allreduce_sum(torch.zeros(cloud.npad, device=device))
-        shard.allgather_rows(torch.zeros((args.wps_per_gpu, 7), device=device))
+        if by_points:
+            shard.allreduce_max(torch.zeros(4 * n_virtual, dtype=torch.int32, device=device))
+            shard.allreduce_sum(torch.zeros(8 + 40 * n_virtual, dtype=torch.float64, device=device))
+        else:
+            shard.allreduce_sum(torch.zeros(cloud.npad, device=device))
+            shard.allgather_rows(torch.zeros((args.wps_per_gpu, 7), device=device))
         torch.cuda.synchronize(device)
 
     rewards_buf = torch.empty(cloud.n, dtype=torch.float32, device=device)   # refilled by every forward
@@ -448,6 +467,13 @@ def main():
     def step(flags):
         rewards = rewards_buf
         poses, quats = at["poses"], at["quats"]
+        if by_points:
+            # pass 1 | MAX of the waypoints' extrema | flags, log-odds, rewards, gradient sums | SUM of 40 doubles per waypoint | finish
+            st = pstep.get(flags)
+            if st is None:
+                st = pstep[flags] = ops.PointShardStep(cloud, args.points, n_local_wps, cam, ws, shard, rig=rig, flags=flags)
+            rewards, scalars, pg, qg = st.step(poses, quats)
+            return scalars, pg, qg, rewards
         if shard is None and args.fused_step == "on":
             # no collective between forward and backward: the whole step is ONE library call, five launches
             rewards, scalars, pg, qg, _, _ = ops.traj_forward_backward(cloud, poses, quats, cam, ws, gout, rig=rig, flags=flags, lo_sum=lo_buf,
@@ -458,11 +484,11 @@ def main():
             ops.allreduce_log_odds(shard, cloud, ws, lo_sum)  # the one data-path collective: N floats over xGMI (or the union's slots)
         if args.fused_reward == "on":
             # rewards, mean and loss share the backward's first launch (tohip_traj_reward_backward: two launches instead of three)
-            rewards, scalars, pg, qg = ops.traj_reward_backward(cloud, args.wps_per_gpu, cam, ws, lo_sum, gout, rewards=rewards,
+            rewards, scalars, pg, qg = ops.traj_reward_backward(cloud, n_local_wps, cam, ws, lo_sum, gout, rewards=rewards,
                                                                prefilled=True, rig=rig, flags=flags)
         else:
             rewards, scalars = ops.traj_reward(cloud, lo_sum, cam, ws, rewards=rewards, prefilled=True)
-            pg, qg = ops.traj_backward(cloud, args.wps_per_gpu, cam, ws, lo_sum, scalars=scalars, gout=gout, rig=rig, flags=flags)
+            pg, qg = ops.traj_backward(cloud, n_local_wps, cam, ws, lo_sum, scalars=scalars, gout=gout, rig=rig, flags=flags)
         if shard is not None:
             g = shard.allgather_rows(torch.cat([pg, qg], dim=1))  # (W_total, 7) floats: every rank can step the optimiser
             pg, qg = g[:, :3], g[:, 3:]
@@ -535,6 +561,46 @@ def main():
             fence()
             out.append(1e3 * (time.perf_counter() - t0) / args.steps)
         return sorted(out)
+
+    def comm_leg_points(flags):
+        """--shard points: the two collectives alone (events on the compute stream around K of each, which waits for RCCL's), and
+        the step's launches with the collectives left out."""
+        st = pstep[flags]
+        out = {}
+        for name, t, fn in (("extrema_allreduce_max", st.extrema, shard.allreduce_max), ("sums_allreduce_sum", st.partial, shard.allreduce_sum)):
+            keep = t.clone()
+            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
+            fence()
+            for e in ev:
+                t.copy_(keep)
+                e[0].record()
+                fn(t)
+                e[1].record()
+            fence()
+            d = sorted(e[0].elapsed_time(e[1]) for e in ev)
+            out[name] = {"ms_median": d[len(d) // 2], "ms_max": d[-1], "bytes": int(t.numel() * t.element_size())}
+            t.copy_(keep)
+
+        class _NoComm:
+            world_size, rank, kind = shard.world_size, shard.rank, "points"
+
+            @staticmethod
+            def allreduce_max(t):
+                return t
+
+            @staticmethod
+            def allreduce_sum(t):
+                return t
+        real, st.shard = st.shard, _NoComm
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st.step(at["poses"], at["quats"])
+        fence()
+        st.shard = real
+        out.update(step_without_collectives_ms=1e3 * (time.perf_counter() - t0) / args.steps, backend=dist.get_backend(), shard="points",
+                   note="rank 0's view; the collectives' sizes do not depend on the cloud: 16 B and 320 B per virtual waypoint (+ 64 B)")
+        return out
 
     def comm_leg(flags):
         """N > 1: where the step's time goes.  The same K steps with events around the two collectives (on the compute stream,
@@ -666,7 +732,7 @@ def main():
     value = evals_per_step * args.steps / dt
     win_dense = windows(dense_flags)
     win_culled = windows(0) if args.mode == "both" else win_dense
-    comm = comm_leg(dense_flags) if shard is not None else None
+    comm = (comm_leg_points(dense_flags) if by_points else comm_leg(dense_flags)) if shard is not None else None
     moved = moved_leg() if (shard is None and args.moved == "on" and args.mode == "both" and args.cameras == 1) else None
 
     if rank == 0 and args.dump:
@@ -674,7 +740,7 @@ def main():
     if rank == 0:
         # dominant kernel: pass 1, the one launch that evaluates every pair.  VALU-issue roofline (module docstring).
         mix = isa_mix()
-        local_evals = args.points * n_virtual
+        local_evals = cloud.n * n_virtual   # this rank's evaluations (its points x its virtual waypoints)
         evals_per_iter = 64 * mix["points_per_lane"]
         cyc_per_iter = (mix["packed_f32"] * ISSUE_CYCLES["packed_f32"] + mix["transcendental"] * ISSUE_CYCLES["transcendental"] +
                         mix["other_valu"] * ISSUE_CYCLES["other_valu"])
@@ -701,10 +767,12 @@ def main():
                                    f"({w_total} total)" + (f" x {args.cameras} cameras" if args.cameras > 1 else "") +
                                    ", fwd + bwd (x,y,z,quaternion) gradients",
                        "n_points": args.points, "waypoints_total": w_total, "cameras": args.cameras,
-                       "parallelism": f"waypoint-shard x{n_gpus}" if n_gpus > 1 else "single GPU",
+                       "parallelism": (f"point-shard x{n_gpus}" if by_points else f"waypoint-shard x{n_gpus}") if n_gpus > 1 else "single GPU",
                        "launch": "HIP graph replay of the step's launches" if use_graph else
                                  ("tohip_traj_forward_backward: one host call, five launches" if (shard is None and args.fused_step == "on") else
-                                  "tohip_traj_forward -> [all-reduce] -> tohip_traj_reward_backward [-> all-gather]: five launches"),
+                                  ("tohip_traj_pshard_pass1 -> [MAX all-reduce, 16 B / waypoint] -> tohip_traj_pshard_local -> [SUM all-reduce, 320 B / "
+                                   "waypoint] -> tohip_traj_pshard_finish: six launches" if by_points else
+                                   "tohip_traj_forward -> [all-reduce] -> tohip_traj_reward_backward [-> all-gather]: five launches")),
                        "mode": "dense: every (point, waypoint) pair evaluated, no data-dependent skipping; the 0.7 % of "
                                "(256-point slot, waypoint) pairs that can contribute are then revisited by the sparse kernel",
                        "loss_vis": float(out[0][1].item())},

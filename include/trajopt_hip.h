@@ -194,6 +194,33 @@ int tohip_traj_forward_backward_multi(const void *packed, int64_t n_points, cons
                                       float *minmax, float *rewards, float *scalars, const float *gout, float *poses_grad,
                                       float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- a POINT-sharded step (the alternative to sharding waypoints) ------------------------------------------------
+ * Every rank packs N / R of the points and evaluates ALL W waypoints on them.  What the ranks exchange does not grow with N:
+ *   tohip_traj_pshard_pass1   records, probe and pass 1 on this rank's points: per-waypoint extrema of ITS points in the workspace
+ *   (collective 1)            element-wise MAX over the int32 words tohip_traj_extrema_view points at (4 per virtual waypoint:
+ *                             -bits(min p), bits(max p), 0, 0 — p >= 0, so the integer order is the float order), IN PLACE
+ *   tohip_traj_pshard_local   flags against the (now global) extrema, log-odds, rewards of this rank's points (complete: the rank
+ *                             has every waypoint), the gradient sums of its flagged pairs with unit upstream gradient, and per
+ *                             waypoint the 40 sums everything after is linear in -> partial[tohip_traj_pshard_partial_count(V)]
+ *   (collective 2)            SUM over `partial` (doubles; [0] the reward sum in fixed point, [1] NaN marks, [2] point counts)
+ *   tohip_traj_pshard_finish  mean reward of ALL points, loss_vis, dL/d reward, tie shares, chain -> scalars, poses_grad, quats_grad
+ *                             (identical on every rank)
+ * n_global = the points of all ranks (the fixed-point scale of the reward sum and the mean's denominator).  lo_sum (Npad_local),
+ * minmax (V,2), rewards (n_local, this rank's points in the caller's order): as in tohip_traj_forward_backward.  One trajectory. */
+size_t tohip_traj_pshard_partial_count(int64_t n_virtual);
+int tohip_traj_extrema_view(int64_t n_points, int64_t n_virtual, void *workspace, size_t workspace_bytes, int32_t **words_out_host,
+                            int64_t *n_words_out_host);
+int tohip_traj_pshard_pass1(const void *packed, int64_t n_local, int64_t n_global, const float *poses, const float *quats,
+                            int64_t n_wps, const tohip_camera *cam_host, const tohip_rig *rig_host, int flags,
+                            const uint32_t *occlusion_bits, float *lo_sum, float *rewards, void *workspace, size_t workspace_bytes,
+                            void *stream);
+int tohip_traj_pshard_local(const void *packed, int64_t n_local, int64_t n_global, int64_t n_wps, const tohip_camera *cam_host,
+                            const tohip_rig *rig_host, int flags, const uint32_t *occlusion_bits, float *lo_sum, float *minmax,
+                            float *rewards, double *partial, void *workspace, size_t workspace_bytes, void *stream);
+int tohip_traj_pshard_finish(int64_t n_local, int64_t n_global, int64_t n_wps, const tohip_camera *cam_host,
+                             const tohip_rig *rig_host, const double *partial, const float *gout, float *scalars,
+                             float *poses_grad, float *quats_grad, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- a waypoint-sharded step's all-reduce, compacted (the one data-path collective) ------------------------------
  * A rank's partial log-odds vector is exactly zero outside the 256-point slots its forward listed as candidates (6-8 % of the
  * slots on the BASELINE workloads).  Instead of all-reducing N floats: (1) tohip_traj_candidate_flags -> one 0/1 int32 per slot

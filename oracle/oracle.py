@@ -83,6 +83,56 @@ def traj_backward(points, poses, quats, K, img_w, img_h, fwd, gout=1.0, min_dist
     return pg, qg
 
 
+# ---- the same path cut where a point-sharded run cuts it (tests/test_distributed_cpu.py: the CPU rehearsal of distributed.PointShard)
+
+def traj_extrema(points, poses, quats, K, img_w, img_h, min_dist=1.0, max_dist=5.0, prec="f64"):
+    """-> (min p, max p) per waypoint over THESE points (ranks combine them with min / max)."""
+    pts, poses, quats, K = _f32(points), _f32(poses), _f32(quats), _f32(K)
+    W = poses.shape[0]
+    pmin, pmax = np.empty(W, _DT[prec]), np.empty(W, _DT[prec])
+    fn = getattr(lib(), "oracle_traj_extrema_" + prec)
+    assert fn(_ptr(pts), c_i64(pts.shape[0]), _ptr(poses), _ptr(quats), c_i64(W), _ptr(K), c_f(img_w), c_f(img_h), c_f(min_dist), c_f(max_dist),
+              _ptr(pmin), _ptr(pmax)) == 0
+    return pmin, pmax
+
+
+def traj_forward_ext(points, poses, quats, K, img_w, img_h, ext_min, ext_max, min_dist=1.0, max_dist=5.0, prec="f64"):
+    """-> (lo_sum, rewards) of these points for GIVEN per-waypoint extrema (min p, max p)."""
+    pts, poses, quats, K = _f32(points), _f32(poses), _f32(quats), _f32(K)
+    dt = _DT[prec]
+    lo, rew = np.empty(pts.shape[0], dt), np.empty(pts.shape[0], dt)
+    emin, emax = np.ascontiguousarray(ext_min, dtype=dt), np.ascontiguousarray(ext_max, dtype=dt)
+    fn = getattr(lib(), "oracle_traj_forward_ext_" + prec)
+    assert fn(_ptr(pts), c_i64(pts.shape[0]), _ptr(poses), _ptr(quats), c_i64(poses.shape[0]), _ptr(K), c_f(img_w), c_f(img_h), c_f(min_dist),
+              c_f(max_dist), _ptr(emin), _ptr(emax), _ptr(lo), _ptr(rew)) == 0
+    return lo, rew
+
+
+def traj_backward_partial(points, poses, quats, K, img_w, img_h, ext_min, ext_max, rewards, min_dist=1.0, max_dist=5.0, prec="f64"):
+    """-> (W, 40) float64: these points' sums per waypoint with dL/d reward = 1 (additive over parts of the cloud)."""
+    pts, poses, quats, K = _f32(points), _f32(poses), _f32(quats), _f32(K)
+    dt = _DT[prec]
+    W = poses.shape[0]
+    out = np.empty((W, 40), np.float64)
+    emin, emax, rew = (np.ascontiguousarray(a, dtype=dt) for a in (ext_min, ext_max, rewards))
+    fn = getattr(lib(), "oracle_traj_backward_partial_" + prec)
+    assert fn(_ptr(pts), c_i64(pts.shape[0]), _ptr(poses), _ptr(quats), c_i64(W), _ptr(K), c_f(img_w), c_f(img_h), c_f(min_dist), c_f(max_dist),
+              _ptr(emin), _ptr(emax), _ptr(rew), _ptr(out)) == 0
+    return out
+
+
+def traj_backward_final(poses, quats, partial, scale, prec="f64"):
+    """The parts' sums added up -> (poses_grad, quats_grad); scale = dL/d reward (-gout vis^2 / N_all)."""
+    poses, quats = _f32(poses), _f32(quats)
+    W = poses.shape[0]
+    dt = _DT[prec]
+    pg, qg = np.empty((W, 3), dt), np.empty((W, 4), dt)
+    part = np.ascontiguousarray(partial, dtype=np.float64)
+    fn = getattr(lib(), "oracle_traj_backward_final_" + prec)
+    assert fn(_ptr(poses), _ptr(quats), c_i64(W), _ptr(part), c_d(float(scale)), _ptr(pg), _ptr(qg)) == 0
+    return pg, qg
+
+
 def pose_forward(points, trans, quat, K, img_w, img_h, min_dist=1.0, max_dist=5.0, mask=None, prec="f32"):
     pts, trans, quat, K = _f32(points), _f32(trans).reshape(3), _f32(quat).reshape(4), _f32(K)
     mask = _f32(mask) if mask is not None else None

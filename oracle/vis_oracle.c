@@ -253,6 +253,101 @@ int FN(oracle_traj_forward)(const float *xyz, int64_t N, const float *poses, con
 static double FN(g_act_shift) = 0.0;
 void FN(oracle_set_act_shift)(double shift) { FN(g_act_shift) = shift; }
 
+/* The sums of one waypoint that everything after is linear in, for given extrema (a = min p, M = max p - a: the waypoint's
+ * own, or — a point-sharded run, tests/test_distributed_cpu.py — those over ALL ranks' points) and dL/d reward_n = coef for every n:
+ *   out[0..2] sum G/M dp/dc   [3..11] sum y (x) G/M dp/dc   [12] S1 = sum G (p_hat - 1)/M   [13] S2 = sum G (-p_hat)/M
+ *   [14..25] the argmin set's sum dp/dc, sum y (x) dp/dc, [26] its size      [27..38], [39] the same for the argmax set
+ * p: scratch of N REALs.  All of it is additive over the points. */
+static void FN(bwd_sums)(const FN(consts_t) *kp, const FN(cam_t) *camp, const float *xyz, int64_t N, const float *occ_row,
+                         const REAL *rewards, REAL a, REAL M, double coef, REAL *p, double out[40]) {
+    const FN(consts_t) k = *kp;
+    const FN(cam_t) cam = *camp;
+    double S1 = 0, S2 = 0, Gt[3] = {0, 0, 0}, GR[9] = {0};
+    double At_min[3] = {0}, AR_min[9] = {0}, At_max[3] = {0}, AR_max[9] = {0};
+    long n_min = 0, n_max = 0;
+#pragma omp parallel
+    {
+        double s1 = 0, s2 = 0, gt[3] = {0}, gr[9] = {0}, atn[3] = {0}, arn[9] = {0}, atx[3] = {0}, arx[9] = {0};
+        long cmin = 0, cmax = 0;
+#pragma omp for schedule(static) nowait
+        for (int64_t n = 0; n < N; ++n) {
+            const REAL pp = p[n] - a;
+            const REAL ph = pp / M;
+            const int is_min = (p[n] == a), is_max = (pp == M);
+            const int act = ((double)ph >= 0.5 + FN(g_act_shift) && ph <= k.clip_hi);
+            if (!act && !is_min && !is_max) continue;
+            REAL x[3] = {(REAL)xyz[3 * n], (REAL)xyz[3 * n + 1], (REAL)xyz[3 * n + 2]}, c[3], g[3];
+            FN(vis_t) s;
+            FN(to_cam)(&cam, x, c);
+            FN(soft_vis)(&k, c, &s);
+            FN(dvis_dc)(&k, c, &s, g);
+            if (occ_row) for (int i = 0; i < 3; ++i) g[i] = (REAL)occ_row[n] * g[i]; /* d(occ*p)/dc */
+            const double y[3] = {(double)x[0] - (double)cam.t[0], (double)x[1] - (double)cam.t[1], (double)x[2] - (double)cam.t[2]};
+            if (act) {
+                const double r = (double)rewards[n];
+                const double G = coef * r * (1.0 - r) / ((double)ph * (1.0 - (double)ph));
+                s1 += G * ((double)ph - 1.0) / (double)M;
+                s2 += G * (-(double)ph) / (double)M;
+                const double wgt = G / (double)M;
+                for (int i = 0; i < 3; ++i) gt[i] += wgt * (double)g[i];
+                for (int j = 0; j < 3; ++j)
+                    for (int i = 0; i < 3; ++i) gr[3 * j + i] += wgt * y[j] * (double)g[i];
+            }
+            if (is_min) {
+                ++cmin;
+                for (int i = 0; i < 3; ++i) atn[i] += (double)g[i];
+                for (int j = 0; j < 3; ++j)
+                    for (int i = 0; i < 3; ++i) arn[3 * j + i] += y[j] * (double)g[i];
+            }
+            if (is_max) {
+                ++cmax;
+                for (int i = 0; i < 3; ++i) atx[i] += (double)g[i];
+                for (int j = 0; j < 3; ++j)
+                    for (int i = 0; i < 3; ++i) arx[3 * j + i] += y[j] * (double)g[i];
+            }
+        }
+#pragma omp critical
+        {
+            S1 += s1; S2 += s2; n_min += cmin; n_max += cmax;
+            for (int i = 0; i < 3; ++i) { Gt[i] += gt[i]; At_min[i] += atn[i]; At_max[i] += atx[i]; }
+            for (int i = 0; i < 9; ++i) { GR[i] += gr[i]; AR_min[i] += arn[i]; AR_max[i] += arx[i]; }
+        }
+    }
+    for (int i = 0; i < 3; ++i) { out[i] = Gt[i]; out[14 + i] = At_min[i]; out[27 + i] = At_max[i]; }
+    for (int i = 0; i < 9; ++i) { out[3 + i] = GR[i]; out[17 + i] = AR_min[i]; out[30 + i] = AR_max[i]; }
+    out[12] = S1; out[13] = S2; out[26] = (double)n_min; out[39] = (double)n_max;
+}
+
+/* sums (scaled by `scale`: the dL/d reward factor when they were taken with coef = 1) -> the waypoint's gradient: the shares of
+ * the argmin / argmax sets (torch splits the gradient of min() / max() evenly among ties), then the chain to (position, quaternion) */
+static void FN(bwd_final)(const FN(cam_t) *cam, const double in[40], double scale, REAL *pg, REAL *qg) {
+    double Gt[3], GR[9];
+    const double S1 = scale * in[12], S2 = scale * in[13];
+    const double wmin = in[26] > 0 ? S1 / in[26] : 0.0, wmax = in[39] > 0 ? S2 / in[39] : 0.0;
+    for (int i = 0; i < 3; ++i) Gt[i] = scale * in[i] + wmin * in[14 + i] + wmax * in[27 + i];
+    for (int i = 0; i < 9; ++i) GR[i] = scale * in[3 + i] + wmin * in[17 + i] + wmax * in[30 + i];
+    FN(pose_chain)(cam, Gt, GR, pg, qg);
+}
+
+/* p of every point for one waypoint into p[]; returns its min (NaN when some p is NaN: torch.min() propagates it, model.py:226) */
+static REAL FN(eval_waypoint)(const FN(consts_t) *k, const FN(cam_t) *cam, const float *xyz, int64_t N, const float *occ_row, REAL *p,
+                              int *has_nan_out) {
+    REAL a = INFINITY;
+    int has_nan = 0;
+#pragma omp parallel for reduction(min : a) reduction(| : has_nan) schedule(static)
+    for (int64_t n = 0; n < N; ++n) {
+        REAL x[3] = {(REAL)xyz[3 * n], (REAL)xyz[3 * n + 1], (REAL)xyz[3 * n + 2]}, c[3];
+        FN(to_cam)(cam, x, c);
+        p[n] = FN(soft_vis)(k, c, NULL);
+        if (occ_row) p[n] = (REAL)occ_row[n] * p[n];
+        if (p[n] < a) a = p[n];
+        if (p[n] != p[n]) has_nan = 1;
+    }
+    if (has_nan) a = (REAL)NAN;
+    *has_nan_out = has_nan;
+    return a;
+}
+
 /* Backward of loss_vis w.r.t. the evaluated waypoints' (poses, quats).  rewards/pmin/pmax from the
  * forward; gout = dL/d loss_vis.  Outputs poses_grad[W*3], quats_grad[W*4]. */
 int FN(oracle_traj_backward)(const float *xyz, int64_t N, const float *poses, const float *quats, int64_t W,
@@ -267,18 +362,8 @@ int FN(oracle_traj_backward)(const float *xyz, int64_t N, const float *poses, co
     for (int64_t w = 0; w < W; ++w) {
         FN(cam_t) cam;
         FN(make_cam)(&cam, quats + 4 * w, poses + 3 * w, 1);
-        REAL a = INFINITY;
-        int has_nan = 0;
-#pragma omp parallel for reduction(min : a) reduction(| : has_nan) schedule(static)
-        for (int64_t n = 0; n < N; ++n) {
-            REAL x[3] = {(REAL)xyz[3 * n], (REAL)xyz[3 * n + 1], (REAL)xyz[3 * n + 2]}, c[3];
-            FN(to_cam)(&cam, x, c);
-            p[n] = FN(soft_vis)(&k, c, NULL);
-            if (occ) p[n] = (REAL)occ[w * N + n] * p[n];
-            if (p[n] < a) a = p[n];
-            if (p[n] != p[n]) has_nan = 1;
-        }
-        if (has_nan) a = (REAL)NAN; /* torch.min() / max() propagate a NaN (a NaN or inf coordinate in the cloud): model.py:226 */
+        int has_nan;
+        const REAL a = FN(eval_waypoint)(&k, &cam, xyz, N, occ ? occ + w * N : NULL, p, &has_nan);
         REAL M = -INFINITY;
 #pragma omp parallel for reduction(max : M) schedule(static)
         for (int64_t n = 0; n < N; ++n) {
@@ -286,68 +371,94 @@ int FN(oracle_traj_backward)(const float *xyz, int64_t N, const float *poses, co
             if (pp > M) M = pp;
         }
         if (has_nan) M = (REAL)NAN;
-        /* S1 = sum G (phat-1)/M -> shared by argmin ties ; S2 = sum G (-phat)/M -> argmax ties */
-        double S1 = 0, S2 = 0, Gt[3] = {0, 0, 0}, GR[9] = {0};
-        double At_min[3] = {0}, AR_min[9] = {0}, At_max[3] = {0}, AR_max[9] = {0};
-        long n_min = 0, n_max = 0;
-#pragma omp parallel
-        {
-            double s1 = 0, s2 = 0, gt[3] = {0}, gr[9] = {0}, atn[3] = {0}, arn[9] = {0}, atx[3] = {0}, arx[9] = {0};
-            long cmin = 0, cmax = 0;
-#pragma omp for schedule(static) nowait
-            for (int64_t n = 0; n < N; ++n) {
-                const REAL pp = p[n] - a;
-                const REAL ph = pp / M;
-                const int is_min = (p[n] == a), is_max = (pp == M);
-                const int act = ((double)ph >= 0.5 + FN(g_act_shift) && ph <= k.clip_hi);
-                if (!act && !is_min && !is_max) continue;
-                REAL x[3] = {(REAL)xyz[3 * n], (REAL)xyz[3 * n + 1], (REAL)xyz[3 * n + 2]}, c[3], g[3];
-                FN(vis_t) s;
-                FN(to_cam)(&cam, x, c);
-                FN(soft_vis)(&k, c, &s);
-                FN(dvis_dc)(&k, c, &s, g);
-                if (occ) for (int i = 0; i < 3; ++i) g[i] = (REAL)occ[w * N + n] * g[i]; /* d(occ*p)/dc */
-                const double y[3] = {(double)x[0] - (double)cam.t[0], (double)x[1] - (double)cam.t[1], (double)x[2] - (double)cam.t[2]};
-                if (act) {
-                    const double r = (double)rewards[n];
-                    const double G = coef * r * (1.0 - r) / ((double)ph * (1.0 - (double)ph));
-                    s1 += G * ((double)ph - 1.0) / (double)M;
-                    s2 += G * (-(double)ph) / (double)M;
-                    const double wgt = G / (double)M;
-                    for (int i = 0; i < 3; ++i) gt[i] += wgt * (double)g[i];
-                    for (int j = 0; j < 3; ++j)
-                        for (int i = 0; i < 3; ++i) gr[3 * j + i] += wgt * y[j] * (double)g[i];
-                }
-                if (is_min) {
-                    ++cmin;
-                    for (int i = 0; i < 3; ++i) atn[i] += (double)g[i];
-                    for (int j = 0; j < 3; ++j)
-                        for (int i = 0; i < 3; ++i) arn[3 * j + i] += y[j] * (double)g[i];
-                }
-                if (is_max) {
-                    ++cmax;
-                    for (int i = 0; i < 3; ++i) atx[i] += (double)g[i];
-                    for (int j = 0; j < 3; ++j)
-                        for (int i = 0; i < 3; ++i) arx[3 * j + i] += y[j] * (double)g[i];
-                }
-            }
-#pragma omp critical
-            {
-                S1 += s1; S2 += s2; n_min += cmin; n_max += cmax;
-                for (int i = 0; i < 3; ++i) { Gt[i] += gt[i]; At_min[i] += atn[i]; At_max[i] += atx[i]; }
-                for (int i = 0; i < 9; ++i) { GR[i] += gr[i]; AR_min[i] += arn[i]; AR_max[i] += arx[i]; }
-            }
-        }
-        const double wmin = n_min ? S1 / (double)n_min : 0.0, wmax = n_max ? S2 / (double)n_max : 0.0;
-        for (int i = 0; i < 3; ++i) Gt[i] += wmin * At_min[i] + wmax * At_max[i];
-        for (int i = 0; i < 9; ++i) GR[i] += wmin * AR_min[i] + wmax * AR_max[i];
-        FN(pose_chain)(&cam, Gt, GR, poses_grad + 3 * w, quats_grad + 4 * w);
+        double sums[40];
+        FN(bwd_sums)(&k, &cam, xyz, N, occ ? occ + w * N : NULL, rewards, a, M, coef, p, sums);
+        FN(bwd_final)(&cam, sums, 1.0, poses_grad + 3 * w, quats_grad + 4 * w);
         if (has_nan) { /* autograd through the NaN min / max: every entry of the waypoint's gradient is NaN (probed on the reference) */
             for (int i = 0; i < 3; ++i) poses_grad[3 * w + i] = (REAL)NAN;
             for (int i = 0; i < 4; ++i) quats_grad[4 * w + i] = (REAL)NAN;
         }
     }
     free(p);
+    return 0;
+}
+
+/* ---- the same path cut where a POINT-sharded run cuts it (every rank a part of the cloud and all the waypoints; the CPU rehearsal
+ * of distributed.PointShard in tests/test_distributed_cpu.py) ------------------------------------------------------------------ */
+/* this part's extrema per waypoint: pmin[w] = min p, pmax[w] = max p (NOT minus the minimum: ranks combine them with min / max) */
+int FN(oracle_traj_extrema)(const float *xyz, int64_t N, const float *poses, const float *quats, int64_t W, const float *K, float img_w,
+                            float img_h, float min_dist, float max_dist, REAL *pmin, REAL *pmax) {
+    FN(consts_t) k;
+    FN(make_consts)(&k, K, img_w, img_h, min_dist, max_dist);
+    REAL *p = (REAL *)malloc(sizeof(REAL) * (size_t)(N > 0 ? N : 1));
+    if (!p) return -1;
+    for (int64_t w = 0; w < W; ++w) {
+        FN(cam_t) cam;
+        FN(make_cam)(&cam, quats + 4 * w, poses + 3 * w, 1);
+        int has_nan;
+        pmin[w] = FN(eval_waypoint)(&k, &cam, xyz, N, NULL, p, &has_nan);
+        REAL mx = -INFINITY;
+        for (int64_t n = 0; n < N; ++n) if (p[n] > mx) mx = p[n];
+        pmax[w] = has_nan ? (REAL)NAN : mx;
+    }
+    free(p);
+    return 0;
+}
+
+/* log-odds sums and rewards of this part's points for GIVEN extrema (the global ones), model.py:226-237 */
+int FN(oracle_traj_forward_ext)(const float *xyz, int64_t N, const float *poses, const float *quats, int64_t W, const float *K,
+                                float img_w, float img_h, float min_dist, float max_dist, const REAL *ext_min, const REAL *ext_max,
+                                REAL *lo_sum, REAL *rewards) {
+    FN(consts_t) k;
+    FN(make_consts)(&k, K, img_w, img_h, min_dist, max_dist);
+    REAL *p = (REAL *)malloc(sizeof(REAL) * (size_t)(N > 0 ? N : 1));
+    if (!p) return -1;
+    for (int64_t n = 0; n < N; ++n) lo_sum[n] = 0;
+    for (int64_t w = 0; w < W; ++w) {
+        FN(cam_t) cam;
+        FN(make_cam)(&cam, quats + 4 * w, poses + 3 * w, 1);
+        int has_nan;
+        (void)FN(eval_waypoint)(&k, &cam, xyz, N, NULL, p, &has_nan);
+        const REAL a = ext_min[w], M = ext_max[w] - ext_min[w];
+#pragma omp parallel for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            REAL ph = (p[n] - a) / M;
+            ph = ph < (REAL)0.5 ? (REAL)0.5 : (ph > k.clip_hi ? k.clip_hi : ph);
+            lo_sum[n] = lo_sum[n] + r_log(ph / ((REAL)1 - ph));
+        }
+    }
+    for (int64_t n = 0; n < N; ++n) rewards[n] = (REAL)1 / ((REAL)1 + r_exp(-lo_sum[n]));
+    free(p);
+    return 0;
+}
+
+/* this part's 40 sums per waypoint (bwd_sums) with dL/d reward = 1 for given extrema: partial[W * 40] */
+int FN(oracle_traj_backward_partial)(const float *xyz, int64_t N, const float *poses, const float *quats, int64_t W, const float *K,
+                                     float img_w, float img_h, float min_dist, float max_dist, const REAL *ext_min, const REAL *ext_max,
+                                     const REAL *rewards, double *partial) {
+    FN(consts_t) k;
+    FN(make_consts)(&k, K, img_w, img_h, min_dist, max_dist);
+    REAL *p = (REAL *)malloc(sizeof(REAL) * (size_t)(N > 0 ? N : 1));
+    if (!p) return -1;
+    for (int64_t w = 0; w < W; ++w) {
+        FN(cam_t) cam;
+        FN(make_cam)(&cam, quats + 4 * w, poses + 3 * w, 1);
+        int has_nan;
+        (void)FN(eval_waypoint)(&k, &cam, xyz, N, NULL, p, &has_nan);
+        FN(bwd_sums)(&k, &cam, xyz, N, NULL, rewards, ext_min[w], ext_max[w] - ext_min[w], 1.0, p, partial + 40 * w);
+    }
+    free(p);
+    return 0;
+}
+
+/* the ranks' sums added up -> gradients; scale = dL/d reward (the same for every point: -gout vis^2 / N_all) */
+int FN(oracle_traj_backward_final)(const float *poses, const float *quats, int64_t W, const double *partial, double scale,
+                                   REAL *poses_grad, REAL *quats_grad) {
+    for (int64_t w = 0; w < W; ++w) {
+        FN(cam_t) cam;
+        FN(make_cam)(&cam, quats + 4 * w, poses + 3 * w, 1);
+        FN(bwd_final)(&cam, partial + 40 * w, scale, poses_grad + 3 * w, quats_grad + 4 * w);
+    }
     return 0;
 }
 

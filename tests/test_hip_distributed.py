@@ -86,6 +86,89 @@ def test_sharded_model_equals_single_process(tmp_path):
     np.testing.assert_allclose(r0["opt_quats"], m2.quats.detach().cpu().numpy(), atol=2e-4)
 
 
+# ---- point sharding (distributed.PointShard): every rank a part of the cloud, all the waypoints ------------------------------
+
+def _worker_points(rank, world, port, out_dir, vwd, rig):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from trajectory_optimization_amd import synth
+    from trajectory_optimization_amd.distributed import PointShard, init_from_env
+    from trajectory_optimization_amd.model import ModelTraj
+    from trajectory_optimization_amd.optimizer import optimize_trajectory
+    _, _, device = init_from_env(backend="gloo")
+    pts = synth.make_cloud(70_001, seed=19)   # (an odd count: the ranks' parts differ in size)
+    poses, quats = synth.make_path(11, optical=True, jitter_seed=19)
+    kw = dict(rig=synth.camera_rig(3)) if rig else {}
+
+    def model():
+        return ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(synth.K_INTRINS),
+                         synth.IMG_WIDTH, synth.IMG_HEIGHT, device=device, shard=PointShard(), **kw)
+    m = model()
+    lo_p, hi_p = m._shard.point_bounds(len(pts))
+    assert m.points.shape[0] == hi_p - lo_p and m._n_global == len(pts)
+    loss = m(vis_wps_dist=vwd)
+    loss.backward()
+    m2 = model()
+    res = optimize_trajectory(m2, n_opt_steps=4, lr_pose=0.05, lr_quat=0.01, rewards_th=1e9, vis_wps_dist=vwd)
+    ext = m._point_step((len(poses) + m._wps_step(vwd) - 1) // m._wps_step(vwd)).extrema.cpu().numpy()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=loss.item(), vis=float(m.loss["vis"]), rewards=m.rewards.detach().cpu().numpy(),
+             bounds=np.array([lo_p, hi_p]), pg=m.poses.grad.cpu().numpy(), qg=m.quats.grad.cpu().numpy(), extrema=ext,
+             opt_poses=m2.poses.detach().cpu().numpy(), opt_quats=m2.quats.detach().cpu().numpy(), opt_losses=np.asarray(res.losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("vwd,rig", [(0.0, False), (2.5, False), (0.0, True)])
+def test_point_sharded_model_equals_single_process(tmp_path, vwd, rig):
+    """Two gloo ranks on the one GPU, each with half of the cloud and ALL the waypoints (PointShard): the extrema all-reduced
+    after pass 1 are the single process's to the bit (a maximum does not depend on how the points are split), rewards within
+    1e-6, loss and gradients (identical on both ranks) within 1e-5 of the single-process model; the launch-only optimiser follows."""
+    sys.path.insert(0, REPO)
+    from trajectory_optimization_amd import ops, synth
+    from trajectory_optimization_amd.model import ModelTraj
+    from trajectory_optimization_amd.optimizer import optimize_trajectory
+    world = 2
+    mp.spawn(_worker_points, args=(world, _free_port(), str(tmp_path), vwd, rig), nprocs=world, join=True)
+    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in range(world))
+    for k in ("loss", "vis", "pg", "qg", "extrema", "opt_poses", "opt_quats", "opt_losses"):
+        assert np.array_equal(r0[k], r1[k]), k   # replicated state identical on both ranks
+    dev = torch.device("cuda:0")
+    pts = synth.make_cloud(70_001, seed=19)
+    poses, quats = synth.make_path(11, optical=True, jitter_seed=19)
+    kw = dict(rig=synth.camera_rig(3)) if rig else {}
+    m = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(synth.K_INTRINS),
+                  synth.IMG_WIDTH, synth.IMG_HEIGHT, device=dev, **kw)
+    loss = m(vis_wps_dist=vwd)
+    loss.backward()
+    # the waypoints' extrema: bitwise the single process's (its workspace holds them in the same words)
+    step_w = m._wps_step(vwd)
+    n_eval = (len(poses) + step_w - 1) // step_w
+    C = 3 if rig else 1
+    words, n_words = __import__("ctypes").c_void_p(), __import__("ctypes").c_int64()
+    from trajectory_optimization_amd import _lib
+    ws = m._workspace(n_eval)
+    _lib.check(_lib.lib().tohip_traj_extrema_view(m._cloud.n, n_eval * C, _lib.ptr(ws.buf), ws.bytes, __import__("ctypes").byref(words),
+                                                  __import__("ctypes").byref(n_words)), "extrema view")
+    off = words.value - ws.buf.data_ptr()
+    single_ext = ws.buf[off:off + 4 * n_words.value].view(torch.int32).cpu().numpy()
+    assert np.array_equal(single_ext, r0["extrema"])
+    rewards = m.rewards.detach().cpu().numpy()
+    for r in (r0, r1):
+        lo_p, hi_p = r["bounds"]
+        np.testing.assert_allclose(r["rewards"], rewards[lo_p:hi_p], rtol=1e-6, atol=0)
+    assert abs(float(r0["loss"]) - loss.item()) <= 2e-6 * abs(loss.item())
+    pg, qg = m.poses.grad.cpu().numpy(), m.quats.grad.cpu().numpy()
+    assert np.abs(r0["pg"] - pg).max() <= 1e-5 * np.abs(pg).max()
+    assert np.abs(r0["qg"] - qg).max() <= 1e-5 * np.abs(qg).max()
+    m2 = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(synth.K_INTRINS),
+                   synth.IMG_WIDTH, synth.IMG_HEIGHT, device=dev, **kw)
+    res = optimize_trajectory(m2, n_opt_steps=4, lr_pose=0.05, lr_quat=0.01, rewards_th=1e9, vis_wps_dist=vwd)
+    np.testing.assert_allclose(r0["opt_losses"], res.losses, rtol=2e-5)
+    np.testing.assert_allclose(r0["opt_poses"], m2.poses.detach().cpu().numpy(), atol=2e-4)
+    np.testing.assert_allclose(r0["opt_quats"], m2.quats.detach().cpu().numpy(), atol=2e-4)
+
+
 # ---- bench.py's own N>1 step (the code the driver's 8-GPU run executes), rehearsed on the one GPU of the test box ------------
 
 def _run(cmd, env_extra, timeout=600):
@@ -152,3 +235,31 @@ def test_bench_step_through_rccl_on_one_rank(bench_one_rank, tmp_path):
     c = np.load(tmp_path / "rcclc.npz")
     for k in ("scalars", "pg", "qg", "rewards"):
         assert np.array_equal(a[k], c[k]), k
+
+
+def test_bench_point_shard_two_ranks_and_one_rank_rccl(bench_one_rank, tmp_path):
+    """bench.py --shard points: every rank a part of the cloud and all the waypoints.  Two gloo ranks on the one GPU, and a ONE-rank
+    nccl group (the MAX all-reduce of the extrema words and the SUM all-reduce of the partial sums go through RCCL): loss and
+    gradients equal the single-rank run's within the tolerance of a different summation order (f64 partials across ranks)."""
+    import json
+    a = bench_one_rank
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--wps-per-gpu", "32", "--shard", "points",
+                "--dump", str(tmp_path / "p2.npz")] + _BENCH_COMMON, {"TOHIP_DIST_BACKEND": "gloo"})
+    line = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["waypoints_total"] == 64 and line["config"]["parallelism"] == "point-shard x2"
+    assert line["comm"]["shard"] == "points" and line["comm"]["extrema_allreduce_max"]["bytes"] == 64 * 16
+    b = np.load(tmp_path / "p2.npz")
+    np.testing.assert_allclose(b["scalars"][:2], a["scalars"][:2], rtol=2e-6)
+    np.testing.assert_allclose(b["rewards"], a["rewards"][:len(b["rewards"])], rtol=1e-6, atol=0)   # rank 0's rows
+    assert np.abs(b["pg"] - a["pg"]).max() <= 1e-5 * np.abs(a["pg"]).max()
+    assert np.abs(b["qg"] - a["qg"]).max() <= 1e-5 * np.abs(a["qg"]).max()
+    out = _run([sys.executable, "bench.py", "--gpus", "1", "--wps-per-gpu", "64", "--shard", "points", "--dump", str(tmp_path / "p1.npz")] + _BENCH_COMMON,
+               {"TOHIP_DIST_FORCE_INIT": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(_free_port())})
+    line = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+    assert line["comm"]["backend"] == "nccl" and line["comm"]["shard"] == "points"
+    c = np.load(tmp_path / "p1.npz")
+    assert np.array_equal(c["rewards"], a["rewards"]) and np.array_equal(c["scalars"][:2], a["scalars"][:2])
+    assert np.abs(c["pg"] - a["pg"]).max() <= 1e-6 * np.abs(a["pg"]).max()
+    assert np.abs(c["qg"] - a["qg"]).max() <= 1e-6 * np.abs(a["qg"]).max()

@@ -470,14 +470,16 @@ struct __attribute__((aligned(128))) WayRec {
 static_assert(sizeof(WayRec) == 128, "WayRec is two 64-byte lines");
 
 // Per-waypoint extrema of p as bit patterns (p >= +0: the integer order is the float order; a NaN sorts above +inf).
-// Initialised by the probe with (U, L), improved by pass 1 with atomicMin / atomicMax — order independent, hence
-// deterministic.  a = min p, M = max p - a, p_hat = (p - a) / M  (model.py:226-227).
+// Initialised by the probe with (U, L), improved by pass 1 with atomicMax — order independent, hence deterministic.  The
+// minimum is kept NEGATED (nmn = -bits(min p)) so that both fields only ever grow: a point-sharded run (every rank holds a part
+// of the cloud, distributed.PointShard) combines the ranks' arrays with ONE element-wise MAX all-reduce over the int32 view, in
+// place (the pad words are zero everywhere).  a = min p, M = max p - a, p_hat = (p - a) / M  (model.py:226-227).
 struct __attribute__((aligned(16))) Extrema {
-    int mn, mx;
+    int nmn, mx;
     int pad[2];
 };
 __device__ __forceinline__ void load_norm(const Extrema& e, float& a, float& pmax, float& M, float& invM) {
-    a = __builtin_bit_cast(float, e.mn);
+    a = __builtin_bit_cast(float, -e.nmn);
     pmax = __builtin_bit_cast(float, e.mx);
     M = pmax - a;          // == max(p - a): rounding is monotone
     invM = 1.0f / M;

@@ -409,7 +409,7 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
         rec[v].azero = (mn == 0.f) ? 1.f : 0.f;
         scull[0] = thr; scull[1] = sthr; scull[2] = (mn == 0.f) ? 1.f : 0.f;
         Extrema e;
-        e.mn = __builtin_bit_cast(int, mn);
+        e.nmn = -__builtin_bit_cast(int, mn);
         e.mx = __builtin_bit_cast(int, mx);
         e.pad[0] = e.pad[1] = 0;
         ext[v] = e;
@@ -464,7 +464,7 @@ __device__ __forceinline__ bool fold_extrema(Extrema* __restrict__ ext, int v, f
     const int Ub = __builtin_bit_cast(int, r.U);
     if (Ub != 0) {
         const int mnb = __builtin_bit_cast(int, mn);
-        if (mnb < Ub) atomicMin(&ext[v].mn, mnb);
+        if (mnb < Ub) atomicMax(&ext[v].nmn, -mnb);
     }
     return cand;
 }
@@ -703,7 +703,7 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
     if (t == 0) {
         for (int w = 0; w < 2 * TO_SP_WAVES; ++w) { bmx = max(bmx, L.mx[w]); bmn = min(bmn, L.mn[w]); }
         if (bmx > __builtin_bit_cast(int, r.L)) atomicMax(&ext[v].mx, bmx);
-        if (bmn < __builtin_bit_cast(int, r.U)) atomicMin(&ext[v].mn, bmn);
+        if (bmn < __builtin_bit_cast(int, r.U)) atomicMax(&ext[v].nmn, -bmn);
     }
     for (int w = t; w < fv_words; w += TO_SP_THREADS) {
         const unsigned long long word = L.cand[w];
@@ -1364,9 +1364,12 @@ __global__ void k_bwd_finish2(const float* __restrict__ vgrad, const WayHot* __r
 // The sums of a FUSED step were taken with unit dL/d reward: post = 1 scales them by scalars[4*seg+2] * gout[seg] (scalars
 // written by k_traj_reward in the same step), post = 2 by the same factor computed here from the integer reward sum
 // (RewardAcc::a), which the first block of each trajectory also turns into that trajectory's scalars.
+#define TO_PSHARD_HDR 8      // doubles in front of the per-waypoint partials of a point-sharded step
+#define TO_PSHARD_NSUM 40    // per virtual waypoint: 14 sums of the flagged pairs, 13 + 13 of the argmin / argmax sets
 struct FinishPost {
     const unsigned long long* live;   // culled pass 1: bit (v, slot) = the pair was evaluated (`part` holds it); NULL: all were
-    int mode;                  // 0: none   1: scalars + gout   2: acc + gout (+ scalars_out)
+    double* partial;           // mode 3: TO_PSHARD_HDR + V x TO_PSHARD_NSUM doubles (this rank's sums: the ranks add them up)
+    int mode;                  // 0: none   1: scalars + gout   2: acc + gout (+ scalars_out)   3: stop at the sums (point-sharded step)
     const float* scalars;
     const float* gout;
     const RewardAcc* acc;
@@ -1597,6 +1600,30 @@ k_traj_finish(CloudView cv, const float* __restrict__ bpart, int nslots, const u
     }
     __shared__ double stot[16];
     __shared__ float s_sc[4];   // the trajectory's scalars (the step's epilogue wants them)
+    if (post.mode == 3) {
+        // a point-sharded step: this rank holds a part of the cloud, so these are PARTIAL sums — everything below (the factor
+        // dL/d reward from the mean of ALL rewards, the tie sets' shares, the chain) is linear in them or needs the other ranks'
+        // too: they leave here, the ranks add them up (one all-reduce), k_traj_pshard_final goes on
+        __syncthreads();   // stie
+        double* dst = post.partial + TO_PSHARD_HDR + (int64_t)v * TO_PSHARD_NSUM;
+        if (t < 14) {
+            double q = 0.0;
+            for (int gg = 0; gg < 64; ++gg) q += sgrp[gg][t];
+            dst[t] = q;
+        } else if (t < 40) {
+            dst[t] = stie[(t - 14) / 13][(t - 14) % 13];
+        }
+        if (v == 0 && t == 64) {   // the rank's reward sum (fixed point, exact in a double), NaN mark and point count
+            long long sfix = 0;
+            unsigned nan = 0;
+            for (int i = 0; i < 8; ++i) { sfix += post.acc->a[i].sum; nan |= post.acc->a[i].nan; }
+            post.partial[0] = (double)((long long)cv.n * (1ll << (post.shift - 1)) + sfix);
+            post.partial[1] = nan ? 1.0 : 0.0;
+            post.partial[2] = (double)cv.n;
+            for (int i = 3; i < TO_PSHARD_HDR; ++i) post.partial[i] = 0.0;
+        }
+        return;
+    }
     if (t < 16) {
         double q = 0.0;
         for (int gg = 0; gg < 64; ++gg) q += sgrp[gg][t];
@@ -1822,7 +1849,8 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
     p.off_ctl = o;   o += sizeof(RewardAcc) * (size_t)(n_traj < 1 ? 1 : n_traj);   // first: all tohip_traj_reward uses
     p.off_toff = o;  o += align_up(sizeof(int) * (size_t)((n_traj < 1 ? 1 : n_traj) + 1), 256);   // the forward's copy of the trajectory offsets
     p.off_rec = o;   o += align_up((size_t)V * sizeof(WayRec), 256);
-    p.off_cold = o;  o += align_up((size_t)W * sizeof(WayCold), 256);
+    (void)W;
+    p.off_cold = o;  o += align_up((size_t)V * sizeof(WayCold), 256);   // (one per BODY waypoint; sized by V so that the layout depends on (n, V, n_traj) only)
     p.off_ext = o;   o += align_up((size_t)V * sizeof(Extrema), 256);
     p.off_cbits = o; o += align_up((size_t)p.ncbits * TO_CBIT_STRIDE * sizeof(unsigned long long), 256);   // a bit per (trajectory, slot): pass 1's candidates
     p.off_ctr = o;   o += (size_t)TO_PL_SHARDS * TO_PL_STRIDE * sizeof(int);                // the pair sub-lists' lengths, one to a 128-byte line
@@ -2047,7 +2075,7 @@ inline int launch_finish(const TrajStep& s, const FinishPost& post, float* poses
         k_traj_finish<256><<<V, 256, 0, s.st>>>(s.cv, s.bpart, s.pl.nslots, s.fv, s.pl.fv_words, s.rec, s.ext, s.k, s.ties, s.part, V, s.occ, s.occw,
                                                 s.vgrad, s.cold, single ? 1 : 0, poses_grad, quats_grad, post, s.opt);
     TO_HIP_CHECK_LAUNCH();
-    if (!single) {
+    if (!single && post.mode != 3) {
         k_traj_bwd_finish2<<<(int)((s.W + 63) / 64), 64, 0, s.st>>>(s.vgrad, s.rec, s.cold, (int)s.W, s.C, s.rq, s.rt, poses_grad, quats_grad, s.opt,
                                                                     post.scalars_out);
         TO_HIP_CHECK_LAUNCH();
@@ -2058,6 +2086,7 @@ inline int launch_finish(const TrajStep& s, const FinishPost& post, float* poses
 inline FinishPost finish_post(const TrajStep& s, int mode, const float* scalars, const float* gout, float* scalars_out, float eps) {
     FinishPost p;
     p.live = s.cull ? s.live : nullptr;
+    p.partial = nullptr;
     p.mode = mode; p.scalars = scalars; p.gout = gout; p.acc = s.acc; p.scalars_out = scalars_out; p.n = s.n; p.shift = s.shift; p.eps = eps;
     p.toff = s.toff; p.C = s.C;
     return p;
@@ -2291,6 +2320,128 @@ extern "C" int tohip_traj_opt_step(const tohip_traj_opt* o, int32_t step_index, 
     rc = traj_fused_forward(s, o->poses, o->quats, o->lo_sum, o->minmax, o->rewards);
     if (rc != TOHIP_OK) return rc;
     return launch_finish(s, finish_post(s, 2, nullptr, nullptr, o->scalars, o->cam.eps), o->poses_grad_eval, o->quats_grad_eval);
+}
+
+// ---- point-sharded step (the alternative to waypoint sharding) ------------------------------------------------
+// Every rank holds N / R points and evaluates ALL waypoints on them.  What crosses ranks is small and does not grow with N:
+//   after pass 1    the per-waypoint extrema: ONE element-wise MAX all-reduce over the int32 view of the Extrema array (the
+//                   minimum is kept negated), 16 bytes per virtual waypoint
+//   after the sums  TO_PSHARD_HDR + V x 40 doubles: the rank's reward sum (fixed point), and per waypoint the 14 gradient sums
+//                   of its flagged pairs and the 13 + 13 of its argmin / argmax sets — all of it additive over the points
+// The log-odds sum of a point is complete on its own rank (it has every waypoint), so rewards never travel.
+__global__ void __launch_bounds__(64)
+k_traj_pshard_final(const double* __restrict__ partial, const WayRec* __restrict__ rec, const Extrema* __restrict__ ext,
+                    const WayCold* __restrict__ cold, int single, int shift, float eps, const float* __restrict__ gout,
+                    float* __restrict__ scalars_out, float* __restrict__ vgrad, float* __restrict__ poses_grad,
+                    float* __restrict__ quats_grad) {
+    __shared__ float sgy[12];
+    const int v = blockIdx.x, t = threadIdx.x;
+    const double* src = partial + TO_PSHARD_HDR + (int64_t)v * TO_PSHARD_NSUM;
+    const WayRec& r = rec[v];
+    float a, pmax, M, invM;
+    load_norm(ext[v], a, pmax, M, invM);
+    // the scalars from the ranks' total: every reward of every rank, N = all points
+    float sc[4];
+    reward_scalars((long long)partial[0], partial[1] != 0.0, (int64_t)partial[2], shift, eps, sc);
+    if (v == 0 && t == 0 && scalars_out) { scalars_out[0] = sc[0]; scalars_out[1] = sc[1]; scalars_out[2] = sc[2]; scalars_out[3] = sc[3]; }
+    if (t < 12) {
+        const double coef = (double)(sc[2] * (gout ? gout[0] : 1.0f));
+        const double nmin = src[14 + 12], nmax = src[27 + 12];
+        const double wmin = nmin > 0.0 ? coef * src[12] / nmin : 0.0;
+        const double wmax = nmax > 0.0 ? coef * src[13] / nmax : 0.0;
+        sgy[t] = (float)(coef * src[t] + wmin * src[14 + t] + wmax * src[27 + t]);
+        if (!(M > 0.f) || !(invM < INFINITY)) sgy[t] = __builtin_nanf("");   // degenerate waypoint: NaN like its rewards (k_traj_finish)
+    }
+    __syncthreads();
+    if (t < 12) {
+        float out;
+        if (t < 3) out = (float)((double)r.m[3 * t] * sgy[0] + (double)r.m[3 * t + 1] * sgy[1] + (double)r.m[3 * t + 2] * sgy[2]);
+        else {
+            const int j = (t - 3) / 3, i = (t - 3) % 3;
+            out = (float)((double)sgy[3 + 3 * j] * r.m[3 * i] + (double)sgy[3 + 3 * j + 1] * r.m[3 * i + 1] + (double)sgy[3 + 3 * j + 2] * r.m[3 * i + 2]);
+        }
+        vgrad[v * 12 + t] = out;
+    }
+    if (single) {
+        __syncthreads();
+        if (t == 0) {
+            float o[7];
+            finish_waypoint(v, vgrad, RecRows{rec}, cold, 1, nullptr, nullptr, o);
+            store_grad_row(v, o, poses_grad, quats_grad);
+        }
+    }
+}
+
+extern "C" size_t tohip_traj_pshard_partial_count(int64_t n_virtual) {
+    return n_virtual > 0 ? (size_t)(TO_PSHARD_HDR + n_virtual * TO_PSHARD_NSUM) : 0;
+}
+
+// host helper: where the step's per-waypoint extrema live in the workspace, as int32 words (4 per virtual waypoint: -bits(min),
+// bits(max), 0, 0) — the array a point-sharded run MAX-all-reduces in place between tohip_traj_pshard_pass1 and _local
+extern "C" int tohip_traj_extrema_view(int64_t n_points, int64_t n_virtual, void* workspace, size_t workspace_bytes, int32_t** words,
+                                       int64_t* n_words) {
+    if (n_points <= 0 || n_virtual <= 0 || !workspace || !words || !n_words) return TOHIP_EINVAL;
+    const TrajPlan pl = make_plan(n_points, n_virtual, n_virtual, 1);
+    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
+    *words = (int32_t*)((char*)workspace + pl.off_ext);
+    *n_words = n_virtual * 4;
+    return TOHIP_OK;
+}
+
+extern "C" int tohip_traj_pshard_pass1(const void* packed, int64_t n_local, int64_t n_global, const float* poses, const float* quats, int64_t W,
+                                       const tohip_camera* cam, const tohip_rig* rig, int flags, const uint32_t* occlusion_bits,
+                                       float* lo_sum, float* rewards, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!poses || !quats || !lo_sum || !rewards || n_global < n_local) return TOHIP_EINVAL;
+    TrajStep s;
+    int rc = traj_step_init(s, packed, n_local, W, 1, nullptr, cam, rig, flags, occlusion_bits, workspace, workspace_bytes, stream_, true);
+    if (rc != TOHIP_OK) return rc;
+    return launch_probe_pass1(s, poses, quats, lo_sum, rewards);
+}
+
+extern "C" int tohip_traj_pshard_local(const void* packed, int64_t n_local, int64_t n_global, int64_t W, const tohip_camera* cam,
+                                       const tohip_rig* rig, int flags, const uint32_t* occlusion_bits, float* lo_sum, float* minmax,
+                                       float* rewards, double* partial, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!lo_sum || !minmax || !rewards || !partial || n_global < n_local) return TOHIP_EINVAL;
+    TrajStep s;
+    int rc = traj_step_init(s, packed, n_local, W, 1, nullptr, cam, rig, flags, occlusion_bits, workspace, workspace_bytes, stream_, false);
+    if (rc != TOHIP_OK) return rc;
+    s.shift = reward_shift(n_global);   // one fixed-point scale on every rank: the ranks' sums add up exactly
+    SparseArgs a = sparse_args(s, lo_sum);
+    a.minmax = minmax;
+    a.rewards = rewards;
+    a.prefilled = 1;
+    rc = launch_sparse<TO_SP_FUSED>(s, a);
+    if (rc != TOHIP_OK) return rc;
+    rc = launch_pairs(s, a);
+    if (rc != TOHIP_OK) return rc;
+    FinishPost post = finish_post(s, 3, nullptr, nullptr, nullptr, cam->eps);
+    post.partial = partial;
+    return launch_finish(s, post, nullptr, nullptr);
+}
+
+extern "C" int tohip_traj_pshard_finish(int64_t n_local, int64_t n_global, int64_t W, const tohip_camera* cam, const tohip_rig* rig,
+                                        const double* partial, const float* gout, float* scalars, float* poses_grad, float* quats_grad,
+                                        void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!cam || !partial || !scalars || !poses_grad || !quats_grad || !workspace || n_local <= 0 || n_global < n_local || W <= 0) return TOHIP_EINVAL;
+    const int C = rig_cams(rig);
+    const int64_t V = W * C;
+    const TrajPlan pl = make_plan(n_local, V, W, 1);
+    if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    const WayRec* rec = (const WayRec*)(ws + pl.off_rec);
+    const WayCold* cold = (const WayCold*)(ws + pl.off_cold);
+    float* vgrad = (float*)(ws + pl.off_vgrad);
+    const bool single = C == 1 && !(rig && rig->rig_quats);
+    k_traj_pshard_final<<<(int)V, 64, 0, st>>>(partial, rec, (const Extrema*)(ws + pl.off_ext), cold, single ? 1 : 0, reward_shift(n_global), cam->eps,
+                                               gout, scalars, vgrad, poses_grad, quats_grad);
+    TO_HIP_CHECK_LAUNCH();
+    if (!single) {
+        k_traj_bwd_finish2<<<(int)((W + 63) / 64), 64, 0, st>>>(vgrad, rec, cold, (int)W, C, rig->rig_quats, rig->rig_trans, poses_grad, quats_grad,
+                                                                OptStep{}, nullptr);
+        TO_HIP_CHECK_LAUNCH();
+    }
+    return TOHIP_OK;
 }
 
 // ---- the log-odds vector of a waypoint-sharded step, compacted for its all-reduce ---------------------------------------------

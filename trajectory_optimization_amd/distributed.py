@@ -1,5 +1,8 @@
-"""Waypoint sharding over the GPUs of one node (not in the reference, which is
-single-process).
+"""Sharding over the GPUs of one node (not in the reference, which is single-process): by waypoints
+(WaypointShard, the north star's design) or by points (PointShard, the survey's alternative: collectives that do not grow
+with the cloud).
+
+WaypointShard.
 
 One process per GPU; the cloud is replicated (12 MB at 1 M points), the evaluated waypoints are split
 into contiguous per-rank ranges.  The only data-path collective is ONE all-reduce (sum, f32, N floats) of
@@ -8,7 +11,13 @@ the per-waypoint min/max normalisation is rank-local by construction.  In the ba
 produces the gradient rows of its own waypoints and a (W,7)-float all-reduce assembles them so that a
 replicated optimiser steps identically everywhere.
 
-The class holds no kernels: it only places waypoints and issues collectives, so its logic is covered by
+PointShard.  Every rank packs N / R of the points and evaluates ALL waypoints on them.  A point's log-odds sum is then complete
+on its own rank (rewards never travel); what the ranks exchange is per WAYPOINT: after pass 1 the extrema (one element-wise MAX
+all-reduce of 4 int32 per virtual waypoint: the minimum is kept negated), after the gradient sums 40 doubles per virtual waypoint
+plus the reward sum (one SUM all-reduce) — 2 KB and 41 KB at 128 waypoints whatever N is, against 4 MB per step for the log-odds
+vector of a waypoint-sharded run at 1 M points.  Every rank ends up with the same loss and the same gradients.
+
+The classes hold no kernels: they only place work and issue collectives, so their logic is covered by
 world_size-2 gloo tests on CPU (tests/test_distributed_cpu.py).
 """
 import torch
@@ -16,6 +25,8 @@ import torch.distributed as dist
 
 
 class WaypointShard:
+    kind = "waypoints"
+
     def __init__(self, process_group=None, force_collectives=False, compact=False):
         """force_collectives: issue the collectives even in a one-rank group (a rehearsal of the RCCL calls on one GPU).
         compact: all-reduce only the 256-point slots some rank's forward listed as candidates (the log-odds vector is exactly zero
@@ -77,6 +88,23 @@ class WaypointShard:
         out = src.new_empty((self.world_size * src.shape[0],) + tuple(src.shape[1:]))
         dist.all_gather_into_tensor(out, src, group=self.group)
         return out.to(t.device) if staged else out
+
+
+class PointShard(WaypointShard):
+    """Placement of the POINTS over the ranks: rank r owns the contiguous rows point_bounds(N) of the caller's cloud and every
+    waypoint.  ModelTraj(points, ..., shard=PointShard()) takes the WHOLE cloud (or this rank's rows with n_points_global=) and
+    keeps only its own rows; model.rewards are then this rank's rows' rewards."""
+    kind = "points"
+
+    def __init__(self, process_group=None, force_collectives=False):
+        super().__init__(process_group, force_collectives, compact=False)
+
+    def bounds(self, n_wps, rank=None):
+        return 0, n_wps   # every rank evaluates every waypoint
+
+    def point_bounds(self, n_points, rank=None):
+        """Contiguous, balanced range [lo, hi) of the n_points rows owned by `rank`."""
+        return WaypointShard.bounds(self, n_points, rank)
 
 
 def init_from_env(backend=None, use_gpu=None, force=False):

@@ -338,6 +338,64 @@ class _TrajLoss(torch.autograd.Function):
         return pg_all, qg_all, None, None
 
 
+class _TrajLossPoints(torch.autograd.Function):
+    """ModelTraj.forward of a POINT-sharded model (distributed.PointShard): this rank's part of the cloud, every waypoint, two
+    small collectives inside the forward (the waypoints' extrema after pass 1; 40 sums per waypoint and the reward sum after
+    the gradient sums) — ops.PointShardStep.  The forward has the gradient of the visibility loss in hand when it returns (the
+    sums are taken with unit upstream gradient), so the backward issues no kernel and no collective: it scales.  Loss, loss terms
+    and gradients are identical on every rank; `rewards` are this rank's rows.  A loss built on model.rewards would need the
+    other ranks' upstream gradients per point: not supported (raises)."""
+
+    @staticmethod
+    def forward(ctx, poses, quats, model, step_w):
+        L = _lib.lib()
+        dev = poses.device
+        if not (poses.is_contiguous() and quats.is_contiguous() and poses.dtype == torch.float32 and quats.dtype == torch.float32):
+            raise RuntimeError("ModelTraj: poses / quats must be contiguous float32 tensors")
+        p_all, q_all = poses.detach(), quats.detach()
+        W = p_all.shape[0]
+        n_eval = (W + step_w - 1) // step_w
+        st = model._point_step(n_eval)
+        rewards, scalars, pg_e, qg_e = st.step(p_all, q_all, flags_extra=((step_w - 1) & 0xffff) << 8)   # every step_w-th waypoint, read in place
+        terms = torch.empty(8, dtype=torch.float32, device=dev)
+        reg_sum = torch.empty((W, 3), dtype=torch.float32, device=dev)
+        reg_terms = torch.empty((3, W, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.tohip_traj_regularizers(ptr(p_all), ptr(model.poses0), W, float(model.smoothness_weight),
+                                            float(model.traj_length_weight), float(model.eps), ptr(scalars), ptr(terms),
+                                            ptr(reg_sum), 0, None, ptr(reg_terms), stream_ptr()), "tohip_traj_regularizers")
+        ctx.step_w, ctx.W, ctx.n_eval = step_w, W, n_eval
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(pg_e.clone(), qg_e.clone(), reg_sum, reg_terms)
+        vis, l2, length, smooth, total = terms[:5].unbind()
+        return total, rewards.clone(), vis, l2, length, smooth
+
+    @staticmethod
+    def backward(ctx, g_loss, g_rewards, g_vis, g_l2, g_length, g_smooth):
+        if g_rewards is not None:
+            raise NotImplementedError("ModelTraj(shard=PointShard()): the rewards are rank-local; a loss built on model.rewards is not "
+                                      "supported with point sharding (use WaypointShard, or model.loss / the returned loss)")
+        pg_e, qg_e, reg_sum, reg_terms = ctx.saved_tensors
+        g_loss, g_vis = _f32(g_loss), _f32(g_vis)
+        c_vis = g_vis if g_loss is None else (g_loss if g_vis is None else g_loss + g_vis)
+        dev = pg_e.device
+        pg = torch.zeros((ctx.W, 3), dtype=torch.float32, device=dev)
+        qg = torch.zeros((ctx.W, 4), dtype=torch.float32, device=dev)
+        if c_vis is not None:
+            rows = slice(0, (ctx.n_eval - 1) * ctx.step_w + 1, ctx.step_w)
+            pg[rows], qg[rows] = c_vis * pg_e, c_vis * qg_e
+        g_terms = (g_l2, g_length, g_smooth)
+        if all(g is None for g in g_terms):
+            if g_loss is not None:
+                pg = pg + g_loss * reg_sum
+        else:
+            for k, g in enumerate(g_terms):
+                c = g_loss if g is None else (g.to(torch.float32) if g_loss is None else g_loss + g.to(torch.float32))
+                if c is not None:
+                    pg = pg + c * reg_terms[k]
+        return pg, qg, None, None
+
+
 class _LossPlan:
     """A ModelTraj as the library sees it (struct tohip_traj_loss): built once per (model, waypoint step), it owns the step's
     workspace and scratch vectors, so that model() and loss.backward() are one library call each with five pointers."""
@@ -722,14 +780,29 @@ class ModelTraj(nn.Module):
                  min_dist=1.0, max_dist=5.0,
                  smoothness_weight=14.0, traj_length_weight=0.02,
                  device=torch.device('cuda'),
-                 *, rig=None, shard=None, dense=False, occlusion=None, occlusion_limits=(1.0, 15.0)):
+                 *, rig=None, shard=None, dense=False, occlusion=None, occlusion_limits=(1.0, 15.0), n_points_global=None):
         super().__init__()
         assert wps_poses.dim() == wps_quats.dim()
         assert wps_poses.size()[1] == 3
         assert wps_quats.size()[1] == 4
 
         self.device = torch.device(device)
-        self.points = torch.as_tensor(points, dtype=torch.float32).to(self.device)
+        self._n_global = None
+        if shard is not None and getattr(shard, "kind", "waypoints") == "points":
+            # point sharding: this rank keeps its own rows of the cloud (the whole cloud is handed in, or — n_points_global — the
+            # rows already); model.rewards are those rows' rewards
+            pts = torch.as_tensor(points, dtype=torch.float32)
+            if n_points_global is None:
+                self._n_global = int(pts.shape[0])
+                lo_p, hi_p = shard.point_bounds(self._n_global)
+                pts = pts[lo_p:hi_p]
+            else:
+                self._n_global = int(n_points_global)
+            if occlusion is not None:
+                raise ValueError("occlusion-aware rewards need the whole cloud on every rank: not available with PointShard")
+            self.points = pts.contiguous().to(self.device)
+        else:
+            self.points = torch.as_tensor(points, dtype=torch.float32).to(self.device)
         self.rewards = None
         self.observations = None
         self.lo_sum = 0.0  # attribute kept for the reference's surface (its accumulated log-odds); the kernels hold theirs in packed order
@@ -799,6 +872,14 @@ class ModelTraj(nn.Module):
             ws = self._ws_cache[v] = ops.TrajWorkspace(self._cloud, v)
         return ws
 
+    def _point_step(self, n_eval):
+        """The point-sharded step's buffers (ops.PointShardStep) for n_eval evaluated waypoints."""
+        st = self._ws_cache.get(("points", n_eval))
+        if st is None:
+            st = self._ws_cache[("points", n_eval)] = ops.PointShardStep(self._cloud, self._n_global, n_eval, self._cam, self._workspace(n_eval),
+                                                                         self._shard, rig=self._rig, flags=self._flags)
+        return st
+
     def _plan(self, step_w):
         """The library-side description of this model for the one-call forward / backward (rebuilt when something it froze
         has changed: the weights of criterion, the mode, the initial trajectory, the number of waypoints)."""
@@ -826,6 +907,12 @@ class ModelTraj(nn.Module):
         t0 = time()
         N_wps = len(self.poses)
         wps_step = self._wps_step(vis_wps_dist)
+        if self._n_global is not None:
+            if not (N_wps >= 3 and type(self).criterion is ModelTraj.criterion):
+                raise NotImplementedError("ModelTraj(shard=PointShard()) supports the reference's criterion on >= 3 waypoints")
+            loss, self.rewards, vis, l2, length, smooth = _TrajLossPoints.apply(self.poses, self.quats, self, wps_step)
+            self.loss = {'vis': vis, 'length': length, 'l2': l2, 'smooth': smooth}
+            return loss
         if self.fused_loss and N_wps >= 3 and type(self).criterion is ModelTraj.criterion:
             if self._occlusion is None and self._shard.world_size == 1 and not getattr(self._shard, "_always", False):
                 plan = self._plan(wps_step)

@@ -257,6 +257,47 @@ def traj_backward_multi(cloud, n_wps, n_traj, cam, ws, lo_sum, grad_rewards=None
     return pg, qg
 
 
+class PointShardStep:
+    """One point-sharded visibility step (tohip_traj_pshard_*; distributed.PointShard): this rank's part of the cloud, all the
+    waypoints, two small collectives.  Buffers are allocated once; step(poses, quats) -> (rewards of this rank's points, scalars
+    (4: mean reward of ALL points, loss_vis, d loss_vis / d reward, -), poses_grad (W,3), quats_grad (W,4)) — scalars and
+    gradients identical on every rank (gradients for dL/d loss_vis = 1)."""
+
+    def __init__(self, cloud, n_global, n_wps, cam, ws, shard, rig=None, flags=0):
+        L = _lib.lib()
+        self.cloud, self.n_global, self.n_wps, self.cam, self.ws, self.shard, self.rig, self.flags = cloud, int(n_global), int(n_wps), cam, ws, shard, rig, int(flags)
+        dev = cloud.device
+        C = rig.n_cams if rig is not None else 1
+        V = n_wps * C
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.lo_sum, self.minmax = torch.empty(cloud.npad, **f32), torch.empty((V, 2), **f32)
+        self.rewards, self.scalars = torch.empty(cloud.n, **f32), torch.empty(4, **f32)
+        self.pg, self.qg = torch.empty((n_wps, 3), **f32), torch.empty((n_wps, 4), **f32)
+        self.partial = torch.empty(L.tohip_traj_pshard_partial_count(V), dtype=torch.float64, device=dev)
+        words, n_words = ctypes.c_void_p(), ctypes.c_int64()
+        check(L.tohip_traj_extrema_view(cloud.n, V, ptr(ws.buf), ws.bytes, ctypes.byref(words), ctypes.byref(n_words)), "tohip_traj_extrema_view")
+        off = words.value - ws.buf.data_ptr()
+        self.extrema = ws.buf[off:off + 4 * n_words.value].view(torch.int32)   # the workspace's own words: reduced in place
+        self.rig_ref = rig.ref() if rig is not None else _NULL_RIG
+
+    def step(self, poses, quats, flags_extra=0):
+        """flags_extra: TOHIP_TRAJ_STRIDE bits (the evaluated waypoints as every step-th row of poses / quats, read in place)."""
+        L, c, ws = _lib.lib(), self.cloud, self.ws
+        with torch.cuda.device(c.device):
+            s = stream_ptr()
+            check(L.tohip_traj_pshard_pass1(ptr(c.blob), c.n, self.n_global, ptr(poses), ptr(quats), self.n_wps, self.cam.ref(), self.rig_ref,
+                                            self.flags | int(flags_extra), None, ptr(self.lo_sum), ptr(self.rewards), ptr(ws.buf), ws.bytes, s), "tohip_traj_pshard_pass1")
+            ws.generation += 1
+            self.shard.allreduce_max(self.extrema)      # collective 1: the waypoints' extrema over all points (16 B per virtual waypoint)
+            check(L.tohip_traj_pshard_local(ptr(c.blob), c.n, self.n_global, self.n_wps, self.cam.ref(), self.rig_ref, self.flags, None,
+                                            ptr(self.lo_sum), ptr(self.minmax), ptr(self.rewards), ptr(self.partial), ptr(ws.buf), ws.bytes, s),
+                  "tohip_traj_pshard_local")
+            self.shard.allreduce_sum(self.partial)      # collective 2: the sums everything after is linear in (40 doubles per virtual waypoint)
+            check(L.tohip_traj_pshard_finish(c.n, self.n_global, self.n_wps, self.cam.ref(), self.rig_ref, ptr(self.partial), None,
+                                             ptr(self.scalars), ptr(self.pg), ptr(self.qg), ptr(ws.buf), ws.bytes, s), "tohip_traj_pshard_finish")
+        return self.rewards, self.scalars, self.pg, self.qg
+
+
 def allreduce_log_odds(shard, cloud, ws, lo_sum, local=True):
     """The one data-path collective of a waypoint-sharded step: the sum of the ranks' partial log-odds vectors, in
     place.  With shard.compact only the slots some rank's forward listed as candidates travel (tohip_traj_candidate_flags ...

@@ -117,11 +117,50 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
     pass inside the step and goes through the separate calls (forward | all-reduce | reward + backward | tohip_traj_step_tail).
     (A HIP-graph replay of the step was measured slower than issuing its launches — a replay costs 10-16 us of host time by
     itself, five launches 17 us, and the GPU side is the same — so there is no graph variant.)"""
+    if getattr(model, "_n_global", None) is not None:
+        return _optimize_trajectory_points(model, n_opt_steps, lr_pose, lr_quat, rewards_th, smoothness_th, vis_wps_dist, betas, adam_eps)
     if model._shard.world_size > 1 or getattr(model._shard, "_always", False) or model._occlusion is not None:
         return _optimize_trajectory_split(model, n_opt_steps, lr_pose, lr_quat, rewards_th, smoothness_th, vis_wps_dist, betas, adam_eps)
     run = _OptRun([model], n_opt_steps, lr_pose, lr_quat, rewards_th, smoothness_th, vis_wps_dist, betas, adam_eps)
     run.run(n_opt_steps)
     return run.results(n_opt_steps)[0]
+
+
+@torch.no_grad()
+def _optimize_trajectory_points(model, n_opt_steps, lr_pose, lr_quat, rewards_th, smoothness_th, vis_wps_dist, betas, adam_eps):
+    """optimize_trajectory of a POINT-sharded model (distributed.PointShard): per step the point-sharded visibility step
+    (ops.PointShardStep: this rank's points, every waypoint, two small collectives) and the replicated O(W) remainder
+    (tohip_traj_step_tail) — every rank holds the same gradients, so every rank takes the same step."""
+    L = _lib.lib()
+    dev = model.device
+    W = model.poses.shape[0]
+    step_w = model._wps_step(vis_wps_dist)
+    n_eval = (W + step_w - 1) // step_w
+    st = model._point_step(n_eval)
+    f32 = dict(dtype=torch.float32, device=dev)
+    pg, qg = torch.zeros((W, 3), **f32), torch.zeros((W, 4), **f32)
+    loss_terms = torch.zeros((n_opt_steps + 1, 8), **f32)
+    state = torch.zeros(8, **f32)
+    mp, vp = torch.zeros((W, 3), **f32), torch.zeros((W, 3), **f32)
+    mq, vq = torch.zeros((W, 4), **f32), torch.zeros((W, 4), **f32)
+    poses, quats = model.poses.data, model.quats.data
+    stride = ((step_w - 1) & 0xffff) << 8
+    with torch.cuda.device(dev):
+        for _ in range(n_opt_steps):
+            rewards, scalars, pg_e, qg_e = st.step(poses, quats, flags_extra=stride)
+            check(L.tohip_traj_step_tail(ptr(poses), ptr(quats), ptr(model.poses0), W, ptr(pg_e), ptr(qg_e), n_eval, step_w,
+                                         ptr(pg), ptr(qg), ptr(mp), ptr(vp), ptr(mq), ptr(vq), float(model.smoothness_weight),
+                                         float(model.traj_length_weight), float(model.eps), float(lr_pose), float(lr_quat),
+                                         betas[0], betas[1], adam_eps, float(rewards_th), float(smoothness_th), ptr(scalars),
+                                         ptr(loss_terms), ptr(state), stream_ptr()), "step tail")
+    torch.autograd.graph.increment_version(model.poses)
+    torch.autograd.graph.increment_version(model.quats)
+    stt = state.cpu()  # the run's only host synchronisation
+    steps = int(stt[3].item())
+    lt_host = loss_terms[:max(steps, 1)].cpu()
+    model.rewards = st.rewards
+    model.loss = {"vis": lt_host[-1, 0], "l2": lt_host[-1, 1], "length": lt_host[-1, 2], "smooth": lt_host[-1, 3]}
+    return TrajOptResult(steps, bool(stt[2].item() != 0), lt_host[:, 4].tolist(), float(stt[4]), float(stt[5]))
 
 
 @torch.no_grad()
