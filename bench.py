@@ -336,6 +336,54 @@ def aux_leg(device, sizes=(1_000_000, 16_000_000), reps=20):
     return out
 
 
+def occlusion_leg(device, steps=20):
+    """The occlusion-aware reward (the reference's TODO, tools.py:61-62 / model.py:210) on the headline workload:
+    per waypoint the hard pipeline of pc_processor.py:171-178 (exact transform -> hard frustum cull -> HPR from the camera centre,
+    or a z-buffer splat) turns into one bit per (waypoint, point).  Per method: milliseconds per mask refresh (all 128 waypoints),
+    and per optimisation step (optimizer.optimize_trajectory) with the masks rebuilt every step and every tenth step
+    (ModelTraj(occlusion_refresh_every=10): the masks are piecewise constant in the poses)."""
+    from trajectory_optimization_amd.model import ModelTraj
+    from trajectory_optimization_amd.optimizer import optimize_trajectory
+    pts = torch.from_numpy(synth.make_cloud(N_POINTS, seed=0)).to(device)
+    poses, quats = synth.make_path(WPS_PER_GPU, optical=True)
+    K = torch.from_numpy(synth.K_INTRINS)
+    out = {}
+    for method in ("hpr", "zbuffer"):
+        def model(k):
+            return ModelTraj(pts, torch.from_numpy(poses), torch.from_numpy(quats), K, synth.IMG_WIDTH, synth.IMG_HEIGHT, device=device,
+                             occlusion=method, occlusion_refresh_every=k)
+        m = model(1)
+        ps, qs = m.poses.data, m.quats.data
+        m._build_occlusion_rows(ps, qs)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            rows = m._build_occlusion_rows(ps, qs)
+        torch.cuda.synchronize(device)
+        refresh_ms = 1e3 * (time.perf_counter() - t0) / 3
+        bits = rows.view(torch.int32)
+        total_bits = 32.0 * bits.numel()
+        set_bits = float(sum(int(((bits >> b) & 1).sum().item()) for b in range(32)))
+        row = {"refresh_ms": refresh_ms, "hidden_fraction_of_pairs": 1.0 - set_bits / total_bits}
+        for k in (1, 10):
+            m = model(k)
+            n = 5 if k == 1 else steps
+            optimize_trajectory(m, n_opt_steps=1, lr_pose=0.1, lr_quat=0.02, rewards_th=1e9, vis_wps_dist=0.0)
+            m.refresh_occlusion()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            res = optimize_trajectory(m, n_opt_steps=n, lr_pose=0.1, lr_quat=0.02, rewards_th=1e9, vis_wps_dist=0.0)
+            torch.cuda.synchronize(device)
+            row[f"step_ms_refresh_every_{k}"] = 1e3 * (time.perf_counter() - t0) / n
+            row[f"loss_after_{n}_steps_refresh_every_{k}"] = res.losses[-1]
+        out[method] = row
+        del m
+    out["note"] = ("1 M points x 128 waypoints; refresh = cull of the cloud for every waypoint + one batched hull pass (hpr) or one z-buffer per "
+                   "waypoint (zbuffer) + the bit rows; a step = optimize_trajectory's (forward | reward + backward | step tail) with the rows "
+                   "multiplied into p")
+    return out
+
+
 def density_leg(device, steps=20, warmup=3):
     """The same 1 M points x 128 waypoints in ever smaller rooms (the path scaled with the room): the headline workload flags
     0.7 % of the (256-point slot, waypoint) pairs; an indoor cloud flags 10-20 %, and the kernels after pass 1 cost in proportion.
@@ -403,6 +451,7 @@ def main():
     ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dropin", choices=["on", "off"], default="on", help="time the reference's own loop over the drop-in classes (N = 1 only)")
     ap.add_argument("--density", choices=["on", "off"], default="on", help="step time versus flagged fraction: 1 M points in ever smaller rooms (N = 1 only)")
+    ap.add_argument("--occlusion", choices=["on", "off"], default="on", help="the occlusion-aware reward on the headline workload: ms per mask refresh and per step (N = 1 only)")
     ap.add_argument("--aux", choices=["on", "off"], default="on", help="the HBM-bound kernels around the hot path (ModelPose, flip, cull, masks, ingest) at 1 M and 16 M points")
     ap.add_argument("--moved", choices=["on", "off"], default="on", help="time the same step on the trajectory after 100 optimiser steps (N = 1 only)")
     ap.add_argument("--dump", default=None, help="write the last dense step's outputs (scalars, gradient rows, rewards) to this .npz "
@@ -825,6 +874,8 @@ def main():
                 line["density_sweep"] = density_leg(device)
             if args.aux == "on":
                 line["aux"] = aux_leg(device)
+            if args.occlusion == "on":
+                line["occlusion"] = occlusion_leg(device)
             line["hpr"] = hpr_leg(pts, device)
             line["cpu_baseline"] = cpu_baseline(pts, poses_all, quats_all, args.cpu_wps)
             line["reference_cpu_container"] = {

@@ -121,6 +121,14 @@ int tohip_occlusion_rows(int64_t n_points, const int32_t *inv_perm, const int32_
                          const int32_t *vis_idx, const int32_t *vis_off, const int32_t *all_visible, int64_t n_wps,
                          uint32_t *rows, void *stream);
 
+/* The same from per-point visibility VALUES instead of index lists: waypoint w's kept point j is hidden when
+ * visible[seg_off[w] + j] == 0 (seg_off: n_wps device int64) — the mask tohip_hidden_pts_removal_batched writes over the waypoints'
+ * kept points laid end to end, or tohip_zbuffer_visible_batched's (seg_off[w] = w * n).  A waypoint with fewer than min_points kept
+ * points keeps its row of ones (a hull needs 4).  Three launches for all waypoints. */
+int tohip_occlusion_rows_masked(int64_t n_points, const int32_t *inv_perm, const int32_t *kept_idx, const int32_t *kept_count,
+                                const float *visible, const int64_t *seg_off, int32_t min_points, int64_t n_wps, uint32_t *rows,
+                                void *stream);
+
 /* rewards[0..N) = sigmoid(lo_sum) in the CALLER'S point order (model.py:237); scalars[0] = mean(rewards),
  * scalars[1] = loss_vis = 1/(mean+eps) (model.py:246), scalars[2] = -loss_vis^2/N (d loss_vis / d reward_n).
  * One launch.  prefilled != 0: the caller promises rewards[0..N) == 0.5 on entry (tohip_traj_forward's rewards_half).
@@ -531,6 +539,15 @@ size_t tohip_render_workspace_bytes(int32_t width, int32_t height);
 int tohip_render_points(const float *verts, int64_t n_points, const float *K9_host, int32_t width, int32_t height,
                         float radius, float znear, float zfar, float background, float *image, int32_t *owner,
                         int32_t *owns_pixel, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The z-buffer visibility sets of n_clouds camera-frame clouds at once (tohip_render_points' owns_pixel for each): cloud w = the
+ * first count[w] (device int32) rows of verts + w * n_stride * 3 — the layout tohip_cull_waypoints writes — with its own z-buffer;
+ * visible[w * n_stride + j] = 1.0f when its point j owns a pixel, else 0.  Clouds go through in chunks of as many z-buffers as the
+ * workspace holds (tohip_zbuffer_batched_workspace_bytes: up to 2 GB): three launches per chunk. */
+size_t tohip_zbuffer_batched_workspace_bytes(int32_t width, int32_t height, int64_t n_clouds);
+int tohip_zbuffer_visible_batched(const float *verts, int64_t n_stride, const int32_t *count, int64_t n_clouds, const float *K9_host,
+                                  int32_t width, int32_t height, float radius, float znear, float zfar, float *visible,
+                                  void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- optional per-kernel timing (bench.py's roofline leg) -----------------------------------------
  * When enabled, every launch of the big kernels is bracketed by hipEventRecord on its own stream.

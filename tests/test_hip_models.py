@@ -284,6 +284,47 @@ def test_occlusion_aware_traj_model(dev, method):
     assert torch.equal(md.rewards, m.rewards)
 
 
+def test_occlusion_refresh_policy(dev):
+    """ModelTraj(occlusion_refresh_every=k): the masks are rebuilt on every k-th forward and reused in between (they are piecewise
+    constant in the poses and carry no gradient).  k = 1 is the model without the policy, bit for bit; k = 3 holds the same rows
+    object for three forwards; refresh_occlusion() forces a rebuild; the launch-only optimiser follows the same rule."""
+    from trajectory_optimization_amd.model import ModelTraj
+    from trajectory_optimization_amd.optimizer import optimize_trajectory
+    pts = torch.from_numpy(synth.make_cloud(80_000, seed=33))
+    poses, quats = synth.make_path(6, optical=True, jitter_seed=33)
+
+    def model(k):
+        return ModelTraj(pts, torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(K), IW, IH, device=dev, occlusion="zbuffer",
+                         occlusion_refresh_every=k)
+
+    def loop(m, n):
+        opt = torch.optim.Adam([{"params": [m.poses], "lr": 0.1}, {"params": [m.quats], "lr": 0.02}])
+        ids, losses = [], []
+        for _ in range(n):
+            opt.zero_grad()
+            loss = m(vis_wps_dist=0.0)
+            loss.backward()
+            opt.step()
+            ids.append(m._occ_cache[0].data_ptr())
+            losses.append(loss.item())
+        return ids, losses
+    m1 = model(1)
+    ids1, l1 = loop(m1, 6)
+    m3 = model(3)
+    ids3, l3 = loop(m3, 7)
+    assert ids3[0] == ids3[1] == ids3[2] and ids3[3] == ids3[4] == ids3[5] and ids3[2] != ids3[3] and ids3[5] != ids3[6]
+    assert l3[0] == l1[0]                       # the first forward builds the same masks
+    assert abs(l3[5] - l1[5]) < 0.05 * l1[5]    # and reusing them for two more steps changes little (0.1 m per step)
+    m3.refresh_occlusion()
+    m3(vis_wps_dist=0.0)
+    assert m3._occ_cache[2] == 1 and m3._occ_cache[0].data_ptr() != ids3[6]
+    # the launch-only loop: 1 step with k = 1 == 1 step with k = 3 (same first masks); 4 steps differ only through the masks' age
+    a, b = model(1), model(3)
+    ra = optimize_trajectory(a, n_opt_steps=1, lr_pose=0.1, lr_quat=0.02, rewards_th=1e9, vis_wps_dist=0.0)
+    rb = optimize_trajectory(b, n_opt_steps=1, lr_pose=0.1, lr_quat=0.02, rewards_th=1e9, vis_wps_dist=0.0)
+    assert ra.losses == rb.losses and torch.equal(a.poses.data, b.poses.data)
+
+
 def test_sample_script_and_npz_format(dev, tmp_path):
     """The ROS-free twin of trajectory_optimization_sample.py on files in the reference's .npz sample format
     ((3,N) point layout included): runs, improves visibility, writes normalised quaternions."""

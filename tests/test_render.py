@@ -51,3 +51,45 @@ def test_render_pc_image_api_full_size():
     # identity extrinsics == none
     img2 = render_pc_image(v, K, height, width, R=torch.eye(3), T=torch.zeros(3), device=dev)
     assert torch.equal(img, img2)
+
+
+@pytest.mark.gpu
+def test_batched_zbuffer_equals_one_cloud_at_a_time():
+    """tohip_zbuffer_visible_batched (all waypoints' z-buffers in the same launches: discs of near points rasterised by a whole wave,
+    bids only where a plain load says they can win) marks exactly the points tohip_render_points' z-buffer lets own a pixel, cloud
+    by cloud — ragged counts, an empty cloud, near points with discs of hundreds of pixels, the real image size."""
+    import ctypes
+    from trajectory_optimization_amd import _lib, ops
+    from trajectory_optimization_amd._lib import check, ptr, stream_ptr
+    from trajectory_optimization_amd.tools import load_intrinsics
+    dev = torch.device("cuda:0")
+    K, width, height = load_intrinsics(dev)
+    counts = [60_000, 0, 17, 25_001, 3]
+    n_stride = max(counts)
+    verts = torch.zeros((len(counts), n_stride, 3), device=dev)
+    rng = np.random.default_rng(4)
+    for w, c in enumerate(counts):
+        if c:
+            v = (rng.random((c, 3)) * np.array([8.0, 8.0, 14.0]) - np.array([4.0, 4.0, -0.6])).astype(np.float32)   # depths 0.6 .. 14.6 m
+            verts[w, :c] = torch.from_numpy(v).to(dev)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    wsb = L.tohip_zbuffer_batched_workspace_bytes(int(width), int(height), len(counts))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    vis = torch.empty((len(counts), n_stride), device=dev)
+    K9 = (ctypes.c_float * 9)(*K.cpu().reshape(9).tolist())
+    check(L.tohip_zbuffer_visible_batched(ptr(verts), n_stride, ptr(cnt), len(counts), K9, int(width), int(height), 0.03, 1.0, 15.0, ptr(vis), ptr(ws),
+                                          wsb, stream_ptr()), "tohip_zbuffer_visible_batched")
+    # with room for two z-buffers only: three chunks, same result
+    vis2 = torch.empty_like(vis)
+    small = 2 * int(width) * int(height) * 8
+    check(L.tohip_zbuffer_visible_batched(ptr(verts), n_stride, ptr(cnt), len(counts), K9, int(width), int(height), 0.03, 1.0, 15.0, ptr(vis2), ptr(ws),
+                                          small, stream_ptr()), "tohip_zbuffer_visible_batched")
+    assert torch.equal(vis, vis2)
+    for w, c in enumerate(counts):
+        assert float(vis[w, c:].abs().sum()) == 0.0
+        if c == 0:
+            continue
+        owns = ops.render_points(verts[w, :c].contiguous(), K, height, width, znear=1.0, zfar=15.0)[2]
+        assert torch.equal(vis[w, :c] != 0, owns), w
+        assert 0 < int(owns.sum()) <= c

@@ -96,6 +96,10 @@ SIGNATURES = {
     "tohip_traj_opt_step": (ctypes.c_int, [ctypes.POINTER(TrajOpt), c_i32, c_vp]),
     "tohip_inverse_permutation": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "tohip_occlusion_rows": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "tohip_occlusion_rows_masked": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
+    "tohip_zbuffer_batched_workspace_bytes": (c_sz, [c_i32, c_i32, c_i64]),
+    "tohip_zbuffer_visible_batched": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, ctypes.POINTER(c_f), c_i32, c_i32, c_f, c_f, c_f, c_vp, c_vp,
+                                                      c_sz, c_vp]),
     "tohip_occlusion_row": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tohip_traj_reward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_f, ctypes.c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_traj_backward": (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig), ctypes.c_int, c_vp,

@@ -1790,6 +1790,45 @@ extern "C" int tohip_occlusion_rows(int64_t n, const int32_t* inv_perm, const in
     return TOHIP_OK;
 }
 
+// rows from per-point visibility values instead of index lists: waypoint w's kept point j (kept_idx[w][j], j < kept_count[w]) is
+// hidden when visible[seg_off[w] + j] == 0 — the mask a batched hull pass writes over the waypoints' kept points laid end to end,
+// or the batched z-buffer's (seg_off[w] = w x n).  A waypoint with fewer than min_points kept points keeps its row of ones.
+__global__ void k_occ_rows_masked(const int* __restrict__ inv, const int32_t* __restrict__ kept_idx, int64_t n,
+                                  const int32_t* __restrict__ kept_count, const float* __restrict__ visible,
+                                  const int64_t* __restrict__ seg_off, int min_points, uint32_t* __restrict__ rows, int64_t roww) {
+    const int w = blockIdx.y;
+    const int m = kept_count[w];
+    if (m < min_points) return;
+    const int32_t* kk = kept_idx + (int64_t)w * n;
+    const float* vis = visible + seg_off[w];
+    uint32_t* row = rows + (int64_t)w * roww;
+    const int stride = gridDim.x * blockDim.x;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        if (vis[j] == 0.f) {
+            const int s = inv[kk[j]];
+            atomicAnd(&row[s >> 5], ~(1u << (s & 31)));
+        }
+    }
+}
+
+extern "C" int tohip_occlusion_rows_masked(int64_t n, const int32_t* inv_perm, const int32_t* kept_idx, const int32_t* kept_count,
+                                           const float* visible, const int64_t* seg_off, int32_t min_points, int64_t n_wps, uint32_t* rows,
+                                           void* stream_) {
+    if (!inv_perm || !kept_idx || !kept_count || !visible || !seg_off || !rows || n <= 0 || n_wps <= 0 || n_wps > 65535) return TOHIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    const int64_t npad = tohip_padded_points(n);
+    const int64_t roww = npad / 32;
+    hipError_t e = hipMemsetAsync(rows, 0xff, (size_t)roww * (size_t)n_wps * sizeof(uint32_t), st);
+    if (e != hipSuccess) return (int)e;
+    int nb = (int)((n + 255) / 256);
+    if (nb > 256) nb = 256;
+    k_occ_rows_masked<<<dim3((unsigned)nb, (unsigned)n_wps), 256, 0, st>>>(inv_perm, kept_idx, n, kept_count, visible, seg_off, min_points, rows, roww);
+    TO_HIP_CHECK_LAUNCH();
+    k_occ_rows_pad<<<(int)((n_wps + 63) / 64), 64, 0, st>>>(n, npad, rows, roww, (int)n_wps);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
 extern "C" int tohip_inverse_permutation(const void* packed, int64_t n, int32_t* inv, void* stream_) {
     if (!packed || !inv || n <= 0) return TOHIP_EINVAL;
     const CloudView cv = cloud_view(packed, n);

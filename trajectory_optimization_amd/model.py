@@ -780,7 +780,8 @@ class ModelTraj(nn.Module):
                  min_dist=1.0, max_dist=5.0,
                  smoothness_weight=14.0, traj_length_weight=0.02,
                  device=torch.device('cuda'),
-                 *, rig=None, shard=None, dense=False, occlusion=None, occlusion_limits=(1.0, 15.0), n_points_global=None):
+                 *, rig=None, shard=None, dense=False, occlusion=None, occlusion_limits=(1.0, 15.0), occlusion_refresh_every=1,
+                 n_points_global=None):
         super().__init__()
         assert wps_poses.dim() == wps_quats.dim()
         assert wps_poses.size()[1] == 3
@@ -834,6 +835,12 @@ class ModelTraj(nn.Module):
         if occlusion not in (None, "hpr", "zbuffer"):
             raise ValueError("occlusion must be None, 'hpr' or 'zbuffer'")
         self._occlusion, self._occlusion_limits = occlusion, occlusion_limits
+        # The occlusion masks are piecewise constant in the poses (a point is hidden from a waypoint or it is not) and carry no
+        # gradient; building them — a hard cull and a convex hull (or a z-buffer) per waypoint — costs hundreds of plain steps.
+        # occlusion_refresh_every = k: they are rebuilt on every k-th forward of the model (k = 1: every forward, the bits of a
+        # model without the policy) and reused in between; refresh_occlusion() forces a rebuild at the next forward.
+        self.occlusion_refresh_every = max(1, int(occlusion_refresh_every))
+        self._occ_cache = None   # (rows, shape key, forwards since the rebuild)
         self._ws_cache = {}
         self._plan_obj, self._plan_key = None, None
         self._wps_step_cache = {}
@@ -846,9 +853,24 @@ class ModelTraj(nn.Module):
         for p in (self.poses, self.quats):
             tag_parameter(p)   # torch.optim.Adam.step() may update them with one launch (optimizer.accelerate_torch_adam)
 
+    def refresh_occlusion(self):
+        """The next forward rebuilds the occlusion masks whatever occlusion_refresh_every says."""
+        self._occ_cache = None
+
     def _occlusion_rows(self, ps, qs):
         """Occlusion bit rows of the given body waypoints, one row per virtual waypoint v = w*C + c (with a rig: the cameras'
-        own poses t_v = t_w + R(q_w) l_c, q_v = q_w/|q_w| (x) q_c — the composition the kernels apply)."""
+        own poses t_v = t_w + R(q_w) l_c, q_v = q_w/|q_w| (x) q_c — the composition the kernels apply); rebuilt on every
+        occlusion_refresh_every-th call, reused in between."""
+        key = (tuple(ps.shape), tuple(qs.shape))
+        c = self._occ_cache
+        if c is not None and c[1] == key and c[2] < self.occlusion_refresh_every:
+            self._occ_cache = (c[0], key, c[2] + 1)
+            return c[0]
+        rows = self._build_occlusion_rows(ps, qs)
+        self._occ_cache = (rows, key, 1)
+        return rows
+
+    def _build_occlusion_rows(self, ps, qs):
         if self._rig is not None:
             qn = qs / qs.norm(dim=1, keepdim=True).clamp_min(1e-12)
             qc, lc = self._rig.q, self._rig.t

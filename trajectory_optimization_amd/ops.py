@@ -399,73 +399,117 @@ def occlusion_bits(cloud, points, poses, quats, cam, min_dist, max_dist, method=
     return rows
 
 
+_SCRATCH = {}
+
+
+def _scratch(device, tag, nbytes):
+    """A grow-only byte buffer per (device, purpose): the occlusion rows are rebuilt again and again over buffers of GBs whose
+    sizes vary a little from call to call — allocating them anew every time cost more than the kernels (12 of 34 ms per rebuild at
+    1 M points x 128 waypoints).  release_scratch() gives the memory back."""
+    key = (str(device), tag)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nbytes:
+        _SCRATCH.pop(key, None)
+        t = _SCRATCH[key] = torch.empty(int(nbytes * 1.1) + 256, dtype=torch.uint8, device=device)
+    return t
+
+
+def release_scratch():
+    _SCRATCH.clear()
+
+
 def _occlusion_rows_chunk(cloud, points, poses, quats, cam, min_dist, max_dist, method, rows):
     L = _lib.lib()
     dev = cloud.device
     W = poses.shape[0]
     n = cloud.n
-    # transform -> cull -> gather for all waypoints of the chunk in three launches
-    kept_all, pts_all, counts, kcnt_all = cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True)
-    kept_idx = [kept_all[w, :counts[w]] for w in range(W)]
-    kept_pts = [pts_all[w, :counts[w]] for w in range(W)]
-    vis = [None] * W
+    # transform -> cull -> gather for all waypoints of the chunk in three launches (one host read: the counts size the hull pass)
+    kept_all, pts_all, counts, kcnt_all = cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True, scratch=True)
     if method == "zbuffer":
-        K33 = torch.tensor([cam.c.K[i] for i in range(9)]).reshape(3, 3)
-        for w in range(W):
-            if kept_idx[w].numel() >= 4:
-                owns = render_points(kept_pts[w], K33, cam.c.img_height, cam.c.img_width, znear=min_dist, zfar=max_dist)[2]
-                vis[w] = torch.nonzero(owns).squeeze(1).to(torch.int32)
+        # every waypoint's z-buffer in the same three launches (chunks of as many z-buffers as 2 GB hold); visible[w, j] = 1 when
+        # kept point j of waypoint w owns a pixel
+        K9 = (ctypes.c_float * 9)(*[cam.c.K[i] for i in range(9)])
+        width, height = int(cam.c.img_width), int(cam.c.img_height)
+        wsb = L.tohip_zbuffer_batched_workspace_bytes(width, height, W)
+        zws = _scratch(dev, "zbuf", wsb)
+        visible = _scratch(dev, "zvis", 4 * W * max(n, 1))[:4 * W * max(n, 1)].view(torch.float32)
+        seg_off = torch.arange(W, dtype=torch.int64, device=dev) * max(n, 1)
+        with torch.cuda.device(dev):
+            check(L.tohip_zbuffer_visible_batched(ptr(pts_all), max(n, 1), ptr(kcnt_all), W, K9, width, height, 0.03, float(min_dist), float(max_dist),
+                                                  ptr(visible), ptr(zws), wsb, stream_ptr()), "tohip_zbuffer_visible_batched")
     else:
-        # one batched hull pass over the waypoints' culled clouds (chunked to bound the workspace)
+        # one batched hull pass over the waypoints' culled clouds laid end to end (several when they exceed HPR_BATCH_POINTS)
+        offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        tot = int(offs[-1])
+        visible = _scratch(dev, "hvis", 4 * max(tot, 1))[:4 * max(tot, 1)].view(torch.float32)
+        cat = _scratch(dev, "hcat", 12 * max(tot, 1))[:12 * max(tot, 1)].view(torch.float32).view(-1, 3)
+        for w in range(W):   # (device-to-device copies of each waypoint's kept rows: no host round trip)
+            if counts[w]:
+                cat[int(offs[w]):int(offs[w + 1])].copy_(pts_all[w, :counts[w]])
         w0 = 0
         while w0 < W:
-            w1, tot = w0, 0
-            while w1 < W and (w1 == w0 or tot + kept_idx[w1].numel() <= HPR_BATCH_POINTS):
-                tot += kept_idx[w1].numel()
+            w1 = w0 + 1
+            while w1 < W and offs[w1 + 1] - offs[w0] <= HPR_BATCH_POINTS:
                 w1 += 1
-            offs = [0]
-            for w in range(w0, w1):
-                offs.append(offs[-1] + kept_idx[w].numel())
-            idx, voff, _, status = hidden_pts_removal_batched(torch.cat(kept_pts[w0:w1]), offs, 2)
-            if bool((status == 3).any()):
-                raise ValueError("Points cannot contain NaN")  # scipy's error in the reference's pipeline
-            if bool((status == 2).any()):
-                raise _lib.HipError("occlusion_bits: a waypoint's culled cloud is flat (no 3-D hull; Qhull raises QH6154)")
-            for j, w in enumerate(range(w0, w1)):
-                if kept_idx[w].numel() >= 4:
-                    vis[w] = (idx[int(voff[j]):int(voff[j + 1])] - offs[j]).contiguous()
+            lo, hi = int(offs[w0]), int(offs[w1])
+            if hi > lo:
+                status = _hpr_batched_mask(cat[lo:hi], [int(o) - lo for o in offs[w0:w1 + 1]], visible[lo:hi])
+                if bool((status == 3).any()):
+                    raise ValueError("Points cannot contain NaN")  # scipy's error in the reference's pipeline
+                if bool(((status == 2) & (kcnt_all[w0:w1] >= 4)).any()):
+                    raise _lib.HipError("occlusion_bits: a waypoint's culled cloud is flat (no 3-D hull; Qhull raises QH6154)")
             w0 = w1
-    # all rows in four launches: the visible positions of every waypoint end to end, with their offsets
-    all_visible = torch.tensor([1 if vis[w] is None else 0 for w in range(W)], dtype=torch.int32, device=dev)  # < 4 kept points
-    lens = [0 if vis[w] is None else int(vis[w].numel()) for w in range(W)]
-    vis_off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=dev)
-    parts = [vis[w] for w in range(W) if vis[w] is not None and vis[w].numel() > 0]
-    vis_cat = torch.cat(parts).to(torch.int32).contiguous() if parts else torch.zeros(1, dtype=torch.int32, device=dev)
+        seg_off = torch.from_numpy(offs[:W].copy()).to(dev)
     for w0 in range(0, W, 65535):
         w1 = min(W, w0 + 65535)
         with torch.cuda.device(dev):
-            check(L.tohip_occlusion_rows(n, ptr(cloud.inv_perm), ptr(kept_all[w0:w1]), ptr(kcnt_all[w0:w1]), ptr(vis_cat),
-                                         ptr(vis_off[w0:w1 + 1]), ptr(all_visible[w0:w1]), w1 - w0, ptr(rows[w0:w1]), stream_ptr()),
-                  "tohip_occlusion_rows")
+            check(L.tohip_occlusion_rows_masked(n, ptr(cloud.inv_perm), ptr(kept_all[w0:w1]), ptr(kcnt_all[w0:w1]), ptr(visible),
+                                                ptr(seg_off[w0:w1]), 4, w1 - w0, ptr(rows[w0:w1]), stream_ptr()), "tohip_occlusion_rows_masked")
 
 
-def cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True):
+def _hpr_batched_mask(points, seg_offsets, mask_out):
+    """tohip_hidden_pts_removal_batched for its mask only (mask_out: n_total f32, 1 = visible), over cached scratch -> status (B,) int32."""
+    L = _lib.lib()
+    n, dev = points.shape[0], points.device
+    B = len(seg_offsets) - 1
+    c_offs = (ctypes.c_int64 * (B + 1))(*[int(o) for o in seg_offsets])
+    idx = _scratch(dev, "hidx", 4 * max(n, 1))[:4 * max(n, 1)].view(torch.int32)
+    voff = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    wsb = L.tohip_hpr_batched_workspace_bytes(n, B)
+    for _ in range(4):
+        ws = _scratch(dev, "hull", wsb)
+        with torch.cuda.device(dev):
+            rc = L.tohip_hidden_pts_removal_batched(ptr(points), c_offs, B, 2.0, ptr(idx), ptr(voff), ptr(mask_out), ptr(status), ptr(ws), ws.numel(),
+                                                    stream_ptr())
+        if rc != _lib.ENOSPC:
+            check(rc, "tohip_hidden_pts_removal_batched")
+            return status
+        wsb *= 4   # most of a cloud's points on its hull: every extra byte goes to faces
+    raise _lib.HipError("hull workspace: still out of face capacity at 64x the recommended size")
+
+
+def cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True, scratch=False):
     """Exact transform + hard frustum cull of `points` (N,3) for W poses at once (tohip_cull_waypoints).
     -> (kept_idx (W,N) int32, kept_pts (W,N,3) f32 camera frame, counts list[int], counts on the device (W,) int32): pose
     w's kept points are the first counts[w] rows of kept_idx[w] / kept_pts[w], in input order.  One host synchronisation
-    (the counts)."""
+    (the counts).  scratch: the two worst-case sized outputs live in cached buffers (valid until the next such call)."""
     _require_cuda(points, "points")
     pts = points.detach().to(torch.float32).contiguous()
     dev, n, W = pts.device, pts.shape[0], poses.shape[0]
     p_in, q_in = poses.detach().to(torch.float32).contiguous(), quats.detach().to(torch.float32).contiguous()
-    kept_all = torch.empty((W, max(n, 1)), dtype=torch.int32, device=dev)
-    pts_all = torch.empty((W, max(n, 1), 3), dtype=torch.float32, device=dev)
+    if scratch:
+        kept_all = _scratch(dev, "kept", 4 * W * max(n, 1))[:4 * W * max(n, 1)].view(torch.int32).view(W, max(n, 1))
+        pts_all = _scratch(dev, "kpts", 12 * W * max(n, 1))[:12 * W * max(n, 1)].view(torch.float32).view(W, max(n, 1), 3)
+    else:
+        kept_all = torch.empty((W, max(n, 1)), dtype=torch.int32, device=dev)
+        pts_all = torch.empty((W, max(n, 1), 3), dtype=torch.float32, device=dev)
     kcnt_all = torch.zeros(W, dtype=torch.int32, device=dev)
     L = _lib.lib()
     for w0 in range(0, W, 65535):  # grid.y limit
         w1 = min(W, w0 + 65535)
         wsb = L.tohip_cull_waypoints_workspace_bytes(n, w1 - w0)
-        fws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        fws = _scratch(dev, "cullws", wsb) if scratch else torch.empty(wsb, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             check(L.tohip_cull_waypoints(ptr(pts), n, ptr(p_in[w0:w1]), ptr(q_in[w0:w1]), w1 - w0, int(bool(normalize)), cam.ref(),
                                          float(min_dist), float(max_dist), ptr(kept_all[w0:w1]), ptr(pts_all[w0:w1]),
