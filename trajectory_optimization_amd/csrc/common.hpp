@@ -276,6 +276,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 pk_splat(float s) { return (f2)(s); }
+__device__ __forceinline__ f2 pk_splat(f2 v) { return v; }   // (a record whose fields are register pairs already: WayRecPk)
 __device__ __forceinline__ f2 pk_rcp(f2 x) { return f2{to_rcp(x.x), to_rcp(x.y)}; }
 
 __device__ __forceinline__ f2 to_exp_pk(f2 x) {
@@ -405,6 +406,41 @@ __device__ __forceinline__ float wave_max63_nn(float f) {
     v = max(v, TO_DPP_I(v, v, 0x142, 0xA, false));
     v = max(v, TO_DPP_I(v, v, 0x143, 0xC, false));
     return __builtin_bit_cast(float, v);
+}
+
+// SIXTEEN sums over the wave at once (a transposed reduction): at each of four in-row steps the two lanes of a pair split the
+// values still alive between them — one keeps the even ones and takes the partner's, the other the odd ones — so the number of
+// live values halves while the lanes summed double: 8 + 4 + 2 + 1 exchanges of 3 instructions instead of 16 x 6 for sixteen
+// separate trees.  Afterwards lane l holds the row's total of value  bit3(l) + 2 bit2(l) + 4 bit1(l) + 8 bit0(l)  (the partners
+// are the DPP network's: row_mirror flips all four lane bits, row_half_mirror the low three, quad_perm [2,3,0,1] bit 1, [1,0,3,2]
+// bit 0; the selector of a step is a bit its exchange flips and the later ones do not), and two cross-row butterflies add the
+// four rows.  Fixed order: deterministic.  wave_sum16_index(lane) names the value a lane ends up with.
+__device__ __forceinline__ int wave_sum16_index(int lane) {
+    return ((lane >> 3) & 1) | (((lane >> 2) & 1) << 1) | (((lane >> 1) & 1) << 2) | ((lane & 1) << 3);
+}
+__device__ __forceinline__ float wave_sum16_transposed(const float (&v)[16], int lane) {
+    float a[8], b[4], c[2];
+    const bool s3 = (lane >> 3) & 1, s2 = (lane >> 2) & 1, s1 = (lane >> 1) & 1, s0 = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float keep = s3 ? v[2 * i + 1] : v[2 * i], give = s3 ? v[2 * i] : v[2 * i + 1];
+        a[i] = keep + TO_DPP_F(0.f, give, 0x140, 0xF, true);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = s2 ? a[2 * i + 1] : a[2 * i], give = s2 ? a[2 * i] : a[2 * i + 1];
+        b[i] = keep + TO_DPP_F(0.f, give, 0x141, 0xF, true);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = s1 ? b[2 * i + 1] : b[2 * i], give = s1 ? b[2 * i] : b[2 * i + 1];
+        c[i] = keep + TO_DPP_F(0.f, give, 0x4E, 0xF, true);
+    }
+    const float keep = s0 ? c[1] : c[0], give = s0 ? c[0] : c[1];
+    float r = keep + TO_DPP_F(0.f, give, 0xB1, 0xF, true);
+    r += __shfl_xor(r, 16);
+    r += __shfl_xor(r, 32);
+    return r;
 }
 
 // block-wide double sum (fixed order -> deterministic), valid in every thread: a butterfly inside each wave, then the
@@ -559,6 +595,23 @@ __device__ __forceinline__ f2 vis_p_pk(const Rec& r, const EvalK& k, f2 x, f2 y,
 template <class Rec>
 __device__ __forceinline__ f2 vis_p_pk(const Rec& r, const EvalK& k, f2 x, f2 y, f2 z) {
     return vis_p_pk(r, k, x, y, z, pk_splat(k.eps), pk_splat(k.l2e_eps), pk_splat(k.scd));
+}
+
+// Line 0 of a record with every field in BOTH halves of a vector register pair.  A packed instruction takes ONE scalar operand;
+// the gradient's chains use two fields of the record in one instruction all the time (f0 - q f2, scd y + sp, ...), and the
+// compiler then moves a scalar into a register pair on the spot, every time (87 v_mov_b32 per pair in the pair kernel).  A wave
+// that evaluates 256 points against one waypoint fills these fifteen pairs once.
+struct WayRecPk {
+    f2 t[3], f0[3], f1[3], f2[3], sp[3];
+};
+__device__ __forceinline__ WayRecPk wayrec_pk(const WayRec& r) {
+    WayRecPk o;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        o.t[i] = pk_splat(r.t[i]); o.f0[i] = pk_splat(r.f0[i]); o.f1[i] = pk_splat(r.f1[i]); o.f2[i] = pk_splat(r.f2[i]); o.sp[i] = pk_splat(r.sp[i]);
+        asm volatile("" : "+v"(o.t[i]), "+v"(o.f0[i]), "+v"(o.f1[i]), "+v"(o.f2[i]), "+v"(o.sp[i]));
+    }
+    return o;
 }
 
 // d p / d y (y = x - t, world-aligned) of the same evaluation; zero where p underflowed or the pair is occluded.

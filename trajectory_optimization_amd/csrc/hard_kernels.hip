@@ -588,6 +588,19 @@ __global__ void k_selftest_wave_reduce(const float* __restrict__ in, int k, floa
         const bool ok = wave_min63_nn(a) == wave_min63(a) && wave_max63_nn(a) == wave_max63(a);
         if (lane == 63) { osum[c] = ok ? s : __builtin_nanf(""); omin[c] = ok ? mn : __builtin_nanf(""); omax[c] = mx; }
     }
+    // the transposed reduction of sixteen columns at a time (the pair kernel's): each column's total must land in the lane
+    // wave_sum16_index names, and agree with the single-value tree to rounding — a mismatch poisons the column's sum
+    for (int c0 = 0; c0 < k; c0 += 16) {
+        float v16[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v16[j] = c0 + j < k ? in[lane * k + c0 + j] : 0.f;
+        const float tot = wave_sum16_transposed(v16, lane);
+        const int col = c0 + wave_sum16_index(lane);
+        if (lane < 16 && col < k) {
+            const float ref = osum[col];
+            if (!(fabsf(tot - ref) <= 1e-4f * (1.0f + fabsf(ref)))) osum[col] = __builtin_nanf("");
+        }
+    }
 }
 
 extern "C" int tohip_selftest_wave_reduce(const float* in, int32_t k, float* osum, float* omin, float* omax, void* stream_) {

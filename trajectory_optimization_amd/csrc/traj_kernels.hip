@@ -1079,17 +1079,18 @@ __device__ __forceinline__ void pair_sums(const SparseArgs& a, int slot, int v, 
     f2 acc[TO_BWD_NSUM];
 #pragma unroll
     for (int j = 0; j < TO_BWD_NSUM; ++j) acc[j] = pk_splat(0.f);
+    const WayRecPk rp = wayrec_pk(r);   // the record's first line in register pairs (common.hpp)
     bool any_act = false;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         VisGrad2 vg;
-        const f2 p = vis_p_pk_grad(r, k, f2{x[2 * h], x[2 * h + 1]}, f2{y[2 * h], y[2 * h + 1]}, f2{z[2 * h], z[2 * h + 1]}, vg) *
+        const f2 p = vis_p_pk_grad(rp, k, f2{x[2 * h], x[2 * h + 1]}, f2{y[2 * h], y[2 * h + 1]}, f2{z[2 * h], z[2 * h + 1]}, vg) *
                      f2{om[2 * h], om[2 * h + 1]};
         const f2 ph = (p - pk_splat(av)) * pk_splat(invM);
         const bool act0 = (ph.x >= 0.5f) && (ph.x <= k.clip_hi), act1 = (ph.y >= 0.5f) && (ph.y <= k.clip_hi);
         if (act0 | act1) {
             f2 g[3];
-            dvis_dy_pk(r, k, p, vg, g);
+            dvis_dy_pk(rp, k, p, vg, g);
             const f2 G = f2{gn[2 * h], gn[2 * h + 1]} * pk_rcp(ph * (pk_splat(1.0f) - ph));
             f2 wgt = G * pk_splat(invM);
             wgt = f2{act0 ? wgt.x : 0.f, act1 ? wgt.y : 0.f};
@@ -1103,20 +1104,15 @@ __device__ __forceinline__ void pair_sums(const SparseArgs& a, int slot, int v, 
             any_act = true;
         }
     }
-    float sum[TO_BWD_NSUM];
+    // the pair's 14 sums over the wave in one transposed reduction (common.hpp): lane l ends up with the sum wave_sum16_index(l),
+    // and the first sixteen lanes store the pair's row (columns 14 and 15 are zero: the finish kernel adds all 16 of a row)
+    float sum[16];
 #pragma unroll
     for (int j = 0; j < TO_BWD_NSUM; ++j) sum[j] = acc[j].x + acc[j].y;
-    if (__any(any_act)) {
-#pragma unroll
-        for (int j = 0; j < TO_BWD_NSUM; ++j) sum[j] = wave_sum63(sum[j]);
-    }
-    if (lane == 63) {
-        float4* dst = reinterpret_cast<float4*>(a.bpart + ((int64_t)v * a.nslots + slot) * 16);
-        dst[0] = make_float4(sum[0], sum[1], sum[2], sum[3]);
-        dst[1] = make_float4(sum[4], sum[5], sum[6], sum[7]);
-        dst[2] = make_float4(sum[8], sum[9], sum[10], sum[11]);
-        dst[3] = make_float4(sum[12], sum[13], 0.f, 0.f);   // the finish kernel adds all 16 columns of a row
-    }
+    sum[14] = sum[15] = 0.f;
+    float total = 0.f;
+    if (__any(any_act)) total = wave_sum16_transposed(sum, lane);
+    if (lane < 16) a.bpart[((int64_t)v * a.nslots + slot) * 16 + wave_sum16_index(lane)] = total;
 }
 
 // block b of nb (TO_SP_THREADS threads each): wave gw = 16 b + wave of 16 nb takes the pairs gw, gw + 16 nb, ...
