@@ -9,8 +9,17 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless its name ends in _host;
- *   - the caller allocates every input, output and workspace buffer; the library keeps no state
- *     between calls, allocates nothing and frees nothing;
+ *   - the caller allocates every input, output and workspace buffer, and no DEVICE memory is ever allocated or freed by the
+ *     library.  Nothing a call computes is kept for a later call.  The two things the library does keep, both HOST-side
+ *     scratch that never changes a result:
+ *       * the hull builds (tohip_convex_hull_vertices, tohip_hidden_pts_removal and its _batched form: the calls that read
+ *         counters back and therefore synchronise): two
+ *         pinned read-back buffers (~2 KB each) and two events per (calling thread, device), created at the first such call
+ *         of the thread on that device and released when the thread ends;
+ *       * tohip_profile_enable(1): a pool of timing events per process, grown on demand while profiling is on, released by
+ *         tohip_profile_enable(0) after tohip_profile_read;
+ *     and the process-wide switches tohip_profile_enable / tohip_profile_clock themselves.  Everything else is stateless:
+ *     two threads may call any entry point concurrently on different streams with different workspaces;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are only enqueued,
  *     no entry point synchronises unless its comment says so;
  *   - return value: 0 = ok, >0 = a hipError_t from a launch, <0 = an argument error (TOHIP_E*);

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Run ON THE GPU BOX (gpurun): rocprofv3 summaries of the bench command, written under gpurun_out/prof_<tag>/.
 #   kernel-trace + stats for the dense and the culled mode, then counter passes of the dense mode in their own runs
-#   (FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ_* in a third), as MI355X_MICROARCH.md prescribes.
+#   (FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ_* in a third), as MI355X_MICROARCH.md prescribes; the whole optimisation
+#   loop (tools/prof_opt.py) and the streaming kernels around the path at 16 M points (tools/prof_aux.py) the same way.
 # Afterwards, here:  python tools/summarize_profiles.py gpurun_out/prof_<tag> rNN   -> profiles/rNN_*
 set -euo pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
@@ -17,4 +18,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_sq" -o pmc -- python3 "$root/bench.py" $common --mode dense > "$out/pmc_sq.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/hpr" -o hpr -- python3 "$root/tools/hpr_batched_once.py" 3 > "$out/hpr.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/hpr1m" -o hpr1m -- python3 "$root/tools/hpr_once.py" 1000000 3 > "$out/hpr1m.log" 2>&1
-find "$out" -name "*.csv" | head -40
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/opt" -o opt -- python3 "$root/tools/prof_opt.py" --steps 120 > "$out/opt.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/aux" -o aux -- python3 "$root/tools/prof_aux.py" 16000000 > "$out/aux.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/aux_fetch" -o pmc -- python3 "$root/tools/prof_aux.py" 16000000 > "$out/aux_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/aux_write" -o pmc -- python3 "$root/tools/prof_aux.py" 16000000 > "$out/aux_write.log" 2>&1
+find "$out" -name "*.csv" | head -60

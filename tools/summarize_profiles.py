@@ -2,6 +2,7 @@
 """Turn the rocprofv3 output of tools/collect_profiles.sh into the committed summaries:
     python tools/summarize_profiles.py gpurun_out/prof_r02 r02
  -> profiles/rNN_bench_{dense,culled}_kernel_stats.csv, profiles/rNN_hpr_{batched,1m}_kernel_stats.csv (copies) and
+    profiles/rNN_optimize_kernel_stats.csv (tools/prof_opt.py), profiles/rNN_aux_kernel_stats.csv + rNN_aux_pmc.json (tools/prof_aux.py) and
     profiles/rNN_bench_dense_pmc.json: per kernel, HBM bytes per launch = 2 x FETCH_SIZE (gfx950 counts a wide coalesced read
     at half its bytes, MI355X_MICROARCH.md) + WRITE_SIZE, both reported in KB, and the VALU busy fraction
     SQ_ACTIVE_INST_VALU / (32 x GRBM_GUI_ACTIVE)."""
@@ -32,6 +33,29 @@ def short(name):
     return name.split("(")[0]
 
 
+def aux_pmc(src, path):
+    """tools/prof_aux.py at 16 M points under FETCH_SIZE and WRITE_SIZE (two runs): HBM bytes per launch of every streaming kernel
+    around the path, with the corrected read bytes (x2, see the module docstring) and the rate over the launch's duration."""
+    out = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace -- python3 tools/prof_aux.py 16000000  (two runs)",
+           "units": "KB per launch as reported; hbm_bytes_per_launch_corrected = (2 x FETCH_SIZE + WRITE_SIZE) x 1024", "kernels": {}}
+    ks = out["kernels"]
+    for sub, n in (("aux_fetch", "FETCH_SIZE"), ("aux_write", "WRITE_SIZE")):
+        acc, dur = per_kernel(os.path.join(src, sub, "pmc_counter_collection.csv"))
+        for k, counters in acc.items():
+            if "k_" not in k or "rocprim" in k or "at::" in k or n not in counters:
+                continue
+            e = ks.setdefault(short(k), {})
+            e["launches"] = len(dur[k])
+            e[f"duration_ns_mean_{sub}"] = sum(dur[k]) / len(dur[k])
+            e[f"{n}_mean_per_launch"] = sum(counters[n]) / len(counters[n])
+    for e in ks.values():
+        if "FETCH_SIZE_mean_per_launch" in e and "WRITE_SIZE_mean_per_launch" in e:
+            e["hbm_bytes_per_launch_corrected"] = (2.0 * e["FETCH_SIZE_mean_per_launch"] + e["WRITE_SIZE_mean_per_launch"]) * 1024.0
+            e["hbm_GBps_over_traced_duration"] = e["hbm_bytes_per_launch_corrected"] / e["duration_ns_mean_aux_fetch"]
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,6 +66,11 @@ def main():
         shutil.copy(os.path.join(src, "hpr", "hpr_kernel_stats.csv"), os.path.join(dst, f"{tag}_hpr_batched_kernel_stats.csv"))
     if os.path.exists(os.path.join(src, "hpr1m", "hpr1m_kernel_stats.csv")):
         shutil.copy(os.path.join(src, "hpr1m", "hpr1m_kernel_stats.csv"), os.path.join(dst, f"{tag}_hpr_1m_kernel_stats.csv"))
+    for sub, name in (("opt", "optimize"), ("aux", "aux")):
+        if os.path.exists(os.path.join(src, sub, f"{sub}_kernel_stats.csv")):
+            shutil.copy(os.path.join(src, sub, f"{sub}_kernel_stats.csv"), os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
+    if os.path.exists(os.path.join(src, "aux_fetch", "pmc_counter_collection.csv")):
+        aux_pmc(src, os.path.join(dst, f"{tag}_aux_pmc.json"))
     out = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --kernel-trace -- python3 bench.py --steps 20 --warmup 5 "
                       "--cpu-wps 0 --dropin off --density off --mode dense   (three separate runs, tools/collect_profiles.sh)",
            "units": "FETCH_SIZE/WRITE_SIZE in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)",

@@ -55,16 +55,6 @@ struct __attribute__((aligned(64))) WayHot {
     float sthr;   // sqrt(thr)
 };
 
-// Per-waypoint side record (32 B): pass-1 culling data from the probe, and M for the backward.
-struct WayAux {
-    float M;      // max_n (p - a)
-    float L;      // lower bound of max_n p found by the probe (0 = none)
-    float thr1;   // squared-distance bound for the max search (+inf = no culling)
-    float sthr1;
-    float azero;  // 1 = the probe exhibited a point with p == 0, hence min_n p == 0 exactly
-    float pad[3];
-};
-
 // Cold record used by the gradient chain.
 struct WayCold {
     float qn[4];  // normalised body quaternion
@@ -161,13 +151,6 @@ __device__ __forceinline__ float to_exp(float x) {
     return fmaf(y, r * 0.693147180559945f, y);
 }
 
-// exp(x) without the correction term: relative error ~|x| * 6e-8.  Used for the depth sigmoid only, where
-// it is harmless: S = 1/(1+e) inherits e/(1+e) of it (< 4e-7 for |Z| <= 6 m, and S ~ e^Z is negligible
-// together with every other factor of p for points far behind the camera).
-// No clamp: v_exp_f32 saturates to 0 / +inf by itself and there is no correction term that could turn that into a NaN
-// (1 + inf = inf, rcp(inf) = 0).
-__device__ __forceinline__ float to_exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
-
 __device__ __forceinline__ float to_log2(float x) { return __builtin_amdgcn_logf(x); }
 
 // Squared-distance bound thr such that  d2 > thr  =>  exp(-0.5 * d2 * inv_var) < tau * (1 - 1e-4), i.e. the
@@ -184,93 +167,12 @@ __device__ inline void cull_threshold(float tau, float inv_var, float* thr, floa
     *sthr = sqrtf(th) * 1.000001f;
 }
 
-// camera-frame squared distance to the Gaussian centre (model.py:22), same expression as soft_vis uses
-__device__ __forceinline__ float dist2_mean(float X, float Y, float Z, float mean) {
-    const float dx = X - mean, dy = Y - mean, dz = Z - mean;
-    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-}
-
 // ----------------------------------------------------------------------------------------------
-// Soft visibility of one camera-frame point: p = D * (S * Gw * Gh)   (model.py:13-47, :110/:223).
-// The three Gaussians share one exponential: exp(a)exp(b)exp(c) = exp(a+b+c).
-
-struct Vis {
-    float p, S, u, v, rz;
-};
-
-template <bool PINHOLE>
-__device__ __forceinline__ float soft_vis(const CamConsts& k, float X, float Y, float Z, Vis* o) {
-    const float d2 = dist2_mean(X, Y, Z, k.mean);
-    float g0, g1, h2;  // the scaled projections (ks0 . c), (ks1 . c) and the depth
-    if (PINHOLE) {
-        g0 = fmaf(k.ks0[2], Z, k.ks0[0] * X);
-        g1 = fmaf(k.ks1[2], Z, k.ks1[1] * Y);
-        h2 = Z;
-    } else {
-        g0 = fmaf(k.ks0[2], Z, fmaf(k.ks0[1], Y, k.ks0[0] * X));
-        g1 = fmaf(k.ks1[2], Z, fmaf(k.ks1[1], Y, k.ks1[0] * X));
-        h2 = fmaf(k.k[8], Z, fmaf(k.k[7], Y, k.k[6] * X));
-    }
-    const float rz = to_rcp(h2 + k.eps);
-    const float au = fmaf(g0, rz, -k.cw), av = fmaf(g1, rz, -k.ch);
-    float arg = d2 * k.half_inv_var;     // 1/2 (dist/std)^2
-    arg = fmaf(au, au, arg);
-    arg = fmaf(av, av, arg);
-    const float E = to_exp(-arg);
-    const float S = to_rcp(1.0f + to_exp_fast(-h2));
-    const float p = S * E;
-    if (o) {  // the gradient also wants the pixel coordinates themselves
-        float h0, h1;
-        if (PINHOLE) {
-            h0 = fmaf(k.k[2], Z, k.k[0] * X);
-            h1 = fmaf(k.k[5], Z, k.k[4] * Y);
-        } else {
-            h0 = fmaf(k.k[2], Z, fmaf(k.k[1], Y, k.k[0] * X));
-            h1 = fmaf(k.k[5], Z, fmaf(k.k[4], Y, k.k[3] * X));
-        }
-        o->p = p; o->S = S; o->u = h0 * rz; o->v = h1 * rz; o->rz = rz;
-    }
-    return p;
-}
-
-// d p / d c for the same point; zero where p underflowed.
-template <bool PINHOLE>
-__device__ __forceinline__ void dvis_dc(const CamConsts& k, float X, float Y, float Z, const Vis& s, float g[3]) {
-    const float gw = -(s.u - k.halfw) * (k.inv_w * k.inv_w);
-    const float gh = -(s.v - k.halfh) * (k.inv_h * k.inv_h);
-    const float a0 = gw * s.rz, a1 = gh * s.rz;
-    const float a2 = (1.0f - s.S) - fmaf(gw, s.u, gh * s.v) * s.rz;
-    float k0, k1, k2;
-    if (PINHOLE) {
-        k0 = k.k[0] * a0;
-        k1 = k.k[4] * a1;
-        k2 = fmaf(k.k[2], a0, fmaf(k.k[5], a1, a2));
-    } else {
-        k0 = fmaf(k.k[0], a0, fmaf(k.k[3], a1, k.k[6] * a2));
-        k1 = fmaf(k.k[1], a0, fmaf(k.k[4], a1, k.k[7] * a2));
-        k2 = fmaf(k.k[2], a0, fmaf(k.k[5], a1, k.k[8] * a2));
-    }
-    const bool live = s.p > 0.0f;
-    g[0] = live ? s.p * fmaf(-(X - k.mean), k.inv_var, k0) : 0.0f;
-    g[1] = live ? s.p * fmaf(-(Y - k.mean), k.inv_var, k1) : 0.0f;
-    g[2] = live ? s.p * fmaf(-(Z - k.mean), k.inv_var, k2) : 0.0f;
-}
-
-// world point -> camera frame of a virtual waypoint
-__device__ __forceinline__ void to_cam(const WayHot& h, float x, float y, float z, float& X, float& Y, float& Z,
-                                       float& y0, float& y1, float& y2) {
-    y0 = x - h.t[0]; y1 = y - h.t[1]; y2 = z - h.t[2];
-    X = fmaf(h.m[2], y2, fmaf(h.m[1], y1, h.m[0] * y0));
-    Y = fmaf(h.m[5], y2, fmaf(h.m[4], y1, h.m[3] * y0));
-    Z = fmaf(h.m[8], y2, fmaf(h.m[7], y1, h.m[6] * y0));
-}
-
-// ----------------------------------------------------------------------------------------------
-// Packed-f32 twins of the functions above: two points per lane in a 64-bit register pair, so that the
-// FMA-class arithmetic issues as v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (one wave64 VALU instruction
-// occupies its SIMD for 4 cycles whether it carries one float per lane or two).  Every element goes through
-// exactly the operation sequence of the scalar function, each operation IEEE-rounded per element, so the
-// results are bit-identical to the scalar path; transcendentals, med3 and min/max stay per element.
+// Packed f32: two points per lane in a 64-bit register pair, so that the FMA-class arithmetic issues as v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32 (one wave64 VALU instruction occupies its SIMD for 4 cycles whether it carries one float per lane
+// or two).  Every element goes through exactly the operation sequence of the scalar function (vis_p / dvis_dy below), each
+// operation IEEE-rounded per element, so the results are bit-identical to the scalar path; transcendentals, med3 and min/max
+// stay per element.
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -278,73 +180,6 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 __device__ __forceinline__ f2 pk_splat(float s) { return (f2)(s); }
 __device__ __forceinline__ f2 pk_splat(f2 v) { return v; }   // (a record whose fields are register pairs already: WayRecPk)
 __device__ __forceinline__ f2 pk_rcp(f2 x) { return f2{to_rcp(x.x), to_rcp(x.y)}; }
-
-__device__ __forceinline__ f2 to_exp_pk(f2 x) {
-    x = f2{__builtin_amdgcn_fmed3f(x.x, -150.0f, 88.0f), __builtin_amdgcn_fmed3f(x.y, -150.0f, 88.0f)};
-    const float L2E = 1.44269504088896341f, L2E_LO = 1.925963033500519e-8f;
-    const f2 e = x * pk_splat(L2E);
-    f2 r = pk_fma(x, pk_splat(L2E), -e);
-    r = pk_fma(x, pk_splat(L2E_LO), r);
-    const f2 y = f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-    return pk_fma(y, r * pk_splat(0.693147180559945f), y);
-}
-
-__device__ __forceinline__ f2 to_exp_fast_pk(f2 x) {
-    const f2 e = x * pk_splat(1.44269504088896341f);
-    return f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-}
-
-__device__ __forceinline__ f2 dist2_mean_pk(f2 X, f2 Y, f2 Z, float mean) {
-    const f2 m = pk_splat(mean);
-    const f2 dx = X - m, dy = Y - m, dz = Z - m;
-    return pk_fma(dz, dz, pk_fma(dy, dy, dx * dx));
-}
-
-struct Vis2 {
-    f2 p, S, u, v, rz;
-};
-
-template <bool PINHOLE>
-__device__ __forceinline__ f2 soft_vis_pk(const CamConsts& k, f2 X, f2 Y, f2 Z, Vis2* o) {
-    const f2 d2 = dist2_mean_pk(X, Y, Z, k.mean);
-    f2 g0, g1, h2;
-    if (PINHOLE) {
-        g0 = pk_fma(pk_splat(k.ks0[2]), Z, pk_splat(k.ks0[0]) * X);
-        g1 = pk_fma(pk_splat(k.ks1[2]), Z, pk_splat(k.ks1[1]) * Y);
-        h2 = Z;
-    } else {
-        g0 = pk_fma(pk_splat(k.ks0[2]), Z, pk_fma(pk_splat(k.ks0[1]), Y, pk_splat(k.ks0[0]) * X));
-        g1 = pk_fma(pk_splat(k.ks1[2]), Z, pk_fma(pk_splat(k.ks1[1]), Y, pk_splat(k.ks1[0]) * X));
-        h2 = pk_fma(pk_splat(k.k[8]), Z, pk_fma(pk_splat(k.k[7]), Y, pk_splat(k.k[6]) * X));
-    }
-    const f2 rz = pk_rcp(h2 + pk_splat(k.eps));
-    const f2 au = pk_fma(g0, rz, pk_splat(-k.cw)), av = pk_fma(g1, rz, pk_splat(-k.ch));
-    f2 arg = d2 * pk_splat(k.half_inv_var);
-    arg = pk_fma(au, au, arg);
-    arg = pk_fma(av, av, arg);
-    const f2 E = to_exp_pk(-arg);
-    const f2 S = pk_rcp(pk_splat(1.0f) + to_exp_fast_pk(-h2));
-    const f2 p = S * E;
-    if (o) {
-        f2 h0, h1;
-        if (PINHOLE) {
-            h0 = pk_fma(pk_splat(k.k[2]), Z, pk_splat(k.k[0]) * X);
-            h1 = pk_fma(pk_splat(k.k[5]), Z, pk_splat(k.k[4]) * Y);
-        } else {
-            h0 = pk_fma(pk_splat(k.k[2]), Z, pk_fma(pk_splat(k.k[1]), Y, pk_splat(k.k[0]) * X));
-            h1 = pk_fma(pk_splat(k.k[5]), Z, pk_fma(pk_splat(k.k[4]), Y, pk_splat(k.k[3]) * X));
-        }
-        o->p = p; o->S = S; o->u = h0 * rz; o->v = h1 * rz; o->rz = rz;
-    }
-    return p;
-}
-
-__device__ __forceinline__ void to_cam_pk(const WayHot& h, f2 x, f2 y, f2 z, f2& X, f2& Y, f2& Z, f2& y0, f2& y1, f2& y2) {
-    y0 = x - pk_splat(h.t[0]); y1 = y - pk_splat(h.t[1]); y2 = z - pk_splat(h.t[2]);
-    X = pk_fma(pk_splat(h.m[2]), y2, pk_fma(pk_splat(h.m[1]), y1, pk_splat(h.m[0]) * y0));
-    Y = pk_fma(pk_splat(h.m[5]), y2, pk_fma(pk_splat(h.m[4]), y1, pk_splat(h.m[3]) * y0));
-    Z = pk_fma(pk_splat(h.m[8]), y2, pk_fma(pk_splat(h.m[7]), y1, pk_splat(h.m[6]) * y0));
-}
 
 // ----------------------------------------------------------------------------------------------
 // Wave64 reductions on the DPP network; the result is valid in lane 63.

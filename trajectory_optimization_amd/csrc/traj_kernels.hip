@@ -2022,6 +2022,7 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
         const bool occ = s.occ != nullptr;
         if (s.cull) {
             const dim3 grid(V <= 256 ? 2 : 1, V);   // two blocks to a row while that fills the chip once; a block's fixed cost otherwise
+                                                      // (3, 4, 8 blocks to a row measured in r04: +3 ... +11 us on the slab, nothing gained in a 10 m room)
             if (occ) k_traj_pass1_cull<true><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.live, s.occ, s.occw, oi);
             else k_traj_pass1_cull<false><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.live, s.occ, s.occw, oi);
         } else {

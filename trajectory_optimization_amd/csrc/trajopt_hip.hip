@@ -30,6 +30,10 @@ extern "C" int tohip_profile_enable(int on) {
     s.on = on != 0;
     s.recs.clear();
     s.used = 0;
+    if (!s.on) {   // the header's contract: profiling off = nothing kept
+        for (hipEvent_t e : s.pool) (void)hipEventDestroy(e);
+        s.pool.clear();
+    }
     return TOHIP_OK;
 }
 
