@@ -80,9 +80,9 @@ def isa_mix():
 
 def pmc_figures(kernel):
     """(HBM bytes per launch, VALU busy fraction) of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r03_bench_dense_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes; SQ_ACTIVE_INST_VALU x4 over the SIMD
+    (profiles/r04_bench_dense_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes; SQ_ACTIVE_INST_VALU x4 over the SIMD
     cycles of the kernel), or (None, None, None)."""
-    d = _profile_json("r03_bench_dense_pmc.json")
+    d = _profile_json("r04_bench_dense_pmc.json")
     try:
         for name, v in d["kernels"].items():
             if kernel in name and "hbm_bytes_per_launch_corrected" in v:
@@ -847,7 +847,7 @@ def main():
                                      "diagnostic pass): what the blocks themselves take; kernel_ms_per_launch also holds the "
                                      "launch / queueing share of a back-to-back dependent launch"},
                          "hbm_counter_frac": (traffic / (p1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "traffic_note": "HBM bytes per launch from profiles/r03_bench_dense_pmc.json (separate --pmc passes of "
+                         "traffic_note": "HBM bytes per launch from profiles/r04_bench_dense_pmc.json (separate --pmc passes of "
                                          "this command: 2 x FETCH_SIZE + WRITE_SIZE); a few per cent of the HBM peak: points live "
                                          "in registers, waypoints stream through SGPRs, the 8-byte (min, max) stores go out as "
                                          "32-byte sectors",

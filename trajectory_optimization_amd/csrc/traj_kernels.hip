@@ -713,10 +713,12 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// sparse: 1024-thread blocks (16 waves) take the candidate (slot, trajectory) bits pass 1 set (6-8 % of the slots on the BASELINE
-// workloads; every slot of a dense indoor cloud).  Every wave holds the slot's 256 points (four consecutive points per lane, as
-// two packed pairs); the slot's flagged waypoints of a trajectory, in ascending order, go round-robin to the waves (rank & 15):
-// a fixed order that depends only on the flag set, which DENSE and CULL share.
+// sparse: blocks of NW waves (4 by default: up to four blocks to a CU, 1 024 resident; 16 behind TOHIP_SPARSE_WAVES for comparison)
+// take the candidate (slot, trajectory) bits pass 1 set (6-8 % of the slots on the BASELINE workloads; 15-37 % once an optimisation
+// has moved the trajectory or in an indoor cloud).  Every wave holds the slot's 256 points (four consecutive points per lane, as
+// two packed pairs); the slot's flagged waypoints of a trajectory, in ascending order, are dealt by rank & 15 into SIXTEEN partial
+// sums — wave w keeps the 16 / NW of them with (rank & 15) % NW == w — a fixed order that depends only on the flag set, which DENSE
+// and CULL share, and bitwise the same sums whatever NW is.
 //   flags     lane per waypoint: the slot's (min, max) against the waypoint's final extrema — flagged when its maximum
 //             has p_hat >= 1/2 (the predicate applied per point below, on an attained value), or it holds an argmin point
 //             while a > 0 (that set carries gradient, model.py:226); a degenerate waypoint (max == min, or a NaN: the
