@@ -579,7 +579,7 @@ struct CullLds {
     unsigned long long row[TO_PROBE_MAXFW];    // the waypoint's reachable slots (its row of `live`)
     int pre[TO_PROBE_MAXFW];                   // set bits before each word
     int list[TO_CULL_LIST];                    // the reachable slots in ascending order, while they fit
-    int mx[2 * TO_SP_WAVES], mn[2 * TO_SP_WAVES];
+    int mx[2 * TO_SP_WAVES], mn[2 * TO_SP_WAVES];   // (of the block's NW <= TO_SP_WAVES waves)
     int total;
 };
 
@@ -600,8 +600,8 @@ __device__ __forceinline__ int cull_select(const CullLds& L, int fv_words, int j
     return lo * 64 + __builtin_ctzll(__ballot(hit));
 }
 
-template <bool OCC>
-__global__ void __launch_bounds__(TO_SP_THREADS)
+template <bool OCC, int NW>
+__global__ void __launch_bounds__(NW * 64)
 k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, float2* __restrict__ part, Extrema* __restrict__ ext,
                   unsigned long long* __restrict__ cbits, int fv_words, const unsigned long long* __restrict__ live,
                   const uint32_t* __restrict__ occ, int64_t occw, OutInit oi) {
@@ -609,9 +609,9 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int v = blockIdx.y;
     TO_STAMP(TO_STAMP_CULL, 0);
-    for (int w = t; w < fv_words; w += TO_SP_THREADS) { L.row[w] = live[(int64_t)v * fv_words + w]; L.cand[w] = 0ull; }
+    for (int w = t; w < fv_words; w += NW * 64) { L.row[w] = live[(int64_t)v * fv_words + w]; L.cand[w] = 0ull; }
     // the outputs' start values (the dense pass 1 sets them itself): stores nobody here waits for
-    for (int64_t i = (((int64_t)v * gridDim.x + blockIdx.x) * TO_SP_THREADS + t) * 4; i < oi.npad; i += (int64_t)gridDim.y * gridDim.x * TO_SP_THREADS * 4)
+    for (int64_t i = (((int64_t)v * gridDim.x + blockIdx.x) * (NW * 64) + t) * 4; i < oi.npad; i += (int64_t)gridDim.y * gridDim.x * (NW * 64) * 4)
         init_outputs(i, oi);
     __syncthreads();
     TO_STAMP(TO_STAMP_CULL, 1);   // the waypoint's row of reachable slots is in LDS
@@ -634,14 +634,14 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
     const int n = L.total;
     const bool listed = n <= TO_CULL_LIST;   // block-uniform: the set bits written out once, a pair is then one LDS read
     if (listed) {
-        for (int w = wave; w < fv_words; w += TO_SP_WAVES) {
+        for (int w = wave; w < fv_words; w += NW) {
             const unsigned long long word = L.row[w];
             if ((word >> lane) & 1ull) L.list[L.pre[w] + __popcll(word & ((1ull << lane) - 1ull))] = w * 64 + lane;
         }
         __syncthreads();
     }
     TO_STAMP(TO_STAMP_CULL, 2);   // prefix and list
-    const int wr = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * TO_SP_WAVES) + wave), WR = (int)gridDim.x * TO_SP_WAVES;
+    const int wr = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * NW) + wave), WR = (int)gridDim.x * NW;
     const WayRec& r = rec[v];
     int bmx = __builtin_bit_cast(int, r.L), bmn = __builtin_bit_cast(int, r.U);   // p >= +0: the bit patterns order like the values
     // A wave takes TWO reachable slots at a time — lanes 0..31 the one, 32..63 the other, eight points per lane: the dense kernel's
@@ -654,28 +654,18 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
     };
     if (wr < nunits) {
         constexpr int P8 = TO_PD;
-        int slot = unit_slot(wr);
-        float x[P8], y[P8], z[P8];
-        load_points<P8>(cv.soa, cv.npad, (int64_t)slot * TO_SLOT + (lane & 31) * P8, x, y, z);
-        f2 eps2 = pk_splat(k.eps), l2e2 = pk_splat(k.l2e_eps), scd2 = pk_splat(k.scd);
-        for (int u = wr; u < nunits; u += WR) {
-            const int cur = slot;
+        const f2 eps2 = pk_splat(k.eps), l2e2 = pk_splat(k.l2e_eps), scd2 = pk_splat(k.scd);
+        // one unit: the lane's eight points of slot `cur` against the block's waypoint
+        auto eval_unit = [&](int u, int cur, const float (&x)[P8], const float (&y)[P8], const float (&z)[P8]) {
             const bool valid = 2 * u + half < n;
-            const int64_t base = (int64_t)cur * TO_SLOT + (lane & 31) * P8;
-            float nx[P8], ny[P8], nz[P8];
-            const bool more = u + WR < nunits;
-            if (more) {   // the next unit's points are in flight while this one is evaluated
-                slot = unit_slot(u + WR);
-                load_points<P8>(cv.soa, cv.npad, (int64_t)slot * TO_SLOT + (lane & 31) * P8, nx, ny, nz);
-            }
             float om[P8];
-            load_occ<P8, OCC>(occ, occw, v, base, om);
+            load_occ<P8, OCC>(occ, occw, v, (int64_t)cur * TO_SLOT + (lane & 31) * P8, om);
             f2 p[P8 / 2];
 #pragma unroll
             for (int i = 0; i < P8; i += 2)
                 p[i / 2] = vis_p_pk(r, k, f2{x[i], x[i + 1]}, f2{y[i], y[i + 1]}, f2{z[i], z[i + 1]}, eps2, l2e2, scd2) * f2{om[i], om[i + 1]};
             const float m1 = fmaxf(fmaxf(p[0].x, p[0].y), p[1].x), m2 = fmaxf(fmaxf(p[1].y, p[2].x), p[2].y);
-            float mx = half_max31_nn_fused(fmaxf(m2, fmaxf(fmaxf(p[3].x, p[3].y), m1)));
+            const float mx = half_max31_nn_fused(fmaxf(m2, fmaxf(fmaxf(p[3].x, p[3].y), m1)));
             float mn = 0.f;   // wanted only while the probe has not exhibited a zero (see the dense kernel)
             if (__builtin_bit_cast(int, r.U) != 0) {
                 mn = fminf(fminf(fminf(p[0].x, p[0].y), fminf(p[1].x, p[1].y)), fminf(fminf(p[2].x, p[2].y), fminf(p[3].x, p[3].y)));
@@ -690,10 +680,25 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
                 }
                 if (__builtin_bit_cast(int, r.U) != 0) bmn = min(bmn, __builtin_bit_cast(int, mn));
             }
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < P8; ++i) { x[i] = nx[i]; y[i] = ny[i]; z[i] = nz[i]; }
+        };
+        // Two register sets take turns: while one unit is evaluated the next one's points arrive in the other set (a single set
+        // refilled by 24 moves per unit cost a seventh of the loop's vector instructions).
+        float xa[P8], ya[P8], za[P8], xb[P8], yb[P8], zb[P8];
+        int sa = unit_slot(wr), sb = 0;
+        load_points<P8>(cv.soa, cv.npad, (int64_t)sa * TO_SLOT + (lane & 31) * P8, xa, ya, za);
+        for (int u = wr; u < nunits; u += 2 * WR) {
+            const bool more1 = u + WR < nunits, more2 = u + 2 * WR < nunits;
+            if (more1) {
+                sb = unit_slot(u + WR);
+                load_points<P8>(cv.soa, cv.npad, (int64_t)sb * TO_SLOT + (lane & 31) * P8, xb, yb, zb);
             }
+            eval_unit(u, sa, xa, ya, za);
+            if (!more1) break;
+            if (more2) {
+                sa = unit_slot(u + 2 * WR);
+                load_points<P8>(cv.soa, cv.npad, (int64_t)sa * TO_SLOT + (lane & 31) * P8, xa, ya, za);
+            }
+            eval_unit(u + WR, sb, xb, yb, zb);
         }
     }
     TO_STAMP(TO_STAMP_CULL, 3);   // wave 0's pairs evaluated
@@ -701,11 +706,11 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
     __syncthreads();
     TO_STAMP(TO_STAMP_CULL, 4);   // every wave's
     if (t == 0) {
-        for (int w = 0; w < 2 * TO_SP_WAVES; ++w) { bmx = max(bmx, L.mx[w]); bmn = min(bmn, L.mn[w]); }
+        for (int w = 0; w < 2 * NW; ++w) { bmx = max(bmx, L.mx[w]); bmn = min(bmn, L.mn[w]); }
         if (bmx > __builtin_bit_cast(int, r.L)) atomicMax(&ext[v].mx, bmx);
         if (bmn < __builtin_bit_cast(int, r.U)) atomicMax(&ext[v].nmn, -bmn);
     }
-    for (int w = t; w < fv_words; w += TO_SP_THREADS) {
+    for (int w = t; w < fv_words; w += NW * 64) {
         const unsigned long long word = L.cand[w];
         if (word) atomicOr(cbit_word(cbits, fv_words, r.seg, w), word);
     }
@@ -2023,10 +2028,19 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
         TO_PROF(TOHIP_PROF_PASS1, s.st);
         const bool occ = s.occ != nullptr;
         if (s.cull) {
-            const dim3 grid(V <= 256 ? 2 : 1, V);   // two blocks to a row while that fills the chip once; a block's fixed cost otherwise
-                                                      // (3, 4, 8 blocks to a row measured in r04: +3 ... +11 us on the slab, nothing gained in a 10 m room)
-            if (occ) k_traj_pass1_cull<true><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.live, s.occ, s.occw, oi);
-            else k_traj_pass1_cull<false><<<grid, TO_SP_THREADS, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.live, s.occ, s.occw, oi);
+            // blocks of four waves, up to eight to a row: a waypoint's reachable slots are evaluated by 32 waves on up to eight CUs.
+            // (Two 16-wave blocks to a row kept a heavy row — 800 reachable slots in a 10 m room, 100 on the slab — on the eight
+            // SIMDs of two CUs: 17 us of instruction issue there while the light rows' CUs idled.)
+            static const int cull_waves = [] { const char* e = getenv("TOHIP_CULL_WAVES"); return e && atoi(e) == 16 ? 16 : 4; }();
+            if (cull_waves == 16) {
+                const dim3 grid(V <= 256 ? 2 : 1, V);
+                if (occ) k_traj_pass1_cull<true, 16><<<grid, 1024, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.live, s.occ, s.occw, oi);
+                else k_traj_pass1_cull<false, 16><<<grid, 1024, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.live, s.occ, s.occw, oi);
+            } else {
+                const dim3 grid(std::max(1, std::min(8, 1024 / V)), V);
+                if (occ) k_traj_pass1_cull<true, 4><<<grid, 256, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.live, s.occ, s.occw, oi);
+                else k_traj_pass1_cull<false, 4><<<grid, 256, 0, s.st>>>(s.cv, s.rec, V, s.k, s.part, s.ext, s.cbits, s.pl.fv_words, s.live, s.occ, s.occw, oi);
+            }
         } else {
             const int nblk8 = (int)(s.pl.npad / (TO_BLOCK * TO_PD));
             const int nb = dense_blocks(nblk8, V, occ);
