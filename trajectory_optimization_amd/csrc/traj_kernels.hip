@@ -376,16 +376,14 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
                 px[j] = cv.samples[sc]; py[j] = cv.samples[TO_PROBE_MAX + sc]; pz[j] = cv.samples[2 * TO_PROBE_MAX + sc];
             }
         }
-        // two samples to a packed evaluation (bit for bit the scalar one, common.hpp): only half of the CUs hold a probe block, and
-        // sixteen waves of eight scalar evaluations each were 1.8 us of instruction issue on theirs
 #pragma unroll
-        for (int j = 0; j < kBatch; j += 2) {
-            const int s0 = t + (rd * kBatch + j) * TO_PROBE_THREADS, s1 = s0 + TO_PROBE_THREADS;
-            const f2 om = f2{occ_one(occ, occw, v, (int64_t)(s0 < cv.nsamples ? s0 : 0) * cv.sample_step),
-                             occ_one(occ, occw, v, (int64_t)(s1 < cv.nsamples ? s1 : 0) * cv.sample_step)};
-            const f2 p = vis_p_pk(r, k, f2{px[j], px[j + 1]}, f2{py[j], py[j + 1]}, f2{pz[j], pz[j + 1]}) * om;
-            if (s0 < cv.nsamples) { mx = fmaxf(mx, p.x); mn = fminf(mn, p.x); }
-            if (s1 < cv.nsamples) { mx = fmaxf(mx, p.y); mn = fminf(mn, p.y); }
+        for (int j = 0; j < kBatch; ++j) {
+            const int sj = t + (rd * kBatch + j) * TO_PROBE_THREADS;
+            if (sj < cv.nsamples) {
+                const float p = vis_p(r, k, px[j], py[j], pz[j]) * occ_one(occ, occw, v, (int64_t)sj * cv.sample_step);
+                mx = fmaxf(mx, p);
+                mn = fminf(mn, p);
+            }
         }
     }
     for (int s = 32; s > 0; s >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, s)); mn = fminf(mn, __shfl_xor(mn, s)); }
@@ -545,7 +543,7 @@ k_traj_pass1_dense(CloudView cv, const WayRec* __restrict__ rec, int V, int nblk
                 mn = half_min31_nn_fused(mn);
             }
             if ((lane & 31) == 31) {
-                __builtin_nontemporal_store(f2{mn, mx}, reinterpret_cast<f2*>(prow + v));   // streamed: not read again before the next launch
+                prow[v] = make_float2(mn, mx);
                 if (fold_extrema(ext, v, mn, mx, r)) mark_candidate(cbits, fv_words, slot, r.seg);
             }
         }
