@@ -61,9 +61,10 @@ def traj_forward(points, poses, quats, K, img_w, img_h, min_dist=1.0, max_dist=5
     return dict(lo_sum=lo, rewards=rew, pmin=pmin, pmax=pmax, mean_reward=mean.value, loss_vis=loss.value, occ=occ)
 
 
-def traj_backward(points, poses, quats, K, img_w, img_h, fwd, gout=1.0, min_dist=1.0, max_dist=5.0, prec="f32", act_shift=0.0):
+def traj_backward(points, poses, quats, K, img_w, img_h, fwd, gout=1.0, min_dist=1.0, max_dist=5.0, prec="f32", act_shift=0.0, phat_shift=0.0):
     """act_shift != 0 (diagnostic): the lower activity threshold of the clipped log-odds at 1/2 + act_shift instead of 1/2 —
-    the difference of two such gradients is what the points inside the band are worth (tests/test_hip_reference_dense.py)."""
+    the difference of two such gradients is what the points inside the band are worth (tests/test_hip_reference_dense.py).
+    phat_shift != 0 (diagnostic): every p_hat of the backward moved by that much (tools/stress_models.py)."""
     pts, poses, quats, K = _f32(points), _f32(poses), _f32(quats), _f32(K)
     N, W = pts.shape[0], poses.shape[0]
     dt = _DT[prec]
@@ -73,12 +74,16 @@ def traj_backward(points, poses, quats, K, img_w, img_h, fwd, gout=1.0, min_dist
     setter = getattr(lib(), "oracle_set_act_shift_" + prec)
     setter.argtypes = [c_d]
     setter(float(act_shift))
+    setter2 = getattr(lib(), "oracle_set_phat_shift_" + prec)
+    setter2.argtypes = [c_d]
+    setter2(float(phat_shift))
     try:
         rc = fn(_ptr(pts), c_i64(N), _ptr(poses), _ptr(quats), c_i64(W), _ptr(K), c_f(img_w), c_f(img_h),
                 c_f(min_dist), c_f(max_dist), _ptr(fwd.get("occ")), _ptr(rew), c_d(fwd["mean_reward"]), c_d(gout), _ptr(pg),
                 _ptr(qg))
     finally:
         setter(0.0)
+        setter2(0.0)
     assert rc == 0
     return pg, qg
 

@@ -252,6 +252,12 @@ int FN(oracle_traj_forward)(const float *xyz, int64_t N, const float *poses, con
  * reference's formula may differ on a waypoint that has such a point.  0 = the reference's rule. */
 static double FN(g_act_shift) = 0.0;
 void FN(oracle_set_act_shift)(double shift) { FN(g_act_shift) = shift; }
+/* A second diagnostic knob (tools/stress_models.py): EVERY p_hat of the backward moved by `shift` — both activity thresholds and
+ * the weight 1 / (p_hat (1 - p_hat)), which amplifies an error of p_hat by 1 / (1 - p_hat) just below the upper threshold.  The
+ * gradient at +d minus the one at -d is what an uncertainty of d in p_hat (f32: a few 1e-7) is worth to a waypoint: it matters where
+ * a handful of points carry a waypoint's whole gradient and one of them sits at p_hat = 0.999...  0 = the reference's rule. */
+static double FN(g_phat_shift) = 0.0;
+void FN(oracle_set_phat_shift)(double shift) { FN(g_phat_shift) = shift; }
 
 /* The sums of one waypoint that everything after is linear in, for given extrema (a = min p, M = max p - a: the waypoint's
  * own, or — a point-sharded run, tests/test_distributed_cpu.py — those over ALL ranks' points) and dL/d reward_n = coef for every n:
@@ -272,8 +278,9 @@ static void FN(bwd_sums)(const FN(consts_t) *kp, const FN(cam_t) *camp, const fl
 #pragma omp for schedule(static) nowait
         for (int64_t n = 0; n < N; ++n) {
             const REAL pp = p[n] - a;
-            const REAL ph = pp / M;
+            const REAL ph0 = pp / M;
             const int is_min = (p[n] == a), is_max = (pp == M);
+            const REAL ph = FN(g_phat_shift) != 0.0 ? (REAL)((double)ph0 + FN(g_phat_shift)) : ph0;
             const int act = ((double)ph >= 0.5 + FN(g_act_shift) && ph <= k.clip_hi);
             if (!act && !is_min && !is_max) continue;
             REAL x[3] = {(REAL)xyz[3 * n], (REAL)xyz[3 * n + 1], (REAL)xyz[3 * n + 2]}, c[3], g[3];
@@ -374,7 +381,10 @@ int FN(oracle_traj_backward)(const float *xyz, int64_t N, const float *poses, co
         double sums[40];
         FN(bwd_sums)(&k, &cam, xyz, N, occ ? occ + w * N : NULL, rewards, a, M, coef, p, sums);
         FN(bwd_final)(&cam, sums, 1.0, poses_grad + 3 * w, quats_grad + 4 * w);
-        if (has_nan) { /* autograd through the NaN min / max: every entry of the waypoint's gradient is NaN (probed on the reference) */
+        /* autograd through a NaN min / max, through p_hat = 0 / 0 of a waypoint whose p are all equal (in f32: all underflowed to 0),
+         * or from a NaN loss (some waypoint was one of those: NaN log-odds for every point): every entry of the waypoint's gradient
+         * is NaN — torch multiplies the NaN upstream by the clip's 0 / 1 mask (tests/golden/traj_stress_23_134.npz) */
+        if (has_nan || !(M > (REAL)0) || coef != coef) {
             for (int i = 0; i < 3; ++i) poses_grad[3 * w + i] = (REAL)NAN;
             for (int i = 0; i < 4; ++i) quats_grad[4 * w + i] = (REAL)NAN;
         }

@@ -479,6 +479,26 @@ def gen_dense():
                  **ref_vis(pts, poses, quats, clip))
 
 
+def gen_stress():
+    """The reference's own f32 results on what tools/stress_models.py found outside the bars (test_hip_conditioning.STRESS_CASES):
+    amplification just below the upper threshold, cancellation in r (1 - r), and a waypoint whose p underflows to 0 for every point
+    (0 / 0).  Clouds by recipe + checksum.  python tests/golden/make_golden.py stress"""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_hip_conditioning import STRESS_CASES, stress_case
+    for (seed, index), what in STRESS_CASES.items():
+        _, pts, poses, quats, clip, _dense, _j = stress_case(seed, index)
+        m = ref_model.ModelTraj(points=torch.from_numpy(pts), wps_poses=torch.from_numpy(poses), wps_quats=torch.from_numpy(quats),
+                                intrins=K, img_width=IMG_W, img_height=IMG_H, device=CPU, min_dist=clip[0], max_dist=clip[1])
+        m(vis_wps_dist=0.0)
+        m.loss["vis"].backward()
+        save(f"traj_stress_{seed}_{index}", recipe=np.asarray("stress"), seed=seed, index=index, what=np.asarray(what), poses=poses, quats=quats,
+             min_dist=np.float64(clip[0]), max_dist=np.float64(clip[1]), points_checksum=np.float64(pts.astype(np.float64).sum()),
+             loss_vis=m.loss["vis"], rewards=m.rewards, vis_poses_grad=m.poses.grad, vis_quats_grad=m.quats.grad)
+        g = m.poses.grad.numpy()
+        print(f"   {what}: loss {float(m.loss['vis']):.6g}, NaN rewards {int(torch.isnan(m.rewards).sum())} of {len(pts)}, "
+              f"NaN gradient rows {np.flatnonzero(np.isnan(g).any(axis=1)).tolist()}, largest row {np.nanmax(np.abs(g)) if np.isfinite(g).any() else float('nan'):.3g}")
+
+
 def gen_timing():
     """Not a fixture: wall time of the reference itself (torch CPU, this container) on the bench workload's shape, for
     the record kept in profiles/r01_reference_cpu_timing.txt.  python tests/golden/make_golden.py timing"""

@@ -44,3 +44,36 @@ def test_hip_against_the_references_own_f32_gradients(name, dense):
                   f"within {MARGIN:g} of p_hat = 1/2 (worst {rep['worst_excluded']:.1e}, inside what those points are worth; the reference "
                   f"differs from the f64 restatement by as much); global rel_inf poses {rel_inf(gp, d['vis_poses_grad']):.1e} quats "
                   f"{rel_inf(gq, d['vis_quats_grad']):.1e}")
+
+
+@pytest.mark.parametrize("dense", [False, True])
+@pytest.mark.parametrize("name", ["traj_stress_23_4", "traj_stress_31_83", "traj_stress_31_101", "traj_stress_23_134"])
+def test_hip_on_what_the_stress_runs_found(name, dense):
+    """tools/stress_models.py's finds, pinned on the reference's own f32 results (make_golden.py stress; the oracle's twin of this
+    test is tests/test_oracle_golden.py::test_stress_findings_against_the_reference): a waypoint whose p all underflow to 0 in f32
+    (NaN everywhere, as the reference), one point just below the upper threshold carrying a waypoint's gradient (determined to
+    what an f32 uncertainty of p_hat is worth, and the reference no better), a gradient of 7e-9 out of r (1 - r) at r = 0.999999."""
+    from conftest import phat_uncertainty_report
+    from trajectory_optimization_amd.model import ModelTraj
+    d = load_reference_case(name)
+    dev = torch.device("cuda:0")
+    m = ModelTraj(torch.from_numpy(d["points"]), torch.from_numpy(d["poses"]), torch.from_numpy(d["quats"]), torch.from_numpy(K), IW, IH,
+                  min_dist=d["clip"][0], max_dist=d["clip"][1], device=dev, dense=dense)
+    m(vis_wps_dist=0.0)
+    m.loss["vis"].backward()
+    torch.cuda.synchronize()
+    gp, gq, rew = m.poses.grad.cpu().numpy(), m.quats.grad.cpu().numpy(), m.rewards.detach().cpu().numpy()
+    if name == "traj_stress_23_134":
+        assert np.isnan(rew).all() and np.isnan(m.loss["vis"].item()) and np.isnan(gp).all() and np.isnan(gq).all()
+        return
+    assert abs(m.loss["vis"].item() - float(d["loss_vis"])) <= 5e-6 * float(d["loss_vis"])
+    np.testing.assert_allclose(rew, d["rewards"], rtol=1e-5, atol=0)
+    if name == "traj_stress_31_101":
+        ref = d["vis_poses_grad"].astype(np.float64)
+        assert np.array_equal(np.abs(gp).max(axis=1) > 0, np.abs(ref).max(axis=1) > 0)   # the same single waypoint carries gradient
+        assert np.abs(gp - ref).max() <= 0.15 * np.abs(ref).max() and np.abs(gq - d["vis_quats_grad"]).max() <= 0.15 * np.abs(d["vis_quats_grad"]).max()
+        return
+    rep = phat_uncertainty_report(d, gp, gq, MARGIN)
+    assert rep["inside_bar"] >= 2 * len(d["poses"]) - 4, rep
+    warnings.warn(f"{name} ({'dense' if dense else 'culled'}): {rep['inside_bar']} gradient rows within 1e-5 of the reference, {rep['excused']} within "
+                  f"what +-{2 * MARGIN:g} in p_hat is worth to their waypoint (worst {rep['worst']:.1e} of the largest row, worth {rep['worst_worth']:.1e})")

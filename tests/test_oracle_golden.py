@@ -68,6 +68,37 @@ def test_conditional_gradient_bar_against_the_reference(name, prec):
         assert rep["excluded"] >= 1   # the configurations were picked for having such a waypoint
 
 
+STRESS_FIXTURES = ["traj_stress_23_4", "traj_stress_31_83", "traj_stress_31_101", "traj_stress_23_134"]
+
+
+@pytest.mark.parametrize("name", STRESS_FIXTURES)
+def test_stress_findings_against_the_reference(name):
+    """What tools/stress_models.py found outside the bars, pinned on the REFERENCE's own f32 results (make_golden.py stress): the
+    f32 restatement against them.  A waypoint whose p all underflow (0 / 0) makes every reward, the loss and EVERY gradient row NaN;
+    where one point just below p_hat = 1 - 1e-6 carries a waypoint's gradient, the reference is only determined to what an f32
+    uncertainty of p_hat is worth (conftest.phat_uncertainty_report); a gradient of 7e-9 made of r (1 - r) at r = 0.999999 is only
+    determined to the cancellation in 1 - r."""
+    from conftest import load_reference_case, phat_uncertainty_report
+    from test_hip_conditioning import MARGIN
+    d = load_reference_case(name)
+    fwd = oracle.traj_forward(d["points"], d["poses"], d["quats"], K, IW, IH, d["clip"][0], d["clip"][1], prec="f32")
+    pg, qg = oracle.traj_backward(d["points"], d["poses"], d["quats"], K, IW, IH, fwd, min_dist=d["clip"][0], max_dist=d["clip"][1], prec="f32")
+    if name == "traj_stress_23_134":
+        assert np.isnan(d["rewards"]).all() and np.isnan(d["vis_poses_grad"]).all() and np.isnan(d["vis_quats_grad"]).all()
+        assert np.isnan(fwd["rewards"]).all() and np.isnan(fwd["loss_vis"]) and np.isnan(pg).all() and np.isnan(qg).all()
+        return
+    assert abs(fwd["loss_vis"] - float(d["loss_vis"])) <= 2e-6 * float(d["loss_vis"])
+    np.testing.assert_allclose(fwd["rewards"], d["rewards"], rtol=2e-5, atol=2e-6)
+    if name == "traj_stress_31_101":
+        # one waypoint's row of 7e-9, everything else exactly zero: r (1 - r) of a reward one ulp-and-a-bit below 1
+        ref = d["vis_poses_grad"].astype(np.float64)
+        assert (np.abs(ref).max(axis=1) > 0).sum() == 1 and np.abs(ref).max() < 1e-8
+        assert np.abs(pg - ref).max() <= 0.15 * np.abs(ref).max() and np.abs(qg - d["vis_quats_grad"]).max() <= 0.15 * np.abs(d["vis_quats_grad"]).max()
+        return
+    rep = phat_uncertainty_report(d, pg, qg, MARGIN)
+    assert rep["excused"] >= 1 and rep["inside_bar"] >= 2 * len(d["poses"]) - 4, rep
+
+
 def test_known_answers_bundled():
     """SURVEY.md §8c known answers."""
     d = load_golden("traj_bundled_default")
