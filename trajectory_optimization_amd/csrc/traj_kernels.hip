@@ -767,6 +767,8 @@ struct SparseArgs {
     const float* scalars;        //               scalars[4*traj+2] * gout[traj], or (all three NULL) 1
     const float* gout;
     float* bpart;
+    float* unit;                 // n_traj x npad, packed order: r (1 - r) of a candidate slot's points (0 for pads) — FUSED writes it with the
+                                 //   slot's rewards, the pair kernel reads it when the upstream gradient is the unit one
 };
 
 // a flagged waypoint as the evaluations read it (LDS): line 0 of its record, its normalisation, its index
@@ -953,16 +955,19 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
             const int o[4] = {o4.x, o4.y, o4.z, o4.w};
             long long fsum = 0;
             bool fnan = false;
+            float un[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float rw = to_rcp(1.0f + to_exp(-lo[j]));   // == k_traj_reward's value of rewards[perm[i]]
                 if (lo[j] != lo[j]) rw = lo[j];
+                un[j] = base + j < a.cv.n ? 1.0f * rw * (1.0f - rw) : 0.f;   // the pair kernel's d reward / d lo_sum of this point, bit for bit
                 if (base + j < a.cv.n) {                      // pads are not points
                     if (!a.prefilled || lo[j] != 0.f) a.rewards[(int64_t)tr * a.cv.n + o[j]] = rw;
                     if (rw != rw) fnan = true;
                     else fsum += reward_fixed(rw, a.shift) - (1ll << (a.shift - 1));
                 }
             }
+            *reinterpret_cast<float4*>(a.unit + (int64_t)tr * a.cv.npad + base) = make_float4(un[0], un[1], un[2], un[3]);
             for (int s = 32; s > 0; s >>= 1) fsum += __shfl_xor(fsum, s);
             fnan = __any(fnan);
             if (lane == 0) {
@@ -1054,7 +1059,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 16 || SFW == 8) ? 4 : 3) k_tra
 //     [0..2] sum w gy   [3..11] sum w y (x) gy   [12] S1   [13] S2        (w = G/M, gy = dp/dy, y = x - t)
 //   per lane over its four points, then one DPP tree over the wave.  The fused step takes the sums with dL/d reward = 1
 //   (they are linear in it; k_traj_finish scales them once the mean of the rewards is known).
-template <bool OCC>
+// UNIT: the upstream gradient is the unit one AND this step's fused sparse kernel has left r (1 - r) of the slot's points in
+// a.unit: four loads instead of four sigmoids per lane and pair (a slot's points meet dozens of waypoints).
+template <bool OCC, bool UNIT>
 __device__ __forceinline__ void pair_sums(const SparseArgs& a, int slot, int v, int lane) {
     const EvalK& k = a.k;
     const WayRec& r = a.rec[v];
@@ -1062,20 +1069,21 @@ __device__ __forceinline__ void pair_sums(const SparseArgs& a, int slot, int v, 
     const int64_t base = (int64_t)slot * TO_SLOT + lane * 4;
     float x[4], y[4], z[4];
     load_points<4>(a.cv.soa, a.cv.npad, base, x, y, z);
-    const float4 l4 = *reinterpret_cast<const float4*>(a.lo_sum + (int64_t)tr * a.cv.npad + base);
+    const float4 l4 = *reinterpret_cast<const float4*>((UNIT ? a.unit : a.lo_sum) + (int64_t)tr * a.cv.npad + base);
     int4 o4 = make_int4(0, 0, 0, 0);
-    if (a.grad_rewards != nullptr) o4 = *reinterpret_cast<const int4*>(a.cv.perm + base);
+    if (!UNIT && a.grad_rewards != nullptr) o4 = *reinterpret_cast<const int4*>(a.cv.perm + base);
     float om[4];
     load_occ<4, OCC>(a.occ, a.occw, v, base, om);
     float av, pmax, M, invM;
     load_norm(a.ext[v], av, pmax, M, invM);
     if (!(M > 0.f) || !(invM < INFINITY)) invM = __builtin_nanf("");   // degenerate: nothing is active (NaN compares false)
-    const float coef = a.scalars ? a.scalars[4 * tr + 2] * a.gout[tr] : 1.0f;
+    const float coef = (!UNIT && a.scalars) ? a.scalars[4 * tr + 2] * a.gout[tr] : 1.0f;
     const float lo[4] = {l4.x, l4.y, l4.z, l4.w};
     const int o[4] = {o4.x, o4.y, o4.z, o4.w};
     float gn[4];   // dL/d lo_sum_n
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        if (UNIT) { gn[j] = lo[j]; continue; }   // (l4 holds r (1 - r) then)
         float rw = to_rcp(1.0f + to_exp(-lo[j]));
         if (lo[j] != lo[j]) rw = lo[j];
         const bool valid = base + j < a.cv.n;        // pads are not points
@@ -1123,7 +1131,7 @@ __device__ __forceinline__ void pair_sums(const SparseArgs& a, int slot, int v, 
 }
 
 // block b of nb (TO_SP_THREADS threads each): wave gw = 16 b + wave of 16 nb takes the pairs gw, gw + 16 nb, ...
-template <bool OCC>
+template <bool OCC, bool UNIT>
 __device__ __forceinline__ void pair_walk(const SparseArgs& a, int b, int nb) {
     const int lane = threadIdx.x & 63;
     TO_STAMP(TO_STAMP_PAIRS, 0);
@@ -1148,7 +1156,7 @@ __device__ __forceinline__ void pair_walk(const SparseArgs& a, int b, int nb) {
     for (int p = gw; p < P; p += GW) {
         const int2 cur = next;
         if (p + GW < P) next = entry(p + GW);
-        pair_sums<OCC>(a, __builtin_amdgcn_readfirstlane(cur.x), __builtin_amdgcn_readfirstlane(cur.y), lane);
+        pair_sums<OCC, UNIT>(a, __builtin_amdgcn_readfirstlane(cur.x), __builtin_amdgcn_readfirstlane(cur.y), lane);
     }
     TO_STAMP(TO_STAMP_PAIRS, 2);
     TO_STAMP_LAST(TO_STAMP_PAIRS, 3);   // the block's last wave
@@ -1156,7 +1164,7 @@ __device__ __forceinline__ void pair_walk(const SparseArgs& a, int b, int nb) {
 
 // os.mode == 2 (model() as one library call, loss_kernels.hip): one block more than the pairs need turns the integer reward sum
 // — complete since k_traj_sparse — and the prologue's regulariser terms into model()'s scalars and loss terms.
-template <bool OCC>
+template <bool OCC, bool UNIT>
 __global__ void __launch_bounds__(TO_SP_THREADS) k_traj_pairs(SparseArgs a, OptStep os, float* __restrict__ scalars_out) {
     const int extra = os.mode == 2 ? 1 : 0;
     if (extra && blockIdx.x == gridDim.x - 1) {
@@ -1171,7 +1179,7 @@ __global__ void __launch_bounds__(TO_SP_THREADS) k_traj_pairs(SparseArgs a, OptS
         }
         return;
     }
-    pair_walk<OCC>(a, (int)blockIdx.x, (int)gridDim.x - extra);
+    pair_walk<OCC, UNIT>(a, (int)blockIdx.x, (int)gridDim.x - extra);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1255,7 +1263,7 @@ k_traj_reward_bwd(const float* __restrict__ lo_sum, int64_t n, float eps, int pr
         reward_block(lo_sum, a.cv.perm, n, a.cv.npad, eps, a.shift, prefilled, rewards, a.acc, scalars, blockIdx.x % nbx, nbx, blockIdx.x / nbx, lds);
         return;
     }
-    pair_walk<OCC>(a, (int)blockIdx.x - R, (int)gridDim.x - R);
+    pair_walk<OCC, false>(a, (int)blockIdx.x - R, (int)gridDim.x - R);   // (the rewards of this very launch: no r (1 - r) left by a fused forward)
 }
 
 // thread per body waypoint: rig composition, dL/dt = -R sum dL/dc, dL/dR = sum y (x) dL/dc,
@@ -1875,7 +1883,7 @@ struct TrajPlan {
     int vwords;    // (V + 63) / 64
     int V;
     int64_t plcap; // entries of one pair sub-list
-    size_t off_ctl, off_toff, off_rec, off_cold, off_ext, off_cbits, off_ctr, off_part, off_fv, off_live, off_plist, off_ties, off_bpart, off_vgrad, total;
+    size_t off_ctl, off_toff, off_rec, off_cold, off_ext, off_cbits, off_ctr, off_part, off_fv, off_live, off_plist, off_ties, off_bpart, off_vgrad, off_unit, total;
 };
 
 inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
@@ -1904,6 +1912,7 @@ inline TrajPlan make_plan(int64_t n, int64_t V, int64_t W, int64_t n_traj = 1) {
     p.off_ties = o;  o += align_up((size_t)V * sizeof(TieRec), 256);
     p.off_bpart = o; o += align_up((size_t)V * (size_t)p.nslots * 16 * sizeof(float), 256);
     p.off_vgrad = o; o += align_up((size_t)V * 12 * sizeof(float), 256);
+    p.off_unit = o;  o += align_up((size_t)n_traj * (size_t)p.npad * sizeof(float), 256);   // r (1 - r) of the candidate slots' points (sparse -> pairs)
     p.total = o;
     return p;
 }
@@ -1964,6 +1973,7 @@ struct TrajStep {
     unsigned long long *fv, *live;
     TieRec* ties;
     float *bpart, *vgrad;
+    float* unit;
     int shift;
 };
 
@@ -1991,6 +2001,7 @@ inline int traj_step_init(TrajStep& s, const void* packed, int64_t n, int64_t W,
     s.ties = (TieRec*)(ws + s.pl.off_ties);
     s.bpart = (float*)(ws + s.pl.off_bpart);
     s.vgrad = (float*)(ws + s.pl.off_vgrad);
+    s.unit = (float*)(ws + s.pl.off_unit);
     s.k = make_evalk(cam);
     s.cv = cloud_view(packed, n);
     s.cull = !(flags & TOHIP_TRAJ_DENSE) && s.pl.fv_words <= TO_PROBE_MAXFW;   // (beyond 16.7 M points every pair is evaluated)
@@ -2059,7 +2070,7 @@ inline SparseArgs sparse_args(const TrajStep& s, float* lo_sum) {
     a.fv = s.fv; a.ties = s.ties; a.lo_sum = lo_sum; a.minmax = nullptr; a.occ = s.occ; a.occw = s.occw;
     a.toff = s.toff; a.n_traj = (int)s.n_traj; a.C = s.C;
     a.rewards = nullptr; a.prefilled = 0; a.acc = s.acc; a.shift = s.shift;
-    a.grad_rewards = nullptr; a.scalars = nullptr; a.gout = nullptr; a.bpart = s.bpart;
+    a.grad_rewards = nullptr; a.scalars = nullptr; a.gout = nullptr; a.bpart = s.bpart; a.unit = s.unit;
     return a;
 }
 
@@ -2110,8 +2121,14 @@ inline int pair_blocks() {
 
 inline int launch_pairs(const TrajStep& s, const SparseArgs& a) {
     const int grid = pair_blocks() + (s.opt.mode == 2 ? 1 : 0);
-    if (s.occ) k_traj_pairs<true><<<grid, TO_SP_THREADS, 0, s.st>>>(a, s.opt, s.opt_scalars);
-    else k_traj_pairs<false><<<grid, TO_SP_THREADS, 0, s.st>>>(a, s.opt, s.opt_scalars);
+    const bool unit = a.unit != nullptr && a.grad_rewards == nullptr && a.scalars == nullptr;   // the callers with a unit upstream follow a fused forward
+    if (s.occ) {
+        if (unit) k_traj_pairs<true, true><<<grid, TO_SP_THREADS, 0, s.st>>>(a, s.opt, s.opt_scalars);
+        else k_traj_pairs<true, false><<<grid, TO_SP_THREADS, 0, s.st>>>(a, s.opt, s.opt_scalars);
+    } else {
+        if (unit) k_traj_pairs<false, true><<<grid, TO_SP_THREADS, 0, s.st>>>(a, s.opt, s.opt_scalars);
+        else k_traj_pairs<false, false><<<grid, TO_SP_THREADS, 0, s.st>>>(a, s.opt, s.opt_scalars);
+    }
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
@@ -2229,6 +2246,7 @@ int traj_backward_impl(const void* packed, int64_t n, int64_t W, int64_t n_traj,
         a.grad_rewards = grad_rewards;
         a.scalars = grad_rewards ? nullptr : scalars;
         a.gout = grad_rewards ? nullptr : gout;
+        a.unit = nullptr;   // (the forward before this call need not have been a fused one: r (1 - r) from the log-odds vector)
         rc = launch_pairs(s, a);
         if (rc != TOHIP_OK) return rc;
     }
