@@ -336,24 +336,26 @@ k_to_camera_frame(const float* __restrict__ xyz, int64_t n, const float* __restr
 __global__ void __launch_bounds__(TO_BLOCK)
 k_soft_masks(const float* __restrict__ cam_xyz, int64_t n, CamConsts cc, float std_, float img_w, float img_h,
              float* __restrict__ dist_mask, float* __restrict__ fov_mask) {
+    // 12 B in, 8 B out per point: the memory system's job — provided the four exponentials, the square root and the four divisions
+    // of the reference's expressions do not take a hundred instructions.  Hardware v_exp / v_rcp / v_sqrt with the argument's
+    // rounding error folded back in (to_exp: 1.5 ulp) instead of libm's: 85 -> 67 us at 16 M points, results within 2 ulp.
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    const float inv_std = to_rcp(std_), inv_w = to_rcp(img_w), inv_h = to_rcp(img_h);
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
         const float X = cam_xyz[3 * i], Y = cam_xyz[3 * i + 1], Z = cam_xyz[3 * i + 2];
         if (dist_mask) {
             const float dx = X - cc.mean, dy = Y - cc.mean, dz = Z - cc.mean;
-            const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-            const float ds = dist / std_;
-            dist_mask[i] = expf(-0.5f * (ds * ds));
+            const float ds = __builtin_sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) * inv_std;
+            dist_mask[i] = to_exp(-0.5f * (ds * ds));
         }
         if (fov_mask) {
             const float h0 = fmaf(cc.k[2], Z, fmaf(cc.k[1], Y, cc.k[0] * X));
             const float h1 = fmaf(cc.k[5], Z, fmaf(cc.k[4], Y, cc.k[3] * X));
             const float h2 = fmaf(cc.k[8], Z, fmaf(cc.k[7], Y, cc.k[6] * X));
-            const float S = 1.0f / (1.0f + expf(-h2));
-            const float z = h2 + cc.eps;
-            const float au = (h0 / z - cc.halfw) / img_w, av = (h1 / z - cc.halfh) / img_h;
-            const float Gw = expf(-0.5f * (au * au)), Gh = expf(-0.5f * (av * av));
-            fov_mask[i] = S * Gw * Gh;
+            const float S = to_rcp(1.0f + to_exp(-h2));
+            const float rz = to_rcp(h2 + cc.eps);
+            const float au = (h0 * rz - cc.halfw) * inv_w, av = (h1 * rz - cc.halfh) * inv_h;
+            fov_mask[i] = S * to_exp(-0.5f * fmaf(au, au, av * av));
         }
     }
 }
