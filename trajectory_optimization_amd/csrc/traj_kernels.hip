@@ -1007,7 +1007,7 @@ __device__ __forceinline__ void write_minmax(const SparseArgs& a) {
 
 // block b of nb works for trajectory b % n_traj: the q-th, (q + S)-th, ... set bit of that trajectory's candidate bits (bit s =
 // slot s), q = b / n_traj, S = nb / n_traj (the host launches a multiple of n_traj blocks).  Every wave finds them from the same
-// popcount prefix, 64 words at a time (one 16-wave block is resident per CU at this kernel's register count).
+// popcount prefix, 64 words at a time.
 template <int MODE, bool OCC, int NW, int SFW>
 __device__ __forceinline__ void sparse_walk(const SparseArgs& a, int b, int nb, SparseLds<NW, SFW>& L) {
     const int lane = threadIdx.x & 63;
