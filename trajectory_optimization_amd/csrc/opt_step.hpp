@@ -7,8 +7,9 @@
 // The regularisers depend on the positions only, which are known when a step starts; the Adam update of a waypoint's rows
 // needs that waypoint's visibility gradient only, which its own block of k_traj_finish has in hand.  So a step needs no
 // launch of its own for any of this:
-//   prologue   one extra block per trajectory in the probe's launch (traj_kernels.hip): the regularisers' values and their
-//              gradient (W,3), and the step's Adam constants, into the step's scratch
+//   prologue   one extra block per trajectory in the sparse kernel's launch (traj_kernels.hip: a quarter of that launch's blocks
+//              leave at once, it runs beside the others; in the probe's launch it was the longest block): the regularisers' values
+//              and their gradient (W,3), and the step's Adam constants, into the step's scratch
 //   epilogue   every block of k_traj_finish (one per evaluated waypoint) updates the rows [r*step, (r+1)*step) of its
 //              trajectory — full gradient = visibility row (first row only) + regularisers — and the block of a trajectory's
 //              first waypoint also writes the loss log and the next row of the early-stop state

@@ -322,15 +322,10 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
              WayCold* __restrict__ cold, Extrema* __restrict__ ext, TieRec* __restrict__ ties, const uint32_t* __restrict__ occ,
              int64_t occw, unsigned long long* __restrict__ fv, int fv_words, RewardAcc* __restrict__ acc,
              const int* __restrict__ traj_off, int* __restrict__ traj_off_ws, int n_traj, unsigned long long* __restrict__ cbits,
-             int ncbits, int* __restrict__ ctr, int wp_stride, int traj_rows, ProbeCull pc, int V, OptStep os) {
+             int ncbits, int* __restrict__ ctr, int wp_stride, int traj_rows, ProbeCull pc, int V) {
     __shared__ float smx[TO_PROBE_THREADS / 64], smn[TO_PROBE_THREADS / 64];
     __shared__ float scull[4];
     const int v = blockIdx.x, t = threadIdx.x;
-    if (v >= V) {   // the blocks behind the waypoints': a trajectory's regularisers and the step's Adam constants (opt_step.hpp)
-        __shared__ double olds[TO_PROBE_THREADS / 64], osh[4];
-        opt_prologue_block(os, v - V, olds, osh);
-        return;
-    }
     TO_STAMP(TO_STAMP_PROBE, 0);
     for (int j = t; j < fv_words; j += TO_PROBE_THREADS) fv[(int64_t)v * fv_words + j] = 0ull;
     for (int j = v * TO_PROBE_THREADS + t; j < ncbits; j += V * TO_PROBE_THREADS) cbits[(int64_t)j * TO_CBIT_STRIDE] = 0ull;   // the candidate (slot, trajectory) bits
@@ -1038,11 +1033,21 @@ __device__ __forceinline__ void sparse_walk(const SparseArgs& a, int b, int nb, 
 }
 
 template <int MODE, bool OCC, int NW, int SFW>
-__global__ void __launch_bounds__(NW * 64, (NW == 16 || SFW == 8) ? 4 : 3) k_traj_sparse(SparseArgs a) {   // (4 waves per SIMD: 128 registers; 3 where the LDS allows no more)
+__global__ void __launch_bounds__(NW * 64, (NW == 16 || SFW == 8) ? 4 : 3) k_traj_sparse(SparseArgs a, OptStep os) {   // (4 waves per SIMD: 128 registers; 3 where the LDS allows no more)
     __shared__ SparseLds<NW, SFW> L;
+    // The step's prologue (opt_step.hpp: a trajectory's regularisers with their gradient, the step's Adam constants) needs the
+    // positions only and is wanted by the finish kernel: it rides HERE, as one block per trajectory behind the candidates' blocks —
+    // a quarter of those find no candidate and leave after 2 us, so it runs beside the others.  (In the probe's launch, until r04,
+    // its 8 us of serial f64 were that launch's longest block: +1.5 us per optimiser step.)
+    const int extra = os.mode ? os.n_traj : 0;
+    if ((int)blockIdx.x >= (int)gridDim.x - extra) {
+        __shared__ double olds[NW], osh[4];
+        opt_prologue_block(os, (int)blockIdx.x - ((int)gridDim.x - extra), olds, osh);
+        return;
+    }
     TO_STAMP(TO_STAMP_SPARSE, 0);
     if (blockIdx.x == 0) write_minmax(a);
-    sparse_walk<MODE, OCC, NW, SFW>(a, (int)blockIdx.x, (int)gridDim.x, L);
+    sparse_walk<MODE, OCC, NW, SFW>(a, (int)blockIdx.x, (int)gridDim.x - extra, L);
     TO_STAMP(TO_STAMP_SPARSE, 7);
 }
 
@@ -2024,15 +2029,15 @@ inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float
     {
         TO_PROF(TOHIP_PROF_PROBE, s.st);
         const ProbeCull pc{s.cull ? 1 : 0, s.pl.nslots, s.live};
-        const int grid = V + (s.opt.mode ? s.opt.n_traj : 0);   // a block per trajectory behind the waypoints': the step's prologue
+        const int grid = V;
         if (V <= 512)
             k_traj_probe<1024><<<grid, 1024, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
                                                         s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cbits, s.pl.ncbits, s.ctr, s.wp_stride,
-                                                        s.traj_rows, pc, V, s.opt);
+                                                        s.traj_rows, pc, V);
         else
             k_traj_probe<256><<<grid, 256, 0, s.st>>>(s.cv, poses, quats, s.C, s.rq, s.rt, s.k, s.rec, s.cold, s.ext, s.ties, s.occ, s.occw, s.fv,
                                                       s.pl.fv_words, s.acc, s.toff, s.toff_ws, (int)s.n_traj, s.cbits, s.pl.ncbits, s.ctr, s.wp_stride,
-                                                      s.traj_rows, pc, V, s.opt);
+                                                      s.traj_rows, pc, V);
         TO_HIP_CHECK_LAUNCH();
     }
     {
@@ -2093,10 +2098,10 @@ inline int sparse_blocks(const TrajStep& s, int nw) {
 
 template <int MODE, bool OCC, int NW>
 inline void launch_sparse_nw(const TrajStep& s, const SparseArgs& a) {
-    const int grid = sparse_blocks(s, NW);
+    const int grid = sparse_blocks(s, NW) + (s.opt.mode ? s.opt.n_traj : 0);   // (+ the step's prologue blocks)
     // one trajectory of at most TO_SP_STAGE virtual waypoints: its five flag words are all a block holds
-    if (s.n_traj == 1 && s.V <= TO_SP_STAGE) k_traj_sparse<MODE, OCC, NW, 8><<<grid, NW * 64, 0, s.st>>>(a);
-    else k_traj_sparse<MODE, OCC, NW, TO_SP_MAXW><<<grid, NW * 64, 0, s.st>>>(a);
+    if (s.n_traj == 1 && s.V <= TO_SP_STAGE) k_traj_sparse<MODE, OCC, NW, 8><<<grid, NW * 64, 0, s.st>>>(a, s.opt);
+    else k_traj_sparse<MODE, OCC, NW, TO_SP_MAXW><<<grid, NW * 64, 0, s.st>>>(a, s.opt);
 }
 
 template <int MODE>
