@@ -499,6 +499,24 @@ def gen_stress():
               f"NaN gradient rows {np.flatnonzero(np.isnan(g).any(axis=1)).tolist()}, largest row {np.nanmax(np.abs(g)) if np.isfinite(g).any() else float('nan'):.3g}")
 
 
+def gen_full():
+    """The reference itself at the bench cloud's full size: 1 M points (the BASELINE slab, seed 0) x 16 waypoints, fwd + bwd on the
+    CPU (~2 GB of autograd state, a few seconds).  Stored: loss, the gradients, every 997th reward and the rewards' f64 sum — the
+    cloud by recipe + checksum.  python tests/golden/make_golden.py full"""
+    n, w = 1_000_000, 16
+    pts = synth.make_cloud(n, seed=0)
+    poses, quats = synth.make_path(w, optical=True)
+    m = ref_model.ModelTraj(points=torch.from_numpy(pts), wps_poses=torch.from_numpy(poses), wps_quats=torch.from_numpy(quats),
+                            intrins=K, img_width=IMG_W, img_height=IMG_H, device=CPU, min_dist=1.0, max_dist=5.0)
+    m(vis_wps_dist=0.0)
+    m.loss["vis"].backward()
+    r = m.rewards.detach().numpy()
+    save("traj_full_1m_16", recipe=np.asarray("room"), n=n, seed=0, extent=np.asarray((40.0, 40.0, 4.0)), poses=poses, quats=quats,
+         min_dist=np.float64(1.0), max_dist=np.float64(5.0), points_checksum=np.float64(pts.astype(np.float64).sum()),
+         loss_vis=m.loss["vis"], rewards_every_997th=r[::997].copy(), rewards_sum=np.float64(r.astype(np.float64).sum()),
+         rewards_above_half=np.int64((r > 0.5).sum()), vis_poses_grad=m.poses.grad, vis_quats_grad=m.quats.grad)
+
+
 def gen_timing():
     """Not a fixture: wall time of the reference itself (torch CPU, this container) on the bench workload's shape, for
     the record kept in profiles/r01_reference_cpu_timing.txt.  python tests/golden/make_golden.py timing"""

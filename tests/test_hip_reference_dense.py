@@ -77,3 +77,28 @@ def test_hip_on_what_the_stress_runs_found(name, dense):
     assert rep["inside_bar"] >= 2 * len(d["poses"]) - 4, rep
     warnings.warn(f"{name} ({'dense' if dense else 'culled'}): {rep['inside_bar']} gradient rows within 1e-5 of the reference, {rep['excused']} within "
                   f"what +-{2 * MARGIN:g} in p_hat is worth to their waypoint (worst {rep['worst']:.1e} of the largest row, worth {rep['worst_worth']:.1e})")
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_hip_full_size_against_the_reference(dense):
+    """1 M points x 16 waypoints against the reference's own f32 results at that size (make_golden.py full; the oracle's twin:
+    tests/test_oracle_golden.py::test_full_size_against_the_reference)."""
+    from trajectory_optimization_amd.model import ModelTraj
+    d = load_reference_case("traj_full_1m_16")
+    dev = torch.device("cuda:0")
+    m = ModelTraj(torch.from_numpy(d["points"]), torch.from_numpy(d["poses"]), torch.from_numpy(d["quats"]), torch.from_numpy(K), IW, IH,
+                  min_dist=d["clip"][0], max_dist=d["clip"][1], device=dev, dense=dense)
+    m(vis_wps_dist=0.0)
+    m.loss["vis"].backward()
+    torch.cuda.synchronize()
+    rew = m.rewards.detach().cpu().numpy()
+    assert abs(m.loss["vis"].item() - float(d["loss_vis"])) <= 5e-6 * float(d["loss_vis"])
+    np.testing.assert_allclose(rew[::997], d["rewards_every_997th"], rtol=1e-5, atol=0)
+    assert abs(float(rew.astype(np.float64).sum()) - float(d["rewards_sum"])) <= 1e-6 * float(d["rewards_sum"])
+    assert abs(int((rew > 0.5).sum()) - int(d["rewards_above_half"])) <= 2
+    gp, gq = m.poses.grad.cpu().numpy(), m.quats.grad.cpu().numpy()
+    rep = conditional_gradient_report(d, gp, gq, MARGIN)
+    assert rep["kept"] >= len(d["poses"]) - 1
+    warnings.warn(f"1 M x 16 ({'dense' if dense else 'culled'}) against the reference's f32 results: {rep['kept']} waypoints within 1e-5 (worst "
+                  f"{rep['worst_kept']:.1e} of the largest row, {rep['worst_kept_own_row']:.1e} of their own row), {rep['excluded']} excluded; "
+                  f"global rel_inf poses {rel_inf(gp, d['vis_poses_grad']):.1e} quats {rel_inf(gq, d['vis_quats_grad']):.1e}")

@@ -68,6 +68,23 @@ def test_conditional_gradient_bar_against_the_reference(name, prec):
         assert rep["excluded"] >= 1   # the configurations were picked for having such a waypoint
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_full_size_against_the_reference(prec):
+    """The reference ITSELF at the bench cloud's size (1 M points x 16 waypoints, make_golden.py full): loss, every 997th reward,
+    the rewards' sum, the number of points that gained anything, and the gradients under the conditional 1e-5 bar."""
+    from conftest import conditional_gradient_report, load_reference_case
+    from test_hip_conditioning import MARGIN
+    d = load_reference_case("traj_full_1m_16")
+    fwd = oracle.traj_forward(d["points"], d["poses"], d["quats"], K, IW, IH, d["clip"][0], d["clip"][1], prec=prec)
+    assert abs(fwd["loss_vis"] - float(d["loss_vis"])) <= 2e-6 * float(d["loss_vis"])
+    np.testing.assert_allclose(fwd["rewards"][::997], d["rewards_every_997th"], rtol=2e-5, atol=0)
+    assert abs(float(fwd["rewards"].astype(np.float64).sum()) - float(d["rewards_sum"])) <= 1e-6 * float(d["rewards_sum"])
+    assert abs(int((fwd["rewards"] > 0.5).sum()) - int(d["rewards_above_half"])) <= 2   # (a point exactly on p_hat = 1/2 may fall either way)
+    pg, qg = oracle.traj_backward(d["points"], d["poses"], d["quats"], K, IW, IH, fwd, min_dist=d["clip"][0], max_dist=d["clip"][1], prec=prec)
+    rep = conditional_gradient_report(d, pg, qg, MARGIN)
+    assert rep["kept"] >= len(d["poses"]) - 1
+
+
 STRESS_FIXTURES = ["traj_stress_23_4", "traj_stress_31_83", "traj_stress_31_101", "traj_stress_23_134"]
 
 
