@@ -716,3 +716,37 @@ def test_optimize_trajectories_equals_independent_runs(dev):
     with pytest.raises(ValueError):
         optimize_trajectories([batch[0], ModelTraj(P, torch.from_numpy(paths[0][0][:9]), torch.from_numpy(paths[0][1][:9]),
                                                     torch.from_numpy(K), IW, IH, device=dev)], **kw)
+
+
+def test_models_share_one_packed_cloud(dev):
+    """One packed cloud for many models (the reference builds a model per message over the same map,
+    /root/reference/src/trajectory_optimization.py:129-136): ModelTraj(cloud, ...), ModelTraj(points, ..., cloud=model) and
+    ModelTraj.sharing_cloud_of pack nothing, hold the SAME blob, and give the bits of a model that packed its own copy."""
+    from trajectory_optimization_amd import ops
+    from trajectory_optimization_amd.model import ModelTraj
+    from trajectory_optimization_amd.optimizer import optimize_trajectories
+    pts = synth.make_cloud(60_000, seed=64)
+    P = torch.from_numpy(pts).to(dev)
+    paths = [synth.make_path(11, optical=True, jitter_seed=90 + i) for i in range(3)]
+    Kt = torch.from_numpy(K)
+    own = [ModelTraj(P, torch.from_numpy(p), torch.from_numpy(q), Kt, IW, IH, device=dev) for p, q in paths]
+    cloud = ops.PackedCloud(P)
+    m0 = ModelTraj(cloud, torch.from_numpy(paths[0][0]), torch.from_numpy(paths[0][1]), Kt, IW, IH, device=dev)
+    m1 = ModelTraj(P, torch.from_numpy(paths[1][0]), torch.from_numpy(paths[1][1]), Kt, IW, IH, device=dev, cloud=m0)
+    m2 = ModelTraj.sharing_cloud_of(m0, torch.from_numpy(paths[2][0]), torch.from_numpy(paths[2][1]))
+    shared = [m0, m1, m2]
+    assert all(m._cloud is cloud for m in shared) and all(m.points.data_ptr() == P.data_ptr() for m in shared)
+    for a, b in zip(own, shared):
+        la, lb = a(vis_wps_dist=0.0), b(vis_wps_dist=0.0)
+        la.backward()
+        lb.backward()
+        assert torch.equal(la, lb) and torch.equal(a.rewards, b.rewards)
+        assert torch.equal(a.poses.grad, b.poses.grad) and torch.equal(a.quats.grad, b.quats.grad)
+    kw = dict(n_opt_steps=4, lr_pose=0.05, lr_quat=0.01, rewards_th=1e9, vis_wps_dist=0.0)
+    ra, rb = optimize_trajectories(own, **kw), optimize_trajectories(shared, **kw)
+    for a, b, x, y in zip(own, shared, ra, rb):
+        assert torch.equal(a.poses.data, b.poses.data) and x.losses == y.losses
+    with pytest.raises(ValueError):
+        ModelTraj(ops.PackedCloud(P, sort=False), torch.from_numpy(paths[0][0]), torch.from_numpy(paths[0][1]), Kt, IW, IH, device=dev)
+    with pytest.raises(ValueError):
+        ModelTraj(P[:100], torch.from_numpy(paths[0][0]), torch.from_numpy(paths[0][1]), Kt, IW, IH, device=dev, cloud=cloud)

@@ -6,7 +6,11 @@ k_traj_probe / _pass1_cull / _sparse / _pairs / _finish; the shipped library has
 per kernel: the span from its first block's start to its last block's end, how far apart the blocks start, and the timeline of the
 median and of the slowest block (ns from the block's own start).
 
-    python tools/kernel_timeline.py [culled|dense] [extent_xy] [moved_steps] > profiles/rNN_small_kernel_timelines.txt
+    python tools/kernel_timeline.py [culled|dense] [extent_xy] [moved_steps] [waypoints] [trajectories] > profiles/rNN_small_kernel_timelines.txt
+
+waypoints (default 128) per trajectory; trajectories > 1: that many trajectories side by side (0.8 m apart, tools/time_multi.py's
+set) as ONE batch of virtual waypoints (tohip_traj_forward_backward_multi) — the large-W regime: 1 024 virtual waypoints either
+as one trajectory (BASELINE config 4's work on one GPU) or as eight.
 
 moved_steps > 0: the trajectory first takes that many optimiser steps (optimize_trajectory, lr 0.1 / 0.02): the step a run ends
 with, not the one it starts with (more flagged pairs in more candidate slots).
@@ -43,6 +47,8 @@ def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "culled"
     xy = float(sys.argv[2]) if len(sys.argv) > 2 else 40.0
     moved = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    wps = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    n_traj = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     so = os.path.join(tempfile.gettempdir(), "libtrajopt_stamps.so")
     subprocess.check_call([_lib.HIPCC] + _lib.HIPCC_FLAGS + ["-DTOHIP_STAMPS", _lib.SRC, "-o", so])
     _lib.LIB_PATH = so   # before the first lib() call: this process runs the diagnostic build
@@ -53,7 +59,11 @@ def main():
     dev = torch.device("cuda:0")
     cam = ops.Camera(synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT)
     pts = synth.make_cloud(bench.N_POINTS, seed=0, extent=(xy, xy, 4.0))
-    poses, quats = synth.make_path(bench.WPS_PER_GPU, optical=True, scale=xy / 40.0)
+    wps = wps or bench.WPS_PER_GPU
+    poses, quats = synth.make_path(wps, optical=True, scale=xy / 40.0)
+    if n_traj > 1:
+        poses = np.concatenate([poses + np.float32([0.0, 0.8 * i - 0.4 * n_traj, 0.0]) for i in range(n_traj)])
+        quats = np.concatenate([quats] * n_traj)
     cloud = ops.PackedCloud(torch.from_numpy(pts).to(dev))
     p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
     if moved > 0:
@@ -62,20 +72,24 @@ def main():
         m = ModelTraj(torch.from_numpy(pts).to(dev), p, q, torch.from_numpy(synth.K_INTRINS), synth.IMG_WIDTH, synth.IMG_HEIGHT, device=dev)
         optimize_trajectory(m, n_opt_steps=moved, lr_pose=0.1, lr_quat=0.02, rewards_th=1e9, vis_wps_dist=0.0)
         p, q = m.poses.data.clone(), m.quats.data.clone()
-    ws = ops.TrajWorkspace(cloud, bench.WPS_PER_GPU)
-    gout = torch.ones(1, device=dev)
+    ws = ops.TrajWorkspace(cloud, wps * n_traj, n_traj)
+    gout = torch.ones(n_traj, device=dev)
+    toff = (torch.arange(n_traj + 1, dtype=torch.int32) * wps).to(dev)
     flags = ops.DENSE if mode == "dense" else 0
     buf = (ctypes.c_ulonglong * (len(KERNELS) * BLOCKS * N))()
     runs = []
     for it in range(16):
         L.tohip_stamps_clear()
-        ops.traj_forward_backward(cloud, p, q, cam, ws, gout, flags=flags)
+        if n_traj > 1:
+            ops.traj_forward_backward_multi(cloud, p, q, toff, cam, ws, gout, flags=flags)
+        else:
+            ops.traj_forward_backward(cloud, p, q, cam, ws, gout, flags=flags)
         torch.cuda.synchronize()
         L.tohip_stamps_read(buf)
         if it >= 6:
             runs.append(np.array(buf[:], dtype=np.int64).reshape(len(KERNELS), BLOCKS, N))
     st = ops.traj_step_stats(cloud, ws)
-    print(f"# {bench.N_POINTS} points x {bench.WPS_PER_GPU} waypoints, {mode}, {xy:g} x {xy:g} x 4 m" + (f", after {moved} optimiser steps" if moved else "") +
+    print(f"# {bench.N_POINTS} points x {n_traj} x {wps} waypoints, {mode}, {xy:g} x {xy:g} x 4 m" + (f", after {moved} optimiser steps" if moved else "") +
           f" ({st['flagged_pairs']} flagged pairs in {st['candidate_slots']} candidate slots); ns, 100 MHz counter (10 ns steps); "
           f"thread 0 of each block; last of {len(runs)} stamped steps")
     a = runs[-1]

@@ -1963,6 +1963,7 @@ struct TrajStep {
     const uint32_t* occ;
     int64_t occw;
     bool cull;
+    int max_traj_v = 0;  // several trajectories: the virtual waypoints of the longest one when the host knows (0: it does not)
     int wp_stride = 1;   // rows between two evaluated waypoints in the arrays handed to the probe
     int traj_rows = 0;   // > 0: rows every trajectory owns in those arrays (its evaluated waypoints are rows 0, wp_stride, ... of its own)
     OptStep opt = OptStep{};   // mode != 0: the step's prologue / epilogue ride in the probe's, the pairs' and the finish launches (opt_step.hpp)
@@ -2088,10 +2089,30 @@ inline int sparse_waves() {
     static const int nw = [] { const char* e = getenv("TOHIP_SPARSE_WAVES"); const int v = e ? atoi(e) : 0; return v == 16 ? 16 : 4; }();
     return nw;
 }
+// one 16-wave block per CU, all resident: the pairs are dealt to the grid's waves
+inline int pair_blocks() {
+    static const int cus = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) return prop.multiProcessorCount;
+        return 256;
+    }();
+    return cus;
+}
+
+// Do the flag words of any ONE trajectory fit the small array (8 words: 36 KB of LDS, four 4-wave blocks to a CU instead of three)?
+// One trajectory starts at word 0; one of several may start anywhere inside a word.  max_traj_v = 0: the lengths are on the device
+// only (the generic tohip_*_multi calls), and the blocks hold the large array.
+inline bool sparse_small_flags(const TrajStep& s) {
+    if (s.n_traj == 1) return s.V <= 8 * 64;
+    return s.max_traj_v > 0 && s.max_traj_v <= 7 * 64;
+}
 inline int sparse_blocks(const TrajStep& s, int nw) {
-    // per trajectory: one block per candidate while they fit on the chip at once (a block that finds nothing still costs its
-    // launch and its scan); with several trajectories that many in all
-    const int64_t resident = nw == 16 ? 512 : 1024;
+    // as many blocks as are RESIDENT at once — four 4-wave blocks to a CU with the small flag array, three with the large one, two of
+    // sixteen waves — shared evenly by the trajectories: a block walks its trajectory's candidates q, q + S, ..., and a block that
+    // waits for a CU starts its walk when the others are half way through theirs (r04 launched 1 024 blocks of which 768 were
+    // resident for eight trajectories: 72 us where 55 do)
+    const int64_t resident = (int64_t)pair_blocks() * (nw == 16 ? 2 : (sparse_small_flags(s) ? 4 : 3));
     const int64_t per_traj = std::max<int64_t>(1, std::min<int64_t>(s.pl.nslots, resident / s.n_traj));
     return (int)(per_traj * s.n_traj);
 }
@@ -2099,8 +2120,7 @@ inline int sparse_blocks(const TrajStep& s, int nw) {
 template <int MODE, bool OCC, int NW>
 inline void launch_sparse_nw(const TrajStep& s, const SparseArgs& a) {
     const int grid = sparse_blocks(s, NW) + (s.opt.mode ? s.opt.n_traj : 0);   // (+ the step's prologue blocks)
-    // one trajectory of at most TO_SP_STAGE virtual waypoints: its five flag words are all a block holds
-    if (s.n_traj == 1 && s.V <= TO_SP_STAGE) k_traj_sparse<MODE, OCC, NW, 8><<<grid, NW * 64, 0, s.st>>>(a, s.opt);
+    if (sparse_small_flags(s)) k_traj_sparse<MODE, OCC, NW, 8><<<grid, NW * 64, 0, s.st>>>(a, s.opt);
     else k_traj_sparse<MODE, OCC, NW, TO_SP_MAXW><<<grid, NW * 64, 0, s.st>>>(a, s.opt);
 }
 
@@ -2111,17 +2131,6 @@ inline int launch_sparse(const TrajStep& s, const SparseArgs& a) {
     else { if (w16) launch_sparse_nw<MODE, false, 16>(s, a); else launch_sparse_nw<MODE, false, 4>(s, a); }
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
-}
-
-// one 16-wave block per CU, all resident: the pairs are dealt to the grid's waves
-inline int pair_blocks() {
-    static const int cus = [] {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) return prop.multiProcessorCount;
-        return 256;
-    }();
-    return cus;
 }
 
 inline int launch_pairs(const TrajStep& s, const SparseArgs& a) {
@@ -2374,6 +2383,7 @@ extern "C" int tohip_traj_opt_step(const tohip_traj_opt* o, int32_t step_index, 
     if (rc != TOHIP_OK) return rc;
     s.wp_stride = o->wps_step;
     s.traj_rows = (int)W;
+    s.max_traj_v = (int)(n_eval * s.C);
     OptStep& a = s.opt;
     a.mode = 1;
     a.poses = o->poses; a.quats = o->quats; a.poses0 = o->poses0;

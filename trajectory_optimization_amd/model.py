@@ -781,7 +781,7 @@ class ModelTraj(nn.Module):
                  smoothness_weight=14.0, traj_length_weight=0.02,
                  device=torch.device('cuda'),
                  *, rig=None, shard=None, dense=False, occlusion=None, occlusion_limits=(1.0, 15.0), occlusion_refresh_every=1,
-                 n_points_global=None):
+                 n_points_global=None, cloud=None):
         super().__init__()
         assert wps_poses.dim() == wps_quats.dim()
         assert wps_poses.size()[1] == 3
@@ -789,7 +789,24 @@ class ModelTraj(nn.Module):
 
         self.device = torch.device(device)
         self._n_global = None
-        if shard is not None and getattr(shard, "kind", "waypoints") == "points":
+        # One packed cloud for many models: the reference builds a model per (cloud, path) message pair over the same map
+        # (/root/reference/src/trajectory_optimization.py:129-136); packing — bounding box, Morton sort, tile bounds — costs several
+        # optimiser steps and 20 B/point.  `points` may be an ops.PackedCloud, or `cloud=` names one (or a ModelTraj whose cloud to share).
+        if isinstance(points, ops.PackedCloud):
+            cloud, points = points, None
+        if isinstance(cloud, ModelTraj):
+            cloud = cloud._cloud
+        if cloud is not None:
+            if not isinstance(cloud, ops.PackedCloud) or not cloud.sorted:
+                raise ValueError("cloud= must be an ops.PackedCloud in Morton order (sort=True) or a ModelTraj")
+            if shard is not None and getattr(shard, "kind", "waypoints") == "points":
+                raise ValueError("a shared packed cloud holds the whole cloud: not available with PointShard")
+            if cloud.device != (self.device if self.device.index is not None else torch.device(self.device.type, torch.cuda.current_device())):
+                raise ValueError(f"the packed cloud lives on {cloud.device}, the model on {self.device}")
+            if points is not None and tuple(points.shape) != tuple(cloud.points.shape):
+                raise ValueError("cloud= does not hold these points")
+            self.points = cloud.points
+        elif shard is not None and getattr(shard, "kind", "waypoints") == "points":
             # point sharding: this rank keeps its own rows of the cloud (the whole cloud is handed in, or — n_points_global — the
             # rows already); model.rewards are those rows' rewards
             pts = torch.as_tensor(points, dtype=torch.float32)
@@ -827,7 +844,7 @@ class ModelTraj(nn.Module):
         self.traj_length_weight = traj_length_weight
 
         self.to(self.device)
-        self._cloud = ops.PackedCloud(self.points)
+        self._cloud = cloud if cloud is not None else ops.PackedCloud(self.points)
         self._cam = ops.Camera(self.K, self.img_width, self.img_height, min_dist, max_dist, self.eps)
         self._rig = ops.CameraRig(rig[0], rig[1], self.device) if rig is not None else None
         self._shard = shard if shard is not None else _NoShard()
@@ -852,6 +869,15 @@ class ModelTraj(nn.Module):
         self.fast_backward = True
         for p in (self.poses, self.quats):
             tag_parameter(p)   # torch.optim.Adam.step() may update them with one launch (optimizer.accelerate_torch_adam)
+
+    @classmethod
+    def sharing_cloud_of(cls, other, wps_poses, wps_quats, **kw):
+        """A model of another trajectory over `other`'s cloud: same packed cloud (not packed again), camera and device; keyword
+        arguments as the constructor's (weights, rig, dense, ...)."""
+        kw.setdefault("device", other.device)
+        kw.setdefault("min_dist", other.pc_clip_limits[0])
+        kw.setdefault("max_dist", other.pc_clip_limits[1])
+        return cls(other._cloud, wps_poses, wps_quats, other.K, other.img_width, other.img_height, **kw)
 
     def refresh_occlusion(self):
         """The next forward rebuilds the occlusion masks whatever occlusion_refresh_every says."""

@@ -24,8 +24,10 @@ def _require_cuda(t, what):
 
 
 class PackedCloud:
-    """The cloud in the kernels' layout (x|y|z, padded); built once per model (the cloud is constant over
-    an optimisation run: /root/reference/src/model.py:80,174)."""
+    """The cloud in the kernels' layout (x|y|z, padded); built once per CLOUD (it is constant over an optimisation run:
+    /root/reference/src/model.py:80,174) and shared by every model over it — the reference builds a model per message pair over the
+    same map (/root/reference/src/trajectory_optimization.py:129-136): `ModelTraj(cloud, ...)` / `ModelTraj(points, ..., cloud=other)`
+    take a packed cloud as it is.  `points` keeps the caller's (N,3) f32 tensor (the models' `.points`)."""
 
     def __init__(self, points, sort=True):
         _require_cuda(points, "points")
@@ -33,6 +35,7 @@ class PackedCloud:
         if pts.dim() != 2 or pts.shape[1] != 3 or pts.shape[0] == 0:
             raise ValueError(f"points must be (N,3) with N>0, got {tuple(pts.shape)}")
         L = _lib.lib()
+        self.points, self.sorted = pts, bool(sort)
         self.n = pts.shape[0]
         self.npad = L.tohip_padded_points(self.n)
         self.device = pts.device
