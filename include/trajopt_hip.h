@@ -101,6 +101,12 @@ size_t tohip_traj_workspace_bytes(int64_t n_points, int64_t n_virtual);
  * TOHIP_TRAJ_STRIDE(step) the n_wps evaluated waypoints are rows 0, step, 2 step, ... of poses / quats, read in place (one
  * trajectory; the backward entry points ignore the bits: gradient rows are compact, one per evaluated waypoint). */
 #define TOHIP_TRAJ_STRIDE(step) ((((step) - 1) & 0xffff) << 8)
+/* tohip_traj_opt.flags only: the two N-sized OUTPUTS of a step — lo_sum and rewards, per trajectory — are written by the run's
+ * last step (step_index == n_steps - 1) only.  Every step still computes every reward (their sum, the loss and the gradients need
+ * them); what the earlier steps skip is refilling and scattering two vectors of N floats per trajectory that the next step
+ * overwrites unread — 64 MB of stores per step for eight trajectories over 1 M points
+ * (/root/reference/src/trajectory_optimization.py:147-157 publishes model.rewards once, after the loop). */
+#define TOHIP_TRAJ_OPT_LAST_OUTPUTS 2
 
 /* Forward over the W evaluated waypoints (caller has applied wps_step, model.py:214-217):
  * to_camera_frame -> get_dist_mask * get_fov_mask -> per-waypoint (p-min)/max -> clip -> log-odds,
@@ -310,7 +316,7 @@ typedef struct tohip_traj_opt {
     int64_t n_points;
     int64_t n_wps;             /* W: waypoints of ONE trajectory */
     int32_t wps_step;          /* every wps_step-th waypoint is evaluated for visibility */
-    int32_t flags;             /* TOHIP_TRAJ_DENSE or 0 */
+    int32_t flags;             /* TOHIP_TRAJ_DENSE, TOHIP_TRAJ_OPT_LAST_OUTPUTS or 0 */
     int32_t n_traj;            /* trajectories laid end to end: rows b * W .. b * W + W - 1 of every per-waypoint array */
     int32_t n_steps;           /* rows of the logs below */
     const int32_t *traj_offsets; /* n_traj + 1 device int32: b * ceil(W / wps_step) (NULL when n_traj == 1) */
@@ -324,9 +330,9 @@ typedef struct tohip_traj_opt {
     float *exp_avg_p, *exp_avg_sq_p, *exp_avg_q, *exp_avg_sq_q;   /* Adam moments, zero before the first step */
     float *poses_grad, *quats_grad;   /* outputs (n_traj W, 3 / 4): the step's full gradients (what .grad would hold) */
     float *poses_grad_eval, *quats_grad_eval; /* outputs, may be NULL: (n_traj n_eval, 3 / 4) visibility gradient rows */
-    float *lo_sum;             /* n_traj x Npad (packed order) */
+    float *lo_sum;             /* n_traj x Npad (packed order); with TOHIP_TRAJ_OPT_LAST_OUTPUTS valid after the last step only */
     float *minmax;             /* (V, 2), V = n_traj * n_eval * max(1, n_cams) */
-    float *rewards;            /* n_traj x N, caller's point order */
+    float *rewards;            /* n_traj x N, caller's point order; with TOHIP_TRAJ_OPT_LAST_OUTPUTS valid after the last step only */
     float *scalars;            /* n_traj x 4: mean reward, loss_vis, d loss_vis / d reward, - */
     float *loss_log;           /* n_traj x n_steps x 8: row s of a trajectory = (vis, l2, length, smooth, total) of its s-th step */
     float *state_log;          /* n_traj x (n_steps + 1) x 8, row 0 ZERO before the first step: row i = the early-stop state before

@@ -750,3 +750,36 @@ def test_models_share_one_packed_cloud(dev):
         ModelTraj(ops.PackedCloud(P, sort=False), torch.from_numpy(paths[0][0]), torch.from_numpy(paths[0][1]), Kt, IW, IH, device=dev)
     with pytest.raises(ValueError):
         ModelTraj(P[:100], torch.from_numpy(paths[0][0]), torch.from_numpy(paths[0][1]), Kt, IW, IH, device=dev, cloud=cloud)
+
+
+def test_outputs_left_to_the_last_step_change_nothing(dev):
+    """TOHIP_TRAJ_OPT_LAST_OUTPUTS (optimize_trajectory's default): the N-sized outputs — rewards, log-odds — are written by the run's
+    last step only; every step computes them.  Poses, losses, stop step and the rewards handed back are those of a run whose
+    every step writes everything, bit for bit; a run cut short (run(n) with n below the planned steps) writes them every step."""
+    from trajectory_optimization_amd.model import ModelTraj
+    from trajectory_optimization_amd import optimizer
+    pts = torch.from_numpy(synth.make_cloud(90_000, seed=65)).to(dev)
+    paths = [synth.make_path(12, optical=True, jitter_seed=95 + i) for i in range(3)]
+    Kt = torch.from_numpy(K)
+
+    def models():
+        m0 = ModelTraj(pts, torch.from_numpy(paths[0][0]), torch.from_numpy(paths[0][1]), Kt, IW, IH, device=dev)
+        return [m0] + [ModelTraj.sharing_cloud_of(m0, torch.from_numpy(p), torch.from_numpy(q)) for p, q in paths[1:]]
+    args = (7, 0.05, 0.01, 1.003, 0.5, 0.0, (0.9, 0.999), 1e-8)
+    for B in (1, 3):
+        lean, full = optimizer._OptRun(models()[:B], *args), optimizer._OptRun(models()[:B], *args)
+        assert lean.c.flags & optimizer.LAST_OUTPUTS
+        full.c.flags &= ~optimizer.LAST_OUTPUTS
+        lean.rewards.fill_(-1.0)
+        lean.run(7)
+        full.run(7)
+        ra, rb = lean.results(7), full.results(7)
+        assert torch.equal(lean.rewards, full.rewards) and torch.equal(lean.lo_sum, full.lo_sum) and float(lean.rewards.min()) >= 0.5
+        for a, b, x, y in zip(lean.models, full.models, ra, rb):
+            assert torch.equal(a.poses.data, b.poses.data) and torch.equal(a.quats.data, b.quats.data)
+            assert x.losses == y.losses and x.steps_taken == y.steps_taken and x.stopped == y.stopped
+        short = optimizer._OptRun(models()[:B], *args)
+        short.run(4)   # not the planned seven: the flag is dropped, the rewards are there
+        ref = optimizer._OptRun(models()[:B], 4, *args[1:])
+        ref.run(4)
+        assert torch.equal(short.rewards, ref.rewards)

@@ -76,8 +76,10 @@ struct CloudView {
     int nsamples, sample_step;
 };
 
-#define TO_PROBE_MAX 8192   // capacity of the sample section: step = max(1, n / 4096) gives at most 8191 samples
-static inline int probe_step(int64_t n) { const int64_t s = n / 4096; return (int)(s < 1 ? 1 : s); }
+#define TO_PROBE_MAX 8192   // capacity of the sample section (its layout since r02)
+// every step-th sorted point is a sample: step = ceil(n / 4096) gives at most 4 096 of them — a whole number of rounds of the probe's
+// blocks (the floor of r01-r04 gave 4 099 samples at 1 M points: a third round of loads for three samples in the 256-thread blocks)
+static inline int probe_step(int64_t n) { const int64_t s = (n + 4095) / 4096; return (int)(s < 1 ? 1 : s); }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -156,11 +158,13 @@ __device__ __forceinline__ float to_log2(float x) { return __builtin_amdgcn_logf
 // Squared-distance bound thr such that  d2 > thr  =>  exp(-0.5 * d2 * inv_var) < tau * (1 - 1e-4), i.e. the
 // soft visibility p = S * exp(-0.5 (d2 inv_var + ...)) <= that bound cannot reach tau.  The 1e-4 margin covers
 // every rounding in p (~1e-6).  tau outside (0,1) -> +inf (never cull).
+// (f32 on the hardware's log unit, 1 ulp, rounded away by 1e-5: the probe's thread 0 has every block of its launch waiting, and
+// the double-precision log of r01-r04 was half a microsecond of it.  A larger bound only evaluates a few more pairs.)
 __device__ inline void cull_threshold(float tau, float inv_var, float* thr, float* sthr) {
-    const double t = (double)tau * (1.0 - 1e-4);
+    const float t = tau * (1.0f - 1e-4f);
     float th = INFINITY;
-    if (t > 0.0 && t < 1.0) {
-        th = (float)(-2.0 * log(t) / (double)inv_var * (1.0 + 1e-6));
+    if (t > 0.0f && t < 1.0f) {
+        th = (-2.0f * 0.693147180559945f) * to_log2(t) / inv_var * (1.0f + 1e-5f);
         th = nextafterf(th, INFINITY);
     }
     *thr = th;

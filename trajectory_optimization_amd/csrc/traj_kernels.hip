@@ -156,11 +156,14 @@ struct TieRec {            // slots whose max equals the waypoint's max / whose 
 __device__ __forceinline__ void prep_wayrec(int v, const float* __restrict__ poses, const float* __restrict__ quats, int C,
                                             const float* __restrict__ rig_q, const float* __restrict__ rig_t,
                                             const EvalK& k, WayRec* __restrict__ rec, WayCold* __restrict__ cold,
-                                            const int* __restrict__ traj_off, int n_traj, int wp_stride = 1, int traj_rows = 0) {
+                                            const int* __restrict__ traj_off, int n_traj, int wp_stride = 1, int traj_rows = 0, int seg_known = -1) {
     const int w = v / C, c = v - w * C;
-    int seg = 0;
-    if (traj_off != nullptr)
+    int seg = seg_known;
+    if (traj_off != nullptr && seg < 0) {
+        seg = 0;
         while (seg + 1 < n_traj && w >= traj_off[seg + 1]) ++seg;
+    }
+    if (seg < 0) seg = 0;
     // wp_stride > 1: the evaluated waypoints are every wp_stride-th row of the caller's arrays (model.py:215-217), read in place;
     // traj_rows > 0: every trajectory owns traj_rows rows of them (its evaluated waypoints are rows 0, wp_stride, ... of its own)
     {
@@ -286,6 +289,7 @@ struct OutInit {   // n_traj log-odds vectors of npad floats (and rewards vector
     int n_traj;
 };
 __device__ __forceinline__ void init_outputs(int64_t base, const OutInit& o) {
+    if (o.lo_zero == nullptr) return;   // (a step of an optimisation run that leaves the N-sized outputs to the last one)
     // streaming stores: nothing of this is read again by this kernel
     for (int b = 0; b < o.n_traj; ++b) {
         __builtin_nontemporal_store(f4v{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4v*>(o.lo_zero + (int64_t)b * o.npad + base));
@@ -357,12 +361,24 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
         px[j] = cv.samples[sc]; py[j] = cv.samples[TO_PROBE_MAX + sc]; pz[j] = cv.samples[2 * TO_PROBE_MAX + sc];
     }
     __shared__ WayRec srec;   // the block's record: built by thread 0, read by everybody from LDS (not back from global memory)
-    if (t == 0) { prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, &srec - v, cold, traj_off, n_traj, wp_stride, traj_rows); rec[v] = srec; }
+    // which trajectory is the waypoint's?  Wave 0 looks at up to 64 offsets at once (a walk along them was a dependent load per
+    // trajectory: 1.2 us more for the eighth of eight)
+    int seg = -1;
+    if (traj_off != nullptr && t < 64) {
+        seg = 0;
+        const int w = v / C;
+        for (int j0 = 1; j0 < n_traj; j0 += 64) {
+            const int j = j0 + t;
+            seg += __popcll(__ballot(j < n_traj && w >= traj_off[j]));   // the offsets ascend: the count of those at or below w
+        }
+    }
+    if (t == 0) { prep_wayrec(v, poses, quats, C, rig_q, rig_t, k, &srec - v, cold, traj_off, n_traj, wp_stride, traj_rows, seg); rec[v] = srec; }
     __syncthreads();
     TO_STAMP(TO_STAMP_PROBE, 1);   // record built, samples requested
     const WayRec r = srec;
     float mx = 0.f, mn = INFINITY;
-    for (int rd = 0; rd < kRounds; ++rd) {
+    const int rounds = min(kRounds, (cv.nsamples + TO_PROBE_THREADS * kBatch - 1) / (TO_PROBE_THREADS * kBatch));   // (a round is a memory round trip)
+    for (int rd = 0; rd < rounds; ++rd) {
         if (rd > 0) {
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
@@ -371,13 +387,17 @@ k_traj_probe(CloudView cv, const float* __restrict__ poses, const float* __restr
                 px[j] = cv.samples[sc]; py[j] = cv.samples[TO_PROBE_MAX + sc]; pz[j] = cv.samples[2 * TO_PROBE_MAX + sc];
             }
         }
+        // two samples to a packed instruction (per element the operations of vis_p: the same bits): with a thousand waypoints the
+        // probe is ~6 % of a dense pass 1 and bound by instruction issue, not by its chain of loads
 #pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const int sj = t + (rd * kBatch + j) * TO_PROBE_THREADS;
-            if (sj < cv.nsamples) {
-                const float p = vis_p(r, k, px[j], py[j], pz[j]) * occ_one(occ, occw, v, (int64_t)sj * cv.sample_step);
-                mx = fmaxf(mx, p);
-                mn = fminf(mn, p);
+        for (int j = 0; j < kBatch; j += 2) {
+            const int sj0 = t + (rd * kBatch + j) * TO_PROBE_THREADS, sj1 = sj0 + TO_PROBE_THREADS;
+            if (sj0 < cv.nsamples) {   // (sj1 > sj0: the second one is the first to run out)
+                const f2 p = vis_p_pk(r, k, f2{px[j], px[j + 1]}, f2{py[j], py[j + 1]}, f2{pz[j], pz[j + 1]}) *
+                             f2{occ_one(occ, occw, v, (int64_t)sj0 * cv.sample_step), sj1 < cv.nsamples ? occ_one(occ, occw, v, (int64_t)sj1 * cv.sample_step) : 1.0f};
+                mx = fmaxf(mx, p.x);
+                mn = fminf(mn, p.x);
+                if (sj1 < cv.nsamples) { mx = fmaxf(mx, p.y); mn = fminf(mn, p.y); }
             }
         }
     }
@@ -606,8 +626,9 @@ k_traj_pass1_cull(CloudView cv, const WayRec* __restrict__ rec, int V, EvalK k, 
     TO_STAMP(TO_STAMP_CULL, 0);
     for (int w = t; w < fv_words; w += NW * 64) { L.row[w] = live[(int64_t)v * fv_words + w]; L.cand[w] = 0ull; }
     // the outputs' start values (the dense pass 1 sets them itself): stores nobody here waits for
-    for (int64_t i = (((int64_t)v * gridDim.x + blockIdx.x) * (NW * 64) + t) * 4; i < oi.npad; i += (int64_t)gridDim.y * gridDim.x * (NW * 64) * 4)
-        init_outputs(i, oi);
+    if (oi.lo_zero != nullptr)
+        for (int64_t i = (((int64_t)v * gridDim.x + blockIdx.x) * (NW * 64) + t) * 4; i < oi.npad; i += (int64_t)gridDim.y * gridDim.x * (NW * 64) * 4)
+            init_outputs(i, oi);
     __syncthreads();
     TO_STAMP(TO_STAMP_CULL, 1);   // the waypoint's row of reachable slots is in LDS
     if (t < 64) {   // exclusive prefix of the words' popcounts, 64 words at a time
@@ -942,7 +963,7 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
                 s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
             }
             lo[0] = s.x; lo[1] = s.y; lo[2] = s.z; lo[3] = s.w;
-            if (wave == 0) *reinterpret_cast<float4*>(a.lo_sum + (int64_t)tr * a.cv.npad + base) = s;
+            if (wave == 0 && a.lo_sum != nullptr) *reinterpret_cast<float4*>(a.lo_sum + (int64_t)tr * a.cv.npad + base) = s;
         }
 
         // ---- rewards of the slot's points (wave 0) ----
@@ -957,7 +978,7 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
                 if (lo[j] != lo[j]) rw = lo[j];
                 un[j] = base + j < a.cv.n ? 1.0f * rw * (1.0f - rw) : 0.f;   // the pair kernel's d reward / d lo_sum of this point, bit for bit
                 if (base + j < a.cv.n) {                      // pads are not points
-                    if (!a.prefilled || lo[j] != 0.f) a.rewards[(int64_t)tr * a.cv.n + o[j]] = rw;
+                    if (a.rewards != nullptr && (!a.prefilled || lo[j] != 0.f)) a.rewards[(int64_t)tr * a.cv.n + o[j]] = rw;
                     if (rw != rw) fnan = true;
                     else fsum += reward_fixed(rw, a.shift) - (1ll << (a.shift - 1));
                 }
@@ -1966,6 +1987,7 @@ struct TrajStep {
     int max_traj_v = 0;  // several trajectories: the virtual waypoints of the longest one when the host knows (0: it does not)
     int wp_stride = 1;   // rows between two evaluated waypoints in the arrays handed to the probe
     int traj_rows = 0;   // > 0: rows every trajectory owns in those arrays (its evaluated waypoints are rows 0, wp_stride, ... of its own)
+    bool lean = false;   // an optimisation step that is not the run's last: lo_sum and rewards are nobody's to read (TOHIP_TRAJ_OPT_LAST_OUTPUTS)
     OptStep opt = OptStep{};   // mode != 0: the step's prologue / epilogue ride in the probe's, the pairs' and the finish launches (opt_step.hpp)
     float* opt_scalars = nullptr;   // opt.mode == 2: model()'s scalars (the extra block of the pairs' launch writes them)
     RewardAcc* acc;
@@ -2026,7 +2048,7 @@ inline int traj_step_init(TrajStep& s, const void* packed, int64_t n, int64_t W,
 // launches 1 and 2 of a step: records + probe, pass 1
 inline int launch_probe_pass1(const TrajStep& s, const float* poses, const float* quats, float* lo_sum, float* rewards_half) {
     const int V = (int)s.V;
-    const OutInit oi{lo_sum, rewards_half, s.cv.npad, s.n, (int)s.n_traj};
+    const OutInit oi{s.lean ? nullptr : lo_sum, s.lean ? nullptr : rewards_half, s.cv.npad, s.n, (int)s.n_traj};
     {
         TO_PROF(TOHIP_PROF_PROBE, s.st);
         const ProbeCull pc{s.cull ? 1 : 0, s.pl.nslots, s.live};
@@ -2310,9 +2332,9 @@ namespace {
 int traj_fused_forward(TrajStep& s, const float* poses, const float* quats, float* lo_sum, float* minmax, float* rewards) {
     int rc = launch_probe_pass1(s, poses, quats, lo_sum, rewards);
     if (rc != TOHIP_OK) return rc;
-    SparseArgs a = sparse_args(s, lo_sum);
+    SparseArgs a = sparse_args(s, s.lean ? nullptr : lo_sum);
     a.minmax = minmax;
-    a.rewards = rewards;
+    a.rewards = s.lean ? nullptr : rewards;
     a.prefilled = 1;
     {
         TO_PROF(TOHIP_PROF_PASS2, s.st);
@@ -2371,16 +2393,17 @@ extern "C" int tohip_traj_opt_step(const tohip_traj_opt* o, int32_t step_index, 
     if (!o || !o->packed || !o->poses || !o->quats || !o->poses0 || !o->exp_avg_p || !o->exp_avg_sq_p || !o->exp_avg_q || !o->exp_avg_sq_q ||
         !o->poses_grad || !o->quats_grad || !o->lo_sum || !o->minmax || !o->rewards || !o->scalars || !o->loss_log || !o->state_log ||
         !o->workspace || !o->scratch || o->n_points <= 0 || o->n_wps < 3 || o->wps_step < 1 || o->n_traj < 1 || step_index < 0 ||
-        step_index >= o->n_steps || (o->n_traj > 1 && !o->traj_offsets) || (o->flags >> 8) != 0)
+        step_index >= o->n_steps || (o->n_traj > 1 && !o->traj_offsets) || (o->flags & ~(TOHIP_TRAJ_DENSE | TOHIP_TRAJ_OPT_LAST_OUTPUTS)) != 0)
         return TOHIP_EINVAL;
     const int64_t W = o->n_wps, B = o->n_traj, n_eval = (W + o->wps_step - 1) / o->wps_step;
     const OptLayout l = opt_layout(W, B);
     if (o->scratch_bytes < l.total) return TOHIP_ENOSPC;
     const tohip_rig* rig = (o->rig.n_cams > 0 && o->rig.rig_quats) ? &o->rig : nullptr;
     TrajStep s;
-    int rc = traj_step_init(s, o->packed, o->n_points, B * n_eval, B, o->traj_offsets, &o->cam, rig, o->flags, nullptr, o->workspace,
+    int rc = traj_step_init(s, o->packed, o->n_points, B * n_eval, B, o->traj_offsets, &o->cam, rig, o->flags & TOHIP_TRAJ_DENSE, nullptr, o->workspace,
                             o->workspace_bytes, stream_, true);
     if (rc != TOHIP_OK) return rc;
+    s.lean = (o->flags & TOHIP_TRAJ_OPT_LAST_OUTPUTS) && step_index < o->n_steps - 1;
     s.wp_stride = o->wps_step;
     s.traj_rows = (int)W;
     s.max_traj_v = (int)(n_eval * s.C);

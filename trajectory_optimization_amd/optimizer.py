@@ -16,6 +16,9 @@ from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
 
 
+LAST_OUTPUTS = 2   # TOHIP_TRAJ_OPT_LAST_OUTPUTS
+
+
 class TrajOptResult:
     def __init__(self, steps_taken, stopped, losses, vis_gain, smooth_gain):
         self.steps_taken, self.stopped, self.losses = steps_taken, stopped, losses
@@ -57,7 +60,9 @@ class _OptRun:
         nbytes = L.tohip_traj_opt_scratch_bytes(W, B)
         self.scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         c = _lib.TrajOpt()
-        c.packed, c.n_points, c.n_wps, c.wps_step, c.flags, c.n_traj, c.n_steps = cloud.blob.data_ptr(), cloud.n, W, step_w, int(m0._flags), B, self.n_steps
+        # TOHIP_TRAJ_OPT_LAST_OUTPUTS: the rewards (and the log-odds vector) are materialised by the run's last step only — what the
+        # reference publishes after its loop (trajectory_optimization.py:147-157); every step computes them all the same
+        c.packed, c.n_points, c.n_wps, c.wps_step, c.flags, c.n_traj, c.n_steps = cloud.blob.data_ptr(), cloud.n, W, step_w, int(m0._flags) | LAST_OUTPUTS, B, self.n_steps
         c.traj_offsets = self.toff.data_ptr() if self.toff is not None else None
         c.cam = m0._cam.c
         if rig is not None:
@@ -77,6 +82,8 @@ class _OptRun:
 
     def run(self, n):
         idx = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        if n != self.n_steps:   # a run cut short has no "last step" to leave the rewards: every step writes them
+            self.c.flags &= ~LAST_OUTPUTS
         with torch.cuda.device(idx):
             stream = torch._C._cuda_getCurrentRawStream(idx)
             for i in range(n):
