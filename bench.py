@@ -384,6 +384,32 @@ def occlusion_leg(device, steps=20):
     return out
 
 
+def configs_leg(device, steps=20, warmup=5):
+    """The other named sizes on ONE GPU (BASELINE.json configs 2, 4 and 5 — the N = 1 points of their curves — and eight concurrent
+    trajectories): the loop the reference runs serially per waypoint (/root/reference/src/model.py:217-231), here with 1 024 - 1 280
+    virtual waypoints in one launch sequence.  tools/prof_multi.py's scenarios, both evaluation modes: ms per step, evaluations/s,
+    microseconds per kernel class (HIP events on the launch stream, a separate pass), what the forward found.
+    profiles/r05_multi_*_kernel_stats.csv are the rocprofv3 summaries of the same steps."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import prof_multi
+    out = {}
+    for name, key in (("c2", "config2_100k_x_32_forward_only"), ("c3", "config3_1M_x_128"), ("w1024", "config4_work_on_one_gpu_1M_x_1024"),
+                      ("cam5", "config5_work_on_one_gpu_5_cameras_x_1M_x_256"), ("multi8", "eight_trajectories_x_128_optimize_trajectories")):
+        row = {}
+        for mode in ("culled", "dense"):
+            r = prof_multi.scenario(name, mode, device, steps, warmup)
+            row.setdefault("what", r["what"])
+            row[mode] = {k: r[k] for k in ("ms_per_step", "evals_per_s", "kernel_us", "flagged_pairs", "candidate_slots", "virtual_waypoints") if k in r}
+            if mode == "culled":
+                row[mode]["evaluated_pairs"] = r["evaluated_pairs_culled"]
+            torch.cuda.empty_cache()
+        out[key] = row
+    out["note"] = ("one GPU, inputs resident; ms_per_step = wall over K steps between synchronisations after W warm-up steps; eight trajectories: "
+                   "optimizer steps (tohip_traj_opt_step, the trajectories move while they are timed), the others tohip_traj_forward_backward "
+                   "at fixed poses; kernel_us cost ~5 us per bracket: compare them with each other")
+    return out
+
+
 def density_leg(device, steps=20, warmup=3):
     """The same 1 M points x 128 waypoints in ever smaller rooms (the path scaled with the room): the headline workload flags
     0.7 % of the (256-point slot, waypoint) pairs; an indoor cloud flags 10-20 %, and the kernels after pass 1 cost in proportion.
@@ -450,9 +476,11 @@ def main():
                          "0.139 ms dense, 0.079 vs 0.075 culled - graph kernel nodes cost more than the queue they replace)")
     ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dropin", choices=["on", "off"], default="on", help="time the reference's own loop over the drop-in classes (N = 1 only)")
+    ap.add_argument("--configs", choices=["on", "off"], default="on", help="the other named sizes on one GPU: configs 2, 4, 5 and eight concurrent trajectories (N = 1 only)")
     ap.add_argument("--density", choices=["on", "off"], default="on", help="step time versus flagged fraction: 1 M points in ever smaller rooms (N = 1 only)")
     ap.add_argument("--occlusion", choices=["on", "off"], default="on", help="the occlusion-aware reward on the headline workload: ms per mask refresh and per step (N = 1 only)")
     ap.add_argument("--aux", choices=["on", "off"], default="on", help="the HBM-bound kernels around the hot path (ModelPose, flip, cull, masks, ingest) at 1 M and 16 M points")
+    ap.add_argument("--sustained", choices=["on", "off"], default="on", help="two seconds of back-to-back steps per mode: the step at settled clocks (N = 1 only)")
     ap.add_argument("--moved", choices=["on", "off"], default="on", help="time the same step on the trajectory after 100 optimiser steps (N = 1 only)")
     ap.add_argument("--dump", default=None, help="write the last dense step's outputs (scalars, gradient rows, rewards) to this .npz "
                                                  "(rank 0): tests compare runs at different N")
@@ -611,6 +639,25 @@ def main():
             out.append(1e3 * (time.perf_counter() - t0) / args.steps)
         return sorted(out)
 
+    def sustained_leg(seconds=2.0, chunk=500):
+        """Back-to-back steps for `seconds` per mode (no synchronisation inside a chunk of `chunk` steps): what a step costs after
+        seconds at load — the clocks and the temperature have settled — beside the K-step window the headline is timed on."""
+        res = {}
+        for name, flags in (("culled", 0), ("dense", dense_flags)):
+            fence()
+            t_start = time.perf_counter()
+            chunks = []
+            while time.perf_counter() - t_start < seconds:
+                t0 = time.perf_counter()
+                for _ in range(chunk):
+                    step(flags)
+                torch.cuda.synchronize(device)
+                chunks.append(1e3 * (time.perf_counter() - t0) / chunk)
+            res[name] = {"seconds": time.perf_counter() - t_start, "steps": chunk * len(chunks), "ms_per_step": sum(chunks) / len(chunks),
+                         "ms_per_step_first_chunk": chunks[0], "ms_per_step_last_chunk": chunks[-1], "ms_per_step_best_chunk": min(chunks)}
+        res["note"] = f"chunks of {chunk} steps, one synchronisation per chunk; the culled step is close to what one host thread can issue (~0.045 ms per call)"
+        return res
+
     def comm_leg_points(flags):
         """--shard points: the two collectives alone (events on the compute stream around K of each, which waits for RCCL's), and
         the step's launches with the collectives left out."""
@@ -767,6 +814,9 @@ def main():
     # clocks by the time the timed pass starts), then W warm-up + exactly K timed steps.
     dense_flags = ops.DENSE if args.mode != "culled" else 0
     kern = kernel_times(dense_flags)
+    # two seconds at load per mode BEFORE the timed window (the dense mode last): the W warm-up steps the driver asks for are 0.6 ms,
+    # the clocks take longer than that to settle, and the timed K steps would otherwise read the ramp (r04: 0.129 against 0.118 ms)
+    sustained = sustained_leg() if (shard is None and args.sustained == "on" and args.mode == "both") else None
     dt, out = timed(dense_flags)
     out = tuple(t.clone() for t in out)   # the step's outputs live in buffers the later legs reuse
     span_ms, clock_ghz = in_kernel_span(dense_flags) if (dense_flags and n_gpus == 1) else (None, None)
@@ -870,6 +920,8 @@ def main():
         if n_gpus == 1 and args.cpu_wps > 0 and args.cameras == 1:
             if args.dropin == "on":
                 line["dropin"] = dropin_leg(device)
+            if args.configs == "on":
+                line["configs"] = configs_leg(device)
             if args.density == "on":
                 line["density_sweep"] = density_leg(device)
             if args.aux == "on":
@@ -882,6 +934,8 @@ def main():
                 "value": 1.3e7, "unit": "evals/s", "cores": 8,
                 "note": "the reference ITSELF (torch CPU, fwd+bwd, 1 M x 16) timed in the build container — it cannot travel to the "
                         "GPU box; profiles/r01_reference_cpu_timing.txt"}
+        if sustained is not None:
+            line["sustained"] = sustained
         if comm is not None:
             line["comm"] = comm
         if moved is not None:

@@ -69,6 +69,10 @@ def main():
     for sub, name in (("opt", "optimize"), ("aux", "aux")):
         if os.path.exists(os.path.join(src, sub, f"{sub}_kernel_stats.csv")):
             shutil.copy(os.path.join(src, sub, f"{sub}_kernel_stats.csv"), os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
+    for sc in ("multi8", "w1024", "cam5", "c2"):   # tools/prof_multi.py scenarios
+        f = os.path.join(src, f"multi_{sc}", f"multi_{sc}_kernel_stats.csv")
+        if os.path.exists(f):
+            shutil.copy(f, os.path.join(dst, f"{tag}_multi_{sc}_kernel_stats.csv"))
     if os.path.exists(os.path.join(src, "aux_fetch", "pmc_counter_collection.csv")):
         aux_pmc(src, os.path.join(dst, f"{tag}_aux_pmc.json"))
     out = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --kernel-trace -- python3 bench.py --steps 20 --warmup 5 "
