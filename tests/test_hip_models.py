@@ -783,3 +783,45 @@ def test_outputs_left_to_the_last_step_change_nothing(dev):
         ref = optimizer._OptRun(models()[:B], 4, *args[1:])
         ref.run(4)
         assert torch.equal(short.rewards, ref.rewards)
+
+
+@pytest.mark.parametrize("method", ["zbuffer", "hpr"])
+def test_occlusion_motion_triggered_refresh(dev, method):
+    """ModelTraj(occlusion_refresh_tol=...): rows are rebuilt for the waypoints that have moved by more than the tolerance since
+    THEIR rows were built — nothing while nobody has, only the movers' rows when somebody has (bit for bit the rows a fresh model
+    builds at the new poses), everything when occlusion_refresh_every caps the age."""
+    from trajectory_optimization_amd.model import ModelTraj
+    pts = torch.from_numpy(synth.make_cloud(60_000, seed=34))
+    poses, quats = synth.make_path(5, optical=True, jitter_seed=34)
+
+    def model(p, **kw):
+        return ModelTraj(pts, torch.from_numpy(p), torch.from_numpy(quats), torch.from_numpy(K), IW, IH, device=dev, occlusion=method, **kw)
+    m = model(poses, occlusion_refresh_every=100, occlusion_refresh_tol=0.05, occlusion_check_every=1)
+    with torch.no_grad():
+        m(vis_wps_dist=0.0)
+        rows0 = m._occ_cache[0]
+        assert m.occlusion_rebuilds == [1, 0]
+        m(vis_wps_dist=0.0)                                    # nobody has moved
+        assert m._occ_cache[0] is rows0 and m.occlusion_rebuilds == [1, 0]
+        m.poses.data[1, 0] += 0.01                             # below the tolerance
+        m(vis_wps_dist=0.0)
+        assert m._occ_cache[0] is rows0 and m.occlusion_rebuilds == [1, 0]
+        m.poses.data[3, 1] += 0.3                              # one waypoint beyond it
+        loss = m(vis_wps_dist=0.0)
+        assert m.occlusion_rebuilds == [1, 1] and m._occ_cache[0] is not rows0
+        moved = poses.copy()
+        moved[3, 1] += 0.3
+        fresh = model(moved)
+        fresh(vis_wps_dist=0.0)
+        assert torch.equal(m._occ_cache[0][3], fresh._occ_cache[0][3])           # the mover's row: what a fresh model builds there
+        keep = [0, 1, 2, 4]
+        assert torch.equal(m._occ_cache[0][keep], rows0[keep])                    # the others: kept
+        assert bool((m._occ_cache[0][3] != rows0[3]).any())
+        m.quats.data[0] = torch.nn.functional.normalize(m.quats.data[0] + torch.tensor([0.0, 0.1, 0.0, 0.0], device=dev), dim=0)   # a turn of ~0.2 rad
+        m(vis_wps_dist=0.0)
+        assert m.occlusion_rebuilds == [1, 2]
+        cap = model(poses, occlusion_refresh_every=2, occlusion_refresh_tol=1e9)
+        for _ in range(3):
+            cap(vis_wps_dist=0.0)
+        assert cap.occlusion_rebuilds == [2, 0]
+        assert torch.isfinite(loss)

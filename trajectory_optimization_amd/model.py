@@ -781,7 +781,7 @@ class ModelTraj(nn.Module):
                  smoothness_weight=14.0, traj_length_weight=0.02,
                  device=torch.device('cuda'),
                  *, rig=None, shard=None, dense=False, occlusion=None, occlusion_limits=(1.0, 15.0), occlusion_refresh_every=1,
-                 n_points_global=None, cloud=None):
+                 occlusion_refresh_tol=None, occlusion_check_every=5, n_points_global=None, cloud=None):
         super().__init__()
         assert wps_poses.dim() == wps_quats.dim()
         assert wps_poses.size()[1] == 3
@@ -856,8 +856,18 @@ class ModelTraj(nn.Module):
         # gradient; building them — a hard cull and a convex hull (or a z-buffer) per waypoint — costs hundreds of plain steps.
         # occlusion_refresh_every = k: they are rebuilt on every k-th forward of the model (k = 1: every forward, the bits of a
         # model without the policy) and reused in between; refresh_occlusion() forces a rebuild at the next forward.
+        # occlusion_refresh_tol = metres, or (metres, radians): the MOTION-triggered policy — every occlusion_check_every-th
+        # forward looks (one small device-to-host read) whether a waypoint has moved or turned by more than that since ITS rows were
+        # built; if one has, the rows of every waypoint beyond half the tolerance are rebuilt (one batched pass for them) and the
+        # others kept: a waypoint that has converged stops paying.  occlusion_refresh_every stays the cap on a row's age.
         self.occlusion_refresh_every = max(1, int(occlusion_refresh_every))
-        self._occ_cache = None   # (rows, shape key, forwards since the rebuild)
+        if occlusion_refresh_tol is not None and not isinstance(occlusion_refresh_tol, (tuple, list)):
+            occlusion_refresh_tol = (float(occlusion_refresh_tol), 0.35 * float(occlusion_refresh_tol))   # (1 rad turns a point 3 m away by 3 m)
+        self.occlusion_refresh_tol = tuple(float(x) for x in occlusion_refresh_tol) if occlusion_refresh_tol is not None else None
+        self.occlusion_check_every = max(1, int(occlusion_check_every))
+        self._occ_cache = None   # (rows, shape key, forwards since the last FULL rebuild)
+        self._occ_built = None   # the body poses each waypoint's rows were built for: (positions, normalised quaternions)
+        self.occlusion_rebuilds = [0, 0]   # (full rebuilds, waypoints rebuilt by the motion policy): bookkeeping for tools and tests
         self._ws_cache = {}
         self._plan_obj, self._plan_key = None, None
         self._wps_step_cache = {}
@@ -885,15 +895,35 @@ class ModelTraj(nn.Module):
 
     def _occlusion_rows(self, ps, qs):
         """Occlusion bit rows of the given body waypoints, one row per virtual waypoint v = w*C + c (with a rig: the cameras'
-        own poses t_v = t_w + R(q_w) l_c, q_v = q_w/|q_w| (x) q_c — the composition the kernels apply); rebuilt on every
-        occlusion_refresh_every-th call, reused in between."""
+        own poses t_v = t_w + R(q_w) l_c, q_v = q_w/|q_w| (x) q_c — the composition the kernels apply).  Rebuilt as a whole on
+        every occlusion_refresh_every-th call; with occlusion_refresh_tol set, in between, the rows of the waypoints that have
+        moved (see the constructor); reused otherwise."""
         key = (tuple(ps.shape), tuple(qs.shape))
         c = self._occ_cache
-        if c is not None and c[1] == key and c[2] < self.occlusion_refresh_every:
-            self._occ_cache = (c[0], key, c[2] + 1)
-            return c[0]
-        rows = self._build_occlusion_rows(ps, qs)
-        self._occ_cache = (rows, key, 1)
+        if c is None or c[1] != key or c[2] >= self.occlusion_refresh_every:
+            rows = self._build_occlusion_rows(ps, qs)
+            self._occ_cache = (rows, key, 1)
+            self.occlusion_rebuilds[0] += 1
+            if self.occlusion_refresh_tol is not None:
+                self._occ_built = (ps.clone(), torch.nn.functional.normalize(qs, dim=1))
+            return rows
+        rows, age = c[0], c[2]
+        if self.occlusion_refresh_tol is not None and age % self.occlusion_check_every == 0:
+            tol_p, tol_q = self.occlusion_refresh_tol
+            bp, bq = self._occ_built
+            qn = torch.nn.functional.normalize(qs, dim=1)
+            dist = (ps - bp).norm(dim=1)
+            ang = 2.0 * torch.arccos((qn * bq).sum(dim=1).abs().clamp(max=1.0))   # the rotation between the two orientations
+            if bool(((dist > tol_p) | (ang > tol_q)).any()):   # (the policy's host read)
+                idx = ((dist > 0.5 * tol_p) | (ang > 0.5 * tol_q)).nonzero().flatten()
+                C = self._rig.n_cams if self._rig is not None else 1
+                new = self._build_occlusion_rows(ps[idx].contiguous(), qs[idx].contiguous())
+                vidx = (idx[:, None] * C + torch.arange(C, device=idx.device)[None, :]).flatten()
+                rows = rows.clone()   # (a step whose backward is still to come holds the old rows)
+                rows[vidx] = new
+                bp[idx], bq[idx] = ps[idx], qn[idx]
+                self.occlusion_rebuilds[1] += int(idx.numel())
+        self._occ_cache = (rows, key, age + 1)
         return rows
 
     def _build_occlusion_rows(self, ps, qs):
