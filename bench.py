@@ -410,6 +410,74 @@ def configs_leg(device, steps=20, warmup=5):
     return out
 
 
+def message_leg(device, n_points=N_POINTS, n_wps=WPS_PER_GPU, opt_steps=30, reps=5):
+    """One (cloud, path) message pair end to end, as the reference's TrajOpt.callback handles it
+    (/root/reference/src/trajectory_optimization.py:60-81,129-157, behind launch/voxels_filtering.launch:11-21): PointCloud2 bytes
+    (xyz + intensity, 16-byte points, 1 % NaN rows) -> host-to-device copy -> pointcloud2_to_xyz_array -> voxel_grid_filter (leaf
+    0.1 m, z in [-2.5, 2.5]) -> ModelTraj (packs the cloud) -> opt_steps optimiser steps at the launch file's values -> poses back on
+    the host.  Median of `reps` messages per stage, a synchronisation after each stage (total_ms: one message without them).
+    The reference's comment for its loop alone: "~125 msec" per step (trajectory_optimization.py:108)."""
+    from trajectory_optimization_amd import pointcloud_utils as pcu
+    from trajectory_optimization_amd.model import ModelTraj
+    from trajectory_optimization_amd.optimizer import optimize_trajectory
+    rng = np.random.default_rng(7)
+    pts = synth.make_cloud(n_points, seed=0)
+    xyzi = np.concatenate([pts, rng.random((n_points, 1), dtype=np.float32)], axis=1)
+    xyzi[rng.choice(n_points, n_points // 100, replace=False), rng.integers(0, 3, n_points // 100)] = np.nan
+    msg = pcu.xyzi_array_to_pointcloud2(xyzi)
+    poses, quats = synth.make_path(n_wps, optical=True)
+    K = torch.from_numpy(synth.K_INTRINS)
+    stages = {k: [] for k in ("pointcloud2_to_xyz_incl_h2d", "voxel_grid_filter", "model_and_pack", "optimize", "poses_to_host", "total_without_stage_syncs")}
+    info = {}
+
+    def once(sync):
+        t = [time.perf_counter()]
+
+        def mark():
+            if sync:
+                torch.cuda.synchronize(device)
+            t.append(time.perf_counter())
+        xyz = pcu.pointcloud2_to_xyz_array(msg, device=device)
+        mark()
+        vox = pcu.voxel_grid_filter(xyz, leaf_size=0.1)
+        mark()
+        m = ModelTraj(vox, torch.from_numpy(poses), torch.from_numpy(quats), K, synth.IMG_WIDTH, synth.IMG_HEIGHT, smoothness_weight=28.0, device=device)
+        mark()
+        r = optimize_trajectory(m, n_opt_steps=opt_steps, lr_pose=0.12, lr_quat=0.05, vis_wps_dist=0.0)
+        mark()
+        out = (m.poses.detach().cpu(), torch.nn.functional.normalize(m.quats.detach()).cpu())
+        mark()
+        info.update(points_in=n_points, points_finite=int(xyz.shape[0]), points_after_voxel_grid=int(vox.shape[0]), waypoints=n_wps,
+                    optimiser_steps_taken=r.steps_taken, stopped_early=r.stopped)
+        return [1e3 * (b - a) for a, b in zip(t[:-1], t[1:])], out
+    once(True)   # (allocator warm-up)
+    for _ in range(reps):
+        d, _ = once(True)
+        for k, v in zip(list(stages)[:5], d):
+            stages[k].append(v)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        once(False)
+        torch.cuda.synchronize(device)
+        stages["total_without_stage_syncs"].append(1e3 * (time.perf_counter() - t0))
+    res = {k + "_ms": sorted(v)[len(v) // 2] for k, v in stages.items()}
+    # the device part of the two format kernels alone (inputs resident): HIP events around back-to-back calls
+    xyz = pcu.pointcloud2_to_xyz_array(msg, device=device)
+    from trajectory_optimization_amd import ops
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.PackedCloud(xyz)
+    e1.record()
+    e1.synchronize()
+    res["pack_cloud_device_ms"] = e0.elapsed_time(e1) / 20
+    res.update(info)
+    res["note"] = ("one message pair through the reference's callback path; pointcloud2_to_xyz includes the host-to-device copy of the 16 MB message "
+                   "(PCIe) and the host read of the surviving count; optimize = device-resident loop (one host sync at its end); pack_cloud_device_ms: "
+                   "bounding box, Morton keys, sort, gather, tile bounds of the finite points (rocprofv3: profiles/r05_message_kernel_stats.csv)")
+    return res
+
+
 def density_leg(device, steps=20, warmup=3):
     """The same 1 M points x 128 waypoints in ever smaller rooms (the path scaled with the room): the headline workload flags
     0.7 % of the (256-point slot, waypoint) pairs; an indoor cloud flags 10-20 %, and the kernels after pass 1 cost in proportion.
@@ -477,6 +545,7 @@ def main():
     ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dropin", choices=["on", "off"], default="on", help="time the reference's own loop over the drop-in classes (N = 1 only)")
     ap.add_argument("--configs", choices=["on", "off"], default="on", help="the other named sizes on one GPU: configs 2, 4, 5 and eight concurrent trajectories (N = 1 only)")
+    ap.add_argument("--message", choices=["on", "off"], default="on", help="one PointCloud2 + path message pair end to end, per stage (N = 1 only)")
     ap.add_argument("--density", choices=["on", "off"], default="on", help="step time versus flagged fraction: 1 M points in ever smaller rooms (N = 1 only)")
     ap.add_argument("--occlusion", choices=["on", "off"], default="on", help="the occlusion-aware reward on the headline workload: ms per mask refresh and per step (N = 1 only)")
     ap.add_argument("--aux", choices=["on", "off"], default="on", help="the HBM-bound kernels around the hot path (ModelPose, flip, cull, masks, ingest) at 1 M and 16 M points")
@@ -922,6 +991,8 @@ def main():
                 line["dropin"] = dropin_leg(device)
             if args.configs == "on":
                 line["configs"] = configs_leg(device)
+            if args.message == "on":
+                line["message"] = message_leg(device)
             if args.density == "on":
                 line["density_sweep"] = density_leg(device)
             if args.aux == "on":

@@ -10,7 +10,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-common="--steps 20 --warmup 5 --cpu-wps 0 --dropin off --density off --moved off --aux off --occlusion off --configs off --sustained off"
+common="--steps 20 --warmup 5 --cpu-wps 0 --dropin off --density off --moved off --aux off --occlusion off --configs off --sustained off --message off"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/dense" -o dense -- python3 "$root/bench.py" $common --mode dense > "$out/dense.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/culled" -o culled -- python3 "$root/bench.py" $common --mode culled > "$out/culled.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -o pmc -- python3 "$root/bench.py" $common --mode dense > "$out/pmc_fetch.log" 2>&1

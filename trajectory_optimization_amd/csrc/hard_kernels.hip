@@ -15,29 +15,28 @@
 // cloud packing: (N,3) -> Morton-sorted x|y|z (padded with copies of the last sorted point), the
 // permutation back to the caller's order, and one bounding sphere per 256 sorted points.
 
-__device__ __forceinline__ unsigned fkey(float f) {  // order-preserving float -> uint
-    const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+// order-preserving float -> int (the signed integer order is the float order; -0 and +0 stay neighbours)
+__device__ __forceinline__ int fkey(float f) {
+    const int u = __float_as_int(f);
+    return u >= 0 ? u : (int)(0x80000000u - (unsigned)u);   // negative floats: magnitude grows downwards
 }
-__device__ __forceinline__ float fkey_inv(unsigned k) {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+__device__ __forceinline__ float fkey_inv(int k) {
+    return __int_as_float(k >= 0 ? k : (int)(0x80000000u - (unsigned)k));
 }
 
-// bbox[0..2] = min keys, bbox[3..5] = max keys (pre-set to 0xffffffff / 0)
-__global__ void __launch_bounds__(TO_BLOCK) k_bbox(const float* __restrict__ xyz, int64_t n, unsigned* __restrict__ bbox) {
-    unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
-    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride)
+// the box of the finite coordinates (common.hpp: bounds_commit)
+__global__ void __launch_bounds__(TO_BLOCK) k_bbox(const float* __restrict__ xyz, int64_t n, int* __restrict__ bbox) {
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    for_each_point(xyz, n, [&](float x, float y, float z) {
+        const float p[3] = {x, y, z};
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float f = xyz[3 * i + k];
-            if (f != f) continue;  // NaNs do not shape the box
-            const unsigned u = fkey(f);
+            if (p[k] != p[k]) continue;  // NaNs do not shape the box
+            const int u = fkey(p[k]);
             mn[k] = min(mn[k], u); mx[k] = max(mx[k], u);
         }
-    for (int k = 0; k < 3; ++k) {
-        for (int s = 32; s > 0; s >>= 1) { mn[k] = min(mn[k], (unsigned)__shfl_xor((int)mn[k], s)); mx[k] = max(mx[k], (unsigned)__shfl_xor((int)mx[k], s)); }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&bbox[k], mn[k]); atomicMax(&bbox[3 + k], mx[k]); }
-    }
+    });
+    bounds_commit(mn, mx, bbox);
 }
 
 __device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every third bit
@@ -50,10 +49,12 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every 
 }
 
 __global__ void __launch_bounds__(TO_BLOCK)
-k_morton(const float* __restrict__ xyz, int64_t n, const unsigned* __restrict__ bbox, unsigned* __restrict__ keys,
+k_morton(const float* __restrict__ xyz, int64_t n, const int* __restrict__ bbox, unsigned* __restrict__ keys,
          int* __restrict__ vals) {
-    const float lo[3] = {fkey_inv(bbox[0]), fkey_inv(bbox[1]), fkey_inv(bbox[2])};
-    const float hi[3] = {fkey_inv(bbox[3]), fkey_inv(bbox[4]), fkey_inv(bbox[5])};
+    int bmn[3], bmx[3];
+    bounds_fold(bbox, bmn, bmx);
+    const float lo[3] = {fkey_inv(bmn[0]), fkey_inv(bmn[1]), fkey_inv(bmn[2])};
+    const float hi[3] = {fkey_inv(bmx[0]), fkey_inv(bmx[1]), fkey_inv(bmx[2])};
     // one cell size for all axes (cubic cells: compact tiles), set by the longest side of the box
     const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
     float sc[3];
@@ -75,12 +76,20 @@ __global__ void __launch_bounds__(TO_BLOCK) k_iota(int* __restrict__ vals, int64
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) vals[i] = (int)i;
 }
 
+// block per 256 sorted points (a tile), tiles strided over the grid: gather the tile's points into the SoA rows, the permutation
+// and its inverse, the probe's strided sample — and, the tile's points being in the block's registers, its bounding sphere:
+// centre of the bounding box, radius = max distance to it, padded for the float rounding of the kernels' camera-frame arithmetic
+// (conservative: a larger sphere only culls less).  (Until r05 the bounds were a launch of their own.)
 __global__ void __launch_bounds__(TO_BLOCK)
 k_pack_cloud(const float* __restrict__ xyz, const int* __restrict__ order, int64_t n, int64_t npad, float* __restrict__ soa,
-             int* __restrict__ perm, int* __restrict__ inv, float* __restrict__ samples, int sample_step, int* __restrict__ hdr, int sorted) {
-    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
-    if (blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = sorted;   // (the header was cleared before the launch)
-    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < npad; i += stride) {
+             int* __restrict__ perm, int* __restrict__ inv, float* __restrict__ samples, int sample_step, int* __restrict__ hdr, int sorted,
+             float4* __restrict__ bounds) {
+    __shared__ float smn[3][TO_WAVES_PER_BLOCK], smx[3][TO_WAVES_PER_BLOCK], srad[TO_WAVES_PER_BLOCK];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (blockIdx.x == 0 && t == 0) hdr[0] = sorted;   // (the header was cleared before the launch)
+    const int64_t ntiles = npad / TO_BLOCK;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t i = tile * TO_BLOCK + t;
         const int64_t s = order[i < n ? i : n - 1];
         const float px = xyz[3 * s], py = xyz[3 * s + 1], pz = xyz[3 * s + 2];
         // a NaN / inf coordinate: the reference's min() over p makes every reward of every waypoint NaN (model.py:226) — noted once
@@ -95,39 +104,44 @@ k_pack_cloud(const float* __restrict__ xyz, const int* __restrict__ order, int64
         }
         perm[i] = i < n ? (int)s : -1;
         if (i < n) inv[s] = (int)i;  // the way back, for kernels that produce their output in the caller's order
+        // ---- the tile's bounding sphere (fminf / fmaxf drop a NaN: the radius below does not) ----
+        const float p[3] = {px, py, pz};
+        float mn[3], mx[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = p[k]; mx[k] = p[k];
+            for (int sh = 32; sh > 0; sh >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], sh)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], sh)); }
+            if (lane == 0) { smn[k][wave] = mn[k]; smx[k][wave] = mx[k]; }
+        }
+        __syncthreads();
+        float c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float a = smn[k][0], b = smx[k][0];
+            for (int w = 1; w < TO_WAVES_PER_BLOCK; ++w) { a = fminf(a, smn[k][w]); b = fmaxf(b, smx[k][w]); }
+            c[k] = 0.5f * (a + b);
+        }
+        const float dx = px - c[0], dy = py - c[1], dz = pz - c[2];
+        float r = sqrtf(dx * dx + dy * dy + dz * dz);
+        if (!(r == r)) r = INFINITY;  // a NaN point: never cull this tile
+        for (int sh = 32; sh > 0; sh >>= 1) r = fmaxf(r, __shfl_xor(r, sh));
+        if (lane == 0) srad[wave] = r;
+        __syncthreads();
+        if (t == 0) {
+            float rm = srad[0];
+            for (int w = 1; w < TO_WAVES_PER_BLOCK; ++w) rm = fmaxf(rm, srad[w]);
+            const float amax = fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fabsf(c[2])) + rm;
+            bounds[tile] = make_float4(c[0], c[1], c[2], rm * 1.0001f + 1e-5f * amax + 1e-6f);
+        }
+        __syncthreads();   // the LDS is the next tile's
     }
 }
 
-// block per 256 sorted points: centre of the bounding box, radius = max distance to it, padded for
-// the float rounding of the kernels' camera-frame arithmetic (conservative: a larger sphere only culls less)
-__global__ void __launch_bounds__(TO_BLOCK)
-k_tile_bounds(const float* __restrict__ soa, int64_t npad, float4* __restrict__ bounds) {
-    __shared__ float smn[3][TO_BLOCK], smx[3][TO_BLOCK];
-    const int t = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * TO_BLOCK + t;
-    const float p[3] = {soa[i], soa[npad + i], soa[2 * npad + i]};
-    for (int k = 0; k < 3; ++k) { smn[k][t] = p[k]; smx[k][t] = p[k]; }
-    __syncthreads();
-    for (int s = TO_BLOCK / 2; s > 0; s >>= 1) {
-        if (t < s)
-            for (int k = 0; k < 3; ++k) { smn[k][t] = fminf(smn[k][t], smn[k][t + s]); smx[k][t] = fmaxf(smx[k][t], smx[k][t + s]); }
-        __syncthreads();
-    }
-    const float c[3] = {0.5f * (smn[0][0] + smx[0][0]), 0.5f * (smn[1][0] + smx[1][0]), 0.5f * (smn[2][0] + smx[2][0])};
-    __syncthreads();
-    const float dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];
-    float r = sqrtf(dx * dx + dy * dy + dz * dz);
-    if (!(r == r)) r = INFINITY;  // a NaN point: never cull this tile
-    smx[0][t] = r;
-    __syncthreads();
-    for (int s = TO_BLOCK / 2; s > 0; s >>= 1) {
-        if (t < s) smx[0][t] = fmaxf(smx[0][t], smx[0][t + s]);
-        __syncthreads();
-    }
-    if (t == 0) {
-        const float amax = fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fabsf(c[2])) + smx[0][0];
-        bounds[blockIdx.x] = make_float4(c[0], c[1], c[2], smx[0][0] * 1.0001f + 1e-5f * amax + 1e-6f);
-    }
+// start values of the pack: the box's copies (k_bounds_init's), the blob's header cleared — one launch
+__global__ void k_pack_init(int* __restrict__ bbox, int* __restrict__ hdr) {
+    if (bbox != nullptr)
+        for (int i = threadIdx.x; i < TO_BOUNDS_WORDS; i += blockDim.x) bbox[i] = i < TO_BOUNDS_COPIES * TO_BOUNDS_STRIDE ? 0x7fffffff : (int)0x80000000;
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) hdr[i] = 0;
 }
 
 extern "C" int64_t tohip_padded_points(int64_t n) {
@@ -146,7 +160,7 @@ inline PackPlan pack_plan(int64_t n) {
     p.off_keys2 = o; o += align_up(sizeof(unsigned) * (size_t)n, 256);
     p.off_vals = o;  o += align_up(sizeof(int) * (size_t)n, 256);
     p.off_vals2 = o; o += align_up(sizeof(int) * (size_t)n, 256);
-    p.off_bbox = o;  o += 256;
+    p.off_bbox = o;  o += align_up(sizeof(int) * TO_BOUNDS_WORDS, 256);
     size_t tmp = 0;
     (void)sort_pairs(nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
                                              (int*)nullptr, (int)n, 0, 30, (hipStream_t)0);
@@ -170,39 +184,34 @@ extern "C" int tohip_pack_cloud(const float* xyz, int64_t n, int sort, void* pac
     unsigned* keys2 = (unsigned*)(ws + pl.off_keys2);
     int* vals = (int*)(ws + pl.off_vals);
     int* vals2 = (int*)(ws + pl.off_vals2);
-    unsigned* bbox = (unsigned*)(ws + pl.off_bbox);
+    int* bbox = (int*)(ws + pl.off_bbox);
     const int64_t npad = tohip_padded_points(n);
     int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
     if (nb > 2048) nb = 2048;
     const int* order = vals;
+    const CloudView cv = cloud_view(packed, n);
+    k_pack_init<<<1, TO_BLOCK, 0, st>>>(sort ? bbox : nullptr, (int*)cv.hdr);
     if (sort) {
-        hipError_t e = hipMemsetAsync(bbox, 0xff, 3 * sizeof(unsigned), st);
-        if (e != hipSuccess) return (int)e;
-        e = hipMemsetAsync(bbox + 3, 0, 3 * sizeof(unsigned), st);
-        if (e != hipSuccess) return (int)e;
-        k_bbox<<<(int)(nb < 256 ? nb : 256), TO_BLOCK, 0, st>>>(xyz, n, bbox);  // six same-address atomics per wave: few waves
+        hipError_t e;
+        k_bbox<<<(int)std::min<int64_t>(1024, (n / 4 + TO_BLOCK - 1) / TO_BLOCK + 1), TO_BLOCK, 0, st>>>(xyz, n, bbox);
         TO_HIP_CHECK_LAUNCH();
         k_morton<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, bbox, keys, vals);
         TO_HIP_CHECK_LAUNCH();
         size_t tmp = pl.tmp_bytes;
-        e = sort_pairs(ws + pl.off_tmp, tmp, keys, keys2, vals, vals2, (int)n, 0, 30, st);
+        // by the 21 most significant bits (7 per axis: cells of 1/128 of the box's longest side; the stable sort keeps the caller's
+        // order inside a cell): a radix pass less than all 30 bits, and a 256-point tile spans several cells either way
+        static const int low_bit = [] { const char* ev = getenv("TOHIP_PACK_SORT_LOW_BIT"); return ev ? atoi(ev) : 9; }();   // experiments
+        e = sort_pairs(ws + pl.off_tmp, tmp, keys, keys2, vals, vals2, (int)n, low_bit, 30, st);
         if (e != hipSuccess) return (int)e;
         order = vals2;  // radix sort is stable: equal cells keep the caller's order (deterministic)
     } else {
         k_iota<<<(int)nb, TO_BLOCK, 0, st>>>(vals, n);
         TO_HIP_CHECK_LAUNCH();
     }
-    const CloudView cv = cloud_view(packed, n);
     int64_t nbp = npad / TO_BLOCK;
     if (nbp > 4096) nbp = 4096;
-    {
-        hipError_t e = hipMemsetAsync((void*)cv.hdr, 0, 256, st);
-        if (e != hipSuccess) return (int)e;
-    }
     k_pack_cloud<<<(int)nbp, TO_BLOCK, 0, st>>>(xyz, order, n, npad, (float*)cv.soa, (int*)cv.perm, (int*)cv.inv, (float*)cv.samples,
-                                                cv.sample_step, (int*)cv.hdr, sort ? 1 : 0);
-    TO_HIP_CHECK_LAUNCH();
-    k_tile_bounds<<<(int)(npad / TO_BLOCK), TO_BLOCK, 0, st>>>(cv.soa, npad, (float4*)cv.bounds);
+                                                cv.sample_step, (int*)cv.hdr, sort ? 1 : 0, (float4*)cv.bounds);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }

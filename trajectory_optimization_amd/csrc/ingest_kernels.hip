@@ -176,39 +176,38 @@ __device__ __forceinline__ bool vox_keep(const VoxParams& vp, float x, float y, 
     return true;
 }
 
-// ctrl ints: [0..2] min cell (int, via atomicMin) [3..5] max cell (atomicMax) [6] n kept [7] n voxels [8] overflow
+// the cell range of the kept points (common.hpp: bounds_commit); ctrl[8] = overflow ("leaf size too small")
 __global__ void __launch_bounds__(TO_BLOCK)
-k_vox_bounds(const float* __restrict__ xyz, int64_t n, VoxParams vp, int* __restrict__ ctrl) {
+k_vox_bounds(const float* __restrict__ xyz, int64_t n, VoxParams vp, int* __restrict__ bounds) {
     int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
-        const float p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-        if (!vox_keep(vp, p[0], p[1], p[2])) continue;
+    for_each_point(xyz, n, [&](float x, float y, float z) {
+        if (!vox_keep(vp, x, y, z)) return;
+        const float p[3] = {x, y, z};
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
             // floor(min_p * inv_leaf) == min over points of floor(p * inv_leaf): floor and the scaling are monotone
             const int c = (int)floorf(p[k] * vp.inv_leaf[k]);
             mn[k] = min(mn[k], c); mx[k] = max(mx[k], c);
         }
-    }
-    for (int k = 0; k < 3; ++k) {
-        for (int s = 32; s > 0; s >>= 1) { mn[k] = min(mn[k], __shfl_xor(mn[k], s)); mx[k] = max(mx[k], __shfl_xor(mx[k], s)); }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&ctrl[k], mn[k]); atomicMax(&ctrl[3 + k], mx[k]); }
-    }
+    });
+    bounds_commit(mn, mx, bounds);
 }
 
 __global__ void __launch_bounds__(TO_BLOCK)
-k_vox_keys(const float* __restrict__ xyz, int64_t n, VoxParams vp, int* __restrict__ ctrl, unsigned long long* __restrict__ keys,
-           int* __restrict__ vals) {
-    const long long dx = (long long)ctrl[3] - ctrl[0] + 1, dy = (long long)ctrl[4] - ctrl[1] + 1, dz = (long long)ctrl[5] - ctrl[2] + 1;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && ctrl[0] <= ctrl[3] && dx * dy * dz > 0x7fffffffLL) ctrl[8] = 1;  // PCL: "leaf size too small"
+k_vox_keys(const float* __restrict__ xyz, int64_t n, VoxParams vp, const int* __restrict__ bounds, int* __restrict__ ctrl,
+           unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+    int cmn[3], cmx[3];
+    bounds_fold(bounds, cmn, cmx);
+    const long long dx = (long long)cmx[0] - cmn[0] + 1, dy = (long long)cmx[1] - cmn[1] + 1, dz = (long long)cmx[2] - cmn[2] + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctrl[8] = (cmn[0] <= cmx[0] && dx * dy * dz > 0x7fffffffLL) ? 1 : 0;  // PCL: "leaf size too small"
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
         const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
         unsigned long long key = ~0ull;  // dropped points sort to the end
         if (vox_keep(vp, x, y, z)) {
-            const long long ci = (long long)((int)floorf(x * vp.inv_leaf[0]) - ctrl[0]);
-            const long long cj = (long long)((int)floorf(y * vp.inv_leaf[1]) - ctrl[1]);
-            const long long ck = (long long)((int)floorf(z * vp.inv_leaf[2]) - ctrl[2]);
+            const long long ci = (long long)((int)floorf(x * vp.inv_leaf[0]) - cmn[0]);
+            const long long cj = (long long)((int)floorf(y * vp.inv_leaf[1]) - cmn[1]);
+            const long long ck = (long long)((int)floorf(z * vp.inv_leaf[2]) - cmn[2]);
             key = (unsigned long long)(ci + cj * dx + ck * dx * dy);
         }
         keys[i] = key;
@@ -259,7 +258,7 @@ inline VoxPlan vox_plan(int64_t n) {
     p.off_hpos = o;  o += align_up(sizeof(int) * (size_t)n, 256);
     p.off_tcnt = o;  o += align_up(sizeof(int) * ntiles, 256);
     p.off_toff = o;  o += align_up(sizeof(int) * ntiles, 256);
-    p.off_ctrl = o;  o += 256;
+    p.off_ctrl = o;  o += 256 + align_up(sizeof(int) * TO_BOUNDS_WORDS, 256);   // [8] the overflow mark; the cell range's copies behind it
     size_t tmp = 0;
     (void)sort_pairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                              (const int*)nullptr, (int*)nullptr, (int)n, 0, 64, (hipStream_t)0);
@@ -301,19 +300,18 @@ extern "C" int tohip_voxel_grid(const float* xyz, int64_t n, float leaf_x, float
     vp.inv_leaf[0] = 1.0f / leaf_x; vp.inv_leaf[1] = 1.0f / leaf_y; vp.inv_leaf[2] = 1.0f / leaf_z;  // pcl: inverse_leaf_size_
     vp.field = filter_field < 0 ? -1 : filter_field;
     vp.lim_min = limit_min; vp.lim_max = limit_max;
-    const int init[9] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0, 0};
-    hipError_t e = hipMemcpyAsync(ctrl, init, sizeof(init), hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipStreamSynchronize(st);  // `init` lives on this stack frame
-    if (e != hipSuccess) return (int)e;
+    int* bounds = ctrl + 64;
+    hipError_t e;
+    k_bounds_init<<<1, TO_BLOCK, 0, st>>>(bounds);   // (r04 copied the start values from the host's stack and synchronised the stream for it)
     int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
     if (nb > 2048) nb = 2048;
-    k_vox_bounds<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, vp, ctrl);
+    k_vox_bounds<<<(int)std::min<int64_t>(1024, (n / 4 + TO_BLOCK - 1) / TO_BLOCK + 1), TO_BLOCK, 0, st>>>(xyz, n, vp, bounds);
     TO_HIP_CHECK_LAUNCH();
-    k_vox_keys<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, vp, ctrl, keys, vals);
+    k_vox_keys<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, vp, bounds, ctrl, keys, vals);
     TO_HIP_CHECK_LAUNCH();
     size_t tmp = pl.tmp_bytes;
-    e = sort_pairs(ws + pl.off_tmp, tmp, keys, keys2, vals, vals2, (int)n, 0, 64, st);
+    // a voxel key is below 2^31 (k_vox_keys marks the overflow PCL refuses), a dropped point's low word is all ones: 32 bits order them
+    e = sort_pairs(ws + pl.off_tmp, tmp, keys, keys2, vals, vals2, (int)n, 0, 32, st);
     if (e != hipSuccess) return (int)e;
     k_vox_heads<<<(int)nb, TO_BLOCK, 0, st>>>(keys2, n, head);
     TO_HIP_CHECK_LAUNCH();
