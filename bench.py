@@ -640,9 +640,16 @@ def main():
             pg, qg = g[:, :3], g[:, 3:]
         return scalars, pg, qg, rewards
 
+    def barrier():
+        # under RCCL the barrier is an all-reduce on a device: name it (else torch guesses it from the rank and warns)
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[device.index])
+        else:
+            dist.barrier()
+
     def fence():
         if n_gpus > 1 or forced:
-            dist.barrier()
+            barrier()
         torch.cuda.synchronize(device)
 
     L = _lib.lib()
@@ -1013,7 +1020,7 @@ def main():
             line["after_optimisation"] = moved
         print(json.dumps(line), flush=True)
     if n_gpus > 1 or forced:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 

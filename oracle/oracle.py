@@ -12,11 +12,13 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "_build", "liboracle.so")   # (ORACLE_LIB: the sanitizer build, oracle/Makefile)
 _lib = None
 
 
 def build(force=False):
+    if os.environ.get("ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or \
             os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "vis_oracle.c")):
         subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))

@@ -318,6 +318,27 @@ def gen_pose():
          observations=m.observations, trans_grad=m.trans.grad, quat_grad=m.quat.grad)
 
 
+def gen_nothing():
+    """A pose that sees nothing (/root/reference/src/model.py:124-127: loss = 1/(sum + eps) = 1/eps): a cloud 26.8-28.7 m from the
+    Gaussian's centre, where every observation is below FLT_MIN — subnormal, or zero.  The reference on a CPU adds the subnormals
+    up (sum ~1e-39) and hands back a gradient of ~1e-26; the GPU's exp unit flushes them to zero.  What is pinned: the loss, and
+    the SIZE of the gradient (the HIP path's bound: loss equal, |gradient| <= 1e-20)."""
+    rng = np.random.default_rng(11)
+    cloud = (np.float32([30.7, 3.0, 3.0]) + rng.uniform(-0.9, 0.9, (2000, 3)).astype(np.float32)).astype(np.float32)
+    t0a, q0a = np.zeros((1, 3), np.float32), np.float32([[1.0, 0.0, 0.0, 0.0]])
+    m = ref_model.ModelPose(points=torch.from_numpy(cloud), trans0=torch.from_numpy(t0a), q0=torch.from_numpy(q0a), intrins=K,
+                            img_width=IMG_W, img_height=IMG_H, device=CPU)
+    loss = m()
+    loss.backward()
+    obs = m.observations.detach().numpy()
+    tiny = np.finfo(np.float32).tiny
+    assert obs.max() < tiny and (obs > 0).any(), (obs.max(), (obs > 0).sum())
+    save("pose_sees_nothing", points=cloud, trans0=t0a, q0=q0a, hpr=np.bool_(False), loss=loss, observations=m.observations,
+         trans_grad=m.trans.grad, quat_grad=m.quat.grad, n_subnormal=np.int64((obs > 0).sum()), obs_sum=np.float64(obs.astype(np.float64).sum()))
+    print("pose_sees_nothing: loss", float(loss), "sum of observations", float(obs.astype(np.float64).sum()), "subnormal observations", int((obs > 0).sum()),
+          "| trans grad", m.trans.grad.numpy(), "quat grad", m.quat.grad.numpy())
+
+
 def gen_funcs():
     cloud = synth.make_cloud(4096, seed=3)
     p, q = synth.make_path(3, optical=True, jitter_seed=3)

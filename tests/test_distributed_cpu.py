@@ -23,7 +23,7 @@ def _free_port():
 def _worker(rank, world, port, n_pts, n_wps, out_dir):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), OMP_NUM_THREADS="2")
+                      LOCAL_RANK=str(rank), OMP_NUM_THREADS="2" if world <= 2 else "1")
     from trajectory_optimization_amd import synth
     from trajectory_optimization_amd.distributed import WaypointShard, init_from_env
     from oracle import oracle
@@ -34,9 +34,12 @@ def _worker(rank, world, port, n_pts, n_wps, out_dir):
     pts = synth.make_cloud(n_pts, seed=5)
     poses, quats = synth.make_path(n_wps, optical=True, jitter_seed=5)
     lo, hi = shard.bounds(n_wps)
-    # local forward (stand-in for tohip_traj_forward): partial log-odds of this rank's waypoints
-    f = oracle.traj_forward(pts, poses[lo:hi], quats[lo:hi], K, iw, ih, prec="f64")
-    lo_sum = torch.from_numpy(f["lo_sum"].copy())
+    # local forward (stand-in for tohip_traj_forward): partial log-odds of this rank's waypoints (a rank without any: zeros)
+    if hi > lo:
+        f = oracle.traj_forward(pts, poses[lo:hi], quats[lo:hi], K, iw, ih, prec="f64")
+        lo_sum = torch.from_numpy(f["lo_sum"].copy())
+    else:
+        lo_sum = torch.zeros(n_pts, dtype=torch.float64)
     pending = shard.allreduce_sum_async(lo_sum)                                     # the one data-path collective, started ...
     overlapped = float(np.square(poses[lo:hi]).sum())                               # ... independent work in between (bench: the scan)
     pending.wait()
@@ -44,10 +47,12 @@ def _worker(rank, world, port, n_pts, n_wps, out_dir):
     rewards = 1.0 / (1.0 + torch.exp(-lo_sum))
     mean = rewards.mean().item()
     fwd = dict(rewards=rewards.numpy(), mean_reward=mean)
-    pg_l, qg_l = oracle.traj_backward(pts, poses[lo:hi], quats[lo:hi], K, iw, ih, fwd, prec="f64")
     pg = torch.zeros(n_wps, 3, dtype=torch.float64)
     qg = torch.zeros(n_wps, 4, dtype=torch.float64)
-    pg[lo:hi], qg[lo:hi] = torch.from_numpy(pg_l), torch.from_numpy(qg_l)
+    pg_l, qg_l = np.zeros((0, 3)), np.zeros((0, 4))
+    if hi > lo:
+        pg_l, qg_l = oracle.traj_backward(pts, poses[lo:hi], quats[lo:hi], K, iw, ih, fwd, prec="f64")
+        pg[lo:hi], qg[lo:hi] = torch.from_numpy(pg_l), torch.from_numpy(qg_l)
     pg, qg = shard.allreduce_sum(pg), shard.allreduce_sum(qg)                       # (W,7) gradient assembly
     gathered = None
     if n_wps % world == 0:  # equal shards (bench.py's weak-scaling layout): rows assembled by one all-gather instead
@@ -84,13 +89,40 @@ def test_waypoint_sharding_world2(tmp_path, n_wps):
     np.testing.assert_allclose(r0["qg"], qg, rtol=1e-9, atol=1e-15)
 
 
+@pytest.mark.parametrize("n_wps", [11, 5, 16])
+def test_waypoint_sharding_world8(tmp_path, n_wps):
+    """The driver's N = 8 layout rehearsed on the CPU (gloo, the oracle as the local compute): eight ranks, waypoint counts that do
+    not divide (11: ranks of two and of one), fewer waypoints than ranks (5: three ranks hold none and still take part in every
+    collective) and the even case (16: bench.py's all-gather of equal row blocks)."""
+    sys.path.insert(0, REPO)
+    from trajectory_optimization_amd import synth
+    from oracle import oracle
+    n_pts, world = 3000, 8
+    mp.spawn(_worker, args=(world, _free_port(), n_pts, n_wps, str(tmp_path)), nprocs=world, join=True)
+    rs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert rs[0]["bounds"][0] == 0 and rs[-1]["bounds"][1] == n_wps and all(rs[r]["bounds"][1] == rs[r + 1]["bounds"][0] for r in range(world - 1))
+    sizes = [int(r["bounds"][1] - r["bounds"][0]) for r in rs]
+    assert max(sizes) - min(sizes) <= 1 and (n_wps >= world or min(sizes) == 0)
+    for r in rs[1:]:
+        for k in ("rewards", "pg", "qg"):
+            assert np.array_equal(rs[0][k], r[k]), k
+    K, iw, ih = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
+    pts = synth.make_cloud(n_pts, seed=5)
+    poses, quats = synth.make_path(n_wps, optical=True, jitter_seed=5)
+    f = oracle.traj_forward(pts, poses, quats, K, iw, ih, prec="f64")
+    pg, qg = oracle.traj_backward(pts, poses, quats, K, iw, ih, f, prec="f64")
+    np.testing.assert_allclose(rs[0]["rewards"], f["rewards"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(rs[0]["pg"], pg, rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(rs[0]["qg"], qg, rtol=1e-9, atol=1e-15)
+
+
 def _worker_points(rank, world, port, n_pts, n_wps, out_dir):
     """distributed.PointShard's placement and collectives with the CPU oracle as the local compute: this rank's rows of the cloud,
     every waypoint; MAX of the waypoints' extrema in the int32 words the kernels use (-bits(min), bits(max), 0, 0); SUM of the
     40 doubles per waypoint and of the reward sum."""
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), OMP_NUM_THREADS="2")
+                      LOCAL_RANK=str(rank), OMP_NUM_THREADS="2" if world <= 2 else "1")
     from trajectory_optimization_amd import synth
     from trajectory_optimization_amd.distributed import PointShard, init_from_env
     from oracle import oracle
@@ -189,3 +221,28 @@ def test_bounds_cover_all_ranks():
                 assert lo == prev and hi >= lo
                 prev = hi
             assert prev == n
+
+
+def test_point_sharding_world8(tmp_path):
+    """Eight ranks, a point count that does not divide (3 005): the all-reduced extrema are the single process's to the bit, the
+    rewards concatenate to the single process's, the gradients agree."""
+    sys.path.insert(0, REPO)
+    from trajectory_optimization_amd import synth
+    from oracle import oracle
+    n_pts, n_wps, world = 3005, 5, 8
+    mp.spawn(_worker_points, args=(world, _free_port(), n_pts, n_wps, str(tmp_path)), nprocs=world, join=True)
+    rs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert rs[0]["bounds"][0] == 0 and rs[-1]["bounds"][1] == n_pts and all(rs[r]["bounds"][1] == rs[r + 1]["bounds"][0] for r in range(world - 1))
+    for r in rs[1:]:
+        for k in ("pg", "qg", "vis", "gmin", "gmax"):
+            assert np.array_equal(rs[0][k], r[k]), k
+    K, iw, ih = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
+    pts = synth.make_cloud(n_pts, seed=5)
+    poses, quats = synth.make_path(n_wps, optical=True, jitter_seed=5)
+    smin, smax = oracle.traj_extrema(pts, poses, quats, K, iw, ih, prec="f32")
+    assert np.array_equal(rs[0]["gmin"], smin.astype(np.float32)) and np.array_equal(rs[0]["gmax"], smax.astype(np.float32))
+    f = oracle.traj_forward(pts, poses, quats, K, iw, ih, prec="f64")
+    pg0, qg0 = oracle.traj_backward(pts, poses, quats, K, iw, ih, f, prec="f64")
+    np.testing.assert_allclose(np.concatenate([r["rewards"] for r in rs]), f["rewards"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(rs[0]["pg"], pg0, rtol=1e-8, atol=1e-14)
+    np.testing.assert_allclose(rs[0]["qg"], qg0, rtol=1e-8, atol=1e-14)

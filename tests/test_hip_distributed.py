@@ -263,3 +263,57 @@ def test_bench_point_shard_two_ranks_and_one_rank_rccl(bench_one_rank, tmp_path)
     assert np.array_equal(c["rewards"], a["rewards"]) and np.array_equal(c["scalars"][:2], a["scalars"][:2])
     assert np.abs(c["pg"] - a["pg"]).max() <= 1e-6 * np.abs(a["pg"]).max()
     assert np.abs(c["qg"] - a["qg"]).max() <= 1e-6 * np.abs(a["qg"]).max()
+
+
+# ---- the reference's early stop under point sharding: the replicated mean reward (model.mean_reward) -------------------------
+
+def _worker_points_early_stop(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from trajectory_optimization_amd import synth
+    from trajectory_optimization_amd.distributed import PointShard, init_from_env
+    from trajectory_optimization_amd.model import ModelTraj
+    _, _, device = init_from_env(backend="gloo")
+    # a cloud whose two halves see very different rewards: rows sorted along x, the path over the first half
+    pts = synth.make_cloud(60_000, seed=23)
+    pts = pts[np.argsort(pts[:, 0])]
+    poses, quats = synth.make_path(9, optical=True, jitter_seed=23)
+    m = ModelTraj(torch.from_numpy(pts), torch.from_numpy(poses), torch.from_numpy(quats), torch.from_numpy(synth.K_INTRINS),
+                  synth.IMG_WIDTH, synth.IMG_HEIGHT, device=device, shard=PointShard())
+    opt = torch.optim.Adam([{"params": [m.poses], "lr": 0.05}, {"params": [m.quats], "lr": 0.01}])
+    # TrajOpt.run (/root/reference/src/trajectory_optimization.py:100-127) with the replicated mean in place of torch.mean(model.rewards)
+    rewards_th, smoothness_th, stop_at, local_gains, gains = 1.004, 0.5, -1, [], []
+    reward0 = smooth0 = local0 = None
+    for i in range(40):
+        opt.zero_grad()
+        loss = m(vis_wps_dist=0.0)
+        loss.backward()
+        opt.step()
+        if i == 0:
+            reward0, smooth0, local0 = m.mean_reward.clone(), m.loss["smooth"].detach().clone(), torch.mean(m.rewards.detach())
+        vis_gain, smooth_gain = m.mean_reward / reward0, smooth0 / m.loss["smooth"].detach()
+        gains.append(float(vis_gain))
+        local_gains.append(float(torch.mean(m.rewards.detach()) / local0))
+        if vis_gain > rewards_th and smooth_gain > smoothness_th:
+            stop_at = i
+            break
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), stop_at=stop_at, gains=np.asarray(gains), local_gains=np.asarray(local_gains),
+             poses=m.poses.detach().cpu().numpy(), mean=float(m.mean_reward), local_mean=float(torch.mean(m.rewards.detach())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_point_sharded_early_stop_uses_the_replicated_mean(tmp_path):
+    """ModelTraj(shard=PointShard()).mean_reward: the reference's early-stop rule on it fires at the SAME step on every rank (on
+    torch.mean(model.rewards) — this rank's rows only — the ranks would disagree and the slower one would wait in its next forward's
+    collective for ever)."""
+    world = 2
+    mp.spawn(_worker_points_early_stop, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in range(world))
+    assert int(r0["stop_at"]) == int(r1["stop_at"]) and 0 < int(r0["stop_at"]) < 39, (r0["stop_at"], r1["stop_at"])   # it fired, on both, together
+    assert np.array_equal(r0["gains"], r1["gains"]) and np.array_equal(r0["poses"], r1["poses"]) and float(r0["mean"]) == float(r1["mean"])
+    assert float(r0["local_mean"]) != float(r1["local_mean"])        # the rank-local means are different numbers ...
+    # ... and their gains cross the threshold at different steps (or not at all): the hazard the replicated value removes
+    first = [next((i for i, g in enumerate(r["local_gains"]) if g > 1.004), None) for r in (r0, r1)]
+    assert first[0] != first[1] or not np.allclose(r0["local_gains"], r1["local_gains"]), first

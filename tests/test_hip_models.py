@@ -101,6 +101,27 @@ def test_model_pose_matches_reference(dev, name):
     assert rel_inf(m.quat.grad.cpu().numpy(), d["quat_grad"]) < 1e-5
 
 
+def test_pose_that_sees_nothing(dev):
+    """/root/reference/src/model.py:124-127 with every observation below FLT_MIN (fixture made by running the reference: loss 1/eps,
+    54 subnormal observations summing to 1.3e-43, a gradient of ~1e-29): the hardware's exp flushes subnormals, so the HIP path's
+    observations are zeros where the reference holds 1e-40s — the documented bound: the loss equal, every observation below
+    FLT_MIN, |gradient| <= 1e-20 and finite."""
+    d = load_golden("pose_sees_nothing")
+    m = _pose_model(d, dev)
+    loss = m(hpr=False)
+    loss.backward()
+    tiny = float(np.finfo(np.float32).tiny)
+    assert abs(loss.item() - float(d["loss"])) <= 1e-6 * float(d["loss"])
+    obs = m.observations.detach().cpu().numpy()
+    assert float(obs.max()) < tiny and float(obs.min()) >= 0.0 and float(np.abs(obs - d["observations"]).max()) < tiny
+    for g, ref in ((m.trans.grad, d["trans_grad"]), (m.quat.grad, d["quat_grad"])):
+        g = g.cpu().numpy()
+        assert np.isfinite(g).all() and np.abs(g).max() <= 1e-20 and np.abs(g - ref).max() <= 1e-20
+    from trajectory_optimization_amd.optimizer import optimize_pose
+    res = optimize_pose(_pose_model(d, dev), n_opt_steps=3)   # the launch-only loop: same loss, the pose stays finite
+    assert all(abs(x - float(d["loss"])) <= 1e-6 * float(d["loss"]) for x in res.losses)
+
+
 def test_pose_adam_loop(dev):
     d = load_golden("pose_adam_bundled")
     d["points"] = load_golden("bundled")["pts"]

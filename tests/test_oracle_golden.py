@@ -142,6 +142,26 @@ def test_pose(name, prec):
     assert rel_inf(qg, d["quat_grad"]) < 1e-5
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_pose_that_sees_nothing(prec):
+    """The reference's "camera sees nothing" edge (/root/reference/src/model.py:124-127): every observation below FLT_MIN, loss =
+    1/eps, a gradient of ~1e-29 made of subnormals.  What any implementation owes it: the loss, observations that are nothing
+    (below FLT_MIN), a gradient that is nothing (|g| <= 1e-20).  The f64 restatement, which has no subnormals at these magnitudes,
+    also reproduces the reference's tiny gradient in direction."""
+    d = load_golden("pose_sees_nothing")
+    tiny = np.finfo(np.float32).tiny
+    assert float(d["observations"].max()) < tiny and int(d["n_subnormal"]) > 0 and float(d["loss"]) == pytest.approx(1e6, rel=1e-6)
+    assert np.abs(d["trans_grad"]).max() < 1e-20 and np.abs(d["quat_grad"]).max() < 1e-20
+    obs, loss = oracle.pose_forward(d["points"], d["trans0"], d["q0"], K, IW, IH, prec=prec)
+    assert abs(loss - float(d["loss"])) <= 1e-6 * float(d["loss"]) and float(np.max(obs)) < tiny
+    tg, qg = oracle.pose_backward(d["points"], d["trans0"], d["q0"], K, IW, IH, loss, prec=prec)
+    assert np.abs(tg).max() <= 1e-20 and np.abs(qg).max() <= 1e-20 and np.isfinite(tg).all() and np.isfinite(qg).all()
+    if prec == "f64":
+        a, b = np.asarray(tg, np.float64).ravel() * 1e30, d["trans_grad"].astype(np.float64).ravel() * 1e30   # (1e-60 is not an f32)
+        c = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
+        assert c > 0.9, c
+
+
 def test_elementwise_funcs():
     d = load_golden("funcs")
     cam = oracle.to_camera_frame(d["points"], d["quat"], d["trans"])

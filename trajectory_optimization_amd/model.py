@@ -357,6 +357,7 @@ class _TrajLossPoints(torch.autograd.Function):
         n_eval = (W + step_w - 1) // step_w
         st = model._point_step(n_eval)
         rewards, scalars, pg_e, qg_e = st.step(p_all, q_all, flags_extra=((step_w - 1) & 0xffff) << 8)   # every step_w-th waypoint, read in place
+        model._mean_reward = scalars[0].clone()   # of ALL points, identical on every rank (model.mean_reward)
         terms = torch.empty(8, dtype=torch.float32, device=dev)
         reg_sum = torch.empty((W, 3), dtype=torch.float32, device=dev)
         reg_terms = torch.empty((3, W, 3), dtype=torch.float32, device=dev)
@@ -822,6 +823,7 @@ class ModelTraj(nn.Module):
         else:
             self.points = torch.as_tensor(points, dtype=torch.float32).to(self.device)
         self.rewards = None
+        self._mean_reward = None
         self.observations = None
         self.lo_sum = 0.0  # attribute kept for the reference's surface (its accumulated log-odds); the kernels hold theirs in packed order
 
@@ -888,6 +890,18 @@ class ModelTraj(nn.Module):
         kw.setdefault("min_dist", other.pc_clip_limits[0])
         kw.setdefault("max_dist", other.pc_clip_limits[1])
         return cls(other._cloud, wps_poses, wps_quats, other.K, other.img_width, other.img_height, **kw)
+
+    @property
+    def mean_reward(self):
+        """mean(rewards) over the WHOLE cloud after the last forward, as a 0-d tensor — what the reference's early-stop rule reads
+        (`torch.mean(model.rewards) / reward0`, /root/reference/src/trajectory_optimization.py:119-122).  With point sharding
+        model.rewards holds this rank's rows only and torch.mean of it differs from rank to rank: a loop that stops on it would
+        leave the ranks at different steps, and the ones that go on would wait for ever in the next forward's collectives.  This is
+        the replicated value (the all-reduced reward sum over the global point count); without point sharding it is
+        torch.mean(model.rewards)."""
+        if self._n_global is not None:
+            return self._mean_reward
+        return torch.mean(self.rewards.detach()) if self.rewards is not None else None
 
     def refresh_occlusion(self):
         """The next forward rebuilds the occlusion masks whatever occlusion_refresh_every says."""

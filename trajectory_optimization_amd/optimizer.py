@@ -166,6 +166,7 @@ def _optimize_trajectory_points(model, n_opt_steps, lr_pose, lr_quat, rewards_th
     steps = int(stt[3].item())
     lt_host = loss_terms[:max(steps, 1)].cpu()
     model.rewards = st.rewards
+    model._mean_reward = st.scalars[0].clone()
     model.loss = {"vis": lt_host[-1, 0], "l2": lt_host[-1, 1], "length": lt_host[-1, 2], "smooth": lt_host[-1, 3]}
     return TrajOptResult(steps, bool(stt[2].item() != 0), lt_host[:, 4].tolist(), float(stt[4]), float(stt[5]))
 
