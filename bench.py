@@ -17,7 +17,7 @@ Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed on 
 The roofline is a VALU-ISSUE roofline: the kernels keep points in registers and stream waypoint records through SGPRs,
 so a launch moves ~N*16 B whatever W is (1 % of HBM peak) and is bound by vector-instruction issue.
   achieved = issue cycles the launch's instruction stream needs / kernel time
-             (instruction mix of the compiled inner loop: profiles/r04_pass1_isa_mix.json, from tools/isa_stats.py;
+             (instruction mix of the compiled inner loop: profiles/r05_pass1_isa_mix.json, from tools/isa_stats.py;
               prices per wave64 instruction measured on this chip: profiles/r02_valu_peak.json, tools/valu_peak.hip —
               packed f32 4, transcendental 8, other VALU 4 cycles)
   peak     = 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, max clock)
@@ -71,18 +71,18 @@ def source_hash():
 def isa_mix():
     """VALU instructions of one (wave, waypoint) iteration of k_traj_pass1's dense inner loop (= 64*P evaluations), by class.
     The mix is a checked-in count of the compiled loop: it is only valid for the sources it was counted on."""
-    d = _profile_json("r04_pass1_isa_mix.json")
+    d = _profile_json("r05_pass1_isa_mix.json")
     if d is None:
-        raise SystemExit("profiles/r04_pass1_isa_mix.json is missing (tools/isa_stats.py --json writes it)")
+        raise SystemExit("profiles/r05_pass1_isa_mix.json is missing (tools/isa_stats.py --json writes it)")
     d["stale"] = d.get("source_hash") != source_hash()
     return d
 
 
 def pmc_figures(kernel):
     """(HBM bytes per launch, VALU busy fraction) of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r04_bench_dense_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes; SQ_ACTIVE_INST_VALU x4 over the SIMD
+    (profiles/r05_bench_dense_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes; SQ_ACTIVE_INST_VALU x4 over the SIMD
     cycles of the kernel), or (None, None, None)."""
-    d = _profile_json("r04_bench_dense_pmc.json")
+    d = _profile_json("r05_bench_dense_pmc.json")
     try:
         for name, v in d["kernels"].items():
             if kernel in name and "hbm_bytes_per_launch_corrected" in v:
@@ -973,7 +973,7 @@ def main():
                                      "diagnostic pass): what the blocks themselves take; kernel_ms_per_launch also holds the "
                                      "launch / queueing share of a back-to-back dependent launch"},
                          "hbm_counter_frac": (traffic / (p1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "traffic_note": "HBM bytes per launch from profiles/r04_bench_dense_pmc.json (separate --pmc passes of "
+                         "traffic_note": "HBM bytes per launch from profiles/r05_bench_dense_pmc.json (separate --pmc passes of "
                                          "this command: 2 x FETCH_SIZE + WRITE_SIZE); a few per cent of the HBM peak: points live "
                                          "in registers, waypoints stream through SGPRs, the 8-byte (min, max) stores go out as "
                                          "32-byte sectors",
