@@ -71,7 +71,29 @@ def test_hip_on_what_the_stress_runs_found(name, dense):
     if name == "traj_stress_31_101":
         ref = d["vis_poses_grad"].astype(np.float64)
         assert np.array_equal(np.abs(gp).max(axis=1) > 0, np.abs(ref).max(axis=1) > 0)   # the same single waypoint carries gradient
-        assert np.abs(gp - ref).max() <= 0.15 * np.abs(ref).max() and np.abs(gq - d["vis_quats_grad"]).max() <= 0.15 * np.abs(d["vis_quats_grad"]).max()
+        # the bound, derived on the f64 restatement: the gradient is (dL/dr) r (1 - r) of points with r -> 1, and an f32 r carries
+        # half an ulp of 1 (2^-25) of its own rounding — what is the gradient worth when every reward moves by that much either way?
+        from oracle import oracle
+        f64 = oracle.traj_forward(d["points"], d["poses"], d["quats"], K, IW, IH, d["clip"][0], d["clip"][1], prec="f64")
+        kw = dict(min_dist=d["clip"][0], max_dist=d["clip"][1], prec="f64")
+        pg64, qg64 = oracle.traj_backward(d["points"], d["poses"], d["quats"], K, IW, IH, f64, **kw)
+        spread = []
+        for sgn in (-1.0, 1.0):
+            f = dict(f64)
+            f["rewards"] = np.clip(f64["rewards"] + sgn * 2.0 ** -25, 0.0, 1.0)
+            spread.append(oracle.traj_backward(d["points"], d["poses"], d["quats"], K, IW, IH, f, **kw))
+        worth_p = np.abs(spread[1][0] - spread[0][0]).max()
+        worth_q = np.abs(spread[1][1] - spread[0][1]).max()
+        assert 0.01 * np.abs(pg64).max() < worth_p < np.abs(pg64).max(), (worth_p, np.abs(pg64).max())
+        for got in (gp, ref):   # this implementation and the reference itself, both against the f64 restatement
+            assert np.abs(got - pg64).max() <= 1.05 * worth_p
+        assert np.abs(gq - qg64).max() <= 1.05 * worth_q and np.abs(d["vis_quats_grad"] - qg64).max() <= 1.05 * worth_q
+        # ... and since r05 this implementation takes 1 - r from the exponential (r e, no cancellation): it holds the plain bar here too
+        assert np.abs(gp - ref).max() <= 1e-5 * np.abs(ref).max() and np.abs(gq - d["vis_quats_grad"]).max() <= 1e-5 * np.abs(d["vis_quats_grad"]).max()
+        assert np.abs(gp - pg64).max() <= 1e-5 * np.abs(pg64).max()
+        warnings.warn(f"{name}: one gradient row of {np.abs(ref).max():.1e}; half an ulp of 1 in the rewards, either way, is worth {worth_p / np.abs(pg64).max():.2f} of it; "
+                      f"HIP vs reference {np.abs(gp - ref).max() / np.abs(ref).max():.2e}, HIP vs f64 {np.abs(gp - pg64).max() / np.abs(pg64).max():.2e}, "
+                      f"reference vs f64 {np.abs(ref - pg64).max() / np.abs(pg64).max():.2e}")
         return
     rep = phat_uncertainty_report(d, gp, gq, MARGIN)
     assert rep["inside_bar"] >= 2 * len(d["poses"]) - 4, rep

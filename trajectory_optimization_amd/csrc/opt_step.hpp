@@ -211,7 +211,8 @@ struct OptStep {
     float smooth_w, length_w, eps, lr_pose, lr_quat, beta1, beta2, adam_eps, rewards_th, smoothness_th;
 };
 
-// prologue: block `b` of the extra blocks of the probe's launch = trajectory b
+// prologue: block `b` of the extra blocks of the SPARSE kernel's launch = trajectory b (what it leaves — pro, reg — is for the
+// launches after that one: the pairs' extra block, the finish blocks)
 __device__ __forceinline__ void opt_prologue_block(const OptStep& a, int b, double* lds, double* sh) {
     const float* poses = a.poses + (int64_t)b * a.W * 3;
     const float* poses0 = a.poses0 + (int64_t)b * a.W * 3;

@@ -974,9 +974,11 @@ __device__ __forceinline__ void sparse_slot(const SparseArgs& a, int slot, int t
             float un[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float rw = to_rcp(1.0f + to_exp(-lo[j]));   // == k_traj_reward's value of rewards[perm[i]]
-                if (lo[j] != lo[j]) rw = lo[j];
-                un[j] = base + j < a.cv.n ? 1.0f * rw * (1.0f - rw) : 0.f;   // the pair kernel's d reward / d lo_sum of this point, bit for bit
+                const float ex = to_exp(-lo[j]);
+                float rw = to_rcp(1.0f + ex);   // == k_traj_reward's value of rewards[perm[i]]
+                float om = rw * ex;             // 1 - r = e / (1 + e): taken from the exponential, not from r (see pair_sums)
+                if (lo[j] != lo[j]) { rw = lo[j]; om = lo[j]; }
+                un[j] = base + j < a.cv.n ? 1.0f * rw * om : 0.f;   // the pair kernel's d reward / d lo_sum of this point, bit for bit
                 if (base + j < a.cv.n) {                      // pads are not points
                     if (a.rewards != nullptr && (!a.prefilled || lo[j] != 0.f)) a.rewards[(int64_t)tr * a.cv.n + o[j]] = rw;
                     if (rw != rw) fnan = true;
@@ -1110,12 +1112,17 @@ __device__ __forceinline__ void pair_sums(const SparseArgs& a, int slot, int v, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (UNIT) { gn[j] = lo[j]; continue; }   // (l4 holds r (1 - r) then)
-        float rw = to_rcp(1.0f + to_exp(-lo[j]));
-        if (lo[j] != lo[j]) rw = lo[j];
+        // d reward / d lo_sum = r (1 - r) with 1 - r = e / (1 + e) = r e, e = exp(-lo_sum): where r -> 1 the difference 1 - r taken
+        // from an f32 r keeps one or two digits (r = 0.9999999: 54 % per half ulp of r — the stress fixture traj_stress_31_101,
+        // where the reference's own f32 sits within 2e-6 of the f64 result and r04's 1 - r was 8.5 % off)
+        const float ex = to_exp(-lo[j]);
+        float rw = to_rcp(1.0f + ex);
+        float om = rw * ex;
+        if (lo[j] != lo[j]) { rw = lo[j]; om = lo[j]; }
         const bool valid = base + j < a.cv.n;        // pads are not points
         float gr = coef;
         if (a.grad_rewards != nullptr) gr = valid ? a.grad_rewards[(int64_t)tr * a.cv.n + o[j]] : 0.f;
-        gn[j] = valid ? gr * rw * (1.0f - rw) : 0.f;
+        gn[j] = valid ? gr * rw * om : 0.f;
     }
     f2 acc[TO_BWD_NSUM];
 #pragma unroll
@@ -1988,7 +1995,7 @@ struct TrajStep {
     int wp_stride = 1;   // rows between two evaluated waypoints in the arrays handed to the probe
     int traj_rows = 0;   // > 0: rows every trajectory owns in those arrays (its evaluated waypoints are rows 0, wp_stride, ... of its own)
     bool lean = false;   // an optimisation step that is not the run's last: lo_sum and rewards are nobody's to read (TOHIP_TRAJ_OPT_LAST_OUTPUTS)
-    OptStep opt = OptStep{};   // mode != 0: the step's prologue / epilogue ride in the probe's, the pairs' and the finish launches (opt_step.hpp)
+    OptStep opt = OptStep{};   // mode != 0: the step's prologue / epilogue ride in the sparse kernel's, the pairs' and the finish launches (opt_step.hpp)
     float* opt_scalars = nullptr;   // opt.mode == 2: model()'s scalars (the extra block of the pairs' launch writes them)
     RewardAcc* acc;
     WayRec* rec;
@@ -2371,7 +2378,8 @@ extern "C" int tohip_traj_forward_backward(const void* packed, int64_t n, const 
 // ---- one step of TrajOpt.run (trajectory_optimization.py:100-127) as ONE call and FIVE launches ------------------------------
 // zero_grad(); loss = model(); loss.backward(); optimizer.step(); early-stop bookkeeping — for n_traj trajectories over one cloud.
 // The waypoint selection is a stride of the probe's reads, the regularisers and the step's Adam constants are extra blocks of
-// the probe's launch, the parameter update and the bookkeeping are the tail of every k_traj_finish block (opt_step.hpp).
+// the SPARSE kernel's launch (consumers of pro / reg come after it), the parameter update and the bookkeeping are the tail of
+// every k_traj_finish block (opt_step.hpp).
 namespace {
 struct OptLayout { size_t off_pro, off_reg, total; };
 inline OptLayout opt_layout(int64_t W, int64_t n_traj) {

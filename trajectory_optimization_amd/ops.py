@@ -406,13 +406,19 @@ _SCRATCH = {}
 
 
 def _scratch(device, tag, nbytes):
-    """A grow-only byte buffer per (device, purpose): the occlusion rows are rebuilt again and again over buffers of GBs whose
-    sizes vary a little from call to call — allocating them anew every time cost more than the kernels (12 of 34 ms per rebuild at
-    1 M points x 128 waypoints).  release_scratch() gives the memory back."""
-    key = (str(device), tag)
+    """A grow-only byte buffer per (device, STREAM, purpose): the occlusion rows are rebuilt again and again over buffers of GBs
+    whose sizes vary a little from call to call — allocating them anew every time cost more than the kernels (12 of 34 ms per
+    rebuild at 1 M points x 128 waypoints).  Keyed by the current stream: two models rebuilding their masks on two streams do not
+    share a buffer (on ONE stream the calls are ordered, and a buffer's content is dead when the call that filled it returns its
+    rows).  A buffer that is outgrown is handed to the caching allocator with its stream recorded, so that work still queued on it
+    finishes first.  release_scratch() gives the memory back."""
+    stream = torch.cuda.current_stream(device)
+    key = (str(device), stream.cuda_stream, tag)
     t = _SCRATCH.get(key)
     if t is None or t.numel() < nbytes:
-        _SCRATCH.pop(key, None)
+        old = _SCRATCH.pop(key, None)
+        if old is not None:
+            old.record_stream(stream)
         t = _SCRATCH[key] = torch.empty(int(nbytes * 1.1) + 256, dtype=torch.uint8, device=device)
     return t
 

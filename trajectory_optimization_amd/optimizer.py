@@ -105,10 +105,11 @@ class _OptRun:
                 m.poses.data.copy_(self.poses[b * self.W:(b + 1) * self.W])
                 m.quats.data.copy_(self.quats[b * self.W:(b + 1) * self.W])
             steps = int(st[b, 3].item())
-            row = lt[b, max(steps, 1) - 1]
-            m.rewards = self.rewards[b]
-            m.loss = {"vis": row[0], "l2": row[1], "length": row[2], "smooth": row[3]}
-            out.append(TrajOptResult(steps, bool(st[b, 2].item() != 0), lt[b, :max(steps, 1), 4].tolist(), float(st[b, 4]), float(st[b, 5])))
+            if steps > 0:   # (a trajectory that was never stepped keeps what it had)
+                row = lt[b, steps - 1]
+                m.rewards = self.rewards[b]
+                m.loss = {"vis": row[0], "l2": row[1], "length": row[2], "smooth": row[3]}
+            out.append(TrajOptResult(steps, bool(st[b, 2].item() != 0), lt[b, :steps, 4].tolist(), float(st[b, 4]), float(st[b, 5])))
         return out
 
 
@@ -119,11 +120,13 @@ def optimize_trajectory(model, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewards
     model.poses / model.quats hold the optimised trajectory, model.rewards the last rewards, model.loss the last terms.
 
     A step is ONE library call and FIVE launches (tohip_traj_opt_step): the waypoint selection is a stride of the first launch's
-    reads, the regularisers and Adam's constants are one block more of the first launch, the parameter update and the early-stop
-    bookkeeping are the tail of the last launch's blocks.  A waypoint-sharded or occlusion-aware model has a collective or a hull
+    reads, the regularisers and Adam's constants are one block more of the THIRD launch (the sparse kernel's: nothing launched
+    before it may read them), the parameter update and the early-stop bookkeeping are the tail of the last launch's blocks.  A waypoint-sharded or occlusion-aware model has a collective or a hull
     pass inside the step and goes through the separate calls (forward | all-reduce | reward + backward | tohip_traj_step_tail).
     (A HIP-graph replay of the step was measured slower than issuing its launches — a replay costs 10-16 us of host time by
     itself, five launches 17 us, and the GPU side is the same — so there is no graph variant.)"""
+    if n_opt_steps <= 0:   # nothing to run: the model keeps its rewards and loss terms
+        return TrajOptResult(0, False, [], 0.0, 0.0)
     if getattr(model, "_n_global", None) is not None:
         return _optimize_trajectory_points(model, n_opt_steps, lr_pose, lr_quat, rewards_th, smoothness_th, vis_wps_dist, betas, adam_eps)
     if model._shard.world_size > 1 or getattr(model._shard, "_always", False) or model._occlusion is not None:
@@ -278,6 +281,8 @@ def optimize_trajectories(models, n_opt_steps=10, lr_pose=0.1, lr_quat=0.0, rewa
             raise ValueError("optimize_trajectories: the models must live on one device and share eps")
         if m is not m0 and rig is not None and (m._rig.n_cams != rig.n_cams or not torch.equal(m._rig.q, rig.q) or not torch.equal(m._rig.t, rig.t)):
             raise ValueError("optimize_trajectories: the models must share the camera rig (extrinsics differ)")
+    if n_opt_steps <= 0:   # nothing to run: the models keep their rewards and loss terms
+        return [TrajOptResult(0, False, [], 0.0, 0.0) for _ in models]
     run = _OptRun(list(models), n_opt_steps, lr_pose, lr_quat, rewards_th, smoothness_th, vis_wps_dist, betas, adam_eps)
     run.run(n_opt_steps)
     return run.results(n_opt_steps)
