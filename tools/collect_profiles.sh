@@ -22,6 +22,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/opt" -o opt -- pyt
 for sc in multi8 w1024 cam5 c2; do   # the large-W regime on one GPU (tools/prof_multi.py), culled = the library default
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/multi_$sc" -o multi_$sc -- python3 "$root/tools/prof_multi.py" --scenario $sc --mode culled --steps 40 --warmup 10 --no-events > "$out/multi_$sc.log" 2>&1
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/message" -o message -- python3 "$root/tools/prof_message.py" 3 > "$out/message.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/aux" -o aux -- python3 "$root/tools/prof_aux.py" 16000000 > "$out/aux.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/aux_fetch" -o pmc -- python3 "$root/tools/prof_aux.py" 16000000 > "$out/aux_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/aux_write" -o pmc -- python3 "$root/tools/prof_aux.py" 16000000 > "$out/aux_write.log" 2>&1

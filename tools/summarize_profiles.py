@@ -69,6 +69,8 @@ def main():
     for sub, name in (("opt", "optimize"), ("aux", "aux")):
         if os.path.exists(os.path.join(src, sub, f"{sub}_kernel_stats.csv")):
             shutil.copy(os.path.join(src, sub, f"{sub}_kernel_stats.csv"), os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
+    if os.path.exists(os.path.join(src, "message", "message_kernel_stats.csv")):   # tools/prof_message.py
+        shutil.copy(os.path.join(src, "message", "message_kernel_stats.csv"), os.path.join(dst, f"{tag}_message_kernel_stats.csv"))
     for sc in ("multi8", "w1024", "cam5", "c2"):   # tools/prof_multi.py scenarios
         f = os.path.join(src, f"multi_{sc}", f"multi_{sc}_kernel_stats.csv")
         if os.path.exists(f):

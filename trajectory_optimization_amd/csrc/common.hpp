@@ -286,6 +286,11 @@ __device__ __forceinline__ float wave_sum16_transposed(const float (&v)[16], int
     return r;
 }
 
+// one (x, y, z) row of an (n,3) f32 array as ONE 12-byte load (global_load_dwordx3; rows are 4-byte aligned): a gather through a
+// permutation then touches a row's line once, where three dword loads fetched it three times (2.8 GB for 16 M points)
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+__device__ __forceinline__ F3 load_row3(const float* __restrict__ xyz, int64_t row) { return *reinterpret_cast<const F3*>(xyz + 3 * row); }
+
 // ----------------------------------------------------------------------------------------------
 // Bounds of a cloud (the pack's box, the voxel grid's cell range): a pass over (n,3) f32 whose result is six numbers.
 // Device-scope atomics on ONE cache line are served one after the other (~80 ns each): six per wave from 1 000 waves were 77 us

@@ -15,12 +15,19 @@
 // cloud packing: (N,3) -> Morton-sorted x|y|z (padded with copies of the last sorted point), the
 // permutation back to the caller's order, and one bounding sphere per 256 sorted points.
 
-// order-preserving float -> int (the signed integer order is the float order; -0 and +0 stay neighbours)
-__device__ __forceinline__ int fkey(float f) {
+__device__ __forceinline__ unsigned fkey(float f) {  // order-preserving float -> uint (hull_kernels.hip's boxes)
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// order-preserving float -> int (the SIGNED integer order is the float order: what common.hpp's bounds_commit compares)
+__device__ __forceinline__ int fkey_i(float f) {
     const int u = __float_as_int(f);
     return u >= 0 ? u : (int)(0x80000000u - (unsigned)u);   // negative floats: magnitude grows downwards
 }
-__device__ __forceinline__ float fkey_inv(int k) {
+__device__ __forceinline__ float fkey_i_inv(int k) {
     return __int_as_float(k >= 0 ? k : (int)(0x80000000u - (unsigned)k));
 }
 
@@ -32,7 +39,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_bbox(const float* __restrict__ xyz
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             if (p[k] != p[k]) continue;  // NaNs do not shape the box
-            const int u = fkey(p[k]);
+            const int u = fkey_i(p[k]);
             mn[k] = min(mn[k], u); mx[k] = max(mx[k], u);
         }
     });
@@ -53,8 +60,8 @@ k_morton(const float* __restrict__ xyz, int64_t n, const int* __restrict__ bbox,
          int* __restrict__ vals) {
     int bmn[3], bmx[3];
     bounds_fold(bbox, bmn, bmx);
-    const float lo[3] = {fkey_inv(bmn[0]), fkey_inv(bmn[1]), fkey_inv(bmn[2])};
-    const float hi[3] = {fkey_inv(bmx[0]), fkey_inv(bmx[1]), fkey_inv(bmx[2])};
+    const float lo[3] = {fkey_i_inv(bmn[0]), fkey_i_inv(bmn[1]), fkey_i_inv(bmn[2])};
+    const float hi[3] = {fkey_i_inv(bmx[0]), fkey_i_inv(bmx[1]), fkey_i_inv(bmx[2])};
     // one cell size for all axes (cubic cells: compact tiles), set by the longest side of the box
     const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
     float sc[3];
@@ -91,7 +98,8 @@ k_pack_cloud(const float* __restrict__ xyz, const int* __restrict__ order, int64
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t i = tile * TO_BLOCK + t;
         const int64_t s = order[i < n ? i : n - 1];
-        const float px = xyz[3 * s], py = xyz[3 * s + 1], pz = xyz[3 * s + 2];
+        const F3 row = load_row3(xyz, s);
+        const float px = row.x, py = row.y, pz = row.z;
         // a NaN / inf coordinate: the reference's min() over p makes every reward of every waypoint NaN (model.py:226) — noted once
         // here, honoured by k_traj_probe (fmax / fmin and the culling would drop such a point silently)
         if (i < n && !(isfinite(px) && isfinite(py) && isfinite(pz))) atomicOr(&hdr[1], 1);

@@ -235,8 +235,8 @@ k_vox_centroids(const float* __restrict__ xyz, const unsigned long long* __restr
         float sx = 0.f, sy = 0.f, sz = 0.f;
         int cnt = 0;
         for (; i < n && keys[i] == key; ++i) {
-            const int64_t s = order[i];
-            sx += xyz[3 * s]; sy += xyz[3 * s + 1]; sz += xyz[3 * s + 2];
+            const F3 row = load_row3(xyz, order[i]);
+            sx += row.x; sy += row.y; sz += row.z;
             ++cnt;
         }
         const float c = (float)cnt;
