@@ -555,6 +555,14 @@ int tohip_render_points(const float *verts, int64_t n_points, const float *K9_ho
                         float radius, float znear, float zfar, float background, float *image, int32_t *owner,
                         int32_t *owns_pixel, void *workspace, size_t workspace_bytes, void *stream);
 
+/* render_pc_image's `gamma` (tools.py:122, 160-171: pulsar's blending softness): every disc covering a pixel centre contributes with
+ * weight (1 - distance to the disc's centre / its radius) * exp(normalised depth / gamma), the background with exp(0); the statement
+ * of the blend is in render_kernels.hip (parity unpinned).  Deterministic: integer atomics in fixed point.  gamma > 0, zfar > znear. */
+size_t tohip_render_blend_workspace_bytes(int32_t width, int32_t height);
+int tohip_render_points_blend(const float *verts, int64_t n_points, const float *K9_host, int32_t width, int32_t height, float radius,
+                              float znear, float zfar, float gamma, float background, float *image, void *workspace,
+                              size_t workspace_bytes, void *stream);
+
 /* The z-buffer visibility sets of n_clouds camera-frame clouds at once (tohip_render_points' owns_pixel for each): cloud w = the
  * first count[w] (device int32) rows of verts + w * n_stride * 3 — the layout tohip_cull_waypoints writes — with its own z-buffer;
  * visible[w * n_stride + j] = 1.0f when its point j owns a pixel, else 0.  Clouds go through in chunks of as many z-buffers as the

@@ -36,6 +36,50 @@ def test_hip_render_matches_oracle(n, h, w, seed):
     assert np.array_equal(np.flatnonzero(owns.cpu().numpy()), np.unique(ref_owner[ref_owner >= 0]))
 
 
+def test_oracle_blend_limits():
+    """The stated blend between its two ends: gamma -> 0 leaves the front sphere alone (its colour wherever its falloff is not ~0),
+    a large gamma lets the hidden sphere and the background through."""
+    from oracle import render_oracle
+    K = np.array([[50.0, 0, 32.0], [0, 50.0, 24.0], [0, 0, 1]], np.float32)
+    v = np.array([[0, 0, 2.0], [0, 0, 4.0], [0.5, 0.2, 3.0]], np.float32)
+    hard, owner = render_oracle.render_points(v, K, 48, 64, radius=0.1)
+    sharp = render_oracle.render_points_blend(v, K, 48, 64, radius=0.1, gamma=1e-5)
+    np.testing.assert_allclose(sharp, hard, atol=1e-6)
+    soft = render_oracle.render_points_blend(v, K, 48, 64, radius=0.1, gamma=1.0)
+    c = (v - v.min()) / (v.max() - v.min())
+    p = soft[24, 32]            # centre pixel: discs of points 0 and 1 and the background
+    assert np.all(np.abs(p - c[0]) > 1e-3) and np.all(np.abs(p - 1.0) > 1e-3)
+    assert np.all(soft[owner < 0] == 1.0) and soft.min() >= 0.0 and soft.max() <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,h,w,seed,gamma", [(1, 48, 64, 0, 0.1), (800, 96, 128, 1, 0.1), (5000, 120, 90, 2, 1.0), (5000, 120, 90, 2, 1e-3),
+                                             (3000, 96, 128, 3, 1e-5)])
+def test_hip_blend_matches_oracle(n, h, w, seed, gamma):
+    """tohip_render_points_blend (fixed-point integer sums) against the float64 restatement, tolerance 1e-5 on colours in 0..1; the
+    same bits on a second run; gamma = 1e-5 is the nearest-depth splat."""
+    from oracle import render_oracle
+    from trajectory_optimization_amd import ops
+    dev = torch.device("cuda:0")
+    K = np.array([[80.0, 0, w / 2], [0, 82.0, h / 2], [0, 0, 1]], np.float32)
+    v = _scene(n, seed)
+    vt = torch.from_numpy(v).to(dev)
+    img = ops.render_points_blend(vt, K, h, w, gamma=gamma)
+    ref = render_oracle.render_points_blend(v, K, h, w, gamma=gamma)
+    np.testing.assert_allclose(img.cpu().numpy(), ref, rtol=0, atol=1e-5)
+    assert torch.equal(img, ops.render_points_blend(vt, K, h, w, gamma=gamma))
+    if gamma <= 1e-5:
+        hard = ops.render_points(vt, K, h, w)[0]
+        assert float((img - hard).abs().max()) < 1e-5
+    from trajectory_optimization_amd import _lib
+    from trajectory_optimization_amd._lib import ptr
+    import ctypes
+    K9 = (ctypes.c_float * 9)(*K.reshape(9).tolist())
+    ws = torch.empty(_lib.lib().tohip_render_blend_workspace_bytes(w, h), dtype=torch.uint8, device=dev)
+    assert _lib.lib().tohip_render_points_blend(ptr(vt), n, K9, w, h, 0.03, 1.0, 10.0, 0.0, 1.0, ptr(img), ptr(ws), ws.numel(), None) == -1   # gamma = 0: EINVAL
+    assert _lib.lib().tohip_render_points_blend(ptr(vt), n, K9, w, h, 0.03, 1.0, 10.0, 0.1, 1.0, ptr(img), ptr(ws), 64, None) == -2            # ENOSPC
+
+
 @pytest.mark.gpu
 def test_render_pc_image_api_full_size():
     """Reference call shape: render_pc_image(points (N,3) camera frame, K, height, width) at the real 1616x1232."""
@@ -51,6 +95,11 @@ def test_render_pc_image_api_full_size():
     # identity extrinsics == none
     img2 = render_pc_image(v, K, height, width, R=torch.eye(3), T=torch.zeros(3), device=dev)
     assert torch.equal(img, img2)
+    # gamma: the default 0.1 blends, 1e-5 is the nearest-depth splat that gamma=None returns directly
+    hard = render_pc_image(v, K, height, width, device=dev, gamma=None)
+    diff = (render_pc_image(v, K, height, width, device=dev, gamma=1e-5) - hard).abs().amax(dim=2)
+    assert float((diff > 1e-5).float().mean()) < 1e-3      # (two spheres within 1e-5 x 9 m of depth over one pixel still mix)
+    assert float((img - hard).abs().max()) > 1e-2
 
 
 @pytest.mark.gpu

@@ -152,6 +152,9 @@ SIGNATURES = {
     "tohip_render_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "tohip_render_points": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(c_f), c_i32, c_i32, c_f, c_f, c_f, c_f, c_vp, c_vp,
                                             c_vp, c_vp, c_sz, c_vp]),
+    "tohip_render_blend_workspace_bytes": (c_sz, [c_i32, c_i32]),
+    "tohip_render_points_blend": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(c_f), c_i32, c_i32, c_f, c_f, c_f, c_f, c_f, c_vp, c_vp, c_sz,
+                                                  c_vp]),
     "tohip_traj_pshard_partial_count": (c_sz, [c_i64]),
     "tohip_traj_extrema_view": (ctypes.c_int, [c_i64, c_i64, c_vp, c_sz, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64)]),
     "tohip_traj_pshard_pass1": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(Camera), ctypes.POINTER(Rig), ctypes.c_int,

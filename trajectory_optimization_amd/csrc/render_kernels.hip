@@ -136,6 +136,143 @@ extern "C" int tohip_render_points(const float* verts, int64_t n, const float* K
 }
 
 // ---------------------------------------------------------------------------------------------
+// Soft blend (`gamma`, tools.py:122 / 160-171: pulsar's blending softness, 1e-5 = hard .. 1 = everything shines through).  The
+// build's statement of pulsar's published per-pixel blend (parity UNPINNED, oracle/render_oracle.py restates this text):
+//
+//   normalised depth of sphere i   zn_i = (zfar - Z_i) / (zfar - znear)            (1 at the near plane, 0 at the far plane)
+//   falloff across its disc        d_i  = 1 - |pixel centre - (u_i, v_i)| / rho_i   (1 at the centre, 0 on the rim)
+//   weight                         w_i  = d_i exp(zn_i / gamma),   background  w_bg = exp(0 / gamma) = 1 (it sits on the far plane)
+//   pixel                          (sum_i w_i c_i + w_bg c_bg) / (sum_i w_i + w_bg)  over the discs covering the pixel centre
+//
+// exp(zn / gamma) overflows for gamma < 0.011, so every weight is taken relative to the pixel's front sphere, whose depth the
+// z-buffer of the nearest-depth pass already holds: exp((zn_i - zn_front) / gamma) <= 1.  The sums are 64-bit integer atomics of
+// the terms in 2^-36 fixed point — no float atomics: the image is the same bits on every run whatever order the discs arrive in
+// (terms <= 1: 2^28 discs over one pixel before the sum wraps; a term under 2^-37 rounds to zero, and spheres more than
+// 26 gamma behind the front are skipped for it).  A pixel whose every weight rounds to zero (it sits exactly on the rim of its only
+// disc and the background's weight underflows) takes the front sphere's colour, as the nearest-depth splat gives it.
+#define TO_BLEND_SCALE 68719476736.0   // 2^36
+__global__ void __launch_bounds__(TO_BLOCK) k_blend_clear(unsigned long long* __restrict__ acc, int64_t nwords) {
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < nwords; i += stride) acc[i] = 0ull;
+}
+
+__device__ __forceinline__ float mm_decode(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_blend_accum(const float* __restrict__ verts, int64_t n, RenderParams rp, float inv_gamma, const unsigned* __restrict__ mm,
+              const unsigned long long* __restrict__ zbuf, unsigned long long* __restrict__ acc) {
+    const float lo = mm_decode(mm[0]), span = mm_decode(mm[1]) - lo;
+    const float inv_range = 1.0f / (rp.zfar - rp.znear);
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float X = verts[3 * i], Y = verts[3 * i + 1], Z = verts[3 * i + 2];
+        if (!(Z >= rp.znear && Z <= rp.zfar)) continue;
+        const float u = rp.fx * X / Z + rp.cx, v = rp.fy * Y / Z + rp.cy;
+        const float rho = rp.fx * rp.radius / Z;
+        if (!(u + rho >= 0.f && u - rho <= (float)rp.width && v + rho >= 0.f && v - rho <= (float)rp.height)) continue;
+        const int j0 = max(0, (int)floorf(u - rho - 0.5f)), j1 = min(rp.width - 1, (int)ceilf(u + rho - 0.5f));
+        const int i0 = max(0, (int)floorf(v - rho - 0.5f)), i1 = min(rp.height - 1, (int)ceilf(v + rho - 0.5f));
+        const float r2 = rho * rho;
+        const double cr = (double)((X - lo) / span), cg = (double)((Y - lo) / span), cb = (double)((Z - lo) / span);
+        for (int pi = i0; pi <= i1; ++pi) {
+            const float dy = ((float)pi + 0.5f) - v;
+            for (int pj = j0; pj <= j1; ++pj) {
+                const float dx = ((float)pj + 0.5f) - u;
+                const float q2 = dx * dx + dy * dy;
+                if (!(q2 <= r2)) continue;
+                const int64_t p = (int64_t)pi * rp.width + pj;
+                const float zf = __uint_as_float((unsigned)(zbuf[p] >> 32));   // the front sphere's depth (<= Z: this disc bid there too)
+                const float t = (zf - Z) * inv_range * inv_gamma;              // (zn_i - zn_front) / gamma <= 0
+                if (t < -26.0f) continue;
+                const float d = fmaxf(1.0f - sqrtf(q2) / rho, 0.0f);
+                const double w = (double)(d * expf(t)) * TO_BLEND_SCALE;
+                const unsigned long long qw = __double2ull_rn(w);
+                if (qw == 0ull) continue;
+                unsigned long long* a = acc + 4 * p;
+                atomicAdd(a, qw);
+                atomicAdd(a + 1, __double2ull_rn(w * cr));
+                atomicAdd(a + 2, __double2ull_rn(w * cg));
+                atomicAdd(a + 3, __double2ull_rn(w * cb));
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(TO_BLOCK)
+k_blend_resolve(const unsigned long long* __restrict__ zbuf, const unsigned long long* __restrict__ acc, int64_t npix,
+                const float* __restrict__ verts, const unsigned* __restrict__ mm, RenderParams rp, float inv_gamma, float bg,
+                float* __restrict__ image) {
+    const float lo = mm_decode(mm[0]), span = mm_decode(mm[1]) - lo;
+    const float inv_range = 1.0f / (rp.zfar - rp.znear);
+    const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
+    for (int64_t p = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; p < npix; p += stride) {
+        const unsigned long long key = zbuf[p];
+        float r = bg, g = bg, b = bg;
+        if (key != ~0ull) {
+            const float zf = __uint_as_float((unsigned)(key >> 32));
+            const double wbg = (double)expf((zf - rp.zfar) * inv_range * inv_gamma);   // exp((0 - zn_front) / gamma)
+            const double W = (double)acc[4 * p] * (1.0 / TO_BLEND_SCALE) + wbg;
+            if (W > 0.0) {
+                r = (float)(((double)acc[4 * p + 1] * (1.0 / TO_BLEND_SCALE) + wbg * (double)bg) / W);
+                g = (float)(((double)acc[4 * p + 2] * (1.0 / TO_BLEND_SCALE) + wbg * (double)bg) / W);
+                b = (float)(((double)acc[4 * p + 3] * (1.0 / TO_BLEND_SCALE) + wbg * (double)bg) / W);
+            } else {
+                const int64_t i = (int64_t)(key & 0xffffffffull);
+                r = (verts[3 * i] - lo) / span; g = (verts[3 * i + 1] - lo) / span; b = (verts[3 * i + 2] - lo) / span;
+            }
+        }
+        image[3 * p] = r; image[3 * p + 1] = g; image[3 * p + 2] = b;
+    }
+}
+
+extern "C" size_t tohip_render_blend_workspace_bytes(int32_t width, int32_t height) {
+    if (width <= 0 || height <= 0) return 256;
+    return align_up((size_t)width * height * sizeof(unsigned long long), 256) + align_up((size_t)width * height * 4 * sizeof(unsigned long long), 256) + 256;
+}
+
+// image: (height, width, 3) f32, the blend above; gamma > 0 (pulsar takes 1e-5 .. 1).
+extern "C" int tohip_render_points_blend(const float* verts, int64_t n, const float* K9_host, int32_t width, int32_t height,
+                                         float radius, float znear, float zfar, float gamma, float background, float* image,
+                                         void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!K9_host || !image || !workspace || width <= 0 || height <= 0 || n < 0 || n > 0x7fffffffLL || (n > 0 && !verts) ||
+        !(radius > 0.f) || !(znear > 0.f) || !(zfar > znear) || !(gamma > 0.f))
+        return TOHIP_EINVAL;
+    if (workspace_bytes < tohip_render_blend_workspace_bytes(width, height)) return TOHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream_;
+    const int64_t npix = (int64_t)width * height;
+    unsigned long long* zbuf = (unsigned long long*)workspace;
+    unsigned long long* acc = (unsigned long long*)((char*)workspace + align_up((size_t)npix * sizeof(unsigned long long), 256));
+    unsigned* mm = (unsigned*)((char*)acc + align_up((size_t)npix * 4 * sizeof(unsigned long long), 256));
+    RenderParams rp;
+    rp.fx = K9_host[0]; rp.cx = K9_host[2]; rp.fy = K9_host[4]; rp.cy = K9_host[5];
+    rp.width = width; rp.height = height; rp.radius = radius; rp.znear = znear; rp.zfar = zfar;
+    hipError_t e = hipMemsetAsync(mm, 0xff, sizeof(unsigned), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(mm + 1, 0, sizeof(unsigned), st);
+    if (e != hipSuccess) return (int)e;
+    int64_t nbp = (npix + TO_BLOCK - 1) / TO_BLOCK;
+    if (nbp > 4096) nbp = 4096;
+    k_zbuf_clear<<<(int)nbp, TO_BLOCK, 0, st>>>(zbuf, npix);
+    TO_HIP_CHECK_LAUNCH();
+    k_blend_clear<<<(int)nbp, TO_BLOCK, 0, st>>>(acc, 4 * npix);
+    TO_HIP_CHECK_LAUNCH();
+    const float inv_gamma = 1.0f / gamma;
+    if (n > 0) {
+        int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
+        if (nb > 4096) nb = 4096;
+        k_minmax_all<<<(int)nb, TO_BLOCK, 0, st>>>(verts, 3 * n, mm);
+        TO_HIP_CHECK_LAUNCH();
+        k_splat<<<(int)nb, TO_BLOCK, 0, st>>>(verts, n, rp, zbuf);
+        TO_HIP_CHECK_LAUNCH();
+        k_blend_accum<<<(int)nb, TO_BLOCK, 0, st>>>(verts, n, rp, inv_gamma, mm, zbuf, acc);
+        TO_HIP_CHECK_LAUNCH();
+    }
+    k_blend_resolve<<<(int)nbp, TO_BLOCK, 0, st>>>(zbuf, acc, npix, verts, mm, rp, inv_gamma, background, image);
+    TO_HIP_CHECK_LAUNCH();
+    return TOHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // The z-buffer visibility sets of MANY camera-frame clouds at once (the occlusion-aware reward's `zbuffer` method: one cloud per
 // waypoint): cloud w = the first count[w] rows of verts[w] (n_stride rows apart — the layout tohip_cull_waypoints
 // writes), its own z-buffer, visible[w][j] = 1.0f when point j owns a pixel (nearest depth, ties by the smaller index: k_splat's

@@ -714,6 +714,23 @@ def render_points(verts, K, height, width, radius=0.03, znear=1.0, zfar=10.0, ba
     return img, owner, owns[:n].bool()
 
 
+def render_points_blend(verts, K, height, width, radius=0.03, znear=1.0, zfar=10.0, gamma=0.1, background=1.0):
+    """-> image (H,W,3) f32: the depth-weighted blend of every disc over each pixel (render_kernels.hip; `gamma` = pulsar's softness)."""
+    _require_cuda(verts, "verts")
+    v = verts.detach().to(torch.float32).contiguous()
+    dev = v.device
+    H, W = int(height), int(width)
+    Kh = torch.as_tensor(K, dtype=torch.float32).detach().cpu()[:3, :3].reshape(9).tolist()
+    Kc = (ctypes.c_float * 9)(*Kh)
+    img = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    wsb = _lib.lib().tohip_render_blend_workspace_bytes(W, H)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().tohip_render_points_blend(ptr(v), v.shape[0], Kc, W, H, float(radius), float(znear), float(zfar), float(gamma),
+                                                   float(background), ptr(img), ptr(ws), wsb, stream_ptr()), "tohip_render_points_blend")
+    return img
+
+
 def selftest_wave_reduce(mat64xk):
     k = mat64xk.shape[1]
     dev = mat64xk.device

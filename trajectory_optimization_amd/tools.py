@@ -56,15 +56,19 @@ def render_pc_image(verts, K, height, width, R=None, T=None, device=torch.device
                     zfar=10.0):
     """/root/reference/src/tools.py:122-173: image (height, width, 3) of a camera-frame cloud (N,3): spheres of
     0.03 m, nearest point per pixel, white background, colours = coordinates min-max normalised over the whole
-    tensor.  The reference delegates to pytorch3d's pulsar renderer, which cannot be pinned offline; this is its
-    deterministic nearest-depth core (`gamma`, pulsar's blending softness, is accepted and ignored).
+    tensor.  The reference delegates to pytorch3d's pulsar renderer, which cannot be pinned offline; this is the build's
+    statement of that configuration (render_kernels.hip): every disc over a pixel weighted by its falloff and
+    exp(normalised depth / gamma) — `gamma` is pulsar's blending softness, 1e-5 = the nearest point alone .. 1 = everything
+    shines through; `gamma=None` gives the nearest-depth splat itself.
     R, T (pytorch3d row-vector convention X_cam = X R + T) default to the identity like the reference's."""
     v = torch.as_tensor(verts, dtype=torch.float32).to(device)
     if R is not None or T is not None:
         Rm = torch.eye(3, device=v.device) if R is None else torch.as_tensor(R, dtype=torch.float32).to(v.device).reshape(3, 3)
         Tv = torch.zeros(3, device=v.device) if T is None else torch.as_tensor(T, dtype=torch.float32).to(v.device).reshape(3)
         v = v @ Rm + Tv
-    return ops.render_points(v, K, int(height), int(width), radius=0.03, znear=znear, zfar=zfar, background=1.0)[0]
+    if gamma is None:
+        return ops.render_points(v, K, int(height), int(width), radius=0.03, znear=znear, zfar=zfar, background=1.0)[0]
+    return ops.render_points_blend(v, K, int(height), int(width), radius=0.03, znear=znear, zfar=zfar, gamma=float(gamma), background=1.0)
 
 
 def zbuffer_visible_points(verts, K, height, width, znear=1.0, zfar=10.0, radius=0.03):
