@@ -707,11 +707,16 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
 __device__ __forceinline__ void far_arg_points(const Bufs& b, int f_lo, int vblock, int nvblocks) {
     const int nlive = b.ctrl[kCtrlNLive];
     const int stride = nvblocks * TO_BLOCK;
-    for (int j = vblock * TO_BLOCK + threadIdx.x; j < nlive; j += stride) {
-        const int i = b.live[j];
-        const int f = b.pface[i];
-        if (f < f_lo) continue;
-        if (dkey(fdist(b, f, i)) == b.fmax[f]) atomicMin(&b.fapex[f], ((unsigned long long)(unsigned)b.perm[i] << 32) | (unsigned)i);
+    constexpr int U = 4;   // four (live -> pface) chains in flight per thread, as in reassign_points
+    for (int j0 = vblock * TO_BLOCK + threadIdx.x; j0 < nlive; j0 += U * stride) {
+        int ii[U], ff[U];
+        for (int u = 0; u < U; ++u) ii[u] = j0 + u * stride < nlive ? b.live[j0 + u * stride] : -1;
+        for (int u = 0; u < U; ++u) ff[u] = ii[u] >= 0 ? b.pface[ii[u]] : kNone;
+        for (int u = 0; u < U; ++u) {
+            const int i = ii[u], f = ff[u];
+            if (i < 0 || f < f_lo || f < 0) continue;
+            if (dkey(fdist(b, f, i)) == b.fmax[f]) atomicMin(&b.fapex[f], ((unsigned long long)(unsigned)b.perm[i] << 32) | (unsigned)i);
+        }
     }
 }
 
@@ -971,29 +976,36 @@ __device__ __forceinline__ void reassign_points(const Bufs& b, FaceMaxTable& tab
     face_max_init(tab);
     const int stride = nvblocks * TO_BLOCK;
     const int nlive = b.ctrl[kCtrlNLive];
-    const int nloop = (nlive + stride - 1) / stride;
+    // Most live points' faces survive a round: the loop is a scan of (live -> pface -> fflags), three dependent loads per point.
+    // Four points per thread and trip keep four such chains in flight (12.3 M live points right after the join: 165 -> see DESIGN 6).
+    constexpr int U = 4;
+    const int nloop = (nlive + U * stride - 1) / (U * stride);
     for (int it = 0; it < nloop; ++it) {
-        const int j = vblock * TO_BLOCK + threadIdx.x + it * stride;
-        const int i = j < nlive ? b.live[j] : 0;
-        double best = 0.0; int bf = kNone;
-        const int g = j < nlive ? b.pface[i] : kNone;
-        if (g >= 0 && (b.fflags[g] & 4)) {
-            const int o = b.fowner[g];
-            const int ap = apex_pos(b.fapex[o]);
-            const double x = b.px[i], y = b.py[i], z = b.pz[i];
-            // (every new face has the apex as a vertex and two older ones, whose copies retired when THEY went in)
-            if (i != ap && !(x == b.px[ap] && y == b.py[ap] && z == b.pz[ap])) {
-                int steps = 0;
-                for (int f = b.nfhead[o]; f >= 0 && steps < (1 << 20); ++steps) {
-                    const FaceRec r = b.frec[f];  // one line per step of the list: plane, anchor and link
-                    const double d = plane_dist(r, x, y, z);
-                    if (d > best) { best = d; bf = f; }
-                    f = r.next;
+        int jj[U], ii[U], gg[U], fl[U];
+        for (int u = 0; u < U; ++u) { jj[u] = vblock * TO_BLOCK + threadIdx.x + (it * U + u) * stride; ii[u] = jj[u] < nlive ? b.live[jj[u]] : 0; }
+        for (int u = 0; u < U; ++u) gg[u] = jj[u] < nlive ? b.pface[ii[u]] : kNone;
+        for (int u = 0; u < U; ++u) fl[u] = gg[u] >= 0 ? b.fflags[gg[u]] : 0;
+        for (int u = 0; u < U; ++u) {
+            const int i = ii[u], g = gg[u];
+            double best = 0.0; int bf = kNone;
+            if (g >= 0 && (fl[u] & 4)) {
+                const int o = b.fowner[g];
+                const int ap = apex_pos(b.fapex[o]);
+                const double x = b.px[i], y = b.py[i], z = b.pz[i];
+                // (every new face has the apex as a vertex and two older ones, whose copies retired when THEY went in)
+                if (i != ap && !(x == b.px[ap] && y == b.py[ap] && z == b.pz[ap])) {
+                    int steps = 0;
+                    for (int f = b.nfhead[o]; f >= 0 && steps < (1 << 20); ++steps) {
+                        const FaceRec r = b.frec[f];  // one line per step of the list: plane, anchor and link
+                        const double d = plane_dist(r, x, y, z);
+                        if (d > best) { best = d; bf = f; }
+                        f = r.next;
+                    }
                 }
+                b.pface[i] = bf;  // the apex retires as a vertex; a point outside no new face retires inside the hull
             }
-            b.pface[i] = bf;  // the apex retires as a vertex; a point outside no new face retires inside the hull
+            wave_face_max(b, tab, bf, dkey(best));  // feeds the apex search of the new face
         }
-        wave_face_max(b, tab, bf, dkey(best));  // feeds the apex search of the new face
     }
     face_max_flush(b, tab);
 }
@@ -1535,7 +1547,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
             ncand = candidates(round & 1);
             if (trace) fprintf(stderr, "hull: all points joined after round %d: faces %d live %d candidates %d\n", round, nf, h[kCtrlNLive], ncand);
             stalled = false;
-            live_bound = b.m1;
+            live_bound = std::max(1, h[kCtrlNLive]);   // the join compacted the list: this readback holds its length
             batches_since_compaction = 0;
             compaction_pending_until = round;
             continue;
