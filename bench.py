@@ -301,9 +301,16 @@ def aux_leg(device, sizes=(1_000_000, 16_000_000), reps=20):
         pblob = torch.empty(L.tohip_packed_cloud_bytes(n), dtype=torch.uint8, device=device)
         pws = torch.empty(L.tohip_pack_workspace_bytes(n), dtype=torch.uint8, device=device)
         vout, vws = torch.empty((n, 3), **f32), torch.empty(L.tohip_voxel_grid_workspace_bytes(n), dtype=torch.uint8, device=device)
+        # the same points in an order that has locality (here: their own Morton order — what a map that was packed before, a voxel
+        # grid's output or a lidar scan look like to the gathers; make_cloud's order is uniformly random, the gathers' worst case)
+        _sorted = ops.PackedCloud(pts)
+        pts_local = pts[_sorted.perm[:n].long()].contiguous()
+        del _sorted
         calls = {
             "pack_cloud, Morton order (k_bbox + k_morton + radix passes + k_pack_cloud)": (32.0, lambda: L.tohip_pack_cloud(ptr(pts), n, 1, ptr(pblob), ptr(pws), pws.numel(), s)),
             "voxel_grid_filter, leaf 0.1 m (k_vox_bounds + keys + radix passes + heads + centroids)": (24.0, lambda: L.tohip_voxel_grid(ptr(pts), n, 0.1, 0.1, 0.1, 2, -2.5, 2.5, ptr(vout), ptr(cnt), ptr(vws), vws.numel(), s)),
+            "pack_cloud, points arriving in an order with locality": (32.0, lambda: L.tohip_pack_cloud(ptr(pts_local), n, 1, ptr(pblob), ptr(pws), pws.numel(), s)),
+            "voxel_grid_filter, points arriving in an order with locality": (24.0, lambda: L.tohip_voxel_grid(ptr(pts_local), n, 0.1, 0.1, 0.1, 2, -2.5, 2.5, ptr(vout), ptr(cnt), ptr(vws), vws.numel(), s)),
             "pose_forward (k_pose_stream<fwd>)": (16.0, lambda: L.tohip_pose_forward(ptr(cloud.blob), n, ptr(trans), ptr(quat), cam.ref(), None, ptr(obs), ptr(scal), ptr(ws.buf), ws.bytes, s)),
             "pose_forward_backward (k_pose_stream<fwd, grad>: one pass)": (16.0, lambda: L.tohip_pose_forward_backward(ptr(cloud.blob), n, ptr(trans), ptr(quat), cam.ref(), None, ptr(obs), ptr(scal), None, ptr(tg), ptr(qg), ptr(ws.buf), ws.bytes, s)),
             "pose_backward (k_pose_stream<grad>)": (12.0, lambda: L.tohip_pose_backward(ptr(cloud.blob), n, ptr(trans), ptr(quat), cam.ref(), None, None, ptr(scal), ptr(gout), ptr(tg), ptr(qg), ptr(ws.buf), ws.bytes, s)),
@@ -332,7 +339,7 @@ def aux_leg(device, sizes=(1_000_000, 16_000_000), reps=20):
             gbs = bpp * n / (us * 1e-6) / 1e9
             rows[name] = {"us_per_call": us, "algorithmic_bytes_per_point": bpp, "GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
         out[f"{n}_points"] = rows
-        del pts, cloud, cam3, camn3, flipped, out3, msg, raw, obs, pblob, pws, vout, vws
+        del pts, pts_local, cloud, cam3, camn3, flipped, out3, msg, raw, obs, pblob, pws, vout, vws
         torch.cuda.empty_cache()
     out["note"] = ("algorithmic bytes per point: pack 12 B read + 20 B written, voxel grid 12 + (at most) 12 — both are bound by their sorts, not by these bytes; "
                    "pose 12 B read + 4 B written (16), backward alone 12; flip 12 + 12; cull 12 + 2 + 4 per kept point; "
