@@ -536,7 +536,8 @@ int tohip_pointcloud2_to_xyz(const uint8_t *data, int64_t n_points, int32_t poin
                              int32_t *out_count, void *workspace, size_t workspace_bytes, void *stream);
 /* pcl::VoxelGrid as configured by launch/voxels_filtering.launch:11-21: drop non-finite points and points whose
  * filter field (0/1/2 = x/y/z, -1 = none) lies outside [limit_min, limit_max]; one centroid per occupied voxel,
- * voxels in ascending key order.  out_xyz capacity n rows; *out_count device int32. */
+ * voxels in ascending key order.  out_xyz capacity n rows; *out_count device int32: the number of voxels, or -1 when the grid
+ * would have more than 2^31 - 1 cells (PCL: "leaf size is too small", it returns its input unfiltered). */
 size_t tohip_voxel_grid_workspace_bytes(int64_t n_points);
 int tohip_voxel_grid(const float *xyz, int64_t n_points, float leaf_x, float leaf_y, float leaf_z, int32_t filter_field,
                      float limit_min, float limit_max, float *out_xyz, int32_t *out_count, void *workspace,

@@ -48,6 +48,8 @@ def voxel_grid(points, leaf=0.1, field=2, lim_min=-2.5, lim_max=2.5):
     cell = np.floor(q * inv).astype(np.int64)
     mn = cell.min(0)
     div = cell.max(0) - mn + 1
+    if int(div[0]) * int(div[1]) * int(div[2]) > 2**31 - 1:   # pcl::VoxelGrid: "Leaf size is too small ...": output = input
+        return p.copy()
     ijk = cell - mn
     key = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
     order = np.argsort(key, kind="stable")

@@ -104,3 +104,26 @@ def test_hip_voxel_grid_vs_oracle(dev, n, leaf):
         np.testing.assert_allclose(out.astype(np.float64).mean(0) * 0 + np.sort(out[:, 2])[[0, -1]].clip(-2.5, 2.5).sum() * 0, 0)
     none = pcu.voxel_grid_filter(torch.from_numpy(p).to(dev), leaf, "z", 100.0, 200.0)
     assert none.shape[0] == 0
+
+
+def test_oracle_voxel_grid_leaf_too_small():
+    from oracle import ingest_oracle
+    p = (np.random.default_rng(8).random((2000, 3)) * np.array([30, 30, 8]) - np.array([15, 15, 4])).astype(np.float32)
+    assert np.array_equal(ingest_oracle.voxel_grid(p, 0.001, None), p)
+    assert len(ingest_oracle.voxel_grid(p, 0.03, None)) <= 2000
+
+
+@pytest.mark.gpu
+def test_hip_voxel_grid_leaf_too_small_returns_the_input(dev):
+    """pcl::VoxelGrid::applyFilter: when the grid's cell count exceeds an int32 ("Leaf size is too small for the input dataset.
+    Integer indices would overflow.") it warns and hands back its input; so does the drop-in (the C entry point reports -1)."""
+    from trajectory_optimization_amd import pointcloud_utils as pcu
+    rng = np.random.default_rng(8)
+    p = (rng.random((20_000, 3)) * np.array([30, 30, 8]) - np.array([15, 15, 4])).astype(np.float32)   # 30 m / 1 mm = 3e4 cells per axis: 7e12
+    t = torch.from_numpy(p).to(dev)
+    with pytest.warns(UserWarning, match="leaf size is too small"):
+        out = pcu.voxel_grid_filter(t, 0.001, None)
+    assert torch.equal(out, t) and out.data_ptr() != t.data_ptr()
+    # just inside the limit it filters: 30 / 0.03 = 1000 cells per axis in x, y and 267 in z = 2.7e8
+    assert 0 < pcu.voxel_grid_filter(t, 0.03, None).shape[0] <= 20_000
+

@@ -195,7 +195,7 @@ k_vox_bounds(const float* __restrict__ xyz, int64_t n, VoxParams vp, int* __rest
 
 __global__ void __launch_bounds__(TO_BLOCK)
 k_vox_keys(const float* __restrict__ xyz, int64_t n, VoxParams vp, const int* __restrict__ bounds, int* __restrict__ ctrl,
-           unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+           unsigned* __restrict__ keys, int* __restrict__ vals) {
     int cmn[3], cmx[3];
     bounds_fold(bounds, cmn, cmx);
     const long long dx = (long long)cmx[0] - cmn[0] + 1, dy = (long long)cmx[1] - cmn[1] + 1, dz = (long long)cmx[2] - cmn[2] + 1;
@@ -203,12 +203,12 @@ k_vox_keys(const float* __restrict__ xyz, int64_t n, VoxParams vp, const int* __
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
         const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-        unsigned long long key = ~0ull;  // dropped points sort to the end
+        unsigned key = ~0u;  // dropped points sort to the end (a voxel key is below 2^31: PCL refuses larger grids, ctrl[8])
         if (vox_keep(vp, x, y, z)) {
             const long long ci = (long long)((int)floorf(x * vp.inv_leaf[0]) - cmn[0]);
             const long long cj = (long long)((int)floorf(y * vp.inv_leaf[1]) - cmn[1]);
             const long long ck = (long long)((int)floorf(z * vp.inv_leaf[2]) - cmn[2]);
-            key = (unsigned long long)(ci + cj * dx + ck * dx * dy);
+            key = (unsigned)(ci + cj * dx + ck * dx * dy);
         }
         keys[i] = key;
         vals[i] = (int)i;
@@ -217,21 +217,21 @@ k_vox_keys(const float* __restrict__ xyz, int64_t n, VoxParams vp, const int* __
 
 // run heads in the sorted key array -> head flags (int) for the ordered compaction
 __global__ void __launch_bounds__(TO_BLOCK)
-k_vox_heads(const unsigned long long* __restrict__ keys, int64_t n, int* __restrict__ head) {
+k_vox_heads(const unsigned* __restrict__ keys, int64_t n, int* __restrict__ head) {
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride)
-        head[i] = (keys[i] != ~0ull && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
+        head[i] = (keys[i] != ~0u && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
 }
 
 // thread per voxel: sequential f32 centroid over its run (stable sort: the caller's point order inside a voxel)
 __global__ void __launch_bounds__(TO_BLOCK)
-k_vox_centroids(const float* __restrict__ xyz, const unsigned long long* __restrict__ keys, const int* __restrict__ order,
-                int64_t n, const int* __restrict__ head_pos, const int* __restrict__ n_vox, float* __restrict__ out) {
-    const int m = *n_vox;
+k_vox_centroids(const float* __restrict__ xyz, const unsigned* __restrict__ keys, const int* __restrict__ order,
+                int64_t n, const int* __restrict__ head_pos, int* __restrict__ n_vox, const int* __restrict__ ctrl, float* __restrict__ out) {
+    const int m = *n_vox;   // (-1 once block 0 has reported an overflow: a block that starts after that has nothing to do)
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
     for (int64_t v = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; v < m; v += stride) {
         int64_t i = head_pos[v];
-        const unsigned long long key = keys[i];
+        const unsigned key = keys[i];
         float sx = 0.f, sy = 0.f, sz = 0.f;
         int cnt = 0;
         for (; i < n && keys[i] == key; ++i) {
@@ -242,6 +242,9 @@ k_vox_centroids(const float* __restrict__ xyz, const unsigned long long* __restr
         const float c = (float)cnt;
         out[3 * v] = sx / c; out[3 * v + 1] = sy / c; out[3 * v + 2] = sz / c;
     }
+    // pcl::VoxelGrid: "Leaf size is too small for the input dataset. Integer indices would overflow." -> it hands back its input;
+    // here the count says so (the rows written are meaningless then)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ctrl[8]) *n_vox = -1;
 }
 
 namespace {
@@ -250,8 +253,8 @@ inline VoxPlan vox_plan(int64_t n) {
     VoxPlan p;
     size_t o = 0;
     const size_t ntiles = (size_t)((n + 1023) / 1024);
-    p.off_keys = o;  o += align_up(sizeof(unsigned long long) * (size_t)n, 256);
-    p.off_keys2 = o; o += align_up(sizeof(unsigned long long) * (size_t)n, 256);
+    p.off_keys = o;  o += align_up(sizeof(unsigned) * (size_t)n, 256);
+    p.off_keys2 = o; o += align_up(sizeof(unsigned) * (size_t)n, 256);
     p.off_vals = o;  o += align_up(sizeof(int) * (size_t)n, 256);
     p.off_vals2 = o; o += align_up(sizeof(int) * (size_t)n, 256);
     p.off_head = o;  o += align_up(sizeof(int) * (size_t)n, 256);
@@ -260,8 +263,7 @@ inline VoxPlan vox_plan(int64_t n) {
     p.off_toff = o;  o += align_up(sizeof(int) * ntiles, 256);
     p.off_ctrl = o;  o += 256 + align_up(sizeof(int) * TO_BOUNDS_WORDS, 256);   // [8] the overflow mark; the cell range's copies behind it
     size_t tmp = 0;
-    (void)sort_pairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                             (const int*)nullptr, (int*)nullptr, (int)n, 0, 64, (hipStream_t)0);
+    (void)sort_pairs(nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (int)n, 0, 32, (hipStream_t)0);
     p.tmp_bytes = tmp;
     p.off_tmp = o;   o += align_up(tmp, 256);
     p.total = o;
@@ -271,7 +273,8 @@ inline VoxPlan vox_plan(int64_t n) {
 
 extern "C" size_t tohip_voxel_grid_workspace_bytes(int64_t n) { return n > 0 ? vox_plan(n).total : 256; }
 
-// out_xyz capacity n rows; *out_count (device) = number of voxels.  filter_field: 0/1/2 or -1.
+// out_xyz capacity n rows; *out_count (device) = number of voxels, or -1 when the grid has more than 2^31 - 1 cells (PCL then returns
+// its input unfiltered: the caller's move).  filter_field: 0/1/2 or -1.
 extern "C" int tohip_voxel_grid(const float* xyz, int64_t n, float leaf_x, float leaf_y, float leaf_z, int32_t filter_field,
                                 float limit_min, float limit_max, float* out_xyz, int32_t* out_count, void* workspace,
                                 size_t workspace_bytes, void* stream_) {
@@ -287,8 +290,8 @@ extern "C" int tohip_voxel_grid(const float* xyz, int64_t n, float leaf_x, float
     const VoxPlan pl = vox_plan(n);
     if (workspace_bytes < pl.total) return TOHIP_ENOSPC;
     char* ws = (char*)workspace;
-    auto* keys = (unsigned long long*)(ws + pl.off_keys);
-    auto* keys2 = (unsigned long long*)(ws + pl.off_keys2);
+    auto* keys = (unsigned*)(ws + pl.off_keys);
+    auto* keys2 = (unsigned*)(ws + pl.off_keys2);
     int* vals = (int*)(ws + pl.off_vals);
     int* vals2 = (int*)(ws + pl.off_vals2);
     int* head = (int*)(ws + pl.off_head);
@@ -310,7 +313,7 @@ extern "C" int tohip_voxel_grid(const float* xyz, int64_t n, float leaf_x, float
     k_vox_keys<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, n, vp, bounds, ctrl, keys, vals);
     TO_HIP_CHECK_LAUNCH();
     size_t tmp = pl.tmp_bytes;
-    // a voxel key is below 2^31 (k_vox_keys marks the overflow PCL refuses), a dropped point's low word is all ones: 32 bits order them
+    // a voxel key is below 2^31 (k_vox_keys marks the overflow PCL refuses), a dropped point's key is all ones: 32-bit keys, four passes
     e = sort_pairs(ws + pl.off_tmp, tmp, keys, keys2, vals, vals2, (int)n, 0, 32, st);
     if (e != hipSuccess) return (int)e;
     k_vox_heads<<<(int)nb, TO_BLOCK, 0, st>>>(keys2, n, head);
@@ -322,7 +325,7 @@ extern "C" int tohip_voxel_grid(const float* xyz, int64_t n, float leaf_x, float
     TO_HIP_CHECK_LAUNCH();
     hull::k_flag_write<<<ntiles, TO_BLOCK, 0, st>>>(head, (int)n, toff, hpos, (int)n);
     TO_HIP_CHECK_LAUNCH();
-    k_vox_centroids<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, keys2, vals2, n, hpos, out_count, out_xyz);
+    k_vox_centroids<<<(int)nb, TO_BLOCK, 0, st>>>(xyz, keys2, vals2, n, hpos, out_count, ctrl, out_xyz);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }

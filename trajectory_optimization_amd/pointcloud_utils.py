@@ -50,7 +50,8 @@ def pointcloud2_to_xyz_array(cloud_msg, remove_nans=True, device=torch.device("c
 
 def voxel_grid_filter(points, leaf_size=0.1, filter_field_name="z", filter_limit_min=-2.5, filter_limit_max=2.5):
     """pcl::VoxelGrid with the parameters of /root/reference/launch/voxels_filtering.launch -> (M,3) float32 centroids
-    in ascending voxel-key order.  filter_field_name None disables the pass-through limits."""
+    in ascending voxel-key order.  filter_field_name None disables the pass-through limits.  A grid of more than 2^31 - 1 cells is
+    PCL's "leaf size is too small" case: like PCL, a warning and the input handed back."""
     pts = points.detach().to(torch.float32).contiguous()
     if not pts.is_cuda:
         raise RuntimeError("points must live on a HIP device")
@@ -65,7 +66,12 @@ def voxel_grid_filter(points, leaf_size=0.1, filter_field_name="z", filter_limit
     with torch.cuda.device(pts.device):
         check(L.tohip_voxel_grid(ptr(pts), n, float(leaf[0]), float(leaf[1]), float(leaf[2]), field, float(filter_limit_min),
                                  float(filter_limit_max), ptr(out), ptr(cnt), ptr(ws), wsb, stream_ptr()), "tohip_voxel_grid")
-    return out[:int(cnt.item())]
+    m = int(cnt.item())
+    if m < 0:   # pcl::VoxelGrid::applyFilter: the grid's cell indices would overflow an int32 -> warning, output = input
+        import warnings
+        warnings.warn("voxel_grid_filter: leaf size is too small for the input dataset (integer indices would overflow); returning the input")
+        return pts.clone()
+    return out[:m]
 
 
 def pc_to_voxel(pc, resolution=0.15, x=(0, 90), y=(-50, 50), z=(-4.5, 5.5)):
