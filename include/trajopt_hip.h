@@ -37,7 +37,9 @@
 extern "C" {
 #endif
 
-#define TOHIP_ABI_VERSION 11
+/* 12 (r05): + tohip_render_points_blend / tohip_render_blend_workspace_bytes; + TOHIP_TRAJ_OPT_LAST_OUTPUTS; tohip_voxel_grid reports
+ * PCL's "leaf size too small" case as *out_count = -1.  (11: r04) */
+#define TOHIP_ABI_VERSION 12
 
 #define TOHIP_OK 0
 #define TOHIP_EINVAL (-1)   /* bad size / null pointer */

@@ -209,7 +209,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 11  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
+ABI_VERSION = 12  # TOHIP_ABI_VERSION of include/trajopt_hip.h (tests/test_host_cpu.py checks the two agree)
 ENOSPC = -2  # TOHIP_ENOSPC
 ENAN = -4    # TOHIP_ENAN
 
