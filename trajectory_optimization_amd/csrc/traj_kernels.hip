@@ -1163,12 +1163,14 @@ __device__ __forceinline__ void pair_sums(const SparseArgs& a, int slot, int v, 
     if (lane < 16) a.bpart[((int64_t)v * a.nslots + slot) * 16 + wave_sum16_index(lane)] = total;
 }
 
-// block b of nb (TO_SP_THREADS threads each): wave gw = 16 b + wave of 16 nb takes the pairs gw, gw + 16 nb, ...
+// block b of nb (TO_SP_THREADS threads each): wave gw = wave * nb + b of 16 nb takes the pairs gw, gw + 16 nb, ...
 template <bool OCC, bool UNIT>
 __device__ __forceinline__ void pair_walk(const SparseArgs& a, int b, int nb) {
     const int lane = threadIdx.x & 63;
     TO_STAMP(TO_STAMP_PAIRS, 0);
-    const int gw = __builtin_amdgcn_readfirstlane(b * TO_SP_WAVES + (int)(threadIdx.x >> 6)), GW = nb * TO_SP_WAVES;
+    // wave-major numbering: the step's pairs rarely divide by the grid's waves, and the waves that take one pair more should be ONE per
+    // SIMD of every CU, not all sixteen waves of the first blocks (21.5 k pairs over 4 096 waves: 65 CUs did six rounds, 191 five)
+    const int gw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) * nb + b), GW = nb * TO_SP_WAVES;
     // lane l holds sub-list l's length; the step's pairs are numbered through the sub-lists in order (an inclusive scan), and the
     // grid's waves take the numbers gw, gw + GW, ...: the chip is evenly loaded whatever the sub-lists' lengths
     const int cnt = a.npairs[lane * TO_PL_STRIDE];
