@@ -187,7 +187,15 @@ def build(force=False, verbose=False):
     cmd = [HIPCC] + HIPCC_FLAGS + [SRC, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # into a file of this process's own, then renamed: a second process building at the same time (the ranks of a launcher) or
+    # loading the library never sees half of one
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+    try:
+        subprocess.check_call(cmd[:-1] + [tmp])
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB_PATH
 
 
