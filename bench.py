@@ -1,7 +1,10 @@
 """bench.py — point-visibility evaluations/s (fwd+bwd) of the HIP hot path on MI355X.
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W     -> ONE JSON line on rank 0.
-For N>1 the driver launches it under torch.distributed.run, one rank per GPU (RCCL).
+Contract (driver):  python bench.py --gpus N --steps K --warmup W     -> the LAST stdout line is ONE compact JSON object (< 8 KB:
+the driver keeps an 8 KB tail) on rank 0.  Everything else the run measures (side legs, per-kernel tables, the ISA mix) is printed
+as EARLIER stdout lines ({"detail": <name>, ...}) and written to gpurun_out/bench_details.json (--details-file).
+For N>1 the driver launches it under torch.distributed.run, one rank per GPU (RCCL); started plainly with --gpus N > 1 (no WORLD_SIZE
+in the environment) it spawns that launcher itself, before anything touches the GPU, relays rank 0's line and exits with its status.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): a 1 M-point synthetic
 cloud x 128 waypoints per GPU, full forward + backward to (x,y,z) and quaternion gradients, through the
@@ -50,12 +53,16 @@ ALGO_BYTES_FWD_BWD = 48.0
 PASS1 = "k_traj_pass1"
 
 
-def _profile_json(name):
-    try:
-        with open(os.path.join(REPO, "profiles", name)) as f:
-            return json.load(f)
-    except (OSError, ValueError):
-        return None
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one (name, parsed JSON), or (None, None)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_" + suffix)), reverse=True):
+        try:
+            with open(path) as f:
+                return os.path.basename(path), json.load(f)
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def source_hash():
@@ -71,49 +78,55 @@ def source_hash():
 def isa_mix():
     """VALU instructions of one (wave, waypoint) iteration of k_traj_pass1's dense inner loop (= 64*P evaluations), by class.
     The mix is a checked-in count of the compiled loop: it is only valid for the sources it was counted on."""
-    d = _profile_json("r05_pass1_isa_mix.json")
+    name, d = _latest_profile("pass1_isa_mix.json")
     if d is None:
-        raise SystemExit("profiles/r05_pass1_isa_mix.json is missing (tools/isa_stats.py --json writes it)")
+        raise SystemExit("profiles/rNN_pass1_isa_mix.json is missing (tools/isa_stats.py --json writes it)")
     d["stale"] = d.get("source_hash") != source_hash()
+    d["file"] = "profiles/" + name
     return d
 
 
 def pmc_figures(kernel):
-    """(HBM bytes per launch, VALU busy fraction) of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r05_bench_dense_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes; SQ_ACTIVE_INST_VALU x4 over the SIMD
-    cycles of the kernel), or (None, None, None)."""
-    d = _profile_json("r05_bench_dense_pmc.json")
+    """Counter figures of `kernel` from the committed rocprofv3 --pmc passes of this same command (the latest
+    profiles/rNN_bench_dense_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes; SQ_ACTIVE_INST_VALU x4 over the SIMD cycles of
+    the kernel) -> dict(file, traffic, valu_busy, valu_busy_resident, kernel_ms) or {}.  Counters cannot be collected by the run that
+    prints them (rocprofv3 wraps the process), so the line names the file and profile_age() compares its kernel time with the run's."""
+    fname, d = _latest_profile("bench_dense_pmc.json")
     try:
         for name, v in d["kernels"].items():
             if kernel in name and "hbm_bytes_per_launch_corrected" in v:
-                return float(v["hbm_bytes_per_launch_corrected"]), v.get("valu_busy_fraction"), v.get("valu_busy_while_resident")
+                durs = [v[k] for k in v if k.startswith("duration_ns_mean_")]
+                return {"file": "profiles/" + fname, "traffic": float(v["hbm_bytes_per_launch_corrected"]), "valu_busy": v.get("valu_busy_fraction"),
+                        "valu_busy_resident": v.get("valu_busy_while_resident"), "kernel_ms": (min(durs) * 1e-6) if durs else None}
     except (TypeError, KeyError, ValueError):
         pass
-    return None, None, None
+    return {}
 
 
-def cpu_baseline(points, poses, quats, n_wps_sample, budget_s=12.0):
-    """The oracle (oracle/vis_oracle.c, f32, OpenMP over the host cores this process may use) on a bounded
-    sample of the same workload: fwd+bwd over `n_wps_sample` of the waypoints, repeated for ~budget_s."""
-    from oracle import oracle
-    K, iw, ih = synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT
-    sel = np.linspace(0, len(poses) - 1, n_wps_sample).astype(int)
-    p, q = poses[sel], quats[sel]
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    f = oracle.traj_forward(points, p[:1], q[:1], K, iw, ih)  # warm-up (page in, thread pool)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        f = oracle.traj_forward(points, p, q, K, iw, ih)
-        oracle.traj_backward(points, p, q, K, iw, ih, f)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or reps >= 50:
-            break
-    return {"value": points.shape[0] * n_wps_sample * reps / dt, "unit": "evals/s",
-            "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
-            "sample": f"{points.shape[0]} points x {n_wps_sample} waypoints fwd+bwd x {reps} repetitions, "
-                      f"oracle f32 (C + OpenMP), {dt:.2f} s"}
+def profile_age(pmc, live_kernel_ms, tol=0.10):
+    """The committed counters belong to a kernel that took pmc["kernel_ms"]; the run just measured live_kernel_ms for the same launch.
+    More than `tol` apart -> the profile is from other sources or another clock regime: say so on the line (the HIP-event bracket of
+    the live figure costs ~5 %, so the comparison allows for it)."""
+    ref = pmc.get("kernel_ms")
+    if not ref or not live_kernel_ms:
+        return {"checked": False}
+    ratio = live_kernel_ms / ref
+    return {"checked": True, "profile_kernel_ms": ref, "live_kernel_ms": live_kernel_ms, "ratio": ratio,
+            "stale": bool(abs(ratio - 1.0) > tol)}
+
+
+def cpu_baseline(n_points, n_wps, n_wps_sample, timeout_s=240):
+    """The oracle (oracle/vis_oracle.c, f32, OpenMP) on a bounded sample of the same workload — fwd+bwd over `n_wps_sample` of the
+    waypoints — in a process of its own (oracle/cpu_baseline.py: OMP_NUM_THREADS = the cores this job may use (affinity and cgroup
+    quota), OMP_PROC_BIND=close, OMP_PLACES=cores set before the OpenMP runtime loads; one warm-up, then the MEDIAN of >= 5 timed
+    repetitions with every repetition's time on the line).  The child never touches the GPU."""
+    import subprocess
+    from oracle import cpu_baseline as cb
+    cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--points", str(n_points), "--waypoints", str(n_wps), "--sample-waypoints", str(n_wps_sample)]
+    r = subprocess.run(cmd, cwd=REPO, env=cb.child_env(), capture_output=True, text=True, timeout=timeout_s)
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-300:], "kind": "port"}
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def hpr_leg(points, device):
@@ -527,6 +540,128 @@ def density_leg(device, steps=20, warmup=3):
     return out
 
 
+def spawn_ranks(n, argv=None, script=None):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>`
+    as a CHILD (never an exec: this pool forbids replacing a process, and this one must stay GPU-free), pass its stdout through with
+    rank 0's headline held back to be the last line, return its exit status (non-zero if any rank failed: the launcher's status)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=REPO)
+    headline = None
+    for raw in proc.stdout:
+        raw = raw.rstrip("\n")
+        if raw.startswith('{"metric"'):
+            headline = raw
+        elif raw:
+            print(raw, flush=True)
+    rc = proc.wait()
+    if headline is not None:
+        print(headline, flush=True)
+    elif rc == 0:
+        print(f"bench.py: the {n} ranks exited 0 without a headline line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def _short(x, digits=6):
+    """Floats to `digits` significant digits, recursively (the headline line is for reading and for an 8 KB tail)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _short(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_short(v, digits) for v in x]
+    return x
+
+
+def _drop_notes(x):
+    return {k: _drop_notes(v) for k, v in x.items() if k != "note"} if isinstance(x, dict) else x
+
+
+HEADLINE_BUDGET = 6000   # bytes; tests/test_host_cpu.py holds the line below 8 000 on canned numbers
+
+
+def compact_line(full):
+    """The ONE line the driver parses, cut from the full record: the contract's keys, a trimmed roofline, the culled default,
+    cpu_baseline, sustained, and one or two figures of each side leg that ran.  Everything else stays in the details file."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: full[k] for k in keep if k in full}
+    line["config"] = {k: v for k, v in full["config"].items() if k in ("workload", "n_points", "waypoints_total", "cameras", "parallelism", "launch", "mode", "loss_vis")}
+    w = full.get("ms_per_step_windows") or {}
+    line["ms_per_step_windows"] = {k: w[k] for k in ("median", "min", "max", "windows") if k in w}
+    r = full["roofline"]
+    line["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_per_launch", "kernel_share_of_step",
+                                              "valu_busy_pmc", "valu_busy_while_resident_pmc", "hbm_counter_frac", "algorithmic_bytes_frac",
+                                              "isa_mix_stale", "pmc_file", "profile_age")}
+    ik = r.get("in_kernel")
+    if ik:
+        line["roofline"]["in_kernel_frac_of_peak"] = ik.get("frac_of_peak")
+    line["roofline"]["note"] = ("VALU-issue roofline: achieved = ISA-counted issue cycles per launch / HIP-event kernel time (live); peak = 1024 SIMDs x 2.4 GHz; "
+                                "traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) and valu_busy from the committed --pmc passes in pmc_file; "
+                                "algorithmic_bytes_frac = 48 B/eval streaming model over 8 TB/s (> 1: points stay in registers, nothing streams)")
+    c = full.get("culled_exact")
+    if c:
+        line["culled_exact"] = {k: c.get(k) for k in ("value", "unit", "ms_per_step", "bitwise_identical_to_dense")}
+    if "cpu_baseline" in full:
+        b = full["cpu_baseline"]
+        line["cpu_baseline"] = {k: b[k] for k in ("value", "unit", "cores", "kind", "sample", "reps", "rep_s_min", "rep_s_max", "spread_max_over_min",
+                                                  "nproc", "affinity", "cgroup_quota_cores", "error") if k in b}
+    if full.get("sustained"):
+        line["sustained"] = {m: {k: v[k] for k in ("ms_per_step", "seconds", "steps")} for m, v in full["sustained"].items() if isinstance(v, dict)}
+        line["sustained"]["note"] = "back-to-back steps AFTER the timed windows (settled clocks); the headline is the driver's W + K protocol"
+    if full.get("hpr"):
+        line["hpr"] = {k: full["hpr"].get(k) for k in ("points", "visible", "gpu_ms", "gpu_ms_best", "qhull_ms_host_1core", "index_set_equal_to_qhull")}
+    if full.get("aux"):
+        big = full["aux"].get("16000000_points") or next((v for k, v in full["aux"].items() if k.endswith("_points")), {})
+        pick = {}
+        for name, v in big.items():
+            short = name.split(" ")[0].rstrip(",")
+            if short in ("pointcloud2_to_xyz", "frustum_cull", "to_camera_frame", "pose_forward", "pose_forward_backward", "spherical_flip", "soft_masks") and short not in pick:
+                pick[short] = {"us": v["us_per_call"], "frac_of_hbm_peak": v["frac_of_hbm_peak"]}
+        line["aux_16M_points"] = pick
+        small = full["aux"].get("1000000_points")
+        if small:
+            line["aux_1M_points"] = {name.split(" ")[0]: {"us": v["us_per_call"]} for name, v in small.items() if name.startswith("frustum_cull")}
+    if full.get("after_optimisation"):
+        m = full["after_optimisation"]
+        line["after_optimisation"] = {"dense_ms_per_step": m["dense"]["ms_per_step"], "culled_ms_per_step": m["culled"]["ms_per_step"], "flagged_pairs": m.get("flagged_pairs")}
+    if full.get("dropin"):
+        d = full["dropin"].get("synthetic_1M_x_128", {}).get("variants", {})
+        line["dropin_1M_x_128_ms_per_step"] = {k: v.get("ms_per_step") for k, v in d.items() if "ms_per_step" in v}
+    if full.get("occlusion"):
+        line["occlusion"] = {m: {k: v.get(k) for k in ("refresh_ms", "step_ms_refresh_every_10")} for m, v in full["occlusion"].items() if isinstance(v, dict)}
+    if full.get("density_sweep"):
+        line["density_sweep_culled_ms"] = {"x".join(str(int(e)) for e in row["extent_m"]): row["culled_ms_per_step"] for row in full["density_sweep"]}
+    if full.get("configs"):
+        line["configs_culled_ms_per_step"] = {k: v["culled"]["ms_per_step"] for k, v in full["configs"].items() if isinstance(v, dict) and "culled" in v}
+    if full.get("message"):
+        line["message_total_ms"] = full["message"].get("total_without_stage_syncs_ms")
+    if full.get("comm"):
+        cm = full["comm"]
+        line["comm"] = _drop_notes(cm)
+    for k in ("ranks_seen", "backend", "details_file", "bench_wall_s"):
+        if k in full:
+            line[k] = full[k]
+    line = _short(line)
+    out = json.dumps(line, separators=(",", ":"))
+    if len(out) > HEADLINE_BUDGET:   # never let the line grow past the driver's tail again: drop the optional objects, largest first
+        for k in sorted((k for k in line if k not in keep + ("config", "roofline", "cpu_baseline", "culled_exact", "sustained")),
+                        key=lambda k: -len(json.dumps(line[k]))):
+            line.pop(k)
+            line["dropped_from_headline"] = line.get("dropped_from_headline", []) + [k]
+            out = json.dumps(line, separators=(",", ":"))
+            if len(out) <= HEADLINE_BUDGET:
+                break
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -555,27 +690,46 @@ def main():
     ap.add_argument("--graph", choices=["on", "off"], default="off",
                     help="replay the step's launches from a HIP graph in the timed region (measured SLOWER on ROCm 7.2: 0.151 vs "
                          "0.139 ms dense, 0.079 vs 0.075 culled - graph kernel nodes cost more than the queue they replace)")
-    ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--dropin", choices=["on", "off"], default="on", help="time the reference's own loop over the drop-in classes (N = 1 only)")
-    ap.add_argument("--configs", choices=["on", "off"], default="on", help="the other named sizes on one GPU: configs 2, 4, 5 and eight concurrent trajectories (N = 1 only)")
-    ap.add_argument("--message", choices=["on", "off"], default="on", help="one PointCloud2 + path message pair end to end, per stage (N = 1 only)")
-    ap.add_argument("--density", choices=["on", "off"], default="on", help="step time versus flagged fraction: 1 M points in ever smaller rooms (N = 1 only)")
-    ap.add_argument("--occlusion", choices=["on", "off"], default="on", help="the occlusion-aware reward on the headline workload: ms per mask refresh and per step (N = 1 only)")
-    ap.add_argument("--aux", choices=["on", "off"], default="on", help="the HBM-bound kernels around the hot path (ModelPose, flip, cull, masks, ingest) at 1 M and 16 M points")
-    ap.add_argument("--sustained", choices=["on", "off"], default="on", help="two seconds of back-to-back steps per mode: the step at settled clocks (N = 1 only)")
-    ap.add_argument("--moved", choices=["on", "off"], default="on", help="time the same step on the trajectory after 100 optimiser steps (N = 1 only)")
+    ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip the N = 1 side legs altogether)")
+    ap.add_argument("--details", choices=["off", "brief", "full"], default="brief",
+                    help="side legs beside the headline (N = 1 only): off = none; brief (default, what the driver's command runs) = sustained, "
+                         "hpr, aux at 16 M points, cpu_baseline; full = also dropin, configs, message, density, occlusion, moved, aux at 1 M.  "
+                         "Each leg's own flag overrides the level")
+    ap.add_argument("--details-file", default=os.path.join(REPO, "gpurun_out", "bench_details.json"),
+                    help="where the full record (headline + every leg + per-kernel tables + ISA mix) is written; 'none' = nowhere")
+    for leg, what in (("dropin", "time the reference's own loop over the drop-in classes"),
+                      ("configs", "the other named sizes on one GPU: configs 2, 4, 5 and eight concurrent trajectories"),
+                      ("message", "one PointCloud2 + path message pair end to end, per stage"),
+                      ("density", "step time versus flagged fraction: 1 M points in ever smaller rooms"),
+                      ("occlusion", "the occlusion-aware reward on the headline workload: ms per mask refresh and per step"),
+                      ("aux", "the HBM-bound kernels around the hot path (ModelPose, flip, cull, masks, ingest)"),
+                      ("sustained", "seconds of back-to-back steps per mode AFTER the timed windows: the step at settled clocks"),
+                      ("moved", "time the same step on the trajectory after 100 optimiser steps"),
+                      ("hpr", "hidden-point removal of the cloud from the origin: ms, hull points/s, index set against Qhull"),
+                      ("cpu", "the CPU oracle on a bounded sample (cpu_baseline)")):
+        ap.add_argument(f"--{leg}", choices=["on", "off"], default=None, help=what + " (N = 1 only)")
     ap.add_argument("--dump", default=None, help="write the last dense step's outputs (scalars, gradient rows, rewards) to this .npz "
                                                  "(rank 0): tests compare runs at different N")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly: this process has not touched the GPU (importing torch does not) and never will — it starts the ranks as
+        # children, relays their output and exits with their status
+        raise SystemExit(spawn_ranks(args.gpus))
+    BRIEF, FULL = {"sustained", "hpr", "aux", "cpu"}, {"sustained", "hpr", "aux", "cpu", "dropin", "configs", "message", "density", "occlusion", "moved"}
+
+    def leg_on(name):
+        v = getattr(args, name)
+        if v is not None:
+            return v == "on"
+        return name in {"off": set(), "brief": BRIEF, "full": FULL}[args.details]
 
     from trajectory_optimization_amd import _lib, ops
     from trajectory_optimization_amd.distributed import init_from_env, WaypointShard, PointShard
     import torch.distributed as dist
 
     rank, world, device = init_from_env()
-    if world != args.gpus:
-        if args.gpus != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if world != args.gpus and args.gpus != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the visibility path has no CPU fallback")
     n_gpus = world
@@ -899,13 +1053,13 @@ def main():
                  for x in range(8) if ((ext[:, 3] & 0xf) == x).any()]
         return max(spans), float(np.median(pair[ok, 0] / pair[ok, 1]) * 0.1)
 
-    # headline: DENSE — every (point, waypoint) pair is evaluated.  The instrumented pass runs first (the chip is at its working
-    # clocks by the time the timed pass starts), then W warm-up + exactly K timed steps.
+    # headline: DENSE — every (point, waypoint) pair is evaluated.  The instrumented pass (K steps with HIP events: the roofline's
+    # kernel time) runs first, then the driver's protocol exactly: W warm-up steps + K timed steps between fences.  Nothing else is
+    # run ahead of the timed window (r05 ran 2 x 2 s of load first, which moved the figure by clocks, not by kernels); the settled-clock
+    # figure is the `sustained` object, measured AFTER the windows.
+    t_bench0 = time.perf_counter()
     dense_flags = ops.DENSE if args.mode != "culled" else 0
     kern = kernel_times(dense_flags)
-    # two seconds at load per mode BEFORE the timed window (the dense mode last): the W warm-up steps the driver asks for are 0.6 ms,
-    # the clocks take longer than that to settle, and the timed K steps would otherwise read the ramp (r04: 0.129 against 0.118 ms)
-    sustained = sustained_leg() if (shard is None and args.sustained == "on" and args.mode == "both") else None
     dt, out = timed(dense_flags)
     out = tuple(t.clone() for t in out)   # the step's outputs live in buffers the later legs reuse
     span_ms, clock_ghz = in_kernel_span(dense_flags) if (dense_flags and n_gpus == 1) else (None, None)
@@ -920,8 +1074,10 @@ def main():
     value = evals_per_step * args.steps / dt
     win_dense = windows(dense_flags)
     win_culled = windows(0) if args.mode == "both" else win_dense
+    side = shard is None and n_gpus == 1 and args.cpu_wps > 0 and args.cameras == 1   # the N = 1 side legs
+    sustained = sustained_leg(seconds=1.0) if (side and leg_on("sustained") and args.mode == "both") else None
     comm = (comm_leg_points(dense_flags) if by_points else comm_leg(dense_flags)) if shard is not None else None
-    moved = moved_leg() if (shard is None and args.moved == "on" and args.mode == "both" and args.cameras == 1) else None
+    moved = moved_leg() if (side and leg_on("moved") and args.mode == "both") else None
 
     if rank == 0 and args.dump:
         np.savez(args.dump, scalars=out[0].cpu().numpy(), pg=out[1].cpu().numpy(), qg=out[2].cpu().numpy(), rewards=out[3].cpu().numpy())
@@ -943,7 +1099,8 @@ def main():
             issue_cycles *= share
             achieved *= share
         peak = N_SIMDS * CLOCK_GHZ
-        traffic, valu_busy, valu_busy_res = pmc_figures(PASS1)
+        pmc = pmc_figures(PASS1)
+        traffic, valu_busy, valu_busy_res = pmc.get("traffic"), pmc.get("valu_busy"), pmc.get("valu_busy_resident")
         step_ms = 1e3 * dt / args.steps
         line = {
             "metric": "point-visibility evals/sec (fwd+bwd)", "value": value, "unit": "evals/s",
@@ -975,6 +1132,8 @@ def main():
                                       "(the chip clocks 2.2-2.4 GHz under this load; packed f32 measures 4.0-4.4 cycles)",
                          "valu_busy_pmc": valu_busy,
                          "valu_busy_while_resident_pmc": valu_busy_res,
+                         "pmc_file": pmc.get("file"),
+                         "profile_age": profile_age(pmc, p1_ms),
                          "valu_busy_note": "SQ_ACTIVE_INST_VALU x 4 over the SIMD cycles of the whole dispatch (GRBM_GUI_ACTIVE), and over the "
                                            "cycles the shader engines hold the kernel's waves (SQ_BUSY_CYCLES / 32 SEs): the difference, "
                                            "~12 % of a 100 us dispatch, is the kernel boundary (launch, cache invalidate / write-back, drain)",
@@ -986,7 +1145,7 @@ def main():
                                      "diagnostic pass): what the blocks themselves take; kernel_ms_per_launch also holds the "
                                      "launch / queueing share of a back-to-back dependent launch"},
                          "hbm_counter_frac": (traffic / (p1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "traffic_note": "HBM bytes per launch from profiles/r05_bench_dense_pmc.json (separate --pmc passes of "
+                         "traffic_note": "HBM bytes per launch from pmc_file (separate --pmc passes of "
                                          "this command: 2 x FETCH_SIZE + WRITE_SIZE); a few per cent of the HBM peak: points live "
                                          "in registers, waypoints stream through SGPRs, the 8-byte (min, max) stores go out as "
                                          "32-byte sectors",
@@ -1006,32 +1165,55 @@ def main():
             "kernel_ms": {k: v[0] / args.steps for k, v in kern_c.items()},
             "note": "library default (what ModelTraj runs): pass 1 skips pairs that provably can neither be a waypoint's maximum "
                     "nor contribute, via a Morton-sorted cloud, per-256-point bounding spheres and a distance bound on p"}
-        if n_gpus == 1 and args.cpu_wps > 0 and args.cameras == 1:
-            if args.dropin == "on":
-                line["dropin"] = dropin_leg(device)
-            if args.configs == "on":
-                line["configs"] = configs_leg(device)
-            if args.message == "on":
-                line["message"] = message_leg(device)
-            if args.density == "on":
-                line["density_sweep"] = density_leg(device)
-            if args.aux == "on":
-                line["aux"] = aux_leg(device)
-            if args.occlusion == "on":
-                line["occlusion"] = occlusion_leg(device)
-            line["hpr"] = hpr_leg(pts, device)
-            line["cpu_baseline"] = cpu_baseline(pts, poses_all, quats_all, args.cpu_wps)
-            line["reference_cpu_container"] = {
-                "value": 1.3e7, "unit": "evals/s", "cores": 8,
-                "note": "the reference ITSELF (torch CPU, fwd+bwd, 1 M x 16) timed in the build container — it cannot travel to the "
-                        "GPU box; profiles/r01_reference_cpu_timing.txt"}
+        if n_gpus > 1 or forced:
+            line["ranks_seen"], line["backend"] = dist.get_world_size(), dist.get_backend()
         if sustained is not None:
             line["sustained"] = sustained
         if comm is not None:
             line["comm"] = comm
         if moved is not None:
             line["after_optimisation"] = moved
-        print(json.dumps(line), flush=True)
+
+        def emit(name, obj):
+            """A side leg's result: into the record, and on stdout as a line of its own BEFORE the headline."""
+            line[name] = obj
+            print(json.dumps({"detail": name, name: _short(obj)}, separators=(",", ":")), flush=True)
+        if side:
+            if leg_on("dropin"):
+                emit("dropin", dropin_leg(device))
+            if leg_on("configs"):
+                emit("configs", configs_leg(device))
+            if leg_on("message"):
+                emit("message", message_leg(device))
+            if leg_on("density"):
+                emit("density_sweep", density_leg(device))
+            if leg_on("aux"):
+                emit("aux", aux_leg(device, sizes=(1_000_000, 16_000_000) if args.details == "full" else (16_000_000,)))
+            if leg_on("occlusion"):
+                emit("occlusion", occlusion_leg(device))
+            if leg_on("hpr"):
+                emit("hpr", hpr_leg(pts, device))
+            if leg_on("cpu"):
+                emit("cpu_baseline", cpu_baseline(args.points, w_total, args.cpu_wps))
+            line["reference_cpu_container"] = {
+                "value": 1.3e7, "unit": "evals/s", "cores": 8,
+                "note": "the reference ITSELF (torch CPU, fwd+bwd, 1 M x 16) timed in the build container — it cannot travel to the "
+                        "GPU box; profiles/r01_reference_cpu_timing.txt"}
+        for name in ("sustained", "comm", "after_optimisation"):
+            if name in line:
+                print(json.dumps({"detail": name, name: _short(line[name])}, separators=(",", ":")), flush=True)
+        print(json.dumps({"detail": "roofline_full", "roofline": _short(line["roofline"]), "culled_exact": _short(line["culled_exact"])},
+                         separators=(",", ":")), flush=True)
+        line["bench_wall_s"] = time.perf_counter() - t_bench0
+        if args.details_file and args.details_file not in ("-", "none"):
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(args.details_file)), exist_ok=True)
+                with open(args.details_file, "w") as f:
+                    json.dump(line, f, indent=1)
+                line["details_file"] = os.path.relpath(args.details_file, REPO)
+            except OSError as e:   # a read-only tree: the earlier stdout lines still carry everything
+                line["details_file"] = f"not written: {e}"[:80]
+        print(compact_line(line), flush=True)
     if n_gpus > 1 or forced:
         barrier()
         dist.destroy_process_group()

@@ -188,21 +188,29 @@ def bench_one_rank(tmp_path_factory):
     import json
     d = tmp_path_factory.mktemp("bench")
     out = _run([sys.executable, "bench.py", "--gpus", "1", "--wps-per-gpu", "64", "--dump", str(d / "n1.npz")] + _BENCH_COMMON, {})
-    line = json.loads(out.strip().splitlines()[-1])
+    last = out.strip().splitlines()[-1]
+    assert len(last) < 8000      # the driver keeps an 8 KB tail of stdout: the headline must fit it whole
+    line = json.loads(last)
     assert line["n_gpus"] == 1 and line["roofline"]["bound"] == "valu" and 0.0 < line["roofline"]["frac"] <= 1.0
     return np.load(d / "n1.npz")
 
 
 def test_bench_step_two_ranks_equal_one_rank(bench_one_rank, tmp_path):
-    """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` (gloo rendezvous, both ranks on the one GPU, host-staged
-    collectives): waypoint shards of 32 + 32, ONE all-reduce of the log-odds vector, all-gather of the (W,7) gradient rows —
-    the step's outputs equal the single-rank run over the same 64 waypoints."""
+    """`python bench.py --gpus 2` as the driver types it, NO launcher around it: bench.py starts `torch.distributed.run
+    --nproc-per-node 2` itself (before anything touches the GPU), relays rank 0's headline as its own last line and exits with the
+    ranks' status.  gloo rendezvous, both ranks on the one GPU, host-staged collectives: waypoint shards of 32 + 32, ONE all-reduce
+    of the log-odds vector, all-gather of the (W,7) gradient rows — the step's outputs equal the single-rank run over the same 64
+    waypoints."""
     import json
-    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--wps-per-gpu", "32", "--dump", str(tmp_path / "n2.npz")]
-               + _BENCH_COMMON, {"TOHIP_DIST_BACKEND": "gloo"})
-    line = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+    env = {"TOHIP_DIST_BACKEND": "gloo"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        assert k not in os.environ, k
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--wps-per-gpu", "32", "--dump", str(tmp_path / "n2.npz")] + _BENCH_COMMON, env)
+    last = out.strip().splitlines()[-1]
+    assert len(last) < 8000
+    line = json.loads(last)
     assert line["n_gpus"] == 2 and line["config"]["waypoints_total"] == 64 and line["scaling"] == "weak"
+    assert line["ranks_seen"] == 2 and line["backend"] == "gloo" and "allreduce_ms_median" in line["comm"]
     a, b = bench_one_rank, np.load(tmp_path / "n2.npz")
     # the two shards' log-odds are added in a different association than the single run's: 1e-6-level differences
     np.testing.assert_allclose(b["rewards"], a["rewards"], rtol=2e-6, atol=2e-7)
@@ -210,6 +218,11 @@ def test_bench_step_two_ranks_equal_one_rank(bench_one_rank, tmp_path):
     assert b["pg"].shape == a["pg"].shape == (64, 3) and b["qg"].shape == (64, 4)
     assert np.abs(b["pg"] - a["pg"]).max() <= 2e-5 * np.abs(a["pg"]).max()
     assert np.abs(b["qg"] - a["qg"]).max() <= 2e-5 * np.abs(a["qg"]).max()
+    # a launcher around it (the driver's N > 1 command) still works: the ranks find WORLD_SIZE and do not spawn again
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--wps-per-gpu", "32"] + _BENCH_COMMON, env)
+    line2 = json.loads([l for l in out.strip().splitlines() if l.startswith('{"metric"')][-1])
+    assert line2["ranks_seen"] == 2 and line2["config"]["loss_vis"] == line["config"]["loss_vis"]
 
 
 def test_bench_step_through_rccl_on_one_rank(bench_one_rank, tmp_path):

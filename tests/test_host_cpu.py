@@ -113,14 +113,13 @@ def test_denormalize_like_reference():
 
 
 def test_committed_isa_mix_was_counted_on_these_sources():
-    """bench.py prices pass 1's instruction stream from a checked-in count of the compiled loop (profiles/r05_pass1_isa_mix.json,
-    tools/isa_stats.py --json): it must have been counted on the sources as they are (else the line says isa_mix_stale)."""
-    import json
+    """bench.py prices pass 1's instruction stream from a checked-in count of the compiled loop (the latest
+    profiles/rNN_pass1_isa_mix.json, tools/isa_stats.py --json): it must have been counted on the sources as they are (else the
+    line says isa_mix_stale)."""
     import sys
     sys.path.insert(0, REPO)
     import bench
-    with open(os.path.join(REPO, "profiles", "r05_pass1_isa_mix.json")) as f:
-        mix = json.load(f)
-    assert mix["source_hash"] == bench.source_hash(), "run: python tools/isa_stats.py --json profiles/r05_pass1_isa_mix.json"
+    mix = bench.isa_mix()
+    assert not mix["stale"], f"run: python tools/isa_stats.py --json {mix['file']}  (or a new round's file)"
     cycles = 4 * mix["packed_f32"] + 8 * mix["transcendental"] + 4 * mix["other_valu"]
     assert 600 < cycles < 800 and mix["evaluations_per_iteration"] == 512

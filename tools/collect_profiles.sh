@@ -5,12 +5,12 @@
 #   loop (tools/prof_opt.py) and the streaming kernels around the path at 16 M points (tools/prof_aux.py) the same way.
 # Afterwards, here:  python tools/summarize_profiles.py gpurun_out/prof_<tag> rNN   -> profiles/rNN_*
 set -euo pipefail
-tag=${1:-r05}
+tag=${1:-r06}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-common="--steps 20 --warmup 5 --cpu-wps 0 --dropin off --density off --moved off --aux off --occlusion off --configs off --sustained off --message off"
+common="--steps 20 --warmup 5 --cpu-wps 0 --details off --details-file none"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/dense" -o dense -- python3 "$root/bench.py" $common --mode dense > "$out/dense.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/culled" -o culled -- python3 "$root/bench.py" $common --mode culled > "$out/culled.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -o pmc -- python3 "$root/bench.py" $common --mode dense > "$out/pmc_fetch.log" 2>&1

@@ -78,7 +78,7 @@ def main():
     if os.path.exists(os.path.join(src, "aux_fetch", "pmc_counter_collection.csv")):
         aux_pmc(src, os.path.join(dst, f"{tag}_aux_pmc.json"))
     out = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> --kernel-trace -- python3 bench.py --steps 20 --warmup 5 "
-                      "--cpu-wps 0 --dropin off --density off --mode dense   (three separate runs, tools/collect_profiles.sh)",
+                      "--cpu-wps 0 --details off --mode dense   (three separate runs, tools/collect_profiles.sh)",
            "units": "FETCH_SIZE/WRITE_SIZE in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)",
            "kernels": {}}
     ks = out["kernels"]
