@@ -156,10 +156,11 @@ def dropin_leg(device, steps=200, warmup=10):
     """The reference's OWN loop (/root/reference/src/trajectory_optimization.py:109-116) over the drop-in classes:
         optimizer.zero_grad(); loss = model(); loss.backward(); optimizer.step()
     timed without any synchronisation inside the loop (one at the end), with torch.optim.Adam as the reference builds it (two
-    parameter groups), with torch's fused Adam, with this package's one-launch Adam (same constructor), with the whole step
+    parameter groups; nothing hooked: the hooks are opt-in since r06), the same optimizer after accelerate_torch_adam(opt) (its step()
+    updates these Parameters with one launch), with torch's fused Adam, with this package's one-launch Adam (same constructor), with the whole step
     captured into a HIP graph (torch.cuda.graph + capturable Adam), and the launch-only optimize_trajectory beside them."""
     from trajectory_optimization_amd.model import ModelTraj
-    from trajectory_optimization_amd.optimizer import optimize_trajectory, Adam as HipAdam
+    from trajectory_optimization_amd.optimizer import optimize_trajectory, accelerate_torch_adam, Adam as HipAdam
     b = np.load(os.path.join(REPO, "tests", "golden", "bundled.npz"))
     ident = np.tile(np.array([[1, 0, 0, 0]], np.float32), (len(b["poses"]), 1))
     cases = {"bundled_40k_x_27": (b["pts"].astype(np.float32), b["poses"].astype(np.float32), ident, 0.5),
@@ -185,6 +186,7 @@ def dropin_leg(device, steps=200, warmup=10):
 
         res = {}
         variants = {"torch.optim.Adam": lambda m: torch.optim.Adam(groups(m)),
+                    "accelerate_torch_adam(torch.optim.Adam)": lambda m: accelerate_torch_adam(torch.optim.Adam(groups(m))),
                     "torch.optim.Adam(fused=True)": lambda m: torch.optim.Adam(groups(m), fused=True),
                     "trajectory_optimization_amd.optimizer.Adam": lambda m: HipAdam(groups(m))}
         for vname, mk in variants.items():
@@ -249,7 +251,8 @@ def dropin_leg(device, steps=200, warmup=10):
     def pose_model():
         return ModelPose(Pb, torch.tensor([[6.0, 2.0, 0.0]]), torch.tensor([[1.0, 0.0, 0.0, 0.0]]), K, synth.IMG_WIDTH, synth.IMG_HEIGHT, device=device)
     res = {}
-    for vname, mk in (("torch.optim.Adam", torch.optim.Adam), ("trajectory_optimization_amd.optimizer.Adam", HipAdam)):
+    for vname, mk in (("torch.optim.Adam", torch.optim.Adam), ("accelerate_torch_adam(torch.optim.Adam)", lambda g: accelerate_torch_adam(torch.optim.Adam(g))),
+                      ("trajectory_optimization_amd.optimizer.Adam", HipAdam)):
         m = pose_model()
         opt = mk([{"params": [m.trans], "lr": 0.1}, {"params": [m.quat], "lr": 0.1}])
 
@@ -685,7 +688,7 @@ def main():
                          "128 N waypoints (the same evaluations per rank); two collectives per step whose size does not depend on the cloud "
                          "(16 B per waypoint, then 320 B per waypoint)")
     ap.add_argument("--compact-allreduce", choices=["on", "off"], default="off",
-                    help="N > 1: all-reduce only the slots some rank lists as candidates (a flag per slot MAX-reduced first; one host read of "
+                    help="EXPERIMENTAL. N > 1: all-reduce only the slots some rank lists as candidates (a flag per slot MAX-reduced first; one host read of "
                          "the union's size per step) instead of the whole N-float log-odds vector")
     ap.add_argument("--graph", choices=["on", "off"], default="off",
                     help="replay the step's launches from a HIP graph in the timed region (measured SLOWER on ROCm 7.2: 0.151 vs "

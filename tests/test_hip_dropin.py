@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import REPO, load_golden
 from trajectory_optimization_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -145,16 +145,19 @@ def test_backward_after_a_step_and_another_forward_raises(dev):
 
 
 def test_torch_adam_with_the_one_launch_update(dev):
-    """torch.optim.Adam over the models' Parameters: with the step pre-hook (one launch, torch's own state entries) and without
-    it the trajectories agree to rounding; gradients are back in .grad after step(); the state keeps torch's layout; a
-    configuration the kernel does not cover (weight decay) is left to torch."""
+    """torch.optim.Adam over the models' Parameters: with the step pre-hook (one launch, torch's own state entries) — asked for per
+    optimizer INSTANCE or process-wide — and without it the trajectories agree to rounding; gradients are back in .grad after
+    step(); the state keeps torch's layout; a configuration the kernel does not cover (weight decay) is left to torch."""
     from trajectory_optimization_amd import optimizer as O
     runs = []
-    for accel in (True, False):
-        O.accelerate_torch_adam(accel)
+    for accel in ("instance", True, False):
+        O.accelerate_torch_adam(accel is True)
         try:
             m = _model(dev)
             opt = torch.optim.Adam(_groups(m))
+            if accel == "instance":
+                assert O.accelerate_torch_adam(opt) is opt and O.accelerate_torch_adam(opt) is opt   # (asking twice registers once)
+                assert len(opt._optimizer_step_pre_hooks) == 1 and O.torch_adam_accelerated()[0] is False
             sched = torch.optim.lr_scheduler.ExponentialLR(optimizer=opt, gamma=0.9)
             for i in range(8):
                 opt.zero_grad()
@@ -169,27 +172,66 @@ def test_torch_adam_with_the_one_launch_update(dev):
                     sched.step()
             st = opt.state[m.poses]
             assert set(st.keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(st["step"]) == 8.0 and not st["step"].is_cuda
+            assert ("_tohip_adam_arr" in opt.__dict__) == (accel is not False)      # the one-launch update ran / did not run
             runs.append((m.poses.detach().clone(), m.quats.detach().clone(), early))
         finally:
-            O.accelerate_torch_adam(True)
+            O.accelerate_torch_adam(False)
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])   # per instance == process-wide, to the bit
     # Adam's first steps are sign-like (|update| = lr wherever g != 0): 1e-6 differences in g near 0 can move a coordinate by a
     # visible fraction of lr; elsewhere the two agree to float rounding
-    np.testing.assert_allclose(runs[0][0].cpu().numpy(), runs[1][0].cpu().numpy(), rtol=0, atol=2e-3)
-    np.testing.assert_allclose(runs[0][1].cpu().numpy(), runs[1][1].cpu().numpy(), rtol=0, atol=2e-3)
-    assert np.median(np.abs(runs[0][2].cpu().numpy() - runs[1][2].cpu().numpy())) < 1e-6   # after two steps: rounding only
+    np.testing.assert_allclose(runs[0][0].cpu().numpy(), runs[2][0].cpu().numpy(), rtol=0, atol=2e-3)
+    np.testing.assert_allclose(runs[0][1].cpu().numpy(), runs[2][1].cpu().numpy(), rtol=0, atol=2e-3)
+    assert np.median(np.abs(runs[0][2].cpu().numpy() - runs[2][2].cpu().numpy())) < 1e-6   # after two steps: rounding only
     # switching between the two in mid-run continues on the same state; weight decay is torch's business
     m = _model(dev)
     opt = torch.optim.Adam(_groups(m))
     for accel in (True, False, True):
         O.accelerate_torch_adam(accel)
         opt.zero_grad(); m(vis_wps_dist=0.0).backward(); opt.step()
-    O.accelerate_torch_adam(True)
     assert float(opt.state[m.poses]["step"]) == 3.0
+    # an instance with its own hooks under the process-wide switch: updated ONCE per step
+    m2 = _model(dev)
+    opt2 = O.accelerate_torch_adam(torch.optim.Adam(_groups(m2)))
+    opt2.zero_grad(); m2(vis_wps_dist=0.0).backward(); opt2.step()
+    assert float(opt2.state[m2.poses]["step"]) == 1.0
+    O.accelerate_torch_adam(False)
     m = _model(dev)
-    opt = torch.optim.Adam(_groups(m), weight_decay=0.1)
+    opt = O.accelerate_torch_adam(torch.optim.Adam(_groups(m), weight_decay=0.1))
     p0 = m.poses.detach().clone()
     opt.zero_grad(); m(vis_wps_dist=0.0).backward(); opt.step()
     assert not torch.equal(m.poses.detach(), p0) and "_tohip_adam_arr" not in opt.__dict__
+
+
+def test_building_a_model_changes_no_global_torch_state():
+    """A fresh process: building ModelTraj / ModelPose and running the reference's loop registers NO optimizer hook anywhere (until
+    r05 the first model installed two process-wide ones); ModelTraj(..., fast_adam=True) is the spelled-out opt-in."""
+    import subprocess
+    import sys
+    code = """
+import sys, torch
+sys.path.insert(0, %r)
+from torch.optim import optimizer as TO
+from trajectory_optimization_amd import synth, optimizer as O
+from trajectory_optimization_amd.model import ModelTraj, ModelPose
+dev = torch.device('cuda:0')
+pts = torch.from_numpy(synth.make_cloud(5000, seed=1))
+poses, quats = (torch.from_numpy(a) for a in synth.make_path(5, optical=True))
+K = torch.from_numpy(synth.K_INTRINS)
+m = ModelTraj(pts, poses, quats, K, synth.IMG_WIDTH, synth.IMG_HEIGHT, device=dev)
+mp = ModelPose(pts, torch.zeros(1, 3), torch.tensor([[1.0, 0, 0, 0]]), K, synth.IMG_WIDTH, synth.IMG_HEIGHT, device=dev)
+opt = torch.optim.Adam([{'params': [m.poses], 'lr': 0.1}, {'params': [m.quats], 'lr': 0.02}])
+opt.zero_grad(); m(vis_wps_dist=0.0).backward(); opt.step()
+assert len(TO._global_optimizer_pre_hooks) == 0 and len(TO._global_optimizer_post_hooks) == 0
+assert len(opt._optimizer_step_pre_hooks) == 0 and O.torch_adam_accelerated() == (False, False) and '_tohip_adam_arr' not in opt.__dict__
+m2 = ModelTraj(pts, poses, quats, K, synth.IMG_WIDTH, synth.IMG_HEIGHT, device=dev, fast_adam=True)
+assert len(TO._global_optimizer_pre_hooks) == 1 and O.torch_adam_accelerated() == (True, True)
+opt2 = torch.optim.Adam([{'params': [m2.poses], 'lr': 0.1}, {'params': [m2.quats], 'lr': 0.02}])
+opt2.zero_grad(); m2(vis_wps_dist=0.0).backward(); opt2.step()
+assert '_tohip_adam_arr' in opt2.__dict__
+print('ok')
+""" % REPO
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-1000:] + r.stderr[-3000:]
 
 
 def test_adam_trajectory_fixture_through_the_shortcuts(dev):

@@ -285,6 +285,14 @@ def test_hpr_with_duplicate_rows_vs_reference(dev, name):
         hull = convexHull(sphericalFlip(pts, dev, 2), dev).vertices.cpu().numpy()
         assert np.array_equal(hull[:-1], got) and hull[-1] == len(d["points"])
     assert int((got != ref).sum()) > 0   # the fixture does exercise the difference between the two rules
+    # the guard for callers that need Qhull's own row indices: it fires on this cloud and stays silent on one without duplicates
+    with pytest.raises(ValueError, match="duplicate rows"):
+        hidden_pts_removal(pts, dev, duplicate_rows="error")
+    clean = torch.from_numpy(load_golden("hpr_synth_100k")["points"]).to(dev)
+    vis_c, mask_c = hidden_pts_removal(clean, dev, duplicate_rows="error")
+    assert np.array_equal(np.flatnonzero(mask_c.cpu().numpy()), load_golden("hpr_synth_100k")["visible_idx"])
+    with pytest.raises(ValueError):
+        hidden_pts_removal(clean, dev, duplicate_rows="first")
 
 
 def test_hull_builds_repeat(dev):

@@ -63,7 +63,9 @@ def test_conditional_gradient_bar_against_the_reference(name, prec):
     np.testing.assert_allclose(fwd["rewards"], d["rewards"], rtol=2e-5, atol=2e-6)
     pg, qg = oracle.traj_backward(d["points"], d["poses"], d["quats"], K, IW, IH, fwd, min_dist=d["clip"][0], max_dist=d["clip"][1], prec=prec)
     rep = conditional_gradient_report(d, pg, qg, MARGIN)
-    assert rep["kept"] >= len(d["poses"]) - 2
+    from conftest import EXCLUDED_WAYPOINTS
+    # exactly the waypoints the fixtures were picked for are outside the plain bar — nobody else is excused
+    assert rep["excluded_waypoints"] == EXCLUDED_WAYPOINTS[name] and rep["kept"] == len(d["poses"]) - len(EXCLUDED_WAYPOINTS[name])
     if name.startswith("traj_conditioning"):
         assert rep["excluded"] >= 1   # the configurations were picked for having such a waypoint
 
@@ -82,7 +84,7 @@ def test_full_size_against_the_reference(prec):
     assert abs(int((fwd["rewards"] > 0.5).sum()) - int(d["rewards_above_half"])) <= 2   # (a point exactly on p_hat = 1/2 may fall either way)
     pg, qg = oracle.traj_backward(d["points"], d["poses"], d["quats"], K, IW, IH, fwd, min_dist=d["clip"][0], max_dist=d["clip"][1], prec=prec)
     rep = conditional_gradient_report(d, pg, qg, MARGIN)
-    assert rep["kept"] >= len(d["poses"]) - 1
+    assert rep["excluded_waypoints"] == [] and rep["kept"] == len(d["poses"]) == 16   # all 16 waypoints hold the plain bar
 
 
 STRESS_FIXTURES = ["traj_stress_23_4", "traj_stress_31_83", "traj_stress_31_101", "traj_stress_23_134"]
@@ -113,7 +115,10 @@ def test_stress_findings_against_the_reference(name):
         assert np.abs(pg - ref).max() <= 0.15 * np.abs(ref).max() and np.abs(qg - d["vis_quats_grad"]).max() <= 0.15 * np.abs(d["vis_quats_grad"]).max()
         return
     rep = phat_uncertainty_report(d, pg, qg, MARGIN)
-    assert rep["excused"] >= 1 and rep["inside_bar"] >= 2 * len(d["poses"]) - 4, rep
+    from conftest import EXCLUDED_WAYPOINTS
+    # ONE waypoint per fixture is undetermined at the bar's level; every row of every other waypoint holds the plain bar (asserted
+    # inside the report), so at most that waypoint's two rows are excused
+    assert rep["uncertain_waypoints"] == EXCLUDED_WAYPOINTS[name] and rep["excused"] >= 1 and rep["inside_bar"] >= 2 * (len(d["poses"]) - 1), rep
 
 
 def test_known_answers_bundled():

@@ -29,9 +29,12 @@ class WaypointShard:
 
     def __init__(self, process_group=None, force_collectives=False, compact=False):
         """force_collectives: issue the collectives even in a one-rank group (a rehearsal of the RCCL calls on one GPU).
-        compact: all-reduce only the 256-point slots some rank's forward listed as candidates (the log-odds vector is exactly zero
-        elsewhere): a 0/1 flag per slot MAX-reduced first, then the union's slots summed — ~0.3 MB instead of 4 MB at 1 M points, for
-        one host read of the union's size per step (ops.allreduce_log_odds)."""
+        compact — EXPERIMENTAL, off by default, not used by any model or optimiser path: all-reduce only the 256-point slots some
+        rank's forward listed as candidates (the log-odds vector is exactly zero elsewhere): a 0/1 flag per slot MAX-reduced first,
+        then the union's slots summed — ~0.3 MB instead of 4 MB at 1 M points, for one host read of the union's size per step
+        (ops.allreduce_log_odds).  Through a one-rank RCCL group it costs 65 us against 14.6 us for the full vector (DESIGN.md 7);
+        it is kept only so that the first N > 1 run can measure both (bench.py's `comm.other_allreduce`) and is to be removed if the
+        4 MB ring all-reduce stays below that there.  PointShard makes the question moot (its messages do not grow with the cloud)."""
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = process_group

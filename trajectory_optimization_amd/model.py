@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
-from .optimizer import tag_parameter
+from .optimizer import accelerate_torch_adam, tag_parameter
 from .tools import hidden_pts_removal
 
 
@@ -679,7 +679,7 @@ class ModelPose(nn.Module):
                  intrins: torch.tensor,  # pinhole matrix K, shape (3, 3)
                  img_width, img_height,
                  min_dist=1.0, max_dist=5.0,
-                 device=torch.device('cuda:0')):
+                 device=torch.device('cuda:0'), *, fast_adam=False):
         super().__init__()
         assert trans0.size() == torch.Size([1, 3])
         assert q0.size() == torch.Size([1, 4])
@@ -712,7 +712,9 @@ class ModelPose(nn.Module):
         self.fast_backward = True   # a plain `loss.backward()` on what forward() returned runs on the calling thread
         self._plan = _PosePlan(self)
         for p in (self.trans, self.quat):
-            tag_parameter(p)   # torch.optim.Adam.step() may update them with one launch (optimizer.accelerate_torch_adam)
+            tag_parameter(p)   # torch.optim.Adam.step() MAY update them with one launch — once the caller opts in:
+        if fast_adam:          # fast_adam=True here, optimizer.accelerate_torch_adam(True) or accelerate_torch_adam(opt) (nothing is hooked otherwise)
+            accelerate_torch_adam(True)
 
     def forward(self, debug=False, hpr=False):
         t0 = time()
@@ -782,7 +784,7 @@ class ModelTraj(nn.Module):
                  smoothness_weight=14.0, traj_length_weight=0.02,
                  device=torch.device('cuda'),
                  *, rig=None, shard=None, dense=False, occlusion=None, occlusion_limits=(1.0, 15.0), occlusion_refresh_every=1,
-                 occlusion_refresh_tol=None, occlusion_check_every=5, n_points_global=None, cloud=None):
+                 occlusion_refresh_tol=None, occlusion_check_every=5, n_points_global=None, cloud=None, fast_adam=False):
         super().__init__()
         assert wps_poses.dim() == wps_quats.dim()
         assert wps_poses.size()[1] == 3
@@ -804,8 +806,12 @@ class ModelTraj(nn.Module):
                 raise ValueError("a shared packed cloud holds the whole cloud: not available with PointShard")
             if cloud.device != (self.device if self.device.index is not None else torch.device(self.device.type, torch.cuda.current_device())):
                 raise ValueError(f"the packed cloud lives on {cloud.device}, the model on {self.device}")
-            if points is not None and tuple(points.shape) != tuple(cloud.points.shape):
-                raise ValueError("cloud= does not hold these points")
+            if points is not None and not (torch.is_tensor(points) and points.data_ptr() == cloud.points.data_ptr()):
+                # a different tensor object: it must hold the packed cloud's rows (an equal-sized OTHER cloud would silently be
+                # replaced by cloud.points otherwise); the comparison is one pass over the rows, paid only by callers who hand both
+                pt = torch.as_tensor(points, dtype=torch.float32)
+                if tuple(pt.shape) != tuple(cloud.points.shape) or not torch.equal(pt.to(cloud.points.device), cloud.points):
+                    raise ValueError("cloud= does not hold these points")
             self.points = cloud.points
         elif shard is not None and getattr(shard, "kind", "waypoints") == "points":
             # point sharding: this rank keeps its own rows of the cloud (the whole cloud is handed in, or — n_points_global — the
@@ -863,12 +869,10 @@ class ModelTraj(nn.Module):
         # built; if one has, the rows of every waypoint beyond half the tolerance are rebuilt (one batched pass for them) and the
         # others kept: a waypoint that has converged stops paying.  occlusion_refresh_every stays the cap on a row's age.
         self.occlusion_refresh_every = max(1, int(occlusion_refresh_every))
-        if occlusion_refresh_tol is not None and not isinstance(occlusion_refresh_tol, (tuple, list)):
-            occlusion_refresh_tol = (float(occlusion_refresh_tol), 0.35 * float(occlusion_refresh_tol))   # (1 rad turns a point 3 m away by 3 m)
-        self.occlusion_refresh_tol = tuple(float(x) for x in occlusion_refresh_tol) if occlusion_refresh_tol is not None else None
-        self.occlusion_check_every = max(1, int(occlusion_check_every))
         self._occ_cache = None   # (rows, shape key, forwards since the last FULL rebuild)
         self._occ_built = None   # the body poses each waypoint's rows were built for: (positions, normalised quaternions)
+        self.occlusion_refresh_tol = occlusion_refresh_tol   # (property: a scalar becomes (metres, radians); setting it later restarts the policy)
+        self.occlusion_check_every = max(1, int(occlusion_check_every))
         self.occlusion_rebuilds = [0, 0]   # (full rebuilds, waypoints rebuilt by the motion policy): bookkeeping for tools and tests
         self._ws_cache = {}
         self._plan_obj, self._plan_key = None, None
@@ -880,7 +884,9 @@ class ModelTraj(nn.Module):
         # a plain `loss.backward()` on what forward() returned runs on the calling thread (_FastBackward); False: always torch's engine
         self.fast_backward = True
         for p in (self.poses, self.quats):
-            tag_parameter(p)   # torch.optim.Adam.step() may update them with one launch (optimizer.accelerate_torch_adam)
+            tag_parameter(p)   # torch.optim.Adam.step() MAY update them with one launch — once the caller opts in:
+        if fast_adam:          # fast_adam=True here, optimizer.accelerate_torch_adam(True) or accelerate_torch_adam(opt) (nothing is hooked otherwise)
+            accelerate_torch_adam(True)
 
     @classmethod
     def sharing_cloud_of(cls, other, wps_poses, wps_quats, **kw):
@@ -907,6 +913,19 @@ class ModelTraj(nn.Module):
         """The next forward rebuilds the occlusion masks whatever occlusion_refresh_every says."""
         self._occ_cache = None
 
+    @property
+    def occlusion_refresh_tol(self):
+        return self._occ_tol
+
+    @occlusion_refresh_tol.setter
+    def occlusion_refresh_tol(self, tol):
+        """None, metres, or (metres, radians).  Public like occlusion_refresh_every: changing it after a forward drops the cached rows,
+        so the next forward is a full rebuild that records the poses the motion policy compares against."""
+        if tol is not None and not isinstance(tol, (tuple, list)):
+            tol = (float(tol), 0.35 * float(tol))   # (1 rad turns a point 3 m away by 3 m)
+        self._occ_tol = tuple(float(x) for x in tol) if tol is not None else None
+        self._occ_cache, self._occ_built = None, None
+
     def _occlusion_rows(self, ps, qs):
         """Occlusion bit rows of the given body waypoints, one row per virtual waypoint v = w*C + c (with a rig: the cameras'
         own poses t_v = t_w + R(q_w) l_c, q_v = q_w/|q_w| (x) q_c — the composition the kernels apply).  Rebuilt as a whole on
@@ -914,7 +933,7 @@ class ModelTraj(nn.Module):
         moved (see the constructor); reused otherwise."""
         key = (tuple(ps.shape), tuple(qs.shape))
         c = self._occ_cache
-        if c is None or c[1] != key or c[2] >= self.occlusion_refresh_every:
+        if c is None or c[1] != key or c[2] >= self.occlusion_refresh_every or (self.occlusion_refresh_tol is not None and self._occ_built is None):
             rows = self._build_occlusion_rows(ps, qs)
             self._occ_cache = (rows, key, 1)
             self.occlusion_rebuilds[0] += 1

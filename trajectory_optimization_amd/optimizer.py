@@ -407,26 +407,46 @@ class Adam(torch.optim.Optimizer):
 # ---- torch.optim.Adam itself, for the models' Parameters ----------------------------------------------------------------------
 # The reference builds `torch.optim.Adam([{'params': [model.poses], 'lr': lr_pose}, {'params': [model.quats], 'lr': lr_quat}])`
 # (/root/reference/src/trajectory_optimization.py:91-94).  Its step() is ~14 foreach launches and 0.13-0.15 ms of host time for
-# these two small tensors — longer than everything else in the loop together.  While this is enabled (default), a step pre-hook
-# updates the Parameters that belong to a model of this package (tagged at construction) with the one-launch kernel, on
-# torch's own state entries (`step`, `exp_avg`, `exp_avg_sq`: state_dict(), schedulers and a later switch back all keep working),
-# and hides their gradients from torch's step for its duration; every other parameter, and every optimizer configuration other
-# than plain Adam (amsgrad, weight decay, maximize, capturable, fused, differentiable, a closure) is left to torch.
+# these two small tensors — longer than everything else in the loop together.  OPT-IN (r06; until r05 the hooks were installed
+# process-wide when the first model was built — a drop-in must not change global torch state on its own): after
+#     accelerate_torch_adam(opt)            # this optimizer instance only (Optimizer.register_step_pre_hook / _post_hook), or
+#     accelerate_torch_adam(True)           # every torch.optim.Adam of the process (the global hook registry), or
+#     ModelTraj(..., fast_adam=True)        # = accelerate_torch_adam(True), said where the model is built
+# a step pre-hook updates the Parameters that belong to a model of this package (tagged at construction) with the one-launch
+# kernel, on torch's own state entries (`step`, `exp_avg`, `exp_avg_sq`: state_dict(), schedulers and a later switch back all keep
+# working), and hides their gradients from torch's step for its duration; every other parameter, and every optimizer configuration
+# other than plain Adam (amsgrad, weight decay, maximize, capturable, fused, differentiable, a closure) is left to torch.
+# Nothing is registered anywhere until one of the three is called.
 
-_ACCEL = {"on": True, "installed": False}
+_ACCEL = {"on": False, "installed": False}
 
 
 def accelerate_torch_adam(enable=True):
-    """Switch the one-launch update of tagged Parameters inside torch.optim.Adam.step() on or off (process-wide)."""
+    """enable = a torch.optim.Adam INSTANCE: take over the update of tagged Parameters inside that optimizer's step() (hooks on the
+    instance; returns it).  enable = True / False: the same for every torch.optim.Adam of the process, on / off (the process-wide
+    hooks are registered on the first True and do nothing while off).  Off and nowhere registered by default."""
+    if isinstance(enable, torch.optim.Optimizer):
+        opt = enable
+        if not opt.__dict__.get("_tohip_accel"):
+            opt.register_step_pre_hook(_adam_pre_hook_instance)
+            opt.register_step_post_hook(_adam_post_hook)
+            opt.__dict__["_tohip_accel"] = True
+        return opt
     _ACCEL["on"] = bool(enable)
     if enable:
         _install_hooks()
+    return None
+
+
+def torch_adam_accelerated():
+    """-> (process-wide switch on?, process-wide hooks registered?)"""
+    return _ACCEL["on"], _ACCEL["installed"]
 
 
 def tag_parameter(p):
-    """Mark a Parameter as one whose plain-Adam update may be taken over (the models call this for poses / quats / trans / quat)."""
+    """Mark a Parameter as one whose plain-Adam update MAY be taken over once the user asks for it (the models call this for
+    poses / quats / trans / quat).  Registers nothing."""
     p._tohip_param = True
-    _install_hooks()
     return p
 
 
@@ -452,9 +472,13 @@ def _restore_stash(opt):
                 p.grad = g
 
 
-def _adam_pre_hook(opt, args, kwargs):
+def _adam_pre_hook_instance(opt, args, kwargs):
+    return _adam_pre_hook(opt, args, kwargs, force=True)
+
+
+def _adam_pre_hook(opt, args, kwargs, force=False):
     _restore_stash(opt)   # a step() that raised between the two hooks left the gradients hidden: put them back first
-    if not _ACCEL["on"] or type(opt) is not torch.optim.Adam or (len(args) > 1 and args[1] is not None) or kwargs.get("closure") is not None:   # args[0] is the optimizer
+    if (not force and (not _ACCEL["on"] or opt.__dict__.get("_tohip_accel"))) or type(opt) is not torch.optim.Adam or (len(args) > 1 and args[1] is not None) or kwargs.get("closure") is not None:   # args[0] is the optimizer
         return None
     entries = []
     for group in opt.param_groups:

@@ -33,11 +33,28 @@ def convexHull(points, device):
     return types.SimpleNamespace(vertices=idx)
 
 
-def hidden_pts_removal(pts: torch.Tensor, device, R_param: int = 2):
+def hidden_pts_removal(pts: torch.Tensor, device, R_param: int = 2, duplicate_rows: str = "lowest"):
     """/root/reference/src/tools.py:67-85 -> (pts_visible (V,3), visibleMask (N,) float32 of 0/1).
-    Keeps the reference's quirk: the LAST hull vertex is dropped whether or not it is the origin."""
+    Keeps the reference's quirk: the LAST hull vertex is dropped whether or not it is the origin.
+
+    duplicate_rows — what to do when a VISIBLE point has exact copies (identical xyz rows) elsewhere in the cloud.  The visible set
+    is the same either way (count and coordinates); what differs is which of the identical rows carries the index / mask bit:
+      "lowest" (default)  the copy with the lowest row index, whatever the build's schedule.  Qhull (the reference, tools.py:79)
+                          reports whichever copy its insertion history met first — the first copy in ~70 % of the cases, a later one
+                          otherwise — which a parallel build cannot reproduce (DESIGN.md 6);
+      "error"             raise ValueError if that situation occurs: for callers that need Qhull's exact row indices and would
+                          rather de-duplicate (a VoxelGrid-filtered cloud has no duplicates) than get a different, equally valid row."""
+    if duplicate_rows not in ("lowest", "error"):
+        raise ValueError('duplicate_rows must be "lowest" or "error"')
     pts = torch.as_tensor(pts).to(device)
     idx, mask = ops.hidden_pts_removal(pts, R_param)
+    if duplicate_rows == "error" and idx.numel():
+        _, inverse, counts = torch.unique(pts.to(torch.float32), dim=0, return_inverse=True, return_counts=True)
+        dup = counts[inverse[idx.long()]] > 1
+        if bool(dup.any()):
+            rows = idx[dup][:8].tolist()
+            raise ValueError(f"{int(dup.sum())} visible point(s) have exact duplicate rows in the cloud (e.g. rows {rows}): their indices follow the "
+                             "lowest-row rule here and Qhull's insertion history in the reference; de-duplicate the cloud or pass duplicate_rows='lowest'")
     pts_visible = pts[idx.long(), :]
     return pts_visible, mask
 
