@@ -693,7 +693,7 @@ def main():
     ap.add_argument("--graph", choices=["on", "off"], default="off",
                     help="replay the step's launches from a HIP graph in the timed region (measured SLOWER on ROCm 7.2: 0.151 vs "
                          "0.139 ms dense, 0.079 vs 0.075 culled - graph kernel nodes cost more than the queue they replace)")
-    ap.add_argument("--cpu-wps", type=int, default=32, help="waypoints in the CPU-baseline sample (0 = skip the N = 1 side legs altogether)")
+    ap.add_argument("--cpu-wps", type=int, default=64, help="waypoints in the CPU-baseline sample (0 = skip the N = 1 side legs altogether)")
     ap.add_argument("--details", choices=["off", "brief", "full"], default="brief",
                     help="side legs beside the headline (N = 1 only): off = none; brief (default, what the driver's command runs) = sustained, "
                          "hpr, aux at 16 M points, cpu_baseline; full = also dropin, configs, message, density, occlusion, moved, aux at 1 M.  "

@@ -771,6 +771,10 @@ def test_models_share_one_packed_cloud(dev):
         ModelTraj(ops.PackedCloud(P, sort=False), torch.from_numpy(paths[0][0]), torch.from_numpy(paths[0][1]), Kt, IW, IH, device=dev)
     with pytest.raises(ValueError):
         ModelTraj(P[:100], torch.from_numpy(paths[0][0]), torch.from_numpy(paths[0][1]), Kt, IW, IH, device=dev, cloud=cloud)
+    with pytest.raises(ValueError):   # an equal-sized OTHER cloud must not be replaced silently by the packed one
+        ModelTraj(P + 0.25, torch.from_numpy(paths[0][0]), torch.from_numpy(paths[0][1]), Kt, IW, IH, device=dev, cloud=cloud)
+    # the same rows in another tensor (e.g. still on the host) are fine
+    ModelTraj(P.cpu().clone(), torch.from_numpy(paths[0][0]), torch.from_numpy(paths[0][1]), Kt, IW, IH, device=dev, cloud=cloud)
 
 
 def test_outputs_left_to_the_last_step_change_nothing(dev):

@@ -126,4 +126,19 @@ def test_hip_voxel_grid_leaf_too_small_returns_the_input(dev):
     assert torch.equal(out, t) and out.data_ptr() != t.data_ptr()
     # just inside the limit it filters: 30 / 0.03 = 1000 cells per axis in x, y and 267 in z = 2.7e8
     assert 0 < pcu.voxel_grid_filter(t, 0.03, None).shape[0] <= 20_000
+    # the same at the C ABI (include/trajopt_hip.h: *out_count = -1), ten times over: the count is -1 every time (no block reads the
+    # count in the launch that overwrites it) and a good call on the same workspace afterwards is not disturbed by the overflow mark
+    from trajectory_optimization_amd import _lib
+    from trajectory_optimization_amd._lib import ptr, stream_ptr
+    L = _lib.lib()
+    n = t.shape[0]
+    out = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(L.tohip_voxel_grid_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    for _ in range(10):
+        cnt.fill_(12345)
+        assert L.tohip_voxel_grid(ptr(t), n, 0.001, 0.001, 0.001, -1, 0.0, 0.0, ptr(out), ptr(cnt), ptr(ws), ws.numel(), stream_ptr()) == 0
+        assert int(cnt.item()) == -1
+    assert L.tohip_voxel_grid(ptr(t), n, 0.03, 0.03, 0.03, -1, 0.0, 0.0, ptr(out), ptr(cnt), ptr(ws), ws.numel(), stream_ptr()) == 0
+    assert int(cnt.item()) == pcu.voxel_grid_filter(t, 0.03, None).shape[0]
 

@@ -199,6 +199,7 @@ extern "C" int tohip_pack_cloud(const float* xyz, int64_t n, int sort, void* pac
     const int* order = vals;
     const CloudView cv = cloud_view(packed, n);
     k_pack_init<<<1, TO_BLOCK, 0, st>>>(sort ? bbox : nullptr, (int*)cv.hdr);
+    TO_HIP_CHECK_LAUNCH();
     if (sort) {
         hipError_t e;
         k_bbox<<<(int)std::min<int64_t>(1024, (n / 4 + TO_BLOCK - 1) / TO_BLOCK + 1), TO_BLOCK, 0, st>>>(xyz, n, bbox);
@@ -208,7 +209,8 @@ extern "C" int tohip_pack_cloud(const float* xyz, int64_t n, int sort, void* pac
         size_t tmp = pl.tmp_bytes;
         // by the 21 most significant bits (7 per axis: cells of 1/128 of the box's longest side; the stable sort keeps the caller's
         // order inside a cell): a radix pass less than all 30 bits, and a 256-point tile spans several cells either way
-        static const int low_bit = [] { const char* ev = getenv("TOHIP_PACK_SORT_LOW_BIT"); return ev ? atoi(ev) : 9; }();   // experiments
+        // (TOHIP_PACK_SORT_LOW_BIT: an experiment knob, clamped to the bits the sort's plan was sized for — begin_bit < end_bit = 30)
+        static const int low_bit = [] { const char* ev = getenv("TOHIP_PACK_SORT_LOW_BIT"); const int v = ev ? atoi(ev) : 9; return v < 0 ? 0 : (v > 29 ? 29 : v); }();
         e = sort_pairs(ws + pl.off_tmp, tmp, keys, keys2, vals, vals2, (int)n, low_bit, 30, st);
         if (e != hipSuccess) return (int)e;
         order = vals2;  // radix sort is stable: equal cells keep the caller's order (deterministic)

@@ -109,6 +109,8 @@ struct Bufs {
     int early_out;         // k_owner_claim: candidates beaten by a neighbouring candidate do not walk
     int origin;            // 1: the last slot of a segment is the appended origin; 0: it repeats the segment's first point and never takes part
     int sub;               // > 1 while only every sub-th point (in Morton order) takes part: the first rounds of a large build
+    int serial;            // 1: the sample's hull is built by k_sample_hull (a block per segment, sequential insertion out of LDS);
+                           //    the sample is then every sample_stride()-th position of a segment, counted from its first
 };
 
 constexpr unsigned long long kNoApex = ~0ull;
@@ -182,7 +184,7 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
         if (tmp32 > tmp) tmp = tmp32;
     }
     p = take(tmp); if (b) { b->sort_tmp = p; b->sort_tmp_bytes = tmp; }
-    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; b->origin = 1; b->hbits = 0; b->early_out = 0; }
+    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; b->origin = 1; b->hbits = 0; b->early_out = 0; b->serial = 0; }
     return o;
 }
 
@@ -1083,6 +1085,305 @@ __global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int wi
 // polytope (k_assign_all: f64 plane tests from LDS, ~1 ms for 13.6 M points x 500 faces) — points inside retire without ever
 // having been moved — and the build goes on with all of them.
 
+// ---- the sample's hull by sequential insertion, a block per segment (r06) ---------------------------------------------------
+// The rounds above cost ~45 us each whatever they insert (five dependent launches of latency-bound kernels), and while a hull has
+// a few hundred faces a round inserts a handful of points: the first ~22 rounds of a million-point build were 1 ms of its 4.8.
+// A polytope of a few hundred faces and a sample of <= 4 096 points fit ONE workgroup: faces, planes and the polytope's vertices
+// in LDS, eight sample points per thread in registers, and classic quickhull — insert the point that is highest above its
+// conflict face, one at a time: the region it sees (breadth first from its conflict face: connected by construction, coplanar
+// faces elsewhere cannot join it by rounding), one new face per horizon edge, sibling links by matching the horizon's vertices,
+// the dead faces' points to the new faces.  An insertion is a dozen block barriers (2-3 us), no launch and no memory round trip.
+// The block leaves what the join (k_seg_faces, k_assign_all, k_far_arg_all, k_rebuild_candidates) expects of a sample phase:
+// faces with planes and links, dead faces unflagged, the sample points' conflict faces and the faces' maxima over them.
+// Face ids: the tetrahedron's 4 sg .. 4 sg + 3, then a block of KL - 4 ids per segment behind all tetrahedra (unused ones stay
+// dead).  Any intermediate state of quickhull is a convex polytope on input points, so — like the sample rounds it replaces —
+// this changes the schedule, not the result.
+constexpr int kSerialThreads = 512, kSerialPts = 8, kSerialHmax = 512, kSerialReg = 512;
+
+__device__ __forceinline__ int sample_stride(const Bufs& b, int lo, int hi) {
+    return b.serial ? max(1, (hi - lo + kSerialThreads * kSerialPts - 1) / (kSerialThreads * kSerialPts)) : b.sub;
+}
+__device__ __forceinline__ bool is_sample(const Bufs& b, int lo, int hi, int j) {
+    return b.serial ? ((j - lo) % sample_stride(b, lo, hi) == 0) : (j % b.sub == 0);
+}
+
+__host__ __device__ inline size_t sample_hull_lds_bytes(int KL) {
+    // per face: plane 6 doubles, inv_norm, 3 vertices, 3 neighbours, a mark, a flag byte; per vertex (<= KL / 2 + 4): 3 doubles + position
+    const size_t nv = (size_t)KL / 2 + 8;
+    return sizeof(double) * 6 * KL + sizeof(double) * 3 * nv + sizeof(unsigned long long) * 24 + sizeof(float) * KL +
+           sizeof(int) * (7 * (size_t)KL + 2 * nv + 4 * kSerialHmax + kSerialReg + 16) + (size_t)KL + 64;
+}
+
+// maximum of 64-bit keys over the wave on the DPP network (common.hpp: wave_max63_nn); valid in lane 63
+__device__ __forceinline__ unsigned long long wave_max63_u64(unsigned long long key) {
+    unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+#define TO_U64_MAX_STEP(ctrl, rmask, bc) { \
+        const unsigned h2 = (unsigned)TO_DPP_I(hi, hi, ctrl, rmask, bc), l2 = (unsigned)TO_DPP_I(lo, lo, ctrl, rmask, bc); \
+        const bool take = h2 > hi || (h2 == hi && l2 > lo); \
+        hi = take ? h2 : hi; lo = take ? l2 : lo; }
+    TO_U64_MAX_STEP(0xB1, 0xF, true) TO_U64_MAX_STEP(0x4E, 0xF, true) TO_U64_MAX_STEP(0x141, 0xF, true) TO_U64_MAX_STEP(0x140, 0xF, true)
+    TO_U64_MAX_STEP(0x142, 0xA, false) TO_U64_MAX_STEP(0x143, 0xC, false)
+#undef TO_U64_MAX_STEP
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ void __launch_bounds__(kSerialThreads) k_sample_hull(Bufs b, int KL, int target) {
+    extern __shared__ double smem[];
+    const int NV = KL / 2 + 8;
+    double* const s_nx = smem;            double* const s_ny = s_nx + KL;  double* const s_nz = s_ny + KL;
+    double* const s_x0 = s_nz + KL;       double* const s_y0 = s_x0 + KL;  double* const s_z0 = s_y0 + KL;
+    double* const s_vx = s_z0 + KL;       double* const s_vy = s_vx + NV;  double* const s_vz = s_vy + NV;
+    unsigned long long* const s_red = (unsigned long long*)(s_vz + NV);   // [0..15] wave maxima, [16..19] the apex: x, y, z (bits), conflict face
+    float* const s_inv = (float*)(s_red + 24);
+    int* const s_fv = (int*)(s_inv + KL);     // [k * KL + f]: LOCAL vertex numbers
+    int* const s_fn = s_fv + 3 * KL;          // [k * KL + f]: local face numbers
+    int* const s_vpos = s_fn + 3 * KL;        // local vertex -> position
+    int* const s_hu = s_vpos + NV;            // horizon: start vertex, end vertex, neighbour across, (visible face, edge)
+    int* const s_hv = s_hu + kSerialHmax;
+    int* const s_hn = s_hv + kSerialHmax;
+    int* const s_hg = s_hn + kSerialHmax;
+    int* const s_reg = s_hg + kSerialHmax;    // the region the apex sees (faces), breadth-first order
+    int* const s_vslot = s_reg + kSerialReg;  // local vertex -> the horizon entry that starts at it (this insertion's; stale otherwise)
+    int* const s_misc = s_vslot + NV;         // [1] horizon size of this insertion (-1: it does not fit), [2] error
+    int* const s_vis = s_misc + 16;           // per face: seen by the current apex
+    unsigned char* const s_alive = (unsigned char*)(s_vis + KL);
+
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int sg = blockIdx.x, lo = b.seg_off[sg], hi = b.seg_off[sg + 1], fb = 4 * sg;
+    const int K = KL - 4, base = 4 * b.nseg + sg * K;
+    auto gid = [&](int f) { return f < 4 ? fb + f : base + f - 4; };
+    if (sg == 0 && t == 0) b.ctrl[kCtrlNFaces + 8] = 4 * b.nseg + b.nseg * K;   // every id handed out: the unused ones are dead faces
+    if (!(b.fflags[fb] & 1)) {   // no hull for this segment (too few points, flat, NaN): its ids stay dead
+        for (int f = t; f < K; f += kSerialThreads) b.fflags[base + f] = 0;
+        return;
+    }
+    // ---- the tetrahedron: faces 0..3, vertices 0..3 = a, c1, c2, d (init_tetrahedron's F = {a,c1,c2},{c1,a,d},{c2,c1,d},{a,c2,d})
+    const int cpos[4] = {b.fv[3 * fb], b.fv[3 * fb + 1], b.fv[3 * fb + 2], b.fv[3 * fb + 5]};
+    if (t < 4) {
+        s_vpos[t] = cpos[t]; s_vx[t] = b.px[cpos[t]]; s_vy[t] = b.py[cpos[t]]; s_vz[t] = b.pz[cpos[t]];
+        const FaceRec r = b.frec[fb + t];
+        s_nx[t] = r.nx; s_ny[t] = r.ny; s_nz[t] = r.nz; s_x0[t] = r.x0; s_y0[t] = r.y0; s_z0[t] = r.z0; s_inv[t] = r.inv_norm;
+        for (int k = 0; k < 3; ++k) {
+            const int v = b.fv[3 * (fb + t) + k];
+            s_fv[k * KL + t] = v == cpos[0] ? 0 : (v == cpos[1] ? 1 : (v == cpos[2] ? 2 : 3));
+            s_fn[k * KL + t] = b.fn[3 * (fb + t) + k] - fb;
+        }
+        s_alive[t] = 1;
+    }
+    for (int f = t; f < KL; f += kSerialThreads) { s_vis[f] = 0; if (f >= 4) s_alive[f] = 0; }
+    if (t < 16) s_misc[t] = 0;
+    __syncthreads();
+    auto pdist = [&](int f, double x, double y, double z) {   // plane_dist's expression on the LDS copy of the record
+        const double dx = x - s_x0[f], dy = y - s_y0[f], dz = z - s_z0[f];
+        return s_nx[f] * dx + s_ny[f] * dy + s_nz[f] * dz;
+    };
+    // ---- this thread's sample points: positions lo + (p * 1024 + t) * stride
+    const int stride = sample_stride(b, lo, hi);
+    double px[kSerialPts], py[kSerialPts], pz[kSerialPts];
+    float hgt[kSerialPts];
+    int cf[kSerialPts];
+#pragma unroll
+    for (int p = 0; p < kSerialPts; ++p) {
+        const long long jl = (long long)lo + (long long)(p * kSerialThreads + t) * stride;
+        const int j = jl < hi ? (int)jl : -1;
+        bool ok = j >= 0 && j != cpos[0] && j != cpos[1] && j != cpos[2] && j != cpos[3] && (b.origin || b.perm[j] != hi - 1);
+        px[p] = ok ? b.px[j] : 0.0; py[p] = ok ? b.py[j] : 0.0; pz[p] = ok ? b.pz[j] : 0.0;
+        cf[p] = kNone; hgt[p] = 0.f;
+        if (ok) {
+            bool copy = false;   // an exact copy of a corner lies ON the tetrahedron whatever the rounding says (k_assign0: on_a_vertex)
+            for (int c = 0; c < 4; ++c) copy |= px[p] == s_vx[c] && py[p] == s_vy[c] && pz[p] == s_vz[c];
+            double best = 0.0;
+            if (!copy)
+                for (int f = 0; f < 4; ++f) {
+                    const double d = pdist(f, px[p], py[p], pz[p]);
+                    if (d > best) { best = d; cf[p] = f; }
+                }
+            if (cf[p] >= 0) hgt[p] = (float)best * s_inv[cf[p]];
+        }
+    }
+#ifdef TOHIP_SH_STAMPS   // diagnostic build (tools/hpr_sample_stamps.sh): where an insertion's time goes, in shader clocks and 100 MHz ticks
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = clock64();
+    const unsigned long long st_w0 = wall_clock64();
+#define SH_STAMP(i) { const unsigned long long st_n = clock64(); st_acc[i] += st_n - st_t; st_t = st_n; }
+#else
+#define SH_STAMP(i)
+#endif
+    int nf = 4, nv = 4, created = 0;
+    // Two block barriers per insertion: (1) after every wave has put its best point forward, (2) after the topology.  Face ids are
+    // never reused, so a dead face keeps its mark (nobody's neighbour, nobody's conflict face: never looked at again) and nothing
+    // has to be retired between insertions.
+    while (created < target) {
+        // ---- 1. the apex: the sample point highest above its conflict face (ties: the lowest position)
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int p = 0; p < kSerialPts; ++p)
+            if (cf[p] >= 0) {
+                const unsigned j = (unsigned)(lo + (p * kSerialThreads + t) * stride);
+                const unsigned long long k2 = ((unsigned long long)__float_as_uint(hgt[p]) << 32) | (0xffffffffu - j);
+                key = k2 > key ? k2 : key;
+            }
+        key = wave_max63_u64(key);
+        if (lane == 63) s_red[wid] = key;
+        SH_STAMP(0)
+        __syncthreads();
+        SH_STAMP(1)
+        key = 0ull;
+        for (int w = 0; w < kSerialThreads / 64; ++w) key = s_red[w] > key ? s_red[w] : key;
+        if (key == 0ull) break;   // nobody outside: the sample's hull is complete (block-uniform)
+        const int ja = (int)(0xffffffffu - (unsigned)(key & 0xffffffffull));
+        const int ka = (ja - lo) / stride;
+        // ---- 2. ONE wave does the topology — the wave that owns the apex (its coordinates are in its registers): the region the apex
+        // sees, breadth first from its conflict face, 64 (face, edge) pairs per step and no block barrier; an edge whose far side the
+        // apex does not see is a horizon edge, found by the same test; then one new face per horizon edge and the sibling links.
+        // The other waves wait at the barrier below.
+        if (wid == (ka % kSerialThreads) >> 6) {
+            double ax = 0.0, ay = 0.0, az = 0.0; int acf = 0;
+#pragma unroll
+            for (int p = 0; p < kSerialPts; ++p)
+                if (p == ka / kSerialThreads) { ax = px[p]; ay = py[p]; az = pz[p]; acf = cf[p]; }
+            const int src = (ka % kSerialThreads) & 63;
+            ax = __shfl(ax, src); ay = __shfl(ay, src); az = __shfl(az, src); acf = __shfl(acf, src);
+            if (lane == 0) { s_reg[0] = acf; s_vis[acf] = 1; }
+            int r_lo = 0, r_hi = 1, H = 0;   // the frontier: s_reg[r_lo .. r_hi); horizon entries so far
+            bool full = false;
+            while (r_lo < r_hi && !full) {
+                int r_new = r_hi;
+                for (int e0 = 0; e0 < 3 * (r_hi - r_lo); e0 += 64) {
+                    const int e = e0 + lane;
+                    bool add = false, hor = false; int n = 0, f = 0, k = 0;
+                    if (e < 3 * (r_hi - r_lo)) {
+                        f = s_reg[r_lo + e / 3]; k = e % 3;
+                        n = s_fn[k * KL + f];
+                        const bool seen = pdist(n, ax, ay, az) > 0.0;   // (a face of the region already passes this test too)
+                        if (seen) add = atomicExch(&s_vis[n], 1) == 0;      // two lanes on one face: one adds it
+                        hor = !seen;
+                    }
+                    const unsigned long long bal = __ballot(add), bah = __ballot(hor);
+                    const int pos = r_new + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (add && pos < kSerialReg) s_reg[pos] = n;
+                    r_new += __popcll(bal);
+                    const int slot = H + __popcll(bah & ((1ull << lane) - 1ull));
+                    if (hor && slot < kSerialHmax) {
+                        const int u = s_fv[k * KL + f];
+                        s_hu[slot] = u; s_hv[slot] = s_fv[((k + 1) % 3) * KL + f]; s_hn[slot] = n; s_hg[slot] = f;
+                        s_vslot[u] = slot;   // the horizon is a cycle: every vertex starts exactly one of its edges
+                    }
+                    H += __popcll(bah);
+                    if (r_new > kSerialReg || H > kSerialHmax) { full = true; break; }
+                }
+                r_lo = r_hi; r_hi = full ? r_hi : r_new;
+            }
+            const int nreg = r_hi;
+            const bool fits = !full && nf + H <= KL && nv + 1 <= NV;
+            if (!fits) {   // no room for this insertion: the polytope stays as it is, the loop ends
+                if (full) { for (int f = lane; f < nf; f += 64) s_vis[f] = 0; }   // (faces were marked that the list could not take)
+                else { for (int i = lane; i < nreg; i += 64) s_vis[s_reg[i]] = 0; }
+                if (lane == 0) s_misc[1] = -1;
+            } else {
+                if (lane == 0) { s_vpos[nv] = ja; s_vx[nv] = ax; s_vy[nv] = ay; s_vz[nv] = az; s_misc[1] = H;
+                                 s_red[16] = (unsigned long long)__double_as_longlong(ax); s_red[17] = (unsigned long long)__double_as_longlong(ay);
+                                 s_red[18] = (unsigned long long)__double_as_longlong(az); }
+                for (int i = lane; i < nreg; i += 64) s_alive[s_reg[i]] = 0;   // the region dies (its marks stay: the points look at them)
+                // one new face (u, v, apex) per horizon edge (u, v); its neighbour across the horizon re-pointed; sibling links: edge 1
+                // of (u, v, apex) is (v, apex) -> the new face that STARTS at v, and that face's edge 2 comes back
+                for (int q = lane; q < H; q += 64) {
+                    const int id = nf + q, u = s_hu[q], v = s_hv[q], n = s_hn[q], g = s_hg[q];
+                    const int nxt = s_vslot[v];
+                    s_fv[id] = u; s_fv[KL + id] = v; s_fv[2 * KL + id] = nv;
+                    s_fn[id] = n;
+                    // set_plane's expression: a = u, c1 = v, c2 = apex
+                    const double x0 = s_vx[u], y0 = s_vy[u], z0 = s_vz[u];
+                    const double ux = s_vx[v] - x0, uy = s_vy[v] - y0, uz = s_vz[v] - z0;
+                    const double wx = ax - x0, wy = ay - y0, wz = az - z0;
+                    const double nx = uy * wz - uz * wy, ny = uz * wx - ux * wz, nz = ux * wy - uy * wx;
+                    s_nx[id] = nx; s_ny[id] = ny; s_nz[id] = nz; s_x0[id] = x0; s_y0[id] = y0; s_z0[id] = z0;
+                    s_inv[id] = (float)__builtin_amdgcn_rsq(nx * nx + ny * ny + nz * nz);   // ranks candidates only (set_plane: 1 / sqrt)
+                    s_alive[id] = 1;
+                    for (int jn = 0; jn < 3; ++jn)
+                        if (s_fn[jn * KL + n] == g) s_fn[jn * KL + n] = id;   // (an edge belongs to one horizon entry: nobody else writes this word)
+                    if (nxt < 0 || nxt >= H || s_hu[nxt] != v) s_misc[2] = 1;   // the horizon is not a closed cycle: inconsistent predicates
+                    else { s_fn[KL + id] = nf + nxt; s_fn[2 * KL + nf + nxt] = id; }
+                }
+            }
+        }
+        SH_STAMP(2)
+        __syncthreads();
+        SH_STAMP(3)
+        const int H = s_misc[1];
+        if (H < 0 || s_misc[2]) break;   // (block-uniform)
+        const double ax = __longlong_as_double((long long)s_red[16]), ay = __longlong_as_double((long long)s_red[17]),
+                     az = __longlong_as_double((long long)s_red[18]);
+        // ---- 3. the points of the faces that died: to the new face they are farthest outside of, or inside.  Faces outside, points
+        // inside: a plane is read once for the thread's (up to eight) orphans
+        unsigned orphan = 0u;
+#pragma unroll
+        for (int p = 0; p < kSerialPts; ++p)
+            if (cf[p] >= 0 && s_vis[cf[p]]) orphan |= 1u << p;
+        if (orphan) {
+            double best[kSerialPts];
+            int bf[kSerialPts];
+            unsigned test = 0u;   // the orphans that look for a new face: not the apex (a vertex now) nor its exact copies
+#pragma unroll
+            for (int p = 0; p < kSerialPts; ++p) {
+                best[p] = 0.0; bf[p] = kNone;
+                const int j = lo + (p * kSerialThreads + t) * stride;
+                if (((orphan >> p) & 1u) && j != ja && !(px[p] == ax && py[p] == ay && pz[p] == az)) test |= 1u << p;
+                if ((orphan >> p) & 1u) { cf[p] = kNone; hgt[p] = 0.f; }
+            }
+            for (int q = 0; q < H; ++q) {
+                const int f = nf + q;
+                const double nx = s_nx[f], ny = s_ny[f], nz = s_nz[f], x0 = s_x0[f], y0 = s_y0[f], z0 = s_z0[f];
+#pragma unroll
+                for (int p = 0; p < kSerialPts; ++p)
+                    if ((test >> p) & 1u) {
+                        const double dx = px[p] - x0, dy = py[p] - y0, dz = pz[p] - z0;   // plane_dist's expression
+                        const double d = nx * dx + ny * dy + nz * dz;
+                        if (d > best[p]) { best[p] = d; bf[p] = f; }
+                    }
+            }
+#pragma unroll
+            for (int p = 0; p < kSerialPts; ++p)
+                if ((test >> p) & 1u) { cf[p] = bf[p]; hgt[p] = bf[p] >= 0 ? (float)best[p] * s_inv[bf[p]] : 0.f; }
+        }
+        nf += H; nv += 1; created += H;
+        SH_STAMP(4)
+    }
+#ifdef TOHIP_SH_STAMPS
+    if (sg == 0 && lane == 0) {   // per wave: [phase 1 | barrier 1 wait | topology (or nothing) | barrier 2 wait | phase 3], insertions, wall ticks
+        unsigned long long* o = b.keys2 + 16 * wid;
+        for (int i = 0; i < 5; ++i) o[i] = st_acc[i];
+        o[5] = (unsigned long long)nv - 4; o[6] = wall_clock64() - st_w0; o[7] = (unsigned long long)nf;
+    }
+#endif
+    __syncthreads();
+    __syncthreads();
+    if (s_misc[2] && t == 0) atomicOr(&b.ctrl[kCtrlError], kErrTopology);
+    // ---- what the join expects: the faces ...
+    for (int f = t; f < KL; f += kSerialThreads) {
+        const int g = gid(f);
+        if (f >= nf) { b.fflags[g] = 0; continue; }
+        for (int k = 0; k < 3; ++k) { b.fv[3 * g + k] = s_vpos[s_fv[k * KL + f]]; b.fn[3 * g + k] = gid(s_fn[k * KL + f]); }
+        FaceRec r;
+        r.nx = s_nx[f]; r.ny = s_ny[f]; r.nz = s_nz[f]; r.x0 = s_x0[f]; r.y0 = s_y0[f]; r.z0 = s_z0[f];
+        r.next = kNone; r.inv_norm = s_inv[f]; r.pad[0] = 0; r.pad[1] = 0;
+        b.frec[g] = r;
+        b.fflags[g] = s_alive[f] ? 1 : 0;
+        b.fowner[g] = kNone; b.fmax[g] = 0ull; b.fapex[g] = kNoApex; b.nfhead[g] = kNone;
+        b.newface[3 * g] = kNone; b.newface[3 * g + 1] = kNone; b.newface[3 * g + 2] = kNone;
+    }
+    __syncthreads();   // (the maxima below go to words this block has just zeroed)
+    // ... and the sample points: conflict face, and the faces' maxima over them (the other points add theirs in k_assign_all)
+#pragma unroll
+    for (int p = 0; p < kSerialPts; ++p) {
+        const long long jl = (long long)lo + (long long)(p * kSerialThreads + t) * stride;
+        if (jl >= hi) continue;
+        const int j = (int)jl;
+        if (j == cpos[0] || j == cpos[1] || j == cpos[2] || j == cpos[3]) continue;
+        b.pface[j] = cf[p] >= 0 ? gid(cf[p]) : kNone;
+        if (cf[p] >= 0) atomicMax(&b.fmax[gid(cf[p])], dkey(pdist(cf[p], px[p], py[p], pz[p])));
+    }
+}
+
 __global__ void __launch_bounds__(TO_BLOCK) k_live_stride(Bufs b) {  // live list = the sample
     const int cnt = (b.m1 + b.sub - 1) / b.sub;
     const int stride = gridDim.x * TO_BLOCK;
@@ -1135,7 +1436,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign_all(Bufs b, const int* __re
         for (int k = 0; k < kAssignPts; ++k) {
             const int j = base + k * TO_BLOCK + threadIdx.x;
             // the sample's points have their faces (or have retired) already
-            mine[k] = j < hi && j % b.sub != 0 && j != c0 && j != c1 && j != c2 && j != c3 && (b.origin || b.perm[j] != hi - 1);
+            mine[k] = j < hi && !is_sample(b, lo, hi, j) && j != c0 && j != c1 && j != c2 && j != c3 && (b.origin || b.perm[j] != hi - 1);
             x[k] = mine[k] ? b.px[j] : 0.0; y[k] = mine[k] ? b.py[j] : 0.0; z[k] = mine[k] ? b.pz[j] : 0.0;
             best[k] = mine[k] ? 0.0 : INFINITY; bf[k] = kNone;   // (nothing beats infinity: the other lanes never ask for a test)
         }
@@ -1378,10 +1679,47 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         k_init<<<b.nseg, HULL_INIT_THREADS, 0, st>>>(b);
     }
     TO_HIP_CHECK_LAUNCH();
-    if (b.sub > 1) k_live_stride<<<nblocks((b.m1 + b.sub - 1) / b.sub), TO_BLOCK, 0, st>>>(b);
-    k_assign0<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
-    k_far_arg_all<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);
-    k_round_tail<<<kSubLists, TO_BLOCK, 0, st>>>(b, 1, 0, 0);  // round 0's candidates: the tetrahedra's faces with points outside
+    // Large segments: the sample's hull by sequential insertion, one block per segment out of LDS (k_sample_hull) instead of the
+    // first ~20-25 rounds; then the join below, immediately.  TOHIP_HULL_SERIAL=0: the sample's rounds as until r05 (experiments);
+    // TOHIP_HULL_SERIAL_IDS: face ids per segment (LDS: 92 bytes each), TOHIP_HULL_SERIAL_FACES: stop after that many created.
+    int serial_ids = 0;
+    if (b.sub > 1) {
+        static const int want = getenv("TOHIP_HULL_SERIAL") ? atoi(getenv("TOHIP_HULL_SERIAL")) : 1;
+        // measured (tools/hpr_serial_sweep.sh, r06): an insertion costs ~5 us here, a round ~45 us for one hull and ~160 us for 128 —
+        // one hull is best served by 192-448 ids (flat), a batch by 768-896
+        static const int ids_env = getenv("TOHIP_HULL_SERIAL_IDS") ? atoi(getenv("TOHIP_HULL_SERIAL_IDS")) : 0;
+        const int ids = std::max(64, std::min(1536, (ids_env > 0 ? ids_env : (b.nseg == 1 ? 320 : 768)) / 2 * 2));
+        if (want && (int64_t)4 * b.nseg + (int64_t)b.nseg * (ids - 4) <= (int64_t)b.fcap) {
+            static int lds_ok_for = 0;   // the dynamic-LDS limit of the kernel is raised once per size
+            const size_t lds = sample_hull_lds_bytes(ids);
+            if (lds_ok_for != ids) {
+                if (hipFuncSetAttribute((const void*)k_sample_hull, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) lds_ok_for = ids;
+                else (void)hipGetLastError();
+            }
+            if (lds_ok_for == ids) serial_ids = ids;
+        }
+    }
+    if (serial_ids) {
+        static const int faces_env = getenv("TOHIP_HULL_SERIAL_FACES") ? atoi(getenv("TOHIP_HULL_SERIAL_FACES")) : 0;
+        const int target = faces_env > 0 ? faces_env : serial_ids;   // (the loop also stops when an insertion no longer fits the ids)
+        b.serial = 1;
+        k_sample_hull<<<b.nseg, kSerialThreads, sample_hull_lds_bytes(serial_ids), st>>>(b, serial_ids, target);
+#ifdef TOHIP_SH_STAMPS
+        {
+            unsigned long long hst[16 * 8];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(hst, b.keys2, sizeof(hst), hipMemcpyDeviceToHost);
+            for (int w = 0; w < 8; ++w)
+                fprintf(stderr, "sample hull wave %d: phase1 %llu  wait1 %llu  topology %llu  wait2 %llu  phase3 %llu clocks; %llu insertions, %llu faces, %.1f us wall\n", w,
+                        hst[16 * w], hst[16 * w + 1], hst[16 * w + 2], hst[16 * w + 3], hst[16 * w + 4], hst[16 * w + 5], hst[16 * w + 7], hst[16 * w + 6] * 0.01);
+        }
+#endif
+    } else {
+        if (b.sub > 1) k_live_stride<<<nblocks((b.m1 + b.sub - 1) / b.sub), TO_BLOCK, 0, st>>>(b);
+        k_assign0<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
+        k_far_arg_all<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);
+        k_round_tail<<<kSubLists, TO_BLOCK, 0, st>>>(b, 1, 0, 0);  // round 0's candidates: the tetrahedra's faces with points outside
+    }
     TO_HIP_CHECK_LAUNCH();
     // One readback = the scalars and the candidate counters of both parities, into pinned memory behind an event: the host
     // keeps ONE batch of rounds enqueued ahead of the readback it is waiting for, so the GPU never idles while the host looks
@@ -1527,11 +1865,11 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         if (ej != hipSuccess) return (int)ej;
         k_rebuild_candidates<<<kSubLists * (int)std::min<int64_t>(16, std::max<int64_t>(1, cdiv(nf, kSubLists * TO_BLOCK))), TO_BLOCK, 0, st>>>(b, par, round);
         TO_HIP_CHECK_LAUNCH();
-        b.sub = 1;
+        b.sub = 1; b.serial = 0;
         return TOHIP_OK;
     };
     while ((ncand > 0 || b.sub > 1) && round < max_rounds) {
-        if (b.sub > 1 && (nf >= switch_faces || ncand == 0 || round >= 96)) {
+        if (b.sub > 1 && (b.serial || nf >= switch_faces || ncand == 0 || round >= 96)) {
             while (inflight > 0) {  // the rounds in flight belong to the sample
                 e = collect();
                 if (e != hipSuccess) return drain((int)e);

@@ -227,7 +227,15 @@ k_vox_heads(const unsigned* __restrict__ keys, int64_t n, int* __restrict__ head
 __global__ void __launch_bounds__(TO_BLOCK)
 k_vox_centroids(const float* __restrict__ xyz, const unsigned* __restrict__ keys, const int* __restrict__ order,
                 int64_t n, const int* __restrict__ head_pos, int* __restrict__ n_vox, const int* __restrict__ ctrl, float* __restrict__ out) {
-    const int m = *n_vox;   // (-1 once block 0 has reported an overflow: a block that starts after that has nothing to do)
+    // pcl::VoxelGrid: "Leaf size is too small for the input dataset. Integer indices would overflow." -> it hands back its input;
+    // here the count says so: -1.  ctrl[8] was written by k_vox_keys (an earlier launch), so EVERY block takes this branch or none
+    // does: nobody reads *n_vox in a launch that overwrites it (r05 had block 0 write the -1 at its end while other blocks could still
+    // be reading the count), and the meaningless centroid pass is skipped
+    if (ctrl[8]) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *n_vox = -1;
+        return;
+    }
+    const int m = *n_vox;
     const int64_t stride = (int64_t)gridDim.x * TO_BLOCK;
     for (int64_t v = (int64_t)blockIdx.x * TO_BLOCK + threadIdx.x; v < m; v += stride) {
         int64_t i = head_pos[v];
@@ -242,9 +250,6 @@ k_vox_centroids(const float* __restrict__ xyz, const unsigned* __restrict__ keys
         const float c = (float)cnt;
         out[3 * v] = sx / c; out[3 * v + 1] = sy / c; out[3 * v + 2] = sz / c;
     }
-    // pcl::VoxelGrid: "Leaf size is too small for the input dataset. Integer indices would overflow." -> it hands back its input;
-    // here the count says so (the rows written are meaningless then)
-    if (blockIdx.x == 0 && threadIdx.x == 0 && ctrl[8]) *n_vox = -1;
 }
 
 namespace {
@@ -306,6 +311,7 @@ extern "C" int tohip_voxel_grid(const float* xyz, int64_t n, float leaf_x, float
     int* bounds = ctrl + 64;
     hipError_t e;
     k_bounds_init<<<1, TO_BLOCK, 0, st>>>(bounds);   // (r04 copied the start values from the host's stack and synchronised the stream for it)
+    TO_HIP_CHECK_LAUNCH();
     int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
     if (nb > 2048) nb = 2048;
     k_vox_bounds<<<(int)std::min<int64_t>(1024, (n / 4 + TO_BLOCK - 1) / TO_BLOCK + 1), TO_BLOCK, 0, st>>>(xyz, n, vp, bounds);

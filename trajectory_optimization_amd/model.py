@@ -806,7 +806,8 @@ class ModelTraj(nn.Module):
                 raise ValueError("a shared packed cloud holds the whole cloud: not available with PointShard")
             if cloud.device != (self.device if self.device.index is not None else torch.device(self.device.type, torch.cuda.current_device())):
                 raise ValueError(f"the packed cloud lives on {cloud.device}, the model on {self.device}")
-            if points is not None and not (torch.is_tensor(points) and points.data_ptr() == cloud.points.data_ptr()):
+            if points is not None and not (torch.is_tensor(points) and points.data_ptr() == cloud.points.data_ptr() and
+                                           tuple(points.shape) == tuple(cloud.points.shape) and points.stride() == cloud.points.stride()):
                 # a different tensor object: it must hold the packed cloud's rows (an equal-sized OTHER cloud would silently be
                 # replaced by cloud.points otherwise); the comparison is one pass over the rows, paid only by callers who hand both
                 pt = torch.as_tensor(points, dtype=torch.float32)
