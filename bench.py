@@ -311,7 +311,11 @@ def aux_leg(device, sizes=(1_000_000, 16_000_000), reps=20):
         msg = torch.zeros((n, 4), **f32)
         msg[:, :3] = pts
         raw = msg.view(torch.uint8).reshape(-1)
+        msg_nan = msg.clone()   # the same message with 1 % of its rows invalid (a NaN in y): what a depth camera publishes
+        msg_nan[torch.randperm(n, generator=torch.Generator().manual_seed(5))[: n // 100].to(device), 1] = float("nan")
+        raw_nan = msg_nan.view(torch.uint8).reshape(-1)
         iws = torch.empty(L.tohip_ingest_workspace_bytes(n), dtype=torch.uint8, device=device)
+        iws_nan = torch.empty(L.tohip_ingest_workspace_bytes(n), dtype=torch.uint8, device=device)
         q1, t1 = quat.reshape(4).contiguous(), trans.reshape(3).contiguous()
         s = stream_ptr()
         pblob = torch.empty(L.tohip_packed_cloud_bytes(n), dtype=torch.uint8, device=device)
@@ -331,10 +335,11 @@ def aux_leg(device, sizes=(1_000_000, 16_000_000), reps=20):
             "pose_forward_backward (k_pose_stream<fwd, grad>: one pass)": (16.0, lambda: L.tohip_pose_forward_backward(ptr(cloud.blob), n, ptr(trans), ptr(quat), cam.ref(), None, ptr(obs), ptr(scal), None, ptr(tg), ptr(qg), ptr(ws.buf), ws.bytes, s)),
             "pose_backward (k_pose_stream<grad>)": (12.0, lambda: L.tohip_pose_backward(ptr(cloud.blob), n, ptr(trans), ptr(quat), cam.ref(), None, None, ptr(scal), ptr(gout), ptr(tg), ptr(qg), ptr(ws.buf), ws.bytes, s)),
             "spherical_flip (k_norm_max + k_flip)": (24.0, lambda: L.tohip_spherical_flip(ptr(pts), n, 2.0, ptr(flipped), ptr(rad), ptr(flws), 8192, s)),
-            "frustum_cull (k_frustum_count + scan + k_frustum_write)": (None, lambda: L.tohip_frustum_cull(ptr(cam3), n, cam.ref(), 1.0, 10.0, ptr(dm), ptr(fm), ptr(kept), ptr(cnt), ptr(fws), fws.numel(), s)),
+            "frustum_cull (k_frustum_count + k_frustum_write; above 2 M points a scan launch between them)": (None, lambda: L.tohip_frustum_cull(ptr(cam3), n, cam.ref(), 1.0, 10.0, ptr(dm), ptr(fm), ptr(kept), ptr(cnt), ptr(fws), fws.numel(), s)),
             "soft_masks (k_soft_masks)": (20.0, lambda: L.tohip_soft_masks(ptr(camn3), n, cam.ref(), ptr(d_m), ptr(f_m), s)),
             "to_camera_frame (k_to_camera_frame)": (24.0, lambda: L.tohip_to_camera_frame(ptr(pts), n, ptr(q1), ptr(t1), 1, 0, ptr(out3), s)),
-            "pointcloud2_to_xyz (k_pc2_*: 16-byte xyzi points)": (None, lambda: L.tohip_pointcloud2_to_xyz(ptr(raw), n, 16, 0, 4, 8, 7, 0, 1, ptr(out3), ptr(cnt), ptr(iws), iws.numel(), s)),
+            "pointcloud2_to_xyz (k_pc2_*: 16-byte xyzi points, no invalid row: one read of the message from the second call on)": (None, lambda: L.tohip_pointcloud2_to_xyz(ptr(raw), n, 16, 0, 4, 8, 7, 0, 1, ptr(out3), ptr(cnt), ptr(iws), iws.numel(), s)),
+            "pointcloud2_to_xyz_1pct_nan_rows (k_pc2_*: the same message with 1 % invalid rows: count | scan | write)": (None, lambda: L.tohip_pointcloud2_to_xyz(ptr(raw_nan), n, 16, 0, 4, 8, 7, 0, 1, ptr(out3), ptr(cnt), ptr(iws_nan), iws_nan.numel(), s)),
         }
         rows = {}
         for name, (bpp, fn) in calls.items():
@@ -355,7 +360,7 @@ def aux_leg(device, sizes=(1_000_000, 16_000_000), reps=20):
             gbs = bpp * n / (us * 1e-6) / 1e9
             rows[name] = {"us_per_call": us, "algorithmic_bytes_per_point": bpp, "GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
         out[f"{n}_points"] = rows
-        del pts, pts_local, cloud, cam3, camn3, flipped, out3, msg, raw, obs, pblob, pws, vout, vws
+        del pts, pts_local, cloud, cam3, camn3, flipped, out3, msg, raw, msg_nan, raw_nan, obs, pblob, pws, vout, vws
         torch.cuda.empty_cache()
     out["note"] = ("algorithmic bytes per point: pack 12 B read + 20 B written, voxel grid 12 + (at most) 12 — both are bound by their sorts, not by these bytes; "
                    "pose 12 B read + 4 B written (16), backward alone 12; flip 12 + 12; cull 12 + 2 + 4 per kept point; "
@@ -626,7 +631,7 @@ def compact_line(full):
         pick = {}
         for name, v in big.items():
             short = name.split(" ")[0].rstrip(",")
-            if short in ("pointcloud2_to_xyz", "frustum_cull", "to_camera_frame", "pose_forward", "pose_forward_backward", "spherical_flip", "soft_masks") and short not in pick:
+            if short in ("pointcloud2_to_xyz", "pointcloud2_to_xyz_1pct_nan_rows", "frustum_cull", "to_camera_frame", "pose_forward", "pose_forward_backward", "spherical_flip", "soft_masks") and short not in pick:
                 pick[short] = {"us": v["us_per_call"], "frac_of_hbm_peak": v["frac_of_hbm_peak"]}
         line["aux_16M_points"] = pick
         small = full["aux"].get("1000000_points")
@@ -1191,7 +1196,7 @@ def main():
             if leg_on("density"):
                 emit("density_sweep", density_leg(device))
             if leg_on("aux"):
-                emit("aux", aux_leg(device, sizes=(1_000_000, 16_000_000) if args.details == "full" else (16_000_000,)))
+                emit("aux", aux_leg(device))
             if leg_on("occlusion"):
                 emit("occlusion", occlusion_leg(device))
             if leg_on("hpr"):

@@ -43,13 +43,50 @@ def usable_cores():
     return n, aff, nproc, quota
 
 
+def idlest_cores(n, sample_s=0.25):
+    """The n allowed cores that were least busy over the last `sample_s` seconds (/proc/stat), as a sorted list — a GPU box is a slice of
+    a larger host whose other tenants tend to sit on the first cores; None where /proc/stat cannot say."""
+    def snap():
+        out = {}
+        with open("/proc/stat") as f:
+            for line in f:
+                if line.startswith("cpu") and line[3].isdigit():
+                    p = line.split()
+                    v = [int(x) for x in p[1:9]]
+                    out[int(p[0][3:])] = (sum(v), v[3] + v[4])   # (total, idle + iowait)
+        return out
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        a = snap()
+        time.sleep(sample_s)
+        b = snap()
+        busy = {c: 1.0 - (b[c][1] - a[c][1]) / max(1, b[c][0] - a[c][0]) for c in allowed if c in a and c in b}
+        if len(busy) < n:
+            return None
+        # a contiguous run of allowed cores (neighbours share caches): the run of n with the lowest total load
+        best, best_load = None, None
+        for i in range(0, len(allowed) - n + 1):
+            run = allowed[i:i + n]
+            load = sum(busy.get(c, 1.0) for c in run)
+            if best_load is None or load < best_load - 1e-9:
+                best, best_load = run, load
+        return best
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
 def child_env(threads=None):
-    """The environment bench.py starts this module with (set BEFORE the OpenMP runtime loads)."""
+    """The environment bench.py starts this module with (set BEFORE the OpenMP runtime loads): one thread per usable core, bound
+    (OMP_PROC_BIND=close) to explicit places — the least busy contiguous run of allowed cores, or OMP_PLACES=cores where that
+    cannot be measured."""
     n, _, _, _ = usable_cores()
+    n = threads or n
     env = dict(os.environ)
-    env["OMP_NUM_THREADS"] = str(threads or n)
+    env["OMP_NUM_THREADS"] = str(n)
     env.setdefault("OMP_PROC_BIND", "close")
-    env.setdefault("OMP_PLACES", "cores")
+    if "OMP_PLACES" not in env:
+        cores = idlest_cores(n)
+        env["OMP_PLACES"] = ",".join("{%d}" % c for c in cores) if cores else "cores"
     env.setdefault("OMP_DYNAMIC", "false")
     return env
 

@@ -318,9 +318,12 @@ inline void launch_scan_tiles(const int32_t* tile_count, int ntiles, int32_t* ti
 // pass C: ascending indices of kept points.  A WAVE per tile: its sixteen keep words arrive in one request (lanes 0-15), the wave
 // walks them in point order with the running offset in a scalar, and no wave waits for another — a block per tile was 15 625
 // blocks of a few instructions at 16 M points; a block striding over tiles chained eight dependent loads (26 us for 4 MB written).
+// tile_off == nullptr (clouds of up to 2 M points: at most 2 048 tiles): no scan launch — the wave adds up the counts of the
+// tiles before its own itself (32 independent loads per lane at most, one or two memory round trips, where the single-block scan
+// and its launch were a third of a 1 M-point call), and the wave of the last tile writes the total.
 __global__ void __launch_bounds__(TO_BLOCK)
 k_frustum_write(int64_t n, const unsigned long long* __restrict__ keep, const int32_t* __restrict__ tile_off,
-                int32_t* __restrict__ kept_idx) {
+                const int32_t* __restrict__ tile_count, int32_t* __restrict__ total, int32_t* __restrict__ kept_idx) {
     const int lane = threadIdx.x & 63;
     const int64_t nwords = (n + 63) >> 6;
     const int ntiles = (int)((n + TO_CULL_TILE - 1) / TO_CULL_TILE);
@@ -329,7 +332,17 @@ k_frustum_write(int64_t n, const unsigned long long* __restrict__ keep, const in
         const int64_t tile0 = (int64_t)tile * TO_CULL_TILE;
         const int64_t w0 = tile0 >> 6;
         const unsigned long long mine = (lane < TO_CULL_TILE / 64 && w0 + lane < nwords) ? keep[w0 + lane] : 0ull;
-        int off = tile_off[tile];
+        int off;
+        if (tile_off != nullptr) {
+            off = tile_off[tile];
+        } else {
+            int s = 0;
+            for (int j = lane; j < tile; j += 64) s += tile_count[j];
+            for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+            off = s;
+            if (tile == ntiles - 1 && lane == 0 && total != nullptr) *total = s + tile_count[tile];
+        }
+        if (kept_idx == nullptr) continue;
 #pragma unroll
         for (int q = 0; q < TO_CULL_TILE / 64; ++q) {
             const unsigned long long b = (unsigned long long)__shfl((long long)mine, q);
@@ -372,13 +385,19 @@ extern "C" int tohip_frustum_cull(const float* cam_3xN, int64_t n, const tohip_c
     unsigned long long* keep = (unsigned long long*)((char*)workspace + 2 * seg + 256);
     k_frustum_count<<<ntiles, TO_BLOCK, 0, st>>>(cam_3xN, n, f, dist_mask, fov_mask, tile_count, keep);
     TO_HIP_CHECK_LAUNCH();
+    const int wblocks = (ntiles + TO_WAVES_PER_BLOCK - 1) / TO_WAVES_PER_BLOCK;
+    static const int own_prefix = getenv("TOHIP_FRUSTUM_OWN_PREFIX") ? atoi(getenv("TOHIP_FRUSTUM_OWN_PREFIX")) : 1;   // experiments: 0 = always scan
+    if (own_prefix && ntiles <= 2048 && (kept_idx || kept_count)) {   // two launches: every wave of the write pass finds its own offset
+        k_frustum_write<<<wblocks, TO_BLOCK, 0, st>>>(n, keep, nullptr, tile_count, kept_count, kept_idx);
+        TO_HIP_CHECK_LAUNCH();
+        return TOHIP_OK;
+    }
     if (kept_idx || kept_count) {
         launch_scan_tiles(tile_count, ntiles, tile_off, kept_count ? kept_count : total_scratch, st);
         TO_HIP_CHECK_LAUNCH();
     }
     if (kept_idx) {
-        const int wblocks = (ntiles + TO_WAVES_PER_BLOCK - 1) / TO_WAVES_PER_BLOCK;
-        k_frustum_write<<<wblocks < 8192 ? wblocks : 8192, TO_BLOCK, 0, st>>>(n, keep, tile_off, kept_idx);
+        k_frustum_write<<<wblocks < 8192 ? wblocks : 8192, TO_BLOCK, 0, st>>>(n, keep, tile_off, nullptr, nullptr, kept_idx);
         TO_HIP_CHECK_LAUNCH();
     }
     return TOHIP_OK;

@@ -23,6 +23,9 @@ def _field(msg, name):
     raise KeyError(f"PointCloud2 has no field {name!r}")
 
 
+_PC2_WORKSPACES = {}
+
+
 def pointcloud2_to_xyz_array(cloud_msg, remove_nans=True, device=torch.device("cuda")):
     """/root/reference/src/pointcloud_utils.py:197-198 -> (N,3) float32 tensor on `device`, message order,
     rows with a non-finite coordinate removed (the reference returns float64 and its callers cast to float32,
@@ -39,7 +42,14 @@ def pointcloud2_to_xyz_array(cloud_msg, remove_nans=True, device=torch.device("c
     out = torch.empty((max(n, 1), 3), dtype=torch.float32, device=device)
     cnt = torch.zeros(1, dtype=torch.int32, device=device)
     wsb = L.tohip_ingest_workspace_bytes(n)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=device)
+    # one workspace per (device, stream, size), kept between messages: it carries the library's hint whether the last message had
+    # invalid rows (a dense message is then unpacked in one read, include/trajopt_hip.h)
+    key = (torch.device(device).index, int(torch.cuda.current_stream(device).cuda_stream), wsb)
+    ws = _PC2_WORKSPACES.get(key)
+    if ws is None:
+        if len(_PC2_WORKSPACES) >= 8:
+            _PC2_WORKSPACES.clear()
+        ws = _PC2_WORKSPACES[key] = torch.zeros(wsb, dtype=torch.uint8, device=device)
     with torch.cuda.device(device):
         check(L.tohip_pointcloud2_to_xyz(ptr(data), n, int(cloud_msg.point_step), int(fx.offset), int(fy.offset),
                                          int(fz.offset), int(fx.datatype), int(bool(getattr(cloud_msg, "is_bigendian", False))),
