@@ -556,38 +556,44 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
     const bool has_nan = b.seg_nan[sg] != 0;
     const bool enough = hi - lo - 1 >= 4 && !has_nan;  // Qhull needs d+1 input points; the appended origin comes on top
     if (enough) {
+        // Any four input points that span a volume start a hull; extreme ones start it well.  A large segment looks for them among
+        // every eighth point (Morton order: a uniform sample — the four passes over 107 k points per view were 0.35 ms of a 128-view
+        // build, r06) and only falls back to all points if the sample's tetrahedron is degenerate (a flat verdict must come from all).
         // ties go to the caller's lowest index (perm), whatever the internal order
-        double best = -INFINITY; int bi = 0x7fffffff;
-        for (int i = lo + t; i < hi; i += HULL_INIT_THREADS) {
-            const double k = -b.px[i]; const int e = b.perm[i];
-            if (k > best || (k == best && e < bi)) { best = k; bi = e; }
+        for (int st = (hi - lo >= 32768) ? 8 : 1; ; st = 1) {
+            double best = -INFINITY; int bi = 0x7fffffff;
+            for (int i = lo + t * st; i < hi; i += HULL_INIT_THREADS * st) {
+                const double k = -b.px[i]; const int e = b.perm[i];
+                if (k > best || (k == best && e < bi)) { best = k; bi = e; }
+            }
+            i0 = b.inv[block_argmax(best, bi, skey, sidx, nullptr)];
+            x0 = b.px[i0]; y0 = b.py[i0]; z0 = b.pz[i0];
+            best = -INFINITY; bi = 0x7fffffff;
+            for (int i = lo + t * st; i < hi; i += HULL_INIT_THREADS * st) {
+                const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
+                const double k = dx * dx + dy * dy + dz * dz; const int e = b.perm[i];
+                if (k > best || (k == best && e < bi)) { best = k; bi = e; }
+            }
+            i1 = b.inv[block_argmax(best, bi, skey, sidx, &kk)];
+            const double ex = b.px[i1] - x0, ey = b.py[i1] - y0, ez = b.pz[i1] - z0;
+            best = -INFINITY; bi = 0x7fffffff;
+            for (int i = lo + t * st; i < hi; i += HULL_INIT_THREADS * st) {
+                const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
+                const double cx = dy * ez - dz * ey, cy = dz * ex - dx * ez, cz = dx * ey - dy * ex;
+                const double k = cx * cx + cy * cy + cz * cz; const int e = b.perm[i];
+                if (k > best || (k == best && e < bi)) { best = k; bi = e; }
+            }
+            i2 = b.inv[block_argmax(best, bi, skey, sidx, &k2)];
+            const double fx = b.px[i2] - x0, fy = b.py[i2] - y0, fz = b.pz[i2] - z0;
+            nx = ey * fz - ez * fy; ny = ez * fx - ex * fz; nz = ex * fy - ey * fx;
+            best = -INFINITY; bi = 0x7fffffff;
+            for (int i = lo + t * st; i < hi; i += HULL_INIT_THREADS * st) {
+                const double k = fabs(nx * (b.px[i] - x0) + ny * (b.py[i] - y0) + nz * (b.pz[i] - z0)); const int e = b.perm[i];
+                if (k > best || (k == best && e < bi)) { best = k; bi = e; }
+            }
+            i3 = b.inv[block_argmax(best, bi, skey, sidx, &k3)];
+            if (st == 1 || (kk > 0.0 && k2 > 0.0 && k3 > 0.0)) break;   // (block-uniform: block_argmax hands every thread the same values)
         }
-        i0 = b.inv[block_argmax(best, bi, skey, sidx, nullptr)];
-        x0 = b.px[i0]; y0 = b.py[i0]; z0 = b.pz[i0];
-        best = -INFINITY; bi = 0x7fffffff;
-        for (int i = lo + t; i < hi; i += HULL_INIT_THREADS) {
-            const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
-            const double k = dx * dx + dy * dy + dz * dz; const int e = b.perm[i];
-            if (k > best || (k == best && e < bi)) { best = k; bi = e; }
-        }
-        i1 = b.inv[block_argmax(best, bi, skey, sidx, &kk)];
-        const double ex = b.px[i1] - x0, ey = b.py[i1] - y0, ez = b.pz[i1] - z0;
-        best = -INFINITY; bi = 0x7fffffff;
-        for (int i = lo + t; i < hi; i += HULL_INIT_THREADS) {
-            const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
-            const double cx = dy * ez - dz * ey, cy = dz * ex - dx * ez, cz = dx * ey - dy * ex;
-            const double k = cx * cx + cy * cy + cz * cz; const int e = b.perm[i];
-            if (k > best || (k == best && e < bi)) { best = k; bi = e; }
-        }
-        i2 = b.inv[block_argmax(best, bi, skey, sidx, &k2)];
-        const double fx = b.px[i2] - x0, fy = b.py[i2] - y0, fz = b.pz[i2] - z0;
-        nx = ey * fz - ez * fy; ny = ez * fx - ex * fz; nz = ex * fy - ey * fx;
-        best = -INFINITY; bi = 0x7fffffff;
-        for (int i = lo + t; i < hi; i += HULL_INIT_THREADS) {
-            const double k = fabs(nx * (b.px[i] - x0) + ny * (b.py[i] - y0) + nz * (b.pz[i] - z0)); const int e = b.perm[i];
-            if (k > best || (k == best && e < bi)) { best = k; bi = e; }
-        }
-        i3 = b.inv[block_argmax(best, bi, skey, sidx, &k3)];
     }
     if (t == 0) init_tetrahedron(b, sg, enough, has_nan, i0, i1, i2, i3, kk, k2, k3, nx, ny, nz, x0, y0, z0);
 }
@@ -1892,7 +1898,9 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         }
         if (!stalled) {
             while (inflight < ahead) {  // keep one batch ahead of the readback being waited for
-                const int rc = enqueue_rounds(always_careful ? 1 : batch, always_careful);
+                // few candidates left: the build is about to end, and every round enqueued beyond its end is five launches of
+                // nothing (up to eight such rounds at four per readback: 0.1 ms of a 4 ms build) -> two per readback from here on
+                const int rc = enqueue_rounds(always_careful ? 1 : ((ncand <= 512 && batch > 2) ? 2 : batch), always_careful);
                 if (rc != TOHIP_OK) return drain(rc);
                 round_of[wslot] = round;
                 e = post_readback();
