@@ -744,8 +744,22 @@ __global__ void __launch_bounds__(TO_BLOCK) k_far_arg_all(Bufs b) { far_arg_poin
 // face stolen later) can only cost that candidate this round; a round that accepts nobody is repeated with k_owner_prop
 // run to convergence.
 constexpr int kClaimFront = 128, kClaimMax = 4096, kClaimLog = 192;
-__global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int par) {
+// verdict != 0 (r06, the fast path): the walk also DECIDES who is accepted, so the round needs no k_accept launch.  k_accept's rule —
+// a candidate stays accepted iff it owns every face its apex sees and no better candidate owns a face across its horizon — is
+// settled where ownership changes hands: a walk that meets a face it sees in better hands, or a better owner across its horizon,
+// fails itself; a walk that robs a face, or finds a worse owner across its horizon, fails that one; an incomplete walk fails itself.
+// Every claimed face's three neighbours are looked at AFTER the claim's CAS has returned (the next level of the walk), and claims
+// and looks are atomics at the memory side: of two candidates that take adjacent faces at the same time at least one sees the
+// other, whichever order the CASes land in.  The verdict is what k_accept computed from the final ownership: the accepted bit
+// (fflags bit 1) of the candidates nobody failed.  Block 0 does k_accept's housekeeping.
+__global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int par, int verdict) {
     __shared__ int fr[TO_WAVES_PER_BLOCK][2][kClaimFront];
+    if (verdict && blockIdx.x == 0) {
+        // nothing has been inserted yet this round: the staged count is the face count; it is published here for the
+        // kernels that run while k_new_faces raises the staged one.  The next round's lists start empty.
+        if (threadIdx.x == 0) { b.ctrl[kCtrlNFaces] = min(b.ctrl[kCtrlNFaces + 8], b.fcap); b.ctrl[kCtrlAccepted] = 0; }
+        if (threadIdx.x < kSubLists) { *ccnt(b, par ^ 1, threadIdx.x) = 0; *ocnt(b, par ^ 1, threadIdx.x) = 0; }
+    }
     __shared__ int lg[TO_WAVES_PER_BLOCK][kClaimLog];
     __shared__ int lgc[TO_WAVES_PER_BLOCK][kClaimLog];   // who claimed it
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -797,9 +811,13 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
                     }
                 }
             }
-            if (__any(doomed)) continue;
+            if (__any(doomed)) {
+                if (verdict && lane == 0) atomicAnd(&b.fflags[o], ~2);
+                continue;
+            }
         }
         int cur = 0, ncur = 1, claimed = 0;
+        bool failed = false;   // (wave-uniform)
         if (lane == 0) fr[wid][0][0] = o;
         while (ncur > 0 && claimed < kClaimMax) {
             int nnext = 0;
@@ -807,6 +825,8 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
                 const int t = base + lane;
                 bool mine = false;
                 int n = kNone;
+                bool fail_me = false;
+                int fail_other = kNone;
                 if (t < 3 * ncur) {
                     const int cg = fr[wid][cur][t / 3];
                     n = b.fn[3 * cg + t % 3];
@@ -815,11 +835,20 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
                     if (sees && !(co == o || (co >= 0 && b.fprio[co] <= po))) {
                         while (true) {
                             const int old = atomicCAS(&b.fowner[n], co, o);
-                            if (old == co) { mine = true; break; }  // two lanes on the same face: the second finds `o` there
+                            if (old == co) { mine = true; fail_other = co; break; }  // two lanes on the same face: the second finds `o` there; a robbed owner has lost
                             co = old;
-                            if (co == o || (co >= 0 && b.fprio[co] <= po)) break;
+                            if (co == o) break;
+                            if (co >= 0 && b.fprio[co] <= po) { fail_me = true; break; }   // a better one was quicker
                         }
+                    } else if (sees) {
+                        fail_me = co != o;                     // a face my apex sees, in better hands
+                    } else if (co >= 0 && co != o) {           // across my horizon: the worse of the two neighbours loses
+                        if (b.fprio[co] < po) fail_me = true; else fail_other = co;
                     }
+                }
+                if (verdict) {
+                    if (fail_other >= 0) atomicAnd(&b.fflags[fail_other], ~2);
+                    failed = failed || __any(fail_me);
                 }
                 const unsigned long long bal = __ballot(mine);
                 const int cnt = __popcll(bal), rank = __popcll(bal & ((1ull << lane) - 1ull));
@@ -830,9 +859,12 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
                 nnext += cnt;
             }
             claimed += nnext;
+            if (nnext > kClaimFront) failed = true;   // faces were claimed whose neighbours nobody will look at: an incomplete walk
             ncur = nnext < kClaimFront ? nnext : kClaimFront;
             cur ^= 1;
         }
+        if (ncur > 0) failed = true;                  // the claim budget ran out with a frontier left
+        if (verdict && failed && lane == 0) atomicAnd(&b.fflags[o], ~2);
     }
     flush();
 }
@@ -916,6 +948,7 @@ __device__ __forceinline__ bool owned_accepted(const Bufs& b, int g, int* owner)
 // then taken by a better candidate): the entry that counts is the one made by the candidate that owns the face now — exactly one
 // (a candidate claims a face at most once), decided without an atomic whose answer the thread would have to wait for.
 __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
+    if (b.ctrl[kCtrlOverflow] != 0) return;   // a claimed face is missing from the lists: nobody is inserted this round (the build ends: capacity)
     const ListWalk w = list_walk(b, par, blockIdx.x, gridDim.x);
     for (int it = 0; it < w.loops; ++it) {
         int claimer = kNone;
@@ -1813,6 +1846,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     static const bool always_careful = getenv("TOHIP_HULL_CAREFUL") != nullptr;                   // experiments: the slow path only
     static const int compact_every = getenv("TOHIP_HULL_COMPACT") ? atoi(getenv("TOHIP_HULL_COMPACT")) : 2;
     static const bool trace = getenv("TOHIP_HULL_TRACE") != nullptr;   // experiments: the build's progress, one line per readback
+    static const int fused_verdict = getenv("TOHIP_HULL_FUSED_ACCEPT") ? atoi(getenv("TOHIP_HULL_FUSED_ACCEPT")) : 1;   // experiments: 0 = a k_accept launch per round
     static const int join_faces = getenv("TOHIP_HULL_JOIN_FACES") ? atoi(getenv("TOHIP_HULL_JOIN_FACES")) : 192;  // experiments
 
     // `careful`: ownership propagated to convergence with the host checking (after a batch that accepted nobody)
@@ -1825,7 +1859,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
             if (!careful) {
                 // Fast path: a wave per candidate walks and claims its region (one launch, no readback).  Incomplete
                 // ownership is safe — a candidate is accepted only if it owns every face its apex sees (k_accept).
-                k_owner_claim<<<ga, TO_BLOCK, 0, st>>>(b, round, par);
+                k_owner_claim<<<ga, TO_BLOCK, 0, st>>>(b, round, par, fused_verdict);
                 TO_HIP_CHECK_LAUNCH();
             } else {
                 while (true) {
@@ -1843,7 +1877,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
                 TO_HIP_CHECK_LAUNCH();
             }
             const int gr = nblocks(live_bound, 1024);
-            k_accept<<<gl, TO_BLOCK, 0, st>>>(b, round, par);
+            if (careful || !fused_verdict) k_accept<<<gl, TO_BLOCK, 0, st>>>(b, round, par);   // (the fast path's walk has given its verdict)
             k_new_faces<<<gl, TO_BLOCK, 0, st>>>(b, par);
             k_link_reassign<<<gl + gr, TO_BLOCK, 0, st>>>(b, par, gl);
             const int gt = std::max(gl, std::min(2048, (nblocks(live_bound) + kSubLists - 1) / kSubLists * kSubLists));
