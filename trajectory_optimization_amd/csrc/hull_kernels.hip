@@ -14,7 +14,8 @@
 //                faces its apex sees; a hashed total order breaks overlaps
 //            (3) a candidate is accepted iff it owns every face its apex sees and no better candidate
 //                owns a face across its horizon -> accepted regions are pairwise non-adjacent, so the
-//                insertions commute and equal the sequential result
+//                insertions commute and equal the sequential result (r06: decided inside step (2)'s walk —
+//                k_owner_claim's `verdict` — the k_accept launch is the careful path's)
 //            (4) one new triangle per horizon edge, linked to its two siblings by rotating around the
 //                shared horizon vertex; (5) points of deleted faces move to a new face or retire
 //   end      no point is outside any face; hull vertices = vertices of the live faces
@@ -706,7 +707,8 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
 }
 
 // ---- round --------------------------------------------------------------------------------------
-// Five launches: claim | accept | new faces | link + reassign | tail, all of them over the round's face LISTS (candidates and
+// Four launches (r06: the claim walk gives the verdict; five with k_accept in the careful path): claim | new faces | link + reassign | tail,
+// all of them over the round's face LISTS (candidates and
 // claimed faces, list_walk) and the live points — never over every face of the hull.  `par` is the round's parity (which of
 // the two candidate lists it reads), `round` salts the candidates' ranking.  What each reads of the control block:
 //   kCtrlNFaces      published face count = the faces that existed before THIS round's insertions (written by k_accept)
