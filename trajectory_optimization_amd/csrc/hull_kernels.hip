@@ -9,7 +9,7 @@
 //   state    points (x,y,z as f64, the origin appended as point M), per point its conflict face
 //            (a face it lies strictly outside of, or -1), triangles with CCW outward orientation,
 //            neighbour links per edge, unnormalised plane normals
-//   round    (1) per face: farthest outside point = apex candidate (atomicMax on ordered f64 bits)
+//   round    (1) per face: farthest outside point = apex candidate (one atomicMax on (float distance, ~position): apex_key)
 //            (2) label propagation over the face graph: each candidate claims the connected set of
 //                faces its apex sees; a hashed total order breaks overlaps
 //            (3) a candidate is accepted iff it owns every face its apex sees and no better candidate
@@ -63,9 +63,7 @@ struct Bufs {
     int* fv;               // 3 * fcap
     int* fn;               // 3 * fcap
     FaceRec* frec;         // fcap
-    unsigned long long* fmax;  // fcap
-    unsigned long long* fapex;  // fcap   apex candidate: its EXPANDED index (high word: ties go to the caller's lowest index) and its
-                           //        position (low word: what the kernels want, without a trip through `inv`); kNoApex = none
+    unsigned long long* fmax;  // fcap   apex_key of the face's farthest outside point (0: none)
     int* fowner;           // fcap
     unsigned long long* fprio;  // fcap   rank of a candidate this round (smaller = better), written by the previous round's tail
     int* fflags;           // fcap   bit0 alive, bit1 candidate / accepted, bit2 dies at the end of this round
@@ -114,8 +112,15 @@ struct Bufs {
                            //    the sample is then every sample_stride()-th position of a segment, counted from its first
 };
 
-constexpr unsigned long long kNoApex = ~0ull;
-__device__ __forceinline__ int apex_pos(unsigned long long a) { return (int)(unsigned)(a & 0xffffffffull); }
+// A face's farthest outside point lives in ONE word, fmax[f] (r06; until r05 a 64-bit distance there and a second pass over the live
+// points to find who attains it): the distance as a float in the high word, ~position in the low one — atomicMax keeps the farthest
+// point, the lowest position among equals (float rounding is monotone; any outside point is a valid apex, the farthest a good one).
+// 0 = no point outside the face.
+__device__ __forceinline__ unsigned long long apex_key(double d, int pos) {
+    return d > 0.0 ? (((unsigned long long)__float_as_uint((float)d)) << 32) | (unsigned long long)(0xffffffffu - (unsigned)pos) : 0ull;
+}
+__device__ __forceinline__ int apex_pos(unsigned long long k) { return (int)(0xffffffffu - (unsigned)(k & 0xffffffffull)); }
+__device__ __forceinline__ float apex_dist(unsigned long long k) { return __uint_as_float((unsigned)(k >> 32)); }
 
 __host__ inline size_t seg(size_t bytes) { return align_up(bytes, 256); }
 
@@ -123,8 +128,8 @@ __host__ inline size_t seg(size_t bytes) { return align_up(bytes, 256); }
 // The default suits clouds whose hull is a small fraction of the points (HPR of a scene: 2-5 %); a build that runs out
 // returns TOHIP_ENOSPC and the caller retries with a larger workspace — every byte beyond the fixed part is used for
 // faces (faces_for_bytes), up to the never-exceeded-in-practice 8 per point.
-constexpr size_t kBytesPerFace = 16 * sizeof(int) + 3 * sizeof(double) + 64;  // the per-face arrays carved below
-constexpr int kFaceArrays = 14;
+constexpr size_t kBytesPerFace = 16 * sizeof(int) + 2 * sizeof(double) + 64;  // the per-face arrays carved below
+constexpr int kFaceArrays = 13;
 
 __host__ inline int default_face_capacity(int64_t m1, int64_t nseg) {
     int64_t c = m1 / 2 + 64 * nseg + 4096;
@@ -146,7 +151,6 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * 3 * (size_t)fcap); if (b) b->fn = (int*)p;
     p = take(sizeof(FaceRec) * (size_t)fcap); if (b) b->frec = (FaceRec*)p;
     p = take(sizeof(unsigned long long) * (size_t)fcap); if (b) b->fmax = (unsigned long long*)p;
-    p = take(sizeof(unsigned long long) * (size_t)fcap); if (b) b->fapex = (unsigned long long*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->fowner = (int*)p;
     p = take(sizeof(unsigned long long) * (size_t)fcap); if (b) b->fprio = (unsigned long long*)p;
     p = take(sizeof(int) * (size_t)fcap); if (b) b->fflags = (int*)p;
@@ -202,11 +206,6 @@ __host__ inline int faces_for_bytes(int64_t n_points, int64_t nseg, size_t bytes
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long dkey(double d) {
-    // order-preserving map of non-negative doubles (and of all doubles) to unsigned integers
-    unsigned long long u = (unsigned long long)__double_as_longlong(d);
-    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
-}
 
 __device__ __forceinline__ unsigned hash32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -222,7 +221,6 @@ __device__ __forceinline__ unsigned long long make_prio(int f, int round, float 
     const unsigned inv = ((1u << hbits) - 1u) - hb;
     return ((unsigned long long)inv << 48) | ((unsigned long long)(h & 0xffffu) << 32) | (unsigned)f;
 }
-__device__ __forceinline__ double dkey_inv_pos(unsigned long long k) { return __longlong_as_double((long long)(k & 0x7fffffffffffffffull)); }
 
 // an ACCEPTED candidate's record doubles as the table of its region's new faces (k_new_faces): words 0..11 = the plane it no longer needs
 constexpr int kRegionTab = 12;
@@ -508,7 +506,7 @@ __device__ void init_tetrahedron(const Bufs& b, int sg, bool enough, bool has_na
             for (int f = fb; f < fb + 4; ++f) {
                 for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = lo; b.fn[3 * f + k] = f; }
                 b.frec[f] = FaceRec{0.0, 0.0, 0.0, b.px[lo], b.py[lo], b.pz[lo], kNone, 0.f, {0, 0}};
-                b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.fapex[f] = kNoApex; b.nfhead[f] = 0;
+                b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.nfhead[f] = 0;
                 b.newface[3 * f] = kNone;
             }
             return;
@@ -526,7 +524,6 @@ __device__ void init_tetrahedron(const Bufs& b, int sg, bool enough, bool has_na
             b.fflags[f] = 1;
             b.fowner[f] = kNone;
             b.fmax[f] = 0ull;
-            b.fapex[f] = kNoApex;
             b.nfhead[f] = 0;
             b.newface[3 * f] = kNone;
         }
@@ -701,7 +698,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
                 b.pface[i] = bf;
             }
         }
-        wave_face_max(b, tab, bf, dkey(best));
+        wave_face_max(b, tab, bf, apex_key(best, i));
     }
     face_max_flush(b, tab);
 }
@@ -715,26 +712,6 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
 //   kCtrlNFaces + 8  staged count: every face created so far (k_new_faces allocates from it)
 //   kCtrlAccepted    regions accepted this round
 // The tail prepares the NEXT round (per-face reset, next candidate list), so a round has no reset launch of its own.
-
-// apex of the faces with id >= f_lo: lowest caller's index among the points at the face's maximum distance.  A face's
-// outside set never changes after its creation round, so its apex is computed once; older faces keep theirs.
-__device__ __forceinline__ void far_arg_points(const Bufs& b, int f_lo, int vblock, int nvblocks) {
-    const int nlive = b.ctrl[kCtrlNLive];
-    const int stride = nvblocks * TO_BLOCK;
-    constexpr int U = 4;   // four (live -> pface) chains in flight per thread, as in reassign_points
-    for (int j0 = vblock * TO_BLOCK + threadIdx.x; j0 < nlive; j0 += U * stride) {
-        int ii[U], ff[U];
-        for (int u = 0; u < U; ++u) ii[u] = j0 + u * stride < nlive ? b.live[j0 + u * stride] : -1;
-        for (int u = 0; u < U; ++u) ff[u] = ii[u] >= 0 ? b.pface[ii[u]] : kNone;
-        for (int u = 0; u < U; ++u) {
-            const int i = ii[u], f = ff[u];
-            if (i < 0 || f < f_lo || f < 0) continue;
-            if (dkey(fdist(b, f, i)) == b.fmax[f]) atomicMin(&b.fapex[f], ((unsigned long long)(unsigned)b.perm[i] << 32) | (unsigned)i);
-        }
-    }
-}
-
-__global__ void __launch_bounds__(TO_BLOCK) k_far_arg_all(Bufs b) { far_arg_points(b, 0, blockIdx.x, gridDim.x); }
 
 // The ownership propagation of a round in ONE launch, one WAVE per candidate: breadth first over the region the candidate's
 // apex sees, the frontier in LDS, every (frontier face, edge) pair on its own lane — a level costs one chain of dependent
@@ -786,9 +763,9 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
     };
     for (int c = (blockIdx.x / kSubLists) * TO_WAVES_PER_BLOCK + wid; c < ncand; c += wstep) {
         const int o = cand[c];
-        const unsigned long long ax = b.fapex[o];
+        const unsigned long long ax = b.fmax[o];
         const int n0 = (b.early_out && lane < 3) ? b.fn[3 * o + lane] : kNone;   // for the look at the neighbours below: requested with the apex
-        if (ax == kNoApex) {  // no apex found for a face with points outside it (never seen): not a candidate
+        if (ax == 0ull) {  // a candidate without a point outside its face (never seen): not a candidate
             if (lane == 0) { b.fowner[o] = kNone; atomicAnd(&b.fflags[o], ~2); }
             continue;
         }
@@ -806,8 +783,8 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
             if (n0 >= 0) {
                 const int n = n0;
                 if ((b.fflags[n] & 3) == 3 && b.fprio[n] < po) {
-                    const unsigned long long an = b.fapex[n];
-                    if (an != kNoApex) {
+                    const unsigned long long an = b.fmax[n];
+                    if (an != 0ull) {
                         const int pa = apex_pos(an);
                         doomed = plane_dist(b.frec[o], b.px[pa], b.py[pa], b.pz[pa]) > 0.0;
                     }
@@ -881,13 +858,13 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_prop(Bufs b, int round) {
     for (int g = blockIdx.x * TO_BLOCK + threadIdx.x; g < nf; g += stride) {
         if (!(b.fflags[g] & 1)) continue;
         int best = b.fowner[g];
-        if (best == g && b.fapex[g] == kNoApex) { b.fowner[g] = kNone; atomicAnd(&b.fflags[g], ~2); continue; }
+        if (best == g && b.fmax[g] == 0ull) { b.fowner[g] = kNone; atomicAnd(&b.fflags[g], ~2); continue; }
         unsigned long long bp = best >= 0 ? b.fprio[best] : ~0ull;
         for (int k = 0; k < 3; ++k) {
             const int o = b.fowner[b.fn[3 * g + k]];
-            if (o < 0 || o == best || b.fapex[o] == kNoApex) continue;
+            if (o < 0 || o == best || b.fmax[o] == 0ull) continue;
             const unsigned long long op = b.fprio[o];
-            if (op < bp && fdist(b, g, apex_pos(b.fapex[o])) > 0.0) { best = o; bp = op; }
+            if (op < bp && fdist(b, g, apex_pos(b.fmax[o])) > 0.0) { best = o; bp = op; }
         }
         if (best != b.fowner[g]) { b.fowner[g] = best; changed = true; }
     }
@@ -925,7 +902,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_accept(Bufs b, int round, int par)
         const int o = b.fowner[g];
         if (o < 0) continue;
         if (b.fowner[o] != o) { continue; }  // o lost its own face: not a candidate (owned_accepted() checks the same)
-        const int apex = apex_pos(b.fapex[o]);
+        const int apex = apex_pos(b.fmax[o]);
         bool ok = !overflow;
         for (int k = 0; k < 3; ++k) {
             const int n = b.fn[3 * g + k];
@@ -968,7 +945,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
         if (acc != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&b.ctrl[kCtrlAccepted], __popcll(acc));
         int id = block_alloc(&b.ctrl[kCtrlNFaces + 8], want);
         if (want == 0) continue;
-        const int apex = apex_pos(b.fapex[o]);
+        const int apex = apex_pos(b.fmax[o]);
         for (int k = 0; k < 3; ++k) {
             if (!hor[k]) continue;
             if (id >= b.fcap) { b.ctrl[kCtrlError] |= kErrCapacity; break; }
@@ -978,7 +955,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
             b.fv[3 * id] = u; b.fv[3 * id + 1] = v; b.fv[3 * id + 2] = apex;
             b.fn[3 * id] = n; b.fn[3 * id + 1] = kNone; b.fn[3 * id + 2] = kNone;
             set_plane(b, id);
-            b.fflags[id] = 1; b.fowner[id] = kNone; b.fmax[id] = 0ull; b.fapex[id] = kNoApex; b.nfhead[id] = 0;
+            b.fflags[id] = 1; b.fowner[id] = kNone; b.fmax[id] = 0ull; b.nfhead[id] = 0;
             b.newface[3 * g + k] = id;
             for (int j = 0; j < 3; ++j)
                 if (b.fn[3 * n + j] == g) b.fn[3 * n + j] = id;
@@ -1042,7 +1019,7 @@ __device__ __forceinline__ void reassign_points(const Bufs& b, FaceMaxTable& tab
             double best = 0.0; int bf = kNone;
             if (g >= 0 && (fl[u] & 4)) {
                 const int o = b.fowner[g];
-                const int ap = apex_pos(b.fapex[o]);
+                const int ap = apex_pos(b.fmax[o]);
                 const double x = b.px[i], y = b.py[i], z = b.pz[i];
                 // (every new face has the apex as a vertex and two older ones, whose copies retired when THEY went in)
                 if (i != ap && !(x == b.px[ap] && y == b.py[ap] && z == b.pz[ap])) {
@@ -1070,7 +1047,7 @@ __device__ __forceinline__ void reassign_points(const Bufs& b, FaceMaxTable& tab
                 }
                 b.pface[i] = bf;  // the apex retires as a vertex; a point outside no new face retires inside the hull
             }
-            wave_face_max(b, tab, bf, dkey(best));  // feeds the apex search of the new face
+            wave_face_max(b, tab, bf, apex_key(best, i));  // the new face's farthest point so far
         }
     }
     face_max_flush(b, tab);
@@ -1088,8 +1065,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_link_reassign(Bufs b, int par, int
 // regions' faces die and the round's ownership is cleared; the candidates that are still alive and the new faces with points
 // outside them enter the next round's candidate list as their own owners.  Also run once after the initial tetrahedra
 // (no lists yet; every face is new).  Needs a grid that is a multiple of kSubLists.
-__global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int with_far_arg, int next_round) {
-    if (with_far_arg) far_arg_points(b, b.ctrl[kCtrlNFaces], blockIdx.x, gridDim.x);
+__global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int next_round) {
     const int sl = blockIdx.x % kSubLists, cap = sub_cap(b);
     int* __restrict__ next = b.cand[par ^ 1] + (size_t)sl * cap;
     int* next_n = ccnt(b, par ^ 1, sl);
@@ -1114,7 +1090,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int wi
                 b.fowner[f1] = cand ? f1 : kNone;
                 b.fflags[f1] = alive | (cand ? 2 : 0);
                 if (from_cand) b.nfhead[f1] = 0;
-                if (cand && from_cand) b.fprio[f1] = make_prio(f1, next_round, (float)dkey_inv_pos(b.fmax[f1]) * b.frec[f1].inv_norm, b.hbits);
+                if (cand && from_cand) b.fprio[f1] = make_prio(f1, next_round, apex_dist(b.fmax[f1]) * b.frec[f1].inv_norm, b.hbits);
             }
             c1 = cand && from_cand;  // a candidate enters through its own entry, not through a claim's
         }
@@ -1124,7 +1100,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int wi
             c2 = f2 < nf && (b.fflags[f2] & 1) && b.fmax[f2] != 0ull;
             if (c2) {
                 b.fowner[f2] = f2; b.fflags[f2] = 3;
-                b.fprio[f2] = make_prio(f2, next_round, (float)dkey_inv_pos(b.fmax[f2]) * b.frec[f2].inv_norm, b.hbits);
+                b.fprio[f2] = make_prio(f2, next_round, apex_dist(b.fmax[f2]) * b.frec[f2].inv_norm, b.hbits);
             }
         }
         const int slot = block_alloc(next_n, (c1 ? 1 : 0) + (c2 ? 1 : 0));
@@ -1157,7 +1133,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int wi
 // conflict face, one at a time: the region it sees (breadth first from its conflict face: connected by construction, coplanar
 // faces elsewhere cannot join it by rounding), one new face per horizon edge, sibling links by matching the horizon's vertices,
 // the dead faces' points to the new faces.  An insertion is a dozen block barriers (2-3 us), no launch and no memory round trip.
-// The block leaves what the join (k_seg_faces, k_assign_all, k_far_arg_all, k_rebuild_candidates) expects of a sample phase:
+// The block leaves what the join (k_seg_faces, k_assign_all, k_rebuild_candidates) expects of a sample phase:
 // faces with planes and links, dead faces unflagged, the sample points' conflict faces and the faces' maxima over them.
 // Face ids: the tetrahedron's 4 sg .. 4 sg + 3, then a block of KL - 4 ids per segment behind all tetrahedra (unused ones stay
 // dead).  Any intermediate state of quickhull is a convex polytope on input points, so — like the sample rounds it replaces —
@@ -1432,7 +1408,7 @@ __global__ void __launch_bounds__(kSerialThreads) k_sample_hull(Bufs b, int KL, 
         r.next = kNone; r.inv_norm = s_inv[f]; r.pad[0] = 0; r.pad[1] = 0;
         b.frec[g] = r;
         b.fflags[g] = s_alive[f] ? 1 : 0;
-        b.fowner[g] = kNone; b.fmax[g] = 0ull; b.fapex[g] = kNoApex; b.nfhead[g] = 0;
+        b.fowner[g] = kNone; b.fmax[g] = 0ull; b.nfhead[g] = 0;
         b.newface[3 * g] = kNone; b.newface[3 * g + 1] = kNone; b.newface[3 * g + 2] = kNone;
     }
     __syncthreads();   // (the maxima below go to words this block has just zeroed)
@@ -1444,7 +1420,7 @@ __global__ void __launch_bounds__(kSerialThreads) k_sample_hull(Bufs b, int KL, 
         const int j = (int)jl;
         if (j == cpos[0] || j == cpos[1] || j == cpos[2] || j == cpos[3]) continue;
         b.pface[j] = cf[p] >= 0 ? gid(cf[p]) : kNone;
-        if (cf[p] >= 0) atomicMax(&b.fmax[gid(cf[p])], dkey(pdist(cf[p], px[p], py[p], pz[p])));
+        if (cf[p] >= 0) atomicMax(&b.fmax[gid(cf[p])], apex_key(pdist(cf[p], px[p], py[p], pz[p]), j));
     }
 }
 
@@ -1470,8 +1446,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_seg_faces(Bufs b, int* __restrict_
         const int sg = find_seg(b, b.fv[3 * f]);  // positions are grouped by segment like the expanded indices
         const int k = atomicAdd(&cnt[sg], 1);
         if (list) list[off[sg] + k] = f;
-        // every alive face gets a fresh apex search (k_far_arg_all) once the dormant points have joined its outside set
-        if (list) b.fapex[f] = kNoApex;
+        // (the dormant points that join a face's outside set raise its fmax — and with it its apex — as they come: k_assign_all)
     }
 }
 
@@ -1538,7 +1513,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign_all(Bufs b, const int* __re
         for (int k = 0; k < kAssignPts; ++k) {
             const int j = base + k * TO_BLOCK + threadIdx.x;
             if (mine[k]) b.pface[j] = bf[k];
-            wave_face_max(b, tab, mine[k] ? bf[k] : kNone, dkey(mine[k] ? best[k] : 0.0));
+            wave_face_max(b, tab, mine[k] ? bf[k] : kNone, apex_key(mine[k] ? best[k] : 0.0, j));
         }
     }
     face_max_flush(b, tab);
@@ -1557,7 +1532,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_rebuild_candidates(Bufs b, int par
         const bool alive = f < nf && (b.fflags[f] & 1);
         const bool cand = alive && b.fmax[f] != 0ull;
         if (alive) { b.fowner[f] = cand ? f : kNone; b.fflags[f] = 1 | (cand ? 2 : 0); b.nfhead[f] = 0; }
-        if (cand) b.fprio[f] = make_prio(f, next_round, (float)dkey_inv_pos(b.fmax[f]) * b.frec[f].inv_norm, b.hbits);
+        if (cand) b.fprio[f] = make_prio(f, next_round, apex_dist(b.fmax[f]) * b.frec[f].inv_norm, b.hbits);
         const int slot = block_alloc(next_n, cand ? 1 : 0);
         if (cand) {
             if (slot < cap) next[slot] = f;
@@ -1781,8 +1756,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     } else {
         if (b.sub > 1) k_live_stride<<<nblocks((b.m1 + b.sub - 1) / b.sub), TO_BLOCK, 0, st>>>(b);
         k_assign0<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b);
-        k_far_arg_all<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);
-        k_round_tail<<<kSubLists, TO_BLOCK, 0, st>>>(b, 1, 0, 0);  // round 0's candidates: the tetrahedra's faces with points outside
+        k_round_tail<<<kSubLists, TO_BLOCK, 0, st>>>(b, 1, 0);  // round 0's candidates: the tetrahedra's faces with points outside
     }
     TO_HIP_CHECK_LAUNCH();
     // One readback = the scalars and the candidate counters of both parities, into pinned memory behind an event: the host
@@ -1882,8 +1856,8 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
             if (careful || !fused_verdict) k_accept<<<gl, TO_BLOCK, 0, st>>>(b, round, par);   // (the fast path's walk has given its verdict)
             k_new_faces<<<gl, TO_BLOCK, 0, st>>>(b, par);
             k_link_reassign<<<gl + gr, TO_BLOCK, 0, st>>>(b, par, gl);
-            const int gt = std::max(gl, std::min(2048, (nblocks(live_bound) + kSubLists - 1) / kSubLists * kSubLists));
-            k_round_tail<<<gt, TO_BLOCK, 0, st>>>(b, par, 1, round + 1);
+            const int gt = gl;   // (a list walk: the apexes of the new faces come with their maxima since r06, no pass over the live points)
+            k_round_tail<<<gt, TO_BLOCK, 0, st>>>(b, par, round + 1);
             TO_HIP_CHECK_LAUNCH();
         }
         return TOHIP_OK;
@@ -1924,7 +1898,6 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         k_live_write<<<ntl, TO_BLOCK, 0, st>>>(b, b.m1, b.tile_off);
         TO_HIP_CHECK_LAUNCH();
         int* t = b.live; b.live = b.live2; b.live2 = t;
-        k_far_arg_all<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b);  // apexes over the whole outside sets (k_seg_faces cleared them)
         const int par = round & 1;
         ej = hipMemsetAsync(b.ctrl + kCtrlInts + par * kSubLists * kCntStride, 0, sizeof(int) * kSubLists * kCntStride, st);
         if (ej != hipSuccess) return (int)ej;
