@@ -264,6 +264,36 @@ def test_sample_hull_by_sequential_insertion_on_many_shapes(dev, kind):
     assert np.array_equal(idx[voff[1]:voff[2]] - offs[1], oracle.hidden_pts_removal(small)[0])
 
 
+def test_a_build_that_runs_out_of_faces_is_retried_cleanly(dev):
+    """A cloud most of whose points are visible needs more faces than the recommended workspace holds: the build returns TOHIP_ENOSPC
+    and ops retries with 4x the bytes.  The host only learns of the overflow from its next readback — up to two batches of rounds are
+    enqueued behind the failing one; they must not walk the half-built round (r06: a memory fault found by tools/stress_hpr_repeat.py,
+    on exactly this path, when the workspace held another build's bytes).  Three builds into poisoned memory: no fault, Qhull's set."""
+    from oracle import oracle
+    from trajectory_optimization_amd import _lib, ops
+    from trajectory_optimization_amd._lib import ptr, stream_ptr
+    rng = np.random.default_rng(17)
+    u = rng.normal(size=(120_000, 3))   # a noisy shell around the viewpoint: more than half of its points are visible
+    pts = (u / np.linalg.norm(u, axis=1, keepdims=True) * 12.0 * (1 + 0.01 * rng.normal(size=(120_000, 1)))).astype(np.float32)
+    ref = oracle.hidden_pts_removal(pts)[0]
+    assert len(ref) > 50_000   # ~6 faces are created per vertex: more than the 262 144 the recommended workspace of a small cloud holds
+    P = torch.from_numpy(pts).to(dev)
+    L = _lib.lib()
+    n = len(pts)
+    wsb = L.tohip_hpr_workspace_bytes(n)
+    idx, cnt, mask = torch.empty(n, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), torch.empty(n, device=dev)
+    for fill in (0xFF, 0x01, 0x7F):
+        ws = torch.full((wsb,), fill, dtype=torch.uint8, device=dev)
+        rc = L.tohip_hidden_pts_removal(ptr(P), n, 2.0, ptr(idx), ptr(cnt), ptr(mask), ptr(ws), wsb, stream_ptr())
+        torch.cuda.synchronize()
+        assert rc == _lib.ENOSPC, rc          # the recommended size is too small for this cloud ...
+        del ws
+        poison = torch.full((4 * wsb,), fill, dtype=torch.uint8, device=dev)   # ... and the retry's 4x block comes back full of this
+        del poison
+        got = ops.hidden_pts_removal(P)[0].cpu().numpy().astype(np.int64)
+        assert np.array_equal(got, ref)
+
+
 def test_sample_rounds_and_sequential_insertion_agree_in_a_child_process():
     """TOHIP_HULL_SERIAL=0 (the sample's rounds of r05) gives the same index sets as the default: the sample phase is a schedule, not a result."""
     import os, subprocess, sys

@@ -39,9 +39,10 @@ for s, pts in enumerate(segs):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     got = ops.hidden_pts_removal(P)[0]
     torch.cuda.synchronize(); dt = 1e3 * (time.perf_counter() - t0)
-    ok = np.array_equal(got.cpu().numpy().astype(np.int64), ref)
+    g = got.cpu().numpy().astype(np.int64)
+    ok = np.array_equal(g, ref)
     bad += not ok
-    print(f"{kinds[s]:8s} n={len(pts):7d} visible={len(ref):7d} {dt:7.2f} ms {'ok' if ok else 'MISMATCH'}")
+    print(f"{kinds[s]:8s} n={len(pts):7d} visible={len(ref):7d} {dt:7.2f} ms {'ok' if ok else 'MISMATCH: got %d, missing %d, extra %d' % (len(g), len(np.setdiff1d(ref, g)), len(np.setdiff1d(g, ref)))}")
 offs = np.concatenate([[0], np.cumsum([len(s) for s in segs])])
 allp = torch.from_numpy(np.concatenate(segs)).to(dev)
 ops.hidden_pts_removal_batched(allp, offs)
@@ -50,6 +51,7 @@ idx, voff, mask, status = ops.hidden_pts_removal_batched(allp, offs)
 torch.cuda.synchronize(); dt = 1e3 * (time.perf_counter() - t0)
 idx = idx.cpu().numpy().astype(np.int64)
 for s in range(B):
-    if not np.array_equal(idx[voff[s]:voff[s + 1]] - offs[s], refs[s]):
-        bad += 1; print("batched MISMATCH", s, kinds[s])
+    gb = idx[voff[s]:voff[s + 1]] - offs[s]
+    if not np.array_equal(gb, refs[s]):
+        bad += 1; print("batched MISMATCH", s, kinds[s], len(segs[s]), "got", len(gb), "ref", len(refs[s]), "missing", len(np.setdiff1d(refs[s], gb)), "extra", len(np.setdiff1d(gb, refs[s])), "status", int(status[s]))
 print(f"batched: {B} clouds, {offs[-1]} points: {dt:.2f} ms; failures: {bad}")

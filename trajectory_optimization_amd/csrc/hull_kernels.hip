@@ -54,7 +54,7 @@ struct __attribute__((aligned(64))) FaceRec {
     double nx, ny, nz, x0, y0, z0;
     int next;
     float inv_norm;        // 1 / |n|: heights (distance in length units) rank the candidates
-    int pad[2];
+    int pad[2];            // [0]: head of the overflow chain of region_tab (an accepted candidate's region of more than ten faces)
 };
 
 struct Bufs {
@@ -108,6 +108,7 @@ struct Bufs {
     int early_out;         // k_owner_claim: candidates beaten by a neighbouring candidate do not walk
     int origin;            // 1: the last slot of a segment is the appended origin; 0: it repeats the segment's first point and never takes part
     int sub;               // > 1 while only every sub-th point (in Morton order) takes part: the first rounds of a large build
+    int key32;             // 1: segment number + Morton cell fit 32-bit sort keys
     int serial;            // 1: the sample's hull is built by k_sample_hull (a block per segment, sequential insertion out of LDS);
                            //    the sample is then every sample_stride()-th position of a segment, counted from its first
 };
@@ -184,12 +185,12 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     (void)sort_pairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const int*)nullptr, (int*)nullptr, (int)m1, 0, 64,
                      (hipStream_t)0);
     {
-        size_t tmp32 = 0;   // a single segment sorts 30-bit keys as 32-bit words
-        (void)sort_pairs(nullptr, tmp32, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (int)m1, 0, 30, (hipStream_t)0);
+        size_t tmp32 = 0;   // up to 256 segments sort 32-bit keys
+        (void)sort_pairs(nullptr, tmp32, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (int)m1, 0, 32, (hipStream_t)0);
         if (tmp32 > tmp) tmp = tmp32;
     }
     p = take(tmp); if (b) { b->sort_tmp = p; b->sort_tmp_bytes = tmp; }
-    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; b->origin = 1; b->hbits = 0; b->early_out = 0; b->serial = 0; }
+    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; b->origin = 1; b->hbits = 0; b->early_out = 0; b->serial = 0; b->key32 = 1; }
     return o;
 }
 
@@ -254,6 +255,7 @@ __device__ __forceinline__ void set_plane(const Bufs& b, int f) {
     r.nz = ux * vy - uy * vx;
     r.x0 = ax; r.y0 = ay; r.z0 = az;
     r.next = kNone;
+    r.pad[0] = kNone;      // (region_tab's overflow head: only ever written once, when the face is an accepted candidate)
     r.inv_norm = (float)(1.0 / sqrt(r.nx * r.nx + r.ny * r.ny + r.nz * r.nz));
 }
 
@@ -442,32 +444,88 @@ __global__ void __launch_bounds__(TO_BLOCK) k_bbox(Bufs b, const float* __restri
     flush();
 }
 
-__device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every third bit
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
+// ONE segment (r06): the walk above keeps a wave on one long run so that a segment's six words see few atomics — 512 waves on a
+// million points, 59 us.  With a single segment every block can reduce its points in LDS and send six atomics to copy
+// (block & 63) of the box — 64 copies on lines of their own in `copies` (the sort's output buffer, free until the sort) — and one
+// small block folds them: 8 us.  (The pack's k_bbox does the same with its own key function.)
+__global__ void __launch_bounds__(TO_BLOCK) k_bbox1_init(unsigned* __restrict__ copies) {
+    for (int i = threadIdx.x; i < 64 * 32; i += TO_BLOCK) copies[i] = (i & 31) < 3 ? 0xffffffffu : 0u;   // [copy * 32 + k]: min x,y,z | max x,y,z
+}
+__global__ void __launch_bounds__(TO_BLOCK) k_bbox1(Bufs b, const float* __restrict__ pts, int with_origin, unsigned* __restrict__ copies) {
+    __shared__ unsigned slo[3][TO_WAVES_PER_BLOCK], shi[3][TO_WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+    bool nan = false;
+    for (int e = blockIdx.x * TO_BLOCK + threadIdx.x; e < b.m1; e += gridDim.x * TO_BLOCK) {
+        float c[3];
+        source_point(b, pts, with_origin, e, 0, &c[0], &c[1], &c[2]);
+        for (int k = 0; k < 3; ++k) {
+            if (c[k] == c[k]) { const unsigned key = fkey(c[k]); lo[k] = min(lo[k], key); hi[k] = max(hi[k], key); }
+            else nan = true;   // NaN coordinates take no part in the box and void the segment (scipy: "Points cannot contain NaN")
+        }
+    }
+    for (int k = 0; k < 3; ++k)
+        for (int s = 32; s > 0; s >>= 1) {
+            lo[k] = min(lo[k], (unsigned)__shfl_xor((int)lo[k], s));
+            hi[k] = max(hi[k], (unsigned)__shfl_xor((int)hi[k], s));
+        }
+    if (__any(nan) && lane == 0) b.seg_nan[0] = 1;
+    if (lane == 0) for (int k = 0; k < 3; ++k) { slo[k][wave] = lo[k]; shi[k][wave] = hi[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x % 3;
+        unsigned v = threadIdx.x < 3 ? slo[k][0] : shi[k][0];
+        for (int w = 1; w < TO_WAVES_PER_BLOCK; ++w) v = threadIdx.x < 3 ? min(v, slo[k][w]) : max(v, shi[k][w]);
+        unsigned* dst = copies + (blockIdx.x & 63) * 32 + threadIdx.x;
+        if (threadIdx.x < 3) atomicMin(dst, v); else atomicMax(dst, v);
+    }
+}
+__global__ void __launch_bounds__(64) k_bbox1_fold(Bufs b, const unsigned* __restrict__ copies) {
+    const int lane = threadIdx.x;
+    for (int k = 0; k < 6; ++k) {
+        unsigned v = copies[lane * 32 + k];
+        for (int s = 32; s > 0; s >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)v, s);
+            v = k < 3 ? min(v, o) : max(v, o);
+        }
+        if (lane == 0) b.seg_bbox[k] = v;
+    }
 }
 
-// sort key: segment in the high bits (segments stay where they are), 30-bit Morton code of the position in the
-// segment's bounding box below; the value is the expanded index
+__device__ __forceinline__ unsigned spread8(unsigned v) {  // 8 bits -> every third bit
+    v &= 0xffu;
+    v = (v | (v << 8)) & 0x0000f00fu;
+    v = (v | (v << 4)) & 0x000c30c3u;
+    v = (v | (v << 2)) & 0x00249249u;
+    return v;
+}
+// The Morton cell of a point inside its segment's bounding box: 8 bits per axis (r06; 10 until r05 — cells of 1/256 of the box keep a
+// wave's lanes on neighbouring points just as well, and 24 bits are three radix passes where 30 were four; with the segment number above
+// them the keys of up to 256 segments are 32-bit words, four passes where the 64-bit keys took five).  ONE function for the sort key
+// and for lowest_identical_row's walk over "equal cells": the two must agree (r05 found out with 208 ms builds).
+constexpr int kMortonBits = 24;
+__device__ __forceinline__ unsigned morton_of(const Bufs& b, int sg, float x, float y, float z) {
+    const float c[3] = {x, y, z};
+    unsigned q[3];
+    for (int k = 0; k < 3; ++k) {
+        const float lo = fkey_inv(b.seg_bbox[6 * sg + k]), hi = fkey_inv(b.seg_bbox[6 * sg + 3 + k]);
+        const float t = (c[k] - lo) / (hi - lo) * 255.0f;  // NaN / empty extent -> 0 below
+        q[k] = t >= 0.0f ? (t < 255.0f ? (unsigned)t : 255u) : 0u;
+    }
+    return spread8(q[0]) | (spread8(q[1]) << 1) | (spread8(q[2]) << 2);
+}
+
+// sort key: segment in the high bits (segments stay where they are), the Morton cell of the position in the segment's bounding box
+// below; the value is the expanded index.  32-bit keys while segment number and cell fit (b.key32), 64-bit ones beyond 256 segments
 __global__ void __launch_bounds__(TO_BLOCK) k_sort_keys(Bufs b, const float* __restrict__ pts, int with_origin) {
     const int stride = gridDim.x * TO_BLOCK;
     for (int e = blockIdx.x * TO_BLOCK + threadIdx.x; e < b.m1; e += stride) {
         const int sg = find_seg(b, e);
         float c[3];
         source_point(b, pts, with_origin, e, sg, &c[0], &c[1], &c[2]);
-        unsigned q[3];
-        for (int k = 0; k < 3; ++k) {
-            const float lo = fkey_inv(b.seg_bbox[6 * sg + k]), hi = fkey_inv(b.seg_bbox[6 * sg + 3 + k]);
-            const float t = (c[k] - lo) / (hi - lo) * 1023.0f;  // NaN / empty extent -> 0 below
-            q[k] = t >= 0.0f ? (t < 1023.0f ? (unsigned)t : 1023u) : 0u;
-        }
-        const unsigned m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
-        if (b.nseg == 1) reinterpret_cast<unsigned*>(b.keys)[e] = m;   // one hull: 32-bit keys sort in half the time
-        else b.keys[e] = ((unsigned long long)(unsigned)sg << 30) | m;
+        const unsigned m = morton_of(b, sg, c[0], c[1], c[2]);
+        if (b.key32) reinterpret_cast<unsigned*>(b.keys)[e] = ((unsigned)sg << kMortonBits) | m;   // 32-bit keys sort in half the time
+        else b.keys[e] = ((unsigned long long)(unsigned)sg << kMortonBits) | m;
         b.vals[e] = e;
     }
 }
@@ -505,7 +563,7 @@ __device__ void init_tetrahedron(const Bufs& b, int sg, bool enough, bool has_na
             // no hull for this segment: its four face slots stay dead (never candidates, never neighbours of a live face)
             for (int f = fb; f < fb + 4; ++f) {
                 for (int k = 0; k < 3; ++k) { b.fv[3 * f + k] = lo; b.fn[3 * f + k] = f; }
-                b.frec[f] = FaceRec{0.0, 0.0, 0.0, b.px[lo], b.py[lo], b.pz[lo], kNone, 0.f, {0, 0}};
+                b.frec[f] = FaceRec{0.0, 0.0, 0.0, b.px[lo], b.py[lo], b.pz[lo], kNone, 0.f, {kNone, 0}};
                 b.fflags[f] = 0; b.fowner[f] = kNone; b.fmax[f] = 0ull; b.nfhead[f] = 0;
                 b.newface[3 * f] = kNone;
             }
@@ -733,6 +791,7 @@ constexpr int kClaimFront = 128, kClaimMax = 4096, kClaimLog = 192;
 // (fflags bit 1) of the candidates nobody failed.  Block 0 does k_accept's housekeeping.
 __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int par, int verdict) {
     __shared__ int fr[TO_WAVES_PER_BLOCK][2][kClaimFront];
+    if (b.ctrl[kCtrlError] != 0) return;   // (see round_dead)
     if (verdict && blockIdx.x == 0) {
         // nothing has been inserted yet this round: the staged count is the face count; it is published here for the
         // kernels that run while k_new_faces raises the staged one.  The next round's lists start empty.
@@ -811,6 +870,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
                     n = b.fn[3 * cg + t % 3];
                     int co = __hip_atomic_load(&b.fowner[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const bool sees = plane_dist(b.frec[n], px, py, pz) > 0.0;  // loaded alongside the owner, not after it
+                    if (co >= b.fcap) co = kNone;   // (never: an owner is a face id)
                     if (sees && !(co == o || (co >= 0 && b.fprio[co] <= po))) {
                         while (true) {
                             const int old = atomicCAS(&b.fowner[n], co, o);
@@ -888,6 +948,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owned_list(Bufs b, int par) {
 }
 
 __global__ void __launch_bounds__(TO_BLOCK) k_accept(Bufs b, int round, int par) {
+    if (b.ctrl[kCtrlError] != 0) return;   // (see round_dead)
     if (blockIdx.x == 0) {
         // nothing has been inserted yet this round: the staged count is the face count; it is published here for the
         // kernels that run while k_new_faces raises the staged one.  The next round's lists start empty.
@@ -927,7 +988,12 @@ __device__ __forceinline__ bool owned_accepted(const Bufs& b, int g, int* owner)
 // then taken by a better candidate): the entry that counts is the one made by the candidate that owns the face now — exactly one
 // (a candidate claims a face at most once), decided without an atomic whose answer the thread would have to wait for.
 __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
-    if (b.ctrl[kCtrlOverflow] != 0) return;   // a claimed face is missing from the lists: nobody is inserted this round (the build ends: capacity)
+    // An error (face capacity, a claimed-face list that ran full, inconsistent topology) ends the build — but the host only learns of
+    // it from its next readback, up to two batches of rounds later, and a round cut short by the capacity leaves horizon edges without
+    // faces, links unset and `newface` words stale: walking that structure reads owners out of records nobody wrote (r06: a memory
+    // fault in tools/stress_hpr_repeat.py, on the build that runs out of faces and is retried).  So every round kernel leaves at
+    // once when the error word is set: the rounds behind the failing one do nothing (round_dead).
+    if (b.ctrl[kCtrlError] != 0 || b.ctrl[kCtrlOverflow] != 0) return;
     const ListWalk w = list_walk(b, par, blockIdx.x, gridDim.x);
     for (int it = 0; it < w.loops; ++it) {
         int claimer = kNone;
@@ -964,7 +1030,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
             // walking a linked list, one dependent load per face (13 -> 8 us per round at 1 M points, r06); a region of more than
             // ten faces chains the rest through the records' `next` as before
             if (slot < kRegionTab) region_tab(b, o)[slot] = id;
-            else { const int prev = atomicExch(&b.frec[o].next, id); b.frec[id].next = prev; }
+            else { const int prev = atomicExch(&b.frec[o].pad[0], id); b.frec[id].next = prev; }   // (NOT o's own `next`: that is o's link in the list it was born into)
             ++id;
         }
     }
@@ -1038,7 +1104,7 @@ __device__ __forceinline__ void reassign_points(const Bufs& b, FaceMaxTable& tab
                         if (d > best) { best = d; bf = ids[k]; }
                     }
                     int steps = 0;
-                    for (int f = cnt > kRegionTab ? b.frec[o].next : kNone; f >= 0 && steps < (1 << 20); ++steps) {
+                    for (int f = cnt > kRegionTab ? b.frec[o].pad[0] : kNone; f >= 0 && steps < (1 << 20); ++steps) {
                         const FaceRec r = b.frec[f];  // one line per step of the list: plane, anchor and link
                         const double d = plane_dist(r, x, y, z);
                         if (d > best) { best = d; bf = f; }
@@ -1057,6 +1123,7 @@ __device__ __forceinline__ void reassign_points(const Bufs& b, FaceMaxTable& tab
 // nothing of each other: one launch, the first `link_blocks` blocks link, the others move points
 __global__ void __launch_bounds__(TO_BLOCK) k_link_reassign(Bufs b, int par, int link_blocks) {
     __shared__ FaceMaxTable tab;
+    if (b.ctrl[kCtrlError] != 0) return;   // (k_new_faces ran out of faces in THIS round, or an earlier round failed: round_dead)
     if ((int)blockIdx.x < link_blocks) link_faces(b, par, blockIdx.x, link_blocks);
     else reassign_points(b, tab, blockIdx.x - link_blocks, gridDim.x - link_blocks);
 }
@@ -1066,6 +1133,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_link_reassign(Bufs b, int par, int
 // outside them enter the next round's candidate list as their own owners.  Also run once after the initial tetrahedra
 // (no lists yet; every face is new).  Needs a grid that is a multiple of kSubLists.
 __global__ void __launch_bounds__(TO_BLOCK) k_round_tail(Bufs b, int par, int next_round) {
+    if (b.ctrl[kCtrlError] != 0) return;   // (round_dead)
     const int sl = blockIdx.x % kSubLists, cap = sub_cap(b);
     int* __restrict__ next = b.cand[par ^ 1] + (size_t)sl * cap;
     int* next_n = ccnt(b, par ^ 1, sl);
@@ -1405,7 +1473,7 @@ __global__ void __launch_bounds__(kSerialThreads) k_sample_hull(Bufs b, int KL, 
         for (int k = 0; k < 3; ++k) { b.fv[3 * g + k] = s_vpos[s_fv[k * KL + f]]; b.fn[3 * g + k] = gid(s_fn[k * KL + f]); }
         FaceRec r;
         r.nx = s_nx[f]; r.ny = s_ny[f]; r.nz = s_nz[f]; r.x0 = s_x0[f]; r.y0 = s_y0[f]; r.z0 = s_z0[f];
-        r.next = kNone; r.inv_norm = s_inv[f]; r.pad[0] = 0; r.pad[1] = 0;
+        r.next = kNone; r.inv_norm = s_inv[f]; r.pad[0] = kNone; r.pad[1] = 0;
         b.frec[g] = r;
         b.fflags[g] = s_alive[f] ? 1 : 0;
         b.fowner[g] = kNone; b.fmax[g] = 0ull; b.nfhead[g] = 0;
@@ -1541,16 +1609,9 @@ __global__ void __launch_bounds__(TO_BLOCK) k_rebuild_candidates(Bufs b, int par
     }
 }
 
-// the 30-bit Morton cell of sorted position j — what k_sort_keys computed for it (same operations on the same floats)
+// the Morton cell of sorted position j — what k_sort_keys computed for it (same operations on the same floats)
 __device__ __forceinline__ unsigned morton_cell(const Bufs& b, int j, int sg) {
-    const float c[3] = {(float)b.px[j], (float)b.py[j], (float)b.pz[j]};
-    unsigned q[3];
-    for (int k = 0; k < 3; ++k) {
-        const float lo = fkey_inv(b.seg_bbox[6 * sg + k]), hi = fkey_inv(b.seg_bbox[6 * sg + 3 + k]);
-        const float t = (c[k] - lo) / (hi - lo) * 1023.0f;
-        q[k] = t >= 0.0f ? (t < 1023.0f ? (unsigned)t : 1023u) : 0u;
-    }
-    return spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    return morton_of(b, sg, (float)b.px[j], (float)b.py[j], (float)b.pz[j]);
 }
 
 // Which of several IDENTICAL rows carries a hull vertex is the build's business (copies of a vertex are treated as lying on the
@@ -1691,18 +1752,26 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     if (e != hipSuccess) return (int)e;
     k_bbox_init<<<(6 * b.nseg + TO_BLOCK - 1) / TO_BLOCK, TO_BLOCK, 0, st>>>(b);
     // six same-address atomics per wave and segment: 4096 waves on ONE segment's box cost 0.27 ms, 512 cost 0.03
-    k_bbox<<<nblocks(b.m1, b.nseg == 1 ? 128 : 1024), TO_BLOCK, 0, st>>>(b, pts, with_origin);
+    if (b.nseg == 1 && b.m1 >= 65536) {
+        unsigned* copies = reinterpret_cast<unsigned*>(b.keys2);
+        k_bbox1_init<<<1, TO_BLOCK, 0, st>>>(copies);
+        k_bbox1<<<nblocks(b.m1, 1024), TO_BLOCK, 0, st>>>(b, pts, with_origin, copies);
+        k_bbox1_fold<<<1, 64, 0, st>>>(b, copies);
+    } else {
+        k_bbox<<<nblocks(b.m1, b.nseg == 1 ? 128 : 1024), TO_BLOCK, 0, st>>>(b, pts, with_origin);
+    }
+    int seg_bits = 0;
+    while ((1 << seg_bits) < b.nseg) ++seg_bits;
+    b.key32 = kMortonBits + seg_bits <= 32 ? 1 : 0;
     k_sort_keys<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, pts, with_origin);
     TO_HIP_CHECK_LAUNCH();
     {
-        int seg_bits = 0;
-        while ((1 << seg_bits) < b.nseg) ++seg_bits;
         size_t tmp = b.sort_tmp_bytes;
         // stable: equal cells keep the caller's order
-        const hipError_t es = b.nseg == 1
+        const hipError_t es = b.key32
             ? sort_pairs(b.sort_tmp, tmp, reinterpret_cast<const unsigned*>(b.keys), reinterpret_cast<unsigned*>(b.keys2),
-                                                 b.vals, b.perm, b.m1, 0, 30, st)
-            : sort_pairs(b.sort_tmp, tmp, b.keys, b.keys2, b.vals, b.perm, b.m1, 0, 30 + seg_bits, st);
+                                                 b.vals, b.perm, b.m1, 0, kMortonBits + seg_bits, st)
+            : sort_pairs(b.sort_tmp, tmp, b.keys, b.keys2, b.vals, b.perm, b.m1, 0, kMortonBits + seg_bits, st);
         if (es != hipSuccess) return (int)es;
     }
     k_load<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, pts, with_origin);
