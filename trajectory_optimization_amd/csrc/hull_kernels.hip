@@ -542,6 +542,7 @@ k_load(Bufs b, const float* __restrict__ pts, int with_origin) {
         b.inv[e] = j;
         b.pface[j] = kNone;
         b.vflag[j] = 0;
+        b.vals[j] = 0;        // (the sort's input values are free now: k_mark_vertices' "this vertex has been looked up" marks)
         b.live[j] = j;
     }
     // the control block was zero-filled by the host; no face is published before the first round's k_accept
@@ -1458,7 +1459,7 @@ __global__ void __launch_bounds__(kSerialThreads) k_sample_hull(Bufs b, int KL, 
     }
 #ifdef TOHIP_SH_STAMPS
     if (sg == 0 && lane == 0) {   // per wave: [phase 1 | barrier 1 wait | topology (or nothing) | barrier 2 wait | phase 3], insertions, wall ticks
-        unsigned long long* o = b.keys2 + 16 * wid;
+        unsigned long long* o = b.keys + 16 * wid;
         for (int i = 0; i < 5; ++i) o[i] = st_acc[i];
         o[5] = (unsigned long long)nv - 4; o[6] = wall_clock64() - st_w0; o[7] = (unsigned long long)nf;
     }
@@ -1609,26 +1610,22 @@ __global__ void __launch_bounds__(TO_BLOCK) k_rebuild_candidates(Bufs b, int par
     }
 }
 
-// the Morton cell of sorted position j — what k_sort_keys computed for it (same operations on the same floats)
-__device__ __forceinline__ unsigned morton_cell(const Bufs& b, int j, int sg) {
-    return morton_of(b, sg, (float)b.px[j], (float)b.py[j], (float)b.pz[j]);
-}
-
 // Which of several IDENTICAL rows carries a hull vertex is the build's business (copies of a vertex are treated as lying on the
 // hull), and it depends on the schedule (a large build's sample may meet a later copy first).  Reported is always the row with
-// the LOWEST original index: identical rows share a Morton cell, the sort is stable, so inside the run of equal cells around the
-// vertex the first row with its coordinates is that one.  (Qhull's own choice among identical rows follows its insertion history
-// — the first copy in ~70 % of the cases, the last in the others — and cannot be reproduced by a parallel build.)
+// the LOWEST original index: identical rows share a sort key (segment, Morton cell), the sort is stable, so inside the run of
+// equal keys around the vertex the first row with its coordinates is that one.  The sorted keys are still in keys2 (r06: until then
+// the walk recomputed every row's cell from its coordinates — 13 us per build with 30-bit cells, 78 with the 24-bit ones).  (Qhull's
+// own choice among identical rows follows its insertion history — the first copy in ~70 % of the cases, the last in the others —
+// and cannot be reproduced by a parallel build.)
+__device__ __forceinline__ unsigned long long sorted_key(const Bufs& b, int j) {
+    return b.key32 ? (unsigned long long)reinterpret_cast<const unsigned*>(b.keys2)[j] : b.keys2[j];
+}
 __device__ __forceinline__ int lowest_identical_row(const Bufs& b, int j) {
-    const int e = b.perm[j];
-    const int sg = find_seg(b, e);
-    const int lo = b.seg_off[sg], hi = b.seg_off[sg + 1];
-    const unsigned cell = morton_cell(b, j, sg);
+    const unsigned long long key = sorted_key(b, j);
     const double x = b.px[j], y = b.py[j], z = b.pz[j];
     int first = j;
-    for (int i = j - 1; i >= lo && morton_cell(b, i, sg) == cell; --i)
+    for (int i = j - 1; i >= 0 && sorted_key(b, i) == key; --i)
         if (b.px[i] == x && b.py[i] == y && b.pz[i] == z) first = i;
-    (void)hi;
     return first;
 }
 
@@ -1637,7 +1634,11 @@ __global__ void __launch_bounds__(TO_BLOCK) k_mark_vertices(Bufs b) {
     const int stride = gridDim.x * TO_BLOCK;
     for (int f = blockIdx.x * TO_BLOCK + threadIdx.x; f < nf; f += stride)
         if (b.fflags[f] & 1)
-            for (int k = 0; k < 3; ++k) b.vflag[b.perm[lowest_identical_row(b, b.fv[3 * f + k])]] = 1;  // flags in the caller's (expanded) numbering
+            for (int k = 0; k < 3; ++k) {
+                const int v = b.fv[3 * f + k];
+                // a vertex belongs to ~6 faces: the first of them looks its row up (a walk over the run of equal sort keys)
+                if (atomicExch(&b.vals[v], 1) == 0) b.vflag[b.perm[lowest_identical_row(b, v)]] = 1;  // flags in the caller's (expanded) numbering
+            }
 }
 
 // ---- compaction of the live-point list (ordered: the Morton locality stays) -----------------------
@@ -1777,8 +1778,9 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     k_load<<<nblocks(b.m1), TO_BLOCK, 0, st>>>(b, pts, with_origin);
     TO_HIP_CHECK_LAUNCH();
     if (b.nseg == 1 && b.m1 >= 65536) {
-        // keys2 (8 bytes per point) is free again after the sort: the passes' partials and the selections live there
-        double* pkey = (double*)b.keys2;
+        // the UNSORTED keys (8 bytes per point) are free after the sort: the passes' partials and the selections live there
+        // (keys2 keeps the sorted keys: k_mark_vertices compares them)
+        double* pkey = (double*)b.keys;
         int* pidx = (int*)(pkey + 4 * kInitBlocks);
         InitSel* sel = (InitSel*)(pidx + 4 * kInitBlocks);
         for (int pass = 0; pass < 4; ++pass) k_init1_pass<<<kInitBlocks, HULL_INIT_THREADS, 0, st>>>(b, pass, pkey, pidx, sel);
@@ -1816,7 +1818,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         {
             unsigned long long hst[16 * 8];
             (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(hst, b.keys2, sizeof(hst), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hst, b.keys, sizeof(hst), hipMemcpyDeviceToHost);
             for (int w = 0; w < 8; ++w)
                 fprintf(stderr, "sample hull wave %d: phase1 %llu  wait1 %llu  topology %llu  wait2 %llu  phase3 %llu clocks; %llu insertions, %llu faces, %.1f us wall\n", w,
                         hst[16 * w], hst[16 * w + 1], hst[16 * w + 2], hst[16 * w + 3], hst[16 * w + 4], hst[16 * w + 5], hst[16 * w + 7], hst[16 * w + 6] * 0.01);
