@@ -909,6 +909,143 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
     flush();
 }
 
+// The same walk for rounds with TENS OF THOUSANDS of candidates (a batch of views: up to 150 k per round), four or eight candidates
+// to a wave (r06; eight is the default).  There a wave's walk is a chain of dependent accesses (neighbour -> owner and plane -> CAS, ~4.5 us per candidate) on
+// the 10-20 lanes its region's edges fill, every wave of the chip holds one, and the launch is as long as the 18 candidates a wave
+// walks one after the other (80 us per round for 128 views).  Regions are small in such rounds, so each QUARTER (or eighth) of a wave
+// takes a candidate of its own: sixteen (eight) (face, edge) pairs per step, a frontier of at most 32 faces per level — a walk that outgrows it is
+// incomplete: the candidate fails itself and comes back in a later round — four chains in flight per wave.  The four walks are
+// independent but move in lock-step through one instruction stream: every ballot is the whole wave's, a quarter reads its bits of
+// it.  Same claims, same log, same verdict rule as k_owner_claim (verdict = 1 always: this kernel is the fast path's).
+constexpr int kSubFront = 32;
+template <int SL>   // lanes per candidate: 16 (four to a wave) or 8 (eight)
+__global__ void __launch_bounds__(TO_BLOCK) k_owner_claim_sub(Bufs b, int round, int par) {
+    constexpr int NG = 64 / SL;
+    __shared__ int fr[TO_WAVES_PER_BLOCK][NG][2][kSubFront];
+    __shared__ int lg[TO_WAVES_PER_BLOCK][kClaimLog];
+    __shared__ int lgc[TO_WAVES_PER_BLOCK][kClaimLog];
+    if (b.ctrl[kCtrlError] != 0) return;   // (see round_dead)
+    if (blockIdx.x == 0) {   // k_accept's housekeeping (see k_owner_claim)
+        if (threadIdx.x == 0) { b.ctrl[kCtrlNFaces] = min(b.ctrl[kCtrlNFaces + 8], b.fcap); b.ctrl[kCtrlAccepted] = 0; }
+        if (threadIdx.x < kSubLists) { *ccnt(b, par ^ 1, threadIdx.x) = 0; *ocnt(b, par ^ 1, threadIdx.x) = 0; }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, grp = lane / SL, gl = lane % SL;
+    const unsigned long long gm = ((1ull << SL) - 1ull) << (SL * grp), below = (1ull << lane) - 1ull;
+    const int sl = blockIdx.x % kSubLists, cap = sub_cap(b);
+    const int* __restrict__ cand = b.cand[par] + (size_t)sl * cap;
+    int* __restrict__ own = b.olist + (size_t)sl * cap;
+    int* __restrict__ ownc = b.oclaim + (size_t)sl * cap;
+    int* own_n = ocnt(b, par, sl);
+    const int ncand = min(*ccnt(b, par, sl), cap);
+    const int cstep = (gridDim.x / kSubLists) * TO_WAVES_PER_BLOCK * NG;
+    int c = ((blockIdx.x / kSubLists) * TO_WAVES_PER_BLOCK + wid) * NG + grp;   // this quarter's next candidate
+    int logn = 0;
+    auto flush = [&]() {  // wave-uniform
+        if (logn == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(own_n, logn);
+        base = __shfl(base, 0);
+        for (int i = lane; i < logn; i += 64) {
+            if (base + i < cap) { own[base + i] = lg[wid][i]; ownc[base + i] = lgc[wid][i]; }
+            else { b.ctrl[kCtrlOverflow] = 1; b.ctrl[kCtrlError] |= kErrCapacity; }
+        }
+        logn = 0;
+    };
+    // a quarter's walk (the same values in its sixteen lanes)
+    bool active = false, failed = false;
+    int o = kNone, cur = 0, ncur = 0, nnext = 0, claimed = 0, base = 0;
+    unsigned long long po = 0ull;
+    double px = 0.0, py = 0.0, pz = 0.0;
+    while (true) {
+        // ---- quarters without a walk take their next candidate (one try per turn)
+        const bool fetch = !active && c < ncand;
+        if (!__any(active || fetch)) break;
+        {
+            int oc = kNone;
+            unsigned long long ax = 0ull;
+            bool ok = false, doomed = false;
+            if (fetch) {
+                oc = cand[c];
+                ax = b.fmax[oc];
+                const int n0 = (b.early_out && gl < 3) ? b.fn[3 * oc + gl] : kNone;
+                if (ax == 0ull) {   // (never seen: a candidate without a point outside its face)
+                    if (gl == 0) { b.fowner[oc] = kNone; atomicAnd(&b.fflags[oc], ~2); }
+                } else if (__hip_atomic_load(&b.fowner[oc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == oc) {
+                    ok = true;
+                    po = b.fprio[oc];
+                    const int apex = apex_pos(ax);
+                    px = b.px[apex]; py = b.py[apex]; pz = b.pz[apex];
+                    if (n0 >= 0 && (b.fflags[n0] & 3) == 3 && b.fprio[n0] < po) {   // a better candidate next door whose apex sees this face
+                        const unsigned long long an = b.fmax[n0];
+                        if (an != 0ull) {
+                            const int pa = apex_pos(an);
+                            doomed = plane_dist(b.frec[oc], b.px[pa], b.py[pa], b.pz[pa]) > 0.0;
+                        }
+                    }
+                }
+                c += cstep;
+            }
+            const bool gd = (__ballot(doomed) & gm) != 0ull;   // (the whole wave's ballot; this quarter's bits)
+            if (fetch && ok) {
+                if (gd) { if (gl == 0) atomicAnd(&b.fflags[oc], ~2); }
+                else {
+                    o = oc; active = true; failed = false; cur = 0; ncur = 1; nnext = 0; claimed = 0; base = 0;
+                    if (gl == 0) fr[wid][grp][0][0] = o;
+                }
+            }
+        }
+        // ---- one step of every walking quarter: sixteen (face, edge) pairs of its current level
+        const int t = base + gl;
+        bool mine = false, fail_me = false;
+        int n = kNone, fail_other = kNone;
+        if (active && t < 3 * ncur) {
+            const int cg = fr[wid][grp][cur][t / 3];
+            n = b.fn[3 * cg + t % 3];
+            int co = __hip_atomic_load(&b.fowner[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool sees = plane_dist(b.frec[n], px, py, pz) > 0.0;
+            if (co >= b.fcap) co = kNone;   // (never: an owner is a face id)
+            if (sees && !(co == o || (co >= 0 && b.fprio[co] <= po))) {
+                while (true) {
+                    const int old = atomicCAS(&b.fowner[n], co, o);
+                    if (old == co) { mine = true; fail_other = co; break; }
+                    co = old;
+                    if (co == o) break;
+                    if (co >= 0 && b.fprio[co] <= po) { fail_me = true; break; }
+                }
+            } else if (sees) {
+                fail_me = co != o;
+            } else if (co >= 0 && co != o) {
+                if (b.fprio[co] < po) fail_me = true; else fail_other = co;
+            }
+        }
+        if (fail_other >= 0) atomicAnd(&b.fflags[fail_other], ~2);
+        const unsigned long long bal = __ballot(mine), balf = __ballot(fail_me);
+        const int total = __popcll(bal);
+        if (logn + total > kClaimLog) flush();
+        if (mine) { const int r = logn + __popcll(bal & below); lg[wid][r] = n; lgc[wid][r] = o; }
+        logn += total;
+        if (active) {
+            const int cnt = __popcll(bal & gm), rank = __popcll(bal & gm & below);
+            if (mine && nnext + rank < kSubFront) fr[wid][grp][cur ^ 1][nnext + rank] = n;   // beyond: the walk stays incomplete
+            nnext += cnt;
+            failed = failed || (balf & gm) != 0ull;
+            base += SL;
+            if (base >= 3 * ncur) {   // the level is done (the same in all lanes of the quarter)
+                claimed += nnext;
+                if (nnext > kSubFront) failed = true;
+                ncur = nnext < kSubFront ? nnext : kSubFront;
+                cur ^= 1; nnext = 0; base = 0;
+                if (ncur == 0 || claimed >= kClaimMax) {
+                    if (ncur > 0) failed = true;
+                    if (failed && gl == 0) atomicAnd(&b.fflags[o], ~2);
+                    active = false;
+                }
+            }
+        }
+    }
+    flush();
+}
+
 // The careful path (after a round that accepted nobody): each live face adopts the best-priority owner among its neighbours
 // whose apex sees it, launched until nothing changes (host-checked); k_owned_list then lists the owned faces.  Both walk
 // every face ever created — rare enough not to deserve a list of the alive ones.
@@ -1894,6 +2031,8 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     static const int compact_every = getenv("TOHIP_HULL_COMPACT") ? atoi(getenv("TOHIP_HULL_COMPACT")) : 2;
     static const bool trace = getenv("TOHIP_HULL_TRACE") != nullptr;   // experiments: the build's progress, one line per readback
     static const int fused_verdict = getenv("TOHIP_HULL_FUSED_ACCEPT") ? atoi(getenv("TOHIP_HULL_FUSED_ACCEPT")) : 1;   // experiments: 0 = a k_accept launch per round
+    static const int sub_claim = getenv("TOHIP_HULL_SUB_CLAIM") ? atoi(getenv("TOHIP_HULL_SUB_CLAIM")) : 4;   // experiments: candidates per wave from which the quarter-wave walk takes over (0 = never)
+    static const int sub_lanes = getenv("TOHIP_HULL_SUB_LANES") ? atoi(getenv("TOHIP_HULL_SUB_LANES")) : 8;   // eight candidates to a wave (measured: 12.0-12.1 ms for 128 views; 16 lanes each: 12.3-12.4; a wave each: 13.9-14.0)
     static const int join_faces = getenv("TOHIP_HULL_JOIN_FACES") ? atoi(getenv("TOHIP_HULL_JOIN_FACES")) : 192;  // experiments
 
     // `careful`: ownership propagated to convergence with the host checking (after a batch that accepted nobody)
@@ -1906,7 +2045,11 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
             if (!careful) {
                 // Fast path: a wave per candidate walks and claims its region (one launch, no readback).  Incomplete
                 // ownership is safe — a candidate is accepted only if it owns every face its apex sees (k_accept).
-                k_owner_claim<<<ga, TO_BLOCK, 0, st>>>(b, round, par, fused_verdict);
+                // many candidates (a batch of views): four to a wave (k_owner_claim_sub); else a wave each
+                if (fused_verdict && sub_claim && (int64_t)ncand >= (int64_t)sub_claim * ga * TO_WAVES_PER_BLOCK)
+                    { if (sub_lanes == 8) k_owner_claim_sub<8><<<ga, TO_BLOCK, 0, st>>>(b, round, par); else k_owner_claim_sub<16><<<ga, TO_BLOCK, 0, st>>>(b, round, par); }
+                else
+                    k_owner_claim<<<ga, TO_BLOCK, 0, st>>>(b, round, par, fused_verdict);
                 TO_HIP_CHECK_LAUNCH();
             } else {
                 while (true) {
