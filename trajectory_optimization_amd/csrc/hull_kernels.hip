@@ -1139,9 +1139,22 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
         int o = kNone, want = 0;
         bool hor[3] = {false, false, false};
         const int fl = g >= 0 ? b.fflags[g] : 0;
+        // Everything the new faces need is asked for BEFORE the ids are (block_alloc waits for a returning atomic and two barriers;
+        // r05 loaded apex, vertices and the neighbours' links behind it: three more dependent accesses per round): the face's
+        // neighbours and vertices, their coordinates, the apex and its coordinates, the links of the neighbours across the horizon
+        int nn[3] = {kNone, kNone, kNone}, vv[3] = {0, 0, 0}, nfn[3][3], apex = 0;
+        double vx[3] = {0, 0, 0}, vy[3] = {0, 0, 0}, vz[3] = {0, 0, 0}, ax = 0, ay = 0, az = 0;
         if (g >= 0 && (fl & 1) && owned_accepted(b, g, &o) && claimer == o) {
             b.fflags[g] = fl | 4;   // nobody else writes this face's flags in this launch
-            for (int k = 0; k < 3; ++k) { hor[k] = b.fowner[b.fn[3 * g + k]] != o; want += hor[k]; }
+            for (int k = 0; k < 3; ++k) { nn[k] = b.fn[3 * g + k]; vv[k] = b.fv[3 * g + k]; }
+            for (int k = 0; k < 3; ++k) { hor[k] = b.fowner[nn[k]] != o; want += hor[k]; }
+            if (want) {
+                apex = apex_pos(b.fmax[o]);
+                ax = b.px[apex]; ay = b.py[apex]; az = b.pz[apex];
+                for (int k = 0; k < 3; ++k) { vx[k] = b.px[vv[k]]; vy[k] = b.py[vv[k]]; vz[k] = b.pz[vv[k]]; }
+                for (int k = 0; k < 3; ++k)
+                    for (int j = 0; j < 3; ++j) nfn[k][j] = hor[k] ? b.fn[3 * nn[k] + j] : kNone;
+            }
         } else {
             o = kNone;
         }
@@ -1149,20 +1162,28 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
         if (acc != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&b.ctrl[kCtrlAccepted], __popcll(acc));
         int id = block_alloc(&b.ctrl[kCtrlNFaces + 8], want);
         if (want == 0) continue;
-        const int apex = apex_pos(b.fmax[o]);
         for (int k = 0; k < 3; ++k) {
             if (!hor[k]) continue;
             if (id >= b.fcap) { b.ctrl[kCtrlError] |= kErrCapacity; break; }
-            const int n = b.fn[3 * g + k];
-            const int u = b.fv[3 * g + k], v = b.fv[3 * g + (k + 1) % 3];
+            const int n = nn[k], k1 = (k + 1) % 3;
+            const int u = vv[k], v = vv[k1];
             const int slot = atomicAdd(&b.nfhead[o], 1);   // the region's table of new faces: asked for first, stored last
             b.fv[3 * id] = u; b.fv[3 * id + 1] = v; b.fv[3 * id + 2] = apex;
             b.fn[3 * id] = n; b.fn[3 * id + 1] = kNone; b.fn[3 * id + 2] = kNone;
-            set_plane(b, id);
+            {   // set_plane's expression on the coordinates already in hand: a = u, c1 = v, c2 = the apex
+                const double ux = vx[k1] - vx[k], uy = vy[k1] - vy[k], uz = vz[k1] - vz[k];
+                const double wx = ax - vx[k], wy = ay - vy[k], wz = az - vz[k];
+                FaceRec r;
+                r.nx = uy * wz - uz * wy; r.ny = uz * wx - ux * wz; r.nz = ux * wy - uy * wx;
+                r.x0 = vx[k]; r.y0 = vy[k]; r.z0 = vz[k];
+                r.next = kNone; r.pad[0] = kNone; r.pad[1] = 0;
+                r.inv_norm = (float)(1.0 / sqrt(r.nx * r.nx + r.ny * r.ny + r.nz * r.nz));
+                b.frec[id] = r;
+            }
             b.fflags[id] = 1; b.fowner[id] = kNone; b.fmax[id] = 0ull; b.nfhead[id] = 0;
             b.newface[3 * g + k] = id;
             for (int j = 0; j < 3; ++j)
-                if (b.fn[3 * n + j] == g) b.fn[3 * n + j] = id;
+                if (nfn[k][j] == g) b.fn[3 * n + j] = id;   // (each of n's three words changes only from its own region face to that face's new one)
             // The candidate's own record is free from here on (its plane was last read by k_accept; it dies at the end of the round):
             // its first twelve words take the region's new faces — a moving point then asks for all of them at once instead of
             // walking a linked list, one dependent load per face (13 -> 8 us per round at 1 M points, r06); a region of more than
@@ -1217,38 +1238,42 @@ __device__ __forceinline__ void reassign_points(const Bufs& b, FaceMaxTable& tab
         int jj[U], ii[U], gg[U], fl[U];
         for (int u = 0; u < U; ++u) { jj[u] = vblock * TO_BLOCK + threadIdx.x + (it * U + u) * stride; ii[u] = jj[u] < nlive ? b.live[jj[u]] : 0; }
         for (int u = 0; u < U; ++u) gg[u] = jj[u] < nlive ? b.pface[ii[u]] : kNone;
-        for (int u = 0; u < U; ++u) fl[u] = gg[u] >= 0 ? b.fflags[gg[u]] : 0;
+        int fo[U];
+        for (int u = 0; u < U; ++u) { fl[u] = gg[u] >= 0 ? b.fflags[gg[u]] : 0; fo[u] = gg[u] >= 0 ? b.fowner[gg[u]] : kNone; }   // (both by the face: one trip)
         for (int u = 0; u < U; ++u) {
             const int i = ii[u], g = gg[u];
             double best = 0.0; int bf = kNone;
             if (g >= 0 && (fl[u] & 4)) {
-                const int o = b.fowner[g];
-                const int ap = apex_pos(b.fmax[o]);
+                const int o = fo[u];
+                // everything that hangs on the candidate is asked for at once: its apex (position), how many new faces its region
+                // has, the table of their ids (three 16-byte loads out of its own record) — then the apex's coordinates, the
+                // point's and the new faces' records together; a region of more than ten faces goes on through the records' `next`
+                const unsigned long long akey = b.fmax[o];
+                const int cnt = b.nfhead[o];
+                const int4* rt = reinterpret_cast<const int4*>(region_tab(b, o));
+                const int4 t0 = rt[0], t1 = rt[1], t2 = rt[2];
+                const int over = cnt > kRegionTab ? b.frec[o].pad[0] : kNone;
+                const int ap = apex_pos(akey);
                 const double x = b.px[i], y = b.py[i], z = b.pz[i];
-                // (every new face has the apex as a vertex and two older ones, whose copies retired when THEY went in)
-                if (i != ap && !(x == b.px[ap] && y == b.py[ap] && z == b.pz[ap])) {
-                    // the region's new faces: up to twelve ids in the candidate's record (three 16-byte loads), the records behind
-                    // them requested together; a longer list goes on through `next`
-                    const int cnt = b.nfhead[o];
-                    const int4* rt = reinterpret_cast<const int4*>(region_tab(b, o));
-                    const int4 t0 = rt[0], t1 = rt[1], t2 = rt[2];
-                    const int ids[kRegionTab] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
-                    const int inl = cnt < kRegionTab ? cnt : kRegionTab;
+                const double apx = b.px[ap], apy = b.py[ap], apz = b.pz[ap];
+                const int ids[kRegionTab] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
+                const int inl = cnt < kRegionTab ? cnt : kRegionTab;
 #pragma unroll
-                    for (int k = 0; k < kRegionTab; ++k) {
-                        if (k >= inl) break;
-                        const FaceRec r = b.frec[ids[k]];
-                        const double d = plane_dist(r, x, y, z);
-                        if (d > best) { best = d; bf = ids[k]; }
-                    }
-                    int steps = 0;
-                    for (int f = cnt > kRegionTab ? b.frec[o].pad[0] : kNone; f >= 0 && steps < (1 << 20); ++steps) {
-                        const FaceRec r = b.frec[f];  // one line per step of the list: plane, anchor and link
-                        const double d = plane_dist(r, x, y, z);
-                        if (d > best) { best = d; bf = f; }
-                        f = r.next;
-                    }
+                for (int k = 0; k < kRegionTab; ++k) {
+                    if (k >= inl) break;
+                    const FaceRec r = b.frec[ids[k]];
+                    const double d = plane_dist(r, x, y, z);
+                    if (d > best) { best = d; bf = ids[k]; }
                 }
+                int steps = 0;
+                for (int f = over; f >= 0 && steps < (1 << 20); ++steps) {
+                    const FaceRec r = b.frec[f];  // one line per step of the list: plane, anchor and link
+                    const double d = plane_dist(r, x, y, z);
+                    if (d > best) { best = d; bf = f; }
+                    f = r.next;
+                }
+                // (every new face has the apex as a vertex and two older ones, whose copies retired when THEY went in)
+                if (i == ap || (x == apx && y == apy && z == apz)) { best = 0.0; bf = kNone; }
                 b.pface[i] = bf;  // the apex retires as a vertex; a point outside no new face retires inside the hull
             }
             wave_face_max(b, tab, bf, apex_key(best, i));  // the new face's farthest point so far
@@ -1264,6 +1289,16 @@ __global__ void __launch_bounds__(TO_BLOCK) k_link_reassign(Bufs b, int par, int
     if (b.ctrl[kCtrlError] != 0) return;   // (k_new_faces ran out of faces in THIS round, or an earlier round failed: round_dead)
     if ((int)blockIdx.x < link_blocks) link_faces(b, par, blockIdx.x, link_blocks);
     else reassign_points(b, tab, blockIdx.x - link_blocks, gridDim.x - link_blocks);
+}
+// (experiments, TOHIP_HULL_SPLIT_LINK=1: the two halves as launches of their own, so that a profile shows which one the round waits for)
+__global__ void __launch_bounds__(TO_BLOCK) k_link_only(Bufs b, int par) {
+    if (b.ctrl[kCtrlError] != 0) return;
+    link_faces(b, par, blockIdx.x, gridDim.x);
+}
+__global__ void __launch_bounds__(TO_BLOCK) k_reassign_only(Bufs b) {
+    __shared__ FaceMaxTable tab;
+    if (b.ctrl[kCtrlError] != 0) return;
+    reassign_points(b, tab, blockIdx.x, gridDim.x);
 }
 
 // End of a round = start of the next: apexes of the faces created this round (point loop), then per listed face: the accepted
@@ -2033,6 +2068,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     static const int fused_verdict = getenv("TOHIP_HULL_FUSED_ACCEPT") ? atoi(getenv("TOHIP_HULL_FUSED_ACCEPT")) : 1;   // experiments: 0 = a k_accept launch per round
     static const int sub_claim = getenv("TOHIP_HULL_SUB_CLAIM") ? atoi(getenv("TOHIP_HULL_SUB_CLAIM")) : 4;   // experiments: candidates per wave from which the quarter-wave walk takes over (0 = never)
     static const int sub_lanes = getenv("TOHIP_HULL_SUB_LANES") ? atoi(getenv("TOHIP_HULL_SUB_LANES")) : 8;   // eight candidates to a wave (measured: 12.0-12.1 ms for 128 views; 16 lanes each: 12.3-12.4; a wave each: 13.9-14.0)
+    static const int split_link = getenv("TOHIP_HULL_SPLIT_LINK") ? atoi(getenv("TOHIP_HULL_SPLIT_LINK")) : 0;   // experiments
     static const int join_faces = getenv("TOHIP_HULL_JOIN_FACES") ? atoi(getenv("TOHIP_HULL_JOIN_FACES")) : 192;  // experiments
 
     // `careful`: ownership propagated to convergence with the host checking (after a batch that accepted nobody)
@@ -2069,7 +2105,8 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
             const int gr = nblocks(live_bound, 1024);
             if (careful || !fused_verdict) k_accept<<<gl, TO_BLOCK, 0, st>>>(b, round, par);   // (the fast path's walk has given its verdict)
             k_new_faces<<<gl, TO_BLOCK, 0, st>>>(b, par);
-            k_link_reassign<<<gl + gr, TO_BLOCK, 0, st>>>(b, par, gl);
+            if (split_link) { k_link_only<<<gl, TO_BLOCK, 0, st>>>(b, par); k_reassign_only<<<gr, TO_BLOCK, 0, st>>>(b); }
+            else k_link_reassign<<<gl + gr, TO_BLOCK, 0, st>>>(b, par, gl);
             const int gt = gl;   // (a list walk: the apexes of the new faces come with their maxima since r06, no pass over the live points)
             k_round_tail<<<gt, TO_BLOCK, 0, st>>>(b, par, round + 1);
             TO_HIP_CHECK_LAUNCH();
