@@ -106,6 +106,7 @@ struct Bufs {
     int nseg;
     int hbits;             // bits of the apex height in a candidate's rank (make_prio)
     int early_out;         // k_owner_claim: candidates beaten by a neighbouring candidate do not walk
+    int share_edges;       // k_owner_claim: regions that share a horizon edge convexly are accepted together (convex_across)
     int origin;            // 1: the last slot of a segment is the appended origin; 0: it repeats the segment's first point and never takes part
     int sub;               // > 1 while only every sub-th point (in Morton order) takes part: the first rounds of a large build
     int key32;             // 1: segment number + Morton cell fit 32-bit sort keys
@@ -190,7 +191,7 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
         if (tmp32 > tmp) tmp = tmp32;
     }
     p = take(tmp); if (b) { b->sort_tmp = p; b->sort_tmp_bytes = tmp; }
-    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; b->origin = 1; b->hbits = 0; b->early_out = 0; b->serial = 0; b->key32 = 1; }
+    if (b) { b->m1 = (int)m1; b->fcap = fcap; b->nseg = (int)nseg; b->sub = 1; b->origin = 1; b->hbits = 0; b->early_out = 0; b->share_edges = 0; b->serial = 0; b->key32 = 1; }
     return o;
 }
 
@@ -782,6 +783,28 @@ __global__ void __launch_bounds__(TO_BLOCK) k_assign0(Bufs b) {
 // face stolen later) can only cost that candidate this round; a round that accepts nobody is repeated with k_owner_prop
 // run to convergence.
 constexpr int kClaimFront = 128, kClaimMax = 4096, kClaimLog = 192;
+
+// Two regions that share a horizon edge (u, v) can BOTH go in this round when the new faces on it, (u, v, mine) and (v, u, theirs),
+// meet convexly: their apex lies strictly below the plane of my new face (and then mine below theirs).  In the sequential order
+// either apex, put in second, then sees exactly its own region — what an apex sees is connected across edges, the faces across its
+// horizon are the old ones (unchanged) or such a new face — so the two insertions commute like those of regions that do not touch
+// (r06: until then any two adjacent regions excluded each other, and a round accepted 7 % of its candidates).  Each side asks with
+// its own rounding; a side that says no fails the worse of the two, and failing is always safe.  `cg`, `k`: my region's face and its
+// edge on the horizon; (ax, ay, az): my apex; `co`: the candidate that holds the face across.
+constexpr double kConvexTol = 1e-9;   // relative: a pair within rounding of coplanar waits a round
+__device__ __forceinline__ bool convex_across(const Bufs& b, int cg, int k, double ax, double ay, double az, int co) {
+    const int u = b.fv[3 * cg + k], v = b.fv[3 * cg + (k == 2 ? 0 : k + 1)];
+    const unsigned long long theirs = b.fmax[co];
+    if (theirs == 0ull) return false;
+    const int q = apex_pos(theirs);
+    const double ux = b.px[u], uy = b.py[u], uz = b.pz[u];
+    const double ex = b.px[v] - ux, ey = b.py[v] - uy, ez = b.pz[v] - uz;
+    const double wx = ax - ux, wy = ay - uy, wz = az - uz;
+    const double tx = b.px[q] - ux, ty = b.py[q] - uy, tz = b.pz[q] - uz;
+    const double nx = ey * wz - ez * wy, ny = ez * wx - ex * wz, nz = ex * wy - ey * wx;
+    const double d = nx * tx + ny * ty + nz * tz;
+    return d < 0.0 && d * d > (kConvexTol * kConvexTol) * (nx * nx + ny * ny + nz * nz) * (tx * tx + ty * ty + tz * tz);
+}
 // verdict != 0 (r06, the fast path): the walk also DECIDES who is accepted, so the round needs no k_accept launch.  k_accept's rule —
 // a candidate stays accepted iff it owns every face its apex sees and no better candidate owns a face across its horizon — is
 // settled where ownership changes hands: a walk that meets a face it sees in better hands, or a better owner across its horizon,
@@ -882,8 +905,10 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim(Bufs b, int round, int
                         }
                     } else if (sees) {
                         fail_me = co != o;                     // a face my apex sees, in better hands
-                    } else if (co >= 0 && co != o) {           // across my horizon: the worse of the two neighbours loses
-                        if (b.fprio[co] < po) fail_me = true; else fail_other = co;
+                    } else if (co >= 0 && co != o && verdict) { // across my horizon, in other hands: unless the two fit, the worse one loses
+                        if (!b.share_edges || !convex_across(b, cg, t % 3, px, py, pz, co)) {
+                            if (b.fprio[co] < po) fail_me = true; else fail_other = co;
+                        }
                     }
                 }
                 if (verdict) {
@@ -1014,8 +1039,10 @@ __global__ void __launch_bounds__(TO_BLOCK) k_owner_claim_sub(Bufs b, int round,
                 }
             } else if (sees) {
                 fail_me = co != o;
-            } else if (co >= 0 && co != o) {
-                if (b.fprio[co] < po) fail_me = true; else fail_other = co;
+            } else if (co >= 0 && co != o) {   // (see k_owner_claim)
+                if (!b.share_edges || !convex_across(b, cg, t % 3, px, py, pz, co)) {
+                    if (b.fprio[co] < po) fail_me = true; else fail_other = co;
+                }
             }
         }
         if (fail_other >= 0) atomicAnd(&b.fflags[fail_other], ~2);
@@ -1137,7 +1164,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
         int claimer = kNone;
         const int g = list_face(w, it, nullptr, &claimer);
         int o = kNone, want = 0;
-        bool hor[3] = {false, false, false};
+        bool hor[3] = {false, false, false}, ndies[3] = {false, false, false};
         const int fl = g >= 0 ? b.fflags[g] : 0;
         // Everything the new faces need is asked for BEFORE the ids are (block_alloc waits for a returning atomic and two barriers;
         // r05 loaded apex, vertices and the neighbours' links behind it: three more dependent accesses per round): the face's
@@ -1147,7 +1174,11 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
         if (g >= 0 && (fl & 1) && owned_accepted(b, g, &o) && claimer == o) {
             b.fflags[g] = fl | 4;   // nobody else writes this face's flags in this launch
             for (int k = 0; k < 3; ++k) { nn[k] = b.fn[3 * g + k]; vv[k] = b.fv[3 * g + k]; }
-            for (int k = 0; k < 3; ++k) { hor[k] = b.fowner[nn[k]] != o; want += hor[k]; }
+            int on[3];
+            for (int k = 0; k < 3; ++k) { on[k] = b.fowner[nn[k]]; hor[k] = on[k] != o; want += hor[k]; }
+            // a face across the horizon that dies in ANOTHER accepted region this round (regions that share an edge, convex_across):
+            // its links stay as they are — both regions' walks read them — and the two new faces on the edge find each other in link_faces
+            for (int k = 0; k < 3; ++k) ndies[k] = hor[k] && on[k] >= 0 && b.fowner[on[k]] == on[k] && (b.fflags[on[k]] & 2);
             if (want) {
                 apex = apex_pos(b.fmax[o]);
                 ax = b.px[apex]; ay = b.py[apex]; az = b.pz[apex];
@@ -1183,7 +1214,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_new_faces(Bufs b, int par) {
             b.fflags[id] = 1; b.fowner[id] = kNone; b.fmax[id] = 0ull; b.nfhead[id] = 0;
             b.newface[3 * g + k] = id;
             for (int j = 0; j < 3; ++j)
-                if (nfn[k][j] == g) b.fn[3 * n + j] = id;   // (each of n's three words changes only from its own region face to that face's new one)
+                if (nfn[k][j] == g && !ndies[k]) b.fn[3 * n + j] = id;   // (each of n's three words changes only from its own region face to that face's new one)
             // The candidate's own record is free from here on (its plane was last read by k_accept; it dies at the end of the round):
             // its first twelve words take the region's new faces — a moving point then asks for all of them at once instead of
             // walking a linked list, one dependent load per face (13 -> 8 us per round at 1 M points, r06); a region of more than
@@ -1207,6 +1238,16 @@ __device__ __forceinline__ void link_faces(const Bufs& b, int par, int vblock, i
             if (b.fowner[b.fn[3 * g + k]] == o) continue;
             const int my = b.newface[3 * g + k];
             if (my < 0 || my >= b.fcap) continue;
+            {   // the face across died in another region this round: my neighbour across the edge is ITS new face on it
+                const int n = b.fn[3 * g + k];
+                if (b.fflags[n] & 4) {
+                    int j = 0;
+                    while (j < 3 && b.fn[3 * n + j] != g) ++j;
+                    const int other = j < 3 ? b.newface[3 * n + j] : kNone;
+                    if (other < 0 || other >= b.fcap) { b.ctrl[kCtrlError] |= kErrTopology; continue; }
+                    b.fn[3 * my] = other;
+                }
+            }
             int cur = g, e = (k + 1) % 3, steps = 0;
             while (true) {
                 const int n2 = b.fn[3 * cur + e];
@@ -1913,6 +1954,8 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         b.hbits = hb < 0 ? 0 : (hb > 16 ? 16 : hb);
         static const int eo = getenv("TOHIP_HULL_EARLY_OUT") ? atoi(getenv("TOHIP_HULL_EARLY_OUT")) : 1;  // experiments
         b.early_out = eo;
+        static const int se = getenv("TOHIP_HULL_SHARE_EDGES") ? atoi(getenv("TOHIP_HULL_SHARE_EDGES")) : 1;    // experiments: 0 = adjacent regions exclude each other (r05)
+        b.share_edges = se;
     }
     {
         // large segments: the first rounds on a sample (see k_assign_all)
