@@ -1937,6 +1937,22 @@ k_finish_visible(const int* __restrict__ idx, const int* __restrict__ total, int
     }
 }
 
+// What the host wants to know of a batch of rounds, written by ONE wave straight into host memory the GPU has mapped (r06; until
+// then a 16 KB copy of the control block behind an event: the copy's kernel was 1.4 us between two gaps of 12 and 6 us — the
+// system-scope flush and the signal — on every one of a build's ten readbacks): the scalars, the two candidate counts summed
+// over their sub-lists, and last, released at system scope, the sequence number the host is polling for.
+constexpr int kRepCand = kCtrlInts, kRepSeq = kCtrlInts + 2, kRepInts = 32;
+__global__ void __launch_bounds__(64) k_report(Bufs b, int* __restrict__ rec, int seq) {
+    static_assert(kSubLists == 64, "a lane per sub-list");
+    const int lane = threadIdx.x;
+    int c0 = *ccnt(b, 0, lane), c1 = *ccnt(b, 1, lane);
+    for (int s = 32; s > 0; s >>= 1) { c0 += __shfl_xor(c0, s); c1 += __shfl_xor(c1, s); }
+    if (lane < kCtrlInts) rec[lane] = b.ctrl[lane];
+    if (lane == 0) { rec[kRepCand] = c0; rec[kRepCand + 1] = c1; }
+    __threadfence_system();   // (one wave: every lane's stores are out before lane 0 goes on)
+    if (lane == 0) __hip_atomic_store(&rec[kRepSeq], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 inline int nblocks(int64_t n, int cap = 2048) {
     int64_t nb = (n + TO_BLOCK - 1) / TO_BLOCK;
     return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
@@ -2045,31 +2061,31 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         k_round_tail<<<kSubLists, TO_BLOCK, 0, st>>>(b, 1, 0);  // round 0's candidates: the tetrahedra's faces with points outside
     }
     TO_HIP_CHECK_LAUNCH();
-    // One readback = the scalars and the candidate counters of both parities, into pinned memory behind an event: the host
-    // keeps ONE batch of rounds enqueued ahead of the readback it is waiting for, so the GPU never idles while the host looks
-    // at the counts (35 us per readback, 50 readbacks per million-point build).  Rounds enqueued after the hull is complete
-    // find no candidate and change nothing; the counts only size grids, and every kernel strides over its lists.
-    constexpr int kRead = kCtrlInts + 2 * kSubLists * kCntStride;
+    // One readback = k_report's record in mapped host memory, the host polling its sequence number: the host keeps ONE batch of
+    // rounds enqueued ahead of the readback it is waiting for, so the GPU never idles while the host looks at the counts.
+    // Rounds enqueued after the hull is complete find no candidate and change nothing; the counts only size grids, and every
+    // kernel strides over its lists.
     struct Pinned {
-        int* buf[2] = {nullptr, nullptr};
-        hipEvent_t ev[2] = {nullptr, nullptr};
+        int* rec[2] = {nullptr, nullptr};    // host addresses
+        int* drec[2] = {nullptr, nullptr};   // the same records as the device sees them
+        int seq = 0;                         // last sequence number handed out (never reused: a stale record cannot match)
         bool ok = false;
-        Pinned() {   // on the device that is current: events belong to a device; portable pinned memory is usable from all
-            ok = hipHostMalloc((void**)&buf[0], sizeof(int) * kRead, hipHostMallocPortable) == hipSuccess &&
-                 hipHostMalloc((void**)&buf[1], sizeof(int) * kRead, hipHostMallocPortable) == hipSuccess &&
-                 hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+        Pinned() {   // mapped, coherent host memory: the GPU's stores land in it without a copy
+            ok = true;
+            for (int i = 0; i < 2 && ok; ++i) {
+                ok = hipHostMalloc((void**)&rec[i], sizeof(int) * kRepInts, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess &&
+                     hipHostGetDevicePointer((void**)&drec[i], rec[i], 0) == hipSuccess;
+                if (ok) for (int k = 0; k < kRepInts; ++k) rec[i][k] = 0;
+            }
         }
         ~Pinned() {
-            for (int i = 0; i < 2; ++i) {
-                if (buf[i]) (void)hipHostFree(buf[i]);
-                if (ev[i]) (void)hipEventDestroy(ev[i]);
-            }
+            for (int i = 0; i < 2; ++i)
+                if (rec[i]) (void)hipHostFree(rec[i]);
         }
         Pinned(const Pinned&) = delete;
         Pinned& operator=(const Pinned&) = delete;
     };
-    // one set per (thread, device): it lives as long as the thread (a build must not pay two pinned allocations), and a build on
-    // another GPU of the same process gets events of ITS device (an event recorded on a stream of another device is an error)
+    // one set per (thread, device): it lives as long as the thread (a build must not pay two pinned allocations)
     static thread_local std::map<int, std::unique_ptr<Pinned>> pins;
     int cur_dev = 0;
     if (hipGetDevice(&cur_dev) != hipSuccess) return TOHIP_EINVAL;
@@ -2077,24 +2093,39 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     if (!pin_slot) pin_slot.reset(new Pinned());
     Pinned& pin = *pin_slot;
     if (!pin.ok) return TOHIP_EINVAL;
-    const int* h = pin.buf[0];
+    const int* h = pin.rec[0];
     int wslot = 0, rslot = 0, inflight = 0;
-    auto post_readback = [&]() -> hipError_t {  // enqueue the copy; collect() waits for it
-        hipError_t er = hipMemcpyAsync(pin.buf[wslot], b.ctrl, sizeof(int) * kRead, hipMemcpyDeviceToHost, st);
-        if (er == hipSuccess) er = hipEventRecord(pin.ev[wslot], st);
+    int want_seq[2] = {0, 0};
+    auto post_readback = [&]() -> hipError_t {  // enqueue the report; collect() waits for it
+        want_seq[wslot] = ++pin.seq;
+        k_report<<<1, 64, 0, st>>>(b, pin.drec[wslot], want_seq[wslot]);
+        const hipError_t er = hipGetLastError();
         wslot ^= 1; ++inflight;
         return er;
     };
     double host_enqueue_us = 0.0, host_wait_us = 0.0;  // for the trace: where the host's time goes
     auto collect = [&]() -> hipError_t {
         const auto t0 = std::chrono::steady_clock::now();
-        const hipError_t er = hipEventSynchronize(pin.ev[rslot]);
+        hipError_t er = hipSuccess;
+        const volatile int* seqp = pin.rec[rslot] + kRepSeq;
+        // poll; every so often ask the stream whether it is still working (a fault, or a report that never ran, must not hang the host)
+        for (long spin = 1; __atomic_load_n(seqp, __ATOMIC_ACQUIRE) != want_seq[rslot]; ++spin) {
+            if ((spin & 0x3fff) == 0) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) {   // everything enqueued has run: the record is there, or it never will be
+                    if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != want_seq[rslot]) er = hipErrorUnknown;
+                    break;
+                }
+                if (q != hipErrorNotReady) { er = q; break; }
+            }
+            __builtin_ia32_pause();
+        }
         host_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        h = pin.buf[rslot];
+        h = pin.rec[rslot];
         rslot ^= 1; --inflight;
         return er;
     };
-    auto candidates = [&](int par) { int n = 0; for (int sl = 0; sl < kSubLists; ++sl) n += h[kCtrlInts + (par * kSubLists + sl) * kCntStride]; return n; };
+    auto candidates = [&](int par) { return h[kRepCand + par]; };
     auto cdiv = [](int64_t a, int64_t d) { return (a + d - 1) / d; };
     e = post_readback();
     if (e == hipSuccess) e = collect();
@@ -2111,14 +2142,18 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     static const int fused_verdict = getenv("TOHIP_HULL_FUSED_ACCEPT") ? atoi(getenv("TOHIP_HULL_FUSED_ACCEPT")) : 1;   // experiments: 0 = a k_accept launch per round
     static const int sub_claim = getenv("TOHIP_HULL_SUB_CLAIM") ? atoi(getenv("TOHIP_HULL_SUB_CLAIM")) : 4;   // experiments: candidates per wave from which the quarter-wave walk takes over (0 = never)
     static const int sub_lanes = getenv("TOHIP_HULL_SUB_LANES") ? atoi(getenv("TOHIP_HULL_SUB_LANES")) : 8;   // eight candidates to a wave (measured: 12.0-12.1 ms for 128 views; 16 lanes each: 12.3-12.4; a wave each: 13.9-14.0)
+    static const int grid_scale = getenv("TOHIP_HULL_GRID_SCALE") ? std::max(1, atoi(getenv("TOHIP_HULL_GRID_SCALE"))) : 4;   // experiments (1 M points: 2.97 / 2.89 / 2.85 / 2.84 ms at 1 / 2 / 4 / 8)
     static const int split_link = getenv("TOHIP_HULL_SPLIT_LINK") ? atoi(getenv("TOHIP_HULL_SPLIT_LINK")) : 0;   // experiments
     static const int join_faces = getenv("TOHIP_HULL_JOIN_FACES") ? atoi(getenv("TOHIP_HULL_JOIN_FACES")) : 192;  // experiments
 
     // `careful`: ownership propagated to convergence with the host checking (after a batch that accepted nobody)
     auto enqueue_rounds_inner = [&](int nrounds, bool careful) -> int {
         // grids: a wave per candidate; a thread per listed face (a candidate claims a handful of faces; lists grow within a batch)
-        const int ga = kSubLists * (int)std::min<int64_t>(32, std::max<int64_t>(1, cdiv(ncand, kSubLists * TO_WAVES_PER_BLOCK)));
-        const int gl = kSubLists * (int)std::min<int64_t>(16, std::max<int64_t>(1, cdiv((int64_t)ncand * 16, kSubLists * TO_BLOCK)));
+        // (`ncand` is what a readback said two batches ago, and while a hull grows its candidates multiply by ~1.25 per round: the
+        // grids are cut for `grid_scale` times as many — a wave that finds no candidate leaves, one that finds three walks them in turn)
+        const int64_t nc_grid = (int64_t)ncand * grid_scale;
+        const int ga = kSubLists * (int)std::min<int64_t>(32, std::max<int64_t>(1, cdiv(nc_grid, kSubLists * TO_WAVES_PER_BLOCK)));
+        const int gl = kSubLists * (int)std::min<int64_t>(16, std::max<int64_t>(1, cdiv(nc_grid * 16, kSubLists * TO_BLOCK)));
         for (int r = 0; r < nrounds; ++r, ++round) {
             const int par = round & 1;
             if (!careful) {
