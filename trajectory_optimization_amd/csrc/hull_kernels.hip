@@ -2135,7 +2135,8 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     int nf = h[kCtrlNFaces + 8];
     const int max_rounds = 100000;
     int round = 0 /* rounds enqueued */, ncand = candidates(0), live_bound = (b.m1 + b.sub - 1) / b.sub;
-    static const int batch = getenv("TOHIP_HULL_BATCH") ? atoi(getenv("TOHIP_HULL_BATCH")) : 4;  // experiments: rounds per readback
+    static const bool batch_env = getenv("TOHIP_HULL_BATCH") != nullptr;
+    static const int batch = batch_env ? std::max(1, atoi(getenv("TOHIP_HULL_BATCH"))) : 3;  // experiments: rounds per readback (1 M points: 2.38 / 2.29 / 2.26 / 2.29 / 2.30 / 2.37 ms at 1 / 2 / 3 / 4 / 6 / 8)
     static const bool always_careful = getenv("TOHIP_HULL_CAREFUL") != nullptr;                   // experiments: the slow path only
     static const int compact_every = getenv("TOHIP_HULL_COMPACT") ? atoi(getenv("TOHIP_HULL_COMPACT")) : 2;
     static const bool trace = getenv("TOHIP_HULL_TRACE") != nullptr;   // experiments: the build's progress, one line per readback
@@ -2261,7 +2262,10 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
             while (inflight < ahead) {  // keep one batch ahead of the readback being waited for
                 // few candidates left: the build is about to end, and every round enqueued beyond its end is five launches of
                 // nothing (up to eight such rounds at four per readback: 0.1 ms of a 4 ms build) -> two per readback from here on
-                const int rc = enqueue_rounds(always_careful ? 1 : ((ncand <= 512 && batch > 2) ? 2 : batch), always_careful);
+                // ... and with tens of thousands of candidates (a batch of views) a round is hundreds of microseconds: the host is
+                // ahead anyway, and one round per readback wastes the fewest at the end (128 views: 9.5 ms at 4, 9.0 at 2, 8.9 at 1)
+                const int per = batch_env ? batch : (ncand >= 16384 ? 1 : (ncand <= 512 ? 2 : batch));
+                const int rc = enqueue_rounds(always_careful ? 1 : per, always_careful);
                 if (rc != TOHIP_OK) return drain(rc);
                 round_of[wslot] = round;
                 e = post_readback();
