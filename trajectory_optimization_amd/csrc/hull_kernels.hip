@@ -2029,7 +2029,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         // measured (tools/hpr_serial_sweep.sh, r06): an insertion costs ~5 us here, a round ~45 us for one hull and ~160 us for 128 —
         // one hull is best served by 192-448 ids (flat), a batch by 768-896
         static const int ids_env = getenv("TOHIP_HULL_SERIAL_IDS") ? atoi(getenv("TOHIP_HULL_SERIAL_IDS")) : 0;
-        const int ids = std::max(64, std::min(1536, (ids_env > 0 ? ids_env : (b.nseg == 1 ? 320 : 768)) / 2 * 2));
+        const int ids = std::max(64, std::min(1536, (ids_env > 0 ? ids_env : (b.nseg == 1 ? 320 : 512)) / 2 * 2));   // (with regions sharing edges, r06: one hull flat from 48 to 256; 128 views 9.0 / 8.8 / 8.7 / 8.9 / 9.2 ms at 256 / 384 / 512 / 768 / 1024)
         if (want && (int64_t)4 * b.nseg + (int64_t)b.nseg * (ids - 4) <= (int64_t)b.fcap) {
             static int lds_ok_for = 0;   // the dynamic-LDS limit of the kernel is raised once per size
             const size_t lds = sample_hull_lds_bytes(ids);
@@ -2143,6 +2143,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     static const int fused_verdict = getenv("TOHIP_HULL_FUSED_ACCEPT") ? atoi(getenv("TOHIP_HULL_FUSED_ACCEPT")) : 1;   // experiments: 0 = a k_accept launch per round
     static const int sub_claim = getenv("TOHIP_HULL_SUB_CLAIM") ? atoi(getenv("TOHIP_HULL_SUB_CLAIM")) : 4;   // experiments: candidates per wave from which the quarter-wave walk takes over (0 = never)
     static const int sub_lanes = getenv("TOHIP_HULL_SUB_LANES") ? atoi(getenv("TOHIP_HULL_SUB_LANES")) : 8;   // eight candidates to a wave (measured: 12.0-12.1 ms for 128 views; 16 lanes each: 12.3-12.4; a wave each: 13.9-14.0)
+    static const int reassign_cap = getenv("TOHIP_HULL_REASSIGN_CAP") ? std::max(64, atoi(getenv("TOHIP_HULL_REASSIGN_CAP"))) : 1024;   // experiments: blocks of the point kernel
     static const int grid_scale = getenv("TOHIP_HULL_GRID_SCALE") ? std::max(1, atoi(getenv("TOHIP_HULL_GRID_SCALE"))) : 4;   // experiments (1 M points: 2.97 / 2.89 / 2.85 / 2.84 ms at 1 / 2 / 4 / 8)
     static const int split_link = getenv("TOHIP_HULL_SPLIT_LINK") ? atoi(getenv("TOHIP_HULL_SPLIT_LINK")) : 0;   // experiments
     static const int join_faces = getenv("TOHIP_HULL_JOIN_FACES") ? atoi(getenv("TOHIP_HULL_JOIN_FACES")) : 192;  // experiments
@@ -2181,7 +2182,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
                 k_owned_list<<<kSubLists * (int)std::min<int64_t>(16, std::max<int64_t>(1, cdiv(nf, kSubLists * TO_BLOCK))), TO_BLOCK, 0, st>>>(b, par);
                 TO_HIP_CHECK_LAUNCH();
             }
-            const int gr = nblocks(live_bound, 1024);
+            const int gr = nblocks(live_bound, reassign_cap);
             if (careful || !fused_verdict) k_accept<<<gl, TO_BLOCK, 0, st>>>(b, round, par);   // (the fast path's walk has given its verdict)
             k_new_faces<<<gl, TO_BLOCK, 0, st>>>(b, par);
             if (split_link) { k_link_only<<<gl, TO_BLOCK, 0, st>>>(b, par); k_reassign_only<<<gr, TO_BLOCK, 0, st>>>(b); }
