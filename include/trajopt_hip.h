@@ -417,6 +417,14 @@ size_t tohip_cull_waypoints_workspace_bytes(int64_t n_points, int64_t n_wps);
 int tohip_cull_waypoints(const float *xyz, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
                          int normalize, const tohip_camera *cam_host, float min_dist, float max_dist, int32_t *kept_idx,
                          float *kept_pts, int32_t *kept_count, void *workspace, size_t workspace_bytes, void *stream);
+/* The same with the poses' kept points laid END TO END in kept_pts (what tohip_hidden_pts_removal_batched reads: the occlusion
+ * refresh's next stage, pc_processor.py:171-187 per camera): pose w's rows are [seg_off[w], seg_off[w+1]) of kept_pts, seg_off
+ * (n_wps + 1 device int64) is written here; kept_idx keeps its (n_wps, n) layout.  kept_pts must still hold n_wps * n rows
+ * (nobody knows the counts beforehand).  One launch more than tohip_cull_waypoints, no copy afterwards. */
+int tohip_cull_waypoints_packed(const float *xyz, int64_t n_points, const float *poses, const float *quats, int64_t n_wps,
+                                int normalize, const tohip_camera *cam_host, float min_dist, float max_dist, int32_t *kept_idx,
+                                float *kept_pts, int32_t *kept_count, int64_t *seg_off, void *workspace, size_t workspace_bytes,
+                                void *stream);
 /* gather rows: out[i,:] = xyz[idx[i],:] for i < *count (device), xyz (N,3) or (3,N) by in_layout. */
 int tohip_gather_points(const float *xyz, int64_t n_points, int in_layout, const int32_t *idx, const int32_t *count,
                         int64_t capacity, float *out_xyz, void *stream);

@@ -67,6 +67,36 @@ def test_frustum_edge_cases(dev):
         assert (~d).all() and idx.numel() == 0
 
 
+def test_cull_of_many_poses_end_to_end_equals_pose_by_pose(dev):
+    """tohip_cull_waypoints_packed (the occlusion refresh's cull: every pose's kept points laid end to end for the batched hull pass)
+    against tohip_cull_waypoints' rows, and those against the single-pose pipeline (exact transform -> frustum_cull): the same
+    indices and bit-identical camera-frame coordinates; a pose that keeps nothing is an empty segment."""
+    from trajectory_optimization_amd import ops
+    cam = ops.Camera(K, IW, IH)
+    for n, W in ((1, 1), (1023, 3), (20_000, 7), (70_001, 5)):
+        pts = torch.from_numpy(synth.make_cloud(n, seed=n)).to(dev)
+        poses, quats = synth.make_path(W, optical=True)
+        poses, quats = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
+        if W >= 3:
+            poses[1] += 1000.0   # sees nothing
+        ki, kp, counts, kc = ops.cull_waypoints(pts, poses, quats, cam, 1.0, 15.0)
+        ki, kp = ki.clone(), kp.clone()
+        ki2, cat, counts2, kc2, offs = ops.cull_waypoints(pts, poses, quats, cam, 1.0, 15.0, packed=True)
+        assert counts == counts2 and torch.equal(kc, kc2)
+        assert offs.cpu().tolist() == np.concatenate([[0], np.cumsum(counts)]).tolist() and cat.shape[0] == sum(counts)
+        for w in range(W):
+            c = counts[w]
+            assert torch.equal(ki[w, :c], ki2[w, :c])
+            seg = cat[int(offs[w]):int(offs[w + 1])]
+            assert seg.shape[0] == c and torch.equal(seg.view(torch.int32), kp[w, :c].view(torch.int32))
+            c3 = ops.to_camera_frame_exact(pts, quats[w], poses[w], normalize=True, transpose=True)
+            _, _, idx = ops.frustum_cull(c3, cam, 1.0, 15.0)
+            assert torch.equal(idx, ki[w, :c])
+            assert torch.equal(c3[:, idx.long()].t().contiguous().view(torch.int32), seg.view(torch.int32))
+        if W >= 3:
+            assert counts[1] == 0
+
+
 def test_spherical_flip_bit_exact(dev):
     from trajectory_optimization_amd.tools import sphericalFlip
     d = load_golden("funcs")

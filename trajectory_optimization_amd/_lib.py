@@ -123,6 +123,8 @@ SIGNATURES = {
     "tohip_cull_waypoints_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "tohip_cull_waypoints": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.c_int, ctypes.POINTER(Camera), c_f, c_f, c_vp,
                                              c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tohip_cull_waypoints_packed": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.c_int, ctypes.POINTER(Camera), c_f, c_f, c_vp,
+                                                    c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tohip_gather_points": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "tohip_hpr_workspace_bytes": (c_sz, [c_i64]),
     "tohip_spherical_flip": (ctypes.c_int, [c_vp, c_i64, c_f, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -461,7 +461,7 @@ k_cull_wps_scan(int32_t* __restrict__ tile_count, int ntiles, int32_t* __restric
 __global__ void __launch_bounds__(TO_BLOCK)
 k_cull_wps_write(const float* __restrict__ xyz, int64_t n, const float* __restrict__ poses, const float* __restrict__ quats,
                  int normalize, FrustumConsts f, int ntiles, const int32_t* __restrict__ tile_off,
-                 int32_t* __restrict__ kept_idx, float* __restrict__ kept_pts) {
+                 int32_t* __restrict__ kept_idx, float* __restrict__ kept_pts, const int64_t* __restrict__ seg_off) {
     __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
     const int w = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -469,7 +469,8 @@ k_cull_wps_write(const float* __restrict__ xyz, int64_t n, const float* __restri
     const int64_t tile0 = (int64_t)blockIdx.x * TO_CULL_TILE;
     int base = tile_off[(int64_t)w * ntiles + blockIdx.x];
     int32_t* ki = kept_idx + (int64_t)w * n;
-    float* kp = kept_pts + (int64_t)w * n * 3;
+    // seg_off: the waypoints' kept points end to end (tohip_cull_waypoints_packed) instead of n rows apart
+    float* kp = kept_pts + (seg_off ? seg_off[w] : (int64_t)w * n) * 3;
     for (int j = 0; j < TO_CULL_TILE / TO_BLOCK; ++j) {
         const int64_t i = tile0 + j * TO_BLOCK + threadIdx.x;
         bool d = false, v = false;
@@ -494,16 +495,42 @@ k_cull_wps_write(const float* __restrict__ xyz, int64_t n, const float* __restri
     }
 }
 
+// seg_off[w] = kept_count[0] + ... + kept_count[w-1], seg_off[n_wps] = the total: one block (n_wps <= 65 535)
+__global__ void __launch_bounds__(TO_BLOCK)
+k_cull_wps_offsets(const int32_t* __restrict__ kept_count, int n_wps, int64_t* __restrict__ seg_off) {
+    __shared__ long long lds[TO_BLOCK];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n_wps; c0 += TO_BLOCK) {
+        const int i = c0 + threadIdx.x;
+        const long long v = i < n_wps ? kept_count[i] : 0;
+        lds[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 1; s < TO_BLOCK; s <<= 1) {
+            const long long add = (int)threadIdx.x >= s ? lds[threadIdx.x - s] : 0;
+            __syncthreads();
+            lds[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n_wps) seg_off[i] = carry + lds[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += lds[TO_BLOCK - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) seg_off[n_wps] = carry;
+}
+
 extern "C" size_t tohip_cull_waypoints_workspace_bytes(int64_t n, int64_t n_wps) {
     if (n <= 0 || n_wps <= 0) return 256;
     const size_t ntiles = (size_t)((n + TO_CULL_TILE - 1) / TO_CULL_TILE);
     return (ntiles * (size_t)n_wps * sizeof(int32_t) + 255) / 256 * 256 + 256;
 }
 
-extern "C" int tohip_cull_waypoints(const float* xyz, int64_t n, const float* poses, const float* quats, int64_t n_wps,
-                                    int normalize, const tohip_camera* cam, float min_dist, float max_dist, int32_t* kept_idx,
-                                    float* kept_pts, int32_t* kept_count, void* workspace, size_t workspace_bytes,
-                                    void* stream_) {
+static int cull_waypoints_impl(const float* xyz, int64_t n, const float* poses, const float* quats, int64_t n_wps,
+                               int normalize, const tohip_camera* cam, float min_dist, float max_dist, int32_t* kept_idx,
+                               float* kept_pts, int32_t* kept_count, int64_t* seg_off, void* workspace, size_t workspace_bytes,
+                               void* stream_) {
     if (!xyz || !poses || !quats || !cam || !kept_idx || !kept_pts || !kept_count || !workspace || n <= 0 || n_wps <= 0 ||
         n > (int64_t)0x7fffffff || n_wps > 65535)
         return TOHIP_EINVAL;
@@ -522,9 +549,30 @@ extern "C" int tohip_cull_waypoints(const float* xyz, int64_t n, const float* po
     TO_HIP_CHECK_LAUNCH();
     k_cull_wps_scan<<<(unsigned)n_wps, TO_BLOCK, 0, st>>>(tile_count, ntiles, kept_count);
     TO_HIP_CHECK_LAUNCH();
-    k_cull_wps_write<<<grid, TO_BLOCK, 0, st>>>(xyz, n, poses, quats, normalize, f, ntiles, tile_count, kept_idx, kept_pts);
+    if (seg_off) {
+        k_cull_wps_offsets<<<1, TO_BLOCK, 0, st>>>(kept_count, (int)n_wps, seg_off);
+        TO_HIP_CHECK_LAUNCH();
+    }
+    k_cull_wps_write<<<grid, TO_BLOCK, 0, st>>>(xyz, n, poses, quats, normalize, f, ntiles, tile_count, kept_idx, kept_pts, seg_off);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
+}
+
+extern "C" int tohip_cull_waypoints(const float* xyz, int64_t n, const float* poses, const float* quats, int64_t n_wps,
+                                    int normalize, const tohip_camera* cam, float min_dist, float max_dist, int32_t* kept_idx,
+                                    float* kept_pts, int32_t* kept_count, void* workspace, size_t workspace_bytes,
+                                    void* stream_) {
+    return cull_waypoints_impl(xyz, n, poses, quats, n_wps, normalize, cam, min_dist, max_dist, kept_idx, kept_pts, kept_count, nullptr,
+                               workspace, workspace_bytes, stream_);
+}
+
+extern "C" int tohip_cull_waypoints_packed(const float* xyz, int64_t n, const float* poses, const float* quats, int64_t n_wps,
+                                           int normalize, const tohip_camera* cam, float min_dist, float max_dist, int32_t* kept_idx,
+                                           float* kept_pts, int32_t* kept_count, int64_t* seg_off, void* workspace,
+                                           size_t workspace_bytes, void* stream_) {
+    if (!seg_off) return TOHIP_EINVAL;
+    return cull_waypoints_impl(xyz, n, poses, quats, n_wps, normalize, cam, min_dist, max_dist, kept_idx, kept_pts, kept_count, seg_off,
+                               workspace, workspace_bytes, stream_);
 }
 
 // out[i,:] = xyz[idx[i],:]  for i < *count

@@ -432,8 +432,13 @@ def _occlusion_rows_chunk(cloud, points, poses, quats, cam, min_dist, max_dist, 
     dev = cloud.device
     W = poses.shape[0]
     n = cloud.n
-    # transform -> cull -> gather for all waypoints of the chunk in three launches (one host read: the counts size the hull pass)
-    kept_all, pts_all, counts, kcnt_all = cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True, scratch=True)
+    # transform -> cull -> gather for all waypoints of the chunk in three launches (one host read: the counts size the hull pass);
+    # for the hull pass the kept clouds are written end to end at once (r06: 128 device copies, 0.83 of a refresh's 11.1 ms, until then)
+    packed = method != "zbuffer" and W <= 65535
+    if packed:
+        kept_all, cat, counts, kcnt_all, seg_off_dev = cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True, scratch=True, packed=True)
+    else:
+        kept_all, pts_all, counts, kcnt_all = cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True, scratch=True)
     if method == "zbuffer":
         # every waypoint's z-buffer in the same three launches (chunks of as many z-buffers as 2 GB hold); visible[w, j] = 1 when
         # kept point j of waypoint w owns a pixel
@@ -451,10 +456,11 @@ def _occlusion_rows_chunk(cloud, points, poses, quats, cam, min_dist, max_dist, 
         offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         tot = int(offs[-1])
         visible = _scratch(dev, "hvis", 4 * max(tot, 1))[:4 * max(tot, 1)].view(torch.float32)
-        cat = _scratch(dev, "hcat", 12 * max(tot, 1))[:12 * max(tot, 1)].view(torch.float32).view(-1, 3)
-        for w in range(W):   # (device-to-device copies of each waypoint's kept rows: no host round trip)
-            if counts[w]:
-                cat[int(offs[w]):int(offs[w + 1])].copy_(pts_all[w, :counts[w]])
+        if not packed:
+            cat = _scratch(dev, "hcat", 12 * max(tot, 1))[:12 * max(tot, 1)].view(torch.float32).view(-1, 3)
+            for w in range(W):   # (device-to-device copies of each waypoint's kept rows: no host round trip)
+                if counts[w]:
+                    cat[int(offs[w]):int(offs[w + 1])].copy_(pts_all[w, :counts[w]])
         w0 = 0
         while w0 < W:
             w1 = w0 + 1
@@ -463,12 +469,13 @@ def _occlusion_rows_chunk(cloud, points, poses, quats, cam, min_dist, max_dist, 
             lo, hi = int(offs[w0]), int(offs[w1])
             if hi > lo:
                 status = _hpr_batched_mask(cat[lo:hi], [int(o) - lo for o in offs[w0:w1 + 1]], visible[lo:hi])
-                if bool((status == 3).any()):
+                st_h = status.cpu().numpy()   # (one host read for both checks)
+                if (st_h == 3).any():
                     raise ValueError("Points cannot contain NaN")  # scipy's error in the reference's pipeline
-                if bool(((status == 2) & (kcnt_all[w0:w1] >= 4)).any()):
+                if ((st_h == 2) & (np.asarray(counts[w0:w1]) >= 4)).any():
                     raise _lib.HipError("occlusion_bits: a waypoint's culled cloud is flat (no 3-D hull; Qhull raises QH6154)")
             w0 = w1
-        seg_off = torch.from_numpy(offs[:W].copy()).to(dev)
+        seg_off = seg_off_dev[:W] if packed else torch.from_numpy(offs[:W].copy()).to(dev)
     for w0 in range(0, W, 65535):
         w1 = min(W, w0 + 65535)
         with torch.cuda.device(dev):
@@ -498,15 +505,19 @@ def _hpr_batched_mask(points, seg_offsets, mask_out):
     raise _lib.HipError("hull workspace: still out of face capacity at 64x the recommended size")
 
 
-def cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True, scratch=False):
+def cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True, scratch=False, packed=False):
     """Exact transform + hard frustum cull of `points` (N,3) for W poses at once (tohip_cull_waypoints).
     -> (kept_idx (W,N) int32, kept_pts (W,N,3) f32 camera frame, counts list[int], counts on the device (W,) int32): pose
     w's kept points are the first counts[w] rows of kept_idx[w] / kept_pts[w], in input order.  One host synchronisation
-    (the counts).  scratch: the two worst-case sized outputs live in cached buffers (valid until the next such call)."""
+    (the counts).  scratch: the two worst-case sized outputs live in cached buffers (valid until the next such call).
+    packed (tohip_cull_waypoints_packed; W <= 65535): kept_pts is (sum(counts), 3) instead — the poses' kept points end to end,
+    pose w's in rows [offs[w], offs[w+1]) — and a fifth value, offs (W+1,) int64 on the device, is returned."""
     _require_cuda(points, "points")
     pts = points.detach().to(torch.float32).contiguous()
     dev, n, W = pts.device, pts.shape[0], poses.shape[0]
     p_in, q_in = poses.detach().to(torch.float32).contiguous(), quats.detach().to(torch.float32).contiguous()
+    if packed and W > 65535:
+        raise ValueError("cull_waypoints(packed=True) takes at most 65535 poses per call")
     if scratch:
         kept_all = _scratch(dev, "kept", 4 * W * max(n, 1))[:4 * W * max(n, 1)].view(torch.int32).view(W, max(n, 1))
         pts_all = _scratch(dev, "kpts", 12 * W * max(n, 1))[:12 * W * max(n, 1)].view(torch.float32).view(W, max(n, 1), 3)
@@ -515,6 +526,16 @@ def cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True
         pts_all = torch.empty((W, max(n, 1), 3), dtype=torch.float32, device=dev)
     kcnt_all = torch.zeros(W, dtype=torch.int32, device=dev)
     L = _lib.lib()
+    if packed:
+        seg_off = torch.empty(W + 1, dtype=torch.int64, device=dev)
+        wsb = L.tohip_cull_waypoints_workspace_bytes(n, W)
+        fws = _scratch(dev, "cullws", wsb) if scratch else torch.empty(wsb, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(L.tohip_cull_waypoints_packed(ptr(pts), n, ptr(p_in), ptr(q_in), W, int(bool(normalize)), cam.ref(), float(min_dist),
+                                                float(max_dist), ptr(kept_all), ptr(pts_all), ptr(kcnt_all), ptr(seg_off), ptr(fws), wsb,
+                                                stream_ptr()), "tohip_cull_waypoints_packed")
+        counts = kcnt_all.cpu().tolist()
+        return kept_all, pts_all.view(-1, 3)[:sum(counts)], counts, kcnt_all, seg_off
     for w0 in range(0, W, 65535):  # grid.y limit
         w1 = min(W, w0 + 65535)
         wsb = L.tohip_cull_waypoints_workspace_bytes(n, w1 - w0)
