@@ -2185,7 +2185,10 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
             const int gr = nblocks(live_bound, reassign_cap);
             if (careful || !fused_verdict) k_accept<<<gl, TO_BLOCK, 0, st>>>(b, round, par);   // (the fast path's walk has given its verdict)
             k_new_faces<<<gl, TO_BLOCK, 0, st>>>(b, par);
-            if (split_link) { k_link_only<<<gl, TO_BLOCK, 0, st>>>(b, par); k_reassign_only<<<gr, TO_BLOCK, 0, st>>>(b); }
+            if (split_link) {
+                k_link_only<<<gl, TO_BLOCK, 0, st>>>(b, par); k_reassign_only<<<gr, TO_BLOCK, 0, st>>>(b);
+                if (split_link == 2) k_reassign_only<<<gr, TO_BLOCK, 0, st>>>(b);   // (experiments: the second pass moves nobody — what the scan alone costs)
+            }
             else k_link_reassign<<<gl + gr, TO_BLOCK, 0, st>>>(b, par, gl);
             const int gt = gl;   // (a list walk: the apexes of the new faces come with their maxima since r06, no pass over the live points)
             k_round_tail<<<gt, TO_BLOCK, 0, st>>>(b, par, round + 1);
