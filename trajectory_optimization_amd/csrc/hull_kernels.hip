@@ -2029,7 +2029,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         // measured (tools/hpr_serial_sweep.sh, r06): an insertion costs ~5 us here, a round ~45 us for one hull and ~160 us for 128 —
         // one hull is best served by 192-448 ids (flat), a batch by 768-896
         static const int ids_env = getenv("TOHIP_HULL_SERIAL_IDS") ? atoi(getenv("TOHIP_HULL_SERIAL_IDS")) : 0;
-        const int ids = std::max(64, std::min(1536, (ids_env > 0 ? ids_env : (b.nseg == 1 ? 320 : 512)) / 2 * 2));   // (with regions sharing edges, r06: one hull flat from 48 to 256; 128 views 9.0 / 8.8 / 8.7 / 8.9 / 9.2 ms at 256 / 384 / 512 / 768 / 1024)
+        const int ids = std::max(64, std::min(1536, (ids_env > 0 ? ids_env : (b.nseg == 1 ? 192 : 512)) / 2 * 2));   // (with regions sharing edges and the polled report, r06: one hull 2.19 / 2.19 / 2.17 / 2.23 / 2.26 / 2.39 ms at 64 / 128 / 192 / 256 / 320 / 448, the sample's rounds instead 2.22; 128 views 9.0 / 8.8 / 8.7 / 8.9 / 9.2 ms at 256 / 384 / 512 / 768 / 1024)
         if (want && (int64_t)4 * b.nseg + (int64_t)b.nseg * (ids - 4) <= (int64_t)b.fcap) {
             static int lds_ok_for = 0;   // the dynamic-LDS limit of the kernel is raised once per size
             const size_t lds = sample_hull_lds_bytes(ids);
