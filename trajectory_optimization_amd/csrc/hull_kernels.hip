@@ -337,6 +337,25 @@ __device__ __forceinline__ int find_seg(const Bufs& b, int i) {
     }
     return lo;
 }
+// The set-up kernels walk the points 64 at a time, and 64 consecutive indices share their segment but for the waves on the segments'
+// 127 boundaries: the search runs ONCE per wave on the scalar unit (r06; every lane's own search was seven dependent vector loads per
+// point — most of what k_bbox, k_sort_keys, k_load, k_norm_max_seg and k_flip_seg cost for 128 views).  e0 must be wave-uniform;
+// *end = the first index behind the segment.  The lanes' segment: wave_seg's if e0 + 63 < *end, their own find_seg otherwise.
+__device__ __forceinline__ int wave_seg(const Bufs& b, int e0, int* end) {
+    const int e = __builtin_amdgcn_readfirstlane(e0);
+    int lo = 0, hi = b.nseg;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (b.seg_off[mid] <= e) lo = mid; else hi = mid;
+    }
+    *end = b.seg_off[lo + 1];
+    return lo;
+}
+__device__ __forceinline__ int lane_seg(const Bufs& b, int e0, int e) {
+    int end;
+    const int s0 = wave_seg(b, e0, &end);
+    return e0 + 63 < end ? s0 : find_seg(b, e);   // (wave-uniform branch)
+}
 
 __device__ __forceinline__ int* ccnt(const Bufs& b, int par, int s) { return b.ctrl + kCtrlInts + (par * kSubLists + s) * kCntStride; }
 __device__ __forceinline__ int* ocnt(const Bufs& b, int par, int s) { return ccnt(b, 2 + par, s); }
@@ -401,7 +420,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_bbox(Bufs b, const float* __restri
     const int chunk = ((b.m1 + nwaves - 1) / nwaves + 63) / 64 * 64;
     const int64_t begin64 = (int64_t)wave * chunk;
     const int begin = begin64 < b.m1 ? (int)begin64 : b.m1, end = begin64 + chunk < b.m1 ? (int)(begin64 + chunk) : b.m1;
-    int cur = -1;
+    int cur = -1, cur_seg = -1, cur_end = -1;
     unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
     auto flush = [&]() {  // wave-uniform `cur`: called by all lanes
         if (cur >= 0) {
@@ -421,8 +440,9 @@ __global__ void __launch_bounds__(TO_BLOCK) k_bbox(Bufs b, const float* __restri
         int sg = -1;
         unsigned key[3] = {0u, 0u, 0u};
         bool ok[3] = {false, false, false};
+        if (e0 >= cur_end) cur_seg = wave_seg(b, e0, &cur_end);   // (the run has left the segment it was in: wave-uniform)
         if (e < end) {
-            sg = find_seg(b, e);
+            sg = e0 + 63 < cur_end ? cur_seg : find_seg(b, e);
             float c[3];
             source_point(b, pts, with_origin, e, sg, &c[0], &c[1], &c[2]);
             for (int k = 0; k < 3; ++k) {
@@ -520,8 +540,9 @@ __device__ __forceinline__ unsigned morton_of(const Bufs& b, int sg, float x, fl
 // below; the value is the expanded index.  32-bit keys while segment number and cell fit (b.key32), 64-bit ones beyond 256 segments
 __global__ void __launch_bounds__(TO_BLOCK) k_sort_keys(Bufs b, const float* __restrict__ pts, int with_origin) {
     const int stride = gridDim.x * TO_BLOCK;
-    for (int e = blockIdx.x * TO_BLOCK + threadIdx.x; e < b.m1; e += stride) {
-        const int sg = find_seg(b, e);
+    for (int e = blockIdx.x * TO_BLOCK + threadIdx.x; e - (int)(threadIdx.x & 63) < b.m1; e += stride) {
+        const int sg = lane_seg(b, e - (int)(threadIdx.x & 63), e);   // (all lanes of the wave take part)
+        if (e >= b.m1) continue;
         float c[3];
         source_point(b, pts, with_origin, e, sg, &c[0], &c[1], &c[2]);
         const unsigned m = morton_of(b, sg, c[0], c[1], c[2]);
@@ -531,6 +552,11 @@ __global__ void __launch_bounds__(TO_BLOCK) k_sort_keys(Bufs b, const float* __r
     }
 }
 
+// the sorted key of position j (keys2 keeps the sort's output)
+__device__ __forceinline__ unsigned long long sorted_key(const Bufs& b, int j) {
+    return b.key32 ? (unsigned long long)reinterpret_cast<const unsigned*>(b.keys2)[j] : b.keys2[j];
+}
+
 // position j takes the point perm[j]
 __global__ void __launch_bounds__(TO_BLOCK)
 k_load(Bufs b, const float* __restrict__ pts, int with_origin) {
@@ -538,7 +564,7 @@ k_load(Bufs b, const float* __restrict__ pts, int with_origin) {
     for (int j = blockIdx.x * TO_BLOCK + threadIdx.x; j < b.m1; j += stride) {
         const int e = b.perm[j];
         float x, y, z;
-        source_point(b, pts, with_origin, e, find_seg(b, e), &x, &y, &z);
+        source_point(b, pts, with_origin, e, (int)(sorted_key(b, j) >> kMortonBits), &x, &y, &z);   // (the key's high bits: its segment)
         b.px[j] = (double)x; b.py[j] = (double)y; b.pz[j] = (double)z;
         b.inv[e] = j;
         b.pface[j] = kNone;
@@ -607,6 +633,10 @@ __device__ int block_argmax(double key, int idx, double* skey, int* sidx, double
     return r;
 }
 
+// the k-th point of a segment's 1-in-st sample: runs of 64 consecutive points, 64 st apart — a wave reads whole lines (every st-th
+// point touched as many lines as all of them: the four passes of a 128-view build moved 1.3 GB for a sample of an eighth)
+__device__ __forceinline__ int sample_at(int lo, int k, int st) { return lo + (k >> 6) * (64 * st) + (k & 63); }
+
 // initial tetrahedron of one segment per block: lowest-x point, the point farthest from it, farthest from their
 // line, farthest from their plane.  Segment s owns the face slots 4s .. 4s+3.
 __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
@@ -624,14 +654,14 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
         // ties go to the caller's lowest index (perm), whatever the internal order
         for (int st = (hi - lo >= 32768) ? 8 : 1; ; st = 1) {
             double best = -INFINITY; int bi = 0x7fffffff;
-            for (int i = lo + t * st; i < hi; i += HULL_INIT_THREADS * st) {
+            for (int q = t, i = sample_at(lo, q, st); i < hi; q += HULL_INIT_THREADS, i = sample_at(lo, q, st)) {
                 const double k = -b.px[i]; const int e = b.perm[i];
                 if (k > best || (k == best && e < bi)) { best = k; bi = e; }
             }
             i0 = b.inv[block_argmax(best, bi, skey, sidx, nullptr)];
             x0 = b.px[i0]; y0 = b.py[i0]; z0 = b.pz[i0];
             best = -INFINITY; bi = 0x7fffffff;
-            for (int i = lo + t * st; i < hi; i += HULL_INIT_THREADS * st) {
+            for (int q = t, i = sample_at(lo, q, st); i < hi; q += HULL_INIT_THREADS, i = sample_at(lo, q, st)) {
                 const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
                 const double k = dx * dx + dy * dy + dz * dz; const int e = b.perm[i];
                 if (k > best || (k == best && e < bi)) { best = k; bi = e; }
@@ -639,7 +669,7 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
             i1 = b.inv[block_argmax(best, bi, skey, sidx, &kk)];
             const double ex = b.px[i1] - x0, ey = b.py[i1] - y0, ez = b.pz[i1] - z0;
             best = -INFINITY; bi = 0x7fffffff;
-            for (int i = lo + t * st; i < hi; i += HULL_INIT_THREADS * st) {
+            for (int q = t, i = sample_at(lo, q, st); i < hi; q += HULL_INIT_THREADS, i = sample_at(lo, q, st)) {
                 const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
                 const double cx = dy * ez - dz * ey, cy = dz * ex - dx * ez, cz = dx * ey - dy * ex;
                 const double k = cx * cx + cy * cy + cz * cz; const int e = b.perm[i];
@@ -649,7 +679,7 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
             const double fx = b.px[i2] - x0, fy = b.py[i2] - y0, fz = b.pz[i2] - z0;
             nx = ey * fz - ez * fy; ny = ez * fx - ex * fz; nz = ex * fy - ey * fx;
             best = -INFINITY; bi = 0x7fffffff;
-            for (int i = lo + t * st; i < hi; i += HULL_INIT_THREADS * st) {
+            for (int q = t, i = sample_at(lo, q, st); i < hi; q += HULL_INIT_THREADS, i = sample_at(lo, q, st)) {
                 const double k = fabs(nx * (b.px[i] - x0) + ny * (b.py[i] - y0) + nz * (b.pz[i] - z0)); const int e = b.perm[i];
                 if (k > best || (k == best && e < bi)) { best = k; bi = e; }
             }
@@ -1830,9 +1860,6 @@ __global__ void __launch_bounds__(TO_BLOCK) k_rebuild_candidates(Bufs b, int par
 // the walk recomputed every row's cell from its coordinates — 13 us per build with 30-bit cells, 78 with the 24-bit ones).  (Qhull's
 // own choice among identical rows follows its insertion history — the first copy in ~70 % of the cases, the last in the others —
 // and cannot be reproduced by a parallel build.)
-__device__ __forceinline__ unsigned long long sorted_key(const Bufs& b, int j) {
-    return b.key32 ? (unsigned long long)reinterpret_cast<const unsigned*>(b.keys2)[j] : b.keys2[j];
-}
 __device__ __forceinline__ int lowest_identical_row(const Bufs& b, int j) {
     const unsigned long long key = sorted_key(b, j);
     const double x = b.px[j], y = b.py[j], z = b.pz[j];
@@ -2359,6 +2386,18 @@ __device__ __forceinline__ int find_src_seg(const Bufs& b, int r) {  // segment 
     return lo;
 }
 
+// (wave_seg for source rows: r0 wave-uniform, *end = the first row behind the segment)
+__device__ __forceinline__ int wave_src_seg(const Bufs& b, int r0, int* end) {
+    const int r = __builtin_amdgcn_readfirstlane(r0);
+    int lo = 0, hi = b.nseg;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (b.seg_off[mid] - mid <= r) lo = mid; else hi = mid;
+    }
+    *end = b.seg_off[lo + 1] - (lo + 1);
+    return lo;
+}
+
 __global__ void __launch_bounds__(TO_BLOCK) k_norm_max_seg(Bufs b, const float* __restrict__ xyz, int n) {
     // contiguous run per wave, running maximum of the current segment in a register (as k_bbox)
     const int lane = threadIdx.x & 63;
@@ -2366,7 +2405,7 @@ __global__ void __launch_bounds__(TO_BLOCK) k_norm_max_seg(Bufs b, const float* 
     const int chunk = ((n + nwaves - 1) / nwaves + 63) / 64 * 64;
     const int64_t begin64 = (int64_t)wave * chunk;
     const int begin = begin64 < n ? (int)begin64 : n, end = begin64 + chunk < n ? (int)(begin64 + chunk) : n;
-    int cur = -1, m = 0;
+    int cur = -1, m = 0, cur_seg = -1, cur_end = -1;
     auto flush = [&]() {
         if (cur >= 0) {
             for (int s = 32; s > 0; s >>= 1) m = max(m, __shfl_xor(m, s));
@@ -2377,8 +2416,9 @@ __global__ void __launch_bounds__(TO_BLOCK) k_norm_max_seg(Bufs b, const float* 
     for (int i0 = begin; i0 < end; i0 += 64) {
         const int i = i0 + lane;
         int sg = -1, v = 0;
+        if (i0 >= cur_end) cur_seg = wave_src_seg(b, i0, &cur_end);   // (wave-uniform)
         if (i < end) {
-            sg = find_src_seg(b, i);
+            sg = i0 + 63 < cur_end ? cur_seg : find_src_seg(b, i);
             v = __float_as_int(flip_norm(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])) & 0x7fffffff;
         }
         const int s0 = __shfl(sg, 0);
@@ -2397,8 +2437,11 @@ __global__ void __launch_bounds__(TO_BLOCK) k_norm_max_seg(Bufs b, const float* 
 __global__ void __launch_bounds__(TO_BLOCK)
 k_flip_seg(Bufs b, const float* __restrict__ xyz, int n, float scale, float* __restrict__ flipped) {
     const int stride = gridDim.x * TO_BLOCK;
-    for (int i = blockIdx.x * TO_BLOCK + threadIdx.x; i < n; i += stride) {
-        const float radius = __int_as_float(b.flip_max[find_src_seg(b, i)]) * scale;  // tools.py:45, per viewpoint
+    for (int i = blockIdx.x * TO_BLOCK + threadIdx.x; i - (int)(threadIdx.x & 63) < n; i += stride) {
+        int send;
+        const int i0 = i - (int)(threadIdx.x & 63), s0 = wave_src_seg(b, i0, &send);   // (all lanes of the wave take part)
+        if (i >= n) continue;
+        const float radius = __int_as_float(b.flip_max[i0 + 63 < send ? s0 : find_src_seg(b, i)]) * scale;  // tools.py:45, per viewpoint
         const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
         const float nr = flip_norm(x, y, z);
         const float r = radius - nr;
