@@ -93,9 +93,8 @@ struct Bufs {
     // spatial order: the points are worked on in Morton order of their position inside the segment's bounding box, so
     // that the lanes of a wave hold neighbouring points — which share conflict faces and new-face lists for the whole
     // build (coalesced, mostly wave-uniform reads instead of 64 scattered lists per wave).  px/py/pz, pface and the
-    // faces' vertex ids live in this order; perm/inv translate from/to the caller's (expanded) numbering.
+    // faces' vertex ids live in this order; perm translates to the caller's (expanded) numbering.
     int* perm;             // M1   position -> expanded index
-    int* inv;              // M1   expanded index -> position
     unsigned long long *keys, *keys2;  // M1 each
     int* vals;             // M1
     unsigned* seg_bbox;    // 6 * nseg (ordered-float keys: min x,y,z, max x,y,z)
@@ -177,7 +176,6 @@ __host__ inline size_t carve(Bufs* b, char* base, int64_t n_points, int64_t nseg
     p = take(sizeof(int) * m1); if (b) b->live = (int*)p;
     p = take(sizeof(int) * m1); if (b) b->live2 = (int*)p;
     p = take(sizeof(int) * m1); if (b) b->perm = (int*)p;
-    p = take(sizeof(int) * m1); if (b) b->inv = (int*)p;
     p = take(sizeof(unsigned long long) * m1); if (b) b->keys = (unsigned long long*)p;
     p = take(sizeof(unsigned long long) * m1); if (b) b->keys2 = (unsigned long long*)p;
     p = take(sizeof(int) * m1); if (b) b->vals = (int*)p;
@@ -395,14 +393,19 @@ __global__ void k_single_segment(Bufs b) { b.seg_off[0] = 0; b.seg_off[1] = b.m1
 // coordinates of expanded index e of segment sg: a row of the source array (every earlier segment has spent one slot
 // on its origin), or — the segment's last slot — the appended origin (tools.py:60); without an origin that slot
 // repeats the segment's first point (never a new vertex)
+// a row of an (n,3) f32 array in ONE 12-byte access (three 4-byte loads of a gathered row are three trips through the address unit)
+struct __attribute__((packed, aligned(4))) Row3 { float x, y, z; };
+__device__ __forceinline__ Row3 load_row(const float* __restrict__ xyz, int64_t r) { return reinterpret_cast<const Row3*>(xyz)[r]; }
+
 __device__ __forceinline__ void source_point(const Bufs& b, const float* __restrict__ pts, int with_origin, int e, int sg,
                                              float* x, float* y, float* z) {
     const bool extra = e == b.seg_off[sg + 1] - 1;
     const int r = extra ? b.seg_off[sg] - sg : e - sg;
     const bool zero = extra && with_origin;
-    *x = zero ? 0.0f : pts[3 * r];
-    *y = zero ? 0.0f : pts[3 * r + 1];
-    *z = zero ? 0.0f : pts[3 * r + 2];
+    const Row3 p = load_row(pts, r);
+    *x = zero ? 0.0f : p.x;
+    *y = zero ? 0.0f : p.y;
+    *z = zero ? 0.0f : p.z;
 }
 
 __global__ void __launch_bounds__(TO_BLOCK) k_bbox_init(Bufs b) {
@@ -566,7 +569,6 @@ k_load(Bufs b, const float* __restrict__ pts, int with_origin) {
         float x, y, z;
         source_point(b, pts, with_origin, e, (int)(sorted_key(b, j) >> kMortonBits), &x, &y, &z);   // (the key's high bits: its segment)
         b.px[j] = (double)x; b.py[j] = (double)y; b.pz[j] = (double)z;
-        b.inv[e] = j;
         b.pface[j] = kNone;
         b.vflag[j] = 0;
         b.vals[j] = 0;        // (the sort's input values are free now: k_mark_vertices' "this vertex has been looked up" marks)
@@ -616,18 +618,26 @@ __device__ void init_tetrahedron(const Bufs& b, int sg, bool enough, bool has_na
     }
 }
 
-__device__ int block_argmax(double key, int idx, double* skey, int* sidx, double* out_key) {
+// A candidate of the arg-max passes is (key, caller's index, position): ties go to the caller's lowest index, and the position comes
+// along in the same word (r06; until then the winner's position was looked up in an inverse permutation that k_load had to scatter,
+// 4 random bytes per point).
+typedef unsigned long long tie_t;
+__device__ __forceinline__ tie_t tie_word(int e, int pos) { return ((tie_t)(unsigned)e << 32) | (unsigned)pos; }
+constexpr tie_t kTieNone = ~0ull;
+__device__ __forceinline__ int tie_pos(tie_t w) { return (int)(unsigned)(w & 0xffffffffull); }
+
+__device__ tie_t block_argmax(double key, tie_t idx, double* skey, tie_t* sidx, double* out_key) {
     const int t = threadIdx.x;
     skey[t] = key; sidx[t] = idx;
     __syncthreads();
     for (int s = HULL_INIT_THREADS / 2; s > 0; s >>= 1) {
         if (t < s) {
-            const double k2 = skey[t + s]; const int i2 = sidx[t + s];
+            const double k2 = skey[t + s]; const tie_t i2 = sidx[t + s];
             if (k2 > skey[t] || (k2 == skey[t] && i2 < sidx[t])) { skey[t] = k2; sidx[t] = i2; }
         }
         __syncthreads();
     }
-    const int r = sidx[0];
+    const tie_t r = sidx[0];
     if (out_key) *out_key = skey[0];
     __syncthreads();
     return r;
@@ -641,7 +651,7 @@ __device__ __forceinline__ int sample_at(int lo, int k, int st) { return lo + (k
 // line, farthest from their plane.  Segment s owns the face slots 4s .. 4s+3.
 __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
     __shared__ double skey[HULL_INIT_THREADS];
-    __shared__ int sidx[HULL_INIT_THREADS];
+    __shared__ tie_t sidx[HULL_INIT_THREADS];
     const int t = threadIdx.x, sg = blockIdx.x, lo = b.seg_off[sg], hi = b.seg_off[sg + 1], fb = 4 * sg;
     double kk = 0.0, k2 = 0.0, k3 = 0.0, nx = 0.0, ny = 0.0, nz = 0.0, x0 = 0.0, y0 = 0.0, z0 = 0.0;
     int i0 = lo, i1 = lo, i2 = lo, i3 = lo;
@@ -653,37 +663,37 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
         // build, r06) and only falls back to all points if the sample's tetrahedron is degenerate (a flat verdict must come from all).
         // ties go to the caller's lowest index (perm), whatever the internal order
         for (int st = (hi - lo >= 32768) ? 8 : 1; ; st = 1) {
-            double best = -INFINITY; int bi = 0x7fffffff;
+            double best = -INFINITY; tie_t bi = kTieNone;
             for (int q = t, i = sample_at(lo, q, st); i < hi; q += HULL_INIT_THREADS, i = sample_at(lo, q, st)) {
-                const double k = -b.px[i]; const int e = b.perm[i];
+                const double k = -b.px[i]; const tie_t e = tie_word(b.perm[i], i);
                 if (k > best || (k == best && e < bi)) { best = k; bi = e; }
             }
-            i0 = b.inv[block_argmax(best, bi, skey, sidx, nullptr)];
+            i0 = tie_pos(block_argmax(best, bi, skey, sidx, nullptr));
             x0 = b.px[i0]; y0 = b.py[i0]; z0 = b.pz[i0];
-            best = -INFINITY; bi = 0x7fffffff;
+            best = -INFINITY; bi = kTieNone;
             for (int q = t, i = sample_at(lo, q, st); i < hi; q += HULL_INIT_THREADS, i = sample_at(lo, q, st)) {
                 const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
-                const double k = dx * dx + dy * dy + dz * dz; const int e = b.perm[i];
+                const double k = dx * dx + dy * dy + dz * dz; const tie_t e = tie_word(b.perm[i], i);
                 if (k > best || (k == best && e < bi)) { best = k; bi = e; }
             }
-            i1 = b.inv[block_argmax(best, bi, skey, sidx, &kk)];
+            i1 = tie_pos(block_argmax(best, bi, skey, sidx, &kk));
             const double ex = b.px[i1] - x0, ey = b.py[i1] - y0, ez = b.pz[i1] - z0;
-            best = -INFINITY; bi = 0x7fffffff;
+            best = -INFINITY; bi = kTieNone;
             for (int q = t, i = sample_at(lo, q, st); i < hi; q += HULL_INIT_THREADS, i = sample_at(lo, q, st)) {
                 const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
                 const double cx = dy * ez - dz * ey, cy = dz * ex - dx * ez, cz = dx * ey - dy * ex;
-                const double k = cx * cx + cy * cy + cz * cz; const int e = b.perm[i];
+                const double k = cx * cx + cy * cy + cz * cz; const tie_t e = tie_word(b.perm[i], i);
                 if (k > best || (k == best && e < bi)) { best = k; bi = e; }
             }
-            i2 = b.inv[block_argmax(best, bi, skey, sidx, &k2)];
+            i2 = tie_pos(block_argmax(best, bi, skey, sidx, &k2));
             const double fx = b.px[i2] - x0, fy = b.py[i2] - y0, fz = b.pz[i2] - z0;
             nx = ey * fz - ez * fy; ny = ez * fx - ex * fz; nz = ex * fy - ey * fx;
-            best = -INFINITY; bi = 0x7fffffff;
+            best = -INFINITY; bi = kTieNone;
             for (int q = t, i = sample_at(lo, q, st); i < hi; q += HULL_INIT_THREADS, i = sample_at(lo, q, st)) {
-                const double k = fabs(nx * (b.px[i] - x0) + ny * (b.py[i] - y0) + nz * (b.pz[i] - z0)); const int e = b.perm[i];
+                const double k = fabs(nx * (b.px[i] - x0) + ny * (b.py[i] - y0) + nz * (b.pz[i] - z0)); const tie_t e = tie_word(b.perm[i], i);
                 if (k > best || (k == best && e < bi)) { best = k; bi = e; }
             }
-            i3 = b.inv[block_argmax(best, bi, skey, sidx, &k3)];
+            i3 = tie_pos(block_argmax(best, bi, skey, sidx, &k3));
             if (st == 1 || (kk > 0.0 && k2 > 0.0 && k3 > 0.0)) break;   // (block-uniform: block_argmax hands every thread the same values)
         }
     }
@@ -696,21 +706,21 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init(Bufs b) {
 constexpr int kInitBlocks = 128;
 struct InitSel { int i[4]; double key[4]; };
 
-__device__ __forceinline__ int init_fold(const Bufs& b, const double* __restrict__ pkey, const int* __restrict__ pidx, int nparts,
-                                         double* skey, int* sidx, double* out_key) {
+__device__ __forceinline__ int init_fold(const Bufs& b, const double* __restrict__ pkey, const tie_t* __restrict__ pidx, int nparts,
+                                         double* skey, tie_t* sidx, double* out_key) {
     const int t = threadIdx.x;
-    double best = -INFINITY; int bi = 0x7fffffff;
+    double best = -INFINITY; tie_t bi = kTieNone;
     for (int j = t; j < nparts; j += HULL_INIT_THREADS) {
-        const double k = pkey[j]; const int e = pidx[j];
+        const double k = pkey[j]; const tie_t e = pidx[j];
         if (k > best || (k == best && e < bi)) { best = k; bi = e; }
     }
-    return b.inv[block_argmax(best, bi, skey, sidx, out_key)];
+    return tie_pos(block_argmax(best, bi, skey, sidx, out_key));
 }
 
-__global__ void __launch_bounds__(HULL_INIT_THREADS) k_init1_pass(Bufs b, int pass, double* __restrict__ pkey, int* __restrict__ pidx,
+__global__ void __launch_bounds__(HULL_INIT_THREADS) k_init1_pass(Bufs b, int pass, double* __restrict__ pkey, tie_t* __restrict__ pidx,
                                                                   InitSel* __restrict__ sel) {
     __shared__ double skey[HULL_INIT_THREADS];
-    __shared__ int sidx[HULL_INIT_THREADS];
+    __shared__ tie_t sidx[HULL_INIT_THREADS];
     const int t = threadIdx.x, lo = b.seg_off[0], hi = b.seg_off[1];
     const int nparts = gridDim.x;
     double x0 = 0, y0 = 0, z0 = 0, ex = 0, ey = 0, ez = 0, nx = 0, ny = 0, nz = 0;
@@ -731,7 +741,7 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init1_pass(Bufs b, int pa
             nx = ey * fz - ez * fy; ny = ez * fx - ex * fz; nz = ex * fy - ey * fx;
         }
     }
-    double best = -INFINITY; int bi = 0x7fffffff;
+    double best = -INFINITY; tie_t bi = kTieNone;
     for (int i = lo + blockIdx.x * HULL_INIT_THREADS + t; i < hi; i += nparts * HULL_INIT_THREADS) {
         const double dx = b.px[i] - x0, dy = b.py[i] - y0, dz = b.pz[i] - z0;
         double k;
@@ -739,18 +749,18 @@ __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init1_pass(Bufs b, int pa
         else if (pass == 1) k = dx * dx + dy * dy + dz * dz;
         else if (pass == 2) { const double cx = dy * ez - dz * ey, cy = dz * ex - dx * ez, cz = dx * ey - dy * ex; k = cx * cx + cy * cy + cz * cz; }
         else k = fabs(nx * dx + ny * dy + nz * dz);
-        const int e = b.perm[i];
+        const tie_t e = tie_word(b.perm[i], i);
         if (k > best || (k == best && e < bi)) { best = k; bi = e; }
     }
     double bk;
-    const int r = block_argmax(best, bi, skey, sidx, &bk);
+    const tie_t r = block_argmax(best, bi, skey, sidx, &bk);
     if (t == 0) { pkey[(size_t)pass * kInitBlocks + blockIdx.x] = bk; pidx[(size_t)pass * kInitBlocks + blockIdx.x] = r; }
 }
 
 __global__ void __launch_bounds__(HULL_INIT_THREADS) k_init1_finish(Bufs b, int nparts, const double* __restrict__ pkey,
-                                                                    const int* __restrict__ pidx, const InitSel* __restrict__ sel) {
+                                                                    const tie_t* __restrict__ pidx, const InitSel* __restrict__ sel) {
     __shared__ double skey[HULL_INIT_THREADS];
-    __shared__ int sidx[HULL_INIT_THREADS];
+    __shared__ tie_t sidx[HULL_INIT_THREADS];
     if (b.seg_nan[0] != 0) {
         const int lo = b.seg_off[0];
         if (threadIdx.x == 0) init_tetrahedron(b, 0, false, true, lo, lo, lo, lo, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);
@@ -2039,7 +2049,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         // the UNSORTED keys (8 bytes per point) are free after the sort: the passes' partials and the selections live there
         // (keys2 keeps the sorted keys: k_mark_vertices compares them)
         double* pkey = (double*)b.keys;
-        int* pidx = (int*)(pkey + 4 * kInitBlocks);
+        tie_t* pidx = (tie_t*)(pkey + 4 * kInitBlocks);
         InitSel* sel = (InitSel*)(pidx + 4 * kInitBlocks);
         for (int pass = 0; pass < 4; ++pass) k_init1_pass<<<kInitBlocks, HULL_INIT_THREADS, 0, st>>>(b, pass, pkey, pidx, sel);
         k_init1_finish<<<1, HULL_INIT_THREADS, 0, st>>>(b, kInitBlocks, pkey, pidx, sel);
@@ -2419,7 +2429,8 @@ __global__ void __launch_bounds__(TO_BLOCK) k_norm_max_seg(Bufs b, const float* 
         if (i0 >= cur_end) cur_seg = wave_src_seg(b, i0, &cur_end);   // (wave-uniform)
         if (i < end) {
             sg = i0 + 63 < cur_end ? cur_seg : find_src_seg(b, i);
-            v = __float_as_int(flip_norm(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])) & 0x7fffffff;
+            const Row3 p = load_row(xyz, i);
+            v = __float_as_int(flip_norm(p.x, p.y, p.z)) & 0x7fffffff;
         }
         const int s0 = __shfl(sg, 0);
         if (__all(sg == s0 || sg < 0)) {
@@ -2442,12 +2453,15 @@ k_flip_seg(Bufs b, const float* __restrict__ xyz, int n, float scale, float* __r
         const int i0 = i - (int)(threadIdx.x & 63), s0 = wave_src_seg(b, i0, &send);   // (all lanes of the wave take part)
         if (i >= n) continue;
         const float radius = __int_as_float(b.flip_max[i0 + 63 < send ? s0 : find_src_seg(b, i)]) * scale;  // tools.py:45, per viewpoint
-        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        const Row3 p = load_row(xyz, i);
+        const float x = p.x, y = p.y, z = p.z;
         const float nr = flip_norm(x, y, z);
         const float r = radius - nr;
-        flipped[3 * i] = (2.0f * (r * x)) / nr + x;  // tools.py:46-52
-        flipped[3 * i + 1] = (2.0f * (r * y)) / nr + y;
-        flipped[3 * i + 2] = (2.0f * (r * z)) / nr + z;
+        Row3 o;
+        o.x = (2.0f * (r * x)) / nr + x;  // tools.py:46-52
+        o.y = (2.0f * (r * y)) / nr + y;
+        o.z = (2.0f * (r * z)) / nr + z;
+        reinterpret_cast<Row3*>(flipped)[i] = o;
     }
 }
 
