@@ -141,7 +141,9 @@ int tohip_occlusion_rows(int64_t n_points, const int32_t *inv_perm, const int32_
 /* The same from per-point visibility VALUES instead of index lists: waypoint w's kept point j is hidden when
  * visible[seg_off[w] + j] == 0 (seg_off: n_wps device int64) — the mask tohip_hidden_pts_removal_batched writes over the waypoints'
  * kept points laid end to end, or tohip_zbuffer_visible_batched's (seg_off[w] = w * n).  A waypoint with fewer than min_points kept
- * points keeps its row of ones (a hull needs 4).  Three launches for all waypoints. */
+ * points keeps its row of ones (a hull needs 4).  Three launches for all waypoints.  inv_perm may be NULL: kept_idx then holds
+ * positions in the packed cloud's order already (the cull ran over the sorted points) in ascending order, and the hidden bits of a
+ * word are combined on their way (one atomic per run of neighbours instead of one per hidden point). */
 int tohip_occlusion_rows_masked(int64_t n_points, const int32_t *inv_perm, const int32_t *kept_idx, const int32_t *kept_count,
                                 const float *visible, const int64_t *seg_off, int32_t min_points, int64_t n_wps, uint32_t *rows,
                                 void *stream);

@@ -52,6 +52,17 @@ class PackedCloud:
         self.inv_perm = self.blob[inv0:inv0 + 4 * self.n].view(torch.int32)  # caller's index -> sorted position
 
 
+def _sorted_rows(cloud):
+    """The cloud's points as (N,3) rows in the PACKED order (row s = the caller's row perm[s]); built on first use, kept with the cloud
+    (12 bytes per point).  The occlusion refresh culls THESE rows: a waypoint's kept indices are then positions of the packed order,
+    ascending — its bit row is written run by run instead of bit by scattered bit, and the hull pass's gather walks memory in order."""
+    t = getattr(cloud, "_sorted_rows", None)
+    if t is None:
+        t = cloud.points[cloud.perm[:cloud.n].long()].contiguous() if cloud.sorted else cloud.points
+        cloud._sorted_rows = t
+    return t
+
+
 class Camera:
     """Host-side camera constants (struct tohip_camera)."""
 
@@ -435,8 +446,12 @@ def _occlusion_rows_chunk(cloud, points, poses, quats, cam, min_dist, max_dist, 
     # transform -> cull -> gather for all waypoints of the chunk in three launches (one host read: the counts size the hull pass);
     # for the hull pass the kept clouds are written end to end at once (r06: 128 device copies, 0.83 of a refresh's 11.1 ms, until then)
     packed = method != "zbuffer" and W <= 65535
+    # ... and culled in the packed cloud's order (same points, same arithmetic per point; a hull is a property of the SET, and among
+    # exact duplicates the lowest row is reported in either order: the packing sort is stable): kept indices = packed positions
+    in_packed_order = packed and points.data_ptr() == cloud.points.data_ptr() and tuple(points.shape) == tuple(cloud.points.shape) and points.is_contiguous()
     if packed:
-        kept_all, cat, counts, kcnt_all, seg_off_dev = cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True, scratch=True, packed=True)
+        kept_all, cat, counts, kcnt_all, seg_off_dev = cull_waypoints(_sorted_rows(cloud) if in_packed_order else points, poses, quats, cam, min_dist,
+                                                                      max_dist, normalize=True, scratch=True, packed=True)
     else:
         kept_all, pts_all, counts, kcnt_all = cull_waypoints(points, poses, quats, cam, min_dist, max_dist, normalize=True, scratch=True)
     if method == "zbuffer":
@@ -479,7 +494,7 @@ def _occlusion_rows_chunk(cloud, points, poses, quats, cam, min_dist, max_dist, 
     for w0 in range(0, W, 65535):
         w1 = min(W, w0 + 65535)
         with torch.cuda.device(dev):
-            check(L.tohip_occlusion_rows_masked(n, ptr(cloud.inv_perm), ptr(kept_all[w0:w1]), ptr(kcnt_all[w0:w1]), ptr(visible),
+            check(L.tohip_occlusion_rows_masked(n, None if in_packed_order else ptr(cloud.inv_perm), ptr(kept_all[w0:w1]), ptr(kcnt_all[w0:w1]), ptr(visible),
                                                 ptr(seg_off[w0:w1]), 4, w1 - w0, ptr(rows[w0:w1]), stream_ptr()), "tohip_occlusion_rows_masked")
 
 
