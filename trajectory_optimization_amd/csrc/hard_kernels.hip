@@ -408,13 +408,18 @@ extern "C" int tohip_frustum_cull(const float* cam_3xN, int64_t n, const tohip_c
 // whole cloud into every waypoint's camera frame, hard frustum test, ordered compaction — three launches instead of
 // five per waypoint.  kept_idx[w*n ..] / kept_pts[(w*n + j)*3 ..] receive waypoint w's kept points in input order,
 // kept_count[w] their number.
+constexpr int kCullWords = (TO_CULL_TILE / TO_BLOCK) * TO_WAVES_PER_BLOCK;   // verdict words per (waypoint, tile): [trip][wave]
 __global__ void __launch_bounds__(TO_BLOCK)
 k_cull_wps_count(const float* __restrict__ xyz, int64_t n, const float* __restrict__ poses, const float* __restrict__ quats,
-                 int normalize, FrustumConsts f, int ntiles, int32_t* __restrict__ tile_count) {
+                 int normalize, FrustumConsts f, int ntiles, int32_t* __restrict__ tile_count, unsigned long long* __restrict__ keep) {
     __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
     const int w = blockIdx.y;
     const ExactPose e = exact_pose(quats + 4 * w, poses + 3 * w, normalize);
     const int64_t tile0 = (int64_t)blockIdx.x * TO_CULL_TILE;
+    // the verdicts go to memory as well — a 64-bit word per (wave, trip), kCullWords per (waypoint, tile) — so that the write pass
+    // transforms the kept points only (a ninth of the pairs on the occlusion workload; the test is 90 instructions per pair with its
+    // three exact divisions, and both passes ran it: 0.37 + 0.46 ms for 128 x 1 M until r06)
+    unsigned long long* kw = keep + ((int64_t)w * ntiles + blockIdx.x) * kCullWords;
     int cnt = 0;
     for (int j = 0; j < TO_CULL_TILE / TO_BLOCK; ++j) {
         const int64_t i = tile0 + j * TO_BLOCK + threadIdx.x;
@@ -424,7 +429,9 @@ k_cull_wps_count(const float* __restrict__ xyz, int64_t n, const float* __restri
             exact_to_cam(e, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], X, Y, Z);
             frustum_pred(f, X, Y, Z, d, v);
         }
-        cnt += __popcll(__ballot(d && v));
+        const unsigned long long bal = __ballot(d && v);
+        if ((threadIdx.x & 63) == 0) kw[j * TO_WAVES_PER_BLOCK + (threadIdx.x >> 6)] = bal;
+        cnt += __popcll(bal);
     }
     if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
     __syncthreads();
@@ -460,38 +467,42 @@ k_cull_wps_scan(int32_t* __restrict__ tile_count, int ntiles, int32_t* __restric
 
 __global__ void __launch_bounds__(TO_BLOCK)
 k_cull_wps_write(const float* __restrict__ xyz, int64_t n, const float* __restrict__ poses, const float* __restrict__ quats,
-                 int normalize, FrustumConsts f, int ntiles, const int32_t* __restrict__ tile_off,
+                 int normalize, int ntiles, const int32_t* __restrict__ tile_off, const unsigned long long* __restrict__ keep,
                  int32_t* __restrict__ kept_idx, float* __restrict__ kept_pts, const int64_t* __restrict__ seg_off) {
-    __shared__ int wave_cnt[TO_WAVES_PER_BLOCK];
     const int w = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long* kw = keep + ((int64_t)w * ntiles + blockIdx.x) * kCullWords;
+    // this wave's verdict words and where its kept points go: the tile's offset + everything kept in earlier trips + in earlier waves
+    // of the same trip — sixteen words, read by everybody, no barrier
+    unsigned long long mine[TO_CULL_TILE / TO_BLOCK];
+    int off[TO_CULL_TILE / TO_BLOCK];
+    int run = tile_off[(int64_t)w * ntiles + blockIdx.x];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < TO_CULL_TILE / TO_BLOCK; ++j) {
+#pragma unroll
+        for (int k = 0; k < TO_WAVES_PER_BLOCK; ++k) {
+            const unsigned long long word = kw[j * TO_WAVES_PER_BLOCK + k];
+            if (k == wave) { mine[j] = word; off[j] = run; }
+            run += __popcll(word);
+        }
+        any = any || mine[j] != 0ull;
+    }
+    if (!any) return;   // (wave-uniform) most waves of a waypoint's tiles keep nothing
     const ExactPose e = exact_pose(quats + 4 * w, poses + 3 * w, normalize);
     const int64_t tile0 = (int64_t)blockIdx.x * TO_CULL_TILE;
-    int base = tile_off[(int64_t)w * ntiles + blockIdx.x];
     int32_t* ki = kept_idx + (int64_t)w * n;
     // seg_off: the waypoints' kept points end to end (tohip_cull_waypoints_packed) instead of n rows apart
     float* kp = kept_pts + (seg_off ? seg_off[w] : (int64_t)w * n) * 3;
+#pragma unroll
     for (int j = 0; j < TO_CULL_TILE / TO_BLOCK; ++j) {
+        if (!((mine[j] >> lane) & 1ull)) continue;
         const int64_t i = tile0 + j * TO_BLOCK + threadIdx.x;
-        bool d = false, v = false;
-        float X = 0.f, Y = 0.f, Z = 0.f;
-        if (i < n) {
-            exact_to_cam(e, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], X, Y, Z);
-            frustum_pred(f, X, Y, Z, d, v);
-        }
-        const bool keep = d && v;
-        const unsigned long long b = __ballot(keep);
-        if (lane == 0) wave_cnt[wave] = __popcll(b);
-        __syncthreads();
-        int off = base;
-        for (int k = 0; k < wave; ++k) off += wave_cnt[k];
-        if (keep) {
-            const int dst = off + __popcll(b & ((1ull << lane) - 1ull));
-            ki[dst] = (int32_t)i;
-            kp[3 * (int64_t)dst] = X; kp[3 * (int64_t)dst + 1] = Y; kp[3 * (int64_t)dst + 2] = Z;
-        }
-        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
+        float X, Y, Z;
+        exact_to_cam(e, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], X, Y, Z);
+        const int dst = off[j] + __popcll(mine[j] & ((1ull << lane) - 1ull));
+        ki[dst] = (int32_t)i;
+        kp[3 * (int64_t)dst] = X; kp[3 * (int64_t)dst + 1] = Y; kp[3 * (int64_t)dst + 2] = Z;
     }
 }
 
@@ -524,7 +535,7 @@ k_cull_wps_offsets(const int32_t* __restrict__ kept_count, int n_wps, int64_t* _
 extern "C" size_t tohip_cull_waypoints_workspace_bytes(int64_t n, int64_t n_wps) {
     if (n <= 0 || n_wps <= 0) return 256;
     const size_t ntiles = (size_t)((n + TO_CULL_TILE - 1) / TO_CULL_TILE);
-    return (ntiles * (size_t)n_wps * sizeof(int32_t) + 255) / 256 * 256 + 256;
+    return (ntiles * (size_t)n_wps * sizeof(int32_t) + 255) / 256 * 256 + ntiles * (size_t)n_wps * kCullWords * sizeof(unsigned long long) + 256;
 }
 
 static int cull_waypoints_impl(const float* xyz, int64_t n, const float* poses, const float* quats, int64_t n_wps,
@@ -538,6 +549,7 @@ static int cull_waypoints_impl(const float* xyz, int64_t n, const float* poses, 
     hipStream_t st = (hipStream_t)stream_;
     const int ntiles = (int)((n + TO_CULL_TILE - 1) / TO_CULL_TILE);
     int32_t* tile_count = (int32_t*)workspace;
+    unsigned long long* keep = (unsigned long long*)((char*)workspace + ((size_t)ntiles * (size_t)n_wps * sizeof(int32_t) + 255) / 256 * 256);
     FrustumConsts f;
     for (int i = 0; i < 9; ++i) f.k[i] = cam->K[i];
     f.wl = (float)((double)cam->img_width - 1.0);
@@ -545,7 +557,7 @@ static int cull_waypoints_impl(const float* xyz, int64_t n, const float* poses, 
     f.dmin = min_dist;
     f.dmax = max_dist;
     const dim3 grid((unsigned)ntiles, (unsigned)n_wps);
-    k_cull_wps_count<<<grid, TO_BLOCK, 0, st>>>(xyz, n, poses, quats, normalize, f, ntiles, tile_count);
+    k_cull_wps_count<<<grid, TO_BLOCK, 0, st>>>(xyz, n, poses, quats, normalize, f, ntiles, tile_count, keep);
     TO_HIP_CHECK_LAUNCH();
     k_cull_wps_scan<<<(unsigned)n_wps, TO_BLOCK, 0, st>>>(tile_count, ntiles, kept_count);
     TO_HIP_CHECK_LAUNCH();
@@ -553,7 +565,7 @@ static int cull_waypoints_impl(const float* xyz, int64_t n, const float* poses, 
         k_cull_wps_offsets<<<1, TO_BLOCK, 0, st>>>(kept_count, (int)n_wps, seg_off);
         TO_HIP_CHECK_LAUNCH();
     }
-    k_cull_wps_write<<<grid, TO_BLOCK, 0, st>>>(xyz, n, poses, quats, normalize, f, ntiles, tile_count, kept_idx, kept_pts, seg_off);
+    k_cull_wps_write<<<grid, TO_BLOCK, 0, st>>>(xyz, n, poses, quats, normalize, ntiles, tile_count, keep, kept_idx, kept_pts, seg_off);
     TO_HIP_CHECK_LAUNCH();
     return TOHIP_OK;
 }
