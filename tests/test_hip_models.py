@@ -664,6 +664,25 @@ def test_occlusion_rows_do_not_depend_on_the_chunking(dev, monkeypatch):
     assert 0 < int((a != -1).sum())   # something is occluded
 
 
+def test_occlusion_rows_culled_in_packed_order_equal_the_rows_culled_in_the_callers_order(dev):
+    """The refresh culls the cloud in its PACKED order (kept indices = packed positions, ascending: bit rows written run by run,
+    tohip_occlusion_rows_masked with inv_perm = NULL); handed a copy of the points it cannot take that shortcut and culls in the
+    caller's order (scattered bits through inv_perm).  Same rows, bit for bit — with exact duplicates in the cloud too, where the
+    hull reports the lowest row of each set of copies in either order."""
+    from trajectory_optimization_amd import ops
+    pts = synth.make_cloud(60_000, seed=45)
+    pts[1000:1400] = pts[50_000:50_400]          # exact copies, far apart in the caller's order
+    poses, quats = synth.make_path(9, optical=True, jitter_seed=45)
+    P = torch.from_numpy(pts).to(dev)
+    cloud = ops.PackedCloud(P)
+    cam = ops.Camera(K, IW, IH)
+    p, q = torch.from_numpy(poses).to(dev), torch.from_numpy(quats).to(dev)
+    a = ops.occlusion_bits(cloud, cloud.points, p, q, cam, 1.0, 15.0, "hpr")
+    b = ops.occlusion_bits(cloud, P.clone(), p, q, cam, 1.0, 15.0, "hpr")
+    assert torch.equal(a, b)
+    assert 0 < int((a != -1).sum())
+
+
 @pytest.mark.parametrize("dense,lens", [(False, [9, 17, 5]), (True, [9, 17, 5]), (False, [40, 50, 23]), (True, [33, 1, 64])])
 def test_several_trajectories_in_one_pass_equal_separate_calls(dev, dense, lens):
     """tohip_traj_*_multi: B trajectories' waypoints as one batch of virtual waypoints, each with its own log-odds vector,
