@@ -445,7 +445,9 @@ int tohip_spherical_flip(const float *xyz, int64_t n_points, float param, float 
  * precision quickhull on the GPU), visible = hull vertices in ascending index order minus the LAST
  * one (the reference drops hull.vertices[-1] unconditionally).  visible_idx capacity N int32;
  * *visible_count device int32; mask (N floats of 0/1, may be NULL).  SYNCHRONISES the stream (the hull
- * is built in rounds whose convergence is read back). */
+ * is built in rounds whose convergence is read back).  The read-back is a 128-byte record that a one-wave kernel writes into mapped
+ * host memory and the calling thread polls: the library keeps two such records per (host thread, device) — the one piece of state it
+ * holds between calls, allocated on the thread's first build on that device and freed when the thread ends. */
 int tohip_hidden_pts_removal(const float *xyz, int64_t n_points, float param, int32_t *visible_idx,
                              int32_t *visible_count, float *mask, void *workspace, size_t workspace_bytes,
                              void *stream);

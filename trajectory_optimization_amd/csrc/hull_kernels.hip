@@ -2318,7 +2318,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
         if (!stalled) {
             while (inflight < ahead) {  // keep one batch ahead of the readback being waited for
                 // few candidates left: the build is about to end, and every round enqueued beyond its end is five launches of
-                // nothing (up to eight such rounds at four per readback: 0.1 ms of a 4 ms build) -> two per readback from here on
+                // nothing (up to eight such rounds at four per readback: 0.1 ms of a build) -> two per readback from here on
                 // ... and with tens of thousands of candidates (a batch of views) a round is hundreds of microseconds: the host is
                 // ahead anyway, and one round per readback wastes the fewest at the end (128 views: 9.5 ms at 4, 9.0 at 2, 8.9 at 1)
                 const int per = batch_env ? batch : (ncand >= 16384 ? 1 : (ncand <= 512 ? 2 : batch));
@@ -2368,7 +2368,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
             launch_scan_tiles(b.tile_cnt, ntl, b.tile_off, b.ctrl + kCtrlNLive, st);
             k_live_write<<<ntl, TO_BLOCK, 0, st>>>(b, nlive, b.tile_off);
             {
-                const hipError_t el = hipGetLastError();   // a readback may be in flight on the shared pinned buffers: drain before leaving
+                const hipError_t el = hipGetLastError();   // a report may be in flight into the shared mapped records: drain before leaving
                 if (el != hipSuccess) return drain((int)el);
             }
             int* t = b.live; b.live = b.live2; b.live2 = t;
@@ -2383,7 +2383,7 @@ static int build(const Bufs& b_in, const float* pts, int with_origin, int64_t ma
     if (rounds_out) *rounds_out = round;
     k_mark_vertices<<<nblocks(nf), TO_BLOCK, 0, st>>>(b);
     TO_HIP_CHECK_LAUNCH();
-    while (inflight > 0) {  // the pinned buffers and events are this thread's next build's too
+    while (inflight > 0) {  // the mapped records are this thread's next build's too
         e = collect();
         if (e != hipSuccess) return (int)e;
     }
