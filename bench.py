@@ -147,9 +147,32 @@ def hpr_leg(points, device):
     t0 = time.perf_counter()
     ref, _ = oracle.hidden_pts_removal(points)
     cpu_s = time.perf_counter() - t0
-    return {"points": int(points.shape[0]), "visible": int(idx.numel()), "gpu_ms": 1e3 * gpu_s, "gpu_ms_best": 1e3 * min(times),
-            "hull_points_per_s": points.shape[0] / gpu_s, "qhull_ms_host_1core": 1e3 * cpu_s,
-            "index_set_equal_to_qhull": bool(np.array_equal(idx.cpu().numpy().astype(np.int64), ref))}
+    out = {"points": int(points.shape[0]), "visible": int(idx.numel()), "gpu_ms": 1e3 * gpu_s, "gpu_ms_best": 1e3 * min(times),
+           "hull_points_per_s": points.shape[0] / gpu_s, "qhull_ms_host_1core": 1e3 * cpu_s,
+           "index_set_equal_to_qhull": bool(np.array_equal(idx.cpu().numpy().astype(np.int64), ref))}
+    # the hull as the occlusion refresh uses it: the cloud culled to the frustum of every waypoint of the bench path (camera frame,
+    # viewpoint = the camera: pc_processor.py:158-187), all views in ONE batched pass; two of them checked against Qhull
+    poses, quats = synth.make_path(WPS_PER_GPU, optical=True)
+    cam = ops.Camera(synth.K_INTRINS, synth.IMG_WIDTH, synth.IMG_HEIGHT)
+    _, cat, counts, _, _ = ops.cull_waypoints(P, torch.from_numpy(poses).to(device), torch.from_numpy(quats).to(device), cam, 1.0, 15.0, packed=True)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ops.hidden_pts_removal_batched(cat, offs)
+    torch.cuda.synchronize(device)
+    times = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        bidx, voff, _, status = ops.hidden_pts_removal_batched(cat, offs)
+        torch.cuda.synchronize(device)
+        times.append(time.perf_counter() - t0)
+    bidx, voff = bidx.cpu().numpy().astype(np.int64), voff.numpy()
+    same = True
+    for w in (0, len(counts) // 2):
+        if counts[w] >= 4:
+            seg = cat[int(offs[w]):int(offs[w + 1])].cpu().numpy()
+            same = same and bool(np.array_equal(bidx[voff[w]:voff[w + 1]] - offs[w], oracle.hidden_pts_removal(seg)[0]))
+    out["batched"] = {"views": len(counts), "points": int(offs[-1]), "gpu_ms": 1e3 * sum(times) / len(times), "gpu_ms_best": 1e3 * min(times),
+                      "status_ok": bool((status == 0).all().item()), "two_views_equal_to_qhull": same}
+    return out
 
 
 def dropin_leg(device, steps=200, warmup=10):
@@ -630,6 +653,8 @@ def compact_line(full):
         line["sustained"]["note"] = "back-to-back steps AFTER the timed windows (settled clocks); the headline is the driver's W + K protocol"
     if full.get("hpr"):
         line["hpr"] = {k: full["hpr"].get(k) for k in ("points", "visible", "gpu_ms", "gpu_ms_best", "qhull_ms_host_1core", "index_set_equal_to_qhull")}
+        if isinstance(full["hpr"].get("batched"), dict):
+            line["hpr"]["batched"] = {k: full["hpr"]["batched"].get(k) for k in ("views", "points", "gpu_ms", "status_ok", "two_views_equal_to_qhull")}
     if full.get("aux"):
         big = full["aux"].get("16000000_points") or next((v for k, v in full["aux"].items() if k.endswith("_points")), {})
         pick = {}
