@@ -18,6 +18,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_sq" -o pmc -- python3 "$root/bench.py" $common --mode dense > "$out/pmc_sq.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/hpr" -o hpr -- python3 "$root/tools/hpr_batched_once.py" 3 > "$out/hpr.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/hpr1m" -o hpr1m -- python3 "$root/tools/hpr_once.py" 1000000 3 > "$out/hpr1m.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/refresh" -o refresh -- python3 "$root/tools/prof_refresh.py" 4 hpr > "$out/refresh.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/opt" -o opt -- python3 "$root/tools/prof_opt.py" --steps 120 > "$out/opt.log" 2>&1
 for sc in multi8 w1024 cam5 c2; do   # the large-W regime on one GPU (tools/prof_multi.py), culled = the library default
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/multi_$sc" -o multi_$sc -- python3 "$root/tools/prof_multi.py" --scenario $sc --mode culled --steps 40 --warmup 10 --no-events > "$out/multi_$sc.log" 2>&1

@@ -66,6 +66,8 @@ def main():
         shutil.copy(os.path.join(src, "hpr", "hpr_kernel_stats.csv"), os.path.join(dst, f"{tag}_hpr_batched_kernel_stats.csv"))
     if os.path.exists(os.path.join(src, "hpr1m", "hpr1m_kernel_stats.csv")):
         shutil.copy(os.path.join(src, "hpr1m", "hpr1m_kernel_stats.csv"), os.path.join(dst, f"{tag}_hpr_1m_kernel_stats.csv"))
+    if os.path.exists(os.path.join(src, "refresh", "refresh_kernel_stats.csv")):
+        shutil.copy(os.path.join(src, "refresh", "refresh_kernel_stats.csv"), os.path.join(dst, f"{tag}_occlusion_refresh_kernel_stats.csv"))
     for sub, name in (("opt", "optimize"), ("aux", "aux")):
         if os.path.exists(os.path.join(src, sub, f"{sub}_kernel_stats.csv")):
             shutil.copy(os.path.join(src, sub, f"{sub}_kernel_stats.csv"), os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
